@@ -1,0 +1,378 @@
+// HBM-bound glue kernels of the Ultravox hot path (16-byte vector access everywhere).
+//   swiglu fwd/bwd      — SwiGLU (ultravox_model.py:739-742: first half = value, second half = gate)
+//                         and the [3P] LlamaMLP act_fn(gate)*up (gate_first = 1 in our fused layout)
+//   rope_inplace        — [3P] apply_rotary_pos_emb (rotate_half form), forward and inverse
+//   embed_gather        — embed_tokens(input_ids)            (ultravox_model.py:314-316)
+//   merge_audio(+bwd)   — the sequential in-place overwrite  (ultravox_model.py:390-394, :259-275)
+//   transposes / im2col — layout changes feeding the one NT GEMM kernel
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <typename T>
+__global__ void swiglu_fwd_k(const T* __restrict__ in, T* __restrict__ out, long long n8, int half, int gate_first) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int hv = half / 8;
+  const long long row = i / hv;
+  const int c = (int)(i % hv) * 8;
+  const T* r = in + row * 2 * half;
+  float a[8], g[8], o[8];
+  ld8<T>(r + (gate_first ? half : 0) + c, a);   // value / up
+  ld8<T>(r + (gate_first ? 0 : half) + c, g);   // gate
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = rnd<T>(g[k] / (1.0f + expf(-g[k]))) * a[k];
+  st8<T>(out + row * half + c, o);
+}
+
+template <typename T>
+__global__ void swiglu_bwd_k(const T* __restrict__ dout, const T* __restrict__ in, T* __restrict__ din,
+                             long long n8, int half, int gate_first) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int hv = half / 8;
+  const long long row = i / hv;
+  const int c = (int)(i % hv) * 8;
+  const T* r = in + row * 2 * half;
+  T* dr = din + row * 2 * half;
+  const int voff = gate_first ? half : 0, goff = gate_first ? 0 : half;
+  float a[8], g[8], d[8], da[8], dg[8];
+  ld8<T>(r + voff + c, a);
+  ld8<T>(r + goff + c, g);
+  ld8<T>(dout + row * half + c, d);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float s = 1.0f / (1.0f + expf(-g[k]));
+    const float silu = g[k] * s;
+    da[k] = d[k] * rnd<T>(silu);
+    dg[k] = d[k] * a[k] * (s * (1.0f + g[k] * (1.0f - s)));
+  }
+  st8<T>(dr + voff + c, da);
+  st8<T>(dr + goff + c, dg);
+}
+
+// cos_sin: [T_table, D/2, 2] f32.  x: [rows, ld]; heads 0..H-1 of width D start at column 0.
+template <typename T>
+__global__ void rope_k(T* __restrict__ x, const float* __restrict__ cs, const int32_t* __restrict__ pos,
+                       long long n_items, int Tlen, int H, int D, int ld, float sgn) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  const int per_head = D / 16;  // 8-element vectors in the first half
+  const int per_row = H * per_head;
+  const long long row = i / per_row;
+  const int rem = (int)(i % per_row);
+  const int h = rem / per_head, c = (rem % per_head) * 8;
+  const int p = pos ? pos[row] : (int)(row % Tlen);
+  T* base = x + row * ld + h * D;
+  const float* t = cs + ((long long)p * (D / 2) + c) * 2;
+  float lo[8], hi[8], olo[8], ohi[8];
+  ld8<T>(base + c, lo);
+  ld8<T>(base + D / 2 + c, hi);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float co = rnd<T>(t[2 * k]), si = rnd<T>(t[2 * k + 1]) * sgn;
+    olo[k] = rnd<T>(lo[k] * co) + rnd<T>(-hi[k] * si);
+    ohi[k] = rnd<T>(hi[k] * co) + rnd<T>(lo[k] * si);
+  }
+  st8<T>(base + c, olo);
+  st8<T>(base + D / 2 + c, ohi);
+}
+
+template <typename T>
+__global__ void embed_gather_k(const T* __restrict__ table, const int64_t* __restrict__ ids, T* __restrict__ out,
+                               long long n8, int D, int vocab) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int dv = D / 8;
+  const long long row = i / dv;
+  const int c = (int)(i % dv) * 8;
+  long long id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  float v[8];
+  ld8<T>(table + id * D + c, v);
+  st8<T>(out + row * D + c, v);
+}
+
+// ---- merge: "last writer wins" reproduces the reference's sequential python loop exactly ----
+// owner[b*T + t] = largest audio index i_a whose [start, start+len) range covers row t of batch b.
+__global__ void merge_owner_k(int32_t* __restrict__ owner, int32_t* __restrict__ item_batch,
+                              const int64_t* __restrict__ audio_batch_size, const int64_t* __restrict__ start,
+                              const int32_t* __restrict__ len, int B, int n_items, int T, int Na) {
+  __shared__ int ib[1024];
+  if (threadIdx.x == 0) {
+    int a = 0;
+    for (int b = 0; b < B; ++b) {
+      const int cnt = (int)audio_batch_size[b];
+      for (int k = 0; k < cnt && a < n_items; ++k, ++a) { ib[a & 1023] = b; item_batch[a] = b; }
+    }
+    for (; a < n_items; ++a) item_batch[a] = -1;  // more audio items than audio_batch_size accounts for
+  }
+  __syncthreads();
+  for (long long i = threadIdx.x; i < (long long)n_items * Na; i += blockDim.x) {
+    const int a = (int)(i / Na), j = (int)(i % Na);
+    const int b = item_batch[a];
+    if (b < 0) continue;
+    const int l = min((int)len[a], Na);
+    const long long t = start[a] + j;
+    if (j < l && t >= 0 && t < T) atomicMax(owner + (long long)b * T + t, a);
+  }
+}
+
+template <typename T>
+__global__ void merge_copy_k(T* __restrict__ embeds, const T* __restrict__ audio, const int32_t* __restrict__ owner,
+                             const int32_t* __restrict__ item_batch, const int64_t* __restrict__ start,
+                             const int32_t* __restrict__ len, long long n8, int Tlen, int D, int Na, int bwd,
+                             T* __restrict__ daudio) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int dv = D / 8;
+  const long long r = i / dv;  // audio row = a*Na + j
+  const int c = (int)(i % dv) * 8;
+  const int a = (int)(r / Na), j = (int)(r % Na);
+  const int b = item_batch[a];
+  const int l = min((int)len[a], Na);
+  const long long t = start[a] + j;
+  const bool live = b >= 0 && j < l && t >= 0 && t < Tlen && owner[(long long)b * Tlen + t] == a;
+  float v[8];
+  if (!bwd) {
+    if (!live) return;
+    ld8<T>(audio + r * D + c, v);
+    st8<T>(embeds + ((long long)b * Tlen + t) * D + c, v);
+  } else {
+    if (live) ld8<T>(embeds + ((long long)b * Tlen + t) * D + c, v);
+    else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    }
+    st8<T>(daudio + r * D + c, v);
+  }
+}
+
+// ---- generic 2-D transpose through LDS: out[c, r] = in[r, c]; pads rows..ld_out region with zeros ----
+template <typename T>
+__global__ void transpose_k(const T* __restrict__ in, T* __restrict__ out, int rows, int cols, int ld_in, int ld_out,
+                            int out_cols_total, long long s_in, long long s_out) {
+  __shared__ T tile[64][65];
+  const T* ib = in + blockIdx.z * s_in;
+  T* ob = out + blockIdx.z * s_out;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows per pass
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    tile[rr][tx] = (r < rows && c < cols) ? ib[(long long)r * ld_in + c] : (T)0;
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, r = r0 + tx;
+    if (c < cols && r < out_cols_total) ob[(long long)c * ld_out + r] = tile[tx][cc];
+  }
+}
+
+// conv1 im2col: out[(b*F + t), k*n_mels + c] = mel[b, c, t + k - 1]  (zero outside [0, F)), cols padded to Kp
+template <typename T, typename TIN>
+__global__ void im2col_conv1_k(const TIN* __restrict__ mel, T* __restrict__ out, int n_mels, int F, int F_stride,
+                               int Kp) {
+  extern __shared__ float sm[];  // [n_mels][66]
+  const int b = blockIdx.y, t0 = blockIdx.x * 64;
+  const TIN* mb = mel + (long long)b * n_mels * F_stride;
+  for (int i = threadIdx.x; i < n_mels * 66; i += blockDim.x) {
+    const int c = i / 66, tt = t0 - 1 + (i % 66);
+    float v = 0.f;
+    if (tt >= 0 && tt < F) {
+      if constexpr (sizeof(TIN) == 4) v = rnd<T>((float)mb[(long long)c * F_stride + tt]);
+      else v = ldf<T>((const T*)mb + (long long)c * F_stride + tt);
+    }
+    sm[i] = v;
+  }
+  __syncthreads();
+  const int tmax = min(64, F - t0);
+  for (long long i = threadIdx.x; i < (long long)tmax * Kp; i += blockDim.x) {
+    const int tl = (int)(i / Kp), col = (int)(i % Kp);
+    float v = 0.f;
+    if (col < 3 * n_mels) {
+      const int k = col / n_mels, c = col % n_mels;
+      v = sm[c * 66 + tl + k];
+    }
+    stf<T>(out + ((long long)b * F + t0 + tl) * Kp + col, v);
+  }
+}
+
+template <typename T>
+__global__ void add_k(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float x[8], y[8];
+  ld8<T>(a + i * 8, x);
+  ld8<T>(b + i * 8, y);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] += y[k];
+  st8<T>(o + i * 8, x);
+}
+
+template <typename T>
+__global__ void cast_from_f32_k(const float* __restrict__ in, T* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stf<T>(out + i, in[i]);
+}
+
+inline int grid1d(long long n, int th) { return (int)((n + th - 1) / th); }
+
+}  // namespace
+
+#define DISPATCH_T(dtype, KERNEL, grid, block, shmem, st, ...)                                        \
+  do {                                                                                                \
+    if ((dtype) == uvx::DT_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, grid, block, shmem, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<float>, grid, block, shmem, st, __VA_ARGS__);                      \
+    UVX_LAUNCH_CHECK();                                                                               \
+  } while (0)
+
+namespace uvx {
+
+int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first) {
+  UVX_CHECK(half % 8 == 0, UVX_ERR_SHAPE, "swiglu: half=%d must be a multiple of 8", half);
+  const long long n8 = (long long)rows * half / 8;
+  if (n8 == 0) return UVX_OK;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(swiglu_fwd_k<bf16_t>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, n8, half, gate_first);
+  else
+    hipLaunchKernelGGL(swiglu_fwd_k<float>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const float*)in, (float*)out, n8, half, gate_first);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
+               int gate_first) {
+  UVX_CHECK(half % 8 == 0, UVX_ERR_SHAPE, "swiglu_bwd: half=%d must be a multiple of 8", half);
+  const long long n8 = (long long)rows * half / 8;
+  if (n8 == 0) return UVX_OK;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(swiglu_bwd_k<bf16_t>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, n8, half, gate_first);
+  else
+    hipLaunchKernelGGL(swiglu_bwd_k<float>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const float*)dout, (const float*)in, (float*)din, n8, half, gate_first);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int rope_inplace(hipStream_t st, int dtype, void* x, const float* cos_sin, const int32_t* pos, int rows, int T,
+                 int n_heads_rot, int head_dim, int ld, int inverse) {
+  UVX_CHECK(head_dim % 16 == 0 && ld % 8 == 0, UVX_ERR_SHAPE, "rope: head_dim=%d ld=%d unsupported", head_dim, ld);
+  const long long n = (long long)rows * n_heads_rot * (head_dim / 16);
+  if (n == 0) return UVX_OK;
+  const float sgn = inverse ? -1.f : 1.f;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(rope_k<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, (bf16_t*)x, cos_sin, pos, n, T, n_heads_rot, head_dim, ld, sgn);
+  else
+    hipLaunchKernelGGL(rope_k<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, (float*)x, cos_sin, pos, n, T, n_heads_rot, head_dim, ld, sgn);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int embed_gather(hipStream_t st, int dtype, const void* table, const int64_t* ids, void* out, int rows, int D,
+                 int vocab) {
+  UVX_CHECK(D % 8 == 0, UVX_ERR_SHAPE, "embed_gather: D=%d must be a multiple of 8", D);
+  const long long n8 = (long long)rows * D / 8;
+  if (n8 == 0) return UVX_OK;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(embed_gather_k<bf16_t>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const bf16_t*)table, ids, (bf16_t*)out, n8, D, vocab);
+  else
+    hipLaunchKernelGGL(embed_gather_k<float>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const float*)table, ids, (float*)out, n8, D, vocab);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int merge_owner(hipStream_t st, int32_t* owner, int32_t* item_batch, const int64_t* audio_batch_size,
+                const int64_t* start, const int32_t* len, int B, int n_items, int T, int Na) {
+  UVX_CHECK(n_items <= 1024, UVX_ERR_SHAPE, "merge: more than 1024 audio items per step (%d)", n_items);
+  UVX_HIP(hipMemsetAsync(owner, 0xff, sizeof(int32_t) * (size_t)B * T, st));
+  if (n_items == 0) return UVX_OK;
+  hipLaunchKernelGGL(merge_owner_k, dim3(1), dim3(1024), 0, st, owner, item_batch, audio_batch_size, start, len, B,
+                     n_items, T, Na);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int merge_audio(hipStream_t st, int dtype, void* embeds, const void* audio, void* daudio, const int32_t* owner,
+                const int32_t* item_batch, const int64_t* start, const int32_t* len, int n_items, int T, int D,
+                int Na, int bwd) {
+  UVX_CHECK(D % 8 == 0, UVX_ERR_SHAPE, "merge: D=%d must be a multiple of 8", D);
+  const long long n8 = (long long)n_items * Na * D / 8;
+  if (n8 == 0) return UVX_OK;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(merge_copy_k<bf16_t>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (bf16_t*)embeds, (const bf16_t*)audio, owner, item_batch, start, len, n8, T, D, Na, bwd, (bf16_t*)daudio);
+  else
+    hipLaunchKernelGGL(merge_copy_k<float>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (float*)embeds, (const float*)audio, owner, item_batch, start, len, n8, T, D, Na, bwd, (float*)daudio);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int transpose2d(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in, int ld_out,
+                int batch, long long s_in, long long s_out) {
+  if (rows == 0 || cols == 0) return UVX_OK;
+  // the zero padded region out[:, rows..ld_out) is written too (the GEMM K dimension must be 64-aligned)
+  dim3 grid(cdiv(ld_out, 64), cdiv(cols, 64), batch);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(transpose_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, ld_out, s_in, s_out);
+  else
+    hipLaunchKernelGGL(transpose_k<float>, grid, dim3(256), 0, st, (const float*)in, (float*)out, rows, cols, ld_in, ld_out, ld_out, s_in, s_out);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int heads_transpose(hipStream_t st, int dtype, const void* in, void* out, int B, int T, int Tp, int H, int D, int ld) {
+  // [B, T, H, D] (token stride ld) -> [B, H, D, Tp]: a batched transpose with a two-level batch index,
+  // expressed as B launches of the (H-batched) 2-D transpose.
+  const size_t es = dtype == DT_BF16 ? 2 : 4;
+  for (int b = 0; b < B; ++b) {
+    const char* ib = (const char*)in + (size_t)b * T * ld * es;
+    char* ob = (char*)out + (size_t)b * H * D * Tp * es;
+    int rc = transpose2d(st, dtype, ib, ob, T, D, ld, Tp, H, D, (long long)D * Tp);
+    if (rc) return rc;
+  }
+  return UVX_OK;
+}
+
+int im2col_conv1(hipStream_t st, int dtype, const void* mel, int mel_is_f32, void* out, int B, int n_mels, int F,
+                 int F_stride, int Kp) {
+  UVX_CHECK(Kp >= 3 * n_mels, UVX_ERR_SHAPE, "im2col: Kp=%d < 3*n_mels", Kp);
+  if (B == 0 || F == 0) return UVX_OK;
+  dim3 grid(cdiv(F, 64), B);
+  const size_t sh = sizeof(float) * n_mels * 66;
+  if (dtype == DT_BF16) {
+    if (mel_is_f32) hipLaunchKernelGGL((im2col_conv1_k<bf16_t, float>), grid, dim3(256), sh, st, (const float*)mel, (bf16_t*)out, n_mels, F, F_stride, Kp);
+    else hipLaunchKernelGGL((im2col_conv1_k<bf16_t, bf16_t>), grid, dim3(256), sh, st, (const bf16_t*)mel, (bf16_t*)out, n_mels, F, F_stride, Kp);
+  } else {
+    UVX_CHECK(mel_is_f32, UVX_ERR_INVALID, "im2col: f32 mode needs f32 mel");
+    hipLaunchKernelGGL((im2col_conv1_k<float, float>), grid, dim3(256), sh, st, (const float*)mel, (float*)out, n_mels, F, F_stride, Kp);
+  }
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int add_rows(hipStream_t st, int dtype, const void* a, const void* b, void* out, long long n) {
+  UVX_CHECK(n % 8 == 0, UVX_ERR_SHAPE, "add: n must be a multiple of 8");
+  if (n == 0) return UVX_OK;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(add_k<bf16_t>, dim3(grid1d(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / 8);
+  else
+    hipLaunchKernelGGL(add_k<float>, dim3(grid1d(n / 8, 256)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n / 8);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int cast_f32_to(hipStream_t st, int dtype, const float* in, void* out, long long n) {
+  if (n == 0) return UVX_OK;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(cast_from_f32_k<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, in, (bf16_t*)out, n);
+  else
+    hipLaunchKernelGGL(cast_from_f32_k<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, in, (float*)out, n);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int fill_zero(hipStream_t st, void* p, long long bytes) {
+  if (bytes > 0) UVX_HIP(hipMemsetAsync(p, 0, (size_t)bytes, st));
+  return UVX_OK;
+}
+
+}  // namespace uvx

@@ -1,0 +1,196 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias) (+ residual)
+//
+// Every linear layer on the Ultravox hot path is this "NT" form (activations [tokens, K] times an
+// nn.Linear weight [N, K], reference ultravox_model.py:793,798 and the [3P] Whisper/Llama layers).
+// The frozen-weight dgrad GEMMs (dX = dY . W) are ALSO run through this kernel against a transposed
+// copy of W that is materialised once at load time (288 GB HBM makes the 2x weight copy free), and
+// the projector wgrad (dW = dY^T . X) runs on transposed activations.  One kernel to tune.
+//
+// Tile: 128(M) x 128(N) x 64(K), 256 threads = 4 waves in 2(M) x 2(N), each wave 64x64 as 4x4
+// v_mfma_f32_16x16x32_bf16.  Both operands are K-contiguous so each tile row is one 128-byte line:
+// staged global->LDS with global_load_lds_dwordx4 (16 B/lane, 1 KiB per wave instruction, LDS image
+// lane-linear).  LDS rows are XOR-swizzled at 16-byte granularity (chunk ^= row & 7) by permuting
+// the per-lane SOURCE address inside the same 128-byte line (coalescing unchanged) and applying the
+// same involution on the ds_read_b128 fragment reads, which makes them bank-conflict free.
+//
+// The MFMA "A" operand is the weight tile and "B" the activation tile, so the accumulator fragment
+// (rows = 4 consecutive n per lane, col = m) stores 4 consecutive output columns per lane: 8-byte
+// bf16x4 / 16-byte f32x4 stores, bias as one vector load.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const bf16_t* bias;
+  const bf16_t* residual;
+  int M, N, K;
+  int lda, ldb, ldc, ldr;
+  int res_mod;
+  long long sA, sB, sC, sR;
+  int act;
+  int out_f32;
+  int accumulate;  // f32 output only: C += result
+  float alpha;
+  int tiles_m, tiles_n;
+};
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+__device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * BM * BK * 2];
+  char* ldsX = lds;
+  char* ldsW = lds + BM * BK * 2;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w >> 1, wc = w & 1;
+
+  // XCD-aware bijective remap: block b is dispatched to XCD b % 8; give every XCD a contiguous run
+  // of tile ids so that neighbouring tiles (same weight panel) share that XCD's L2.
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const long long z = blockIdx.y;
+  const bf16_t* A = p.A + z * p.sA;
+  const bf16_t* B = p.B + z * p.sB;
+
+  // ---- staging addresses: wave w issues instructions (i*4 + w), each covering 8 tile rows ----
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const bf16_t* ap[4];
+  const bf16_t* bp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = (i * 4 + w) * 8 + srow;
+    const int am = min(m0 + rr, p.M - 1);
+    const int bn = min(n0 + rr, p.N - 1);
+    ap[i] = A + (long long)am * p.lda + schunk * 8;
+    bp[i] = B + (long long)bn * p.ldb + schunk * 8;
+  }
+
+  // ---- fragment read offsets (bytes inside a tile) ----
+  const int frow = lane & 15, fg = lane >> 4;
+  int xoff[2], woff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int pos = (ks * 4 + fg) ^ (frow & 7);
+    xoff[ks] = (wr * 64 + frow) * 128 + pos * 16;
+    woff[ks] = (wc * 64 + frow) * 128 + pos * 16;
+  }
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < p.K; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(ap[i] + k0, ldsX + (i * 4 + w) * 1024);
+      glds16(bp[i] + k0, ldsW + (i * 4 + w) * 1024);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): LDS-DMA landed (this wave)
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t xa[4], wa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xa[i] = *reinterpret_cast<const bf16x8_t*>(ldsX + xoff[ks] + i * 16 * 128);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        wa[j] = *reinterpret_cast<const bf16x8_t*>(ldsW + woff[ks] + j * 16 * 128);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[j][i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const bool bf16_out = !p.out_f32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + fg * 4;
+    if (n >= p.N) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + frow;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = acc[j][i][e] * p.alpha + bv[e];
+        if (bf16_out) t = bf2f(f2bf(t));  // the reference rounds the linear output before act/residual
+        if (p.act == 1) {
+          t = gelu_erf(t);
+          if (bf16_out) t = bf2f(f2bf(t));
+        }
+        v[e] = t;
+      }
+      if (p.residual) {
+        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+        u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
+      }
+      const long long off = z * p.sC + (long long)m * p.ldc + n;
+      if (bf16_out) {
+        u16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *reinterpret_cast<u16x4_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
+      } else {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off);
+        if (p.accumulate) {
+          float4 c = *dst;
+          v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
+        }
+        *dst = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
+  UVX_CHECK(d.M > 0 && d.N > 0 && d.K > 0, UVX_ERR_SHAPE, "gemm: empty problem %dx%dx%d", d.M, d.N, d.K);
+  UVX_CHECK(d.K % BK == 0, UVX_ERR_SHAPE, "gemm: K=%d must be a multiple of %d", d.K, BK);
+  UVX_CHECK(d.N % 4 == 0 && d.ldc % 4 == 0, UVX_ERR_SHAPE, "gemm: N=%d / ldc=%d must be multiples of 4", d.N, d.ldc);
+  UVX_CHECK(d.lda % 8 == 0 && d.ldb % 8 == 0, UVX_ERR_SHAPE, "gemm: lda=%d / ldb=%d must be multiples of 8", d.lda, d.ldb);
+  UVX_CHECK(!d.residual || d.ldr % 4 == 0, UVX_ERR_SHAPE, "gemm: ldr=%d must be a multiple of 4", d.ldr);
+  UVX_CHECK(!d.accumulate || d.out_f32, UVX_ERR_INVALID, "gemm: accumulate needs f32 output");
+  GemmArgs a;
+  a.A = (const bf16_t*)d.A; a.B = (const bf16_t*)d.B; a.C = d.C;
+  a.bias = (const bf16_t*)d.bias; a.residual = (const bf16_t*)d.residual;
+  a.M = d.M; a.N = d.N; a.K = d.K;
+  a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr;
+  a.res_mod = d.res_mod;
+  a.sA = d.sA; a.sB = d.sB; a.sC = d.sC; a.sR = d.sR;
+  a.act = d.act; a.out_f32 = d.out_f32; a.accumulate = d.accumulate; a.alpha = d.alpha;
+  a.tiles_m = cdiv(d.M, BM); a.tiles_n = cdiv(d.N, BN);
+  dim3 grid(a.tiles_m * a.tiles_n, d.batch > 0 ? d.batch : 1);
+  hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, st, a);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}

@@ -1,0 +1,120 @@
+// Internal C++ launcher interface shared by the kernel translation units and the C-ABI layer.
+// (Nothing here is exported; the exported surface is include/uvx.h.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace uvx {
+
+enum DType { DT_BF16 = 0, DT_F32 = 1 };
+
+struct GemmDesc {
+  const void* A = nullptr;  // [M, K], row stride lda (activations)
+  const void* B = nullptr;  // [N, K], row stride ldb (nn.Linear weight layout)
+  void* C = nullptr;        // [M, N], row stride ldc
+  const void* bias = nullptr;      // [N] or null
+  const void* residual = nullptr;  // [M or res_mod, N] (row stride ldr) or null
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldb = 0, ldc = 0, ldr = 0;
+  int res_mod = 0;   // >0: residual row = m % res_mod (positional-embedding add)
+  int batch = 1;
+  long long sA = 0, sB = 0, sC = 0, sR = 0;  // batch strides in elements
+  int act = 0;       // 0 none, 1 exact-erf GELU
+  int out_f32 = 0;   // bf16 path only: write f32 (wgrad)
+  int accumulate = 0;
+  float alpha = 1.0f;
+};
+
+// bf16 operands, f32 accumulate (MFMA 16x16x32).
+int gemm_nt(hipStream_t st, const GemmDesc& d);
+// f32 operands/outputs (parity mode; MFMA 16x16x4 f32).
+int gemm_nt_f32(hipStream_t st, const GemmDesc& d);
+// dispatch on dtype
+inline int gemm(hipStream_t st, int dtype, const GemmDesc& d) {
+  return dtype == DT_BF16 ? gemm_nt(st, d) : gemm_nt_f32(st, d);
+}
+
+// ---- norms.hip ----
+int layernorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, const void* b, void* y,
+                  int rows, int cols, float eps);
+// y = rmsnorm(x) * w ; optionally stores rstd[rows] (f32) for backward
+int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, float* rstd,
+                int rows, int cols, float eps);
+// dx = d(rmsnorm)/dx (+ dx_add if given: residual-stream gradient), optional dw partial accumulation
+// (f32 [cols], atomically accumulated; must be zeroed by the caller).
+int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w,
+                const void* dx_add, void* dx, float* dw, int rows, int cols, float eps);
+// StackAudioFrames + RMSNorm (ultravox_model.py:722-730, 791): x [B, T, C] -> y [B, Tp/S, C*S]
+int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked,
+                      int B, int T, int C, int S, float eps);
+
+// ---- elementwise.hip ----
+int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first);
+int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
+               int gate_first);
+int rope_inplace(hipStream_t st, int dtype, void* qkv, const float* cos_sin, const int32_t* pos, int rows,
+                 int T, int n_heads_rot, int head_dim, int ld, int inverse);
+int embed_gather(hipStream_t st, int dtype, const void* table, const int64_t* ids, void* out, int rows,
+                 int D, int vocab);
+int merge_audio(hipStream_t st, int dtype, void* embeds, const void* audio, const int32_t* item_batch,
+                const int64_t* start, const int32_t* len, int n_items, int T, int D, int Na);
+int merge_audio_bwd(hipStream_t st, int dtype, const void* dembeds, void* daudio, const int32_t* row_src,
+                    int n_items, int Na, int D);
+int transpose2d(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in,
+                int ld_out, int batch, long long s_in, long long s_out);
+int im2col_conv1(hipStream_t st, int dtype, const void* mel, int mel_is_f32, void* out, int B, int n_mels,
+                 int F, int F_stride, int Kp);
+int add_rows(hipStream_t st, int dtype, const void* a, const void* b, void* out, long long n);
+int cast_f32_to(hipStream_t st, int dtype, const float* in, void* out, long long n);
+int fill_zero(hipStream_t st, void* p, long long bytes);
+
+// ---- attention.hip ----
+struct AttnDesc {
+  const void* q = nullptr;   // [B, T, Hq, D] with row (token) stride ldq elements
+  const void* k = nullptr;   // [B, T, Hkv, D] row stride ldk
+  const void* v = nullptr;   // [B, T, Hkv, D] row stride ldv (backward only)
+  const void* vt = nullptr;  // [B, Hkv, D, Tp]  (forward)
+  void* o = nullptr;         // [B, T, Hq*D] row stride ldo
+  float* lse = nullptr;      // [B, Hq, T]
+  const int32_t* kv_start = nullptr;  // [B] first valid key (left padding) or null
+  const int32_t* kv_len = nullptr;    // [B] one-past-last valid key or null
+  int B = 0, T = 0, Tp = 0, Hq = 0, Hkv = 0, D = 0;
+  int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+  int causal = 0;
+  int block = 0;  // >0: block-causal "latency" mask, block size in positions
+  float scale = 1.0f;
+};
+int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d);
+struct AttnBwdDesc {
+  AttnDesc f;
+  const void* dout = nullptr;  // [B, T, Hq*D] row stride ldo
+  const void* qt = nullptr;    // [B, Hq, D, Tp]
+  const void* kt = nullptr;    // [B, Hkv, D, Tp]
+  const void* dot = nullptr;   // [B, Hq, D, Tp]
+  float* delta = nullptr;      // [B, Hq, T] scratch
+  void* dq = nullptr; void* dk = nullptr; void* dv = nullptr;  // same layouts/strides as q,k,v
+  int lddq = 0, lddk = 0, lddv = 0;
+};
+int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d);
+// [B, T, H, D] (row stride ld) -> [B, H, D, Tp], zero padded in T
+int heads_transpose(hipStream_t st, int dtype, const void* in, void* out, int B, int T, int Tp, int H,
+                    int D, int ld);
+
+// ---- loss.hip ----
+// Shifted causal-LM cross entropy over bf16/f32 logits [rows=B*T, V] (ld = ldl).
+// labels [B, T] int64 (ignore_index -100).  Writes loss (f32 scalar, mean over valid shifted tokens),
+// n_valid, and (if dlogits) d loss / d logits in the logits dtype, IN PLACE allowed.
+int ce_loss_fwd_bwd(hipStream_t st, int dtype, const void* logits, const int64_t* labels, float* loss,
+                    float* scratch, void* dlogits, int B, int T, int V, int ldl, float grad_scale);
+
+// ---- optim.hip ----
+int grad_sq_norm(hipStream_t st, const float* g, long long n, float* out_sumsq);
+int adamw_clip_step(hipStream_t st, int param_dtype, void* param, float* master, const float* grad,
+                    float* m, float* v, long long n, const float* sumsq, float max_norm, float lr,
+                    float beta1, float beta2, float eps, float wd, int step);
+
+// ---- logmel.hip ----
+int logmel(hipStream_t st, const float* pcm, const float* dft_cos_sin, const float* mel_fb, float* out,
+           float* scratch, int B, int L, int n_mels, int F_out, int F_stride);
+
+}  // namespace uvx

@@ -1,0 +1,242 @@
+// LayerNorm / RMSNorm kernels (HBM-bound; 16-byte vector access, f32 statistics).
+//
+//  layernorm_fwd      — [3P] nn.LayerNorm inside WhisperEncoderLayer + final layer_norm
+//                       (reference call sites ultravox_model.py:966-973, :980), eps 1e-5.
+//  rmsnorm_fwd/bwd    — LlamaRMSNorm semantics (ultravox_model.py:733-736): statistics in f32,
+//                       x_hat cast to the activation dtype BEFORE the weight multiply.
+//  stack_rmsnorm_fwd  — StackAudioFrames (ultravox_model.py:722-730) fused with ln_pre (:791).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXV = 6;  // 8-element vectors per thread kept in registers (cols <= 256*8*6 = 12288)
+
+template <typename T>
+__global__ void layernorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ b,
+                                T* __restrict__ y, int cols, float eps) {
+  __shared__ float red[16];
+  const long long row = blockIdx.x;
+  const T* xr = x + row * cols;
+  T* yr = y + row * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) {
+    float v[8];
+    ld8<T>(xr + c, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+  }
+  const float mean = block_sum(s, red) / cols;
+  float q = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) {
+    float v[8];
+    ld8<T>(xr + c, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; q += d * d; }
+  }
+  const float rstd = rsqrtf(block_sum(q, red) / cols + eps);
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) {
+    float v[8], wv[8], bv[8], o[8];
+    ld8<T>(xr + c, v);
+    ld8<T>(w + c, wv);
+    ld8<T>(b + c, bv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (v[i] - mean) * rstd * wv[i] + bv[i];
+    st8<T>(yr + c, o);
+  }
+}
+
+// Row addressing shared by the plain and the frame-stacking RMSNorm: a logical row of `cols`
+// elements starts at `base` and only the first `valid` elements exist (the rest read as zero).
+struct RowMap {
+  int J, T, S, C;  // S == 0: plain [rows, cols]
+};
+__device__ __forceinline__ void row_span(const RowMap& m, long long row, int cols, long long& base, int& valid) {
+  if (m.S == 0) { base = row * cols; valid = cols; return; }
+  const long long b = row / m.J;
+  const int j = (int)(row % m.J);
+  base = (b * m.T + (long long)j * m.S) * m.C;
+  const int frames = min(m.S, m.T - j * m.S);
+  valid = frames * m.C;
+}
+
+template <typename T>
+__global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y,
+                              T* __restrict__ stacked, float* __restrict__ rstd_out, int cols, float eps,
+                              RowMap map) {
+  __shared__ float red[16];
+  const long long row = blockIdx.x;
+  long long base; int valid;
+  row_span(map, row, cols, base, valid);
+  const T* xr = x + base;
+  T* yr = y + row * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x * 8; c < valid; c += blockDim.x * 8) {
+    float v[8];
+    ld8<T>(xr + c, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i] * v[i];
+  }
+  const float rstd = rsqrtf(block_sum(s, red) / cols + eps);
+  if (rstd_out && threadIdx.x == 0) rstd_out[row] = rstd;
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) {
+    float v[8], wv[8], o[8];
+    if (c < valid) ld8<T>(xr + c, v);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+    ld8<T>(w + c, wv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = wv[i] * rnd<T>(v[i] * rstd);
+    st8<T>(yr + c, o);
+    if (stacked) st8<T>(stacked + row * cols + c, v);
+  }
+}
+
+// One block handles `rpb` consecutive rows; each thread owns fixed columns so the weight gradient
+// is accumulated in registers and flushed with one atomicAdd per column per block.
+template <typename T, bool WANT_DX, bool WANT_DW>
+__global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
+                              const T* __restrict__ dx_add, T* __restrict__ dx, float* __restrict__ dw,
+                              int rows, int cols, float eps, int rpb) {
+  __shared__ float red[16];
+  __shared__ float red2[16];
+  float dwacc[MAXV][8];
+  if (WANT_DW) {
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dwacc[j][i] = 0.f;
+  }
+  const int r0 = blockIdx.x * rpb;
+  const int r1 = min(rows, r0 + rpb);
+  for (int row = r0; row < r1; ++row) {
+    const T* xr = x + (long long)row * cols;
+    const T* dyr = dy + (long long)row * cols;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) {
+      float xv[8], gv[8], wv[8];
+      ld8<T>(xr + c, xv);
+      ld8<T>(dyr + c, gv);
+      ld8<T>(w + c, wv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s1 += xv[i] * xv[i]; s2 += gv[i] * wv[i] * xv[i]; }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red2);
+    const float r = rsqrtf(s1 / cols + eps);
+    const float coef = r * r * r * s2 / cols;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {  // static trip count: dwacc[j] must stay in registers
+      const int c = (j * blockDim.x + threadIdx.x) * 8;
+      if (c >= cols) continue;
+      float xv[8], gv[8], wv[8];
+      ld8<T>(xr + c, xv);
+      ld8<T>(dyr + c, gv);
+      if (WANT_DX) {
+        ld8<T>(w + c, wv);
+        float o[8];
+        if (dx_add) ld8<T>(dx_add + (long long)row * cols + c, o);
+        else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += r * gv[i] * wv[i] - xv[i] * coef;
+        st8<T>(dx + (long long)row * cols + c, o);
+      }
+      if (WANT_DW) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dwacc[j][i] += gv[i] * rnd<T>(xv[i] * r);
+      }
+    }
+  }
+  if (WANT_DW) {
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int c = (j * blockDim.x + threadIdx.x) * 8;
+      if (c >= cols) continue;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(dw + c + i, dwacc[j][i]);
+    }
+  }
+}
+
+int norm_threads(int cols) {
+  int t = ((cols / 8) + 63) / 64 * 64;
+  return t < 64 ? 64 : (t > 256 ? 256 : t);
+}
+
+}  // namespace
+
+namespace uvx {
+
+int layernorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, const void* b, void* y, int rows,
+                  int cols, float eps) {
+  UVX_CHECK(cols % 8 == 0, UVX_ERR_SHAPE, "layernorm: cols=%d must be a multiple of 8", cols);
+  if (rows == 0) return UVX_OK;
+  const int th = norm_threads(cols);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(layernorm_fwd_k<bf16_t>, dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w,
+                       (const bf16_t*)b, (bf16_t*)y, cols, eps);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_k<float>, dim3(rows), dim3(th), 0, st, (const float*)x, (const float*)w,
+                       (const float*)b, (float*)y, cols, eps);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+static int rms_launch(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked,
+                      float* rstd, long long rows, int cols, float eps, RowMap map) {
+  UVX_CHECK(cols % 8 == 0, UVX_ERR_SHAPE, "rmsnorm: cols=%d must be a multiple of 8", cols);
+  if (rows == 0) return UVX_OK;
+  const int th = norm_threads(cols);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(rmsnorm_fwd_k<bf16_t>, dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w,
+                       (bf16_t*)y, (bf16_t*)stacked, rstd, cols, eps, map);
+  else
+    hipLaunchKernelGGL(rmsnorm_fwd_k<float>, dim3(rows), dim3(th), 0, st, (const float*)x, (const float*)w,
+                       (float*)y, (float*)stacked, rstd, cols, eps, map);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, float* rstd, int rows,
+                int cols, float eps) {
+  return rms_launch(st, dtype, x, w, y, nullptr, rstd, rows, cols, eps, RowMap{0, 0, 0, 0});
+}
+
+int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked, int B,
+                      int T, int C, int S, float eps) {
+  UVX_CHECK(S > 0 && C % 8 == 0, UVX_ERR_SHAPE, "stack_rmsnorm: bad S=%d C=%d", S, C);
+  const int J = (T + S - 1) / S;
+  return rms_launch(st, dtype, x, w, y, stacked, nullptr, (long long)B * J, C * S, eps, RowMap{J, T, S, C});
+}
+
+template <typename T>
+static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const void* w, const void* dx_add,
+                          void* dx, float* dw, int rows, int cols, float eps) {
+  const int th = 256;
+  UVX_CHECK(cols % 8 == 0 && cols <= th * 8 * MAXV, UVX_ERR_SHAPE, "rmsnorm_bwd: cols=%d unsupported", cols);
+  if (rows == 0) return UVX_OK;
+  const int rpb = dw ? 16 : 1;
+  const int grid = (rows + rpb - 1) / rpb;
+#define L(DX, DW)                                                                                         \
+  hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x, \
+                     (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb)
+  if (dx && dw) L(true, true);
+  else if (dx) L(true, false);
+  else if (dw) L(false, true);
+#undef L
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w, const void* dx_add,
+                void* dx, float* dw, int rows, int cols, float eps) {
+  return dtype == DT_BF16 ? rms_bwd_launch<bf16_t>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps)
+                          : rms_bwd_launch<float>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps);
+}
+
+}  // namespace uvx
