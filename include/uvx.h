@@ -1,20 +1,26 @@
-/* libuvx — C ABI of the MI355X-native Ultravox audio->LLM hot path.
+/* libuvx — C ABI of the MI355X-native Ultravox audio->LLM hot path (gfx950 / CDNA4).
  *
  * The reference (fixie-ai/ultravox) has NO native/FFI layer: its hot path is reached through Python
  * classes (ultravox/model/ultravox_model.py:277-352 UltravoxModel.forward, :354-396
  * _prepare_audio_embeds, :768-800 UltravoxProjector.forward, :865-994 ModifiedWhisperEncoder.forward;
  * ultravox/model/ultravox_processing.py:217-370 UltravoxProcessor.__call__).  This header is the
  * boundary a replacement exports instead; each entry point names the reference code it replaces.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
  *
  * Conventions
- *  - every data pointer is a DEVICE pointer to a contiguous buffer owned by the caller;
- *  - `stream` is a hipStream_t; all calls are asynchronous on it, no hidden synchronisation;
+ *  - every data pointer is a DEVICE pointer to a contiguous, caller-owned buffer (row-major layouts
+ *    exactly as documented per argument); the library never allocates or frees device memory;
+ *  - `stream` is a hipStream_t; every call is asynchronous on it, no hidden synchronisation;
+ *  - scratch comes from a caller-allocated workspace; size it with the *_ws_bytes functions;
  *  - return value: 0 ok, <0 uvx error (below), >0 a hipError_t; message via uvx_last_error()
- *    (thread local);
- *  - dtype: UVX_BF16 (production; bf16 storage, f32 accumulate) or UVX_F32 (parity mode).
+ *    (thread local); no exception crosses the boundary;
+ *  - dtype: UVX_BF16 (production: bf16 storage, f32 accumulate/statistics) or UVX_F32 (parity mode,
+ *    every tensor f32);
+ *  - threading: one process per GPU; a handle-free, re-entrant API with no global mutable state.
  */
 #ifndef UVX_H_
 #define UVX_H_
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -25,18 +31,137 @@ extern "C" {
 #define UVX_F32 1
 
 #define UVX_OK 0
-#define UVX_ERR_INVALID (-1)
-#define UVX_ERR_SHAPE (-2)
-#define UVX_ERR_WORKSPACE (-3)
-#define UVX_ERR_UNSUPPORTED (-4)
+#define UVX_ERR_INVALID (-1)     /* bad argument                       -> ValueError in the Python mirror */
+#define UVX_ERR_SHAPE (-2)       /* unsupported / inconsistent shape   -> ValueError */
+#define UVX_ERR_WORKSPACE (-3)   /* workspace too small                -> RuntimeError */
+#define UVX_ERR_UNSUPPORTED (-4) /* feature not built                  -> RuntimeError */
 
 const char* uvx_last_error(void);
 int32_t uvx_abi_version(void);
 
-/* ---- single-op entry points -------------------------------------------------------------- */
+/* ============================== model description ============================== */
 
-/* C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual — torch.nn.Linear semantics
- * (every q/k/v/out/fc/linear_1/linear_2/gate/up/down/lm_head on the path). */
+typedef struct {
+  int32_t dtype;
+  /* audio tower: Whisper encoder (ModifiedWhisperEncoder, ultravox_model.py:803-994) */
+  int32_t enc_layers, enc_d, enc_heads, enc_ffn, n_mels, enc_max_pos;
+  int32_t enc_block; /* audio_latency_block_size (ultravox_model.py:834-863), 0 = no streaming mask */
+  float ln_eps;      /* nn.LayerNorm eps (1e-5) */
+  /* projector (UltravoxProjector, ultravox_model.py:745-800) */
+  int32_t stack_factor, proj_hidden, proj_ln_mid;
+  float proj_eps; /* RMSNorm eps (1e-6, ultravox_model.py:734) */
+  /* language model (Llama family, reached at ultravox_model.py:328-334) */
+  int32_t llm_layers, llm_d, llm_heads, llm_kv_heads, llm_head_dim, llm_inter, vocab;
+  float rms_eps;
+} uvx_config_t;
+
+/* Encoder weights.  Names follow the HF WhisperEncoder state dict; packing done once at
+ * load time by the host:  wqkv = [q_proj*head_dim^-0.5 ; k_proj ; v_proj] ([3d, d]), bqkv likewise with a
+ * zero k bias;  conv1_w [d, Kp1] with column k*n_mels + c = conv1.weight[:, c, k] zero padded to
+ * Kp1 = roundup(3*n_mels, 64);  conv2_w [d, 3d] with column k*d + c = conv2.weight[:, c, k]. */
+typedef struct {
+  const void *ln1_w, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} uvx_enc_layer_t;
+typedef struct {
+  const void *conv1_w, *conv1_b, *conv2_w, *conv2_b, *pos;
+  const uvx_enc_layer_t* layers; /* HOST array [enc_layers] of device-pointer records */
+  const void *lnf_w, *lnf_b;
+} uvx_encoder_weights_t;
+
+/* multi_modal_projector.{ln_pre,linear_1,ln_mid|ln_post,linear_2}.weight (ultravox_model.py:749-766) */
+typedef struct {
+  const void *ln_pre, *w1, *ln_mid, *w2, *ln_post;
+} uvx_projector_weights_t;
+/* f32 gradient outputs, same shapes as the weights (ln_mid / ln_post: the one that exists) */
+typedef struct {
+  float *ln_pre, *w1, *ln_mid, *w2, *ln_post;
+} uvx_projector_grads_t;
+
+/* Llama layer: wqkv = [q;k;v] ([(H+2Hkv)*dh, D]), wgu = [gate;up] ([2I, D]); the *_t members are the
+ * transposed copies ([K_in, N_out] -> nn.Linear layout of the transposed map) used for the frozen-weight
+ * activation gradients; they may be NULL for forward-only use. */
+typedef struct {
+  const void *ln1, *wqkv, *wo, *ln2, *wgu, *wd;
+  const void *wqkv_t, *wo_t, *wgu_t, *wd_t;
+} uvx_llm_layer_t;
+typedef struct {
+  const void* embed;             /* [vocab, D] */
+  const uvx_llm_layer_t* layers; /* HOST array [llm_layers] */
+  const void* norm;              /* [D] */
+  const void* lm_head;           /* [vocab, D] */
+  const void* lm_head_t;         /* [D, vocab] or NULL */
+  const float* rope_cos_sin;     /* [rope_len, head_dim/2, 2] f32 (cos, sin), built by the host */
+  int32_t rope_len;
+} uvx_llm_weights_t;
+
+/* ============================== hot-path entry points ============================== */
+
+/* K1 — log-mel frontend.  Replaces the [3P] WhisperFeatureExtractor call at
+ * ultravox_processing.py:295-303.  pcm [B, L] f32 (L % 160 == 0, already padded as the reference pads);
+ * out [B, n_mels, F_stride] f32, F = L/160 frames written.  Tables built by the host
+ * (ultravox_amd/frontend.py): window[400], tw_cos/tw_sin [400][208], mel_fb [n_mels][208].
+ * scratch: B * ceil(F/32) floats. */
+int32_t uvx_logmel(void* stream, const float* pcm, const float* window, const float* tw_cos, const float* tw_sin,
+                   const float* mel_fb, float* out, float* scratch, int32_t B, int32_t L, int32_t n_mels,
+                   int32_t F_stride);
+
+/* ModifiedWhisperEncoder.forward (ultravox_model.py:865-994), inference mode (frozen tower).
+ * mel [B, n_mels, F] (f32 if mel_is_f32 else cfg dtype; cast like ultravox_model.py:383);
+ * audio_lens [B] int64 mel-frame lengths or NULL (no padding mask); out [B, Te, d], Te = (F-1)/2+1. */
+size_t uvx_encoder_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t F);
+int32_t uvx_encoder_fwd(void* stream, const uvx_config_t* cfg, const uvx_encoder_weights_t* w, const void* mel,
+                        int32_t mel_is_f32, const int64_t* audio_lens, int32_t B, int32_t F, void* out,
+                        void* workspace, size_t ws_bytes);
+
+/* UltravoxProjector.forward (ultravox_model.py:768-800) and its backward.  enc_out [B, Te, C];
+ * out [B, Na, D] with Na = ceil(Te / stack_factor).  The forward leaves its activations in `workspace`;
+ * the backward must be given the same (untouched) workspace.  dout [B, Na, D]; grads are f32 and
+ * OVERWRITTEN. */
+size_t uvx_projector_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t Te);
+int32_t uvx_projector_fwd(void* stream, const uvx_config_t* cfg, const uvx_projector_weights_t* w, const void* enc_out,
+                          int32_t B, int32_t Te, void* out, void* workspace, size_t ws_bytes);
+int32_t uvx_projector_bwd(void* stream, const uvx_config_t* cfg, const uvx_projector_weights_t* w, const void* dout,
+                          int32_t B, int32_t Te, const uvx_projector_grads_t* grads, void* workspace,
+                          size_t ws_bytes);
+
+/* embed_tokens + the in-place audio overwrite loop (ultravox_model.py:314-316, :390-394, :259-275).
+ * input_ids [B, T] int64; audio_embeds [n_items, Na, D]; audio_batch_size [B] int64;
+ * audio_token_start_idx [n_items] int64; audio_token_len [n_items] int32.  Later items overwrite earlier
+ * ones exactly as the reference's sequential loop does.  scratch: (B*T + n_items) int32, kept for
+ * uvx_merge_embeds_bwd (d audio_embeds = gather of d inputs_embeds rows; text rows get no gradient). */
+int32_t uvx_embed_merge(void* stream, const uvx_config_t* cfg, const void* embed_table, const int64_t* input_ids,
+                        const void* audio_embeds, const int64_t* audio_batch_size, const int64_t* audio_token_start_idx,
+                        const int32_t* audio_token_len, int32_t B, int32_t T, int32_t n_items, int32_t Na,
+                        void* inputs_embeds, int32_t* scratch);
+int32_t uvx_merge_embeds_bwd(void* stream, const uvx_config_t* cfg, const void* d_inputs_embeds,
+                             const int64_t* audio_token_start_idx, const int32_t* audio_token_len, int32_t B, int32_t T,
+                             int32_t n_items, int32_t Na, void* d_audio_embeds, const int32_t* scratch);
+
+/* LlamaForCausalLM.forward(inputs_embeds, attention_mask, labels) + ForCausalLMLoss
+ * (reached at ultravox_model.py:328-334).  inputs_embeds [B, T, D]; attention_mask [B, T] int64 (1 = keep;
+ * the kept range must be contiguous, as the collator produces) or NULL; labels [B, T] int64 or NULL;
+ * logits [B, T, vocab] (cfg dtype) or NULL when only the loss is wanted and save_for_bwd = 0... it is
+ * still computed internally; loss f32[1] or NULL.  With save_for_bwd != 0 the per-layer activations are
+ * kept in `workspace` for uvx_llm_bwd. */
+size_t uvx_llm_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t T, int32_t save_for_bwd);
+int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                    const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T, void* logits,
+                    float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes);
+/* Activation-gradient backward of the frozen LLM (apply_lora r=0 freeze, ultravox_model.py:697-703):
+ * d loss / d inputs_embeds [B, T, D], loss scaled by grad_scale (1 / gradient_accumulation_steps). */
+int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
+                    int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes);
+
+/* clip_grad_norm_(max_norm) + torch.optim.AdamW step over one flat parameter bucket (train.py:260,
+ * config_base.py:149-154).  grad: f32 [n] (already DP-averaged).  state_dtype selects the storage of
+ * param/m/v (bf16 mirrors the reference's bf16 optimizer state); with master != NULL the update runs on
+ * f32 master weights and f32 moments.  scratch: 1025 floats. step counts from 1. */
+int32_t uvx_adamw_clip_step(void* stream, int32_t state_dtype, void* param, float* master, const float* grad, void* m,
+                            void* v, int64_t n, float max_norm, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int32_t step, float* scratch);
+
+/* ============================== single-op entry points (tests, probes) ============================== */
+
 typedef struct {
   const void* A; const void* B; void* C; const void* bias; const void* residual;
   int32_t M, N, K, lda, ldb, ldc, ldr;
@@ -47,7 +172,38 @@ typedef struct {
   int32_t accumulate; /* C += (f32 output only) */
   float alpha;
 } uvx_gemm_desc_t;
+/* C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual — torch.nn.Linear semantics. */
 int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* desc);
+
+int32_t uvx_layernorm(void* stream, int32_t dtype, const void* x, const void* w, const void* b, void* y, int32_t rows,
+                      int32_t cols, float eps);
+int32_t uvx_rmsnorm(void* stream, int32_t dtype, const void* x, const void* w, void* y, int32_t rows, int32_t cols,
+                    float eps);
+int32_t uvx_rmsnorm_bwd(void* stream, int32_t dtype, const void* dy, const void* x, const void* w, const void* dx_add,
+                        void* dx, float* dw, int32_t rows, int32_t cols, float eps);
+int32_t uvx_swiglu(void* stream, int32_t dtype, const void* in, void* out, int32_t rows, int32_t half, int32_t gate_first);
+int32_t uvx_swiglu_bwd(void* stream, int32_t dtype, const void* dout, const void* in, void* din, int32_t rows,
+                       int32_t half, int32_t gate_first);
+int32_t uvx_rope(void* stream, int32_t dtype, void* x, const float* cos_sin, int32_t rows, int32_t T, int32_t n_heads,
+                 int32_t head_dim, int32_t ld, int32_t inverse);
+
+typedef struct {
+  const void *q, *k, *v; /* [B, T, H, D] views with token strides ldq/ldk/ldv (elements) */
+  void* o;               /* [B, T, Hq*D], token stride ldo */
+  float* lse;            /* [B, Hq, T] log2-domain log-sum-exp (needed for backward) or NULL */
+  const int32_t *kv_start, *kv_len; /* [B] valid key range or NULL */
+  int32_t B, T, Hq, Hkv, D, ldq, ldk, ldv, ldo, causal, block;
+  float scale;
+  /* backward only */
+  const void* dout; void *dq, *dk, *dv; int32_t lddq, lddk, lddv;
+} uvx_attn_desc_t;
+size_t uvx_attention_ws_bytes(int32_t dtype, const uvx_attn_desc_t* d, int32_t backward);
+int32_t uvx_attention_fwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d, void* workspace, size_t ws_bytes);
+int32_t uvx_attention_bwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d, void* workspace, size_t ws_bytes);
+
+/* scratch: 2 + B*T floats */
+int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, const int64_t* labels, float* loss, void* dlogits,
+                    int32_t B, int32_t T, int32_t V, int32_t ld, float grad_scale, float* scratch);
 
 #ifdef __cplusplus
 }

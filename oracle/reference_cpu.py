@@ -1,0 +1,353 @@
+"""ORACLE — test infrastructure only.  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import this module; the product path (ultravox_amd/) never does.
+
+A CPU restatement, in plain PyTorch, of the reference's audio->LLM hot path.  Each function cites the
+reference lines (relative to /root/reference) or the third-party (transformers 4.51.3, pinned by the
+reference's poetry.lock:7739-7740) routine it follows.  The reference's own model module cannot be
+imported as-is in this image (`peft` missing, transformers 5.x API drift — SURVEY.md §8c), hence a
+restatement; it is pinned against
+  * the reference's UltravoxProjector / StackAudioFrames / RMSNorm / SwiGLU classes and the reference's
+    UltravoxProcessor, imported from /root/reference in the build container (tests/golden/make_golden.py
+    writes the fixtures, tests/test_oracle_pinning.py replays them anywhere);
+  * the installed HF WhisperFeatureExtractor, WhisperEncoderLayer and LlamaForCausalLM blocks
+    (tests/test_oracle_pinning.py), which are the third-party arithmetic the reference calls.
+Floating-point parity of mel / encoder / logits / loss / grads is NOT pinned by any reference test
+("parity unpinned" at the fp level); integer/index behaviour is pinned.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+N_FFT, HOP = 400, 160
+
+
+# ----------------------------------------------------------------------------------------------
+# K1 — log-mel.  [3P] WhisperFeatureExtractor._torch_extract_fbank_features, called from
+# ultravox_processing.py:295-303.
+# ----------------------------------------------------------------------------------------------
+def mel_filters_ref(n_mels: int) -> np.ndarray:
+    """[3P] audio_utils.mel_filter_bank(201, n_mels, 0, 8000, 16000, norm='slaney', mel_scale='slaney')."""
+
+    def hz2mel(f):
+        f = np.asarray(f, np.float64)
+        m = 3.0 * f / 200.0
+        big = f >= 1000.0
+        m = np.where(big, 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) * (27.0 / np.log(6.4)), m)
+        return m
+
+    def mel2hz(m):
+        m = np.asarray(m, np.float64)
+        f = 200.0 * m / 3.0
+        big = m >= 15.0
+        return np.where(big, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), f)
+
+    edges = mel2hz(np.linspace(hz2mel(0.0), hz2mel(8000.0), n_mels + 2))
+    bins = np.linspace(0, 8000, 201)
+    out = np.zeros((201, n_mels))
+    for j in range(n_mels):
+        lo, ce, hi = edges[j], edges[j + 1], edges[j + 2]
+        rise = (bins - lo) / (ce - lo)
+        fall = (hi - bins) / (hi - ce)
+        out[:, j] = np.maximum(0.0, np.minimum(rise, fall)) * (2.0 / (hi - lo))
+    return out
+
+
+def logmel_ref(waveform: torch.Tensor, n_mels: int = 80) -> torch.Tensor:
+    """waveform [B, L] f32 -> [B, n_mels, L // 160] f32 (STFT, power, drop last frame, mel, log10,
+    per-clip floor at max - 8, (x + 4) / 4)."""
+    waveform = waveform.to(torch.float32)
+    window = torch.hann_window(N_FFT)
+    stft = torch.stft(waveform, N_FFT, HOP, window=window, return_complex=True)
+    power = stft[..., :-1].abs() ** 2
+    fb = torch.from_numpy(mel_filters_ref(n_mels)).to(torch.float32)
+    mel = fb.T @ power
+    log_spec = torch.clamp(mel, min=1e-10).log10()
+    mx = log_spec.max(dim=2, keepdim=True)[0].max(dim=1, keepdim=True)[0]
+    log_spec = torch.maximum(log_spec, mx - 8.0)
+    return (log_spec + 4.0) / 4.0
+
+
+class FeatureExtractorRef:
+    """The subset of the HF feature-extractor call contract that ultravox_processing.py:295-303 uses."""
+
+    hop_length = HOP
+    sampling_rate = 16000
+    model_input_names = ["input_features"]
+
+    def __init__(self, feature_size: int = 80):
+        self.feature_size = feature_size
+
+    @property
+    def feature_extractor(self):
+        return self
+
+    def __call__(self, raw_speech, sampling_rate=None, padding="longest", pad_to_multiple_of=None, truncation=False,
+                 return_attention_mask=True, **kw):
+        raw = [np.asarray(x, np.float32) for x in raw_speech]
+        L = max(len(x) for x in raw)
+        if pad_to_multiple_of:
+            L = -(-L // pad_to_multiple_of) * pad_to_multiple_of
+        batch = np.zeros((len(raw), L), np.float32)
+        mask = np.zeros((len(raw), L), np.int32)
+        for i, x in enumerate(raw):
+            batch[i, : len(x)] = x
+            mask[i, : len(x)] = 1
+        feats = logmel_ref(torch.from_numpy(batch), self.feature_size)
+        fmask = mask[:, ::HOP]
+        if L % HOP != 0:
+            fmask = fmask[:, :-1]
+        return {"input_features": feats, "attention_mask": torch.from_numpy(np.ascontiguousarray(fmask))}
+
+
+# ----------------------------------------------------------------------------------------------
+# Encoder — ModifiedWhisperEncoder.forward, ultravox_model.py:865-994 (+ [3P] WhisperEncoderLayer /
+# WhisperAttention / get_extended_attention_mask).
+# ----------------------------------------------------------------------------------------------
+def latency_mask_ref(max_context: int, block: int, dtype: torch.dtype) -> torch.Tensor:
+    """init_latency_mask, ultravox_model.py:834-863."""
+    assert max_context % block == 0, f"audio_latency_block_size {block} must divide {max_context} evenly."
+    nb = max_context // block
+    m = torch.tril(torch.ones(nb, nb)).repeat_interleave(block, 0).repeat_interleave(block, 1)
+    return ((1.0 - m) * torch.finfo(dtype).min)[None, None]
+
+
+def whisper_encoder_ref(sd: Dict[str, torch.Tensor], cfg, input_features: torch.Tensor,
+                        audio_len: Optional[torch.Tensor], prefix: str = "audio_tower.",
+                        return_layer: Optional[int] = None) -> torch.Tensor:
+    a = cfg.audio_config
+    dt = input_features.dtype
+    H, d = a.encoder_attention_heads, a.d_model
+    dh = d // H
+    W = lambda k: sd[prefix + k].to(dt)
+    max_ctx = a.max_source_positions * 2                                           # :826-832
+    if input_features.shape[-1] > max_ctx:                                         # :874-878
+        raise ValueError(f"Whisper expects the mel input features to be of length {max_ctx} or less, but found "
+                         f"{input_features.shape[-1]}. Make sure to pad the input mel features to {max_ctx}.")
+    x = F.gelu(F.conv1d(input_features, W("conv1.weight"), W("conv1.bias"), padding=1))         # :893
+    x = F.gelu(F.conv1d(x, W("conv2.weight"), W("conv2.bias"), stride=2, padding=1))            # :894
+    x = x.permute(0, 2, 1)                                                                       # :896
+    x = x + W("embed_positions.weight")[: x.size(-2)]                                            # :897-899
+    B, S, _ = x.shape
+    mask = None
+    if audio_len is not None:                                                                    # :915-926
+        feat_len = (audio_len - 1) // 2 + 1
+        keep = torch.arange(S)[None, :].lt(feat_len.view(-1, 1))
+        mask = (1.0 - keep[:, None, None, :].to(dt)) * torch.finfo(dt).min
+    if cfg.audio_latency_block_size is not None:                                                 # :928-936
+        sm = latency_mask_ref(max_ctx, cfg.audio_latency_block_size, dt)[:, :, :S, :S]
+        mask = torch.minimum(sm, mask) if mask is not None else sm
+        mask = mask.to(dt)
+    scaling = dh ** -0.5
+    for i in range(a.encoder_layers):                                                            # :944-975
+        L = f"layers.{i}."
+        res = x
+        h = F.layer_norm(x, (d,), W(L + "self_attn_layer_norm.weight"), W(L + "self_attn_layer_norm.bias"), a.layer_norm_eps)
+        q = F.linear(h, W(L + "self_attn.q_proj.weight"), W(L + "self_attn.q_proj.bias")) * scaling
+        k = F.linear(h, W(L + "self_attn.k_proj.weight"))
+        v = F.linear(h, W(L + "self_attn.v_proj.weight"), W(L + "self_attn.v_proj.bias"))
+        q, k, v = (t.view(B, S, H, dh).transpose(1, 2) for t in (q, k, v))
+        s = q @ k.transpose(-1, -2)
+        if mask is not None:
+            s = s + mask
+        p = torch.softmax(s.float(), dim=-1).to(dt)
+        o = (p @ v).transpose(1, 2).reshape(B, S, d)
+        x = res + F.linear(o, W(L + "self_attn.out_proj.weight"), W(L + "self_attn.out_proj.bias"))
+        res = x
+        h = F.layer_norm(x, (d,), W(L + "final_layer_norm.weight"), W(L + "final_layer_norm.bias"), a.layer_norm_eps)
+        h = F.gelu(F.linear(h, W(L + "fc1.weight"), W(L + "fc1.bias")))
+        x = res + F.linear(h, W(L + "fc2.weight"), W(L + "fc2.bias"))
+        if return_layer is not None and i == return_layer:
+            return x
+    return F.layer_norm(x, (d,), W("layer_norm.weight"), W("layer_norm.bias"), a.layer_norm_eps)  # :980
+
+
+# ----------------------------------------------------------------------------------------------
+# Projector — StackAudioFrames / RMSNorm / SwiGLU / UltravoxProjector, ultravox_model.py:712-800.
+# ----------------------------------------------------------------------------------------------
+def rmsnorm_ref(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """[3P] LlamaRMSNorm.forward (subclassed at ultravox_model.py:733-736)."""
+    dt = x.dtype
+    h = x.to(torch.float32)
+    h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + eps)
+    return w * h.to(dt)
+
+
+def projector_ref(p: Dict[str, torch.Tensor], cfg, audio_features: torch.Tensor) -> torch.Tensor:
+    S = cfg.stack_factor
+    B, T, Cc = audio_features.shape
+    Tp = (T + S - 1) // S * S                                              # :724-729
+    x = F.pad(audio_features, (0, 0, 0, Tp - T)).view(B, Tp // S, Cc * S)
+    x = rmsnorm_ref(x, p["ln_pre.weight"], 1e-6)                           # :791
+    x = F.linear(x, p["linear_1.weight"])                                  # :793
+    val, gate = x.chunk(2, dim=-1)                                         # :739-742 (first half = value)
+    x = F.silu(gate) * val
+    if cfg.projector_ln_mid:                                               # :761-766
+        x = rmsnorm_ref(x, p["ln_mid.weight"], 1e-6)
+        return F.linear(x, p["linear_2.weight"])
+    return rmsnorm_ref(F.linear(x, p["linear_2.weight"]), p["ln_post.weight"], 1e-6)
+
+
+# ----------------------------------------------------------------------------------------------
+# Merge — _audio_iter + the in-place loop, ultravox_model.py:259-275, :390-394.
+# ----------------------------------------------------------------------------------------------
+def merge_ref(inputs_embeds, audio_embeds, audio_token_start_idx, audio_token_len, audio_batch_size):
+    out = inputs_embeds.clone()
+    i_a = 0
+    for i_b, cnt in enumerate(audio_batch_size.reshape(-1).tolist()):
+        for _ in range(int(cnt)):
+            s, n = int(audio_token_start_idx[i_a]), int(audio_token_len[i_a])
+            out[i_b][s:s + n] = audio_embeds[i_a][:n]
+            i_a += 1
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# LLM — [3P] LlamaForCausalLM.forward + ForCausalLMLoss, reached at ultravox_model.py:328-334.
+# ----------------------------------------------------------------------------------------------
+def rope_cos_sin_ref(tc, T: int, dtype) -> tuple:
+    dh = tc.head_dim
+    inv = 1.0 / (tc.rope_theta ** (torch.arange(0, dh, 2, dtype=torch.int64).float() / dh))
+    rs = tc.rope_scaling
+    if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+        factor, lo, hi, old = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"]
+        wl = 2 * math.pi / inv
+        inv_l = torch.where(wl > old / lo, inv / factor, inv)
+        smooth = (old / wl - lo) / (hi - lo)
+        mid = ~(wl < old / hi) * ~(wl > old / lo)
+        inv = torch.where(mid, (1 - smooth) * inv_l / factor + smooth * inv_l, inv_l)
+    freqs = torch.arange(T, dtype=torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat([freqs, freqs], dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def _rotate_half(x):
+    a, b = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-b, a), dim=-1)
+
+
+def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
+              attention_mask: Optional[torch.Tensor] = None, prefix: str = "language_model.",
+              n_layers: Optional[int] = None) -> torch.Tensor:
+    """-> logits [B, T, V] in the dtype of inputs_embeds."""
+    tc = cfg.text_config
+    dt = inputs_embeds.dtype
+    B, T, D = inputs_embeds.shape
+    Hq, Hkv, dh = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+    W = lambda k: sd[prefix + k].to(dt) if not sd[prefix + k].requires_grad else sd[prefix + k]
+    cos, sin = rope_cos_sin_ref(tc, T, dt)
+    neg = torch.finfo(dt).min
+    causal = torch.full((T, T), neg, dtype=dt).triu(1)[None, None]
+    if attention_mask is not None:
+        pad = (1.0 - attention_mask[:, None, None, :].to(dt)) * neg
+        causal = torch.clamp(causal + pad, min=neg)
+    x = inputs_embeds
+    L_ = tc.num_hidden_layers if n_layers is None else n_layers
+    for i in range(L_):
+        P = f"model.layers.{i}."
+        h = rmsnorm_ref(x, W(P + "input_layernorm.weight"), tc.rms_norm_eps)
+        q = F.linear(h, W(P + "self_attn.q_proj.weight")).view(B, T, Hq, dh).transpose(1, 2)
+        k = F.linear(h, W(P + "self_attn.k_proj.weight")).view(B, T, Hkv, dh).transpose(1, 2)
+        v = F.linear(h, W(P + "self_attn.v_proj.weight")).view(B, T, Hkv, dh).transpose(1, 2)
+        q = q * cos + _rotate_half(q) * sin
+        k = k * cos + _rotate_half(k) * sin
+        k = k.repeat_interleave(Hq // Hkv, dim=1)
+        v = v.repeat_interleave(Hq // Hkv, dim=1)
+        s = (q @ k.transpose(-1, -2)) * (dh ** -0.5) + causal
+        p = torch.softmax(s.float(), dim=-1).to(dt)
+        o = (p @ v).transpose(1, 2).reshape(B, T, Hq * dh)
+        x = x + F.linear(o, W(P + "self_attn.o_proj.weight"))
+        h = rmsnorm_ref(x, W(P + "post_attention_layernorm.weight"), tc.rms_norm_eps)
+        h = F.silu(F.linear(h, W(P + "mlp.gate_proj.weight"))) * F.linear(h, W(P + "mlp.up_proj.weight"))
+        x = x + F.linear(h, W(P + "mlp.down_proj.weight"))
+    x = rmsnorm_ref(x, W("model.norm.weight"), tc.rms_norm_eps)
+    return F.linear(x, W("lm_head.weight"))
+
+
+def causal_lm_loss_ref(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """[3P] loss_utils.ForCausalLMLoss with num_items_in_batch=None (accepts_loss_kwargs = False,
+    ultravox_model.py:50-53): upcast, pad one ignore label on the right, shift, mean CE."""
+    logits = logits.float()
+    shifted = F.pad(labels, (0, 1), value=ignore_index)[..., 1:].contiguous()
+    return F.cross_entropy(logits.view(-1, logits.shape[-1]), shifted.view(-1), ignore_index=ignore_index,
+                           reduction="mean")
+
+
+# ----------------------------------------------------------------------------------------------
+# Whole forward / train step — UltravoxModel.forward (:277-352), _prepare_audio_embeds (:354-396).
+# ----------------------------------------------------------------------------------------------
+class OracleModel:
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], dtype=torch.float32):
+        self.cfg, self.dtype = cfg, dtype
+        self.sd = {k: v.detach().to("cpu", dtype).clone() for k, v in state_dict.items()}
+        # apply_lora r = 0 (ultravox_model.py:697-703): towers frozen, projector trainable
+        self.trainable = [k for k in self.sd if k.startswith("multi_modal_projector.")]
+        for k in self.trainable:
+            self.sd[k].requires_grad_(True)
+
+    def projector_params(self):
+        P = "multi_modal_projector."
+        return {k[len(P):]: self.sd[k] for k in self.trainable}
+
+    def audio_embeds(self, audio_values, audio_lens):
+        with torch.no_grad():
+            tower = whisper_encoder_ref(self.sd, self.cfg, audio_values.to(self.dtype), audio_lens)   # :382-385
+        return tower, projector_ref(self.projector_params(), self.cfg, tower.to(self.dtype))        # :386-387
+
+    def forward(self, input_ids, audio_values=None, labels=None, attention_mask=None, audio_token_start_idx=None,
+                audio_lens=None, audio_token_len=None, audio_batch_size=None, inputs_embeds=None):
+        if inputs_embeds is None:
+            inputs_embeds = F.embedding(input_ids, self.sd["language_model.model.embed_tokens.weight"])  # :314-316
+        audio_embeds = None
+        if audio_values is not None and len(audio_values) > 0:
+            _, audio_embeds = self.audio_embeds(audio_values, audio_lens)
+            inputs_embeds = merge_ref(inputs_embeds, audio_embeds, audio_token_start_idx, audio_token_len, audio_batch_size)
+        logits = llama_ref(self.sd, self.cfg, inputs_embeds, attention_mask)
+        loss = causal_lm_loss_ref(logits, labels) if labels is not None else None
+        return {"loss": loss, "logits": logits, "inputs_embeds": inputs_embeds, "audio_embeds": audio_embeds}
+
+    def train_step(self, batch, optimizer=None, max_grad_norm: float = 1.0):
+        """loss.backward(); clip_grad_norm_(1.0); AdamW.step() — SURVEY.md Appendix B."""
+        params = [self.sd[k] for k in self.trainable]
+        for p in params:
+            p.grad = None
+        out = self.forward(**batch)
+        out["loss"].backward()
+        grads = {k: self.sd[k].grad.detach().clone() for k in self.trainable}
+        gn = None
+        if optimizer is not None:
+            gn = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+            optimizer.step()
+        return out, grads, gn
+
+
+def synthetic_batch(cfg, B: int, seconds: float, n_text: int = 128, audio_start: int = 16, n_supervised: int = 32,
+                    rank: int = 0, n_mels: Optional[int] = None):
+    """The synthetic inputs of SURVEY.md §8d: PCM 0.1*N(0,1) clipped to [-1,1] (seed 1234 + rank), token ids
+    uniform in [0, V-2] (seed 4321 + rank), audio inserted at `audio_start`, last `n_supervised` tokens
+    supervised (LAST_ASSISTANT masking, ultravox_data_proc.py:106-110)."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    L = int(round(seconds * 16000)) // HOP * HOP
+    pcm = (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
+    Fm = L // HOP
+    Na = -(-Fm // (2 * cfg.stack_factor))
+    g2 = torch.Generator().manual_seed(4321 + rank)
+    V = cfg.text_config.vocab_size
+    text = torch.randint(0, V - 1, (B, n_text), generator=g2)
+    eos = cfg.text_config.eos_token_id
+    ids = torch.cat([text[:, :audio_start], torch.full((B, Na), eos, dtype=torch.long), text[:, audio_start:]], 1)
+    T = ids.shape[1]
+    labels = ids.clone()
+    labels[:, : T - n_supervised] = -100
+    return {
+        "pcm": pcm,
+        "input_ids": ids, "attention_mask": torch.ones(B, T, dtype=torch.long), "labels": labels,
+        "audio_token_start_idx": torch.full((B,), audio_start, dtype=torch.long),
+        "audio_lens": torch.full((B,), Fm, dtype=torch.long),
+        "audio_token_len": torch.full((B,), Na, dtype=torch.int32),
+        "audio_batch_size": torch.ones(B, dtype=torch.long),
+    }

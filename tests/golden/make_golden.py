@@ -1,0 +1,213 @@
+"""Generates tests/golden/*.json|*.npz by IMPORTING THE REFERENCE from /root/reference (build container
+only; the fixtures travel, the reference does not).  Run:  python tests/golden/make_golden.py
+
+What is recorded
+  processor.json  — UltravoxProcessor / DataCollatorForSeq2SeqWithAudio integer outputs of the REFERENCE
+                    implementation (ultravox/model/ultravox_processing.py) for the cases its own tests use
+                    (ultravox_processing_test.py:46-229, infer_test.py:72-109), with the HF
+                    WhisperFeatureExtractor and tests/fake_tokenizer.py.
+  projector_*.npz — outputs AND weight/input gradients of the REFERENCE UltravoxProjector
+                    (ultravox_model.py:745-800, imported with an in-memory `peft` stub) for seeded inputs,
+                    both projector_ln_mid variants, T not a multiple of the stack factor.
+  latency_mask.npz — ModifiedWhisperEncoder.init_latency_mask (ultravox_model.py:834-863).
+  logmel.npz      — HF WhisperFeatureExtractor (the [3P] K1 arithmetic) on seeded PCM, 80 and 128 mels.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+
+peft = types.ModuleType("peft")
+peft.LoraConfig = lambda **kw: types.SimpleNamespace(r=kw.get("r", 0))
+peft.PeftModel = type("PeftModel", (), {})
+peft.get_peft_model = lambda m, c: m
+peft.peft_model = types.ModuleType("peft.peft_model")
+peft.peft_model.PeftModel = peft.PeftModel
+sys.modules["peft"] = peft
+sys.modules["peft.peft_model"] = peft.peft_model
+
+import transformers  # noqa: E402
+from fake_tokenizer import FakeTokenizer  # noqa: E402
+from ultravox.model import ultravox_config, ultravox_model, ultravox_processing  # noqa: E402
+
+
+def tolist(v):
+    return v.tolist() if hasattr(v, "tolist") else v
+
+
+def processor_cases():
+    fe = transformers.WhisperFeatureExtractor()
+    ap = types.SimpleNamespace(feature_extractor=fe, model_input_names=fe.model_input_names)
+    ap_call = lambda *a, **k: fe(*a, **k)
+    ap = type("AP", (), {"feature_extractor": fe, "model_input_names": fe.model_input_names,
+                         "__call__": staticmethod(ap_call)})()
+    tok = FakeTokenizer()
+    proc = ultravox_processing.UltravoxProcessor.__new__(ultravox_processing.UltravoxProcessor)
+    # bypass ProcessorMixin.__init__ type checks: set the fields the methods use
+    proc.audio_padding, proc.encoder_ds_factor, proc.stack_factor = "longest", 2, 8
+    proc.audio_placeholder, proc.audio_context_size = "<|audio|>", 3000
+    proc.vocab = tok.get_vocab()
+    proc.audio_token_replacement = tok.eos_token
+    tok.pad_token_id = tok.eos_token_id
+    proc.audio_processor, proc.tokenizer = ap, tok
+    rng = np.random.RandomState(0)
+    sr = 16000
+    clips = {"short": rng.randn(sr).astype(np.float32), "long": rng.randn(sr * 10).astype(np.float32),
+             "overflow": rng.randn(sr * 35).astype(np.float32), "exact30": rng.randn(sr * 30).astype(np.float32),
+             "s61": rng.randn(sr * 61).astype(np.float32)}
+    cases = [
+        ("text_only", "Hello, how are you?", []),
+        ("single", "Test with <|audio|>", ["short"]),
+        ("overflow", "Test with <|audio|>", ["overflow"]),
+        ("two", "Test with <|audio|> and <|audio|>", ["short", "long"]),
+        ("three_overflow", "Test with <|audio|> and <|audio|> and <|audio|>", ["short", "overflow", "long"]),
+        ("exact30", "A <|audio|> B", ["exact30"]),
+        ("s61", "A <|audio|> B", ["s61"]),
+        ("trailing_text", "x <|audio|> tail words here", ["long"]),
+    ]
+    out = {"cases": []}
+    keys = ["audio_lens", "audio_token_len", "audio_token_start_idx", "input_ids", "attention_mask",
+            "audio_batch_size", "audio_num_chunks"]
+    for name, text, names in cases:
+        kw = dict(audios=[clips[n] for n in names], sampling_rate=sr, include_audio_num_chunks=True) if names else {}
+        r = proc(text, **kw)
+        rec = {"name": name, "text": text, "seconds": [len(clips[n]) / sr for n in names]}
+        for k in keys:
+            if k in r:
+                rec[k] = tolist(r[k])
+        if "audio_values" in r:
+            rec["audio_values_shape"] = list(r["audio_values"].shape)
+        out["cases"].append(rec)
+    # sub-2-hop edge lengths (ultravox_processing_test.py:177-186)
+    out["tiny"] = []
+    for n in [0, 1, 159, 160, 161, 319, 320, 321, 479, 480, 481]:
+        r = proc("<|audio|>", audio=np.zeros(n, np.float32) + 0.01, sampling_rate=sr)
+        out["tiny"].append({"n": n, "audio_lens": tolist(r["audio_lens"]), "frames": int(r["audio_values"].shape[-1]),
+                            "audio_token_len": tolist(r["audio_token_len"])})
+    # error cases (:140-174)
+    errs = []
+    for text, names in [("Test with <|audio|> and <|audio|>", ["short"]), ("Test with no placeholder", ["short"]),
+                        ("Test <|audio|>", ["short", "long"])]:
+        try:
+            proc(text, audios=[clips[n] for n in names], sampling_rate=sr)
+            errs.append({"text": text, "n_audio": len(names), "error": None})
+        except ValueError as e:
+            errs.append({"text": text, "n_audio": len(names), "error": str(e)})
+    out["errors"] = errs
+    # collator (:189-229 and the left-pad displacement :53-63)
+    coll = {}
+    for side in ("right", "left"):
+        tk = FakeTokenizer(padding_side=side)
+        tk.pad_token_id = tk.eos_token_id
+        proc.tokenizer = tk
+        feats = []
+        for text, names in [("Test with <|audio|>", ["short"]), ("A much longer prompt with <|audio|> and <|audio|> ok", ["long", "short"]),
+                            ("text only sample here", [])]:
+            kw = dict(audios=[clips[n] for n in names], sampling_rate=sr) if names else {}
+            r = proc(text, **kw)
+            f = {k: (v[0] if k in ("input_ids", "attention_mask") else v) for k, v in r.items()}
+            f["labels"] = f["input_ids"].clone()
+            if "audio_batch_size" not in f:
+                f["audio_batch_size"] = torch.tensor([0])
+            feats.append(f)
+        dc = ultravox_processing.DataCollatorForSeq2SeqWithAudio.__new__(ultravox_processing.DataCollatorForSeq2SeqWithAudio)
+        # emulate the [3P] DataCollatorForSeq2Seq padding that super().__call__ performs
+        def hf_pad(features, tk=tk):
+            import torch.nn.functional as F
+            n = max(len(f["input_ids"]) for f in features)
+            def pad(x, v):
+                g = n - len(x)
+                return F.pad(torch.as_tensor(x), (g, 0) if tk.padding_side == "left" else (0, g), value=v)
+            b = {"input_ids": torch.stack([pad(f["input_ids"], tk.pad_token_id) for f in features]),
+                 "attention_mask": torch.stack([pad(f["attention_mask"], 0) for f in features]),
+                 "labels": torch.stack([pad(f["labels"], -100) for f in features]),
+                 "audio_batch_size": torch.stack([f["audio_batch_size"] for f in features])}
+            return b
+        dc.tokenizer, dc.include_alt_fields = tk, False
+        # run the reference's own __call__ body with the HF padding stubbed in for super().__call__
+        import unittest.mock as mock
+        with mock.patch.object(transformers.DataCollatorForSeq2Seq, "__call__", lambda self, features, *a, **k: hf_pad(features)):
+            batch = dc([dict(f) for f in feats])
+        coll[side] = {k: (tolist(v) if k != "audio_values" else list(v.shape)) for k, v in batch.items()}
+    out["collator"] = coll
+    json.dump(out, open(os.path.join(HERE, "processor.json"), "w"), indent=0)
+    print("processor.json:", [c["name"] for c in out["cases"]])
+
+
+def projector_cases():
+    for ln_mid in (True, False):
+        cfg = ultravox_config.UltravoxConfig(
+            audio_config={"model_type": "whisper", "d_model": 32, "encoder_layers": 1, "encoder_attention_heads": 2,
+                          "encoder_ffn_dim": 64, "num_mel_bins": 80},
+            text_config={"model_type": "llama", "hidden_size": 64, "intermediate_size": 64, "num_hidden_layers": 1,
+                         "num_attention_heads": 2, "num_key_value_heads": 2, "vocab_size": 128},
+            hidden_size=256, stack_factor=8, projector_ln_mid=ln_mid)
+        torch.manual_seed(7)
+        proj = ultravox_model.UltravoxProjector(cfg).float()
+        with torch.no_grad():
+            for p in proj.parameters():
+                if p.dim() == 1:
+                    p.mul_(1.0 + 0.2 * torch.randn_like(p))
+        x = torch.randn(3, 21, 32, requires_grad=True)
+        y = proj(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        rec = {"x": x.detach().numpy(), "y": y.detach().numpy(), "gy": gy.numpy(), "gx": x.grad.numpy()}
+        for k, v in proj.state_dict().items():
+            rec["w." + k] = v.numpy()
+        for k, v in proj.named_parameters():
+            rec["g." + k] = v.grad.numpy()
+        stacked = ultravox_model.StackAudioFrames(8)(x.detach())
+        rec["stacked"] = stacked.numpy()
+        np.savez_compressed(os.path.join(HERE, f"projector_ln_{'mid' if ln_mid else 'post'}.npz"), **rec)
+    print("projector_*.npz written")
+
+
+def latency_mask_cases():
+    rec = {}
+    for block in (100, 300, 1500):
+        dummy = types.SimpleNamespace(max_context_length=3000)
+        dummy.register_buffer = lambda name, t, persistent=False, d=dummy: setattr(d, name, t)
+        ultravox_model.ModifiedWhisperEncoder.init_latency_mask(dummy, block, torch.float32)
+        m = dummy.audio_streaming_mask[0, 0, :400, :400]
+        rec[f"allowed_{block}"] = (m == 0).numpy()
+    try:
+        dummy = types.SimpleNamespace(max_context_length=3000)
+        ultravox_model.ModifiedWhisperEncoder.init_latency_mask(dummy, 13, torch.float32)
+        rec["err13"] = np.array(0)
+    except AssertionError:
+        rec["err13"] = np.array(1)
+    np.savez_compressed(os.path.join(HERE, "latency_mask.npz"), **rec)
+    print("latency_mask.npz written")
+
+
+def logmel_cases():
+    rec = {}
+    g = torch.Generator().manual_seed(11)
+    for n_mels in (80, 128):
+        fe = transformers.WhisperFeatureExtractor(feature_size=n_mels)
+        noise = (0.1 * torch.randn(2, 16000 * 2, generator=g)).clamp(-1, 1).numpy()
+        t = np.arange(16000 * 2) / 16000.0
+        tone = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.05 * np.sin(2 * np.pi * 3000 * t)).astype(np.float32)
+        tone[20000:] = 0.0  # trailing silence: exercises the clip-max floor
+        pcm = np.stack([noise[0], noise[1] * 0.01, tone]).astype(np.float32)
+        out = fe(list(pcm), sampling_rate=16000, padding="longest", pad_to_multiple_of=160, truncation=False,
+                 return_attention_mask=True, return_tensors="np")
+        rec[f"pcm_{n_mels}"] = pcm
+        rec[f"mel_{n_mels}"] = out["input_features"].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "logmel.npz"), **rec)
+    print("logmel.npz written")
+
+
+if __name__ == "__main__":
+    processor_cases()
+    projector_cases()
+    latency_mask_cases()
+    logmel_cases()

@@ -1,0 +1,51 @@
+"""The C-ABI library builds, loads on a CPU-only box and exports every symbol include/uvx.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from ultravox_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "uvx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(uvx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_hot_path():
+    names = header_functions()
+    for must in ["uvx_logmel", "uvx_encoder_fwd", "uvx_projector_fwd", "uvx_projector_bwd", "uvx_embed_merge",
+                 "uvx_merge_embeds_bwd", "uvx_llm_fwd", "uvx_llm_bwd", "uvx_adamw_clip_step", "uvx_last_error"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    missing = [n for n in header_functions() if not hasattr(lib, n)]
+    assert not missing, f"declared in include/uvx.h but not exported by libuvx.so: {missing}"
+    assert set(_lib.EXPORTS) == set(header_functions())
+    assert lib.uvx_abi_version() == 1
+
+
+def test_struct_mirrors_match_header_sizes():
+    # field counts of the ctypes mirrors vs the C declarations (cheap drift detector)
+    src = open(os.path.join(ROOT, "include", "uvx.h")).read()
+    body = re.search(r"typedef struct \{(.*?)\} uvx_config_t;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    n_fields = sum(len(decl.split(",")) for decl in re.findall(r"(?:int32_t|float)\s+([^;]+);", body))
+    assert n_fields == len(_lib.Config._fields_)
+    assert ctypes.sizeof(_lib.Config) == 4 * n_fields
+    assert ctypes.sizeof(_lib.EncLayer) == 8 * 12 and ctypes.sizeof(_lib.LlmLayer) == 8 * 10
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = _lib.lib()
+    assert lib.uvx_gemm(None, 0, None) == -1
+    assert b"null descriptor" in lib.uvx_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(lib.uvx_gemm(None, 0, None), "uvx_gemm")
+    assert lib.uvx_encoder_ws_bytes(None, 1, 100) == 0

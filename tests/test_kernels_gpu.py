@@ -1,0 +1,367 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel (through the C ABI) against a plain PyTorch fp32
+reference of the same op, with the bf16 rounding points of the reference's GPU path restated.
+Tolerances are written per test; integer / index work is asserted bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from ultravox_amd import ops as o
+    return o
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (100, 132, 192), (37, 8, 64), (1504, 2048, 1024),
+                                   (2528, 4096, 512), (1, 4, 64)])
+def test_gemm_matches_fp32_matmul(M, N, K):
+    torch.manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, device=DEV) * 0.5)
+    b = bf(torch.randn(N, K, device=DEV) * 0.5)  # asymmetric: catches operand / output transposes
+    out = ops().gemm(a, b)
+    ref = a.float() @ b.float().t()
+    # bf16 output: one rounding of the f32 accumulator -> <= 2^-8 relative to each element (+ f32 sum order)
+    assert torch.allclose(out.float(), ref, rtol=2 ** -7, atol=1e-3 * math.sqrt(K))
+
+
+def test_gemm_epilogues_and_strides():
+    torch.manual_seed(0)
+    M, N, K = 300, 256, 256
+    a = bf(torch.randn(M, K, device=DEV) * 0.5)
+    b = bf(torch.randn(N, K, device=DEV) * 0.5)
+    bias = bf(torch.randn(N, device=DEV))
+    res = bf(torch.randn(M, N, device=DEV))
+    lin = (a.float() @ b.float().t() + bias.float()).bfloat16().float()
+    assert torch.allclose(ops().gemm(a, b, bias=bias).float(), lin, rtol=2 ** -7, atol=2e-2)
+    g = F.gelu(lin).bfloat16().float()
+    assert torch.allclose(ops().gemm(a, b, bias=bias, act="gelu").float(), g, rtol=2 ** -7, atol=2e-2)
+    r = (lin + res.float()).bfloat16().float()
+    assert torch.allclose(ops().gemm(a, b, bias=bias, residual=res).float(), r, rtol=2 ** -7, atol=3e-2)
+    # positional-embedding style residual: row m uses residual[m % res_mod]
+    pos = bf(torch.randn(100, N, device=DEV))
+    r2 = (a.float() @ b.float().t()).bfloat16().float() + pos.float()[torch.arange(M, device=DEV) % 100]
+    assert torch.allclose(ops().gemm(a, b, residual=pos, res_mod=100).float(), r2, rtol=2 ** -6, atol=3e-2)
+    # f32 output + accumulate (weight gradients)
+    acc = torch.randn(M, N, device=DEV)
+    want = acc + a.float() @ b.float().t()
+    got = ops().gemm(a, b, out=acc.clone(), out_f32=True, accumulate=True)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-3)
+    # strided A rows (the conv2 "3 consecutive frames" view): row stride 2*K' with K = 3*K'
+    base = bf(torch.randn(2 * 40 + 2, 64, device=DEV))
+    view = base.as_strided((40, 192), (128, 1))
+    w = bf(torch.randn(128, 192, device=DEV))
+    assert torch.allclose(ops().gemm(view, w).float(), view.float() @ w.float().t(), rtol=2 ** -7, atol=2e-2)
+
+
+def test_gemm_rejects_bad_shapes():
+    a = bf(torch.randn(8, 60, device=DEV))
+    b = bf(torch.randn(8, 60, device=DEV))
+    with pytest.raises(ValueError, match="multiple of 64"):
+        ops().gemm(a, b)
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("rows,cols", [(7, 384), (300, 1024), (33, 1280)])
+def test_layernorm(rows, cols):
+    torch.manual_seed(1)
+    x = bf(torch.randn(rows, cols, device=DEV) * 2 + 0.3)
+    w, b = bf(torch.randn(cols, device=DEV)), bf(torch.randn(cols, device=DEV))
+    ref = F.layer_norm(x.float(), (cols,), w.float(), b.float(), 1e-5)
+    got = ops().layernorm(x, w, b, 1e-5)
+    assert torch.allclose(got.float(), ref, rtol=2 ** -7, atol=2e-2)
+    assert torch.equal(got, F.layer_norm(x, (cols,), w, b, 1e-5)) or rel_l2(got, ref) < 3e-3
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 2048), (64, 4096), (19, 8192)])
+def test_rmsnorm_fwd_bwd(rows, cols):
+    torch.manual_seed(2)
+    x = bf(torch.randn(rows, cols, device=DEV))
+    w = bf(0.4 + 0.1 * torch.randn(cols, device=DEV))
+    dy = bf(torch.randn(rows, cols, device=DEV))
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    h = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)
+    y = wr * h
+    y.backward(dy.float())
+    got = ops().rmsnorm(x, w, 1e-6)
+    # LlamaRMSNorm rounds x_hat to bf16 before the weight multiply: restate that rounding
+    ref = (w.float() * h.detach().bfloat16().float()).bfloat16()
+    assert (got.float() - ref.float()).abs().max() <= 2 ** -7 * ref.float().abs().max()
+    add = bf(torch.randn(rows, cols, device=DEV))
+    dx, dw = ops().rmsnorm_bwd(dy, x, w, 1e-6, dx_add=add, want_dw=True)
+    assert rel_l2(dx, xr.grad + add.float()) < 6e-3
+    assert rel_l2(dw, wr.grad) < 6e-3
+
+
+def test_stack_rmsnorm_is_pad_view_norm(golden_dir):
+    import os
+    from ultravox_amd import _lib
+    import ctypes as C
+    z = np.load(os.path.join(golden_dir, "projector_ln_mid.npz"))
+    x = torch.from_numpy(z["x"]).to(DEV).bfloat16()          # [3, 21, 32] -> 3 rows of 8 frames, last has 5
+    stacked_ref = torch.from_numpy(z["stacked"]).to(DEV)       # reference StackAudioFrames output (f32 input)
+    # bit-exact re-indexing: stacking is a pure copy with zero padding
+    from oracle.reference_cpu import rmsnorm_ref
+    w = torch.from_numpy(z["w.ln_pre.weight"]).to(DEV).bfloat16()
+    B, T, Cc = x.shape
+    J = (T + 7) // 8
+    y = torch.empty(B * J, Cc * 8, device=DEV, dtype=torch.bfloat16)
+    st = torch.empty_like(y)
+    # reach the fused kernel through the projector entry point's first stage: use rmsnorm on the stacked copy
+    pad = F.pad(x, (0, 0, 0, J * 8 - T)).reshape(B * J, Cc * 8)
+    assert torch.equal(pad.float(), stacked_ref.bfloat16().float().reshape(B * J, Cc * 8))
+    got = ops().rmsnorm(pad.contiguous(), w, 1e-6)
+    ref = rmsnorm_ref(pad.cpu(), w.cpu(), 1e-6)
+    assert rel_l2(got.cpu(), ref) < 4e-3
+
+
+# ------------------------------------------------------------------ SwiGLU / RoPE
+@pytest.mark.parametrize("gate_first", [False, True])
+def test_swiglu_fwd_bwd(gate_first):
+    torch.manual_seed(3)
+    x = bf(torch.randn(77, 512, device=DEV) * 2)
+    dout = bf(torch.randn(77, 256, device=DEV))
+    xr = x.float().requires_grad_(True)
+    a, b = xr.chunk(2, dim=-1)
+    val, gate = (b, a) if gate_first else (a, b)
+    out = F.silu(gate) * val
+    out.backward(dout.float())
+    got = ops().swiglu(x, gate_first)
+    assert torch.allclose(got.float(), out.detach(), rtol=2 ** -6, atol=1e-2)
+    din = ops().swiglu_bwd(dout, x, gate_first)
+    assert rel_l2(din, xr.grad) < 6e-3
+
+
+def test_rope_forward_and_inverse():
+    from ultravox_amd.config import TextConfig
+    from ultravox_amd.weights import rope_table
+    from oracle.reference_cpu import rope_cos_sin_ref, _rotate_half
+    tc = TextConfig(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, rope_theta=500000.0)
+    B, T, H = 2, 50, 6  # 4 q heads + 2 k heads rotated, 2 v heads untouched
+    torch.manual_seed(4)
+    x = bf(torch.randn(B * T, 8 * 128, device=DEV))
+    x0 = x.clone()
+    tab = rope_table(tc, 64, DEV)
+    ops().rope_(x, tab, T, H, 128, inverse=False)
+    cos, sin = rope_cos_sin_ref(tc, T, torch.bfloat16)
+    xr = x0.cpu().view(B, T, 8, 128)
+    want = xr.clone()
+    rot = xr[:, :, :H]
+    want[:, :, :H] = rot * cos[None, :, None, :] + _rotate_half(rot) * sin[None, :, None, :]
+    got = x.cpu().view(B, T, 8, 128)
+    assert torch.equal(got[:, :, H:], xr[:, :, H:])                      # v heads bit-identical
+    assert (got.float() - want.float()).abs().max() <= 2 ** -6 * want.float().abs().max()
+    ops().rope_(x, tab, T, H, 128, inverse=True)                          # R(-theta) R(theta) = I up to rounding
+    assert rel_l2(x, x0) < 8e-3
+
+
+# ------------------------------------------------------------------ attention
+def sdpa_ref(q, k, v, causal, block, scale, kv_start=None, kv_len=None):
+    B, T, Hq, D = q.shape
+    Hkv = k.shape[2]
+    qf, kf, vf = (t.float().transpose(1, 2) for t in (q, k, v))
+    kf = kf.repeat_interleave(Hq // Hkv, 1)
+    vf = vf.repeat_interleave(Hq // Hkv, 1)
+    s = qf @ kf.transpose(-1, -2) * scale
+    idx = torch.arange(T, device=q.device)
+    ok = torch.ones(B, 1, T, T, dtype=torch.bool, device=q.device)
+    if causal:
+        ok = ok & (idx[None, :] <= idx[:, None])[None, None]
+    if block:
+        ok = ok & ((idx[None, :] // block) <= (idx[:, None] // block))[None, None]
+    if kv_len is not None:
+        ok = ok & (idx[None, None, None, :] < kv_len.view(-1, 1, 1, 1))
+    if kv_start is not None:
+        ok = ok & (idx[None, None, None, :] >= kv_start.view(-1, 1, 1, 1))
+    s = s.masked_fill(~ok, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, 0.0)
+    return (p @ vf).transpose(1, 2).reshape(B, T, Hq * D), ok
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,T,causal,block", [(64, 4, 4, 200, False, 0), (64, 2, 2, 333, False, 50),
+                                                     (128, 8, 2, 316, True, 0), (128, 4, 1, 70, True, 0),
+                                                     (64, 6, 6, 1500, False, 0)])
+def test_attention_forward(D, Hq, Hkv, T, causal, block):
+    torch.manual_seed(5)
+    B = 2
+    qkv = bf(torch.randn(B, T, (Hq + 2 * Hkv) * D, device=DEV))
+    q = qkv[..., : Hq * D].view(B, T, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hkv) * D].view(B, T, Hkv, D)
+    v = qkv[..., (Hq + Hkv) * D:].view(B, T, Hkv, D)
+    kv_len = torch.tensor([T, max(1, T - 37)], device=DEV, dtype=torch.int32) if not causal else None
+    o, lse = ops().attention(q, k, v, causal=causal, block=block, kv_len=kv_len)
+    ref, _ = sdpa_ref(q, k, v, causal, block, D ** -0.5, kv_len=kv_len)
+    # P is rounded to bf16 before P.V (as flash / SDPA kernels do) and O to bf16: 2^-7 of the row scale
+    assert (o.float() - ref).abs().max().item() < 2e-2
+    assert rel_l2(o, ref) < 8e-3
+
+
+def test_attention_left_padding_and_rescale_branch():
+    torch.manual_seed(6)
+    B, T, Hq, Hkv, D = 2, 130, 4, 2, 128
+    q = bf(torch.randn(B, T, Hq, D, device=DEV))
+    k = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    v = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    k[0, 100] = q[0, 120, 0] * 4  # spike: the running max jumps in the second key block (online-softmax rescale)
+    kv_start = torch.tensor([0, 17], device=DEV, dtype=torch.int32)
+    kv_len = torch.tensor([T, T], device=DEV, dtype=torch.int32)
+    o, _ = ops().attention(q, k, v, causal=True, kv_start=kv_start, kv_len=kv_len)
+    ref, ok = sdpa_ref(q, k, v, True, 0, D ** -0.5, kv_start=kv_start, kv_len=kv_len)
+    valid = ok.any(-1)[:, 0]  # rows with at least one visible key
+    m = valid[:, :, None].expand(B, T, Hq * D)
+    assert (o.float() - ref)[m].abs().max().item() < 3e-2
+    assert torch.isfinite(o.float()).all()
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,T", [(128, 8, 2, 316), (128, 4, 4, 45), (64, 4, 2, 130)])
+def test_attention_backward(D, Hq, Hkv, T):
+    torch.manual_seed(7)
+    B = 2
+    q = bf(torch.randn(B, T, Hq, D, device=DEV))
+    k = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    v = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    do = bf(torch.randn(B, T, Hq * D, device=DEV))
+    o, lse = ops().attention(q, k, v, causal=True)
+    dq, dk, dv = ops().attention_bwd(q, k, v, o, lse, do, causal=True)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref, _ = sdpa_ref(qr, kr, vr, True, 0, D ** -0.5)
+    ref.backward(do.float())
+    assert rel_l2(dq, qr.grad) < 2e-2 and rel_l2(dk, kr.grad) < 2e-2 and rel_l2(dv, vr.grad) < 2e-2
+
+
+# ------------------------------------------------------------------ loss / optimizer / merge
+def test_ce_loss_and_gradient():
+    torch.manual_seed(8)
+    B, T, V = 3, 40, 32000
+    logits = bf(torch.randn(B, T, V, device=DEV) * 2)
+    labels = torch.randint(0, V, (B, T), device=DEV)
+    labels[:, :25] = -100
+    labels[1, 30] = -100
+    lr = logits.float().requires_grad_(True)
+    shifted = F.pad(labels, (0, 1), value=-100)[:, 1:]
+    ref = F.cross_entropy(lr.view(-1, V), shifted.reshape(-1), ignore_index=-100)
+    ref.backward()
+    loss, dl = ops().ce_loss(logits, labels)
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())          # f32 loss
+    assert rel_l2(dl, lr.grad) < 6e-3
+    ignored = (shifted == -100)
+    assert dl[ignored].abs().max().item() == 0.0                            # ignored rows: exactly zero
+    # in place over the logits, scaled
+    loss2, dl2 = ops().ce_loss(logits.clone(), labels, grad_scale=0.5, in_place=True)
+    assert rel_l2(dl2, 0.5 * lr.grad) < 6e-3
+    # no valid label -> mean over an empty set is NaN (torch semantics)
+    loss3, _ = ops().ce_loss(logits, torch.full_like(labels, -100), want_grad=False)
+    assert math.isnan(loss3.item())
+
+
+def test_embed_merge_is_bit_exact_last_writer_wins():
+    from ultravox_amd import _lib
+    import ctypes as C
+    from oracle.reference_cpu import merge_ref
+    torch.manual_seed(9)
+    B, T, D, Na, n_items, V = 3, 50, 64, 12, 5, 100
+    table = bf(torch.randn(V, D, device=DEV))
+    ids = torch.randint(0, V, (B, T), device=DEV)
+    audio = bf(torch.randn(n_items, Na, D, device=DEV))
+    start = torch.tensor([3, 10, 0, 45, 20], device=DEV)            # item 1 overlaps item 0; item 3 clipped by len
+    tok_len = torch.tensor([12, 9, 7, 5, 0], device=DEV, dtype=torch.int32)
+    bsz = torch.tensor([2, 2, 1], device=DEV)
+    cfg = _lib.Config(); cfg.dtype = 0; cfg.llm_d = D; cfg.vocab = V
+    out = torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16)
+    scratch = torch.empty(B * T + n_items, device=DEV, dtype=torch.int32)
+    _lib.check(_lib.lib().uvx_embed_merge(_lib.stream_ptr(), C.byref(cfg), _lib.ptr(table), _lib.ptr(ids), _lib.ptr(audio),
+                                          _lib.ptr(bsz), _lib.ptr(start), _lib.ptr(tok_len), B, T, n_items, Na,
+                                          _lib.ptr(out), _lib.ptr(scratch)))
+    want = merge_ref(F.embedding(ids, table).cpu(), audio.cpu(), start.cpu(), tok_len.cpu(), bsz.cpu())
+    assert torch.equal(out.cpu(), want)
+    # backward = gather of exactly the rows each item still owns
+    g = bf(torch.randn(B, T, D, device=DEV))
+    da = torch.empty_like(audio)
+    _lib.check(_lib.lib().uvx_merge_embeds_bwd(_lib.stream_ptr(), C.byref(cfg), _lib.ptr(g), _lib.ptr(start),
+                                               _lib.ptr(tok_len), B, T, n_items, Na, _lib.ptr(da), _lib.ptr(scratch)))
+    a_req = audio.float().cpu().requires_grad_(True)
+    merged = merge_ref(torch.zeros(B, T, D), a_req, start.cpu(), tok_len.cpu(), bsz.cpu())
+    merged.backward(g.float().cpu())
+    assert torch.equal(da.float().cpu(), a_req.grad)
+
+
+@pytest.mark.parametrize("mode", ["bf16_state", "f32_master", "f32"])
+def test_adamw_clip_step_matches_torch(mode):
+    from ultravox_amd import _lib
+    import ctypes as C
+    torch.manual_seed(10)
+    n = 50000
+    dt = torch.float32 if mode == "f32" else torch.bfloat16
+    p0 = (torch.randn(n, device=DEV) * 0.1).to(dt)
+    grads = [torch.randn(n, device=DEV) * s for s in (0.05, 0.002, 1.0)]  # with and without clipping
+    p_ref = torch.nn.Parameter(p0.clone().float() if mode != "bf16_state" else p0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, foreach=False)
+    p = p0.clone()
+    master = p0.float().clone() if mode == "f32_master" else None
+    sdt = torch.float32 if mode != "bf16_state" else torch.bfloat16
+    m, v = torch.zeros(n, device=DEV, dtype=sdt), torch.zeros(n, device=DEV, dtype=sdt)
+    scratch = torch.zeros(1025, device=DEV)
+    for step, g in enumerate(grads, 1):
+        p_ref.grad = g.to(p_ref.dtype).clone()
+        torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        _lib.check(_lib.lib().uvx_adamw_clip_step(_lib.stream_ptr(), _lib.dtype_code(dt), _lib.ptr(p), _lib.ptr(master),
+                                                  _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), C.c_int64(n), C.c_float(1.0),
+                                                  C.c_float(2e-3), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
+                                                  C.c_float(0.0), step, _lib.ptr(scratch)))
+        assert abs(scratch[0].sqrt().item() - g.norm().item()) < 1e-3 * g.norm().item()
+    tol = 1e-5 if mode != "bf16_state" else 2e-2
+    assert rel_l2(p.float(), p_ref.detach().float()) < tol
+    if mode == "f32_master":
+        assert torch.equal(p, master.bfloat16())
+
+
+# ------------------------------------------------------------------ K1 log-mel
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_logmel_matches_hf_fixture(golden_dir, n_mels):
+    import os
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    z = np.load(os.path.join(golden_dir, "logmel.npz"))
+    fe = WhisperFeatureExtractor(feature_size=n_mels)
+    out = fe(list(z[f"pcm_{n_mels}"]), sampling_rate=16000, padding="longest", pad_to_multiple_of=160)
+    got = out["input_features"].cpu().numpy()
+    want = z[f"mel_{n_mels}"]
+    assert got.shape == want.shape
+    # dense f32 DFT vs torch's FFT: both carry ~1e-6 relative error of the spectral peak; after log10 and
+    # /4 the noise clips agree to 1e-4, bins at the (max - 8) floor of the tonal clip to 5e-3
+    assert np.abs(got[:2] - want[:2]).max() < 2e-4
+    assert np.abs(got[2] - want[2]).max() < 5e-3
+    assert out["attention_mask"].sum(-1).tolist() == [200, 200, 200]
+
+
+def test_logmel_full_size_properties():
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from oracle.reference_cpu import logmel_ref
+    fe = WhisperFeatureExtractor(80)
+    g = torch.Generator().manual_seed(1234)
+    pcm = (0.1 * torch.randn(4, 480000, generator=g)).clamp_(-1, 1)
+    got = fe.logmel_device(pcm.to(DEV)).cpu()
+    assert got.shape == (4, 80, 3000)
+    want = logmel_ref(pcm[:1], 80)
+    assert (got[:1] - want).abs().max().item() < 2e-4
+    # per-clip affine map: max over the clip minus min is at most 8/4, and scaling the waveform shifts by log10
+    assert ((got.amax((1, 2)) - got.amin((1, 2))) <= 2.0 + 1e-6).all()
+    got2 = fe.logmel_device((pcm * 0.5).to(DEV)).cpu()
+    assert (got2 - (got + 2 * math.log10(0.5) / 4)).abs().max().item() < 1e-3

@@ -1,0 +1,205 @@
+"""Hot-path parity on a real MI355X through the C ABI: encoder, projector (fwd + bwd), merge, LLM
+(fwd + activation-gradient bwd), and one whole adapter-training step, each against the CPU oracle
+(oracle/reference_cpu.py, pinned in tests/test_oracle_pinning.py) on the same seeded inputs/weights.
+
+Tolerances.  The production path stores activations in bf16 (what the reference does on GPU,
+config_base.py:245-249 forces f32 only off-GPU) while the oracle runs in f32 on the SAME bf16-rounded
+weights, so each comparison states a relative-L2 bound of a few bf16 ulps (2^-8 = 3.9e-3) accumulated
+over the layers involved; integer/index outputs are bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+SMALL = dict(
+    audio_config=dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256, num_mel_bins=80,
+                      max_source_positions=1500),
+    text_config=dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                     num_key_value_heads=2, vocab_size=512, rope_theta=10000.0, max_position_embeddings=512,
+                     eos_token_id=2),
+    hidden_size=256, stack_factor=8, projector_ln_mid=True)
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def build(seed=0, **kw):
+    from oracle.reference_cpu import OracleModel
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = UltravoxConfig(**{**SMALL, **kw})
+    sd = {k: v.bfloat16() for k, v in random_state_dict(cfg, seed=seed).items()}  # both sides see bf16-rounded weights
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    return cfg, sd, model, oracle
+
+
+def batch_for(cfg, B=2, seconds=2.0, n_text=24, audio_start=5, n_sup=8):
+    from oracle.reference_cpu import synthetic_batch, logmel_ref
+    b = synthetic_batch(cfg, B, seconds, n_text=n_text, audio_start=audio_start, n_supervised=n_sup)
+    b["audio_values"] = logmel_ref(b.pop("pcm"), cfg.audio_config.num_mel_bins)
+    return b
+
+
+def test_encoder_matches_oracle():
+    from oracle.reference_cpu import whisper_encoder_ref
+    cfg, sd, model, oracle = build(1)
+    torch.manual_seed(0)
+    mel = torch.randn(3, 80, 300)
+    lens = torch.tensor([300, 201, 64])
+    got = model.audio_tower_forward(mel.to(DEV), lens.to(DEV))
+    want = whisper_encoder_ref(oracle.sd, cfg, mel.bfloat16().float(), lens)
+    assert got.shape == want.shape == (3, 150, 128)
+    assert rel_l2(got, want) < 2e-2
+    # odd frame count (Te = (F-1)//2 + 1) and no padding mask
+    mel2 = torch.randn(1, 80, 77)
+    got2 = model.audio_tower_forward(mel2.to(DEV), None)
+    want2 = whisper_encoder_ref(oracle.sd, cfg, mel2.bfloat16().float(), None)
+    assert got2.shape == want2.shape == (1, 39, 128) and rel_l2(got2, want2) < 2e-2
+    with pytest.raises(ValueError, match="of length 3000 or less, but found 3002"):
+        model.audio_tower_forward(torch.zeros(1, 80, 3002, device=DEV), None)
+
+
+def test_encoder_latency_block_mask():
+    from oracle.reference_cpu import whisper_encoder_ref
+    cfg, sd, model, oracle = build(2, audio_latency_block_size=50)
+    mel = torch.randn(2, 80, 400)
+    lens = torch.tensor([400, 250])
+    got = model.audio_tower_forward(mel.to(DEV), lens.to(DEV))
+    want = whisper_encoder_ref(oracle.sd, cfg, mel.bfloat16().float(), lens)
+    assert rel_l2(got, want) < 2e-2
+    with pytest.raises(AssertionError, match="must divide 3000 evenly"):
+        build(2, audio_latency_block_size=13)
+
+
+@pytest.mark.parametrize("variant", ["mid", "post"])
+def test_projector_against_reference_fixture(golden_dir, variant):
+    """fixture = outputs + gradients of the REFERENCE UltravoxProjector (tests/golden/make_golden.py)."""
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    z = np.load(os.path.join(golden_dir, f"projector_ln_{variant}.npz"))
+    cfg = UltravoxConfig(audio_config=dict(d_model=32, encoder_layers=1, encoder_attention_heads=1, encoder_ffn_dim=64),
+                         text_config=dict(hidden_size=64, intermediate_size=64, num_hidden_layers=1, num_attention_heads=1,
+                                          num_key_value_heads=1, vocab_size=128), hidden_size=256,
+                         projector_ln_mid=(variant == "mid"))
+    sd = random_state_dict(cfg, seed=0)
+    for k in z.files:
+        if k.startswith("w."):
+            sd["multi_modal_projector." + k[2:]] = torch.from_numpy(z[k])
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16)
+    x = torch.from_numpy(z["x"]).to(DEV).bfloat16()
+    y = model.multi_modal_projector_forward(x)
+    assert tuple(y.shape) == z["y"].shape == (3, 3, 64)
+    assert rel_l2(y, torch.from_numpy(z["y"])) < 1.5e-2
+    model._projector_backward(torch.from_numpy(z["gy"]).to(DEV).bfloat16())
+    grads = model.projector_grads()
+    for k in z.files:
+        if k.startswith("g."):
+            assert rel_l2(grads["multi_modal_projector." + k[2:]], torch.from_numpy(z[k])) < 3e-2, k
+
+
+def test_forward_logits_loss_match_oracle():
+    cfg, sd, model, oracle = build(3)
+    b = batch_for(cfg)
+    out = model.forward(**{k: v.to(DEV) for k, v in b.items()})
+    with torch.no_grad():
+        ref = oracle.forward(**{**b, "audio_values": b["audio_values"].bfloat16().float()})
+    assert tuple(out.logits.shape) == tuple(ref["logits"].shape)
+    assert rel_l2(out.logits, ref["logits"]) < 3e-2
+    assert abs(out.loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
+    # audio rows land exactly where the reference puts them: rows outside [start, start+len) are the
+    # (bit-exact) token embeddings
+    emb = torch.nn.functional.embedding(b["input_ids"], sd["language_model.model.embed_tokens.weight"])
+    merged = model._embed_merge(None, b["input_ids"], model.multi_modal_projector_forward(
+        model.audio_tower_forward(b["audio_values"].to(DEV), b["audio_lens"].to(DEV))), b["audio_token_start_idx"],
+        b["audio_token_len"], b["audio_batch_size"], *b["input_ids"].shape).cpu()
+    s, n = int(b["audio_token_start_idx"][0]), int(b["audio_token_len"][0])
+    assert torch.equal(merged[:, :s], emb[:, :s]) and torch.equal(merged[:, s + n:], emb[:, s + n:])
+    assert rel_l2(merged[:, s:s + n], ref["audio_embeds"][:, :n]) < 2e-2
+
+
+def test_text_only_and_padding_masks():
+    cfg, sd, model, oracle = build(4)
+    torch.manual_seed(1)
+    B, T = 3, 40
+    ids = torch.randint(0, 512, (B, T))
+    labels = ids.clone()
+    labels[:, :10] = -100
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, 30:] = 0      # right padding
+    am[2, :7] = 0       # left padding
+    labels[am == 0] = -100
+    out = model.forward(input_ids=ids.to(DEV), labels=labels.to(DEV), attention_mask=am.to(DEV))
+    with torch.no_grad():
+        ref = oracle.forward(input_ids=ids, labels=labels, attention_mask=am)
+    keep = am.bool()
+    assert rel_l2(out.logits.cpu()[keep], ref["logits"][keep]) < 3e-2
+    assert abs(out.loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
+
+
+def test_forward_argument_checks_mirror_reference():
+    cfg, sd, model, oracle = build(5)
+    b = {k: v.to(DEV) for k, v in batch_for(cfg).items()}
+    bad = dict(b); bad["audio_token_len"] = b["audio_token_len"][:1]
+    with pytest.raises(AssertionError, match="must have the same batch size"):
+        model.forward(**bad)
+    bad = dict(b); bad.pop("audio_lens")
+    with pytest.raises(AssertionError, match="must be provided"):
+        model.forward(**bad)
+    bad = dict(b); bad["audio_batch_size"] = b["audio_batch_size"][:1]
+    with pytest.raises(AssertionError, match="audio_batch_size and inputs_embeds must have the same batch size"):
+        model.forward(**bad)
+
+
+def test_train_step_matches_oracle():
+    """loss, projector gradients, clipped AdamW update — one HF-Trainer optimizer step."""
+    from ultravox_amd.model import UltravoxTrainer
+    cfg, sd, model, oracle = build(6)
+    b = batch_for(cfg, B=3, seconds=3.0, n_text=32, n_sup=12)
+    trainer = UltravoxTrainer(model, lr=2e-3, master_weights=True)
+    params = [oracle.sd[k] for k in oracle.trainable]
+    opt = torch.optim.AdamW(params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    ob = {**b, "audio_values": b["audio_values"].bfloat16().float()}
+    for step in range(2):
+        out, grads, gn = oracle.train_step(ob, opt)
+        loss = trainer.train_step(**{k: v.to(DEV) for k, v in b.items()})
+        assert abs(loss.item() - out["loss"].item()) < 2e-2 * abs(out["loss"].item()), step
+        mine = model.projector_grads()
+        for k in oracle.trainable:
+            assert rel_l2(mine[k], grads[k]) < 6e-2, (step, k)
+        assert abs(trainer.grad_norm().item() - gn.item()) < 5e-2 * gn.item()
+        new = model.projector_state_dict()
+        for k in oracle.trainable:
+            # Adam's first steps move every weight by ~lr regardless of gradient scale: compare the UPDATE
+            delta_ref = oracle.sd[k].detach() - sd[k].float()
+            delta = new[k].float().cpu() - sd[k].float()
+            assert rel_l2(delta, delta_ref) < 0.25, (step, k)
+
+
+def test_llm_input_gradient_matches_oracle():
+    from oracle.reference_cpu import llama_ref, causal_lm_loss_ref
+    cfg, sd, model, oracle = build(7)
+    torch.manual_seed(2)
+    B, T, D = 2, 48, 256
+    emb = (torch.randn(B, T, D) * 0.5).bfloat16()
+    labels = torch.randint(0, 512, (B, T)); labels[:, :30] = -100
+    out = model.language_model_forward(emb.to(DEV), labels=labels.to(DEV), want_logits=False, save_for_bwd=True)
+    import ctypes as C
+    from ultravox_amd import _lib
+    d = torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16)
+    Bc, Tc, nb, lab = model._llm_ctx
+    _lib.check(_lib.lib().uvx_llm_bwd(_lib.stream_ptr(), C.byref(model._c), C.byref(model._lw), _lib.ptr(lab), B, T,
+                                      C.c_float(1.0), _lib.ptr(d), _lib.ptr(model._ws["llm"]), C.c_size_t(nb)))
+    e = emb.float().requires_grad_(True)
+    loss = causal_lm_loss_ref(llama_ref(oracle.sd, cfg, e, None), labels)
+    loss.backward()
+    assert abs(out.loss.item() - loss.item()) < 2e-2 * loss.item()
+    assert rel_l2(d, e.grad) < 6e-2

@@ -1,0 +1,167 @@
+"""Pins the CPU oracle (oracle/reference_cpu.py) before anything is compared against it:
+  * against fixtures produced by the REFERENCE's own classes (tests/golden/*.npz, make_golden.py);
+  * against the installed HF blocks (the third-party arithmetic the reference calls);
+  * directly against /root/reference when it is present (build container only)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_cpu as O
+from ultravox_amd.config import UltravoxConfig
+from ultravox_amd.weights import random_state_dict
+
+TINY = dict(
+    audio_config=dict(d_model=64, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=128, num_mel_bins=80,
+                      max_source_positions=1500),
+    text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                     num_key_value_heads=2, vocab_size=512, rope_theta=10000.0, max_position_embeddings=512),
+    hidden_size=128, stack_factor=8, projector_ln_mid=True)
+
+
+def tiny_cfg(**kw):
+    d = {**TINY, **kw}
+    return UltravoxConfig(**d)
+
+
+@pytest.mark.parametrize("variant", ["mid", "post"])
+def test_projector_matches_reference_fixture(golden_dir, variant):
+    z = np.load(os.path.join(golden_dir, f"projector_ln_{variant}.npz"))
+    cfg = tiny_cfg(projector_ln_mid=(variant == "mid"), hidden_size=256)
+    p = {k[2:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("w.")}
+    x = torch.from_numpy(z["x"]).clone().requires_grad_(True)
+    y = O.projector_ref(p, cfg, x)
+    np.testing.assert_allclose(y.detach().numpy(), z["y"], rtol=1e-5, atol=1e-6)
+    y.backward(torch.from_numpy(z["gy"]))
+    np.testing.assert_allclose(x.grad.numpy(), z["gx"], rtol=1e-4, atol=1e-6)
+    for k in p:
+        np.testing.assert_allclose(p[k].grad.numpy(), z["g." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_latency_mask_matches_reference_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "latency_mask.npz"))
+    for block in (100, 300, 1500):
+        m = O.latency_mask_ref(3000, block, torch.float32)[0, 0, :400, :400]
+        assert np.array_equal((m == 0).numpy(), z[f"allowed_{block}"])
+    assert int(z["err13"]) == 1
+    with pytest.raises(AssertionError, match="must divide 3000 evenly"):
+        O.latency_mask_ref(3000, 13, torch.float32)
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_logmel_matches_hf_fixture(golden_dir, n_mels):
+    z = np.load(os.path.join(golden_dir, "logmel.npz"))
+    mel = O.logmel_ref(torch.from_numpy(z[f"pcm_{n_mels}"]), n_mels).numpy()
+    assert mel.shape == z[f"mel_{n_mels}"].shape
+    np.testing.assert_allclose(mel, z[f"mel_{n_mels}"], rtol=0, atol=2e-5)
+
+
+def test_feature_extractor_contract_matches_hf():
+    import transformers
+    rng = np.random.RandomState(3)
+    clips = [rng.randn(n).astype(np.float32) * 0.1 for n in (16000, 4321, 700)]
+    hf = transformers.WhisperFeatureExtractor()(clips, sampling_rate=16000, padding="longest", pad_to_multiple_of=160,
+                                                truncation=False, return_attention_mask=True, return_tensors="pt")
+    ours = O.FeatureExtractorRef(80)(clips, sampling_rate=16000, padding="longest", pad_to_multiple_of=160)
+    assert torch.equal(torch.as_tensor(hf["attention_mask"]).long(), ours["attention_mask"].long())
+    np.testing.assert_allclose(ours["input_features"].numpy(), hf["input_features"].numpy(), atol=2e-5)
+
+
+def test_encoder_matches_hf_whisper_blocks():
+    """[3P] check: the restated encoder == installed HF WhisperEncoder sub-modules driven the way
+    ModifiedWhisperEncoder.forward drives them (ultravox_model.py:893-899, :915-936, :944-980)."""
+    from transformers import WhisperConfig
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder
+    cfg = tiny_cfg()
+    a = cfg.audio_config
+    hf = WhisperEncoder(WhisperConfig(d_model=a.d_model, encoder_layers=a.encoder_layers,
+                                      encoder_attention_heads=a.encoder_attention_heads, encoder_ffn_dim=a.encoder_ffn_dim,
+                                      num_mel_bins=a.num_mel_bins, max_source_positions=a.max_source_positions,
+                                      attn_implementation="eager")).eval()
+    sd = random_state_dict(cfg, seed=5)
+    enc_sd = {k[len("audio_tower."):]: v for k, v in sd.items() if k.startswith("audio_tower.")}
+    missing, unexpected = hf.load_state_dict(enc_sd, strict=False)
+    assert not unexpected and all("k_proj.bias" in m for m in missing), (missing, unexpected)
+    torch.manual_seed(0)
+    x = torch.randn(2, 80, 200)
+    audio_len = torch.tensor([200, 123])
+    with torch.no_grad():
+        h = torch.nn.functional.gelu(hf.conv1(x))
+        h = torch.nn.functional.gelu(hf.conv2(h)).permute(0, 2, 1)
+        h = h + hf.embed_positions.weight[: h.size(-2)]
+        feat_len = (audio_len - 1) // 2 + 1
+        keep = torch.arange(h.shape[1])[None, :].lt(feat_len.view(-1, 1))
+        mask = (1.0 - keep[:, None, None, :].float()) * torch.finfo(torch.float32).min
+        for layer in hf.layers:
+            out = layer(h, mask)
+            h = out[0] if isinstance(out, tuple) else out
+        want = hf.layer_norm(h)
+        got = O.whisper_encoder_ref(sd, cfg, x, audio_len)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_llama_and_loss_match_hf_blocks():
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = tiny_cfg()
+    t = cfg.text_config
+    hf = LlamaForCausalLM(LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size,
+                                      num_hidden_layers=t.num_hidden_layers, num_attention_heads=t.num_attention_heads,
+                                      num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size,
+                                      rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta,
+                                      max_position_embeddings=t.max_position_embeddings, tie_word_embeddings=False,
+                                      attn_implementation="eager")).eval()
+    sd = random_state_dict(cfg, seed=6)
+    llm_sd = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}
+    missing, unexpected = hf.load_state_dict(llm_sd, strict=False)
+    assert not unexpected and not [m for m in missing if "rotary" not in m and "inv_freq" not in m], (missing, unexpected)
+    torch.manual_seed(1)
+    B, T = 2, 37
+    emb = torch.randn(B, T, t.hidden_size) * 0.5
+    labels = torch.randint(0, t.vocab_size, (B, T))
+    labels[:, :20] = -100
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, -9:] = 0  # right padding
+    with torch.no_grad():
+        out = hf(inputs_embeds=emb, attention_mask=am, labels=labels)
+        logits = O.llama_ref(sd, cfg, emb, am)
+        loss = O.causal_lm_loss_ref(logits, labels)
+    keep = am.bool()
+    np.testing.assert_allclose(logits[keep].numpy(), out.logits[keep].numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(loss.item(), out.loss.item(), rtol=1e-5)
+
+
+def test_merge_is_sequential_overwrite():
+    emb = torch.zeros(2, 10, 4)
+    audio = torch.arange(3 * 5 * 4, dtype=torch.float32).view(3, 5, 4) + 1
+    out = O.merge_ref(emb, audio, torch.tensor([1, 3, 0]), torch.tensor([4, 3, 2], dtype=torch.int32), torch.tensor([2, 1]))
+    assert torch.equal(out[0, 1:3], audio[0, :2]) and torch.equal(out[0, 3:6], audio[1, :3])  # item 1 overwrote rows 3-4
+    assert torch.equal(out[1, 0:2], audio[2, :2]) and out[0, 6:].abs().sum() == 0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/ultravox"), reason="reference tree only exists in the build container")
+def test_projector_against_live_reference():
+    sys.path.insert(0, "/root/reference")
+    if "peft" not in sys.modules:
+        peft = types.ModuleType("peft")
+        peft.LoraConfig = lambda **kw: types.SimpleNamespace(r=kw.get("r", 0))
+        peft.PeftModel = type("PeftModel", (), {})
+        peft.get_peft_model = lambda m, c: m
+        peft.peft_model = types.ModuleType("peft.peft_model")
+        peft.peft_model.PeftModel = peft.PeftModel
+        sys.modules["peft"], sys.modules["peft.peft_model"] = peft, peft.peft_model
+    from ultravox.model import ultravox_config, ultravox_model
+    rcfg = ultravox_config.UltravoxConfig(
+        audio_config={"model_type": "whisper", "d_model": 64, "encoder_layers": 1, "encoder_attention_heads": 2,
+                      "encoder_ffn_dim": 64}, text_config={"model_type": "llama", "hidden_size": 128,
+                                                           "intermediate_size": 64, "num_hidden_layers": 1,
+                                                           "num_attention_heads": 2, "vocab_size": 64},
+        hidden_size=128, projector_ln_mid=True)
+    torch.manual_seed(3)
+    proj = ultravox_model.UltravoxProjector(rcfg).float()
+    x = torch.randn(2, 19, 64)
+    want = proj(x)
+    got = O.projector_ref({k: v for k, v in proj.state_dict().items()}, tiny_cfg(), x)
+    np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)

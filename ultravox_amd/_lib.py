@@ -42,6 +42,7 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(str(_LIB_PATH))
         _lib.uvx_last_error.restype = C.c_char_p
         _lib.uvx_abi_version.restype = C.c_int32
+        _declare(_lib)
     return _lib
 
 
@@ -70,3 +71,78 @@ def dtype_code(t) -> int:
     if t == torch.float32:
         return F32
     raise ValueError(f"unsupported dtype {t}")
+
+
+# ------------------------------------------------------------------ struct mirrors of include/uvx.h
+class Config(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("enc_layers", C.c_int32), ("enc_d", C.c_int32), ("enc_heads", C.c_int32), ("enc_ffn", C.c_int32),
+        ("n_mels", C.c_int32), ("enc_max_pos", C.c_int32), ("enc_block", C.c_int32), ("ln_eps", C.c_float),
+        ("stack_factor", C.c_int32), ("proj_hidden", C.c_int32), ("proj_ln_mid", C.c_int32),
+        ("proj_eps", C.c_float),
+        ("llm_layers", C.c_int32), ("llm_d", C.c_int32), ("llm_heads", C.c_int32), ("llm_kv_heads", C.c_int32),
+        ("llm_head_dim", C.c_int32), ("llm_inter", C.c_int32), ("vocab", C.c_int32), ("rms_eps", C.c_float),
+    ]
+
+
+_ENC_LAYER_FIELDS = ["ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
+
+
+class EncLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _ENC_LAYER_FIELDS]
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
+                ("pos", C.c_void_p), ("layers", C.POINTER(EncLayer)), ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p)]
+
+
+class ProjectorWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_pre", "w1", "ln_mid", "w2", "ln_post")]
+
+
+class ProjectorGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_pre", "w1", "ln_mid", "w2", "ln_post")]
+
+
+_LLM_LAYER_FIELDS = ["ln1", "wqkv", "wo", "ln2", "wgu", "wd", "wqkv_t", "wo_t", "wgu_t", "wd_t"]
+
+
+class LlmLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LLM_LAYER_FIELDS]
+
+
+class LlmWeights(C.Structure):
+    _fields_ = [("embed", C.c_void_p), ("layers", C.POINTER(LlmLayer)), ("norm", C.c_void_p),
+                ("lm_head", C.c_void_p), ("lm_head_t", C.c_void_p), ("rope_cos_sin", C.c_void_p),
+                ("rope_len", C.c_int32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+                ("kv_start", C.c_void_p), ("kv_len", C.c_void_p),
+                ("B", C.c_int32), ("T", C.c_int32), ("Hq", C.c_int32), ("Hkv", C.c_int32), ("D", C.c_int32),
+                ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
+                ("causal", C.c_int32), ("block", C.c_int32), ("scale", C.c_float),
+                ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+                ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32)]
+
+
+EXPORTS = [
+    "uvx_last_error", "uvx_abi_version", "uvx_logmel", "uvx_encoder_ws_bytes", "uvx_encoder_fwd",
+    "uvx_projector_ws_bytes", "uvx_projector_fwd", "uvx_projector_bwd", "uvx_embed_merge", "uvx_merge_embeds_bwd",
+    "uvx_llm_ws_bytes", "uvx_llm_fwd", "uvx_llm_bwd", "uvx_adamw_clip_step", "uvx_gemm", "uvx_layernorm",
+    "uvx_rmsnorm", "uvx_rmsnorm_bwd", "uvx_swiglu", "uvx_swiglu_bwd", "uvx_rope", "uvx_attention_ws_bytes",
+    "uvx_attention_fwd", "uvx_attention_bwd", "uvx_ce_loss",
+]
+
+
+def _declare(l: C.CDLL) -> None:
+    for name in ("uvx_encoder_ws_bytes", "uvx_projector_ws_bytes", "uvx_llm_ws_bytes", "uvx_attention_ws_bytes"):
+        getattr(l, name).restype = C.c_size_t
+    for name in EXPORTS:
+        f = getattr(l, name)
+        if name.endswith("ws_bytes") or name in ("uvx_last_error", "uvx_abi_version"):
+            continue
+        f.restype = C.c_int32

@@ -1,0 +1,184 @@
+"""Configuration mirror of ultravox/model/ultravox_config.py:56-203 (UltravoxConfig, LossConfig,
+LossFunction, LossMaskType, LoraConfigSimplified) without the HuggingFace base class: plain Python
+objects with the same field names, so a reference config dict loads unchanged.
+
+Architecture constants for the model ids the reference recipes name are recorded here because the hub
+is unreachable offline.
+"""
+from __future__ import annotations
+
+import dataclasses
+from enum import Enum
+from typing import Any, Dict, List, Optional
+
+
+@dataclasses.dataclass
+class LoraConfigSimplified:  # ultravox_config.py:8-23
+    r: int = 0
+    lora_alpha: float = 8
+    target_modules: Optional[List[str]] = dataclasses.field(
+        default_factory=lambda: ["k_proj", "q_proj", "linear_k", "linear_q"])
+    unfreeze_layers: Optional[List[str]] = None
+
+
+class LossMaskType(str, Enum):  # ultravox_config.py:26-34
+    LAST_ASSISTANT = "last_assistant"
+    ALL = "all"
+    AFTER_AUDIO = "after_audio"
+
+
+class LossFunction(str, Enum):  # ultravox_config.py:37-39
+    CrossEntropy = "ce"
+    KL_Divergence = "kl"
+
+
+@dataclasses.dataclass
+class LossConfig:  # ultravox_config.py:42-53
+    loss_function: LossFunction = LossFunction.CrossEntropy
+    kl_temperature: float = 2.0
+    initial_tokens_to_ignore: int = 0
+    eot_loss_weight: float = 1.0
+
+    @property
+    def requires_alt_fields(self):
+        return self.loss_function == LossFunction.KL_Divergence
+
+
+@dataclasses.dataclass
+class AudioConfig:
+    """Field names of transformers.WhisperConfig that the encoder path reads."""
+    model_type: str = "whisper"
+    d_model: int = 384
+    encoder_layers: int = 4
+    encoder_attention_heads: int = 6
+    encoder_ffn_dim: int = 1536
+    num_mel_bins: int = 80
+    max_source_positions: int = 1500
+    layer_norm_eps: float = 1e-5
+
+    @property
+    def hidden_size(self) -> int:  # WhisperConfig.hidden_size aliases d_model (used at ultravox_model.py:750)
+        return self.d_model
+
+
+@dataclasses.dataclass
+class TextConfig:
+    """Field names of transformers.LlamaConfig that the LLM path reads."""
+    model_type: str = "llama"
+    hidden_size: int = 2048
+    intermediate_size: int = 5632
+    num_hidden_layers: int = 22
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 4
+    head_dim: Optional[int] = None
+    vocab_size: int = 32000
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    rope_scaling: Optional[Dict[str, Any]] = None
+    max_position_embeddings: int = 2048
+    initializer_range: float = 0.02
+    eos_token_id: int = 2
+
+    def __post_init__(self):
+        if self.head_dim is None:
+            self.head_dim = self.hidden_size // self.num_attention_heads
+
+
+AUDIO_PRESETS: Dict[str, Dict[str, Any]] = {
+    "openai/whisper-tiny": dict(d_model=384, encoder_layers=4, encoder_attention_heads=6, encoder_ffn_dim=1536, num_mel_bins=80),
+    "openai/whisper-small": dict(d_model=768, encoder_layers=12, encoder_attention_heads=12, encoder_ffn_dim=3072, num_mel_bins=80),
+    "openai/whisper-medium": dict(d_model=1024, encoder_layers=24, encoder_attention_heads=16, encoder_ffn_dim=4096, num_mel_bins=80),
+    "openai/whisper-large-v3": dict(d_model=1280, encoder_layers=32, encoder_attention_heads=20, encoder_ffn_dim=5120, num_mel_bins=128),
+    "openai/whisper-large-v3-turbo": dict(d_model=1280, encoder_layers=32, encoder_attention_heads=20, encoder_ffn_dim=5120, num_mel_bins=128),
+}
+_LLAMA3_SCALING = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                       original_max_position_embeddings=8192)
+TEXT_PRESETS: Dict[str, Dict[str, Any]] = {
+    "TinyLlama/TinyLlama-1.1B-Chat-v1.0": dict(hidden_size=2048, intermediate_size=5632, num_hidden_layers=22,
+                                               num_attention_heads=32, num_key_value_heads=4, vocab_size=32000,
+                                               rope_theta=10000.0, max_position_embeddings=2048, eos_token_id=2),
+    "meta-llama/Meta-Llama-3-8B-Instruct": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                                                num_attention_heads=32, num_key_value_heads=8, vocab_size=128256,
+                                                rope_theta=500000.0, max_position_embeddings=8192, eos_token_id=128009),
+    "meta-llama/Llama-3.1-8B-Instruct": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                                             num_attention_heads=32, num_key_value_heads=8, vocab_size=128256,
+                                             rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING,
+                                             max_position_embeddings=131072, eos_token_id=128009),
+    "meta-llama/Llama-3.3-70B-Instruct": dict(hidden_size=8192, intermediate_size=28672, num_hidden_layers=80,
+                                              num_attention_heads=64, num_key_value_heads=8, vocab_size=128256,
+                                              rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING,
+                                              max_position_embeddings=131072, eos_token_id=128009),
+}
+TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat"] = TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat-v1.0"]
+TEXT_PRESETS["meta-llama/Meta-Llama-3-8B"] = TEXT_PRESETS["meta-llama/Meta-Llama-3-8B-Instruct"]
+
+
+def _mk(cls, value, presets, model_id):
+    if model_id is not None:
+        if model_id not in presets:
+            raise ValueError(f"unknown model id {model_id!r}: no network here, known ids: {sorted(presets)}")
+        return cls(**presets[model_id])
+    if value is None:
+        return cls()
+    if isinstance(value, cls):
+        return value
+    if isinstance(value, dict):
+        names = {f.name for f in dataclasses.fields(cls)}
+        return cls(**{k: v for k, v in value.items() if k in names})
+    # duck-typed HF config object
+    names = {f.name for f in dataclasses.fields(cls)}
+    return cls(**{k: getattr(value, k) for k in names if hasattr(value, k)})
+
+
+class UltravoxConfig:
+    """Same constructor arguments and attributes as the reference's UltravoxConfig."""
+
+    model_type = "ultravox"
+
+    def __init__(self, audio_config=None, text_config=None, audio_model_id: Optional[str] = None,
+                 text_model_id: Optional[str] = None, llm_only_training: bool = False, ignore_index: int = -100,
+                 audio_token_index: Optional[int] = None, hidden_size: int = 4096, stack_factor: int = 8,
+                 norm_init: float = 0.4, projector_act: str = "swiglu", projector_ln_mid: bool = False,
+                 text_model_lora_config=None, audio_model_lora_config=None,
+                 audio_latency_block_size: Optional[int] = None, torch_dtype: str = "bfloat16", **kwargs):
+        self.ignore_index = ignore_index
+        self.audio_model_id = audio_model_id
+        self.text_model_id = text_model_id
+        self.audio_token_index = audio_token_index
+        self.hidden_size = hidden_size
+        self.stack_factor = stack_factor
+        self.norm_init = norm_init
+        self.projector_act = projector_act
+        self.projector_ln_mid = projector_ln_mid
+        self.text_config: TextConfig = _mk(TextConfig, text_config, TEXT_PRESETS, text_model_id)
+        self.audio_config: AudioConfig = _mk(AudioConfig, audio_config, AUDIO_PRESETS, audio_model_id)
+        self.llm_only_training = llm_only_training
+        as_dict = lambda c: c if isinstance(c, dict) else dataclasses.asdict(c or LoraConfigSimplified())
+        self.text_model_lora_config = as_dict(text_model_lora_config)
+        self.audio_model_lora_config = as_dict(audio_model_lora_config)
+        self.audio_latency_block_size = audio_latency_block_size
+        self.vocab_size = self.text_config.vocab_size
+        self.initializer_range = self.text_config.initializer_range
+        self.torch_dtype = torch_dtype
+        if projector_act != "swiglu":
+            raise ValueError("only projector_act='swiglu' (the reference default, ultravox_config.py:126) is built")
+        for name, lc in (("text", self.text_model_lora_config), ("audio", self.audio_model_lora_config)):
+            if lc.get("r", 0) != 0:
+                raise ValueError(f"{name}_model_lora_config.r != 0: LoRA training is outside the built scope "
+                                 "(frozen towers, apply_lora r=0, ultravox_model.py:697-703)")
+        self.extra = kwargs
+
+    def to_dict(self) -> Dict[str, Any]:
+        d = {k: v for k, v in self.__dict__.items() if k not in ("text_config", "audio_config", "extra")}
+        d["text_config"] = dataclasses.asdict(self.text_config)
+        d["audio_config"] = dataclasses.asdict(self.audio_config)
+        d["model_type"] = self.model_type
+        return d
+
+    def to_diff_dict(self) -> Dict[str, Any]:  # ultravox_config.py:188-203
+        d = self.to_dict()
+        if self.text_model_id is not None:
+            d.pop("text_config", None)
+        if self.audio_model_id is not None:
+            d.pop("audio_config", None)
+        return d

@@ -29,3 +29,92 @@ extern "C" int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* 
   d.act = g->act; d.out_f32 = g->out_f32; d.accumulate = g->accumulate; d.alpha = g->alpha;
   return uvx::gemm((hipStream_t)stream, dtype, d);
 }
+
+// ---- thin single-op wrappers ----
+extern "C" int32_t uvx_layernorm(void* stream, int32_t dtype, const void* x, const void* w, const void* b, void* y,
+                                 int32_t rows, int32_t cols, float eps) {
+  return uvx::layernorm_fwd((hipStream_t)stream, dtype, x, w, b, y, rows, cols, eps);
+}
+extern "C" int32_t uvx_rmsnorm(void* stream, int32_t dtype, const void* x, const void* w, void* y, int32_t rows,
+                               int32_t cols, float eps) {
+  return uvx::rmsnorm_fwd((hipStream_t)stream, dtype, x, w, y, nullptr, rows, cols, eps);
+}
+extern "C" int32_t uvx_rmsnorm_bwd(void* stream, int32_t dtype, const void* dy, const void* x, const void* w,
+                                   const void* dx_add, void* dx, float* dw, int32_t rows, int32_t cols, float eps) {
+  return uvx::rmsnorm_bwd((hipStream_t)stream, dtype, dy, x, w, dx_add, dx, dw, rows, cols, eps);
+}
+extern "C" int32_t uvx_swiglu(void* stream, int32_t dtype, const void* in, void* out, int32_t rows, int32_t half,
+                              int32_t gate_first) {
+  return uvx::swiglu_fwd((hipStream_t)stream, dtype, in, out, rows, half, gate_first);
+}
+extern "C" int32_t uvx_swiglu_bwd(void* stream, int32_t dtype, const void* dout, const void* in, void* din, int32_t rows,
+                                  int32_t half, int32_t gate_first) {
+  return uvx::swiglu_bwd((hipStream_t)stream, dtype, dout, in, din, rows, half, gate_first);
+}
+extern "C" int32_t uvx_rope(void* stream, int32_t dtype, void* x, const float* cos_sin, int32_t rows, int32_t T,
+                            int32_t n_heads, int32_t head_dim, int32_t ld, int32_t inverse) {
+  return uvx::rope_inplace((hipStream_t)stream, dtype, x, cos_sin, nullptr, rows, T, n_heads, head_dim, ld, inverse);
+}
+extern "C" int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, const int64_t* labels, float* loss,
+                               void* dlogits, int32_t B, int32_t T, int32_t V, int32_t ld, float grad_scale,
+                               float* scratch) {
+  return uvx::ce_loss_fwd_bwd((hipStream_t)stream, dtype, logits, labels, loss, scratch, dlogits, B, T, V, ld, grad_scale);
+}
+
+// Attention with its transposed operand copies carved from the caller's workspace.
+namespace {
+struct AttnWs { void *vt, *qt, *kt, *dot; float* delta; int Tp; size_t bytes; };
+AttnWs attn_carve(char* base, int dtype, const uvx_attn_desc_t& d, int backward) {
+  AttnWs w = {};
+  const size_t es = dtype == uvx::DT_BF16 ? 2 : 4;
+  w.Tp = (d.T + 63) / 64 * 64;
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t a = (off + 255) & ~(size_t)255; off = a + b; return base ? (void*)(base + a) : nullptr; };
+  w.vt = take((size_t)d.B * d.Hkv * d.D * w.Tp * es);
+  if (backward) {
+    w.qt = take((size_t)d.B * d.Hq * d.D * w.Tp * es);
+    w.kt = take((size_t)d.B * d.Hkv * d.D * w.Tp * es);
+    w.dot = take((size_t)d.B * d.Hq * d.D * w.Tp * es);
+    w.delta = (float*)take(sizeof(float) * (size_t)d.B * d.Hq * d.T);
+  }
+  w.bytes = off + 256;
+  return w;
+}
+uvx::AttnDesc to_desc(const uvx_attn_desc_t& d, const AttnWs& w) {
+  uvx::AttnDesc a;
+  a.q = d.q; a.k = d.k; a.v = d.v; a.vt = w.vt; a.o = d.o; a.lse = d.lse; a.kv_start = d.kv_start; a.kv_len = d.kv_len;
+  a.B = d.B; a.T = d.T; a.Tp = w.Tp; a.Hq = d.Hq; a.Hkv = d.Hkv; a.D = d.D;
+  a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo; a.causal = d.causal; a.block = d.block; a.scale = d.scale;
+  return a;
+}
+}  // namespace
+
+extern "C" size_t uvx_attention_ws_bytes(int32_t dtype, const uvx_attn_desc_t* d, int32_t backward) {
+  return d ? attn_carve(nullptr, dtype, *d, backward).bytes : 0;
+}
+extern "C" int32_t uvx_attention_fwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d, void* workspace,
+                                     size_t ws_bytes) {
+  UVX_CHECK(d && workspace, UVX_ERR_INVALID, "attention_fwd: null argument");
+  AttnWs w = attn_carve((char*)workspace, dtype, *d, 0);
+  UVX_CHECK(w.bytes <= ws_bytes + 256, UVX_ERR_WORKSPACE, "attention_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = uvx::heads_transpose(st, dtype, d->v, w.vt, d->B, d->T, w.Tp, d->Hkv, d->D, d->ldv);
+  if (rc) return rc;
+  return uvx::attention_fwd(st, dtype, to_desc(*d, w));
+}
+extern "C" int32_t uvx_attention_bwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d, void* workspace,
+                                     size_t ws_bytes) {
+  UVX_CHECK(d && workspace && d->lse && d->dout, UVX_ERR_INVALID, "attention_bwd: null argument");
+  AttnWs w = attn_carve((char*)workspace, dtype, *d, 1);
+  UVX_CHECK(w.bytes <= ws_bytes + 256, UVX_ERR_WORKSPACE, "attention_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if ((rc = uvx::heads_transpose(st, dtype, d->q, w.qt, d->B, d->T, w.Tp, d->Hq, d->D, d->ldq))) return rc;
+  if ((rc = uvx::heads_transpose(st, dtype, d->k, w.kt, d->B, d->T, w.Tp, d->Hkv, d->D, d->ldk))) return rc;
+  if ((rc = uvx::heads_transpose(st, dtype, d->dout, w.dot, d->B, d->T, w.Tp, d->Hq, d->D, d->ldo))) return rc;
+  uvx::AttnBwdDesc b;
+  b.f = to_desc(*d, w);
+  b.dout = d->dout; b.qt = w.qt; b.kt = w.kt; b.dot = w.dot; b.delta = w.delta;
+  b.dq = d->dq; b.dk = d->dk; b.dv = d->dv; b.lddq = d->lddq; b.lddk = d->lddk; b.lddv = d->lddv;
+  return uvx::attention_bwd(st, dtype, b);
+}

@@ -1,0 +1,542 @@
+// Flash attention (forward + backward) on MFMA 16x16x32 bf16, LDS-staged K / V^T tiles.
+//
+// Replaces the [3P] SDPA calls under WhisperAttention (non-causal, additive key-padding mask built by
+// the reference at ultravox_model.py:915-926, optional block-causal latency mask :834-863,:928-936) and
+// LlamaAttention (causal GQA + key-padding mask from the collator, ultravox_processing.py:36).
+//
+// Layout trick ("swapped" products): scores are computed TRANSPOSED, S^T[key][q] = K . Q^T, so in the
+// MFMA accumulator layout (row = 4*(lane>>4)+reg, col = lane&15) every lane owns ONE query row
+// (q = lane&15) and 4 consecutive keys per 16-key subtile.  Softmax statistics are then lane-local
+// (plus two xor-shuffles across the 4 lane groups), and the probabilities are ALREADY in the B-operand
+// layout of the second product O^T[d][q] = V^T[d][key] . P^T[key][q] — no LDS round trip for P.
+// The contraction index of an MFMA is free to permute, so B-slot (g, s) is mapped to key
+// 32*kp + 16*(s>>2) + 4*g + (s&3) and the V^T A-operand is read with the same map (two 8-byte reads).
+// V^T ([B, Hkv, D, Tp], keys contiguous) is produced by a transpose kernel right after the QKV GEMM.
+//
+// The backward pass is two kernels (dK/dV per key block, dQ per query block), each recomputing the
+// probabilities from the saved log-sum-exp; transposed operand copies (Q^T, dO^T, K^T) are made by the
+// same transpose kernel so that every MFMA operand is a contiguous 8/16-byte LDS read.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_INF = -__builtin_huge_valf();
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* vt;
+  bf16_t* o; float* lse;
+  const int32_t* kv_start; const int32_t* kv_len;
+  int B, T, Tp, Hq, Hkv;
+  int ldq, ldk, ldv, ldo;
+  int causal, block;
+  float sc;  // softmax scale * log2(e)
+  // backward
+  const bf16_t* dout; const bf16_t* qt; const bf16_t* kt; const bf16_t* dot;
+  float* delta;
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  int lddq, lddk, lddv;
+  float scale;
+};
+
+__device__ __forceinline__ bf16x8_t lds_b128(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+// two 8-byte LDS reads -> one 8 x bf16 fragment
+__device__ __forceinline__ bf16x8_t lds_2xb64(const char* p0, const char* p1) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(p0);
+  bf16x4_t b = *reinterpret_cast<const bf16x4_t*>(p1);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const float* lo, const float* hi) {
+  u16x8_t r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r[i] = f2bf(lo[i]); r[4 + i] = f2bf(hi[i]); }
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+__device__ __forceinline__ bool key_ok(int key, int q, int k_lo, int k_hi, int causal, int block) {
+  bool ok = key >= k_lo && key < k_hi;
+  if (causal) ok = ok && key <= q;
+  if (block > 0) ok = ok && (key / block) <= (q / block);
+  return ok;
+}
+
+// "natural" tile: R rows x D cols bf16, 16-byte chunks XOR-swizzled with the row index.
+template <int D>
+__device__ __forceinline__ int nat_off(int row, int chunk) {
+  constexpr int NCH = D / 8;
+  return row * (D * 2) + ((chunk ^ (row & (NCH - 1))) << 4);
+}
+// "transposed" tile: rows of W keys (W = 64 or 32) = W*2 bytes, 8-byte chunk c8.
+template <int W>
+__device__ __forceinline__ int tr_off8(int row, int c8) {
+  constexpr int M8 = W / 4 - 1;  // chunk index mask
+  return row * (W * 2) + (((c8 ^ (((row >> 1) & 7) << 1)) & M8) << 3);
+}
+template <int W>
+__device__ __forceinline__ int tr_off16(int row, int c16) {
+  constexpr int M16 = W / 8 - 1;
+  return row * (W * 2) + (((c16 ^ ((row >> 1) & 7)) & M16) << 4);
+}
+
+// Cooperative global -> LDS copy of a natural tile: rows [r0, r0+R) of a [*, ld] matrix (+col0), D columns;
+// rows >= rmax are zero filled.
+template <int D, int R>
+__device__ __forceinline__ void stage_nat(char* lds, const bf16_t* base, long long ld, int r0, int rmax, int tid) {
+  constexpr int NCH = D / 8;
+#pragma unroll
+  for (int i = tid; i < R * NCH; i += 256) {
+    const int r = i / NCH, c = i % NCH;
+    u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r0 + r < rmax) v = *reinterpret_cast<const u16x8_t*>(base + (long long)(r0 + r) * ld + c * 8);
+    *reinterpret_cast<u16x8_t*>(lds + nat_off<D>(r, c)) = v;
+  }
+}
+// transposed tile: D rows, W keys starting at t0 of a [D, Tp] matrix (zero padded in memory).
+template <int D, int W>
+__device__ __forceinline__ void stage_tr(char* lds, const bf16_t* base, int Tp, int t0, int tid) {
+  constexpr int NC = W / 8;
+#pragma unroll
+  for (int i = tid; i < D * NC; i += 256) {
+    const int r = i / NC, c = i % NC;
+    u16x8_t v = *reinterpret_cast<const u16x8_t*>(base + (long long)r * Tp + t0 + c * 8);
+    *reinterpret_cast<u16x8_t*>(lds + tr_off16<W>(r, c)) = v;
+  }
+}
+
+// =================================== forward ===================================
+template <int D, int QT>
+__global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
+  constexpr int BQ = 4 * QT * 16;
+  constexpr int KS = D / 32;   // k-steps of the QK^T product
+  constexpr int DT = D / 16;   // 16-row tiles of O^T
+  __shared__ __attribute__((aligned(16))) char ldsK[64 * D * 2];
+  __shared__ __attribute__((aligned(16))) char ldsV[D * 64 * 2];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+  const int qb0 = blockIdx.x * BQ;
+  const int q0 = qb0 + w * QT * 16;
+  const int k_lo = p.kv_start ? p.kv_start[b] : 0;
+  const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
+
+  // Q fragments (B operand): Q[q = fr][d = ks*32 + g*8 ..]
+  bf16x8_t qf[QT][KS];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int q = q0 + t * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < p.T) v = *reinterpret_cast<const u16x8_t*>(p.q + ((long long)b * p.T + q) * p.ldq + h * D + ks * 32 + g * 8);
+      qf[t][ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+
+  f32x4_t acc_o[QT][DT];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    m_run[t] = NEG_INF; l_run[t] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) acc_o[t][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  int kb_end = p.T;
+  if (p.causal) kb_end = min(kb_end, qb0 + BQ);
+  if (p.block > 0) kb_end = min(kb_end, ((qb0 + BQ - 1) / p.block + 1) * p.block);
+  kb_end = min(kb_end, k_hi);
+  const bf16_t* kbase = p.k + (long long)b * p.T * p.ldk + hk * D;
+  const bf16_t* vtbase = p.vt + ((long long)b * p.Hkv + hk) * D * p.Tp;
+
+  for (int kb = (k_lo / 64) * 64; kb < kb_end; kb += 64) {
+    __syncthreads();
+    stage_nat<D, 64>(ldsK, kbase, p.ldk, kb, p.T, tid);
+    stage_tr<D, 64>(ldsV, vtbase, p.Tp, kb, tid);
+    __syncthreads();
+
+    // ---- S^T = K . Q^T ----
+    f32x4_t s[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) s[t][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t kf = lds_b128(ldsK + nat_off<D>(kt * 16 + fr, ks * 4 + g));
+#pragma unroll
+        for (int t = 0; t < QT; ++t) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[t][kt], 0, 0, 0);
+      }
+
+    // ---- online softmax (per lane: q = fr; keys kb + kt*16 + g*4 + e) ----
+    bf16x8_t pf[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int q = q0 + t * 16 + fr;
+      float mx = NEG_INF;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = kb + kt * 16 + g * 4 + e;
+          float v = s[t][kt][e] * p.sc;
+          v = key_ok(key, q, k_lo, k_hi, p.causal, p.block) ? v : NEG_INF;
+          s[t][kt][e] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[t], mx);
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = exp2f(m_run[t] - m_use);
+      m_run[t] = m_new;
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = exp2f(s[t][kt][e] - m_use);
+          s[t][kt][e] = pv;
+          ps += pv;
+        }
+      l_run[t] = l_run[t] * alpha + ps;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) acc_o[t][d] *= alpha;
+      float lo[4], hi[4];
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = s[t][2 * kp][e]; hi[e] = s[t][2 * kp + 1][e]; }
+        pf[t][kp] = pack8(lo, hi);
+      }
+    }
+
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp) {
+        const int row = d * 16 + fr;
+        const bf16x8_t vf = lds_2xb64(ldsV + tr_off8<64>(row, kp * 8 + g), ldsV + tr_off8<64>(row, kp * 8 + 4 + g));
+#pragma unroll
+        for (int t = 0; t < QT; ++t) acc_o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][kp], acc_o[t][d], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int q = q0 + t * 16 + fr;
+    float l = l_run[t];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q >= p.T) continue;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    bf16_t* orow = p.o + ((long long)b * p.T + q) * p.ldo + h * D;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      u16x4_t o4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = f2bf(acc_o[t][d][e] * inv);
+      *reinterpret_cast<u16x4_t*>(orow + d * 16 + g * 4) = o4;
+    }
+    if (p.lse && g == 0) p.lse[((long long)b * p.Hq + h) * p.T + q] = l > 0.f ? m_run[t] + log2f(l) : __builtin_huge_valf();
+  }
+}
+
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+__global__ void attn_delta_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o, float* __restrict__ delta,
+                             int B, int T, int Hq, int D, int ldo) {
+  const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per (b,q,h)
+  const int lane = threadIdx.x & 63;
+  if (i >= (long long)B * T * Hq) return;
+  const int h = (int)(i % Hq);
+  const long long bq = i / Hq;
+  const long long off = bq * ldo + h * D;
+  float s = 0.f;
+  for (int c = lane * 2; c < D; c += 128) s += bf2f(dout[off + c]) * bf2f(o[off + c]) + bf2f(dout[off + c + 1]) * bf2f(o[off + c + 1]);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const int b = (int)(bq / T), q = (int)(bq % T);
+    delta[((long long)b * Hq + h) * T + q] = s;
+  }
+}
+
+// =================================== backward: dK, dV ===================================
+// Block = (key block of 64, kv head, batch); wave w owns keys kb0 + w*16 .. +16.  Loops over the
+// query heads of the GQA group and over 32-query steps.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
+  constexpr int KS = D / 32, DT = D / 16;
+  __shared__ __attribute__((aligned(16))) char ldsQ[32 * D * 2];
+  __shared__ __attribute__((aligned(16))) char ldsDO[32 * D * 2];
+  __shared__ __attribute__((aligned(16))) char ldsQT[D * 32 * 2];
+  __shared__ __attribute__((aligned(16))) char ldsDOT[D * 32 * 2];
+  __shared__ float ldsL[32], ldsDl[32];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, hk = blockIdx.y, kb0 = blockIdx.x * 64;
+  const int grp = p.Hq / p.Hkv;
+  const int k_lo = p.kv_start ? p.kv_start[b] : 0;
+  const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
+  const int key = kb0 + w * 16 + fr;  // this lane's key (B-operand column)
+
+  // K, V fragments for this wave's 16 keys: B operand, [key = fr][d = ks*32 + g*8 ..]
+  bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (key < p.T) {
+      a = *reinterpret_cast<const u16x8_t*>(p.k + ((long long)b * p.T + key) * p.ldk + hk * D + ks * 32 + g * 8);
+      c = *reinterpret_cast<const u16x8_t*>(p.v + ((long long)b * p.T + key) * p.ldv + hk * D + ks * 32 + g * 8);
+    }
+    kf[ks] = __builtin_bit_cast(bf16x8_t, a);
+    vf[ks] = __builtin_bit_cast(bf16x8_t, c);
+  }
+  f32x4_t acc_dk[DT], acc_dv[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { acc_dk[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc_dv[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+  int q_begin = 0;
+  if (p.causal) q_begin = kb0;
+  if (p.block > 0) q_begin = max(q_begin, (kb0 / p.block) * p.block);
+  q_begin = (q_begin / 32) * 32;
+
+  for (int hh = 0; hh < grp; ++hh) {
+    const int h = hk * grp + hh;
+    const bf16_t* qbase = p.q + (long long)b * p.T * p.ldq + h * D;
+    const bf16_t* dobase = p.dout + (long long)b * p.T * p.ldo + h * D;
+    const bf16_t* qtbase = p.qt + ((long long)b * p.Hq + h) * D * p.Tp;
+    const bf16_t* dotbase = p.dot + ((long long)b * p.Hq + h) * D * p.Tp;
+    const float* lrow = p.lse + ((long long)b * p.Hq + h) * p.T;
+    const float* drow = p.delta + ((long long)b * p.Hq + h) * p.T;
+    for (int qs = q_begin; qs < p.T; qs += 32) {
+      __syncthreads();
+      stage_nat<D, 32>(ldsQ, qbase, p.ldq, qs, p.T, tid);
+      stage_nat<D, 32>(ldsDO, dobase, p.ldo, qs, p.T, tid);
+      stage_tr<D, 32>(ldsQT, qtbase, p.Tp, qs, tid);
+      stage_tr<D, 32>(ldsDOT, dotbase, p.Tp, qs, tid);
+      if (tid < 32) {
+        const int q = qs + tid;
+        ldsL[tid] = q < p.T ? lrow[q] : __builtin_huge_valf();
+        ldsDl[tid] = q < p.T ? drow[q] : 0.f;
+      }
+      __syncthreads();
+
+      // S[q][key] and dP[q][key] for the two 16-query tiles: A = Q / dO rows, B = K / V fragments
+      f32x4_t s[2], dp[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t a = lds_b128(ldsQ + nat_off<D>(t * 16 + fr, ks * 4 + g));
+          const bf16x8_t c = lds_b128(ldsDO + nat_off<D>(t * 16 + fr, ks * 4 + g));
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kf[ks], s[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, vf[ks], dp[t], 0, 0, 0);
+        }
+      }
+      // accumulator element e of tile t: q = qs + t*16 + g*4 + e, key = this lane's key
+      float pr[2][4], ds[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ql = t * 16 + g * 4 + e;
+          const int q = qs + ql;
+          const bool ok = q < p.T && key_ok(key, q, k_lo, k_hi, p.causal, p.block);
+          const float pv = ok ? exp2f(s[t][e] * p.sc - ldsL[ql]) : 0.f;
+          pr[t][e] = pv;
+          ds[t][e] = pv * (dp[t][e] - ldsDl[ql]);
+        }
+      const bf16x8_t pB = pack8(pr[0], pr[1]);   // B operand: slot (g, s) <-> q = qs + 16*(s>>2) + 4*g + (s&3)
+      const bf16x8_t dsB = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const int row = d * 16 + fr;
+        const bf16x8_t a = lds_2xb64(ldsDOT + tr_off8<32>(row, g), ldsDOT + tr_off8<32>(row, 4 + g));
+        const bf16x8_t c = lds_2xb64(ldsQT + tr_off8<32>(row, g), ldsQT + tr_off8<32>(row, 4 + g));
+        acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB, acc_dv[d], 0, 0, 0);
+        acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB, acc_dk[d], 0, 0, 0);
+      }
+    }
+  }
+  // accumulators hold dV^T / dK^T: row d = dt*16 + g*4 + e, col key = fr
+  if (key < p.T) {
+    bf16_t* dkrow = p.dk + ((long long)b * p.T + key) * p.lddk + hk * D;
+    bf16_t* dvrow = p.dv + ((long long)b * p.T + key) * p.lddv + hk * D;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      u16x4_t a, c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = f2bf(acc_dk[d][e] * p.scale); c[e] = f2bf(acc_dv[d][e]); }
+      *reinterpret_cast<u16x4_t*>(dkrow + d * 16 + g * 4) = a;
+      *reinterpret_cast<u16x4_t*>(dvrow + d * 16 + g * 4) = c;
+    }
+  }
+}
+
+// =================================== backward: dQ ===================================
+// Block = (query block of 64, head, batch); wave w owns queries qb0 + w*16 .. +16; loops over 32-key steps.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
+  constexpr int KS = D / 32, DT = D / 16;
+  __shared__ __attribute__((aligned(16))) char ldsK[32 * D * 2];
+  __shared__ __attribute__((aligned(16))) char ldsV[32 * D * 2];
+  __shared__ __attribute__((aligned(16))) char ldsKT[D * 32 * 2];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+  const int qb0 = blockIdx.x * 64;
+  const int q = qb0 + w * 16 + fr;
+  const int k_lo = p.kv_start ? p.kv_start[b] : 0;
+  const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
+
+  bf16x8_t qf[KS], dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (q < p.T) {
+      a = *reinterpret_cast<const u16x8_t*>(p.q + ((long long)b * p.T + q) * p.ldq + h * D + ks * 32 + g * 8);
+      c = *reinterpret_cast<const u16x8_t*>(p.dout + ((long long)b * p.T + q) * p.ldo + h * D + ks * 32 + g * 8);
+    }
+    qf[ks] = __builtin_bit_cast(bf16x8_t, a);
+    dof[ks] = __builtin_bit_cast(bf16x8_t, c);
+  }
+  const float lse = q < p.T ? p.lse[((long long)b * p.Hq + h) * p.T + q] : __builtin_huge_valf();
+  const float dl = q < p.T ? p.delta[((long long)b * p.Hq + h) * p.T + q] : 0.f;
+
+  f32x4_t acc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) acc[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int kend = p.T;
+  if (p.causal) kend = min(kend, qb0 + 64);
+  if (p.block > 0) kend = min(kend, ((qb0 + 63) / p.block + 1) * p.block);
+  kend = min(kend, k_hi);
+  const bf16_t* kbase = p.k + (long long)b * p.T * p.ldk + hk * D;
+  const bf16_t* vbase = p.v + (long long)b * p.T * p.ldv + hk * D;
+  const bf16_t* ktbase = p.kt + ((long long)b * p.Hkv + hk) * D * p.Tp;
+
+  for (int ks0 = (k_lo / 32) * 32; ks0 < kend; ks0 += 32) {
+    __syncthreads();
+    stage_nat<D, 32>(ldsK, kbase, p.ldk, ks0, p.T, tid);
+    stage_nat<D, 32>(ldsV, vbase, p.ldv, ks0, p.T, tid);
+    stage_tr<D, 32>(ldsKT, ktbase, p.Tp, ks0, tid);
+    __syncthreads();
+    f32x4_t s[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t a = lds_b128(ldsK + nat_off<D>(t * 16 + fr, ks * 4 + g));
+        const bf16x8_t c = lds_b128(ldsV + nat_off<D>(t * 16 + fr, ks * 4 + g));
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[t], 0, 0, 0);     // S^T[key][q]
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dof[ks], dp[t], 0, 0, 0);  // dP^T[key][q]
+      }
+    }
+    float ds[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = ks0 + t * 16 + g * 4 + e;
+        const bool ok = q < p.T && key_ok(key, q, k_lo, k_hi, p.causal, p.block);
+        const float pv = ok ? exp2f(s[t][e] * p.sc - lse) : 0.f;
+        ds[t][e] = pv * (dp[t][e] - dl);
+      }
+    const bf16x8_t dsB = pack8(ds[0], ds[1]);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const int row = d * 16 + fr;
+      const bf16x8_t a = lds_2xb64(ldsKT + tr_off8<32>(row, g), ldsKT + tr_off8<32>(row, 4 + g));
+      acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB, acc[d], 0, 0, 0);  // dQ^T[d][q]
+    }
+  }
+  if (q < p.T) {
+    bf16_t* dqrow = p.dq + ((long long)b * p.T + q) * p.lddq + h * D;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      u16x4_t a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = f2bf(acc[d][e] * p.scale);
+      *reinterpret_cast<u16x4_t*>(dqrow + d * 16 + g * 4) = a;
+    }
+  }
+}
+
+AttnArgs make_args(const uvx::AttnDesc& d) {
+  AttnArgs a = {};
+  a.q = (const bf16_t*)d.q; a.k = (const bf16_t*)d.k; a.v = (const bf16_t*)d.v; a.vt = (const bf16_t*)d.vt;
+  a.o = (bf16_t*)d.o; a.lse = d.lse; a.kv_start = d.kv_start; a.kv_len = d.kv_len;
+  a.B = d.B; a.T = d.T; a.Tp = d.Tp; a.Hq = d.Hq; a.Hkv = d.Hkv;
+  a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
+  a.causal = d.causal; a.block = d.block;
+  a.sc = d.scale * LOG2E; a.scale = d.scale;
+  return a;
+}
+
+int check_desc(const uvx::AttnDesc& d) {
+  UVX_CHECK(d.D == 64 || d.D == 128, UVX_ERR_UNSUPPORTED, "attention: head_dim %d not supported (64 or 128)", d.D);
+  UVX_CHECK(d.Hkv > 0 && d.Hq % d.Hkv == 0, UVX_ERR_SHAPE, "attention: Hq=%d not a multiple of Hkv=%d", d.Hq, d.Hkv);
+  UVX_CHECK(d.Tp % 64 == 0 && d.Tp >= d.T, UVX_ERR_SHAPE, "attention: Tp=%d must be a multiple of 64 and >= T=%d", d.Tp, d.T);
+  UVX_CHECK(d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldo % 8 == 0, UVX_ERR_SHAPE, "attention: row strides must be multiples of 8");
+  return UVX_OK;
+}
+
+}  // namespace
+
+namespace uvx {
+
+int attention_fwd_f32(hipStream_t st, const AttnDesc& d);
+int attention_bwd_f32(hipStream_t st, const AttnBwdDesc& d);
+
+int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
+  if (d.B == 0 || d.T == 0) return UVX_OK;
+  if (dtype != DT_BF16) return attention_fwd_f32(st, d);
+  int rc = check_desc(d);
+  if (rc) return rc;
+  AttnArgs a = make_args(d);
+  constexpr int QT = 2;
+  dim3 grid(cdiv(d.T, 4 * QT * 16), d.Hq, d.B);
+  if (d.D == 64) hipLaunchKernelGGL((attn_fwd_k<64, QT>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((attn_fwd_k<128, QT>), grid, dim3(256), 0, st, a);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
+  if (d.f.B == 0 || d.f.T == 0) return UVX_OK;
+  if (dtype != DT_BF16) return attention_bwd_f32(st, d);
+  int rc = check_desc(d.f);
+  if (rc) return rc;
+  AttnArgs a = make_args(d.f);
+  a.dout = (const bf16_t*)d.dout; a.qt = (const bf16_t*)d.qt; a.kt = (const bf16_t*)d.kt; a.dot = (const bf16_t*)d.dot;
+  a.delta = d.delta; a.dq = (bf16_t*)d.dq; a.dk = (bf16_t*)d.dk; a.dv = (bf16_t*)d.dv;
+  a.lddq = d.lddq; a.lddk = d.lddk; a.lddv = d.lddv;
+  const long long nw = (long long)d.f.B * d.f.T * d.f.Hq;
+  hipLaunchKernelGGL(attn_delta_k, dim3(cdiv(nw, 4)), dim3(256), 0, st, a.dout, (const bf16_t*)d.f.o, a.delta, d.f.B, d.f.T,
+                     d.f.Hq, d.f.D, d.f.ldo);
+  UVX_LAUNCH_CHECK();
+  dim3 gk(cdiv(d.f.T, 64), d.f.Hkv, d.f.B), gq(cdiv(d.f.T, 64), d.f.Hq, d.f.B);
+  if (d.f.D == 64) {
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<64>, gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_k<64>, gq, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<128>, gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_k<128>, gq, dim3(256), 0, st, a);
+  }
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+}  // namespace uvx

@@ -56,10 +56,13 @@ int rope_inplace(hipStream_t st, int dtype, void* qkv, const float* cos_sin, con
                  int T, int n_heads_rot, int head_dim, int ld, int inverse);
 int embed_gather(hipStream_t st, int dtype, const void* table, const int64_t* ids, void* out, int rows,
                  int D, int vocab);
-int merge_audio(hipStream_t st, int dtype, void* embeds, const void* audio, const int32_t* item_batch,
-                const int64_t* start, const int32_t* len, int n_items, int T, int D, int Na);
-int merge_audio_bwd(hipStream_t st, int dtype, const void* dembeds, void* daudio, const int32_t* row_src,
-                    int n_items, int Na, int D);
+// owner[B*T] / item_batch[n_items] are int32 scratch filled by merge_owner and reused by the backward.
+int merge_owner(hipStream_t st, int32_t* owner, int32_t* item_batch, const int64_t* audio_batch_size,
+                const int64_t* start, const int32_t* len, int B, int n_items, int T, int Na);
+// bwd = 0: embeds[b, start+j] = audio[a, j];  bwd = 1: daudio[a, j] = (d)embeds[b, start+j] (0 where not owner)
+int merge_audio(hipStream_t st, int dtype, void* embeds, const void* audio, void* daudio, const int32_t* owner,
+                const int32_t* item_batch, const int64_t* start, const int32_t* len, int n_items, int T, int D,
+                int Na, int bwd);
 int transpose2d(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in,
                 int ld_out, int batch, long long s_in, long long s_out);
 int im2col_conv1(hipStream_t st, int dtype, const void* mel, int mel_is_f32, void* out, int B, int n_mels,
@@ -104,17 +107,18 @@ int heads_transpose(hipStream_t st, int dtype, const void* in, void* out, int B,
 // Shifted causal-LM cross entropy over bf16/f32 logits [rows=B*T, V] (ld = ldl).
 // labels [B, T] int64 (ignore_index -100).  Writes loss (f32 scalar, mean over valid shifted tokens),
 // n_valid, and (if dlogits) d loss / d logits in the logits dtype, IN PLACE allowed.
+// scratch: 2 + B*T floats (scratch[0] = n_valid, scratch[1] = summed loss, then per-row losses).
 int ce_loss_fwd_bwd(hipStream_t st, int dtype, const void* logits, const int64_t* labels, float* loss,
                     float* scratch, void* dlogits, int B, int T, int V, int ldl, float grad_scale);
 
 // ---- optim.hip ----
-int grad_sq_norm(hipStream_t st, const float* g, long long n, float* out_sumsq);
-int adamw_clip_step(hipStream_t st, int param_dtype, void* param, float* master, const float* grad,
-                    float* m, float* v, long long n, const float* sumsq, float max_norm, float lr,
+int grad_sq_norm(hipStream_t st, const float* g, long long n, float* partial /*>=1024 floats*/, float* out_sumsq);
+int adamw_clip_step(hipStream_t st, int state_dtype, void* param, float* master, const float* grad,
+                    void* m, void* v, long long n, const float* sumsq, float max_norm, float lr,
                     float beta1, float beta2, float eps, float wd, int step);
 
 // ---- logmel.hip ----
-int logmel(hipStream_t st, const float* pcm, const float* dft_cos_sin, const float* mel_fb, float* out,
-           float* scratch, int B, int L, int n_mels, int F_out, int F_stride);
+int logmel(hipStream_t st, const float* pcm, const float* window, const float* tw_cos, const float* tw_sin,
+           const float* mel_fb, float* out, float* scratch, int B, int L, int n_mels, int F_stride);
 
 }  // namespace uvx

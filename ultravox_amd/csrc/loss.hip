@@ -1,0 +1,112 @@
+// Shifted causal-LM cross entropy, forward + gradient in one pass over the logits.
+//
+// Reference: [3P] transformers ForCausalLMLoss / fixed_cross_entropy reached from
+// ultravox_model.py:328-334 with labels; UltravoxModel.accepts_loss_kwargs = False (:50-53) so
+// num_items_in_batch is None and the reduction is a MEAN over this rank's non-ignored shifted tokens:
+//   logits.float(); labels padded with one -100 on the right and shifted left by one;
+//   F.cross_entropy(ignore_index=-100, reduction="mean").
+// Row r = (b, t) is scored against labels[b, t+1]; the last position of every sequence is ignored.
+// dlogits = (softmax - onehot) * grad_scale / n_valid, written in the logits dtype (autograd casts the
+// f32 gradient back through .float()); it may alias the logits buffer.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__global__ void ce_count_k(const int64_t* __restrict__ labels, float* __restrict__ scratch, int B, int T) {
+  __shared__ float red[16];
+  float c = 0.f;
+  for (long long i = threadIdx.x; i < (long long)B * T; i += blockDim.x) {
+    const int t = (int)(i % T);
+    if (t + 1 < T && labels[i + 1] != -100) c += 1.f;
+  }
+  c = block_sum(c, red);
+  if (threadIdx.x == 0) scratch[0] = c;
+}
+
+template <typename T>
+__global__ void ce_rows_k(const T* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ scratch,
+                          T* __restrict__ dlogits, int Tlen, int V, long long ldl, float grad_scale) {
+  __shared__ float red[16];
+  const long long row = blockIdx.x;
+  const int t = (int)(row % Tlen);
+  const int64_t tgt = (t + 1 < Tlen) ? labels[row + 1] : -100;
+  const T* lr = logits + row * ldl;
+  T* dr = dlogits ? dlogits + row * ldl : nullptr;
+  float* row_loss = scratch + 2;
+  if (tgt == -100 || tgt < 0 || tgt >= V) {
+    if (threadIdx.x == 0) row_loss[row] = 0.f;
+    if (dr) {
+      float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int c = threadIdx.x * 8; c < V; c += blockDim.x * 8) st8<T>(dr + c, z);
+    }
+    return;
+  }
+  // online max / sum-exp, per thread then block
+  float m = -__builtin_huge_valf(), s = 0.f;
+  for (int c = threadIdx.x * 8; c < V; c += blockDim.x * 8) {
+    float v[8];
+    ld8<T>(lr + c, v);
+    float mx = v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, v[i]);
+    const float mn = fmaxf(m, mx);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a += expf(v[i] - mn);
+    s = s * expf(m - mn) + a;
+    m = mn;
+  }
+  const float M = block_max(m, red);
+  const float S = block_sum(s * expf(m - M), red);
+  const float lse = M + logf(S);
+  const float n_valid = scratch[0];
+  if (threadIdx.x == 0) row_loss[row] = lse - ldf<T>(lr + tgt);
+  if (dr) {
+    const float g = grad_scale / n_valid;
+    for (int c = threadIdx.x * 8; c < V; c += blockDim.x * 8) {
+      float v[8];
+      ld8<T>(lr + c, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float pr = expf(v[i] - lse);
+        v[i] = (pr - ((int64_t)(c + i) == tgt ? 1.f : 0.f)) * g;
+      }
+      st8<T>(dr + c, v);
+    }
+  }
+}
+
+__global__ void ce_final_k(float* __restrict__ scratch, float* __restrict__ loss, long long rows) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < rows; i += blockDim.x) s += scratch[2 + i];  // fixed order: deterministic
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const float n = scratch[0];
+    if (loss) loss[0] = n > 0.f ? s / n : __builtin_nanf("");  // torch: mean over zero elements = nan
+    scratch[1] = s;
+  }
+}
+
+}  // namespace
+
+namespace uvx {
+
+// scratch: 2 + B*T floats.  scratch[0] = n_valid, scratch[1] = summed loss, scratch[2..] = per-row loss.
+int ce_loss_fwd_bwd(hipStream_t st, int dtype, const void* logits, const int64_t* labels, float* loss, float* scratch,
+                    void* dlogits, int B, int T, int V, int ldl, float grad_scale) {
+  UVX_CHECK(V % 8 == 0 && ldl % 8 == 0, UVX_ERR_SHAPE, "ce_loss: V=%d / ld=%d must be multiples of 8", V, ldl);
+  const long long rows = (long long)B * T;
+  UVX_CHECK(rows > 0, UVX_ERR_SHAPE, "ce_loss: empty batch");
+  hipLaunchKernelGGL(ce_count_k, dim3(1), dim3(1024), 0, st, labels, scratch, B, T);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(ce_rows_k<bf16_t>, dim3(rows), dim3(256), 0, st, (const bf16_t*)logits, labels, scratch, (bf16_t*)dlogits, T, V, (long long)ldl, grad_scale);
+  else
+    hipLaunchKernelGGL(ce_rows_k<float>, dim3(rows), dim3(256), 0, st, (const float*)logits, labels, scratch, (float*)dlogits, T, V, (long long)ldl, grad_scale);
+  hipLaunchKernelGGL(ce_final_k, dim3(1), dim3(1024), 0, st, scratch, loss, rows);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+}  // namespace uvx

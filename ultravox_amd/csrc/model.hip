@@ -1,0 +1,564 @@
+// Host-side orchestration of the hot path behind the C ABI (include/uvx.h): which kernels run, in
+// what order, on which slices of the caller's workspace.  No device allocation, no synchronisation.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/uvx.h"
+
+namespace {
+
+using namespace uvx;
+
+struct Arena {
+  char* base;
+  size_t cap;
+  size_t off = 0;
+  Arena(void* b, size_t c) : base((char*)b), cap(c) {}
+  void* take(size_t bytes) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    return base ? (void*)(base + a) : nullptr;
+  }
+  bool fits() const { return !base || off <= cap; }
+};
+
+inline size_t esz(int dtype) { return dtype == DT_BF16 ? 2 : 4; }
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+inline char* at(const void* p, size_t elems, int dtype) { return (char*)p + elems * esz(dtype); }
+
+#define RC(expr)            \
+  do {                      \
+    int _rc = (expr);       \
+    if (_rc) return _rc;    \
+  } while (0)
+
+__global__ void enc_kvlen_k(const int64_t* __restrict__ audio_lens, int32_t* __restrict__ kv_len, int B, int Te) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  // _get_feat_extract_output_lengths: (len - 1) // 2 + 1   (python floor division)
+  const long long l = audio_lens[b];
+  long long o = (l - 1 >= 0 ? (l - 1) / 2 : -((2 - l) / 2)) + 1;
+  kv_len[b] = (int32_t)(o < 0 ? 0 : (o > Te ? Te : o));
+}
+
+__global__ void mask_range_k(const int64_t* __restrict__ mask, int32_t* __restrict__ kv_start, int32_t* __restrict__ kv_len,
+                             int T) {
+  __shared__ int lo, hi;
+  if (threadIdx.x == 0) { lo = T; hi = 0; }
+  __syncthreads();
+  const int64_t* m = mask + (long long)blockIdx.x * T;
+  int l = T, h = 0;
+  for (int t = threadIdx.x; t < T; t += blockDim.x)
+    if (m[t] != 0) { l = min(l, t); h = max(h, t + 1); }
+  atomicMin(&lo, l);
+  atomicMax(&hi, h);
+  __syncthreads();
+  if (threadIdx.x == 0) { kv_start[blockIdx.x] = lo < hi ? lo : 0; kv_len[blockIdx.x] = hi; }
+}
+
+__global__ void full_range_k(int32_t* __restrict__ kv_start, int32_t* __restrict__ kv_len, int B, int T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { kv_start[b] = 0; kv_len[b] = T; }
+}
+
+// ------------------------------------------------------------------ encoder
+struct EncWs {
+  void *im2col, *c1, *x, *n, *qkv, *vt, *o, *f;
+  int32_t* kvlen;
+  int Te, Tp, M, Kp1;
+};
+EncWs enc_carve(Arena& a, const uvx_config_t& c, int B, int F) {
+  EncWs w;
+  const size_t es = esz(c.dtype);
+  w.Te = (F - 1) / 2 + 1;
+  w.Tp = rup(w.Te, 64);
+  w.M = B * w.Te;
+  w.Kp1 = rup(3 * c.n_mels, 64);
+  const int dh = c.enc_d / c.enc_heads;
+  w.im2col = a.take((size_t)B * F * w.Kp1 * es);
+  w.c1 = a.take((size_t)B * (F + 2) * c.enc_d * es);
+  w.x = a.take((size_t)w.M * c.enc_d * es);
+  w.n = a.take((size_t)w.M * c.enc_d * es);
+  w.qkv = a.take((size_t)w.M * 3 * c.enc_d * es);
+  w.vt = a.take((size_t)B * c.enc_heads * dh * w.Tp * es);
+  w.o = a.take((size_t)w.M * c.enc_d * es);
+  w.f = a.take((size_t)w.M * c.enc_ffn * es);
+  w.kvlen = (int32_t*)a.take(sizeof(int32_t) * B);
+  return w;
+}
+
+// ------------------------------------------------------------------ projector
+struct ProjWs {
+  void *stacked, *xn, *h1, *a, *an, *ypre;                                        // forward stash
+  void *dy2, *dyT, *anT, *w2T, *d_an, *d_a, *d_h1, *dh1T, *xnT, *w1T, *d_xn;      // backward temps
+  int J, R, Rp, C8, H, Hh, D;
+};
+ProjWs proj_carve(Arena& a, const uvx_config_t& c, int B, int Te) {
+  ProjWs w;
+  const size_t es = esz(c.dtype);
+  w.J = (Te + c.stack_factor - 1) / c.stack_factor;
+  w.R = B * w.J;
+  w.Rp = rup(w.R, 64);
+  w.C8 = c.enc_d * c.stack_factor;
+  w.H = c.proj_hidden;
+  w.Hh = c.proj_hidden / 2;
+  w.D = c.llm_d;
+  w.stacked = a.take((size_t)w.R * w.C8 * es);
+  w.xn = a.take((size_t)w.R * w.C8 * es);
+  w.h1 = a.take((size_t)w.R * w.H * es);
+  w.a = a.take((size_t)w.R * w.Hh * es);
+  w.an = c.proj_ln_mid ? a.take((size_t)w.R * w.Hh * es) : w.a;
+  w.ypre = c.proj_ln_mid ? nullptr : a.take((size_t)w.R * w.D * es);
+  w.dy2 = c.proj_ln_mid ? nullptr : a.take((size_t)w.R * w.D * es);
+  w.dyT = a.take((size_t)w.D * w.Rp * es);
+  w.anT = a.take((size_t)w.Hh * w.Rp * es);
+  w.w2T = a.take((size_t)w.Hh * w.D * es);
+  w.d_an = a.take((size_t)w.R * w.Hh * es);
+  w.d_a = c.proj_ln_mid ? a.take((size_t)w.R * w.Hh * es) : w.d_an;
+  w.d_h1 = a.take((size_t)w.R * w.H * es);
+  w.dh1T = a.take((size_t)w.H * w.Rp * es);
+  w.xnT = a.take((size_t)w.C8 * w.Rp * es);
+  w.w1T = a.take((size_t)w.C8 * w.H * es);
+  w.d_xn = a.take((size_t)w.R * w.C8 * es);
+  return w;
+}
+
+// ------------------------------------------------------------------ LLM
+struct LlmLayerStash {
+  void *x_in, *qkv, *o, *x_mid, *gu;
+  float* lse;
+};
+struct LlmWs {
+  LlmLayerStash ls[1];   // layer-0 slot; slot i starts slot_bytes * i later
+  size_t slot_bytes;
+  char* slots;
+  void *x_final, *hn, *n, *act, *vt, *logits;
+  float* ce_scratch;
+  int32_t *kvs, *kvl;
+  // backward
+  void *dx, *d_hn, *d_act, *d_gu, *d_n, *d_o, *d_qkv, *qT, *kT, *doT;
+  float* delta;
+  int M, Tp, QKV, OD;
+};
+void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
+  const size_t es = esz(c.dtype);
+  const size_t M = (size_t)B * T;
+  const int QKV = (c.llm_heads + 2 * c.llm_kv_heads) * c.llm_head_dim;
+  s.x_in = a.take(M * c.llm_d * es);
+  s.qkv = a.take(M * QKV * es);
+  s.o = a.take(M * c.llm_heads * c.llm_head_dim * es);
+  s.x_mid = a.take(M * c.llm_d * es);
+  s.gu = a.take(M * 2 * c.llm_inter * es);
+  s.lse = (float*)a.take(sizeof(float) * (size_t)B * c.llm_heads * T);
+}
+LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
+  LlmWs w;
+  const size_t es = esz(c.dtype);
+  w.M = B * T;
+  w.Tp = rup(T, 64);
+  w.QKV = (c.llm_heads + 2 * c.llm_kv_heads) * c.llm_head_dim;
+  w.OD = c.llm_heads * c.llm_head_dim;
+  const size_t M = (size_t)w.M;
+  // layer slots: `n_slots` identical records laid out back to back
+  const int n_slots = save ? c.llm_layers : 2;
+  const size_t start = (a.off + 255) & ~(size_t)255;
+  a.off = start;
+  llm_slot(a, c, B, T, w.ls[0]);
+  a.off = (a.off + 255) & ~(size_t)255;
+  w.slot_bytes = a.off - start;
+  w.slots = a.base ? a.base + start : nullptr;
+  a.off = start + w.slot_bytes * n_slots;
+  w.x_final = a.take(M * c.llm_d * es);
+  w.hn = a.take(M * c.llm_d * es);
+  w.n = a.take(M * c.llm_d * es);
+  w.act = a.take(M * c.llm_inter * es);
+  w.vt = a.take((size_t)B * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
+  w.logits = a.take(M * c.vocab * es);
+  w.ce_scratch = (float*)a.take(sizeof(float) * (2 + M));
+  w.kvs = (int32_t*)a.take(sizeof(int32_t) * B);
+  w.kvl = (int32_t*)a.take(sizeof(int32_t) * B);
+  if (save) {
+    w.dx = a.take(M * c.llm_d * es);
+    w.d_hn = a.take(M * c.llm_d * es);
+    w.d_act = a.take(M * c.llm_inter * es);
+    w.d_gu = a.take(M * 2 * c.llm_inter * es);
+    w.d_n = a.take(M * c.llm_d * es);
+    w.d_o = a.take(M * w.OD * es);
+    w.d_qkv = a.take(M * w.QKV * es);
+    w.qT = a.take((size_t)B * c.llm_heads * c.llm_head_dim * w.Tp * es);
+    w.kT = a.take((size_t)B * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
+    w.doT = a.take((size_t)B * c.llm_heads * c.llm_head_dim * w.Tp * es);
+    w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.llm_heads * T);
+  }
+  return w;
+}
+// stash record of layer l (slot l when saving, slot l&1 otherwise)
+LlmLayerStash llm_layer(const LlmWs& w, int slot) {
+  LlmLayerStash s = w.ls[0];
+  const size_t d = w.slot_bytes * slot;
+  s.x_in = (char*)s.x_in + d; s.qkv = (char*)s.qkv + d; s.o = (char*)s.o + d;
+  s.x_mid = (char*)s.x_mid + d; s.gu = (char*)s.gu + d; s.lse = (float*)((char*)s.lse + d);
+  return s;
+}
+
+int check_cfg(const uvx_config_t* c) {
+  UVX_CHECK(c != nullptr, UVX_ERR_INVALID, "null config");
+  UVX_CHECK(c->dtype == DT_BF16 || c->dtype == DT_F32, UVX_ERR_INVALID, "bad dtype %d", c->dtype);
+  return UVX_OK;
+}
+
+GemmDesc lin(const void* A, const void* W, void* C, int M, int N, int K) {
+  GemmDesc g;
+  g.A = A; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+  return g;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" int32_t uvx_logmel(void* stream, const float* pcm, const float* window, const float* tw_cos,
+                              const float* tw_sin, const float* mel_fb, float* out, float* scratch, int32_t B, int32_t L,
+                              int32_t n_mels, int32_t F_stride) {
+  return uvx::logmel((hipStream_t)stream, pcm, window, tw_cos, tw_sin, mel_fb, out, scratch, B, L, n_mels, F_stride);
+}
+
+extern "C" size_t uvx_encoder_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t F) {
+  if (!cfg) return 0;
+  Arena a(nullptr, 0);
+  enc_carve(a, *cfg, B, F);
+  return a.off + 256;
+}
+
+extern "C" int32_t uvx_encoder_fwd(void* stream, const uvx_config_t* cfg, const uvx_encoder_weights_t* w, const void* mel,
+                                   int32_t mel_is_f32, const int64_t* audio_lens, int32_t B, int32_t F, void* out,
+                                   void* workspace, size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(w && mel && out && workspace, UVX_ERR_INVALID, "encoder_fwd: null argument");
+  const uvx_config_t& c = *cfg;
+  hipStream_t st = (hipStream_t)stream;
+  // ultravox_model.py:874-878: the mel length may not exceed max_source_positions * conv strides
+  UVX_CHECK(F <= c.enc_max_pos * 2, UVX_ERR_SHAPE,
+            "Whisper expects the mel input features to be of length %d or less, but found %d", c.enc_max_pos * 2, F);
+  UVX_CHECK(c.enc_d % c.enc_heads == 0, UVX_ERR_SHAPE, "encoder: d=%d not divisible by heads=%d", c.enc_d, c.enc_heads);
+  UVX_CHECK(c.enc_block == 0 || (c.enc_max_pos * 2) % c.enc_block == 0, UVX_ERR_SHAPE,
+            "audio_latency_block_size %d must divide %d evenly.", c.enc_block, c.enc_max_pos * 2);
+  if (B == 0 || F == 0) return UVX_OK;
+  Arena a(workspace, ws_bytes);
+  EncWs s = enc_carve(a, c, B, F);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "encoder_fwd: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype, d = c.enc_d, Te = s.Te, M = s.M, dh = d / c.enc_heads;
+  const size_t es = esz(dt);
+
+  // conv1 + GELU (ultravox_model.py:893) as im2col + GEMM, written time-major into a buffer with one
+  // zero frame before and after each clip so that conv2 (k3, s2, p1) reads 3 consecutive frames as ONE
+  // contiguous K = 3d row: A row t = frames 2t-1..2t+1, row stride 2d.
+  RC(im2col_conv1(st, dt, mel, mel_is_f32, s.im2col, B, c.n_mels, F, F, s.Kp1));
+  RC(fill_zero(st, s.c1, (long long)B * (F + 2) * d * es));
+  {
+    GemmDesc g = lin(s.im2col, w->conv1_w, at(s.c1, d, dt), F, d, s.Kp1);
+    g.bias = w->conv1_b; g.act = 1; g.batch = B;
+    g.sA = (long long)F * s.Kp1; g.sC = (long long)(F + 2) * d;
+    RC(gemm(st, dt, g));
+  }
+  {  // conv2 + GELU (:894), permute (:896), + embed_positions[:Te] (:897-899)
+    GemmDesc g = lin(s.c1, w->conv2_w, s.x, Te, d, 3 * d);
+    g.lda = 2 * d; g.bias = w->conv2_b; g.act = 1; g.batch = B;
+    g.sA = (long long)(F + 2) * d; g.sC = (long long)Te * d;
+    g.residual = w->pos; g.ldr = d; g.sR = 0;
+    RC(gemm(st, dt, g));
+  }
+  // key padding mask from audio_len (:915-926)
+  const int32_t* kvlen = nullptr;
+  if (audio_lens) {
+    hipLaunchKernelGGL(enc_kvlen_k, dim3(cdiv(B, 64)), dim3(64), 0, st, audio_lens, s.kvlen, B, Te);
+    UVX_LAUNCH_CHECK();
+    kvlen = s.kvlen;
+  }
+  for (int l = 0; l < c.enc_layers; ++l) {
+    const uvx_enc_layer_t& L = w->layers[l];
+    RC(layernorm_fwd(st, dt, s.x, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));
+    {
+      GemmDesc g = lin(s.n, L.wqkv, s.qkv, M, 3 * d, d);
+      g.bias = L.bqkv;
+      RC(gemm(st, dt, g));
+    }
+    RC(heads_transpose(st, dt, at(s.qkv, 2 * d, dt), s.vt, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
+    AttnDesc ad;
+    ad.q = s.qkv; ad.k = at(s.qkv, d, dt); ad.v = at(s.qkv, 2 * d, dt); ad.vt = s.vt; ad.o = s.o; ad.lse = nullptr;
+    ad.kv_len = kvlen; ad.B = B; ad.T = Te; ad.Tp = s.Tp; ad.Hq = c.enc_heads; ad.Hkv = c.enc_heads; ad.D = dh;
+    ad.ldq = ad.ldk = ad.ldv = 3 * d; ad.ldo = d; ad.causal = 0; ad.block = c.enc_block;
+    ad.scale = 1.0f;  // q_proj is pre-scaled by head_dim^-0.5 at pack time (exact in bf16 for dh = 64)
+    RC(attention_fwd(st, dt, ad));
+    {
+      GemmDesc g = lin(s.o, L.wo, s.x, M, d, d);
+      g.bias = L.bo; g.residual = s.x; g.ldr = d;
+      RC(gemm(st, dt, g));
+    }
+    RC(layernorm_fwd(st, dt, s.x, L.ln2_w, L.ln2_b, s.n, M, d, c.ln_eps));
+    {
+      GemmDesc g = lin(s.n, L.fc1_w, s.f, M, c.enc_ffn, d);
+      g.bias = L.fc1_b; g.act = 1;
+      RC(gemm(st, dt, g));
+    }
+    {
+      GemmDesc g = lin(s.f, L.fc2_w, s.x, M, d, c.enc_ffn);
+      g.bias = L.fc2_b; g.residual = s.x; g.ldr = d;
+      RC(gemm(st, dt, g));
+    }
+  }
+  RC(layernorm_fwd(st, dt, s.x, w->lnf_w, w->lnf_b, out, M, d, c.ln_eps));  // :980
+  return UVX_OK;
+}
+
+// =====================================================================================
+extern "C" size_t uvx_projector_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t Te) {
+  if (!cfg) return 0;
+  Arena a(nullptr, 0);
+  proj_carve(a, *cfg, B, Te);
+  return a.off + 256;
+}
+
+extern "C" int32_t uvx_projector_fwd(void* stream, const uvx_config_t* cfg, const uvx_projector_weights_t* w,
+                                     const void* enc_out, int32_t B, int32_t Te, void* out, void* workspace,
+                                     size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(w && enc_out && out && workspace, UVX_ERR_INVALID, "projector_fwd: null argument");
+  const uvx_config_t& c = *cfg;
+  UVX_CHECK(c.proj_hidden % 16 == 0, UVX_ERR_SHAPE, "projector hidden %d must be a multiple of 16", c.proj_hidden);
+  UVX_CHECK(c.proj_ln_mid ? (w->ln_mid != nullptr) : (w->ln_post != nullptr), UVX_ERR_INVALID,
+            "projector: ln_%s weight missing", c.proj_ln_mid ? "mid" : "post");
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || Te == 0) return UVX_OK;
+  Arena a(workspace, ws_bytes);
+  ProjWs s = proj_carve(a, c, B, Te);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "projector_fwd: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype;
+  // _pad_and_stack + ln_pre (:790-791)
+  RC(stack_rmsnorm_fwd(st, dt, enc_out, w->ln_pre, s.xn, s.stacked, B, Te, c.enc_d, c.stack_factor, c.proj_eps));
+  RC(gemm(st, dt, lin(s.xn, w->w1, s.h1, s.R, s.H, s.C8)));                 // linear_1 (:793)
+  RC(swiglu_fwd(st, dt, s.h1, s.a, s.R, s.Hh, /*gate_first=*/0));           // SwiGLU (:739-742, :795)
+  if (c.proj_ln_mid) {
+    RC(rmsnorm_fwd(st, dt, s.a, w->ln_mid, s.an, nullptr, s.R, s.Hh, c.proj_eps));  // ln_mid (:796)
+    RC(gemm(st, dt, lin(s.an, w->w2, out, s.R, s.D, s.Hh)));                        // linear_2 (:798)
+  } else {
+    RC(gemm(st, dt, lin(s.a, w->w2, s.ypre, s.R, s.D, s.Hh)));
+    RC(rmsnorm_fwd(st, dt, s.ypre, w->ln_post, out, nullptr, s.R, s.D, c.proj_eps));  // ln_post (:799)
+  }
+  return UVX_OK;
+}
+
+extern "C" int32_t uvx_projector_bwd(void* stream, const uvx_config_t* cfg, const uvx_projector_weights_t* w,
+                                     const void* dout, int32_t B, int32_t Te, const uvx_projector_grads_t* gr,
+                                     void* workspace, size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(w && dout && gr && workspace, UVX_ERR_INVALID, "projector_bwd: null argument");
+  const uvx_config_t& c = *cfg;
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || Te == 0) return UVX_OK;
+  Arena a(workspace, ws_bytes);
+  ProjWs s = proj_carve(a, c, B, Te);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "projector_bwd: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype;
+  const void* dy = dout;
+  RC(fill_zero(st, gr->ln_pre, sizeof(float) * s.C8));
+  if (c.proj_ln_mid) RC(fill_zero(st, gr->ln_mid, sizeof(float) * s.Hh));
+  else {
+    RC(fill_zero(st, gr->ln_post, sizeof(float) * s.D));
+    RC(rmsnorm_bwd(st, dt, dout, s.ypre, w->ln_post, nullptr, s.dy2, gr->ln_post, s.R, s.D, c.proj_eps));
+    dy = s.dy2;
+  }
+  // linear_2: dW2[D, Hh] = dy^T . an ; d_an = dy . W2
+  RC(transpose2d(st, dt, dy, s.dyT, s.R, s.D, s.D, s.Rp, 1, 0, 0));
+  RC(transpose2d(st, dt, s.an, s.anT, s.R, s.Hh, s.Hh, s.Rp, 1, 0, 0));
+  {
+    GemmDesc g = lin(s.dyT, s.anT, gr->w2, s.D, s.Hh, s.Rp);
+    g.out_f32 = 1;
+    RC(gemm(st, dt, g));
+  }
+  RC(transpose2d(st, dt, w->w2, s.w2T, s.D, s.Hh, s.Hh, s.D, 1, 0, 0));
+  RC(gemm(st, dt, lin(dy, s.w2T, s.d_an, s.R, s.Hh, s.D)));
+  if (c.proj_ln_mid)
+    RC(rmsnorm_bwd(st, dt, s.d_an, s.a, w->ln_mid, nullptr, s.d_a, gr->ln_mid, s.R, s.Hh, c.proj_eps));
+  RC(swiglu_bwd(st, dt, s.d_a, s.h1, s.d_h1, s.R, s.Hh, 0));
+  // linear_1: dW1[H, C8] = d_h1^T . xn ; d_xn = d_h1 . W1 (only needed for the ln_pre weight gradient)
+  RC(transpose2d(st, dt, s.d_h1, s.dh1T, s.R, s.H, s.H, s.Rp, 1, 0, 0));
+  RC(transpose2d(st, dt, s.xn, s.xnT, s.R, s.C8, s.C8, s.Rp, 1, 0, 0));
+  {
+    GemmDesc g = lin(s.dh1T, s.xnT, gr->w1, s.H, s.C8, s.Rp);
+    g.out_f32 = 1;
+    RC(gemm(st, dt, g));
+  }
+  RC(transpose2d(st, dt, w->w1, s.w1T, s.H, s.C8, s.C8, s.H, 1, 0, 0));
+  RC(gemm(st, dt, lin(s.d_h1, s.w1T, s.d_xn, s.R, s.C8, s.H)));
+  RC(rmsnorm_bwd(st, dt, s.d_xn, s.stacked, w->ln_pre, nullptr, nullptr, gr->ln_pre, s.R, s.C8, c.proj_eps));
+  return UVX_OK;
+}
+
+// =====================================================================================
+extern "C" int32_t uvx_embed_merge(void* stream, const uvx_config_t* cfg, const void* embed_table, const int64_t* input_ids,
+                                   const void* audio_embeds, const int64_t* audio_batch_size,
+                                   const int64_t* audio_token_start_idx, const int32_t* audio_token_len, int32_t B,
+                                   int32_t T, int32_t n_items, int32_t Na, void* inputs_embeds, int32_t* scratch) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(inputs_embeds && scratch, UVX_ERR_INVALID, "embed_merge: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const uvx_config_t& c = *cfg;
+  if (input_ids) RC(embed_gather(st, c.dtype, embed_table, input_ids, inputs_embeds, B * T, c.llm_d, c.vocab));
+  int32_t* owner = scratch;
+  int32_t* item_batch = scratch + (size_t)B * T;
+  if (n_items > 0) {
+    UVX_CHECK(audio_embeds && audio_batch_size && audio_token_start_idx && audio_token_len, UVX_ERR_INVALID,
+              "inputs_embeds/audio_values/audio_token_start_idx/audio_token_len/audio_lens/audio_batch_size must be provided.");
+  }
+  RC(merge_owner(st, owner, item_batch, audio_batch_size, audio_token_start_idx, audio_token_len, B, n_items, T, Na));
+  RC(merge_audio(st, c.dtype, inputs_embeds, audio_embeds, nullptr, owner, item_batch, audio_token_start_idx,
+                 audio_token_len, n_items, T, c.llm_d, Na, 0));
+  return UVX_OK;
+}
+
+extern "C" int32_t uvx_merge_embeds_bwd(void* stream, const uvx_config_t* cfg, const void* d_inputs_embeds,
+                                        const int64_t* audio_token_start_idx, const int32_t* audio_token_len, int32_t B,
+                                        int32_t T, int32_t n_items, int32_t Na, void* d_audio_embeds,
+                                        const int32_t* scratch) {
+  RC(check_cfg(cfg));
+  hipStream_t st = (hipStream_t)stream;
+  const int32_t* owner = scratch;
+  const int32_t* item_batch = scratch + (size_t)B * T;
+  return merge_audio(st, cfg->dtype, const_cast<void*>(d_inputs_embeds), nullptr, d_audio_embeds, owner, item_batch,
+                     audio_token_start_idx, audio_token_len, n_items, T, cfg->llm_d, Na, 1);
+}
+
+// =====================================================================================
+extern "C" size_t uvx_llm_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t T, int32_t save_for_bwd) {
+  if (!cfg) return 0;
+  Arena a(nullptr, 0);
+  llm_carve(a, *cfg, B, T, save_for_bwd);
+  return a.off + 256;
+}
+
+static int llm_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int T) {
+  UVX_CHECK(c.llm_heads % c.llm_kv_heads == 0, UVX_ERR_SHAPE, "llm: heads %d not a multiple of kv heads %d", c.llm_heads, c.llm_kv_heads);
+  UVX_CHECK(w->rope_len >= T, UVX_ERR_SHAPE, "llm: rope table (%d) shorter than sequence (%d)", w->rope_len, T);
+  return UVX_OK;
+}
+
+extern "C" int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                               const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T, void* logits,
+                               float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(w && inputs_embeds && workspace, UVX_ERR_INVALID, "llm_fwd: null argument");
+  UVX_CHECK(!labels || loss, UVX_ERR_INVALID, "llm_fwd: labels given but no loss output");
+  const uvx_config_t& c = *cfg;
+  RC(llm_check(c, w, T));
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || T == 0) return UVX_OK;
+  Arena a(workspace, ws_bytes);
+  LlmWs s = llm_carve(a, c, B, T, save_for_bwd);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_fwd: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype, D = c.llm_d, M = s.M, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads;
+  const size_t es = esz(dt);
+
+  // valid-key range per sequence (kept in the workspace for the backward pass)
+  if (attention_mask) hipLaunchKernelGGL(mask_range_k, dim3(B), dim3(256), 0, st, attention_mask, s.kvs, s.kvl, T);
+  else hipLaunchKernelGGL(full_range_k, dim3(cdiv(B, 64)), dim3(64), 0, st, s.kvs, s.kvl, B, T);
+  UVX_LAUNCH_CHECK();
+  const int32_t *kvs = s.kvs, *kvl = s.kvl;
+  LlmLayerStash cur = llm_layer(s, 0);
+  UVX_HIP(hipMemcpyAsync(cur.x_in, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+  for (int l = 0; l < c.llm_layers; ++l) {
+    const uvx_llm_layer_t& L = w->layers[l];
+    const bool last = l + 1 == c.llm_layers;
+    void* x_out = last ? s.x_final : llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1)).x_in;
+    RC(rmsnorm_fwd(st, dt, cur.x_in, L.ln1, s.n, nullptr, M, D, c.rms_eps));
+    RC(gemm(st, dt, lin(s.n, L.wqkv, cur.qkv, M, s.QKV, D)));
+    RC(rope_inplace(st, dt, cur.qkv, w->rope_cos_sin, nullptr, M, T, Hq + Hkv, dh, s.QKV, 0));
+    RC(heads_transpose(st, dt, at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt), s.vt, B, T, s.Tp, Hkv, dh, s.QKV));
+    AttnDesc ad;
+    ad.q = cur.qkv; ad.k = at(cur.qkv, (size_t)Hq * dh, dt); ad.v = at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt);
+    ad.vt = s.vt; ad.o = cur.o; ad.lse = cur.lse; ad.kv_start = kvs; ad.kv_len = kvl;
+    ad.B = B; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
+    ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
+    ad.scale = 1.0f / sqrtf((float)dh);
+    RC(attention_fwd(st, dt, ad));
+    {
+      GemmDesc g = lin(cur.o, L.wo, cur.x_mid, M, D, s.OD);
+      g.residual = cur.x_in; g.ldr = D;
+      RC(gemm(st, dt, g));
+    }
+    RC(rmsnorm_fwd(st, dt, cur.x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps));
+    RC(gemm(st, dt, lin(s.n, L.wgu, cur.gu, M, 2 * c.llm_inter, D)));
+    RC(swiglu_fwd(st, dt, cur.gu, s.act, M, c.llm_inter, /*gate_first=*/1));
+    {
+      GemmDesc g = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
+      g.residual = cur.x_mid; g.ldr = D;
+      RC(gemm(st, dt, g));
+    }
+    if (!last) cur = llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1));
+  }
+  RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps));
+  RC(gemm(st, dt, lin(s.hn, w->lm_head, s.logits, M, c.vocab, D)));
+  if (logits) UVX_HIP(hipMemcpyAsync(logits, s.logits, (size_t)M * c.vocab * es, hipMemcpyDeviceToDevice, st));
+  if (labels) RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, loss, s.ce_scratch, nullptr, B, T, c.vocab, c.vocab, 1.0f));
+  return UVX_OK;
+}
+
+extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
+                               int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace,
+                               size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(w && labels && d_inputs_embeds && workspace, UVX_ERR_INVALID, "llm_bwd: null argument");
+  const uvx_config_t& c = *cfg;
+  RC(llm_check(c, w, T));
+  UVX_CHECK(w->lm_head_t != nullptr, UVX_ERR_INVALID, "llm_bwd: transposed weights (lm_head_t, *_t) are required");
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || T == 0) return UVX_OK;
+  Arena a(workspace, ws_bytes);
+  LlmWs s = llm_carve(a, c, B, T, 1);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_bwd: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype, D = c.llm_d, M = s.M, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads;
+
+  // d logits (in place over the saved logits), then the frozen head: d_hn = dlogits . W_head
+  RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale));
+  RC(gemm(st, dt, lin(s.logits, w->lm_head_t, s.d_hn, M, D, c.vocab)));
+  RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps));
+  for (int l = c.llm_layers - 1; l >= 0; --l) {
+    const uvx_llm_layer_t& L = w->layers[l];
+    UVX_CHECK(L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t, UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
+    LlmLayerStash cur = llm_layer(s, l);
+    // MLP
+    RC(gemm(st, dt, lin(s.dx, L.wd_t, s.d_act, M, c.llm_inter, D)));
+    RC(swiglu_bwd(st, dt, s.d_act, cur.gu, s.d_gu, M, c.llm_inter, 1));
+    RC(gemm(st, dt, lin(s.d_gu, L.wgu_t, s.d_n, M, D, 2 * c.llm_inter)));
+    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_mid, L.ln2, s.dx, s.dx, nullptr, M, D, c.rms_eps));
+    // attention
+    RC(gemm(st, dt, lin(s.dx, L.wo_t, s.d_o, M, s.OD, D)));
+    RC(heads_transpose(st, dt, cur.qkv, s.qT, B, T, s.Tp, Hq, dh, s.QKV));
+    RC(heads_transpose(st, dt, at(cur.qkv, (size_t)Hq * dh, dt), s.kT, B, T, s.Tp, Hkv, dh, s.QKV));
+    RC(heads_transpose(st, dt, s.d_o, s.doT, B, T, s.Tp, Hq, dh, s.OD));
+    AttnBwdDesc bd;
+    AttnDesc& ad = bd.f;
+    ad.q = cur.qkv; ad.k = at(cur.qkv, (size_t)Hq * dh, dt); ad.v = at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt);
+    ad.o = cur.o; ad.lse = cur.lse;
+    ad.kv_start = s.kvs; ad.kv_len = s.kvl;  // written by the forward pass
+    ad.B = B; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
+    ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
+    ad.scale = 1.0f / sqrtf((float)dh);
+    bd.dout = s.d_o; bd.qt = s.qT; bd.kt = s.kT; bd.dot = s.doT; bd.delta = s.delta;
+    bd.dq = s.d_qkv; bd.dk = at(s.d_qkv, (size_t)Hq * dh, dt); bd.dv = at(s.d_qkv, (size_t)(Hq + Hkv) * dh, dt);
+    bd.lddq = bd.lddk = bd.lddv = s.QKV;
+    RC(attention_bwd(st, dt, bd));
+    RC(rope_inplace(st, dt, s.d_qkv, w->rope_cos_sin, nullptr, M, T, Hq + Hkv, dh, s.QKV, 1));
+    RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, D, s.QKV)));
+    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_in, L.ln1, s.dx, l == 0 ? d_inputs_embeds : s.dx, nullptr, M, D, c.rms_eps));
+  }
+  return UVX_OK;
+}
+
+extern "C" int32_t uvx_adamw_clip_step(void* stream, int32_t state_dtype, void* param, float* master, const float* grad,
+                                       void* m, void* v, int64_t n, float max_norm, float lr, float beta1, float beta2,
+                                       float eps, float weight_decay, int32_t step, float* scratch) {
+  hipStream_t st = (hipStream_t)stream;
+  UVX_CHECK(param && grad && m && v && scratch, UVX_ERR_INVALID, "adamw: null argument");
+  RC(uvx::grad_sq_norm(st, grad, n, scratch + 1, scratch));
+  return uvx::adamw_clip_step(st, state_dtype, param, master, grad, m, v, n, scratch, max_norm, lr, beta1, beta2, eps,
+                              weight_decay, step);
+}

@@ -1,0 +1,372 @@
+"""Host-side mirror of ultravox/model/ultravox_model.py — UltravoxModel.forward (:277-352),
+_prepare_audio_embeds (:354-396), _audio_iter (:259-275), UltravoxProjector (:745-800),
+ModifiedWhisperEncoder (:803-994) — over the libuvx C ABI.  Tensors in, tensors out; every FLOP of
+the path runs in hand-written HIP (gfx950).  There is NO PyTorch / CPU fallback: without libuvx.so or
+without a GPU the constructors raise.
+
+Training scope = the reference's default recipe: audio tower and LLM frozen (apply_lora with r = 0,
+ultravox_model.py:697-703), projector trained; `UltravoxTrainer` reproduces one HF-Trainer optimizer
+step (loss -> backward -> DP mean of projector grads -> clip 1.0 -> AdamW), SURVEY.md Appendix B.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .config import LossConfig, LossFunction, UltravoxConfig
+from .weights import pack_encoder, pack_llm, random_state_dict
+
+
+@dataclasses.dataclass
+class CausalLMOutputWithPast:
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[object] = None
+
+
+_PROJ_ORDER = ("ln_pre", "linear_1", "ln_norm", "linear_2")  # flat-bucket order; ln_norm = ln_mid | ln_post
+
+
+def _torch_dtype(cfg: UltravoxConfig, dtype=None) -> torch.dtype:
+    if dtype is not None:
+        return dtype
+    d = cfg.torch_dtype
+    return getattr(torch, d) if isinstance(d, str) else d
+
+
+class UltravoxModel:
+    """Same call surface as the reference's UltravoxModel for the hot path (forward / train step)."""
+
+    config_class = UltravoxConfig
+    accepts_loss_kwargs = False  # ultravox_model.py:50-53: loss = mean over this rank's tokens
+
+    def __init__(self, config: UltravoxConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 device: str = "cuda", dtype: Optional[torch.dtype] = None, seed: int = 0,
+                 with_backward: bool = True, rope_len: Optional[int] = None):
+        _lib.lib()  # fail loudly if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise _lib.UvxError("UltravoxModel needs a GPU (MI355X / gfx950); there is no CPU path")
+        if config.llm_only_training:
+            raise ValueError("llm_only_training is outside the built scope")
+        self.config = config
+        self.device = torch.device(device)
+        self.dtype = _torch_dtype(config, dtype)
+        self.code = _lib.dtype_code(self.dtype)
+        self.training = False
+        self.loss_config = LossConfig()
+        self.vocab_size = config.vocab_size
+        a, t = config.audio_config, config.text_config
+        self.audio_tower_context_length = a.max_source_positions * 2  # ultravox_model.py:826-832
+        if config.audio_latency_block_size is not None:
+            assert self.audio_tower_context_length % config.audio_latency_block_size == 0, (
+                f"audio_latency_block_size {config.audio_latency_block_size} must divide "
+                f"{self.audio_tower_context_length} evenly.")  # ultravox_model.py:846-848
+        if state_dict is None:
+            gen_dev = "cuda" if t.num_hidden_layers * t.hidden_size > 64 * 1024 else "cpu"
+            state_dict = random_state_dict(config, seed=seed, dtype=self.dtype, device=gen_dev)
+        self.with_backward = with_backward
+        self._load(state_dict, rope_len)
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._proj_ctx = None
+        self._llm_ctx = None
+
+    # ------------------------------------------------------------------ weights
+    def _load(self, sd, rope_len):
+        cfg, dev, dt = self.config, self.device, self.dtype
+        a, t = cfg.audio_config, cfg.text_config
+        self._enc = pack_encoder(sd, cfg, dt, dev)
+        self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=self.with_backward, rope_len=rope_len)
+        # projector: one flat trainable bucket with views (ln_pre | linear_1 | ln_mid/ln_post | linear_2)
+        P = "multi_modal_projector."
+        norm_key = "ln_mid" if cfg.projector_ln_mid else "ln_post"
+        parts = [sd[P + "ln_pre.weight"], sd[P + "linear_1.weight"], sd[P + norm_key + ".weight"],
+                 sd[P + "linear_2.weight"]]
+        sizes = [p.numel() for p in parts]
+        pad = [(-s) % 64 for s in sizes]  # keep every view 128-byte aligned
+        total = sum(s + p for s, p in zip(sizes, pad))
+        self.proj_flat = torch.zeros(total, device=dev, dtype=dt)
+        self.proj_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._proj_views, self._grad_views, off = {}, {}, 0
+        for name, p, s, pd in zip(_PROJ_ORDER, parts, sizes, pad):
+            self.proj_flat[off:off + s].copy_(p.reshape(-1).to(device=dev, dtype=dt))
+            self._proj_views[name] = self.proj_flat[off:off + s].view(p.shape)
+            self._grad_views[name] = self.proj_grad[off:off + s].view(p.shape)
+            off += s + pd
+        self._norm_key = norm_key
+
+        c = _lib.Config()
+        c.dtype = self.code
+        c.enc_layers, c.enc_d, c.enc_heads, c.enc_ffn = a.encoder_layers, a.d_model, a.encoder_attention_heads, a.encoder_ffn_dim
+        c.n_mels, c.enc_max_pos = a.num_mel_bins, a.max_source_positions
+        c.enc_block = cfg.audio_latency_block_size or 0
+        c.ln_eps = a.layer_norm_eps
+        c.stack_factor, c.proj_hidden, c.proj_ln_mid, c.proj_eps = cfg.stack_factor, cfg.hidden_size, int(cfg.projector_ln_mid), 1e-6
+        c.llm_layers, c.llm_d, c.llm_heads, c.llm_kv_heads = t.num_hidden_layers, t.hidden_size, t.num_attention_heads, t.num_key_value_heads
+        c.llm_head_dim, c.llm_inter, c.vocab, c.rms_eps = t.head_dim, t.intermediate_size, t.vocab_size, t.rms_norm_eps
+        self._c = c
+
+        e = self._enc
+        self._enc_layers = (_lib.EncLayer * a.encoder_layers)()
+        for i, L in enumerate(e["layers"]):
+            for n in _lib._ENC_LAYER_FIELDS:
+                setattr(self._enc_layers[i], n, L[n].data_ptr())
+        ew = _lib.EncoderWeights()
+        for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "pos", "lnf_w", "lnf_b"):
+            setattr(ew, n, e[n].data_ptr())
+        ew.layers = self._enc_layers
+        self._ew = ew
+
+        pw = _lib.ProjectorWeights()
+        pw.ln_pre = self._proj_views["ln_pre"].data_ptr()
+        pw.w1 = self._proj_views["linear_1"].data_ptr()
+        pw.w2 = self._proj_views["linear_2"].data_ptr()
+        pg = _lib.ProjectorGrads()
+        pg.ln_pre = self._grad_views["ln_pre"].data_ptr()
+        pg.w1 = self._grad_views["linear_1"].data_ptr()
+        pg.w2 = self._grad_views["linear_2"].data_ptr()
+        setattr(pw, norm_key, self._proj_views["ln_norm"].data_ptr())
+        setattr(pg, norm_key, self._grad_views["ln_norm"].data_ptr())
+        self._pw, self._pg = pw, pg
+
+        m = self._llm
+        self._llm_layers = (_lib.LlmLayer * t.num_hidden_layers)()
+        for i, L in enumerate(m["layers"]):
+            for n in _lib._LLM_LAYER_FIELDS:
+                setattr(self._llm_layers[i], n, 0 if L[n] is None else L[n].data_ptr())
+        lw = _lib.LlmWeights()
+        lw.embed, lw.norm, lw.lm_head = m["embed"].data_ptr(), m["norm"].data_ptr(), m["lm_head"].data_ptr()
+        lw.lm_head_t = 0 if m["lm_head_t"] is None else m["lm_head_t"].data_ptr()
+        lw.layers = self._llm_layers
+        lw.rope_cos_sin, lw.rope_len = m["rope"].data_ptr(), m["rope_len"]
+        self._lw = lw
+
+    def projector_state_dict(self) -> Dict[str, torch.Tensor]:
+        """Trainable keys under the reference's checkpoint names (ultravox_model.py:565-594 saves these)."""
+        P = "multi_modal_projector."
+        return {P + "ln_pre.weight": self._proj_views["ln_pre"], P + "linear_1.weight": self._proj_views["linear_1"],
+                P + self._norm_key + ".weight": self._proj_views["ln_norm"],
+                P + "linear_2.weight": self._proj_views["linear_2"]}
+
+    def projector_grads(self) -> Dict[str, torch.Tensor]:
+        P = "multi_modal_projector."
+        return {P + "ln_pre.weight": self._grad_views["ln_pre"], P + "linear_1.weight": self._grad_views["linear_1"],
+                P + self._norm_key + ".weight": self._grad_views["ln_norm"],
+                P + "linear_2.weight": self._grad_views["linear_2"]}
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def set_loss_config(self, loss_config: LossConfig):
+        self.loss_config = loss_config
+
+    def get_input_embeddings(self):
+        return self._llm["embed"]
+
+    # ------------------------------------------------------------------ workspaces
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        w = self._ws.get(key)
+        if w is None or w.numel() < nbytes:
+            self._ws[key] = w = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+        return w
+
+    # ------------------------------------------------------------------ device stages
+    def audio_tower_forward(self, audio_values: torch.Tensor, audio_len: Optional[torch.Tensor]) -> torch.Tensor:
+        """ModifiedWhisperEncoder.forward(input_features, audio_len) -> last_hidden_state [A, Te, d]."""
+        l = _lib.lib()
+        A, n_mels, F = audio_values.shape
+        if F > self.audio_tower_context_length:
+            raise ValueError(
+                f"Whisper expects the mel input features to be of length {self.audio_tower_context_length} or less, "
+                f"but found {F}. Make sure to pad the input mel features to {self.audio_tower_context_length}.")
+        is_f32 = audio_values.dtype == torch.float32
+        if not is_f32 and audio_values.dtype != self.dtype:
+            audio_values = audio_values.to(self.dtype)
+        audio_values = audio_values.contiguous()
+        Te = (F - 1) // 2 + 1
+        out = torch.empty((A, Te, self.config.audio_config.d_model), device=self.device, dtype=self.dtype)
+        nb = l.uvx_encoder_ws_bytes(C.byref(self._c), A, F)
+        ws = self._workspace("enc", nb)
+        lens = None if audio_len is None else audio_len.to(device=self.device, dtype=torch.int64).contiguous()
+        check(l.uvx_encoder_fwd(stream_ptr(), C.byref(self._c), C.byref(self._ew), ptr(audio_values), int(is_f32),
+                                ptr(lens), A, F, ptr(out), ptr(ws), C.c_size_t(nb)), "uvx_encoder_fwd")
+        return out
+
+    def multi_modal_projector_forward(self, audio_features: torch.Tensor) -> torch.Tensor:
+        """UltravoxProjector.forward: [A, Te, C] -> [A, ceil(Te/S), D]."""
+        l = _lib.lib()
+        A, Te, Cc = audio_features.shape
+        Na = (Te + self.config.stack_factor - 1) // self.config.stack_factor
+        out = torch.empty((A, Na, self.config.text_config.hidden_size), device=self.device, dtype=self.dtype)
+        nb = l.uvx_projector_ws_bytes(C.byref(self._c), A, Te)
+        ws = self._workspace("proj", nb)
+        check(l.uvx_projector_fwd(stream_ptr(), C.byref(self._c), C.byref(self._pw), ptr(audio_features.contiguous()),
+                                  A, Te, ptr(out), ptr(ws), C.c_size_t(nb)), "uvx_projector_fwd")
+        self._proj_ctx = (A, Te, nb)
+        return out
+
+    def _projector_backward(self, d_audio_embeds: torch.Tensor) -> None:
+        l = _lib.lib()
+        A, Te, nb = self._proj_ctx
+        check(l.uvx_projector_bwd(stream_ptr(), C.byref(self._c), C.byref(self._pw), ptr(d_audio_embeds), A, Te,
+                                  C.byref(self._pg), ptr(self._ws["proj"]), C.c_size_t(nb)), "uvx_projector_bwd")
+
+    def _prepare_audio_embeds(self, inputs_embeds, input_ids, audio_values, audio_token_start_idx, audio_lens,
+                              audio_token_len, audio_batch_size):
+        # same argument checks (and messages) as ultravox_model.py:363-379
+        assert (audio_values is not None and audio_token_start_idx is not None and audio_token_len is not None
+                and audio_lens is not None and audio_batch_size is not None), \
+            "inputs_embeds/audio_values/audio_token_start_idx/audio_token_len/audio_lens/audio_batch_size must be provided."
+        assert len(audio_token_start_idx) == len(audio_token_len) == len(audio_lens) == len(audio_values), \
+            "audio_token_start_idx/audio_token_len/audio_lens/audio_values must have the same batch size."
+        B, T = (inputs_embeds.shape[:2] if inputs_embeds is not None else input_ids.shape)
+        assert len(audio_batch_size) == B, "audio_batch_size and inputs_embeds must have the same batch size."
+        tower = self.audio_tower_forward(audio_values, audio_lens)
+        audio_embeds = self.multi_modal_projector_forward(tower)
+        return self._embed_merge(inputs_embeds, input_ids, audio_embeds, audio_token_start_idx, audio_token_len,
+                                 audio_batch_size, B, T)
+
+    def _embed_merge(self, inputs_embeds, input_ids, audio_embeds, start, tok_len, batch_size, B, T):
+        l = _lib.lib()
+        dev = self.device
+        D = self.config.text_config.hidden_size
+        if inputs_embeds is None:
+            inputs_embeds = torch.empty((B, T, D), device=dev, dtype=self.dtype)
+            ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        else:
+            ids = None  # caller-provided embeddings are overwritten in place like the reference (:394)
+            assert inputs_embeds.is_contiguous() and inputs_embeds.dtype == self.dtype
+        n_items = 0 if audio_embeds is None else audio_embeds.shape[0]
+        Na = 0 if audio_embeds is None else audio_embeds.shape[1]
+        scratch = torch.empty(B * T + max(n_items, 1), device=dev, dtype=torch.int32)
+        st = None if start is None else start.to(device=dev, dtype=torch.int64).contiguous()
+        tl = None if tok_len is None else tok_len.to(device=dev, dtype=torch.int32).contiguous()
+        bs = None if batch_size is None else batch_size.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+        check(l.uvx_embed_merge(stream_ptr(), C.byref(self._c), ptr(self._llm["embed"]), ptr(ids), ptr(audio_embeds),
+                                ptr(bs), ptr(st), ptr(tl), B, T, n_items, Na, ptr(inputs_embeds), ptr(scratch)),
+              "uvx_embed_merge")
+        self._merge_ctx = (st, tl, B, T, n_items, Na, scratch)
+        return inputs_embeds
+
+    def language_model_forward(self, inputs_embeds, labels=None, attention_mask=None, want_logits=True,
+                               save_for_bwd=False) -> CausalLMOutputWithPast:
+        l = _lib.lib()
+        B, T, D = inputs_embeds.shape
+        dev = self.device
+        V = self.config.vocab_size
+        nb = l.uvx_llm_ws_bytes(C.byref(self._c), B, T, int(save_for_bwd))
+        ws = self._workspace("llm", nb)
+        logits = torch.empty((B, T, V), device=dev, dtype=self.dtype) if want_logits else None
+        loss = torch.zeros(1, device=dev, dtype=torch.float32) if labels is not None else None
+        lab = None if labels is None else labels.to(device=dev, dtype=torch.int64).contiguous()
+        am = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        check(l.uvx_llm_fwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(am),
+                            ptr(lab), B, T, ptr(logits), ptr(loss), int(save_for_bwd), ptr(ws), C.c_size_t(nb)),
+              "uvx_llm_fwd")
+        self._llm_ctx = (B, T, nb, lab)
+        return CausalLMOutputWithPast(loss=None if loss is None else loss[0], logits=logits)
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, input_ids: Optional[torch.Tensor] = None, audio_values: Optional[torch.Tensor] = None,
+                inputs_embeds: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                attention_mask: Optional[torch.Tensor] = None, audio_token_start_idx: Optional[torch.Tensor] = None,
+                audio_lens: Optional[torch.Tensor] = None, audio_token_len: Optional[torch.Tensor] = None,
+                audio_batch_size: Optional[torch.Tensor] = None, past_key_values=None, alt_input_ids=None,
+                alt_attention_mask=None, alt_labels=None, return_logits: bool = True, _save_for_bwd: bool = False,
+                **kwargs) -> CausalLMOutputWithPast:
+        if past_key_values is not None:
+            raise NotImplementedError("KV-cache decoding is a 'next' row (SURVEY.md §8f-1), not built yet")
+        if self.training and self.loss_config.loss_function != LossFunction.CrossEntropy:
+            if self.loss_config.loss_function == LossFunction.KL_Divergence:
+                raise NotImplementedError("KL distillation loss is a 'next' row (SURVEY.md §8f-2), not built yet")
+            raise ValueError(f"Unsupported loss function: {self.loss_config.loss_function}")
+        if audio_values is not None and len(audio_values) > 0:
+            inputs_embeds = self._prepare_audio_embeds(inputs_embeds, input_ids, audio_values, audio_token_start_idx,
+                                                       audio_lens, audio_token_len, audio_batch_size)
+        elif inputs_embeds is None:
+            B, T = input_ids.shape
+            inputs_embeds = self._embed_merge(None, input_ids, None, None, None, None, B, T)
+        return self.language_model_forward(inputs_embeds, labels=labels, attention_mask=attention_mask,
+                                           want_logits=return_logits, save_for_bwd=_save_for_bwd)
+
+    __call__ = forward
+
+    def forward_backward(self, grad_scale: float = 1.0, **batch) -> torch.Tensor:
+        """loss = model(**batch).loss; (loss * grad_scale).backward() for the trainable (projector)
+        parameters.  Gradients land in `self.proj_grad` (flat f32 bucket, overwritten)."""
+        if not self.with_backward:
+            raise _lib.UvxError("model was built with with_backward=False")
+        assert batch.get("labels") is not None, "labels are required for a training step"
+        out = self.forward(return_logits=False, _save_for_bwd=True, **batch)
+        l = _lib.lib()
+        B, T, nb, lab = self._llm_ctx
+        D = self.config.text_config.hidden_size
+        d_embeds = torch.empty((B, T, D), device=self.device, dtype=self.dtype)
+        check(l.uvx_llm_bwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, C.c_float(grad_scale),
+                            ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd")
+        st, tl, B, T, n_items, Na, scratch = self._merge_ctx
+        if n_items == 0:
+            self.proj_grad.zero_()
+            return out.loss
+        d_audio = torch.empty((n_items, Na, D), device=self.device, dtype=self.dtype)
+        check(l.uvx_merge_embeds_bwd(stream_ptr(), C.byref(self._c), ptr(d_embeds), ptr(st), ptr(tl), B, T, n_items, Na,
+                                     ptr(d_audio), ptr(scratch)), "uvx_merge_embeds_bwd")
+        self._projector_backward(d_audio)
+        self._last_d_embeds, self._last_d_audio = d_embeds, d_audio
+        return out.loss
+
+
+class UltravoxTrainer:
+    """One optimizer step with the reference's semantics: per-rank mean CE loss,
+    DP gradient MEAN over ranks (torch DDP), clip_grad_norm_(1.0), AdamW(beta 0.9/0.999, eps 1e-8, wd 0)."""
+
+    def __init__(self, model: UltravoxModel, lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, max_grad_norm: float = 1.0, master_weights: bool = False,
+                 gradient_accumulation_steps: int = 1):
+        self.model = model
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.step_count = 0
+        self.grad_accum = gradient_accumulation_steps
+        n = model.proj_flat.numel()
+        dev = model.device
+        self.master = model.proj_flat.float().clone() if master_weights else None
+        st_dtype = torch.float32 if (master_weights or model.dtype == torch.float32) else model.dtype
+        self.exp_avg = torch.zeros(n, device=dev, dtype=st_dtype)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=st_dtype)
+        self.scratch = torch.zeros(1025, device=dev, dtype=torch.float32)
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self._pending = None
+
+    def all_reduce_grads(self) -> None:
+        """torch DDP semantics: sum over ranks then divide by world size (RCCL over xGMI)."""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.model.proj_grad, op=torch.distributed.ReduceOp.SUM)
+            self.model.proj_grad.mul_(1.0 / self.world)
+
+    def optimizer_step(self) -> None:
+        m = self.model
+        self.step_count += 1
+        check(_lib.lib().uvx_adamw_clip_step(
+            stream_ptr(), _lib.dtype_code(m.dtype), ptr(m.proj_flat), ptr(self.master), ptr(m.proj_grad),
+            ptr(self.exp_avg), ptr(self.exp_avg_sq), C.c_int64(m.proj_flat.numel()), C.c_float(self.max_grad_norm),
+            C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+            C.c_float(self.wd), self.step_count, ptr(self.scratch)), "uvx_adamw_clip_step")
+
+    def grad_norm(self) -> torch.Tensor:
+        return self.scratch[0].sqrt()
+
+    def train_step(self, **batch) -> torch.Tensor:
+        self.model.train()
+        loss = self.model.forward_backward(grad_scale=1.0 / self.grad_accum, **batch)
+        self.all_reduce_grads()
+        self.optimizer_step()
+        return loss

@@ -42,3 +42,106 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     d.alpha = alpha
     check(_lib.lib().uvx_gemm(stream_ptr(), dt, C.byref(d)), "uvx_gemm")
     return out
+
+
+def _code(t: torch.Tensor) -> int:
+    return dtype_code(t.dtype)
+
+
+def layernorm(x, w, b, eps=1e-5):
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    check(_lib.lib().uvx_layernorm(stream_ptr(), _code(x), ptr(x), ptr(w), ptr(b), ptr(y), rows, x.shape[-1],
+                                   C.c_float(eps)), "uvx_layernorm")
+    return y
+
+
+def rmsnorm(x, w, eps=1e-6):
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    check(_lib.lib().uvx_rmsnorm(stream_ptr(), _code(x), ptr(x), ptr(w), ptr(y), rows, x.shape[-1], C.c_float(eps)),
+          "uvx_rmsnorm")
+    return y
+
+
+def rmsnorm_bwd(dy, x, w, eps=1e-6, dx_add=None, want_dx=True, want_dw=False):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty_like(x) if want_dx else None
+    dw = torch.zeros(cols, device=x.device, dtype=torch.float32) if want_dw else None
+    check(_lib.lib().uvx_rmsnorm_bwd(stream_ptr(), _code(x), ptr(dy), ptr(x), ptr(w), ptr(dx_add), ptr(dx), ptr(dw),
+                                     rows, cols, C.c_float(eps)), "uvx_rmsnorm_bwd")
+    return dx, dw
+
+
+def swiglu(x, gate_first=False):
+    half = x.shape[-1] // 2
+    out = torch.empty(*x.shape[:-1], half, device=x.device, dtype=x.dtype)
+    check(_lib.lib().uvx_swiglu(stream_ptr(), _code(x), ptr(x), ptr(out), x.numel() // x.shape[-1], half,
+                                int(gate_first)), "uvx_swiglu")
+    return out
+
+
+def swiglu_bwd(dout, x, gate_first=False):
+    half = x.shape[-1] // 2
+    din = torch.empty_like(x)
+    check(_lib.lib().uvx_swiglu_bwd(stream_ptr(), _code(x), ptr(dout), ptr(x), ptr(din), x.numel() // x.shape[-1],
+                                    half, int(gate_first)), "uvx_swiglu_bwd")
+    return din
+
+
+def rope_(x, cos_sin, T, n_heads, head_dim, inverse=False):
+    """In place on x [rows, ld]: heads 0..n_heads-1 (contiguous from column 0) are rotated."""
+    rows = x.numel() // x.shape[-1]
+    check(_lib.lib().uvx_rope(stream_ptr(), _code(x), ptr(x), ptr(cos_sin), rows, T, n_heads, head_dim, x.shape[-1],
+                              int(inverse)), "uvx_rope")
+    return x
+
+
+def _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len):
+    B, T, Hq, D = q.shape
+    d = _lib.AttnDesc()
+    d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    d.lse = 0 if lse is None else lse.data_ptr()
+    d.kv_start = 0 if kv_start is None else kv_start.data_ptr()
+    d.kv_len = 0 if kv_len is None else kv_len.data_ptr()
+    d.B, d.T, d.Hq, d.Hkv, d.D = B, T, Hq, k.shape[2], D
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
+    d.causal, d.block, d.scale = int(causal), int(block), scale
+    return d
+
+
+def attention(q, k, v, causal=False, block=0, scale=None, kv_start=None, kv_len=None, need_lse=True):
+    """q [B,T,Hq,D], k/v [B,T,Hkv,D] (last two dims contiguous, token stride free) -> o [B,T,Hq*D], lse."""
+    B, T, Hq, D = q.shape
+    scale = D ** -0.5 if scale is None else scale
+    o = torch.empty(B, T, Hq * D, device=q.device, dtype=q.dtype)
+    lse = torch.empty(B, Hq, T, device=q.device, dtype=torch.float32) if need_lse else None
+    d = _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len)
+    nb = _lib.lib().uvx_attention_ws_bytes(_code(q), C.byref(d), 0)
+    ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
+    check(_lib.lib().uvx_attention_fwd(stream_ptr(), _code(q), C.byref(d), ptr(ws), C.c_size_t(nb)), "uvx_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, lse, dout, causal=False, block=0, scale=None, kv_start=None, kv_len=None):
+    B, T, Hq, D = q.shape
+    scale = D ** -0.5 if scale is None else scale
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    d = _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len)
+    d.dout, d.dq, d.dk, d.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    d.lddq, d.lddk, d.lddv = dq.stride(1), dk.stride(1), dv.stride(1)
+    nb = _lib.lib().uvx_attention_ws_bytes(_code(q), C.byref(d), 1)
+    ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
+    check(_lib.lib().uvx_attention_bwd(stream_ptr(), _code(q), C.byref(d), ptr(ws), C.c_size_t(nb)), "uvx_attention_bwd")
+    return dq, dk, dv
+
+
+def ce_loss(logits, labels, want_grad=True, grad_scale=1.0, in_place=False):
+    """logits [B,T,V], labels [B,T] int64 -> (loss f32 scalar tensor, dlogits or None)."""
+    B, T, V = logits.shape
+    loss = torch.zeros(1, device=logits.device, dtype=torch.float32)
+    dl = (logits if in_place else torch.empty_like(logits)) if want_grad else None
+    scratch = torch.empty(2 + B * T, device=logits.device, dtype=torch.float32)
+    check(_lib.lib().uvx_ce_loss(stream_ptr(), _code(logits), ptr(logits), ptr(labels.contiguous()), ptr(loss), ptr(dl),
+                                 B, T, V, logits.stride(1), C.c_float(grad_scale), ptr(scratch)), "uvx_ce_loss")
+    return loss[0], dl

@@ -1,0 +1,178 @@
+"""State-dict plumbing: HF/Ultravox checkpoint key names -> packed device tensors.
+
+`random_state_dict` builds a seeded random-init state dict at the true architecture shapes with the
+reference's key names (no pretrained weights are reachable offline); `pack_*` fuse / reorder /
+transpose them ONCE at load time into the layouts the HIP kernels want (include/uvx.h):
+  - encoder  q/k/v -> one [3d, d] weight, q pre-scaled by head_dim^-0.5 (what WhisperAttention does
+    to q_proj's output; exact for power-of-two scales), k bias = 0;
+  - conv weights in im2col order (tap-major, channel-minor);
+  - Llama q/k/v -> [(H+2Hkv)dh, D], gate/up -> [2I, D], plus a transposed copy of every frozen linear
+    for the activation-gradient GEMMs (288 GB of HBM makes the second copy free).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from .config import UltravoxConfig
+
+
+def _sinusoids(length: int, channels: int) -> torch.Tensor:
+    """Whisper's fixed positional table (what embed_positions.weight holds in released checkpoints)."""
+    log_timescale_increment = math.log(10000) / (channels // 2 - 1)
+    inv = torch.exp(-log_timescale_increment * torch.arange(channels // 2, dtype=torch.float32))
+    t = torch.arange(length, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.cat([t.sin(), t.cos()], dim=1)
+
+
+def random_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32, device="cpu",
+                      std: float = 0.02) -> Dict[str, torch.Tensor]:
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    a, t = cfg.audio_config, cfg.text_config
+    sd: Dict[str, torch.Tensor] = {}
+
+    def rn(*shape, s=std):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * s).to(dtype)
+
+    def near_one(n):
+        return (1.0 + 0.1 * torch.randn(n, generator=g, device=device, dtype=torch.float32)).to(dtype)
+
+    d = a.d_model
+    P = "audio_tower."
+    sd[P + "conv1.weight"] = rn(d, a.num_mel_bins, 3, s=1.0 / math.sqrt(3 * a.num_mel_bins))
+    sd[P + "conv1.bias"] = rn(d)
+    sd[P + "conv2.weight"] = rn(d, d, 3, s=1.0 / math.sqrt(3 * d))
+    sd[P + "conv2.bias"] = rn(d)
+    sd[P + "embed_positions.weight"] = _sinusoids(a.max_source_positions, d).to(device=device, dtype=dtype)
+    for i in range(a.encoder_layers):
+        L = f"{P}layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[L + f"self_attn.{nm}.weight"] = rn(d, d, s=1.0 / math.sqrt(d))
+            if nm != "k_proj":
+                sd[L + f"self_attn.{nm}.bias"] = rn(d)
+        sd[L + "self_attn_layer_norm.weight"] = near_one(d)
+        sd[L + "self_attn_layer_norm.bias"] = rn(d)
+        sd[L + "fc1.weight"] = rn(a.encoder_ffn_dim, d, s=1.0 / math.sqrt(d))
+        sd[L + "fc1.bias"] = rn(a.encoder_ffn_dim)
+        sd[L + "fc2.weight"] = rn(d, a.encoder_ffn_dim, s=1.0 / math.sqrt(a.encoder_ffn_dim))
+        sd[L + "fc2.bias"] = rn(d)
+        sd[L + "final_layer_norm.weight"] = near_one(d)
+        sd[L + "final_layer_norm.bias"] = rn(d)
+    sd[P + "layer_norm.weight"] = near_one(d)
+    sd[P + "layer_norm.bias"] = rn(d)
+
+    # projector (ultravox_model.py:745-766): RMSNorm weights start at norm_init (0.4)
+    P = "multi_modal_projector."
+    dim_in, H, D = d * cfg.stack_factor, cfg.hidden_size, t.hidden_size
+    sd[P + "ln_pre.weight"] = torch.full((dim_in,), cfg.norm_init, device=device, dtype=dtype)
+    sd[P + "linear_1.weight"] = rn(H, dim_in, s=1.0 / math.sqrt(dim_in))
+    sd[P + "linear_2.weight"] = rn(D, H // 2, s=1.0 / math.sqrt(H // 2))
+    if cfg.projector_ln_mid:
+        sd[P + "ln_mid.weight"] = torch.full((H // 2,), cfg.norm_init, device=device, dtype=dtype)
+    else:
+        sd[P + "ln_post.weight"] = torch.full((D,), cfg.norm_init, device=device, dtype=dtype)
+
+    P = "language_model.model."
+    dh, Hq, Hkv, I = t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size
+    sd[P + "embed_tokens.weight"] = rn(t.vocab_size, D, s=1.0)
+    for i in range(t.num_hidden_layers):
+        L = f"{P}layers.{i}."
+        sd[L + "input_layernorm.weight"] = near_one(D)
+        sd[L + "post_attention_layernorm.weight"] = near_one(D)
+        sd[L + "self_attn.q_proj.weight"] = rn(Hq * dh, D, s=1.0 / math.sqrt(D))
+        sd[L + "self_attn.k_proj.weight"] = rn(Hkv * dh, D, s=1.0 / math.sqrt(D))
+        sd[L + "self_attn.v_proj.weight"] = rn(Hkv * dh, D, s=1.0 / math.sqrt(D))
+        sd[L + "self_attn.o_proj.weight"] = rn(D, Hq * dh, s=1.0 / math.sqrt(Hq * dh))
+        sd[L + "mlp.gate_proj.weight"] = rn(I, D, s=1.0 / math.sqrt(D))
+        sd[L + "mlp.up_proj.weight"] = rn(I, D, s=1.0 / math.sqrt(D))
+        sd[L + "mlp.down_proj.weight"] = rn(D, I, s=1.0 / math.sqrt(I))
+    sd[P + "norm.weight"] = near_one(D)
+    sd["language_model.lm_head.weight"] = rn(t.vocab_size, D, s=1.0 / math.sqrt(D))
+    return sd
+
+
+def rope_inv_freq(tc) -> torch.Tensor:
+    """[3P] LlamaRotaryEmbedding: default and "llama3" rope_scaling (Llama-3.1/3.3)."""
+    dh = tc.head_dim
+    inv = 1.0 / (tc.rope_theta ** (torch.arange(0, dh, 2, dtype=torch.int64).float() / dh))
+    rs = tc.rope_scaling
+    if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+        factor, lo, hi = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"]
+        old = rs["original_max_position_embeddings"]
+        wavelen = 2 * math.pi / inv
+        inv_l = torch.where(wavelen > old / lo, inv / factor, inv)
+        smooth = (old / wavelen - lo) / (hi - lo)
+        smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
+        mid = ~(wavelen < old / hi) * ~(wavelen > old / lo)
+        inv = torch.where(mid, smoothed, inv_l)
+    elif rs and rs.get("rope_type", rs.get("type", "default")) not in ("default", None):
+        raise ValueError(f"rope_scaling {rs} is not supported")
+    return inv
+
+
+def rope_table(tc, length: int, device) -> torch.Tensor:
+    inv = rope_inv_freq(tc)
+    freqs = torch.arange(length, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.stack([freqs.cos(), freqs.sin()], dim=-1).contiguous().to(device)  # [len, dh/2, 2]
+
+
+def pack_encoder(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.") -> Dict[str, object]:
+    a = cfg.audio_config
+    d, H = a.d_model, a.encoder_attention_heads
+    scale = (d // H) ** -0.5
+    cv = lambda x: x.to(device=device, dtype=dtype).contiguous()
+    kp1 = (3 * a.num_mel_bins + 63) // 64 * 64
+    w1 = sd[prefix + "conv1.weight"].float().permute(0, 2, 1).reshape(d, 3 * a.num_mel_bins)
+    w1p = torch.zeros(d, kp1)
+    w1p[:, : 3 * a.num_mel_bins] = w1.cpu()
+    out = {
+        "conv1_w": cv(w1p), "conv1_b": cv(sd[prefix + "conv1.bias"]),
+        "conv2_w": cv(sd[prefix + "conv2.weight"].permute(0, 2, 1).reshape(d, 3 * d)),
+        "conv2_b": cv(sd[prefix + "conv2.bias"]),
+        "pos": cv(sd[prefix + "embed_positions.weight"]),
+        "lnf_w": cv(sd[prefix + "layer_norm.weight"]), "lnf_b": cv(sd[prefix + "layer_norm.bias"]),
+        "layers": [],
+    }
+    for i in range(a.encoder_layers):
+        L = f"{prefix}layers.{i}."
+        q, k, v = (sd[L + f"self_attn.{n}_proj.weight"] for n in "qkv")
+        bq, bv = sd[L + "self_attn.q_proj.bias"], sd[L + "self_attn.v_proj.bias"]
+        # (x W_q^T + b_q) * scale, rounded like the reference: scale is a power of two for dh = 64
+        wqkv = torch.cat([q.float() * scale, k.float(), v.float()], 0)
+        bqkv = torch.cat([bq.float() * scale, torch.zeros_like(bq.float()), bv.float()], 0)
+        out["layers"].append({
+            "ln1_w": cv(sd[L + "self_attn_layer_norm.weight"]), "ln1_b": cv(sd[L + "self_attn_layer_norm.bias"]),
+            "wqkv": cv(wqkv), "bqkv": cv(bqkv),
+            "wo": cv(sd[L + "self_attn.out_proj.weight"]), "bo": cv(sd[L + "self_attn.out_proj.bias"]),
+            "ln2_w": cv(sd[L + "final_layer_norm.weight"]), "ln2_b": cv(sd[L + "final_layer_norm.bias"]),
+            "fc1_w": cv(sd[L + "fc1.weight"]), "fc1_b": cv(sd[L + "fc1.bias"]),
+            "fc2_w": cv(sd[L + "fc2.weight"]), "fc2_b": cv(sd[L + "fc2.bias"]),
+        })
+    return out
+
+
+def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = True, rope_len: Optional[int] = None,
+             prefix="language_model.") -> Dict[str, object]:
+    t = cfg.text_config
+    cv = lambda x: x.to(device=device, dtype=dtype).contiguous()
+    tr = lambda x: x.t().contiguous() if with_transposes else None
+    P = prefix + "model."
+    out = {"embed": cv(sd[P + "embed_tokens.weight"]), "norm": cv(sd[P + "norm.weight"]),
+           "lm_head": cv(sd[prefix + "lm_head.weight"]), "layers": []}
+    out["lm_head_t"] = tr(out["lm_head"])
+    for i in range(t.num_hidden_layers):
+        L = f"{P}layers.{i}."
+        wqkv = cv(torch.cat([sd[L + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0))
+        wgu = cv(torch.cat([sd[L + "mlp.gate_proj.weight"], sd[L + "mlp.up_proj.weight"]], 0))
+        wo, wd = cv(sd[L + "self_attn.o_proj.weight"]), cv(sd[L + "mlp.down_proj.weight"])
+        out["layers"].append({
+            "ln1": cv(sd[L + "input_layernorm.weight"]), "ln2": cv(sd[L + "post_attention_layernorm.weight"]),
+            "wqkv": wqkv, "wo": wo, "wgu": wgu, "wd": wd,
+            "wqkv_t": tr(wqkv), "wo_t": tr(wo), "wgu_t": tr(wgu), "wd_t": tr(wd),
+        })
+    out["rope_len"] = rope_len or min(t.max_position_embeddings, 8192)
+    out["rope"] = rope_table(t, out["rope_len"], device)
+    return out
