@@ -1,0 +1,234 @@
+"""bench.py — adapter-train step of the Ultravox audio->LLM hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): audio-seconds / second / node for one adapter-train step (Whisper-medium encoder +
+Llama-3-8B, both frozen; projector trained).  One "step" = log-mel (K1) -> encoder -> projector -> embed/merge
+-> LLM forward + CE -> activation-gradient backward -> projector dgrad/wgrad -> DP gradient mean (RCCL) ->
+clip + AdamW, over one synthetic batch of B = 8 clips x 30 s (16 kHz) + 128 text tokens per GPU, inputs
+resident in HBM before the timed region.  Weights: seeded random init at the true architecture shapes (no
+checkpoints offline); data: synthetic.  Weak scaling: per-GPU work is fixed.
+
+The JSON line also carries
+  roofline     — the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs of every launch / its duration,
+                 timed live with HIP events on the launch stream inside the timed region, vs 2.5 PFLOP/s;
+  cpu_baseline — the CPU oracle (oracle/reference_cpu.py, a port of the reference path) timed on this box's
+                 host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; 2:1-sparse figures excluded)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "c2": dict(name="Llama-3-8B (frozen) + whisper-medium, bs=8x30s clips, adapter train",
+               audio="openai/whisper-medium", text="meta-llama/Meta-Llama-3-8B-Instruct", B=8, seconds=30.0),
+    # BASELINE.json configs[0] shapes (plumbing-sized), for quick checks
+    "c1": dict(name="TinyLlama-1.1B + whisper-tiny, 1x4s clip, adapter train",
+               audio="openai/whisper-tiny", text="TinyLlama/TinyLlama-1.1B-Chat-v1.0", B=1, seconds=4.0),
+}
+
+
+def flops_per_sample(cfg, seconds: float, n_text: int = 128):
+    """Algorithmic FLOPs of one sample: matmul [m,k]x[k,n] = 2mkn, causal attention = 1/2."""
+    a, t = cfg.audio_config, cfg.text_config
+    F = int(seconds * 100)
+    Te = F // 2
+    Na = -(-F // 16)
+    T = n_text + Na
+    d, Le, ffn = a.d_model, a.encoder_layers, a.encoder_ffn_dim
+    E = 2 * F * a.num_mel_bins * 3 * d + 2 * Te * d * 3 * d + Le * (8 * Te * d * d + 4 * Te * Te * d + 4 * Te * d * ffn)
+    H, D = cfg.hidden_size, t.hidden_size
+    P = 2 * Na * (8 * d * H + (H // 2) * D)
+    h, kv, dh, I, V, L = t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.intermediate_size, t.vocab_size, t.num_hidden_layers
+    attn = L * 2 * T * T * h * dh
+    M = L * (2 * T * (2 * D * h * dh + 2 * D * kv * dh) + 6 * T * D * I) + attn + 2 * T * D * V
+    step = E + 3 * P + M + (M + attn)
+    return dict(encoder=E, projector=P, llm_fwd=M, step=step)
+
+
+def cpu_baseline(cfg, seconds: float, n_text: int = 128):
+    """Bounded sample of the SAME workload through the oracle on the host cores: B = 1 clip, the full-size
+    log-mel + conv stem + 2 encoder layers, the projector, 1 LLM layer (fwd + bwd) and the lm_head + CE
+    (fwd + bwd); per-layer times are scaled to the real layer counts."""
+    from oracle import reference_cpu as O
+    from ultravox_amd.config import AudioConfig, TextConfig, UltravoxConfig
+    import dataclasses
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    a, t = cfg.audio_config, cfg.text_config
+    small = UltravoxConfig(audio_config=dataclasses.replace(a, encoder_layers=2),
+                           text_config=dataclasses.replace(t, num_hidden_layers=1),
+                           hidden_size=cfg.hidden_size, stack_factor=cfg.stack_factor,
+                           projector_ln_mid=cfg.projector_ln_mid)
+    from ultravox_amd.weights import random_state_dict
+    sd = random_state_dict(small, seed=0, dtype=torch.float32)
+    om = O.OracleModel(small, sd, dtype=torch.float32)
+    b = O.synthetic_batch(small, 1, seconds, n_text=n_text)
+    pcm = b.pop("pcm")
+
+    def timed(fn, reps=1):
+        fn()  # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        return (time.perf_counter() - t0) / reps, r
+
+    t_mel, mel = timed(lambda: O.logmel_ref(pcm, a.num_mel_bins))
+    with torch.no_grad():
+        t_enc2, _ = timed(lambda: O.whisper_encoder_ref(om.sd, small, mel, b["audio_lens"]))
+        small0 = UltravoxConfig(audio_config=dataclasses.replace(a, encoder_layers=0), text_config=small.text_config,
+                                hidden_size=cfg.hidden_size, projector_ln_mid=cfg.projector_ln_mid)
+        t_enc0, _ = timed(lambda: O.whisper_encoder_ref(om.sd, small0, mel, b["audio_lens"]))
+    per_enc_layer = max(t_enc2 - t_enc0, 0.0) / 2
+    batch = {**b, "audio_values": mel}
+
+    def llm_step(n_layers):
+        def f():
+            for k in om.trainable:
+                om.sd[k].grad = None
+            _, audio_embeds = om.audio_embeds(mel, b["audio_lens"])   # encoder(2 layers) + projector
+            emb = torch.nn.functional.embedding(b["input_ids"], om.sd["language_model.model.embed_tokens.weight"])
+            emb = O.merge_ref(emb, audio_embeds, b["audio_token_start_idx"], b["audio_token_len"], b["audio_batch_size"])
+            logits = O.llama_ref(om.sd, small, emb, b["attention_mask"], n_layers=n_layers)
+            O.causal_lm_loss_ref(logits, b["labels"]).backward()
+        return f
+
+    t_l1, _ = timed(llm_step(1))
+    t_l0, _ = timed(llm_step(0))
+    per_llm_layer = max(t_l1 - t_l0, 0.0)
+    rest = t_l0 - t_enc2  # projector fwd+bwd, merge, head + CE fwd+bwd
+    step = t_mel + t_enc0 + per_enc_layer * a.encoder_layers + max(rest, 0.0) + per_llm_layer * t.num_hidden_layers
+    return {
+        "value": seconds / step, "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+        "sample": (f"oracle f32, B=1x{seconds:g}s clip: log-mel + conv stem + 2/{a.encoder_layers} encoder layers, projector, "
+                   f"1/{t.num_hidden_layers} LLM layer fwd+bwd, lm_head+CE fwd+bwd; per-layer times scaled to full depth "
+                   f"(extrapolated step {step:.1f} s)"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the live HIP-event timing of the GEMM kernel")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    from ultravox_amd import _lib
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel, UltravoxTrainer
+    from ultravox_amd.synthetic import synthetic_batch
+
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl["B"]
+    cfg = UltravoxConfig(audio_model_id=wl["audio"], text_model_id=wl["text"], hidden_size=4096, stack_factor=8,
+                         projector_ln_mid=True, torch_dtype="bfloat16")
+    model = UltravoxModel(cfg, device=str(dev), dtype=torch.bfloat16, seed=0, rope_len=1024)
+    trainer = UltravoxTrainer(model, lr=2e-3, max_grad_norm=1.0)
+    fe = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins, device=str(dev))
+    batch = synthetic_batch(cfg, B, wl["seconds"], n_text=128, audio_start=16, n_supervised=32, rank=rank)
+    pcm = batch.pop("pcm").to(dev)
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    T = batch["input_ids"].shape[1]
+
+    def step():
+        mel = fe.logmel_device(pcm)                        # K1 on device, inside the step
+        return trainer.train_step(audio_values=mel, **batch)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    prof = (C.c_double * 12)()
+    if not args.no_prof:
+        _lib.lib().uvx_prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if not args.no_prof:
+        _lib.check(_lib.lib().uvx_prof_end(prof, 3), "uvx_prof_end")
+    loss_val = float(loss.item())
+    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t_max.item())
+
+    if rank == 0:
+        fl = flops_per_sample(cfg, wl["seconds"])
+        audio_s = B * world * wl["seconds"] * args.steps
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "audio-seconds/sec/node adapter-train step (Whisper-med + Llama-3-8B)" if args.workload == "c2"
+                      else "audio-seconds/sec/node adapter-train step",
+            "value": audio_s / dt, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded PCM + token ids; seeded random-init weights)",
+            "config": {"workload": wl["name"], "clips_per_gpu": B, "clip_seconds": wl["seconds"], "text_tokens": 128,
+                       "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "audio_model": wl["audio"], "text_model": wl["text"], "optimizer": "AdamW bf16 state, clip 1.0"},
+            "samples_per_sec": B * world * args.steps / dt,
+            "step_tflops_algorithmic": fl["step"] * B / 1e12,
+            "mfu": fl["step"] * B * world * args.steps / dt / (PEAK_BF16_TFLOPS * 1e12 * world),
+            "loss": loss_val,
+        }
+        if not args.no_prof and prof[0] > 0:
+            ach = prof[2] / (prof[1] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                               "launches_per_step": prof[0] / args.steps, "gemm_ms_per_step": prof[1] / args.steps,
+                               "avg_launch_us": prof[1] / prof[0] * 1e3,
+                               "algorithmic_gflop_per_launch": prof[2] / prof[0] / 1e9}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, wl["seconds"])
+            except Exception as e:  # the GPU number stands on its own; report why the CPU leg is missing
+                out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -205,6 +205,12 @@ int32_t uvx_attention_bwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d,
 int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, const int64_t* labels, float* loss, void* dlogits,
                     int32_t B, int32_t T, int32_t V, int32_t ld, float grad_scale, float* scratch);
 
+/* ---- live kernel timing (bench.py roofline leg): HIP events on the launch stream around every GEMM.
+ * uvx_prof_end fills out[class*4 + {0: launches, 1: total ms, 2: algorithmic FLOPs, 3: algorithmic bytes}]
+ * for class 0 = bf16 MFMA GEMM (classes 1.. reserved) and synchronises on the recorded events. */
+int32_t uvx_prof_begin(void);
+int32_t uvx_prof_end(double* out, int32_t n_classes);
+
 #ifdef __cplusplus
 }
 #endif

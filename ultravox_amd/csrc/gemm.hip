@@ -190,6 +190,9 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.act = d.act; a.out_f32 = d.out_f32; a.accumulate = d.accumulate; a.alpha = d.alpha;
   a.tiles_m = cdiv(d.M, BM); a.tiles_n = cdiv(d.N, BN);
   dim3 grid(a.tiles_m * a.tiles_n, d.batch > 0 ? d.batch : 1);
+  const int batch = d.batch > 0 ? d.batch : 1;
+  uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K * batch,
+                      ((double)d.M * d.K + (double)d.N * d.K) * 2.0 * batch + (double)d.M * d.N * batch * (d.out_f32 ? 4.0 : 2.0));
   hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, st, a);
   UVX_LAUNCH_CHECK();
   return UVX_OK;

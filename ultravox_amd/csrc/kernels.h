@@ -8,6 +8,17 @@ namespace uvx {
 
 enum DType { DT_BF16 = 0, DT_F32 = 1 };
 
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) ----
+enum ProfClass { PROF_GEMM = 0, PROF_ATTN = 1, PROF_OTHER = 2, PROF_NCLASS = 3 };
+void prof_record_begin(hipStream_t st, int cls, double flops, double bytes);
+void prof_record_end(hipStream_t st);
+extern bool g_prof_on;
+struct ProfScope {
+  hipStream_t st; bool on;
+  ProfScope(hipStream_t s, int cls, double flops, double bytes) : st(s), on(g_prof_on) { if (on) prof_record_begin(s, cls, flops, bytes); }
+  ~ProfScope() { if (on) prof_record_end(st); }
+};
+
 struct GemmDesc {
   const void* A = nullptr;  // [M, K], row stride lda (activations)
   const void* B = nullptr;  // [N, K], row stride ldb (nn.Linear weight layout)
