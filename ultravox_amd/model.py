@@ -348,9 +348,8 @@ class UltravoxTrainer:
 
     def all_reduce_grads(self) -> None:
         """torch DDP semantics: sum over ranks then divide by world size (RCCL over xGMI)."""
-        if self.world > 1:
-            torch.distributed.all_reduce(self.model.proj_grad, op=torch.distributed.ReduceOp.SUM)
-            self.model.proj_grad.mul_(1.0 / self.world)
+        from .parallel import dp_mean_
+        dp_mean_(self.model.proj_grad)
 
     def optimizer_step(self) -> None:
         m = self.model
