@@ -82,28 +82,51 @@ __device__ __forceinline__ int tr_off16(int row, int c16) {
   return row * (W * 2) + (((c16 ^ ((row >> 1) & 7)) & M16) << 4);
 }
 
-// Cooperative global -> LDS copy of a natural tile: rows [r0, r0+R) of a [*, ld] matrix (+col0), D columns;
-// rows >= rmax are zero filled.
+// Register-staged tiles (async-STAGE split): the global loads of tile j+1 are ISSUED before the MFMA work
+// of tile j and written to the other LDS buffer after it, so HBM/L2 latency hides under compute and
+// there is one barrier per tile.
+// natural tile: rows [r0, r0+R) of a [*, ld] matrix, D columns; rows >= rmax read as zero.
 template <int D, int R>
-__device__ __forceinline__ void stage_nat(char* lds, const bf16_t* base, long long ld, int r0, int rmax, int tid) {
-  constexpr int NCH = D / 8;
+struct NatRegs { u16x8_t v[R * (D / 8) / 256]; };
+template <int D, int R>
+__device__ __forceinline__ void load_nat(NatRegs<D, R>& g, const bf16_t* base, long long ld, int r0, int rmax, int tid) {
+  constexpr int NCH = D / 8, N = R * NCH / 256;
 #pragma unroll
-  for (int i = tid; i < R * NCH; i += 256) {
-    const int r = i / NCH, c = i % NCH;
+  for (int k = 0; k < N; ++k) {
+    const int i = tid + k * 256, r = i / NCH, c = i % NCH;
     u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (r0 + r < rmax) v = *reinterpret_cast<const u16x8_t*>(base + (long long)(r0 + r) * ld + c * 8);
-    *reinterpret_cast<u16x8_t*>(lds + nat_off<D>(r, c)) = v;
+    g.v[k] = v;
+  }
+}
+template <int D, int R>
+__device__ __forceinline__ void store_nat(char* lds, const NatRegs<D, R>& g, int tid) {
+  constexpr int NCH = D / 8, N = R * NCH / 256;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int i = tid + k * 256, r = i / NCH, c = i % NCH;
+    *reinterpret_cast<u16x8_t*>(lds + nat_off<D>(r, c)) = g.v[k];
   }
 }
 // transposed tile: D rows, W keys starting at t0 of a [D, Tp] matrix (zero padded in memory).
 template <int D, int W>
-__device__ __forceinline__ void stage_tr(char* lds, const bf16_t* base, int Tp, int t0, int tid) {
-  constexpr int NC = W / 8;
+struct TrRegs { u16x8_t v[D * (W / 8) / 256]; };
+template <int D, int W>
+__device__ __forceinline__ void load_tr(TrRegs<D, W>& g, const bf16_t* base, int Tp, int t0, int tid) {
+  constexpr int NC = W / 8, N = D * NC / 256;
 #pragma unroll
-  for (int i = tid; i < D * NC; i += 256) {
-    const int r = i / NC, c = i % NC;
-    u16x8_t v = *reinterpret_cast<const u16x8_t*>(base + (long long)r * Tp + t0 + c * 8);
-    *reinterpret_cast<u16x8_t*>(lds + tr_off16<W>(r, c)) = v;
+  for (int k = 0; k < N; ++k) {
+    const int i = tid + k * 256, r = i / NC, c = i % NC;
+    g.v[k] = *reinterpret_cast<const u16x8_t*>(base + (long long)r * Tp + t0 + c * 8);
+  }
+}
+template <int D, int W>
+__device__ __forceinline__ void store_tr(char* lds, const TrRegs<D, W>& g, int tid) {
+  constexpr int NC = W / 8, N = D * NC / 256;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int i = tid + k * 256, r = i / NC, c = i % NC;
+    *reinterpret_cast<u16x8_t*>(lds + tr_off16<W>(r, c)) = g.v[k];
   }
 }
 
@@ -113,8 +136,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   constexpr int BQ = 4 * QT * 16;
   constexpr int KS = D / 32;   // k-steps of the QK^T product
   constexpr int DT = D / 16;   // 16-row tiles of O^T
-  __shared__ __attribute__((aligned(16))) char ldsK[64 * D * 2];
-  __shared__ __attribute__((aligned(16))) char ldsV[D * 64 * 2];
+  constexpr int TILE = 64 * D * 2;  // bytes of one K tile == one V^T tile
+  __shared__ __attribute__((aligned(16))) char ldsKV[4 * TILE];  // [buf][K | V^T]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -153,11 +176,25 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   const bf16_t* kbase = p.k + (long long)b * p.T * p.ldk + hk * D;
   const bf16_t* vtbase = p.vt + ((long long)b * p.Hkv + hk) * D * p.Tp;
 
-  for (int kb = (k_lo / 64) * 64; kb < kb_end; kb += 64) {
-    __syncthreads();
-    stage_nat<D, 64>(ldsK, kbase, p.ldk, kb, p.T, tid);
-    stage_tr<D, 64>(ldsV, vtbase, p.Tp, kb, tid);
-    __syncthreads();
+  NatRegs<D, 64> kreg;
+  TrRegs<D, 64> vreg;
+  const int kb_begin = (k_lo / 64) * 64;
+  if (kb_begin < kb_end) {
+    load_nat<D, 64>(kreg, kbase, p.ldk, kb_begin, p.T, tid);
+    load_tr<D, 64>(vreg, vtbase, p.Tp, kb_begin, tid);
+    store_nat<D, 64>(ldsKV, kreg, tid);
+    store_tr<D, 64>(ldsKV + TILE, vreg, tid);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kb = kb_begin; kb < kb_end; kb += 64, cur ^= 1) {
+    const char* ldsK = ldsKV + cur * 2 * TILE;
+    const char* ldsV = ldsK + TILE;
+    const bool has_next = kb + 64 < kb_end;
+    if (has_next) {  // issue next tile's global loads now; they land while this tile computes
+      load_nat<D, 64>(kreg, kbase, p.ldk, kb + 64, p.T, tid);
+      load_tr<D, 64>(vreg, vtbase, p.Tp, kb + 64, tid);
+    }
 
     // ---- S^T = K . Q^T ----
     f32x4_t s[QT][4];
@@ -227,6 +264,11 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) acc_o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][kp], acc_o[t][d], 0, 0, 0);
       }
+    if (has_next) {  // the other buffer was last read one iteration ago, before the previous barrier
+      store_nat<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE, kreg, tid);
+      store_tr<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE + TILE, vreg, tid);
+    }
+    __syncthreads();
   }
 
   // ---- epilogue ----
@@ -274,11 +316,9 @@ __global__ void attn_delta_k(const bf16_t* __restrict__ dout, const bf16_t* __re
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
   constexpr int KS = D / 32, DT = D / 16;
-  __shared__ __attribute__((aligned(16))) char ldsQ[32 * D * 2];
-  __shared__ __attribute__((aligned(16))) char ldsDO[32 * D * 2];
-  __shared__ __attribute__((aligned(16))) char ldsQT[D * 32 * 2];
-  __shared__ __attribute__((aligned(16))) char ldsDOT[D * 32 * 2];
-  __shared__ float ldsL[32], ldsDl[32];
+  constexpr int TILE = 32 * D * 2;
+  __shared__ __attribute__((aligned(16))) char ldsAll[8 * TILE + 2 * 64 * 4];  // [buf][Q | dO | Q^T | dO^T], then [buf][lse | delta]
+  float* ldsStat = reinterpret_cast<float*>(ldsAll + 8 * TILE);
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -309,26 +349,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
   if (p.block > 0) q_begin = max(q_begin, (kb0 / p.block) * p.block);
   q_begin = (q_begin / 32) * 32;
 
-  for (int hh = 0; hh < grp; ++hh) {
-    const int h = hk * grp + hh;
-    const bf16_t* qbase = p.q + (long long)b * p.T * p.ldq + h * D;
-    const bf16_t* dobase = p.dout + (long long)b * p.T * p.ldo + h * D;
-    const bf16_t* qtbase = p.qt + ((long long)b * p.Hq + h) * D * p.Tp;
-    const bf16_t* dotbase = p.dot + ((long long)b * p.Hq + h) * D * p.Tp;
-    const float* lrow = p.lse + ((long long)b * p.Hq + h) * p.T;
-    const float* drow = p.delta + ((long long)b * p.Hq + h) * p.T;
-    for (int qs = q_begin; qs < p.T; qs += 32) {
-      __syncthreads();
-      stage_nat<D, 32>(ldsQ, qbase, p.ldq, qs, p.T, tid);
-      stage_nat<D, 32>(ldsDO, dobase, p.ldo, qs, p.T, tid);
-      stage_tr<D, 32>(ldsQT, qtbase, p.Tp, qs, tid);
-      stage_tr<D, 32>(ldsDOT, dotbase, p.Tp, qs, tid);
-      if (tid < 32) {
-        const int q = qs + tid;
-        ldsL[tid] = q < p.T ? lrow[q] : __builtin_huge_valf();
-        ldsDl[tid] = q < p.T ? drow[q] : 0.f;
-      }
-      __syncthreads();
+  // flattened (head-in-group, 32-query step) iteration space, software pipelined like the forward
+  const int nq = q_begin < p.T ? (p.T - q_begin + 31) / 32 : 0;
+  const int n_it = grp * nq;
+  NatRegs<D, 32> qreg, doreg;
+  TrRegs<D, 32> qtreg, dotreg;
+  float lreg = 0.f, dlreg = 0.f;
+  auto issue = [&](int it) {
+    const int h = hk * grp + it / nq, qs = q_begin + (it % nq) * 32;
+    load_nat<D, 32>(qreg, p.q + (long long)b * p.T * p.ldq + h * D, p.ldq, qs, p.T, tid);
+    load_nat<D, 32>(doreg, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
+    load_tr<D, 32>(qtreg, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
+    load_tr<D, 32>(dotreg, p.dot + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
+    if (tid < 32) {
+      const int q = qs + tid;
+      lreg = q < p.T ? p.lse[((long long)b * p.Hq + h) * p.T + q] : __builtin_huge_valf();
+      dlreg = q < p.T ? p.delta[((long long)b * p.Hq + h) * p.T + q] : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+    char* base = ldsAll + buf * 4 * TILE;
+    store_nat<D, 32>(base, qreg, tid);
+    store_nat<D, 32>(base + TILE, doreg, tid);
+    store_tr<D, 32>(base + 2 * TILE, qtreg, tid);
+    store_tr<D, 32>(base + 3 * TILE, dotreg, tid);
+    if (tid < 32) { ldsStat[buf * 64 + tid] = lreg; ldsStat[buf * 64 + 32 + tid] = dlreg; }
+  };
+  if (n_it > 0) { issue(0); commit(0); }
+  __syncthreads();
+  {
+    for (int it = 0; it < n_it; ++it) {
+      const int cur = it & 1;
+      const int qs = q_begin + (it % nq) * 32;
+      const char* ldsQ = ldsAll + cur * 4 * TILE;
+      const char* ldsDO = ldsQ + TILE;
+      const char* ldsQT = ldsQ + 2 * TILE;
+      const char* ldsDOT = ldsQ + 3 * TILE;
+      const float* ldsL = ldsStat + cur * 64;
+      const float* ldsDl = ldsL + 32;
+      if (it + 1 < n_it) issue(it + 1);
 
       // S[q][key] and dP[q][key] for the two 16-query tiles: A = Q / dO rows, B = K / V fragments
       f32x4_t s[2], dp[2];
@@ -366,6 +425,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
         acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB, acc_dv[d], 0, 0, 0);
         acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB, acc_dk[d], 0, 0, 0);
       }
+      if (it + 1 < n_it) commit(cur ^ 1);
+      __syncthreads();
     }
   }
   // accumulators hold dV^T / dK^T: row d = dt*16 + g*4 + e, col key = fr
@@ -388,9 +449,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
   constexpr int KS = D / 32, DT = D / 16;
-  __shared__ __attribute__((aligned(16))) char ldsK[32 * D * 2];
-  __shared__ __attribute__((aligned(16))) char ldsV[32 * D * 2];
-  __shared__ __attribute__((aligned(16))) char ldsKT[D * 32 * 2];
+  constexpr int TILE = 32 * D * 2;
+  __shared__ __attribute__((aligned(16))) char ldsAll[6 * TILE];  // [buf][K | V | K^T]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -426,12 +486,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
   const bf16_t* vbase = p.v + (long long)b * p.T * p.ldv + hk * D;
   const bf16_t* ktbase = p.kt + ((long long)b * p.Hkv + hk) * D * p.Tp;
 
-  for (int ks0 = (k_lo / 32) * 32; ks0 < kend; ks0 += 32) {
-    __syncthreads();
-    stage_nat<D, 32>(ldsK, kbase, p.ldk, ks0, p.T, tid);
-    stage_nat<D, 32>(ldsV, vbase, p.ldv, ks0, p.T, tid);
-    stage_tr<D, 32>(ldsKT, ktbase, p.Tp, ks0, tid);
-    __syncthreads();
+  NatRegs<D, 32> kreg, vreg;
+  TrRegs<D, 32> ktreg;
+  const int k_begin = (k_lo / 32) * 32;
+  auto issue = [&](int ks0) {
+    load_nat<D, 32>(kreg, kbase, p.ldk, ks0, p.T, tid);
+    load_nat<D, 32>(vreg, vbase, p.ldv, ks0, p.T, tid);
+    load_tr<D, 32>(ktreg, ktbase, p.Tp, ks0, tid);
+  };
+  auto commit = [&](int buf) {
+    store_nat<D, 32>(ldsAll + buf * 3 * TILE, kreg, tid);
+    store_nat<D, 32>(ldsAll + buf * 3 * TILE + TILE, vreg, tid);
+    store_tr<D, 32>(ldsAll + buf * 3 * TILE + 2 * TILE, ktreg, tid);
+  };
+  if (k_begin < kend) { issue(k_begin); commit(0); }
+  __syncthreads();
+  int cur = 0;
+  for (int ks0 = k_begin; ks0 < kend; ks0 += 32, cur ^= 1) {
+    const char* ldsK = ldsAll + cur * 3 * TILE;
+    const char* ldsV = ldsK + TILE;
+    const char* ldsKT = ldsK + 2 * TILE;
+    const bool has_next = ks0 + 32 < kend;
+    if (has_next) issue(ks0 + 32);
     f32x4_t s[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -461,6 +537,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
       const bf16x8_t a = lds_2xb64(ldsKT + tr_off8<32>(row, g), ldsKT + tr_off8<32>(row, 4 + g));
       acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB, acc[d], 0, 0, 0);  // dQ^T[d][q]
     }
+    if (has_next) commit(cur ^ 1);
+    __syncthreads();
   }
   if (q < p.T) {
     bf16_t* dqrow = p.dq + ((long long)b * p.T + q) * p.lddq + h * D;

@@ -149,12 +149,14 @@ __global__ void merge_copy_k(T* __restrict__ embeds, const T* __restrict__ audio
   }
 }
 
-// ---- generic 2-D transpose through LDS: out[c, r] = in[r, c]; pads rows..ld_out region with zeros ----
+// ---- batched 2-D transpose through LDS: out[z][c, r] = in[z][r, c]; the padded region r in [rows, ld_out)
+// is written as zeros.  Two-level batch index z = zo * nzi + zi (e.g. batch x heads).
 template <typename T>
 __global__ void transpose_k(const T* __restrict__ in, T* __restrict__ out, int rows, int cols, int ld_in, int ld_out,
-                            int out_cols_total, long long s_in, long long s_out) {
+                            int nzi, long long s_in_o, long long s_in_i, long long s_out) {
   __shared__ T tile[64][65];
-  const T* ib = in + blockIdx.z * s_in;
+  const int zo = blockIdx.z / nzi, zi = blockIdx.z % nzi;
+  const T* ib = in + zo * s_in_o + zi * s_in_i;
   T* ob = out + blockIdx.z * s_out;
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows per pass
@@ -165,7 +167,7 @@ __global__ void transpose_k(const T* __restrict__ in, T* __restrict__ out, int r
   __syncthreads();
   for (int cc = ty; cc < 64; cc += 4) {
     const int c = c0 + cc, r = r0 + tx;
-    if (c < cols && r < out_cols_total) ob[(long long)c * ld_out + r] = tile[tx][cc];
+    if (c < cols && r < ld_out) ob[(long long)c * ld_out + r] = tile[tx][cc];
   }
 }
 
@@ -306,30 +308,27 @@ int merge_audio(hipStream_t st, int dtype, void* embeds, const void* audio, void
   return UVX_OK;
 }
 
-int transpose2d(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in, int ld_out,
-                int batch, long long s_in, long long s_out) {
-  if (rows == 0 || cols == 0) return UVX_OK;
+static int transpose_launch(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in,
+                            int ld_out, int nzo, int nzi, long long s_in_o, long long s_in_i, long long s_out) {
+  if (rows == 0 || cols == 0 || nzo * nzi == 0) return UVX_OK;
   // the zero padded region out[:, rows..ld_out) is written too (the GEMM K dimension must be 64-aligned)
-  dim3 grid(cdiv(ld_out, 64), cdiv(cols, 64), batch);
+  dim3 grid(cdiv(ld_out, 64), cdiv(cols, 64), nzo * nzi);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL(transpose_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, ld_out, s_in, s_out);
+    hipLaunchKernelGGL(transpose_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, nzi, s_in_o, s_in_i, s_out);
   else
-    hipLaunchKernelGGL(transpose_k<float>, grid, dim3(256), 0, st, (const float*)in, (float*)out, rows, cols, ld_in, ld_out, ld_out, s_in, s_out);
+    hipLaunchKernelGGL(transpose_k<float>, grid, dim3(256), 0, st, (const float*)in, (float*)out, rows, cols, ld_in, ld_out, nzi, s_in_o, s_in_i, s_out);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
 
+int transpose2d(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in, int ld_out,
+                int batch, long long s_in, long long s_out) {
+  return transpose_launch(st, dtype, in, out, rows, cols, ld_in, ld_out, batch, 1, s_in, 0, s_out);
+}
+
 int heads_transpose(hipStream_t st, int dtype, const void* in, void* out, int B, int T, int Tp, int H, int D, int ld) {
-  // [B, T, H, D] (token stride ld) -> [B, H, D, Tp]: a batched transpose with a two-level batch index,
-  // expressed as B launches of the (H-batched) 2-D transpose.
-  const size_t es = dtype == DT_BF16 ? 2 : 4;
-  for (int b = 0; b < B; ++b) {
-    const char* ib = (const char*)in + (size_t)b * T * ld * es;
-    char* ob = (char*)out + (size_t)b * H * D * Tp * es;
-    int rc = transpose2d(st, dtype, ib, ob, T, D, ld, Tp, H, D, (long long)D * Tp);
-    if (rc) return rc;
-  }
-  return UVX_OK;
+  // [B, T, H, D] (token stride ld) -> [B, H, D, Tp] in ONE launch: z = b * H + h
+  return transpose_launch(st, dtype, in, out, T, D, ld, Tp, B, H, (long long)T * ld, D, (long long)D * Tp);
 }
 
 int im2col_conv1(hipStream_t st, int dtype, const void* mel, int mel_is_f32, void* out, int B, int n_mels, int F,

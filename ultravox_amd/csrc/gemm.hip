@@ -313,23 +313,25 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide_kernel(GemmArgs p) {
   }
 }
 
-// Tile choice: model time as (rounds of tiles over 256 CUs) x (work per tile ~ BM x BN), plus a mild
-// preference for the wide kernel's higher per-tile efficiency.  variant 0 = 128x128 narrow kernel.
+// Tile choice.  Every CU works through ceil(tiles / 256) tiles (few rounds) or ~tiles/256 + 0.4 (many
+// rounds, dynamic dispatch smooths the tail); a tile costs BM x BN / speed(variant), speeds measured on
+// MI355X (profiles/r01_gemm_variants.txt).  variant 0 = 128x128 narrow; 1..4 = {128,160,192,256} x 256 wide.
+// (A 32x32x16-MFMA flavour of the wide kernel was measured 10-20 % SLOWER than 16x16x32 and dropped.)
+struct Variant { int bm, bn; double speed; };
+constexpr int kNumVariants = 5;
+const Variant kVariants[kNumVariants] = {{128, 128, 850.}, {128, 256, 870.}, {160, 256, 1010.}, {192, 256, 1050.},
+                                         {256, 256, 1080.}};
 int pick_variant(int M, int N, int batch) {
   const int forced = uvx::g_gemm_variant;
   if (forced >= 0) return forced;
-  const double n_cu = 256.0;
   double best = 1e30;
   int best_v = 0;
-  const int bms[5] = {0, 128, 160, 192, 256};
-  for (int v = 0; v < 5; ++v) {
-    const int bm = v == 0 ? 128 : bms[v], bn = v == 0 ? 128 : 256;
-    const double tiles = (double)cdiv(M, bm) * cdiv(N, bn) * batch;
-    const double per_cu = v == 0 ? 3.0 : 1.0;  // co-resident blocks per CU
-    const double rounds = ceil(tiles / (n_cu * per_cu));
-    const double eff = v == 0 ? 0.62 : 1.0;    // measured: narrow ~0.85-0.95 PF, wide target ~1.4 PF
-    const double tcost = rounds * per_cu * bm * bn / eff;
-    if (tcost < best) { best = tcost; best_v = v; }
+  for (int v = 0; v < kNumVariants; ++v) {
+    const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
+    const double r = tiles / 256.0;
+    const double rounds = r <= 4.0 ? ceil(r) : r + 0.4;
+    const double cost = rounds * kVariants[v].bm * kVariants[v].bn / kVariants[v].speed;
+    if (cost < best) { best = cost; best_v = v; }
   }
   return best_v;
 }
@@ -354,10 +356,8 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.tiles_m = cdiv(d.M, BM); a.tiles_n = cdiv(d.N, BN);
   const int batch = d.batch > 0 ? d.batch : 1;
   const int variant = pick_variant(d.M, d.N, batch);
-  if (variant > 0) {
-    const int bm = variant == 1 ? 128 : variant == 2 ? 160 : variant == 3 ? 192 : 256;
-    a.tiles_m = cdiv(d.M, bm); a.tiles_n = cdiv(d.N, 256);
-  }
+  UVX_CHECK(variant >= 0 && variant < kNumVariants, UVX_ERR_INVALID, "gemm: bad tile variant %d", variant);
+  a.tiles_m = cdiv(d.M, kVariants[variant].bm); a.tiles_n = cdiv(d.N, kVariants[variant].bn);
   dim3 grid(a.tiles_m * a.tiles_n, batch);
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K * batch,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 * batch + (double)d.M * d.N * batch * (d.out_f32 ? 4.0 : 2.0));
