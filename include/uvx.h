@@ -212,6 +212,8 @@ int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, const int64
  * for class 0 = bf16 MFMA GEMM (classes 1.. reserved) and synchronises on the recorded events. */
 int32_t uvx_prof_begin(void);
 int32_t uvx_prof_end(double* out, int32_t n_classes);
+/* per-launch GEMM records of the region (call before uvx_prof_end): out[i*6 + {M,N,K,batch,variant,ms}] */
+int32_t uvx_prof_records(double* out, int32_t max_records);
 
 #ifdef __cplusplus
 }

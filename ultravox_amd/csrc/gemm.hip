@@ -361,6 +361,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   dim3 grid(a.tiles_m * a.tiles_n, batch);
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K * batch,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 * batch + (double)d.M * d.N * batch * (d.out_f32 ? 4.0 : 2.0));
+  if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, batch, variant);
   switch (variant) {
     case 0: hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, st, a); break;
     case 1: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<128>, grid, dim3(512), 0, st, a); break;

@@ -12,6 +12,7 @@ enum DType { DT_BF16 = 0, DT_F32 = 1 };
 enum ProfClass { PROF_GEMM = 0, PROF_ATTN = 1, PROF_OTHER = 2, PROF_NCLASS = 3 };
 void prof_record_begin(hipStream_t st, int cls, double flops, double bytes);
 void prof_record_end(hipStream_t st);
+void prof_tag(int m, int n, int k, int batch, int variant);
 extern bool g_prof_on;
 struct ProfScope {
   hipStream_t st; bool on;

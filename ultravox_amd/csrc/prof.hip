@@ -9,7 +9,7 @@
 namespace uvx {
 bool g_prof_on = false;
 namespace {
-struct Rec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct Rec { hipEvent_t a, b; int cls; double flops, bytes; int m, n, k, batch, variant; };
 std::vector<Rec> g_pool;
 size_t g_used = 0;
 }  // namespace
@@ -21,8 +21,11 @@ void prof_record_begin(hipStream_t st, int cls, double flops, double bytes) {
     g_pool.push_back(r);
   }
   Rec& r = g_pool[g_used];
-  r.cls = cls; r.flops = flops; r.bytes = bytes;
+  r.cls = cls; r.flops = flops; r.bytes = bytes; r.m = r.n = r.k = r.batch = r.variant = 0;
   hipEventRecord(r.a, st);
+}
+void prof_tag(int m, int n, int k, int batch, int variant) {
+  if (g_used < g_pool.size()) { Rec& r = g_pool[g_used]; r.m = m; r.n = n; r.k = k; r.batch = batch; r.variant = variant; }
 }
 void prof_record_end(hipStream_t st) {
   if (g_used < g_pool.size()) hipEventRecord(g_pool[g_used++].b, st);
@@ -33,6 +36,23 @@ extern "C" int32_t uvx_prof_begin(void) {
   uvx::g_used = 0;
   uvx::g_prof_on = true;
   return UVX_OK;
+}
+
+// Per-launch records of the last profiled region (call BEFORE uvx_prof_end): out[i*6 + {M, N, K, batch,
+// variant, ms}] for the first min(count, max_records) GEMM launches; returns the number of records.
+extern "C" int32_t uvx_prof_records(double* out, int32_t max_records) {
+  int n = 0;
+  for (size_t i = 0; i < uvx::g_used && n < max_records; ++i) {
+    auto& r = uvx::g_pool[i];
+    if (r.cls != uvx::PROF_GEMM) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) break;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.a, r.b);
+    double* o = out + (size_t)n * 6;
+    o[0] = r.m; o[1] = r.n; o[2] = r.k; o[3] = r.batch; o[4] = r.variant; o[5] = ms;
+    ++n;
+  }
+  return n;
 }
 
 // out[cls] = {launches, total_ms, total_flops, total_bytes}; synchronises on the recorded events.
