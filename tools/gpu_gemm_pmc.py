@@ -1,0 +1,10 @@
+"""Run ONE GEMM shape with ONE forced tile variant a few times (for rocprofv3 --pmc passes)."""
+import sys, torch
+from ultravox_amd import ops, _lib
+v, M, N, K = (int(x) for x in sys.argv[1:5])
+_lib.lib().uvx_gemm_force_variant(v)
+torch.manual_seed(0)
+a = torch.randn(M, K, device="cuda").bfloat16(); b = torch.randn(N, K, device="cuda").bfloat16()
+out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+for _ in range(4): ops.gemm(a, b, out=out)
+torch.cuda.synchronize()

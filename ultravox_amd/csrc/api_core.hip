@@ -64,7 +64,7 @@ extern "C" int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, 
 
 // Attention with its transposed operand copies carved from the caller's workspace.
 namespace {
-struct AttnWs { void *vt, *qt, *kt, *dot; float* delta; int Tp; size_t bytes; };
+struct AttnWs { void *vt, *qt, *kt, *dot; float* delta; float* part; int Tp; size_t bytes; };
 AttnWs attn_carve(char* base, int dtype, const uvx_attn_desc_t& d, int backward) {
   AttnWs w = {};
   const size_t es = dtype == uvx::DT_BF16 ? 2 : 4;
@@ -77,6 +77,7 @@ AttnWs attn_carve(char* base, int dtype, const uvx_attn_desc_t& d, int backward)
     w.kt = take((size_t)d.B * d.Hkv * d.D * w.Tp * es);
     w.dot = take((size_t)d.B * d.Hq * d.D * w.Tp * es);
     w.delta = (float*)take(sizeof(float) * (size_t)d.B * d.Hq * d.T);
+    w.part = (float*)take(sizeof(float) * 2 * (size_t)d.B * d.T * d.Hq * d.D);
   }
   w.bytes = off + 256;
   return w;
@@ -115,7 +116,7 @@ extern "C" int32_t uvx_attention_bwd(void* stream, int32_t dtype, const uvx_attn
   if ((rc = uvx::heads_transpose(st, dtype, d->dout, w.dot, d->B, d->T, w.Tp, d->Hq, d->D, d->ldo))) return rc;
   uvx::AttnBwdDesc b;
   b.f = to_desc(*d, w);
-  b.dout = d->dout; b.qt = w.qt; b.kt = w.kt; b.dot = w.dot; b.delta = w.delta;
+  b.dout = d->dout; b.qt = w.qt; b.kt = w.kt; b.dot = w.dot; b.delta = w.delta; b.dkv_part = w.part;
   b.dq = d->dq; b.dk = d->dk; b.dv = d->dv; b.lddq = d->lddq; b.lddk = d->lddk; b.lddv = d->lddv;
   return uvx::attention_bwd(st, dtype, b);
 }

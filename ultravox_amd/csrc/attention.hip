@@ -38,6 +38,7 @@ struct AttnArgs {
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
   int lddq, lddk, lddv;
   float scale;
+  float* dkv_part;  // [2][B, T, Hq, D] f32 per-query-head partials (GQA) or null
 };
 
 __device__ __forceinline__ bf16x8_t lds_b128(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
@@ -322,8 +323,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, hk = blockIdx.y, kb0 = blockIdx.x * 64;
-  const int grp = p.Hq / p.Hkv;
+  // With `dkv_part` every block handles ONE query head (grid.y = Hq: 4x the parallelism under GQA) and
+  // writes f32 partials that gqa_reduce_k sums in a fixed order; without it the block loops over its group.
+  const int grp_all = p.Hq / p.Hkv;
+  const bool split = p.dkv_part != nullptr;
+  const int b = blockIdx.z, kb0 = blockIdx.x * 64;
+  const int hk = split ? blockIdx.y / grp_all : blockIdx.y;
+  const int h_first = split ? blockIdx.y : hk * grp_all;
+  const int grp = split ? 1 : grp_all;
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
   const int key = kb0 + w * 16 + fr;  // this lane's key (B-operand column)
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
   TrRegs<D, 32> qtreg, dotreg;
   float lreg = 0.f, dlreg = 0.f;
   auto issue = [&](int it) {
-    const int h = hk * grp + it / nq, qs = q_begin + (it % nq) * 32;
+    const int h = h_first + it / nq, qs = q_begin + (it % nq) * 32;
     load_nat<D, 32>(qreg, p.q + (long long)b * p.T * p.ldq + h * D, p.ldq, qs, p.T, tid);
     load_nat<D, 32>(doreg, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
     load_tr<D, 32>(qtreg, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
@@ -430,7 +437,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
     }
   }
   // accumulators hold dV^T / dK^T: row d = dt*16 + g*4 + e, col key = fr
-  if (key < p.T) {
+  if (split) {
+    if (key < p.T) {
+      float* dkp = p.dkv_part + (((long long)b * p.T + key) * p.Hq + h_first) * D;
+      float* dvp = dkp + (long long)p.B * p.T * p.Hq * D;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        *reinterpret_cast<float4*>(dkp + d * 16 + g * 4) = make_float4(acc_dk[d][0] * p.scale, acc_dk[d][1] * p.scale, acc_dk[d][2] * p.scale, acc_dk[d][3] * p.scale);
+        *reinterpret_cast<float4*>(dvp + d * 16 + g * 4) = make_float4(acc_dv[d][0], acc_dv[d][1], acc_dv[d][2], acc_dv[d][3]);
+      }
+    }
+  } else if (key < p.T) {
     bf16_t* dkrow = p.dk + ((long long)b * p.T + key) * p.lddk + hk * D;
     bf16_t* dvrow = p.dv + ((long long)b * p.T + key) * p.lddv + hk * D;
 #pragma unroll
@@ -552,6 +569,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
   }
 }
 
+// dk/dv[b, t, hk, :] = sum over the GQA group (fixed order) of the f32 per-query-head partials
+__global__ void gqa_reduce_k(const float* __restrict__ part, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int B, int T,
+                             int Hq, int Hkv, int D, int lddk, int lddv) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of one (b, t, hk)
+  const int dv4 = D / 4;
+  const long long n = (long long)B * T * Hkv * dv4;
+  if (i >= n) return;
+  const int c = (int)(i % dv4) * 4, hk = (int)((i / dv4) % Hkv);
+  const long long bt = i / ((long long)dv4 * Hkv);
+  const int grp = Hq / Hkv;
+  const long long half = (long long)B * T * Hq * D;
+  float4 sk = make_float4(0.f, 0.f, 0.f, 0.f), sv = sk;
+  for (int gq = 0; gq < grp; ++gq) {
+    const float* pk = part + (bt * Hq + hk * grp + gq) * D + c;
+    const float4 a = *reinterpret_cast<const float4*>(pk);
+    const float4 v = *reinterpret_cast<const float4*>(pk + half);
+    sk.x += a.x; sk.y += a.y; sk.z += a.z; sk.w += a.w;
+    sv.x += v.x; sv.y += v.y; sv.z += v.z; sv.w += v.w;
+  }
+  u16x4_t ok = {f2bf(sk.x), f2bf(sk.y), f2bf(sk.z), f2bf(sk.w)}, ov = {f2bf(sv.x), f2bf(sv.y), f2bf(sv.z), f2bf(sv.w)};
+  *reinterpret_cast<u16x4_t*>(dk + bt * lddk + hk * D + c) = ok;
+  *reinterpret_cast<u16x4_t*>(dv + bt * lddv + hk * D + c) = ov;
+}
+
 AttnArgs make_args(const uvx::AttnDesc& d) {
   AttnArgs a = {};
   a.q = (const bf16_t*)d.q; a.k = (const bf16_t*)d.k; a.v = (const bf16_t*)d.v; a.vt = (const bf16_t*)d.vt;
@@ -601,17 +642,23 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   a.dout = (const bf16_t*)d.dout; a.qt = (const bf16_t*)d.qt; a.kt = (const bf16_t*)d.kt; a.dot = (const bf16_t*)d.dot;
   a.delta = d.delta; a.dq = (bf16_t*)d.dq; a.dk = (bf16_t*)d.dk; a.dv = (bf16_t*)d.dv;
   a.lddq = d.lddq; a.lddk = d.lddk; a.lddv = d.lddv;
+  a.dkv_part = (d.f.Hq != d.f.Hkv) ? d.dkv_part : nullptr;
   const long long nw = (long long)d.f.B * d.f.T * d.f.Hq;
   hipLaunchKernelGGL(attn_delta_k, dim3(cdiv(nw, 4)), dim3(256), 0, st, a.dout, (const bf16_t*)d.f.o, a.delta, d.f.B, d.f.T,
                      d.f.Hq, d.f.D, d.f.ldo);
   UVX_LAUNCH_CHECK();
-  dim3 gk(cdiv(d.f.T, 64), d.f.Hkv, d.f.B), gq(cdiv(d.f.T, 64), d.f.Hq, d.f.B);
+  dim3 gk(cdiv(d.f.T, 64), a.dkv_part ? d.f.Hq : d.f.Hkv, d.f.B), gq(cdiv(d.f.T, 64), d.f.Hq, d.f.B);
   if (d.f.D == 64) {
     hipLaunchKernelGGL(attn_bwd_dkdv_k<64>, gk, dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dq_k<64>, gq, dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL(attn_bwd_dkdv_k<128>, gk, dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dq_k<128>, gq, dim3(256), 0, st, a);
+  }
+  if (a.dkv_part) {
+    const long long n4 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 4);
+    hipLaunchKernelGGL(gqa_reduce_k, dim3(cdiv(n4, 256)), dim3(256), 0, st, a.dkv_part, a.dk, a.dv, d.f.B, d.f.T, d.f.Hq,
+                       d.f.Hkv, d.f.D, a.lddk, a.lddv);
   }
   UVX_LAUNCH_CHECK();
   return UVX_OK;

@@ -135,6 +135,17 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+// GELU for the bf16 path: Abramowitz-Stegun 7.1.26 erf (|error| <= 1.5e-7, far below the 2^-9 relative
+// rounding of the bf16 store that follows) with hardware rcp / exp2 — ~4x fewer VALU ops than erff();
+// the f32 parity path keeps the exact erff().
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  const float pe = poly * e;                       // = erfc(|x|/sqrt2): no cancellation in the negative tail
+  return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

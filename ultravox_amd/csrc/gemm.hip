@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
         float t = acc[j][i][e] * p.alpha + bv[e];
         if (bf16_out) t = bf2f(f2bf(t));  // the reference rounds the linear output before act/residual
         if (p.act == 1) {
-          t = gelu_erf(t);
+          t = gelu_fast(t);
           if (bf16_out) t = bf2f(f2bf(t));
         }
         v[e] = t;
@@ -284,7 +284,174 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide_kernel(GemmArgs p) {
         float tv = acc[j][i][e] * p.alpha + bv[e];
         if (bf16_out) tv = bf2f(f2bf(tv));
         if (p.act == 1) {
-          tv = gelu_erf(tv);
+          tv = gelu_fast(tv);
+          if (bf16_out) tv = bf2f(f2bf(tv));
+        }
+        v[e] = tv;
+      }
+      if (p.residual) {
+        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+        u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
+      }
+      const long long off = z * p.sC + (long long)m * p.ldc + n;
+      if (bf16_out) {
+        u16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *reinterpret_cast<u16x4_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
+      } else {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off);
+        if (p.accumulate) {
+          float4 c = *dst;
+          v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
+        }
+        *dst = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong kernel: BM x 256 tile, 8 waves (2 x 4), K consumed in 32-wide sub-tiles held in a 4-deep LDS
+// ring (64-byte rows).  The two waves that share a SIMD (w and w+4, i.e. wr = 0 / 1) run ONE INTERVAL
+// OUT OF PHASE: every sub-tile is processed as an L segment (issue the LDS-DMA for sub-tile s+3, read this
+// sub-tile's 12 fragments, counted s_waitcnt) and an M segment (32 MFMAs under s_setprio 1), separated by
+// workgroup barriers; group wr = 1 executes one extra barrier first, so while one wave of a SIMD is in its
+// MFMA segment the other is in its load segment and the matrix pipe never waits for LDS traffic.
+//   RAW: a wave waits for ITS loads of sub-tile s+1 (s_waitcnt vmcnt(2*NL): sub-tiles s+2, s+3 may stay in
+//        flight) in L(s); two barriers separate that from any wave's first read of s+1.
+//   WAR: sub-tile s+3 lands in the buffer of s-1, whose last fragment reads (L(s-1) of either group) were
+//        retired by lgkmcnt(0) before the barrier that precedes this issue.
+// Swizzle for 64-byte rows: chunk position = chunk ^ ((-(row >> 2)) & 3)  (conflict-free ds_read_b128).
+template <int BM>
+__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
+  constexpr int BNW = 256, KS = 32, NBUF = 4;
+  constexpr int MI = BM / 32;
+  constexpr int XB = BM * 64, WB = BNW * 64, SUB = XB + WB;
+  constexpr int XI = BM / 16;               // wave-instructions per X sub-tile (16 rows x 64 B each)
+  constexpr int XPW = (XI + 7) / 8;         // issued by EVERY wave (out-of-range ones hit a dummy slot)
+  constexpr int NL = XPW + 2;               // LDS-DMA instructions per wave per sub-tile
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * SUB + 1024];
+  char* const dummy = lds + NBUF * SUB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BNW;
+  const long long z = blockIdx.y;
+  const bf16_t* A = p.A + z * p.sA;
+  const bf16_t* B = p.B + z * p.sB;
+
+  // staging: instruction q covers tile rows 16q..16q+15; lane -> row 16q + (lane >> 2), chunk position lane & 3
+  const int srow = lane >> 2;
+  const int schunk = (lane & 3) ^ ((-(srow >> 2)) & 3);
+  const bf16_t* ap[XPW];
+  const bf16_t* bp[2];
+#pragma unroll
+  for (int i = 0; i < XPW; ++i) {
+    const int rr = min((i * 8 + w) * 16 + srow, BM - 1);
+    ap[i] = A + (long long)min(m0 + rr, p.M - 1) * p.lda + schunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rr = (i * 8 + w) * 16 + srow;
+    bp[i] = B + (long long)min(n0 + rr, p.N - 1) * p.ldb + schunk * 8;
+  }
+  const int frow = lane & 15, fg = lane >> 4;
+  const int fpos = fg ^ ((-(frow >> 2)) & 3);
+  const int xoff = (wr * (BM / 2) + frow) * 64 + fpos * 16;
+  const int woff = XB + (wc * 64 + frow) * 64 + fpos * 16;
+
+  f32x4_t acc[4][MI];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int s) {
+    char* buf = lds + (s & (NBUF - 1)) * SUB;
+    const int k0 = s * KS;
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+      const int q = i * 8 + w;
+      glds16(ap[i] + k0, q < XI ? buf + q * 1024 : dummy);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(bp[i] + k0, buf + XB + (i * 8 + w) * 1024);
+  };
+#define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+  const int ns = p.K / KS;
+  issue(0);
+  if (ns > 1) issue(1);
+  if (ns > 2) issue(2);
+  if (ns > 2) UVX_VMCNT(2 * NL);
+  else if (ns > 1) UVX_VMCNT(NL);
+  else UVX_VMCNT(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: this half runs one interval behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int s = 0; s < ns; ++s) {
+    // ---- L segment ----
+    const char* cur = lds + (s & (NBUF - 1)) * SUB;
+    if (s + 3 < ns) issue(s + 3);
+    bf16x8_t xa[MI], wa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wa[j] = *reinterpret_cast<const bf16x8_t*>(cur + woff + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8_t*>(cur + xoff + i * 16 * 64);
+    if (s + 3 < ns) UVX_VMCNT(2 * NL);
+    else if (s + 2 < ns) UVX_VMCNT(NL);
+    else UVX_VMCNT(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M segment ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[j][i], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
+#undef UVX_VMCNT
+
+  const bool bf16_out = !p.out_f32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + fg * 4;
+    if (n >= p.N) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wr * (BM / 2) + i * 16 + frow;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float tv = acc[j][i][e] * p.alpha + bv[e];
+        if (bf16_out) tv = bf2f(f2bf(tv));
+        if (p.act == 1) {
+          tv = gelu_fast(tv);
           if (bf16_out) tv = bf2f(f2bf(tv));
         }
         v[e] = tv;
@@ -318,9 +485,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide_kernel(GemmArgs p) {
 // MI355X (profiles/r01_gemm_variants.txt).  variant 0 = 128x128 narrow; 1..4 = {128,160,192,256} x 256 wide.
 // (A 32x32x16-MFMA flavour of the wide kernel was measured 10-20 % SLOWER than 16x16x32 and dropped.)
 struct Variant { int bm, bn; double speed; };
-constexpr int kNumVariants = 5;
+// 5..8 = ping-pong {128,160,192,256} x 256.  (Also measured and dropped, profiles/r01_gemm_variants.txt: a
+// 32x32x16-MFMA flavour, 10-20 % slower; a 4-wave kernel with 128x128 wave tiles in the 512-register file — the
+// geometry hipBLASLt's hand-scheduled MT256x256x64 kernel uses — 30-60 % slower under hipcc's scheduling.)
+constexpr int kNumVariants = 9;
 const Variant kVariants[kNumVariants] = {{128, 128, 850.}, {128, 256, 870.}, {160, 256, 1010.}, {192, 256, 1050.},
-                                         {256, 256, 1080.}};
+                                         {256, 256, 1085.}, {128, 256, 860.}, {160, 256, 985.}, {192, 256, 980.},
+                                         {256, 256, 1090.}};
 int pick_variant(int M, int N, int batch) {
   const int forced = uvx::g_gemm_variant;
   if (forced >= 0) return forced;
@@ -367,7 +538,11 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
     case 1: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<128>, grid, dim3(512), 0, st, a); break;
     case 2: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<160>, grid, dim3(512), 0, st, a); break;
     case 3: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<192>, grid, dim3(512), 0, st, a); break;
-    default: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<256>, grid, dim3(512), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<256>, grid, dim3(512), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<128>, grid, dim3(512), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<160>, grid, dim3(512), 0, st, a); break;
+    case 7: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<192>, grid, dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), 0, st, a); break;
   }
   UVX_LAUNCH_CHECK();
   return UVX_OK;

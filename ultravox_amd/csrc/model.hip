@@ -137,6 +137,7 @@ struct LlmWs {
   // backward
   void *dx, *d_hn, *d_act, *d_gu, *d_n, *d_o, *d_qkv, *qT, *kT, *doT;
   float* delta;
+  float* dkv_part;
   int M, Tp, QKV, OD;
 };
 void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
@@ -188,6 +189,7 @@ LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
     w.kT = a.take((size_t)B * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
     w.doT = a.take((size_t)B * c.llm_heads * c.llm_head_dim * w.Tp * es);
     w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.llm_heads * T);
+    w.dkv_part = (float*)a.take(sizeof(float) * 2 * M * w.OD);
   }
   return w;
 }
@@ -542,7 +544,7 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
     ad.B = B; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
     ad.scale = 1.0f / sqrtf((float)dh);
-    bd.dout = s.d_o; bd.qt = s.qT; bd.kt = s.kT; bd.dot = s.doT; bd.delta = s.delta;
+    bd.dout = s.d_o; bd.qt = s.qT; bd.kt = s.kT; bd.dot = s.doT; bd.delta = s.delta; bd.dkv_part = s.dkv_part;
     bd.dq = s.d_qkv; bd.dk = at(s.d_qkv, (size_t)Hq * dh, dt); bd.dv = at(s.d_qkv, (size_t)(Hq + Hkv) * dh, dt);
     bd.lddq = bd.lddk = bd.lddv = s.QKV;
     RC(attention_bwd(st, dt, bd));
