@@ -17,10 +17,7 @@ CSRC = PKG / "csrc"
 OBJ = CSRC / "build"
 LIB = PKG / "libuvx.so"
 ARCH = "gfx950"
-# -pragma-unroll-threshold: the 8x8-fragment GEMM epilogue must be FULLY unrolled or its accumulator array
-# (256 registers) falls back to scratch memory
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
-         "-mllvm", "-pragma-unroll-threshold=200000"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:

@@ -213,33 +213,49 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
       }
 
     // ---- online softmax (per lane: q = fr; keys kb + kt*16 + g*4 + e) ----
+    // A tile needs per-element masking only at the edges (padding, diagonal, latency-block boundary); the
+    // test is wave-uniform, so interior tiles skip all of the integer mask arithmetic.
+    bool need_mask = kb < k_lo || kb + 64 > k_hi;
+    if (p.causal) need_mask = need_mask || kb + 63 > q0;
+    if (p.block > 0) need_mask = need_mask || (kb + 63) / p.block > q0 / p.block;
     bf16x8_t pf[QT][2];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       const int q = q0 + t * 16 + fr;
       float mx = NEG_INF;
+      if (need_mask) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int key = kb + kt * 16 + g * 4 + e;
-          float v = s[t][kt][e] * p.sc;
-          v = key_ok(key, q, k_lo, k_hi, p.causal, p.block) ? v : NEG_INF;
-          s[t][kt][e] = v;
-          mx = fmaxf(mx, v);
-        }
+          for (int e = 0; e < 4; ++e) {
+            const int key = kb + kt * 16 + g * 4 + e;
+            float v = s[t][kt][e] * p.sc;
+            v = key_ok(key, q, k_lo, k_hi, p.causal, p.block) ? v : NEG_INF;
+            s[t][kt][e] = v;
+            mx = fmaxf(mx, v);
+          }
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = s[t][kt][e] * p.sc;
+            s[t][kt][e] = v;
+            mx = fmaxf(mx, v);
+          }
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[t], mx);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = exp2f(m_run[t] - m_use);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_use);
       m_run[t] = m_new;
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float pv = exp2f(s[t][kt][e] - m_use);
+          const float pv = __builtin_amdgcn_exp2f(s[t][kt][e] - m_use);  // raw v_exp_f32: args <= 0
           s[t][kt][e] = pv;
           ps += pv;
         }
@@ -411,14 +427,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
       }
       // accumulator element e of tile t: q = qs + t*16 + g*4 + e, key = this lane's key
       float pr[2][4], ds[2][4];
+      const int key_w0 = kb0 + w * 16;  // this wave's 16 keys
+      bool need_mask = key_w0 < k_lo || key_w0 + 16 > k_hi || qs + 32 > p.T;
+      if (p.causal) need_mask = need_mask || key_w0 + 15 > qs;
+      if (p.block > 0) need_mask = need_mask || (key_w0 + 15) / p.block > qs / p.block;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int ql = t * 16 + g * 4 + e;
           const int q = qs + ql;
-          const bool ok = q < p.T && key_ok(key, q, k_lo, k_hi, p.causal, p.block);
-          const float pv = ok ? exp2f(s[t][e] * p.sc - ldsL[ql]) : 0.f;
+          bool ok = true;
+          if (need_mask) ok = q < p.T && key_ok(key, q, k_lo, k_hi, p.causal, p.block);
+          const float pv = ok ? __builtin_amdgcn_exp2f(s[t][e] * p.sc - ldsL[ql]) : 0.f;
           pr[t][e] = pv;
           ds[t][e] = pv * (dp[t][e] - ldsDl[ql]);
         }
@@ -538,13 +559,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
       }
     }
     float ds[2][4];
+    const int q_w0 = qb0 + w * 16;  // this wave's 16 queries
+    bool need_mask = ks0 < k_lo || ks0 + 32 > k_hi || q_w0 + 16 > p.T;
+    if (p.causal) need_mask = need_mask || ks0 + 31 > q_w0;
+    if (p.block > 0) need_mask = need_mask || (ks0 + 31) / p.block > q_w0 / p.block;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int key = ks0 + t * 16 + g * 4 + e;
-        const bool ok = q < p.T && key_ok(key, q, k_lo, k_hi, p.causal, p.block);
-        const float pv = ok ? exp2f(s[t][e] * p.sc - lse) : 0.f;
+        bool ok = true;
+        if (need_mask) ok = q < p.T && key_ok(key, q, k_lo, k_hi, p.causal, p.block);
+        const float pv = ok ? __builtin_amdgcn_exp2f(s[t][e] * p.sc - lse) : 0.f;
         ds[t][e] = pv * (dp[t][e] - dl);
       }
     const bf16x8_t dsB = pack8(ds[0], ds[1]);
