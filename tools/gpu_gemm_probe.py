@@ -8,7 +8,7 @@ torch.manual_seed(0)
 dev = "cuda"
 L = _lib.lib()
 res = {"checks": [], "perf": []}
-VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+VARIANTS = [1, 2, 4, 6, 8, 9, 10]
 
 def check(v, M, N, K):
     L.uvx_gemm_force_variant(v)
@@ -56,4 +56,4 @@ L.uvx_gemm_force_variant(-1)
 print(json.dumps(res))
 print("ALL_OK" if all(c["ok"] for c in res["checks"]) else "SOME_FAILED")
 for r in res["perf"]:
-    print(f"{r['M']:6d} {r['N']:7d} {r['K']:7d} | " + " ".join(f"{k}={r[k]:7.1f}" for k in ["v0","v1","v2","v3","v4","v5","v6","v7","v8","auto","torch"]))
+    print(f"{r['M']:6d} {r['N']:7d} {r['K']:7d} | " + " ".join(f"{k}={r[k]:7.1f}" for k in ["v1","v2","v4","v6","v8","v9","v10","auto","torch"]))

@@ -55,6 +55,10 @@ __host__ __device__ __forceinline__ float bf2f(bf16_t v) {
   return __builtin_bit_cast(float, (uint32_t)v << 16);
 }
 __host__ __device__ __forceinline__ bf16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // native conversion: hipcc lowers this to v_cvt_pk_bf16_f32 (round-to-nearest-even), pairing neighbours
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
   uint32_t u = __builtin_bit_cast(uint32_t, f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
   u += 0x7fffu + ((u >> 16) & 1u);

@@ -480,6 +480,152 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Three-buffer flavour of the wide kernel (BM <= 160 so that 3 x (BM + 256) x 128 B fits the 160 KiB LDS):
+// the LDS-DMA runs TWO K-tiles ahead and is waited for with a counted s_waitcnt vmcnt(NL) (the most recent
+// tile stays in flight across the barrier), giving operand delivery ~2x the latency budget of the
+// double-buffered kernel.  Every wave issues the same number of DMA instructions (out-of-range X rows go to
+// a dummy slot) so the counted wait is exact.
+template <int BM>
+__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide3_kernel(GemmArgs p) {
+  constexpr int BNW = 256;
+  constexpr int MI = BM / 32;
+  constexpr int XB = BM * 128, WB = BNW * 128, BUF = XB + WB;
+  constexpr int XI = BM / 8, XPW = (XI + 7) / 8, NL = XPW + 4;
+  __shared__ __attribute__((aligned(16))) char lds[3 * BUF + 1024];
+  char* const dummy = lds + 3 * BUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BNW;
+  const long long z = blockIdx.y;
+  const bf16_t* A = p.A + z * p.sA;
+  const bf16_t* B = p.B + z * p.sB;
+
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const bf16_t* ap[XPW];
+  const bf16_t* bp[4];
+#pragma unroll
+  for (int i = 0; i < XPW; ++i) {
+    const int rr = min((i * 8 + w) * 8 + srow, BM - 1);
+    ap[i] = A + (long long)min(m0 + rr, p.M - 1) * p.lda + schunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = (i * 8 + w) * 8 + srow;
+    bp[i] = B + (long long)min(n0 + rr, p.N - 1) * p.ldb + schunk * 8;
+  }
+  const int frow = lane & 15, fg = lane >> 4;
+  int xoff[2], woff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int pos = (ks * 4 + fg) ^ (frow & 7);
+    xoff[ks] = (wr * (BM / 2) + frow) * 128 + pos * 16;
+    woff[ks] = XB + (wc * 64 + frow) * 128 + pos * 16;
+  }
+  f32x4_t acc[4][MI];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int t) {
+    char* buf = lds + (t % 3) * BUF;
+    const int k0 = t * BK;
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+      const int q = i * 8 + w;
+      glds16(ap[i] + k0, q < XI ? buf + q * 1024 : dummy);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(bp[i] + k0, buf + XB + (i * 8 + w) * 1024);
+  };
+#define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+  const int nt = p.K / BK;
+  stage(0);
+  if (nt > 1) { stage(1); UVX_VMCNT(NL); } else { UVX_VMCNT(0); }
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < nt; ++t) {
+    const char* cur = lds + (t % 3) * BUF;
+    if (t + 2 < nt) stage(t + 2);   // into the buffer read in iteration t-1 (every wave is past that barrier)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t xa[MI], wa[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wa[j] = *reinterpret_cast<const bf16x8_t*>(cur + woff[ks] + j * 16 * 128);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8_t*>(cur + xoff[ks] + i * 16 * 128);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[j][i], 0, 0, 0);
+    }
+    // tile t+1 (issued one iteration ago) must have landed; tile t+2 may stay in flight
+    if (t + 2 < nt) UVX_VMCNT(NL); else UVX_VMCNT(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef UVX_VMCNT
+
+  const bool bf16_out = !p.out_f32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + fg * 4;
+    if (n >= p.N) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wr * (BM / 2) + i * 16 + frow;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float tv = acc[j][i][e] * p.alpha + bv[e];
+        if (bf16_out) tv = bf2f(f2bf(tv));
+        if (p.act == 1) {
+          tv = gelu_fast(tv);
+          if (bf16_out) tv = bf2f(f2bf(tv));
+        }
+        v[e] = tv;
+      }
+      if (p.residual) {
+        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+        u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
+      }
+      const long long off = z * p.sC + (long long)m * p.ldc + n;
+      if (bf16_out) {
+        u16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *reinterpret_cast<u16x4_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
+      } else {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off);
+        if (p.accumulate) {
+          float4 c = *dst;
+          v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
+        }
+        *dst = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
 // Tile choice.  Every CU works through ceil(tiles / 256) tiles (few rounds) or ~tiles/256 + 0.4 (many
 // rounds, dynamic dispatch smooths the tail); a tile costs BM x BN / speed(variant), speeds measured on
 // MI355X (profiles/r01_gemm_variants.txt).  variant 0 = 128x128 narrow; 1..4 = {128,160,192,256} x 256 wide.
@@ -488,20 +634,23 @@ struct Variant { int bm, bn; double speed; };
 // 5..8 = ping-pong {128,160,192,256} x 256.  (Also measured and dropped, profiles/r01_gemm_variants.txt: a
 // 32x32x16-MFMA flavour, 10-20 % slower; a 4-wave kernel with 128x128 wave tiles in the 512-register file — the
 // geometry hipBLASLt's hand-scheduled MT256x256x64 kernel uses — 30-60 % slower under hipcc's scheduling.)
-constexpr int kNumVariants = 9;
+constexpr int kNumVariants = 11;  // 9, 10 = three-buffer {128,160} x 256 (speed 0: probe only)
 const Variant kVariants[kNumVariants] = {{128, 128, 850.}, {128, 256, 870.}, {160, 256, 1010.}, {192, 256, 1050.},
                                          {256, 256, 1085.}, {128, 256, 860.}, {160, 256, 985.}, {192, 256, 980.},
-                                         {256, 256, 1090.}};
-int pick_variant(int M, int N, int batch) {
+                                         {256, 256, 1090.}, {128, 256, 0.}, {160, 256, 0.}};
+int pick_variant(int M, int N, int K, int batch) {
   const int forced = uvx::g_gemm_variant;
   if (forced >= 0) return forced;
   double best = 1e30;
   int best_v = 0;
   for (int v = 0; v < kNumVariants; ++v) {
+    double speed = kVariants[v].speed;
+    if (v == 10) speed = K >= 16384 ? 1100. : 980.;  // three-buffer 160x256: +15 % on very deep K, -3 % otherwise (measured)
+    if (speed <= 0.) continue;
     const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
     const double r = tiles / 256.0;
     const double rounds = r <= 4.0 ? ceil(r) : r + 0.4;
-    const double cost = rounds * kVariants[v].bm * kVariants[v].bn / kVariants[v].speed;
+    const double cost = rounds * kVariants[v].bm * kVariants[v].bn / speed;
     if (cost < best) { best = cost; best_v = v; }
   }
   return best_v;
@@ -526,7 +675,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.act = d.act; a.out_f32 = d.out_f32; a.accumulate = d.accumulate; a.alpha = d.alpha;
   a.tiles_m = cdiv(d.M, BM); a.tiles_n = cdiv(d.N, BN);
   const int batch = d.batch > 0 ? d.batch : 1;
-  const int variant = pick_variant(d.M, d.N, batch);
+  const int variant = pick_variant(d.M, d.N, d.K, batch);
   UVX_CHECK(variant >= 0 && variant < kNumVariants, UVX_ERR_INVALID, "gemm: bad tile variant %d", variant);
   a.tiles_m = cdiv(d.M, kVariants[variant].bm); a.tiles_n = cdiv(d.N, kVariants[variant].bn);
   dim3 grid(a.tiles_m * a.tiles_n, batch);
@@ -542,7 +691,9 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
     case 5: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<128>, grid, dim3(512), 0, st, a); break;
     case 6: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<160>, grid, dim3(512), 0, st, a); break;
     case 7: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<192>, grid, dim3(512), 0, st, a); break;
-    default: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), 0, st, a); break;
+    case 9: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<128>, grid, dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<160>, grid, dim3(512), 0, st, a); break;
   }
   UVX_LAUNCH_CHECK();
   return UVX_OK;
