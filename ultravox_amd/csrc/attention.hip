@@ -71,18 +71,18 @@ __device__ __forceinline__ int nat_off(int row, int chunk) {
   constexpr int NCH = D / 8;
   return row * (D * 2) + ((chunk ^ (row & (NCH - 1))) << 4);
 }
-// "transposed" tile: rows of W keys (W = 64 or 32) = W*2 bytes, 8-byte chunk c8.
+// "transposed" tile: D rows of W keys (W = 64 or 32) = W*2 bytes per row, addressed in 8-byte chunks c8 and
+// XOR-swizzled with tr_sw(row).  The swizzle is chosen to be conflict-free for BOTH forms hipcc may emit
+// for the paired 8-byte fragment reads: plain ds_read_b64 (2 x 32 lanes, bank = (addr/4) mod 64) and the
+// merged ds_read2st64_b64 (contiguous 16-lane groups, bank = (addr/4) mod 32).  An odd swizzle swaps the two
+// 8-byte halves of a 16-byte chunk, which the 16-byte staging store mirrors in registers.
+template <int W>
+__device__ __forceinline__ int tr_sw(int row) { return W == 64 ? (row & 15) : ((row >> 1) & 7); }
 template <int W>
 __device__ __forceinline__ int tr_off8(int row, int c8) {
   constexpr int M8 = W / 4 - 1;  // chunk index mask
-  return row * (W * 2) + (((c8 ^ (((row >> 1) & 7) << 1)) & M8) << 3);
+  return row * (W * 2) + (((c8 ^ tr_sw<W>(row)) & M8) << 3);
 }
-template <int W>
-__device__ __forceinline__ int tr_off16(int row, int c16) {
-  constexpr int M16 = W / 8 - 1;
-  return row * (W * 2) + (((c16 ^ ((row >> 1) & 7)) & M16) << 4);
-}
-
 // Register-staged tiles (async-STAGE split): the global loads of tile j+1 are ISSUED before the MFMA work
 // of tile j and written to the other LDS buffer after it, so HBM/L2 latency hides under compute and
 // there is one barrier per tile.
@@ -127,7 +127,10 @@ __device__ __forceinline__ void store_tr(char* lds, const TrRegs<D, W>& g, int t
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int i = tid + k * 256, r = i / NC, c = i % NC;
-    *reinterpret_cast<u16x8_t*>(lds + tr_off16<W>(r, c)) = g.v[k];
+    const int sw = tr_sw<W>(r);
+    u16x8_t v = g.v[k];
+    if (sw & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+    *reinterpret_cast<u16x8_t*>(lds + r * (W * 2) + (((c ^ (sw >> 1)) & (NC - 1)) << 4)) = v;
   }
 }
 
@@ -223,14 +226,15 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
     for (int t = 0; t < QT; ++t) {
       const int q = q0 + t * 16 + fr;
       float mx = NEG_INF;
+      // scores stay RAW (unscaled) in s[][]; sc > 0, so the row max commutes with the scale and the scale
+      // is folded into the exp2 argument as one fma per element
       if (need_mask) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int key = kb + kt * 16 + g * 4 + e;
-            float v = s[t][kt][e] * p.sc;
-            v = key_ok(key, q, k_lo, k_hi, p.causal, p.block) ? v : NEG_INF;
+            const float v = key_ok(key, q, k_lo, k_hi, p.causal, p.block) ? s[t][kt][e] : NEG_INF;
             s[t][kt][e] = v;
             mx = fmaxf(mx, v);
           }
@@ -238,16 +242,14 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = s[t][kt][e] * p.sc;
-            s[t][kt][e] = v;
-            mx = fmaxf(mx, v);
-          }
+          for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[t][kt][e]);
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx *= p.sc;  // (-inf stays -inf)
       const float m_new = fmaxf(m_run[t], mx);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const bool changed = m_new != m_run[t];
       const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_use);
       m_run[t] = m_new;
       float ps = 0.f;
@@ -255,13 +257,15 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(s[t][kt][e] - m_use);  // raw v_exp_f32: args <= 0
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][kt][e], p.sc, -m_use));  // raw v_exp_f32: args <= 0
           s[t][kt][e] = pv;
           ps += pv;
         }
       l_run[t] = l_run[t] * alpha + ps;
+      if (__any(changed)) {  // wave-uniform: once the running max has settled the O rescale is skipped (alpha == 1 exactly)
 #pragma unroll
-      for (int d = 0; d < DT; ++d) acc_o[t][d] *= alpha;
+        for (int d = 0; d < DT; ++d) acc_o[t][d] *= alpha;
+      }
       float lo[4], hi[4];
 #pragma unroll
       for (int kp = 0; kp < 2; ++kp) {

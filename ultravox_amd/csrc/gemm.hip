@@ -20,7 +20,7 @@
 #include "common.h"
 #include "kernels.h"
 
-namespace uvx { int g_gemm_variant = -1; }  // -1 = automatic; tests / probes may force a tile variant
+namespace uvx { int g_gemm_variant = -1; int g_gemm_split = 1; }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
 
@@ -638,22 +638,47 @@ constexpr int kNumVariants = 11;  // 9, 10 = three-buffer {128,160} x 256 (speed
 const Variant kVariants[kNumVariants] = {{128, 128, 850.}, {128, 256, 870.}, {160, 256, 1010.}, {192, 256, 1050.},
                                          {256, 256, 1085.}, {128, 256, 860.}, {160, 256, 985.}, {192, 256, 980.},
                                          {256, 256, 1090.}, {128, 256, 0.}, {160, 256, 0.}};
-int pick_variant(int M, int N, int K, int batch) {
+double variant_speed(int v, int K) {
+  if (v == 10) return K >= 16384 ? 1100. : 980.;  // three-buffer 160x256: +15 % on very deep K, -3 % otherwise (measured)
+  return kVariants[v].speed;
+}
+double variant_cost(int v, int M, int N, int K, int batch) {
+  const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
+  const double r = tiles / 256.0;
+  const double rounds = r <= 4.0 ? ceil(r) : r + 0.4;
+  return rounds * kVariants[v].bm * kVariants[v].bn / variant_speed(v, K);
+}
+int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
   const int forced = uvx::g_gemm_variant;
-  if (forced >= 0) return forced;
   double best = 1e30;
   int best_v = 0;
   for (int v = 0; v < kNumVariants; ++v) {
-    double speed = kVariants[v].speed;
-    if (v == 10) speed = K >= 16384 ? 1100. : 980.;  // three-buffer 160x256: +15 % on very deep K, -3 % otherwise (measured)
-    if (speed <= 0.) continue;
-    const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
-    const double r = tiles / 256.0;
-    const double rounds = r <= 4.0 ? ceil(r) : r + 0.4;
-    const double cost = rounds * kVariants[v].bm * kVariants[v].bn / speed;
+    if (forced >= 0 && v != forced) continue;
+    if (forced < 0 && variant_speed(v, K) <= 0.) continue;
+    const double cost = variant_cost(v, M, N, K, batch);
     if (cost < best) { best = cost; best_v = v; }
   }
+  if (cost_out) *cost_out = best;
   return best_v;
+}
+
+void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int batch) {
+  a.M = M; a.N = N;
+  a.tiles_m = cdiv(M, kVariants[variant].bm); a.tiles_n = cdiv(N, kVariants[variant].bn);
+  dim3 grid(a.tiles_m * a.tiles_n, batch);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<128>, grid, dim3(512), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<160>, grid, dim3(512), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<192>, grid, dim3(512), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<256>, grid, dim3(512), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<128>, grid, dim3(512), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<160>, grid, dim3(512), 0, st, a); break;
+    case 7: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<192>, grid, dim3(512), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), 0, st, a); break;
+    case 9: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<128>, grid, dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<160>, grid, dim3(512), 0, st, a); break;
+  }
 }
 
 }  // namespace
@@ -673,27 +698,38 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.res_mod = d.res_mod;
   a.sA = d.sA; a.sB = d.sB; a.sC = d.sC; a.sR = d.sR;
   a.act = d.act; a.out_f32 = d.out_f32; a.accumulate = d.accumulate; a.alpha = d.alpha;
-  a.tiles_m = cdiv(d.M, BM); a.tiles_n = cdiv(d.N, BN);
   const int batch = d.batch > 0 ? d.batch : 1;
-  const int variant = pick_variant(d.M, d.N, d.K, batch);
+  double cost_whole = 0.;
+  const int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole);
   UVX_CHECK(variant >= 0 && variant < kNumVariants, UVX_ERR_INVALID, "gemm: bad tile variant %d", variant);
-  a.tiles_m = cdiv(d.M, kVariants[variant].bm); a.tiles_n = cdiv(d.N, kVariants[variant].bn);
-  dim3 grid(a.tiles_m * a.tiles_n, batch);
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K * batch,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 * batch + (double)d.M * d.N * batch * (d.out_f32 ? 4.0 : 2.0));
-  if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, batch, variant);
-  switch (variant) {
-    case 0: hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, st, a); break;
-    case 1: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<128>, grid, dim3(512), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<160>, grid, dim3(512), 0, st, a); break;
-    case 3: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<192>, grid, dim3(512), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<256>, grid, dim3(512), 0, st, a); break;
-    case 5: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<128>, grid, dim3(512), 0, st, a); break;
-    case 6: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<160>, grid, dim3(512), 0, st, a); break;
-    case 7: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<192>, grid, dim3(512), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), 0, st, a); break;
-    case 9: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<128>, grid, dim3(512), 0, st, a); break;
-    default: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<160>, grid, dim3(512), 0, st, a); break;
+  // Tail split (tile-quantisation fix): when the last round of big tiles would leave most CUs idle, the
+  // trailing weight panels (a column range of C) are computed by a second launch with its own best variant.
+  const Variant& V = kVariants[variant];
+  const int tm = cdiv(d.M, V.bm), tn = cdiv(d.N, V.bn);
+  const long long tiles = (long long)tm * tn;
+  int n_main = d.N, tail_variant = -1;
+  if (batch == 1 && uvx::g_gemm_split && tiles > 256 && tiles % 256 != 0) {
+    const int full_rounds = (int)(tiles / 256);
+    const int main_panels = (int)((full_rounds * 256LL) / tm);           // whole weight panels in the full rounds
+    const int tail_n = d.N - main_panels * V.bn;
+    if (main_panels > 0 && tail_n > 0) {
+      double cost_tail = 0.;
+      const int tv = pick_variant(d.M, tail_n, d.K, 1, &cost_tail);
+      const double cost_split = variant_cost(variant, d.M, main_panels * V.bn, d.K, 1) + cost_tail;
+      if (cost_split < 0.93 * cost_whole) { n_main = main_panels * V.bn; tail_variant = tv; }
+    }
+  }
+  if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, batch, tail_variant >= 0 ? 100 + variant : variant);
+  launch_variant(st, variant, a, d.M, n_main, batch);
+  if (tail_variant >= 0) {
+    GemmArgs t = a;
+    t.B = a.B + (long long)n_main * a.ldb;
+    if (a.bias) t.bias = a.bias + n_main;
+    if (a.residual) t.residual = a.residual + n_main;
+    t.C = a.out_f32 ? (void*)((float*)a.C + n_main) : (void*)((bf16_t*)a.C + n_main);
+    launch_variant(st, tail_variant, t, d.M, d.N - n_main, 1);
   }
   UVX_LAUNCH_CHECK();
   return UVX_OK;
