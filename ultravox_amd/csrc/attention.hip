@@ -86,7 +86,7 @@ __device__ __forceinline__ int tr_off8(int row, int c8) {
 // Register-staged tiles (async-STAGE split): the global loads of tile j+1 are ISSUED before the MFMA work
 // of tile j and written to the other LDS buffer after it, so HBM/L2 latency hides under compute and
 // there is one barrier per tile.
-// natural tile: rows [r0, r0+R) of a [*, ld] matrix, D columns; rows >= rmax read as zero.
+// natural tile: rows [r0, r0+R) of a [*, ld] matrix, D columns (rows clamped to rmax-1).
 template <int D, int R>
 struct NatRegs { u16x8_t v[R * (D / 8) / 256]; };
 template <int D, int R>
@@ -95,9 +95,10 @@ __device__ __forceinline__ void load_nat(NatRegs<D, R>& g, const bf16_t* base, l
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int i = tid + k * 256, r = i / NCH, c = i % NCH;
-    u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r0 + r < rmax) v = *reinterpret_cast<const u16x8_t*>(base + (long long)(r0 + r) * ld + c * 8);
-    g.v[k] = v;
+    // UNCONDITIONAL load of a clamped row: a fixed number of VMEM ops per iteration lets hipcc place counted
+    // s_waitcnt vmcnt(N) instead of draining the prefetch with vmcnt(0); rows >= rmax repeat row rmax-1 and are
+    // always masked out by the callers (they are finite, so 0 * x stays 0)
+    g.v[k] = *reinterpret_cast<const u16x8_t*>(base + (long long)min(r0 + r, rmax - 1) * ld + c * 8);
   }
 }
 template <int D, int R>
@@ -194,11 +195,11 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   for (int kb = kb_begin; kb < kb_end; kb += 64, cur ^= 1) {
     const char* ldsK = ldsKV + cur * 2 * TILE;
     const char* ldsV = ldsK + TILE;
-    const bool has_next = kb + 64 < kb_end;
-    if (has_next) {  // issue next tile's global loads now; they land while this tile computes
-      load_nat<D, 64>(kreg, kbase, p.ldk, kb + 64, p.T, tid);
-      load_tr<D, 64>(vreg, vtbase, p.Tp, kb + 64, tid);
-    }
+    // issue the next tile's global loads now; they land while this tile computes (the last iteration re-loads
+    // its own tile: branch-free, so the VMEM count per iteration is static)
+    const int kn = kb + 64 < kb_end ? kb + 64 : kb;
+    load_nat<D, 64>(kreg, kbase, p.ldk, kn, p.T, tid);
+    load_tr<D, 64>(vreg, vtbase, p.Tp, kn, tid);
 
     // ---- S^T = K . Q^T ----
     f32x4_t s[QT][4];
@@ -285,10 +286,9 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) acc_o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][kp], acc_o[t][d], 0, 0, 0);
       }
-    if (has_next) {  // the other buffer was last read one iteration ago, before the previous barrier
-      store_nat<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE, kreg, tid);
-      store_tr<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE + TILE, vreg, tid);
-    }
+    // the other buffer was last read one iteration ago, before the previous barrier
+    store_nat<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE, kreg, tid);
+    store_tr<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE + TILE, vreg, tid);
     __syncthreads();
   }
 
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
       const char* ldsDOT = ldsQ + 3 * TILE;
       const float* ldsL = ldsStat + cur * 64;
       const float* ldsDl = ldsL + 32;
-      if (it + 1 < n_it) issue(it + 1);
+      issue(it + 1 < n_it ? it + 1 : it);
 
       // S[q][key] and dP[q][key] for the two 16-query tiles: A = Q / dO rows, B = K / V fragments
       f32x4_t s[2], dp[2];
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
         acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB, acc_dv[d], 0, 0, 0);
         acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB, acc_dk[d], 0, 0, 0);
       }
-      if (it + 1 < n_it) commit(cur ^ 1);
+      commit(cur ^ 1);
       __syncthreads();
     }
   }
@@ -548,8 +548,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
     const char* ldsK = ldsAll + cur * 3 * TILE;
     const char* ldsV = ldsK + TILE;
     const char* ldsKT = ldsK + 2 * TILE;
-    const bool has_next = ks0 + 32 < kend;
-    if (has_next) issue(ks0 + 32);
+    issue(ks0 + 32 < kend ? ks0 + 32 : ks0);
     f32x4_t s[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -584,7 +583,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
       const bf16x8_t a = lds_2xb64(ldsKT + tr_off8<32>(row, g), ldsKT + tr_off8<32>(row, 4 + g));
       acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB, acc[d], 0, 0, 0);  // dQ^T[d][q]
     }
-    if (has_next) commit(cur ^ 1);
+    commit(cur ^ 1);
     __syncthreads();
   }
   if (q < p.T) {
