@@ -203,3 +203,67 @@ def test_llm_input_gradient_matches_oracle():
     loss.backward()
     assert abs(out.loss.item() - loss.item()) < 2e-2 * loss.item()
     assert rel_l2(d, e.grad) < 6e-2
+
+
+def test_processor_collator_model_end_to_end_ragged_batch():
+    """Whole reference call chain on ragged input: UltravoxProcessor (log-mel ON DEVICE, chunking of a 35 s clip
+    into 2 encoder items, placeholder expansion) -> DataCollatorForSeq2SeqWithAudio (right padding, a text-only
+    sample with audio_batch_size 0, audio right-padded to the longest item) -> UltravoxModel.forward, against
+    the oracle fed with the same batch."""
+    from fake_tokenizer import FakeTokenizer
+    from oracle.reference_cpu import FeatureExtractorRef
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.processing import DataCollatorForSeq2SeqWithAudio, UltravoxProcessor
+    cfg, sd, model, oracle = build(8)
+    tok = FakeTokenizer()
+    proc = UltravoxProcessor(WhisperFeatureExtractor(80, device=DEV), tokenizer=tok)
+    proc_ref = UltravoxProcessor(FeatureExtractorRef(80), tokenizer=FakeTokenizer())
+    rng = np.random.RandomState(5)
+    clips = [rng.randn(16000 * 35).astype(np.float32) * 0.1, rng.randn(16000 * 3 + 77).astype(np.float32) * 0.1]
+    samples = [("Describe <|audio|> please now", [clips[0]]), ("no audio in this one at all", []),
+               ("two words <|audio|>", [clips[1]])]
+    feats, feats_ref = [], []
+    for text, aud in samples:
+        for P, out in ((proc, feats), (proc_ref, feats_ref)):
+            kw = dict(audios=aud, sampling_rate=16000) if aud else {}
+            r = P(text, **kw)
+            f = {k: (v[0] if k in ("input_ids", "attention_mask") else v) for k, v in r.items()}
+            ids = f["input_ids"] % 512          # fold the fake token ids into the tiny vocabulary
+            f["input_ids"] = ids
+            f["labels"] = ids.clone()
+            f["labels"][: len(ids) // 2] = -100
+            if "audio_batch_size" not in f:
+                f["audio_batch_size"] = torch.tensor([0])
+            out.append(f)
+    batch = DataCollatorForSeq2SeqWithAudio(tok)(feats)
+    ref_batch = DataCollatorForSeq2SeqWithAudio(tok)(feats_ref)
+    # integer contract identical whether the mel came from the device or from the oracle
+    for k in ("input_ids", "attention_mask", "labels", "audio_token_start_idx", "audio_lens", "audio_token_len", "audio_batch_size"):
+        assert torch.equal(batch[k].cpu(), ref_batch[k].cpu()), k
+    assert batch["audio_batch_size"].reshape(-1).tolist() == [2, 0, 1] and batch["audio_values"].shape[0] == 3
+    assert (batch["audio_values"].cpu() - ref_batch["audio_values"]).abs().max().item() < 5e-4
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    gb["audio_batch_size"] = gb["audio_batch_size"].reshape(-1)
+    out = model.forward(**gb)
+    ob = {k: v.cpu() for k, v in batch.items()}
+    ob["audio_batch_size"] = ob["audio_batch_size"].reshape(-1)
+    ob["audio_values"] = ob["audio_values"].bfloat16().float()
+    with torch.no_grad():
+        ref = oracle.forward(**ob)
+    keep = ob["attention_mask"].bool()
+    assert rel_l2(out.logits.cpu()[keep], ref["logits"][keep]) < 3e-2
+    assert abs(out.loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
+
+
+def test_overlapping_audio_ranges_follow_reference_loop_order():
+    """Two audio items whose placeholder ranges overlap: the reference's python loop lets the LATER item win
+    (ultravox_model.py:390-394); the device merge must do the same, bit-exactly in placement."""
+    cfg, sd, model, oracle = build(9)
+    b = batch_for(cfg, B=2, seconds=2.0, n_text=40, audio_start=5, n_sup=8)
+    # give sample 0 both audio items: item 1 starts inside item 0's range
+    b["audio_batch_size"] = torch.tensor([2, 0])
+    b["audio_token_start_idx"] = torch.tensor([5, 10])
+    out = model.forward(**{k: v.to(DEV) for k, v in b.items()})
+    with torch.no_grad():
+        ref = oracle.forward(**{**b, "audio_values": b["audio_values"].bfloat16().float()})
+    assert rel_l2(out.logits, ref["logits"]) < 3e-2

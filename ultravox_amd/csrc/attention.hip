@@ -388,10 +388,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
     load_nat<D, 32>(doreg, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
     load_tr<D, 32>(qtreg, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
     load_tr<D, 32>(dotreg, p.dot + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
-    if (tid < 32) {
-      const int q = qs + tid;
-      lreg = q < p.T ? p.lse[((long long)b * p.Hq + h) * p.T + q] : __builtin_huge_valf();
-      dlreg = q < p.T ? p.delta[((long long)b * p.Hq + h) * p.T + q] : 0.f;
+    {  // every thread loads (clamped index, branch-free: keeps the per-iteration VMEM count static);
+       // queries >= T are masked by the consumers
+      const int q = min(qs + (tid & 31), p.T - 1);
+      lreg = p.lse[((long long)b * p.Hq + h) * p.T + q];
+      dlreg = p.delta[((long long)b * p.Hq + h) * p.T + q];
     }
   };
   auto commit = [&](int buf) {
