@@ -176,6 +176,8 @@ typedef struct {
 int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* desc);
 /* probes/tests: force the bf16 GEMM tile variant (-1 auto, 0 = 128x128, 1..4 = {128,160,192,256} x 256) */
 int32_t uvx_gemm_force_variant(int32_t variant);
+/* probes: force the attention forward q-tile count per wave (1 or 2; 0 = automatic) */
+int32_t uvx_attention_force_qt(int32_t qt);
 
 int32_t uvx_layernorm(void* stream, int32_t dtype, const void* x, const void* w, const void* b, void* y, int32_t rows,
                       int32_t cols, float eps);

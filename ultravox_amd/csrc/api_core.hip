@@ -17,6 +17,8 @@ extern "C" void uvx_set_error(const char* fmt, ...) {
 
 extern "C" const char* uvx_last_error(void) { return g_err; }
 extern "C" int32_t uvx_abi_version(void) { return UVX_ABI_VERSION; }
+namespace uvx { extern int g_attn_qt; }
+extern "C" int32_t uvx_attention_force_qt(int32_t qt) { uvx::g_attn_qt = qt; return UVX_OK; }
 extern "C" int32_t uvx_gemm_force_variant(int32_t v) {
   if (v <= -2) { uvx::g_gemm_variant = -1; uvx::g_gemm_split = 0; }  // -2: automatic variant, tail split off (A/B probes)
   else { uvx::g_gemm_variant = v; uvx::g_gemm_split = 1; }

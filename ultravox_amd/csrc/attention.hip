@@ -646,6 +646,7 @@ int check_desc(const uvx::AttnDesc& d) {
 
 namespace uvx {
 
+int g_attn_qt = 0;  // probes: force the forward kernel's q-tile count (0 = automatic)
 int attention_fwd_f32(hipStream_t st, const AttnDesc& d);
 int attention_bwd_f32(hipStream_t st, const AttnBwdDesc& d);
 
@@ -655,10 +656,17 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
   int rc = check_desc(d);
   if (rc) return rc;
   AttnArgs a = make_args(d);
-  constexpr int QT = 2;
-  dim3 grid(cdiv(d.T, 4 * QT * 16), d.Hq, d.B);
-  if (d.D == 64) hipLaunchKernelGGL((attn_fwd_k<64, QT>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((attn_fwd_k<128, QT>), grid, dim3(256), 0, st, a);
+  // q rows per block = 64 * QT.  Long sequences (the encoder's 1500 frames) want QT = 2 for K/V reuse; short
+  // ones (the LLM's few hundred tokens) are latency-bound and want more, smaller blocks and fewer registers.
+  const int qt = uvx::g_attn_qt > 0 ? uvx::g_attn_qt : (d.T >= 1024 ? 2 : 1);
+  dim3 grid(cdiv(d.T, 4 * qt * 16), d.Hq, d.B);
+  if (d.D == 64) {
+    if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<64, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_k<64, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<128, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_k<128, 1>), grid, dim3(256), 0, st, a);
+  }
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

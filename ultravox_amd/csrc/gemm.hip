@@ -626,8 +626,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide3_kernel(GemmArgs p) 
   }
 }
 
-// Tile choice.  Every CU works through ceil(tiles / 256) tiles (few rounds) or ~tiles/256 + 0.4 (many
-// rounds, dynamic dispatch smooths the tail); a tile costs BM x BN / speed(variant), speeds measured on
+// Tile choice.  Every CU works through ~tiles/256 rounds of tiles (see variant_cost for the partial last
+// round); a tile costs BM x BN / speed(variant), speeds measured on
 // MI355X (profiles/r01_gemm_variants.txt).  variant 0 = 128x128 narrow; 1..4 = {128,160,192,256} x 256 wide.
 // (A 32x32x16-MFMA flavour of the wide kernel was measured 10-20 % SLOWER than 16x16x32 and dropped.)
 struct Variant { int bm, bn; double speed; };
@@ -644,8 +644,11 @@ double variant_speed(int v, int K) {
 }
 double variant_cost(int v, int M, int N, int K, int batch) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
+  // Rounds of tiles over the 256 CUs.  A partly filled last round is cheaper than a full one (the kernel is
+  // bound by operand delivery through the shared L2 / fabric, so fewer active CUs each run faster):
+  // measured behaviour is well described by floor(r) + sqrt(frac(r)).
   const double r = tiles / 256.0;
-  const double rounds = r <= 4.0 ? ceil(r) : r + 0.4;
+  const double rounds = floor(r) + sqrt(r - floor(r));
   return rounds * kVariants[v].bm * kVariants[v].bn / variant_speed(v, K);
 }
 int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
