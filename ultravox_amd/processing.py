@@ -92,7 +92,9 @@ class UltravoxProcessor:
                 pieces.append(piece)
                 piece_lens.append(min(n - off, ctx))
                 continuation.append(cont)
-        dev = audio_values.device
+        # index tensors live on the host (in the reference everything here is a CPU tensor; with the device
+        # log-mel frontend only `audio_values` stays on the GPU)
+        dev = torch.device("cpu")
         data = {
             "audio_values": torch.stack(pieces, dim=0),
             "audio_lens": torch.tensor(piece_lens, dtype=torch.int64, device=dev),
@@ -126,7 +128,7 @@ class UltravoxProcessor:
             values = feats["input_features"] if "input_features" in feats else feats["input_values"]
             values = torch.as_tensor(values)
             frame_lens = torch.as_tensor(feats["attention_mask"]).sum(-1)
-            data.update(self._chunk_and_pad_audio(values, frame_lens.to(values.device), include_audio_num_chunks))
+            data.update(self._chunk_and_pad_audio(values, frame_lens.cpu(), include_audio_num_chunks))
             is_cont = data.pop("audio_is_continuation").tolist()
             data["audio_token_len"] = torch.ceil(
                 data["audio_lens"] / (self.encoder_ds_factor * self.stack_factor)).to(dtype=torch.int)
