@@ -237,6 +237,8 @@ def test_processor_collator_model_end_to_end_ragged_batch():
             out.append(f)
     batch = DataCollatorForSeq2SeqWithAudio(tok)(feats)
     ref_batch = DataCollatorForSeq2SeqWithAudio(tok)(feats_ref)
+    for bt in (batch, ref_batch):   # the collator pads with the (huge) EOS id: fold it into the tiny vocabulary too
+        bt["input_ids"] = bt["input_ids"] % 512
     # integer contract identical whether the mel came from the device or from the oracle
     for k in ("input_ids", "attention_mask", "labels", "audio_token_start_idx", "audio_lens", "audio_token_len", "audio_batch_size"):
         assert torch.equal(batch[k].cpu(), ref_batch[k].cpu()), k
