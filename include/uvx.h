@@ -77,7 +77,8 @@ typedef struct {
   float *ln_pre, *w1, *ln_mid, *w2, *ln_post;
 } uvx_projector_grads_t;
 
-/* Llama layer: wqkv = [q;k;v] ([(H+2Hkv)*dh, D]), wgu = [gate;up] ([2I, D]); the *_t members are the
+/* Llama layer: wqkv = [q;k;v] ([(H+2Hkv)*dh, D]), wgu = gate and up rows interleaved in 16-row blocks
+ * ([2I, D]: rows 32k..32k+15 = gate rows 16k.., rows 32k+16..32k+31 = up rows 16k..); the *_t members are the
  * transposed copies ([K_in, N_out] -> nn.Linear layout of the transposed map) used for the frozen-weight
  * activation gradients; they may be NULL for forward-only use. */
 typedef struct {

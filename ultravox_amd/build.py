@@ -18,6 +18,10 @@ OBJ = CSRC / "build"
 LIB = PKG / "libuvx.so"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+# per-file extras.  attention: keep MFMA results in VGPRs (gfx950 has a unified 512-entry file): the softmax
+# consumes every accumulator element on the VALU, and the default AGPR form costs a v_accvgpr_read/write per
+# element plus ~60 registers of occupancy.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -36,7 +40,7 @@ def _compile(src: Path, hipcc: str, hdr_mtime: float, force: bool) -> Path:
     obj = OBJ / (src.stem + ".o")
     if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_mtime):
         return obj
-    cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+    cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr[-4000:]}")

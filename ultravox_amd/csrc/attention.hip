@@ -661,7 +661,9 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
   const int qt = uvx::g_attn_qt > 0 ? uvx::g_attn_qt : (d.T >= 1024 ? 2 : 1);
   dim3 grid(cdiv(d.T, 4 * qt * 16), d.Hq, d.B);
   if (d.D == 64) {
-    if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<64, 2>), grid, dim3(256), 0, st, a);
+    if (qt == 4) hipLaunchKernelGGL((attn_fwd_k<64, 4>), grid, dim3(256), 0, st, a);
+    else if (qt == 3) hipLaunchKernelGGL((attn_fwd_k<64, 3>), grid, dim3(256), 0, st, a);
+    else if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<64, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_k<64, 1>), grid, dim3(256), 0, st, a);
   } else {
     if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<128, 2>), grid, dim3(256), 0, st, a);

@@ -19,8 +19,10 @@ __global__ void swiglu_fwd_k(const T* __restrict__ in, T* __restrict__ out, long
   const int c = (int)(i % hv) * 8;
   const T* r = in + row * 2 * half;
   float a[8], g[8], o[8];
-  ld8<T>(r + (gate_first ? half : 0) + c, a);   // value / up
-  ld8<T>(r + (gate_first ? 0 : half) + c, g);   // gate
+  const int voff = gate_first == 2 ? (c / 16) * 32 + (c % 16) + 16 : (gate_first ? half + c : c);
+  const int goff = gate_first == 2 ? (c / 16) * 32 + (c % 16) : (gate_first ? c : half + c);
+  ld8<T>(r + voff, a);   // value / up
+  ld8<T>(r + goff, g);   // gate
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[k] = rnd<T>(g[k] / (1.0f + expf(-g[k]))) * a[k];
   st8<T>(out + row * half + c, o);
@@ -36,10 +38,11 @@ __global__ void swiglu_bwd_k(const T* __restrict__ dout, const T* __restrict__ i
   const int c = (int)(i % hv) * 8;
   const T* r = in + row * 2 * half;
   T* dr = din + row * 2 * half;
-  const int voff = gate_first ? half : 0, goff = gate_first ? 0 : half;
+  const int voff = gate_first == 2 ? (c / 16) * 32 + (c % 16) + 16 : (gate_first ? half + c : c);
+  const int goff = gate_first == 2 ? (c / 16) * 32 + (c % 16) : (gate_first ? c : half + c);
   float a[8], g[8], d[8], da[8], dg[8];
-  ld8<T>(r + voff + c, a);
-  ld8<T>(r + goff + c, g);
+  ld8<T>(r + voff, a);
+  ld8<T>(r + goff, g);
   ld8<T>(dout + row * half + c, d);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -48,8 +51,8 @@ __global__ void swiglu_bwd_k(const T* __restrict__ dout, const T* __restrict__ i
     da[k] = d[k] * rnd<T>(silu);
     dg[k] = d[k] * a[k] * (s * (1.0f + g[k] * (1.0f - s)));
   }
-  st8<T>(dr + voff + c, da);
-  st8<T>(dr + goff + c, dg);
+  st8<T>(dr + voff, da);
+  st8<T>(dr + goff, dg);
 }
 
 // cos_sin: [T_table, D/2, 2] f32.  x: [rows, ld]; heads 0..H-1 of width D start at column 0.
@@ -232,7 +235,7 @@ inline int grid1d(long long n, int th) { return (int)((n + th - 1) / th); }
 namespace uvx {
 
 int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first) {
-  UVX_CHECK(half % 8 == 0, UVX_ERR_SHAPE, "swiglu: half=%d must be a multiple of 8", half);
+  UVX_CHECK(half % 8 == 0 && (gate_first != 2 || half % 16 == 0), UVX_ERR_SHAPE, "swiglu: half=%d must be a multiple of 8 (16 when interleaved)", half);
   const long long n8 = (long long)rows * half / 8;
   if (n8 == 0) return UVX_OK;
   if (dtype == DT_BF16)

@@ -39,6 +39,9 @@ struct GemmArgs {
   int accumulate;  // f32 output only: C += result
   float alpha;
   int tiles_m, tiles_n;
+  bf16_t* C2;      // swiglu mode: activation output [M, N/2]
+  int ldc2;
+  int swiglu;      // 1: columns alternate 16-wide gate / up blocks; also write silu(gate) * up to C2
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -46,6 +49,91 @@ constexpr int BM = 128, BN = 128, BK = 64;
 __device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+
+// Shared epilogue.  acc[j][i] is the 16x16 accumulator fragment whose rows are output columns
+// n_base + 16 j + 4 fg .. +3 (4 consecutive per lane) and whose column is output row m_base + 16 i + frow.
+// The reference's bf16 rounding points are restated: round(acc*alpha + bias), round(act(.)), then + residual.
+template <int NJ, int MI>
+__device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ][MI], int m_base, int n_base, int frow,
+                                           int fg, long long z) {
+  const bool bf16_out = !p.out_f32;
+  if (p.swiglu) {
+    // fused LlamaMLP activation: fragment j (even) holds 16 gate columns, fragment j+1 the matching up columns
+    // (weights are packed that way at load time); gate|up is stored for the backward pass and
+    // act = round(silu(round(gate))) * round(up) — the reference's rounding points — goes to C2.
+#pragma unroll
+    for (int j = 0; j < NJ; j += 2) {
+      const int n = n_base + j * 16 + fg * 4;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = m_base + i * 16 + frow;
+        if (m >= p.M) continue;
+        u16x4_t og, ou, oa;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          og[e] = f2bf(acc[j][i][e] * p.alpha);
+          ou[e] = f2bf(acc[j + 1][i][e] * p.alpha);
+          const float g = bf2f(og[e]);
+          oa[e] = f2bf(bf2f(f2bf(g / (1.0f + __expf(-g)))) * bf2f(ou[e]));
+        }
+        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n;
+        *reinterpret_cast<u16x4_t*>(crow) = og;
+        *reinterpret_cast<u16x4_t*>(crow + 16) = ou;
+        *reinterpret_cast<u16x4_t*>(p.C2 + (long long)m * p.ldc2 + (n_base + j * 16) / 2 + fg * 4) = oa;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n_base + j * 16 + fg * 4;
+    if (n >= p.N) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m_base + i * 16 + frow;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = acc[j][i][e] * p.alpha + bv[e];
+        if (bf16_out) t = bf2f(f2bf(t));
+        if (p.act == 1) {
+          t = gelu_fast(t);
+          if (bf16_out) t = bf2f(f2bf(t));
+        }
+        v[e] = t;
+      }
+      if (p.residual) {
+        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+        u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
+      }
+      const long long off = z * p.sC + (long long)m * p.ldc + n;
+      if (bf16_out) {
+        u16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *reinterpret_cast<u16x4_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
+      } else {
+        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off);
+        if (p.accumulate) {
+          float4 c = *dst;
+          v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
+        }
+        *dst = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
@@ -124,54 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
   }
 
   // ---- epilogue ----
-  const bool bf16_out = !p.out_f32;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wc * 64 + j * 16 + fg * 4;
-    if (n >= p.N) continue;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-      u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wr * 64 + i * 16 + frow;
-      if (m >= p.M) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = acc[j][i][e] * p.alpha + bv[e];
-        if (bf16_out) t = bf2f(f2bf(t));  // the reference rounds the linear output before act/residual
-        if (p.act == 1) {
-          t = gelu_fast(t);
-          if (bf16_out) t = bf2f(f2bf(t));
-        }
-        v[e] = t;
-      }
-      if (p.residual) {
-        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
-        u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
-      }
-      const long long off = z * p.sC + (long long)m * p.ldc + n;
-      if (bf16_out) {
-        u16x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        *reinterpret_cast<u16x4_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
-      } else {
-        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off);
-        if (p.accumulate) {
-          float4 c = *dst;
-          v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
-        }
-        *dst = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
+  store_tile<4, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, frow, fg, z);
 }
 
 
@@ -263,54 +304,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  const bool bf16_out = !p.out_f32;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wc * 64 + j * 16 + fg * 4;
-    if (n >= p.N) continue;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-      u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wr * (BM / 2) + i * 16 + frow;
-      if (m >= p.M) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float tv = acc[j][i][e] * p.alpha + bv[e];
-        if (bf16_out) tv = bf2f(f2bf(tv));
-        if (p.act == 1) {
-          tv = gelu_fast(tv);
-          if (bf16_out) tv = bf2f(f2bf(tv));
-        }
-        v[e] = tv;
-      }
-      if (p.residual) {
-        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
-        u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
-      }
-      const long long off = z * p.sC + (long long)m * p.ldc + n;
-      if (bf16_out) {
-        u16x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        *reinterpret_cast<u16x4_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
-      } else {
-        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off);
-        if (p.accumulate) {
-          float4 c = *dst;
-          v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
-        }
-        *dst = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
+  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -430,54 +424,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
 #undef UVX_VMCNT
 
-  const bool bf16_out = !p.out_f32;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wc * 64 + j * 16 + fg * 4;
-    if (n >= p.N) continue;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-      u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wr * (BM / 2) + i * 16 + frow;
-      if (m >= p.M) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float tv = acc[j][i][e] * p.alpha + bv[e];
-        if (bf16_out) tv = bf2f(f2bf(tv));
-        if (p.act == 1) {
-          tv = gelu_fast(tv);
-          if (bf16_out) tv = bf2f(f2bf(tv));
-        }
-        v[e] = tv;
-      }
-      if (p.residual) {
-        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
-        u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
-      }
-      const long long off = z * p.sC + (long long)m * p.ldc + n;
-      if (bf16_out) {
-        u16x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        *reinterpret_cast<u16x4_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
-      } else {
-        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off);
-        if (p.accumulate) {
-          float4 c = *dst;
-          v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
-        }
-        *dst = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
+  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,54 +523,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide3_kernel(GemmArgs p) 
   }
 #undef UVX_VMCNT
 
-  const bool bf16_out = !p.out_f32;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wc * 64 + j * 16 + fg * 4;
-    if (n >= p.N) continue;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-      u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wr * (BM / 2) + i * 16 + frow;
-      if (m >= p.M) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float tv = acc[j][i][e] * p.alpha + bv[e];
-        if (bf16_out) tv = bf2f(f2bf(tv));
-        if (p.act == 1) {
-          tv = gelu_fast(tv);
-          if (bf16_out) tv = bf2f(f2bf(tv));
-        }
-        v[e] = tv;
-      }
-      if (p.residual) {
-        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
-        u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
-      }
-      const long long off = z * p.sC + (long long)m * p.ldc + n;
-      if (bf16_out) {
-        u16x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        *reinterpret_cast<u16x4_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = o;
-      } else {
-        float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + off);
-        if (p.accumulate) {
-          float4 c = *dst;
-          v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
-        }
-        *dst = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
+  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z);
 }
 
 // Tile choice.  Every CU works through ~tiles/256 rounds of tiles (see variant_cost for the partial last
@@ -701,6 +601,9 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.res_mod = d.res_mod;
   a.sA = d.sA; a.sB = d.sB; a.sC = d.sC; a.sR = d.sR;
   a.act = d.act; a.out_f32 = d.out_f32; a.accumulate = d.accumulate; a.alpha = d.alpha;
+  a.C2 = (bf16_t*)d.C2; a.ldc2 = d.ldc2; a.swiglu = d.swiglu;
+  UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
+            UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
   const int batch = d.batch > 0 ? d.batch : 1;
   double cost_whole = 0.;
   const int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole);
@@ -731,6 +634,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
     t.B = a.B + (long long)n_main * a.ldb;
     if (a.bias) t.bias = a.bias + n_main;
     if (a.residual) t.residual = a.residual + n_main;
+    if (a.swiglu) t.C2 = a.C2 + n_main / 2;
     t.C = a.out_f32 ? (void*)((float*)a.C + n_main) : (void*)((bf16_t*)a.C + n_main);
     launch_variant(st, tail_variant, t, d.M, d.N - n_main, 1);
   }

@@ -35,6 +35,11 @@ struct GemmDesc {
   int out_f32 = 0;   // bf16 path only: write f32 (wgrad)
   int accumulate = 0;
   float alpha = 1.0f;
+  // fused LlamaMLP activation (bf16 path): B's rows alternate 16 gate / 16 up rows; C gets gate|up in that
+  // interleaved order, C2 [M, N/2] (row stride ldc2) gets silu(gate) * up
+  void* C2 = nullptr;
+  int ldc2 = 0;
+  int swiglu = 0;
 };
 
 extern int g_gemm_variant;
@@ -63,6 +68,7 @@ int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, v
                       int B, int T, int C, int S, float eps);
 
 // ---- elementwise.hip ----
+// layout: 0 = [value | gate] halves (UltravoxProjector), 1 = [gate | up] halves, 2 = 16-wide gate/up blocks interleaved
 int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first);
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
                int gate_first);

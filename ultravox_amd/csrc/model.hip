@@ -439,6 +439,7 @@ extern "C" size_t uvx_llm_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t T
 
 static int llm_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int T) {
   UVX_CHECK(c.llm_heads % c.llm_kv_heads == 0, UVX_ERR_SHAPE, "llm: heads %d not a multiple of kv heads %d", c.llm_heads, c.llm_kv_heads);
+  UVX_CHECK(c.llm_inter % 16 == 0, UVX_ERR_SHAPE, "llm: intermediate size %d must be a multiple of 16", c.llm_inter);
   UVX_CHECK(w->rope_len >= T, UVX_ERR_SHAPE, "llm: rope table (%d) shorter than sequence (%d)", w->rope_len, T);
   return UVX_OK;
 }
@@ -487,8 +488,12 @@ extern "C" int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_
       RC(gemm(st, dt, g));
     }
     RC(rmsnorm_fwd(st, dt, cur.x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps));
-    RC(gemm(st, dt, lin(s.n, L.wgu, cur.gu, M, 2 * c.llm_inter, D)));
-    RC(swiglu_fwd(st, dt, cur.gu, s.act, M, c.llm_inter, /*gate_first=*/1));
+    {  // gate|up projection; wgu rows are packed as alternating 16-row gate / up blocks (weights.py)
+      GemmDesc g = lin(s.n, L.wgu, cur.gu, M, 2 * c.llm_inter, D);
+      if (dt == DT_BF16) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }   // SwiGLU fused into the epilogue
+      RC(gemm(st, dt, g));
+      if (dt != DT_BF16) RC(swiglu_fwd(st, dt, cur.gu, s.act, M, c.llm_inter, /*layout=*/2));
+    }
     {
       GemmDesc g = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
       g.residual = cur.x_mid; g.ldr = D;
@@ -528,7 +533,7 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
     LlmLayerStash cur = llm_layer(s, l);
     // MLP
     RC(gemm(st, dt, lin(s.dx, L.wd_t, s.d_act, M, c.llm_inter, D)));
-    RC(swiglu_bwd(st, dt, s.d_act, cur.gu, s.d_gu, M, c.llm_inter, 1));
+    RC(swiglu_bwd(st, dt, s.d_act, cur.gu, s.d_gu, M, c.llm_inter, /*layout=*/2));
     RC(gemm(st, dt, lin(s.d_gu, L.wgu_t, s.d_n, M, D, 2 * c.llm_inter)));
     RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_mid, L.ln2, s.dx, s.dx, nullptr, M, D, c.rms_eps));
     // attention

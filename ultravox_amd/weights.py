@@ -6,7 +6,7 @@ transpose them ONCE at load time into the layouts the HIP kernels want (include/
   - encoder  q/k/v -> one [3d, d] weight, q pre-scaled by head_dim^-0.5 (what WhisperAttention does
     to q_proj's output; exact for power-of-two scales), k bias = 0;
   - conv weights in im2col order (tap-major, channel-minor);
-  - Llama q/k/v -> [(H+2Hkv)dh, D], gate/up -> [2I, D], plus a transposed copy of every frozen linear
+  - Llama q/k/v -> [(H+2Hkv)dh, D], gate/up -> [2I, D] (16-row gate / up blocks interleaved), plus a transposed copy of every frozen linear
     for the activation-gradient GEMMs (288 GB of HBM makes the second copy free).
 """
 from __future__ import annotations
@@ -166,7 +166,12 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
     for i in range(t.num_hidden_layers):
         L = f"{P}layers.{i}."
         wqkv = cv(torch.cat([sd[L + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0))
-        wgu = cv(torch.cat([sd[L + "mlp.gate_proj.weight"], sd[L + "mlp.up_proj.weight"]], 0))
+        # gate / up rows interleaved in 16-row blocks: a GEMM tile then holds matching gate and up columns and
+        # the SwiGLU runs in its epilogue (csrc/gemm.hip store_tile)
+        gate, up = sd[L + "mlp.gate_proj.weight"], sd[L + "mlp.up_proj.weight"]
+        I, Dm = gate.shape
+        assert I % 16 == 0, "intermediate_size must be a multiple of 16"
+        wgu = cv(torch.stack([gate.reshape(I // 16, 16, Dm), up.reshape(I // 16, 16, Dm)], 1).reshape(2 * I, Dm))
         wo, wd = cv(sd[L + "self_attn.o_proj.weight"]), cv(sd[L + "mlp.down_proj.weight"])
         out["layers"].append({
             "ln1": cv(sd[L + "input_layernorm.weight"]), "ln2": cv(sd[L + "post_attention_layernorm.weight"]),
