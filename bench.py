@@ -239,8 +239,15 @@ def main():
         }
         if not args.no_prof and prof[0] > 0:
             ach = prof[2] / (prof[1] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+            # memory-side traffic per GEMM launch from the PMC passes of the SAME command (tools/pmc_traffic.sh,
+            # separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 on gfx950), committed under profiles/
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if args.workload == "c2" and os.path.exists(tfile):
+                traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_* (all tile variants)", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": prof[3] / prof[0],
                                "launches_per_step": prof[0] / args.steps, "gemm_ms_per_step": prof[1] / args.steps,
                                "avg_launch_us": prof[1] / prof[0] * 1e3,
                                "algorithmic_gflop_per_launch": prof[2] / prof[0] / 1e9}

@@ -153,6 +153,25 @@ int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights
 int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
                     int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes);
 
+/* ---- inference: prefill + KV-cache decode.  Replaces the [3P] HF language_model.generate
+ * that UltravoxModel.generate delegates to (ultravox_model.py:398-426) for GREEDY decoding.
+ * kv_cache: [llm_layers][2 (k, v)][B][Tmax][kv_heads * head_dim] in the cfg dtype, caller-owned.
+ * prefill: inputs_embeds [B, T, D], attention_mask [B, T] int64 or NULL (left padding allowed; position ids are
+ * cumsum(mask) - 1 as HF derives them); fills cache rows [0, T), writes next_pos[b] = number of real tokens,
+ * kv_start[b] = first real position, and the logits of the LAST position [B, vocab].
+ * decode: one new token per sequence: token_embeds [B, D], positions[b] = next_pos[b] + step, cache row cur_len is
+ * appended (cur_len = T + step), logits [B, vocab]. */
+size_t uvx_kv_cache_bytes(const uvx_config_t* cfg, int32_t B, int32_t Tmax);
+size_t uvx_llm_infer_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t T);
+int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                        const int64_t* attention_mask, int32_t B, int32_t T, void* kv_cache, int32_t Tmax, int32_t* next_pos,
+                        int32_t* kv_start, void* logits_last, void* workspace, size_t ws_bytes);
+int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* token_embeds,
+                       const int32_t* positions, const int32_t* kv_start, void* kv_cache, int32_t Tmax, int32_t cur_len,
+                       int32_t B, void* logits, void* workspace, size_t ws_bytes);
+/* out[r] = argmax_v logits[r, v] (lowest index on ties, like torch.argmax) */
+int32_t uvx_argmax(void* stream, int32_t dtype, const void* logits, int32_t rows, int32_t V, int64_t* out);
+
 /* clip_grad_norm_(max_norm) + torch.optim.AdamW step over one flat parameter bucket (train.py:260,
  * config_base.py:149-154).  grad: f32 [n] (already DP-averaged).  state_dtype selects the storage of
  * param/m/v (bf16 mirrors the reference's bf16 optimizer state); with master != NULL the update runs on

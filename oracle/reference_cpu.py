@@ -232,14 +232,18 @@ def _rotate_half(x):
 
 def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
               attention_mask: Optional[torch.Tensor] = None, prefix: str = "language_model.",
-              n_layers: Optional[int] = None) -> torch.Tensor:
+              n_layers: Optional[int] = None, position_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> logits [B, T, V] in the dtype of inputs_embeds."""
     tc = cfg.text_config
     dt = inputs_embeds.dtype
     B, T, D = inputs_embeds.shape
     Hq, Hkv, dh = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     W = lambda k: sd[prefix + k].to(dt) if not sd[prefix + k].requires_grad else sd[prefix + k]
-    cos, sin = rope_cos_sin_ref(tc, T, dt)
+    if position_ids is None:
+        cos, sin = rope_cos_sin_ref(tc, T, dt)
+    else:  # [B, T] position ids (HF generate derives them from the attention mask) -> [B, 1, T, dh] tables
+        cos_t, sin_t = rope_cos_sin_ref(tc, int(position_ids.max()) + 1, dt)
+        cos, sin = cos_t[position_ids][:, None], sin_t[position_ids][:, None]
     neg = torch.finfo(dt).min
     causal = torch.full((T, T), neg, dtype=dt).triu(1)[None, None]
     if attention_mask is not None:
@@ -309,6 +313,33 @@ class OracleModel:
         logits = llama_ref(self.sd, self.cfg, inputs_embeds, attention_mask)
         loss = causal_lm_loss_ref(logits, labels) if labels is not None else None
         return {"loss": loss, "logits": logits, "inputs_embeds": inputs_embeds, "audio_embeds": audio_embeds}
+
+    @torch.no_grad()
+    def generate_greedy(self, max_new_tokens: int, eos_token_id: int, pad_token_id: Optional[int] = None, **batch):
+        """UltravoxModel.generate (ultravox_model.py:398-426) + [3P] HF greedy search, restated WITHOUT a KV cache
+        (every step re-runs the whole sequence): merged embeddings once, position ids = cumsum(mask) - 1 (1 where
+        masked), next = argmax of the last position, finished sequences emit pad_token_id."""
+        ids = batch["input_ids"]
+        mask = batch.get("attention_mask")
+        if mask is None:
+            mask = torch.ones_like(ids)
+        fwd = {k: v for k, v in batch.items() if k not in ("labels",)}
+        embeds = self.forward(**{**fwd, "attention_mask": mask})["inputs_embeds"]
+        table = self.sd["language_model.model.embed_tokens.weight"]
+        pad = eos_token_id if pad_token_id is None else pad_token_id
+        out, unfinished = [ids], torch.ones(ids.shape[0], dtype=torch.bool)
+        for _ in range(max_new_tokens):
+            pos = (mask.long().cumsum(-1) - 1).masked_fill(mask == 0, 1)
+            logits = llama_ref(self.sd, self.cfg, embeds, mask, position_ids=pos)
+            nxt = logits[:, -1].float().argmax(-1)
+            tok = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+            out.append(tok[:, None])
+            unfinished = unfinished & (tok != eos_token_id)
+            if not bool(unfinished.any()):
+                break
+            embeds = torch.cat([embeds, F.embedding(tok, table)[:, None].to(embeds.dtype)], 1)
+            mask = torch.cat([mask, torch.ones_like(mask[:, :1])], 1)
+        return torch.cat(out, 1)
 
     def train_step(self, batch, optimizer=None, max_grad_norm: float = 1.0):
         """loss.backward(); clip_grad_norm_(1.0); AdamW.step() — SURVEY.md Appendix B."""

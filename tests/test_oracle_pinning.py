@@ -165,3 +165,33 @@ def test_projector_against_live_reference():
     want = proj(x)
     got = O.projector_ref({k: v for k, v in proj.state_dict().items()}, tiny_cfg(), x)
     np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_greedy_generate_matches_hf_generate_with_left_padding():
+    """[3P] check of the oracle's generate restatement: HF LlamaForCausalLM.generate (greedy, KV cache, position ids
+    from the attention mask) on a LEFT-padded batch == the cache-free restatement, token for token."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = tiny_cfg()
+    t = cfg.text_config
+    hf = LlamaForCausalLM(LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size,
+                                      num_hidden_layers=t.num_hidden_layers, num_attention_heads=t.num_attention_heads,
+                                      num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size,
+                                      rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta,
+                                      max_position_embeddings=t.max_position_embeddings, tie_word_embeddings=False,
+                                      attn_implementation="eager", eos_token_id=3, pad_token_id=3)).eval()
+    sd = random_state_dict(cfg, seed=8)
+    sd["language_model.model.embed_tokens.weight"] = sd["language_model.model.embed_tokens.weight"] * 0.3
+    hf.load_state_dict({k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}, strict=False)
+    torch.manual_seed(4)
+    B, T = 3, 11
+    ids = torch.randint(4, t.vocab_size, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[0, :4] = 0
+    am[2, :1] = 0
+    ids[am == 0] = 3
+    with torch.no_grad():
+        want = hf.generate(input_ids=ids, attention_mask=am, max_new_tokens=6, do_sample=False, eos_token_id=3, pad_token_id=3)
+    om = O.OracleModel(cfg, sd)
+    got = om.generate_greedy(6, eos_token_id=3, pad_token_id=3, input_ids=ids, attention_mask=am)
+    n = min(got.shape[1], want.shape[1])
+    assert torch.equal(got[:, :n], want[:, :n]), (got, want)

@@ -134,15 +134,17 @@ EXPORTS = [
     "uvx_projector_ws_bytes", "uvx_projector_fwd", "uvx_projector_bwd", "uvx_embed_merge", "uvx_merge_embeds_bwd",
     "uvx_llm_ws_bytes", "uvx_llm_fwd", "uvx_llm_bwd", "uvx_adamw_clip_step", "uvx_gemm", "uvx_layernorm",
     "uvx_rmsnorm", "uvx_rmsnorm_bwd", "uvx_swiglu", "uvx_swiglu_bwd", "uvx_rope", "uvx_attention_ws_bytes",
-    "uvx_attention_fwd", "uvx_attention_bwd", "uvx_ce_loss", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records", "uvx_gemm_force_variant", "uvx_attention_force_qt",
+    "uvx_attention_fwd", "uvx_attention_bwd", "uvx_ce_loss", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records", "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes",
+    "uvx_llm_prefill", "uvx_llm_decode", "uvx_argmax",
 ]
 
 
 def _declare(l: C.CDLL) -> None:
-    for name in ("uvx_encoder_ws_bytes", "uvx_projector_ws_bytes", "uvx_llm_ws_bytes", "uvx_attention_ws_bytes"):
+    for name in ("uvx_encoder_ws_bytes", "uvx_projector_ws_bytes", "uvx_llm_ws_bytes", "uvx_attention_ws_bytes",
+                 "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes"):
         getattr(l, name).restype = C.c_size_t
     for name in EXPORTS:
         f = getattr(l, name)
-        if name.endswith("ws_bytes") or name in ("uvx_last_error", "uvx_abi_version"):
+        if name.endswith("_bytes") or name in ("uvx_last_error", "uvx_abi_version"):
             continue
         f.restype = C.c_int32

@@ -1,0 +1,279 @@
+// Inference path of the LLM: prefill + KV-cache decode.
+//
+// Reference: UltravoxModel.generate (ultravox_model.py:398-426) builds the merged inputs_embeds once and
+// delegates to the [3P] HF language_model.generate: one prefill pass over the prompt, then a 1-token
+// decode loop over a KV cache.  With an attention_mask HF derives position ids as cumsum(mask) - 1
+// (1 where masked) — left-padded batches (infer.py:155-194) start counting at their first real token.
+//
+// Round-1 scope: correctness-first.  The prefill reuses the training-path kernels; the decode step runs the
+// same GEMM family at M = batch (weight-streaming bound; a dedicated skinny-M kernel is the next step) and a
+// simple one-wave-per-(sequence, head) attention over the cache.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/uvx.h"
+
+namespace {
+using namespace uvx;
+
+struct Arena {
+  char* base; size_t cap; size_t off = 0;
+  Arena(void* b, size_t c) : base((char*)b), cap(c) {}
+  void* take(size_t bytes) { const size_t a = (off + 255) & ~(size_t)255; off = a + bytes; return base ? (void*)(base + a) : nullptr; }
+  bool fits() const { return !base || off <= cap; }
+};
+inline size_t esz(int dtype) { return dtype == DT_BF16 ? 2 : 4; }
+inline char* at(const void* p, size_t elems, int dtype) { return (char*)p + elems * esz(dtype); }
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+struct InferWs {
+  void *x, *x2, *n, *qkv, *vt, *o, *gu, *act, *last, *hn;
+  int32_t *kvs, *kvl, *pos;
+  int M, Tp, QKV, OD;
+};
+InferWs carve(Arena& a, const uvx_config_t& c, int B, int T) {
+  InferWs w;
+  const size_t es = esz(c.dtype), M = (size_t)B * T;
+  w.M = B * T; w.Tp = (T + 63) / 64 * 64;
+  w.QKV = (c.llm_heads + 2 * c.llm_kv_heads) * c.llm_head_dim; w.OD = c.llm_heads * c.llm_head_dim;
+  w.x = a.take(M * c.llm_d * es); w.x2 = a.take(M * c.llm_d * es); w.n = a.take(M * c.llm_d * es);
+  w.qkv = a.take(M * w.QKV * es);
+  w.vt = a.take((size_t)B * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
+  w.o = a.take(M * w.OD * es);
+  w.gu = a.take(M * 2 * c.llm_inter * es); w.act = a.take(M * c.llm_inter * es);
+  w.last = a.take((size_t)B * c.llm_d * es); w.hn = a.take((size_t)B * c.llm_d * es);
+  w.kvs = (int32_t*)a.take(sizeof(int32_t) * B); w.kvl = (int32_t*)a.take(sizeof(int32_t) * B);
+  w.pos = (int32_t*)a.take(sizeof(int32_t) * M);
+  return w;
+}
+
+// position ids + valid key range from the attention mask (HF prepare_inputs_for_generation semantics)
+__global__ void mask_positions_k(const int64_t* __restrict__ mask, int32_t* __restrict__ pos, int32_t* __restrict__ kv_start,
+                                 int32_t* __restrict__ kv_len, int32_t* __restrict__ next_pos, int T) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  int run = 0, lo = T, hi = 0;
+  for (int t = 0; t < T; ++t) {
+    const bool keep = mask ? mask[(long long)b * T + t] != 0 : true;
+    if (keep) { pos[b * T + t] = run++; lo = min(lo, t); hi = t + 1; }
+    else pos[b * T + t] = 1;
+  }
+  kv_start[b] = lo < hi ? lo : 0;
+  kv_len[b] = hi;
+  next_pos[b] = run;
+}
+
+// cache[layer][0|1][b][t0 + t][:] = k|v part of qkv row (b, t)
+template <typename T>
+__global__ void kv_append_k(const T* __restrict__ qkv, T* __restrict__ cache_k, T* __restrict__ cache_v, int B, int Tn,
+                            int Tmax, int t0, int QKV, int koff, int KVD) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = KVD / 8;
+  if (i >= (long long)B * Tn * per_row) return;
+  const int c = (int)(i % per_row) * 8;
+  const long long row = i / per_row;
+  const int b = (int)(row / Tn), t = (int)(row % Tn);
+  float k[8], v[8];
+  ld8<T>(qkv + row * QKV + koff + c, k);
+  ld8<T>(qkv + row * QKV + koff + KVD + c, v);
+  const long long dst = ((long long)b * Tmax + t0 + t) * KVD + c;
+  st8<T>(cache_k + dst, k);
+  st8<T>(cache_v + dst, v);
+}
+
+// One wave per (sequence, query head): q . K^T over the cached keys, online softmax, P . V.
+template <typename T, int D>
+__global__ void attn_decode_k(const T* __restrict__ qkv, const T* __restrict__ cache_k, const T* __restrict__ cache_v,
+                              T* __restrict__ out, const int32_t* __restrict__ kv_start, int B, int Hq, int Hkv, int Tmax,
+                              int len, int QKV, float scale) {
+  const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wid >= B * Hq) return;
+  const int b = wid / Hq, h = wid % Hq, hk = h / (Hq / Hkv);
+  constexpr int E = D / 64;
+  float q[E], acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { q[e] = ldf<T>(qkv + (long long)b * QKV + h * D + lane + 64 * e); acc[e] = 0.f; }
+  const int KVD = Hkv * D;
+  float m = -__builtin_huge_valf(), l = 0.f;
+  for (int j = kv_start ? kv_start[b] : 0; j < len; ++j) {
+    const T* kr = cache_k + ((long long)b * Tmax + j) * KVD + hk * D;
+    const T* vr = cache_v + ((long long)b * Tmax + j) * KVD + hk * D;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += q[e] * ldf<T>(kr + lane + 64 * e);
+    s = wave_sum(s) * scale;
+    const float mn = fmaxf(m, s);
+    const float alpha = expf(m - mn), p = rnd<T>(expf(s - mn));
+    l = l * alpha + p;
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = acc[e] * alpha + p * ldf<T>(vr + lane + 64 * e);
+    m = mn;
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) stf<T>(out + (long long)b * Hq * D + h * D + lane + 64 * e, acc[e] * inv);
+}
+
+template <typename T>
+__global__ void argmax_k(const T* __restrict__ logits, int64_t* __restrict__ out, int V) {
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  const T* r = logits + (long long)blockIdx.x * V;
+  float best = -__builtin_huge_valf();
+  int idx = 0;
+  for (int c = threadIdx.x; c < V; c += blockDim.x) {
+    const float v = ldf<T>(r + c);
+    if (v > best) { best = v; idx = c; }  // strict >: the lowest index wins ties, like torch.argmax
+  }
+  bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float o = bv[threadIdx.x + s];
+      const int oi = bi[threadIdx.x + s];
+      if (o > bv[threadIdx.x] || (o == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = o; bi[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = bi[0];
+}
+
+GemmDesc lin(const void* A, const void* W, void* C, int M, int N, int K) {
+  GemmDesc g;
+  g.A = A; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+  return g;
+}
+
+// one decoder layer on M = B*T rows; attention supplied by the caller
+struct LayerIO { void *x_in, *x_mid; };
+
+int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, void* x_mid, void* x_out) {
+  const int dt = c.dtype, D = c.llm_d;
+  RC(rmsnorm_fwd(st, dt, x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps));
+  GemmDesc g = lin(s.n, L.wgu, s.gu, M, 2 * c.llm_inter, D);
+  if (dt == DT_BF16) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
+  RC(gemm(st, dt, g));
+  if (dt != DT_BF16) RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2));
+  GemmDesc d = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
+  d.residual = x_mid; d.ldr = D;
+  return gemm(st, dt, d);
+}
+
+}  // namespace
+
+extern "C" size_t uvx_kv_cache_bytes(const uvx_config_t* cfg, int32_t B, int32_t Tmax) {
+  if (!cfg) return 0;
+  return (size_t)cfg->llm_layers * 2 * B * Tmax * cfg->llm_kv_heads * cfg->llm_head_dim * esz(cfg->dtype);
+}
+
+extern "C" size_t uvx_llm_infer_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t T) {
+  if (!cfg) return 0;
+  Arena a(nullptr, 0);
+  carve(a, *cfg, B, T);
+  return a.off + 256;
+}
+
+extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                                   const int64_t* attention_mask, int32_t B, int32_t T, void* kv_cache, int32_t Tmax,
+                                   int32_t* next_pos, int32_t* kv_start, void* logits_last, void* workspace, size_t ws_bytes) {
+  UVX_CHECK(cfg && w && inputs_embeds && kv_cache && next_pos && kv_start && logits_last && workspace, UVX_ERR_INVALID,
+            "llm_prefill: null argument");
+  const uvx_config_t& c = *cfg;
+  UVX_CHECK(T >= 1 && T <= Tmax, UVX_ERR_SHAPE, "llm_prefill: prompt length %d exceeds the cache length %d", T, Tmax);
+  UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
+  hipStream_t st = (hipStream_t)stream;
+  Arena a(workspace, ws_bytes);
+  InferWs s = carve(a, c, B, T);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_prefill: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype, D = c.llm_d, M = s.M, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads, KVD = Hkv * dh;
+  const size_t es = esz(dt);
+  hipLaunchKernelGGL(mask_positions_k, dim3(B), dim3(64), 0, st, attention_mask, s.pos, kv_start, s.kvl, next_pos, T);
+  UVX_LAUNCH_CHECK();
+  UVX_HIP(hipMemcpyAsync(s.x, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+  const size_t layer_stride = (size_t)2 * B * Tmax * KVD;  // elements
+  for (int l = 0; l < c.llm_layers; ++l) {
+    const uvx_llm_layer_t& L = w->layers[l];
+    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps));
+    RC(gemm(st, dt, lin(s.n, L.wqkv, s.qkv, M, s.QKV, D)));
+    RC(rope_inplace(st, dt, s.qkv, w->rope_cos_sin, s.pos, M, T, Hq + Hkv, dh, s.QKV, 0));
+    {
+      char* ck = at(kv_cache, l * layer_stride, dt);
+      char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
+      const long long n = (long long)M * (KVD / 8);
+      if (dt == DT_BF16)
+        hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, T, Tmax, 0, s.QKV, Hq * dh, KVD);
+      else
+        hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, T, Tmax, 0, s.QKV, Hq * dh, KVD);
+      UVX_LAUNCH_CHECK();
+    }
+    RC(heads_transpose(st, dt, at(s.qkv, (size_t)(Hq + Hkv) * dh, dt), s.vt, B, T, s.Tp, Hkv, dh, s.QKV));
+    AttnDesc ad;
+    ad.q = s.qkv; ad.k = at(s.qkv, (size_t)Hq * dh, dt); ad.v = at(s.qkv, (size_t)(Hq + Hkv) * dh, dt);
+    ad.vt = s.vt; ad.o = s.o; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = s.kvl;
+    ad.B = B; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
+    ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.scale = 1.0f / sqrtf((float)dh);
+    RC(attention_fwd(st, dt, ad));
+    GemmDesc g = lin(s.o, L.wo, s.x2, M, D, s.OD);
+    g.residual = s.x; g.ldr = D;
+    RC(gemm(st, dt, g));
+    RC(mlp_block(st, c, L, s, M, s.x2, s.x));
+  }
+  // logits of the LAST position of every sequence only (what generate() consumes)
+  UVX_HIP(hipMemcpy2DAsync(s.last, (size_t)D * es, at(s.x, (size_t)(T - 1) * D, dt), (size_t)T * D * es, (size_t)D * es, B,
+                           hipMemcpyDeviceToDevice, st));
+  RC(rmsnorm_fwd(st, dt, s.last, w->norm, s.hn, nullptr, B, D, c.rms_eps));
+  return gemm(st, dt, lin(s.hn, w->lm_head, logits_last, B, c.vocab, D));
+}
+
+extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* token_embeds,
+                                  const int32_t* positions, const int32_t* kv_start, void* kv_cache, int32_t Tmax,
+                                  int32_t cur_len, int32_t B, void* logits, void* workspace, size_t ws_bytes) {
+  UVX_CHECK(cfg && w && token_embeds && positions && kv_cache && logits && workspace, UVX_ERR_INVALID, "llm_decode: null argument");
+  const uvx_config_t& c = *cfg;
+  UVX_CHECK(cur_len >= 0 && cur_len < Tmax, UVX_ERR_SHAPE, "llm_decode: cache full (%d of %d)", cur_len, Tmax);
+  hipStream_t st = (hipStream_t)stream;
+  Arena a(workspace, ws_bytes);
+  InferWs s = carve(a, c, B, 1);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_decode: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype, D = c.llm_d, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads, KVD = Hkv * dh;
+  UVX_CHECK(dh == 64 || dh == 128, UVX_ERR_UNSUPPORTED, "llm_decode: head_dim %d not supported", dh);
+  const size_t es = esz(dt);
+  UVX_HIP(hipMemcpyAsync(s.x, token_embeds, (size_t)B * D * es, hipMemcpyDeviceToDevice, st));
+  const size_t layer_stride = (size_t)2 * B * Tmax * KVD;
+  const float scale = 1.0f / sqrtf((float)dh);
+  for (int l = 0; l < c.llm_layers; ++l) {
+    const uvx_llm_layer_t& L = w->layers[l];
+    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps));
+    RC(gemm(st, dt, lin(s.n, L.wqkv, s.qkv, B, s.QKV, D)));
+    RC(rope_inplace(st, dt, s.qkv, w->rope_cos_sin, positions, B, 1, Hq + Hkv, dh, s.QKV, 0));
+    char* ck = at(kv_cache, l * layer_stride, dt);
+    char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
+    const long long n = (long long)B * (KVD / 8);
+    const int nw = B * Hq;
+    if (dt == DT_BF16) {
+      hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
+      if (dh == 64) hipLaunchKernelGGL((attn_decode_k<bf16_t, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
+      else hipLaunchKernelGGL((attn_decode_k<bf16_t, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
+    } else {
+      hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
+      if (dh == 64) hipLaunchKernelGGL((attn_decode_k<float, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
+      else hipLaunchKernelGGL((attn_decode_k<float, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
+    }
+    UVX_LAUNCH_CHECK();
+    GemmDesc g = lin(s.o, L.wo, s.x2, B, D, s.OD);
+    g.residual = s.x; g.ldr = D;
+    RC(gemm(st, dt, g));
+    RC(mlp_block(st, c, L, s, B, s.x2, s.x));
+  }
+  RC(rmsnorm_fwd(st, dt, s.x, w->norm, s.hn, nullptr, B, D, c.rms_eps));
+  return gemm(st, dt, lin(s.hn, w->lm_head, logits, B, c.vocab, D));
+}
+
+extern "C" int32_t uvx_argmax(void* stream, int32_t dtype, const void* logits, int32_t rows, int32_t V, int64_t* out) {
+  UVX_CHECK(logits && out, UVX_ERR_INVALID, "argmax: null argument");
+  if (rows == 0) return UVX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(argmax_k<bf16_t>, dim3(rows), dim3(256), 0, st, (const bf16_t*)logits, out, V);
+  else hipLaunchKernelGGL(argmax_k<float>, dim3(rows), dim3(256), 0, st, (const float*)logits, out, V);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}

@@ -299,6 +299,62 @@ class UltravoxModel:
 
     __call__ = forward
 
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, audio_values: Optional[torch.Tensor] = None,
+                 inputs_embeds: Optional[torch.Tensor] = None, audio_token_start_idx: Optional[torch.Tensor] = None,
+                 audio_lens: Optional[torch.Tensor] = None, audio_token_len: Optional[torch.Tensor] = None,
+                 audio_batch_size: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 max_new_tokens: int = 20, eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
+                 do_sample: bool = False, **kwargs) -> torch.Tensor:
+        """UltravoxModel.generate (ultravox_model.py:398-426): merged embeddings built ONCE, then the LLM's
+        prefill + KV-cache decode loop (greedy).  Returns prompt + generated ids, [B, T + n_new], finished
+        sequences padded with pad_token_id like HF's GenerationMixin."""
+        if do_sample or kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("only greedy decoding is built (SURVEY.md §8f-1)")
+        l = _lib.lib()
+        dev = self.device
+        if audio_values is not None and len(audio_values) > 0:
+            inputs_embeds = self._prepare_audio_embeds(inputs_embeds, input_ids, audio_values, audio_token_start_idx,
+                                                       audio_lens, audio_token_len, audio_batch_size)
+        elif inputs_embeds is None:
+            inputs_embeds = self._embed_merge(None, input_ids, None, None, None, None, *input_ids.shape)
+        B, T, D = inputs_embeds.shape
+        V = self.config.vocab_size
+        eos = self.config.text_config.eos_token_id if eos_token_id is None else eos_token_id
+        pad = eos if pad_token_id is None else pad_token_id
+        Tmax = T + max_new_tokens
+        if Tmax > self._llm["rope_len"]:
+            raise ValueError(f"prompt + max_new_tokens = {Tmax} exceeds the RoPE table ({self._llm['rope_len']})")
+        cache = self._workspace("kv", l.uvx_kv_cache_bytes(C.byref(self._c), B, Tmax))
+        nb = max(l.uvx_llm_infer_ws_bytes(C.byref(self._c), B, T), l.uvx_llm_infer_ws_bytes(C.byref(self._c), B, 1))
+        ws = self._workspace("infer", nb)
+        next_pos = torch.empty(B, device=dev, dtype=torch.int32)
+        kv_start = torch.empty(B, device=dev, dtype=torch.int32)
+        logits = torch.empty(B, V, device=dev, dtype=self.dtype)
+        am = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        check(l.uvx_llm_prefill(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(am),
+                                B, T, ptr(cache), Tmax, ptr(next_pos), ptr(kv_start), ptr(logits), ptr(ws),
+                                C.c_size_t(nb)), "uvx_llm_prefill")
+        out = [input_ids.to(dev)]
+        nxt = torch.empty(B, device=dev, dtype=torch.int64)
+        emb = torch.empty(B, D, device=dev, dtype=self.dtype)
+        unfinished = torch.ones(B, device=dev, dtype=torch.bool)
+        for step in range(max_new_tokens):
+            check(l.uvx_argmax(stream_ptr(), self.code, ptr(logits), B, V, ptr(nxt)), "uvx_argmax")
+            tok = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+            out.append(tok[:, None])
+            unfinished = unfinished & (tok != eos)
+            if step + 1 == max_new_tokens or not bool(unfinished.any()):
+                break
+            tok = tok.contiguous()
+            check(l.uvx_embed_merge(stream_ptr(), C.byref(self._c), ptr(self._llm["embed"]), ptr(tok), None, None, None,
+                                    None, B, 1, 0, 0, ptr(emb), ptr(torch.empty(B + 1, device=dev, dtype=torch.int32))),
+                  "uvx_embed_merge")
+            pos = (next_pos + step).contiguous()
+            check(l.uvx_llm_decode(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(emb), ptr(pos), ptr(kv_start),
+                                   ptr(cache), Tmax, T + step, B, ptr(logits), ptr(ws), C.c_size_t(nb)), "uvx_llm_decode")
+        return torch.cat(out, dim=1)
+
     def forward_backward(self, grad_scale: float = 1.0, **batch) -> torch.Tensor:
         """loss = model(**batch).loss; (loss * grad_scale).backward() for the trainable (projector)
         parameters.  Gradients land in `self.proj_grad` (flat f32 bucket, overwritten)."""
