@@ -152,6 +152,22 @@ int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights
  * d loss / d inputs_embeds [B, T, D], loss scaled by grad_scale (1 / gradient_accumulation_steps). */
 int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
                     int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes);
+/* labels == NULL: the saved logits already hold d loss / d logits (see uvx_llm_kl_loss). */
+
+/* KL-distillation loss: UltravoxModel._compute_kl_loss (ultravox_model.py:200-256) with the
+ * prediction / end-of-turn masks of _get_prediction_mask (:157-198) handed over as row pairs.  Call order:
+ *   uvx_llm_fwd(teacher: alt embeddings, save_for_bwd = 0, logits -> teacher_logits [teacher_rows, vocab])
+ *   uvx_llm_fwd(student: merged embeddings, save_for_bwd = 1, labels = NULL)
+ *   uvx_llm_kl_loss(...)   -- reads the student logits kept in `workspace`, writes loss[0] and replaces them
+ *                             by d loss / d logits (scaled by grad_scale)
+ *   uvx_llm_bwd(labels = NULL, ...)
+ * pair_row: int32 [2][B*T]: for student row r = b*T + t, slot 0 = teacher row paired with it among the prediction
+ * positions, slot 1 = teacher row paired with it among the end-of-turn positions; -1 = none.  pair_w: f32 [2][B*T],
+ * the weights (1 / n_pred and eot_loss_weight / n_eot: F.kl_div reduction="batchmean").
+ * loss = sum_r sum_slot w * KL(softmax(teacher / temperature) || softmax(student / temperature)). */
+int32_t uvx_llm_kl_loss(void* stream, const uvx_config_t* cfg, const void* teacher_logits, int64_t teacher_rows,
+                        const int32_t* pair_row, const float* pair_w, int32_t B, int32_t T, float temperature,
+                        float grad_scale, float* loss, void* workspace, size_t ws_bytes);
 
 /* ---- inference: prefill + KV-cache decode.  Replaces the [3P] HF language_model.generate
  * that UltravoxModel.generate delegates to (ultravox_model.py:398-426) for GREEDY decoding.
@@ -228,6 +244,12 @@ int32_t uvx_attention_bwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d,
 /* scratch: 2 + B*T floats */
 int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, const int64_t* labels, float* loss, void* dlogits,
                     int32_t B, int32_t T, int32_t V, int32_t ld, float grad_scale, float* scratch);
+
+/* the kernel behind uvx_llm_kl_loss on caller-owned logits [rows, V]; dlogits may alias student_logits or be NULL;
+ * scratch: rows floats */
+int32_t uvx_kl_loss(void* stream, int32_t dtype, const void* student_logits, const void* teacher_logits,
+                    const int32_t* pair_row, const float* pair_w, float* loss, void* dlogits, int64_t rows, int32_t V,
+                    int32_t ld_student, int32_t ld_teacher, float temperature, float grad_scale, float* scratch);
 
 /* ---- live kernel timing (bench.py roofline leg): HIP events on the launch stream around every GEMM.
  * uvx_prof_end fills out[class*4 + {0: launches, 1: total ms, 2: algorithmic FLOPs, 3: algorithmic bytes}]

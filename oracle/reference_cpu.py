@@ -281,6 +281,35 @@ def causal_lm_loss_ref(logits: torch.Tensor, labels: torch.Tensor, ignore_index:
                            reduction="mean")
 
 
+def prediction_mask_ref(labels: torch.Tensor):
+    """UltravoxModel._get_prediction_mask (ultravox_model.py:157-198): positions whose NEXT token carries a label,
+    and, per sequence, the last such position (the one that predicts the end-of-turn token)."""
+    label_mask = labels != -100
+    pred = torch.zeros_like(label_mask)
+    pred[:, :-1] = label_mask[:, 1:]
+    eot = torch.zeros_like(pred)
+    for b in range(labels.shape[0]):
+        pos = torch.where(pred[b])[0]
+        if len(pos) > 0:
+            eot[b, pos[-1]] = True
+    return pred, eot
+
+
+def kl_loss_ref(student_logits, labels, teacher_logits, alt_labels, temperature: float = 2.0, eot_loss_weight: float = 1.0):
+    """UltravoxModel._compute_kl_loss (ultravox_model.py:223-256): KL(teacher || student) at temperature over the
+    prediction positions ("batchmean": divided by the number of rows), plus eot_loss_weight x the same over the
+    end-of-turn positions.  The teacher is detached (:212-222 run it under no_grad)."""
+    pm, em = prediction_mask_ref(labels)
+    apm, aem = prediction_mask_ref(alt_labels)
+    t = teacher_logits.detach()
+    kl = F.kl_div(F.log_softmax(student_logits[pm] / temperature, dim=-1), F.softmax(t[apm] / temperature, dim=-1),
+                  reduction="batchmean")
+    if eot_loss_weight > 0:
+        kl = kl + eot_loss_weight * F.kl_div(F.log_softmax(student_logits[em] / temperature, dim=-1),
+                                             F.softmax(t[aem] / temperature, dim=-1), reduction="batchmean")
+    return kl
+
+
 # ----------------------------------------------------------------------------------------------
 # Whole forward / train step — UltravoxModel.forward (:277-352), _prepare_audio_embeds (:354-396).
 # ----------------------------------------------------------------------------------------------
@@ -303,7 +332,10 @@ class OracleModel:
         return tower, projector_ref(self.projector_params(), self.cfg, tower.to(self.dtype))        # :386-387
 
     def forward(self, input_ids, audio_values=None, labels=None, attention_mask=None, audio_token_start_idx=None,
-                audio_lens=None, audio_token_len=None, audio_batch_size=None, inputs_embeds=None):
+                audio_lens=None, audio_token_len=None, audio_batch_size=None, inputs_embeds=None, alt_input_ids=None,
+                alt_attention_mask=None, alt_labels=None, kl: Optional[dict] = None):
+        """kl = {"temperature": .., "eot_loss_weight": ..} selects LossFunction.KL_Divergence in training mode
+        (ultravox_model.py:335-351): the text-only teacher pass over alt_* (:212-222) and _compute_kl_loss."""
         if inputs_embeds is None:
             inputs_embeds = F.embedding(input_ids, self.sd["language_model.model.embed_tokens.weight"])  # :314-316
         audio_embeds = None
@@ -312,7 +344,13 @@ class OracleModel:
             inputs_embeds = merge_ref(inputs_embeds, audio_embeds, audio_token_start_idx, audio_token_len, audio_batch_size)
         logits = llama_ref(self.sd, self.cfg, inputs_embeds, attention_mask)
         loss = causal_lm_loss_ref(logits, labels) if labels is not None else None
-        return {"loss": loss, "logits": logits, "inputs_embeds": inputs_embeds, "audio_embeds": audio_embeds}
+        out = {"loss": loss, "logits": logits, "inputs_embeds": inputs_embeds, "audio_embeds": audio_embeds}
+        if kl is not None:
+            with torch.no_grad():
+                alt_embeds = F.embedding(alt_input_ids, self.sd["language_model.model.embed_tokens.weight"])
+                out["alt_logits"] = llama_ref(self.sd, self.cfg, alt_embeds, alt_attention_mask)
+            out["loss"] = kl_loss_ref(logits, labels, out["alt_logits"], alt_labels, kl["temperature"], kl["eot_loss_weight"])
+        return out
 
     @torch.no_grad()
     def generate_greedy(self, max_new_tokens: int, eos_token_id: int, pad_token_id: Optional[int] = None, **batch):

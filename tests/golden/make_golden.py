@@ -10,6 +10,9 @@ What is recorded
                     (ultravox_model.py:745-800, imported with an in-memory `peft` stub) for seeded inputs,
                     both projector_ln_mid variants, T not a multiple of the stack factor.
   latency_mask.npz — ModifiedWhisperEncoder.init_latency_mask (ultravox_model.py:834-863).
+  kl_loss.npz     — the REFERENCE UltravoxModel._get_prediction_mask / _compute_kl_loss (ultravox_model.py:157-256) called
+                    unbound on a stub `self` whose language model returns recorded teacher logits: masks, loss and
+                    d loss / d student logits for seeded logits, several eot weights / temperatures / ragged labels.
   logmel.npz      — HF WhisperFeatureExtractor (the [3P] K1 arithmetic) on seeded PCM, 80 and 128 mels.
 """
 import json
@@ -206,8 +209,53 @@ def logmel_cases():
     print("logmel.npz written")
 
 
+def kl_cases():
+    """Reference KL loss on seeded logits.  `self` is a stub: get_input_embeddings().forward -> passthrough,
+    language_model.forward -> the recorded teacher logits."""
+    M = ultravox_model.UltravoxModel
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    V = 64
+    cases = [
+        # (name, student label spans per row (start, end), teacher spans, T_student, T_teacher, temperature, eot_w)
+        ("basic", [(10, 16), (8, 14)], [(5, 11), (3, 9)], 16, 11, 2.0, 1.0),
+        ("no_eot", [(10, 16), (8, 14)], [(5, 11), (3, 9)], 16, 11, 2.0, 0.0),
+        ("temp1_w05", [(4, 9), (6, 12), (2, 5)], [(2, 7), (1, 7), (3, 6)], 12, 9, 1.0, 0.5),
+        ("one_empty_row", [(10, 16), None, (9, 12)], [(5, 11), None, (4, 7)], 16, 11, 3.0, 1.0),
+        ("padded_tail", [(6, 10), (3, 12)], [(2, 6), (1, 10)], 14, 12, 2.0, 2.0),
+    ]
+    for name, sp, tp, Ts, Tt, temp, w in cases:
+        B = len(sp)
+        labels = torch.full((B, Ts), -100, dtype=torch.long)
+        alt_labels = torch.full((B, Tt), -100, dtype=torch.long)
+        for b in range(B):
+            if sp[b] is not None:
+                labels[b, sp[b][0]:sp[b][1]] = torch.randint(0, V, (sp[b][1] - sp[b][0],), generator=g)
+                alt_labels[b, tp[b][0]:tp[b][1]] = labels[b, sp[b][0]:sp[b][1]]
+        student = (2.0 * torch.randn(B, Ts, V, generator=g)).requires_grad_(True)
+        teacher = 2.0 * torch.randn(B, Tt, V, generator=g)
+        stub = types.SimpleNamespace()
+        stub.get_input_embeddings = lambda: types.SimpleNamespace(forward=lambda ids: ids)
+        stub.language_model = types.SimpleNamespace(forward=lambda **kw: types.SimpleNamespace(logits=teacher))
+        stub.loss_config = ultravox_config.LossConfig(loss_function=ultravox_config.LossFunction.KL_Divergence,
+                                                      kl_temperature=temp, eot_loss_weight=w)
+        stub._get_prediction_mask = lambda l: M._get_prediction_mask(stub, l)
+        loss = M._compute_kl_loss(stub, lm_output=types.SimpleNamespace(logits=student), labels=labels,
+                                  alt_input_ids=torch.zeros(B, Tt, dtype=torch.long),
+                                  alt_attention_mask=torch.ones(B, Tt, dtype=torch.long), alt_labels=alt_labels)
+        loss.backward()
+        pm, em = M._get_prediction_mask(stub, labels)
+        for k, v in (("labels", labels), ("alt_labels", alt_labels), ("student", student.detach()), ("teacher", teacher),
+                     ("loss", loss.detach()), ("dstudent", student.grad), ("pred_mask", pm), ("eot_mask", em),
+                     ("temperature", torch.tensor(temp)), ("eot_loss_weight", torch.tensor(w))):
+            out[f"{name}.{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "kl_loss.npz"), **out)
+    print("kl_loss.npz:", [c[0] for c in cases])
+
+
 if __name__ == "__main__":
     processor_cases()
     projector_cases()
     latency_mask_cases()
     logmel_cases()
+    kl_cases()

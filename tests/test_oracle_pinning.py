@@ -9,6 +9,7 @@ import types
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import reference_cpu as O
 from ultravox_amd.config import UltravoxConfig
@@ -195,3 +196,53 @@ def test_greedy_generate_matches_hf_generate_with_left_padding():
     got = om.generate_greedy(6, eos_token_id=3, pad_token_id=3, input_ids=ids, attention_mask=am)
     n = min(got.shape[1], want.shape[1])
     assert torch.equal(got[:, :n], want[:, :n]), (got, want)
+
+
+KL_CASES = ["basic", "no_eot", "temp1_w05", "one_empty_row", "padded_tail"]
+
+
+@pytest.mark.parametrize("case", KL_CASES)
+def test_kl_loss_matches_reference_fixture(golden_dir, case):
+    """kl_loss.npz holds the REFERENCE UltravoxModel._compute_kl_loss / _get_prediction_mask outputs
+    (make_golden.py:kl_cases): masks bit-exact, loss and d loss / d student logits to f32 round-off."""
+    z = np.load(os.path.join(golden_dir, "kl_loss.npz"))
+    g = lambda k: torch.from_numpy(z[f"{case}.{k}"])
+    labels, alt_labels = g("labels"), g("alt_labels")
+    pm, em = O.prediction_mask_ref(labels)
+    assert torch.equal(pm, g("pred_mask")) and torch.equal(em, g("eot_mask"))
+    student = g("student").clone().requires_grad_(True)
+    loss = O.kl_loss_ref(student, labels, g("teacher"), alt_labels, float(g("temperature")), float(g("eot_loss_weight")))
+    loss.backward()
+    assert abs(loss.item() - float(g("loss"))) <= 1e-6 * max(1.0, abs(float(g("loss"))))
+    assert (student.grad - g("dstudent")).abs().max().item() < 1e-7
+
+
+@pytest.mark.parametrize("case", KL_CASES)
+def test_kl_row_pairs_reproduce_reference_masks(golden_dir, case):
+    """The host-side pairing handed to uvx_llm_kl_loss, evaluated with plain torch, gives the reference loss: this is
+    what pins the (pair_row, pair_w) contract of the C ABI without a GPU."""
+    from ultravox_amd.model import kl_row_pairs
+    z = np.load(os.path.join(golden_dir, "kl_loss.npz"))
+    g = lambda k: torch.from_numpy(z[f"{case}.{k}"])
+    labels, alt_labels, tau = g("labels"), g("alt_labels"), float(g("temperature"))
+    pair_row, pair_w, n_pred = kl_row_pairs(labels, alt_labels, float(g("eot_loss_weight")))
+    assert n_pred == int(g("pred_mask").sum())
+    assert torch.equal(pair_row[0] >= 0, g("pred_mask").reshape(-1))
+    if float(g("eot_loss_weight")) > 0:
+        assert torch.equal(pair_row[1] >= 0, g("eot_mask").reshape(-1))
+    s = g("student").reshape(-1, g("student").shape[-1])
+    t = g("teacher").reshape(-1, g("teacher").shape[-1])
+    tot = 0.0
+    for slot in range(2):
+        for r in torch.nonzero(pair_row[slot] >= 0)[:, 0].tolist():
+            lt = F.log_softmax(t[pair_row[slot, r]] / tau, -1)
+            tot += pair_w[slot, r].item() * (lt.exp() * (lt - F.log_softmax(s[r] / tau, -1))).sum().item()
+    assert abs(tot - float(g("loss"))) <= 2e-6 * max(1.0, abs(float(g("loss"))))
+
+
+def test_kl_row_pairs_rejects_unpairable_masks():
+    from ultravox_amd.model import kl_row_pairs
+    labels = torch.full((1, 8), -100); labels[0, 4:8] = 1
+    alt = torch.full((1, 6), -100); alt[0, 3:6] = 1
+    with pytest.raises(ValueError):
+        kl_row_pairs(labels, alt, 1.0)

@@ -67,6 +67,14 @@ extern "C" int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, 
                                float* scratch) {
   return uvx::ce_loss_fwd_bwd((hipStream_t)stream, dtype, logits, labels, loss, scratch, dlogits, B, T, V, ld, grad_scale);
 }
+extern "C" int32_t uvx_kl_loss(void* stream, int32_t dtype, const void* student_logits, const void* teacher_logits,
+                               const int32_t* pair_row, const float* pair_w, float* loss, void* dlogits, int64_t rows,
+                               int32_t V, int32_t ld_student, int32_t ld_teacher, float temperature, float grad_scale,
+                               float* scratch) {
+  UVX_CHECK(student_logits && teacher_logits && pair_row && pair_w && scratch, UVX_ERR_INVALID, "kl_loss: null argument");
+  return uvx::kl_loss_fwd_bwd((hipStream_t)stream, dtype, student_logits, teacher_logits, pair_row, pair_w, loss, scratch,
+                              dlogits, rows, V, ld_student, ld_teacher, temperature, grad_scale);
+}
 
 // Attention with its transposed operand copies carved from the caller's workspace.
 namespace {

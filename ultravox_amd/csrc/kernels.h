@@ -132,6 +132,12 @@ int heads_transpose(hipStream_t st, int dtype, const void* in, void* out, int B,
 int ce_loss_fwd_bwd(hipStream_t st, int dtype, const void* logits, const int64_t* labels, float* loss,
                     float* scratch, void* dlogits, int B, int T, int V, int ldl, float grad_scale);
 
+// KL distillation: loss = sum_r sum_slot w[slot][r] * KL(softmax(teacher[pair_row[slot][r]]/tau) || softmax(student[r]/tau)),
+// and (if dlogits, IN PLACE allowed) d loss / d student logits * grad_scale.  scratch: rows floats.
+int kl_loss_fwd_bwd(hipStream_t st, int dtype, const void* student, const void* teacher, const int32_t* pair_row,
+                    const float* pair_w, float* loss, float* scratch, void* dlogits, long long rows, int V, int ld_s, int ld_t,
+                    float temperature, float grad_scale);
+
 // ---- optim.hip ----
 int grad_sq_norm(hipStream_t st, const float* g, long long n, float* partial /*>=1024 floats*/, float* out_sumsq);
 int adamw_clip_step(hipStream_t st, int state_dtype, void* param, float* master, const float* grad,

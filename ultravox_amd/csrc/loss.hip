@@ -89,6 +89,118 @@ __global__ void ce_final_k(float* __restrict__ scratch, float* __restrict__ loss
   }
 }
 
+
+// ---- KL-distillation loss (ultravox_model.py:157-256) ----
+// Student row r is paired with up to two teacher rows: slot 0 = its partner among the prediction positions
+// (F.kl_div over logits[pred_mask] vs alt logits[alt_pred_mask], "batchmean" -> weight 1 / n_pred), slot 1 = its
+// partner among the end-of-turn positions (weight eot_loss_weight / n_eot).  Per pair
+//   KL = sum_v softmax(t/tau)_v * (log_softmax(t/tau)_v - log_softmax(s/tau)_v)
+//   d KL / d s_v = (softmax(s/tau)_v - softmax(t/tau)_v) / tau
+// Everything is evaluated in f32 from the stored logits; rows without a partner get a zero gradient.
+struct OnlineLse {
+  float m = -__builtin_huge_valf(), s = 0.f;
+  __device__ __forceinline__ void add8(const float* v) {
+    float mx = v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, v[i]);
+    const float mn = fmaxf(m, mx);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a += expf(v[i] - mn);
+    s = s * expf(m - mn) + a;
+    m = mn;
+  }
+  __device__ __forceinline__ float finish(float* red) {
+    const float M = block_max(m, red);
+    const float S = block_sum(s * expf(m - M), red);
+    return M + logf(S);
+  }
+};
+
+template <typename T>
+__global__ void kl_rows_k(const T* __restrict__ student, const T* __restrict__ teacher, const int32_t* __restrict__ pair_row,
+                          const float* __restrict__ pair_w, float* __restrict__ row_loss, T* __restrict__ dlogits,
+                          long long rows, int V, long long ld_s, long long ld_t, float inv_tau, float grad_scale) {
+  __shared__ float red[16];
+  const long long row = blockIdx.x;
+  const int32_t t0 = pair_row[row], t1 = pair_row[rows + row];
+  const float w0 = t0 >= 0 ? pair_w[row] : 0.f, w1 = t1 >= 0 ? pair_w[rows + row] : 0.f;
+  const T* sr = student + row * ld_s;
+  T* dr = dlogits ? dlogits + row * ld_s : nullptr;
+  if (t0 < 0 && t1 < 0) {
+    if (threadIdx.x == 0) row_loss[row] = 0.f;
+    if (dr) {
+      float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int c = threadIdx.x * 8; c < V; c += blockDim.x * 8) st8<T>(dr + c, z);
+    }
+    return;
+  }
+  const T* tr0 = teacher + (long long)(t0 >= 0 ? t0 : t1) * ld_t;
+  const T* tr1 = teacher + (long long)(t1 >= 0 ? t1 : t0) * ld_t;
+  const bool two = t0 >= 0 && t1 >= 0 && t0 != t1;   // the usual case pairs both slots with the same teacher row
+  OnlineLse ls, l0, l1;
+  for (int c = threadIdx.x * 8; c < V; c += blockDim.x * 8) {
+    float v[8];
+    ld8<T>(sr + c, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= inv_tau;
+    ls.add8(v);
+    ld8<T>(tr0 + c, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= inv_tau;
+    l0.add8(v);
+    if (two) {
+      ld8<T>(tr1 + c, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= inv_tau;
+      l1.add8(v);
+    }
+  }
+  const float lse_s = ls.finish(red), lse_0 = l0.finish(red), lse_1 = two ? l1.finish(red) : lse_0;
+  // slot weights: if both slots name the same teacher row they simply add up
+  const float wa = two ? (t0 >= 0 ? w0 : 0.f) : (w0 + w1), wb = two ? w1 : 0.f;
+  float kl_a = 0.f, kl_b = 0.f;
+  const float g = grad_scale * inv_tau;
+  for (int c = threadIdx.x * 8; c < V; c += blockDim.x * 8) {
+    float a[8], b[8], o[8];
+    ld8<T>(sr + c, a);
+    ld8<T>(tr0 + c, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float la = a[i] * inv_tau - lse_s, lb = b[i] * inv_tau - lse_0;
+      const float pt = expf(lb);
+      kl_a += pt * (lb - la);
+      a[i] = la;
+      o[i] = wa * (expf(la) - pt);
+    }
+    if (two) {
+      ld8<T>(tr1 + c, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float lb = b[i] * inv_tau - lse_1;
+        const float pt = expf(lb);
+        kl_b += pt * (lb - a[i]);
+        o[i] += wb * (expf(a[i]) - pt);
+      }
+    }
+    if (dr) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] *= g;
+      st8<T>(dr + c, o);
+    }
+  }
+  const float tot = block_sum(wa * kl_a + wb * kl_b, red);
+  if (threadIdx.x == 0) row_loss[row] = tot;
+}
+
+__global__ void kl_final_k(const float* __restrict__ row_loss, float* __restrict__ loss, long long rows) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < rows; i += blockDim.x) s += row_loss[i];  // fixed order: deterministic
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) loss[0] = s;
+}
+
 }  // namespace
 
 namespace uvx {
@@ -105,6 +217,23 @@ int ce_loss_fwd_bwd(hipStream_t st, int dtype, const void* logits, const int64_t
   else
     hipLaunchKernelGGL(ce_rows_k<float>, dim3(rows), dim3(256), 0, st, (const float*)logits, labels, scratch, (float*)dlogits, T, V, (long long)ldl, grad_scale);
   hipLaunchKernelGGL(ce_final_k, dim3(1), dim3(1024), 0, st, scratch, loss, rows);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+// scratch: rows floats (per-row weighted KL).  pair_row: int32 [2][rows] teacher row or -1; pair_w: f32 [2][rows].
+int kl_loss_fwd_bwd(hipStream_t st, int dtype, const void* student, const void* teacher, const int32_t* pair_row,
+                    const float* pair_w, float* loss, float* scratch, void* dlogits, long long rows, int V, int ld_s, int ld_t,
+                    float temperature, float grad_scale) {
+  UVX_CHECK(V % 8 == 0 && ld_s % 8 == 0 && ld_t % 8 == 0, UVX_ERR_SHAPE, "kl_loss: V=%d / ld=%d,%d must be multiples of 8", V, ld_s, ld_t);
+  UVX_CHECK(rows > 0, UVX_ERR_SHAPE, "kl_loss: empty batch");
+  UVX_CHECK(temperature > 0.f, UVX_ERR_INVALID, "kl_loss: temperature must be positive");
+  const float it = 1.0f / temperature;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(kl_rows_k<bf16_t>, dim3(rows), dim3(256), 0, st, (const bf16_t*)student, (const bf16_t*)teacher, pair_row, pair_w, scratch, (bf16_t*)dlogits, rows, V, (long long)ld_s, (long long)ld_t, it, grad_scale);
+  else
+    hipLaunchKernelGGL(kl_rows_k<float>, dim3(rows), dim3(256), 0, st, (const float*)student, (const float*)teacher, pair_row, pair_w, scratch, (float*)dlogits, rows, V, (long long)ld_s, (long long)ld_t, it, grad_scale);
+  if (loss) hipLaunchKernelGGL(kl_final_k, dim3(1), dim3(1024), 0, st, scratch, loss, rows);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

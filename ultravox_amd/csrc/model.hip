@@ -508,11 +508,27 @@ extern "C" int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_
   return UVX_OK;
 }
 
+extern "C" int32_t uvx_llm_kl_loss(void* stream, const uvx_config_t* cfg, const void* teacher_logits, int64_t teacher_rows,
+                                   const int32_t* pair_row, const float* pair_w, int32_t B, int32_t T, float temperature,
+                                   float grad_scale, float* loss, void* workspace, size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(teacher_logits && pair_row && pair_w && loss && workspace, UVX_ERR_INVALID, "llm_kl_loss: null argument");
+  UVX_CHECK(teacher_rows > 0, UVX_ERR_SHAPE, "llm_kl_loss: no teacher rows");
+  const uvx_config_t& c = *cfg;
+  if (B == 0 || T == 0) return UVX_OK;
+  Arena a(workspace, ws_bytes);
+  LlmWs s = llm_carve(a, c, B, T, 1);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_kl_loss: workspace %zu < %zu bytes", ws_bytes, a.off);
+  // student logits were left in the workspace by uvx_llm_fwd(save_for_bwd = 1); their gradient replaces them
+  return kl_loss_fwd_bwd((hipStream_t)stream, c.dtype, s.logits, teacher_logits, pair_row, pair_w, loss, s.ce_scratch + 2,
+                         s.logits, (long long)s.M, c.vocab, c.vocab, c.vocab, temperature, grad_scale);
+}
+
 extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
                                int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace,
                                size_t ws_bytes) {
   RC(check_cfg(cfg));
-  UVX_CHECK(w && labels && d_inputs_embeds && workspace, UVX_ERR_INVALID, "llm_bwd: null argument");
+  UVX_CHECK(w && d_inputs_embeds && workspace, UVX_ERR_INVALID, "llm_bwd: null argument");
   const uvx_config_t& c = *cfg;
   RC(llm_check(c, w, T));
   UVX_CHECK(w->lm_head_t != nullptr, UVX_ERR_INVALID, "llm_bwd: transposed weights (lm_head_t, *_t) are required");
@@ -524,7 +540,8 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
   const int dt = c.dtype, D = c.llm_d, M = s.M, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads;
 
   // d logits (in place over the saved logits), then the frozen head: d_hn = dlogits . W_head
-  RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale));
+  // (labels == NULL: uvx_llm_kl_loss already replaced the saved logits by their gradient)
+  if (labels) RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale));
   RC(gemm(st, dt, lin(s.logits, w->lm_head_t, s.d_hn, M, D, c.vocab)));
   RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps));
   for (int l = c.llm_layers - 1; l >= 0; --l) {

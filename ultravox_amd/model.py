@@ -39,6 +39,39 @@ def _torch_dtype(cfg: UltravoxConfig, dtype=None) -> torch.dtype:
     return getattr(torch, d) if isinstance(d, str) else d
 
 
+def kl_row_pairs(labels: torch.Tensor, alt_labels: torch.Tensor, eot_loss_weight: float):
+    """Host mirror of UltravoxModel._get_prediction_mask (ultravox_model.py:157-198) for both label tensors, turned
+    into the row pairs uvx_llm_kl_loss takes: the i-th prediction position of the student is scored against the
+    i-th prediction position of the teacher (boolean-mask indexing order, :226-237), likewise the end-of-turn
+    positions (:240-254).  Returns (pair_row int32 [2, B*T], pair_w f32 [2, B*T], n_pred)."""
+    def masks(lab):
+        lab = lab.detach().to("cpu")
+        lm = lab != -100
+        pred = torch.zeros_like(lm)
+        pred[:, :-1] = lm[:, 1:]
+        has = pred.any(dim=1)
+        last = pred.shape[1] - 1 - torch.flip(pred, dims=[1]).to(torch.int8).argmax(dim=1)
+        eot = torch.zeros_like(pred)
+        eot[has, last[has]] = True
+        return pred.reshape(-1), eot.reshape(-1)
+    ps, es = masks(labels)
+    pt, et = masks(alt_labels)
+    R = ps.numel()
+    pair_row = torch.full((2, R), -1, dtype=torch.int32)
+    pair_w = torch.zeros((2, R), dtype=torch.float32)
+    for slot, (ms, mt, w) in enumerate(((ps, pt, 1.0), (es, et, float(eot_loss_weight)))):
+        if slot == 1 and not eot_loss_weight > 0:
+            break                                                   # :240: the eot term only exists for a positive weight
+        i_s, i_t = torch.nonzero(ms)[:, 0], torch.nonzero(mt)[:, 0]
+        if len(i_s) != len(i_t):
+            raise ValueError(f"KL loss: {len(i_s)} student positions vs {len(i_t)} teacher positions "
+                             f"({'prediction' if slot == 0 else 'end-of-turn'} mask); the reference's F.kl_div cannot pair them")
+        pair_row[slot, i_s] = i_t.to(torch.int32)
+        if len(i_s):
+            pair_w[slot, i_s] = w / len(i_s)
+    return pair_row, pair_w, int(ps.sum())
+
+
 class UltravoxModel:
     """Same call surface as the reference's UltravoxModel for the hot path (forward / train step)."""
 
@@ -58,6 +91,7 @@ class UltravoxModel:
         self.dtype = _torch_dtype(config, dtype)
         self.code = _lib.dtype_code(self.dtype)
         self.training = False
+        self._kl_grad_scale = 1.0
         self.loss_config = LossConfig()
         self.vocab_size = config.vocab_size
         a, t = config.audio_config, config.text_config
@@ -283,21 +317,61 @@ class UltravoxModel:
                 alt_attention_mask=None, alt_labels=None, return_logits: bool = True, _save_for_bwd: bool = False,
                 **kwargs) -> CausalLMOutputWithPast:
         if past_key_values is not None:
-            raise NotImplementedError("KV-cache decoding is a 'next' row (SURVEY.md §8f-1), not built yet")
+            raise NotImplementedError("forward() with an external KV cache is not built; use generate() (prefill + decode)")
+        use_kl = False
         if self.training and self.loss_config.loss_function != LossFunction.CrossEntropy:
-            if self.loss_config.loss_function == LossFunction.KL_Divergence:
-                raise NotImplementedError("KL distillation loss is a 'next' row (SURVEY.md §8f-2), not built yet")
-            raise ValueError(f"Unsupported loss function: {self.loss_config.loss_function}")
+            if self.loss_config.loss_function != LossFunction.KL_Divergence:
+                raise ValueError(f"Unsupported loss function: {self.loss_config.loss_function}")
+            use_kl = True
         if audio_values is not None and len(audio_values) > 0:
             inputs_embeds = self._prepare_audio_embeds(inputs_embeds, input_ids, audio_values, audio_token_start_idx,
                                                        audio_lens, audio_token_len, audio_batch_size)
         elif inputs_embeds is None:
             B, T = input_ids.shape
             inputs_embeds = self._embed_merge(None, input_ids, None, None, None, None, B, T)
-        return self.language_model_forward(inputs_embeds, labels=labels, attention_mask=attention_mask,
-                                           want_logits=return_logits, save_for_bwd=_save_for_bwd)
+        if not use_kl:
+            return self.language_model_forward(inputs_embeds, labels=labels, attention_mask=attention_mask,
+                                               want_logits=return_logits, save_for_bwd=_save_for_bwd)
+        return self._kl_forward(inputs_embeds, labels, attention_mask, alt_input_ids, alt_attention_mask, alt_labels,
+                                return_logits)
 
     __call__ = forward
+
+    def _kl_forward(self, inputs_embeds, labels, attention_mask, alt_input_ids, alt_attention_mask, alt_labels,
+                    return_logits) -> CausalLMOutputWithPast:
+        """LossFunction.KL_Divergence (ultravox_model.py:335-345 -> _compute_kl_loss :200-256): a text-only teacher
+        pass of the same frozen LLM over alt_input_ids (no_grad), then KL(teacher || student) at kl_temperature over
+        the prediction positions plus eot_loss_weight x the end-of-turn positions."""
+        if labels is None:
+            raise ValueError("labels must be provided")          # _get_prediction_mask, :178-179
+        if alt_input_ids is None or alt_labels is None:
+            raise ValueError("alt_input_ids / alt_labels are required for the KL loss (include_alt_fields)")
+        l = _lib.lib()
+        dev = self.device
+        V = self.config.vocab_size
+        pair_row, pair_w, n_pred = kl_row_pairs(labels, alt_labels, self.loss_config.eot_loss_weight)
+        # teacher (its own workspace: the student's holds the activations for the backward pass)
+        Bt, Tt = alt_input_ids.shape
+        alt_embeds = self._embed_merge(None, alt_input_ids, None, None, None, None, Bt, Tt)
+        nbt = l.uvx_llm_ws_bytes(C.byref(self._c), Bt, Tt, 0)
+        wst = self._workspace("llm_teacher", nbt)
+        t_logits = self._workspace("teacher_logits", Bt * Tt * V * self.proj_flat.element_size()).view(self.dtype)[: Bt * Tt * V]
+        am = None if alt_attention_mask is None else alt_attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        check(l.uvx_llm_fwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(alt_embeds.contiguous()), ptr(am), None,
+                            Bt, Tt, ptr(t_logits), None, 0, ptr(wst), C.c_size_t(nbt)), "uvx_llm_fwd")
+        # student: activations kept for the backward pass; logits stay in the workspace
+        out = self.language_model_forward(inputs_embeds, labels=None, attention_mask=attention_mask,
+                                          want_logits=return_logits, save_for_bwd=True)
+        B, T, nb, _ = self._llm_ctx
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        pr, pw = pair_row.to(dev), pair_w.to(dev)
+        check(l.uvx_llm_kl_loss(stream_ptr(), C.byref(self._c), ptr(t_logits), C.c_int64(Bt * Tt), ptr(pr), ptr(pw), B, T,
+                                C.c_float(self.loss_config.kl_temperature), C.c_float(self._kl_grad_scale), ptr(loss),
+                                ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_kl_loss")
+        if n_pred == 0:
+            loss = loss + float("nan")       # F.kl_div(reduction="batchmean") over zero rows: 0 / 0
+        self._llm_ctx = (B, T, nb, None)     # uvx_llm_bwd(labels = NULL): gradient already in place of the logits
+        return CausalLMOutputWithPast(loss=loss[0], logits=out.logits)
 
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, audio_values: Optional[torch.Tensor] = None,
@@ -361,7 +435,9 @@ class UltravoxModel:
         if not self.with_backward:
             raise _lib.UvxError("model was built with with_backward=False")
         assert batch.get("labels") is not None, "labels are required for a training step"
+        self._kl_grad_scale = grad_scale
         out = self.forward(return_logits=False, _save_for_bwd=True, **batch)
+        self._kl_grad_scale = 1.0
         l = _lib.lib()
         B, T, nb, lab = self._llm_ctx
         D = self.config.text_config.hidden_size

@@ -145,3 +145,15 @@ def ce_loss(logits, labels, want_grad=True, grad_scale=1.0, in_place=False):
     check(_lib.lib().uvx_ce_loss(stream_ptr(), _code(logits), ptr(logits), ptr(labels.contiguous()), ptr(loss), ptr(dl),
                                  B, T, V, logits.stride(1), C.c_float(grad_scale), ptr(scratch)), "uvx_ce_loss")
     return loss[0], dl
+
+
+def kl_loss(student, teacher, pair_row, pair_w, temperature, want_grad=True, grad_scale=1.0):
+    """student [R, V], teacher [Rt, V]; pair_row int32 [2, R], pair_w f32 [2, R] -> (loss, dlogits or None)."""
+    R, V = student.shape
+    loss = torch.zeros(1, device=student.device, dtype=torch.float32)
+    dl = torch.empty_like(student) if want_grad else None
+    scratch = torch.empty(R, device=student.device, dtype=torch.float32)
+    check(_lib.lib().uvx_kl_loss(stream_ptr(), _code(student), ptr(student), ptr(teacher), ptr(pair_row.contiguous()),
+                                 ptr(pair_w.contiguous()), ptr(loss), ptr(dl), C.c_int64(R), V, student.stride(0),
+                                 teacher.stride(0), C.c_float(temperature), C.c_float(grad_scale), ptr(scratch)), "uvx_kl_loss")
+    return loss[0], dl
