@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the live HIP-event timing of the GEMM kernel")
+    ap.add_argument("--gemm-override", default=None, help="probe: 'MxNxK=variant,...' tile-variant overrides")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table (from the HIP events) here")
     args = ap.parse_args()
 
@@ -169,6 +170,11 @@ def main():
     from ultravox_amd.model import UltravoxModel, UltravoxTrainer
     from ultravox_amd.synthetic import synthetic_batch
 
+    if args.gemm_override:
+        for item in args.gemm_override.split(","):
+            shp, v = item.split("=")
+            m, n, k = (int(x) for x in shp.split("x"))
+            _lib.lib().uvx_gemm_override_variant(m, n, k, int(v))
     wl = WORKLOADS[args.workload]
     B = args.batch or wl["B"]
     cfg = UltravoxConfig(audio_model_id=wl["audio"], text_model_id=wl["text"], hidden_size=4096, stack_factor=8,

@@ -25,6 +25,14 @@ extern "C" int32_t uvx_gemm_force_variant(int32_t v) {
   return UVX_OK;
 }
 
+extern "C" int32_t uvx_gemm_override_variant(int32_t M, int32_t N, int32_t K, int32_t variant) {
+  if (variant < 0) { uvx::g_gemm_ovr_n = 0; return UVX_OK; }
+  UVX_CHECK(uvx::g_gemm_ovr_n < 32, UVX_ERR_INVALID, "gemm override table full");
+  int* o = uvx::g_gemm_ovr[uvx::g_gemm_ovr_n++];
+  o[0] = M; o[1] = N; o[2] = K; o[3] = variant;
+  return UVX_OK;
+}
+
 extern "C" int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g) {
   UVX_CHECK(g != nullptr, UVX_ERR_INVALID, "uvx_gemm: null descriptor");
   uvx::GemmDesc d;

@@ -17,10 +17,15 @@
 // (rows = 4 consecutive n per lane, col = m) stores 4 consecutive output columns per lane: 8-byte
 // bf16x4 / 16-byte f32x4 stores, bias as one vector load.
 #include <math.h>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
-namespace uvx { int g_gemm_variant = -1; int g_gemm_split = 1; }  // -1 = automatic; probes may force a tile variant / disable the tail split
+namespace uvx {
+int g_gemm_variant = -1; int g_gemm_split = 1;
+// probe hook: per-shape variant overrides (in-situ A/B of the tile choice inside bench.py)
+int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
+}  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
 
@@ -319,7 +324,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide_kernel(GemmArgs p) {
 //   WAR: sub-tile s+3 lands in the buffer of s-1, whose last fragment reads (L(s-1) of either group) were
 //        retired by lgkmcnt(0) before the barrier that precedes this issue.
 // Swizzle for 64-byte rows: chunk position = chunk ^ ((-(row >> 2)) & 3)  (conflict-free ds_read_b128).
-template <int BM>
+// MODE (probe builds only): 0 = the kernel; 1 = operand delivery only (fragments are read, MFMAs skipped);
+// 2 = arithmetic only (no LDS-DMA after the prologue: stale LDS contents are multiplied).
+template <int BM, int MODE = 0>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   constexpr int BNW = 256, KS = 32, NBUF = 4;
   constexpr int MI = BM / 32;
@@ -396,13 +403,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   for (int s = 0; s < ns; ++s) {
     // ---- L segment ----
     const char* cur = lds + (s & (NBUF - 1)) * SUB;
-    if (s + 3 < ns) issue(s + 3);
+    if (MODE != 2 && s + 3 < ns) issue(s + 3);
     bf16x8_t xa[MI], wa[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wa[j] = *reinterpret_cast<const bf16x8_t*>(cur + woff + j * 16 * 64);
 #pragma unroll
     for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8_t*>(cur + xoff + i * 16 * 64);
-    if (s + 3 < ns) UVX_VMCNT(2 * NL);
+    if (MODE == 2) UVX_VMCNT(0);
+    else if (s + 3 < ns) UVX_VMCNT(2 * NL);
     else if (s + 2 < ns) UVX_VMCNT(NL);
     else UVX_VMCNT(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -414,8 +422,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[j][i], 0, 0, 0);
+      for (int i = 0; i < MI; ++i) {
+        if (MODE != 1) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[j][i], 0, 0, 0);
+        else asm volatile("" ::"v"(wa[j]), "v"(xa[i]));
+      }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -425,6 +435,309 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 #undef UVX_VMCNT
 
   store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Eight-phase kernel: 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 per wave), full 128-byte rows in LDS (one
+// L2 request per cache line, half the requests of the k32 ring above), four phases per K-tile.  The K-tile is
+// staged as four 16 KiB half-tiles chosen so that each is read in exactly ONE phase by every wave:
+//   XA = the first 64 rows of each wave-row's 128 X rows,  XB = the other 64;
+//   WA = the first 32 rows of each wave-column's 64 W rows, WB = the other 32.
+// Phase      ds_read (per wave)           MFMA (16 each: 4 X frags x 2 W frags x 2 k-halves)   LDS-DMA issued (2 per wave)
+//   1        XA (8) + WA (4)              XA x WA                                              XB of tile t+1
+//   2        WB (4)                       XA x WB                                              XA of tile t+2
+//   3        XB (8)                       XB x WB                                              WA of tile t+2
+//   4        -                            XB x WA  (WA kept in registers)                      WB of tile t+2
+// Two buffer sets (tile parity) x 4 half-tiles = 128 KiB.  The only DMA wait is a counted vmcnt(6) in phase 4
+// (the three half-tiles issued in phases 2-4 stay in flight): everything of tile t+1 has then landed and is read
+// from the next phase on.  Every phase is [reads + DMA issue, lgkmcnt(0), barrier, MFMAs under setprio, barrier];
+// wave-row 1 runs one barrier behind wave-row 0, so on every SIMD one wave is in its MFMA section while the
+// other is in its load section.
+//   RAW: a half-tile is read >= one full phase after the counted wait (+ barrier) that retired its DMA.
+//   WAR: a half-tile is re-staged >= one phase after its last read, whose lgkmcnt(0) precedes that phase's
+//        first barrier in BOTH wave groups.
+__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
+  constexpr int BM = 256, BNW = 256;
+  constexpr int HT = 128 * 128;                 // one half-tile: 128 rows x 128 B
+  constexpr int SET = 4 * HT;                   // XA, XB, WA, WB
+  __shared__ __attribute__((aligned(16))) char lds[2 * SET];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BNW;
+  const long long z = blockIdx.y;
+  const bf16_t* A = p.A + z * p.sA;
+  const bf16_t* B = p.B + z * p.sB;
+
+  // staging: wave w issues instructions q = 2w, 2w+1 of every half-tile; instruction q covers half-tile rows
+  // 8q .. 8q+7, lane -> row 8q + (lane >> 3), LDS chunk position lane & 7 holds source chunk (lane & 7) ^ (row & 7)
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  const bf16_t* gx[2][2];   // [half A/B][instruction]
+  const bf16_t* gw[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int hr = (2 * w + i) * 8 + srow;                       // half-tile row 0..127
+    const int xr = (hr >> 6) * 128 + (hr & 63);                  // X tile row of half A (half B: + 64)
+    const int wn = (hr >> 5) * 64 + (hr & 31);                   // W tile row of half A (half B: + 32)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      gx[h][i] = A + (long long)min(m0 + xr + h * 64, p.M - 1) * p.lda + schunk * 8;
+      gw[h][i] = B + (long long)min(n0 + wn + h * 32, p.N - 1) * p.ldb + schunk * 8;
+    }
+  }
+  const int frow = lane & 15, fg = lane >> 4;
+  // fragment byte offsets inside a half-tile for k-half 0 / 1 (chunk fg + 4 kh, swizzled by row & 7 = frow & 7)
+  int xo[2], wo[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const int c = ((fg + 4 * kh) ^ (frow & 7)) * 16;
+    xo[kh] = (wr * 64 + frow) * 128 + c;
+    wo[kh] = (wc * 32 + frow) * 128 + c;
+  }
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // half ids inside a buffer set: 0 = XA, 1 = XB, 2 = WA, 3 = WB
+  auto stage = [&](int t, int half) {
+    char* dst = lds + (t & 1) * SET + half * HT + (2 * w) * 1024;
+    const int k0 = t * BK;
+    const bf16_t* const* g = half < 2 ? gx[half] : gw[half - 2];
+    glds16(g[0] + k0, dst);
+    glds16(g[1] + k0, dst + 1024);
+  };
+#define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define UVX_PHASE_SYNC()                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  __builtin_amdgcn_s_barrier();                            \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  __builtin_amdgcn_s_setprio(1)
+#define UVX_PHASE_END()                                    \
+  __builtin_amdgcn_s_setprio(0);                           \
+  __builtin_amdgcn_sched_barrier(0);                       \
+  __builtin_amdgcn_s_barrier();                            \
+  __builtin_amdgcn_sched_barrier(0)
+
+  const int nk = p.K / BK;
+  stage(0, 0); stage(0, 2); stage(0, 3); stage(0, 1);
+  if (nk > 1) { stage(1, 0); stage(1, 2); stage(1, 3); UVX_VMCNT(6); }
+  else UVX_VMCNT(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: this half runs one barrier behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int t = 0; t < nk; ++t) {
+    const char* set = lds + (t & 1) * SET;
+    bf16x8_t xa[4][2], wa[2][2], wb[2][2];
+    // ---- phase 1: XA x WA ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) wa[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + 2 * HT + wo[kh] + j * 16 * 128);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xo[kh] + i * 16 * 128);
+    if (t + 1 < nk) stage(t + 1, 1);
+    UVX_PHASE_SYNC();
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][i], 0, 0, 0);
+    UVX_PHASE_END();
+    // ---- phase 2: XA x WB ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) wb[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + 3 * HT + wo[kh] + j * 16 * 128);
+    if (t + 2 < nk) stage(t + 2, 0);
+    UVX_PHASE_SYNC();
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[2 + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][i], 0, 0, 0);
+    UVX_PHASE_END();
+    // ---- phase 3: XB x WB ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + HT + xo[kh] + i * 16 * 128);
+    if (t + 2 < nk) stage(t + 2, 2);
+    UVX_PHASE_SYNC();
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[2 + j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][4 + i], 0, 0, 0);
+    UVX_PHASE_END();
+    // ---- phase 4: XB x WA; the counted wait that retires tile t+1 ----
+    if (t + 2 < nk) { stage(t + 2, 3); UVX_VMCNT(6); }
+    else UVX_VMCNT(0);
+    UVX_PHASE_SYNC();
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][4 + i], 0, 0, 0);
+    UVX_PHASE_END();
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
+#undef UVX_VMCNT
+#undef UVX_PHASE_SYNC
+#undef UVX_PHASE_END
+
+  store_tile<4, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, frow, fg, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Four-wave kernel: 256 x 256 tile, ONE wave per SIMD, 128 x 128 per wave (64 accumulator fragments = 256
+// registers, the other half of the 512-entry file holds two generations of operand fragments).  Per 32-wide
+// K stage a wave issues 64 MFMAs against 16 ds_read_b128 and 8 LDS-DMA instructions - half the LDS read traffic
+// per FLOP of the 8-wave kernels - and nothing else competes for its SIMD, so all latency hiding is software
+// pipelining inside the wave: while stage s is multiplied from registers, the fragments of stage s+1 are read
+// from LDS into the other register generation and the DMA for stage s+3 is issued; sched_group_barrier pins the
+// interleave (1 DS read and at most 1 DMA per 4 MFMAs).  4-deep LDS ring of 32 KiB stages, one barrier per stage.
+//   RAW: stage s+2 is waited for (counted vmcnt) + barrier at the end of stage s, read during stage s+1.
+//   WAR: the DMA for stage s+3 overwrites the buffer of stage s-1, whose fragment reads (issued during stage
+//        s-2) were retired by lgkmcnt(0) before the barrier that ended stage s-2.
+__global__ __launch_bounds__(256, 1) void gemm_nt_bf16_q4_kernel(GemmArgs p) {
+  constexpr int BM = 256, BNW = 256, KS = 32, NBUF = 4;
+  constexpr int XB = BM * 64, SUB = XB + BNW * 64;
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * SUB];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BNW;
+  const long long z = blockIdx.y;
+  const bf16_t* A = p.A + z * p.sA;
+  const bf16_t* B = p.B + z * p.sB;
+
+  // staging: instruction q (0..15 for X, 0..15 for W) covers tile rows 16q..16q+15; wave w issues q = w, w+4, w+8, w+12
+  const int srow = lane >> 2;
+  const int schunk = (lane & 3) ^ ((-(srow >> 2)) & 3);
+  const bf16_t* ap[4];
+  const bf16_t* bp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = (i * 4 + w) * 16 + srow;
+    ap[i] = A + (long long)min(m0 + rr, p.M - 1) * p.lda + schunk * 8;
+    bp[i] = B + (long long)min(n0 + rr, p.N - 1) * p.ldb + schunk * 8;
+  }
+  const int frow = lane & 15, fg = lane >> 4;
+  const int fpos = fg ^ ((-(frow >> 2)) & 3);
+  const int xoff = (wr * 128 + frow) * 64 + fpos * 16;
+  const int woff = XB + (wc * 128 + frow) * 64 + fpos * 16;
+
+  f32x4_t acc[8][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int s) {
+    char* buf = lds + (s & (NBUF - 1)) * SUB;
+    const int k0 = s * KS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(ap[i] + k0, buf + (i * 4 + w) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(bp[i] + k0, buf + XB + (i * 4 + w) * 1024);
+  };
+#define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+  const int ns = p.K / KS;   // even (K is a multiple of 64)
+  issue(0);
+  issue(1);
+  if (ns > 2) { issue(2); UVX_VMCNT(8); }
+  else UVX_VMCNT(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  bf16x8_t xa[2][8], wa[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wa[0][j] = *reinterpret_cast<const bf16x8_t*>(lds + woff + j * 16 * 64);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xa[0][i] = *reinterpret_cast<const bf16x8_t*>(lds + xoff + i * 16 * 64);
+
+  // DMA / FRAG are compile-time so that the steady-state body is ONE basic block (sched_group_barrier cannot
+  // interleave across branches); the last stages are peeled below.
+  auto stage = [&](auto PAR, auto DMA_, auto FRAG_, int s) {
+    constexpr int P = decltype(PAR)::value;
+    constexpr bool DMA = decltype(DMA_)::value, FRAG = decltype(FRAG_)::value;
+    if (DMA) issue(s + 3);
+    if (FRAG) {
+      const char* nb = lds + ((s + 1) & (NBUF - 1)) * SUB;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wa[P ^ 1][j] = *reinterpret_cast<const bf16x8_t*>(nb + woff + j * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xa[P ^ 1][i] = *reinterpret_cast<const bf16x8_t*>(nb + xoff + i * 16 * 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[P][j], xa[P][i], acc[j][i], 0, 0, 0);
+    // interleave: 16 groups of {MFMA, DS read, MFMA, DMA (first 8 groups), 2 MFMA}
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (FRAG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (DMA && g < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (DMA) UVX_VMCNT(8);
+    else UVX_VMCNT(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using T = std::true_type;
+  using F = std::false_type;
+  int s = 0;
+  for (; s + 4 < ns; s += 2) {
+    stage(I0{}, T{}, T{}, s);
+    stage(I1{}, T{}, T{}, s + 1);
+  }
+  if (ns - s == 4) {
+    stage(I0{}, T{}, T{}, s);
+    stage(I1{}, F{}, T{}, s + 1);
+    s += 2;
+  }
+  stage(I0{}, F{}, T{}, s);
+  stage(I1{}, F{}, F{}, s + 1);
+#undef UVX_VMCNT
+
+  store_tile<8, 8>(p, acc, m0 + wr * 128, n0 + wc * 128, frow, fg, z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,12 +847,17 @@ struct Variant { int bm, bn; double speed; };
 // 5..8 = ping-pong {128,160,192,256} x 256.  (Also measured and dropped, profiles/r01_gemm_variants.txt: a
 // 32x32x16-MFMA flavour, 10-20 % slower; a 4-wave kernel with 128x128 wave tiles in the 512-register file — the
 // geometry hipBLASLt's hand-scheduled MT256x256x64 kernel uses — 30-60 % slower under hipcc's scheduling.)
-constexpr int kNumVariants = 11;  // 9, 10 = three-buffer {128,160} x 256 (speed 0: probe only)
-const Variant kVariants[kNumVariants] = {{128, 128, 850.}, {128, 256, 870.}, {160, 256, 1010.}, {192, 256, 1050.},
-                                         {256, 256, 1085.}, {128, 256, 860.}, {160, 256, 985.}, {192, 256, 980.},
-                                         {256, 256, 1090.}, {128, 256, 0.}, {160, 256, 0.}};
-double variant_speed(int v, int K) {
-  if (v == 10) return K >= 16384 ? 1100. : 980.;  // three-buffer 160x256: +15 % on very deep K, -3 % otherwise (measured)
+constexpr int kNumVariants = 15;  // 9 = three-buffer 128 x 256 (speed 0: probe only); 11 = 8-phase 256 x 256
+// Speeds (TF/s at a whole number of rounds) come from tools/gpu_gemm_cold_probe.py: every launch reads a DIFFERENT
+// weight matrix, as in the training step (16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache).
+// A back-to-back probe on one weight buffer overstates the double-buffered kernels by 10-25 % and ranks them wrongly.
+const Variant kVariants[kNumVariants] = {{128, 128, 850.}, {128, 256, 870.}, {160, 256, 950.}, {192, 256, 1050.},
+                                         {256, 256, 1085.}, {128, 256, 860.}, {160, 256, 970.}, {192, 256, 980.},
+                                         {256, 256, 1110.}, {128, 256, 0.}, {160, 256, 1070.}, {256, 256, 1190.}, {256, 256, 0.}, {256, 256, 0.}, {256, 256, 0.}};
+double variant_speed(int v, int K, double tiles) {
+  // three-buffer 160x256: the only variant whose prefetch depth (two K-tiles in flight) covers HBM latency with a
+  // single resident block per CU: 1040-1105 when the problem is ONE round of tiles, ~990 over several rounds
+  if (v == 10) return tiles <= 256. ? (K >= 16384 ? 1105. : 1070.) : 990.;
   return kVariants[v].speed;
 }
 double variant_cost(int v, int M, int N, int K, int batch) {
@@ -549,15 +867,20 @@ double variant_cost(int v, int M, int N, int K, int batch) {
   // measured behaviour is well described by floor(r) + sqrt(frac(r)).
   const double r = tiles / 256.0;
   const double rounds = floor(r) + sqrt(r - floor(r));
-  return rounds * kVariants[v].bm * kVariants[v].bn / variant_speed(v, K);
+  return rounds * kVariants[v].bm * kVariants[v].bn / variant_speed(v, K, tiles);
 }
 int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
-  const int forced = uvx::g_gemm_variant;
+  int forced = uvx::g_gemm_variant;
+  for (int i = 0; i < uvx::g_gemm_ovr_n; ++i)
+    if (uvx::g_gemm_ovr[i][0] == M && uvx::g_gemm_ovr[i][1] == N && uvx::g_gemm_ovr[i][2] == K) forced = uvx::g_gemm_ovr[i][3];
   double best = 1e30;
   int best_v = 0;
+  if (forced >= 0 && forced < kNumVariants) {   // probe-only variants carry speed 0: never let the cost model veto them
+    if (cost_out) *cost_out = kVariants[forced].speed > 0. ? variant_cost(forced, M, N, K, batch) : 0.;
+    return forced;
+  }
   for (int v = 0; v < kNumVariants; ++v) {
-    if (forced >= 0 && v != forced) continue;
-    if (forced < 0 && variant_speed(v, K) <= 0.) continue;
+    if (kVariants[v].speed <= 0.) continue;
     const double cost = variant_cost(v, M, N, K, batch);
     if (cost < best) { best = cost; best_v = v; }
   }
@@ -580,7 +903,11 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 7: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<192>, grid, dim3(512), 0, st, a); break;
     case 8: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), 0, st, a); break;
     case 9: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<128>, grid, dim3(512), 0, st, a); break;
-    default: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<160>, grid, dim3(512), 0, st, a); break;
+    case 10: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<160>, grid, dim3(512), 0, st, a); break;
+    case 11: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel, grid, dim3(512), 0, st, a); break;
+    case 12: hipLaunchKernelGGL(gemm_nt_bf16_q4_kernel, grid, dim3(256), 0, st, a); break;
+    case 13: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 1>), grid, dim3(512), 0, st, a); break;   // probe: delivery only
+    default: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 2>), grid, dim3(512), 0, st, a); break;  // probe: arithmetic only
   }
 }
 

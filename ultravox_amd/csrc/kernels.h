@@ -44,6 +44,8 @@ struct GemmDesc {
 
 extern int g_gemm_variant;
 extern int g_gemm_split;
+extern int g_gemm_ovr_n;
+extern int g_gemm_ovr[32][4];
 // bf16 operands, f32 accumulate (MFMA 16x16x32).
 int gemm_nt(hipStream_t st, const GemmDesc& d);
 // f32 operands/outputs (parity mode; MFMA 16x16x4 f32).

@@ -352,7 +352,9 @@ class UltravoxModel:
         pair_row, pair_w, n_pred = kl_row_pairs(labels, alt_labels, self.loss_config.eot_loss_weight)
         # teacher (its own workspace: the student's holds the activations for the backward pass)
         Bt, Tt = alt_input_ids.shape
+        student_merge = self._merge_ctx          # the teacher's plain embedding lookup must not replace it
         alt_embeds = self._embed_merge(None, alt_input_ids, None, None, None, None, Bt, Tt)
+        self._merge_ctx = student_merge
         nbt = l.uvx_llm_ws_bytes(C.byref(self._c), Bt, Tt, 0)
         wst = self._workspace("llm_teacher", nbt)
         t_logits = self._workspace("teacher_logits", Bt * Tt * V * self.proj_flat.element_size()).view(self.dtype)[: Bt * Tt * V]
