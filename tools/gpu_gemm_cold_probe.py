@@ -12,8 +12,11 @@ L = _lib.lib()
 VARIANTS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 4, 6, 8, 10]
 shapes = [(2528, 4096, 14336), (2528, 4096, 4096), (2528, 4096, 6144), (2528, 4096, 28672), (2528, 28672, 4096),
           (2528, 14336, 4096), (2528, 6144, 4096)]
+if len(sys.argv) > 2 and sys.argv[2] == "enc":   # encoder / projector shapes (small weights: the pool still rotates them)
+    shapes = [(12000, 4096, 1024), (12000, 1024, 4096), (12000, 3072, 1024), (12000, 1024, 1024), (1504, 4096, 8192),
+              (1504, 8192, 4096), (4096, 8192, 1536)]
 for (M, N, K) in shapes:
-    npool = max(2, -(-(1200 << 20) // (N * K * 2)))
+    npool = min(64, max(2, -(-(1200 << 20) // (N * K * 2))))
     ws = [torch.randn(N, K, device=dev).bfloat16() for _ in range(npool)]
     a = torch.randn(M, K, device=dev).bfloat16()
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)

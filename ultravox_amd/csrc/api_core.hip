@@ -25,6 +25,8 @@ extern "C" int32_t uvx_gemm_force_variant(int32_t v) {
   return UVX_OK;
 }
 
+extern "C" int32_t uvx_gemm_pick_variant(int32_t M, int32_t N, int32_t K, int32_t batch) { return uvx::gemm_pick_variant(M, N, K, batch); }
+
 extern "C" int32_t uvx_gemm_override_variant(int32_t M, int32_t N, int32_t K, int32_t variant) {
   if (variant < 0) { uvx::g_gemm_ovr_n = 0; return UVX_OK; }
   UVX_CHECK(uvx::g_gemm_ovr_n < 32, UVX_ERR_INVALID, "gemm override table full");

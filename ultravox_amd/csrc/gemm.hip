@@ -456,11 +456,26 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 //   RAW: a half-tile is read >= one full phase after the counted wait (+ barrier) that retired its DMA.
 //   WAR: a half-tile is re-staged >= one phase after its last read, whose lgkmcnt(0) precedes that phase's
 //        first barrier in BOTH wave groups.
+// Generalised to BM x 256 tiles (BM = 32 MI): each wave-row owns MI fragments of X rows, split MA = ceil(MI/2) in
+// half A and MB = MI - MA in half B; phases 1/2 issue 2 MA x 2 MFMAs, phases 3/4 issue 2 MB x 2.  The DMA schedule is
+// an ordered list of 1 KiB instructions (8 rows x 128 B): [XB of t+1] in phase 1 and [XA | WA | WB of t+2] spread
+// evenly over phases 2-4; every wave issues the same count per phase (surplus slots go to a dummy 1 KiB target),
+// so the counted wait in phase 4 is exact.
+template <int BM>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
-  constexpr int BM = 256, BNW = 256;
-  constexpr int HT = 128 * 128;                 // one half-tile: 128 rows x 128 B
-  constexpr int SET = 4 * HT;                   // XA, XB, WA, WB
-  __shared__ __attribute__((aligned(16))) char lds[2 * SET];
+  constexpr int BNW = 256;
+  constexpr int MI = BM / 32, MA = (MI + 1) / 2, MB = MI - MA;
+  constexpr int XA_ROWS = 2 * MA * 16, XB_ROWS = 2 * MB * 16;
+  constexpr int XA_I = XA_ROWS / 8, XB_I = XB_ROWS / 8, W_I = 16;          // DMA instructions per region
+  constexpr int O_XA = 0, O_XB = XA_ROWS * 128, O_WA = O_XB + XB_ROWS * 128, O_WB = O_WA + 128 * 128;
+  constexpr int SET = O_WB + 128 * 128;
+  constexpr int REST = XA_I + 2 * W_I;
+  constexpr int N1 = (XB_I + 7) / 8;                                       // per wave, phase 1
+  constexpr int N234 = (REST + 7) / 8;                                     // per wave, phases 2-4 together
+  constexpr int N2 = (N234 + 2) / 3, N3 = (N234 - N2 + 1) / 2, N4 = N234 - N2 - N3;
+  static_assert(8 * N2 <= XA_I + W_I, "WB must not be re-staged in the phase that reads it");
+  __shared__ __attribute__((aligned(16))) char lds[2 * SET + 1024];
+  constexpr int O_DUMMY = 2 * SET;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -474,45 +489,53 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
 
-  // staging: wave w issues instructions q = 2w, 2w+1 of every half-tile; instruction q covers half-tile rows
-  // 8q .. 8q+7, lane -> row 8q + (lane >> 3), LDS chunk position lane & 7 holds source chunk (lane & 7) ^ (row & 7)
+  // one DMA instruction = rows 8q .. 8q+7 of a region; lane -> row 8q + (lane >> 3), LDS chunk position lane & 7
+  // holds source chunk (lane & 7) ^ (row & 7)
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const bf16_t* gx[2][2];   // [half A/B][instruction]
-  const bf16_t* gw[2][2];
+  struct Slot { const bf16_t* g; int off; };
+  auto x_slot = [&](bool half_b, int q) {
+    const int per = (half_b ? MB : MA) * 16;
+    const int hr = q * 8 + srow, wrr = hr / per, rem = hr - wrr * per;
+    const int row = wrr * (BM / 2) + (half_b ? MA * 16 : 0) + rem;
+    return Slot{A + (long long)min(m0 + row, p.M - 1) * p.lda + schunk * 8, (half_b ? O_XB : O_XA) + q * 1024};
+  };
+  auto w_slot = [&](bool half_b, int q) {
+    const int hr = q * 8 + srow;
+    const int n = (hr >> 5) * 64 + (half_b ? 32 : 0) + (hr & 31);
+    return Slot{B + (long long)min(n0 + n, p.N - 1) * p.ldb + schunk * 8, (half_b ? O_WB : O_WA) + q * 1024};
+  };
+  const Slot dummy = Slot{A + (long long)min(m0, p.M - 1) * p.lda + schunk * 8, -1};
+  Slot sxb[N1], srest[N234];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int hr = (2 * w + i) * 8 + srow;                       // half-tile row 0..127
-    const int xr = (hr >> 6) * 128 + (hr & 63);                  // X tile row of half A (half B: + 64)
-    const int wn = (hr >> 5) * 64 + (hr & 31);                   // W tile row of half A (half B: + 32)
+  for (int k = 0; k < N1; ++k) {
+    const int g = k * 8 + w;
+    sxb[k] = g < XB_I ? x_slot(true, g) : dummy;
+  }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      gx[h][i] = A + (long long)min(m0 + xr + h * 64, p.M - 1) * p.lda + schunk * 8;
-      gw[h][i] = B + (long long)min(n0 + wn + h * 32, p.N - 1) * p.ldb + schunk * 8;
-    }
+  for (int k = 0; k < N234; ++k) {
+    const int g = k * 8 + w;
+    srest[k] = g < XA_I ? x_slot(false, g) : g < XA_I + W_I ? w_slot(false, g - XA_I) : g < REST ? w_slot(true, g - XA_I - W_I) : dummy;
   }
   const int frow = lane & 15, fg = lane >> 4;
-  // fragment byte offsets inside a half-tile for k-half 0 / 1 (chunk fg + 4 kh, swizzled by row & 7 = frow & 7)
-  int xo[2], wo[2];
+  int xo[2], wo[2];   // fragment byte offsets (k-half 0 / 1) relative to the region base
 #pragma unroll
   for (int kh = 0; kh < 2; ++kh) {
     const int c = ((fg + 4 * kh) ^ (frow & 7)) * 16;
-    xo[kh] = (wr * 64 + frow) * 128 + c;
+    xo[kh] = frow * 128 + c;
     wo[kh] = (wc * 32 + frow) * 128 + c;
   }
+  const int xa_base = O_XA + wr * MA * 16 * 128, xb_base = O_XB + wr * MB * 16 * 128;
 
-  f32x4_t acc[4][8];
+  f32x4_t acc[4][MI];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // half ids inside a buffer set: 0 = XA, 1 = XB, 2 = WA, 3 = WB
-  auto stage = [&](int t, int half) {
-    char* dst = lds + (t & 1) * SET + half * HT + (2 * w) * 1024;
-    const int k0 = t * BK;
-    const bf16_t* const* g = half < 2 ? gx[half] : gw[half - 2];
-    glds16(g[0] + k0, dst);
-    glds16(g[1] + k0, dst + 1024);
+  auto dma = [&](const Slot& sl, int t) {
+    // the dummy target lives behind both sets: undo the set offset for it (wave-uniform select)
+    const int set_off = (t & 1) * SET;
+    glds16(sl.g + t * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_off));
   };
 #define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define UVX_PHASE_SYNC()                                   \
@@ -528,9 +551,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   __builtin_amdgcn_sched_barrier(0)
 
   const int nk = p.K / BK;
-  stage(0, 0); stage(0, 2); stage(0, 3); stage(0, 1);
-  if (nk > 1) { stage(1, 0); stage(1, 2); stage(1, 3); UVX_VMCNT(6); }
-  else UVX_VMCNT(0);
+#pragma unroll
+  for (int k = 0; k < N234; ++k) dma(srest[k], 0);
+#pragma unroll
+  for (int k = 0; k < N1; ++k) dma(sxb[k], 0);
+  if (nk > 1) {
+#pragma unroll
+    for (int k = 0; k < N234; ++k) dma(srest[k], 1);
+    UVX_VMCNT(N234);
+  } else {
+    UVX_VMCNT(0);
+  }
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: this half runs one barrier behind
@@ -538,67 +569,81 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 
   for (int t = 0; t < nk; ++t) {
     const char* set = lds + (t & 1) * SET;
-    bf16x8_t xa[4][2], wa[2][2], wb[2][2];
-    // ---- phase 1: XA x WA ----
+    bf16x8_t xa[MA][2], wa[2][2], wb[2][2];
+    // ---- phase 1: XA x WA; DMA: XB of tile t+1 ----
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) wa[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + 2 * HT + wo[kh] + j * 16 * 128);
+      for (int kh = 0; kh < 2; ++kh) wa[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + O_WA + wo[kh] + j * 16 * 128);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MA; ++i)
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xo[kh] + i * 16 * 128);
-    if (t + 1 < nk) stage(t + 1, 1);
+      for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xa_base + xo[kh] + i * 16 * 128);
+    if (t + 1 < nk) {
+#pragma unroll
+      for (int k = 0; k < N1; ++k) dma(sxb[k], t + 1);
+    }
     UVX_PHASE_SYNC();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MA; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][i], 0, 0, 0);
     UVX_PHASE_END();
-    // ---- phase 2: XA x WB ----
+    // ---- phase 2: XA x WB; DMA: first third of [XA | WA | WB] of tile t+2 ----
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) wb[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + 3 * HT + wo[kh] + j * 16 * 128);
-    if (t + 2 < nk) stage(t + 2, 0);
+      for (int kh = 0; kh < 2; ++kh) wb[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + O_WB + wo[kh] + j * 16 * 128);
+    if (t + 2 < nk) {
+#pragma unroll
+      for (int k = 0; k < N2; ++k) dma(srest[k], t + 2);
+    }
     UVX_PHASE_SYNC();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MA; ++i)
           acc[2 + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][i], 0, 0, 0);
     UVX_PHASE_END();
     // ---- phase 3: XB x WB ----
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + HT + xo[kh] + i * 16 * 128);
-    if (t + 2 < nk) stage(t + 2, 2);
+      for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xb_base + xo[kh] + i * 16 * 128);
+    if (t + 2 < nk) {
+#pragma unroll
+      for (int k = 0; k < N3; ++k) dma(srest[N2 + k], t + 2);
+    }
     UVX_PHASE_SYNC();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[2 + j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][4 + i], 0, 0, 0);
+        for (int i = 0; i < MB; ++i)
+          acc[2 + j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][MA + i], 0, 0, 0);
     UVX_PHASE_END();
-    // ---- phase 4: XB x WA; the counted wait that retires tile t+1 ----
-    if (t + 2 < nk) { stage(t + 2, 3); UVX_VMCNT(6); }
-    else UVX_VMCNT(0);
+    // ---- phase 4: XB x WA (WA kept in registers); the counted wait that retires tile t+1 ----
+    if (t + 2 < nk) {
+#pragma unroll
+      for (int k = 0; k < N4; ++k) dma(srest[N2 + N3 + k], t + 2);
+      UVX_VMCNT(N234);
+    } else {
+      UVX_VMCNT(0);
+    }
     UVX_PHASE_SYNC();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][4 + i], 0, 0, 0);
+        for (int i = 0; i < MB; ++i)
+          acc[j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][MA + i], 0, 0, 0);
     UVX_PHASE_END();
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
@@ -606,7 +651,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 #undef UVX_PHASE_SYNC
 #undef UVX_PHASE_END
 
-  store_tile<4, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, frow, fg, z);
+  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -843,31 +888,33 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide3_kernel(GemmArgs p) 
 // round); a tile costs BM x BN / speed(variant), speeds measured on
 // MI355X (profiles/r01_gemm_variants.txt).  variant 0 = 128x128 narrow; 1..4 = {128,160,192,256} x 256 wide.
 // (A 32x32x16-MFMA flavour of the wide kernel was measured 10-20 % SLOWER than 16x16x32 and dropped.)
-struct Variant { int bm, bn; double speed; };
-// 5..8 = ping-pong {128,160,192,256} x 256.  (Also measured and dropped, profiles/r01_gemm_variants.txt: a
-// 32x32x16-MFMA flavour, 10-20 % slower; a 4-wave kernel with 128x128 wave tiles in the 512-register file — the
-// geometry hipBLASLt's hand-scheduled MT256x256x64 kernel uses — 30-60 % slower under hipcc's scheduling.)
-constexpr int kNumVariants = 15;  // 9 = three-buffer 128 x 256 (speed 0: probe only); 11 = 8-phase 256 x 256
-// Speeds (TF/s at a whole number of rounds) come from tools/gpu_gemm_cold_probe.py: every launch reads a DIFFERENT
-// weight matrix, as in the training step (16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache).
-// A back-to-back probe on one weight buffer overstates the double-buffered kernels by 10-25 % and ranks them wrongly.
-const Variant kVariants[kNumVariants] = {{128, 128, 850.}, {128, 256, 870.}, {160, 256, 950.}, {192, 256, 1050.},
-                                         {256, 256, 1085.}, {128, 256, 860.}, {160, 256, 970.}, {192, 256, 980.},
-                                         {256, 256, 1110.}, {128, 256, 0.}, {160, 256, 1070.}, {256, 256, 1190.}, {256, 256, 0.}, {256, 256, 0.}, {256, 256, 0.}};
-double variant_speed(int v, int K, double tiles) {
-  // three-buffer 160x256: the only variant whose prefetch depth (two K-tiles in flight) covers HBM latency with a
-  // single resident block per CU: 1040-1105 when the problem is ONE round of tiles, ~990 over several rounds
-  if (v == 10) return tiles <= 256. ? (K >= 16384 ? 1105. : 1070.) : 990.;
-  return kVariants[v].speed;
-}
+struct Variant { int bm, bn; double speed; double c; };
+// Tile variants: 0 = 128x128 (4 waves, several blocks per CU); 1..4 = double-buffered {128,160,192,256} x 256;
+// 5..8 = ping-pong k32 ring {128,160,192,256} x 256; 9, 10 = three-buffer {128,160} x 256; 11, 15, 16, 17 = eight-phase
+// {256,160,192,128} x 256; 12 = 4-wave kernel with 128x128 wave tiles (probe only: hipcc shuffles its 256
+// accumulators through v_accvgpr moves, 570 TF); 13, 14 = probe modes of 8.  (Also measured and dropped,
+// profiles/r01_gemm_variants.txt: a 32x32x16-MFMA flavour, 10-20 % slower.)
+//
+// Cost model.  time ~ rounds(tiles) * bm * bn * (K/64 + c) / speed: `speed` is the asymptotic TF/s of a full round of
+// tiles, `c` the fixed per-tile cost (pipeline fill, epilogue) in K-tiles.  Both are fitted to
+// tools/gpu_gemm_cold_probe.py (profiles/r01_gemm_cold_probe*.txt), where every launch reads a DIFFERENT weight matrix
+// as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
+// back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
+// speed 0 = probe only.
+constexpr int kNumVariants = 18;
+const Variant kVariants[kNumVariants] = {
+    {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
+    {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
+    {160, 256, 1162., 8.9}, {256, 256, 1380., 8.5}, {256, 256, 0., 9.},      {256, 256, 0., 9.},      {256, 256, 0., 9.},
+    {160, 256, 1230., 9.},  {192, 256, 1390., 12.}, {128, 256, 1116., 6.}};
 double variant_cost(int v, int M, int N, int K, int batch) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
-  // Rounds of tiles over the 256 CUs.  A partly filled last round is cheaper than a full one (the kernel is
-  // bound by operand delivery through the shared L2 / fabric, so fewer active CUs each run faster):
-  // measured behaviour is well described by floor(r) + sqrt(frac(r)).
-  const double r = tiles / 256.0;
-  const double rounds = floor(r) + sqrt(r - floor(r));
-  return rounds * kVariants[v].bm * kVariants[v].bn / variant_speed(v, K, tiles);
+  // Rounds of tiles over the 256 CUs.  A partly filled last round is cheaper than a full one (the kernels are bound
+  // by operand delivery through the shared L2 / fabric, so fewer active CUs each run faster) but never cheaper
+  // than ~0.55 of one: measured behaviour is well described by max(0.55, frac^0.6).
+  const double r = tiles / 256.0, frac = r - floor(r);
+  const double rounds = floor(r) + (frac > 0. ? fmax(0.55, pow(frac, 0.6)) : 0.);
+  return rounds * kVariants[v].bm * kVariants[v].bn * (K / 64.0 + kVariants[v].c) / kVariants[v].speed;
 }
 int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
   int forced = uvx::g_gemm_variant;
@@ -904,7 +951,10 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 8: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), 0, st, a); break;
     case 9: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<128>, grid, dim3(512), 0, st, a); break;
     case 10: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<160>, grid, dim3(512), 0, st, a); break;
-    case 11: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel, grid, dim3(512), 0, st, a); break;
+    case 11: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<256>, grid, dim3(512), 0, st, a); break;
+    case 15: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<160>, grid, dim3(512), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<192>, grid, dim3(512), 0, st, a); break;
+    case 17: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<128>, grid, dim3(512), 0, st, a); break;
     case 12: hipLaunchKernelGGL(gemm_nt_bf16_q4_kernel, grid, dim3(256), 0, st, a); break;
     case 13: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 1>), grid, dim3(512), 0, st, a); break;   // probe: delivery only
     default: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 2>), grid, dim3(512), 0, st, a); break;  // probe: arithmetic only
@@ -912,6 +962,8 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
 }
 
 }  // namespace
+
+int uvx::gemm_pick_variant(int M, int N, int K, int batch) { return pick_variant(M, N, K, batch > 0 ? batch : 1); }
 
 int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   UVX_CHECK(d.M > 0 && d.N > 0 && d.K > 0, UVX_ERR_SHAPE, "gemm: empty problem %dx%dx%d", d.M, d.N, d.K);
