@@ -461,7 +461,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // an ordered list of 1 KiB instructions (8 rows x 128 B): [XB of t+1] in phase 1 and [XA | WA | WB of t+2] spread
 // evenly over phases 2-4; every wave issues the same count per phase (surplus slots go to a dummy 1 KiB target),
 // so the counted wait in phase 4 is exact.
-template <int BM>
+// (Tried and dropped: reading the next tile's WA fragments in phase 4 to balance the per-phase LDS reads 8/4/8/4
+// instead of 12/4/8/0 - 3-10 % slower: the extra counted wait it needs in phase 3 shortens the DMA window.)
+// NS = number of buffer sets (K-tiles resident in LDS): 2, or 3 where 3 sets fit the 160 KiB (BM <= 160); with NS sets
+// the DMA runs NS-1 tiles ahead: phase 1 issues XB of tile t+NS-1, phases 2-4 [XA | WA | WB] of tile t+NS, and the
+// counted wait of phase 4 leaves (NS-1) N234 + (NS-2) N1 instructions in flight.
+template <int BM, int NS = 2>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   constexpr int BNW = 256;
   constexpr int MI = BM / 32, MA = (MI + 1) / 2, MB = MI - MA;
@@ -474,8 +479,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   constexpr int N234 = (REST + 7) / 8;                                     // per wave, phases 2-4 together
   constexpr int N2 = (N234 + 2) / 3, N3 = (N234 - N2 + 1) / 2, N4 = N234 - N2 - N3;
   static_assert(8 * N2 <= XA_I + W_I, "WB must not be re-staged in the phase that reads it");
-  __shared__ __attribute__((aligned(16))) char lds[2 * SET + 1024];
-  constexpr int O_DUMMY = 2 * SET;
+  static_assert(NS * SET + 1024 <= 160 * 1024, "buffer sets exceed the LDS");
+  __shared__ __attribute__((aligned(16))) char lds[NS * SET + 1024];
+  constexpr int O_DUMMY = NS * SET;
+  constexpr int INFLIGHT = (NS - 1) * N234 + (NS - 2) * N1;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -532,10 +539,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto dma = [&](const Slot& sl, int t) {
-    // the dummy target lives behind both sets: undo the set offset for it (wave-uniform select)
-    const int set_off = (t & 1) * SET;
-    glds16(sl.g + t * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_off));
+  auto dma = [&](const Slot& sl, int t, int set_idx) {   // set_idx = t % NS, tracked by the caller
+    glds16(sl.g + t * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_idx * SET));
   };
 #define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define UVX_PHASE_SYNC()                                   \
@@ -551,24 +556,29 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   __builtin_amdgcn_sched_barrier(0)
 
   const int nk = p.K / BK;
+  // prologue: REST(0), XB(0), REST(1), XB(1), ..., REST(NS-1)  (the steady-state issue order)
 #pragma unroll
-  for (int k = 0; k < N234; ++k) dma(srest[k], 0);
+  for (int tt = 0; tt < NS; ++tt) {
+    if (tt < nk) {
 #pragma unroll
-  for (int k = 0; k < N1; ++k) dma(sxb[k], 0);
-  if (nk > 1) {
+      for (int k = 0; k < N234; ++k) dma(srest[k], tt, tt);
+      if (tt < NS - 1) {
 #pragma unroll
-    for (int k = 0; k < N234; ++k) dma(srest[k], 1);
-    UVX_VMCNT(N234);
-  } else {
-    UVX_VMCNT(0);
+        for (int k = 0; k < N1; ++k) dma(sxb[k], tt, tt);
+      }
+    }
   }
+  if (nk >= NS) UVX_VMCNT(INFLIGHT);
+  else UVX_VMCNT(0);
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: this half runs one barrier behind
   __builtin_amdgcn_sched_barrier(0);
 
+  int cs = 0;   // t % NS
   for (int t = 0; t < nk; ++t) {
-    const char* set = lds + (t & 1) * SET;
+    const char* set = lds + cs * SET;
+    const int ps = cs == 0 ? NS - 1 : cs - 1;   // (t + NS - 1) % NS
     bf16x8_t xa[MA][2], wa[2][2], wb[2][2];
     // ---- phase 1: XA x WA; DMA: XB of tile t+1 ----
 #pragma unroll
@@ -579,9 +589,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     for (int i = 0; i < MA; ++i)
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xa_base + xo[kh] + i * 16 * 128);
-    if (t + 1 < nk) {
+    if (t + NS - 1 < nk) {
 #pragma unroll
-      for (int k = 0; k < N1; ++k) dma(sxb[k], t + 1);
+      for (int k = 0; k < N1; ++k) dma(sxb[k], t + NS - 1, ps);
     }
     UVX_PHASE_SYNC();
 #pragma unroll
@@ -597,9 +607,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) wb[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + O_WB + wo[kh] + j * 16 * 128);
-    if (t + 2 < nk) {
+    if (t + NS < nk) {
 #pragma unroll
-      for (int k = 0; k < N2; ++k) dma(srest[k], t + 2);
+      for (int k = 0; k < N2; ++k) dma(srest[k], t + NS, cs);
     }
     UVX_PHASE_SYNC();
 #pragma unroll
@@ -615,9 +625,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xb_base + xo[kh] + i * 16 * 128);
-    if (t + 2 < nk) {
+    if (t + NS < nk) {
 #pragma unroll
-      for (int k = 0; k < N3; ++k) dma(srest[N2 + k], t + 2);
+      for (int k = 0; k < N3; ++k) dma(srest[N2 + k], t + NS, cs);
     }
     UVX_PHASE_SYNC();
 #pragma unroll
@@ -629,10 +639,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
           acc[2 + j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][MA + i], 0, 0, 0);
     UVX_PHASE_END();
     // ---- phase 4: XB x WA (WA kept in registers); the counted wait that retires tile t+1 ----
-    if (t + 2 < nk) {
+    if (t + NS < nk) {
 #pragma unroll
-      for (int k = 0; k < N4; ++k) dma(srest[N2 + N3 + k], t + 2);
-      UVX_VMCNT(N234);
+      for (int k = 0; k < N4; ++k) dma(srest[N2 + N3 + k], t + NS, cs);
+      UVX_VMCNT(INFLIGHT);
     } else {
       UVX_VMCNT(0);
     }
@@ -645,6 +655,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
         for (int i = 0; i < MB; ++i)
           acc[j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][MA + i], 0, 0, 0);
     UVX_PHASE_END();
+    cs = cs == NS - 1 ? 0 : cs + 1;
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
 #undef UVX_VMCNT
@@ -901,12 +912,13 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 18;
+constexpr int kNumVariants = 20;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
     {160, 256, 1162., 8.9}, {256, 256, 1380., 8.5}, {256, 256, 0., 9.},      {256, 256, 0., 9.},      {256, 256, 0., 9.},
-    {160, 256, 1230., 9.},  {192, 256, 1390., 12.}, {128, 256, 1116., 6.}};
+    {160, 256, 1230., 9.},  {192, 256, 1390., 12.}, {128, 256, 1116., 6.},
+    {160, 256, 1245., 9.},  {128, 256, 0., 6.}};   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 double variant_cost(int v, int M, int N, int K, int batch) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
   // Rounds of tiles over the 256 CUs.  A partly filled last round is cheaper than a full one (the kernels are bound
@@ -955,6 +967,8 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 15: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<160>, grid, dim3(512), 0, st, a); break;
     case 16: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<192>, grid, dim3(512), 0, st, a); break;
     case 17: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<128>, grid, dim3(512), 0, st, a); break;
+    case 18: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 3>), grid, dim3(512), 0, st, a); break;
+    case 19: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 3>), grid, dim3(512), 0, st, a); break;
     case 12: hipLaunchKernelGGL(gemm_nt_bf16_q4_kernel, grid, dim3(256), 0, st, a); break;
     case 13: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 1>), grid, dim3(512), 0, st, a); break;   // probe: delivery only
     default: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 2>), grid, dim3(512), 0, st, a); break;  // probe: arithmetic only
@@ -1003,7 +1017,8 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
       double cost_tail = 0.;
       const int tv = pick_variant(d.M, tail_n, d.K, 1, &cost_tail);
       const double cost_split = variant_cost(variant, d.M, main_panels * V.bn, d.K, 1) + cost_tail;
-      if (cost_split < 0.93 * cost_whole) { n_main = main_panels * V.bn; tail_variant = tv; }
+      // (the second launch costs a round of its own plus a launch gap: only worth it for a clear modelled win)
+      if (cost_split < 0.88 * cost_whole) { n_main = main_panels * V.bn; tail_variant = tv; }
     }
   }
   if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, batch, tail_variant >= 0 ? 100 + variant : variant);
