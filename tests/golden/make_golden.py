@@ -13,6 +13,8 @@ What is recorded
   kl_loss.npz     — the REFERENCE UltravoxModel._get_prediction_mask / _compute_kl_loss (ultravox_model.py:157-256) called
                     unbound on a stub `self` whose language model returns recorded teacher logits: masks, loss and
                     d loss / d student logits for seeded logits, several eot weights / temperatures / ragged labels.
+  diff_state_dict.json — key sets kept by the REFERENCE UltravoxModel.diff_state_dict (ultravox_model.py:565-584) for stub
+                    models (trainable / frozen / keep_params / FSDP-wrapped names).
   logmel.npz      — HF WhisperFeatureExtractor (the [3P] K1 arithmetic) on seeded PCM, 80 and 128 mels.
 """
 import json
@@ -253,9 +255,34 @@ def kl_cases():
     print("kl_loss.npz:", [c[0] for c in cases])
 
 
+def diff_state_dict_cases():
+    M = ultravox_model.UltravoxModel
+    cases = []
+    defs = [
+        ("projector_only", ["multi_modal_projector.ln_pre.weight", "multi_modal_projector.linear_1.weight"], [],
+         ["audio_tower.conv1.weight", "language_model.model.norm.weight"]),
+        ("with_keep", ["multi_modal_projector.linear_2.weight"], ["audio_tower.conv1.weight"],
+         ["audio_tower.conv1.weight", "audio_tower.conv2.weight", "language_model.lm_head.weight"]),
+        ("fsdp_names", ["audio_tower.base_model.model.layers.0._fsdp_wrapped_module.self_attn.k_proj.lora_B.default.weight"], [],
+         ["audio_tower.base_model.model.layers.0.self_attn.k_proj.lora_B.default.weight", "audio_tower.conv1.weight"]),
+    ]
+    for name, trainable, keep, frozen in defs:
+        params = [(k, types.SimpleNamespace(requires_grad=True)) for k in trainable] + \
+                 [(k, types.SimpleNamespace(requires_grad=False)) for k in frozen]
+        stub = types.SimpleNamespace(named_parameters=lambda params=params: params, keep_params=set(keep))
+        # the state dict carries the NORMALISED names (what FSDP's full state dict returns)
+        sd = {k.replace("_fsdp_wrapped_module.", ""): 0 for k, _ in params}
+        kept = sorted(M.diff_state_dict(stub, sd).keys())
+        cases.append({"name": name, "trainable": trainable, "keep_params": keep, "state_dict_keys": sorted(sd), "kept": kept})
+    with open(os.path.join(HERE, "diff_state_dict.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("diff_state_dict.json:", [c["name"] for c in cases])
+
+
 if __name__ == "__main__":
     processor_cases()
     projector_cases()
     latency_mask_cases()
     logmel_cases()
     kl_cases()
+    diff_state_dict_cases()

@@ -1,0 +1,57 @@
+"""Checkpoint I/O: diff-state-dict semantics pinned against the reference
+(tests/golden/diff_state_dict.json from ultravox_model.py:565-584), safetensors round trip, merge rules."""
+import json
+import os
+
+import pytest
+import torch
+
+from ultravox_amd import checkpoint
+from ultravox_amd.config import UltravoxConfig
+
+
+def test_diff_state_dict_matches_reference_fixture(golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "diff_state_dict.json"))):
+        sd = {k: torch.zeros(1) for k in c["state_dict_keys"]}
+        kept = checkpoint.diff_state_dict(sd, c["trainable"], c["keep_params"])
+        assert sorted(kept) == c["kept"], c["name"]
+
+
+def test_save_load_round_trip_is_bit_exact(tmp_path):
+    from test_model_gpu import SMALL
+    cfg = UltravoxConfig(**SMALL)
+    g = torch.Generator().manual_seed(0)
+    P = "multi_modal_projector."
+    sd = {P + "ln_pre.weight": torch.randn(64, generator=g).bfloat16(), P + "linear_1.weight": torch.randn(32, 64, generator=g).bfloat16(),
+          "audio_tower.conv1.weight": torch.randn(8, 4, 3, generator=g).bfloat16(),
+          "language_model.model.norm.weight": torch.randn(16, generator=g).bfloat16()}
+    kept = checkpoint.save_pretrained(str(tmp_path), cfg, sd, trainable_params=[k for k in sd if k.startswith(P)],
+                                      keep_params=["audio_tower.conv1.weight"])
+    assert sorted(kept) == sorted([P + "ln_pre.weight", P + "linear_1.weight", "audio_tower.conv1.weight"])
+    assert sorted(os.listdir(tmp_path)) == ["config.json", "model.safetensors"]          # the HF layout
+    cfg2, ck = checkpoint.load_pretrained(str(tmp_path))
+    assert sorted(ck) == sorted(kept)
+    for k in ck:
+        assert ck[k].dtype == torch.bfloat16 and torch.equal(ck[k], sd[k])
+    assert cfg2.to_dict() == cfg.to_dict()
+    # config.json is the reference's to_diff_dict: sub-configs with a model id are not inlined (ultravox_config.py:188-203)
+    cj = json.load(open(tmp_path / "config.json"))
+    assert ("text_config" in cj) == (cfg.text_model_id is None) and ("audio_config" in cj) == (cfg.audio_model_id is None)
+
+
+def test_merge_state_dict_rules():
+    base = {"a": torch.zeros(2, 3), "b": torch.zeros(4)}
+    merged, keep = checkpoint.merge_state_dict(base, {"b": torch.ones(4)})
+    assert torch.equal(merged["b"], torch.ones(4)) and merged["a"] is base["a"] and keep == {"b"}
+    with pytest.raises(KeyError):
+        checkpoint.merge_state_dict(base, {"c": torch.ones(1)})
+    with pytest.raises(ValueError):
+        checkpoint.merge_state_dict(base, {"b": torch.ones(5)})
+
+
+def test_trainer_state_round_trip(tmp_path):
+    t = {"exp_avg": torch.arange(8, dtype=torch.float32).bfloat16(), "exp_avg_sq": torch.ones(8), "master": None}
+    checkpoint.save_trainer_state(str(tmp_path), 7, t, {"lr": 2e-3})
+    step, tt, extra = checkpoint.load_trainer_state(str(tmp_path))
+    assert step == 7 and extra["lr"] == 2e-3 and "master" not in tt
+    assert torch.equal(tt["exp_avg"], t["exp_avg"]) and tt["exp_avg"].dtype == torch.bfloat16

@@ -92,6 +92,7 @@ class UltravoxModel:
         self.code = _lib.dtype_code(self.dtype)
         self.training = False
         self._kl_grad_scale = 1.0
+        self.keep_params = set()                 # ultravox_model.py:59
         self.loss_config = LossConfig()
         self.vocab_size = config.vocab_size
         a, t = config.audio_config, config.text_config
@@ -185,6 +186,54 @@ class UltravoxModel:
         return {P + "ln_pre.weight": self._proj_views["ln_pre"], P + "linear_1.weight": self._proj_views["linear_1"],
                 P + self._norm_key + ".weight": self._proj_views["ln_norm"],
                 P + "linear_2.weight": self._proj_views["linear_2"]}
+
+    # ------------------------------------------------------------------ checkpoint I/O (ultravox_model.py:565-594)
+    def trainable_parameter_names(self):
+        return list(self.projector_state_dict().keys())
+
+    def diff_state_dict(self, state_dict: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """Trainable parameters + keys carried by a previously loaded checkpoint (`keep_params`)."""
+        from . import checkpoint
+        sd = self.projector_state_dict() if state_dict is None else state_dict
+        return checkpoint.diff_state_dict(sd, self.trainable_parameter_names(), self.keep_params)
+
+    def save_pretrained(self, save_directory: str, state_dict: Optional[Dict[str, torch.Tensor]] = None):
+        from . import checkpoint
+        sd = self.projector_state_dict() if state_dict is None else state_dict
+        return checkpoint.save_pretrained(save_directory, self.config, sd, self.trainable_parameter_names(), self.keep_params)
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = False):
+        """In-place load of projector keys (the trainable set); frozen-tower keys are only accepted at construction
+        time (`from_pretrained`), where they are packed into the device layouts.  Every loaded key joins keep_params."""
+        mine = self.projector_state_dict()
+        unexpected = [k for k in state_dict if k not in mine]
+        missing = [k for k in mine if k not in state_dict]
+        if unexpected and (strict or any(not k.startswith(("audio_tower.", "language_model.")) for k in unexpected)):
+            raise KeyError(f"unexpected key(s): {unexpected[:5]}")
+        if strict and missing:
+            raise KeyError(f"missing key(s): {missing}")
+        for k, v in state_dict.items():
+            if k in mine:
+                if tuple(v.shape) != tuple(mine[k].shape):
+                    raise ValueError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(mine[k].shape)}")
+                mine[k].copy_(v.to(device=self.device, dtype=self.dtype))
+        self.keep_params.update(state_dict.keys())
+        return missing, unexpected
+
+    @classmethod
+    def from_pretrained(cls, directory: str, base_state_dict: Optional[Dict[str, torch.Tensor]] = None, **kwargs):
+        """config.json + model.safetensors written by save_pretrained (here or by the reference).  The towers come from
+        `base_state_dict` (the weights `audio_model_id` / `text_model_id` name: there is no hub access here) or, absent
+        that, from the seeded random initialisation; checkpoint keys override either."""
+        from . import checkpoint
+        config, ckpt = checkpoint.load_pretrained(directory)
+        dtype = _torch_dtype(config, kwargs.get("dtype"))
+        base = base_state_dict if base_state_dict is not None else random_state_dict(
+            config, seed=kwargs.get("seed", 0), dtype=dtype)
+        merged, keep = checkpoint.merge_state_dict(base, ckpt)
+        model = cls(config, state_dict=merged, **kwargs)
+        model.keep_params.update(keep)
+        return model
 
     def projector_grads(self) -> Dict[str, torch.Tensor]:
         P = "multi_modal_projector."
@@ -479,6 +528,30 @@ class UltravoxTrainer:
         self.scratch = torch.zeros(1025, device=dev, dtype=torch.float32)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self._pending = None
+
+    def save_checkpoint(self, directory: str) -> None:
+        """checkpoint-N/ of the HF Trainer: the model's diff state dict + optimizer moments + step."""
+        from . import checkpoint
+        self.model.save_pretrained(directory)
+        checkpoint.save_trainer_state(directory, self.step_count,
+                                      {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "master": self.master},
+                                      {"lr": self.lr, "betas": list(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                                       "max_grad_norm": self.max_grad_norm})
+
+    def load_checkpoint(self, directory: str) -> None:
+        """resume_from_checkpoint: restores projector weights, AdamW moments, master weights and the step counter,
+        so that training continues bit-identically."""
+        from . import checkpoint
+        _, ckpt = checkpoint.load_pretrained(directory)
+        self.model.load_state_dict(ckpt)
+        step, t, _ = checkpoint.load_trainer_state(directory)
+        self.step_count = step
+        self.exp_avg.copy_(t["exp_avg"].to(self.exp_avg.device))
+        self.exp_avg_sq.copy_(t["exp_avg_sq"].to(self.exp_avg_sq.device))
+        if self.master is not None:
+            if "master" not in t:
+                raise KeyError("checkpoint has no f32 master weights but the trainer was built with master_weights=True")
+            self.master.copy_(t["master"].to(self.master.device))
 
     def all_reduce_grads(self) -> None:
         """torch DDP semantics: sum over ranks then divide by world size (RCCL over xGMI)."""
