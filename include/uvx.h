@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 1
+#define UVX_ABI_VERSION 2
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -207,6 +207,11 @@ typedef struct {
   int32_t out_f32;    /* bf16 inputs, f32 output (weight gradients) */
   int32_t accumulate; /* C += (f32 output only) */
   float alpha;
+  /* fused LlamaMLP epilogues (bf16 only; weights/activations in the interleaved gate|up layout of weights.py: 16-column
+   * gate block, then the matching 16-column up block).  epilogue 1: C [M, N] = gate|up pre-activations,
+   * C2 [M, N/2] = silu(gate) * up.  epilogue 2: the tile is d act [M, N]; with C2 = gate|up [M, 2N] (input) it is turned
+   * into d gate|up written to C [M, 2N] (ldc >= 2N). */
+  void* C2; int32_t ldc2; int32_t epilogue;
 } uvx_gemm_desc_t;
 /* C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual — torch.nn.Linear semantics. */
 int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* desc);

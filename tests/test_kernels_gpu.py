@@ -366,3 +366,38 @@ def test_logmel_full_size_properties():
     assert ((got.amax((1, 2)) - got.amin((1, 2))) <= 2.0 + 1e-6).all()
     got2 = fe.logmel_device((pcm * 0.5).to(DEV)).cpu()
     assert (got2 - (got + 2 * math.log10(0.5) / 4)).abs().max().item() < 1e-3
+
+
+def _interleave_gate_up(wg, wu):
+    """weights.py packing: alternating 16-row blocks of gate / up rows."""
+    I, K = wg.shape
+    return torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], 1).reshape(2 * I, K)
+
+
+@pytest.mark.parametrize("M,I,K", [(300, 512, 256), (2528, 1024, 512), (77, 96, 128)])
+def test_gemm_fused_swiglu_epilogues_match_unfused_path(M, I, K):
+    """Epilogue 1 (gate|up GEMM + SwiGLU) and epilogue 2 (down-projection dgrad + SwiGLU backward) are bit-identical to
+    the GEMM followed by the elementwise kernels they replace (same bf16 rounding points)."""
+    from ultravox_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+    wg = (torch.randn(I, K, device=DEV, generator=g) * 0.1).bfloat16()
+    wu = (torch.randn(I, K, device=DEV, generator=g) * 0.1).bfloat16()
+    wgu = _interleave_gate_up(wg, wu)
+    # forward
+    gu_ref = ops.gemm(x, wgu)
+    act_ref = ops.swiglu(gu_ref, gate_first=2)
+    act = torch.empty(M, I, device=DEV, dtype=torch.bfloat16)
+    gu = ops.gemm(x, wgu, epilogue=1, c2=act)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    ref = (F.silu((x.float() @ wg.float().t()).bfloat16().float()).bfloat16().float() * (x.float() @ wu.float().t()).bfloat16().float())
+    assert rel_l2(act, ref) < 1e-2
+    # backward: d act = dy . Wd (as an NT GEMM on Wd^T [I, D]), then SwiGLU backward
+    D = 256
+    dy = (torch.randn(M, D, device=DEV, generator=g) * 0.5).bfloat16()
+    wd_t = (torch.randn(I, D, device=DEV, generator=g) * 0.1).bfloat16()
+    d_act = ops.gemm(dy, wd_t)
+    dgu_ref = ops.swiglu_bwd(d_act, gu_ref, gate_first=2)
+    dgu = torch.empty(M, 2 * I, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(dy, wd_t, out=dgu, epilogue=2, c2=gu_ref)
+    assert torch.equal(dgu, dgu_ref)

@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64),
         ("stride_r", C.c_int64),
         ("act", C.c_int32), ("out_f32", C.c_int32), ("accumulate", C.c_int32), ("alpha", C.c_float),
+        ("C2", C.c_void_p), ("ldc2", C.c_int32), ("epilogue", C.c_int32),
     ]
 
 

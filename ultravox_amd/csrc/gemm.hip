@@ -64,7 +64,7 @@ template <int NJ, int MI>
 __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ][MI], int m_base, int n_base, int frow,
                                            int fg, long long z) {
   const bool bf16_out = !p.out_f32;
-  if (p.swiglu) {
+  if (p.swiglu == 1) {
     // fused LlamaMLP activation: fragment j (even) holds 16 gate columns, fragment j+1 the matching up columns
     // (weights are packed that way at load time); gate|up is stored for the backward pass and
     // act = round(silu(round(gate))) * round(up) — the reference's rounding points — goes to C2.
@@ -88,6 +88,38 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
         *reinterpret_cast<u16x4_t*>(crow) = og;
         *reinterpret_cast<u16x4_t*>(crow + 16) = ou;
         *reinterpret_cast<u16x4_t*>(p.C2 + (long long)m * p.ldc2 + (n_base + j * 16) / 2 + fg * 4) = oa;
+      }
+    }
+    return;
+  }
+  if (p.swiglu == 2) {
+    // fused LlamaMLP activation BACKWARD: the tile holds d act = dY . W_down^T; with gate|up (C2, interleaved 16-column
+    // blocks as above) it becomes d gate | d up in the same interleaved layout (C, ldc = 2 N) - the arithmetic and the
+    // bf16 rounding points of swiglu_bwd_k (elementwise.hip), which this replaces on the bf16 path.
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n_base + j * 16 + fg * 4;
+      if (n >= p.N) continue;
+      const int goff = (n >> 4) * 32 + (n & 15);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = m_base + i * 16 + frow;
+        if (m >= p.M) continue;
+        const bf16_t* gu = p.C2 + (long long)m * p.ldc2 + goff;
+        const u16x4_t g4 = *reinterpret_cast<const u16x4_t*>(gu);
+        const u16x4_t u4 = *reinterpret_cast<const u16x4_t*>(gu + 16);
+        u16x4_t dg4, du4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = bf2f(f2bf(acc[j][i][e] * p.alpha));
+          const float g = bf2f(g4[e]), u = bf2f(u4[e]);
+          const float sg = 1.0f / (1.0f + expf(-g));
+          du4[e] = f2bf(d * bf2f(f2bf(g * sg)));
+          dg4[e] = f2bf(d * u * (sg * (1.0f + g * (1.0f - sg))));
+        }
+        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + goff;
+        *reinterpret_cast<u16x4_t*>(crow) = dg4;
+        *reinterpret_cast<u16x4_t*>(crow + 16) = du4;
       }
     }
     return;
@@ -997,6 +1029,8 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.C2 = (bf16_t*)d.C2; a.ldc2 = d.ldc2; a.swiglu = d.swiglu;
   UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
+  UVX_CHECK(d.swiglu != 2 || (d.N % 16 == 0 && d.ldc >= 2 * d.N && d.ldc2 >= 2 * d.N), UVX_ERR_INVALID,
+            "gemm: swiglu-backward epilogue writes [M, 2N]: ldc=%d / ldc2=%d too small for N=%d", d.ldc, d.ldc2, d.N);
   const int batch = d.batch > 0 ? d.batch : 1;
   double cost_whole = 0.;
   const int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole);
@@ -1028,8 +1062,9 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
     t.B = a.B + (long long)n_main * a.ldb;
     if (a.bias) t.bias = a.bias + n_main;
     if (a.residual) t.residual = a.residual + n_main;
-    if (a.swiglu) t.C2 = a.C2 + n_main / 2;
+    if (a.swiglu == 1) t.C2 = a.C2 + n_main / 2;
     t.C = a.out_f32 ? (void*)((float*)a.C + n_main) : (void*)((bf16_t*)a.C + n_main);
+    if (a.swiglu == 2) { t.C2 = a.C2 + 2 * n_main; t.C = (void*)((bf16_t*)a.C + 2 * n_main); }   // [M, 2N] operands
     launch_variant(st, tail_variant, t, d.M, d.N - n_main, 1);
   }
   UVX_LAUNCH_CHECK();

@@ -549,8 +549,14 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
     UVX_CHECK(L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t, UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
     LlmLayerStash cur = llm_layer(s, l);
     // MLP
-    RC(gemm(st, dt, lin(s.dx, L.wd_t, s.d_act, M, c.llm_inter, D)));
-    RC(swiglu_bwd(st, dt, s.d_act, cur.gu, s.d_gu, M, c.llm_inter, /*layout=*/2));
+    if (dt == DT_BF16) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
+      GemmDesc g = lin(s.dx, L.wd_t, s.d_gu, M, c.llm_inter, D);
+      g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2;
+      RC(gemm(st, dt, g));
+    } else {
+      RC(gemm(st, dt, lin(s.dx, L.wd_t, s.d_act, M, c.llm_inter, D)));
+      RC(swiglu_bwd(st, dt, s.d_act, cur.gu, s.d_gu, M, c.llm_inter, /*layout=*/2));
+    }
     RC(gemm(st, dt, lin(s.d_gu, L.wgu_t, s.d_n, M, D, 2 * c.llm_inter)));
     RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_mid, L.ln2, s.dx, s.dx, nullptr, M, D, c.rms_eps));
     // attention
