@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the live HIP-event timing of the GEMM kernel")
+    ap.add_argument("--opt", default=None, help="probe: 'key=value,...' for uvx_set_option")
     ap.add_argument("--gemm-override", default=None, help="probe: 'MxNxK=variant,...' tile-variant overrides")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table (from the HIP events) here")
     args = ap.parse_args()
@@ -170,6 +171,10 @@ def main():
     from ultravox_amd.model import UltravoxModel, UltravoxTrainer
     from ultravox_amd.synthetic import synthetic_batch
 
+    if args.opt:
+        for item in args.opt.split(","):
+            k, v = item.split("=")
+            _lib.lib().uvx_set_option(int(k), int(v))
     if args.gemm_override:
         for item in args.gemm_override.split(","):
             shp, v = item.split("=")

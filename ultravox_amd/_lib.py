@@ -136,7 +136,7 @@ EXPORTS = [
     "uvx_llm_ws_bytes", "uvx_llm_fwd", "uvx_llm_bwd", "uvx_adamw_clip_step", "uvx_gemm", "uvx_layernorm",
     "uvx_rmsnorm", "uvx_rmsnorm_bwd", "uvx_swiglu", "uvx_swiglu_bwd", "uvx_rope", "uvx_attention_ws_bytes",
     "uvx_attention_fwd", "uvx_attention_bwd", "uvx_ce_loss", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records", "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes",
-    "uvx_llm_prefill", "uvx_llm_decode", "uvx_argmax", "uvx_llm_kl_loss", "uvx_kl_loss", "uvx_gemm_override_variant", "uvx_gemm_pick_variant",
+    "uvx_llm_prefill", "uvx_llm_decode", "uvx_argmax", "uvx_llm_kl_loss", "uvx_kl_loss", "uvx_gemm_override_variant", "uvx_gemm_pick_variant", "uvx_set_option",
 ]
 
 

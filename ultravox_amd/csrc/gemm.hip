@@ -25,6 +25,10 @@ namespace uvx {
 int g_gemm_variant = -1; int g_gemm_split = 1;
 // probe hook: per-shape variant overrides (in-situ A/B of the tile choice inside bench.py)
 int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
+// probe hook (uvx_set_option): [1] 16-byte epilogue access (on: -0.5 ms/step at C2), [2] SwiGLU backward fused into the
+// dgrad GEMM (off: measured neutral at C2 - the separate elementwise kernel runs at 6.7 TB/s, the fused epilogue is
+// serialised behind each tile's main loop)
+int g_options[8] = {0, 1, 0, 0, 0, 0, 0, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -47,6 +51,7 @@ struct GemmArgs {
   bf16_t* C2;      // swiglu mode: activation output [M, N/2]
   int ldc2;
   int swiglu;      // 1: columns alternate 16-wide gate / up blocks; also write silu(gate) * up to C2
+  int wide_io;     // 16-byte epilogue loads / stores (probe switch; on by default)
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -57,6 +62,33 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
 }
 
 
+// Epilogue memory access in 16-byte pieces.  The accumulator layout gives a lane 4 consecutive output columns of a row
+// (8 bytes of bf16) and the store / load path is issue-bound (32 accesses per lane per operand for a 128 x 64 wave
+// tile).  Two row fragments (i, i+1) are therefore exchanged between the lane groups fg and fg ^ 1 with
+// v_permlane16_swap: afterwards a lane holds 8 consecutive columns of ONE row (fragment i for even fg, i+1 for odd fg)
+// = one dwordx4.  The exchange is an involution, so 16-byte LOADS are brought into fragment layout the same way.
+// a = packed columns (0-1, 2-3) of fragment i, b = of fragment i+1.  Every lane of the wave must take part.
+__device__ __forceinline__ void frag_pair_swap(uint32_t (&a)[2], uint32_t (&b)[2]) {
+  const auto s0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  a[0] = s0[0]; b[0] = s0[1]; a[1] = s1[0]; b[1] = s1[1];
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float unpack_lo(uint32_t v) { return bf2f((bf16_t)(v & 0xffffu)); }
+__device__ __forceinline__ float unpack_hi(uint32_t v) { return bf2f((bf16_t)(v >> 16)); }
+// fragment-layout pair -> one 16-byte store at `dst` (the lane's row / 8-column slot), if ok
+__device__ __forceinline__ void store_pair16(bf16_t* dst, bool ok, uint32_t (&a)[2], uint32_t (&b)[2]) {
+  frag_pair_swap(a, b);
+  if (ok) *reinterpret_cast<uint4*>(dst) = make_uint4(a[0], a[1], b[0], b[1]);
+}
+// one 16-byte load from `src` (zeros if !ok) -> fragment-layout pair
+__device__ __forceinline__ void load_pair16(const bf16_t* src, bool ok, uint32_t (&a)[2], uint32_t (&b)[2]) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (ok) v = *reinterpret_cast<const uint4*>(src);
+  a[0] = v.x; a[1] = v.y; b[0] = v.z; b[1] = v.w;
+  frag_pair_swap(a, b);
+}
+
 // Shared epilogue.  acc[j][i] is the 16x16 accumulator fragment whose rows are output columns
 // n_base + 16 j + 4 fg .. +3 (4 consecutive per lane) and whose column is output row m_base + 16 i + frow.
 // The reference's bf16 rounding points are restated: round(acc*alpha + bias), round(act(.)), then + residual.
@@ -64,30 +96,56 @@ template <int NJ, int MI>
 __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ][MI], int m_base, int n_base, int frow,
                                            int fg, long long z) {
   const bool bf16_out = !p.out_f32;
+  constexpr int MI2 = MI & ~1;
+  // row / column slot of this lane in the 16-byte layout (see frag_pair_swap): row fragment i + (fg & 1), columns 8 (fg >> 1)
+  const int prow = (fg & 1) * 16 + frow, pcol = (fg >> 1) * 8;
   if (p.swiglu == 1) {
     // fused LlamaMLP activation: fragment j (even) holds 16 gate columns, fragment j+1 the matching up columns
     // (weights are packed that way at load time); gate|up is stored for the backward pass and
     // act = round(silu(round(gate))) * round(up) — the reference's rounding points — goes to C2.
+    const bool wide = p.wide_io && (p.ldc & 7) == 0 && (p.ldc2 & 7) == 0 && ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.C2 & 15) == 0;
 #pragma unroll
     for (int j = 0; j < NJ; j += 2) {
       const int n = n_base + j * 16 + fg * 4;
-      if (n >= p.N) continue;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = m_base + i * 16 + frow;
-        if (m >= p.M) continue;
-        u16x4_t og, ou, oa;
+      for (int i = 0; i < MI; i += 2) {
+        const bool pair = wide && i + 1 < MI;          // compile-time per i, wave-uniform
+        uint32_t pg[2][2], pu[2][2], pa[2][2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          og[e] = f2bf(acc[j][i][e] * p.alpha);
-          ou[e] = f2bf(acc[j + 1][i][e] * p.alpha);
-          const float g = bf2f(og[e]);
-          oa[e] = f2bf(bf2f(f2bf(g / (1.0f + __expf(-g)))) * bf2f(ou[e]));
+        for (int h = 0; h < 2; ++h) {
+          if (i + h >= MI) break;
+          float a[4];
+          bf16_t og[4], ou[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            og[e] = f2bf(acc[j][i + h][e] * p.alpha);
+            ou[e] = f2bf(acc[j + 1][i + h][e] * p.alpha);
+            const float g = bf2f(og[e]);
+            a[e] = bf2f(f2bf(g / (1.0f + __expf(-g)))) * bf2f(ou[e]);
+          }
+          pg[h][0] = (uint32_t)og[0] | ((uint32_t)og[1] << 16); pg[h][1] = (uint32_t)og[2] | ((uint32_t)og[3] << 16);
+          pu[h][0] = (uint32_t)ou[0] | ((uint32_t)ou[1] << 16); pu[h][1] = (uint32_t)ou[2] | ((uint32_t)ou[3] << 16);
+          pa[h][0] = pack2(a[0], a[1]); pa[h][1] = pack2(a[2], a[3]);
         }
-        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n;
-        *reinterpret_cast<u16x4_t*>(crow) = og;
-        *reinterpret_cast<u16x4_t*>(crow + 16) = ou;
-        *reinterpret_cast<u16x4_t*>(p.C2 + (long long)m * p.ldc2 + (n_base + j * 16) / 2 + fg * 4) = oa;
+        if (pair) {
+          const int m = m_base + i * 16 + prow, n8 = n_base + j * 16 + pcol;
+          const bool ok = m < p.M && n8 < p.N;
+          bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n8;
+          store_pair16(crow, ok, pg[0], pg[1]);
+          store_pair16(crow + 16, ok, pu[0], pu[1]);
+          store_pair16(p.C2 + (long long)m * p.ldc2 + (n_base + j * 16) / 2 + pcol, ok, pa[0], pa[1]);
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (i + h >= MI) break;
+            const int m = m_base + (i + h) * 16 + frow;
+            if (m >= p.M || n >= p.N) continue;
+            bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n;
+            *reinterpret_cast<uint2*>(crow) = make_uint2(pg[h][0], pg[h][1]);
+            *reinterpret_cast<uint2*>(crow + 16) = make_uint2(pu[h][0], pu[h][1]);
+            *reinterpret_cast<uint2*>(p.C2 + (long long)m * p.ldc2 + (n_base + j * 16) / 2 + fg * 4) = make_uint2(pa[h][0], pa[h][1]);
+          }
+        }
       }
     }
     return;
@@ -96,33 +154,118 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
     // fused LlamaMLP activation BACKWARD: the tile holds d act = dY . W_down^T; with gate|up (C2, interleaved 16-column
     // blocks as above) it becomes d gate | d up in the same interleaved layout (C, ldc = 2 N) - the arithmetic and the
     // bf16 rounding points of swiglu_bwd_k (elementwise.hip), which this replaces on the bf16 path.
+    const bool wide = p.wide_io && (p.ldc & 7) == 0 && (p.ldc2 & 7) == 0 && ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.C2 & 15) == 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int n = n_base + j * 16 + fg * 4;
-      if (n >= p.N) continue;
       const int goff = (n >> 4) * 32 + (n & 15);
+      const int nb = n_base + j * 16;                      // first column of the fragment
+      const int goff8 = (nb >> 4) * 32 + pcol;             // the lane's 8-column slot in the interleaved layout
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = m_base + i * 16 + frow;
-        if (m >= p.M) continue;
-        const bf16_t* gu = p.C2 + (long long)m * p.ldc2 + goff;
-        const u16x4_t g4 = *reinterpret_cast<const u16x4_t*>(gu);
-        const u16x4_t u4 = *reinterpret_cast<const u16x4_t*>(gu + 16);
-        u16x4_t dg4, du4;
+      for (int i = 0; i < MI; i += 2) {
+        const bool pair = wide && i + 1 < MI;
+        uint32_t g2[2][2], u2[2][2], dg2[2][2], du2[2][2];
+        if (pair) {
+          const int m = m_base + i * 16 + prow;
+          const bool ok = m < p.M && nb + pcol < p.N;
+          const bf16_t* gu = p.C2 + (long long)m * p.ldc2 + goff8;
+          load_pair16(gu, ok, g2[0], g2[1]);
+          load_pair16(gu + 16, ok, u2[0], u2[1]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d = bf2f(f2bf(acc[j][i][e] * p.alpha));
-          const float g = bf2f(g4[e]), u = bf2f(u4[e]);
-          const float sg = 1.0f / (1.0f + expf(-g));
-          du4[e] = f2bf(d * bf2f(f2bf(g * sg)));
-          dg4[e] = f2bf(d * u * (sg * (1.0f + g * (1.0f - sg))));
+          for (int h = 0; h < 2; ++h) {
+            if (i + h >= MI) break;
+            const int m = m_base + (i + h) * 16 + frow;
+            uint2 gv = make_uint2(0u, 0u), uv = make_uint2(0u, 0u);
+            if (m < p.M && n < p.N) {
+              const bf16_t* gu = p.C2 + (long long)m * p.ldc2 + goff;
+              gv = *reinterpret_cast<const uint2*>(gu);
+              uv = *reinterpret_cast<const uint2*>(gu + 16);
+            }
+            g2[h][0] = gv.x; g2[h][1] = gv.y; u2[h][0] = uv.x; u2[h][1] = uv.y;
+          }
         }
-        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + goff;
-        *reinterpret_cast<u16x4_t*>(crow) = dg4;
-        *reinterpret_cast<u16x4_t*>(crow + 16) = du4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (i + h >= MI) break;
+          float dgv[4], duv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = bf2f(f2bf(acc[j][i + h][e] * p.alpha));
+            const uint32_t gw = g2[h][e >> 1], uw = u2[h][e >> 1];
+            const float g = (e & 1) ? unpack_hi(gw) : unpack_lo(gw), u = (e & 1) ? unpack_hi(uw) : unpack_lo(uw);
+            const float sg = 1.0f / (1.0f + expf(-g));
+            duv[e] = d * bf2f(f2bf(g * sg));
+            dgv[e] = d * u * (sg * (1.0f + g * (1.0f - sg)));
+          }
+          dg2[h][0] = pack2(dgv[0], dgv[1]); dg2[h][1] = pack2(dgv[2], dgv[3]);
+          du2[h][0] = pack2(duv[0], duv[1]); du2[h][1] = pack2(duv[2], duv[3]);
+        }
+        if (pair) {
+          const int m = m_base + i * 16 + prow;
+          const bool ok = m < p.M && nb + pcol < p.N;
+          bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + goff8;
+          store_pair16(crow, ok, dg2[0], dg2[1]);
+          store_pair16(crow + 16, ok, du2[0], du2[1]);
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (i + h >= MI) break;
+            const int m = m_base + (i + h) * 16 + frow;
+            if (m >= p.M || n >= p.N) continue;
+            bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + goff;
+            *reinterpret_cast<uint2*>(crow) = make_uint2(dg2[h][0], dg2[h][1]);
+            *reinterpret_cast<uint2*>(crow + 16) = make_uint2(du2[h][0], du2[h][1]);
+          }
+        }
       }
     }
     return;
+  }
+  // bf16 output: 16-byte stores (and residual loads) for the paired row fragments; the rest takes the 8-byte path below
+  const bool wide_store = p.wide_io && bf16_out && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.sC & 7) == 0 && ((uintptr_t)p.C & 15) == 0;
+  const bool wide_res = p.residual && p.res_mod == 0 && (p.ldr & 7) == 0 && (p.sR & 7) == 0 && ((uintptr_t)p.residual & 15) == 0;
+  if (wide_store) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n_base + j * 16 + fg * 4;
+      const bool n_ok = n < p.N;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n_ok) {
+        u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI2; i += 2) {
+        const int mp = m_base + i * 16 + prow, n8 = n_base + j * 16 + pcol;
+        const bool ok = mp < p.M && n8 < p.N;
+        uint32_t r2[2][2] = {{0u, 0u}, {0u, 0u}};
+        if (wide_res) load_pair16(p.residual + z * p.sR + (long long)mp * p.ldr + n8, ok, r2[0], r2[1]);
+        uint32_t pk[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = m_base + (i + h) * 16 + frow;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = bf2f(f2bf(acc[j][i + h][e] * p.alpha + bv[e]));
+            if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));
+            v[e] = t;
+          }
+          if (wide_res) {
+            v[0] += unpack_lo(r2[h][0]); v[1] += unpack_hi(r2[h][0]); v[2] += unpack_lo(r2[h][1]); v[3] += unpack_hi(r2[h][1]);
+          } else if (p.residual && n_ok && m < p.M) {
+            const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+            u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
+          }
+          pk[h][0] = pack2(v[0], v[1]); pk[h][1] = pack2(v[2], v[3]);
+        }
+        store_pair16(reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)mp * p.ldc + n8, ok, pk[0], pk[1]);
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -136,6 +279,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      if (wide_store && i < MI2) continue;             // already stored above
       const int m = m_base + i * 16 + frow;
       if (m >= p.M) continue;
       float v[4];
@@ -1027,6 +1171,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.sA = d.sA; a.sB = d.sB; a.sC = d.sC; a.sR = d.sR;
   a.act = d.act; a.out_f32 = d.out_f32; a.accumulate = d.accumulate; a.alpha = d.alpha;
   a.C2 = (bf16_t*)d.C2; a.ldc2 = d.ldc2; a.swiglu = d.swiglu;
+  a.wide_io = uvx::g_options[1];
   UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
   UVX_CHECK(d.swiglu != 2 || (d.N % 16 == 0 && d.ldc >= 2 * d.N && d.ldc2 >= 2 * d.N), UVX_ERR_INVALID,

@@ -44,6 +44,7 @@ struct GemmDesc {
 
 extern int g_gemm_variant;
 extern int g_gemm_split;
+extern int g_options[8];
 int gemm_pick_variant(int M, int N, int K, int batch);  // host only: the tile variant the cost model picks
 extern int g_gemm_ovr_n;
 extern int g_gemm_ovr[32][4];

@@ -549,7 +549,7 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
     UVX_CHECK(L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t, UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
     LlmLayerStash cur = llm_layer(s, l);
     // MLP
-    if (dt == DT_BF16) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
+    if (dt == DT_BF16 && g_options[2]) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
       GemmDesc g = lin(s.dx, L.wd_t, s.d_gu, M, c.llm_inter, D);
       g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2;
       RC(gemm(st, dt, g));
