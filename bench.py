@@ -44,8 +44,10 @@ WORKLOADS = {
 }
 
 
-def flops_per_sample(cfg, seconds: float, n_text: int = 128):
-    """Algorithmic FLOPs of one sample: matmul [m,k]x[k,n] = 2mkn, causal attention = 1/2."""
+def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int = 32):
+    """Algorithmic FLOPs of one sample: matmul [m,k]x[k,n] = 2mkn, causal attention = 1/2.  The LM head
+    is counted on the supervised positions only (the rows that enter the loss; the other rows of the logits have zero
+    weight and zero gradient, and the training step does not compute them) - `step_full_head` keeps the all-rows count."""
     a, t = cfg.audio_config, cfg.text_config
     F = int(seconds * 100)
     Te = F // 2
@@ -57,9 +59,11 @@ def flops_per_sample(cfg, seconds: float, n_text: int = 128):
     P = 2 * Na * (8 * d * H + (H // 2) * D)
     h, kv, dh, I, V, L = t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.intermediate_size, t.vocab_size, t.num_hidden_layers
     attn = L * 2 * T * T * h * dh
-    M = L * (2 * T * (2 * D * h * dh + 2 * D * kv * dh) + 6 * T * D * I) + attn + 2 * T * D * V
+    body = L * (2 * T * (2 * D * h * dh + 2 * D * kv * dh) + 6 * T * D * I) + attn
+    head, head_full = 2 * n_supervised * D * V, 2 * T * D * V
+    M = body + head
     step = E + 3 * P + M + (M + attn)
-    return dict(encoder=E, projector=P, llm_fwd=M, step=step)
+    return dict(encoder=E, projector=P, llm_fwd=M, step=step, step_full_head=step + 2 * (head_full - head))
 
 
 def cpu_baseline(cfg, seconds: float, n_text: int = 128):
@@ -242,9 +246,12 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded PCM + token ids; seeded random-init weights)",
             "config": {"workload": wl["name"], "clips_per_gpu": B, "clip_seconds": wl["seconds"], "text_tokens": 128,
                        "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "audio_model": wl["audio"], "text_model": wl["text"], "optimizer": "AdamW bf16 state, clip 1.0"},
+                       "audio_model": wl["audio"], "text_model": wl["text"], "optimizer": "AdamW bf16 state, clip 1.0",
+                       "supervised_tokens_per_clip": 32,
+                       "loss_head": "LM head + CE on the supervised positions only (identical loss and gradients)"},
             "samples_per_sec": B * world * args.steps / dt,
             "step_tflops_algorithmic": fl["step"] * B / 1e12,
+            "step_tflops_with_full_logits": fl["step_full_head"] * B / 1e12,
             "mfu": fl["step"] * B * world * args.steps / dt / (PEAK_BF16_TFLOPS * 1e12 * world),
             "loss": loss_val,
         }

@@ -269,3 +269,41 @@ def test_overlapping_audio_ranges_follow_reference_loop_order():
     with torch.no_grad():
         ref = oracle.forward(**{**b, "audio_values": b["audio_values"].bfloat16().float()})
     assert rel_l2(out.logits, ref["logits"]) < 3e-2
+
+
+@pytest.mark.parametrize("T,first_label", [(48, 30), (300, 10)])
+def test_loss_head_on_supervised_rows_split_k(T, first_label):
+    """The loss head runs on the supervised rows only (uvx_llm_fwd/bwd): here with a vocabulary / MLP wide enough that the
+    head dgrad takes its split-K path, and (T = 300) with more supervised rows than the split-K cap of 512, so that the
+    remainder GEMM + offset scatter run too.  Loss and d loss / d inputs_embeds against the f32 oracle."""
+    from oracle.reference_cpu import llama_ref, causal_lm_loss_ref
+    tc = dict(SMALL["text_config"], vocab_size=4096, intermediate_size=1024)
+    cfg, sd, model, oracle = build(9, text_config=tc)
+    torch.manual_seed(3)
+    B, D = 2, 256
+    emb = (torch.randn(B, T, D) * 0.5).bfloat16()
+    labels = torch.randint(0, 4096, (B, T)); labels[:, :first_label] = -100
+    labels[1, T - 5:] = -100                                   # ragged supervision
+    out = model.language_model_forward(emb.to(DEV), labels=labels.to(DEV), want_logits=False, save_for_bwd=True)
+    import ctypes as C
+    from ultravox_amd import _lib
+    d = torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16)
+    Bc, Tc, nb, lab = model._llm_ctx
+    _lib.check(_lib.lib().uvx_llm_bwd(_lib.stream_ptr(), C.byref(model._c), C.byref(model._lw), _lib.ptr(lab), B, T,
+                                      C.c_float(1.0), _lib.ptr(d), _lib.ptr(model._ws["llm"]), C.c_size_t(nb)))
+    e = emb.float().requires_grad_(True)
+    loss = causal_lm_loss_ref(llama_ref(oracle.sd, cfg, e, None), labels)
+    loss.backward()
+    assert abs(out.loss.item() - loss.item()) < 2e-2 * loss.item()
+    assert rel_l2(d, e.grad) < 6e-2
+    # the same step with the full-logits head (option 3 off) agrees to bf16 round-off of one dgrad
+    _lib.lib().uvx_set_option(3, 0)
+    try:
+        out2 = model.language_model_forward(emb.to(DEV), labels=labels.to(DEV), want_logits=False, save_for_bwd=True)
+        d2 = torch.empty_like(d)
+        _lib.check(_lib.lib().uvx_llm_bwd(_lib.stream_ptr(), C.byref(model._c), C.byref(model._lw), _lib.ptr(lab), B, T,
+                                          C.c_float(1.0), _lib.ptr(d2), _lib.ptr(model._ws["llm"]), C.c_size_t(nb)))
+    finally:
+        _lib.lib().uvx_set_option(3, 1)
+    assert abs(out2.loss.item() - out.loss.item()) < 1e-6 * out.loss.item()   # same per-row losses; the f32 row sum groups differently
+    assert rel_l2(d, d2) < 5e-3

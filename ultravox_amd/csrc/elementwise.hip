@@ -221,6 +221,38 @@ __global__ void cast_from_f32_k(const float* __restrict__ in, T* __restrict__ ou
   if (i < n) stf<T>(out + i, in[i]);
 }
 
+// rows: compaction list of sup_rows (count at rows[n]).  GATHER: dst[c] = src[rows[c]];  SCATTER: dst[rows[c]] = src[c].
+template <typename T, bool SCATTER>
+__global__ void move_rows_k(const T* __restrict__ src, const int32_t* __restrict__ rows, long long n, T* __restrict__ dst, int D,
+                            int first) {
+  const long long c = blockIdx.x + first;
+  if (c >= rows[n]) return;
+  const long long r = rows[c];
+  const T* s = src + (SCATTER ? c - first : r) * D;
+  T* d = dst + (SCATTER ? r : c) * D;
+  for (int k = threadIdx.x * 8; k < D; k += blockDim.x * 8) {
+    float v[8];
+    ld8<T>(s + k, v);
+    st8<T>(d + k, v);
+  }
+}
+
+template <typename T>
+__global__ void splitk_reduce_scatter_k(const float* __restrict__ partial, int nsplit, int cap, const int32_t* __restrict__ rows,
+                                        long long n, T* __restrict__ dst, int D) {
+  const int c = blockIdx.x;
+  if (c >= rows[n] || c >= cap) return;
+  T* d = dst + (long long)rows[c] * D;
+  for (int k = threadIdx.x * 4; k < D; k += blockDim.x * 4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < nsplit; ++z) {                 // fixed order: deterministic
+      const float4 v = *reinterpret_cast<const float4*>(partial + ((long long)z * cap + c) * D + k);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    stf<T>(d + k, a.x); stf<T>(d + k + 1, a.y); stf<T>(d + k + 2, a.z); stf<T>(d + k + 3, a.w);
+  }
+}
+
 inline int grid1d(long long n, int th) { return (int)((n + th - 1) / th); }
 
 }  // namespace
@@ -374,6 +406,34 @@ int cast_f32_to(hipStream_t st, int dtype, const float* in, void* out, long long
 
 int fill_zero(hipStream_t st, void* p, long long bytes) {
   if (bytes > 0) UVX_HIP(hipMemsetAsync(p, 0, (size_t)bytes, st));
+  return UVX_OK;
+}
+
+int gather_rows(hipStream_t st, int dtype, const void* src, const int32_t* rows, long long n, void* dst, int D) {
+  UVX_CHECK(D % 8 == 0, UVX_ERR_SHAPE, "gather_rows: D=%d must be a multiple of 8", D);
+  if (n == 0) return UVX_OK;
+  if (dtype == DT_BF16) hipLaunchKernelGGL((move_rows_k<bf16_t, false>), dim3(n), dim3(256), 0, st, (const bf16_t*)src, rows, n, (bf16_t*)dst, D, 0);
+  else hipLaunchKernelGGL((move_rows_k<float, false>), dim3(n), dim3(256), 0, st, (const float*)src, rows, n, (float*)dst, D, 0);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int scatter_rows(hipStream_t st, int dtype, const void* src, const int32_t* rows, long long n, void* dst, int D, int first) {
+  UVX_CHECK(D % 8 == 0, UVX_ERR_SHAPE, "scatter_rows: D=%d must be a multiple of 8", D);
+  if (n - first <= 0) return UVX_OK;
+  if (dtype == DT_BF16) hipLaunchKernelGGL((move_rows_k<bf16_t, true>), dim3(n - first), dim3(256), 0, st, (const bf16_t*)src, rows, n, (bf16_t*)dst, D, first);
+  else hipLaunchKernelGGL((move_rows_k<float, true>), dim3(n - first), dim3(256), 0, st, (const float*)src, rows, n, (float*)dst, D, first);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int splitk_reduce_scatter(hipStream_t st, int dtype, const float* partial, int nsplit, int cap, const int32_t* rows,
+                          long long n, void* dst, int D) {
+  UVX_CHECK(D % 4 == 0, UVX_ERR_SHAPE, "splitk_reduce: D=%d must be a multiple of 4", D);
+  if (cap <= 0) return UVX_OK;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(splitk_reduce_scatter_k<bf16_t>, dim3(cap), dim3(256), 0, st, partial, nsplit, cap, rows, n, (bf16_t*)dst, D);
+  else hipLaunchKernelGGL(splitk_reduce_scatter_k<float>, dim3(cap), dim3(256), 0, st, partial, nsplit, cap, rows, n, (float*)dst, D);
+  UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
 

@@ -27,8 +27,8 @@ int g_gemm_variant = -1; int g_gemm_split = 1;
 int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // probe hook (uvx_set_option): [1] 16-byte epilogue access (on: -0.5 ms/step at C2), [2] SwiGLU backward fused into the
 // dgrad GEMM (off: measured neutral at C2 - the separate elementwise kernel runs at 6.7 TB/s, the fused epilogue is
-// serialised behind each tile's main loop)
-int g_options[8] = {0, 1, 0, 0, 0, 0, 0, 0};
+// serialised behind each tile's main loop), [3] loss head on the supervised rows only (on)
+int g_options[8] = {0, 1, 0, 1, 0, 0, 0, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -52,6 +52,8 @@ struct GemmArgs {
   int ldc2;
   int swiglu;      // 1: columns alternate 16-wide gate / up blocks; also write silu(gate) * up to C2
   int wide_io;     // 16-byte epilogue loads / stores (probe switch; on by default)
+  const int32_t* m_dev;  // device-side row count (nullptr: M is exact)
+  int m_dev_off;         // rows of the compact list handled by earlier launches
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -333,6 +335,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
+  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
+    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
+    if (m0 >= me) return;
+    p.M = me;
+  }
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -421,6 +428,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide_kernel(GemmArgs p) {
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BNW;
+  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
+    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
+    if (m0 >= me) return;
+    p.M = me;
+  }
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -521,6 +533,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BNW;
+  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
+    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
+    if (m0 >= me) return;
+    p.M = me;
+  }
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -668,6 +685,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BNW;
+  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
+    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
+    if (m0 >= me) return;
+    p.M = me;
+  }
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -865,6 +887,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_q4_kernel(GemmArgs p) {
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BNW;
+  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
+    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
+    if (m0 >= me) return;
+    p.M = me;
+  }
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -995,6 +1022,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide3_kernel(GemmArgs p) 
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BNW;
+  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
+    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
+    if (m0 >= me) return;
+    p.M = me;
+  }
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -1172,6 +1204,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.act = d.act; a.out_f32 = d.out_f32; a.accumulate = d.accumulate; a.alpha = d.alpha;
   a.C2 = (bf16_t*)d.C2; a.ldc2 = d.ldc2; a.swiglu = d.swiglu;
   a.wide_io = uvx::g_options[1];
+  a.m_dev = d.m_dev; a.m_dev_off = d.m_dev_off;
   UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
   UVX_CHECK(d.swiglu != 2 || (d.N % 16 == 0 && d.ldc >= 2 * d.N && d.ldc2 >= 2 * d.N), UVX_ERR_INVALID,
@@ -1181,7 +1214,8 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   const int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole);
   UVX_CHECK(variant >= 0 && variant < kNumVariants, UVX_ERR_INVALID, "gemm: bad tile variant %d", variant);
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K * batch,
-                      ((double)d.M * d.K + (double)d.N * d.K) * 2.0 * batch + (double)d.M * d.N * batch * (d.out_f32 ? 4.0 : 2.0));
+                      ((double)d.M * d.K + (double)d.N * d.K) * 2.0 * batch + (double)d.M * d.N * batch * (d.out_f32 ? 4.0 : 2.0),
+                      /*enable=*/d.m_dev == nullptr);   // device-side row count: the true work is unknown here, leave it out
   // Tail split (tile-quantisation fix): when the last round of big tiles would leave most CUs idle, the
   // trailing weight panels (a column range of C) are computed by a second launch with its own best variant.
   const Variant& V = kVariants[variant];
@@ -1200,7 +1234,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
       if (cost_split < 0.88 * cost_whole) { n_main = main_panels * V.bn; tail_variant = tv; }
     }
   }
-  if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, batch, tail_variant >= 0 ? 100 + variant : variant);
+  if (uvx::g_prof_on && !d.m_dev) uvx::prof_tag(d.M, d.N, d.K, batch, tail_variant >= 0 ? 100 + variant : variant);
   launch_variant(st, variant, a, d.M, n_main, batch);
   if (tail_variant >= 0) {
     GemmArgs t = a;

@@ -16,7 +16,7 @@ void prof_tag(int m, int n, int k, int batch, int variant);
 extern bool g_prof_on;
 struct ProfScope {
   hipStream_t st; bool on;
-  ProfScope(hipStream_t s, int cls, double flops, double bytes) : st(s), on(g_prof_on) { if (on) prof_record_begin(s, cls, flops, bytes); }
+  ProfScope(hipStream_t s, int cls, double flops, double bytes, bool enable = true) : st(s), on(g_prof_on && enable) { if (on) prof_record_begin(s, cls, flops, bytes); }
   ~ProfScope() { if (on) prof_record_end(st); }
 };
 
@@ -40,6 +40,9 @@ struct GemmDesc {
   void* C2 = nullptr;
   int ldc2 = 0;
   int swiglu = 0;
+  // device-side row count: effective M = min(M, *m_dev) (tiles beyond it exit at once); M stays the launch bound
+  const int32_t* m_dev = nullptr;
+  int m_dev_off = 0;   // effective M = clamp(*m_dev - m_dev_off, 0, M): this launch covers compact rows [m_dev_off, ...)
 };
 
 extern int g_gemm_variant;
@@ -134,7 +137,17 @@ int heads_transpose(hipStream_t st, int dtype, const void* in, void* out, int B,
 // n_valid, and (if dlogits) d loss / d logits in the logits dtype, IN PLACE allowed.
 // scratch: 2 + B*T floats (scratch[0] = n_valid, scratch[1] = summed loss, then per-row losses).
 int ce_loss_fwd_bwd(hipStream_t st, int dtype, const void* logits, const int64_t* labels, float* loss,
-                    float* scratch, void* dlogits, int B, int T, int V, int ldl, float grad_scale);
+                    float* scratch, void* dlogits, int B, int T, int V, int ldl, float grad_scale,
+                    const int32_t* sup = nullptr);
+// rows[0..count) = positions (b*T + t) whose NEXT token carries a scorable label, in order; rest -1; rows[B*T] = count
+int sup_rows(hipStream_t st, const int64_t* labels, int32_t* rows, int B, int T, int V);
+// dst[c, :] = src[rows[c], :] for c < rows[n]; / dst[rows[c], :] = src[c, :] (dst pre-zeroed by the caller)
+int gather_rows(hipStream_t st, int dtype, const void* src, const int32_t* rows, long long n, void* dst, int D);
+int scatter_rows(hipStream_t st, int dtype, const void* src, const int32_t* rows, long long n, void* dst, int D,
+                 int first = 0);   // compact rows [first, count): src row c - first -> dst row rows[c]
+// dst[rows[c], :] = round(sum_z partial[z][c][:]) for c < min(count, cap); partial: f32 [nsplit][cap][D], fixed order
+int splitk_reduce_scatter(hipStream_t st, int dtype, const float* partial, int nsplit, int cap, const int32_t* rows,
+                          long long n, void* dst, int D);
 
 // KL distillation: loss = sum_r sum_slot w[slot][r] * KL(softmax(teacher[pair_row[slot][r]]/tau) || softmax(student[r]/tau)),
 // and (if dlogits, IN PLACE allowed) d loss / d student logits * grad_scale.  scratch: rows floats.

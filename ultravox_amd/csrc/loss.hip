@@ -24,18 +24,68 @@ __global__ void ce_count_k(const int64_t* __restrict__ labels, float* __restrict
   if (threadIdx.x == 0) scratch[0] = c;
 }
 
+// Supervised rows, in order: r = (b, t) with t + 1 < T and a scorable label at (b, t + 1).  rows[0 .. count) are their
+// indices, rows[count .. B*T) = -1; count goes to rows[B*T].  One block, ordered chunked scan (B*T is a few thousand).
+__global__ void sup_rows_k(const int64_t* __restrict__ labels, int32_t* __restrict__ rows, int B, int Tlen, int V) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const long long n = (long long)B * Tlen;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (long long c0 = 0; c0 < n; c0 += blockDim.x) {
+    const long long r = c0 + threadIdx.x;
+    bool ok = false;
+    if (r < n) {
+      const int t = (int)(r % Tlen);
+      if (t + 1 < Tlen) {
+        const int64_t tgt = labels[r + 1];
+        ok = tgt != -100 && tgt >= 0 && tgt < V;
+      }
+    }
+    const unsigned long long bal = __ballot(ok);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int i = 0; i < w; ++i) off += wsum[i];
+    if (ok) rows[off + before] = (int32_t)r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += wsum[i];
+      base += tot;
+    }
+    __syncthreads();
+  }
+  const int cnt = base;
+  for (long long r = cnt + threadIdx.x; r < n; r += blockDim.x) rows[r] = -1;
+  if (threadIdx.x == 0) rows[n] = cnt;
+}
+
+// rows == nullptr: logits row = sequence position (b, t).  rows != nullptr: logits are COMPACT, logits row c belongs to
+// position rows[c] (c < count = rows[n_rows]); scratch[0] (n_valid) is then the count.
 template <typename T>
 __global__ void ce_rows_k(const T* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ scratch,
-                          T* __restrict__ dlogits, int Tlen, int V, long long ldl, float grad_scale) {
+                          T* __restrict__ dlogits, int Tlen, int V, long long ldl, float grad_scale,
+                          const int32_t* __restrict__ rows, long long n_rows) {
   __shared__ float red[16];
-  const long long row = blockIdx.x;
+  const long long lrow = blockIdx.x;
+  float* row_loss = scratch + 2;
+  long long row = lrow;
+  if (rows) {
+    if (lrow >= rows[n_rows]) {                 // beyond the compact range: nothing was computed for this slot
+      if (threadIdx.x == 0) row_loss[lrow] = 0.f;
+      return;
+    }
+    row = rows[lrow];
+  }
   const int t = (int)(row % Tlen);
   const int64_t tgt = (t + 1 < Tlen) ? labels[row + 1] : -100;
-  const T* lr = logits + row * ldl;
-  T* dr = dlogits ? dlogits + row * ldl : nullptr;
-  float* row_loss = scratch + 2;
+  const T* lr = logits + lrow * ldl;
+  T* dr = dlogits ? dlogits + lrow * ldl : nullptr;
   if (tgt == -100 || tgt < 0 || tgt >= V) {
-    if (threadIdx.x == 0) row_loss[row] = 0.f;
+    if (threadIdx.x == 0) row_loss[lrow] = 0.f;
     if (dr) {
       float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int c = threadIdx.x * 8; c < V; c += blockDim.x * 8) st8<T>(dr + c, z);
@@ -61,7 +111,7 @@ __global__ void ce_rows_k(const T* __restrict__ logits, const int64_t* __restric
   const float S = block_sum(s * expf(m - M), red);
   const float lse = M + logf(S);
   const float n_valid = scratch[0];
-  if (threadIdx.x == 0) row_loss[row] = lse - ldf<T>(lr + tgt);
+  if (threadIdx.x == 0) row_loss[lrow] = lse - ldf<T>(lr + tgt);
   if (dr) {
     const float g = grad_scale / n_valid;
     for (int c = threadIdx.x * 8; c < V; c += blockDim.x * 8) {
@@ -201,21 +251,33 @@ __global__ void kl_final_k(const float* __restrict__ row_loss, float* __restrict
   if (threadIdx.x == 0) loss[0] = s;
 }
 
+__global__ void ce_count_from_rows_k(const int32_t* __restrict__ rows, float* __restrict__ scratch, long long n_rows) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) scratch[0] = (float)rows[n_rows];
+}
+
 }  // namespace
 
 namespace uvx {
 
+int sup_rows(hipStream_t st, const int64_t* labels, int32_t* rows, int B, int T, int V) {
+  hipLaunchKernelGGL(sup_rows_k, dim3(1), dim3(1024), 0, st, labels, rows, B, T, V);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
 // scratch: 2 + B*T floats.  scratch[0] = n_valid, scratch[1] = summed loss, scratch[2..] = per-row loss.
+// sup != nullptr: `logits` / `dlogits` hold only the supervised rows, compacted in the order of sup_rows().
 int ce_loss_fwd_bwd(hipStream_t st, int dtype, const void* logits, const int64_t* labels, float* loss, float* scratch,
-                    void* dlogits, int B, int T, int V, int ldl, float grad_scale) {
+                    void* dlogits, int B, int T, int V, int ldl, float grad_scale, const int32_t* sup) {
   UVX_CHECK(V % 8 == 0 && ldl % 8 == 0, UVX_ERR_SHAPE, "ce_loss: V=%d / ld=%d must be multiples of 8", V, ldl);
   const long long rows = (long long)B * T;
   UVX_CHECK(rows > 0, UVX_ERR_SHAPE, "ce_loss: empty batch");
-  hipLaunchKernelGGL(ce_count_k, dim3(1), dim3(1024), 0, st, labels, scratch, B, T);
+  if (sup) hipLaunchKernelGGL(ce_count_from_rows_k, dim3(1), dim3(64), 0, st, sup, scratch, rows);
+  else hipLaunchKernelGGL(ce_count_k, dim3(1), dim3(1024), 0, st, labels, scratch, B, T);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL(ce_rows_k<bf16_t>, dim3(rows), dim3(256), 0, st, (const bf16_t*)logits, labels, scratch, (bf16_t*)dlogits, T, V, (long long)ldl, grad_scale);
+    hipLaunchKernelGGL(ce_rows_k<bf16_t>, dim3(rows), dim3(256), 0, st, (const bf16_t*)logits, labels, scratch, (bf16_t*)dlogits, T, V, (long long)ldl, grad_scale, sup, rows);
   else
-    hipLaunchKernelGGL(ce_rows_k<float>, dim3(rows), dim3(256), 0, st, (const float*)logits, labels, scratch, (float*)dlogits, T, V, (long long)ldl, grad_scale);
+    hipLaunchKernelGGL(ce_rows_k<float>, dim3(rows), dim3(256), 0, st, (const float*)logits, labels, scratch, (float*)dlogits, T, V, (long long)ldl, grad_scale, sup, rows);
   hipLaunchKernelGGL(ce_final_k, dim3(1), dim3(1024), 0, st, scratch, loss, rows);
   UVX_LAUNCH_CHECK();
   return UVX_OK;

@@ -133,6 +133,7 @@ struct LlmWs {
   char* slots;
   void *x_final, *hn, *n, *act, *vt, *logits;
   float* ce_scratch;
+  int32_t* sup;          // supervised-row compaction list (sup_rows), count at [M]
   int32_t *kvs, *kvl;
   // backward
   void *dx, *d_hn, *d_act, *d_gu, *d_n, *d_o, *d_qkv, *qT, *kT, *doT;
@@ -175,6 +176,7 @@ LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
   w.vt = a.take((size_t)B * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
   w.logits = a.take(M * c.vocab * es);
   w.ce_scratch = (float*)a.take(sizeof(float) * (2 + M));
+  w.sup = (int32_t*)a.take(sizeof(int32_t) * (M + 1));
   w.kvs = (int32_t*)a.take(sizeof(int32_t) * B);
   w.kvl = (int32_t*)a.take(sizeof(int32_t) * B);
   if (save) {
@@ -502,6 +504,20 @@ extern "C" int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_
     if (!last) cur = llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1));
   }
   RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps));
+  if (labels && dt == DT_BF16 && g_options[3]) {
+    // Loss path on the SUPERVISED rows only (positions whose next token carries a label): every other row of the
+    // logits has zero weight in ForCausalLMLoss and a zero gradient, so the head GEMM, the CE and (uvx_llm_bwd) the
+    // head dgrad run on the compacted rows - identical loss and gradients, ~T / n_supervised less head work.  The
+    // row list is built on the device (no host sync): GEMMs are launched for M rows and clamp to the device count.
+    if (logits) RC(gemm(st, dt, lin(s.hn, w->lm_head, logits, M, c.vocab, D)));   // the caller's full logits, if asked
+    RC(sup_rows(st, labels, s.sup, B, T, c.vocab));
+    RC(gather_rows(st, dt, s.hn, s.sup, M, s.n, D));
+    GemmDesc g = lin(s.n, w->lm_head, s.logits, M, c.vocab, D);
+    g.m_dev = s.sup + M;
+    RC(gemm(st, dt, g));
+    RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, loss, s.ce_scratch, nullptr, B, T, c.vocab, c.vocab, 1.0f, s.sup));
+    return UVX_OK;
+  }
   RC(gemm(st, dt, lin(s.hn, w->lm_head, s.logits, M, c.vocab, D)));
   if (logits) UVX_HIP(hipMemcpyAsync(logits, s.logits, (size_t)M * c.vocab * es, hipMemcpyDeviceToDevice, st));
   if (labels) RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, loss, s.ce_scratch, nullptr, B, T, c.vocab, c.vocab, 1.0f));
@@ -541,8 +557,38 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
 
   // d logits (in place over the saved logits), then the frozen head: d_hn = dlogits . W_head
   // (labels == NULL: uvx_llm_kl_loss already replaced the saved logits by their gradient)
-  if (labels) RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale));
-  RC(gemm(st, dt, lin(s.logits, w->lm_head_t, s.d_hn, M, D, c.vocab)));
+  if (labels && dt == DT_BF16 && g_options[3]) {
+    // compact supervised rows (see uvx_llm_fwd): d logits in place, head dgrad on those rows, scattered back
+    RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale, s.sup));
+    UVX_HIP(hipMemsetAsync(s.d_hn, 0, (size_t)M * D * esz(dt), st));
+    // d_hn[rows] = d logits_c . W_head: few rows x D outputs over K = vocab -> split K for parallelism on the first
+    // `cap` compact rows (f32 partials in the not-yet-used d_gu scratch, summed in a fixed order), plain GEMM beyond
+    const int nkt = c.vocab / 64;
+    const int cap = M < 512 ? M : 512;
+    const size_t room = (size_t)M * 2 * c.llm_inter * esz(dt) / ((size_t)cap * D * sizeof(float));
+    int nsplit = 1;
+    for (int d = 2; d <= 24 && (size_t)d <= room; ++d)
+      if (c.vocab % 64 == 0 && nkt % d == 0 && nkt / d >= 16) nsplit = d;
+    if (nsplit > 1) {
+      float* partial = (float*)s.d_gu;
+      const int Kc = c.vocab / nsplit;
+      GemmDesc g = lin(s.logits, w->lm_head_t, partial, cap, D, Kc);
+      g.lda = c.vocab; g.ldb = c.vocab; g.batch = nsplit; g.sA = Kc; g.sB = Kc; g.sC = (long long)cap * D; g.out_f32 = 1;
+      g.m_dev = s.sup + M;
+      RC(gemm(st, dt, g));
+      RC(splitk_reduce_scatter(st, dt, partial, nsplit, cap, s.sup, M, s.d_hn, D));
+    }
+    const int first = nsplit > 1 ? cap : 0;
+    if (M > first) {
+      GemmDesc g = lin(at(s.logits, (size_t)first * c.vocab, dt), w->lm_head_t, s.d_n, M - first, D, c.vocab);
+      g.m_dev = s.sup + M; g.m_dev_off = first;
+      RC(gemm(st, dt, g));
+      RC(scatter_rows(st, dt, s.d_n, s.sup, M, s.d_hn, D, first));
+    }
+  } else {
+    if (labels) RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale));
+    RC(gemm(st, dt, lin(s.logits, w->lm_head_t, s.d_hn, M, D, c.vocab)));
+  }
   RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps));
   for (int l = c.llm_layers - 1; l >= 0; --l) {
     const uvx_llm_layer_t& L = w->layers[l];
