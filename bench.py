@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the live HIP-event timing of the GEMM kernel")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: sequential all-reduce + optimizer step (no overlap)")
     ap.add_argument("--opt", default=None, help="probe: 'key=value,...' for uvx_set_option")
     ap.add_argument("--gemm-override", default=None, help="probe: 'MxNxK=variant,...' tile-variant overrides")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table (from the HIP events) here")
@@ -189,7 +190,7 @@ def main():
     cfg = UltravoxConfig(audio_model_id=wl["audio"], text_model_id=wl["text"], hidden_size=4096, stack_factor=8,
                          projector_ln_mid=True, torch_dtype="bfloat16")
     model = UltravoxModel(cfg, device=str(dev), dtype=torch.bfloat16, seed=0, rope_len=1024)
-    trainer = UltravoxTrainer(model, lr=2e-3, max_grad_norm=1.0)
+    trainer = UltravoxTrainer(model, lr=2e-3, max_grad_norm=1.0, overlap_comm=world > 1 and not args.no_overlap)
     fe = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins, device=str(dev))
     batch = synthetic_batch(cfg, B, wl["seconds"], n_text=128, audio_start=16, n_supervised=32, rank=rank)
     pcm = batch.pop("pcm").to(dev)
@@ -207,6 +208,7 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
+    trainer.flush()
     barrier()
     prof = (C.c_double * 12)()
     if not args.no_prof:
@@ -214,6 +216,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    trainer.flush()            # the last step's deferred all-reduce + optimizer step belong to the timed region
     barrier()
     dt = time.perf_counter() - t0
     shapes = None
@@ -245,7 +248,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded PCM + token ids; seeded random-init weights)",
             "config": {"workload": wl["name"], "clips_per_gpu": B, "clip_seconds": wl["seconds"], "text_tokens": 128,
-                       "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}" + (" (all-reduce overlapped with the next step's frozen encoder)" if trainer.overlap_comm else ""),
                        "audio_model": wl["audio"], "text_model": wl["text"], "optimizer": "AdamW bf16 state, clip 1.0",
                        "supervised_tokens_per_clip": 32,
                        "loss_head": "LM head + CE on the supervised positions only (identical loss and gradients)"},

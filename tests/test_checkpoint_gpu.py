@@ -65,3 +65,42 @@ def test_load_state_dict_rejects_foreign_keys_and_shapes():
     w = torch.full_like(m.projector_state_dict()[k], 0.5)
     m.load_state_dict({k: w})
     assert torch.equal(m.projector_state_dict()[k], w) and k in m.keep_params
+
+
+def test_overlapped_all_reduce_schedule_is_bit_identical():
+    """UltravoxTrainer(overlap_comm=True): the gradient all-reduce is asynchronous and clip + AdamW are deferred until the
+    next step reaches the projector.  Exercised here on a 1-rank RCCL group (the collective machinery runs, the reduction
+    is the identity): parameters after 3 steps must equal the sequential schedule's bit for bit, audio and text-only
+    batches mixed."""
+    import os
+    import torch.distributed as dist
+    from test_model_gpu import SMALL
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel, UltravoxTrainer
+    from ultravox_amd.weights import random_state_dict
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        cfg = UltravoxConfig(**SMALL)
+        sd = random_state_dict(cfg, seed=8, dtype=torch.bfloat16)
+        batches = [_batch(cfg, r) for r in range(3)]
+        text_only = {k: v for k, v in batches[1].items() if k in ("input_ids", "attention_mask", "labels")}
+        seq = [batches[0], text_only, batches[2], batches[1]]
+        res = []
+        for overlap in (False, True):
+            m = UltravoxModel(cfg, state_dict=sd, device=DEV)
+            t = UltravoxTrainer(m, lr=2e-3, overlap_comm=overlap)
+            losses = [t.train_step(**b).item() for b in seq]
+            t.flush()
+            res.append((losses, {k: v.clone() for k, v in m.projector_state_dict().items()}, t.exp_avg.clone(), t.step_count))
+        assert res[0][0] == res[1][0] and res[0][3] == res[1][3] == 4
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], res[1][1][k]), k
+        assert torch.equal(res[0][2], res[1][2])
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -659,7 +659,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // NS = number of buffer sets (K-tiles resident in LDS): 2, or 3 where 3 sets fit the 160 KiB (BM <= 160); with NS sets
 // the DMA runs NS-1 tiles ahead: phase 1 issues XB of tile t+NS-1, phases 2-4 [XA | WA | WB] of tile t+NS, and the
 // counted wait of phase 4 leaves (NS-1) N234 + (NS-2) N1 instructions in flight.
-template <int BM, int NS = 2>
+// MODE (probe builds): 0 = the kernel; 1 = operand delivery only (MFMAs skipped); 2 = arithmetic only (no DMA after the prologue)
+template <int BM, int NS = 2, int MODE = 0>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   constexpr int BNW = 256;
   constexpr int MI = BM / 32, MA = (MI + 1) / 2, MB = MI - MA;
@@ -738,6 +739,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   auto dma = [&](const Slot& sl, int t, int set_idx) {   // set_idx = t % NS, tracked by the caller
+    if (MODE == 2 && t >= NS) return;
     glds16(sl.g + t * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_idx * SET));
   };
 #define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -798,7 +800,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < MA; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][i], 0, 0, 0);
+          if (MODE != 1) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][i], 0, 0, 0);
+          else asm volatile("" ::"v"(wa[j][kh]), "v"(xa[i][kh]));
     UVX_PHASE_END();
     // ---- phase 2: XA x WB; DMA: first third of [XA | WA | WB] of tile t+2 ----
 #pragma unroll
@@ -816,7 +819,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < MA; ++i)
-          acc[2 + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][i], 0, 0, 0);
+          if (MODE != 1) acc[2 + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][i], 0, 0, 0);
+          else asm volatile("" ::"v"(wb[j][kh]), "v"(xa[i][kh]));
     UVX_PHASE_END();
     // ---- phase 3: XB x WB ----
 #pragma unroll
@@ -834,7 +838,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < MB; ++i)
-          acc[2 + j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][MA + i], 0, 0, 0);
+          if (MODE != 1) acc[2 + j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][MA + i], 0, 0, 0);
+          else asm volatile("" ::"v"(wb[j][kh]), "v"(xa[i][kh]));
     UVX_PHASE_END();
     // ---- phase 4: XB x WA (WA kept in registers); the counted wait that retires tile t+1 ----
     if (t + NS < nk) {
@@ -851,7 +856,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < MB; ++i)
-          acc[j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][MA + i], 0, 0, 0);
+          if (MODE != 1) acc[j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][MA + i], 0, 0, 0);
+          else asm volatile("" ::"v"(wa[j][kh]), "v"(xa[i][kh]));
     UVX_PHASE_END();
     cs = cs == NS - 1 ? 0 : cs + 1;
   }
@@ -1120,13 +1126,13 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 20;
+constexpr int kNumVariants = 22;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
     {160, 256, 1162., 8.9}, {256, 256, 1380., 8.5}, {256, 256, 0., 9.},      {256, 256, 0., 9.},      {256, 256, 0., 9.},
     {160, 256, 1230., 9.},  {192, 256, 1390., 12.}, {128, 256, 1116., 6.},
-    {160, 256, 1245., 9.},  {128, 256, 0., 6.}};   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
+    {160, 256, 1245., 9.},  {128, 256, 0., 6.},   {256, 256, 0., 9.},   {256, 256, 0., 9.}};  // 20, 21 = probe modes of 11   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 double variant_cost(int v, int M, int N, int K, int batch) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
   // Rounds of tiles over the 256 CUs.  A partly filled last round is cheaper than a full one (the kernels are bound
@@ -1177,6 +1183,8 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 17: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<128>, grid, dim3(512), 0, st, a); break;
     case 18: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 3>), grid, dim3(512), 0, st, a); break;
     case 19: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 3>), grid, dim3(512), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 1>), grid, dim3(512), 0, st, a); break;
+    case 21: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 2>), grid, dim3(512), 0, st, a); break;
     case 12: hipLaunchKernelGGL(gemm_nt_bf16_q4_kernel, grid, dim3(256), 0, st, a); break;
     case 13: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 1>), grid, dim3(512), 0, st, a); break;   // probe: delivery only
     default: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 2>), grid, dim3(512), 0, st, a); break;  // probe: arithmetic only

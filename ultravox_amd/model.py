@@ -92,6 +92,7 @@ class UltravoxModel:
         self.code = _lib.dtype_code(self.dtype)
         self.training = False
         self._kl_grad_scale = 1.0
+        self._before_projector = None
         self.keep_params = set()                 # ultravox_model.py:59
         self.loss_config = LossConfig()
         self.vocab_size = config.vocab_size
@@ -313,6 +314,8 @@ class UltravoxModel:
         B, T = (inputs_embeds.shape[:2] if inputs_embeds is not None else input_ids.shape)
         assert len(audio_batch_size) == B, "audio_batch_size and inputs_embeds must have the same batch size."
         tower = self.audio_tower_forward(audio_values, audio_lens)
+        if self._before_projector is not None:   # the trainer's deferred all-reduce + optimizer step (overlapped with the
+            self._before_projector()             # frozen encoder above, which does not read the trainable weights)
         audio_embeds = self.multi_modal_projector_forward(tower)
         return self._embed_merge(inputs_embeds, input_ids, audio_embeds, audio_token_start_idx, audio_token_len,
                                  audio_batch_size, B, T)
@@ -513,12 +516,13 @@ class UltravoxTrainer:
 
     def __init__(self, model: UltravoxModel, lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, max_grad_norm: float = 1.0, master_weights: bool = False,
-                 gradient_accumulation_steps: int = 1):
+                 gradient_accumulation_steps: int = 1, overlap_comm: bool = False):
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
         self.grad_accum = gradient_accumulation_steps
+        self.overlap_comm = overlap_comm
         n = model.proj_flat.numel()
         dev = model.device
         self.master = model.proj_flat.float().clone() if master_weights else None
@@ -532,6 +536,7 @@ class UltravoxTrainer:
     def save_checkpoint(self, directory: str) -> None:
         """checkpoint-N/ of the HF Trainer: the model's diff state dict + optimizer moments + step."""
         from . import checkpoint
+        self.flush()
         self.model.save_pretrained(directory)
         checkpoint.save_trainer_state(directory, self.step_count,
                                       {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "master": self.master},
@@ -568,11 +573,39 @@ class UltravoxTrainer:
             C.c_float(self.wd), self.step_count, ptr(self.scratch)), "uvx_adamw_clip_step")
 
     def grad_norm(self) -> torch.Tensor:
+        self.flush()
         return self.scratch[0].sqrt()
 
     def train_step(self, **batch) -> torch.Tensor:
+        """One optimizer step.  With `overlap_comm` (and more than one rank) the gradient all-reduce is launched
+        asynchronously after the backward pass and waited for - together with clip + AdamW - only when the NEXT step
+        reaches the projector: the next step's log-mel and frozen-encoder forward, which do not read the trainable
+        weights, hide the collective.  Same arithmetic in the same order as the sequential schedule; call flush() before
+        reading the parameters or the gradient norm."""
         self.model.train()
-        loss = self.model.forward_backward(grad_scale=1.0 / self.grad_accum, **batch)
-        self.all_reduce_grads()
-        self.optimizer_step()
+        if self._pending is not None:
+            av = batch.get("audio_values")
+            if av is not None and len(av) > 0:
+                self.model._before_projector = self.flush
+            else:
+                self.flush()    # text-only batch: no encoder work to hide behind, and its backward rewrites the bucket
+        try:
+            loss = self.model.forward_backward(grad_scale=1.0 / self.grad_accum, **batch)
+        finally:
+            self.model._before_projector = None
+        assert self._pending is None
+        if self.overlap_comm and torch.distributed.is_available() and torch.distributed.is_initialized():
+            self._pending = torch.distributed.all_reduce(self.model.proj_grad, op=torch.distributed.ReduceOp.SUM, async_op=True)
+        else:
+            self.all_reduce_grads()
+            self.optimizer_step()
         return loss
+
+    def flush(self) -> None:
+        """Complete a deferred all-reduce + optimizer step (no-op when nothing is pending)."""
+        if self._pending is None:
+            return
+        work, self._pending = self._pending, None
+        work.wait()                                    # the compute stream waits for the collective
+        self.model.proj_grad.mul_(1.0 / self.world)    # DDP: sum, then divide by the world size
+        self.optimizer_step()
