@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in header_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in include/uvx.h but not exported by libuvx.so: {missing}"
     assert set(_lib.EXPORTS) == set(header_functions())
-    assert lib.uvx_abi_version() == 2
+    assert lib.uvx_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_struct_mirrors_match_header_sizes():
@@ -49,3 +49,13 @@ def test_argument_errors_are_reported_without_a_gpu():
     with pytest.raises(ValueError):
         _lib.check(lib.uvx_gemm(None, 0, None), "uvx_gemm")
     assert lib.uvx_encoder_ws_bytes(None, 1, 100) == 0
+
+
+def test_graft_entry_build_and_abi_version_agree():
+    """The driver's build hook must succeed on the CPU container, and the three statements of the ABI version
+    (include/uvx.h, the library, the ctypes mirrors) must agree."""
+    import re
+    import __graft_entry__ as g
+    g.build()
+    hdr = open(os.path.join(ROOT, "include", "uvx.h")).read()
+    assert int(re.search(r"#define\s+UVX_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.ABI_VERSION == _lib.lib().uvx_abi_version()

@@ -79,7 +79,11 @@ def test_overlapped_all_reduce_schedule_is_bit_identical():
     from ultravox_amd.model import UltravoxModel, UltravoxTrainer
     from ultravox_amd.weights import random_state_dict
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     created = False
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))

@@ -32,6 +32,9 @@ class GemmDesc(C.Structure):
     ]
 
 
+ABI_VERSION = 2   # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -43,6 +46,11 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(str(_LIB_PATH))
         _lib.uvx_last_error.restype = C.c_char_p
         _lib.uvx_abi_version.restype = C.c_int32
+        got = _lib.uvx_abi_version()
+        if got != ABI_VERSION:      # a stale .so next to newer struct mirrors would corrupt memory silently
+            _lib = None
+            raise UvxError(f"{_LIB_PATH} has ABI version {got}, this package expects {ABI_VERSION}: rebuild with "
+                           "`python -m ultravox_amd.build --force`")
         _declare(_lib)
     return _lib
 
