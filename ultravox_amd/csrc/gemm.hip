@@ -25,10 +25,11 @@ namespace uvx {
 int g_gemm_variant = -1; int g_gemm_split = 1;
 // probe hook: per-shape variant overrides (in-situ A/B of the tile choice inside bench.py)
 int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
-// probe hook (uvx_set_option): [1] 16-byte epilogue access (on: -0.5 ms/step at C2), [2] SwiGLU backward fused into the
+// probe hook (uvx_set_option): [1] epilogue access: 0 = 8-byte fragment layout, 1 = 16 bytes via v_permlane16_swap
+// (-0.5 ms/step at C2), 2 = row-contiguous through LDS (default), [2] SwiGLU backward fused into the
 // dgrad GEMM (off: measured neutral at C2 - the separate elementwise kernel runs at 6.7 TB/s, the fused epilogue is
 // serialised behind each tile's main loop), [3] loss head on the supervised rows only (on)
-int g_options[8] = {0, 1, 0, 1, 0, 0, 0, 0};
+int g_options[8] = {0, 2, 0, 1, 0, 0, 0, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -94,10 +95,98 @@ __device__ __forceinline__ void load_pair16(const bf16_t* src, bool ok, uint32_t
 // Shared epilogue.  acc[j][i] is the 16x16 accumulator fragment whose rows are output columns
 // n_base + 16 j + 4 fg .. +3 (4 consecutive per lane) and whose column is output row m_base + 16 i + frow.
 // The reference's bf16 rounding points are restated: round(acc*alpha + bias), round(act(.)), then + residual.
+// Row-contiguous output through LDS.  A store instruction in fragment layout touches 32 rows x 32 bytes: HBM sees
+// quarter-line writes and the fixed cost of a launch is (output bytes) / ~2 TB/s (tools/gpu_gemm_overhead_probe.py).
+// With `stage` (this wave's MI*16 x 128-byte slice of the block's LDS, free after the main loop) the finished bf16
+// fragments are written to LDS (16-byte chunks XOR-swizzled by row), read back row-wise - 8 lanes = one 128-byte row of
+// the wave tile - and stored / residual-added as full lines.  Same values, same rounding order.
+template <int ROWS, int CH /*16-byte chunks per row*/>
+__device__ __forceinline__ char* stage_slot(char* stage, int row, int chunk) {
+  return stage + row * (CH * 16) + ((chunk ^ (row & (CH - 1))) << 4);
+}
+
 template <int NJ, int MI>
 __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ][MI], int m_base, int n_base, int frow,
-                                           int fg, long long z) {
+                                           int fg, long long z, char* stage = nullptr) {
   const bool bf16_out = !p.out_f32;
+  const int lane = fg * 16 + frow;
+  if (NJ == 4 && stage && p.wide_io == 2 && bf16_out && p.swiglu != 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.sC & 7) == 0 &&
+      ((uintptr_t)p.C & 15) == 0 &&
+      (p.swiglu == 0 || ((p.ldc2 & 7) == 0 && ((uintptr_t)p.C2 & 15) == 0)) &&
+      (!p.residual || ((p.ldr & 7) == 0 && (p.sR & 7) == 0 && ((uintptr_t)p.residual & 15) == 0))) {
+    constexpr int ROWS = MI * 16;
+    // ---- pass 1: the [ROWS x 64] tile of C ----
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n_base + j * 16 + fg * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.N) {
+        u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = bf2f(f2bf(acc[j][i][e] * p.alpha + bv[e]));
+          if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));
+          v[e] = t;
+        }
+        *reinterpret_cast<uint2*>(stage_slot<ROWS, 8>(stage, i * 16 + frow, 2 * j + (fg >> 1)) + (fg & 1) * 8) =
+            make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const int c8 = lane & 7, n8 = n_base + c8 * 8;
+#pragma unroll
+      for (int it = 0; it < ROWS / 8; ++it) {
+        const int row = it * 8 + (lane >> 3), m = m_base + row;
+        uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 8>(stage, row, c8));
+        if (m < p.M && n8 < p.N) {
+          if (p.residual) {
+            const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+            const uint4 r = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
+            o.x = pack2(unpack_lo(o.x) + unpack_lo(r.x), unpack_hi(o.x) + unpack_hi(r.x));
+            o.y = pack2(unpack_lo(o.y) + unpack_lo(r.y), unpack_hi(o.y) + unpack_hi(r.y));
+            o.z = pack2(unpack_lo(o.z) + unpack_lo(r.z), unpack_hi(o.z) + unpack_hi(r.z));
+            o.w = pack2(unpack_lo(o.w) + unpack_lo(r.w), unpack_hi(o.w) + unpack_hi(r.w));
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n8) = o;
+        }
+      }
+    }
+    if (p.swiglu != 1) return;
+    // ---- pass 2 (fused SwiGLU): act = round(silu(gate)) * up, [ROWS x 32] -> C2; gate = fragment j (even), up = j + 1 ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pass-1 reads done before the slice is overwritten
+#pragma unroll
+    for (int j = 0; j < NJ; j += 2) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = bf2f(f2bf(acc[j][i][e] * p.alpha));
+          a[e] = bf2f(f2bf(g / (1.0f + __expf(-g)))) * bf2f(f2bf(acc[j + 1][i][e] * p.alpha));
+        }
+        *reinterpret_cast<uint2*>(stage_slot<ROWS, 4>(stage, i * 16 + frow, j + (fg >> 1)) + (fg & 1) * 8) =
+            make_uint2(pack2(a[0], a[1]), pack2(a[2], a[3]));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const int c4 = lane & 3, n8 = n_base / 2 + c4 * 8;
+#pragma unroll
+      for (int it = 0; it < ROWS / 16; ++it) {
+        const int row = it * 16 + (lane >> 2), m = m_base + row;
+        const uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 4>(stage, row, c4));
+        if (m < p.M && 2 * n8 < p.N) *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc2 + n8) = o;
+      }
+    }
+    return;
+  }
   constexpr int MI2 = MI & ~1;
   // row / column slot of this lane in the 16-byte layout (see frag_pair_swap): row fragment i + (fg & 1), columns 8 (fg >> 1)
   const int prow = (fg & 1) * 16 + frow, pcol = (fg >> 1) * 8;
@@ -400,7 +489,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
   }
 
   // ---- epilogue ----
-  store_tile<4, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, frow, fg, z);
+  __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
+  store_tile<4, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, frow, fg, z, lds + w * (4 * 16 * 128));
 }
 
 
@@ -497,7 +587,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z);
+  __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
+  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,7 +718,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
 #undef UVX_VMCNT
 
-  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z);
+  __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
+  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -866,7 +958,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 #undef UVX_PHASE_SYNC
 #undef UVX_PHASE_END
 
-  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z);
+  __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
+  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1106,7 +1199,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide3_kernel(GemmArgs p) 
   }
 #undef UVX_VMCNT
 
-  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z);
+  __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
+  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
 }
 
 // Tile choice.  Every CU works through ~tiles/256 rounds of tiles (see variant_cost for the partial last
