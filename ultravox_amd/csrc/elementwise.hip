@@ -174,6 +174,39 @@ __global__ void transpose_k(const T* __restrict__ in, T* __restrict__ out, int r
   }
 }
 
+// bf16, 16-byte global access on both sides (ld_in, ld_out, cols and all strides multiples of 8, 16-byte aligned bases):
+// 2 loads + 2 stores per thread for a 64 x 64 tile instead of 16 + 16 two-byte ones; the transposition itself is done
+// with 2-byte LDS accesses on a 65-element row stride (conflict-free for both the row-wise writes and the column gathers).
+__global__ void transpose_bf16_v8_k(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols, int ld_in,
+                                    int ld_out, int nzi, long long s_in_o, long long s_in_i, long long s_out) {
+  __shared__ bf16_t tile[64][65];
+  const int zo = blockIdx.z / nzi, zi = blockIdx.z % nzi;
+  const bf16_t* ib = in + zo * s_in_o + zi * s_in_i;
+  bf16_t* ob = out + blockIdx.z * s_out;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = threadIdx.x + k * 256, rr = idx >> 3, ch = idx & 7;
+    const int r = r0 + rr, c = c0 + ch * 8;
+    u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < rows && c < cols) v = *reinterpret_cast<const u16x8_t*>(ib + (long long)r * ld_in + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[rr][ch * 8 + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = threadIdx.x + k * 256, cc = idx >> 3, r8 = idx & 7;
+    const int c = c0 + cc, r = r0 + r8 * 8;
+    if (c < cols && r < ld_out) {
+      u16x8_t v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[r8 * 8 + e][cc];
+      *reinterpret_cast<u16x8_t*>(ob + (long long)c * ld_out + r) = v;
+    }
+  }
+}
+
 // conv1 im2col: out[(b*F + t), k*n_mels + c] = mel[b, c, t + k - 1]  (zero outside [0, F)), cols padded to Kp
 template <typename T, typename TIN>
 __global__ void im2col_conv1_k(const TIN* __restrict__ mel, T* __restrict__ out, int n_mels, int F, int F_stride,
@@ -348,7 +381,11 @@ static int transpose_launch(hipStream_t st, int dtype, const void* in, void* out
   if (rows == 0 || cols == 0 || nzo * nzi == 0) return UVX_OK;
   // the zero padded region out[:, rows..ld_out) is written too (the GEMM K dimension must be 64-aligned)
   dim3 grid(cdiv(ld_out, 64), cdiv(cols, 64), nzo * nzi);
-  if (dtype == DT_BF16)
+  const bool v8 = dtype == DT_BF16 && ((ld_in | ld_out | cols) & 7) == 0 && ((s_in_o | s_in_i | s_out) & 7) == 0 &&
+                  (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+  if (v8)
+    hipLaunchKernelGGL(transpose_bf16_v8_k, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, nzi, s_in_o, s_in_i, s_out);
+  else if (dtype == DT_BF16)
     hipLaunchKernelGGL(transpose_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, nzi, s_in_o, s_in_i, s_out);
   else
     hipLaunchKernelGGL(transpose_k<float>, grid, dim3(256), 0, st, (const float*)in, (float*)out, rows, cols, ld_in, ld_out, nzi, s_in_o, s_in_i, s_out);
