@@ -77,7 +77,7 @@ def test_gemm_rejects_bad_shapes():
 
 
 # ------------------------------------------------------------------ norms
-@pytest.mark.parametrize("rows,cols", [(7, 384), (300, 1024), (33, 1280)])
+@pytest.mark.parametrize("rows,cols", [(7, 384), (300, 1024), (33, 1280), (1501, 512), (6, 4096)])
 def test_layernorm(rows, cols):
     torch.manual_seed(1)
     x = bf(torch.randn(rows, cols, device=DEV) * 2 + 0.3)
@@ -107,6 +107,9 @@ def test_rmsnorm_fwd_bwd(rows, cols):
     dx, dw = ops().rmsnorm_bwd(dy, x, w, 1e-6, dx_add=add, want_dw=True)
     assert rel_l2(dx, xr.grad + add.float()) < 6e-3
     assert rel_l2(dw, wr.grad) < 6e-3
+    dx_only = ops().rmsnorm_bwd(dy, x, w, 1e-6, dx_add=add, want_dw=False)       # the frozen-LLM variant (row cached in registers)
+    dx_only = dx_only[0] if isinstance(dx_only, tuple) else dx_only
+    assert rel_l2(dx_only, xr.grad + add.float()) < 6e-3
 
 
 def test_stack_rmsnorm_is_pad_view_norm(golden_dir):
