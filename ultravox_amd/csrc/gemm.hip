@@ -105,7 +105,9 @@ __device__ __forceinline__ char* stage_slot(char* stage, int row, int chunk) {
   return stage + row * (CH * 16) + ((chunk ^ (row & (CH - 1))) << 4);
 }
 
-template <int NJ, int MI>
+// GI = row fragments staged per pass: MI (the whole wave tile, MI*16 x 128 B of LDS per wave) or 1 (16 rows = 2 KiB per
+// wave: the persistent kernels, whose operand buffers are already being refilled for the next tile).
+template <int NJ, int MI, int GI = MI>
 __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ][MI], int m_base, int n_base, int frow,
                                            int fg, long long z, char* stage = nullptr) {
   const bool bf16_out = !p.out_f32;
@@ -114,75 +116,85 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
       ((uintptr_t)p.C & 15) == 0 &&
       (p.swiglu == 0 || ((p.ldc2 & 7) == 0 && ((uintptr_t)p.C2 & 15) == 0)) &&
       (!p.residual || ((p.ldr & 7) == 0 && (p.sR & 7) == 0 && ((uintptr_t)p.residual & 15) == 0))) {
-    constexpr int ROWS = MI * 16;
-    // ---- pass 1: the [ROWS x 64] tile of C ----
+    constexpr int ROWS = GI * 16;
+    static_assert(MI % GI == 0, "row fragments per pass must divide the wave tile");
+    float bv[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int n = n_base + j * 16 + fg * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[j][e] = 0.f;
       if (p.bias && n < p.N) {
         u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = bf2f(f2bf(acc[j][i][e] * p.alpha + bv[e]));
-          if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));
-          v[e] = t;
-        }
-        *reinterpret_cast<uint2*>(stage_slot<ROWS, 8>(stage, i * 16 + frow, 2 * j + (fg >> 1)) + (fg & 1) * 8) =
-            make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+        for (int e = 0; e < 4; ++e) bv[j][e] = bf2f(b4[e]);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-      const int c8 = lane & 7, n8 = n_base + c8 * 8;
 #pragma unroll
-      for (int it = 0; it < ROWS / 8; ++it) {
-        const int row = it * 8 + (lane >> 3), m = m_base + row;
-        uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 8>(stage, row, c8));
-        if (m < p.M && n8 < p.N) {
-          if (p.residual) {
-            const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
-            const uint4 r = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
-            o.x = pack2(unpack_lo(o.x) + unpack_lo(r.x), unpack_hi(o.x) + unpack_hi(r.x));
-            o.y = pack2(unpack_lo(o.y) + unpack_lo(r.y), unpack_hi(o.y) + unpack_hi(r.y));
-            o.z = pack2(unpack_lo(o.z) + unpack_lo(r.z), unpack_hi(o.z) + unpack_hi(r.z));
-            o.w = pack2(unpack_lo(o.w) + unpack_lo(r.w), unpack_hi(o.w) + unpack_hi(r.w));
+    for (int i0 = 0; i0 < MI; i0 += GI) {
+      if (i0 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads are done (WAR on the slice)
+      // ---- pass 1: [ROWS x 64] of C ----
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int ii = 0; ii < GI; ++ii) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = bf2f(f2bf(acc[j][i0 + ii][e] * p.alpha + bv[j][e]));
+            if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));
+            v[e] = t;
           }
-          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n8) = o;
+          *reinterpret_cast<uint2*>(stage_slot<ROWS, 8>(stage, ii * 16 + frow, 2 * j + (fg >> 1)) + (fg & 1) * 8) =
+              make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
         }
       }
-    }
-    if (p.swiglu != 1) return;
-    // ---- pass 2 (fused SwiGLU): act = round(silu(gate)) * up, [ROWS x 32] -> C2; gate = fragment j (even), up = j + 1 ----
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pass-1 reads done before the slice is overwritten
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {
+        const int c8 = lane & 7, n8 = n_base + c8 * 8;
 #pragma unroll
-    for (int j = 0; j < NJ; j += 2) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        float a[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = bf2f(f2bf(acc[j][i][e] * p.alpha));
-          a[e] = bf2f(f2bf(g / (1.0f + __expf(-g)))) * bf2f(f2bf(acc[j + 1][i][e] * p.alpha));
+        for (int it = 0; it < ROWS / 8; ++it) {
+          const int row = it * 8 + (lane >> 3), m = m_base + i0 * 16 + row;
+          uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 8>(stage, row, c8));
+          if (m < p.M && n8 < p.N) {
+            if (p.residual) {
+              const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+              const uint4 r = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
+              o.x = pack2(unpack_lo(o.x) + unpack_lo(r.x), unpack_hi(o.x) + unpack_hi(r.x));
+              o.y = pack2(unpack_lo(o.y) + unpack_lo(r.y), unpack_hi(o.y) + unpack_hi(r.y));
+              o.z = pack2(unpack_lo(o.z) + unpack_lo(r.z), unpack_hi(o.z) + unpack_hi(r.z));
+              o.w = pack2(unpack_lo(o.w) + unpack_lo(r.w), unpack_hi(o.w) + unpack_hi(r.w));
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n8) = o;
+          }
         }
-        *reinterpret_cast<uint2*>(stage_slot<ROWS, 4>(stage, i * 16 + frow, j + (fg >> 1)) + (fg & 1) * 8) =
-            make_uint2(pack2(a[0], a[1]), pack2(a[2], a[3]));
       }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-      const int c4 = lane & 3, n8 = n_base / 2 + c4 * 8;
+      if (p.swiglu != 1) continue;
+      // ---- pass 2 (fused SwiGLU): act = round(silu(gate)) * up, [ROWS x 32] -> C2; gate = fragment j (even), up = j + 1 ----
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pass-1 reads done before the slice is overwritten
 #pragma unroll
-      for (int it = 0; it < ROWS / 16; ++it) {
-        const int row = it * 16 + (lane >> 2), m = m_base + row;
-        const uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 4>(stage, row, c4));
-        if (m < p.M && 2 * n8 < p.N) *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc2 + n8) = o;
+      for (int j = 0; j < NJ; j += 2) {
+#pragma unroll
+        for (int ii = 0; ii < GI; ++ii) {
+          float a[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = bf2f(f2bf(acc[j][i0 + ii][e] * p.alpha));
+            a[e] = bf2f(f2bf(g / (1.0f + __expf(-g)))) * bf2f(f2bf(acc[j + 1][i0 + ii][e] * p.alpha));
+          }
+          *reinterpret_cast<uint2*>(stage_slot<ROWS, 4>(stage, ii * 16 + frow, j + (fg >> 1)) + (fg & 1) * 8) =
+              make_uint2(pack2(a[0], a[1]), pack2(a[2], a[3]));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {
+        const int c4 = lane & 3, n8 = n_base / 2 + c4 * 8;
+#pragma unroll
+        for (int it = 0; it < ROWS / 16; ++it) {
+          const int row = it * 16 + (lane >> 2), m = m_base + i0 * 16 + row;
+          const uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 4>(stage, row, c4));
+          if (m < p.M && 2 * n8 < p.N) *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc2 + n8) = o;
+        }
       }
     }
     return;
@@ -751,8 +763,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // NS = number of buffer sets (K-tiles resident in LDS): 2, or 3 where 3 sets fit the 160 KiB (BM <= 160); with NS sets
 // the DMA runs NS-1 tiles ahead: phase 1 issues XB of tile t+NS-1, phases 2-4 [XA | WA | WB] of tile t+NS, and the
 // counted wait of phase 4 leaves (NS-1) N234 + (NS-2) N1 instructions in flight.
-// MODE (probe builds): 0 = the kernel; 1 = operand delivery only (MFMAs skipped); 2 = arithmetic only (no DMA after the prologue)
-template <int BM, int NS = 2, int MODE = 0>
+// MODE (probe builds): 0 = the kernel; 1 = operand delivery only (MFMAs skipped); 2 = arithmetic only (no DMA after the prologue);
+// 3 = no epilogue
+// PERSIST: the grid is one block per CU and every block walks tiles b, b + grid, b + 2 grid, ... (the order the hardware
+// would dispatch them).  When a tile's K loop ends, the DMA for the first NS K-tiles of the NEXT tile is issued before the
+// epilogue of the current one, which stages through its own 2 KiB per wave: the output stores (HBM-write bound, 8 us of
+// a 110 us tile at K = 4096) and the pipeline fill of the next tile overlap instead of adding up.
+// Measured (profiles/r01_gemm_cold_probe_ph8.txt, tools/gpu_gemm_overhead_probe.py): the fixed cost of a 4.4-round launch
+// drops 47.5 -> 39.6 us, +0.5...1.5 % on the multi-round shapes - far less than the 33 us a free epilogue would give
+// (MODE 3 probe): all CUs finish a round together, so the 30-50 MB of output per round is one HBM-write burst that
+// throttles store ISSUE on every CU at once, overlapped or not.  Kept as probe variants (23..26), not selected."
+template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   constexpr int BNW = 256;
   constexpr int MI = BM / 32, MA = (MI + 1) / 2, MB = MI - MA;
@@ -765,24 +786,36 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   constexpr int N234 = (REST + 7) / 8;                                     // per wave, phases 2-4 together
   constexpr int N2 = (N234 + 2) / 3, N3 = (N234 - N2 + 1) / 2, N4 = N234 - N2 - N3;
   static_assert(8 * N2 <= XA_I + W_I, "WB must not be re-staged in the phase that reads it");
-  static_assert(NS * SET + 1024 <= 160 * 1024, "buffer sets exceed the LDS");
-  __shared__ __attribute__((aligned(16))) char lds[NS * SET + 1024];
-  constexpr int O_DUMMY = NS * SET;
+  constexpr int O_DUMMY = NS * SET, O_STAGE = O_DUMMY + 1024, LDS_BYTES = O_STAGE + (PERSIST ? 8 * 2048 : 0);
+  static_assert(LDS_BYTES <= 160 * 1024, "buffer sets exceed the LDS");
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   constexpr int INFLIGHT = (NS - 1) * N234 + (NS - 2) * N1;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;
-  const int nwg = gridDim.x, orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
-  const int m0 = tm * BM, n0 = tn * BNW;
-  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
-    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
-    if (m0 >= me) return;
-    p.M = me;
-  }
+  const int ntiles = p.tiles_m * p.tiles_n;            // == gridDim.x unless PERSIST
+  if (p.m_dev) p.M = min(p.M, max(*p.m_dev - p.m_dev_off, 0));   // rows known only on the device: clamp M
+  int m0, n0;
+  // tile `o` in dispatch order -> its origin (XCD-aware bijective remap); false if o is past the end
+  auto tile_origin = [&](int o, int& m0_, int& n0_) {
+    if (o >= ntiles) return false;
+    const int xcd = o & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (o >> 3);
+    m0_ = (wg % p.tiles_m) * BM; n0_ = (wg / p.tiles_m) * BNW;
+    return true;
+  };
+  // first / next tile with rows to compute (tiles beyond a device-side row count are skipped); uniform over the block
+  auto next_tile = [&](int& o, int& m0_, int& n0_) {
+    for (;;) {
+      if (!tile_origin(o, m0_, n0_)) return false;
+      if (m0_ < p.M) return true;
+      if (!PERSIST) return false;
+      o += gridDim.x;
+    }
+  };
+  int orig = blockIdx.x;
+  if (!next_tile(orig, m0, n0)) return;   // (before any barrier)
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -802,18 +835,21 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     const int n = (hr >> 5) * 64 + (half_b ? 32 : 0) + (hr & 31);
     return Slot{B + (long long)min(n0 + n, p.N - 1) * p.ldb + schunk * 8, (half_b ? O_WB : O_WA) + q * 1024};
   };
-  const Slot dummy = Slot{A + (long long)min(m0, p.M - 1) * p.lda + schunk * 8, -1};
   Slot sxb[N1], srest[N234];
+  auto fill_slots = [&](Slot (&sxb_)[N1], Slot (&srest_)[N234]) {   // for the tile at (m0, n0)
+    const Slot dummy = Slot{A + (long long)min(m0, p.M - 1) * p.lda + schunk * 8, -1};
 #pragma unroll
-  for (int k = 0; k < N1; ++k) {
-    const int g = k * 8 + w;
-    sxb[k] = g < XB_I ? x_slot(true, g) : dummy;
-  }
+    for (int k = 0; k < N1; ++k) {
+      const int g = k * 8 + w;
+      sxb_[k] = g < XB_I ? x_slot(true, g) : dummy;
+    }
 #pragma unroll
-  for (int k = 0; k < N234; ++k) {
-    const int g = k * 8 + w;
-    srest[k] = g < XA_I ? x_slot(false, g) : g < XA_I + W_I ? w_slot(false, g - XA_I) : g < REST ? w_slot(true, g - XA_I - W_I) : dummy;
-  }
+    for (int k = 0; k < N234; ++k) {
+      const int g = k * 8 + w;
+      srest_[k] = g < XA_I ? x_slot(false, g) : g < XA_I + W_I ? w_slot(false, g - XA_I) : g < REST ? w_slot(true, g - XA_I - W_I) : dummy;
+    }
+  };
+  fill_slots(sxb, srest);
   const int frow = lane & 15, fg = lane >> 4;
   int xo[2], wo[2];   // fragment byte offsets (k-half 0 / 1) relative to the region base
 #pragma unroll
@@ -823,12 +859,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     wo[kh] = (wc * 32 + frow) * 128 + c;
   }
   const int xa_base = O_XA + wr * MA * 16 * 128, xb_base = O_XB + wr * MB * 16 * 128;
-
-  f32x4_t acc[4][MI];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   auto dma = [&](const Slot& sl, int t, int set_idx) {   // set_idx = t % NS, tracked by the caller
     if (MODE == 2 && t >= NS) return;
@@ -849,23 +879,36 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 
   const int nk = p.K / BK;
   // prologue: REST(0), XB(0), REST(1), XB(1), ..., REST(NS-1)  (the steady-state issue order)
+  auto issue_prologue = [&](const Slot (&sxb_)[N1], const Slot (&srest_)[N234]) {
 #pragma unroll
-  for (int tt = 0; tt < NS; ++tt) {
-    if (tt < nk) {
+    for (int tt = 0; tt < NS; ++tt) {
+      if (tt < nk) {
 #pragma unroll
-      for (int k = 0; k < N234; ++k) dma(srest[k], tt, tt);
-      if (tt < NS - 1) {
+        for (int k = 0; k < N234; ++k) dma(srest_[k], tt, tt);
+        if (tt < NS - 1) {
 #pragma unroll
-        for (int k = 0; k < N1; ++k) dma(sxb[k], tt, tt);
+          for (int k = 0; k < N1; ++k) dma(sxb_[k], tt, tt);
+        }
       }
     }
-  }
+  };
+  issue_prologue(sxb, srest);
+
+  for (;;) {   // one iteration per output tile (exactly one unless PERSIST)
+  // K-tile 0 has landed when at most INFLIGHT DMA instructions are outstanding (in PERSIST mode the previous tile's
+  // output stores sit in the same counter behind them: the bound on the total still bounds the loads)
   if (nk >= NS) UVX_VMCNT(INFLIGHT);
   else UVX_VMCNT(0);
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: this half runs one barrier behind
   __builtin_amdgcn_sched_barrier(0);
+
+  f32x4_t acc[4][MI];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   int cs = 0;   // t % NS
   for (int t = 0; t < nk; ++t) {
@@ -954,12 +997,39 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     cs = cs == NS - 1 ? 0 : cs + 1;
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
+  __builtin_amdgcn_sched_barrier(0);
+
+  if (MODE == 3) {   // probe: no epilogue (keeps the accumulators alive with one conditional store)
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) t += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+    if (t == 12345.678f) *reinterpret_cast<float*>(p.C) = t;
+    return;
+  }
+  if (!PERSIST) {
+    __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
+    store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
+    break;
+  }
+  // every wave has passed its last fragment read (the barriers above): the operand buffers are free.  Start the next
+  // tile's pipeline fill, THEN write this tile out through the per-wave 2 KiB stage.
+  const int m0_cur = m0, n0_cur = n0;
+  int next = orig + gridDim.x;
+  const bool has_next = next_tile(next, m0, n0);
+  if (has_next) {
+    fill_slots(sxb, srest);
+    issue_prologue(sxb, srest);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  store_tile<4, MI, 1>(p, acc, m0_cur + wr * (BM / 2), n0_cur + wc * 64, frow, fg, z, lds + O_STAGE + w * 2048);
+  if (!has_next) break;
+  orig = next;
+  }
 #undef UVX_VMCNT
 #undef UVX_PHASE_SYNC
 #undef UVX_PHASE_END
-
-  __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
-  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1220,13 +1290,14 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 22;
+constexpr int kNumVariants = 27;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
     {160, 256, 1162., 8.9}, {256, 256, 1380., 8.5}, {256, 256, 0., 9.},      {256, 256, 0., 9.},      {256, 256, 0., 9.},
     {160, 256, 1230., 9.},  {192, 256, 1390., 12.}, {128, 256, 1116., 6.},
-    {160, 256, 1245., 9.},  {128, 256, 0., 6.},   {256, 256, 0., 9.},   {256, 256, 0., 9.}};  // 20, 21 = probe modes of 11   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
+    {160, 256, 1245., 9.},  {128, 256, 0., 6.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   // 20..22 = probe modes of 11
+    {256, 256, 0., 4.},     {192, 256, 0., 6.},     {160, 256, 0., 5.},     {128, 256, 0., 4.}};   // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 double variant_cost(int v, int M, int N, int K, int batch) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
   // Rounds of tiles over the 256 CUs.  A partly filled last round is cheaper than a full one (the kernels are bound
@@ -1279,6 +1350,17 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 19: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 3>), grid, dim3(512), 0, st, a); break;
     case 20: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 1>), grid, dim3(512), 0, st, a); break;
     case 21: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 2>), grid, dim3(512), 0, st, a); break;
+    case 22: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 3>), grid, dim3(512), 0, st, a); break;
+    case 23: case 24: case 25: case 26: {
+      // persistent: one block per CU walks the tiles (batched problems use the plain kernels: grid.y would oversubscribe)
+      if (batch != 1) { launch_variant(st, variant == 23 ? 11 : variant == 24 ? 16 : variant == 25 ? 15 : 17, a, M, N, batch); return; }
+      const dim3 pgrid(a.tiles_m * a.tiles_n < 256 ? a.tiles_m * a.tiles_n : 256);
+      if (variant == 23) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 0, true>), pgrid, dim3(512), 0, st, a);
+      else if (variant == 24) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<192, 2, 0, true>), pgrid, dim3(512), 0, st, a);
+      else if (variant == 25) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 2, 0, true>), pgrid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 2, 0, true>), pgrid, dim3(512), 0, st, a);
+      break;
+    }
     case 12: hipLaunchKernelGGL(gemm_nt_bf16_q4_kernel, grid, dim3(256), 0, st, a); break;
     case 13: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 1>), grid, dim3(512), 0, st, a); break;   // probe: delivery only
     default: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 2>), grid, dim3(512), 0, st, a); break;  // probe: arithmetic only
