@@ -164,11 +164,19 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+    # test hook for the multi-rank code path on a 1-GPU box: UVX_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL refuses two ranks on one device); never set by the driver, and the JSON line says so if it is
+    share_gpu = os.environ.get("UVX_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if share_gpu:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     from ultravox_amd import _lib
     from ultravox_amd.config import UltravoxConfig
@@ -248,7 +256,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded PCM + token ids; seeded random-init weights)",
             "config": {"workload": wl["name"], "clips_per_gpu": B, "clip_seconds": wl["seconds"], "text_tokens": 128,
-                       "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}" + (" (all-reduce overlapped with the next step's frozen encoder)" if trainer.overlap_comm else ""),
+                       "seq_len": T, "global_batch": B * world, "parallelism": ("SHARED-GPU TEST MODE " if share_gpu else "") + f"dp{world}" + (" (all-reduce overlapped with the next step's frozen encoder)" if trainer.overlap_comm else ""),
                        "audio_model": wl["audio"], "text_model": wl["text"], "optimizer": "AdamW bf16 state, clip 1.0",
                        "supervised_tokens_per_clip": 32,
                        "loss_head": "LM head + CE on the supervised positions only (identical loss and gradients)"},
