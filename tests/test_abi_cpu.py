@@ -59,3 +59,26 @@ def test_graft_entry_build_and_abi_version_agree():
     g.build()
     hdr = open(os.path.join(ROOT, "include", "uvx.h")).read()
     assert int(re.search(r"#define\s+UVX_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.ABI_VERSION == _lib.lib().uvx_abi_version()
+
+
+def test_header_is_plain_c99_and_links_from_c(tmp_path):
+    """include/uvx.h is the drop-in boundary: it must compile as C (no C++-isms, no torch types) and a C program must
+    link against libuvx.so and call it (no GPU work: version + the tile picker, which are host-only)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include "uvx.h"\n'
+                   'int main(void) { printf("%d %d\\n", (int)uvx_abi_version(), (int)uvx_gemm_pick_variant(2528, 28672, 4096, 1));'
+                   ' return uvx_last_error() == 0; }\n')
+    exe = tmp_path / "t"
+    libdir = os.path.join(ROOT, "ultravox_amd")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-l:libuvx.so", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ver, variant = out.stdout.split()
+    assert int(ver) == _lib.ABI_VERSION and int(variant) > 0
