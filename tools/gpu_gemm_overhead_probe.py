@@ -7,7 +7,9 @@ from ultravox_amd import ops, _lib
 dev = "cuda"
 L = _lib.lib()
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [11]
-for (M, N) in [(2528, 28672), (2528, 6144), (12000, 4096)]:
+shapes = [(2528, 28672), (2528, 6144), (12000, 4096)]
+if len(sys.argv) > 2: shapes = shapes[: int(sys.argv[2])]
+for (M, N) in shapes:
     for v in variants:
         L.uvx_gemm_force_variant(v)
         pts = []

@@ -758,6 +758,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // an ordered list of 1 KiB instructions (8 rows x 128 B): [XB of t+1] in phase 1 and [XA | WA | WB of t+2] spread
 // evenly over phases 2-4; every wave issues the same count per phase (surplus slots go to a dummy 1 KiB target),
 // so the counted wait in phase 4 is exact.
+// (Tried, no measurable effect on the K-tile time (tools/gpu_gemm_overhead_probe.py slope, +-1 %): dropping s_setprio;
+// waiting for the phase-2/3 fragment reads after the barrier instead of before it.)
 // (Tried and dropped: reading the next tile's WA fragments in phase 4 to balance the per-phase LDS reads 8/4/8/4
 // instead of 12/4/8/0 - 3-10 % slower: the extra counted wait it needs in phase 3 shortens the DMA window.)
 // NS = number of buffer sets (K-tiles resident in LDS): 2, or 3 where 3 sets fit the 160 KiB (BM <= 160); with NS sets
