@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 2
+#define UVX_ABI_VERSION 3
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -61,12 +61,28 @@ typedef struct {
  * Kp1 = roundup(3*n_mels, 64);  conv2_w [d, 3d] with column k*d + c = conv2.weight[:, c, k]. */
 typedef struct {
   const void *ln1_w, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  /* transposed copies ([K_in, N_out]) for the activation gradients of uvx_encoder_bwd; NULL for inference */
+  const void *wqkv_t, *wo_t, *fc1_t, *fc2_t;
 } uvx_enc_layer_t;
 typedef struct {
   const void *conv1_w, *conv1_b, *conv2_w, *conv2_b, *pos;
   const uvx_enc_layer_t* layers; /* HOST array [enc_layers] of device-pointer records */
   const void *lnf_w, *lnf_b;
 } uvx_encoder_weights_t;
+
+/* LoRA on the encoder's q_proj / k_proj (audio_model_lora_config, ultravox_config.py:9-23; applied by peft through
+ * apply_lora, ultravox_model.py:690-709): peft layouts, lora_A.weight [r, d] and lora_B.weight [d, r] in the cfg dtype;
+ * result += lora_B(lora_A(x)) * scaling with scaling = lora_alpha / r.  Gradients: f32, same shapes. */
+typedef struct { const void *a, *b; } uvx_lora_proj_t;
+typedef struct { uvx_lora_proj_t q, k; } uvx_enc_lora_layer_t;
+typedef struct {
+  int32_t r;       /* 1..64 */
+  float scaling;
+  const uvx_enc_lora_layer_t* layers; /* HOST array [enc_layers] */
+} uvx_encoder_lora_t;
+typedef struct { float *a, *b; } uvx_lora_proj_grad_t;
+typedef struct { uvx_lora_proj_grad_t q, k; } uvx_enc_lora_layer_grads_t;
+typedef struct { const uvx_enc_lora_layer_grads_t* layers; } uvx_encoder_lora_grads_t;
 
 /* multi_modal_projector.{ln_pre,linear_1,ln_mid|ln_post,linear_2}.weight (ultravox_model.py:749-766) */
 typedef struct {
@@ -122,8 +138,21 @@ size_t uvx_projector_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t Te);
 int32_t uvx_projector_fwd(void* stream, const uvx_config_t* cfg, const uvx_projector_weights_t* w, const void* enc_out,
                           int32_t B, int32_t Te, void* out, void* workspace, size_t ws_bytes);
 int32_t uvx_projector_bwd(void* stream, const uvx_config_t* cfg, const uvx_projector_weights_t* w, const void* dout,
-                          int32_t B, int32_t Te, const uvx_projector_grads_t* grads, void* workspace,
+                          int32_t B, int32_t Te, const uvx_projector_grads_t* grads, void* d_enc_out, void* workspace,
                           size_t ws_bytes);
+/* d_enc_out: NULL, or [B, Te, C] = d loss / d enc_out (needed only when the encoder itself trains: LoRA). */
+
+/* Encoder under LoRA training (the reference's release configs train the projector plus rank-8
+ * LoRA on the Whisper q_proj / k_proj).  uvx_encoder_fwd_train = uvx_encoder_fwd with the LoRA terms added and a
+ * per-layer activation stash left in `workspace`; uvx_encoder_bwd turns d out [B, Te, d] into the LoRA gradients
+ * (OVERWRITTEN, f32).  The layers need their transposed weight copies (uvx_enc_layer_t.*_t).  Same audio_lens for both. */
+size_t uvx_encoder_train_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t F);
+int32_t uvx_encoder_fwd_train(void* stream, const uvx_config_t* cfg, const uvx_encoder_weights_t* w,
+                              const uvx_encoder_lora_t* lora, const void* mel, int32_t mel_is_f32, const int64_t* audio_lens,
+                              int32_t B, int32_t F, void* out, void* workspace, size_t ws_bytes);
+int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const uvx_encoder_weights_t* w, const uvx_encoder_lora_t* lora,
+                        const void* d_out, const int64_t* audio_lens, int32_t B, int32_t F,
+                        const uvx_encoder_lora_grads_t* grads, void* workspace, size_t ws_bytes);
 
 /* embed_tokens + the in-place audio overwrite loop (ultravox_model.py:314-316, :390-394, :259-275).
  * input_ids [B, T] int64; audio_embeds [n_items, Na, D]; audio_batch_size [B] int64;
@@ -253,6 +282,13 @@ typedef struct {
 size_t uvx_attention_ws_bytes(int32_t dtype, const uvx_attn_desc_t* d, int32_t backward);
 int32_t uvx_attention_fwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d, void* workspace, size_t ws_bytes);
 int32_t uvx_attention_bwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d, void* workspace, size_t ws_bytes);
+
+/* encoder-LoRA backward pieces: LayerNorm backward for a frozen affine (dx [+ dx_add] only), GELU as a separate pass
+ * (the arithmetic of the fused GEMM epilogue) and its exact-derivative backward; n = element count (multiple of 8) */
+int32_t uvx_layernorm_bwd(void* stream, int32_t dtype, const void* dy, const void* x, const void* w, const void* dx_add,
+                          void* dx, int32_t rows, int32_t cols, float eps);
+int32_t uvx_gelu(void* stream, int32_t dtype, const void* pre, void* out, int64_t n);
+int32_t uvx_gelu_bwd(void* stream, int32_t dtype, const void* dout, const void* pre, void* din, int64_t n);
 
 /* scratch: 2 + B*T floats */
 int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, const int64_t* labels, float* loss, void* dlogits,

@@ -118,7 +118,7 @@ def latency_mask_ref(max_context: int, block: int, dtype: torch.dtype) -> torch.
 
 def whisper_encoder_ref(sd: Dict[str, torch.Tensor], cfg, input_features: torch.Tensor,
                         audio_len: Optional[torch.Tensor], prefix: str = "audio_tower.",
-                        return_layer: Optional[int] = None) -> torch.Tensor:
+                        return_layer: Optional[int] = None, lora: Optional[dict] = None) -> torch.Tensor:
     a = cfg.audio_config
     dt = input_features.dtype
     H, d = a.encoder_attention_heads, a.d_model
@@ -147,8 +147,20 @@ def whisper_encoder_ref(sd: Dict[str, torch.Tensor], cfg, input_features: torch.
         L = f"layers.{i}."
         res = x
         h = F.layer_norm(x, (d,), W(L + "self_attn_layer_norm.weight"), W(L + "self_attn_layer_norm.bias"), a.layer_norm_eps)
-        q = F.linear(h, W(L + "self_attn.q_proj.weight"), W(L + "self_attn.q_proj.bias")) * scaling
+        q = F.linear(h, W(L + "self_attn.q_proj.weight"), W(L + "self_attn.q_proj.bias"))
         k = F.linear(h, W(L + "self_attn.k_proj.weight"))
+        if lora is not None:
+            # peft LoRA (apply_lora -> get_peft_model, ultravox_model.py:690-709) on q_proj / k_proj, dropout 0.  peft
+            # (pyproject.toml:15 pins ~0.11.1) is NOT installed here: restated from its published algorithm
+            # (peft/tuners/lora/layer.py, Linear.forward) - parity of this sub-path is unpinned by reference fixtures:
+            # result = base(x) + lora_B(lora_A(x)) * (lora_alpha / r); the adapter matrices live in sd under peft's names
+            def lo(pj):
+                A = sd[f"{prefix}base_model.model.layers.{i}.self_attn.{pj}.lora_A.default.weight"].to(dt)
+                Bm = sd[f"{prefix}base_model.model.layers.{i}.self_attn.{pj}.lora_B.default.weight"].to(dt)
+                return F.linear(F.linear(h, A), Bm) * lora["scaling"]
+            q = q + lo("q_proj")
+            k = k + lo("k_proj")
+        q = q * scaling                                      # WhisperAttention: q_proj(x) * head_dim^-0.5
         v = F.linear(h, W(L + "self_attn.v_proj.weight"), W(L + "self_attn.v_proj.bias"))
         q, k, v = (t.view(B, S, H, dh).transpose(1, 2) for t in (q, k, v))
         s = q @ k.transpose(-1, -2)
@@ -318,17 +330,19 @@ class OracleModel:
         self.cfg, self.dtype = cfg, dtype
         self.sd = {k: v.detach().to("cpu", dtype).clone() for k, v in state_dict.items()}
         # apply_lora r = 0 (ultravox_model.py:697-703): towers frozen, projector trainable
-        self.trainable = [k for k in self.sd if k.startswith("multi_modal_projector.")]
+        self.trainable = [k for k in self.sd if k.startswith("multi_modal_projector.") or ".lora_" in k]
         for k in self.trainable:
             self.sd[k].requires_grad_(True)
+        r = int((getattr(cfg, "audio_model_lora_config", None) or {}).get("r", 0) or 0)
+        self.lora = None if r == 0 else {"scaling": float(cfg.audio_model_lora_config.get("lora_alpha", 8)) / r}
 
     def projector_params(self):
         P = "multi_modal_projector."
-        return {k[len(P):]: self.sd[k] for k in self.trainable}
+        return {k[len(P):]: self.sd[k] for k in self.trainable if k.startswith(P)}
 
     def audio_embeds(self, audio_values, audio_lens):
-        with torch.no_grad():
-            tower = whisper_encoder_ref(self.sd, self.cfg, audio_values.to(self.dtype), audio_lens)   # :382-385
+        with torch.set_grad_enabled(self.lora is not None and torch.is_grad_enabled()):   # frozen tower unless LoRA-adapted
+            tower = whisper_encoder_ref(self.sd, self.cfg, audio_values.to(self.dtype), audio_lens, lora=self.lora)   # :382-385
         return tower, projector_ref(self.projector_params(), self.cfg, tower.to(self.dtype))        # :386-387
 
     def forward(self, input_ids, audio_values=None, labels=None, attention_mask=None, audio_token_start_idx=None,

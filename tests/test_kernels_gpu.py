@@ -233,20 +233,25 @@ def test_attention_left_padding_and_rescale_branch():
     assert torch.isfinite(o.float()).all()
 
 
-@pytest.mark.parametrize("D,Hq,Hkv,T", [(128, 8, 2, 316), (128, 4, 4, 45), (64, 4, 2, 130)])
-def test_attention_backward(D, Hq, Hkv, T):
+@pytest.mark.parametrize("D,Hq,Hkv,T,causal,block", [(128, 8, 2, 316, True, 0), (128, 4, 4, 45, True, 0), (64, 4, 2, 130, True, 0),
+                                                     # the Whisper encoder's masks (non-causal, key padding, latency blocks)
+                                                     (64, 4, 4, 200, False, 0), (64, 2, 2, 333, False, 50), (64, 3, 3, 1500, False, 0)])
+def test_attention_backward(D, Hq, Hkv, T, causal, block):
     torch.manual_seed(7)
     B = 2
     q = bf(torch.randn(B, T, Hq, D, device=DEV))
     k = bf(torch.randn(B, T, Hkv, D, device=DEV))
     v = bf(torch.randn(B, T, Hkv, D, device=DEV))
     do = bf(torch.randn(B, T, Hq * D, device=DEV))
-    o, lse = ops().attention(q, k, v, causal=True)
-    dq, dk, dv = ops().attention_bwd(q, k, v, o, lse, do, causal=True)
+    kv_len = torch.tensor([T, max(1, T - 37)], device=DEV, dtype=torch.int32) if not causal else None
+    o, lse = ops().attention(q, k, v, causal=causal, block=block, kv_len=kv_len)
+    dq, dk, dv = ops().attention_bwd(q, k, v, o, lse, do, causal=causal, block=block, kv_len=kv_len)
     qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
-    ref, _ = sdpa_ref(qr, kr, vr, True, 0, D ** -0.5)
+    ref, _ = sdpa_ref(qr, kr, vr, causal, block, D ** -0.5, kv_len=kv_len)
     ref.backward(do.float())
     assert rel_l2(dq, qr.grad) < 2e-2 and rel_l2(dk, kr.grad) < 2e-2 and rel_l2(dv, vr.grad) < 2e-2
+    if kv_len is not None:      # padded keys receive no gradient
+        assert dk[1, int(kv_len[1]):].abs().max().item() == 0 and dv[1, int(kv_len[1]):].abs().max().item() == 0
 
 
 # ------------------------------------------------------------------ loss / optimizer / merge

@@ -1,0 +1,115 @@
+"""Encoder LoRA (audio_model_lora_config.r > 0: the reference's release recipe, ultravox_model.py:690-709 via peft 0.11.1)
+on the GPU: the new backward kernels against torch, and a whole training step (projector + LoRA gradients, one AdamW
+update) against the CPU oracle's autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_and_gelu_backward_kernels(dtype):
+    from ultravox_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rows, cols = 77, 384
+    x = (torch.randn(rows, cols, device=DEV, generator=g) * 1.5 + 0.2).to(dtype)
+    w = (1 + 0.2 * torch.randn(cols, device=DEV, generator=g)).to(dtype)
+    b = torch.randn(cols, device=DEV, generator=g).to(dtype)
+    dy = torch.randn(rows, cols, device=DEV, generator=g).to(dtype)
+    add = torch.randn(rows, cols, device=DEV, generator=g).to(dtype)
+    xr = x.float().requires_grad_(True)
+    F.layer_norm(xr, (cols,), w.float(), b.float(), 1e-5).backward(dy.float())
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel_l2(ops.layernorm_bwd(dy, x, w, 1e-5), xr.grad) < tol
+    assert rel_l2(ops.layernorm_bwd(dy, x, w, 1e-5, dx_add=add), xr.grad + add.float()) < tol
+    pre = (torch.randn(rows, 512, device=DEV, generator=g) * 2).to(dtype)
+    d = torch.randn(rows, 512, device=DEV, generator=g).to(dtype)
+    pr = pre.float().requires_grad_(True)
+    y = F.gelu(pr)
+    y.backward(d.float())
+    assert rel_l2(ops.gelu(pre), y) < (1e-6 if dtype == torch.float32 else 4e-3)
+    assert rel_l2(ops.gelu_bwd(d, pre), pr.grad) < (1e-5 if dtype == torch.float32 else 4e-3)
+
+
+def _setup(dtype, r=4, seed=31):
+    from oracle.reference_cpu import OracleModel, synthetic_batch
+    from test_model_gpu import SMALL
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    cfg = UltravoxConfig(**SMALL, audio_model_lora_config={"r": r, "lora_alpha": 8})
+    sd = random_state_dict(cfg, seed=seed, dtype=dtype)
+    sd.update(init_lora_state_dict(cfg, seed=seed, dtype=dtype, random_b=True))    # non-zero B: A gets a gradient too
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    b = synthetic_batch(cfg, 2, 3.0, n_text=24, audio_start=5, n_supervised=8)
+    b["audio_lens"] = torch.tensor([300, 230])                                    # key-padding mask on the second clip
+    pcm = b.pop("pcm")
+    mel = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins).logmel_device(pcm.to(DEV))
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    ob = {**b, "audio_values": mel.cpu().to(dtype).float()}
+    return cfg, sd, model, oracle, gb, ob, mel.to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lora_train_step_matches_oracle(dtype):
+    cfg, sd, model, oracle, gb, ob, mel = _setup(dtype)
+    assert len(oracle.trainable) == 4 + 2 * 2 * cfg.audio_config.encoder_layers
+    ref, grads, _ = oracle.train_step(ob)
+    out = model.forward(audio_values=mel, **gb)                      # the LoRA terms are part of the forward pass
+    if dtype == torch.float32:
+        assert (out.logits.cpu() - ref["logits"]).abs().max().item() < 1e-3
+    else:
+        assert rel_l2(out.logits, ref["logits"]) < 3e-2
+    model.train()
+    loss = model.forward_backward(audio_values=mel, **gb)
+    assert abs(loss.item() - ref["loss"].item()) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(ref["loss"].item())
+    mine = model.projector_grads()
+    assert set(mine) == set(grads)
+    tol = 2e-3 if dtype == torch.float32 else 8e-2
+    for k, g in grads.items():
+        assert g.abs().max().item() > 0, k
+        assert rel_l2(mine[k], g) < tol, k
+
+
+def test_lora_trainer_step_and_checkpoint_keys(tmp_path):
+    from ultravox_amd.model import UltravoxTrainer
+    cfg, sd, model, oracle, gb, ob, mel = _setup(torch.float32)
+    params = [oracle.sd[k] for k in oracle.trainable]
+    opt = torch.optim.AdamW(params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    _, _, gn = oracle.train_step(ob, opt)
+    trainer = UltravoxTrainer(model, lr=2e-3)
+    trainer.train_step(audio_values=mel, **gb)
+    assert abs(trainer.grad_norm().item() - gn.item()) < 3e-3 * gn.item()
+    new = model.projector_state_dict()
+    for k in oracle.trainable:
+        delta_ref = oracle.sd[k].detach() - sd[k].float()
+        assert rel_l2(new[k].float().cpu() - sd[k].float(), delta_ref) < 2e-2, k
+    # the diff state dict carries the adapter under peft's names (what the reference's save_pretrained writes)
+    model.save_pretrained(str(tmp_path))
+    from ultravox_amd import checkpoint
+    _, ck = checkpoint.load_pretrained(str(tmp_path))
+    assert "audio_tower.base_model.model.layers.0.self_attn.q_proj.lora_A.default.weight" in ck
+    assert sum(".lora_" in k for k in ck) == 4 * cfg.audio_config.encoder_layers
+
+
+def test_lora_with_zero_b_equals_frozen_tower():
+    """peft initialises lora_B to zero: the adapted tower must reproduce the frozen one bit for bit."""
+    from test_model_gpu import SMALL
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    sd = random_state_dict(UltravoxConfig(**SMALL), seed=4, dtype=torch.bfloat16)
+    m0 = UltravoxModel(UltravoxConfig(**SMALL), state_dict=sd, device=DEV)
+    m1 = UltravoxModel(UltravoxConfig(**SMALL, audio_model_lora_config={"r": 8}), state_dict=sd, device=DEV)
+    mel = torch.randn(2, 80, 200, device=DEV).bfloat16()
+    lens = torch.tensor([200, 150], device=DEV)
+    assert torch.equal(m0.audio_tower_forward(mel, lens), m1.audio_tower_forward(mel, lens))

@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 2   # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+ABI_VERSION = 3   # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
 
 
 def lib() -> C.CDLL:
@@ -95,7 +95,8 @@ class Config(C.Structure):
     ]
 
 
-_ENC_LAYER_FIELDS = ["ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
+_ENC_LAYER_FIELDS = ["ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                     "wqkv_t", "wo_t", "fc1_t", "fc2_t"]
 
 
 class EncLayer(C.Structure):
@@ -105,6 +106,22 @@ class EncLayer(C.Structure):
 class EncoderWeights(C.Structure):
     _fields_ = [("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
                 ("pos", C.c_void_p), ("layers", C.POINTER(EncLayer)), ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p)]
+
+
+class LoraProj(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p)]
+
+
+class EncLoraLayer(C.Structure):
+    _fields_ = [("q", LoraProj), ("k", LoraProj)]
+
+
+class EncoderLora(C.Structure):
+    _fields_ = [("r", C.c_int32), ("scaling", C.c_float), ("layers", C.POINTER(EncLoraLayer))]
+
+
+class EncoderLoraGrads(C.Structure):   # uvx_lora_proj_grad_t has the layout of uvx_lora_proj_t (two pointers)
+    _fields_ = [("layers", C.POINTER(EncLoraLayer))]
 
 
 class ProjectorWeights(C.Structure):
@@ -145,12 +162,13 @@ EXPORTS = [
     "uvx_rmsnorm", "uvx_rmsnorm_bwd", "uvx_swiglu", "uvx_swiglu_bwd", "uvx_rope", "uvx_attention_ws_bytes",
     "uvx_attention_fwd", "uvx_attention_bwd", "uvx_ce_loss", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records", "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes",
     "uvx_llm_prefill", "uvx_llm_decode", "uvx_argmax", "uvx_llm_kl_loss", "uvx_kl_loss", "uvx_gemm_override_variant", "uvx_gemm_pick_variant", "uvx_set_option",
+    "uvx_encoder_train_ws_bytes", "uvx_encoder_fwd_train", "uvx_encoder_bwd", "uvx_layernorm_bwd", "uvx_gelu", "uvx_gelu_bwd",
 ]
 
 
 def _declare(l: C.CDLL) -> None:
     for name in ("uvx_encoder_ws_bytes", "uvx_projector_ws_bytes", "uvx_llm_ws_bytes", "uvx_attention_ws_bytes",
-                 "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes"):
+                 "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes", "uvx_encoder_train_ws_bytes"):
         getattr(l, name).restype = C.c_size_t
     for name in EXPORTS:
         f = getattr(l, name)

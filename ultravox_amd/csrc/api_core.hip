@@ -85,6 +85,16 @@ extern "C" int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, 
                                float* scratch) {
   return uvx::ce_loss_fwd_bwd((hipStream_t)stream, dtype, logits, labels, loss, scratch, dlogits, B, T, V, ld, grad_scale);
 }
+extern "C" int32_t uvx_layernorm_bwd(void* stream, int32_t dtype, const void* dy, const void* x, const void* w, const void* dx_add,
+                                     void* dx, int32_t rows, int32_t cols, float eps) {
+  return uvx::layernorm_bwd((hipStream_t)stream, dtype, dy, x, w, dx_add, dx, rows, cols, eps);
+}
+extern "C" int32_t uvx_gelu(void* stream, int32_t dtype, const void* pre, void* out, int64_t n) {
+  return uvx::gelu_fwd((hipStream_t)stream, dtype, pre, out, n);
+}
+extern "C" int32_t uvx_gelu_bwd(void* stream, int32_t dtype, const void* dout, const void* pre, void* din, int64_t n) {
+  return uvx::gelu_bwd((hipStream_t)stream, dtype, dout, pre, din, n);
+}
 extern "C" int32_t uvx_kl_loss(void* stream, int32_t dtype, const void* student_logits, const void* teacher_logits,
                                const int32_t* pair_row, const float* pair_w, float* loss, void* dlogits, int64_t rows,
                                int32_t V, int32_t ld_student, int32_t ld_teacher, float temperature, float grad_scale,

@@ -97,6 +97,15 @@ int im2col_conv1(hipStream_t st, int dtype, const void* mel, int mel_is_f32, voi
 int add_rows(hipStream_t st, int dtype, const void* a, const void* b, void* out, long long n);
 int cast_f32_to(hipStream_t st, int dtype, const float* in, void* out, long long n);
 int fill_zero(hipStream_t st, void* p, long long bytes);
+// encoder LoRA training: GELU as a separate pass on the stashed pre-activation, its exact-derivative backward,
+// LayerNorm backward for a frozen affine (dx only, + optional residual), LoRA operand packing, strided f32 copy
+int gelu_fwd(hipStream_t st, int dtype, const void* pre, void* out, long long n);
+int gelu_bwd(hipStream_t st, int dtype, const void* dout, const void* pre, void* din, long long n);
+int layernorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w, const void* dx_add, void* dx,
+                  int rows, int cols, float eps);
+int lora_pack(hipStream_t st, int dtype, const void* A, const void* B, void* a_pad, void* b_pad, void* a_t, int ld_at,
+              void* b_t, int r, int d);
+int copy2d_f32(hipStream_t st, const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst);
 
 // ---- attention.hip ----
 struct AttnDesc {

@@ -61,13 +61,39 @@ __global__ void full_range_k(int32_t* __restrict__ kv_start, int32_t* __restrict
 }
 
 // ------------------------------------------------------------------ encoder
+// per-layer stash of the LoRA-training forward (uvx_encoder_fwd_train -> uvx_encoder_bwd)
+struct EncLayerStash {
+  void *x_in, *qkv, *o, *x_mid, *pre, *t;   // t = n . [A_q | A_k]^T (the LoRA down-projections), [M, 128]
+  float* lse;
+  void *a_qk, *bq, *bk, *a_t_qk, *bq_t, *bk_t;   // packed LoRA operands of this layer (lora_pack)
+};
 struct EncWs {
   void *im2col, *c1, *x, *n, *qkv, *vt, *o, *f;
   int32_t* kvlen;
   int Te, Tp, M, Kp1;
+  // training only
+  char* slots; size_t slot_bytes; EncLayerStash ls0;
+  void *dx, *d_n, *d_o, *d_f, *d_qkv, *qT, *kT, *doT, *u, *uT, *tT, *nT, *dqkT;
+  float *delta, *gA, *gB;
+  int Mp;
 };
-EncWs enc_carve(Arena& a, const uvx_config_t& c, int B, int F) {
-  EncWs w;
+void enc_slot(Arena& a, const uvx_config_t& c, int B, int Te, EncLayerStash& s) {
+  const size_t es = esz(c.dtype), M = (size_t)B * Te, d = c.enc_d;
+  s.x_in = a.take(M * d * es); s.qkv = a.take(M * 3 * d * es); s.o = a.take(M * d * es); s.x_mid = a.take(M * d * es);
+  s.pre = a.take(M * c.enc_ffn * es); s.t = a.take(M * 128 * es);
+  s.lse = (float*)a.take(sizeof(float) * (size_t)B * c.enc_heads * Te);
+  s.a_qk = a.take(128 * d * es); s.bq = a.take(d * 64 * es); s.bk = a.take(d * 64 * es);
+  s.a_t_qk = a.take(d * 128 * es); s.bq_t = a.take(64 * d * es); s.bk_t = a.take(64 * d * es);
+}
+EncLayerStash enc_layer(const EncWs& w, int l) {
+  EncLayerStash s = w.ls0;
+  const size_t off = w.slot_bytes * l;
+  void** ps[] = {&s.x_in, &s.qkv, &s.o, &s.x_mid, &s.pre, &s.t, (void**)&s.lse, &s.a_qk, &s.bq, &s.bk, &s.a_t_qk, &s.bq_t, &s.bk_t};
+  for (void** q : ps) if (*q) *q = (char*)*q + off;
+  return s;
+}
+EncWs enc_carve(Arena& a, const uvx_config_t& c, int B, int F, bool train = false) {
+  EncWs w = {};
   const size_t es = esz(c.dtype);
   w.Te = (F - 1) / 2 + 1;
   w.Tp = rup(w.Te, 64);
@@ -83,6 +109,25 @@ EncWs enc_carve(Arena& a, const uvx_config_t& c, int B, int F) {
   w.o = a.take((size_t)w.M * c.enc_d * es);
   w.f = a.take((size_t)w.M * c.enc_ffn * es);
   w.kvlen = (int32_t*)a.take(sizeof(int32_t) * B);
+  if (train) {
+    const size_t M = (size_t)w.M, d = c.enc_d;
+    w.Mp = rup(w.M, 64);
+    const size_t start = (a.off + 255) & ~(size_t)255;
+    a.off = start;
+    enc_slot(a, c, B, w.Te, w.ls0);
+    a.off = (a.off + 255) & ~(size_t)255;
+    w.slot_bytes = a.off - start;
+    w.slots = a.base ? a.base + start : nullptr;
+    a.off = start + w.slot_bytes * c.enc_layers;
+    w.dx = a.take(M * d * es); w.d_n = a.take(M * d * es); w.d_o = a.take(M * d * es);
+    w.d_f = a.take(M * c.enc_ffn * es); w.d_qkv = a.take(M * 3 * d * es);
+    const size_t ht = (size_t)B * c.enc_heads * dh * w.Tp * es;
+    w.qT = a.take(ht); w.kT = a.take(ht); w.doT = a.take(ht);
+    w.u = a.take(M * 128 * es); w.uT = a.take((size_t)128 * w.Mp * es); w.tT = a.take((size_t)128 * w.Mp * es);
+    w.nT = a.take(d * (size_t)w.Mp * es); w.dqkT = a.take(2 * d * (size_t)w.Mp * es);
+    w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.enc_heads * w.Te);
+    w.gA = (float*)a.take(sizeof(float) * 128 * d); w.gB = (float*)a.take(sizeof(float) * 2 * d * 64);
+  }
   return w;
 }
 
@@ -232,22 +277,20 @@ extern "C" size_t uvx_encoder_ws_bytes(const uvx_config_t* cfg, int32_t B, int32
   return a.off + 256;
 }
 
-extern "C" int32_t uvx_encoder_fwd(void* stream, const uvx_config_t* cfg, const uvx_encoder_weights_t* w, const void* mel,
-                                   int32_t mel_is_f32, const int64_t* audio_lens, int32_t B, int32_t F, void* out,
-                                   void* workspace, size_t ws_bytes) {
-  RC(check_cfg(cfg));
-  UVX_CHECK(w && mel && out && workspace, UVX_ERR_INVALID, "encoder_fwd: null argument");
-  const uvx_config_t& c = *cfg;
-  hipStream_t st = (hipStream_t)stream;
+static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_weights_t* w, const uvx_encoder_lora_t* lora,
+                       const void* mel, int mel_is_f32, const int64_t* audio_lens, int B, int F, void* out, void* workspace,
+                       size_t ws_bytes) {
+  const bool train = lora != nullptr;
   // ultravox_model.py:874-878: the mel length may not exceed max_source_positions * conv strides
   UVX_CHECK(F <= c.enc_max_pos * 2, UVX_ERR_SHAPE,
             "Whisper expects the mel input features to be of length %d or less, but found %d", c.enc_max_pos * 2, F);
   UVX_CHECK(c.enc_d % c.enc_heads == 0, UVX_ERR_SHAPE, "encoder: d=%d not divisible by heads=%d", c.enc_d, c.enc_heads);
   UVX_CHECK(c.enc_block == 0 || (c.enc_max_pos * 2) % c.enc_block == 0, UVX_ERR_SHAPE,
             "audio_latency_block_size %d must divide %d evenly.", c.enc_block, c.enc_max_pos * 2);
+  UVX_CHECK(!train || (lora->r > 0 && lora->r <= 64 && lora->layers), UVX_ERR_INVALID, "encoder LoRA: rank must be in 1..64");
   if (B == 0 || F == 0) return UVX_OK;
   Arena a(workspace, ws_bytes);
-  EncWs s = enc_carve(a, c, B, F);
+  EncWs s = enc_carve(a, c, B, F, train);
   UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "encoder_fwd: workspace %zu < %zu bytes", ws_bytes, a.off);
   const int dt = c.dtype, d = c.enc_d, Te = s.Te, M = s.M, dh = d / c.enc_heads;
   const size_t es = esz(dt);
@@ -263,8 +306,9 @@ extern "C" int32_t uvx_encoder_fwd(void* stream, const uvx_config_t* cfg, const 
     g.sA = (long long)F * s.Kp1; g.sC = (long long)(F + 2) * d;
     RC(gemm(st, dt, g));
   }
+  void* x = train ? enc_layer(s, 0).x_in : s.x;   // the running hidden state (training: lives in the layer stashes)
   {  // conv2 + GELU (:894), permute (:896), + embed_positions[:Te] (:897-899)
-    GemmDesc g = lin(s.c1, w->conv2_w, s.x, Te, d, 3 * d);
+    GemmDesc g = lin(s.c1, w->conv2_w, x, Te, d, 3 * d);
     g.lda = 2 * d; g.bias = w->conv2_b; g.act = 1; g.batch = B;
     g.sA = (long long)(F + 2) * d; g.sC = (long long)Te * d;
     g.residual = w->pos; g.ldr = d; g.sR = 0;
@@ -277,39 +321,180 @@ extern "C" int32_t uvx_encoder_fwd(void* stream, const uvx_config_t* cfg, const 
     UVX_LAUNCH_CHECK();
     kvlen = s.kvlen;
   }
+  const float qscale = 1.0f / sqrtf((float)dh);
   for (int l = 0; l < c.enc_layers; ++l) {
     const uvx_enc_layer_t& L = w->layers[l];
-    RC(layernorm_fwd(st, dt, s.x, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));
+    EncLayerStash S = train ? enc_layer(s, l) : EncLayerStash{};
+    void* qkv = train ? S.qkv : s.qkv;
+    void* o = train ? S.o : s.o;
+    void* x_mid = train ? S.x_mid : x;            // inference: the residual stream is updated in place
+    void* x_out = !train ? x : (l + 1 < c.enc_layers ? enc_layer(s, l + 1).x_in : s.x);
+    RC(layernorm_fwd(st, dt, x, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));
     {
-      GemmDesc g = lin(s.n, L.wqkv, s.qkv, M, 3 * d, d);
+      GemmDesc g = lin(s.n, L.wqkv, qkv, M, 3 * d, d);
       g.bias = L.bqkv;
       RC(gemm(st, dt, g));
     }
-    RC(heads_transpose(st, dt, at(s.qkv, 2 * d, dt), s.vt, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
+    if (train) {
+      // peft LoRA on q_proj / k_proj: result += lora_B(lora_A(x)) * scaling (and q carries Whisper's head_dim^-0.5,
+      // folded into wqkv at pack time).  A_q | A_k share one rank-padded GEMM; K = 64 (zero padded rank) for the B side.
+      const uvx_enc_lora_layer_t& R = lora->layers[l];
+      RC(lora_pack(st, dt, R.q.a, R.q.b, S.a_qk, S.bq, S.a_t_qk, 128, S.bq_t, lora->r, d));
+      RC(lora_pack(st, dt, R.k.a, R.k.b, at(S.a_qk, (size_t)64 * d, dt), S.bk, at(S.a_t_qk, 64, dt), 128, S.bk_t, lora->r, d));
+      RC(gemm(st, dt, lin(s.n, S.a_qk, S.t, M, 128, d)));
+      {
+        GemmDesc g = lin(S.t, S.bq, qkv, M, d, 64);
+        g.lda = 128; g.ldc = 3 * d; g.residual = qkv; g.ldr = 3 * d; g.alpha = lora->scaling * qscale;
+        RC(gemm(st, dt, g));
+      }
+      {
+        GemmDesc g = lin(at(S.t, 64, dt), S.bk, at(qkv, d, dt), M, d, 64);
+        g.lda = 128; g.ldc = 3 * d; g.residual = at(qkv, d, dt); g.ldr = 3 * d; g.alpha = lora->scaling;
+        RC(gemm(st, dt, g));
+      }
+    }
+    RC(heads_transpose(st, dt, at(qkv, 2 * d, dt), s.vt, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
     AttnDesc ad;
-    ad.q = s.qkv; ad.k = at(s.qkv, d, dt); ad.v = at(s.qkv, 2 * d, dt); ad.vt = s.vt; ad.o = s.o; ad.lse = nullptr;
+    ad.q = qkv; ad.k = at(qkv, d, dt); ad.v = at(qkv, 2 * d, dt); ad.vt = s.vt; ad.o = o; ad.lse = train ? S.lse : nullptr;
     ad.kv_len = kvlen; ad.B = B; ad.T = Te; ad.Tp = s.Tp; ad.Hq = c.enc_heads; ad.Hkv = c.enc_heads; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = 3 * d; ad.ldo = d; ad.causal = 0; ad.block = c.enc_block;
     ad.scale = 1.0f;  // q_proj is pre-scaled by head_dim^-0.5 at pack time (exact in bf16 for dh = 64)
     RC(attention_fwd(st, dt, ad));
     {
-      GemmDesc g = lin(s.o, L.wo, s.x, M, d, d);
-      g.bias = L.bo; g.residual = s.x; g.ldr = d;
+      GemmDesc g = lin(o, L.wo, x_mid, M, d, d);
+      g.bias = L.bo; g.residual = x; g.ldr = d;
       RC(gemm(st, dt, g));
     }
-    RC(layernorm_fwd(st, dt, s.x, L.ln2_w, L.ln2_b, s.n, M, d, c.ln_eps));
-    {
+    RC(layernorm_fwd(st, dt, x_mid, L.ln2_w, L.ln2_b, s.n, M, d, c.ln_eps));
+    if (train) {   // keep the fc1 pre-activation for the GELU backward
+      GemmDesc g = lin(s.n, L.fc1_w, S.pre, M, c.enc_ffn, d);
+      g.bias = L.fc1_b;
+      RC(gemm(st, dt, g));
+      RC(gelu_fwd(st, dt, S.pre, s.f, (long long)M * c.enc_ffn));
+    } else {
       GemmDesc g = lin(s.n, L.fc1_w, s.f, M, c.enc_ffn, d);
       g.bias = L.fc1_b; g.act = 1;
       RC(gemm(st, dt, g));
     }
     {
-      GemmDesc g = lin(s.f, L.fc2_w, s.x, M, d, c.enc_ffn);
-      g.bias = L.fc2_b; g.residual = s.x; g.ldr = d;
+      GemmDesc g = lin(s.f, L.fc2_w, x_out, M, d, c.enc_ffn);
+      g.bias = L.fc2_b; g.residual = x_mid; g.ldr = d;
       RC(gemm(st, dt, g));
     }
+    x = x_out;
   }
-  RC(layernorm_fwd(st, dt, s.x, w->lnf_w, w->lnf_b, out, M, d, c.ln_eps));  // :980
+  RC(layernorm_fwd(st, dt, x, w->lnf_w, w->lnf_b, out, M, d, c.ln_eps));  // :980
+  return UVX_OK;
+}
+
+extern "C" int32_t uvx_encoder_fwd(void* stream, const uvx_config_t* cfg, const uvx_encoder_weights_t* w, const void* mel,
+                                   int32_t mel_is_f32, const int64_t* audio_lens, int32_t B, int32_t F, void* out,
+                                   void* workspace, size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(w && mel && out && workspace, UVX_ERR_INVALID, "encoder_fwd: null argument");
+  return enc_forward((hipStream_t)stream, *cfg, w, nullptr, mel, mel_is_f32, audio_lens, B, F, out, workspace, ws_bytes);
+}
+
+extern "C" size_t uvx_encoder_train_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t F) {
+  if (!cfg) return 0;
+  Arena a(nullptr, 0);
+  enc_carve(a, *cfg, B, F, true);
+  return a.off + 256;
+}
+
+extern "C" int32_t uvx_encoder_fwd_train(void* stream, const uvx_config_t* cfg, const uvx_encoder_weights_t* w,
+                                         const uvx_encoder_lora_t* lora, const void* mel, int32_t mel_is_f32,
+                                         const int64_t* audio_lens, int32_t B, int32_t F, void* out, void* workspace,
+                                         size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(w && lora && mel && out && workspace, UVX_ERR_INVALID, "encoder_fwd_train: null argument");
+  return enc_forward((hipStream_t)stream, *cfg, w, lora, mel, mel_is_f32, audio_lens, B, F, out, workspace, ws_bytes);
+}
+
+// Backward of the LoRA-adapted encoder: d out [B, Te, d] -> gradients of lora_A / lora_B of q_proj and k_proj in every
+// layer (everything else is frozen: apply_lora, ultravox_model.py:690-709).  Walks the stash of uvx_encoder_fwd_train.
+extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const uvx_encoder_weights_t* w,
+                                   const uvx_encoder_lora_t* lora, const void* d_out, const int64_t* audio_lens, int32_t B,
+                                   int32_t F, const uvx_encoder_lora_grads_t* grads, void* workspace, size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(w && lora && d_out && grads && grads->layers && workspace, UVX_ERR_INVALID, "encoder_bwd: null argument");
+  const uvx_config_t& c = *cfg;
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || F == 0) return UVX_OK;
+  Arena a(workspace, ws_bytes);
+  EncWs s = enc_carve(a, c, B, F, true);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "encoder_bwd: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype, d = c.enc_d, Te = s.Te, M = s.M, Mp = s.Mp, dh = d / c.enc_heads, r = lora->r;
+  const float qscale = 1.0f / sqrtf((float)dh);
+  // ln_post backward: out = LN(x_final); x_final is the running state after the last layer (s.x)
+  RC(layernorm_bwd(st, dt, d_out, s.x, w->lnf_w, nullptr, s.dx, M, d, c.ln_eps));
+  for (int l = c.enc_layers - 1; l >= 0; --l) {
+    const uvx_enc_layer_t& L = w->layers[l];
+    UVX_CHECK(L.wqkv_t && L.wo_t && L.fc1_t && L.fc2_t, UVX_ERR_INVALID, "encoder_bwd: layer %d lacks transposed weights", l);
+    EncLayerStash S = enc_layer(s, l);
+    // ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ----
+    RC(gemm(st, dt, lin(s.dx, L.fc2_t, s.d_f, M, c.enc_ffn, d)));
+    RC(gelu_bwd(st, dt, s.d_f, S.pre, s.d_f, (long long)M * c.enc_ffn));
+    RC(gemm(st, dt, lin(s.d_f, L.fc1_t, s.d_n, M, d, c.enc_ffn)));
+    RC(layernorm_bwd(st, dt, s.d_n, S.x_mid, L.ln2_w, s.dx, s.dx, M, d, c.ln_eps));
+    // ---- attention: x_mid = x_in + wo(attn(q, k, v)) ----
+    RC(gemm(st, dt, lin(s.dx, L.wo_t, s.d_o, M, d, d)));
+    RC(heads_transpose(st, dt, S.qkv, s.qT, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
+    RC(heads_transpose(st, dt, at(S.qkv, d, dt), s.kT, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
+    RC(heads_transpose(st, dt, s.d_o, s.doT, B, Te, s.Tp, c.enc_heads, dh, d));
+    AttnBwdDesc bd;
+    AttnDesc& ad = bd.f;
+    ad.q = S.qkv; ad.k = at(S.qkv, d, dt); ad.v = at(S.qkv, 2 * d, dt); ad.o = S.o; ad.lse = S.lse;
+    ad.kv_len = audio_lens ? s.kvlen : nullptr;          // written by the forward pass (same audio_lens)
+    ad.B = B; ad.T = Te; ad.Tp = s.Tp; ad.Hq = c.enc_heads; ad.Hkv = c.enc_heads; ad.D = dh;
+    ad.ldq = ad.ldk = ad.ldv = 3 * d; ad.ldo = d; ad.causal = 0; ad.block = c.enc_block; ad.scale = 1.0f;
+    bd.dout = s.d_o; bd.qt = s.qT; bd.kt = s.kT; bd.dot = s.doT; bd.delta = s.delta; bd.dkv_part = nullptr;
+    bd.dq = s.d_qkv; bd.dk = at(s.d_qkv, d, dt); bd.dv = at(s.d_qkv, 2 * d, dt);
+    bd.lddq = bd.lddk = bd.lddv = 3 * d;
+    RC(attention_bwd(st, dt, bd));
+    // ---- LoRA gradients of q_proj / k_proj ----
+    // u = [dq . B_q * (scaling * qscale) | dk . B_k * scaling]  [M, 128]
+    {
+      GemmDesc g = lin(s.d_qkv, S.bq_t, s.u, M, 64, d);
+      g.lda = 3 * d; g.ldc = 128; g.alpha = lora->scaling * qscale;
+      RC(gemm(st, dt, g));
+      GemmDesc h = lin(at(s.d_qkv, d, dt), S.bk_t, at(s.u, 64, dt), M, 64, d);
+      h.lda = 3 * d; h.ldc = 128; h.alpha = lora->scaling;
+      RC(gemm(st, dt, h));
+    }
+    RC(layernorm_fwd(st, dt, S.x_in, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));      // n1 recomputed (not stashed)
+    RC(transpose2d(st, dt, s.u, s.uT, M, 128, 128, Mp, 1, 0, 0));
+    RC(transpose2d(st, dt, s.n, s.nT, M, d, d, Mp, 1, 0, 0));
+    RC(transpose2d(st, dt, S.t, s.tT, M, 128, 128, Mp, 1, 0, 0));
+    RC(transpose2d(st, dt, s.d_qkv, s.dqkT, M, 2 * d, 3 * d, Mp, 1, 0, 0));
+    {  // d lora_A = u^T . n  -> [128, d] (rows 0..r-1: A_q, rows 64..64+r-1: A_k)
+      GemmDesc g = lin(s.uT, s.nT, s.gA, 128, d, Mp);
+      g.out_f32 = 1;
+      RC(gemm(st, dt, g));
+    }
+    {  // d lora_B = scale * dq^T . t  -> [d, 64] each (columns 0..r-1)
+      GemmDesc g = lin(s.dqkT, s.tT, s.gB, d, 64, Mp);
+      g.out_f32 = 1; g.alpha = lora->scaling * qscale;
+      RC(gemm(st, dt, g));
+      GemmDesc h = lin(at(s.dqkT, (size_t)d * Mp, dt), at(s.tT, (size_t)64 * Mp, dt), s.gB + (size_t)d * 64, d, 64, Mp);
+      h.out_f32 = 1; h.alpha = lora->scaling;
+      RC(gemm(st, dt, h));
+    }
+    const uvx_enc_lora_layer_grads_t& G = grads->layers[l];
+    RC(copy2d_f32(st, s.gA, G.q.a, r, d, d, d));
+    RC(copy2d_f32(st, s.gA + (size_t)64 * d, G.k.a, r, d, d, d));
+    RC(copy2d_f32(st, s.gB, G.q.b, d, r, 64, r));
+    RC(copy2d_f32(st, s.gB + (size_t)d * 64, G.k.b, d, r, 64, r));
+    if (l == 0) break;   // nothing trainable below layer 0
+    // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k], then LN1 backward into the residual stream ----
+    RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d)));
+    {
+      GemmDesc g = lin(s.u, S.a_t_qk, s.d_n, M, d, 128);
+      g.residual = s.d_n; g.ldr = d;
+      RC(gemm(st, dt, g));
+    }
+    RC(layernorm_bwd(st, dt, s.d_n, S.x_in, L.ln1_w, s.dx, s.dx, M, d, c.ln_eps));
+  }
   return UVX_OK;
 }
 
@@ -352,7 +537,7 @@ extern "C" int32_t uvx_projector_fwd(void* stream, const uvx_config_t* cfg, cons
 
 extern "C" int32_t uvx_projector_bwd(void* stream, const uvx_config_t* cfg, const uvx_projector_weights_t* w,
                                      const void* dout, int32_t B, int32_t Te, const uvx_projector_grads_t* gr,
-                                     void* workspace, size_t ws_bytes) {
+                                     void* d_enc_out, void* workspace, size_t ws_bytes) {
   RC(check_cfg(cfg));
   UVX_CHECK(w && dout && gr && workspace, UVX_ERR_INVALID, "projector_bwd: null argument");
   const uvx_config_t& c = *cfg;
@@ -393,7 +578,16 @@ extern "C" int32_t uvx_projector_bwd(void* stream, const uvx_config_t* cfg, cons
   }
   RC(transpose2d(st, dt, w->w1, s.w1T, s.H, s.C8, s.C8, s.H, 1, 0, 0));
   RC(gemm(st, dt, lin(s.d_h1, s.w1T, s.d_xn, s.R, s.C8, s.H)));
-  RC(rmsnorm_bwd(st, dt, s.d_xn, s.stacked, w->ln_pre, nullptr, nullptr, gr->ln_pre, s.R, s.C8, c.proj_eps));
+  if (!d_enc_out) {
+    RC(rmsnorm_bwd(st, dt, s.d_xn, s.stacked, w->ln_pre, nullptr, nullptr, gr->ln_pre, s.R, s.C8, c.proj_eps));
+    return UVX_OK;
+  }
+  // the encoder trains too (LoRA): d stacked [R, S*C] in place of d_xn, then un-stack: clip b's frames are the first
+  // Te * C elements of its J * S * C block (the padded tail frames get no gradient consumer)
+  RC(rmsnorm_bwd(st, dt, s.d_xn, s.stacked, w->ln_pre, nullptr, s.d_xn, gr->ln_pre, s.R, s.C8, c.proj_eps));
+  const size_t es = esz(dt);
+  UVX_HIP(hipMemcpy2DAsync(d_enc_out, (size_t)Te * c.enc_d * es, s.d_xn, (size_t)s.J * s.C8 * es, (size_t)Te * c.enc_d * es, B,
+                           hipMemcpyDeviceToDevice, st));
   return UVX_OK;
 }
 

@@ -142,6 +142,60 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_wave_k(const bf16_t* __restri
   }
 }
 
+// LayerNorm backward for a FROZEN affine (Whisper encoder under LoRA: only the input gradient is needed):
+//   g = dy * w,  x_hat = (x - mean) * rstd,  dx = rstd * (g - mean(g) - x_hat * mean(g * x_hat)) [+ dx_add]
+// mean / rstd are recomputed exactly as the forward kernel does (two passes), one block per row.
+template <typename T>
+__global__ void layernorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
+                                const T* __restrict__ dx_add, T* __restrict__ dx, int cols, float eps) {
+  __shared__ float red[16];
+  __shared__ float red2[16];
+  const long long row = blockIdx.x;
+  const T* xr = x + row * cols;
+  const T* gr = dy + row * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) {
+    float v[8];
+    ld8<T>(xr + c, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+  }
+  const float mean = block_sum(s, red) / cols;
+  float q = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) {
+    float v[8];
+    ld8<T>(xr + c, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; q += d * d; }
+  }
+  const float rstd = rsqrtf(block_sum(q, red) / cols + eps);
+  float a = 0.f, b = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) {
+    float v[8], g[8], wv[8];
+    ld8<T>(xr + c, v);
+    ld8<T>(gr + c, g);
+    ld8<T>(w + c, wv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float gw = g[i] * wv[i]; a += gw; b += gw * (v[i] - mean) * rstd; }
+  }
+  a = block_sum(a, red) / cols;
+  b = block_sum(b, red2) / cols;
+  for (int c = threadIdx.x * 8; c < cols; c += blockDim.x * 8) {
+    float v[8], g[8], wv[8], o[8];
+    ld8<T>(xr + c, v);
+    ld8<T>(gr + c, g);
+    ld8<T>(w + c, wv);
+    if (dx_add) ld8<T>(dx_add + row * cols + c, o);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] += rstd * (g[i] * wv[i] - a - (v[i] - mean) * rstd * b);
+    st8<T>(dx + row * cols + c, o);
+  }
+}
+
 // Row addressing shared by the plain and the frame-stacking RMSNorm: a logical row of `cols`
 // elements starts at `base` and only the first `valid` elements exist (the rest read as zero).
 struct RowMap {
@@ -295,6 +349,21 @@ int layernorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, const
   else
     hipLaunchKernelGGL(layernorm_fwd_k<float>, dim3(rows), dim3(th), 0, st, (const float*)x, (const float*)w,
                        (const float*)b, (float*)y, cols, eps);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int layernorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w, const void* dx_add, void* dx,
+                  int rows, int cols, float eps) {
+  UVX_CHECK(cols % 8 == 0, UVX_ERR_SHAPE, "layernorm_bwd: cols=%d must be a multiple of 8", cols);
+  if (rows == 0) return UVX_OK;
+  const int th = norm_threads(cols);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(layernorm_bwd_k<bf16_t>, dim3(rows), dim3(th), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)w, (const bf16_t*)dx_add, (bf16_t*)dx, cols, eps);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_k<float>, dim3(rows), dim3(th), 0, st, (const float*)dy, (const float*)x,
+                       (const float*)w, (const float*)dx_add, (float*)dx, cols, eps);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

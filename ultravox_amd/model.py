@@ -19,7 +19,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .config import LossConfig, LossFunction, UltravoxConfig
-from .weights import pack_encoder, pack_llm, random_state_dict
+from .weights import LORA_TARGETS, init_lora_state_dict, lora_key, pack_encoder, pack_llm, random_state_dict
 
 
 @dataclasses.dataclass
@@ -115,25 +115,55 @@ class UltravoxModel:
     def _load(self, sd, rope_len):
         cfg, dev, dt = self.config, self.device, self.dtype
         a, t = cfg.audio_config, cfg.text_config
-        self._enc = pack_encoder(sd, cfg, dt, dev)
+        self.lora_r = int(cfg.audio_model_lora_config.get("r", 0) or 0)      # encoder LoRA rank (0: frozen tower)
+        self._enc = pack_encoder(sd, cfg, dt, dev, with_transposes=self.lora_r > 0 and self.with_backward)
         self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=self.with_backward, rope_len=rope_len)
         # projector: one flat trainable bucket with views (ln_pre | linear_1 | ln_mid/ln_post | linear_2)
         P = "multi_modal_projector."
         norm_key = "ln_mid" if cfg.projector_ln_mid else "ln_post"
         parts = [sd[P + "ln_pre.weight"], sd[P + "linear_1.weight"], sd[P + norm_key + ".weight"],
                  sd[P + "linear_2.weight"]]
+        names = list(_PROJ_ORDER)
+        # encoder LoRA: lora_A / lora_B of q_proj and k_proj of every layer join the SAME flat trainable bucket (one
+        # all-reduce, one AdamW launch); missing keys get peft's initialisation (A kaiming-uniform, B zero)
+        self._lora_names = []
+        if self.lora_r > 0:
+            init = init_lora_state_dict(cfg, seed=0, dtype=dt)
+            for i in range(a.encoder_layers):
+                for pj in LORA_TARGETS:
+                    for which in "AB":
+                        k = lora_key(i, pj, which)
+                        parts.append(sd[k] if k in sd else init[k])
+                        names.append(k)
+                        self._lora_names.append(k)
         sizes = [p.numel() for p in parts]
         pad = [(-s) % 64 for s in sizes]  # keep every view 128-byte aligned
         total = sum(s + p for s, p in zip(sizes, pad))
         self.proj_flat = torch.zeros(total, device=dev, dtype=dt)
         self.proj_grad = torch.zeros(total, device=dev, dtype=torch.float32)
         self._proj_views, self._grad_views, off = {}, {}, 0
-        for name, p, s, pd in zip(_PROJ_ORDER, parts, sizes, pad):
+        for name, p, s, pd in zip(names, parts, sizes, pad):
             self.proj_flat[off:off + s].copy_(p.reshape(-1).to(device=dev, dtype=dt))
             self._proj_views[name] = self.proj_flat[off:off + s].view(p.shape)
             self._grad_views[name] = self.proj_grad[off:off + s].view(p.shape)
             off += s + pd
         self._norm_key = norm_key
+        if self.lora_r > 0:
+            nl = a.encoder_layers
+            self._lora_layers = (_lib.EncLoraLayer * nl)()
+            self._lora_grad_layers = (_lib.EncLoraLayer * nl)()
+            for i in range(nl):
+                for pj, fld in zip(LORA_TARGETS, ("q", "k")):
+                    getattr(self._lora_layers[i], fld).a = self._proj_views[lora_key(i, pj, "A")].data_ptr()
+                    getattr(self._lora_layers[i], fld).b = self._proj_views[lora_key(i, pj, "B")].data_ptr()
+                    getattr(self._lora_grad_layers[i], fld).a = self._grad_views[lora_key(i, pj, "A")].data_ptr()
+                    getattr(self._lora_grad_layers[i], fld).b = self._grad_views[lora_key(i, pj, "B")].data_ptr()
+            self._lora = _lib.EncoderLora()
+            self._lora.r = self.lora_r
+            self._lora.scaling = float(cfg.audio_model_lora_config.get("lora_alpha", 8)) / self.lora_r
+            self._lora.layers = self._lora_layers
+            self._lora_grads = _lib.EncoderLoraGrads()
+            self._lora_grads.layers = self._lora_grad_layers
 
         c = _lib.Config()
         c.dtype = self.code
@@ -150,7 +180,7 @@ class UltravoxModel:
         self._enc_layers = (_lib.EncLayer * a.encoder_layers)()
         for i, L in enumerate(e["layers"]):
             for n in _lib._ENC_LAYER_FIELDS:
-                setattr(self._enc_layers[i], n, L[n].data_ptr())
+                setattr(self._enc_layers[i], n, 0 if L.get(n) is None else L[n].data_ptr())
         ew = _lib.EncoderWeights()
         for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "pos", "lnf_w", "lnf_b"):
             setattr(ew, n, e[n].data_ptr())
@@ -182,11 +212,14 @@ class UltravoxModel:
         self._lw = lw
 
     def projector_state_dict(self) -> Dict[str, torch.Tensor]:
-        """Trainable keys under the reference's checkpoint names (ultravox_model.py:565-594 saves these)."""
+        """Trainable keys under the reference's checkpoint names (ultravox_model.py:565-594 saves these): the projector
+        and, with audio_model_lora_config.r > 0, the encoder's LoRA matrices under peft's names."""
         P = "multi_modal_projector."
-        return {P + "ln_pre.weight": self._proj_views["ln_pre"], P + "linear_1.weight": self._proj_views["linear_1"],
-                P + self._norm_key + ".weight": self._proj_views["ln_norm"],
-                P + "linear_2.weight": self._proj_views["linear_2"]}
+        out = {P + "ln_pre.weight": self._proj_views["ln_pre"], P + "linear_1.weight": self._proj_views["linear_1"],
+               P + self._norm_key + ".weight": self._proj_views["ln_norm"],
+               P + "linear_2.weight": self._proj_views["linear_2"]}
+        out.update({k: self._proj_views[k] for k in self._lora_names})
+        return out
 
     # ------------------------------------------------------------------ checkpoint I/O (ultravox_model.py:565-594)
     def trainable_parameter_names(self):
@@ -238,9 +271,11 @@ class UltravoxModel:
 
     def projector_grads(self) -> Dict[str, torch.Tensor]:
         P = "multi_modal_projector."
-        return {P + "ln_pre.weight": self._grad_views["ln_pre"], P + "linear_1.weight": self._grad_views["linear_1"],
-                P + self._norm_key + ".weight": self._grad_views["ln_norm"],
-                P + "linear_2.weight": self._grad_views["linear_2"]}
+        out = {P + "ln_pre.weight": self._grad_views["ln_pre"], P + "linear_1.weight": self._grad_views["linear_1"],
+               P + self._norm_key + ".weight": self._grad_views["ln_norm"],
+               P + "linear_2.weight": self._grad_views["linear_2"]}
+        out.update({k: self._grad_views[k] for k in self._lora_names})
+        return out
 
     def train(self, mode: bool = True):
         self.training = mode
@@ -277,9 +312,19 @@ class UltravoxModel:
         audio_values = audio_values.contiguous()
         Te = (F - 1) // 2 + 1
         out = torch.empty((A, Te, self.config.audio_config.d_model), device=self.device, dtype=self.dtype)
+        lens = None if audio_len is None else audio_len.to(device=self.device, dtype=torch.int64).contiguous()
+        if self.lora_r > 0:
+            # LoRA-adapted tower (peft merges nothing at run time: base + lora_B(lora_A(x)) * scaling, also in eval mode);
+            # the training workspace keeps the per-layer activations for uvx_encoder_bwd
+            nb = l.uvx_encoder_train_ws_bytes(C.byref(self._c), A, F)
+            ws = self._workspace("enc_train", nb)
+            check(l.uvx_encoder_fwd_train(stream_ptr(), C.byref(self._c), C.byref(self._ew), C.byref(self._lora),
+                                          ptr(audio_values), int(is_f32), ptr(lens), A, F, ptr(out), ptr(ws), C.c_size_t(nb)),
+                  "uvx_encoder_fwd_train")
+            self._enc_ctx = (A, F, nb, lens)
+            return out
         nb = l.uvx_encoder_ws_bytes(C.byref(self._c), A, F)
         ws = self._workspace("enc", nb)
-        lens = None if audio_len is None else audio_len.to(device=self.device, dtype=torch.int64).contiguous()
         check(l.uvx_encoder_fwd(stream_ptr(), C.byref(self._c), C.byref(self._ew), ptr(audio_values), int(is_f32),
                                 ptr(lens), A, F, ptr(out), ptr(ws), C.c_size_t(nb)), "uvx_encoder_fwd")
         return out
@@ -300,8 +345,16 @@ class UltravoxModel:
     def _projector_backward(self, d_audio_embeds: torch.Tensor) -> None:
         l = _lib.lib()
         A, Te, nb = self._proj_ctx
+        d_enc = None
+        if self.lora_r > 0:
+            d_enc = torch.empty((A, Te, self.config.audio_config.d_model), device=self.device, dtype=self.dtype)
         check(l.uvx_projector_bwd(stream_ptr(), C.byref(self._c), C.byref(self._pw), ptr(d_audio_embeds), A, Te,
-                                  C.byref(self._pg), ptr(self._ws["proj"]), C.c_size_t(nb)), "uvx_projector_bwd")
+                                  C.byref(self._pg), ptr(d_enc), ptr(self._ws["proj"]), C.c_size_t(nb)), "uvx_projector_bwd")
+        if self.lora_r > 0:
+            Ae, F, nbe, lens = self._enc_ctx
+            check(l.uvx_encoder_bwd(stream_ptr(), C.byref(self._c), C.byref(self._ew), C.byref(self._lora), ptr(d_enc),
+                                    ptr(lens), Ae, F, C.byref(self._lora_grads), ptr(self._ws["enc_train"]), C.c_size_t(nbe)),
+                  "uvx_encoder_bwd")
 
     def _prepare_audio_embeds(self, inputs_embeds, input_ids, audio_values, audio_token_start_idx, audio_lens,
                               audio_token_len, audio_batch_size):
@@ -313,6 +366,8 @@ class UltravoxModel:
             "audio_token_start_idx/audio_token_len/audio_lens/audio_values must have the same batch size."
         B, T = (inputs_embeds.shape[:2] if inputs_embeds is not None else input_ids.shape)
         assert len(audio_batch_size) == B, "audio_batch_size and inputs_embeds must have the same batch size."
+        if self._before_projector is not None and self.lora_r > 0:
+            self._before_projector()             # a LoRA-adapted encoder reads trainable weights: nothing to hide behind
         tower = self.audio_tower_forward(audio_values, audio_lens)
         if self._before_projector is not None:   # the trainer's deferred all-reduce + optimizer step (overlapped with the
             self._before_projector()             # frozen encoder above, which does not read the trainable weights)

@@ -159,3 +159,23 @@ def kl_loss(student, teacher, pair_row, pair_w, temperature, want_grad=True, gra
                                  ptr(pair_w.contiguous()), ptr(loss), ptr(dl), C.c_int64(R), V, student.stride(0),
                                  teacher.stride(0), C.c_float(temperature), C.c_float(grad_scale), ptr(scratch)), "uvx_kl_loss")
     return loss[0], dl
+
+
+def layernorm_bwd(dy, x, w, eps=1e-5, dx_add=None):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty_like(x)
+    check(_lib.lib().uvx_layernorm_bwd(stream_ptr(), _code(x), ptr(dy), ptr(x), ptr(w), ptr(dx_add), ptr(dx), rows, cols,
+                                       C.c_float(eps)), "uvx_layernorm_bwd")
+    return dx
+
+
+def gelu(pre):
+    out = torch.empty_like(pre)
+    check(_lib.lib().uvx_gelu(stream_ptr(), _code(pre), ptr(pre), ptr(out), C.c_int64(pre.numel())), "uvx_gelu")
+    return out
+
+
+def gelu_bwd(dout, pre):
+    din = torch.empty_like(pre)
+    check(_lib.lib().uvx_gelu_bwd(stream_ptr(), _code(pre), ptr(dout), ptr(pre), ptr(din), C.c_int64(pre.numel())), "uvx_gelu_bwd")
+    return din

@@ -119,7 +119,35 @@ def rope_table(tc, length: int, device) -> torch.Tensor:
     return torch.stack([freqs.cos(), freqs.sin()], dim=-1).contiguous().to(device)  # [len, dh/2, 2]
 
 
-def pack_encoder(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.") -> Dict[str, object]:
+LORA_TARGETS = ("q_proj", "k_proj")     # of the encoder's self_attn (the default target_modules that exist in Whisper)
+
+
+def lora_key(layer: int, proj: str, which: str, prefix="audio_tower.") -> str:
+    """peft's parameter name for a LoRA matrix of the wrapped encoder (get_peft_model, ultravox_model.py:707): the base
+    model sits under `base_model.model.` and the adapter is called `default`."""
+    return f"{prefix}base_model.model.layers.{layer}.self_attn.{proj}.lora_{which}.default.weight"
+
+
+def init_lora_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32, device="cpu", random_b: bool = False):
+    """peft's initialisation: lora_A kaiming-uniform(a = sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)), lora_B zeros
+    (random_b: small random B instead, so that tests see non-zero gradients for A too)."""
+    a = cfg.audio_config
+    r, d = int(cfg.audio_model_lora_config["r"]), a.d_model
+    g = torch.Generator(device=device).manual_seed(seed + 7919)
+    out = {}
+    bound = 1.0 / math.sqrt(d)
+    for i in range(a.encoder_layers):
+        for pj in LORA_TARGETS:
+            A = (torch.rand(r, d, generator=g, device=device) * 2 - 1) * bound
+            B = 0.05 * torch.randn(d, r, generator=g, device=device) if random_b else torch.zeros(d, r, device=device)
+            out[lora_key(i, pj, "A")] = A.to(dtype)
+            out[lora_key(i, pj, "B")] = B.to(dtype)
+    return out
+
+
+def pack_encoder(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.", with_transposes: bool = False) -> Dict[str, object]:
+    if prefix + "conv1.weight" not in sd and prefix + "base_model.model.conv1.weight" in sd:
+        prefix = prefix + "base_model.model."          # a peft-wrapped tower (LoRA checkpoints)
     a = cfg.audio_config
     d, H = a.d_model, a.encoder_attention_heads
     scale = (d // H) ** -0.5
@@ -151,6 +179,9 @@ def pack_encoder(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.") 
             "fc1_w": cv(sd[L + "fc1.weight"]), "fc1_b": cv(sd[L + "fc1.bias"]),
             "fc2_w": cv(sd[L + "fc2.weight"]), "fc2_b": cv(sd[L + "fc2.bias"]),
         })
+        lay = out["layers"][-1]
+        for n, src in (("wqkv_t", "wqkv"), ("wo_t", "wo"), ("fc1_t", "fc1_w"), ("fc2_t", "fc2_w")):
+            lay[n] = lay[src].t().contiguous() if with_transposes else None   # [K_in, N_out]: dgrad operands (LoRA training)
     return out
 
 
