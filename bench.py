@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the live HIP-event timing of the GEMM kernel")
+    ap.add_argument("--audio-lora-r", type=int, default=0,
+                    help="train rank-r LoRA on the encoder's q_proj/k_proj too (the reference's release recipe, "
+                         "audio_model_lora_config.r = 8); 0 = frozen towers, the BASELINE.json configuration")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: sequential all-reduce + optimizer step (no overlap)")
     ap.add_argument("--opt", default=None, help="probe: 'key=value,...' for uvx_set_option")
     ap.add_argument("--gemm-override", default=None, help="probe: 'MxNxK=variant,...' tile-variant overrides")
@@ -196,7 +199,8 @@ def main():
     wl = WORKLOADS[args.workload]
     B = args.batch or wl["B"]
     cfg = UltravoxConfig(audio_model_id=wl["audio"], text_model_id=wl["text"], hidden_size=4096, stack_factor=8,
-                         projector_ln_mid=True, torch_dtype="bfloat16")
+                         projector_ln_mid=True, torch_dtype="bfloat16",
+                         audio_model_lora_config={"r": args.audio_lora_r} if args.audio_lora_r else None)
     model = UltravoxModel(cfg, device=str(dev), dtype=torch.bfloat16, seed=0, rope_len=1024)
     trainer = UltravoxTrainer(model, lr=2e-3, max_grad_norm=1.0, overlap_comm=world > 1 and not args.no_overlap)
     fe = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins, device=str(dev))
@@ -258,6 +262,7 @@ def main():
             "config": {"workload": wl["name"], "clips_per_gpu": B, "clip_seconds": wl["seconds"], "text_tokens": 128,
                        "seq_len": T, "global_batch": B * world, "parallelism": ("SHARED-GPU TEST MODE " if share_gpu else "") + f"dp{world}" + (" (all-reduce overlapped with the next step's frozen encoder)" if trainer.overlap_comm else ""),
                        "audio_model": wl["audio"], "text_model": wl["text"], "optimizer": "AdamW bf16 state, clip 1.0",
+                       "trainable": "projector" + (f" + encoder LoRA r={args.audio_lora_r} (q_proj, k_proj)" if args.audio_lora_r else ""),
                        "supervised_tokens_per_clip": 32,
                        "loss_head": "LM head + CE on the supervised positions only (identical loss and gradients)"},
             "samples_per_sec": B * world * args.steps / dt,

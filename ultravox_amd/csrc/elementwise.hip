@@ -281,30 +281,6 @@ __global__ void gelu_bwd_k(const T* __restrict__ dout, const T* __restrict__ pre
   }
   st8<T>(din + i * 8, g);
 }
-// dst[r, 0..cols) = src[r, 0..cols) for r < rows (element strides ld_dst / ld_src), any 4-byte type
-__global__ void copy2d_f32_k(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int ld_src, int ld_dst) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)rows * cols) return;
-  const int r = (int)(i / cols), c = (int)(i % cols);
-  dst[(long long)r * ld_dst + c] = src[(long long)r * ld_src + c];
-}
-// LoRA operand layouts for one projection (r <= 64): A [r, d], B [d, r] (peft) -> zero-padded GEMM operands
-//   a_pad [64, d] (rows >= r zero), b_pad [d, 64] (cols >= r zero), a_t [d, 64] = A^T padded (row stride ld_at, so that
-//   two projections can sit side by side in one [d, 128] operand), b_t [64, d] = B^T padded
-template <typename T>
-__global__ void lora_pack_k(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ a_pad, T* __restrict__ b_pad,
-                            T* __restrict__ a_t, int ld_at, T* __restrict__ b_t, int r, int d) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 64LL * d) return;
-  const int j = (int)(i / d), c = (int)(i % d);          // j in [0, 64), c in [0, d)
-  const T za = j < r ? A[(long long)j * d + c] : (T)0;    // A[j, c]
-  const T zb = j < r ? B[(long long)c * r + j] : (T)0;    // B[c, j]
-  a_pad[(long long)j * d + c] = za;
-  a_t[(long long)c * ld_at + j] = za;
-  b_pad[(long long)c * 64 + j] = zb;
-  b_t[(long long)j * d + c] = zb;
-}
-
 // rows: compaction list of sup_rows (count at rows[n]).  GATHER: dst[c] = src[rows[c]];  SCATTER: dst[rows[c]] = src[c].
 template <typename T, bool SCATTER>
 __global__ void move_rows_k(const T* __restrict__ src, const int32_t* __restrict__ rows, long long n, T* __restrict__ dst, int D,
@@ -539,22 +515,6 @@ int gelu_bwd(hipStream_t st, int dtype, const void* dout, const void* pre, void*
   if (n == 0) return UVX_OK;
   if (dtype == DT_BF16) hipLaunchKernelGGL(gelu_bwd_k<bf16_t>, dim3(grid1d(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)pre, (bf16_t*)din, n / 8);
   else hipLaunchKernelGGL(gelu_bwd_k<float>, dim3(grid1d(n / 8, 256)), dim3(256), 0, st, (const float*)dout, (const float*)pre, (float*)din, n / 8);
-  UVX_LAUNCH_CHECK();
-  return UVX_OK;
-}
-
-int copy2d_f32(hipStream_t st, const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst) {
-  if (rows <= 0 || cols <= 0) return UVX_OK;
-  hipLaunchKernelGGL(copy2d_f32_k, dim3(grid1d((long long)rows * cols, 256)), dim3(256), 0, st, src, dst, rows, cols, ld_src, ld_dst);
-  UVX_LAUNCH_CHECK();
-  return UVX_OK;
-}
-
-int lora_pack(hipStream_t st, int dtype, const void* A, const void* B, void* a_pad, void* b_pad, void* a_t, int ld_at,
-              void* b_t, int r, int d) {
-  UVX_CHECK(r > 0 && r <= 64, UVX_ERR_SHAPE, "lora_pack: rank %d must be in 1..64", r);
-  if (dtype == DT_BF16) hipLaunchKernelGGL(lora_pack_k<bf16_t>, dim3(grid1d(64LL * d, 256)), dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)a_pad, (bf16_t*)b_pad, (bf16_t*)a_t, ld_at, (bf16_t*)b_t, r, d);
-  else hipLaunchKernelGGL(lora_pack_k<float>, dim3(grid1d(64LL * d, 256)), dim3(256), 0, st, (const float*)A, (const float*)B, (float*)a_pad, (float*)b_pad, (float*)a_t, ld_at, (float*)b_t, r, d);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

@@ -98,14 +98,23 @@ int add_rows(hipStream_t st, int dtype, const void* a, const void* b, void* out,
 int cast_f32_to(hipStream_t st, int dtype, const float* in, void* out, long long n);
 int fill_zero(hipStream_t st, void* p, long long bytes);
 // encoder LoRA training: GELU as a separate pass on the stashed pre-activation, its exact-derivative backward,
-// LayerNorm backward for a frozen affine (dx only, + optional residual), LoRA operand packing, strided f32 copy
+// LayerNorm backward for a frozen affine (dx only, + optional residual)
 int gelu_fwd(hipStream_t st, int dtype, const void* pre, void* out, long long n);
 int gelu_bwd(hipStream_t st, int dtype, const void* dout, const void* pre, void* din, long long n);
 int layernorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w, const void* dx_add, void* dx,
                   int rows, int cols, float eps);
-int lora_pack(hipStream_t st, int dtype, const void* A, const void* B, void* a_pad, void* b_pad, void* a_t, int ld_at,
-              void* b_t, int r, int d);
-int copy2d_f32(hipStream_t st, const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst);
+// ---- lora.hip: rank-r products on the VALU (peft layouts: A [r, C], B [C, r]) ----
+// Y[M, r] = round(alpha * sum_c X[m, c] * W(j, c));  W stored [r][C] (w_is_cr = 0) or [C][r] (1)
+int lora_down(hipStream_t st, int dtype, const void* X, long long ldx, const void* W, int w_is_cr, void* Y, long long ldy,
+              long long M, int C, int r, float alpha);
+// Z[M, C] (+)= round(alpha * sum_j Y[m, j] * W(c, j));  W stored [C][r] (w_is_rc = 0) or [r][C] (1)
+int lora_up(hipStream_t st, int dtype, const void* Y, long long ldy, const void* W, int w_is_rc, void* Z, long long ldz,
+            long long M, int C, int r, float alpha, int accumulate);
+// out = alpha * Y[M, r]^T . X[M, C]  as [r][C] or, transpose_out, [C][r]  (f32; scratch: lora_wgrad_scratch_floats)
+long long lora_wgrad_scratch_floats(long long M, int C, int r);
+int lora_transpose(hipStream_t st, int dtype, const void* in, void* out, int C, int r);   // [C, r] -> [r, C]
+int lora_wgrad(hipStream_t st, int dtype, const void* X, long long ldx, const void* Y, long long ldy, float* out, long long M,
+               int C, int r, int transpose_out, float alpha, float* scratch);
 
 // ---- attention.hip ----
 struct AttnDesc {

@@ -1,0 +1,209 @@
+// Rank-r LoRA products for the encoder's q_proj / k_proj (audio_model_lora_config, peft layouts: A [r, C], B [C, r]).
+//
+// With r = 8 every LoRA product is a "skinny" matrix product whose cost is reading the wide operand once: HBM-bound,
+// 8 FMAs per loaded element.  Padding the rank to an MFMA tile (r -> 64) and running the GEMM family on it - the
+// first version - spent 17 ms of a C2 LoRA-training step in 128x128 tiles that are 87 % zeros or 1 K-tile deep
+// (profiles/r01_kernel_stats_lora.txt).  These kernels do the same arithmetic on the VALU, f32 accumulation, with the
+// bf16 rounding points of the GEMM path (which are peft's: lora_A output, lora_B output, the sum).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int RMAX = 64;
+
+// Y[m, j] = round(alpha * sum_c X[m, c] * W[j, c]),  j < r.   One wave per row; W (r x C) stays in L1 / L2.
+// W_CR: W is stored [C][r] (lora_B used as a down-projection in the backward pass) instead of [r][C]
+template <typename T, bool W_CR>
+__global__ __launch_bounds__(256) void lora_down_k(const T* __restrict__ X, long long ldx, const T* __restrict__ W,
+                                                   T* __restrict__ Y, long long ldy, long long M, int C, int r, float alpha) {
+  const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const T* xr = X + m * ldx;
+  for (int j0 = 0; j0 < r; j0 += 8) {            // 8 output columns per pass (r = 8: one pass)
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = lane * 8; c < C; c += 64 * 8) {
+      float xv[8];
+      ld8<T>(xr + c, xv);
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        if (j0 + jj < r) {
+          float wv[8];
+          if (W_CR) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] = ldf<T>(W + (long long)(c + i) * r + j0 + jj);
+          } else {
+            ld8<T>(W + (long long)(j0 + jj) * C + c, wv);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[jj] += xv[i] * wv[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) acc[jj] = wave_sum(acc[jj]);
+    if (lane == 0) {   // whole group of 8 (zeros beyond r): consumers vector-load Y rows
+      float o[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) o[jj] = acc[jj] * alpha;
+      st8<T>(Y + m * ldy + j0, o);
+    }
+  }
+}
+
+// Z[m, c] = round(Z[m, c] + round(alpha * sum_j Y[m, j] * W[c, j]))   (accumulate = false: Z = round(alpha * ...))
+// W_RC: W is stored [r][C] (lora_A used as an up-projection in the backward pass) instead of [C][r]
+template <typename T, bool ACC, bool W_RC>
+__global__ void lora_up_k(const T* __restrict__ Y, long long ldy, const T* __restrict__ W, T* __restrict__ Z, long long ldz,
+                          long long M, int C, int r, float alpha) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cv = C / 8;
+  if (i >= M * cv) return;
+  const long long m = i / cv;
+  const int c = (int)(i % cv) * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < r; ++j) {
+    const float y = ldf<T>(Y + m * ldy + j);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += y * ldf<T>(W_RC ? W + (long long)j * C + c + k : W + (long long)(c + k) * r + j);
+  }
+  float z[8];
+  if (ACC) ld8<T>(Z + m * ldz + c, z);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) z[k] = ACC ? z[k] + rnd<T>(acc[k] * alpha) : acc[k] * alpha;
+  st8<T>(Z + m * ldz + c, z);
+}
+
+// Weight-gradient contraction over the tokens: P[j][c] = sum_m Y[m, j] * X[m, c]  (j < 8 per pass, c < C).
+// Grid = (C / 64 column tiles) x (row chunks of RCH rows).  A block is 4 waves; in a wave, lane = (row lane 0..7) x
+// (column vector 0..7): 8 lanes read one 128-byte piece of a row, the 8 row lanes take consecutive rows, the 4 waves
+// interleave further.  Each lane keeps acc[8 j][8 c]; row lanes are folded with shuffles, waves through LDS.
+// partial[chunk][j][c]; lora_wgrad_reduce_k sums the few chunks in a fixed order.
+constexpr int RCH = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void lora_wgrad_k(const T* __restrict__ X, long long ldx, const T* __restrict__ Y, long long ldy,
+                                                    float* __restrict__ partial, long long M, int C, int r, int j0) {
+  __shared__ float red[4][8][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cv = lane & 7, rl = lane >> 3;
+  const int c = blockIdx.x * 64 + cv * 8;
+  const long long m0 = (long long)blockIdx.y * RCH, m1 = min(M, m0 + RCH);
+  float acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = 0.f;
+  if (c < C) {
+    for (long long m = m0 + w * 8 + rl; m < m1; m += 32) {
+      float xv[8], yv[8];
+      ld8<T>(X + m * ldx + c, xv);
+      ld8<T>(Y + m * ldy + j0, yv);
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[jj][k] += yv[jj] * xv[k];
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = acc[jj][k];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      acc[jj][k] = v;
+    }
+  if (rl == 0) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[w][jj][cv * 8 + k] = acc[jj][k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+    const int jj = i >> 6, cc = i & 63;
+    if (j0 + jj < r && blockIdx.x * 64 + cc < C)
+      partial[((long long)blockIdx.y * r + j0 + jj) * C + blockIdx.x * 64 + cc] =
+          red[0][jj][cc] + red[1][jj][cc] + red[2][jj][cc] + red[3][jj][cc];
+  }
+}
+
+// out = alpha * sum_chunk partial[chunk]  as [r][C] (transpose_out = 0: lora_A) or [C][r] (1: lora_B)
+__global__ void lora_wgrad_reduce_k(const float* __restrict__ partial, int nchunks, int r, int C, float* __restrict__ out,
+                                    int transpose_out, float alpha) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= r * C) return;
+  const int j = i / C, c = i % C;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += partial[((long long)k * r + j) * C + c];   // fixed order: deterministic
+  out[transpose_out ? (long long)c * r + j : (long long)j * C + c] = s * alpha;
+}
+
+// out[j][c] = in[c][j]: lora_B [C, r] -> [r, C] once per use, so that every product reads its narrow operand row-wise
+template <typename T>
+__global__ void lora_transpose_k(const T* __restrict__ in, T* __restrict__ out, int C, int r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= r * C) return;
+  const int j = i / C, c = i % C;
+  out[i] = in[(long long)c * r + j];
+}
+
+}  // namespace
+
+namespace uvx {
+
+int lora_down(hipStream_t st, int dtype, const void* X, long long ldx, const void* W, int w_is_cr, void* Y, long long ldy,
+              long long M, int C, int r, float alpha) {
+  UVX_CHECK(C % 8 == 0 && ldx % 8 == 0 && r > 0 && r <= RMAX, UVX_ERR_SHAPE, "lora_down: C=%d r=%d unsupported", C, r);
+  if (M == 0) return UVX_OK;
+  const dim3 grid((unsigned)((M + 3) / 4));
+#define L(T, F) hipLaunchKernelGGL((lora_down_k<T, F>), grid, dim3(256), 0, st, (const T*)X, ldx, (const T*)W, (T*)Y, ldy, M, C, r, alpha)
+  if (dtype == DT_BF16) { if (w_is_cr) L(bf16_t, true); else L(bf16_t, false); }
+  else { if (w_is_cr) L(float, true); else L(float, false); }
+#undef L
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int lora_up(hipStream_t st, int dtype, const void* Y, long long ldy, const void* W, int w_is_rc, void* Z, long long ldz,
+            long long M, int C, int r, float alpha, int accumulate) {
+  UVX_CHECK(C % 8 == 0 && ldz % 8 == 0 && r > 0 && r <= RMAX, UVX_ERR_SHAPE, "lora_up: C=%d r=%d unsupported", C, r);
+  if (M == 0) return UVX_OK;
+  const long long n = M * (C / 8);
+  const dim3 grid((unsigned)((n + 255) / 256));
+#define L(T, A, F) hipLaunchKernelGGL((lora_up_k<T, A, F>), grid, dim3(256), 0, st, (const T*)Y, ldy, (const T*)W, (T*)Z, ldz, M, C, r, alpha)
+#define L2(T, A) do { if (w_is_rc) L(T, A, true); else L(T, A, false); } while (0)
+  if (dtype == DT_BF16) { if (accumulate) L2(bf16_t, true); else L2(bf16_t, false); }
+  else { if (accumulate) L2(float, true); else L2(float, false); }
+#undef L2
+#undef L
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+// scratch: lora_wgrad_scratch_floats(M, C, r) floats.  Y rows must be readable in whole groups of 8 (lora_down writes them so).
+long long lora_wgrad_scratch_floats(long long M, int C, int r) { return ((M + RCH - 1) / RCH) * (long long)r * C; }
+
+int lora_wgrad(hipStream_t st, int dtype, const void* X, long long ldx, const void* Y, long long ldy, float* out, long long M,
+               int C, int r, int transpose_out, float alpha, float* scratch) {
+  UVX_CHECK(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && r > 0 && r <= RMAX, UVX_ERR_SHAPE, "lora_wgrad: C=%d r=%d unsupported", C, r);
+  if (M == 0) { UVX_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)r * C, st)); return UVX_OK; }
+  const int nchunks = (int)((M + RCH - 1) / RCH);
+  const dim3 grid((C + 63) / 64, nchunks);
+  for (int j0 = 0; j0 < r; j0 += 8) {
+    if (dtype == DT_BF16) hipLaunchKernelGGL(lora_wgrad_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, scratch, M, C, r, j0);
+    else hipLaunchKernelGGL(lora_wgrad_k<float>, grid, dim3(256), 0, st, (const float*)X, ldx, (const float*)Y, ldy, scratch, M, C, r, j0);
+  }
+  hipLaunchKernelGGL(lora_wgrad_reduce_k, dim3((r * C + 255) / 256), dim3(256), 0, st, scratch, nchunks, r, C, out, transpose_out, alpha);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int lora_transpose(hipStream_t st, int dtype, const void* in, void* out, int C, int r) {
+  if (dtype == DT_BF16) hipLaunchKernelGGL(lora_transpose_k<bf16_t>, dim3((r * C + 255) / 256), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, C, r);
+  else hipLaunchKernelGGL(lora_transpose_k<float>, dim3((r * C + 255) / 256), dim3(256), 0, st, (const float*)in, (float*)out, C, r);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+}  // namespace uvx

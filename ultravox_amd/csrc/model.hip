@@ -63,9 +63,9 @@ __global__ void full_range_k(int32_t* __restrict__ kv_start, int32_t* __restrict
 // ------------------------------------------------------------------ encoder
 // per-layer stash of the LoRA-training forward (uvx_encoder_fwd_train -> uvx_encoder_bwd)
 struct EncLayerStash {
-  void *x_in, *qkv, *o, *x_mid, *pre, *t;   // t = n . [A_q | A_k]^T (the LoRA down-projections), [M, 128]
+  void *x_in, *qkv, *o, *x_mid, *pre, *t;   // t = [lora_A_q(n) | lora_A_k(n)], [M, 128] (columns 0..r-1 and 64..64+r-1)
   float* lse;
-  void *a_qk, *bq, *bk, *a_t_qk, *bq_t, *bk_t;   // packed LoRA operands of this layer (lora_pack)
+  void *bqT, *bkT;                           // lora_B^T [r, d] of this layer: every rank-r product reads rows
 };
 struct EncWs {
   void *im2col, *c1, *x, *n, *qkv, *vt, *o, *f;
@@ -73,8 +73,8 @@ struct EncWs {
   int Te, Tp, M, Kp1;
   // training only
   char* slots; size_t slot_bytes; EncLayerStash ls0;
-  void *dx, *d_n, *d_o, *d_f, *d_qkv, *qT, *kT, *doT, *u, *uT, *tT, *nT, *dqkT;
-  float *delta, *gA, *gB;
+  void *dx, *d_n, *d_o, *d_f, *d_qkv, *qT, *kT, *doT, *u;
+  float *delta, *wg;   // wg: lora_wgrad scratch
   int Mp;
 };
 void enc_slot(Arena& a, const uvx_config_t& c, int B, int Te, EncLayerStash& s) {
@@ -82,13 +82,12 @@ void enc_slot(Arena& a, const uvx_config_t& c, int B, int Te, EncLayerStash& s) 
   s.x_in = a.take(M * d * es); s.qkv = a.take(M * 3 * d * es); s.o = a.take(M * d * es); s.x_mid = a.take(M * d * es);
   s.pre = a.take(M * c.enc_ffn * es); s.t = a.take(M * 128 * es);
   s.lse = (float*)a.take(sizeof(float) * (size_t)B * c.enc_heads * Te);
-  s.a_qk = a.take(128 * d * es); s.bq = a.take(d * 64 * es); s.bk = a.take(d * 64 * es);
-  s.a_t_qk = a.take(d * 128 * es); s.bq_t = a.take(64 * d * es); s.bk_t = a.take(64 * d * es);
+  s.bqT = a.take(64 * d * es); s.bkT = a.take(64 * d * es);
 }
 EncLayerStash enc_layer(const EncWs& w, int l) {
   EncLayerStash s = w.ls0;
   const size_t off = w.slot_bytes * l;
-  void** ps[] = {&s.x_in, &s.qkv, &s.o, &s.x_mid, &s.pre, &s.t, (void**)&s.lse, &s.a_qk, &s.bq, &s.bk, &s.a_t_qk, &s.bq_t, &s.bk_t};
+  void** ps[] = {&s.x_in, &s.qkv, &s.o, &s.x_mid, &s.pre, &s.t, (void**)&s.lse, &s.bqT, &s.bkT};
   for (void** q : ps) if (*q) *q = (char*)*q + off;
   return s;
 }
@@ -123,10 +122,9 @@ EncWs enc_carve(Arena& a, const uvx_config_t& c, int B, int F, bool train = fals
     w.d_f = a.take(M * c.enc_ffn * es); w.d_qkv = a.take(M * 3 * d * es);
     const size_t ht = (size_t)B * c.enc_heads * dh * w.Tp * es;
     w.qT = a.take(ht); w.kT = a.take(ht); w.doT = a.take(ht);
-    w.u = a.take(M * 128 * es); w.uT = a.take((size_t)128 * w.Mp * es); w.tT = a.take((size_t)128 * w.Mp * es);
-    w.nT = a.take(d * (size_t)w.Mp * es); w.dqkT = a.take(2 * d * (size_t)w.Mp * es);
+    w.u = a.take(M * 128 * es);
     w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.enc_heads * w.Te);
-    w.gA = (float*)a.take(sizeof(float) * 128 * d); w.gB = (float*)a.take(sizeof(float) * 2 * d * 64);
+    w.wg = (float*)a.take(sizeof(float) * (size_t)lora_wgrad_scratch_floats(w.M, c.enc_d, 64));
   }
   return w;
 }
@@ -338,20 +336,15 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     if (train) {
       // peft LoRA on q_proj / k_proj: result += lora_B(lora_A(x)) * scaling (and q carries Whisper's head_dim^-0.5,
       // folded into wqkv at pack time).  A_q | A_k share one rank-padded GEMM; K = 64 (zero padded rank) for the B side.
+      // rank-r products on the VALU (lora.hip): HBM-bound, no padding to an MFMA tile
       const uvx_enc_lora_layer_t& R = lora->layers[l];
-      RC(lora_pack(st, dt, R.q.a, R.q.b, S.a_qk, S.bq, S.a_t_qk, 128, S.bq_t, lora->r, d));
-      RC(lora_pack(st, dt, R.k.a, R.k.b, at(S.a_qk, (size_t)64 * d, dt), S.bk, at(S.a_t_qk, 64, dt), 128, S.bk_t, lora->r, d));
-      RC(gemm(st, dt, lin(s.n, S.a_qk, S.t, M, 128, d)));
-      {
-        GemmDesc g = lin(S.t, S.bq, qkv, M, d, 64);
-        g.lda = 128; g.ldc = 3 * d; g.residual = qkv; g.ldr = 3 * d; g.alpha = lora->scaling * qscale;
-        RC(gemm(st, dt, g));
-      }
-      {
-        GemmDesc g = lin(at(S.t, 64, dt), S.bk, at(qkv, d, dt), M, d, 64);
-        g.lda = 128; g.ldc = 3 * d; g.residual = at(qkv, d, dt); g.ldr = 3 * d; g.alpha = lora->scaling;
-        RC(gemm(st, dt, g));
-      }
+      const int r = lora->r;
+      RC(lora_transpose(st, dt, R.q.b, S.bqT, d, r));
+      RC(lora_transpose(st, dt, R.k.b, S.bkT, d, r));
+      RC(lora_down(st, dt, s.n, d, R.q.a, 0, S.t, 128, M, d, r, 1.0f));
+      RC(lora_down(st, dt, s.n, d, R.k.a, 0, at(S.t, 64, dt), 128, M, d, r, 1.0f));
+      RC(lora_up(st, dt, S.t, 128, S.bqT, 1, qkv, 3 * d, M, d, r, lora->scaling * qscale, 1));
+      RC(lora_up(st, dt, at(S.t, 64, dt), 128, S.bkT, 1, at(qkv, d, dt), 3 * d, M, d, r, lora->scaling, 1));
     }
     RC(heads_transpose(st, dt, at(qkv, 2 * d, dt), s.vt, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
     AttnDesc ad;
@@ -424,7 +417,7 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
   Arena a(workspace, ws_bytes);
   EncWs s = enc_carve(a, c, B, F, true);
   UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "encoder_bwd: workspace %zu < %zu bytes", ws_bytes, a.off);
-  const int dt = c.dtype, d = c.enc_d, Te = s.Te, M = s.M, Mp = s.Mp, dh = d / c.enc_heads, r = lora->r;
+  const int dt = c.dtype, d = c.enc_d, Te = s.Te, M = s.M, dh = d / c.enc_heads, r = lora->r;
   const float qscale = 1.0f / sqrtf((float)dh);
   // ln_post backward: out = LN(x_final); x_final is the running state after the last layer (s.x)
   RC(layernorm_bwd(st, dt, d_out, s.x, w->lnf_w, nullptr, s.dx, M, d, c.ln_eps));
@@ -452,47 +445,23 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     bd.dq = s.d_qkv; bd.dk = at(s.d_qkv, d, dt); bd.dv = at(s.d_qkv, 2 * d, dt);
     bd.lddq = bd.lddk = bd.lddv = 3 * d;
     RC(attention_bwd(st, dt, bd));
-    // ---- LoRA gradients of q_proj / k_proj ----
-    // u = [dq . B_q * (scaling * qscale) | dk . B_k * scaling]  [M, 128]
-    {
-      GemmDesc g = lin(s.d_qkv, S.bq_t, s.u, M, 64, d);
-      g.lda = 3 * d; g.ldc = 128; g.alpha = lora->scaling * qscale;
-      RC(gemm(st, dt, g));
-      GemmDesc h = lin(at(s.d_qkv, d, dt), S.bk_t, at(s.u, 64, dt), M, 64, d);
-      h.lda = 3 * d; h.ldc = 128; h.alpha = lora->scaling;
-      RC(gemm(st, dt, h));
-    }
-    RC(layernorm_fwd(st, dt, S.x_in, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));      // n1 recomputed (not stashed)
-    RC(transpose2d(st, dt, s.u, s.uT, M, 128, 128, Mp, 1, 0, 0));
-    RC(transpose2d(st, dt, s.n, s.nT, M, d, d, Mp, 1, 0, 0));
-    RC(transpose2d(st, dt, S.t, s.tT, M, 128, 128, Mp, 1, 0, 0));
-    RC(transpose2d(st, dt, s.d_qkv, s.dqkT, M, 2 * d, 3 * d, Mp, 1, 0, 0));
-    {  // d lora_A = u^T . n  -> [128, d] (rows 0..r-1: A_q, rows 64..64+r-1: A_k)
-      GemmDesc g = lin(s.uT, s.nT, s.gA, 128, d, Mp);
-      g.out_f32 = 1;
-      RC(gemm(st, dt, g));
-    }
-    {  // d lora_B = scale * dq^T . t  -> [d, 64] each (columns 0..r-1)
-      GemmDesc g = lin(s.dqkT, s.tT, s.gB, d, 64, Mp);
-      g.out_f32 = 1; g.alpha = lora->scaling * qscale;
-      RC(gemm(st, dt, g));
-      GemmDesc h = lin(at(s.dqkT, (size_t)d * Mp, dt), at(s.tT, (size_t)64 * Mp, dt), s.gB + (size_t)d * 64, d, 64, Mp);
-      h.out_f32 = 1; h.alpha = lora->scaling;
-      RC(gemm(st, dt, h));
-    }
+    // ---- LoRA gradients of q_proj / k_proj (rank-r products on the VALU, lora.hip) ----
+    const uvx_enc_lora_layer_t& R = lora->layers[l];
     const uvx_enc_lora_layer_grads_t& G = grads->layers[l];
-    RC(copy2d_f32(st, s.gA, G.q.a, r, d, d, d));
-    RC(copy2d_f32(st, s.gA + (size_t)64 * d, G.k.a, r, d, d, d));
-    RC(copy2d_f32(st, s.gB, G.q.b, d, r, 64, r));
-    RC(copy2d_f32(st, s.gB + (size_t)d * 64, G.k.b, d, r, 64, r));
+    // u = [dq . B_q * (scaling * qscale) | dk . B_k * scaling]  [M, 128] (columns 0..r-1 and 64..64+r-1)
+    RC(lora_down(st, dt, s.d_qkv, 3 * d, S.bqT, 0, s.u, 128, M, d, r, lora->scaling * qscale));
+    RC(lora_down(st, dt, at(s.d_qkv, d, dt), 3 * d, S.bkT, 0, at(s.u, 64, dt), 128, M, d, r, lora->scaling));
+    RC(layernorm_fwd(st, dt, S.x_in, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));      // n1 recomputed (not stashed)
+    // d lora_A [r, d] = u^T . n;  d lora_B [d, r] = scale * dq^T . t
+    RC(lora_wgrad(st, dt, s.n, d, s.u, 128, G.q.a, M, d, r, 0, 1.0f, s.wg));
+    RC(lora_wgrad(st, dt, s.n, d, at(s.u, 64, dt), 128, G.k.a, M, d, r, 0, 1.0f, s.wg));
+    RC(lora_wgrad(st, dt, s.d_qkv, 3 * d, S.t, 128, G.q.b, M, d, r, 1, lora->scaling * qscale, s.wg));
+    RC(lora_wgrad(st, dt, at(s.d_qkv, d, dt), 3 * d, at(S.t, 64, dt), 128, G.k.b, M, d, r, 1, lora->scaling, s.wg));
     if (l == 0) break;   // nothing trainable below layer 0
     // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k], then LN1 backward into the residual stream ----
     RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d)));
-    {
-      GemmDesc g = lin(s.u, S.a_t_qk, s.d_n, M, d, 128);
-      g.residual = s.d_n; g.ldr = d;
-      RC(gemm(st, dt, g));
-    }
+    RC(lora_up(st, dt, s.u, 128, R.q.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+    RC(lora_up(st, dt, at(s.u, 64, dt), 128, R.k.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
     RC(layernorm_bwd(st, dt, s.d_n, S.x_in, L.ln1_w, s.dx, s.dx, M, d, c.ln_eps));
   }
   return UVX_OK;
