@@ -248,7 +248,8 @@ int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* desc);
 int32_t uvx_gemm_force_variant(int32_t variant);
 /* probes (same-box A/B inside bench.py): key 1 = 16-byte epilogue loads/stores (default 1), key 2 = SwiGLU backward fused
  * into the down-projection dgrad GEMM (default 0: measured neutral), key 3 = LM head / CE / head dgrad on the supervised
- * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd) */
+ * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
+ * problems of at most 16 rows (the decode step; default 1) */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* host only (no GPU work): the bf16 GEMM tile variant the cost model picks for this problem */
 int32_t uvx_gemm_pick_variant(int32_t M, int32_t N, int32_t K, int32_t batch);

@@ -409,3 +409,36 @@ def test_gemm_fused_swiglu_epilogues_match_unfused_path(M, I, K):
     dgu = torch.empty(M, 2 * I, device=DEV, dtype=torch.bfloat16)
     ops.gemm(dy, wd_t, out=dgu, epilogue=2, c2=gu_ref)
     assert torch.equal(dgu, dgu_ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 6144, 4096), (5, 100, 64), (16, 1028, 14336), (3, 32, 128)])
+def test_gemm_few_rows_weight_streaming_kernel(M, N, K):
+    """M <= 16 (the decode step) runs the weight-streaming kernel (csrc/gemm_skinny.hip): against torch and against the
+    tiled kernels (option 4 off) with every epilogue the decode path uses."""
+    from ultravox_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(11)
+    a = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+    b = (torch.randn(N, K, device=DEV, generator=g) * 0.1).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g).bfloat16()
+    resid = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    L = _lib.lib()
+    out = ops().gemm(a, b, bias=bias, residual=resid, act="gelu")
+    L.uvx_set_option(4, 0)
+    try:
+        tiled = ops().gemm(a, b, bias=bias, residual=resid, act="gelu")
+        plain_tiled = ops().gemm(a, b)
+    finally:
+        L.uvx_set_option(4, 1)
+    ref = F.gelu((a.float() @ b.float().t() + bias.float()).bfloat16().float()).bfloat16().float() + resid.float()
+    assert rel_l2(out, ref) < 5e-3 and rel_l2(out, tiled) < 5e-3
+    assert rel_l2(ops().gemm(a, b), plain_tiled) < 3e-3
+    if N % 32 == 0:     # fused SwiGLU epilogue (interleaved gate / up packing)
+        act = torch.empty(M, N // 2, device=DEV, dtype=torch.bfloat16)
+        gu = ops().gemm(a, b, epilogue=1, c2=act)
+        L.uvx_set_option(4, 0)
+        try:
+            act_t = torch.empty_like(act)
+            gu_t = ops().gemm(a, b, epilogue=1, c2=act_t)
+        finally:
+            L.uvx_set_option(4, 1)
+        assert rel_l2(gu, gu_t) < 3e-3 and rel_l2(act, act_t) < 6e-3

@@ -1,0 +1,30 @@
+"""GPU probe: generate() at the C2 model size - prefill time and decode ms/token (greedy, B prompts of ~316 positions)."""
+import sys, time
+import torch
+from ultravox_amd.config import UltravoxConfig
+from ultravox_amd.frontend import WhisperFeatureExtractor
+from ultravox_amd.model import UltravoxModel
+from ultravox_amd.synthetic import synthetic_batch
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+new = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+dev = "cuda"
+cfg = UltravoxConfig(audio_model_id="openai/whisper-medium", text_model_id="meta-llama/Meta-Llama-3-8B-Instruct",
+                     hidden_size=4096, stack_factor=8, projector_ln_mid=True, torch_dtype="bfloat16")
+model = UltravoxModel(cfg, device=dev, dtype=torch.bfloat16, seed=0, rope_len=1024, with_backward=False)
+batch = synthetic_batch(cfg, B, 30.0, n_text=128, audio_start=16, n_supervised=32)
+pcm = batch.pop("pcm").to(dev)
+batch.pop("labels")
+mel = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins, device=dev).logmel_device(pcm)
+gb = {k: v.to(dev) for k, v in batch.items()}
+for n in (1, new):       # n = 1: prefill only (+ one argmax); n = new: prefill + (new - 1) decode steps
+    model.generate(audio_values=mel, max_new_tokens=n, eos_token_id=-1, **gb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = model.generate(audio_values=mel, max_new_tokens=n, eos_token_id=-1, **gb)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if n == 1: t_prefill = dt
+    print(f"B={B} max_new_tokens={n}: {dt * 1e3:.1f} ms total, output {tuple(out.shape)}", flush=True)
+print(f"prefill (encoder + projector + LLM prefill) {t_prefill * 1e3:.1f} ms; decode {(dt - t_prefill) / (new - 1) * 1e3:.2f} ms/token "
+      f"= {B * (new - 1) / (dt - t_prefill):.0f} tokens/s at batch {B}")

@@ -28,8 +28,9 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // probe hook (uvx_set_option): [1] epilogue access: 0 = 8-byte fragment layout, 1 = 16 bytes via v_permlane16_swap
 // (-0.5 ms/step at C2), 2 = row-contiguous through LDS (default), [2] SwiGLU backward fused into the
 // dgrad GEMM (off: measured neutral at C2 - the separate elementwise kernel runs at 6.7 TB/s, the fused epilogue is
-// serialised behind each tile's main loop), [3] loss head on the supervised rows only (on)
-int g_options[8] = {0, 2, 0, 1, 0, 0, 0, 0};
+// serialised behind each tile's main loop), [3] loss head on the supervised rows only (on), [4] weight-streaming kernel for
+// M <= 16 (on)
+int g_options[8] = {0, 2, 0, 1, 1, 0, 0, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -1380,6 +1381,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   UVX_CHECK(d.lda % 8 == 0 && d.ldb % 8 == 0, UVX_ERR_SHAPE, "gemm: lda=%d / ldb=%d must be multiples of 8", d.lda, d.ldb);
   UVX_CHECK(!d.residual || d.ldr % 4 == 0, UVX_ERR_SHAPE, "gemm: ldr=%d must be a multiple of 4", d.ldr);
   UVX_CHECK(!d.accumulate || d.out_f32, UVX_ERR_INVALID, "gemm: accumulate needs f32 output");
+  if (uvx::g_gemm_variant < 0 && uvx::gemm_skinny_applicable(d)) return uvx::gemm_skinny_bf16(st, d);   // few rows: stream the weights
   GemmArgs a;
   a.A = (const bf16_t*)d.A; a.B = (const bf16_t*)d.B; a.C = d.C;
   a.bias = (const bf16_t*)d.bias; a.residual = (const bf16_t*)d.residual;

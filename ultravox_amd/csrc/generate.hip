@@ -113,6 +113,105 @@ __global__ void attn_decode_k(const T* __restrict__ qkv, const T* __restrict__ c
   for (int e = 0; e < E; ++e) stf<T>(out + (long long)b * Hq * D + h * D + lane + 64 * e, acc[e] * inv);
 }
 
+// One block per (sequence, KV head): the G query heads that share the KV head are served together (K and V rows are read
+// once), the keys are spread over the block - thread = (key lane, 8-dim chunk) - instead of being walked serially by one
+// wave (255 us per layer at 320 keys; this: a few us).  Three phases: scores -> LDS, softmax statistics, P . V.
+// sc: dynamic LDS, G * len floats.  Probabilities are rounded to the storage type before P . V like the tiled kernels.
+template <typename T, int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_grp_k(const T* __restrict__ qkv, const T* __restrict__ cache_k,
+                                                         const T* __restrict__ cache_v, T* __restrict__ out,
+                                                         const int32_t* __restrict__ kv_start, int Hq, int Hkv, int Tmax,
+                                                         int len, int QKV, float scale) {
+  extern __shared__ float sc[];                 // [G][len]
+  __shared__ float qs[G][D];
+  __shared__ float red[4][G][D];
+  __shared__ float stat[2][G];
+  constexpr int CH = D / 8;                     // 16-byte chunks per row
+  constexpr int KL = 256 / CH;                  // keys in flight per pass
+  const int b = blockIdx.x / Hkv, hk = blockIdx.x % Hkv;
+  const int tid = threadIdx.x, ch = tid % CH, kl = tid / CH, lane = tid & 63, w = tid >> 6;
+  const int j0 = kv_start ? kv_start[b] : 0;
+  const int KVD = Hkv * D;
+  const T* kbase = cache_k + (long long)b * Tmax * KVD + hk * D + ch * 8;
+  const T* vbase = cache_v + (long long)b * Tmax * KVD + hk * D + ch * 8;
+  for (int i = tid; i < G * D; i += 256) qs[i / D][i % D] = ldf<T>(qkv + (long long)b * QKV + (hk * G + i / D) * D + i % D);
+  __syncthreads();
+  float q[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[g][e] = qs[g][ch * 8 + e];
+  // ---- phase 1: scores ----
+  for (int j = j0 + kl; j < len; j += KL) {
+    float kv[8];
+    ld8<T>(kbase + (long long)j * KVD, kv);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += q[g][e] * kv[e];
+#pragma unroll
+      for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o, 64);      // the CH threads of a key are consecutive lanes
+      if (ch == 0) sc[g * len + j] = s * scale;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: softmax statistics (one wave per head, heads round-robin) ----
+  for (int g = w; g < G; g += 4) {
+    float m = -__builtin_huge_valf();
+    for (int j = j0 + lane; j < len; j += 64) m = fmaxf(m, sc[g * len + j]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = j0 + lane; j < len; j += 64) {
+      const float p = rnd<T>(expf(sc[g * len + j] - m));
+      sc[g * len + j] = p;
+      l += p;
+    }
+    l = wave_sum(l);
+    if (lane == 0) stat[0][g] = l;
+  }
+  __syncthreads();
+  // ---- phase 3: P . V ----
+  float acc[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+  for (int j = j0 + kl; j < len; j += KL) {
+    float vv[8];
+    ld8<T>(vbase + (long long)j * KVD, vv);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float p = sc[g * len + j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[g][e] += p * vv[e];
+    }
+  }
+  // fold the key lanes: within a wave (64 / CH key lanes), then across the 4 waves through LDS
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[g][e];
+#pragma unroll
+      for (int o = CH; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      acc[g][e] = v;
+    }
+  if (lane < CH) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[w][g][lane * 8 + e] = acc[g][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < G * D; i += 256) {
+    const int g = i / D, dd = i % D;
+    const float l = stat[0][g];
+    const float o = red[0][g][dd] + red[1][g][dd] + red[2][g][dd] + red[3][g][dd];
+    stf<T>(out + (long long)b * Hq * D + (hk * G + g) * D + dd, l > 0.f ? o / l : 0.f);
+  }
+}
+
 template <typename T>
 __global__ void argmax_k(const T* __restrict__ logits, int64_t* __restrict__ out, int V) {
   __shared__ float bv[256];
@@ -251,7 +350,18 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
     const int nw = B * Hq;
     if (dt == DT_BF16) {
       hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
-      if (dh == 64) hipLaunchKernelGGL((attn_decode_k<bf16_t, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
+      const int G = Hq / Hkv, len = cur_len + 1;
+      const size_t sh = sizeof(float) * (size_t)G * len;
+#define UVX_DEC(DD, GG) hipLaunchKernelGGL((attn_decode_grp_k<bf16_t, DD, GG>), dim3(B * Hkv), dim3(256), sh, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale)
+      if (sh <= 48 * 1024 && dh == 128 && G == 4) UVX_DEC(128, 4);
+      else if (sh <= 48 * 1024 && dh == 128 && G == 8) UVX_DEC(128, 8);
+      else if (sh <= 48 * 1024 && dh == 128 && G == 2) UVX_DEC(128, 2);
+      else if (sh <= 48 * 1024 && dh == 128 && G == 1) UVX_DEC(128, 1);
+      else if (sh <= 48 * 1024 && dh == 64 && G == 4) UVX_DEC(64, 4);
+      else if (sh <= 48 * 1024 && dh == 64 && G == 2) UVX_DEC(64, 2);
+      else if (sh <= 48 * 1024 && dh == 64 && G == 1) UVX_DEC(64, 1);
+#undef UVX_DEC
+      else if (dh == 64) hipLaunchKernelGGL((attn_decode_k<bf16_t, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
       else hipLaunchKernelGGL((attn_decode_k<bf16_t, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
     } else {
       hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);

@@ -53,6 +53,9 @@ extern int g_gemm_ovr_n;
 extern int g_gemm_ovr[32][4];
 // bf16 operands, f32 accumulate (MFMA 16x16x32).
 int gemm_nt(hipStream_t st, const GemmDesc& d);
+// gemm_skinny.hip: weight-streaming kernel for M <= 16 rows (the decode step); gemm_nt dispatches to it
+bool gemm_skinny_applicable(const GemmDesc& d);
+int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d);
 // f32 operands/outputs (parity mode; MFMA 16x16x4 f32).
 int gemm_nt_f32(hipStream_t st, const GemmDesc& d);
 // dispatch on dtype
