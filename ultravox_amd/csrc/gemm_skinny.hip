@@ -20,11 +20,14 @@ struct SkinnyArgs {
   float alpha;
 };
 
+// TILES = 16-column MFMA tiles per block: 2 (needed by the fused SwiGLU: gate block + up block) or 1 (twice the blocks:
+// N = 4096 gives 256 blocks instead of 128, one per CU)
+template <int TILES>
 __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
   __shared__ float red[8][2][64][4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int frow = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.x * 32;
+  const int n0 = blockIdx.x * (16 * TILES);
   const bf16_t* b0 = p.B + (long long)min(n0 + frow, p.N - 1) * p.ldb + fg * 8;
   const bf16_t* b1 = p.B + (long long)min(n0 + 16 + frow, p.N - 1) * p.ldb + fg * 8;
   const bool m_ok = frow < p.M;
@@ -33,31 +36,33 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
   const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
   const int nchunk = p.K / 32;
   int i = w;
-  // 4 chunks per iteration: 12 independent 16-byte loads in flight per lane
-  for (; i + 24 < nchunk; i += 32) {
-    bf16x8_t x[4], u[4], v[4];
+  // UN chunks per iteration: 2-3 x UN independent 16-byte loads in flight per lane (the kernel lives on memory-level parallelism)
+  constexpr int UN = TILES == 2 ? 4 : 8;
+  for (; i + 8 * (UN - 1) < nchunk; i += 8 * UN) {
+    bf16x8_t x[UN], u[UN], v[UN];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < UN; ++t) {
       const int kk = (i + 8 * t) * 32;
       u[t] = *reinterpret_cast<const bf16x8_t*>(b0 + kk);
-      v[t] = *reinterpret_cast<const bf16x8_t*>(b1 + kk);
+      if (TILES == 2) v[t] = *reinterpret_cast<const bf16x8_t*>(b1 + kk);
       x[t] = *reinterpret_cast<const bf16x8_t*>(a0 + kk);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < UN; ++t) {
       const bf16x8_t xx = m_ok ? x[t] : zero;
       acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[t], xx, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v[t], xx, acc1, 0, 0, 0);
+      if (TILES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v[t], xx, acc1, 0, 0, 0);
     }
   }
   for (; i < nchunk; i += 8) {
     const int kk = i * 32;
     const bf16x8_t u = *reinterpret_cast<const bf16x8_t*>(b0 + kk);
-    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(b1 + kk);
+    bf16x8_t v = zero;
+    if (TILES == 2) v = *reinterpret_cast<const bf16x8_t*>(b1 + kk);
     const bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(a0 + kk);
     const bf16x8_t xx = m_ok ? x : zero;
     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u, xx, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, xx, acc1, 0, 0, 0);
+    if (TILES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, xx, acc1, 0, 0, 0);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) { red[w][0][lane][e] = acc0[e]; red[w][1][lane][e] = acc1[e]; }
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
     return;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < TILES; ++j) {
     const int n = n0 + 16 * j + fg * 4;
     if (n >= p.N) continue;
     float v[4];
@@ -136,7 +141,8 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 + (double)d.M * d.N * 2.0);
   if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, 1, 200);
-  hipLaunchKernelGGL(gemm_skinny_bf16_k, dim3((d.N + 31) / 32), dim3(512), 0, st, a);
+  if (d.swiglu || d.N >= 16384) hipLaunchKernelGGL(gemm_skinny_bf16_k<2>, dim3((d.N + 31) / 32), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL(gemm_skinny_bf16_k<1>, dim3((d.N + 15) / 16), dim3(512), 0, st, a);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
