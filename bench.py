@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--audio-lora-r", type=int, default=0,
                     help="train rank-r LoRA on the encoder's q_proj/k_proj too (the reference's release recipe, "
                          "audio_model_lora_config.r = 8); 0 = frozen towers, the BASELINE.json configuration")
+    ap.add_argument("--loss", default="ce", choices=["ce", "kl"],
+                    help="ce = the BASELINE.json configuration; kl = LossFunction.KL_Divergence (the reference's meta_config.yaml "
+                         "default): a text-only teacher pass over alt_input_ids (audio replaced by a 48-token transcript)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: sequential all-reduce + optimizer step (no overlap)")
     ap.add_argument("--opt", default=None, help="probe: 'key=value,...' for uvx_set_option")
     ap.add_argument("--gemm-override", default=None, help="probe: 'MxNxK=variant,...' tile-variant overrides")
@@ -206,6 +209,16 @@ def main():
     fe = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins, device=str(dev))
     batch = synthetic_batch(cfg, B, wl["seconds"], n_text=128, audio_start=16, n_supervised=32, rank=rank)
     pcm = batch.pop("pcm").to(dev)
+    if args.loss == "kl":
+        from ultravox_amd.config import LossConfig, LossFunction
+        model.set_loss_config(LossConfig(loss_function=LossFunction.KL_Divergence))
+        ids, Na = batch["input_ids"], int(batch["audio_token_len"][0])
+        g = torch.Generator().manual_seed(777 + rank)
+        tr = torch.randint(0, cfg.text_config.vocab_size - 1, (B, 48), generator=g)
+        alt = torch.cat([ids[:, :16], tr, ids[:, 16 + Na:]], 1)
+        alt_labels = alt.clone()
+        alt_labels[:, : alt.shape[1] - 32] = -100
+        batch.update(alt_input_ids=alt, alt_attention_mask=torch.ones_like(alt), alt_labels=alt_labels)
     batch = {k: v.to(dev) for k, v in batch.items()}
     T = batch["input_ids"].shape[1]
 
@@ -262,6 +275,7 @@ def main():
             "config": {"workload": wl["name"], "clips_per_gpu": B, "clip_seconds": wl["seconds"], "text_tokens": 128,
                        "seq_len": T, "global_batch": B * world, "parallelism": ("SHARED-GPU TEST MODE " if share_gpu else "") + f"dp{world}" + (" (all-reduce overlapped with the next step's frozen encoder)" if trainer.overlap_comm else ""),
                        "audio_model": wl["audio"], "text_model": wl["text"], "optimizer": "AdamW bf16 state, clip 1.0",
+                       "loss": "cross-entropy" if args.loss == "ce" else "KL distillation (teacher: text-only pass of the same LLM over 176 tokens)",
                        "trainable": "projector" + (f" + encoder LoRA r={args.audio_lora_r} (q_proj, k_proj)" if args.audio_lora_r else ""),
                        "supervised_tokens_per_clip": 32,
                        "loss_head": "LM head + CE on the supervised positions only (identical loss and gradients)"},

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 3
+#define UVX_ABI_VERSION 4
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -197,6 +197,22 @@ int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights
 int32_t uvx_llm_kl_loss(void* stream, const uvx_config_t* cfg, const void* teacher_logits, int64_t teacher_rows,
                         const int32_t* pair_row, const float* pair_w, int32_t B, int32_t T, float temperature,
                         float grad_scale, float* loss, void* workspace, size_t ws_bytes);
+
+/* The same with the LM head restricted to the rows that enter the loss (the prediction / end-of-turn positions: 256 of
+ * 2528 at C2): rows = device list of positions b*T + t, ascending, host-known length.
+ *   uvx_llm_fwd_rows(teacher, rows_t, n_t, logits_rows -> [n_t, vocab], save_for_bwd = 0)
+ *   uvx_llm_fwd_rows(student, rows_s, n_s, NULL, save_for_bwd = 1)         -- compact logits + list stay in `workspace`
+ *   uvx_llm_kl_loss_rows(teacher [n_t, vocab], pair [2][n_s] = index into the teacher's rows or -1, pair_w [2][n_s], ...)
+ *   uvx_llm_bwd_rows(...)
+ * bf16 only. */
+int32_t uvx_llm_fwd_rows(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                         const int64_t* attention_mask, int32_t B, int32_t T, const int32_t* rows, int32_t n_rows,
+                         void* logits_rows, int32_t save_for_bwd, void* workspace, size_t ws_bytes);
+int32_t uvx_llm_kl_loss_rows(void* stream, const uvx_config_t* cfg, const void* teacher_logits_rows, const int32_t* pair,
+                             const float* pair_w, int32_t B, int32_t T, int32_t n_rows, float temperature, float grad_scale,
+                             float* loss, void* workspace, size_t ws_bytes);
+int32_t uvx_llm_bwd_rows(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, int32_t B, int32_t T,
+                         void* d_inputs_embeds, void* workspace, size_t ws_bytes);
 
 /* ---- inference: prefill + KV-cache decode.  Replaces the [3P] HF language_model.generate
  * that UltravoxModel.generate delegates to (ultravox_model.py:398-426) for GREEDY decoding.

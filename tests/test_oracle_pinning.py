@@ -246,3 +246,24 @@ def test_kl_row_pairs_rejects_unpairable_masks():
     alt = torch.full((1, 6), -100); alt[0, 3:6] = 1
     with pytest.raises(ValueError):
         kl_row_pairs(labels, alt, 1.0)
+
+
+@pytest.mark.parametrize("case", KL_CASES)
+def test_kl_compact_pairs_reproduce_reference_loss(golden_dir, case):
+    """The compact operands of uvx_llm_fwd_rows / uvx_llm_kl_loss_rows (student rows, unique teacher rows, partner indices),
+    evaluated with plain torch, give the reference loss."""
+    from ultravox_amd.model import kl_compact_pairs, kl_row_pairs
+    z = np.load(os.path.join(golden_dir, "kl_loss.npz"))
+    g = lambda k: torch.from_numpy(z[f"{case}.{k}"])
+    pr, pw, _ = kl_row_pairs(g("labels"), g("alt_labels"), float(g("eot_loss_weight")))
+    rs, rt, pc, pwc = kl_compact_pairs(pr, pw)
+    assert torch.equal(rs.long(), torch.nonzero((pr >= 0).any(0))[:, 0]) and torch.equal(rt, torch.unique(rt))
+    s = g("student").reshape(-1, g("student").shape[-1])[rs.long()]
+    t = g("teacher").reshape(-1, g("teacher").shape[-1])[rt.long()]
+    tau, tot = float(g("temperature")), 0.0
+    for slot in range(2):
+        for r in range(len(rs)):
+            if pc[slot, r] >= 0:
+                lt = F.log_softmax(t[pc[slot, r]] / tau, -1)
+                tot += pwc[slot, r].item() * (lt.exp() * (lt - F.log_softmax(s[r] / tau, -1))).sum().item()
+    assert abs(tot - float(g("loss"))) <= 2e-6 * max(1.0, abs(float(g("loss"))))

@@ -609,9 +609,14 @@ static int llm_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int T) {
   return UVX_OK;
 }
 
-extern "C" int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
-                               const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T, void* logits,
-                               float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes) {
+__global__ void set_i32_k(int32_t* p, int32_t v) { *p = v; }
+
+// rows != nullptr (uvx_llm_fwd_rows): the LM head is evaluated only for the listed positions (device list, ascending,
+// host-known length); the compact logits stay in the workspace with the list, like the supervised-row CE path.
+static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                       const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T, void* logits,
+                       float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes, const int32_t* rows,
+                       int32_t n_rows, void* logits_rows) {
   RC(check_cfg(cfg));
   UVX_CHECK(w && inputs_embeds && workspace, UVX_ERR_INVALID, "llm_fwd: null argument");
   UVX_CHECK(!labels || loss, UVX_ERR_INVALID, "llm_fwd: labels given but no loss output");
@@ -667,6 +672,18 @@ extern "C" int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_
     if (!last) cur = llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1));
   }
   RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps));
+  if (rows) {
+    UVX_CHECK(dt == DT_BF16, UVX_ERR_UNSUPPORTED, "llm_fwd_rows: bf16 only");
+    UVX_CHECK(n_rows >= 0 && n_rows <= M, UVX_ERR_SHAPE, "llm_fwd_rows: %d rows of %d", n_rows, M);
+    if (n_rows > 0) UVX_HIP(hipMemcpyAsync(s.sup, rows, sizeof(int32_t) * n_rows, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(set_i32_k, dim3(1), dim3(1), 0, st, s.sup + M, n_rows);
+    UVX_LAUNCH_CHECK();
+    if (n_rows == 0) return UVX_OK;
+    RC(gather_rows(st, dt, s.hn, s.sup, M, s.n, D));
+    RC(gemm(st, dt, lin(s.n, w->lm_head, s.logits, n_rows, c.vocab, D)));
+    if (logits_rows) UVX_HIP(hipMemcpyAsync(logits_rows, s.logits, (size_t)n_rows * c.vocab * es, hipMemcpyDeviceToDevice, st));
+    return UVX_OK;
+  }
   if (labels && dt == DT_BF16 && g_options[3]) {
     // Loss path on the SUPERVISED rows only (positions whose next token carries a label): every other row of the
     // logits has zero weight in ForCausalLMLoss and a zero gradient, so the head GEMM, the CE and (uvx_llm_bwd) the
@@ -687,6 +704,38 @@ extern "C" int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_
   return UVX_OK;
 }
 
+extern "C" int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                               const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T, void* logits,
+                               float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes) {
+  return llm_forward(stream, cfg, w, inputs_embeds, attention_mask, labels, B, T, logits, loss, save_for_bwd, workspace, ws_bytes,
+                     nullptr, 0, nullptr);
+}
+
+extern "C" int32_t uvx_llm_fwd_rows(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                                    const int64_t* attention_mask, int32_t B, int32_t T, const int32_t* rows, int32_t n_rows,
+                                    void* logits_rows, int32_t save_for_bwd, void* workspace, size_t ws_bytes) {
+  UVX_CHECK(rows != nullptr, UVX_ERR_INVALID, "llm_fwd_rows: null row list");
+  return llm_forward(stream, cfg, w, inputs_embeds, attention_mask, nullptr, B, T, nullptr, nullptr, save_for_bwd, workspace,
+                     ws_bytes, rows, n_rows, logits_rows);
+}
+
+// KL loss on the compact student rows left by uvx_llm_fwd_rows(save_for_bwd = 1): pair [2][n_rows] = index into the teacher's
+// compact rows (or -1), weights alike; d loss / d logits replaces the compact logits in place.
+extern "C" int32_t uvx_llm_kl_loss_rows(void* stream, const uvx_config_t* cfg, const void* teacher_logits_rows,
+                                        const int32_t* pair, const float* pair_w, int32_t B, int32_t T, int32_t n_rows,
+                                        float temperature, float grad_scale, float* loss, void* workspace, size_t ws_bytes) {
+  RC(check_cfg(cfg));
+  UVX_CHECK(teacher_logits_rows && pair && pair_w && loss && workspace, UVX_ERR_INVALID, "llm_kl_loss_rows: null argument");
+  const uvx_config_t& c = *cfg;
+  if (B == 0 || T == 0) return UVX_OK;
+  Arena a(workspace, ws_bytes);
+  LlmWs s = llm_carve(a, c, B, T, 1);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_kl_loss_rows: workspace %zu < %zu bytes", ws_bytes, a.off);
+  UVX_CHECK(n_rows > 0 && n_rows <= s.M, UVX_ERR_SHAPE, "llm_kl_loss_rows: %d rows of %d", n_rows, s.M);
+  return kl_loss_fwd_bwd((hipStream_t)stream, c.dtype, s.logits, teacher_logits_rows, pair, pair_w, loss, s.ce_scratch + 2,
+                         s.logits, (long long)n_rows, c.vocab, c.vocab, c.vocab, temperature, grad_scale);
+}
+
 extern "C" int32_t uvx_llm_kl_loss(void* stream, const uvx_config_t* cfg, const void* teacher_logits, int64_t teacher_rows,
                                    const int32_t* pair_row, const float* pair_w, int32_t B, int32_t T, float temperature,
                                    float grad_scale, float* loss, void* workspace, size_t ws_bytes) {
@@ -703,9 +752,10 @@ extern "C" int32_t uvx_llm_kl_loss(void* stream, const uvx_config_t* cfg, const 
                          s.logits, (long long)s.M, c.vocab, c.vocab, c.vocab, temperature, grad_scale);
 }
 
-extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
-                               int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace,
-                               size_t ws_bytes) {
+// compact_in_place: the workspace holds d loss / d logits for the compact rows of its row list (uvx_llm_kl_loss_rows)
+static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
+                        int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes,
+                        bool compact_in_place) {
   RC(check_cfg(cfg));
   UVX_CHECK(w && d_inputs_embeds && workspace, UVX_ERR_INVALID, "llm_bwd: null argument");
   const uvx_config_t& c = *cfg;
@@ -720,9 +770,10 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
 
   // d logits (in place over the saved logits), then the frozen head: d_hn = dlogits . W_head
   // (labels == NULL: uvx_llm_kl_loss already replaced the saved logits by their gradient)
-  if (labels && dt == DT_BF16 && g_options[3]) {
+  if (compact_in_place || (labels && dt == DT_BF16 && g_options[3])) {
     // compact supervised rows (see uvx_llm_fwd): d logits in place, head dgrad on those rows, scattered back
-    RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale, s.sup));
+    if (!compact_in_place)
+      RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale, s.sup));
     UVX_HIP(hipMemsetAsync(s.d_hn, 0, (size_t)M * D * esz(dt), st));
     // d_hn[rows] = d logits_c . W_head: few rows x D outputs over K = vocab -> split K for parallelism on the first
     // `cap` compact rows (f32 partials in the not-yet-used d_gu scratch, summed in a fixed order), plain GEMM beyond
@@ -790,6 +841,17 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
     RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_in, L.ln1, s.dx, l == 0 ? d_inputs_embeds : s.dx, nullptr, M, D, c.rms_eps));
   }
   return UVX_OK;
+}
+
+extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
+                               int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace,
+                               size_t ws_bytes) {
+  return llm_backward(stream, cfg, w, labels, B, T, grad_scale, d_inputs_embeds, workspace, ws_bytes, false);
+}
+
+extern "C" int32_t uvx_llm_bwd_rows(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, int32_t B, int32_t T,
+                                    void* d_inputs_embeds, void* workspace, size_t ws_bytes) {
+  return llm_backward(stream, cfg, w, nullptr, B, T, 1.0f, d_inputs_embeds, workspace, ws_bytes, true);
 }
 
 extern "C" int32_t uvx_adamw_clip_step(void* stream, int32_t state_dtype, void* param, float* master, const float* grad,

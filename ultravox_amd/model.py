@@ -72,6 +72,20 @@ def kl_row_pairs(labels: torch.Tensor, alt_labels: torch.Tensor, eot_loss_weight
     return pair_row, pair_w, int(ps.sum())
 
 
+def kl_compact_pairs(pair_row: torch.Tensor, pair_w: torch.Tensor):
+    """kl_row_pairs' [2, B*T] tables reduced to the rows that take part: student rows (ascending), teacher rows
+    (ascending, unique) and, per student row, the INDEX of its partner(s) in the teacher list - the operands of
+    uvx_llm_fwd_rows / uvx_llm_kl_loss_rows."""
+    has = (pair_row >= 0).any(dim=0)
+    rows_s = torch.nonzero(has)[:, 0].to(torch.int32)
+    pr = pair_row[:, has]
+    rows_t = torch.unique(pr[pr >= 0]).to(torch.int32)              # sorted ascending
+    pos = torch.full((int(rows_t.max()) + 1 if rows_t.numel() else 1,), -1, dtype=torch.int32)
+    pos[rows_t.long()] = torch.arange(rows_t.numel(), dtype=torch.int32)
+    pair_c = torch.where(pr >= 0, pos[pr.clamp_min(0).long()], torch.full_like(pr, -1))
+    return rows_s, rows_t, pair_c.contiguous(), pair_w[:, has].contiguous()
+
+
 class UltravoxModel:
     """Same call surface as the reference's UltravoxModel for the hot path (forward / train step)."""
 
@@ -457,6 +471,8 @@ class UltravoxModel:
         dev = self.device
         V = self.config.vocab_size
         pair_row, pair_w, n_pred = kl_row_pairs(labels, alt_labels, self.loss_config.eot_loss_weight)
+        if self.dtype == torch.bfloat16 and not return_logits and n_pred > 0:
+            return self._kl_forward_rows(inputs_embeds, attention_mask, alt_input_ids, alt_attention_mask, pair_row, pair_w)
         # teacher (its own workspace: the student's holds the activations for the backward pass)
         Bt, Tt = alt_input_ids.shape
         student_merge = self._merge_ctx          # the teacher's plain embedding lookup must not replace it
@@ -481,6 +497,38 @@ class UltravoxModel:
             loss = loss + float("nan")       # F.kl_div(reduction="batchmean") over zero rows: 0 / 0
         self._llm_ctx = (B, T, nb, None)     # uvx_llm_bwd(labels = NULL): gradient already in place of the logits
         return CausalLMOutputWithPast(loss=loss[0], logits=out.logits)
+
+    def _kl_forward_rows(self, inputs_embeds, attention_mask, alt_input_ids, alt_attention_mask, pair_row, pair_w):
+        """The KL step with both LM heads restricted to the rows that enter the loss (prediction / end-of-turn positions):
+        identical loss and gradients, ~10x less head and KL-kernel work than full [B, T, V] logits for teacher and student."""
+        l = _lib.lib()
+        dev = self.device
+        V = self.config.vocab_size
+        rows_s, rows_t, pair_c, pw = kl_compact_pairs(pair_row, pair_w)
+        ns, nt = int(rows_s.numel()), int(rows_t.numel())
+        rows_s, rows_t, pair_c, pw = rows_s.to(dev), rows_t.to(dev), pair_c.to(dev), pw.to(dev)
+        Bt, Tt = alt_input_ids.shape
+        student_merge = self._merge_ctx
+        alt_embeds = self._embed_merge(None, alt_input_ids, None, None, None, None, Bt, Tt)
+        self._merge_ctx = student_merge
+        nbt = l.uvx_llm_ws_bytes(C.byref(self._c), Bt, Tt, 0)
+        wst = self._workspace("llm_teacher", nbt)
+        t_logits = self._workspace("teacher_logits", nt * V * 2).view(self.dtype)[: nt * V]
+        am = None if alt_attention_mask is None else alt_attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        check(l.uvx_llm_fwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(alt_embeds.contiguous()), ptr(am), Bt, Tt,
+                                 ptr(rows_t), nt, ptr(t_logits), 0, ptr(wst), C.c_size_t(nbt)), "uvx_llm_fwd_rows")
+        B, T, D = inputs_embeds.shape
+        nb = l.uvx_llm_ws_bytes(C.byref(self._c), B, T, 1)
+        ws = self._workspace("llm", nb)
+        ams = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        check(l.uvx_llm_fwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(ams), B, T,
+                                 ptr(rows_s), ns, None, 1, ptr(ws), C.c_size_t(nb)), "uvx_llm_fwd_rows")
+        loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        check(l.uvx_llm_kl_loss_rows(stream_ptr(), C.byref(self._c), ptr(t_logits), ptr(pair_c), ptr(pw), B, T, ns,
+                                     C.c_float(self.loss_config.kl_temperature), C.c_float(self._kl_grad_scale), ptr(loss),
+                                     ptr(ws), C.c_size_t(nb)), "uvx_llm_kl_loss_rows")
+        self._llm_ctx = (B, T, nb, "rows")        # forward_backward: uvx_llm_bwd_rows
+        return CausalLMOutputWithPast(loss=loss[0], logits=None)
 
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, audio_values: Optional[torch.Tensor] = None,
@@ -551,8 +599,12 @@ class UltravoxModel:
         B, T, nb, lab = self._llm_ctx
         D = self.config.text_config.hidden_size
         d_embeds = torch.empty((B, T, D), device=self.device, dtype=self.dtype)
-        check(l.uvx_llm_bwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, C.c_float(grad_scale),
-                            ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd")
+        if isinstance(lab, str):      # "rows": the compact KL path left d logits for its row list in the workspace
+            check(l.uvx_llm_bwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), B, T, ptr(d_embeds),
+                                     ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_rows")
+        else:
+            check(l.uvx_llm_bwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, C.c_float(grad_scale),
+                                ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd")
         st, tl, B, T, n_items, Na, scratch = self._merge_ctx
         if n_items == 0:
             self.proj_grad.zero_()
