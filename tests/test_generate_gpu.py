@@ -82,3 +82,27 @@ def test_bf16_decode_is_consistent_with_teacher_forced_forward():
     rm = ref.topk(2, -1).values
     clear = (rm[:, 0] - rm[:, 1]) > 5e-2
     assert torch.equal(out[:, T].cpu()[clear], ref.argmax(-1)[clear])
+
+
+def test_sampling_policies():
+    """do_sample: top_k = 1 degenerates to greedy; a seeded generator reproduces the draw; with top_k = 5 every sampled token
+    is among the 5 most likely ones of the teacher-forced distribution at its position."""
+    from test_model_gpu import SMALL
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    cfg = UltravoxConfig(**SMALL)
+    model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=3)
+    ids = torch.randint(3, 500, (2, 12), device=DEV)
+    greedy = model.generate(input_ids=ids, max_new_tokens=8, eos_token_id=-1)
+    k1 = model.generate(input_ids=ids, max_new_tokens=8, eos_token_id=-1, do_sample=True, top_k=1, temperature=0.7)
+    assert torch.equal(greedy, k1)
+    g = torch.Generator(device=DEV)
+    a = model.generate(input_ids=ids, max_new_tokens=8, eos_token_id=-1, do_sample=True, top_k=5, top_p=0.95, generator=g.manual_seed(1))
+    b = model.generate(input_ids=ids, max_new_tokens=8, eos_token_id=-1, do_sample=True, top_k=5, top_p=0.95, generator=g.manual_seed(1))
+    assert torch.equal(a, b)
+    logits = model.forward(input_ids=a[:, :-1]).logits.float()
+    for t in range(12, a.shape[1]):
+        top5 = torch.topk(logits[:, t - 1], 5, dim=-1).indices
+        assert bool((top5 == a[:, t:t + 1]).any(dim=-1).all()), t
+    with pytest.raises(ValueError):
+        model.generate(input_ids=ids, max_new_tokens=2, do_sample=True, temperature=0.0)

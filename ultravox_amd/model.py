@@ -536,12 +536,15 @@ class UltravoxModel:
                  audio_lens: Optional[torch.Tensor] = None, audio_token_len: Optional[torch.Tensor] = None,
                  audio_batch_size: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                  max_new_tokens: int = 20, eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
-                 do_sample: bool = False, **kwargs) -> torch.Tensor:
+                 do_sample: bool = False, temperature: float = 1.0, top_k: Optional[int] = None,
+                 top_p: Optional[float] = None, generator: Optional[torch.Generator] = None, **kwargs) -> torch.Tensor:
         """UltravoxModel.generate (ultravox_model.py:398-426): merged embeddings built ONCE, then the LLM's
         prefill + KV-cache decode loop (greedy).  Returns prompt + generated ids, [B, T + n_new], finished
         sequences padded with pad_token_id like HF's GenerationMixin."""
-        if do_sample or kwargs.get("num_beams", 1) != 1:
-            raise NotImplementedError("only greedy decoding is built (SURVEY.md §8f-1)")
+        if kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("beam search is not built (greedy and sampling are)")
+        if do_sample and not temperature > 0:
+            raise ValueError("`temperature` has to be a strictly positive float for sampling")
         l = _lib.lib()
         dev = self.device
         if audio_values is not None and len(audio_values) > 0:
@@ -571,7 +574,10 @@ class UltravoxModel:
         emb = torch.empty(B, D, device=dev, dtype=self.dtype)
         unfinished = torch.ones(B, device=dev, dtype=torch.bool)
         for step in range(max_new_tokens):
-            check(l.uvx_argmax(stream_ptr(), self.code, ptr(logits), B, V, ptr(nxt)), "uvx_argmax")
+            if do_sample:
+                nxt = self._sample(logits, temperature, top_k, top_p, generator)
+            else:
+                check(l.uvx_argmax(stream_ptr(), self.code, ptr(logits), B, V, ptr(nxt)), "uvx_argmax")
             tok = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
             out.append(tok[:, None])
             unfinished = unfinished & (tok != eos)
@@ -585,6 +591,22 @@ class UltravoxModel:
             check(l.uvx_llm_decode(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(emb), ptr(pos), ptr(kv_start),
                                    ptr(cache), Tmax, T + step, B, ptr(logits), ptr(ws), C.c_size_t(nb)), "uvx_llm_decode")
         return torch.cat(out, dim=1)
+
+    @staticmethod
+    def _sample(logits: torch.Tensor, temperature: float, top_k, top_p, generator) -> torch.Tensor:
+        """HF's sampling policy on the last-position logits (the reference's inference default, infer.py:317-324):
+        TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> multinomial.  Host-side policy on [B, V]."""
+        x = logits.float() / temperature
+        if top_k is not None and top_k > 0:
+            kth = torch.topk(x, min(int(top_k), x.shape[-1]), dim=-1).values[:, -1:]
+            x = x.masked_fill(x < kth, float("-inf"))
+        if top_p is not None and top_p < 1.0:
+            sv, si = torch.sort(x, dim=-1, descending=False)
+            cum = torch.softmax(sv, dim=-1).cumsum(dim=-1)
+            remove = cum <= (1.0 - top_p)
+            remove[:, -1] = False                                  # keep at least the most likely token
+            x = x.masked_fill(remove.scatter(1, si, remove), float("-inf"))
+        return torch.multinomial(torch.softmax(x, dim=-1), 1, generator=generator)[:, 0]
 
     def forward_backward(self, grad_scale: float = 1.0, **batch) -> torch.Tensor:
         """loss = model(**batch).loss; (loss * grad_scale).backward() for the trainable (projector)
