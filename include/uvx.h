@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 4
+#define UVX_ABI_VERSION 5
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -197,6 +197,18 @@ int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights
 int32_t uvx_llm_kl_loss(void* stream, const uvx_config_t* cfg, const void* teacher_logits, int64_t teacher_rows,
                         const int32_t* pair_row, const float* pair_w, int32_t B, int32_t T, float temperature,
                         float grad_scale, float* loss, void* workspace, size_t ws_bytes);
+
+/* LLM under LoRA training (text_model_lora_config.r > 0): uvx_llm_fwd / uvx_llm_bwd with rank-r adapters on q_proj and
+ * k_proj (peft layouts as for the encoder; q: [r, D] / [heads*head_dim, r], k: [r, D] / [kv_heads*head_dim, r]); the backward
+ * also returns their f32 gradients.  uvx_llm_lora_t is the encoder's descriptor type. */
+typedef uvx_encoder_lora_t uvx_llm_lora_t;
+typedef uvx_encoder_lora_grads_t uvx_llm_lora_grads_t;
+int32_t uvx_llm_fwd_lora(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const uvx_llm_lora_t* lora,
+                         const void* inputs_embeds, const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T,
+                         void* logits, float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes);
+int32_t uvx_llm_bwd_lora(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const uvx_llm_lora_t* lora,
+                         const int64_t* labels, int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds,
+                         const uvx_llm_lora_grads_t* grads, void* workspace, size_t ws_bytes);
 
 /* The same with the LM head restricted to the rows that enter the loss (the prediction / end-of-turn positions: 256 of
  * 2528 at C2): rows = device list of positions b*T + t, ascending, host-known length.

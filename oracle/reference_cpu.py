@@ -244,8 +244,11 @@ def _rotate_half(x):
 
 def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
               attention_mask: Optional[torch.Tensor] = None, prefix: str = "language_model.",
-              n_layers: Optional[int] = None, position_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """-> logits [B, T, V] in the dtype of inputs_embeds."""
+              n_layers: Optional[int] = None, position_ids: Optional[torch.Tensor] = None,
+              lora: Optional[dict] = None) -> torch.Tensor:
+    """-> logits [B, T, V] in the dtype of inputs_embeds.  lora = {"scaling": ..}: peft adapters on q_proj / k_proj
+    (text_model_lora_config; keys under `language_model.base_model.model.model.layers.N.self_attn.*`), restated like the
+    encoder's (peft 0.11.1 is not installed: unpinned sub-path)."""
     tc = cfg.text_config
     dt = inputs_embeds.dtype
     B, T, D = inputs_embeds.shape
@@ -266,8 +269,17 @@ def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
     for i in range(L_):
         P = f"model.layers.{i}."
         h = rmsnorm_ref(x, W(P + "input_layernorm.weight"), tc.rms_norm_eps)
-        q = F.linear(h, W(P + "self_attn.q_proj.weight")).view(B, T, Hq, dh).transpose(1, 2)
-        k = F.linear(h, W(P + "self_attn.k_proj.weight")).view(B, T, Hkv, dh).transpose(1, 2)
+        q = F.linear(h, W(P + "self_attn.q_proj.weight"))
+        k = F.linear(h, W(P + "self_attn.k_proj.weight"))
+        if lora is not None:
+            def lo(pj):
+                A = sd[f"{prefix}base_model.model.model.layers.{i}.self_attn.{pj}.lora_A.default.weight"].to(dt)
+                Bm = sd[f"{prefix}base_model.model.model.layers.{i}.self_attn.{pj}.lora_B.default.weight"].to(dt)
+                return F.linear(F.linear(h, A), Bm) * lora["scaling"]
+            q = q + lo("q_proj")
+            k = k + lo("k_proj")
+        q = q.view(B, T, Hq, dh).transpose(1, 2)
+        k = k.view(B, T, Hkv, dh).transpose(1, 2)
         v = F.linear(h, W(P + "self_attn.v_proj.weight")).view(B, T, Hkv, dh).transpose(1, 2)
         q = q * cos + _rotate_half(q) * sin
         k = k * cos + _rotate_half(k) * sin
@@ -335,6 +347,8 @@ class OracleModel:
             self.sd[k].requires_grad_(True)
         r = int((getattr(cfg, "audio_model_lora_config", None) or {}).get("r", 0) or 0)
         self.lora = None if r == 0 else {"scaling": float(cfg.audio_model_lora_config.get("lora_alpha", 8)) / r}
+        rt = int((getattr(cfg, "text_model_lora_config", None) or {}).get("r", 0) or 0)
+        self.text_lora = None if rt == 0 else {"scaling": float(cfg.text_model_lora_config.get("lora_alpha", 8)) / rt}
 
     def projector_params(self):
         P = "multi_modal_projector."
@@ -356,7 +370,7 @@ class OracleModel:
         if audio_values is not None and len(audio_values) > 0:
             _, audio_embeds = self.audio_embeds(audio_values, audio_lens)
             inputs_embeds = merge_ref(inputs_embeds, audio_embeds, audio_token_start_idx, audio_token_len, audio_batch_size)
-        logits = llama_ref(self.sd, self.cfg, inputs_embeds, attention_mask)
+        logits = llama_ref(self.sd, self.cfg, inputs_embeds, attention_mask, lora=self.text_lora)
         loss = causal_lm_loss_ref(logits, labels) if labels is not None else None
         out = {"loss": loss, "logits": logits, "inputs_embeds": inputs_embeds, "audio_embeds": audio_embeds}
         if kl is not None:

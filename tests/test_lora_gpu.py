@@ -113,3 +113,44 @@ def test_lora_with_zero_b_equals_frozen_tower():
     mel = torch.randn(2, 80, 200, device=DEV).bfloat16()
     lens = torch.tensor([200, 150], device=DEV)
     assert torch.equal(m0.audio_tower_forward(mel, lens), m1.audio_tower_forward(mel, lens))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_llm_and_encoder_lora_train_step_matches_oracle(dtype):
+    """text_model_lora_config + audio_model_lora_config together: gradients of the projector, the encoder adapters and the
+    LLM adapters (GQA: k_proj is narrower than q_proj; adapters sit before RoPE) against the oracle's autograd."""
+    from oracle.reference_cpu import OracleModel, synthetic_batch
+    from test_model_gpu import SMALL
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    cfg = UltravoxConfig(**SMALL, audio_model_lora_config={"r": 4}, text_model_lora_config={"r": 8, "lora_alpha": 16})
+    sd = random_state_dict(cfg, seed=41, dtype=dtype)
+    sd.update(init_lora_state_dict(cfg, seed=41, dtype=dtype, random_b=True))
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    nl, ne = cfg.text_config.num_hidden_layers, cfg.audio_config.encoder_layers
+    assert len(oracle.trainable) == 4 + 4 * ne + 4 * nl
+    b = synthetic_batch(cfg, 2, 3.0, n_text=24, audio_start=5, n_supervised=8)
+    pcm = b.pop("pcm")
+    mel = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins).logmel_device(pcm.to(DEV)).to(dtype)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    ref, grads, _ = oracle.train_step({**b, "audio_values": mel.cpu().float()})
+    model.train()
+    loss = model.forward_backward(audio_values=mel, **gb)
+    assert abs(loss.item() - ref["loss"].item()) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(ref["loss"].item())
+    mine = model.projector_grads()
+    assert set(mine) == set(grads)
+    tol = 2e-3 if dtype == torch.float32 else 8e-2
+    for k, g in grads.items():
+        assert g.abs().max().item() > 0, k
+        assert rel_l2(mine[k], g) < tol, k
+    # a text-only batch still trains the LLM adapters; projector / encoder-adapter gradients are exactly zero
+    tb = {k: v for k, v in gb.items() if k in ("input_ids", "attention_mask", "labels")}
+    model.forward_backward(**tb)
+    mine = model.projector_grads()
+    assert mine["multi_modal_projector.linear_1.weight"].abs().max().item() == 0
+    assert mine["language_model.base_model.model.model.layers.0.self_attn.q_proj.lora_B.default.weight"].abs().max().item() > 0
+    with pytest.raises(NotImplementedError):
+        model.generate(input_ids=gb["input_ids"], max_new_tokens=2)

@@ -162,21 +162,21 @@ class UltravoxConfig:
         self.torch_dtype = torch_dtype
         if projector_act != "swiglu":
             raise ValueError("only projector_act='swiglu' (the reference default, ultravox_config.py:126) is built")
-        if self.text_model_lora_config.get("r", 0) != 0:
-            raise ValueError("text_model_lora_config.r != 0: LLM LoRA is outside the built scope "
-                             "(frozen LLM, apply_lora r=0, ultravox_model.py:697-703)")
-        ar = int(self.audio_model_lora_config.get("r", 0) or 0)
-        if ar != 0:     # encoder LoRA (the release configs' audio_model_lora_config: r = 8)
+        # LoRA (apply_lora, ultravox_model.py:690-709): rank-r adapters on q_proj + k_proj (the default target_modules that
+        # exist in Whisper / Llama) of the encoder (the release configs: r = 8) and / or the LLM
+        for name, lc in (("audio", self.audio_model_lora_config), ("text", self.text_model_lora_config)):
+            ar = int(lc.get("r", 0) or 0)
+            if ar == 0:
+                continue
             if not 0 < ar <= 64:
-                raise ValueError(f"audio_model_lora_config.r = {ar}: ranks 1..64 are built")
-            tm = self.audio_model_lora_config.get("target_modules") or ["k_proj", "q_proj", "linear_k", "linear_q"]
+                raise ValueError(f"{name}_model_lora_config.r = {ar}: ranks 1..64 are built")
+            tm = lc.get("target_modules") or ["k_proj", "q_proj", "linear_k", "linear_q"]
             hit = {m for m in tm if m in ("q_proj", "k_proj")}
-            other = {m for m in tm if m in ("v_proj", "out_proj", "fc1", "fc2")}
+            other = {m for m in tm if m in ("v_proj", "out_proj", "o_proj", "fc1", "fc2", "gate_proj", "up_proj", "down_proj")}
             if hit != {"q_proj", "k_proj"} or other:
-                raise ValueError(f"audio_model_lora_config.target_modules = {tm}: only the default q_proj + k_proj "
-                                 "adaptation of the Whisper encoder is built")
-            if self.audio_model_lora_config.get("unfreeze_layers"):
-                raise ValueError("audio_model_lora_config.unfreeze_layers is only used with r = 0 and is not built")
+                raise ValueError(f"{name}_model_lora_config.target_modules = {tm}: only the default q_proj + k_proj adaptation is built")
+            if lc.get("unfreeze_layers"):
+                raise ValueError(f"{name}_model_lora_config.unfreeze_layers is only used with r = 0 and is not built")
         self.extra = kwargs
 
     def to_dict(self) -> Dict[str, Any]:

@@ -169,6 +169,7 @@ ProjWs proj_carve(Arena& a, const uvx_config_t& c, int B, int Te) {
 struct LlmLayerStash {
   void *x_in, *qkv, *o, *x_mid, *gu;
   float* lse;
+  void *t, *bqT, *bkT;   // LLM LoRA (text_model_lora_config): [lora_A_q(n) | lora_A_k(n)] [M, 128]; lora_B^T of q / k
 };
 struct LlmWs {
   LlmLayerStash ls[1];   // layer-0 slot; slot i starts slot_bytes * i later
@@ -182,6 +183,8 @@ struct LlmWs {
   void *dx, *d_hn, *d_act, *d_gu, *d_n, *d_o, *d_qkv, *qT, *kT, *doT;
   float* delta;
   float* dkv_part;
+  void* lu;      // LoRA backward: u = [dq . B_q | dk . B_k] [M, 128]
+  float* lwg;    // lora_wgrad scratch
   int M, Tp, QKV, OD;
 };
 void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
@@ -194,6 +197,9 @@ void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
   s.x_mid = a.take(M * c.llm_d * es);
   s.gu = a.take(M * 2 * c.llm_inter * es);
   s.lse = (float*)a.take(sizeof(float) * (size_t)B * c.llm_heads * T);
+  s.t = a.take(M * 128 * es);
+  s.bqT = a.take((size_t)64 * c.llm_heads * c.llm_head_dim * es);
+  s.bkT = a.take((size_t)64 * c.llm_kv_heads * c.llm_head_dim * es);
 }
 LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
   LlmWs w;
@@ -235,6 +241,8 @@ LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
     w.doT = a.take((size_t)B * c.llm_heads * c.llm_head_dim * w.Tp * es);
     w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.llm_heads * T);
     w.dkv_part = (float*)a.take(sizeof(float) * 2 * M * w.OD);
+    w.lu = a.take(M * 128 * es);
+    w.lwg = (float*)a.take(sizeof(float) * (size_t)lora_wgrad_scratch_floats(w.M, c.llm_d > w.OD ? c.llm_d : w.OD, 64));
   }
   return w;
 }
@@ -244,6 +252,7 @@ LlmLayerStash llm_layer(const LlmWs& w, int slot) {
   const size_t d = w.slot_bytes * slot;
   s.x_in = (char*)s.x_in + d; s.qkv = (char*)s.qkv + d; s.o = (char*)s.o + d;
   s.x_mid = (char*)s.x_mid + d; s.gu = (char*)s.gu + d; s.lse = (float*)((char*)s.lse + d);
+  s.t = (char*)s.t + d; s.bqT = (char*)s.bqT + d; s.bkT = (char*)s.bkT + d;
   return s;
 }
 
@@ -616,7 +625,7 @@ __global__ void set_i32_k(int32_t* p, int32_t v) { *p = v; }
 static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
                        const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T, void* logits,
                        float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes, const int32_t* rows,
-                       int32_t n_rows, void* logits_rows) {
+                       int32_t n_rows, void* logits_rows, const uvx_encoder_lora_t* lora = nullptr) {
   RC(check_cfg(cfg));
   UVX_CHECK(w && inputs_embeds && workspace, UVX_ERR_INVALID, "llm_fwd: null argument");
   UVX_CHECK(!labels || loss, UVX_ERR_INVALID, "llm_fwd: labels given but no loss output");
@@ -643,6 +652,16 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     void* x_out = last ? s.x_final : llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1)).x_in;
     RC(rmsnorm_fwd(st, dt, cur.x_in, L.ln1, s.n, nullptr, M, D, c.rms_eps));
     RC(gemm(st, dt, lin(s.n, L.wqkv, cur.qkv, M, s.QKV, D)));
+    if (lora) {   // peft LoRA on q_proj / k_proj (text_model_lora_config): added to the projections, before RoPE
+      const uvx_enc_lora_layer_t& R = lora->layers[l];
+      const int r = lora->r, qc = Hq * dh, kc = Hkv * dh;
+      RC(lora_transpose(st, dt, R.q.b, cur.bqT, qc, r));
+      RC(lora_transpose(st, dt, R.k.b, cur.bkT, kc, r));
+      RC(lora_down(st, dt, s.n, D, R.q.a, 0, cur.t, 128, M, D, r, 1.0f));
+      RC(lora_down(st, dt, s.n, D, R.k.a, 0, at(cur.t, 64, dt), 128, M, D, r, 1.0f));
+      RC(lora_up(st, dt, cur.t, 128, cur.bqT, 1, cur.qkv, s.QKV, M, qc, r, lora->scaling, 1));
+      RC(lora_up(st, dt, at(cur.t, 64, dt), 128, cur.bkT, 1, at(cur.qkv, (size_t)qc, dt), s.QKV, M, kc, r, lora->scaling, 1));
+    }
     RC(rope_inplace(st, dt, cur.qkv, w->rope_cos_sin, nullptr, M, T, Hq + Hkv, dh, s.QKV, 0));
     RC(heads_transpose(st, dt, at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt), s.vt, B, T, s.Tp, Hkv, dh, s.QKV));
     AttnDesc ad;
@@ -755,7 +774,8 @@ extern "C" int32_t uvx_llm_kl_loss(void* stream, const uvx_config_t* cfg, const 
 // compact_in_place: the workspace holds d loss / d logits for the compact rows of its row list (uvx_llm_kl_loss_rows)
 static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
                         int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes,
-                        bool compact_in_place) {
+                        bool compact_in_place, const uvx_encoder_lora_t* lora = nullptr,
+                        const uvx_encoder_lora_grads_t* lgrads = nullptr) {
   RC(check_cfg(cfg));
   UVX_CHECK(w && d_inputs_embeds && workspace, UVX_ERR_INVALID, "llm_bwd: null argument");
   const uvx_config_t& c = *cfg;
@@ -838,6 +858,21 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     RC(attention_bwd(st, dt, bd));
     RC(rope_inplace(st, dt, s.d_qkv, w->rope_cos_sin, nullptr, M, T, Hq + Hkv, dh, s.QKV, 1));
     RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, D, s.QKV)));
+    if (lora) {   // LoRA gradients of q_proj / k_proj and their contribution to d n1 (rank-r products, lora.hip)
+      const uvx_enc_lora_layer_t& R = lora->layers[l];
+      const uvx_enc_lora_layer_grads_t& G = lgrads->layers[l];
+      const int r = lora->r, qc = Hq * dh, kc = Hkv * dh;
+      void* dk = at(s.d_qkv, (size_t)qc, dt);
+      RC(lora_down(st, dt, s.d_qkv, s.QKV, cur.bqT, 0, s.lu, 128, M, qc, r, lora->scaling));
+      RC(lora_down(st, dt, dk, s.QKV, cur.bkT, 0, at(s.lu, 64, dt), 128, M, kc, r, lora->scaling));
+      RC(rmsnorm_fwd(st, dt, cur.x_in, L.ln1, s.n, nullptr, M, D, c.rms_eps));        // n1 recomputed
+      RC(lora_wgrad(st, dt, s.n, D, s.lu, 128, G.q.a, M, D, r, 0, 1.0f, s.lwg));
+      RC(lora_wgrad(st, dt, s.n, D, at(s.lu, 64, dt), 128, G.k.a, M, D, r, 0, 1.0f, s.lwg));
+      RC(lora_wgrad(st, dt, s.d_qkv, s.QKV, cur.t, 128, G.q.b, M, qc, r, 1, lora->scaling, s.lwg));
+      RC(lora_wgrad(st, dt, dk, s.QKV, at(cur.t, 64, dt), 128, G.k.b, M, kc, r, 1, lora->scaling, s.lwg));
+      RC(lora_up(st, dt, s.lu, 128, R.q.a, 1, s.d_n, D, M, D, r, 1.0f, 1));
+      RC(lora_up(st, dt, at(s.lu, 64, dt), 128, R.k.a, 1, s.d_n, D, M, D, r, 1.0f, 1));
+    }
     RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_in, L.ln1, s.dx, l == 0 ? d_inputs_embeds : s.dx, nullptr, M, D, c.rms_eps));
   }
   return UVX_OK;
@@ -847,6 +882,22 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
                                int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace,
                                size_t ws_bytes) {
   return llm_backward(stream, cfg, w, labels, B, T, grad_scale, d_inputs_embeds, workspace, ws_bytes, false);
+}
+
+// LLM under LoRA training (text_model_lora_config.r > 0, apply_lora on the language model, ultravox_model.py:500-526):
+// the forward adds the adapters to q_proj / k_proj, the backward also returns their gradients.
+extern "C" int32_t uvx_llm_fwd_lora(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const uvx_encoder_lora_t* lora,
+                                    const void* inputs_embeds, const int64_t* attention_mask, const int64_t* labels, int32_t B,
+                                    int32_t T, void* logits, float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes) {
+  UVX_CHECK(lora && lora->layers && lora->r > 0 && lora->r <= 64, UVX_ERR_INVALID, "llm_fwd_lora: bad LoRA descriptor");
+  return llm_forward(stream, cfg, w, inputs_embeds, attention_mask, labels, B, T, logits, loss, save_for_bwd, workspace, ws_bytes,
+                     nullptr, 0, nullptr, lora);
+}
+extern "C" int32_t uvx_llm_bwd_lora(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const uvx_encoder_lora_t* lora,
+                                    const int64_t* labels, int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds,
+                                    const uvx_encoder_lora_grads_t* grads, void* workspace, size_t ws_bytes) {
+  UVX_CHECK(lora && lora->layers && grads && grads->layers, UVX_ERR_INVALID, "llm_bwd_lora: bad LoRA descriptor");
+  return llm_backward(stream, cfg, w, labels, B, T, grad_scale, d_inputs_embeds, workspace, ws_bytes, false, lora, grads);
 }
 
 extern "C" int32_t uvx_llm_bwd_rows(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, int32_t B, int32_t T,

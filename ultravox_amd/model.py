@@ -19,7 +19,8 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .config import LossConfig, LossFunction, UltravoxConfig
-from .weights import LORA_TARGETS, init_lora_state_dict, lora_key, pack_encoder, pack_llm, random_state_dict
+from .weights import (LORA_TARGETS, init_lora_state_dict, llm_lora_key, lora_key, pack_encoder, pack_llm,
+                      random_state_dict)
 
 
 @dataclasses.dataclass
@@ -141,15 +142,18 @@ class UltravoxModel:
         # encoder LoRA: lora_A / lora_B of q_proj and k_proj of every layer join the SAME flat trainable bucket (one
         # all-reduce, one AdamW launch); missing keys get peft's initialisation (A kaiming-uniform, B zero)
         self._lora_names = []
-        if self.lora_r > 0:
+        self.text_lora_r = int(cfg.text_model_lora_config.get("r", 0) or 0)   # LLM LoRA rank (0: frozen LLM)
+        if self.lora_r > 0 or self.text_lora_r > 0:
             init = init_lora_state_dict(cfg, seed=0, dtype=dt)
-            for i in range(a.encoder_layers):
-                for pj in LORA_TARGETS:
-                    for which in "AB":
-                        k = lora_key(i, pj, which)
-                        parts.append(sd[k] if k in sd else init[k])
-                        names.append(k)
-                        self._lora_names.append(k)
+            todo = [(lora_key, a.encoder_layers)] * (self.lora_r > 0) + [(llm_lora_key, t.num_hidden_layers)] * (self.text_lora_r > 0)
+            for keyfn, nl in todo:
+                for i in range(nl):
+                    for pj in LORA_TARGETS:
+                        for which in "AB":
+                            k = keyfn(i, pj, which)
+                            parts.append(sd[k] if k in sd else init[k])
+                            names.append(k)
+                            self._lora_names.append(k)
         sizes = [p.numel() for p in parts]
         pad = [(-s) % 64 for s in sizes]  # keep every view 128-byte aligned
         total = sum(s + p for s, p in zip(sizes, pad))
@@ -178,6 +182,22 @@ class UltravoxModel:
             self._lora.layers = self._lora_layers
             self._lora_grads = _lib.EncoderLoraGrads()
             self._lora_grads.layers = self._lora_grad_layers
+        if self.text_lora_r > 0:
+            nl = t.num_hidden_layers
+            self._tlora_layers = (_lib.EncLoraLayer * nl)()
+            self._tlora_grad_layers = (_lib.EncLoraLayer * nl)()
+            for i in range(nl):
+                for pj, fld in zip(LORA_TARGETS, ("q", "k")):
+                    getattr(self._tlora_layers[i], fld).a = self._proj_views[llm_lora_key(i, pj, "A")].data_ptr()
+                    getattr(self._tlora_layers[i], fld).b = self._proj_views[llm_lora_key(i, pj, "B")].data_ptr()
+                    getattr(self._tlora_grad_layers[i], fld).a = self._grad_views[llm_lora_key(i, pj, "A")].data_ptr()
+                    getattr(self._tlora_grad_layers[i], fld).b = self._grad_views[llm_lora_key(i, pj, "B")].data_ptr()
+            self._tlora = _lib.EncoderLora()
+            self._tlora.r = self.text_lora_r
+            self._tlora.scaling = float(cfg.text_model_lora_config.get("lora_alpha", 8)) / self.text_lora_r
+            self._tlora.layers = self._tlora_layers
+            self._tlora_grads = _lib.EncoderLoraGrads()
+            self._tlora_grads.layers = self._tlora_grad_layers
 
         c = _lib.Config()
         c.dtype = self.code
@@ -423,9 +443,14 @@ class UltravoxModel:
         loss = torch.zeros(1, device=dev, dtype=torch.float32) if labels is not None else None
         lab = None if labels is None else labels.to(device=dev, dtype=torch.int64).contiguous()
         am = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
-        check(l.uvx_llm_fwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(am),
-                            ptr(lab), B, T, ptr(logits), ptr(loss), int(save_for_bwd), ptr(ws), C.c_size_t(nb)),
-              "uvx_llm_fwd")
+        if self.text_lora_r > 0:
+            check(l.uvx_llm_fwd_lora(stream_ptr(), C.byref(self._c), C.byref(self._lw), C.byref(self._tlora),
+                                     ptr(inputs_embeds.contiguous()), ptr(am), ptr(lab), B, T, ptr(logits), ptr(loss),
+                                     int(save_for_bwd), ptr(ws), C.c_size_t(nb)), "uvx_llm_fwd_lora")
+        else:
+            check(l.uvx_llm_fwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(am),
+                                ptr(lab), B, T, ptr(logits), ptr(loss), int(save_for_bwd), ptr(ws), C.c_size_t(nb)),
+                  "uvx_llm_fwd")
         self._llm_ctx = (B, T, nb, lab)
         return CausalLMOutputWithPast(loss=None if loss is None else loss[0], logits=logits)
 
@@ -463,6 +488,8 @@ class UltravoxModel:
         """LossFunction.KL_Divergence (ultravox_model.py:335-345 -> _compute_kl_loss :200-256): a text-only teacher
         pass of the same frozen LLM over alt_input_ids (no_grad), then KL(teacher || student) at kl_temperature over
         the prediction positions plus eot_loss_weight x the end-of-turn positions."""
+        if self.text_lora_r > 0:
+            raise NotImplementedError("KL distillation with an LLM LoRA adapter is not built (the teacher pass would need the adapter disabled)")
         if labels is None:
             raise ValueError("labels must be provided")          # _get_prediction_mask, :178-179
         if alt_input_ids is None or alt_labels is None:
@@ -541,6 +568,9 @@ class UltravoxModel:
         """UltravoxModel.generate (ultravox_model.py:398-426): merged embeddings built ONCE, then the LLM's
         prefill + KV-cache decode loop (greedy).  Returns prompt + generated ids, [B, T + n_new], finished
         sequences padded with pad_token_id like HF's GenerationMixin."""
+        if self.text_lora_r > 0:
+            raise NotImplementedError("generate() with an un-merged LLM LoRA adapter is not built: merge the adapter into the base "
+                                      "weights first (the reference's merge_and_unload, ultravox_model.py:528-559)")
         if kwargs.get("num_beams", 1) != 1:
             raise NotImplementedError("beam search is not built (greedy and sampling are)")
         if do_sample and not temperature > 0:
@@ -624,12 +654,21 @@ class UltravoxModel:
         if isinstance(lab, str):      # "rows": the compact KL path left d logits for its row list in the workspace
             check(l.uvx_llm_bwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), B, T, ptr(d_embeds),
                                      ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_rows")
+        elif self.text_lora_r > 0:
+            check(l.uvx_llm_bwd_lora(stream_ptr(), C.byref(self._c), C.byref(self._lw), C.byref(self._tlora), ptr(lab), B, T,
+                                     C.c_float(grad_scale), ptr(d_embeds), C.byref(self._tlora_grads), ptr(self._ws["llm"]),
+                                     C.c_size_t(nb)), "uvx_llm_bwd_lora")
         else:
             check(l.uvx_llm_bwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, C.c_float(grad_scale),
                                 ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd")
         st, tl, B, T, n_items, Na, scratch = self._merge_ctx
-        if n_items == 0:
-            self.proj_grad.zero_()
+        if n_items == 0:     # text-only batch: no gradient reaches the projector / the encoder adapters
+            if self.text_lora_r > 0:
+                for k, g in self._grad_views.items():
+                    if not k.startswith("language_model."):
+                        g.zero_()
+            else:
+                self.proj_grad.zero_()
             return out.loss
         d_audio = torch.empty((n_items, Na, D), device=self.device, dtype=self.dtype)
         check(l.uvx_merge_embeds_bwd(stream_ptr(), C.byref(self._c), ptr(d_embeds), ptr(st), ptr(tl), B, T, n_items, Na,

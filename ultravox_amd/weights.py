@@ -128,20 +128,32 @@ def lora_key(layer: int, proj: str, which: str, prefix="audio_tower.") -> str:
     return f"{prefix}base_model.model.layers.{layer}.self_attn.{proj}.lora_{which}.default.weight"
 
 
+def llm_lora_key(layer: int, proj: str, which: str, prefix="language_model.") -> str:
+    """peft's name for a LoRA matrix of the wrapped LlamaForCausalLM (whose own `model.` level follows peft's)."""
+    return f"{prefix}base_model.model.model.layers.{layer}.self_attn.{proj}.lora_{which}.default.weight"
+
+
 def init_lora_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32, device="cpu", random_b: bool = False):
     """peft's initialisation: lora_A kaiming-uniform(a = sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)), lora_B zeros
     (random_b: small random B instead, so that tests see non-zero gradients for A too)."""
-    a = cfg.audio_config
-    r, d = int(cfg.audio_model_lora_config["r"]), a.d_model
+    a, t = cfg.audio_config, cfg.text_config
     g = torch.Generator(device=device).manual_seed(seed + 7919)
     out = {}
-    bound = 1.0 / math.sqrt(d)
-    for i in range(a.encoder_layers):
+
+    def add(keyfn, i, pj, r, d_in, d_out):
+        A = (torch.rand(r, d_in, generator=g, device=device) * 2 - 1) / math.sqrt(d_in)
+        B = 0.05 * torch.randn(d_out, r, generator=g, device=device) if random_b else torch.zeros(d_out, r, device=device)
+        out[keyfn(i, pj, "A")] = A.to(dtype)
+        out[keyfn(i, pj, "B")] = B.to(dtype)
+
+    ra = int(cfg.audio_model_lora_config.get("r", 0) or 0)
+    for i in range(a.encoder_layers if ra else 0):
         for pj in LORA_TARGETS:
-            A = (torch.rand(r, d, generator=g, device=device) * 2 - 1) * bound
-            B = 0.05 * torch.randn(d, r, generator=g, device=device) if random_b else torch.zeros(d, r, device=device)
-            out[lora_key(i, pj, "A")] = A.to(dtype)
-            out[lora_key(i, pj, "B")] = B.to(dtype)
+            add(lora_key, i, pj, ra, a.d_model, a.d_model)
+    rt = int(cfg.text_model_lora_config.get("r", 0) or 0)
+    for i in range(t.num_hidden_layers if rt else 0):
+        add(llm_lora_key, i, "q_proj", rt, t.hidden_size, t.num_attention_heads * t.head_dim)
+        add(llm_lora_key, i, "k_proj", rt, t.hidden_size, t.num_key_value_heads * t.head_dim)
     return out
 
 
@@ -190,6 +202,8 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
     t = cfg.text_config
     cv = lambda x: x.to(device=device, dtype=dtype).contiguous()
     tr = lambda x: x.t().contiguous() if with_transposes else None
+    if prefix + "model.embed_tokens.weight" not in sd and prefix + "base_model.model.model.embed_tokens.weight" in sd:
+        prefix = prefix + "base_model.model."          # a peft-wrapped LLM (LoRA checkpoints)
     P = prefix + "model."
     out = {"embed": cv(sd[P + "embed_tokens.weight"]), "norm": cv(sd[P + "norm.weight"]),
            "lm_head": cv(sd[prefix + "lm_head.weight"]), "layers": []}
