@@ -154,3 +154,31 @@ def test_llm_and_encoder_lora_train_step_matches_oracle(dtype):
     assert mine["language_model.base_model.model.model.layers.0.self_attn.q_proj.lora_B.default.weight"].abs().max().item() > 0
     with pytest.raises(NotImplementedError):
         model.generate(input_ids=gb["input_ids"], max_new_tokens=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_merge_and_unload_matches_adapter_forward(dtype):
+    """merge_and_unload folds W += scaling * B A into the packed tower weights: same logits as the adapter forward (up to
+    the rounding of the merged weights in bf16), and generate() works afterwards."""
+    from oracle.reference_cpu import synthetic_batch
+    from test_model_gpu import SMALL
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    cfg = UltravoxConfig(**SMALL, audio_model_lora_config={"r": 4}, text_model_lora_config={"r": 8})
+    sd = random_state_dict(cfg, seed=43, dtype=dtype)
+    sd.update(init_lora_state_dict(cfg, seed=43, dtype=dtype, random_b=True))
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    b = synthetic_batch(cfg, 2, 3.0, n_text=24, audio_start=5, n_supervised=8)
+    pcm = b.pop("pcm")
+    mel = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins).logmel_device(pcm.to(DEV)).to(dtype)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    before = model.forward(audio_values=mel, **gb).logits.float()
+    model.merge_and_unload()
+    assert model.lora_r == 0 and model.text_lora_r == 0 and set(model.projector_state_dict()) == {k for k in model.projector_state_dict() if k.startswith("multi_modal_projector.")}
+    after = model.forward(audio_values=mel, **gb).logits.float()
+    assert rel_l2(after, before) < (1e-5 if dtype == torch.float32 else 2e-2)
+    gen = {k: v for k, v in gb.items() if k != "labels"}
+    out = model.generate(audio_values=mel, max_new_tokens=4, eos_token_id=-1, **gen)
+    assert out.shape[1] == gb["input_ids"].shape[1] + 4

@@ -303,6 +303,36 @@ class UltravoxModel:
         model.keep_params.update(keep)
         return model
 
+    @torch.no_grad()
+    def merge_and_unload(self) -> None:
+        """UltravoxModel.merge_and_unload (ultravox_model.py:528-559; peft's merge): fold every LoRA adapter into the packed
+        base weights, W += scaling * B @ A, and drop the adapters - afterwards the towers run their plain (frozen) kernels, so
+        generate() and the KL teacher pass work on a LoRA-trained model.  The merged towers are not exported back to
+        checkpoint form (the reference then saves them whole via keep_params); inference only."""
+        def fold(w_rows: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scale: float) -> None:
+            w_rows.copy_((w_rows.float() + scale * (B.float() @ A.float())).to(w_rows.dtype))
+        if self.lora_r > 0:
+            d = self.config.audio_config.d_model
+            qs = (d // self.config.audio_config.encoder_attention_heads) ** -0.5      # folded into the packed q rows
+            sc = float(self._lora.scaling)
+            for i, L in enumerate(self._enc["layers"]):
+                fold(L["wqkv"][:d], self._proj_views[lora_key(i, "q_proj", "A")], self._proj_views[lora_key(i, "q_proj", "B")], sc * qs)
+                fold(L["wqkv"][d:2 * d], self._proj_views[lora_key(i, "k_proj", "A")], self._proj_views[lora_key(i, "k_proj", "B")], sc)
+                if L.get("wqkv_t") is not None:
+                    L["wqkv_t"].copy_(L["wqkv"].t())
+            self.lora_r = 0
+        if self.text_lora_r > 0:
+            t = self.config.text_config
+            qc, kc = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim
+            sc = float(self._tlora.scaling)
+            for i, L in enumerate(self._llm["layers"]):
+                fold(L["wqkv"][:qc], self._proj_views[llm_lora_key(i, "q_proj", "A")], self._proj_views[llm_lora_key(i, "q_proj", "B")], sc)
+                fold(L["wqkv"][qc:qc + kc], self._proj_views[llm_lora_key(i, "k_proj", "A")], self._proj_views[llm_lora_key(i, "k_proj", "B")], sc)
+                if L.get("wqkv_t") is not None:
+                    L["wqkv_t"].copy_(L["wqkv"].t())
+            self.text_lora_r = 0
+        self._lora_names = []        # the adapters are gone: only the projector remains trainable / saved
+
     def projector_grads(self) -> Dict[str, torch.Tensor]:
         P = "multi_modal_projector."
         out = {P + "ln_pre.weight": self._grad_views["ln_pre"], P + "linear_1.weight": self._grad_views["linear_1"],
@@ -569,8 +599,8 @@ class UltravoxModel:
         prefill + KV-cache decode loop (greedy).  Returns prompt + generated ids, [B, T + n_new], finished
         sequences padded with pad_token_id like HF's GenerationMixin."""
         if self.text_lora_r > 0:
-            raise NotImplementedError("generate() with an un-merged LLM LoRA adapter is not built: merge the adapter into the base "
-                                      "weights first (the reference's merge_and_unload, ultravox_model.py:528-559)")
+            raise NotImplementedError("generate() with an un-merged LLM LoRA adapter is not built: call merge_and_unload() first "
+                                      "(as the reference does before inference, ultravox_model.py:528-559)")
         if kwargs.get("num_beams", 1) != 1:
             raise NotImplementedError("beam search is not built (greedy and sampling are)")
         if do_sample and not temperature > 0:
