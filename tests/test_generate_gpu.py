@@ -106,3 +106,30 @@ def test_sampling_policies():
         assert bool((top5 == a[:, t:t + 1]).any(dim=-1).all()), t
     with pytest.raises(ValueError):
         model.generate(input_ids=ids, max_new_tokens=2, do_sample=True, temperature=0.0)
+
+
+def test_terminator_list_and_streamer_protocol():
+    """eos_token_id as a list of terminators (infer.py:326-328) and the HF streamer protocol: put(prompt), put(token) per
+    step, end() — and the LocalInference wrapper streaming from the real generate()."""
+    cfg, model, oracle = _build(torch.float32, 23)
+    torch.manual_seed(5)
+    ids = torch.randint(3, 512, (1, 12))
+    free = model.generate(ids.to(DEV), max_new_tokens=8, eos_token_id=-1).cpu()[0, 12:].tolist()
+    stop = free[3]                                    # make the 4th generated token a terminator
+    first = free.index(stop)
+
+    class Rec:
+        def __init__(self):
+            self.puts, self.ended = [], False
+
+        def put(self, v):
+            self.puts.append(v.clone())
+
+        def end(self):
+            self.ended = True
+    rec = Rec()
+    got = model.generate(ids.to(DEV), max_new_tokens=8, eos_token_id=[600, stop], streamer=rec).cpu()
+    assert got[0, 12:].tolist() == free[:first + 1]
+    assert rec.ended and torch.equal(rec.puts[0], ids) and [int(p) for p in rec.puts[1:]] == free[:first + 1]
+    with pytest.raises(NotImplementedError):
+        model.generate(ids.to(DEV), past_key_values=object())

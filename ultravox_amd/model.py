@@ -592,12 +592,16 @@ class UltravoxModel:
                  inputs_embeds: Optional[torch.Tensor] = None, audio_token_start_idx: Optional[torch.Tensor] = None,
                  audio_lens: Optional[torch.Tensor] = None, audio_token_len: Optional[torch.Tensor] = None,
                  audio_batch_size: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
-                 max_new_tokens: int = 20, eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
+                 max_new_tokens: int = 20, eos_token_id=None, pad_token_id: Optional[int] = None,
                  do_sample: bool = False, temperature: float = 1.0, top_k: Optional[int] = None,
-                 top_p: Optional[float] = None, generator: Optional[torch.Generator] = None, **kwargs) -> torch.Tensor:
+                 top_p: Optional[float] = None, generator: Optional[torch.Generator] = None, streamer=None,
+                 **kwargs) -> torch.Tensor:
         """UltravoxModel.generate (ultravox_model.py:398-426): merged embeddings built ONCE, then the LLM's
-        prefill + KV-cache decode loop (greedy).  Returns prompt + generated ids, [B, T + n_new], finished
-        sequences padded with pad_token_id like HF's GenerationMixin."""
+        prefill + KV-cache decode loop (greedy or sampling).  Returns prompt + generated ids, [B, T + n_new], finished
+        sequences padded with pad_token_id like HF's GenerationMixin.  `eos_token_id` may be one id or a list of
+        terminators (infer.py:326-328); `streamer` follows HF's protocol: put(prompt ids), put(new ids) per step, end()."""
+        if kwargs.get("past_key_values") is not None:
+            raise NotImplementedError("generate() from an external KV cache is not built: pass the whole dialogue")
         if self.text_lora_r > 0:
             raise NotImplementedError("generate() with an un-merged LLM LoRA adapter is not built: call merge_and_unload() first "
                                       "(as the reference does before inference, ultravox_model.py:528-559)")
@@ -615,7 +619,9 @@ class UltravoxModel:
         B, T, D = inputs_embeds.shape
         V = self.config.vocab_size
         eos = self.config.text_config.eos_token_id if eos_token_id is None else eos_token_id
-        pad = eos if pad_token_id is None else pad_token_id
+        eos_list = [int(e) for e in eos] if isinstance(eos, (list, tuple)) else [int(eos)]
+        eos_ids = torch.tensor(eos_list, device=dev, dtype=torch.int64)
+        pad = eos_list[0] if pad_token_id is None else pad_token_id
         Tmax = T + max_new_tokens
         if Tmax > self._llm["rope_len"]:
             raise ValueError(f"prompt + max_new_tokens = {Tmax} exceeds the RoPE table ({self._llm['rope_len']})")
@@ -630,6 +636,8 @@ class UltravoxModel:
                                 B, T, ptr(cache), Tmax, ptr(next_pos), ptr(kv_start), ptr(logits), ptr(ws),
                                 C.c_size_t(nb)), "uvx_llm_prefill")
         out = [input_ids.to(dev)]
+        if streamer is not None:
+            streamer.put(input_ids.cpu())
         nxt = torch.empty(B, device=dev, dtype=torch.int64)
         emb = torch.empty(B, D, device=dev, dtype=self.dtype)
         unfinished = torch.ones(B, device=dev, dtype=torch.bool)
@@ -640,7 +648,9 @@ class UltravoxModel:
                 check(l.uvx_argmax(stream_ptr(), self.code, ptr(logits), B, V, ptr(nxt)), "uvx_argmax")
             tok = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
             out.append(tok[:, None])
-            unfinished = unfinished & (tok != eos)
+            if streamer is not None:
+                streamer.put(tok.cpu())
+            unfinished = unfinished & ~torch.isin(tok, eos_ids)
             if step + 1 == max_new_tokens or not bool(unfinished.any()):
                 break
             tok = tok.contiguous()
@@ -650,6 +660,8 @@ class UltravoxModel:
             pos = (next_pos + step).contiguous()
             check(l.uvx_llm_decode(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(emb), ptr(pos), ptr(kv_start),
                                    ptr(cache), Tmax, T + step, B, ptr(logits), ptr(ws), C.c_size_t(nb)), "uvx_llm_decode")
+        if streamer is not None:
+            streamer.end()
         return torch.cat(out, dim=1)
 
     @staticmethod
