@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 5
+#define UVX_ABI_VERSION 6
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -242,6 +242,14 @@ int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
 int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* token_embeds,
                        const int32_t* positions, const int32_t* kv_start, void* kv_cache, int32_t Tmax, int32_t cur_len,
                        int32_t B, void* logits, void* workspace, size_t ws_bytes);
+/* prefill of Tn FURTHER tokens per sequence on top of cur_len cached positions: what HF generate does when handed
+ * past_key_values (infer.py:137-139, 208-213: conversation mode runs only input_ids[:, cache_len:]).  inputs_embeds
+ * [B, Tn, D] (no padding inside the chunk); positions0[b] = RoPE position of the chunk's first token (next_pos[b] + tokens
+ * decoded so far); cache rows [cur_len, cur_len + Tn) are appended; logits of the chunk's last position [B, vocab]. */
+size_t uvx_llm_prefill_chunk_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t Tn, int32_t cur_len);
+int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                              int32_t B, int32_t Tn, void* kv_cache, int32_t Tmax, int32_t cur_len, const int32_t* positions0,
+                              const int32_t* kv_start, void* logits_last, void* workspace, size_t ws_bytes);
 /* out[r] = argmax_v logits[r, v] (lowest index on ties, like torch.argmax) */
 int32_t uvx_argmax(void* stream, int32_t dtype, const void* logits, int32_t rows, int32_t V, int64_t* out);
 

@@ -7,6 +7,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
 def _build(dtype, seed):
     from oracle.reference_cpu import OracleModel
     from test_model_gpu import SMALL
@@ -131,5 +136,60 @@ def test_terminator_list_and_streamer_protocol():
     got = model.generate(ids.to(DEV), max_new_tokens=8, eos_token_id=[600, stop], streamer=rec).cpu()
     assert got[0, 12:].tolist() == free[:first + 1]
     assert rec.ended and torch.equal(rec.puts[0], ids) and [int(p) for p in rec.puts[1:]] == free[:first + 1]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):          # only the KVState generate() itself returned is accepted as a cache
         model.generate(ids.to(DEV), past_key_values=object())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chunked_prefill_over_a_cached_prefix(dtype):
+    """generate(past_key_values=state): only input_ids[:, cur_len:] run (uvx_llm_prefill_chunk) — same tokens (f32) and
+    the same cache contents as a fresh full prefill; left padding, a prefix long enough that whole query blocks are
+    skipped, a grown cache, a 1-token chunk, and the fall-back when the cached ids are no longer a prefix."""
+    cfg, model, oracle = _build(dtype, 24)
+    torch.manual_seed(7)
+    B, T1 = 2, 90
+    ids1 = torch.randint(3, 512, (B, T1))
+    am1 = torch.ones(B, T1, dtype=torch.long)
+    am1[1, :5] = 0
+    ids1[am1 == 0] = 2
+    gen = dict(eos_token_id=-1, return_dict_in_generate=True)
+    out1 = model.generate(ids1.to(DEV), attention_mask=am1.to(DEV), max_new_tokens=6, **gen)
+    st1 = out1.past_key_values
+    assert st1.cur_len == T1 + 5 and st1.tokens.shape == (B, T1 + 5) and model.last_prefill_reused == 0
+    ids2 = torch.cat([out1.sequences.cpu(), torch.randint(3, 512, (B, 70))], 1)
+    am2 = torch.cat([am1, torch.ones(B, ids2.shape[1] - T1, dtype=torch.long)], 1)
+    fresh = model.generate(ids2.to(DEV), attention_mask=am2.to(DEV), max_new_tokens=7, **gen)
+    assert model.last_prefill_reused == 0
+    out2 = model.generate(ids2.to(DEV), attention_mask=am2.to(DEV), max_new_tokens=7, past_key_values=st1, **gen)
+    assert model.last_prefill_reused == T1 + 5
+    st2, stf = out2.past_key_values, fresh.past_key_values
+    assert st2.cur_len == stf.cur_len == ids2.shape[1] + 6 and st2.Tmax == stf.Tmax
+    assert torch.equal(st2.pos_next, stf.pos_next) and torch.equal(st2.kv_start, stf.kv_start)
+
+    def planes(st, upto):   # [L * 2 * B, Tmax, kv width] -> rows [0, upto); row 1's left padding holds don't-care values
+        v = st.cache.view(dtype).view(-1, st.Tmax, cfg.text_config.num_key_value_heads * cfg.text_config.head_dim)
+        v = v[:, :upto].float().clone()
+        v.view(-1, B, upto, v.shape[-1])[:, 1, :5] = 0
+        return v
+    T2 = ids2.shape[1]
+    if dtype == torch.float32:
+        assert torch.equal(out2.sequences, fresh.sequences)
+        assert rel_l2(planes(st2, st2.cur_len), planes(stf, st2.cur_len)) < 1e-5
+    else:                    # bf16: the decoded tokens may part ways on a near-tie, the prompt's rows may not
+        assert rel_l2(planes(st2, T2), planes(stf, T2)) < 2e-2
+    # one single further token on top of the (grown) cache: the last generated id, whose keys / values are not cached yet
+    ids3 = out2.sequences.cpu()
+    T3 = ids3.shape[1]
+    am3 = torch.cat([am2, torch.ones(B, T3 - T2, dtype=torch.long)], 1)
+    fresh3 = model.generate(ids3.to(DEV), attention_mask=am3.to(DEV), max_new_tokens=4, **gen)
+    out3 = model.generate(ids3.to(DEV), attention_mask=am3.to(DEV), max_new_tokens=4, past_key_values=st2, **gen)
+    assert model.last_prefill_reused == st2.cur_len == T3 - 1
+    if dtype == torch.float32:
+        assert torch.equal(out3.sequences, fresh3.sequences)
+    assert rel_l2(planes(out3.past_key_values, T3), planes(fresh3.past_key_values, T3)) < (1e-5 if dtype == torch.float32 else 2e-2)
+    # a prompt that no longer starts with the cached ids: the cache is dropped, not trusted
+    bad = ids2.clone()
+    bad[0, 40] = (bad[0, 40] + 1) % 500 + 3
+    want = model.generate(bad.to(DEV), attention_mask=am2.to(DEV), max_new_tokens=3, eos_token_id=-1)
+    got = model.generate(bad.to(DEV), attention_mask=am2.to(DEV), max_new_tokens=3, eos_token_id=-1, past_key_values=st1)
+    assert model.last_prefill_reused == 0 and torch.equal(got, want)

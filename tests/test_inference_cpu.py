@@ -102,8 +102,23 @@ def test_conversation_mode_carries_the_dialogue():
     inf.update_conversation([])
     with pytest.raises(ValueError):
         inf.infer()
-    with pytest.raises(NotImplementedError):
-        inf.update_conversation([], past_key_values=object())
+
+
+def test_conversation_mode_threads_the_kv_state_through_generate():
+    import types
+    inf, model = make(conversation_mode=True)
+    plain = model.generate
+    model.generate = lambda **kw: types.SimpleNamespace(sequences=plain(**kw), past_key_values=("state", len(model.calls)))
+    inf.infer(VoiceSample.from_prompt("One"))
+    assert model.calls[0]["past_key_values"] is None and model.calls[0]["return_dict_in_generate"] is True
+    assert inf.past_key_values == ("state", 1)
+    list(inf.infer_stream(VoiceSample.from_prompt("Two")))
+    assert model.calls[1]["past_key_values"] == ("state", 1) and inf.past_key_values == ("state", 2)
+    inf.update_conversation([])
+    assert inf.past_key_values is None
+    single, m2 = make()
+    single.infer(VoiceSample.from_prompt("One"))
+    assert "past_key_values" not in m2.calls[0]
 
 
 def test_thinking_content_is_split_off():

@@ -30,7 +30,7 @@ struct AttnArgs {
   const int32_t* kv_start; const int32_t* kv_len;
   int B, T, Tp, Hq, Hkv;
   int ldq, ldk, ldv, ldo;
-  int causal, block;
+  int causal, block, q_begin;
   float sc;  // softmax scale * log2(e)
   // backward
   const bf16_t* dout; const bf16_t* qt; const bf16_t* kt; const bf16_t* dot;
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
   const int qb0 = blockIdx.x * BQ;
+  if (qb0 + BQ <= p.q_begin) return;   // chunked prefill: these query rows belong to the cached prefix (block-uniform exit)
   const int q0 = qb0 + w * QT * 16;
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
@@ -629,7 +630,7 @@ AttnArgs make_args(const uvx::AttnDesc& d) {
   a.o = (bf16_t*)d.o; a.lse = d.lse; a.kv_start = d.kv_start; a.kv_len = d.kv_len;
   a.B = d.B; a.T = d.T; a.Tp = d.Tp; a.Hq = d.Hq; a.Hkv = d.Hkv;
   a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
-  a.causal = d.causal; a.block = d.block;
+  a.causal = d.causal; a.block = d.block; a.q_begin = d.q_begin;
   a.sc = d.scale * LOG2E; a.scale = d.scale;
   return a;
 }

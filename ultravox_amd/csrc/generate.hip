@@ -80,6 +80,31 @@ __global__ void kv_append_k(const T* __restrict__ qkv, T* __restrict__ cache_k, 
   st8<T>(cache_v + dst, v);
 }
 
+// full[b][t][koff + c] = cache_k[b][t][c], full[b][t][koff + KVD + c] = cache_v[b][t][c] for t < Tf: the cached keys / values
+// laid back into the [B, Tf, QKV] row format the prefill attention reads (chunked prefill over a cached prefix)
+template <typename T>
+__global__ void kv_gather_k(const T* __restrict__ cache_k, const T* __restrict__ cache_v, T* __restrict__ full, int B, int Tf,
+                            int Tmax, int QKV, int koff, int KVD) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = KVD / 8;
+  if (i >= (long long)B * Tf * per_row) return;
+  const int c = (int)(i % per_row) * 8;
+  const long long row = i / per_row;
+  const int b = (int)(row / Tf), t = (int)(row % Tf);
+  float k[8], v[8];
+  const long long src = ((long long)b * Tmax + t) * KVD + c;
+  ld8<T>(cache_k + src, k);
+  ld8<T>(cache_v + src, v);
+  st8<T>(full + row * QKV + koff + c, k);
+  st8<T>(full + row * QKV + koff + KVD + c, v);
+}
+
+// RoPE positions of a chunk that continues each sequence: pos[b * Tn + i] = pos0[b] + i
+__global__ void chunk_positions_k(const int32_t* __restrict__ pos0, int32_t* __restrict__ pos, int B, int Tn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * Tn) pos[i] = pos0[i / Tn] + i % Tn;
+}
+
 // One wave per (sequence, query head): q . K^T over the cached keys, online softmax, P . V.
 template <typename T, int D>
 __global__ void attn_decode_k(const T* __restrict__ qkv, const T* __restrict__ cache_k, const T* __restrict__ cache_v,
@@ -327,6 +352,95 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   }
   // logits of the LAST position of every sequence only (what generate() consumes)
   UVX_HIP(hipMemcpy2DAsync(s.last, (size_t)D * es, at(s.x, (size_t)(T - 1) * D, dt), (size_t)T * D * es, (size_t)D * es, B,
+                           hipMemcpyDeviceToDevice, st));
+  RC(rmsnorm_fwd(st, dt, s.last, w->norm, s.hn, nullptr, B, D, c.rms_eps));
+  return gemm(st, dt, lin(s.hn, w->lm_head, logits_last, B, c.vocab, D));
+}
+
+namespace {
+struct ChunkWs { void *fq, *fvt, *fo; int Tfp; };
+InferWs carve_chunk(Arena& a, const uvx_config_t& c, int B, int Tn, int Tf, ChunkWs& k) {
+  InferWs s = carve(a, c, B, Tn);
+  const size_t es = esz(c.dtype);
+  k.Tfp = (Tf + 63) / 64 * 64;
+  k.fq = a.take((size_t)B * Tf * s.QKV * es);
+  k.fvt = a.take((size_t)B * c.llm_kv_heads * c.llm_head_dim * k.Tfp * es);
+  k.fo = a.take((size_t)B * Tf * s.OD * es);
+  return s;
+}
+}  // namespace
+
+extern "C" size_t uvx_llm_prefill_chunk_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_t Tn, int32_t cur_len) {
+  if (!cfg) return 0;
+  Arena a(nullptr, 0);
+  ChunkWs k;
+  carve_chunk(a, *cfg, B, Tn, cur_len + Tn, k);
+  return a.off + 256;
+}
+
+// Prefill of Tn further tokens per sequence on top of `cur_len` cached positions (HF generate(past_key_values=...): only
+// input_ids[:, cur_len:] are run).  GEMMs, norms and the MLP run on the B*Tn new rows only; attention runs the prefill
+// kernel over the whole [B, cur_len + Tn] key range with the query blocks of the prefix skipped (AttnDesc::q_begin): K / V
+// of the prefix are gathered from the cache into the kernel's row layout (a few MB per layer against the GBs of weights
+// the layer streams), the new rows are appended to the cache first so one gather serves both.
+extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                                         int32_t B, int32_t Tn, void* kv_cache, int32_t Tmax, int32_t cur_len,
+                                         const int32_t* positions0, const int32_t* kv_start, void* logits_last, void* workspace,
+                                         size_t ws_bytes) {
+  UVX_CHECK(cfg && w && inputs_embeds && kv_cache && positions0 && logits_last && workspace, UVX_ERR_INVALID,
+            "llm_prefill_chunk: null argument");
+  const uvx_config_t& c = *cfg;
+  const int Tf = cur_len + Tn;
+  UVX_CHECK(Tn >= 1 && cur_len >= 0 && Tf <= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: %d cached + %d new positions exceed the cache length %d",
+            cur_len, Tn, Tmax);
+  UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
+  hipStream_t st = (hipStream_t)stream;
+  Arena a(workspace, ws_bytes);
+  ChunkWs k;
+  InferWs s = carve_chunk(a, c, B, Tn, Tf, k);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_prefill_chunk: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype, D = c.llm_d, M = s.M, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads, KVD = Hkv * dh;
+  const size_t es = esz(dt);
+  hipLaunchKernelGGL(chunk_positions_k, dim3(cdiv(M, 256)), dim3(256), 0, st, positions0, s.pos, B, Tn);
+  UVX_LAUNCH_CHECK();
+  UVX_HIP(hipMemcpyAsync(s.x, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+  UVX_HIP(hipMemsetAsync(k.fq, 0, (size_t)B * Tf * s.QKV * es, st));   // the prefix rows' (skipped) query part stays defined
+  const size_t layer_stride = (size_t)2 * B * Tmax * KVD;  // elements
+  for (int l = 0; l < c.llm_layers; ++l) {
+    const uvx_llm_layer_t& L = w->layers[l];
+    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps));
+    RC(gemm(st, dt, lin(s.n, L.wqkv, s.qkv, M, s.QKV, D)));
+    RC(rope_inplace(st, dt, s.qkv, w->rope_cos_sin, s.pos, M, Tn, Hq + Hkv, dh, s.QKV, 0));
+    char* ck = at(kv_cache, l * layer_stride, dt);
+    char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
+    const long long na = (long long)M * (KVD / 8), ng = (long long)B * Tf * (KVD / 8);
+    if (dt == DT_BF16) {
+      hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(na, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, Tn, Tmax, cur_len, s.QKV, Hq * dh, KVD);
+      hipLaunchKernelGGL(kv_gather_k<bf16_t>, dim3(cdiv(ng, 256)), dim3(256), 0, st, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)k.fq, B, Tf, Tmax, s.QKV, Hq * dh, KVD);
+    } else {
+      hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(na, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, Tn, Tmax, cur_len, s.QKV, Hq * dh, KVD);
+      hipLaunchKernelGGL(kv_gather_k<float>, dim3(cdiv(ng, 256)), dim3(256), 0, st, (const float*)ck, (const float*)cv, (float*)k.fq, B, Tf, Tmax, s.QKV, Hq * dh, KVD);
+    }
+    UVX_LAUNCH_CHECK();
+    for (int b = 0; b < B; ++b)   // the new rows' queries into their place in the full-length layout
+      UVX_HIP(hipMemcpy2DAsync(at(k.fq, ((size_t)b * Tf + cur_len) * s.QKV, dt), (size_t)s.QKV * es, at(s.qkv, (size_t)b * Tn * s.QKV, dt),
+                               (size_t)s.QKV * es, (size_t)Hq * dh * es, Tn, hipMemcpyDeviceToDevice, st));
+    RC(heads_transpose(st, dt, at(k.fq, (size_t)(Hq + Hkv) * dh, dt), k.fvt, B, Tf, k.Tfp, Hkv, dh, s.QKV));
+    AttnDesc ad;
+    ad.q = k.fq; ad.k = at(k.fq, (size_t)Hq * dh, dt); ad.v = at(k.fq, (size_t)(Hq + Hkv) * dh, dt);
+    ad.vt = k.fvt; ad.o = k.fo; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = nullptr;
+    ad.B = B; ad.T = Tf; ad.Tp = k.Tfp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
+    ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.q_begin = cur_len; ad.scale = 1.0f / sqrtf((float)dh);
+    RC(attention_fwd(st, dt, ad));
+    for (int b = 0; b < B; ++b)
+      UVX_HIP(hipMemcpyAsync(at(s.o, (size_t)b * Tn * s.OD, dt), at(k.fo, ((size_t)b * Tf + cur_len) * s.OD, dt), (size_t)Tn * s.OD * es,
+                             hipMemcpyDeviceToDevice, st));
+    GemmDesc g = lin(s.o, L.wo, s.x2, M, D, s.OD);
+    g.residual = s.x; g.ldr = D;
+    RC(gemm(st, dt, g));
+    RC(mlp_block(st, c, L, s, M, s.x2, s.x));
+  }
+  UVX_HIP(hipMemcpy2DAsync(s.last, (size_t)D * es, at(s.x, (size_t)(Tn - 1) * D, dt), (size_t)Tn * D * es, (size_t)D * es, B,
                            hipMemcpyDeviceToDevice, st));
   RC(rmsnorm_fwd(st, dt, s.last, w->norm, s.hn, nullptr, B, D, c.rms_eps));
   return gemm(st, dt, lin(s.hn, w->lm_head, logits_last, B, c.vocab, D));

@@ -133,6 +133,7 @@ struct AttnDesc {
   int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
   int causal = 0;
   int block = 0;  // >0: block-causal "latency" mask, block size in positions
+  int q_begin = 0;  // forward only: query rows below this are not needed (chunked prefill over a cached prefix); blocks wholly below it exit
   float scale = 1.0f;
 };
 int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d);

@@ -3,11 +3,12 @@
 counts out, optional token streaming and a conversation mode that carries the dialogue between calls.
 
 What differs from the reference, on purpose:
-  * conversation mode keeps the past MESSAGES (audio turns replaced by `eos * audio_token_len`, infer.py:74-91) and
-    re-prefills the whole dialogue each turn instead of threading an HF `past_key_values` object through `generate`:
-    `uvx_llm_prefill` owns its KV cache, and a prefix-reusing (chunked) prefill is not built yet — the
-    produced tokens are the same, only the prefill work is not amortised;
-  * `infer_stream` therefore needs one pass, not the reference's two (`:205-223` exist only to snapshot the cache);
+  * `past_key_values` is the `KVState` that `UltravoxModel.generate(return_dict_in_generate=True)` returns (the cache
+    `uvx_llm_prefill` filled, owned by the caller) instead of an HF `Cache`; the next turn runs only the new tokens through
+    `uvx_llm_prefill_chunk`.  `generate` re-checks that the cached ids are still a prefix of the new prompt and falls back
+    to a full prefill when a re-tokenised reply no longer matches (the reference trusts the caller);
+  * `infer_stream` needs one pass, not the reference's two (`:205-223` exist only to snapshot the cache before HF's
+    in-place cache grows; a `KVState`'s rows below `cur_len` are never rewritten);
   * resampling uses scipy's polyphase filter (librosa is not a dependency here).
 """
 import copy
@@ -107,15 +108,15 @@ class LocalInference:
         self.dtype = dtype if dtype is not None else getattr(model, "dtype", torch.bfloat16)
         self.conversation_mode = conversation_mode
         self.past_messages: List[Dict[str, str]] = []
+        self.past_key_values: Any = None
         self.data_collator = DataCollatorForSeq2SeqWithAudio(tokenizer=tokenizer, include_alt_fields=False)
         self.chat_template, self.enable_thinking, self.thinking_regex = chat_template, enable_thinking, thinking_regex
         assert self.tokenizer.padding_side == "left", "batched generation needs a left-padding tokenizer (infer.py:47)"
 
     # ---- conversation state (infer.py:49-91) ----
     def update_conversation(self, past_messages: Optional[List[Dict[str, str]]] = None, past_key_values: Any = None) -> None:
-        if past_key_values is not None:
-            raise NotImplementedError("KV reuse across turns is not built: the dialogue is re-prefilled from past_messages")
         self.past_messages = list(past_messages or [])
+        self.past_key_values = past_key_values
 
     def _get_sample_with_past(self, sample: Optional[VoiceSample]) -> VoiceSample:
         if sample is None:
@@ -185,20 +186,24 @@ class LocalInference:
         return ids
 
     def _generate(self, inputs: Dict[str, torch.Tensor], max_new_tokens: Optional[int] = None,
-                  temperature: Optional[float] = None, streamer=None) -> torch.Tensor:
+                  temperature: Optional[float] = None, streamer=None) -> Tuple[torch.Tensor, Any]:
+        """-> (sequences, past_key_values or None); the cache is requested and threaded through in conversation mode only."""
         args: Dict[str, Any] = {"max_new_tokens": max_new_tokens or MAX_NEW_TOKENS}
         if temperature is not None and temperature > 0:
             args.update(do_sample=True, temperature=temperature)
         else:
             args.update(do_sample=False, top_p=None, top_k=None)
-        return self.model.generate(**inputs, **args, pad_token_id=self.tokenizer.eos_token_id,
-                                   eos_token_id=self._terminators(), streamer=streamer)
+        if self.conversation_mode:
+            args.update(past_key_values=self.past_key_values, return_dict_in_generate=True)
+        out = self.model.generate(**inputs, **args, pad_token_id=self.tokenizer.eos_token_id,
+                                  eos_token_id=self._terminators(), streamer=streamer)
+        return getattr(out, "sequences", out), getattr(out, "past_key_values", None)
 
-    def _remember(self, sample: VoiceSample, inputs: Dict[str, torch.Tensor], response_text: str) -> None:
+    def _remember(self, sample: VoiceSample, inputs: Dict[str, torch.Tensor], response_text: str, past_key_values) -> None:
         if self.conversation_mode:
             atl = inputs.get("audio_token_len")
             n_audio = int(atl.reshape(-1)[0]) if atl is not None and atl.numel() else 0
-            self.update_conversation(self._build_past_messages(sample.messages, n_audio, response_text))
+            self.update_conversation(self._build_past_messages(sample.messages, n_audio, response_text), past_key_values)
 
     # ---- public API (infer.py:125-265) ----
     def infer(self, sample: Optional[VoiceSample] = None, max_tokens: Optional[int] = None,
@@ -206,10 +211,10 @@ class LocalInference:
         extended = self._get_sample_with_past(sample)
         inputs = self._dataproc(extended)
         input_len = inputs["input_ids"].shape[1]
-        sequences = self._generate(inputs, max_tokens, temperature)
+        sequences, past = self._generate(inputs, max_tokens, temperature)
         output_tokens = self._strip(sequences[0][input_len:])
         text, thinking = self._postprocess_response(self.tokenizer.decode(output_tokens, skip_special_tokens=True))
-        self._remember(extended, inputs, text)
+        self._remember(extended, inputs, text, past)
         return VoiceOutput(text, input_len, len(output_tokens), thinking_content=thinking)
 
     def _strip(self, tokens: Sequence[int]) -> List[int]:
@@ -232,7 +237,7 @@ class LocalInference:
         tensors = {k: (v.to(self.model.device) if v is not None else v) for k, v in self.data_collator(inputs).items()}
         input_len = tensors["input_ids"].shape[1]
         out = []
-        for row in self._generate(tensors, max_tokens, temperature):
+        for row in self._generate(tensors, max_tokens, temperature)[0]:
             toks = self._strip(row[input_len:])
             text, thinking = self._postprocess_response(self.tokenizer.decode(toks, skip_special_tokens=True))
             out.append(VoiceOutput(text, input_len, len(toks), thinking_content=thinking))
@@ -245,10 +250,11 @@ class LocalInference:
         input_tokens = inputs["input_ids"].shape[1]
         streamer = _TokenQueueStreamer(self.tokenizer)
         failure: List[BaseException] = []
+        result: List[Any] = [None]
 
         def thunk():
             try:
-                self._generate(inputs, max_tokens, temperature, streamer=streamer)
+                result[0] = self._generate(inputs, max_tokens, temperature, streamer=streamer)[1]
             except BaseException as e:      # surface the failure on the consumer's side, never hang the queue
                 failure.append(e)
                 streamer.end()
@@ -268,5 +274,5 @@ class LocalInference:
         if failure:
             raise failure[0]
         response_text, _ = self._postprocess_response(output_text)
-        self._remember(extended, inputs, response_text)
+        self._remember(extended, inputs, response_text, result[0])
         yield InferenceStats(input_tokens, output_token_len)

@@ -24,6 +24,28 @@ from .weights import (LORA_TARGETS, init_lora_state_dict, llm_lora_key, lora_key
 
 
 @dataclasses.dataclass
+class KVState:
+    """What `generate()` hands back as `past_key_values`: the caller-owned KV cache ([L][2][B][Tmax][kv_heads * head_dim],
+    include/uvx.h) with its bookkeeping.  `tokens` are the ids whose keys / values fill rows [0, cur_len) — a later
+    `generate(input_ids, past_key_values=state)` runs only `input_ids[:, cur_len:]` when its prefix still matches them."""
+    cache: torch.Tensor
+    Tmax: int
+    cur_len: int
+    pos_next: torch.Tensor        # [B] int32: RoPE position of the next token of each sequence
+    kv_start: torch.Tensor        # [B] int32: first real cache row (left padding)
+    tokens: torch.Tensor          # [B, cur_len] int64
+
+    def get_seq_length(self) -> int:
+        return self.cur_len
+
+
+@dataclasses.dataclass
+class GenerateOutput:
+    sequences: torch.Tensor
+    past_key_values: Optional[KVState] = None
+
+
+@dataclasses.dataclass
 class CausalLMOutputWithPast:
     loss: Optional[torch.Tensor] = None
     logits: Optional[torch.Tensor] = None
@@ -600,8 +622,10 @@ class UltravoxModel:
         prefill + KV-cache decode loop (greedy or sampling).  Returns prompt + generated ids, [B, T + n_new], finished
         sequences padded with pad_token_id like HF's GenerationMixin.  `eos_token_id` may be one id or a list of
         terminators (infer.py:326-328); `streamer` follows HF's protocol: put(prompt ids), put(new ids) per step, end()."""
-        if kwargs.get("past_key_values") is not None:
-            raise NotImplementedError("generate() from an external KV cache is not built: pass the whole dialogue")
+        past: Optional[KVState] = kwargs.get("past_key_values")
+        return_dict = bool(kwargs.get("return_dict_in_generate", False))
+        if past is not None and not isinstance(past, KVState):
+            raise TypeError("past_key_values must be the KVState a previous generate(return_dict_in_generate=True) returned")
         if self.text_lora_r > 0:
             raise NotImplementedError("generate() with an un-merged LLM LoRA adapter is not built: call merge_and_unload() first "
                                       "(as the reference does before inference, ultravox_model.py:528-559)")
@@ -625,22 +649,52 @@ class UltravoxModel:
         Tmax = T + max_new_tokens
         if Tmax > self._llm["rope_len"]:
             raise ValueError(f"prompt + max_new_tokens = {Tmax} exceeds the RoPE table ({self._llm['rope_len']})")
-        cache = self._workspace("kv", l.uvx_kv_cache_bytes(C.byref(self._c), B, Tmax))
-        nb = max(l.uvx_llm_infer_ws_bytes(C.byref(self._c), B, T), l.uvx_llm_infer_ws_bytes(C.byref(self._c), B, 1))
+        ids_dev = input_ids.to(dev)
+        am = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        # A cache handed in is reused only while it still describes this prompt's prefix (HF trusts the caller here; a
+        # re-tokenised reply that no longer matches would silently corrupt the dialogue, so it is checked and dropped).
+        P = 0
+        if past is not None and past.tokens.shape[0] == B and 0 < past.cur_len < T \
+                and torch.equal(ids_dev[:, :past.cur_len], past.tokens) \
+                and (am is None or bool(am[:, past.cur_len:].all())):
+            P = past.cur_len
+        self.last_prefill_reused = P
+        own_cache = return_dict or P > 0      # a cache that outlives this call cannot live in the shared workspace
+        cache_bytes = l.uvx_kv_cache_bytes(C.byref(self._c), B, Tmax)
+        if P > 0 and past.Tmax >= Tmax:
+            cache, Tmax = past.cache, past.Tmax
+        else:
+            cache = (torch.empty(cache_bytes, device=dev, dtype=torch.uint8) if own_cache else self._workspace("kv", cache_bytes))
+            if P > 0:                          # grow: rows [0, P) of every (layer, k|v, sequence) plane move over
+                planes = self._c.llm_layers * 2 * B
+                row = cache_bytes // (planes * Tmax)                      # bytes of one position: kv_heads * head_dim elements
+                cache[:cache_bytes].view(planes, Tmax, row)[:, :P].copy_(
+                    past.cache[:planes * past.Tmax * row].view(planes, past.Tmax, row)[:, :P])
+        nb = max(l.uvx_llm_infer_ws_bytes(C.byref(self._c), B, T), l.uvx_llm_infer_ws_bytes(C.byref(self._c), B, 1),
+                 l.uvx_llm_prefill_chunk_ws_bytes(C.byref(self._c), B, T - P, P) if P > 0 else 0)
         ws = self._workspace("infer", nb)
         next_pos = torch.empty(B, device=dev, dtype=torch.int32)
         kv_start = torch.empty(B, device=dev, dtype=torch.int32)
         logits = torch.empty(B, V, device=dev, dtype=self.dtype)
-        am = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
-        check(l.uvx_llm_prefill(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(am),
-                                B, T, ptr(cache), Tmax, ptr(next_pos), ptr(kv_start), ptr(logits), ptr(ws),
-                                C.c_size_t(nb)), "uvx_llm_prefill")
-        out = [input_ids.to(dev)]
+        if P > 0:
+            kv_start = past.kv_start
+            chunk = inputs_embeds[:, P:].contiguous()
+            check(l.uvx_llm_prefill_chunk(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(chunk), B, T - P, ptr(cache),
+                                          Tmax, P, ptr(past.pos_next), ptr(kv_start), ptr(logits), ptr(ws), C.c_size_t(nb)),
+                  "uvx_llm_prefill_chunk")
+            next_pos = past.pos_next + (T - P)
+        else:
+            check(l.uvx_llm_prefill(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(am),
+                                    B, T, ptr(cache), Tmax, ptr(next_pos), ptr(kv_start), ptr(logits), ptr(ws),
+                                    C.c_size_t(nb)), "uvx_llm_prefill")
+        out = [ids_dev]
         if streamer is not None:
             streamer.put(input_ids.cpu())
         nxt = torch.empty(B, device=dev, dtype=torch.int64)
         emb = torch.empty(B, D, device=dev, dtype=self.dtype)
+        offs = torch.empty(B + 1, device=dev, dtype=torch.int32)
         unfinished = torch.ones(B, device=dev, dtype=torch.bool)
+        n_decoded = 0
         for step in range(max_new_tokens):
             if do_sample:
                 nxt = self._sample(logits, temperature, top_k, top_p, generator)
@@ -655,14 +709,20 @@ class UltravoxModel:
                 break
             tok = tok.contiguous()
             check(l.uvx_embed_merge(stream_ptr(), C.byref(self._c), ptr(self._llm["embed"]), ptr(tok), None, None, None,
-                                    None, B, 1, 0, 0, ptr(emb), ptr(torch.empty(B + 1, device=dev, dtype=torch.int32))),
-                  "uvx_embed_merge")
+                                    None, B, 1, 0, 0, ptr(emb), ptr(offs)), "uvx_embed_merge")
             pos = (next_pos + step).contiguous()
             check(l.uvx_llm_decode(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(emb), ptr(pos), ptr(kv_start),
                                    ptr(cache), Tmax, T + step, B, ptr(logits), ptr(ws), C.c_size_t(nb)), "uvx_llm_decode")
+            n_decoded += 1
         if streamer is not None:
             streamer.end()
-        return torch.cat(out, dim=1)
+        sequences = torch.cat(out, dim=1)
+        if not return_dict:
+            return sequences
+        # like HF's cache after generate: every token but the last one produced has its keys / values stored
+        state = KVState(cache=cache, Tmax=Tmax, cur_len=T + n_decoded, pos_next=(next_pos + n_decoded).to(torch.int32).contiguous(),
+                        kv_start=kv_start, tokens=sequences[:, :T + n_decoded].contiguous())
+        return GenerateOutput(sequences=sequences, past_key_values=state)
 
     @staticmethod
     def _sample(logits: torch.Tensor, temperature: float, top_k, top_p, generator) -> torch.Tensor:
