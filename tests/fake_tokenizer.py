@@ -49,7 +49,7 @@ class FakeChatTokenizer(FakeTokenizer):
             ids.append(tid)
         return ids
 
-    def apply_chat_template(self, messages, add_generation_prompt=True, tokenize=False, **kw):
+    def apply_chat_template(self, messages, add_generation_prompt=False, tokenize=False, **kw):
         s = "<|begin_of_text|>" + "".join(f"<|start_header_id|>{m['role']}<|end_header_id|>\n\n{m['content']}<|eot_id|>"
                                            for m in messages)
         return s + ("<|start_header_id|>assistant<|end_header_id|>\n\n" if add_generation_prompt else "")

@@ -15,6 +15,9 @@ What is recorded
                     d loss / d student logits for seeded logits, several eot weights / temperatures / ragged labels.
   diff_state_dict.json — key sets kept by the REFERENCE UltravoxModel.diff_state_dict (ultravox_model.py:565-584) for stub
                     models (trainable / frozen / keep_params / FSDP-wrapped names).
+  dataproc.json   — the REFERENCE UltravoxDataproc._process (ultravox_data_proc.py:46-154, imported with a stub `ultravox.data`
+                    package: its real one needs librosa / soundfile) over the reference processor and FakeChatTokenizer:
+                    input_ids / labels / alt_* for every loss-mask type, alt fields, response truncation, inference mode.
   logmel.npz      — HF WhisperFeatureExtractor (the [3P] K1 arithmetic) on seeded PCM, 80 and 128 mels.
 """
 import json
@@ -255,6 +258,84 @@ def kl_cases():
     print("kl_loss.npz:", [c[0] for c in cases])
 
 
+def _reference_processor(tok):
+    fe = transformers.WhisperFeatureExtractor()
+    ap = type("AP", (), {"feature_extractor": fe, "model_input_names": fe.model_input_names,
+                         "__call__": staticmethod(lambda *a, **k: fe(*a, **k))})()
+    proc = ultravox_processing.UltravoxProcessor.__new__(ultravox_processing.UltravoxProcessor)
+    proc.audio_padding, proc.encoder_ds_factor, proc.stack_factor = "longest", 2, 8
+    proc.audio_placeholder, proc.audio_context_size = "<|audio|>", 3000
+    proc.vocab = tok.get_vocab()
+    proc.audio_token_replacement = tok.eos_token
+    tok.pad_token_id = tok.eos_token_id
+    proc.audio_processor, proc.tokenizer = ap, tok
+    return proc
+
+
+DATAPROC_SAMPLES = {
+    "asr": dict(messages=[{"role": "user", "content": "Transcribe\n<|audio|>"}, {"role": "assistant", "content": "the quick brown fox jumps"}],
+                seconds=1.0, transcript="the quick brown fox jumps"),
+    "system_qa": dict(messages=[{"role": "system", "content": "You are helpful ."}, {"role": "user", "content": "Listen to <|audio|> and answer briefly"},
+                                {"role": "assistant", "content": "it says hello world again and again and again"}],
+                      seconds=3.5, transcript="hello world"),
+    "overflow": dict(messages=[{"role": "user", "content": "<|audio|>"}, {"role": "assistant", "content": "a long recording indeed"}],
+                     seconds=35.0, transcript="thirty five seconds of speech"),
+    "text_only": dict(messages=[{"role": "user", "content": "What is two plus two ?"}, {"role": "assistant", "content": "four"}],
+                      seconds=None, transcript=None),
+    "no_transcript": dict(messages=[{"role": "user", "content": "Hear <|audio|> now"}, {"role": "assistant", "content": "ok"}],
+                          seconds=0.5, transcript=None),
+}
+DATAPROC_CONFIGS = [
+    dict(loss_mask_type="last_assistant"), dict(loss_mask_type="after_audio"), dict(loss_mask_type="all"),
+    dict(loss_mask_type="last_assistant", include_alt_fields=True),
+    dict(loss_mask_type="after_audio", include_alt_fields=True, max_response_tokens=3),
+    dict(loss_mask_type="last_assistant", max_response_tokens=2),
+    dict(loss_mask_type="last_assistant", inference_mode=True),      # raises with audio: the mask text loses its placeholder
+    dict(loss_mask_type="after_audio", inference_mode=True),
+    dict(loss_mask_type="all", inference_mode=True, include_alt_fields=True),
+]
+
+
+def dataproc_sample(name):
+    d = DATAPROC_SAMPLES[name]
+    audio = None
+    if d["seconds"] is not None:
+        audio = np.random.RandomState(len(name)).randn(int(16000 * d["seconds"])).astype(np.float32)
+    return types.SimpleNamespace(messages=[dict(m) for m in d["messages"]], audio=audio, sample_rate=16000,
+                                 audio_transcript=d["transcript"])
+
+
+def dataproc_cases():
+    import ultravox
+    stub = types.ModuleType("ultravox.data")      # the real package imports librosa / soundfile; only these names are used
+    stub.Dataproc = type("Dataproc", (), {"__init__": lambda self, dataset: setattr(self, "_dataset", dataset)})
+    stub.SizedIterableDataset = stub.VoiceSample = stub.Augmentation = object
+    sys.modules["ultravox.data"] = ultravox.data = stub
+    from fake_tokenizer import FakeChatTokenizer
+    from ultravox.model import ultravox_data_proc
+    out = []
+    for cfg in DATAPROC_CONFIGS:
+        for name in DATAPROC_SAMPLES:
+            tok = FakeChatTokenizer(padding_side="right")
+            kw = dict(cfg)
+            kw["loss_mask_type"] = ultravox_config.LossMaskType(kw["loss_mask_type"])
+            dp = ultravox_data_proc.UltravoxDataproc([], _reference_processor(tok), **kw)
+            try:
+                r = dp._process(dataproc_sample(name))
+            except ValueError as e:      # e.g. AFTER_AUDIO on a text-only sample: recorded, the mirror must raise the same
+                out.append({"config": cfg, "sample": name, "error": str(e)})
+                continue
+            rec = {"config": cfg, "sample": name}
+            for k, v in r.items():
+                if k == "audio_values":
+                    rec["audio_values_shape"] = list(v.shape)
+                else:
+                    rec[k] = tolist(v)
+            out.append(rec)
+    json.dump({"cases": out}, open(os.path.join(HERE, "dataproc.json"), "w"), indent=0)
+    print("dataproc.json", len(out), "cases")
+
+
 def diff_state_dict_cases():
     M = ultravox_model.UltravoxModel
     cases = []
@@ -286,3 +367,4 @@ if __name__ == "__main__":
     logmel_cases()
     kl_cases()
     diff_state_dict_cases()
+    dataproc_cases()

@@ -171,11 +171,11 @@ class UltravoxProcessor:
         return list(set(self.tokenizer.model_input_names + self.audio_processor.model_input_names))
 
 
-def _pad_1d(seqs: List[torch.Tensor], value: int, side: str) -> torch.Tensor:
-    n = max(int(s.shape[-1]) for s in seqs)
+def _pad_1d(seqs: List[Any], value: int, side: str) -> torch.Tensor:
+    seqs = [torch.as_tensor(s).reshape(-1) for s in seqs]      # UltravoxDataproc hands labels over as plain lists
+    n = max(int(s.shape[0]) for s in seqs)
     out = []
     for s in seqs:
-        s = torch.as_tensor(s).reshape(-1)
         gap = n - s.shape[0]
         out.append(F.pad(s, (gap, 0) if side == "left" else (0, gap), value=value))
     return torch.stack(out)
