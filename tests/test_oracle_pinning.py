@@ -145,7 +145,8 @@ def test_merge_is_sequential_overwrite():
 @pytest.mark.skipif(not os.path.isdir("/root/reference/ultravox"), reason="reference tree only exists in the build container")
 def test_projector_against_live_reference():
     sys.path.insert(0, "/root/reference")
-    if "peft" not in sys.modules:
+    stubbed = "peft" not in sys.modules
+    if stubbed:
         peft = types.ModuleType("peft")
         peft.LoraConfig = lambda **kw: types.SimpleNamespace(r=kw.get("r", 0))
         peft.PeftModel = type("PeftModel", (), {})
@@ -153,7 +154,13 @@ def test_projector_against_live_reference():
         peft.peft_model = types.ModuleType("peft.peft_model")
         peft.peft_model.PeftModel = peft.PeftModel
         sys.modules["peft"], sys.modules["peft.peft_model"] = peft, peft.peft_model
-    from ultravox.model import ultravox_config, ultravox_model
+    try:
+        from ultravox.model import ultravox_config, ultravox_model
+    finally:
+        if stubbed:      # a spec-less stub left behind breaks transformers' own `find_spec("peft")` probes in later tests
+            sys.modules.pop("peft", None)
+            sys.modules.pop("peft.peft_model", None)
+        sys.path.remove("/root/reference")
     rcfg = ultravox_config.UltravoxConfig(
         audio_config={"model_type": "whisper", "d_model": 64, "encoder_layers": 1, "encoder_attention_heads": 2,
                       "encoder_ffn_dim": 64}, text_config={"model_type": "llama", "hidden_size": 128,

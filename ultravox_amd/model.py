@@ -786,12 +786,18 @@ class UltravoxTrainer:
 
     def __init__(self, model: UltravoxModel, lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, max_grad_norm: float = 1.0, master_weights: bool = False,
-                 gradient_accumulation_steps: int = 1, overlap_comm: bool = False):
+                 gradient_accumulation_steps: int = 1, overlap_comm: bool = False, lr_scheduler: str = "constant",
+                 lr_warmup_steps: float = 0, max_steps: int = 0, lr_scheduler_kwargs: Optional[dict] = None):
+        from .schedule import LRSchedule
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.schedule = LRSchedule(lr, lr_scheduler, lr_warmup_steps, max_steps, lr_scheduler_kwargs)
+        self.last_lr = self.schedule(0)
         self.max_grad_norm = max_grad_norm
         self.step_count = 0
-        self.grad_accum = gradient_accumulation_steps
+        self.grad_accum = max(1, int(gradient_accumulation_steps))
+        self._micro = 0                       # micro-batches since the last optimizer step
+        self._accum = None                    # f32 sum of the (1 / grad_accum)-scaled micro-batch gradients
         self.overlap_comm = overlap_comm
         n = model.proj_flat.numel()
         dev = model.device
@@ -834,12 +840,18 @@ class UltravoxTrainer:
         dp_mean_(self.model.proj_grad)
 
     def optimizer_step(self) -> None:
-        m = self.model
+        """clip + AdamW with the schedule's lr for this step (HF steps its LambdaLR after the optimizer: step k, counted
+        from 0, runs with lr * factor(k))."""
+        self.last_lr = self.schedule(self.step_count)
         self.step_count += 1
+        self._adamw(self.last_lr)
+
+    def _adamw(self, lr: float) -> None:
+        m = self.model
         check(_lib.lib().uvx_adamw_clip_step(
             stream_ptr(), _lib.dtype_code(m.dtype), ptr(m.proj_flat), ptr(self.master), ptr(m.proj_grad),
             ptr(self.exp_avg), ptr(self.exp_avg_sq), C.c_int64(m.proj_flat.numel()), C.c_float(self.max_grad_norm),
-            C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+            C.c_float(lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
             C.c_float(self.wd), self.step_count, ptr(self.scratch)), "uvx_adamw_clip_step")
 
     def grad_norm(self) -> torch.Tensor:
@@ -864,6 +876,21 @@ class UltravoxTrainer:
         finally:
             self.model._before_projector = None
         assert self._pending is None
+        if self.grad_accum > 1:
+            # HF / accelerate: micro-batch losses are divided by gradient_accumulation_steps (train.py:285), gradients add up
+            # locally (DDP no_sync) and ranks synchronise once, at the boundary.  forward_backward overwrites the bucket, so
+            # the running sum lives next to it.
+            self._micro += 1
+            if self._micro == 1:
+                if self._accum is None:
+                    self._accum = torch.empty_like(self.model.proj_grad)
+                self._accum.copy_(self.model.proj_grad)
+            else:
+                self._accum.add_(self.model.proj_grad)
+            if self._micro < self.grad_accum:
+                return loss
+            self.model.proj_grad.copy_(self._accum)
+            self._micro = 0
         if self.overlap_comm and torch.distributed.is_available() and torch.distributed.is_initialized():
             self._pending = torch.distributed.all_reduce(self.model.proj_grad, op=torch.distributed.ReduceOp.SUM, async_op=True)
         else:
