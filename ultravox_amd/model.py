@@ -370,6 +370,10 @@ class UltravoxModel:
     def eval(self):
         return self.train(False)
 
+    def __call__(self, *args, **kwargs) -> "CausalLMOutputWithPast":
+        """`model(**batch)` as the reference's callers write it (validate.py:35, train loop): the forward pass."""
+        return self.forward(*args, **kwargs)
+
     def set_loss_config(self, loss_config: LossConfig):
         self.loss_config = loss_config
 
