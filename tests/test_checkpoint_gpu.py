@@ -108,3 +108,33 @@ def test_overlapped_all_reduce_schedule_is_bit_identical():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_gradient_accumulation_and_schedule_on_the_device():
+    """gradient_accumulation_steps = 2 with a warm-up schedule: two micro-batches, ONE optimizer step whose gradient is the
+    sum of the two (1/2)-scaled micro-batch gradients and whose lr is the schedule's — equal, bit for bit, to doing the
+    same by hand on a second model."""
+    from test_model_gpu import SMALL
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel, UltravoxTrainer
+    from ultravox_amd.weights import random_state_dict
+    cfg = UltravoxConfig(**SMALL)
+    sd = random_state_dict(cfg, seed=6, dtype=torch.bfloat16)
+    b1, b2 = _batch(cfg, 0), _batch(cfg, 1)
+    sched = dict(lr_scheduler="constant_with_warmup", lr_warmup_steps=2)
+    m1 = UltravoxModel(cfg, state_dict=sd, device=DEV)
+    t1 = UltravoxTrainer(m1, lr=2e-3, gradient_accumulation_steps=2, **sched)
+    for _ in range(2):                      # 4 micro-batches = 2 optimizer steps (lr 0, then lr / 2)
+        t1.train_step(**b1)
+        t1.train_step(**b2)
+    assert t1.step_count == 2 and t1.last_lr == pytest.approx(1e-3)
+    m2 = UltravoxModel(cfg, state_dict=sd, device=DEV)
+    t2 = UltravoxTrainer(m2, lr=2e-3, **sched)
+    for _ in range(2):
+        m2.forward_backward(grad_scale=0.5, **b1)
+        g = m2.proj_grad.clone()
+        m2.forward_backward(grad_scale=0.5, **b2)
+        m2.proj_grad.add_(g)
+        t2.optimizer_step()
+    assert torch.equal(m1.proj_flat, m2.proj_flat) and torch.equal(t1.exp_avg, t2.exp_avg)
+    assert not torch.equal(m1.proj_flat, UltravoxModel(cfg, state_dict=sd, device=DEV).proj_flat)     # the second step moved the weights
