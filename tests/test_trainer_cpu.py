@@ -83,3 +83,28 @@ def test_default_trainer_keeps_a_constant_lr_and_steps_every_batch():
     for _ in range(3):
         tr.train_step(x=None)
     assert seen == [3e-4] * 3 and tr.step_count == 3
+
+
+def test_generate_logit_policies_match_the_hf_processors():
+    """Host policies generate() applies to the last-position logits, against the installed transformers' processors:
+    repetition penalty (pipeline default 1.1) and the temperature / top-k / top-p warpers."""
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                         TopKLogitsWarper, TopPLogitsWarper)
+    from ultravox_amd.model import UltravoxModel
+    g = torch.Generator().manual_seed(0)
+    scores = torch.randn(3, 50, generator=g) * 3
+    seen = torch.randint(0, 50, (3, 12), generator=g)
+    want = RepetitionPenaltyLogitsProcessor(1.3)(seen, scores.clone())
+    got = UltravoxModel._repetition_penalty(scores.clone(), seen, 1.3)
+    assert torch.equal(got, want) and not torch.equal(got, scores)
+    # the sampling distribution: same support and probabilities as HF's warper chain
+    x = scores.clone()
+    for w in (TemperatureLogitsWarper(0.7), TopKLogitsWarper(20), TopPLogitsWarper(0.8)):
+        x = w(seen, x)
+    p_want = torch.softmax(x, -1)
+    counts = torch.zeros(3, 50)
+    gen = torch.Generator().manual_seed(1)
+    for _ in range(4000):
+        counts[torch.arange(3), UltravoxModel._sample(scores, 0.7, 20, 0.8, gen)] += 1
+    assert torch.all(counts[p_want == 0] == 0)                       # nothing outside the nucleus is ever drawn
+    assert (counts / 4000 - p_want).abs().max() < 0.04

@@ -5,9 +5,10 @@
 // decode loop over a KV cache.  With an attention_mask HF derives position ids as cumsum(mask) - 1
 // (1 where masked) — left-padded batches (infer.py:155-194) start counting at their first real token.
 //
-// Round-1 scope: correctness-first.  The prefill reuses the training-path kernels; the decode step runs the
-// same GEMM family at M = batch (weight-streaming bound; a dedicated skinny-M kernel is the next step) and a
-// simple one-wave-per-(sequence, head) attention over the cache.
+// The prefill reuses the training-path kernels (no stashes).  The decode step is weight streaming and launch-bound and has
+// its own kernels: gemm_skinny.hip (M <= 16) and attn_decode_grp_k below (one block per sequence and KV head).  A further
+// chunk of tokens on top of a filled cache (conversation turns) goes through uvx_llm_prefill_chunk.
+// KV cache layout: [layer][k | v][B][Tmax][kv_heads * head_dim], caller-owned.
 #include "common.h"
 #include "kernels.h"
 #include "../../include/uvx.h"

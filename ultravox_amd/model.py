@@ -628,6 +628,14 @@ class UltravoxModel:
         terminators (infer.py:326-328); `streamer` follows HF's protocol: put(prompt ids), put(new ids) per step, end()."""
         past: Optional[KVState] = kwargs.get("past_key_values")
         return_dict = bool(kwargs.get("return_dict_in_generate", False))
+        rep = kwargs.get("repetition_penalty")
+        rep = None if rep is None or float(rep) == 1.0 else float(rep)
+        if rep is not None and not rep > 0:
+            raise ValueError(f"`repetition_penalty` has to be a strictly positive float, but is {rep}")
+        ignored = set(kwargs) - {"past_key_values", "return_dict_in_generate", "repetition_penalty", "num_beams", "use_cache"}
+        if ignored:
+            import warnings
+            warnings.warn(f"generate(): these arguments have no effect here: {sorted(ignored)}")
         if past is not None and not isinstance(past, KVState):
             raise TypeError("past_key_values must be the KVState a previous generate(return_dict_in_generate=True) returned")
         if self.text_lora_r > 0:
@@ -700,7 +708,10 @@ class UltravoxModel:
         unfinished = torch.ones(B, device=dev, dtype=torch.bool)
         n_decoded = 0
         for step in range(max_new_tokens):
-            if do_sample:
+            if rep is not None:      # HF order: logits processors on f32 scores first, then the warpers / argmax
+                scores = self._repetition_penalty(logits.float(), torch.cat(out, dim=1), rep)
+                nxt = self._sample(scores, temperature, top_k, top_p, generator) if do_sample else torch.argmax(scores, dim=-1)
+            elif do_sample:
                 nxt = self._sample(logits, temperature, top_k, top_p, generator)
             else:
                 check(l.uvx_argmax(stream_ptr(), self.code, ptr(logits), B, V, ptr(nxt)), "uvx_argmax")
@@ -727,6 +738,15 @@ class UltravoxModel:
         state = KVState(cache=cache, Tmax=Tmax, cur_len=T + n_decoded, pos_next=(next_pos + n_decoded).to(torch.int32).contiguous(),
                         kv_start=kv_start, tokens=sequences[:, :T + n_decoded].contiguous())
         return GenerateOutput(sequences=sequences, past_key_values=state)
+
+    @staticmethod
+    def _repetition_penalty(scores: torch.Tensor, seen_ids: torch.Tensor, penalty: float) -> torch.Tensor:
+        """[3P] HF RepetitionPenaltyLogitsProcessor (the reference's pipeline passes 1.1, ultravox_pipeline.py:100-119): every
+        id already in the sequence — prompt, padding and generated tokens alike — has its score divided by the penalty if
+        positive, multiplied if negative.  scores: f32 [B, V] (modified in place), seen_ids: int64 [B, n]."""
+        s = torch.gather(scores, 1, seen_ids)
+        s = torch.where(s < 0, s * penalty, s / penalty)
+        return scores.scatter_(1, seen_ids, s)
 
     @staticmethod
     def _sample(logits: torch.Tensor, temperature: float, top_k, top_p, generator) -> torch.Tensor:
