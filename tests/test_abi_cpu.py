@@ -83,3 +83,40 @@ def test_header_is_plain_c99_and_links_from_c(tmp_path):
     assert out.returncode == 0, out.stderr
     ver, variant = out.stdout.split()
     assert int(ver) == _lib.ABI_VERSION and int(variant) > 0
+
+
+def test_product_fails_loudly_without_the_library_and_never_imports_the_oracle(monkeypatch, tmp_path):
+    """No CPU fallback: a missing libuvx.so is an error at the first device call, and nothing under ultravox_amd/ (or
+    bench.py outside its cpu_baseline leg) reaches into oracle/ (which is test infrastructure)."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_LIB_PATH", tmp_path / "libuvx.so")
+    with pytest.raises(_lib.UvxError, match="no CPU fallback"):
+        _lib.lib()
+    from ultravox_amd import ops
+    import torch
+    with pytest.raises(_lib.UvxError):
+        ops.gemm(torch.zeros(16, 64), torch.zeros(16, 64))
+    monkeypatch.undo()
+    assert _lib.lib().uvx_abi_version() == _lib.ABI_VERSION
+    import ast
+    pkg = os.path.join(ROOT, "ultravox_amd")
+    for name in sorted(os.listdir(pkg)):
+        if not name.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, name)).read())
+        for node in ast.walk(tree):
+            mods = [a.name for a in node.names] if isinstance(node, ast.Import) else \
+                   [node.module or ""] if isinstance(node, ast.ImportFrom) else []
+            assert not any(m == "oracle" or m.startswith("oracle.") for m in mods), f"{name} imports the oracle"
+    for src in ("include/uvx.h",) + tuple(os.path.join("ultravox_amd/csrc", f) for f in os.listdir(os.path.join(pkg, "csrc")) if f.endswith((".hip", ".h"))):
+        assert "oracle" not in open(os.path.join(ROOT, src)).read().lower(), src
+    # bench.py: the oracle is imported inside the cpu_baseline function only
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            mods = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ""]
+            assert not any(m.startswith("oracle") for m in mods), "bench.py imports the oracle at module level"
+    users = [n.name for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)
+             and any(isinstance(x, (ast.Import, ast.ImportFrom)) and "oracle" in (getattr(x, "module", None) or "".join(a.name for a in x.names))
+                     for x in ast.walk(n))]
+    assert users and all("cpu" in u.lower() or "baseline" in u.lower() for u in users), users
