@@ -7,6 +7,10 @@ What differs from the reference, on purpose:
     `uvx_llm_prefill` filled, owned by the caller) instead of an HF `Cache`; the next turn runs only the new tokens through
     `uvx_llm_prefill_chunk`.  `generate` re-checks that the cached ids are still a prefix of the new prompt and falls back
     to a full prefill when a re-tokenised reply no longer matches (the reference trusts the caller);
+    As in the reference, the cache is what keeps an earlier AUDIO turn audible: the past message holds only
+    `eos * audio_token_len` placeholders, the cached keys / values of those positions were computed from the audio
+    embeddings.  A dropped cache (mismatching prefix) therefore degrades old audio turns to placeholders — reusing the
+    longest common prefix instead of all-or-nothing is the planned refinement (DESIGN.md §6.1);
   * `infer_stream` needs one pass, not the reference's two (`:205-223` exist only to snapshot the cache before HF's
     in-place cache grows; a `KVState`'s rows below `cur_len` are never rewritten);
   * resampling uses scipy's polyphase filter (librosa is not a dependency here).
