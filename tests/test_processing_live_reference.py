@@ -16,7 +16,8 @@ from oracle.reference_cpu import FeatureExtractorRef
 from ultravox_amd.processing import UltravoxProcessor
 
 REF = "/root/reference"
-pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "ultravox")), reason="reference tree only exists in the build container")
+pytestmark = [pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "ultravox")), reason="reference tree only exists in the build container"),
+              pytest.mark.filterwarnings("ignore::DeprecationWarning")]      # the reference's own numpy-2 deprecations
 
 # lengths in samples: around the 2-hop minimum, hop boundaries, 1 s, and the 30 s chunk boundary (480000) incl. multi-chunk
 LENGTHS = [0, 1, 159, 160, 161, 319, 320, 321, 4000, 16000, 16001, 47999, 479840, 480000, 480001, 480160, 560000, 960000, 960001]
