@@ -120,3 +120,26 @@ def test_product_fails_loudly_without_the_library_and_never_imports_the_oracle(m
              and any(isinstance(x, (ast.Import, ast.ImportFrom)) and "oracle" in (getattr(x, "module", None) or "".join(a.name for a in x.names))
                      for x in ast.walk(n))]
     assert users and all("cpu" in u.lower() or "baseline" in u.lower() for u in users), users
+
+
+def test_tile_picker_never_selects_a_probe_only_variant():
+    """uvx_gemm_pick_variant is host-only: over random problem sizes the cost model must stay inside the production tile
+    variants (probe-only ones — MFMA-less / DMA-less decomposition builds, the persistent and q4 experiments — carry speed 0),
+    and at the C2 hot shapes it must take the eight-phase family."""
+    import random
+    lib = _lib.lib()
+    production = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 15, 16, 17, 18}
+    probe_only = {9, 12, 13, 14} | set(range(19, 27))
+    rnd = random.Random(0)
+    seen = set()
+    for _ in range(4000):
+        M = rnd.choice([1, 17, 64, 188, 316, 1264, 1504, 2528, 6000, 12000, rnd.randint(1, 20000)])
+        N = rnd.choice([64, 1024, 2048, 3072, 4096, 6144, 8192, 14336, 28672, 128256, 8 * rnd.randint(1, 4000)])
+        K = 64 * rnd.randint(1, 448)
+        v = lib.uvx_gemm_pick_variant(M, N, K, rnd.choice([1, 1, 1, 8, 128]))
+        assert v in production and v not in probe_only, (M, N, K, v)
+        seen.add(v)
+    assert len(seen) >= 4                                   # the model does discriminate between tiles
+    for (M, N, K) in [(2528, 28672, 4096), (2528, 4096, 14336), (2528, 6144, 4096), (2528, 4096, 4096),
+                      (12000, 3072, 1024), (12000, 4096, 1024), (12000, 1024, 4096)]:
+        assert lib.uvx_gemm_pick_variant(M, N, K, 1) in {11, 15, 16, 17, 18}, (M, N, K)
