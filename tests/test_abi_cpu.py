@@ -143,3 +143,28 @@ def test_tile_picker_never_selects_a_probe_only_variant():
     for (M, N, K) in [(2528, 28672, 4096), (2528, 4096, 14336), (2528, 6144, 4096), (2528, 4096, 4096),
                       (12000, 3072, 1024), (12000, 4096, 1024), (12000, 1024, 4096)]:
         assert lib.uvx_gemm_pick_variant(M, N, K, 1) in {11, 15, 16, 17, 18}, (M, N, K)
+
+
+def test_every_entry_point_survives_an_all_null_call():
+    """The boundary never crashes on garbage: called with all-zero arguments (null config, null buffers, zero sizes) every
+    status-returning entry point either reports an argument / shape error through uvx_last_error or is a no-op on the empty
+    problem — before any GPU work, so this runs without a device."""
+    lib = _lib.lib()
+    skip = {"uvx_last_error", "uvx_abi_version", "uvx_set_option", "uvx_gemm_pick_variant", "uvx_gemm_override_variant",
+            "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records"}
+    rejected = 0
+    for name in _lib.EXPORTS:
+        if name in skip:
+            continue
+        f = getattr(ctypes.CDLL(lib._name), name)      # a fresh handle: no argtypes, so 24 zero words fit any signature
+        if name.endswith("_bytes"):
+            f.restype = ctypes.c_size_t
+            assert f(*([ctypes.c_void_p(0)] * 8)) == 0, name
+            continue
+        f.restype = ctypes.c_int32
+        rc = f(*([ctypes.c_void_p(0)] * 24))
+        assert rc in (0, -1, -2), (name, rc)
+        if rc != 0:
+            rejected += 1
+            assert lib.uvx_last_error(), name
+    assert rejected >= 20
