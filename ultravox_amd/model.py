@@ -27,7 +27,10 @@ from .weights import (LORA_TARGETS, init_lora_state_dict, llm_lora_key, lora_key
 class KVState:
     """What `generate()` hands back as `past_key_values`: the caller-owned KV cache ([L][2][B][Tmax][kv_heads * head_dim],
     include/uvx.h) with its bookkeeping.  `tokens` are the ids whose keys / values fill rows [0, cur_len) — a later
-    `generate(input_ids, past_key_values=state)` runs only `input_ids[:, cur_len:]` when its prefix still matches them."""
+    `generate(input_ids, past_key_values=state)` runs only `input_ids[:, cur_len:]` when its prefix still matches them.
+    Like HF's in-place caches, a state is CONSUMED by the call it is handed to: the call may append to the same buffer
+    (rows below `cur_len` are never rewritten, so the old state stays readable, but two continuations of one state would
+    share - and overwrite - the rows above it).  Branch a dialogue from `copy.deepcopy(state)`."""
     cache: torch.Tensor
     Tmax: int
     cur_len: int
