@@ -129,7 +129,7 @@ def test_tile_picker_never_selects_a_probe_only_variant():
     import random
     lib = _lib.lib()
     production = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 15, 16, 17, 18}
-    probe_only = {9, 12, 13, 14} | set(range(19, 27))
+    probe_only = {9, 12, 13, 14} | set(range(19, 28))
     rnd = random.Random(0)
     seen = set()
     for _ in range(4000):

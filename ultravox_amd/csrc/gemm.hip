@@ -767,7 +767,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
 // the DMA runs NS-1 tiles ahead: phase 1 issues XB of tile t+NS-1, phases 2-4 [XA | WA | WB] of tile t+NS, and the
 // counted wait of phase 4 leaves (NS-1) N234 + (NS-2) N1 instructions in flight.
 // MODE (probe builds): 0 = the kernel; 1 = operand delivery only (MFMAs skipped); 2 = arithmetic only (no DMA after the prologue);
-// 3 = no epilogue
+// 3 = no epilogue; 4 = timeline: every wave stamps s_memtime at the start of each phase's load section, at the start of its
+// MFMA section and at its end (3 x 4 stamps per K-tile, low 32 bits, first 64 K-tiles; stamps are taken into SGPRs and
+// written to LDS at the start of the NEXT phase so that no wait lands inside a section) and the first four blocks dump
+// them into C instead of the output tile: [block][wave][K-tile][phase][load start | MFMA start | MFMA end] as u32
+// (tools/gpu_gemm_timeline.py decodes them)
 // PERSIST: the grid is one block per CU and every block walks tiles b, b + grid, b + 2 grid, ... (the order the hardware
 // would dispatch them).  When a tile's K loop ends, the DMA for the first NS K-tiles of the NEXT tile is issued before the
 // epilogue of the current one, which stages through its own 2 KiB per wave: the output stores (HBM-write bound, 8 us of
@@ -789,7 +793,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   constexpr int N234 = (REST + 7) / 8;                                     // per wave, phases 2-4 together
   constexpr int N2 = (N234 + 2) / 3, N3 = (N234 - N2 + 1) / 2, N4 = N234 - N2 - N3;
   static_assert(8 * N2 <= XA_I + W_I, "WB must not be re-staged in the phase that reads it");
-  constexpr int O_DUMMY = NS * SET, O_STAGE = O_DUMMY + 1024, LDS_BYTES = O_STAGE + (PERSIST ? 8 * 2048 : 0);
+  constexpr int TL_TILES = 64, TL_WAVE = TL_TILES * 12 * 4;                // MODE 4: stamp bytes per wave
+  constexpr int O_DUMMY = NS * SET, O_STAGE = O_DUMMY + 1024, LDS_BYTES = O_STAGE + (PERSIST ? 8 * 2048 : 0) + (MODE == 4 ? 8 * TL_WAVE : 0);
   static_assert(LDS_BYTES <= 160 * 1024, "buffer sets exceed the LDS");
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   constexpr int INFLIGHT = (NS - 1) * N234 + (NS - 2) * N1;
@@ -874,6 +879,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   __builtin_amdgcn_s_barrier();                            \
   __builtin_amdgcn_sched_barrier(0);                       \
   __builtin_amdgcn_s_setprio(1)
+// MODE 4 stamps: UVX_TL_TAKE(k) reads the clock into tl[k]; UVX_TL_FLUSH(ph) writes the previous phase's three stamps
+#define UVX_TL_TAKE(k)                                                             \
+  if (MODE == 4) {                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    tl[k] = __builtin_readcyclecounter();                                          \
+  }
+#define UVX_TL_FLUSH(tt, ph)                                                       \
+  if (MODE == 4 && (tt) >= 0 && (tt) < TL_TILES) {                                 \
+    lds_u32* d_ = tl_base + ((tt) * 4 + (ph)) * 3;                                 \
+    d_[0] = (unsigned)tl[0]; d_[1] = (unsigned)tl[1]; d_[2] = (unsigned)tl[2];     \
+  }
 #define UVX_PHASE_END()                                    \
   __builtin_amdgcn_s_setprio(0);                           \
   __builtin_amdgcn_sched_barrier(0);                       \
@@ -914,11 +930,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   int cs = 0;   // t % NS
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  unsigned long long tl[3] = {0ull, 0ull, 0ull};
+  lds_u32* tl_base = (lds_u32*)(lds + O_STAGE + (PERSIST ? 8 * 2048 : 0) + w * TL_WAVE);
   for (int t = 0; t < nk; ++t) {
     const char* set = lds + cs * SET;
     const int ps = cs == 0 ? NS - 1 : cs - 1;   // (t + NS - 1) % NS
     bf16x8_t xa[MA][2], wa[2][2], wb[2][2];
     // ---- phase 1: XA x WA; DMA: XB of tile t+1 ----
+    UVX_TL_FLUSH(t - 1, 3);
+    UVX_TL_TAKE(0);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -932,6 +953,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int k = 0; k < N1; ++k) dma(sxb[k], t + NS - 1, ps);
     }
     UVX_PHASE_SYNC();
+    UVX_TL_TAKE(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -940,8 +962,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
         for (int i = 0; i < MA; ++i)
           if (MODE != 1) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][i], 0, 0, 0);
           else asm volatile("" ::"v"(wa[j][kh]), "v"(xa[i][kh]));
+    UVX_TL_TAKE(2);
     UVX_PHASE_END();
     // ---- phase 2: XA x WB; DMA: first third of [XA | WA | WB] of tile t+2 ----
+    UVX_TL_FLUSH(t, 0);
+    UVX_TL_TAKE(0);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -951,6 +976,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int k = 0; k < N2; ++k) dma(srest[k], t + NS, cs);
     }
     UVX_PHASE_SYNC();
+    UVX_TL_TAKE(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -959,8 +985,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
         for (int i = 0; i < MA; ++i)
           if (MODE != 1) acc[2 + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][i], 0, 0, 0);
           else asm volatile("" ::"v"(wb[j][kh]), "v"(xa[i][kh]));
+    UVX_TL_TAKE(2);
     UVX_PHASE_END();
     // ---- phase 3: XB x WB ----
+    UVX_TL_FLUSH(t, 1);
+    UVX_TL_TAKE(0);
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -970,6 +999,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int k = 0; k < N3; ++k) dma(srest[N2 + k], t + NS, cs);
     }
     UVX_PHASE_SYNC();
+    UVX_TL_TAKE(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -978,8 +1008,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
         for (int i = 0; i < MB; ++i)
           if (MODE != 1) acc[2 + j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][MA + i], 0, 0, 0);
           else asm volatile("" ::"v"(wb[j][kh]), "v"(xa[i][kh]));
+    UVX_TL_TAKE(2);
     UVX_PHASE_END();
     // ---- phase 4: XB x WA (WA kept in registers); the counted wait that retires tile t+1 ----
+    UVX_TL_FLUSH(t, 2);
+    UVX_TL_TAKE(0);
     if (t + NS < nk) {
 #pragma unroll
       for (int k = 0; k < N4; ++k) dma(srest[N2 + N3 + k], t + NS, cs);
@@ -988,6 +1021,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       UVX_VMCNT(0);
     }
     UVX_PHASE_SYNC();
+    UVX_TL_TAKE(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -996,12 +1030,28 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
         for (int i = 0; i < MB; ++i)
           if (MODE != 1) acc[j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][MA + i], 0, 0, 0);
           else asm volatile("" ::"v"(wa[j][kh]), "v"(xa[i][kh]));
+    UVX_TL_TAKE(2);
     UVX_PHASE_END();
     cs = cs == NS - 1 ? 0 : cs + 1;
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
   __builtin_amdgcn_sched_barrier(0);
 
+  if (MODE == 4) {   // probe: dump the stamps of the first four blocks instead of the tile
+    UVX_TL_FLUSH(nk - 1, 3);
+    float keep = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) keep += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (blockIdx.x < 4) {
+      unsigned* out = reinterpret_cast<unsigned*>(p.C) + ((long long)blockIdx.x * 8 + w) * (TL_TILES * 12);
+      for (int i = lane; i < TL_TILES * 12; i += 64) out[i] = i < nk * 12 ? tl_base[i] : 0u;
+      if (keep == 12345.678f) out[0] = 1u;
+    }
+    return;
+  }
   if (MODE == 3) {   // probe: no epilogue (keeps the accumulators alive with one conditional store)
     float t = 0.f;
 #pragma unroll
@@ -1033,6 +1083,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 #undef UVX_VMCNT
 #undef UVX_PHASE_SYNC
 #undef UVX_PHASE_END
+#undef UVX_TL_TAKE
+#undef UVX_TL_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1293,14 +1345,16 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 27;
+constexpr int kNumVariants = 28;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
     {160, 256, 1162., 8.9}, {256, 256, 1380., 8.5}, {256, 256, 0., 9.},      {256, 256, 0., 9.},      {256, 256, 0., 9.},
     {160, 256, 1230., 9.},  {192, 256, 1390., 12.}, {128, 256, 1116., 6.},
     {160, 256, 1245., 9.},  {128, 256, 0., 6.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   // 20..22 = probe modes of 11
-    {256, 256, 0., 4.},     {192, 256, 0., 6.},     {160, 256, 0., 5.},     {128, 256, 0., 4.}};   // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
+    {256, 256, 0., 4.},     {192, 256, 0., 6.},     {160, 256, 0., 5.},     {128, 256, 0., 4.},
+    {256, 256, 0., 9.}};   // 27 = timeline probe of 11 (MODE 4)
+   // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 double variant_cost(int v, int M, int N, int K, int batch) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
   // Rounds of tiles over the 256 CUs.  A partly filled last round is cheaper than a full one (the kernels are bound
@@ -1354,6 +1408,7 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 20: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 1>), grid, dim3(512), 0, st, a); break;
     case 21: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 2>), grid, dim3(512), 0, st, a); break;
     case 22: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 3>), grid, dim3(512), 0, st, a); break;
+    case 27: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 4>), grid, dim3(512), 0, st, a); break;
     case 23: case 24: case 25: case 26: {
       // persistent: one block per CU walks the tiles (batched problems use the plain kernels: grid.y would oversubscribe)
       if (batch != 1) { launch_variant(st, variant == 23 ? 11 : variant == 24 ? 16 : variant == 25 ? 15 : 17, a, M, N, batch); return; }
