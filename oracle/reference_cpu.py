@@ -9,6 +9,8 @@ restatement; it is pinned against
   * the reference's UltravoxProjector / StackAudioFrames / RMSNorm / SwiGLU classes and the reference's
     UltravoxProcessor, imported from /root/reference in the build container (tests/golden/make_golden.py
     writes the fixtures, tests/test_oracle_pinning.py replays them anywhere);
+  * the reference's `_get_prediction_mask` / `_compute_kl_loss`, `init_latency_mask` and `diff_state_dict`, called from the
+    imported reference module on stub objects (fixtures kl_loss.npz, latency_mask.npz, diff_state_dict.json);
   * the installed HF WhisperFeatureExtractor, WhisperEncoderLayer and LlamaForCausalLM blocks
     (tests/test_oracle_pinning.py), which are the third-party arithmetic the reference calls.
 Floating-point parity of mel / encoder / logits / loss / grads is NOT pinned by any reference test
