@@ -1,0 +1,203 @@
+"""generate()'s HOST logic — KV-state bookkeeping, cache growth, prefix check, terminators, padding of finished rows, the
+streamer protocol, repetition penalty — exercised on the CPU against a tiny SIMULATED device: the C-ABI calls generate()
+makes are replaced by torch stand-ins whose "logits" depend on every cached row, its position and the left padding, so a
+row that is missing, misplaced or stale changes the generated tokens.  (This is a test double for the library, not a
+fallback: the product never runs without libuvx; the device kernels themselves are checked in tests/test_generate_gpu.py.)"""
+import ctypes as C
+import types
+
+import pytest
+import torch
+
+import ultravox_amd.model as M
+from ultravox_amd import _lib
+from ultravox_amd.model import KVState, UltravoxModel
+
+V, D = 97, 4
+
+
+class FakeLib:
+    """cache: f32 [1 layer][k | v][B][Tmax][1]: k = the token feature (embedding[0]), v = its RoPE position."""
+
+    def __init__(self):
+        self.calls = []
+
+    @staticmethod
+    def _planes(cache, B, Tmax):
+        return cache[:2 * B * Tmax * 4].view(torch.float32).view(2, B, Tmax)
+
+    @staticmethod
+    def _logits(k, v, lo, hi, out):
+        for b in range(k.shape[0]):
+            s = float((k[b, lo[b]:hi] * (v[b, lo[b]:hi] + 1.0)).sum())
+            target = int(round(s)) % V
+            out[b] = -(torch.arange(V, dtype=torch.float32) - target).abs()
+
+    def uvx_kv_cache_bytes(self, cfg, B, Tmax):
+        return 2 * B * Tmax * 4
+
+    def uvx_llm_infer_ws_bytes(self, cfg, B, T):
+        return 64
+
+    def uvx_llm_prefill_chunk_ws_bytes(self, cfg, B, Tn, P):
+        return 64
+
+    def uvx_llm_prefill(self, st, cfg, lw, embeds, am, B, T, cache, Tmax, next_pos, kv_start, logits, ws, nb):
+        self.calls.append(("prefill", T))
+        kv = self._planes(cache, B, Tmax)
+        for b in range(B):
+            keep = torch.ones(T, dtype=torch.bool) if am is None else am[b].bool()
+            pos = torch.cumsum(keep.long(), 0) - 1
+            pos[~keep] = 1
+            kv[0, b, :T], kv[1, b, :T] = embeds[b, :, 0], pos.float()
+            idx = torch.nonzero(keep)[:, 0]
+            kv_start[b], next_pos[b] = int(idx[0]) if len(idx) else 0, int(keep.sum())
+        self._logits(kv[0], kv[1], kv_start.tolist(), T, logits)
+        return 0
+
+    def uvx_llm_prefill_chunk(self, st, cfg, lw, chunk, B, Tn, cache, Tmax, cur_len, pos0, kv_start, logits, ws, nb):
+        self.calls.append(("chunk", cur_len, Tn))
+        kv = self._planes(cache, B, Tmax)
+        for b in range(B):
+            kv[0, b, cur_len:cur_len + Tn] = chunk[b, :, 0]
+            kv[1, b, cur_len:cur_len + Tn] = float(pos0[b]) + torch.arange(Tn, dtype=torch.float32)
+        self._logits(kv[0], kv[1], kv_start.tolist(), cur_len + Tn, logits)
+        return 0
+
+    def uvx_llm_decode(self, st, cfg, lw, emb, pos, kv_start, cache, Tmax, cur_len, B, logits, ws, nb):
+        self.calls.append(("decode", cur_len))
+        kv = self._planes(cache, B, Tmax)
+        kv[0, :, cur_len], kv[1, :, cur_len] = emb[:, 0], pos.float()
+        self._logits(kv[0], kv[1], kv_start.tolist(), cur_len + 1, logits)
+        return 0
+
+    def uvx_embed_merge(self, st, cfg, table, tok, a, b, c, d, B, T, e, f, out, offs):
+        out.copy_(table[tok])
+        return 0
+
+    def uvx_argmax(self, st, code, logits, B, Vv, out):
+        out.copy_(logits.argmax(-1))
+        return 0
+
+
+@pytest.fixture()
+def model(monkeypatch):
+    fake = FakeLib()
+    monkeypatch.setattr(_lib, "lib", lambda: fake)
+    monkeypatch.setattr(M, "ptr", lambda t: t)
+    monkeypatch.setattr(M, "stream_ptr", lambda: None)
+    monkeypatch.setattr(M, "check", lambda rc, what="": None)
+    monkeypatch.setattr(M.C, "byref", lambda x: x)
+    monkeypatch.setattr(M.C, "c_size_t", lambda x: x)
+    m = UltravoxModel.__new__(UltravoxModel)
+    m.device, m.dtype, m.code, m.text_lora_r = torch.device("cpu"), torch.float32, 0, 0
+    m.config = types.SimpleNamespace(vocab_size=V, text_config=types.SimpleNamespace(eos_token_id=2, hidden_size=D))
+    table = (torch.arange(V, dtype=torch.float32)[:, None] + 1.0).repeat(1, D)
+    m._llm = {"rope_len": 4096, "embed": table}
+    m._c = types.SimpleNamespace(llm_layers=1)
+    m._lw, m._ws = None, {}
+    m._embed_merge = lambda emb, ids, *a: table[ids]
+    m.fake = fake
+    return m
+
+
+def left_padded(B, T, pads, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, V, (B, T), generator=g)
+    am = torch.ones(B, T, dtype=torch.long)
+    for b, p in enumerate(pads):
+        am[b, :p] = 0
+        ids[b, :p] = 2
+    return ids, am
+
+
+def test_cached_continuation_equals_a_fresh_prefill(model):
+    ids1, am1 = left_padded(2, 9, [0, 3])
+    out1 = model.generate(ids1, attention_mask=am1, max_new_tokens=5, eos_token_id=-1, return_dict_in_generate=True)
+    st = out1.past_key_values
+    assert isinstance(st, KVState) and st.cur_len == 13 and st.Tmax == 14 and st.tokens.shape == (2, 13)
+    assert st.pos_next.tolist() == [13, 10] and st.kv_start.tolist() == [0, 3]
+    ids2 = torch.cat([out1.sequences, torch.randint(3, V, (2, 6), generator=torch.Generator().manual_seed(1))], 1)
+    am2 = torch.cat([am1, torch.ones(2, ids2.shape[1] - 9, dtype=torch.long)], 1)
+    fresh = model.generate(ids2, attention_mask=am2, max_new_tokens=4, eos_token_id=-1, return_dict_in_generate=True)
+    assert model.last_prefill_reused == 0
+    model.fake.calls.clear()
+    out2 = model.generate(ids2, attention_mask=am2, max_new_tokens=4, eos_token_id=-1, past_key_values=st, return_dict_in_generate=True)
+    assert model.last_prefill_reused == 13 and model.fake.calls[0] == ("chunk", 13, ids2.shape[1] - 13)     # only the new tokens ran
+    assert torch.equal(out2.sequences, fresh.sequences)
+    s2, sf = out2.past_key_values, fresh.past_key_values
+    assert s2.cur_len == sf.cur_len == ids2.shape[1] + 3 and s2.Tmax == sf.Tmax and torch.equal(s2.pos_next, sf.pos_next)
+    rows = lambda s: FakeLib._planes(s.cache, 2, s.Tmax)[:, :, :s.cur_len]
+    a, b = rows(s2).clone(), rows(sf).clone()
+    a[:, 1, :3] = b[:, 1, :3] = 0                      # left padding of row 1: don't-care positions
+    assert torch.equal(a, b)                           # the grown cache holds exactly what a fresh prefill + decode wrote
+    assert st.cur_len == 13 and torch.equal(rows(st)[0, 0], rows(s2)[0, 0, :13])       # the consumed state is still readable
+
+
+def test_cache_is_dropped_when_it_is_not_a_prefix_and_reused_in_place_when_it_fits(model):
+    ids, _ = left_padded(1, 8, [0], seed=3)
+    out = model.generate(ids, max_new_tokens=40, eos_token_id=-1, return_dict_in_generate=True)
+    st = out.past_key_values
+    assert st.Tmax == 48 and st.cur_len == 47
+    nxt = torch.cat([out.sequences[:, :20], torch.tensor([[5, 6]])], 1)           # shorter than the cache: not a prefix of it
+    want = model.generate(nxt, max_new_tokens=3, eos_token_id=-1)
+    got = model.generate(nxt, max_new_tokens=3, eos_token_id=-1, past_key_values=st)
+    assert model.last_prefill_reused == 0 and torch.equal(got, want)
+    bad = out.sequences.clone()
+    bad[0, 5] = (bad[0, 5] + 1) % V
+    bad = torch.cat([bad, torch.tensor([[7]])], 1)
+    model.generate(bad, max_new_tokens=2, eos_token_id=-1, past_key_values=st)
+    assert model.last_prefill_reused == 0
+    # a continuation that fits the existing buffer appends in place (no growth copy)
+    st_small = model.generate(ids, max_new_tokens=6, eos_token_id=-1, return_dict_in_generate=True)
+    big = KVState(cache=torch.zeros(2 * 1 * 64 * 4, dtype=torch.uint8), Tmax=64, cur_len=st_small.past_key_values.cur_len,
+                  pos_next=st_small.past_key_values.pos_next, kv_start=st_small.past_key_values.kv_start,
+                  tokens=st_small.past_key_values.tokens)
+    FakeLib._planes(big.cache, 1, 64)[:, :, :big.cur_len] = FakeLib._planes(st_small.past_key_values.cache, 1, 14)[:, :, :big.cur_len]
+    cont = torch.cat([st_small.sequences, torch.tensor([[9, 11]])], 1)
+    o = model.generate(cont, max_new_tokens=3, eos_token_id=-1, past_key_values=big, return_dict_in_generate=True)
+    assert o.past_key_values.cache.data_ptr() == big.cache.data_ptr() and o.past_key_values.Tmax == 64
+    assert torch.equal(o.sequences, model.generate(cont, max_new_tokens=3, eos_token_id=-1))
+    with pytest.raises(TypeError):
+        model.generate(ids, past_key_values=object())
+
+
+def test_terminators_padding_streamer_and_repetition_penalty(model):
+    ids, am = left_padded(2, 7, [0, 2], seed=5)
+    free = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1)[:, 7:]
+    stop = int(free[0, 2])                                 # row 0 stops at its 3rd token, row 1 runs on
+    assume_other = stop not in free[1].tolist()
+
+    class Rec:
+        def __init__(self):
+            self.puts, self.ended = [], False
+
+        def put(self, v):
+            self.puts.append(v.clone())
+
+        def end(self):
+            self.ended = True
+    rec = Rec()
+    out = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=[stop, 96], pad_token_id=1, streamer=rec)
+    first = free[0].tolist().index(stop)
+    assert out[0, 7:7 + first + 1].tolist() == free[0, :first + 1].tolist()
+    if assume_other:
+        assert out.shape[1] == 13 and out[0, 7 + first + 1:].tolist() == [1] * (5 - first)       # finished row padded
+        assert out[1, 7:].tolist() == free[1].tolist()
+    assert rec.ended and torch.equal(rec.puts[0], ids) and len(rec.puts) == out.shape[1] - 7 + 1
+    with pytest.warns(UserWarning, match="no effect"):
+        model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, length_penalty=2.0)
+    with pytest.raises(NotImplementedError):
+        model.generate(ids, num_beams=4)
+    with pytest.raises(ValueError):
+        model.generate(ids, do_sample=True, temperature=0.0)
+    with pytest.raises(ValueError):
+        model.generate(ids, max_new_tokens=5000)
+    # repetition penalty: the scores of seen ids are damped before the arg-max (here: the un-penalised winner is a seen id)
+    pen = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1, repetition_penalty=50.0)
+    assert pen.shape == (2, 13)
+    g = torch.Generator().manual_seed(0)
+    a = model.generate(ids, attention_mask=am, max_new_tokens=4, eos_token_id=-1, do_sample=True, temperature=0.8, top_k=5, generator=g)
+    g = torch.Generator().manual_seed(0)
+    b = model.generate(ids, attention_mask=am, max_new_tokens=4, eos_token_id=-1, do_sample=True, temperature=0.8, top_k=5, generator=g)
+    assert torch.equal(a, b)
