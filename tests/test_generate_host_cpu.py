@@ -201,3 +201,56 @@ def test_terminators_padding_streamer_and_repetition_penalty(model):
     g = torch.Generator().manual_seed(0)
     b = model.generate(ids, attention_mask=am, max_new_tokens=4, eos_token_id=-1, do_sample=True, temperature=0.8, top_k=5, generator=g)
     assert torch.equal(a, b)
+
+
+def test_longest_common_prefix_reuse_is_opt_in_and_keeps_the_old_state_intact(model):
+    ids, am = left_padded(2, 10, [0, 2], seed=7)
+    out = model.generate(ids, attention_mask=am, max_new_tokens=8, eos_token_id=-1, return_dict_in_generate=True)
+    st = out.past_key_values
+    snapshot = st.cache.clone()
+    # the new prompt follows the cached ids up to index 12 (row 0) / 14 (row 1), then departs
+    nxt = torch.cat([out.sequences[:, :15], torch.randint(3, V, (2, 5), generator=torch.Generator().manual_seed(2))], 1)
+    nxt[0, 12] = (nxt[0, 12] + 1) % V
+    nxt[1, 14] = (nxt[1, 14] + 1) % V
+    am2 = torch.cat([am, torch.ones(2, 10, dtype=torch.long)], 1)
+    want = model.generate(nxt, attention_mask=am2, max_new_tokens=4, eos_token_id=-1)
+    model.generate(nxt, attention_mask=am2, max_new_tokens=4, eos_token_id=-1, past_key_values=st)
+    assert model.last_prefill_reused == 0                                  # default: all or nothing
+    st.partial_ok = True
+    model.fake.calls.clear()
+    got = model.generate(nxt, attention_mask=am2, max_new_tokens=4, eos_token_id=-1, past_key_values=st, return_dict_in_generate=True)
+    assert model.last_prefill_reused == 12 and model.fake.calls[0] == ("chunk", 12, 8)          # min over the rows
+    assert torch.equal(got.sequences, want)
+    new = got.past_key_values
+    assert new.partial_ok and new.cache.data_ptr() != st.cache.data_ptr() and torch.equal(st.cache, snapshot)
+    # a mismatch inside the left padding region cannot be reused (positions would not line up)
+    early = nxt.clone()
+    early[1, 1] = 5
+    model.generate(early, attention_mask=am2, max_new_tokens=2, eos_token_id=-1, past_key_values=st)
+    assert model.last_prefill_reused == 0
+    # a shorter prompt that is a prefix of the cached ids: everything but its last token comes from the cache
+    short = out.sequences[:, :11]
+    am3 = torch.cat([am, torch.ones(2, 1, dtype=torch.long)], 1)
+    w = model.generate(short, attention_mask=am3, max_new_tokens=3, eos_token_id=-1)
+    g = model.generate(short, attention_mask=am3, max_new_tokens=3, eos_token_id=-1, past_key_values=st)
+    assert model.last_prefill_reused == 10 and torch.equal(g, w)
+
+
+def test_local_inference_marks_its_states_partial_ok():
+    from fake_tokenizer import FakeChatTokenizer
+    from oracle.reference_cpu import FeatureExtractorRef
+    from ultravox_amd.inference import LocalInference, VoiceSample
+    from ultravox_amd.processing import UltravoxProcessor
+    tok = FakeChatTokenizer()
+    state = KVState(cache=torch.zeros(8, dtype=torch.uint8), Tmax=1, cur_len=1, pos_next=torch.zeros(1, dtype=torch.int32),
+                    kv_start=torch.zeros(1, dtype=torch.int32), tokens=torch.zeros(1, 1, dtype=torch.long))
+
+    class Stub:
+        device, dtype = torch.device("cpu"), torch.float32
+
+        def generate(self, **kw):
+            return types.SimpleNamespace(sequences=torch.cat([kw["input_ids"], torch.tensor([[128009]])], 1), past_key_values=state)
+    inf = LocalInference(Stub(), UltravoxProcessor(FeatureExtractorRef(80), tokenizer=tok), tok, dtype=torch.float32, conversation_mode=True)
+    assert not state.partial_ok
+    inf.infer(VoiceSample.from_prompt("Hi"))
+    assert inf.past_key_values is state and state.partial_ok

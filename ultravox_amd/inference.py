@@ -9,8 +9,8 @@ What differs from the reference, on purpose:
     to a full prefill when a re-tokenised reply no longer matches (the reference trusts the caller);
     As in the reference, the cache is what keeps an earlier AUDIO turn audible: the past message holds only
     `eos * audio_token_len` placeholders, the cached keys / values of those positions were computed from the audio
-    embeddings.  A dropped cache (mismatching prefix) therefore degrades old audio turns to placeholders — reusing the
-    longest common prefix instead of all-or-nothing is the planned refinement (DESIGN.md §6.1);
+    embeddings.  The wrapper therefore marks its states `partial_ok`: when the re-templated dialogue departs from the
+    cached ids part-way (a reply that re-tokenises differently), the rows of the longest common prefix are still reused;
   * `infer_stream` needs one pass, not the reference's two (`:205-223` exist only to snapshot the cache before HF's
     in-place cache grows; a `KVState`'s rows below `cur_len` are never rewritten);
   * resampling uses scipy's polyphase filter (librosa is not a dependency here).
@@ -201,7 +201,10 @@ class LocalInference:
             args.update(past_key_values=self.past_key_values, return_dict_in_generate=True)
         out = self.model.generate(**inputs, **args, pad_token_id=self.tokenizer.eos_token_id,
                                   eos_token_id=self._terminators(), streamer=streamer)
-        return getattr(out, "sequences", out), getattr(out, "past_key_values", None)
+        past = getattr(out, "past_key_values", None)
+        if past is not None and hasattr(past, "partial_ok"):
+            past.partial_ok = True      # a reply that re-tokenises differently must not cost the earlier (audio) turns
+        return getattr(out, "sequences", out), past
 
     def _remember(self, sample: VoiceSample, inputs: Dict[str, torch.Tensor], response_text: str, past_key_values) -> None:
         if self.conversation_mode:

@@ -30,13 +30,17 @@ class KVState:
     `generate(input_ids, past_key_values=state)` runs only `input_ids[:, cur_len:]` when its prefix still matches them.
     Like HF's in-place caches, a state is CONSUMED by the call it is handed to: the call may append to the same buffer
     (rows below `cur_len` are never rewritten, so the old state stays readable, but two continuations of one state would
-    share - and overwrite - the rows above it).  Branch a dialogue from `copy.deepcopy(state)`."""
+    share - and overwrite - the rows above it).  Branch a dialogue from `copy.deepcopy(state)`.
+    With `partial_ok` a prompt that departs from `tokens` part-way (a reply that re-tokenised differently) still reuses the
+    rows of the longest common prefix - under causal attention they do not depend on what follows - instead of dropping the
+    cache; `LocalInference` turns it on because in a conversation only the cache remembers earlier AUDIO turns."""
     cache: torch.Tensor
     Tmax: int
     cur_len: int
     pos_next: torch.Tensor        # [B] int32: RoPE position of the next token of each sequence
     kv_start: torch.Tensor        # [B] int32: first real cache row (left padding)
     tokens: torch.Tensor          # [B, cur_len] int64
+    partial_ok: bool = False      # reuse the longest common prefix when the new prompt departs from `tokens` part-way
 
     def get_seq_length(self) -> int:
         return self.cur_len
@@ -669,15 +673,21 @@ class UltravoxModel:
         # A cache handed in is reused only while it still describes this prompt's prefix (HF trusts the caller here; a
         # re-tokenised reply that no longer matches would silently corrupt the dialogue, so it is checked and dropped).
         P = 0
-        if past is not None and past.tokens.shape[0] == B and 0 < past.cur_len < T \
-                and torch.equal(ids_dev[:, :past.cur_len], past.tokens) \
-                and (am is None or bool(am[:, past.cur_len:].all())):
-            P = past.cur_len
+        if past is not None and past.tokens.shape[0] == B and past.cur_len > 0 and T > 1:
+            n = min(past.cur_len, T - 1)                 # at least one token must run to produce logits
+            eq = (ids_dev[:, :n] == past.tokens[:, :n]).all(dim=0)
+            n_match = n if bool(eq.all()) else int(torch.nonzero(~eq)[0, 0])
+            whole = n_match == past.cur_len
+            if (whole or (past.partial_ok and n_match > int(past.kv_start.max()))) \
+                    and (am is None or bool(am[:, n_match:].all())):
+                P = n_match
         self.last_prefill_reused = P
         own_cache = return_dict or P > 0      # a cache that outlives this call cannot live in the shared workspace
         cache_bytes = l.uvx_kv_cache_bytes(C.byref(self._c), B, Tmax)
-        if P > 0 and past.Tmax >= Tmax:
-            cache, Tmax = past.cache, past.Tmax
+        # RoPE position of the first token that runs: positions are consecutive past the left padding
+        pos0 = None if P == 0 else (past.pos_next - (past.cur_len - P)).to(torch.int32).contiguous()
+        if P > 0 and P == past.cur_len and past.Tmax >= Tmax:
+            cache, Tmax = past.cache, past.Tmax          # append in place (rows below cur_len stay as they are)
         else:
             cache = (torch.empty(cache_bytes, device=dev, dtype=torch.uint8) if own_cache else self._workspace("kv", cache_bytes))
             if P > 0:                          # grow: rows [0, P) of every (layer, k|v, sequence) plane move over
@@ -695,9 +705,9 @@ class UltravoxModel:
             kv_start = past.kv_start
             chunk = inputs_embeds[:, P:].contiguous()
             check(l.uvx_llm_prefill_chunk(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(chunk), B, T - P, ptr(cache),
-                                          Tmax, P, ptr(past.pos_next), ptr(kv_start), ptr(logits), ptr(ws), C.c_size_t(nb)),
+                                          Tmax, P, ptr(pos0), ptr(kv_start), ptr(logits), ptr(ws), C.c_size_t(nb)),
                   "uvx_llm_prefill_chunk")
-            next_pos = past.pos_next + (T - P)
+            next_pos = pos0 + (T - P)
         else:
             check(l.uvx_llm_prefill(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(am),
                                     B, T, ptr(cache), Tmax, ptr(next_pos), ptr(kv_start), ptr(logits), ptr(ws),
@@ -739,7 +749,8 @@ class UltravoxModel:
             return sequences
         # like HF's cache after generate: every token but the last one produced has its keys / values stored
         state = KVState(cache=cache, Tmax=Tmax, cur_len=T + n_decoded, pos_next=(next_pos + n_decoded).to(torch.int32).contiguous(),
-                        kv_start=kv_start, tokens=sequences[:, :T + n_decoded].contiguous())
+                        kv_start=kv_start, tokens=sequences[:, :T + n_decoded].contiguous(),
+                        partial_ok=bool(past is not None and past.partial_ok))
         return GenerateOutput(sequences=sequences, past_key_values=state)
 
     @staticmethod
