@@ -140,6 +140,17 @@ def cpu_baseline(cfg, seconds: float, n_text: int = 128):
     }
 
 
+def pmc_traffic_per_launch(profiles_dir=None):
+    """roofline.traffic: memory-side bytes per GEMM launch from the newest committed PMC summary (profiles/rNN_pmc_traffic.json,
+    written by tools/pmc_traffic.sh from separate FETCH_SIZE / WRITE_SIZE passes over this same command), or None."""
+    d = profiles_dir or os.path.join(ROOT, "profiles")
+    try:
+        names = sorted(n for n in os.listdir(d) if n.startswith("r") and n.endswith("_pmc_traffic.json"))
+        return json.load(open(os.path.join(d, names[-1]))).get("traffic_bytes_per_launch") if names else None
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,10 +300,7 @@ def main():
             ach = prof[2] / (prof[1] * 1e-3) / 1e12
             # memory-side traffic per GEMM launch from the PMC passes of the SAME command (tools/pmc_traffic.sh,
             # separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 on gfx950), committed under profiles/
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if args.workload == "c2" and os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
+            traffic = pmc_traffic_per_launch() if args.workload == "c2" else None
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_* (all tile variants)", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": prof[3] / prof[0],

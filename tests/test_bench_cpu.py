@@ -1,0 +1,35 @@
+"""bench.py's host-side definitions, checked without a GPU: the algorithmic FLOP count against SURVEY.md §8(d)'s figures
+for C2 / C3 and the lookup of the committed PMC traffic summary."""
+import json
+import os
+
+import pytest
+
+import bench
+from ultravox_amd.config import UltravoxConfig
+
+
+def test_flops_per_sample_matches_the_survey_figures():
+    c2 = UltravoxConfig(audio_model_id="openai/whisper-medium", text_model_id="meta-llama/Meta-Llama-3-8B-Instruct",
+                        hidden_size=4096, stack_factor=8, projector_ln_mid=True)
+    f = bench.flops_per_sample(c2, 30.0, n_text=128, n_supervised=32)
+    assert f["encoder"] / 1e9 == pytest.approx(1138.07, abs=0.01)          # E
+    assert f["projector"] / 1e9 == pytest.approx(15.77, abs=0.01)          # P
+    assert f["step_full_head"] / 1e9 == pytest.approx(10749.8, abs=0.2)    # 10 749.8 GFLOP per sample with the all-rows head
+    assert f["step"] < f["step_full_head"]                                 # the quoted MFU counts the supervised rows only
+    c3 = UltravoxConfig(audio_model_id="openai/whisper-large-v3", text_model_id="meta-llama/Meta-Llama-3-8B-Instruct",
+                        hidden_size=4096, stack_factor=8, projector_ln_mid=True)
+    g = bench.flops_per_sample(c3, 30.0)
+    assert g["encoder"] / 1e9 == pytest.approx(2273.77, abs=0.01) and g["projector"] / 1e9 == pytest.approx(18.92, abs=0.01)
+    assert g["step_full_head"] / 1e9 == pytest.approx(11894.9, abs=0.2)
+
+
+def test_pmc_traffic_lookup_takes_the_newest_summary_and_never_raises(tmp_path):
+    assert bench.pmc_traffic_per_launch(str(tmp_path)) is None and bench.pmc_traffic_per_launch("/nonexistent") is None
+    for name, v in (("r01_pmc_traffic.json", 1.0), ("r02_pmc_traffic.json", 2.0)):
+        json.dump({"traffic_bytes_per_launch": v}, open(tmp_path / name, "w"))
+    assert bench.pmc_traffic_per_launch(str(tmp_path)) == 2.0
+    (tmp_path / "r03_pmc_traffic.json").write_text("{broken")
+    assert bench.pmc_traffic_per_launch(str(tmp_path)) is None
+    committed = bench.pmc_traffic_per_launch()
+    assert committed is None or committed > 1e8                            # bytes per GEMM launch at C2
