@@ -38,6 +38,10 @@ WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
     "c2": dict(name="Llama-3-8B (frozen) + whisper-medium, bs=8x30s clips, adapter train",
                audio="openai/whisper-medium", text="meta-llama/Meta-Llama-3-8B-Instruct", B=8, seconds=30.0),
+    # BASELINE.json configs[2] per-rank shapes (global batch 64 = 8 clips on each of 8 GPUs): not the quoted configuration,
+    # selectable for the DP-8 run (`--gpus 8 --workload c3`)
+    "c3": dict(name="Llama-3-8B (frozen) + whisper-large-v3, bs=8x30s clips per GPU, adapter train",
+               audio="openai/whisper-large-v3", text="meta-llama/Meta-Llama-3-8B-Instruct", B=8, seconds=30.0),
     # BASELINE.json configs[0] shapes (plumbing-sized), for quick checks
     "c1": dict(name="TinyLlama-1.1B + whisper-tiny, 1x4s clip, adapter train",
                audio="openai/whisper-tiny", text="TinyLlama/TinyLlama-1.1B-Chat-v1.0", B=1, seconds=4.0),
