@@ -9,6 +9,7 @@ TAIL=14 run gemm_timeline   120 python tools/gpu_gemm_timeline.py               
 run gemm_timeline_k 120 python tools/gpu_gemm_timeline.py 2528 4096 4096                                 # a single-round shape
 run lcp_check       200 python tools/gpu_lcp_check.py                                                    # partial KV-cache reuse on the device
 run c3_width        300 python tools/gpu_c3_width_check.py                                               # whisper-large-v3 width parity
+run c4_width        300 python tools/gpu_c4_width_check.py                                               # Llama-3.3-70B width through generate()
 TAIL=20 run chat_probe      300 python tools/gpu_chat_probe.py 6 48 32                                     # cached vs re-prefilled turns
 run bench           200 python bench.py --steps 5 --warmup 2
 du -sh $OUT
