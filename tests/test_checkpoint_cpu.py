@@ -55,3 +55,25 @@ def test_trainer_state_round_trip(tmp_path):
     step, tt, extra = checkpoint.load_trainer_state(str(tmp_path))
     assert step == 7 and extra["lr"] == 2e-3 and "master" not in tt
     assert torch.equal(tt["exp_avg"], t["exp_avg"]) and tt["exp_avg"].dtype == torch.bfloat16
+
+
+def test_pack_llm_consume_frees_the_sources_and_packs_the_same_operands():
+    """pack_llm(consume=True): identical packed operands, and the q/k/v/gate/up sources are popped layer by layer (the
+    70B-parameter LLM then loads at one copy of the model plus a layer instead of 1.65 copies)."""
+    import torch
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import pack_llm, random_state_dict
+    cfg = UltravoxConfig(audio_config=dict(d_model=64, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=128),
+                         text_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                                          num_key_value_heads=2, vocab_size=96), hidden_size=64)
+    sd = random_state_dict(cfg, seed=1, dtype=torch.float32)
+    keep = pack_llm(dict(sd), cfg, torch.float32, "cpu", with_transposes=True, rope_len=64)
+    eaten = dict(sd)
+    got = pack_llm(eaten, cfg, torch.float32, "cpu", with_transposes=True, rope_len=64, consume=True)
+    for k in ("embed", "norm", "lm_head", "lm_head_t", "rope"):
+        assert torch.equal(got[k], keep[k]), k
+    for a, b in zip(got["layers"], keep["layers"]):
+        assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    gone = [k for k in sd if k not in eaten]
+    assert len(gone) == 3 * 5 and all(any(t in k for t in ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj")) for k in gone)
+    assert all(k in eaten for k in sd if "o_proj" in k or "down_proj" in k or "layernorm" in k or "embed" in k)

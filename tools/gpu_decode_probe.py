@@ -1,4 +1,7 @@
-"""GPU probe: generate() at the C2 model size - prefill time and decode ms/token (greedy, B prompts of ~316 positions)."""
+"""GPU probe: generate() at the C2 model size - prefill time and decode ms/token (greedy, B prompts of ~316 positions).
+usage: PYTHONPATH=. python tools/gpu_decode_probe.py [B] [new_tokens] [text_model_id]
+  text_model_id meta-llama/Llama-3.3-70B-Instruct = BASELINE config C4 (141 GB of bf16 weights: loaded with
+  consume_state_dict so the peak stays near one copy; weight-streaming floor 141 GB / 8 TB/s = 17.6 ms per token)"""
 import sys, time
 import torch
 from ultravox_amd.config import UltravoxConfig
@@ -8,10 +11,12 @@ from ultravox_amd.synthetic import synthetic_batch
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 new = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+text_id = sys.argv[3] if len(sys.argv) > 3 else "meta-llama/Meta-Llama-3-8B-Instruct"
 dev = "cuda"
-cfg = UltravoxConfig(audio_model_id="openai/whisper-medium", text_model_id="meta-llama/Meta-Llama-3-8B-Instruct",
+cfg = UltravoxConfig(audio_model_id="openai/whisper-medium", text_model_id=text_id,
                      hidden_size=4096, stack_factor=8, projector_ln_mid=True, torch_dtype="bfloat16")
-model = UltravoxModel(cfg, device=dev, dtype=torch.bfloat16, seed=0, rope_len=1024, with_backward=False)
+model = UltravoxModel(cfg, device=dev, dtype=torch.bfloat16, seed=0, rope_len=1024, with_backward=False, consume_state_dict=True)
+print(f"{text_id}: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak while loading, {torch.cuda.memory_allocated() / 2**30:.1f} GiB resident", flush=True)
 batch = synthetic_batch(cfg, B, 30.0, n_text=128, audio_start=16, n_supervised=32)
 pcm = batch.pop("pcm").to(dev)
 batch.pop("labels")

@@ -124,7 +124,9 @@ class UltravoxModel:
 
     def __init__(self, config: UltravoxConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  device: str = "cuda", dtype: Optional[torch.dtype] = None, seed: int = 0,
-                 with_backward: bool = True, rope_len: Optional[int] = None):
+                 with_backward: bool = True, rope_len: Optional[int] = None, consume_state_dict: bool = False):
+        """consume_state_dict: pop the LLM's q/k/v/gate/up tensors from `state_dict` as they are packed (the dict is left
+        without them) so that loading peaks at one copy of the model plus a layer - for the 70B-parameter LLM (C4)."""
         _lib.lib()  # fail loudly if the HIP library is missing
         if not torch.cuda.is_available():
             raise _lib.UvxError("UltravoxModel needs a GPU (MI355X / gfx950); there is no CPU path")
@@ -150,6 +152,7 @@ class UltravoxModel:
             gen_dev = "cuda" if t.num_hidden_layers * t.hidden_size > 64 * 1024 else "cpu"
             state_dict = random_state_dict(config, seed=seed, dtype=self.dtype, device=gen_dev)
         self.with_backward = with_backward
+        self._consume_sd = bool(consume_state_dict)
         self._load(state_dict, rope_len)
         self._ws: Dict[str, torch.Tensor] = {}
         self._proj_ctx = None
@@ -161,7 +164,8 @@ class UltravoxModel:
         a, t = cfg.audio_config, cfg.text_config
         self.lora_r = int(cfg.audio_model_lora_config.get("r", 0) or 0)      # encoder LoRA rank (0: frozen tower)
         self._enc = pack_encoder(sd, cfg, dt, dev, with_transposes=self.lora_r > 0 and self.with_backward)
-        self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=self.with_backward, rope_len=rope_len)
+        self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=self.with_backward, rope_len=rope_len,
+                             consume=getattr(self, "_consume_sd", False))
         # projector: one flat trainable bucket with views (ln_pre | linear_1 | ln_mid/ln_post | linear_2)
         P = "multi_modal_projector."
         norm_key = "ln_mid" if cfg.projector_ln_mid else "ln_post"

@@ -198,7 +198,11 @@ def pack_encoder(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.", 
 
 
 def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = True, rope_len: Optional[int] = None,
-             prefix="language_model.") -> Dict[str, object]:
+             prefix="language_model.", consume: bool = False) -> Dict[str, object]:
+    """HF-named LLM weights -> the packed per-layer operands of csrc/model.hip.  q/k/v and gate/up are concatenated (new
+    tensors); the other matrices are shared with `sd` when they already have the right device / dtype.  `consume=True` pops
+    the q/k/v/gate/up entries from `sd` layer by layer as soon as they are packed, so the peak stays at one copy of the model
+    plus one layer (what a 70B-parameter LLM needs to load into 288 GB next to its KV cache) — `sd` is left without them."""
     t = cfg.text_config
     cv = lambda x: x.to(device=device, dtype=dtype).contiguous()
     tr = lambda x: x.t().contiguous() if with_transposes else None
@@ -217,6 +221,10 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
         I, Dm = gate.shape
         assert I % 16 == 0, "intermediate_size must be a multiple of 16"
         wgu = cv(torch.stack([gate.reshape(I // 16, 16, Dm), up.reshape(I // 16, 16, Dm)], 1).reshape(2 * I, Dm))
+        del gate, up
+        if consume:
+            for key in [L + f"self_attn.{n}_proj.weight" for n in "qkv"] + [L + "mlp.gate_proj.weight", L + "mlp.up_proj.weight"]:
+                sd.pop(key)
         wo, wd = cv(sd[L + "self_attn.o_proj.weight"]), cv(sd[L + "mlp.down_proj.weight"])
         out["layers"].append({
             "ln1": cv(sd[L + "input_layernorm.weight"]), "ln2": cv(sd[L + "post_attention_layernorm.weight"]),
