@@ -77,3 +77,50 @@ def test_pack_llm_consume_frees_the_sources_and_packs_the_same_operands():
     gone = [k for k in sd if k not in eaten]
     assert len(gone) == 3 * 5 and all(any(t in k for t in ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj")) for k in gone)
     assert all(k in eaten for k in sd if "o_proj" in k or "down_proj" in k or "layernorm" in k or "embed" in k)
+
+
+def test_tower_weights_from_local_hf_checkpoints(tmp_path):
+    """audio_tower_state_dict / language_model_state_dict: a full Whisper file contributes only its encoder (the reference's
+    base_model_prefix = "model.encoder"), a sharded causal-LM checkpoint is stitched from its index, tied embeddings supply
+    the LM head; the result packs (pack_encoder / pack_llm) exactly like the state dict it was written from."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from ultravox_amd import checkpoint
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import pack_encoder, pack_llm, random_state_dict
+    cfg = UltravoxConfig(audio_config=dict(d_model=64, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=128),
+                         text_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                          num_key_value_heads=2, vocab_size=96), hidden_size=64)
+    sd = random_state_dict(cfg, seed=4, dtype=torch.float32)
+    # Whisper: a WhisperForConditionalGeneration-shaped file (encoder + decoder + proj_out)
+    wdir = tmp_path / "whisper"
+    wdir.mkdir()
+    whisper = {"model.encoder." + k[len("audio_tower."):]: v.contiguous() for k, v in sd.items() if k.startswith("audio_tower.")}
+    whisper["model.decoder.embed_tokens.weight"] = torch.zeros(4, 4)
+    whisper["proj_out.weight"] = torch.zeros(4, 4)
+    save_file(whisper, str(wdir / "model.safetensors"))
+    a = checkpoint.audio_tower_state_dict(str(wdir))
+    assert set(a) == {k for k in sd if k.startswith("audio_tower.")} and all(torch.equal(a[k], sd[k]) for k in a)
+    # LLM: two shards + index, tied embeddings (no lm_head.weight in the files)
+    ldir = tmp_path / "llm"
+    ldir.mkdir()
+    llm = {k[len("language_model."):]: v.contiguous() for k, v in sd.items() if k.startswith("language_model.") and "lm_head" not in k}
+    names = sorted(llm)
+    shards = {"model-00001-of-00002.safetensors": names[::2], "model-00002-of-00002.safetensors": names[1::2]}
+    for fn, ks in shards.items():
+        save_file({k: llm[k] for k in ks}, str(ldir / fn))
+    json.dump({"weight_map": {k: fn for fn, ks in shards.items() for k in ks}}, open(ldir / "model.safetensors.index.json", "w"))
+    m = checkpoint.language_model_state_dict(str(ldir))
+    assert torch.equal(m["language_model.lm_head.weight"], sd["language_model.model.embed_tokens.weight"])
+    assert all(torch.equal(m[k], sd[k]) for k in sd if k.startswith("language_model.") and "lm_head" not in k)
+    tied = dict(sd)
+    tied["language_model.lm_head.weight"] = sd["language_model.model.embed_tokens.weight"]
+    got_e, want_e = pack_encoder({**a, **m}, cfg, torch.float32, "cpu"), pack_encoder(tied, cfg, torch.float32, "cpu")
+    got_l, want_l = pack_llm({**a, **m}, cfg, torch.float32, "cpu", rope_len=32), pack_llm(tied, cfg, torch.float32, "cpu", rope_len=32)
+    assert torch.equal(got_e["conv2_w"], want_e["conv2_w"]) and torch.equal(got_e["layers"][1]["wqkv"], want_e["layers"][1]["wqkv"])
+    assert torch.equal(got_l["lm_head"], want_l["lm_head"]) and torch.equal(got_l["layers"][1]["wgu"], want_l["layers"][1]["wgu"])
+    with pytest.raises(FileNotFoundError):
+        checkpoint.load_hf_weights(str(tmp_path))
+    with pytest.raises(KeyError):
+        checkpoint.audio_tower_state_dict(str(ldir))

@@ -62,6 +62,58 @@ def load_pretrained(directory: str) -> Tuple[UltravoxConfig, Dict[str, torch.Ten
     return config, load_file(os.path.join(directory, SAFE_WEIGHTS_NAME))
 
 
+SAFE_WEIGHTS_INDEX_NAME = "model.safetensors.index.json"
+
+
+def load_hf_weights(directory: str) -> Dict[str, torch.Tensor]:
+    """All tensors of a local HF checkpoint directory: `model.safetensors`, or the shards `model.safetensors.index.json`
+    names.  Stands in for the hub download behind `from_pretrained(audio_model_id / text_model_id)`
+    (ultravox_model.py:439-526): there is no network here, the towers' weights come from disk."""
+    single, index = os.path.join(directory, SAFE_WEIGHTS_NAME), os.path.join(directory, SAFE_WEIGHTS_INDEX_NAME)
+    if os.path.exists(single):
+        return load_file(single)
+    if not os.path.exists(index):
+        raise FileNotFoundError(f"{directory}: neither {SAFE_WEIGHTS_NAME} nor {SAFE_WEIGHTS_INDEX_NAME} "
+                                "(only safetensors checkpoints are read)")
+    with open(index) as f:
+        weight_map = json.load(f)["weight_map"]
+    out: Dict[str, torch.Tensor] = {}
+    for shard in sorted(set(weight_map.values())):
+        out.update(load_file(os.path.join(directory, shard)))
+    missing = set(weight_map) - set(out)
+    if missing:
+        raise KeyError(f"{directory}: the index lists tensors no shard holds: {sorted(missing)[:5]}")
+    return out
+
+
+def audio_tower_state_dict(directory: str, prefix: str = "audio_tower.") -> Dict[str, torch.Tensor]:
+    """The encoder of a Whisper checkpoint under the reference's key names.  `ModifiedWhisperEncoder.base_model_prefix` is
+    "model.encoder" (ultravox_model.py:818-820): a full `WhisperForConditionalGeneration` / `WhisperModel` file contributes
+    its `model.encoder.*` (or `encoder.*`) tensors, the decoder and `proj_out` are ignored (:820), an encoder-only file is
+    taken as is."""
+    out = {}
+    for k, v in load_hf_weights(directory).items():
+        for head in ("model.encoder.", "encoder."):
+            if k.startswith(head):
+                out[prefix + k[len(head):]] = v
+                break
+        else:
+            if not k.startswith(("model.decoder.", "decoder.", "proj_out.", "model.")):
+                out[prefix + k] = v
+    if prefix + "conv1.weight" not in out:
+        raise KeyError(f"{directory}: no Whisper encoder weights found (looked for model.encoder.conv1.weight)")
+    return out
+
+
+def language_model_state_dict(directory: str, prefix: str = "language_model.") -> Dict[str, torch.Tensor]:
+    """A causal-LM checkpoint (`model.*`, `lm_head.weight`) under the reference's `language_model.` prefix; a checkpoint with
+    tied embeddings carries no `lm_head.weight`, which then IS the embedding matrix (HF `tie_word_embeddings`)."""
+    sd = {prefix + k: v for k, v in load_hf_weights(directory).items()}
+    if prefix + "lm_head.weight" not in sd:
+        sd[prefix + "lm_head.weight"] = sd[prefix + "model.embed_tokens.weight"]
+    return sd
+
+
 def merge_state_dict(base: Dict[str, torch.Tensor], checkpoint: Dict[str, torch.Tensor],
                      strict_shapes: bool = True) -> Tuple[Dict[str, torch.Tensor], Set[str]]:
     """base (towers from their own ids + freshly initialised projector) overlaid with the checkpoint's keys.

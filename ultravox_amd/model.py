@@ -322,13 +322,23 @@ class UltravoxModel:
         return missing, unexpected
 
     @classmethod
-    def from_pretrained(cls, directory: str, base_state_dict: Optional[Dict[str, torch.Tensor]] = None, **kwargs):
+    def from_pretrained(cls, directory: str, base_state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                        audio_model_dir: Optional[str] = None, text_model_dir: Optional[str] = None, **kwargs):
         """config.json + model.safetensors written by save_pretrained (here or by the reference).  The towers come from
-        `base_state_dict` (the weights `audio_model_id` / `text_model_id` name: there is no hub access here) or, absent
-        that, from the seeded random initialisation; checkpoint keys override either."""
+        `base_state_dict`, or from local HF checkpoint directories of the models `audio_model_id` / `text_model_id` name
+        (`audio_model_dir`, `text_model_dir`: safetensors, single file or sharded - there is no hub access here), or, absent
+        both, from the seeded random initialisation; checkpoint keys override either."""
         from . import checkpoint
         config, ckpt = checkpoint.load_pretrained(directory)
         dtype = _torch_dtype(config, kwargs.get("dtype"))
+        if base_state_dict is None and (audio_model_dir or text_model_dir):
+            if not (audio_model_dir and text_model_dir):
+                raise ValueError("give both audio_model_dir and text_model_dir (or a complete base_state_dict)")
+            base_state_dict = {**checkpoint.audio_tower_state_dict(audio_model_dir),
+                               **checkpoint.language_model_state_dict(text_model_dir)}
+            for k, v in random_state_dict(config, seed=kwargs.get("seed", 0), dtype=dtype).items():
+                if k.startswith("multi_modal_projector."):
+                    base_state_dict.setdefault(k, v)       # a projector the checkpoint does not carry starts from its init
         base = base_state_dict if base_state_dict is not None else random_state_dict(
             config, seed=kwargs.get("seed", 0), dtype=dtype)
         merged, keep = checkpoint.merge_state_dict(base, ckpt)
