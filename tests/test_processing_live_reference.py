@@ -144,3 +144,61 @@ def test_dataproc_agrees_with_the_live_reference(n_samples, mask, alt, max_resp,
         w = want[k].tolist() if hasattr(want[k], "tolist") else want[k]
         g = got[k].tolist() if hasattr(got[k], "tolist") else got[k]
         assert g == w, (k, messages, mask, kw)
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(side=st.sampled_from(["right", "left"]), alt=st.booleans(),
+       picks=st.lists(st.sampled_from(["asr", "qa", "long", "two"]), min_size=1, max_size=4))
+def test_collator_agrees_with_the_live_reference(side, alt, picks):
+    """DataCollatorForSeq2SeqWithAudio over data-proc features: the reference's own __call__ body runs with the [3P]
+    DataCollatorForSeq2Seq padding it inherits stubbed by the same rule (pad ids / mask / labels on tokenizer.padding_side),
+    including the alt fields of the KL path and the left-padding displacement of audio_token_start_idx."""
+    import unittest.mock as mock
+    import torch.nn.functional as F
+    import transformers
+    from fake_tokenizer import FakeChatTokenizer
+    from ultravox_amd.config import LossMaskType
+    from ultravox_amd.data_proc import UltravoxDataproc
+    from ultravox_amd.processing import DataCollatorForSeq2SeqWithAudio
+    sys.path.insert(0, REF)
+    try:
+        from ultravox.model import ultravox_processing
+    finally:
+        sys.path.remove(REF)
+    tok = FakeChatTokenizer(side)
+    tok.pad_token_id = tok.eos_token_id
+    dp = UltravoxDataproc([], UltravoxProcessor(FeatureExtractorRef(80), tokenizer=tok), LossMaskType.LAST_ASSISTANT, include_alt_fields=alt)
+    rng = np.random.RandomState(0)
+    bank = {
+        "asr": ([{"role": "user", "content": "Transcribe <|audio|>"}, {"role": "assistant", "content": "a b c"}], 16000, "a b c"),
+        "qa": ([{"role": "user", "content": "Listen <|audio|> and answer now please"}, {"role": "assistant", "content": "ok then"}], 40000, "hm"),
+        "long": ([{"role": "user", "content": "<|audio|>"}, {"role": "assistant", "content": "long one indeed yes"}], 500000, "x y"),
+        "two": ([{"role": "system", "content": "sys"}, {"role": "user", "content": "A <|audio|> B"}, {"role": "assistant", "content": "r"}], 8000, None),
+    }
+    feats = []
+    for name in picks:
+        msgs, n, tr = bank[name]
+        feats.append(dp._process(types.SimpleNamespace(messages=[dict(m) for m in msgs], audio=rng.randn(n).astype(np.float32) * 0.1,
+                                                       sample_rate=16000, audio_transcript=tr)))
+
+    def hf_pad(features):
+        n = max(len(f["input_ids"]) for f in features)
+
+        def pad(x, v):
+            g = n - len(x)
+            return F.pad(torch.as_tensor(x), (g, 0) if side == "left" else (0, g), value=v)
+        b = {"input_ids": torch.stack([pad(f["input_ids"], tok.pad_token_id) for f in features]),
+             "attention_mask": torch.stack([pad(f["attention_mask"], 0) for f in features]),
+             "labels": torch.stack([pad(f["labels"], -100) for f in features])}
+        if "audio_batch_size" in features[0]:
+            b["audio_batch_size"] = torch.stack([f["audio_batch_size"] for f in features])
+        return b
+    ref = ultravox_processing.DataCollatorForSeq2SeqWithAudio.__new__(ultravox_processing.DataCollatorForSeq2SeqWithAudio)
+    ref.tokenizer, ref.include_alt_fields = tok, alt
+    clone = lambda fs: [{k: (v.clone() if hasattr(v, "clone") else list(v) if isinstance(v, list) else v) for k, v in f.items()} for f in fs]
+    with mock.patch.object(transformers.DataCollatorForSeq2Seq, "__call__", lambda self, features, *a, **k: hf_pad(features)):
+        want = ref(clone(feats))
+    got = DataCollatorForSeq2SeqWithAudio(tok, include_alt_fields=alt)(clone(feats))
+    assert set(got) == set(want), (sorted(got), sorted(want))
+    for k in want:
+        assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape and torch.equal(got[k], want[k]), (k, side, alt, picks)
