@@ -50,7 +50,7 @@ def both():
     return reference_processor(tok), UltravoxProcessor(FeatureExtractorRef(80), tokenizer=tok)
 
 
-@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=30, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(lengths=st.lists(st.sampled_from(LENGTHS), max_size=3), words=st.lists(st.sampled_from(WORDS), min_size=1, max_size=8),
        placeholder_delta=st.sampled_from([0, 0, 0, 0, -1, 1]), chunks=st.booleans(), seed=st.integers(0, 3))
 def test_processor_agrees_with_the_live_reference(both, lengths, words, placeholder_delta, chunks, seed):
@@ -103,7 +103,7 @@ def reference_dataproc_cls():
     return ultravox_data_proc.UltravoxDataproc, ultravox_config.LossMaskType
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=40, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.too_slow])
 @given(n_samples=st.sampled_from([None, 0, 200, 16000, 40000, 560000]), mask=st.sampled_from(["last_assistant", "after_audio", "all"]),
        alt=st.booleans(), max_resp=st.sampled_from([None, 1, 3, 50]), inference=st.booleans(), system=st.booleans(),
        words=st.lists(st.sampled_from(WORDS), min_size=1, max_size=6), reply=st.lists(st.sampled_from(WORDS), min_size=1, max_size=6),
@@ -146,7 +146,7 @@ def test_dataproc_agrees_with_the_live_reference(n_samples, mask, alt, max_resp,
         assert g == w, (k, messages, mask, kw)
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=25, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.too_slow])
 @given(side=st.sampled_from(["right", "left"]), alt=st.booleans(),
        picks=st.lists(st.sampled_from(["asr", "qa", "long", "two"]), min_size=1, max_size=4))
 def test_collator_agrees_with_the_live_reference(side, alt, picks):
