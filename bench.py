@@ -1,6 +1,7 @@
 """bench.py — adapter-train step of the Ultravox audio->LLM hot path on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 20 --warmup 5          # launches its own 8 ranks (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -155,6 +156,21 @@ def pmc_traffic_per_launch(profiles_dir=None):
         return None
 
 
+def self_launch(n: int) -> int:
+    """Re-execute this command line as n ranks of one node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,15 +192,17 @@ def main():
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table (from the HIP events) here")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` (how the driver may invoke it): become the launcher - one rank per GPU under
+        # torch.distributed.run on 127.0.0.1, as the reference is started by torchrun (train.py:126-130, README.md:144-148).
+        # Rank 0 prints the JSON line; the launcher only forwards the exit code.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (torch.distributed.run --nproc-per-node must equal --gpus)")
     # test hook for the multi-rank code path on a 1-GPU box: UVX_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo
     # (RCCL refuses two ranks on one device); never set by the driver, and the JSON line says so if it is
     share_gpu = os.environ.get("UVX_BENCH_SHARE_GPU") == "1"
@@ -299,6 +317,10 @@ def main():
             "step_tflops_with_full_logits": fl["step_full_head"] * B / 1e12,
             "mfu": fl["step"] * B * world * args.steps / dt / (PEAK_BF16_TFLOPS * 1e12 * world),
             "loss": loss_val,
+            "world_size": world,
+            "collective": (None if world == 1 else "gloo (shared-GPU test mode)" if share_gpu
+                           else "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + " all-reduce(sum) of one flat f32 bucket, "
+                                f"{trainer.model.proj_grad.numel() * 4 / 1e6:.0f} MB"),
         }
         if not args.no_prof and prof[0] > 0:
             ach = prof[2] / (prof[1] * 1e-3) / 1e12

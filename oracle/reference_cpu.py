@@ -27,6 +27,44 @@ import torch.nn.functional as F
 
 N_FFT, HOP = 400, 160
 
+# bf16 runs only.  False: eager attention as HF's `eager` class computes it in the model dtype (scores rounded to bf16).
+# True: attention internals as a FUSED kernel computes them (torch SDPA's flash / mem-efficient back ends, which is what the
+# reference's default `sdpa` attention class dispatches to on a GPU, and this repo's flash kernels): q, k, v in the model dtype,
+# scores and softmax statistics in f32, probabilities rounded to the model dtype as the P.V operand, f32 accumulation, one
+# rounding of the output.  Every other rounding point (linear outputs, norms, RoPE, activations, residual adds) is torch's own
+# bf16 module-by-module rounding in both settings.
+FUSED_ATTENTION = False
+
+
+class fused_attention:
+    """with fused_attention(): ... - run the bf16 oracle with f32 attention scores (see FUSED_ATTENTION)."""
+
+    def __enter__(self):
+        global FUSED_ATTENTION
+        self._old, FUSED_ATTENTION = FUSED_ATTENTION, True
+
+    def __exit__(self, *a):
+        global FUSED_ATTENTION
+        FUSED_ATTENTION = self._old
+
+
+def _attend(q, k, v, mask, scale: float):
+    """softmax(q k^T * scale + mask) v over [B, H, T, dh] operands; mask additive (finfo.min) or None."""
+    dt = q.dtype
+    if FUSED_ATTENTION and dt != torch.float32:
+        s = (q.float() @ k.float().transpose(-1, -2)) * scale
+        if mask is not None:
+            s = s + mask.float()
+        p = torch.softmax(s, dim=-1).to(dt)
+        return (p.float() @ v.float()).to(dt)
+    s = q @ k.transpose(-1, -2)
+    if scale != 1.0:
+        s = s * scale
+    if mask is not None:
+        s = s + mask
+    p = torch.softmax(s.float(), dim=-1).to(dt)
+    return p @ v
+
 
 # ----------------------------------------------------------------------------------------------
 # K1 — log-mel.  [3P] WhisperFeatureExtractor._torch_extract_fbank_features, called from
@@ -165,11 +203,7 @@ def whisper_encoder_ref(sd: Dict[str, torch.Tensor], cfg, input_features: torch.
         q = q * scaling                                      # WhisperAttention: q_proj(x) * head_dim^-0.5
         v = F.linear(h, W(L + "self_attn.v_proj.weight"), W(L + "self_attn.v_proj.bias"))
         q, k, v = (t.view(B, S, H, dh).transpose(1, 2) for t in (q, k, v))
-        s = q @ k.transpose(-1, -2)
-        if mask is not None:
-            s = s + mask
-        p = torch.softmax(s.float(), dim=-1).to(dt)
-        o = (p @ v).transpose(1, 2).reshape(B, S, d)
+        o = _attend(q, k, v, mask, 1.0).transpose(1, 2).reshape(B, S, d)
         x = res + F.linear(o, W(L + "self_attn.out_proj.weight"), W(L + "self_attn.out_proj.bias"))
         res = x
         h = F.layer_norm(x, (d,), W(L + "final_layer_norm.weight"), W(L + "final_layer_norm.bias"), a.layer_norm_eps)
@@ -287,9 +321,7 @@ def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
         k = k * cos + _rotate_half(k) * sin
         k = k.repeat_interleave(Hq // Hkv, dim=1)
         v = v.repeat_interleave(Hq // Hkv, dim=1)
-        s = (q @ k.transpose(-1, -2)) * (dh ** -0.5) + causal
-        p = torch.softmax(s.float(), dim=-1).to(dt)
-        o = (p @ v).transpose(1, 2).reshape(B, T, Hq * dh)
+        o = _attend(q, k, v, causal, dh ** -0.5).transpose(1, 2).reshape(B, T, Hq * dh)
         x = x + F.linear(o, W(P + "self_attn.o_proj.weight"))
         h = rmsnorm_ref(x, W(P + "post_attention_layernorm.weight"), tc.rms_norm_eps)
         h = F.silu(F.linear(h, W(P + "mlp.gate_proj.weight"))) * F.linear(h, W(P + "mlp.up_proj.weight"))

@@ -1,0 +1,167 @@
+"""The BASELINE.json configurations other than the benchmarked depth of C2, on the GPU against the CPU oracle:
+
+  * C3 - whisper-large-v3 WIDTH (1280 / 5120 / 20 heads, 128 mel bins; meta_config.yaml:2-3, v0.6_config_llama3_8b.yaml:3) with
+    Llama-3-8B width: the K = 1280 / N = 3840 / 5120 GEMM shapes, 128-bin log-mel, conv1 im2col at K = 384, 20-head D = 64
+    attention and the 10240-wide projector input appear in no other test;
+  * C4 - Llama-3.3-70B WIDTH (8192 / 28672 / 64:8 heads, llama3 rope scaling; v0.6_config_llama3_70b.yaml:2) through
+    generate(): prefill + KV-cache decode, skinny GEMMs at K = 8192 / 28672, grouped decode attention with 8 query heads per
+    KV head;
+  * C2 DEEPER - Llama-3-8B + whisper-medium width at 8 + 8 layers (tests/test_c2_width_gpu.py runs depth 2): error growth of
+    the bf16 production path through more layers, measured against the f32 oracle AND the bf16 oracle, recorded per depth.
+
+Depth is reduced so that the f32 CPU oracle finishes in seconds; every width-dependent choice (tile picker, split-K head,
+head_dim, rope tables) is the full-size one."""
+import pytest
+import torch
+
+from parity_util import max_abs, oracle_threads, record, rel_l2, stage_errors, width_config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+L3_8B, L33_70B = "meta-llama/Meta-Llama-3-8B-Instruct", "meta-llama/Llama-3.3-70B-Instruct"
+
+
+def _train_inputs(cfg, B, n_text, audio_start, n_sup):
+    from oracle.reference_cpu import synthetic_batch
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    b = synthetic_batch(cfg, B, 30.0, n_text=n_text, audio_start=audio_start, n_supervised=n_sup)
+    pcm = b.pop("pcm")
+    mel = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins).logmel_device(pcm.to(DEV))
+    return mel, {k: v.to(DEV) for k, v in b.items()}, {**b, "audio_values": mel.cpu().bfloat16().float()}
+
+
+@pytest.mark.parametrize("lora", [None, {"r": 8}], ids=["frozen", "encoder-lora-r8"])
+def test_c3_width_train_step_matches_oracle(lora):
+    from oracle.reference_cpu import OracleModel
+    from ultravox_amd import _lib
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    cfg = width_config(L3_8B, "openai/whisper-large-v3", 1, 2, audio_model_lora_config=lora)
+    sd = random_state_dict(cfg, seed=3, dtype=torch.bfloat16, device="cuda")
+    if lora:
+        sd.update(init_lora_state_dict(cfg, seed=3, dtype=torch.bfloat16, random_b=True))
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16, rope_len=512)
+    oracle = OracleModel(cfg, {k: v.cpu() for k, v in sd.items()}, dtype=torch.float32)
+    mel, gb, ob = _train_inputs(cfg, 2, 64, 8, 16)
+    assert mel.shape[1] == 128
+    oracle_threads()
+    ref, grads, _ = oracle.train_step(ob)
+    enc = model.audio_tower_forward(mel, gb["audio_lens"])
+    with torch.no_grad():
+        enc_ref, emb_ref = oracle.audio_embeds(ob["audio_values"], ob["audio_lens"])
+    rec = {"encoder_out": stage_errors(enc, enc_ref),
+           "audio_embeds": stage_errors(model.multi_modal_projector_forward(enc), emb_ref)}
+    assert rec["encoder_out"]["rel_l2"] < 2e-2 and rec["audio_embeds"]["rel_l2"] < 2e-2, rec
+    model.train()
+    loss = model.forward_backward(audio_values=mel, **gb)
+    rec["loss"] = [loss.item(), ref["loss"].item()]
+    assert abs(loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
+    mine = model.projector_grads()
+    rec["grads"] = {k: rel_l2(mine[k], g) for k, g in grads.items()}
+    assert len(grads) == (4 if not lora else 4 + 2 * 2 * 2)          # projector (+ A, B for q, k of both encoder layers)
+    for k, v in rec["grads"].items():
+        assert v < 8e-2, (k, v)
+    L = _lib.lib()   # which tile variants whisper-large-v3's encoder shapes take at C3's M = 8 x 1500 rows (for the record)
+    rec["tile_variants_M12000"] = {f"{n}x{k}": L.uvx_gemm_pick_variant(12000, n, k, 1) for n, k in ((3840, 1280), (1280, 1280), (5120, 1280), (1280, 5120))}
+    record("c3_width_" + ("lora" if lora else "frozen"), rec)
+
+
+def test_c4_width_generate_matches_oracle_and_teacher_forcing():
+    from oracle.reference_cpu import OracleModel
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = width_config(L33_70B, "openai/whisper-medium", 2, 1)
+    assert cfg.text_config.rope_scaling and cfg.text_config.hidden_size == 8192
+    sd = random_state_dict(cfg, seed=9, dtype=torch.bfloat16, device="cuda")
+    sd["language_model.model.embed_tokens.weight"] *= 0.3
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16, rope_len=512, with_backward=False)
+    oracle = OracleModel(cfg, {k: v.cpu() for k, v in sd.items()}, dtype=torch.float32)
+    torch.manual_seed(5)
+    oracle_threads()
+    rec = {}
+    for B in (1, 8):
+        T, N = 40, 8
+        ids = torch.randint(3, cfg.vocab_size - 1, (B, T))
+        am = torch.ones(B, T, dtype=torch.long)
+        if B > 1:
+            am[1, :7] = 0                        # one left-padded prompt
+            ids[am == 0] = 2
+        out = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=N, eos_token_id=-1)
+        assert out.shape == (B, T + N)
+        am_full = torch.cat([am, torch.ones(B, N, dtype=torch.long)], 1).to(DEV)
+        logits = model.forward(input_ids=out, attention_mask=am_full).logits.float()
+        top2 = logits.topk(2, -1).values
+        margin, pred = top2[..., 0] - top2[..., 1], logits.argmax(-1)
+        # decode (KV cache, skinny GEMMs) vs the model's own teacher-forced forward, wherever the arg-max is not a bf16 coin toss
+        for t in range(T - 1, T + N - 1):
+            assert bool(((pred[:, t] == out[:, t + 1]) | (margin[:, t] < 5e-2)).all()), (B, t)
+        with torch.no_grad():
+            ref = oracle.forward(input_ids=ids, attention_mask=am)["logits"]
+        keep = am.bool()
+        rec[f"B{B}_prompt_logits"] = stage_errors(logits[:, :T].cpu()[keep], ref[keep])
+        assert rec[f"B{B}_prompt_logits"]["rel_l2"] < 3e-2
+        rm = ref[:, -1].topk(2, -1).values
+        clear = (rm[:, 0] - rm[:, 1]) > 5e-2
+        assert torch.equal(out[:, T].cpu()[clear], ref[:, -1].argmax(-1)[clear])     # first generated token vs the oracle
+        rec[f"B{B}_clear_rows"] = int(clear.sum())
+    record("c4_width_generate", rec)
+
+
+def test_c4_width_generate_token_exact_in_f32():
+    """f32 compute mode: generate() is token-exact against the oracle's cache-free greedy search at Llama-3.3-70B width."""
+    from oracle.reference_cpu import OracleModel
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = width_config(L33_70B, "openai/whisper-medium", 1, 1)
+    sd = random_state_dict(cfg, seed=11, dtype=torch.float32, device="cuda")
+    sd["language_model.model.embed_tokens.weight"] *= 0.3
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32, rope_len=256, with_backward=False)
+    oracle = OracleModel(cfg, {k: v.cpu() for k, v in sd.items()}, dtype=torch.float32)
+    torch.manual_seed(6)
+    oracle_threads()
+    B, T, N = 2, 12, 3
+    ids = torch.randint(3, cfg.vocab_size - 1, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, :3] = 0
+    ids[am == 0] = 2
+    got = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=N, eos_token_id=-1).cpu()
+    want = oracle.generate_greedy(N, -1, pad_token_id=0, input_ids=ids, attention_mask=am)
+    assert torch.equal(got, want)
+
+
+def test_c2_width_deeper_error_growth_is_bounded():
+    """8 LLM + 8 encoder layers at C2 width: the bf16 production path against the f32 oracle (bf16-vs-f32 bars of
+    test_model_gpu.py) and against the bf16 oracle with fused-attention rounding points (the >= 5x tighter dtype-for-dtype
+    bar of test_bf16_rounding_points_gpu.py); the per-depth numbers go to gpurun_out/parity/c2_depth.json."""
+    from oracle.reference_cpu import OracleModel, fused_attention
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    depth = 8
+    cfg = width_config(L3_8B, "openai/whisper-medium", depth, depth)
+    sd = random_state_dict(cfg, seed=3, dtype=torch.bfloat16, device="cuda")
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16, rope_len=512)
+    cpu_sd = {k: v.cpu() for k, v in sd.items()}
+    mel, gb, ob = _train_inputs(cfg, 2, 128, 16, 32)
+    oracle_threads()
+    oracle = OracleModel(cfg, cpu_sd, dtype=torch.float32)
+    ref, grads, _ = oracle.train_step(ob)
+    out = model.forward(audio_values=mel, **gb)
+    rec = {"depth": depth, "vs_f32": {"logits": stage_errors(out.logits, ref["logits"]), "loss": [out.loss.item(), ref["loss"].item()]}}
+    model.train()
+    loss = model.forward_backward(audio_values=mel, **gb)
+    mine = model.projector_grads()
+    rec["vs_f32"]["grads"] = {k: rel_l2(mine[k], g) for k, g in grads.items()}
+    del oracle
+    o16 = OracleModel(cfg, cpu_sd, dtype=torch.bfloat16)
+    with fused_attention():
+        r16, g16, _ = o16.train_step({**ob, "audio_values": ob["audio_values"].bfloat16()})
+    rec["vs_bf16"] = {"logits": stage_errors(out.logits, r16["logits"]), "loss": [out.loss.item(), r16["loss"].item()],
+                      "grads": {k: rel_l2(mine[k], g) for k, g in g16.items()}}
+    record("c2_depth8", rec)
+    assert rec["vs_f32"]["logits"]["rel_l2"] < 3e-2
+    assert abs(loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
+    for k, v in rec["vs_f32"]["grads"].items():
+        assert v < 8e-2, (k, v)
+    assert rec["vs_bf16"]["logits"]["rel_l2"] < 6e-3, rec["vs_bf16"]
+    for k, v in rec["vs_bf16"]["grads"].items():
+        assert v < 1.6e-2, (k, v)

@@ -33,3 +33,27 @@ def test_pmc_traffic_lookup_takes_the_newest_summary_and_never_raises(tmp_path):
     assert bench.pmc_traffic_per_launch(str(tmp_path)) is None
     committed = bench.pmc_traffic_per_launch()
     assert committed is None or committed > 1e8                            # bytes per GEMM launch at C2
+
+
+def test_gpus_n_without_torchrun_becomes_the_launcher(monkeypatch):
+    """`python bench.py --gpus 4` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run
+    (one rank per GPU, 127.0.0.1 rendezvous) and forwards the exit code - it must not exit(2) asking for torchrun."""
+    import subprocess
+    import sys
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

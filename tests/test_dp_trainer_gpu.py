@@ -1,0 +1,122 @@
+"""The N > 1 path of the PRODUCT trainer, end to end on the device: two processes, one rank each, UltravoxTrainer.train_step
+(forward, backward, the flat-bucket all-reduce, clip + AdamW) with and without the overlapped schedule, and `bench.py --gpus 2`
+launching its own ranks.  A gpurun box has one GPU, so both ranks sit on cuda:0 and the collective runs on gloo (RCCL refuses
+two ranks on one device); the trainer code that runs is exactly the one the RCCL ranks run (torch.distributed.all_reduce on
+the f32 bucket, async work handle, deferred optimizer step).
+
+Checked: both ranks end with bit-identical projector weights; the overlapped schedule equals the sequential one bit for
+bit; and both equal a single-process restatement of DDP semantics (train.py:126-130: gradient MEAN over ranks of per-rank
+token-mean losses) computed with the same kernels."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG = dict(
+    audio_config=dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256),
+    text_config=dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                     num_key_value_heads=2, vocab_size=512, eos_token_id=2),
+    hidden_size=256, projector_ln_mid=True)
+STEPS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model_and_batches(world):
+    from oracle.reference_cpu import logmel_ref, synthetic_batch          # inputs only (tests may use the oracle's generators)
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = UltravoxConfig(**CFG)
+    sd = {k: v.bfloat16() for k, v in random_state_dict(cfg, seed=0).items()}
+    model = UltravoxModel(cfg, state_dict=sd, device="cuda:0", dtype=torch.bfloat16)
+    batches = []
+    for r in range(world):
+        b = synthetic_batch(cfg, 2, 2.0, n_text=24, audio_start=5, n_supervised=4 + 3 * r, rank=r)   # token counts differ per rank
+        b["audio_values"] = logmel_ref(b.pop("pcm"), 80)
+        batches.append({k: v.to("cuda:0") for k, v in b.items()})
+    return model, batches
+
+
+def _worker(rank, world, port, overlap, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ultravox_amd.model import UltravoxTrainer
+    model, batches = _model_and_batches(world)
+    trainer = UltravoxTrainer(model, lr=2e-3, master_weights=True, overlap_comm=overlap)
+    assert trainer.world == world
+    losses = [trainer.train_step(**batches[rank]).item() for _ in range(STEPS)]
+    trainer.flush()
+    torch.cuda.synchronize()
+    q.put((rank, losses, trainer.master.cpu(), model.proj_flat.float().cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_trainer_overlapped_equals_sequential_equals_ddp_mean():
+    world = 2
+    seq, ovl = _run(world, False), _run(world, True)
+    for res in (seq, ovl):
+        assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])      # ranks agree bit for bit
+    assert torch.equal(seq[0][2], ovl[0][2]) and seq[0][1] == ovl[0][1] and seq[1][1] == ovl[1][1]
+    # single process: per step, gradient = mean over ranks of each rank's own-token-mean gradient, then clip + AdamW
+    from ultravox_amd.model import UltravoxTrainer
+    model, batches = _model_and_batches(world)
+    trainer = UltravoxTrainer(model, lr=2e-3, master_weights=True)
+    for step in range(STEPS):
+        model.train()
+        acc = torch.zeros_like(model.proj_grad)
+        for r in range(world):
+            loss = model.forward_backward(**batches[r])
+            assert abs(loss.item() - seq[r][1][step]) < 1e-6 * max(1.0, abs(loss.item())), (step, r)
+            acc += model.proj_grad
+        model.proj_grad.copy_(acc * (1.0 / world))
+        trainer.optimizer_step()
+    torch.cuda.synchronize()
+    # gloo sums r0 + r1 in one order, the restatement in another: identical for two addends
+    assert torch.equal(trainer.master.cpu(), seq[0][2])
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it) must start its own ranks and print ONE JSON line from rank 0."""
+    env = dict(os.environ, UVX_BENCH_SHARE_GPU="1", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "c1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["config"]["global_batch"] == 2
+    assert "overlapped" in out["config"]["parallelism"] and out["value"] > 0

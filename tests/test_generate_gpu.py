@@ -193,3 +193,36 @@ def test_chunked_prefill_over_a_cached_prefix(dtype):
     want = model.generate(bad.to(DEV), attention_mask=am2.to(DEV), max_new_tokens=3, eos_token_id=-1)
     got = model.generate(bad.to(DEV), attention_mask=am2.to(DEV), max_new_tokens=3, eos_token_id=-1, past_key_values=st1)
     assert model.last_prefill_reused == 0 and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_longest_common_prefix_reuse_on_the_device(dtype):
+    """KVState.partial_ok (set by LocalInference in conversation mode): a prompt that departs from the cached ids part-way
+    reuses the rows of the longest common prefix - same tokens (f32) / same cache rows as a fresh full prefill."""
+    cfg, model, _ = _build(dtype, 31)
+    torch.manual_seed(11)
+    B, T1 = 2, 90
+    ids = torch.randint(3, 512, (B, T1))
+    am = torch.ones(B, T1, dtype=torch.long)
+    am[1, :5] = 0
+    ids[am == 0] = 2
+    out = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=20, eos_token_id=-1, return_dict_in_generate=True)
+    st = out.past_key_values
+    st.partial_ok = True
+    nxt = torch.cat([out.sequences.cpu()[:, :100], torch.randint(3, 512, (B, 40))], 1)       # departs at index 70 / 100
+    nxt[0, 70] = (nxt[0, 70] + 1) % 500 + 3
+    am2 = torch.cat([am, torch.ones(B, nxt.shape[1] - T1, dtype=torch.long)], 1)
+    gen = dict(attention_mask=am2.to(DEV), max_new_tokens=6, eos_token_id=-1, return_dict_in_generate=True)
+    fresh = model.generate(nxt.to(DEV), **gen)
+    got = model.generate(nxt.to(DEV), past_key_values=st, **gen)
+    assert model.last_prefill_reused == 70
+    kvd = cfg.text_config.num_key_value_heads * cfg.text_config.head_dim
+    T2 = nxt.shape[1]
+
+    def rows(s):
+        v = s.cache.view(dtype).view(-1, s.Tmax, kvd)[:, :T2].float().clone()
+        v.view(-1, B, T2, kvd)[:, 1, :5] = 0
+        return v
+    assert rel_l2(rows(got.past_key_values), rows(fresh.past_key_values)) < (1e-5 if dtype == torch.float32 else 2e-2)
+    if dtype == torch.float32:
+        assert torch.equal(got.sequences, fresh.sequences)
