@@ -124,3 +124,38 @@ def test_tower_weights_from_local_hf_checkpoints(tmp_path):
         checkpoint.load_hf_weights(str(tmp_path))
     with pytest.raises(KeyError):
         checkpoint.audio_tower_state_dict(str(ldir))
+
+
+def test_configs_outside_the_built_arithmetic_are_refused_not_run_as_llama():
+    from ultravox_amd.config import UltravoxConfig
+    ok_text = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1, vocab_size=128)
+    UltravoxConfig(text_config={**ok_text, "model_type": "llama", "attention_bias": False, "tie_word_embeddings": False})
+    for bad in ({"model_type": "qwen2"}, {"attention_bias": True}, {"mlp_bias": True}, {"sliding_window": 4096},
+                {"tie_word_embeddings": True}, {"hidden_act": "gelu_pytorch_tanh"}):
+        with pytest.raises(ValueError):
+            UltravoxConfig(text_config={**ok_text, **bad})
+    with pytest.raises(ValueError, match="model_type"):
+        UltravoxConfig(audio_config={"model_type": "wav2vec2", "d_model": 64})
+    # apply_lora with r = 0 + unfreeze_layers (ultravox_model.py:694-703) is not built: refused, not silently frozen
+    for r in (0, 8):
+        with pytest.raises(ValueError, match="unfreeze_layers"):
+            UltravoxConfig(audio_model_lora_config={"r": r, "unfreeze_layers": ["layers.3"]})
+
+
+def test_from_pretrained_base_gets_adapter_keys_before_the_checkpoint_is_merged():
+    """The merge refuses unknown keys; a LoRA checkpoint's adapter keys must therefore already exist in the base."""
+    from ultravox_amd import checkpoint
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    cfg = UltravoxConfig(audio_config=dict(d_model=64, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=128),
+                         text_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                          num_key_value_heads=1, vocab_size=128), hidden_size=64, audio_model_lora_config={"r": 4})
+    base = random_state_dict(cfg, seed=1)
+    ckpt = {k: v + 1 for k, v in init_lora_state_dict(cfg, seed=1).items()}
+    with pytest.raises(KeyError):
+        checkpoint.merge_state_dict(base, ckpt)
+    seeded = dict(base)
+    for k, v in init_lora_state_dict(cfg, seed=0).items():
+        seeded.setdefault(k, v)
+    merged, keep = checkpoint.merge_state_dict(seeded, ckpt)
+    assert keep == set(ckpt) and all(torch.equal(merged[k], ckpt[k]) for k in ckpt)

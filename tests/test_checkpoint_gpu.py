@@ -138,3 +138,58 @@ def test_gradient_accumulation_and_schedule_on_the_device():
         t2.optimizer_step()
     assert torch.equal(m1.proj_flat, m2.proj_flat) and torch.equal(t1.exp_avg, t2.exp_avg)
     assert not torch.equal(m1.proj_flat, UltravoxModel(cfg, state_dict=sd, device=DEV).proj_flat)     # the second step moved the weights
+
+
+def test_lora_checkpoint_round_trips_through_from_pretrained(tmp_path):
+    """A checkpoint this framework wrote with encoder + LLM LoRA adapters loads back through from_pretrained onto a base
+    state dict that carries NO adapter keys (what a fresh process has), and re-saves the same tensors."""
+    from test_model_gpu import SMALL
+    from ultravox_amd import checkpoint
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel, UltravoxTrainer
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    cfg = UltravoxConfig(**{**SMALL, "audio_model_lora_config": {"r": 4}, "text_model_lora_config": {"r": 2}})
+    base = random_state_dict(cfg, seed=8, dtype=torch.bfloat16)
+    assert not any(".lora_" in k for k in base)
+    m1 = UltravoxModel(cfg, state_dict={**base, **init_lora_state_dict(cfg, seed=8, dtype=torch.bfloat16, random_b=True)}, device=DEV)
+    UltravoxTrainer(m1, lr=2e-3).train_step(**_batch(cfg))          # move projector and adapters off their initial values
+    m1.save_pretrained(str(tmp_path / "a"))
+    m2 = UltravoxModel.from_pretrained(str(tmp_path / "a"), base_state_dict=base, device=DEV)
+    s1, s2 = m1.projector_state_dict(), m2.projector_state_dict()
+    assert set(s1) == set(s2) and sum(".lora_" in k for k in s2) == 2 * 2 * (2 + 2)
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    m2.save_pretrained(str(tmp_path / "b"))
+    _, a = checkpoint.load_pretrained(str(tmp_path / "a"))
+    _, b = checkpoint.load_pretrained(str(tmp_path / "b"))
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    b_ = _batch(cfg)
+    assert m1.forward(**b_).loss.item() == m2.forward(**b_).loss.item()
+
+
+def test_tower_keys_carried_by_a_checkpoint_are_re_saved(tmp_path):
+    """ultravox_model.py:565-591: every keep_param is written again.  A reference checkpoint that carries audio_tower.* /
+    language_model.* tensors (fine-tuned towers) must not lose them on the next save - a reload would silently revert those
+    towers to their base model ids."""
+    from test_model_gpu import SMALL
+    from ultravox_amd import checkpoint
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = UltravoxConfig(**SMALL)
+    base = random_state_dict(cfg, seed=9, dtype=torch.bfloat16)
+    tower_keys = ["audio_tower.layers.0.fc1.weight", "language_model.model.layers.1.mlp.down_proj.weight", "language_model.model.norm.weight"]
+    carried = {k: (base[k].float() * 1.5 + 0.01).bfloat16() for k in tower_keys}
+    carried.update({k: v for k, v in base.items() if k.startswith("multi_modal_projector.")})
+    checkpoint.save_pretrained(str(tmp_path / "ref"), cfg, carried, [k for k in carried if k.startswith("multi_modal_projector.")], tower_keys)
+    m = UltravoxModel.from_pretrained(str(tmp_path / "ref"), base_state_dict=base, device=DEV)
+    assert set(tower_keys) <= m.keep_params
+    plain = UltravoxModel(cfg, state_dict=base, device=DEV)
+    b_ = _batch(cfg)
+    assert m.forward(**b_).loss.item() != plain.forward(**b_).loss.item()       # the carried tower tensors are in use
+    m.save_pretrained(str(tmp_path / "again"))
+    _, again = checkpoint.load_pretrained(str(tmp_path / "again"))
+    assert set(again) == set(carried) and all(torch.equal(again[k], carried[k]) for k in carried)
+    m.keep_params.add("audio_tower.layers.1.fc2.weight")                          # a promise with no tensor behind it raises
+    with pytest.raises(KeyError, match="cannot re-save"):
+        m.save_pretrained(str(tmp_path / "bad"))

@@ -122,12 +122,33 @@ def _mk(cls, value, presets, model_id):
         return cls()
     if isinstance(value, cls):
         return value
-    if isinstance(value, dict):
-        names = {f.name for f in dataclasses.fields(cls)}
-        return cls(**{k: v for k, v in value.items() if k in names})
-    # duck-typed HF config object
     names = {f.name for f in dataclasses.fields(cls)}
+    get = (lambda k: value.get(k)) if isinstance(value, dict) else (lambda k: getattr(value, k, None))   # dict or HF config object
+    _check_supported(cls, get)
+    if isinstance(value, dict):
+        return cls(**{k: v for k, v in value.items() if k in names})
     return cls(**{k: getattr(value, k) for k in names if hasattr(value, k)})
+
+
+def _check_supported(cls, get) -> None:
+    """Fields outside the dataclass are dropped by _mk, so anything that would change the arithmetic must be refused here:
+    a Qwen2 (q/k/v biases), Mistral (sliding window) or Gemma config would otherwise run silently as a bias-free Llama."""
+    want = cls.__dataclass_fields__["model_type"].default
+    mt = get("model_type")
+    if mt is not None and mt != want:
+        raise ValueError(f"{cls.__name__}: model_type {mt!r} is not built (this path implements {want!r})")
+    if cls is TextConfig:
+        for flag in ("attention_bias", "mlp_bias"):
+            if get(flag):
+                raise ValueError(f"text_config.{flag} = True is not built (the LLM kernels are bias-free, as Llama is)")
+        if get("sliding_window"):
+            raise ValueError("text_config.sliding_window is not built (full causal attention only)")
+        if get("tie_word_embeddings"):
+            raise ValueError("text_config.tie_word_embeddings = True: pass the embedding matrix as lm_head.weight "
+                             "(checkpoint.language_model_state_dict does this for tied checkpoints) and leave the flag unset")
+        act = get("hidden_act")
+        if act not in (None, "silu"):
+            raise ValueError(f"text_config.hidden_act {act!r} is not built (SwiGLU / silu only)")
 
 
 class UltravoxConfig:
@@ -166,6 +187,10 @@ class UltravoxConfig:
         # exist in Whisper / Llama) of the encoder (the release configs: r = 8) and / or the LLM
         for name, lc in (("audio", self.audio_model_lora_config), ("text", self.text_model_lora_config)):
             ar = int(lc.get("r", 0) or 0)
+            if lc.get("unfreeze_layers"):
+                # apply_lora with r = 0 unfreezes the matching layers (ultravox_model.py:694-703): full fine-tuning of tower
+                # layers is not built - refuse instead of leaving them silently frozen
+                raise ValueError(f"{name}_model_lora_config.unfreeze_layers is not built (tower layers stay frozen)")
             if ar == 0:
                 continue
             if not 0 < ar <= 64:
@@ -175,8 +200,6 @@ class UltravoxConfig:
             other = {m for m in tm if m in ("v_proj", "out_proj", "o_proj", "fc1", "fc2", "gate_proj", "up_proj", "down_proj")}
             if hit != {"q_proj", "k_proj"} or other:
                 raise ValueError(f"{name}_model_lora_config.target_modules = {tm}: only the default q_proj + k_proj adaptation is built")
-            if lc.get("unfreeze_layers"):
-                raise ValueError(f"{name}_model_lora_config.unfreeze_layers is only used with r = 0 and is not built")
         self.extra = kwargs
 
     def to_dict(self) -> Dict[str, Any]:

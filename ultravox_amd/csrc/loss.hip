@@ -13,12 +13,17 @@
 
 namespace {
 
-__global__ void ce_count_k(const int64_t* __restrict__ labels, float* __restrict__ scratch, int B, int T) {
+// Same validity predicate as ce_rows_k / sup_rows_k: a label outside [0, V) other than -100 (torch raises on it) is
+// treated as ignored by EVERY path - it must not deflate the mean of one path and not of the other.
+__global__ void ce_count_k(const int64_t* __restrict__ labels, float* __restrict__ scratch, int B, int T, int V) {
   __shared__ float red[16];
   float c = 0.f;
   for (long long i = threadIdx.x; i < (long long)B * T; i += blockDim.x) {
     const int t = (int)(i % T);
-    if (t + 1 < T && labels[i + 1] != -100) c += 1.f;
+    if (t + 1 < T) {
+      const int64_t tgt = labels[i + 1];
+      if (tgt != -100 && tgt >= 0 && tgt < V) c += 1.f;
+    }
   }
   c = block_sum(c, red);
   if (threadIdx.x == 0) scratch[0] = c;
@@ -273,7 +278,7 @@ int ce_loss_fwd_bwd(hipStream_t st, int dtype, const void* logits, const int64_t
   const long long rows = (long long)B * T;
   UVX_CHECK(rows > 0, UVX_ERR_SHAPE, "ce_loss: empty batch");
   if (sup) hipLaunchKernelGGL(ce_count_from_rows_k, dim3(1), dim3(64), 0, st, sup, scratch, rows);
-  else hipLaunchKernelGGL(ce_count_k, dim3(1), dim3(1024), 0, st, labels, scratch, B, T);
+  else hipLaunchKernelGGL(ce_count_k, dim3(1), dim3(1024), 0, st, labels, scratch, B, T, V);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(ce_rows_k<bf16_t>, dim3(rows), dim3(256), 0, st, (const bf16_t*)logits, labels, scratch, (bf16_t*)dlogits, T, V, (long long)ldl, grad_scale, sup, rows);
   else

@@ -292,20 +292,32 @@ class UltravoxModel:
     def trainable_parameter_names(self):
         return list(self.projector_state_dict().keys())
 
+    def _full_state_dict(self) -> Dict[str, torch.Tensor]:
+        """What can be saved from this model: the trainable tensors plus the frozen-tower tensors a loaded checkpoint carried
+        (`keep_params`, retained on the host by from_pretrained).  A keep_param with no tensor behind it would silently drop
+        out of the next save - the reload would then revert that tower to its base model id - so it raises instead."""
+        sd = {**getattr(self, "_kept_tensors", {}), **self.projector_state_dict()}
+        lost = sorted(k for k in self.keep_params if k not in sd)
+        if lost:
+            raise KeyError(f"keep_params names {len(lost)} tensor(s) this model cannot re-save (e.g. {lost[:3]}): frozen-tower keys "
+                           "are only retained when they arrive through from_pretrained")
+        return sd
+
     def diff_state_dict(self, state_dict: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """Trainable parameters + keys carried by a previously loaded checkpoint (`keep_params`)."""
         from . import checkpoint
-        sd = self.projector_state_dict() if state_dict is None else state_dict
+        sd = self._full_state_dict() if state_dict is None else state_dict
         return checkpoint.diff_state_dict(sd, self.trainable_parameter_names(), self.keep_params)
 
     def save_pretrained(self, save_directory: str, state_dict: Optional[Dict[str, torch.Tensor]] = None):
         from . import checkpoint
-        sd = self.projector_state_dict() if state_dict is None else state_dict
+        sd = self._full_state_dict() if state_dict is None else state_dict
         return checkpoint.save_pretrained(save_directory, self.config, sd, self.trainable_parameter_names(), self.keep_params)
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = False):
         """In-place load of projector keys (the trainable set); frozen-tower keys are only accepted at construction
-        time (`from_pretrained`), where they are packed into the device layouts.  Every loaded key joins keep_params."""
+        time (`from_pretrained`), where they are packed into the device layouts - here they are skipped (and reported as
+        unexpected).  Every key that was loaded joins keep_params."""
         mine = self.projector_state_dict()
         unexpected = [k for k in state_dict if k not in mine]
         missing = [k for k in mine if k not in state_dict]
@@ -318,7 +330,9 @@ class UltravoxModel:
                 if tuple(v.shape) != tuple(mine[k].shape):
                     raise ValueError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(mine[k].shape)}")
                 mine[k].copy_(v.to(device=self.device, dtype=self.dtype))
-        self.keep_params.update(state_dict.keys())
+        # only what was actually loaded joins keep_params: tower keys are ignored here (strict=False), and recording them would
+        # promise a re-save of tensors this model does not hold
+        self.keep_params.update(k for k in state_dict if k in mine)
         return missing, unexpected
 
     @classmethod
@@ -339,11 +353,19 @@ class UltravoxModel:
             for k, v in random_state_dict(config, seed=kwargs.get("seed", 0), dtype=dtype).items():
                 if k.startswith("multi_modal_projector."):
                     base_state_dict.setdefault(k, v)       # a projector the checkpoint does not carry starts from its init
-        base = base_state_dict if base_state_dict is not None else random_state_dict(
+        base = dict(base_state_dict) if base_state_dict is not None else random_state_dict(
             config, seed=kwargs.get("seed", 0), dtype=dtype)
+        # adapters (apply_lora -> get_peft_model, ultravox_model.py:690-709) exist in the model before the checkpoint is loaded
+        # over it: peft's initialisation unless the base already carries them
+        for k, v in init_lora_state_dict(config, seed=kwargs.get("seed", 0), dtype=dtype).items():
+            base.setdefault(k, v)
         merged, keep = checkpoint.merge_state_dict(base, ckpt)
         model = cls(config, state_dict=merged, **kwargs)
         model.keep_params.update(keep)
+        # frozen-tower tensors a checkpoint carried are re-saved with it (ultravox_model.py:565-591 keeps every keep_param);
+        # they live packed on the device, so the originals are retained on the host for save_pretrained
+        trainable = set(model.trainable_parameter_names())
+        model._kept_tensors = {k: merged[k].detach().to("cpu") for k in keep if k not in trainable}
         return model
 
     @torch.no_grad()
