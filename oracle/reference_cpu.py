@@ -28,16 +28,23 @@ import torch.nn.functional as F
 N_FFT, HOP = 400, 160
 
 # bf16 runs only.  False: eager attention as HF's `eager` class computes it in the model dtype (scores rounded to bf16).
-# True: attention internals as a FUSED kernel computes them (torch SDPA's flash / mem-efficient back ends, which is what the
-# reference's default `sdpa` attention class dispatches to on a GPU, and this repo's flash kernels): q, k, v in the model dtype,
-# scores and softmax statistics in f32, probabilities rounded to the model dtype as the P.V operand, f32 accumulation, one
-# rounding of the output.  Every other rounding point (linear outputs, norms, RoPE, activations, residual adds) is torch's own
-# bf16 module-by-module rounding in both settings.
+# True: attention as a FUSED flash kernel computes it (torch SDPA's flash back end, which the reference's default `sdpa`
+# attention class dispatches to on a GPU, and this repo's kernels): q, k, v in the model dtype, scores and softmax statistics
+# in f32, keys walked in tiles of FLASH_TILE with a running row maximum, the probabilities of a tile rounded to the model
+# dtype RELATIVE TO THE RUNNING MAXIMUM at that tile (exp(s - m_run), un-normalised) as the P.V operand, f32 accumulation
+# with the usual rescaling, one division by the f32 row sum and one rounding of the output.  The backward recomputes
+# P = exp(s - lse) from the saved log-sum-exp and rounds P and dS = P * (dP - delta) to the model dtype as matmul operands.
+# Why the tile walk is restated at all: the rounding of P is the one rounding point of the path whose REALISATION depends on
+# the implementation (normalised vs running-max-relative), and one differently rounded attention output decorrelates every
+# later bf16 rounding - two bf16 implementations that differ only there end up as far apart as bf16 is from f32 (measured:
+# 4.6e-3 rel-L2 after two encoder layers either way).  Every other rounding point (linear outputs, norms, RoPE, activations,
+# residual adds) is torch's own bf16 module-by-module rounding in both settings.
 FUSED_ATTENTION = False
+FLASH_TILE = 64
 
 
 class fused_attention:
-    """with fused_attention(): ... - run the bf16 oracle with f32 attention scores (see FUSED_ATTENTION)."""
+    """with fused_attention(): ... - run the bf16 oracle with flash-kernel attention rounding (see FUSED_ATTENTION)."""
 
     def __enter__(self):
         global FUSED_ATTENTION
@@ -48,15 +55,57 @@ class fused_attention:
         FUSED_ATTENTION = self._old
 
 
+class _FlashAttend(torch.autograd.Function):
+    """Flash attention with the rounding points stated at FUSED_ATTENTION, over [B, H, T, dh] operands."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale):
+        dt = q.dtype
+        s = (q.float() @ k.float().transpose(-1, -2)) * scale
+        if mask is not None:
+            s = s.masked_fill(mask.float().expand_as(s) < -1e30, float("-inf"))
+        Tk = s.shape[-1]
+        m = torch.full(s.shape[:-1], float("-inf"))
+        l = torch.zeros(s.shape[:-1])
+        o = torch.zeros(*s.shape[:-1], v.shape[-1])
+        vf = v.float()
+        for k0 in range(0, Tk, FLASH_TILE):
+            st = s[..., k0:k0 + FLASH_TILE]
+            m_new = torch.maximum(m, st.max(-1).values)
+            m_use = torch.where(torch.isinf(m_new), torch.zeros_like(m_new), m_new)      # a row with no valid key so far
+            alpha = torch.exp(m - m_use)                                                  # exp(-inf) = 0
+            pt = torch.exp(st - m_use[..., None])
+            l = l * alpha + pt.sum(-1)
+            o = o * alpha[..., None] + pt.to(dt).float() @ vf[..., k0:k0 + FLASH_TILE, :]
+            m = m_new
+        out = (o / l[..., None]).to(dt)
+        ctx.save_for_backward(q, k, v, out, m + torch.log(l))
+        ctx.mask, ctx.scale = mask, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dt = q.dtype
+        s = (q.float() @ k.float().transpose(-1, -2)) * ctx.scale
+        if ctx.mask is not None:
+            s = s.masked_fill(ctx.mask.float().expand_as(s) < -1e30, float("-inf"))
+        pr = torch.exp(s - lse[..., None])
+        do = dout.float()
+        delta = (do * out.float()).sum(-1, keepdim=True)
+        dp = do @ v.float().transpose(-1, -2)
+        ds = (pr * (dp - delta)).to(dt).float()
+        dv = (pr.to(dt).float().transpose(-1, -2) @ do).to(dt)
+        dq = ((ds @ k.float()) * ctx.scale).to(dt)
+        dk = ((ds.transpose(-1, -2) @ q.float()) * ctx.scale).to(dt)
+        return dq, dk, dv, None, None
+
+
 def _attend(q, k, v, mask, scale: float):
     """softmax(q k^T * scale + mask) v over [B, H, T, dh] operands; mask additive (finfo.min) or None."""
     dt = q.dtype
     if FUSED_ATTENTION and dt != torch.float32:
-        s = (q.float() @ k.float().transpose(-1, -2)) * scale
-        if mask is not None:
-            s = s + mask.float()
-        p = torch.softmax(s, dim=-1).to(dt)
-        return (p.float() @ v.float()).to(dt)
+        return _FlashAttend.apply(q, k, v, mask, scale)
     s = q @ k.transpose(-1, -2)
     if scale != 1.0:
         s = s * scale

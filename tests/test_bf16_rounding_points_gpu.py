@@ -105,7 +105,7 @@ def test_adamw_update_is_pinned_elementwise_on_the_device_gradients(clip):
         p.grad = model.proj_grad.detach().cpu().clone()                     # the gradients the device produced
         gn = torch.nn.utils.clip_grad_norm_([p], clip)
         opt.step()
-        assert abs(trainer.grad_norm().item() - gn.item()) <= 1e-5 * gn.item()
+        assert abs(trainer.grad_norm().item() - gn.item()) <= 1e-4 * gn.item()     # f32 sum of ~1e6 squares, two summation orders
         d = (trainer.master.cpu() - p.detach()).abs().max().item()
         # one AdamW step moves a weight by <= lr = 2e-3; what may differ is f32 round-off (bias corrections computed in f32
         # here and in double by torch; one ulp of a 0.4-sized weight is 3e-8)

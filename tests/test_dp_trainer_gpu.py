@@ -64,7 +64,8 @@ def _worker(rank, world, port, overlap, q):
     losses = [trainer.train_step(**batches[rank]).item() for _ in range(STEPS)]
     trainer.flush()
     torch.cuda.synchronize()
-    q.put((rank, losses, trainer.master.cpu(), model.proj_flat.float().cpu()))
+    # numpy: pickled by value (a torch tensor travels as a shared-memory handle that dies with this process)
+    q.put((rank, losses, trainer.master.cpu().numpy(), model.proj_flat.float().cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,7 +81,7 @@ def _run(world, overlap):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    return res
+    return [(r, losses, torch.from_numpy(a), torch.from_numpy(b)) for r, losses, a, b in res]
 
 
 def test_two_rank_trainer_overlapped_equals_sequential_equals_ddp_mean():

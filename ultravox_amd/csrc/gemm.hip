@@ -793,6 +793,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   constexpr int N234 = (REST + 7) / 8;                                     // per wave, phases 2-4 together
   constexpr int N2 = (N234 + 2) / 3, N3 = (N234 - N2 + 1) / 2, N4 = N234 - N2 - N3;
   static_assert(8 * N2 <= XA_I + W_I, "WB must not be re-staged in the phase that reads it");
+  constexpr int PRIO = MODE == 5 ? 1 : MODE == 6 ? 2 : MODE == 7 ? 3 : 0;  // MODE 5..7: issue-priority probes
   constexpr int TL_TILES = 64, TL_WAVE = TL_TILES * 12 * 4;                // MODE 4: stamp bytes per wave
   constexpr int O_DUMMY = NS * SET, O_STAGE = O_DUMMY + 1024, LDS_BYTES = O_STAGE + (PERSIST ? 8 * 2048 : 0) + (MODE == 4 ? 8 * TL_WAVE : 0);
   static_assert(LDS_BYTES <= 160 * 1024, "buffer sets exceed the LDS");
@@ -873,12 +874,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     glds16(sl.g + t * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_idx * SET));
   };
 #define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// PRIO (probe): who gets issue priority on a SIMD shared by a wave in its MFMA section and one in its load section.
+// 0 = the MFMA section runs at s_setprio 1 (the template's choice); 1 = no priorities; 2 = the LOAD section runs at
+// priority 1 (a handful of ds_read / LDS-DMA issues that gate the next barrier, against 16 MFMAs that need one issue slot
+// per 16 cycles); 3 = static: the second-dispatched wave row at priority 1 throughout (MI355X_MICROARCH.md item 4).
 #define UVX_PHASE_SYNC()                                   \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
   __builtin_amdgcn_sched_barrier(0);                       \
   __builtin_amdgcn_s_barrier();                            \
   __builtin_amdgcn_sched_barrier(0);                       \
-  __builtin_amdgcn_s_setprio(1)
+  if (PRIO == 0) __builtin_amdgcn_s_setprio(1);            \
+  if (PRIO == 2) __builtin_amdgcn_s_setprio(0)
 // MODE 4 stamps: UVX_TL_TAKE(k) reads the clock into tl[k]; UVX_TL_FLUSH(ph) writes the previous phase's three stamps
 #define UVX_TL_TAKE(k)                                                             \
   if (MODE == 4) {                                                                 \
@@ -891,9 +897,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     d_[0] = (unsigned)tl[0]; d_[1] = (unsigned)tl[1]; d_[2] = (unsigned)tl[2];     \
   }
 #define UVX_PHASE_END()                                    \
-  __builtin_amdgcn_s_setprio(0);                           \
+  if (PRIO == 0) __builtin_amdgcn_s_setprio(0);            \
   __builtin_amdgcn_sched_barrier(0);                       \
   __builtin_amdgcn_s_barrier();                            \
+  if (PRIO == 2) __builtin_amdgcn_s_setprio(1);            \
   __builtin_amdgcn_sched_barrier(0)
 
   const int nk = p.K / BK;
@@ -921,6 +928,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: this half runs one barrier behind
+  if (PRIO == 3 && wr == 1) __builtin_amdgcn_s_setprio(1);
+  if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
   __builtin_amdgcn_sched_barrier(0);
 
   f32x4_t acc[4][MI];
@@ -1035,6 +1044,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     cs = cs == NS - 1 ? 0 : cs + 1;
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
+  if (PRIO >= 2) __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
 
   if (MODE == 4) {   // probe: dump the stamps of the first four blocks instead of the tile
@@ -1345,7 +1355,7 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 28;
+constexpr int kNumVariants = 31;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
@@ -1353,7 +1363,8 @@ const Variant kVariants[kNumVariants] = {
     {160, 256, 1230., 9.},  {192, 256, 1390., 12.}, {128, 256, 1116., 6.},
     {160, 256, 1245., 9.},  {128, 256, 0., 6.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   // 20..22 = probe modes of 11
     {256, 256, 0., 4.},     {192, 256, 0., 6.},     {160, 256, 0., 5.},     {128, 256, 0., 4.},
-    {256, 256, 0., 9.}};   // 27 = timeline probe of 11 (MODE 4)
+    {256, 256, 0., 9.},    // 27 = timeline probe of 11 (MODE 4)
+    {256, 256, 0., 9.},     {256, 256, 0., 9.},     {256, 256, 0., 9.}};   // 28..30 = issue-priority probes of 11 (MODE 5..7)
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 double variant_cost(int v, int M, int N, int K, int batch) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
@@ -1409,6 +1420,9 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 21: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 2>), grid, dim3(512), 0, st, a); break;
     case 22: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 3>), grid, dim3(512), 0, st, a); break;
     case 27: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 4>), grid, dim3(512), 0, st, a); break;
+    case 28: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 5>), grid, dim3(512), 0, st, a); break;
+    case 29: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 6>), grid, dim3(512), 0, st, a); break;
+    case 30: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 7>), grid, dim3(512), 0, st, a); break;
     case 23: case 24: case 25: case 26: {
       // persistent: one block per CU walks the tiles (batched problems use the plain kernels: grid.y would oversubscribe)
       if (batch != 1) { launch_variant(st, variant == 23 ? 11 : variant == 24 ? 16 : variant == 25 ? 15 : 17, a, M, N, batch); return; }
