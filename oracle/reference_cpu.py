@@ -12,7 +12,11 @@ restatement; it is pinned against
   * the reference's `_get_prediction_mask` / `_compute_kl_loss`, `init_latency_mask` and `diff_state_dict`, called from the
     imported reference module on stub objects (fixtures kl_loss.npz, latency_mask.npz, diff_state_dict.json);
   * the installed HF WhisperFeatureExtractor, WhisperEncoderLayer and LlamaForCausalLM blocks
-    (tests/test_oracle_pinning.py), which are the third-party arithmetic the reference calls.
+    (tests/test_oracle_pinning.py), which are the third-party arithmetic the reference calls;
+  * the reference's `apply_lora` (ultravox_model.py:690-709) run on installed-HF towers through tests/peft_stub.py (fixture
+    lora_reference.npz / .json): adapted modules, trainable and checkpoint key names, forward and adapter gradients of the
+    LoRA sub-path.  peft itself (pinned ~0.11.1) cannot be installed here; its Linear.forward is restated by that stub, which is
+    the one part of this pin that is not the reference's or HF's own code.
 Floating-point parity of mel / encoder / logits / loss / grads is NOT pinned by any reference test
 ("parity unpinned" at the fp level); integer/index behaviour is pinned.
 """
@@ -239,10 +243,10 @@ def whisper_encoder_ref(sd: Dict[str, torch.Tensor], cfg, input_features: torch.
         q = F.linear(h, W(L + "self_attn.q_proj.weight"), W(L + "self_attn.q_proj.bias"))
         k = F.linear(h, W(L + "self_attn.k_proj.weight"))
         if lora is not None:
-            # peft LoRA (apply_lora -> get_peft_model, ultravox_model.py:690-709) on q_proj / k_proj, dropout 0.  peft
-            # (pyproject.toml:15 pins ~0.11.1) is NOT installed here: restated from its published algorithm
-            # (peft/tuners/lora/layer.py, Linear.forward) - parity of this sub-path is unpinned by reference fixtures:
-            # result = base(x) + lora_B(lora_A(x)) * (lora_alpha / r); the adapter matrices live in sd under peft's names
+            # peft LoRA (apply_lora -> get_peft_model, ultravox_model.py:690-709) on q_proj / k_proj, dropout 0:
+            # result = base(x) + lora_B(lora_A(x)) * (lora_alpha / r); the adapter matrices live in sd under peft's names.
+            # Pinned by tests/golden/lora_reference.npz: the reference's apply_lora on an HF WhisperEncoder through
+            # tests/peft_stub.py (peft ~0.11.1, pyproject.toml:15, is not installable here; the stub restates its Linear)
             def lo(pj):
                 A = sd[f"{prefix}base_model.model.layers.{i}.self_attn.{pj}.lora_A.default.weight"].to(dt)
                 Bm = sd[f"{prefix}base_model.model.layers.{i}.self_attn.{pj}.lora_B.default.weight"].to(dt)
@@ -332,8 +336,8 @@ def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
               n_layers: Optional[int] = None, position_ids: Optional[torch.Tensor] = None,
               lora: Optional[dict] = None) -> torch.Tensor:
     """-> logits [B, T, V] in the dtype of inputs_embeds.  lora = {"scaling": ..}: peft adapters on q_proj / k_proj
-    (text_model_lora_config; keys under `language_model.base_model.model.model.layers.N.self_attn.*`), restated like the
-    encoder's (peft 0.11.1 is not installed: unpinned sub-path)."""
+    (text_model_lora_config; keys under `language_model.base_model.model.model.layers.N.self_attn.*`), pinned like the
+    encoder's by tests/golden/lora_reference.npz (the reference's apply_lora on an HF LlamaForCausalLM via tests/peft_stub.py)."""
     tc = cfg.text_config
     dt = inputs_embeds.dtype
     B, T, D = inputs_embeds.shape

@@ -19,7 +19,12 @@ What is recorded
                     package: its real one needs librosa / soundfile) over the reference processor and FakeChatTokenizer:
                     input_ids / labels / alt_* for every loss-mask type, alt fields, response truncation, inference mode.
   logmel.npz      — HF WhisperFeatureExtractor (the [3P] K1 arithmetic) on seeded PCM, 80 and 128 mels.
+  lora_reference.npz / .json — the REFERENCE apply_lora (ultravox_model.py:690-709) run on an installed-HF WhisperEncoder and
+                    LlamaForCausalLM with the reference's own LoraConfigSimplified defaults, through tests/peft_stub.py
+                    (peft itself is not installable here: the stub restates peft 0.11.1's LoRA Linear and says so): adapted
+                    module set, trainable names, state-dict key names, forward outputs and adapter gradients.
 """
+import dataclasses
 import json
 import os
 import sys
@@ -31,15 +36,11 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, "/root/reference")
+sys.path.insert(1, os.path.dirname(os.path.dirname(HERE)))      # repo root: ultravox_amd (weights / config only, no GPU)
 
-peft = types.ModuleType("peft")
-peft.LoraConfig = lambda **kw: types.SimpleNamespace(r=kw.get("r", 0))
-peft.PeftModel = type("PeftModel", (), {})
-peft.get_peft_model = lambda m, c: m
-peft.peft_model = types.ModuleType("peft.peft_model")
-peft.peft_model.PeftModel = peft.PeftModel
-sys.modules["peft"] = peft
-sys.modules["peft.peft_model"] = peft.peft_model
+import peft_stub  # noqa: E402  (tests/peft_stub.py: the three names the reference imports from peft, restated)
+
+peft_stub.install()
 
 import transformers  # noqa: E402
 from fake_tokenizer import FakeTokenizer  # noqa: E402
@@ -360,7 +361,97 @@ def diff_state_dict_cases():
     print("diff_state_dict.json:", [c["name"] for c in cases])
 
 
+def lora_cases():
+    """apply_lora on HF towers -> what is adapted, what trains, under which names, and what comes out."""
+    from transformers import LlamaConfig, LlamaForCausalLM, WhisperConfig
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import random_state_dict
+    tiny = dict(audio_config=dict(d_model=64, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=128, num_mel_bins=80,
+                                  max_source_positions=1500),
+                text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                 num_key_value_heads=2, vocab_size=256, rope_theta=10000.0, max_position_embeddings=512),
+                hidden_size=128, stack_factor=8, projector_ln_mid=True)
+    cfg = UltravoxConfig(**tiny)
+    a, t = cfg.audio_config, cfg.text_config
+    sd = random_state_dict(cfg, seed=17)
+    # the reference's own defaults for everything but r: LoraConfigSimplified (ultravox_config.py:8-23)
+    simp = ultravox_config.LoraConfigSimplified
+    arrays, meta = {}, {"tiny": tiny, "seed": 17}
+
+    def lora_dict(r):
+        d = dataclasses.asdict(simp(r=r))
+        meta.setdefault("lora_config", {})[str(r)] = {k: v for k, v in d.items()}
+        return d
+
+    def randomise_b(model, seed):          # peft starts lora_B at zero: give it values so that the forward depends on it
+        g = torch.Generator().manual_seed(seed)
+        for n, p in model.named_parameters():
+            if "lora_B" in n:
+                p.data = 0.05 * torch.randn(p.shape, generator=g)
+
+    # ---- encoder ----
+    enc = WhisperEncoder(WhisperConfig(d_model=a.d_model, encoder_layers=a.encoder_layers, encoder_attention_heads=a.encoder_attention_heads,
+                                       encoder_ffn_dim=a.encoder_ffn_dim, num_mel_bins=a.num_mel_bins,
+                                       max_source_positions=a.max_source_positions, attn_implementation="eager")).eval()
+    enc.load_state_dict({k[len("audio_tower."):]: v for k, v in sd.items() if k.startswith("audio_tower.")}, strict=False)
+    wrapped = ultravox_model.apply_lora(enc, lora_dict(4))
+    randomise_b(wrapped, 1)
+    names = [n for n, p in wrapped.named_parameters() if p.requires_grad]
+    meta["encoder"] = {"trainable": names, "state_dict_keys": sorted(wrapped.state_dict().keys()),
+                       "adapted": sorted({n.split(".lora_")[0] for n in names})}
+    torch.manual_seed(0)
+    x, audio_len = torch.randn(2, 80, 120), torch.tensor([120, 75])
+    inner = wrapped.base_model.model
+    h = torch.nn.functional.gelu(inner.conv1(x))
+    h = torch.nn.functional.gelu(inner.conv2(h)).permute(0, 2, 1)
+    h = h + inner.embed_positions.weight[: h.size(-2)]
+    keep = torch.arange(h.shape[1])[None, :].lt(((audio_len - 1) // 2 + 1).view(-1, 1))
+    mask = (1.0 - keep[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    for layer in inner.layers:
+        out = layer(h, mask)
+        h = out[0] if isinstance(out, tuple) else out
+    y = inner.layer_norm(h)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    (y * gy).sum().backward()
+    arrays.update({"enc.x": x.numpy(), "enc.audio_len": audio_len.numpy(), "enc.y": y.detach().numpy(), "enc.gy": gy.numpy()})
+    for n, p in wrapped.named_parameters():
+        if p.requires_grad:
+            arrays["enc.w." + n], arrays["enc.g." + n] = p.detach().numpy(), p.grad.numpy()
+
+    # ---- language model ----
+    llm = LlamaForCausalLM(LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size, num_hidden_layers=t.num_hidden_layers,
+                                       num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+                                       vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta,
+                                       max_position_embeddings=t.max_position_embeddings, tie_word_embeddings=False,
+                                       attn_implementation="eager")).eval()
+    llm.load_state_dict({k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}, strict=False)
+    wl = ultravox_model.apply_lora(llm, lora_dict(2))
+    randomise_b(wl, 3)
+    names = [n for n, p in wl.named_parameters() if p.requires_grad]
+    meta["llm"] = {"trainable": names, "adapted": sorted({n.split(".lora_")[0] for n in names}),
+                   "n_state_dict_keys": len(wl.state_dict())}
+    emb = 0.5 * torch.randn(2, 21, t.hidden_size, generator=torch.Generator().manual_seed(4))
+    am = torch.ones(2, 21, dtype=torch.long)
+    am[1, -5:] = 0
+    logits = wl(inputs_embeds=emb, attention_mask=am).logits
+    gl = torch.randn(logits.shape, generator=torch.Generator().manual_seed(5)) * am[..., None]
+    (logits * gl).sum().backward()
+    arrays.update({"llm.emb": emb.numpy(), "llm.mask": am.numpy(), "llm.logits": logits.detach().numpy(), "llm.gl": gl.numpy()})
+    for n, p in wl.named_parameters():
+        if p.requires_grad:
+            arrays["llm.w." + n], arrays["llm.g." + n] = p.detach().numpy(), p.grad.numpy()
+    # r = 0: apply_lora freezes everything (no peft call)
+    frozen = ultravox_model.apply_lora(torch.nn.Linear(3, 3), dataclasses.asdict(simp(r=0)))
+    meta["r0_trainable"] = [n for n, p in frozen.named_parameters() if p.requires_grad]
+    np.savez_compressed(os.path.join(HERE, "lora_reference.npz"), **arrays)
+    with open(os.path.join(HERE, "lora_reference.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("lora_reference:", meta["encoder"]["adapted"], meta["llm"]["adapted"])
+
+
 if __name__ == "__main__":
+    lora_cases()
     processor_cases()
     projector_cases()
     latency_mask_cases()

@@ -274,3 +274,46 @@ def test_kl_compact_pairs_reproduce_reference_loss(golden_dir, case):
                 lt = F.log_softmax(t[pc[slot, r]] / tau, -1)
                 tot += pwc[slot, r].item() * (lt.exp() * (lt - F.log_softmax(s[r] / tau, -1))).sum().item()
     assert abs(tot - float(g("loss"))) <= 2e-6 * max(1.0, abs(float(g("loss"))))
+
+
+def test_lora_restatement_matches_reference_apply_lora_fixture(golden_dir):
+    """The REFERENCE's apply_lora (ultravox_model.py:690-709) run on installed-HF towers through tests/peft_stub.py
+    (tests/golden/make_golden.py::lora_cases): the adapted module set, the trainable / checkpoint key names, the forward and
+    the adapter gradients of the adapted encoder and LLM == the oracle's LoRA restatement and this package's key names.
+    (peft's own arithmetic is restated by the stub - peft cannot be installed here - and that residue is stated there.)"""
+    import json
+    from ultravox_amd.weights import init_lora_state_dict, llm_lora_key, lora_key
+    z = np.load(os.path.join(golden_dir, "lora_reference.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "lora_reference.json")))
+    cfg = UltravoxConfig(**meta["tiny"], audio_model_lora_config=meta["lora_config"]["4"], text_model_lora_config=meta["lora_config"]["2"])
+    # the reference's LoraConfigSimplified defaults reach peft unchanged, and r = 0 freezes everything without calling peft
+    assert meta["lora_config"]["4"]["target_modules"] == ["k_proj", "q_proj", "linear_k", "linear_q"] and meta["r0_trainable"] == []
+    assert meta["lora_config"]["4"]["lora_alpha"] == 8
+    # which modules are adapted and under which names the checkpoint carries them
+    enc_names = {"audio_tower." + n for n in meta["encoder"]["trainable"]}
+    llm_names = {"language_model." + n for n in meta["llm"]["trainable"]}
+    mine = set(init_lora_state_dict(cfg))
+    assert mine == enc_names | llm_names
+    assert lora_key(1, "q_proj", "A") in enc_names and llm_lora_key(0, "k_proj", "B") in llm_names
+    assert "base_model.model.layers.0.self_attn.q_proj.base_layer.weight" in meta["encoder"]["state_dict_keys"]   # peft renames the wrapped linear
+    assert "base_model.model.layers.0.self_attn.v_proj.weight" in meta["encoder"]["state_dict_keys"]               # v_proj is not adapted
+    sd = random_state_dict(cfg, seed=meta["seed"])
+    for tower, prefix in (("enc", "audio_tower."), ("llm", "language_model.")):
+        for k in z.files:
+            if k.startswith(tower + ".w."):
+                sd[prefix + k[len(tower) + 3:]] = torch.from_numpy(z[k]).clone().requires_grad_(True)
+    # encoder
+    y = O.whisper_encoder_ref(sd, cfg, torch.from_numpy(z["enc.x"]), torch.from_numpy(z["enc.audio_len"]),
+                              lora={"scaling": meta["lora_config"]["4"]["lora_alpha"] / 4})
+    np.testing.assert_allclose(y.detach().numpy(), z["enc.y"], rtol=1e-4, atol=2e-5)
+    (y * torch.from_numpy(z["enc.gy"])).sum().backward()
+    for n in meta["encoder"]["trainable"]:
+        np.testing.assert_allclose(sd["audio_tower." + n].grad.numpy(), z["enc.g." + n], rtol=2e-4, atol=2e-5, err_msg=n)
+    # language model
+    logits = O.llama_ref(sd, cfg, torch.from_numpy(z["llm.emb"]), torch.from_numpy(z["llm.mask"]),
+                         lora={"scaling": meta["lora_config"]["2"]["lora_alpha"] / 2})
+    keep = torch.from_numpy(z["llm.mask"]).bool()
+    np.testing.assert_allclose(logits.detach()[keep].numpy(), z["llm.logits"][keep.numpy()], rtol=1e-4, atol=2e-5)
+    (logits * torch.from_numpy(z["llm.gl"])).sum().backward()
+    for n in meta["llm"]["trainable"]:
+        np.testing.assert_allclose(sd["language_model." + n].grad.numpy(), z["llm.g." + n], rtol=2e-4, atol=2e-5, err_msg=n)
