@@ -145,6 +145,70 @@ def cpu_baseline(cfg, seconds: float, n_text: int = 128):
     }
 
 
+def cpu_baseline_full(cfg, seconds: float, n_text: int = 128, steps: int = 1):
+    """ONE WHOLE adapter-train step of the workload at B = 1 through the oracle on the host cores - all encoder and LLM layers,
+    nothing extrapolated (`python bench.py --cpu-baseline-full`; the result is cached in profiles/ and quoted by the default
+    run next to the bounded-sample figure).  Weights: one seeded random layer per tower, copied into DISTINCT memory for every
+    layer (generating 8 G random f32 numbers would take longer than the step; the values do not matter for timing, the
+    memory traffic does)."""
+    from oracle import reference_cpu as O
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import random_state_dict
+    import dataclasses
+
+    avail_kb = 0
+    try:
+        avail_kb = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1])
+    except Exception:
+        pass
+    a, t = cfg.audio_config, cfg.text_config
+    need_gb = (t.num_hidden_layers * (4 * t.hidden_size * t.hidden_size // 2 + 3 * t.hidden_size * t.intermediate_size) +
+               2 * t.vocab_size * t.hidden_size) * 4 / 2 ** 30 * 1.5
+    if avail_kb and avail_kb / 2 ** 20 < need_gb:
+        raise MemoryError(f"{avail_kb / 2 ** 20:.0f} GB of host memory available, the f32 oracle needs about {need_gb:.0f} GB")
+    cores = min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    one = UltravoxConfig(audio_config=dataclasses.replace(a, encoder_layers=1), text_config=dataclasses.replace(t, num_hidden_layers=1),
+                         hidden_size=cfg.hidden_size, stack_factor=cfg.stack_factor, projector_ln_mid=cfg.projector_ln_mid)
+    sd = random_state_dict(one, seed=0, dtype=torch.float32)
+    for i in range(1, a.encoder_layers):
+        for k in [k for k in sd if k.startswith("audio_tower.layers.0.")]:
+            sd[k.replace("layers.0.", f"layers.{i}.", 1)] = sd[k].clone()
+    for i in range(1, t.num_hidden_layers):
+        for k in [k for k in sd if k.startswith("language_model.model.layers.0.")]:
+            sd[k.replace("layers.0.", f"layers.{i}.", 1)] = sd[k].clone()
+    om = O.OracleModel(cfg, sd, dtype=torch.float32)
+    del sd
+    b = O.synthetic_batch(cfg, 1, seconds, n_text=n_text)
+    pcm = b.pop("pcm")
+
+    def step():
+        mel = O.logmel_ref(pcm, a.num_mel_bins)
+        out, grads, _ = om.train_step({**b, "audio_values": mel})
+        return float(out["loss"])
+
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        loss = step()
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": seconds / best, "unit": "audio-seconds/sec", "cores": cores, "kind": "port", "step_seconds": times,
+            "sample": f"oracle f32, ONE WHOLE step at B=1x{seconds:g}s: log-mel, {a.encoder_layers} encoder layers, projector, "
+                      f"{t.num_hidden_layers} LLM layers + lm_head + CE forward and backward (nothing extrapolated; loss {loss:.3f})"}
+
+
+def cached_cpu_baseline_full(workload: str, profiles_dir=None):
+    """The newest committed whole-step CPU measurement (profiles/rNN_cpu_baseline_full.json) for this workload, or None."""
+    d = profiles_dir or os.path.join(ROOT, "profiles")
+    try:
+        names = sorted(n for n in os.listdir(d) if n.startswith("r") and n.endswith("_cpu_baseline_full.json"))
+        rec = json.load(open(os.path.join(d, names[-1]))) if names else None
+        return rec if rec and rec.get("workload") == workload else None
+    except (OSError, ValueError):
+        return None
+
+
 def pmc_traffic_per_launch(profiles_dir=None):
     """roofline.traffic: memory-side bytes per GEMM launch from the newest committed PMC summary (profiles/rNN_pmc_traffic.json,
     written by tools/pmc_traffic.sh from separate FETCH_SIZE / WRITE_SIZE passes over this same command), or None."""
@@ -179,6 +243,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", default=None, metavar="OUT.json",
+                    help="CPU only: time ONE WHOLE step of the workload at B = 1 through the oracle (all layers) and write the record")
     ap.add_argument("--no-prof", action="store_true", help="skip the live HIP-event timing of the GEMM kernel")
     ap.add_argument("--audio-lora-r", type=int, default=0,
                     help="train rank-r LoRA on the encoder's q_proj/k_proj too (the reference's release recipe, "
@@ -192,6 +258,16 @@ def main():
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table (from the HIP events) here")
     args = ap.parse_args()
 
+    if args.cpu_baseline_full:
+        from ultravox_amd.config import UltravoxConfig
+        wl = WORKLOADS[args.workload]
+        cfg = UltravoxConfig(audio_model_id=wl["audio"], text_model_id=wl["text"], hidden_size=4096, stack_factor=8, projector_ln_mid=True)
+        rec = cpu_baseline_full(cfg, wl["seconds"])
+        rec["workload"] = args.workload
+        with open(args.cpu_baseline_full, "w") as f:
+            json.dump(rec, f, indent=1)
+        print(json.dumps(rec))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` (how the driver may invoke it): become the launcher - one rank per GPU under
         # torch.distributed.run on 127.0.0.1, as the reference is started by torchrun (train.py:126-130, README.md:144-148).
@@ -338,6 +414,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(cfg, wl["seconds"])
             except Exception as e:  # the GPU number stands on its own; report why the CPU leg is missing
                 out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+            full = cached_cpu_baseline_full(args.workload)
+            if full:   # a whole B = 1 step measured once on a GPU box's host (bench.py --cpu-baseline-full), committed under profiles/
+                out["cpu_baseline"]["whole_step_measured"] = {k: full[k] for k in ("value", "unit", "cores", "sample") if k in full}
         if shapes:
             with open(args.gemm_table, "w") as f:
                 f.write("# per-shape bf16 GEMM time inside the timed region (HIP events), C2 step\n")

@@ -793,7 +793,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   constexpr int N234 = (REST + 7) / 8;                                     // per wave, phases 2-4 together
   constexpr int N2 = (N234 + 2) / 3, N3 = (N234 - N2 + 1) / 2, N4 = N234 - N2 - N3;
   static_assert(8 * N2 <= XA_I + W_I, "WB must not be re-staged in the phase that reads it");
-  constexpr int PRIO = MODE == 5 ? 1 : MODE == 6 ? 2 : MODE == 7 ? 3 : 0;  // MODE 5..7: issue-priority probes
+  constexpr int PRIO = MODE == 5 ? 1 : MODE == 6 ? 2 : MODE == 7 ? 0 : 3;  // production: 3 (static); MODE 5..7: probes of 1, 2, 0
   constexpr int TL_TILES = 64, TL_WAVE = TL_TILES * 12 * 4;                // MODE 4: stamp bytes per wave
   constexpr int O_DUMMY = NS * SET, O_STAGE = O_DUMMY + 1024, LDS_BYTES = O_STAGE + (PERSIST ? 8 * 2048 : 0) + (MODE == 4 ? 8 * TL_WAVE : 0);
   static_assert(LDS_BYTES <= 160 * 1024, "buffer sets exceed the LDS");
@@ -874,10 +874,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     glds16(sl.g + t * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_idx * SET));
   };
 #define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-// PRIO (probe): who gets issue priority on a SIMD shared by a wave in its MFMA section and one in its load section.
-// 0 = the MFMA section runs at s_setprio 1 (the template's choice); 1 = no priorities; 2 = the LOAD section runs at
-// priority 1 (a handful of ds_read / LDS-DMA issues that gate the next barrier, against 16 MFMAs that need one issue slot
-// per 16 cycles); 3 = static: the second-dispatched wave row at priority 1 throughout (MI355X_MICROARCH.md item 4).
+// PRIO: who gets issue priority on a SIMD shared by a wave in its MFMA section and one in its load section.
+// 3 (production) = static: the second-dispatched wave row runs at s_setprio 1 throughout, no per-section flips
+// (MI355X_MICROARCH.md "two waves per SIMD", item 4); 0 = the MFMA section at priority 1 (the 8-phase template's choice);
+// 1 = no priorities; 2 = the LOAD section at priority 1.  Cold-weight probe, same box (profiles/r02_gemm_prio_probe.txt):
+// static is +1.5 ... +6 % over 0 on six of the seven LLM shapes and never slower than -0.3 %; 1 and 2 sit in between.
 #define UVX_PHASE_SYNC()                                   \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
   __builtin_amdgcn_sched_barrier(0);                       \
@@ -1364,7 +1365,7 @@ const Variant kVariants[kNumVariants] = {
     {160, 256, 1245., 9.},  {128, 256, 0., 6.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   // 20..22 = probe modes of 11
     {256, 256, 0., 4.},     {192, 256, 0., 6.},     {160, 256, 0., 5.},     {128, 256, 0., 4.},
     {256, 256, 0., 9.},    // 27 = timeline probe of 11 (MODE 4)
-    {256, 256, 0., 9.},     {256, 256, 0., 9.},     {256, 256, 0., 9.}};   // 28..30 = issue-priority probes of 11 (MODE 5..7)
+    {256, 256, 0., 9.},     {256, 256, 0., 9.},     {256, 256, 0., 9.}};   // 28..30 = issue-priority probes of 11 (MODE 5..7: none / load section / MFMA section at priority 1)
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 double variant_cost(int v, int M, int N, int K, int batch) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
