@@ -16,7 +16,9 @@
  *    (thread local); no exception crosses the boundary;
  *  - dtype: UVX_BF16 (production: bf16 storage, f32 accumulate/statistics) or UVX_F32 (parity mode,
  *    every tensor f32);
- *  - threading: one process per GPU; a handle-free, re-entrant API with no global mutable state.
+ *  - threading: one process per GPU; a handle-free API.  The only process-wide mutable state is the set of tuning knobs
+ *    (uvx_set_option, uvx_gemm_force_variant, uvx_gemm_override_variant, uvx_attention_force_qt, uvx_prof_*): set them
+ *    before the first compute call, not concurrently with one; everything else is re-entrant.
  */
 #ifndef UVX_H_
 #define UVX_H_

@@ -1,6 +1,8 @@
 """GPU check of ONE bf16 GEMM tile variant: correctness on ragged / tiny-K / deep-K shapes with every epilogue, and a
 race screen (the same launch repeated 30x must be bit-identical: a mis-placed wait or barrier shows up as rare
 different tiles).  usage: gpu_gemm_check_variant.py <variant>"""
+import os
+os.environ.setdefault("UVX_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ultravox_amd", "libuvx_probes.so"))  # probe tile variants live in the probes build
 import sys
 import torch
 from ultravox_amd import ops, _lib

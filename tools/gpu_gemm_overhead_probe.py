@@ -1,5 +1,7 @@
 """GPU probe: fixed per-tile cost of a bf16 GEMM tile variant.  time(K) for K = 64 .. 4096 at fixed M, N is a straight line
 a + b * (K / 64); a / rounds is the pipeline fill + epilogue cost of one round of tiles, b the steady-state K-tile time."""
+import os
+os.environ.setdefault("UVX_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ultravox_amd", "libuvx_probes.so"))  # probe tile variants live in the probes build
 import sys
 import torch
 from ultravox_amd import ops, _lib

@@ -8,6 +8,8 @@ Prints, per phase and per wave-row (row 1 runs one barrier behind row 0), the me
 and the K-tile period, next to the un-instrumented kernel's period derived from its launch time.
 (written at the end of round 1 after the GPU budget was spent: the kernel compiles, its ISA was inspected, it has not run yet)
 usage: PYTHONPATH=. python tools/gpu_gemm_timeline.py [M N K]"""
+import os
+os.environ.setdefault("UVX_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ultravox_amd", "libuvx_probes.so"))  # probe tile variants live in the probes build
 import sys
 import torch
 from ultravox_amd import ops, _lib

@@ -8,7 +8,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "libuvx.so"
+import os
+
+# UVX_LIB: the probe tools (tools/gpu_gemm_*.py) load libuvx_probes.so, the same library plus the GEMM probe variants
+_LIB_PATH = Path(os.environ["UVX_LIB"]).resolve() if os.environ.get("UVX_LIB") else Path(__file__).resolve().parent / "libuvx.so"
 _lib = None
 
 BF16, F32 = 0, 1

@@ -507,233 +507,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Wide tile: BM(M) x 256(N) x 64(K), 512 threads = 8 waves in 2(M) x 4(N), each wave (BM/2) x 64.
-// BM in {128, 160, 192, 256} is chosen per problem so that (tiles x BM) fills the 256 CUs with the
-// fewest idle tile-rounds (e.g. M = 2528, N = 4096: BM = 160 gives exactly 16 x 16 = 256 tiles).
-// LDS is double buffered (2 x (BM + 256) x 128 B <= 128 KiB, one block per CU): the LDS-DMA loads of
-// K-tile t+1 are issued BEFORE the fragment reads / MFMAs of K-tile t and waited for only at the end
-// of the tile, so HBM/L2 latency hides under a whole tile of MFMA work and there is ONE barrier per
-// K-tile.  Same XOR swizzle as the narrow kernel.
-template <int BM>
-__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide_kernel(GemmArgs p) {
-  constexpr int BNW = 256;
-  constexpr int MI = BM / 32;               // 16-row fragments per wave along M
-  constexpr int XB = BM * 128, WB = BNW * 128, BUF = XB + WB;
-  constexpr int XI = BM / 8;                // wave-instructions to stage the X tile (8 rows each)
-  constexpr int XPW = (XI + 7) / 8;         // per wave (last one may be partial)
-  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = w >> 2, wc = w & 3;
-  const int nwg = gridDim.x, orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
-  const int m0 = tm * BM, n0 = tn * BNW;
-  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
-    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
-    if (m0 >= me) return;
-    p.M = me;
-  }
-  const long long z = blockIdx.y;
-  const bf16_t* A = p.A + z * p.sA;
-  const bf16_t* B = p.B + z * p.sB;
-
-  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const bf16_t* ap[XPW];
-  const bf16_t* bp[4];
-#pragma unroll
-  for (int i = 0; i < XPW; ++i) {
-    const int rr = min((i * 8 + w) * 8 + srow, BM - 1);
-    ap[i] = A + (long long)min(m0 + rr, p.M - 1) * p.lda + schunk * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rr = (i * 8 + w) * 8 + srow;
-    bp[i] = B + (long long)min(n0 + rr, p.N - 1) * p.ldb + schunk * 8;
-  }
-  const int frow = lane & 15, fg = lane >> 4;
-  int xoff[2], woff[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int pos = (ks * 4 + fg) ^ (frow & 7);
-    xoff[ks] = (wr * (BM / 2) + frow) * 128 + pos * 16;
-    woff[ks] = XB + (wc * 64 + frow) * 128 + pos * 16;
-  }
-
-  f32x4_t acc[4][MI];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  auto stage = [&](int k0, char* buf) {
-#pragma unroll
-    for (int i = 0; i < XPW; ++i)
-      if (i * 8 + w < XI) glds16(ap[i] + k0, buf + (i * 8 + w) * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(bp[i] + k0, buf + XB + (i * 8 + w) * 1024);
-  };
-
-  const int nt = p.K / BK;
-  stage(0, lds);
-  __builtin_amdgcn_s_waitcnt(0x0f70);
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    char* cur = lds + (t & 1) * BUF;
-    if (t + 1 < nt) stage((t + 1) * BK, lds + ((t + 1) & 1) * BUF);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t xa[MI], wa[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wa[j] = *reinterpret_cast<const bf16x8_t*>(cur + woff[ks] + j * 16 * 128);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8_t*>(cur + xoff[ks] + i * 16 * 128);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[j][i], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // next tile's LDS-DMA (issued a whole tile ago) has landed
-    __syncthreads();
-  }
-
-  __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
-  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ping-pong kernel: BM x 256 tile, 8 waves (2 x 4), K consumed in 32-wide sub-tiles held in a 4-deep LDS
-// ring (64-byte rows).  The two waves that share a SIMD (w and w+4, i.e. wr = 0 / 1) run ONE INTERVAL
-// OUT OF PHASE: every sub-tile is processed as an L segment (issue the LDS-DMA for sub-tile s+3, read this
-// sub-tile's 12 fragments, counted s_waitcnt) and an M segment (32 MFMAs under s_setprio 1), separated by
-// workgroup barriers; group wr = 1 executes one extra barrier first, so while one wave of a SIMD is in its
-// MFMA segment the other is in its load segment and the matrix pipe never waits for LDS traffic.
-//   RAW: a wave waits for ITS loads of sub-tile s+1 (s_waitcnt vmcnt(2*NL): sub-tiles s+2, s+3 may stay in
-//        flight) in L(s); two barriers separate that from any wave's first read of s+1.
-//   WAR: sub-tile s+3 lands in the buffer of s-1, whose last fragment reads (L(s-1) of either group) were
-//        retired by lgkmcnt(0) before the barrier that precedes this issue.
-// Swizzle for 64-byte rows: chunk position = chunk ^ ((-(row >> 2)) & 3)  (conflict-free ds_read_b128).
-// MODE (probe builds only): 0 = the kernel; 1 = operand delivery only (fragments are read, MFMAs skipped);
-// 2 = arithmetic only (no LDS-DMA after the prologue: stale LDS contents are multiplied).
-template <int BM, int MODE = 0>
-__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pp_kernel(GemmArgs p) {
-  constexpr int BNW = 256, KS = 32, NBUF = 4;
-  constexpr int MI = BM / 32;
-  constexpr int XB = BM * 64, WB = BNW * 64, SUB = XB + WB;
-  constexpr int XI = BM / 16;               // wave-instructions per X sub-tile (16 rows x 64 B each)
-  constexpr int XPW = (XI + 7) / 8;         // issued by EVERY wave (out-of-range ones hit a dummy slot)
-  constexpr int NL = XPW + 2;               // LDS-DMA instructions per wave per sub-tile
-  __shared__ __attribute__((aligned(16))) char lds[NBUF * SUB + 1024];
-  char* const dummy = lds + NBUF * SUB;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 2, wc = w & 3;
-  const int nwg = gridDim.x, orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
-  const int m0 = tm * BM, n0 = tn * BNW;
-  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
-    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
-    if (m0 >= me) return;
-    p.M = me;
-  }
-  const long long z = blockIdx.y;
-  const bf16_t* A = p.A + z * p.sA;
-  const bf16_t* B = p.B + z * p.sB;
-
-  // staging: instruction q covers tile rows 16q..16q+15; lane -> row 16q + (lane >> 2), chunk position lane & 3
-  const int srow = lane >> 2;
-  const int schunk = (lane & 3) ^ ((-(srow >> 2)) & 3);
-  const bf16_t* ap[XPW];
-  const bf16_t* bp[2];
-#pragma unroll
-  for (int i = 0; i < XPW; ++i) {
-    const int rr = min((i * 8 + w) * 16 + srow, BM - 1);
-    ap[i] = A + (long long)min(m0 + rr, p.M - 1) * p.lda + schunk * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rr = (i * 8 + w) * 16 + srow;
-    bp[i] = B + (long long)min(n0 + rr, p.N - 1) * p.ldb + schunk * 8;
-  }
-  const int frow = lane & 15, fg = lane >> 4;
-  const int fpos = fg ^ ((-(frow >> 2)) & 3);
-  const int xoff = (wr * (BM / 2) + frow) * 64 + fpos * 16;
-  const int woff = XB + (wc * 64 + frow) * 64 + fpos * 16;
-
-  f32x4_t acc[4][MI];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  auto issue = [&](int s) {
-    char* buf = lds + (s & (NBUF - 1)) * SUB;
-    const int k0 = s * KS;
-#pragma unroll
-    for (int i = 0; i < XPW; ++i) {
-      const int q = i * 8 + w;
-      glds16(ap[i] + k0, q < XI ? buf + q * 1024 : dummy);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(bp[i] + k0, buf + XB + (i * 8 + w) * 1024);
-  };
-#define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-
-  const int ns = p.K / KS;
-  issue(0);
-  if (ns > 1) issue(1);
-  if (ns > 2) issue(2);
-  if (ns > 2) UVX_VMCNT(2 * NL);
-  else if (ns > 1) UVX_VMCNT(NL);
-  else UVX_VMCNT(0);
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: this half runs one interval behind
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int s = 0; s < ns; ++s) {
-    // ---- L segment ----
-    const char* cur = lds + (s & (NBUF - 1)) * SUB;
-    if (MODE != 2 && s + 3 < ns) issue(s + 3);
-    bf16x8_t xa[MI], wa[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wa[j] = *reinterpret_cast<const bf16x8_t*>(cur + woff + j * 16 * 64);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8_t*>(cur + xoff + i * 16 * 64);
-    if (MODE == 2) UVX_VMCNT(0);
-    else if (s + 3 < ns) UVX_VMCNT(2 * NL);
-    else if (s + 2 < ns) UVX_VMCNT(NL);
-    else UVX_VMCNT(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- M segment ----
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        if (MODE != 1) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[j][i], 0, 0, 0);
-        else asm volatile("" ::"v"(wa[j]), "v"(xa[i]));
-      }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the other half's extra barrier
-#undef UVX_VMCNT
-
-  __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
-  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
-}
+#ifdef UVX_PROBES
+#include "gemm_probe_kernels.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Eight-phase kernel: 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 per wave), full 128-byte rows in LDS (one
@@ -1098,247 +874,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 #undef UVX_TL_FLUSH
 }
 
-// ------------------------------------------------------------------------------------------------
-// Four-wave kernel: 256 x 256 tile, ONE wave per SIMD, 128 x 128 per wave (64 accumulator fragments = 256
-// registers, the other half of the 512-entry file holds two generations of operand fragments).  Per 32-wide
-// K stage a wave issues 64 MFMAs against 16 ds_read_b128 and 8 LDS-DMA instructions - half the LDS read traffic
-// per FLOP of the 8-wave kernels - and nothing else competes for its SIMD, so all latency hiding is software
-// pipelining inside the wave: while stage s is multiplied from registers, the fragments of stage s+1 are read
-// from LDS into the other register generation and the DMA for stage s+3 is issued; sched_group_barrier pins the
-// interleave (1 DS read and at most 1 DMA per 4 MFMAs).  4-deep LDS ring of 32 KiB stages, one barrier per stage.
-//   RAW: stage s+2 is waited for (counted vmcnt) + barrier at the end of stage s, read during stage s+1.
-//   WAR: the DMA for stage s+3 overwrites the buffer of stage s-1, whose fragment reads (issued during stage
-//        s-2) were retired by lgkmcnt(0) before the barrier that ended stage s-2.
-__global__ __launch_bounds__(256, 1) void gemm_nt_bf16_q4_kernel(GemmArgs p) {
-  constexpr int BM = 256, BNW = 256, KS = 32, NBUF = 4;
-  constexpr int XB = BM * 64, SUB = XB + BNW * 64;
-  __shared__ __attribute__((aligned(16))) char lds[NBUF * SUB];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 1, wc = w & 1;
-  const int nwg = gridDim.x, orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
-  const int m0 = tm * BM, n0 = tn * BNW;
-  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
-    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
-    if (m0 >= me) return;
-    p.M = me;
-  }
-  const long long z = blockIdx.y;
-  const bf16_t* A = p.A + z * p.sA;
-  const bf16_t* B = p.B + z * p.sB;
-
-  // staging: instruction q (0..15 for X, 0..15 for W) covers tile rows 16q..16q+15; wave w issues q = w, w+4, w+8, w+12
-  const int srow = lane >> 2;
-  const int schunk = (lane & 3) ^ ((-(srow >> 2)) & 3);
-  const bf16_t* ap[4];
-  const bf16_t* bp[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rr = (i * 4 + w) * 16 + srow;
-    ap[i] = A + (long long)min(m0 + rr, p.M - 1) * p.lda + schunk * 8;
-    bp[i] = B + (long long)min(n0 + rr, p.N - 1) * p.ldb + schunk * 8;
-  }
-  const int frow = lane & 15, fg = lane >> 4;
-  const int fpos = fg ^ ((-(frow >> 2)) & 3);
-  const int xoff = (wr * 128 + frow) * 64 + fpos * 16;
-  const int woff = XB + (wc * 128 + frow) * 64 + fpos * 16;
-
-  f32x4_t acc[8][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  auto issue = [&](int s) {
-    char* buf = lds + (s & (NBUF - 1)) * SUB;
-    const int k0 = s * KS;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(ap[i] + k0, buf + (i * 4 + w) * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(bp[i] + k0, buf + XB + (i * 4 + w) * 1024);
-  };
-#define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-
-  const int ns = p.K / KS;   // even (K is a multiple of 64)
-  issue(0);
-  issue(1);
-  if (ns > 2) { issue(2); UVX_VMCNT(8); }
-  else UVX_VMCNT(0);
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-
-  bf16x8_t xa[2][8], wa[2][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) wa[0][j] = *reinterpret_cast<const bf16x8_t*>(lds + woff + j * 16 * 64);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) xa[0][i] = *reinterpret_cast<const bf16x8_t*>(lds + xoff + i * 16 * 64);
-
-  // DMA / FRAG are compile-time so that the steady-state body is ONE basic block (sched_group_barrier cannot
-  // interleave across branches); the last stages are peeled below.
-  auto stage = [&](auto PAR, auto DMA_, auto FRAG_, int s) {
-    constexpr int P = decltype(PAR)::value;
-    constexpr bool DMA = decltype(DMA_)::value, FRAG = decltype(FRAG_)::value;
-    if (DMA) issue(s + 3);
-    if (FRAG) {
-      const char* nb = lds + ((s + 1) & (NBUF - 1)) * SUB;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wa[P ^ 1][j] = *reinterpret_cast<const bf16x8_t*>(nb + woff + j * 16 * 64);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) xa[P ^ 1][i] = *reinterpret_cast<const bf16x8_t*>(nb + xoff + i * 16 * 64);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[P][j], xa[P][i], acc[j][i], 0, 0, 0);
-    // interleave: 16 groups of {MFMA, DS read, MFMA, DMA (first 8 groups), 2 MFMA}
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (FRAG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (DMA && g < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (DMA) UVX_VMCNT(8);
-    else UVX_VMCNT(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using T = std::true_type;
-  using F = std::false_type;
-  int s = 0;
-  for (; s + 4 < ns; s += 2) {
-    stage(I0{}, T{}, T{}, s);
-    stage(I1{}, T{}, T{}, s + 1);
-  }
-  if (ns - s == 4) {
-    stage(I0{}, T{}, T{}, s);
-    stage(I1{}, F{}, T{}, s + 1);
-    s += 2;
-  }
-  stage(I0{}, F{}, T{}, s);
-  stage(I1{}, F{}, F{}, s + 1);
-#undef UVX_VMCNT
-
-  store_tile<8, 8>(p, acc, m0 + wr * 128, n0 + wc * 128, frow, fg, z);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Three-buffer flavour of the wide kernel (BM <= 160 so that 3 x (BM + 256) x 128 B fits the 160 KiB LDS):
-// the LDS-DMA runs TWO K-tiles ahead and is waited for with a counted s_waitcnt vmcnt(NL) (the most recent
-// tile stays in flight across the barrier), giving operand delivery ~2x the latency budget of the
-// double-buffered kernel.  Every wave issues the same number of DMA instructions (out-of-range X rows go to
-// a dummy slot) so the counted wait is exact.
-template <int BM>
-__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_wide3_kernel(GemmArgs p) {
-  constexpr int BNW = 256;
-  constexpr int MI = BM / 32;
-  constexpr int XB = BM * 128, WB = BNW * 128, BUF = XB + WB;
-  constexpr int XI = BM / 8, XPW = (XI + 7) / 8, NL = XPW + 4;
-  __shared__ __attribute__((aligned(16))) char lds[3 * BUF + 1024];
-  char* const dummy = lds + 3 * BUF;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 2, wc = w & 3;
-  const int nwg = gridDim.x, orig = blockIdx.x;
-  const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int tm = wg % p.tiles_m, tn = wg / p.tiles_m;
-  const int m0 = tm * BM, n0 = tn * BNW;
-  if (p.m_dev) {   // rows known only on the device: clamp M, drop tiles beyond it (before any barrier)
-    const int me = min(p.M, max(*p.m_dev - p.m_dev_off, 0));
-    if (m0 >= me) return;
-    p.M = me;
-  }
-  const long long z = blockIdx.y;
-  const bf16_t* A = p.A + z * p.sA;
-  const bf16_t* B = p.B + z * p.sB;
-
-  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-  const bf16_t* ap[XPW];
-  const bf16_t* bp[4];
-#pragma unroll
-  for (int i = 0; i < XPW; ++i) {
-    const int rr = min((i * 8 + w) * 8 + srow, BM - 1);
-    ap[i] = A + (long long)min(m0 + rr, p.M - 1) * p.lda + schunk * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rr = (i * 8 + w) * 8 + srow;
-    bp[i] = B + (long long)min(n0 + rr, p.N - 1) * p.ldb + schunk * 8;
-  }
-  const int frow = lane & 15, fg = lane >> 4;
-  int xoff[2], woff[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int pos = (ks * 4 + fg) ^ (frow & 7);
-    xoff[ks] = (wr * (BM / 2) + frow) * 128 + pos * 16;
-    woff[ks] = XB + (wc * 64 + frow) * 128 + pos * 16;
-  }
-  f32x4_t acc[4][MI];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  auto stage = [&](int t) {
-    char* buf = lds + (t % 3) * BUF;
-    const int k0 = t * BK;
-#pragma unroll
-    for (int i = 0; i < XPW; ++i) {
-      const int q = i * 8 + w;
-      glds16(ap[i] + k0, q < XI ? buf + q * 1024 : dummy);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(bp[i] + k0, buf + XB + (i * 8 + w) * 1024);
-  };
-#define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-  const int nt = p.K / BK;
-  stage(0);
-  if (nt > 1) { stage(1); UVX_VMCNT(NL); } else { UVX_VMCNT(0); }
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  for (int t = 0; t < nt; ++t) {
-    const char* cur = lds + (t % 3) * BUF;
-    if (t + 2 < nt) stage(t + 2);   // into the buffer read in iteration t-1 (every wave is past that barrier)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t xa[MI], wa[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wa[j] = *reinterpret_cast<const bf16x8_t*>(cur + woff[ks] + j * 16 * 128);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const bf16x8_t*>(cur + xoff[ks] + i * 16 * 128);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xa[i], acc[j][i], 0, 0, 0);
-    }
-    // tile t+1 (issued one iteration ago) must have landed; tile t+2 may stay in flight
-    if (t + 2 < nt) UVX_VMCNT(NL); else UVX_VMCNT(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef UVX_VMCNT
-
-  __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
-  store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
-}
-
 // Tile choice.  Every CU works through ~tiles/256 rounds of tiles (see variant_cost for the partial last
 // round); a tile costs BM x BN / speed(variant), speeds measured on
 // MI355X (profiles/r01_gemm_variants.txt).  variant 0 = 128x128 narrow; 1..4 = {128,160,192,256} x 256 wide.
@@ -1367,6 +902,16 @@ const Variant kVariants[kNumVariants] = {
     {256, 256, 0., 9.},    // 27 = timeline probe of 11 (MODE 4)
     {256, 256, 0., 9.},     {256, 256, 0., 9.},     {256, 256, 0., 9.}};   // 28..30 = issue-priority probes of 11 (MODE 5..7: none / load section / MFMA section at priority 1)
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
+// The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
+// probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
+constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19); }
+bool variant_available(int v) {
+#ifdef UVX_PROBES
+  return v >= 0 && v < kNumVariants;
+#else
+  return v >= 0 && v < kNumVariants && is_production(v);
+#endif
+}
 double variant_cost(int v, int M, int N, int K, int batch) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
   // Rounds of tiles over the 256 CUs.  A partly filled last round is cheaper than a full one (the kernels are bound
@@ -1387,7 +932,7 @@ int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
     return forced;
   }
   for (int v = 0; v < kNumVariants; ++v) {
-    if (kVariants[v].speed <= 0.) continue;
+    if (kVariants[v].speed <= 0. || !is_production(v)) continue;
     const double cost = variant_cost(v, M, N, K, batch);
     if (cost < best) { best = cost; best_v = v; }
   }
@@ -1401,6 +946,13 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
   dim3 grid(a.tiles_m * a.tiles_n, batch);
   switch (variant) {
     case 0: hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, st, a); break;
+    case 11: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<256>, grid, dim3(512), 0, st, a); break;
+    case 15: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<160>, grid, dim3(512), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<192>, grid, dim3(512), 0, st, a); break;
+    case 17: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<128>, grid, dim3(512), 0, st, a); break;
+    case 18: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 3>), grid, dim3(512), 0, st, a); break;
+    case 19: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 3>), grid, dim3(512), 0, st, a); break;
+#ifdef UVX_PROBES
     case 1: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<128>, grid, dim3(512), 0, st, a); break;
     case 2: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<160>, grid, dim3(512), 0, st, a); break;
     case 3: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<192>, grid, dim3(512), 0, st, a); break;
@@ -1411,16 +963,10 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 8: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), 0, st, a); break;
     case 9: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<128>, grid, dim3(512), 0, st, a); break;
     case 10: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<160>, grid, dim3(512), 0, st, a); break;
-    case 11: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<256>, grid, dim3(512), 0, st, a); break;
-    case 15: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<160>, grid, dim3(512), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<192>, grid, dim3(512), 0, st, a); break;
-    case 17: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<128>, grid, dim3(512), 0, st, a); break;
-    case 18: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 3>), grid, dim3(512), 0, st, a); break;
-    case 19: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 3>), grid, dim3(512), 0, st, a); break;
-    case 20: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 1>), grid, dim3(512), 0, st, a); break;
-    case 21: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 2>), grid, dim3(512), 0, st, a); break;
-    case 22: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 3>), grid, dim3(512), 0, st, a); break;
-    case 27: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 4>), grid, dim3(512), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 1>), grid, dim3(512), 0, st, a); break;   // operand delivery only
+    case 21: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 2>), grid, dim3(512), 0, st, a); break;   // arithmetic only
+    case 22: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 3>), grid, dim3(512), 0, st, a); break;   // no epilogue
+    case 27: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 4>), grid, dim3(512), 0, st, a); break;   // s_memtime timeline
     case 28: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 5>), grid, dim3(512), 0, st, a); break;
     case 29: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 6>), grid, dim3(512), 0, st, a); break;
     case 30: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 7>), grid, dim3(512), 0, st, a); break;
@@ -1436,7 +982,9 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     }
     case 12: hipLaunchKernelGGL(gemm_nt_bf16_q4_kernel, grid, dim3(256), 0, st, a); break;
     case 13: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 1>), grid, dim3(512), 0, st, a); break;   // probe: delivery only
-    default: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 2>), grid, dim3(512), 0, st, a); break;  // probe: arithmetic only
+    case 14: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 2>), grid, dim3(512), 0, st, a); break;   // probe: arithmetic only
+#endif
+    default: break;   // unavailable variants are rejected in gemm_nt before any launch
   }
 }
 
@@ -1470,7 +1018,8 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   const int batch = d.batch > 0 ? d.batch : 1;
   double cost_whole = 0.;
   const int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole);
-  UVX_CHECK(variant >= 0 && variant < kNumVariants, UVX_ERR_INVALID, "gemm: bad tile variant %d", variant);
+  UVX_CHECK(variant_available(variant), UVX_ERR_INVALID,
+            "gemm: tile variant %d is not in this build (probe variants live in libuvx_probes.so, built with -DUVX_PROBES)", variant);
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K * batch,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 * batch + (double)d.M * d.N * batch * (d.out_f32 ? 4.0 : 2.0),
                       /*enable=*/d.m_dev == nullptr);   // device-side row count: the true work is unknown here, leave it out
