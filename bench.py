@@ -253,6 +253,9 @@ def main():
                     help="ce = the BASELINE.json configuration; kl = LossFunction.KL_Divergence (the reference's meta_config.yaml "
                          "default): a text-only teacher pass over alt_input_ids (audio replaced by a 48-token transcript)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: sequential all-reduce + optimizer step (no overlap)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
+                    help="N > 1: gradient exchange through torch.distributed (RCCL; default) or through libuvx.so's own RCCL "
+                         "communicator (uvx_comm_*: the C-ABI route, torch.distributed only hands the 128-byte id around)")
     ap.add_argument("--opt", default=None, help="probe: 'key=value,...' for uvx_set_option")
     ap.add_argument("--gemm-override", default=None, help="probe: 'MxNxK=variant,...' tile-variant overrides")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table (from the HIP events) here")
@@ -314,7 +317,11 @@ def main():
                          projector_ln_mid=True, torch_dtype="bfloat16",
                          audio_model_lora_config={"r": args.audio_lora_r} if args.audio_lora_r else None)
     model = UltravoxModel(cfg, device=str(dev), dtype=torch.bfloat16, seed=0, rope_len=1024)
-    trainer = UltravoxTrainer(model, lr=2e-3, max_grad_norm=1.0, overlap_comm=world > 1 and not args.no_overlap)
+    comm = None
+    if args.comm == "abi" and world > 1 and not share_gpu:
+        from ultravox_amd.parallel import UvxComm
+        comm = UvxComm.from_torch_distributed()
+    trainer = UltravoxTrainer(model, lr=2e-3, max_grad_norm=1.0, overlap_comm=world > 1 and not args.no_overlap, comm=comm)
     fe = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins, device=str(dev))
     batch = synthetic_batch(cfg, B, wl["seconds"], n_text=128, audio_start=16, n_supervised=32, rank=rank)
     pcm = batch.pop("pcm").to(dev)
@@ -395,7 +402,8 @@ def main():
             "loss": loss_val,
             "world_size": world,
             "collective": (None if world == 1 else "gloo (shared-GPU test mode)" if share_gpu
-                           else "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + " all-reduce(sum) of one flat f32 bucket, "
+                           else "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + (" via uvx_comm_* (C ABI)" if comm else " via torch.distributed")
+                                + " all-reduce(sum) of one flat f32 bucket, "
                                 f"{trainer.model.proj_grad.numel() * 4 / 1e6:.0f} MB"),
         }
         if not args.no_prof and prof[0] > 0:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 6
+#define UVX_ABI_VERSION 7
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -37,6 +37,7 @@ extern "C" {
 #define UVX_ERR_SHAPE (-2)       /* unsupported / inconsistent shape   -> ValueError */
 #define UVX_ERR_WORKSPACE (-3)   /* workspace too small                -> RuntimeError */
 #define UVX_ERR_UNSUPPORTED (-4) /* feature not built                  -> RuntimeError */
+#define UVX_ERR_RUNTIME (-5)     /* a collective (RCCL) call failed    -> RuntimeError */
 
 const char* uvx_last_error(void);
 int32_t uvx_abi_version(void);
@@ -262,6 +263,23 @@ int32_t uvx_argmax(void* stream, int32_t dtype, const void* logits, int32_t rows
 int32_t uvx_adamw_clip_step(void* stream, int32_t state_dtype, void* param, float* master, const float* grad, void* m,
                             void* v, int64_t n, float max_norm, float lr, float beta1, float beta2, float eps,
                             float weight_decay, int32_t step, float* scratch);
+
+/* ============================== data-parallel exchange ==============================
+ * Replaces what torch DDP does under HF Trainer / accelerate (train.py:126-130, :282-288): the gradients of the
+ * trainable parameters are summed over the ranks and divided by the world size, once per optimizer step, over the flat f32
+ * bucket.  One communicator per process (one process per GPU); RCCL over xGMI, bound at run time (dlopen), so libuvx.so
+ * does not link it and a host that never trains data-parallel does not need it.  rank 0 creates the 128-byte id and the
+ * caller distributes it to the other ranks by its own channel (file, socket, MPI, torch.distributed's store). */
+#define UVX_COMM_ID_BYTES 128
+typedef struct uvx_comm uvx_comm_t;
+int32_t uvx_comm_unique_id(uint8_t* id /* [UVX_COMM_ID_BYTES] */);
+/* binds the communicator to the CURRENT HIP device of the calling thread; collective over all `world` ranks */
+int32_t uvx_comm_init(uvx_comm_t** comm, int32_t rank, int32_t world, const uint8_t* id);
+int32_t uvx_comm_world_size(const uvx_comm_t* comm);
+int32_t uvx_comm_version(void);   /* RCCL's version code (e.g. 22606), 0 if RCCL cannot be loaded */
+/* buf[i] = (sum over ranks of buf[i]) * scale, in place, asynchronous on `stream`; scale = 1 / world is DDP's gradient mean */
+int32_t uvx_comm_allreduce_f32(uvx_comm_t* comm, void* stream, float* buf, int64_t n, float scale);
+int32_t uvx_comm_destroy(uvx_comm_t* comm);
 
 /* ============================== single-op entry points (tests, probes) ============================== */
 

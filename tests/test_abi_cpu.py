@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in header_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in include/uvx.h but not exported by libuvx.so: {missing}"
     assert set(_lib.EXPORTS) == set(header_functions())
-    assert lib.uvx_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.uvx_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_struct_mirrors_match_header_sizes():
@@ -151,7 +151,8 @@ def test_every_entry_point_survives_an_all_null_call():
     problem — before any GPU work, so this runs without a device."""
     lib = _lib.lib()
     skip = {"uvx_last_error", "uvx_abi_version", "uvx_set_option", "uvx_gemm_pick_variant", "uvx_gemm_override_variant",
-            "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records"}
+            "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records",
+            "uvx_comm_world_size", "uvx_comm_version"}         # value-returning queries, not status codes
     rejected = 0
     for name in _lib.EXPORTS:
         if name in skip:
@@ -168,3 +169,23 @@ def test_every_entry_point_survives_an_all_null_call():
             rejected += 1
             assert lib.uvx_last_error(), name
     assert rejected >= 20
+
+
+def test_comm_entry_points_bind_rccl_at_run_time_and_report_errors():
+    """uvx_comm_* (include/uvx.h "data-parallel exchange"): RCCL is dlopen'ed, not linked - libuvx.so's dependency list stays
+    HIP + libc - and without a device the first RCCL call fails with a status + message instead of crashing."""
+    import subprocess
+    lib = _lib.lib()
+    needed = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-d", lib._name], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower() and "libamdhip64" in needed
+    assert lib.uvx_comm_world_size(None) == 1
+    assert lib.uvx_comm_destroy(None) == 0
+    assert lib.uvx_comm_unique_id(None) == -1 and b"null" in lib.uvx_last_error()
+    import torch
+    if not torch.cuda.is_available():
+        buf = (ctypes.c_uint8 * 128)()
+        rc = lib.uvx_comm_unique_id(buf)
+        assert rc in (0, -4, -5)       # RCCL may hand out an id without a device; else: no RCCL on the path (-4) / RCCL error (-5)
+        assert rc == 0 or lib.uvx_last_error()
+        h = ctypes.c_void_p()
+        assert lib.uvx_comm_init(ctypes.byref(h), 3, 2, buf) == -1   # rank outside the world: argument error before any RCCL call

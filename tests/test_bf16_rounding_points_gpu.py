@@ -45,17 +45,22 @@ SMALL = dict(
 
 
 def ulp_stats(got: torch.Tensor, want: torch.Tensor) -> dict:
-    """bf16 tensors -> fraction of elements that are not bit-equal, and the largest distance in bf16 ulps."""
-    g, w = got.detach().cpu().contiguous().view(torch.int16).int(), want.detach().cpu().contiguous().view(torch.int16).int()
-    key = lambda b: torch.where(b < 0, -(b & 0x7FFF), b)          # sign-magnitude -> monotone integer line (+-0 coincide)
-    d = (key(g) - key(w)).abs()
-    return {"mismatch_frac": (d != 0).float().mean().item(), "max_ulp": int(d.max()), "rel_l2": rel_l2(got, want), "n": d.numel()}
+    """bf16 tensors -> fraction of elements that are not bit-equal, and the largest difference in bf16 ulps.  One ulp of x is
+    taken as 2^-7 |x| (the spacing at the top of x's binade), with |x| floored at 1/16 of the tensor's RMS: an output that is
+    tiny because its terms cancel carries the ABSOLUTE f32 accumulation noise of full-sized terms, and counting that in the
+    ulps of the tiny result (or across a sign change) would measure nothing."""
+    g, w = got.detach().float().cpu(), want.detach().float().cpu()
+    bits = lambda t: t.to(torch.bfloat16).contiguous().view(torch.int16)
+    differ = bits(g) != bits(w)
+    floor = w.pow(2).mean().sqrt() / 16
+    ulps = (g - w).abs() / (2.0 ** -7 * torch.maximum(w.abs(), floor))
+    return {"mismatch_frac": differ.float().mean().item(), "max_ulp": ulps.max().item(), "rel_l2": rel_l2(got, want), "n": w.numel()}
 
 
 def check(name, got, want, rec, max_ulp=1, max_frac=1e-2, max_rel=5e-4):
     st = ulp_stats(got, want)
     rec[name] = st
-    return st["mismatch_frac"] <= max_frac and st["max_ulp"] <= max_ulp and st["rel_l2"] <= max_rel
+    return st["mismatch_frac"] <= max_frac and st["max_ulp"] <= max_ulp + 0.01 and st["rel_l2"] <= max_rel
 
 
 def test_every_kernel_rounds_where_torch_bf16_rounds():

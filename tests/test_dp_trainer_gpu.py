@@ -121,3 +121,32 @@ def test_bench_self_launches_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["config"]["global_batch"] == 2
     assert "overlapped" in out["config"]["parallelism"] and out["value"] > 0
+
+
+def test_uvx_comm_one_rank_rccl_group_and_trainer_route():
+    """The C-ABI exchange (uvx_comm_*) on a real RCCL communicator - a 1-rank group is all one GPU allows: sum over one rank x
+    scale; and UltravoxTrainer(comm=UvxComm) - sequential and overlapped - reproduces the torch.distributed-free trainer bit
+    for bit (same kernels, the exchange on a side stream ordered by events)."""
+    from ultravox_amd.model import UltravoxTrainer
+    from ultravox_amd.parallel import UvxComm
+    assert UvxComm.rccl_version() > 20000
+    comm = UvxComm(0, 1, UvxComm.unique_id())
+    x = torch.randn(1000003, device="cuda:0")
+    want = x * 0.25
+    comm.world = 4                                   # exercises the scale kernel (tail included): 1 / world
+    comm.all_reduce_mean_(x)
+    comm.world = 1
+    assert torch.equal(x, want)
+    with pytest.raises(ValueError):
+        comm.all_reduce_mean_(x.half())
+    results = []
+    for kw in (dict(), dict(comm=comm), dict(comm=comm, overlap_comm=True)):
+        model, batches = _model_and_batches(2)
+        trainer = UltravoxTrainer(model, lr=2e-3, master_weights=True, **kw)
+        for step in range(STEPS):
+            trainer.train_step(**batches[step % 2])
+        trainer.flush()
+        torch.cuda.synchronize()
+        results.append(trainer.master.clone())
+    assert torch.equal(results[0], results[1]) and torch.equal(results[0], results[2])
+    comm.close()

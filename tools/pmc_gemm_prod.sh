@@ -13,7 +13,7 @@ out = "$OUT"
 print("# rocprofv3 --pmc on gemm_nt_bf16_ph8_kernel<256,2,*> at 2528 x 28672 x 4096 bf16 (1120 tiles of 256x256, 64 K-tiles), 4 launches averaged")
 print("# v11 = production (static issue priority, MODE 0); v30 = round-1 form (MFMA section at s_setprio 1, MODE 7)")
 print("# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over all waves; SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES in cycles;")
-print("# GRBM_GUI_ACTIVE summed over the 8 XCDs.  MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD-cycles: SQ_BUSY_CYCLES x 4 / n_SE-normalisation, see below).")
+print("# GRBM_GUI_ACTIVE summed over the 8 XCDs (per XCD / kernel duration = shader clock, here 1.9 GHz).  MFMA pipe utilisation is taken per RESIDENT wave pair: while a tile is resident 8 waves share 4 SIMDs.")
 for v in (11, 30):
     vals = collections.defaultdict(list); dur = []
     for d in ("sq", "lds"):

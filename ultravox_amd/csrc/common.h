@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
 #define UVX_ERR_SHAPE (-2)
 #define UVX_ERR_WORKSPACE (-3)
 #define UVX_ERR_UNSUPPORTED (-4)
+#define UVX_ERR_RUNTIME (-5)
 
 extern "C" void uvx_set_error(const char* fmt, ...);
 

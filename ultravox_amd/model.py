@@ -861,7 +861,9 @@ class UltravoxTrainer:
     def __init__(self, model: UltravoxModel, lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, max_grad_norm: float = 1.0, master_weights: bool = False,
                  gradient_accumulation_steps: int = 1, overlap_comm: bool = False, lr_scheduler: str = "constant",
-                 lr_warmup_steps: float = 0, max_steps: int = 0, lr_scheduler_kwargs: Optional[dict] = None):
+                 lr_warmup_steps: float = 0, max_steps: int = 0, lr_scheduler_kwargs: Optional[dict] = None, comm=None):
+        """comm: a parallel.UvxComm - the gradient exchange then runs through libuvx.so's own RCCL communicator
+        (uvx_comm_allreduce_f32) instead of torch.distributed.all_reduce; same arithmetic (sum over ranks, x 1/world)."""
         from .schedule import LRSchedule
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -880,7 +882,9 @@ class UltravoxTrainer:
         self.exp_avg = torch.zeros(n, device=dev, dtype=st_dtype)
         self.exp_avg_sq = torch.zeros(n, device=dev, dtype=st_dtype)
         self.scratch = torch.zeros(1025, device=dev, dtype=torch.float32)
-        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.comm = comm
+        self.world = comm.world if comm is not None else (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
+        self._comm_stream = torch.cuda.Stream(device=dev) if comm is not None else None
         self._pending = None
 
     def save_checkpoint(self, directory: str) -> None:
@@ -910,6 +914,9 @@ class UltravoxTrainer:
 
     def all_reduce_grads(self) -> None:
         """torch DDP semantics: sum over ranks then divide by world size (RCCL over xGMI)."""
+        if self.comm is not None:
+            self.comm.all_reduce_mean_(self.model.proj_grad)
+            return
         from .parallel import dp_mean_
         dp_mean_(self.model.proj_grad)
 
@@ -965,7 +972,16 @@ class UltravoxTrainer:
                 return loss
             self.model.proj_grad.copy_(self._accum)
             self._micro = 0
-        if self.overlap_comm and torch.distributed.is_available() and torch.distributed.is_initialized():
+        if self.overlap_comm and self.comm is not None:
+            # the exchange runs on a side stream behind the backward pass; flush() makes the compute stream wait for it
+            ready = torch.cuda.Event()
+            ready.record()
+            self._comm_stream.wait_event(ready)
+            self.comm.all_reduce_mean_(self.model.proj_grad, stream=self._comm_stream)
+            done = torch.cuda.Event()
+            done.record(self._comm_stream)
+            self._pending = done
+        elif self.overlap_comm and torch.distributed.is_available() and torch.distributed.is_initialized():
             self._pending = torch.distributed.all_reduce(self.model.proj_grad, op=torch.distributed.ReduceOp.SUM, async_op=True)
         else:
             self.all_reduce_grads()
@@ -977,6 +993,9 @@ class UltravoxTrainer:
         if self._pending is None:
             return
         work, self._pending = self._pending, None
-        work.wait()                                    # the compute stream waits for the collective
-        self.model.proj_grad.mul_(1.0 / self.world)    # DDP: sum, then divide by the world size
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_event(work)   # uvx_comm_allreduce_f32 already applied the 1 / world
+        else:
+            work.wait()                                    # the compute stream waits for the collective
+            self.model.proj_grad.mul_(1.0 / self.world)    # DDP: sum, then divide by the world size
         self.optimizer_step()
