@@ -56,7 +56,14 @@ typedef struct {
   /* language model (Llama family, reached at ultravox_model.py:328-334) */
   int32_t llm_layers, llm_d, llm_heads, llm_kv_heads, llm_head_dim, llm_inter, vocab;
   float rms_eps;
+  /* backbone family behind AutoModelForCausalLM (ultravox_model.py:499-526).  UVX_LLM_LLAMA: RMSNorm w * round(x_hat), SwiGLU.
+   * UVX_LLM_GEMMA (BASELINE config 5): GemmaRMSNorm x_hat * (1 + w) in f32, GeGLU (gelu_pytorch_tanh), inputs_embeds
+   * multiplied by sqrt(hidden_size) in the model dtype INSIDE the model (transformers 4.51.3 GemmaModel.forward: text and
+   * merged audio rows alike), head_dim independent of hidden_size / heads (256), lm_head tied to embed_tokens by the host. */
+  int32_t llm_flavor;
 } uvx_config_t;
+#define UVX_LLM_LLAMA 0
+#define UVX_LLM_GEMMA 1
 
 /* Encoder weights.  Names follow the HF WhisperEncoder state dict; packing done once at
  * load time by the host:  wqkv = [q_proj*head_dim^-0.5 ; k_proj ; v_proj] ([3d, d]), bqkv likewise with a

@@ -331,11 +331,24 @@ def _rotate_half(x):
     return torch.cat((-b, a), dim=-1)
 
 
+def gemma_rmsnorm_ref(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """[3P] GemmaRMSNorm.forward: the whole of x_hat * (1 + w) in f32, one cast at the end
+    ("Llama does x.to(float16) * w whilst Gemma is (x * w).to(float16)")."""
+    h = x.float()
+    h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + eps)
+    return (h * (1.0 + w.float())).type_as(x)
+
+
 def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
               attention_mask: Optional[torch.Tensor] = None, prefix: str = "language_model.",
               n_layers: Optional[int] = None, position_ids: Optional[torch.Tensor] = None,
               lora: Optional[dict] = None) -> torch.Tensor:
-    """-> logits [B, T, V] in the dtype of inputs_embeds.  lora = {"scaling": ..}: peft adapters on q_proj / k_proj
+    """-> logits [B, T, V] in the dtype of inputs_embeds.  text_config.model_type "gemma" (BASELINE config 5; [3P]
+    transformers 4.51.3 modeling_gemma.py): inputs_embeds * tensor(sqrt(hidden_size), dtype) INSIDE the model - the pinned
+    version scales whatever it is given, text and merged audio rows alike (the installed 5.x moved the
+    scale into the embedding module, so the pin in tests feeds pre-scaled embeddings to the installed decoder stack) -,
+    GemmaRMSNorm, gelu_pytorch_tanh(gate) * up, head_dim from the config, lm_head = embed_tokens.
+    lora = {"scaling": ..}: peft adapters on q_proj / k_proj
     (text_model_lora_config; keys under `language_model.base_model.model.model.layers.N.self_attn.*`), pinned like the
     encoder's by tests/golden/lora_reference.npz (the reference's apply_lora on an HF LlamaForCausalLM via tests/peft_stub.py)."""
     tc = cfg.text_config
@@ -343,6 +356,9 @@ def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
     B, T, D = inputs_embeds.shape
     Hq, Hkv, dh = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     W = lambda k: sd[prefix + k].to(dt) if not sd[prefix + k].requires_grad else sd[prefix + k]
+    gemma = getattr(tc, "model_type", "llama") == "gemma"
+    norm = gemma_rmsnorm_ref if gemma else rmsnorm_ref
+    act = (lambda g: F.gelu(g, approximate="tanh")) if gemma else F.silu
     if position_ids is None:
         cos, sin = rope_cos_sin_ref(tc, T, dt)
     else:  # [B, T] position ids (HF generate derives them from the attention mask) -> [B, 1, T, dh] tables
@@ -354,10 +370,12 @@ def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
         pad = (1.0 - attention_mask[:, None, None, :].to(dt)) * neg
         causal = torch.clamp(causal + pad, min=neg)
     x = inputs_embeds
+    if gemma:
+        x = x * torch.tensor(tc.hidden_size ** 0.5, dtype=dt)
     L_ = tc.num_hidden_layers if n_layers is None else n_layers
     for i in range(L_):
         P = f"model.layers.{i}."
-        h = rmsnorm_ref(x, W(P + "input_layernorm.weight"), tc.rms_norm_eps)
+        h = norm(x, W(P + "input_layernorm.weight"), tc.rms_norm_eps)
         q = F.linear(h, W(P + "self_attn.q_proj.weight"))
         k = F.linear(h, W(P + "self_attn.k_proj.weight"))
         if lora is not None:
@@ -376,11 +394,11 @@ def llama_ref(sd: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor,
         v = v.repeat_interleave(Hq // Hkv, dim=1)
         o = _attend(q, k, v, causal, dh ** -0.5).transpose(1, 2).reshape(B, T, Hq * dh)
         x = x + F.linear(o, W(P + "self_attn.o_proj.weight"))
-        h = rmsnorm_ref(x, W(P + "post_attention_layernorm.weight"), tc.rms_norm_eps)
-        h = F.silu(F.linear(h, W(P + "mlp.gate_proj.weight"))) * F.linear(h, W(P + "mlp.up_proj.weight"))
+        h = norm(x, W(P + "post_attention_layernorm.weight"), tc.rms_norm_eps)
+        h = act(F.linear(h, W(P + "mlp.gate_proj.weight"))) * F.linear(h, W(P + "mlp.up_proj.weight"))
         x = x + F.linear(h, W(P + "mlp.down_proj.weight"))
-    x = rmsnorm_ref(x, W("model.norm.weight"), tc.rms_norm_eps)
-    return F.linear(x, W("lm_head.weight"))
+    x = norm(x, W("model.norm.weight"), tc.rms_norm_eps)
+    return F.linear(x, W("lm_head.weight") if prefix + "lm_head.weight" in sd else W("model.embed_tokens.weight"))
 
 
 def causal_lm_loss_ref(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:

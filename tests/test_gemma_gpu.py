@@ -1,0 +1,132 @@
+"""BASELINE.json config 5's backbone (Gemma) on the GPU: the deltas against the Llama family - GemmaRMSNorm (x_hat * (1 + w) in
+f32, one rounding), GeGLU (gelu_pytorch_tanh), head_dim 256 attention (forward, dK/dV, dQ), sqrt(hidden) embedding scale inside
+the model (transformers 4.51.3 semantics: text AND merged audio rows), tied head - against the oracle's Gemma flavour, which
+tests/test_oracle_pinning.py pins to the installed HF GemmaForCausalLM.  f32 mode at north_star's 1e-3, bf16 at the
+bf16-vs-f32 bars of test_model_gpu.py, and Gemma-7B WIDTH (3072 / 24576 / 16 x 256 heads / 256000 vocab) at depth 1."""
+import pytest
+import torch
+
+from parity_util import oracle_threads, record, rel_l2, stage_errors
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("Hq,Hkv,T,causal", [(4, 4, 316, True), (4, 1, 70, True), (2, 2, 200, False)])
+def test_attention_head_dim_256_forward_backward(Hq, Hkv, T, causal):
+    from test_kernels_gpu import sdpa_ref
+    from ultravox_amd import ops
+    torch.manual_seed(5)
+    B, D = 2, 256
+    q, k, v = (bf(torch.randn(B, T, h, D, device=DEV)) for h in (Hq, Hkv, Hkv))
+    do = bf(torch.randn(B, T, Hq * D, device=DEV))
+    kv_len = None if causal else torch.tensor([T, T - 37], device=DEV, dtype=torch.int32)
+    o, lse = ops.attention(q, k, v, causal=causal, kv_len=kv_len)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref, _ = sdpa_ref(qr, kr, vr, causal, 0, D ** -0.5, kv_len=kv_len)
+    assert (o.float() - ref).abs().max().item() < 2e-2 and rel_l2(o, ref.detach()) < 8e-3
+    dq, dk, dv = ops.attention_bwd(q, k, v, o, lse, do, causal=causal, kv_len=kv_len)
+    ref.backward(do.float())
+    assert rel_l2(dq, qr.grad) < 2e-2 and rel_l2(dk, kr.grad) < 2e-2 and rel_l2(dv, vr.grad) < 2e-2
+    # f32 mode
+    qf, kf, vf, dof = (t.float() for t in (q, k, v, do))
+    of, lsef = ops.attention(qf, kf, vf, causal=causal, kv_len=kv_len)
+    assert (of - ref.detach()).abs().max().item() < 5e-5
+    dqf, dkf, dvf = ops.attention_bwd(qf, kf, vf, of, lsef, dof, causal=causal, kv_len=kv_len)
+    assert rel_l2(dqf, qr.grad) < 1e-5 and rel_l2(dkf, kr.grad) < 1e-5 and rel_l2(dvf, vr.grad) < 1e-5
+
+
+def _cfg(head_dim, **kw):
+    from ultravox_amd.config import UltravoxConfig
+    return UltravoxConfig(
+        audio_config=dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256),
+        text_config=dict(model_type="gemma", hidden_size=192, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                         num_key_value_heads=2, head_dim=head_dim, vocab_size=512, rms_norm_eps=1e-6, eos_token_id=1),
+        hidden_size=256, projector_ln_mid=True, **kw)
+
+
+def _step(cfg, dtype, seed):
+    from oracle.reference_cpu import OracleModel, logmel_ref, synthetic_batch
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    sd = {k: v.to(dtype) for k, v in random_state_dict(cfg, seed=seed).items()}
+    assert "language_model.lm_head.weight" not in sd
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    b = synthetic_batch(cfg, 2, 2.0, n_text=24, audio_start=5, n_supervised=8)
+    b["audio_values"] = logmel_ref(b.pop("pcm"), 80).to(dtype)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    ref, grads, _ = oracle.train_step({**b, "audio_values": b["audio_values"].float()})
+    out = model.forward(**gb)
+    model.train()
+    loss = model.forward_backward(**gb)
+    return model, out, loss, ref, grads
+
+
+@pytest.mark.parametrize("head_dim", [64, 256])
+def test_gemma_train_step_f32_within_1e3(head_dim):
+    model, out, loss, ref, grads = _step(_cfg(head_dim), torch.float32, 31)
+    assert (out.logits.cpu() - ref["logits"]).abs().max().item() < 1e-3
+    assert abs(out.loss.item() - ref["loss"].item()) < 1e-4 and abs(loss.item() - ref["loss"].item()) < 1e-4
+    mine = model.projector_grads()
+    for k, g in grads.items():
+        assert rel_l2(mine[k], g) < 2e-3, k
+
+
+@pytest.mark.parametrize("head_dim", [64, 256])
+def test_gemma_train_step_bf16(head_dim):
+    model, out, loss, ref, grads = _step(_cfg(head_dim), torch.bfloat16, 32)
+    rec = {"logits": stage_errors(out.logits, ref["logits"]), "loss": [loss.item(), ref["loss"].item()]}
+    mine = model.projector_grads()
+    rec["grads"] = {k: rel_l2(mine[k], g) for k, g in grads.items()}
+    record(f"gemma_small_bf16_hd{head_dim}", rec)
+    assert rec["logits"]["rel_l2"] < 3e-2
+    assert abs(loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
+    for k, v in rec["grads"].items():
+        assert v < 8e-2, (k, v)
+
+
+def test_gemma_generate_is_refused_not_wrong():
+    from ultravox_amd.model import UltravoxModel
+    cfg = _cfg(64)
+    model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=1)
+    with pytest.raises(NotImplementedError, match="Llama family"):
+        model.generate(torch.randint(3, 500, (1, 8), device=DEV), max_new_tokens=2)
+
+
+def test_c5_gemma_7b_width_train_step_matches_oracle():
+    """Gemma-7B WIDTH (hidden 3072, inter 24576, 16 heads x 256, vocab 256000) at depth 1 behind the whisper-medium-width
+    encoder (depth 1): the N = 49152 gate|up GEMM + GeGLU kernel, K = 24576 down projection, head_dim-256 attention at T = 316,
+    the 256000-row tied head with the supervised-row split-K dgrad."""
+    from oracle.reference_cpu import OracleModel, synthetic_batch
+    from ultravox_amd.config import AUDIO_PRESETS, TEXT_PRESETS, UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    tc = dict(TEXT_PRESETS["google/gemma-7b"], num_hidden_layers=1)
+    ac = dict(AUDIO_PRESETS["openai/whisper-medium"], encoder_layers=1)
+    cfg = UltravoxConfig(text_config=tc, audio_config=ac, hidden_size=4096, stack_factor=8, projector_ln_mid=True, torch_dtype="bfloat16")
+    sd = random_state_dict(cfg, seed=3, dtype=torch.bfloat16, device="cuda")
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16, rope_len=512)
+    oracle = OracleModel(cfg, {k: v.cpu() for k, v in sd.items()}, dtype=torch.float32)
+    b = synthetic_batch(cfg, 2, 30.0, n_text=128, audio_start=16, n_supervised=32)
+    pcm = b.pop("pcm")
+    mel = WhisperFeatureExtractor(80).logmel_device(pcm.to(DEV))
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    oracle_threads()
+    ref, grads, _ = oracle.train_step({**b, "audio_values": mel.cpu().bfloat16().float()})
+    out = model.forward(audio_values=mel, **gb)
+    model.train()
+    loss = model.forward_backward(audio_values=mel, **gb)
+    mine = model.projector_grads()
+    rec = {"logits": stage_errors(out.logits, ref["logits"]), "loss": [loss.item(), ref["loss"].item()],
+           "grads": {k: rel_l2(mine[k], g) for k, g in grads.items()}}
+    record("c5_gemma_7b_width", rec)
+    assert rec["logits"]["rel_l2"] < 3e-2
+    assert abs(loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
+    for k, v in rec["grads"].items():
+        assert v < 8e-2, (k, v)

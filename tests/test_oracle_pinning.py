@@ -317,3 +317,42 @@ def test_lora_restatement_matches_reference_apply_lora_fixture(golden_dir):
     (logits * torch.from_numpy(z["llm.gl"])).sum().backward()
     for n in meta["llm"]["trainable"]:
         np.testing.assert_allclose(sd["language_model." + n].grad.numpy(), z["llm.g." + n], rtol=2e-4, atol=2e-5, err_msg=n)
+
+
+def test_gemma_backbone_matches_hf_blocks():
+    """BASELINE config 5's backbone.  [3P] check: the oracle's Gemma flavour (GemmaRMSNorm, GeGLU, head_dim from the config,
+    tied head, sqrt(hidden) embedding scale) == the installed HF GemmaForCausalLM.  The reference pins transformers 4.51.3,
+    whose GemmaModel.forward multiplies whatever inputs_embeds it receives by the normalizer; the installed 5.x moved that
+    scale into the embedding module, so the installed stack is fed PRE-SCALED embeddings."""
+    from transformers import GemmaConfig, GemmaForCausalLM
+    cfg = UltravoxConfig(audio_config=TINY["audio_config"], hidden_size=64,
+                         text_config=dict(model_type="gemma", hidden_size=96, intermediate_size=256, num_hidden_layers=2,
+                                          num_attention_heads=4, num_key_value_heads=2, head_dim=32, vocab_size=160, rms_norm_eps=1e-6))
+    t = cfg.text_config
+    assert t.is_gemma and t.hidden_act == "gelu_pytorch_tanh" and t.head_dim * t.num_attention_heads != t.hidden_size
+    hf = GemmaForCausalLM(GemmaConfig(hidden_size=96, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                      num_key_value_heads=2, head_dim=32, vocab_size=160, rms_norm_eps=1e-6, rope_theta=t.rope_theta,
+                                      max_position_embeddings=t.max_position_embeddings, hidden_activation="gelu_pytorch_tanh",
+                                      attn_implementation="eager")).eval()
+    sd = random_state_dict(cfg, seed=4)
+    assert "language_model.lm_head.weight" not in sd                      # tied: the head is the embedding matrix
+    llm_sd = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}
+    missing, unexpected = hf.load_state_dict(llm_sd, strict=False)
+    assert not unexpected and missing == ["lm_head.weight"]
+    hf.tie_weights()
+    torch.manual_seed(0)
+    B, T = 2, 19
+    emb = torch.randn(B, T, 96) * 0.1
+    labels = torch.randint(0, 160, (B, T))
+    labels[:, :9] = -100
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, -4:] = 0
+    with torch.no_grad():
+        out = hf(inputs_embeds=emb * (96 ** 0.5), attention_mask=am, labels=labels)
+        logits = O.llama_ref(sd, cfg, emb, am)
+        loss = O.causal_lm_loss_ref(logits, labels)
+    keep = am.bool()
+    np.testing.assert_allclose(logits[keep].numpy(), out.logits[keep].numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(loss.item(), out.loss.item(), rtol=1e-5)
+    # bf16: the normalizer is rounded to the model dtype before it multiplies (4.51.3: torch.tensor(sqrt(H), dtype=...))
+    assert float(torch.tensor(3072 ** 0.5, dtype=torch.bfloat16)) == 55.5

@@ -63,8 +63,11 @@ class AudioConfig:
 
 @dataclasses.dataclass
 class TextConfig:
-    """Field names of transformers.LlamaConfig that the LLM path reads."""
+    """Field names of transformers.LlamaConfig / GemmaConfig that the LLM path reads.  model_type "llama" (default) or "gemma"
+    (BASELINE.json config 5, the alt backbone behind AutoModelForCausalLM, ultravox_model.py:499-526): GemmaRMSNorm, GeGLU
+    (hidden_act gelu_pytorch_tanh), sqrt(hidden_size) embedding scale, explicit head_dim, lm_head tied to embed_tokens."""
     model_type: str = "llama"
+    hidden_act: Optional[str] = None            # None = the family's own: silu (llama), gelu_pytorch_tanh (gemma)
     hidden_size: int = 2048
     intermediate_size: int = 5632
     num_hidden_layers: int = 22
@@ -82,6 +85,18 @@ class TextConfig:
     def __post_init__(self):
         if self.head_dim is None:
             self.head_dim = self.hidden_size // self.num_attention_heads
+        if self.model_type not in ("llama", "gemma"):
+            raise ValueError(f"text_config.model_type {self.model_type!r} is not built (llama, gemma)")
+        want = "silu" if self.model_type == "llama" else "gelu_pytorch_tanh"
+        if self.hidden_act is None:
+            self.hidden_act = want
+        # [3P] GemmaConfig: "gelu" in old checkpoints is the same tanh approximation (hidden_activation defaults to it)
+        if self.hidden_act != want and not (self.model_type == "gemma" and self.hidden_act == "gelu"):
+            raise ValueError(f"text_config.hidden_act {self.hidden_act!r} is not built for {self.model_type} ({want})")
+
+    @property
+    def is_gemma(self) -> bool:
+        return self.model_type == "gemma"
 
 
 AUDIO_PRESETS: Dict[str, Dict[str, Any]] = {
@@ -109,6 +124,13 @@ TEXT_PRESETS: Dict[str, Dict[str, Any]] = {
                                               rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING,
                                               max_position_embeddings=131072, eos_token_id=128009),
 }
+# Gemma-1 (C5).  head_dim 256 is NOT hidden_size / heads for the 7B model (3072 / 16 = 192)
+TEXT_PRESETS["google/gemma-7b"] = dict(model_type="gemma", hidden_size=3072, intermediate_size=24576, num_hidden_layers=28,
+                                       num_attention_heads=16, num_key_value_heads=16, head_dim=256, vocab_size=256000,
+                                       rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=8192, eos_token_id=1)
+TEXT_PRESETS["google/gemma-2b"] = dict(model_type="gemma", hidden_size=2048, intermediate_size=16384, num_hidden_layers=18,
+                                       num_attention_heads=8, num_key_value_heads=1, head_dim=256, vocab_size=256000,
+                                       rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=8192, eos_token_id=1)
 TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat"] = TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat-v1.0"]
 TEXT_PRESETS["meta-llama/Meta-Llama-3-8B"] = TEXT_PRESETS["meta-llama/Meta-Llama-3-8B-Instruct"]
 
@@ -133,22 +155,19 @@ def _mk(cls, value, presets, model_id):
 def _check_supported(cls, get) -> None:
     """Fields outside the dataclass are dropped by _mk, so anything that would change the arithmetic must be refused here:
     a Qwen2 (q/k/v biases), Mistral (sliding window) or Gemma config would otherwise run silently as a bias-free Llama."""
-    want = cls.__dataclass_fields__["model_type"].default
+    want = ("llama", "gemma") if cls is TextConfig else (cls.__dataclass_fields__["model_type"].default,)
     mt = get("model_type")
-    if mt is not None and mt != want:
-        raise ValueError(f"{cls.__name__}: model_type {mt!r} is not built (this path implements {want!r})")
+    if mt is not None and mt not in want:
+        raise ValueError(f"{cls.__name__}: model_type {mt!r} is not built (this path implements {', '.join(want)})")
     if cls is TextConfig:
         for flag in ("attention_bias", "mlp_bias"):
             if get(flag):
                 raise ValueError(f"text_config.{flag} = True is not built (the LLM kernels are bias-free, as Llama is)")
         if get("sliding_window"):
             raise ValueError("text_config.sliding_window is not built (full causal attention only)")
-        if get("tie_word_embeddings"):
+        if get("tie_word_embeddings") and mt != "gemma":     # Gemma ties by definition: the packer uses embed_tokens as the head
             raise ValueError("text_config.tie_word_embeddings = True: pass the embedding matrix as lm_head.weight "
                              "(checkpoint.language_model_state_dict does this for tied checkpoints) and leave the flag unset")
-        act = get("hidden_act")
-        if act not in (None, "silu"):
-            raise ValueError(f"text_config.hidden_act {act!r} is not built (SwiGLU / silu only)")
 
 
 class UltravoxConfig:

@@ -636,7 +636,7 @@ AttnArgs make_args(const uvx::AttnDesc& d) {
 }
 
 int check_desc(const uvx::AttnDesc& d) {
-  UVX_CHECK(d.D == 64 || d.D == 128, UVX_ERR_UNSUPPORTED, "attention: head_dim %d not supported (64 or 128)", d.D);
+  UVX_CHECK(d.D == 64 || d.D == 128 || d.D == 256, UVX_ERR_UNSUPPORTED, "attention: head_dim %d not supported (64, 128 or 256)", d.D);
   UVX_CHECK(d.Hkv > 0 && d.Hq % d.Hkv == 0, UVX_ERR_SHAPE, "attention: Hq=%d not a multiple of Hkv=%d", d.Hq, d.Hkv);
   UVX_CHECK(d.Tp % 64 == 0 && d.Tp >= d.T, UVX_ERR_SHAPE, "attention: Tp=%d must be a multiple of 64 and >= T=%d", d.Tp, d.T);
   UVX_CHECK(d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldo % 8 == 0, UVX_ERR_SHAPE, "attention: row strides must be multiples of 8");
@@ -666,9 +666,11 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
     else if (qt == 3) hipLaunchKernelGGL((attn_fwd_k<64, 3>), grid, dim3(256), 0, st, a);
     else if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<64, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_k<64, 1>), grid, dim3(256), 0, st, a);
-  } else {
+  } else if (d.D == 128) {
     if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<128, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_k<128, 1>), grid, dim3(256), 0, st, a);
+  } else {   // head_dim 256 (Gemma): one q tile per wave keeps the O accumulators (64 registers) + Q fragments in budget
+    hipLaunchKernelGGL((attn_fwd_k<256, 1>), dim3(cdiv(d.T, 64), d.Hq, d.B), dim3(256), 0, st, a);
   }
   UVX_LAUNCH_CHECK();
   return UVX_OK;
@@ -692,9 +694,12 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   if (d.f.D == 64) {
     hipLaunchKernelGGL(attn_bwd_dkdv_k<64>, gk, dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dq_k<64>, gq, dim3(256), 0, st, a);
-  } else {
+  } else if (d.f.D == 128) {
     hipLaunchKernelGGL(attn_bwd_dkdv_k<128>, gk, dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dq_k<128>, gq, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<256>, gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_k<256>, gq, dim3(256), 0, st, a);
   }
   if (a.dkv_part) {
     const long long n4 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 4);

@@ -157,20 +157,21 @@ AArgs mk(const uvx::AttnDesc& d) {
 namespace uvx {
 
 int attention_fwd_f32(hipStream_t st, const AttnDesc& d) {
-  UVX_CHECK(d.D == 64 || d.D == 128, UVX_ERR_UNSUPPORTED, "attention_f32: head_dim %d not supported", d.D);
+  UVX_CHECK(d.D == 64 || d.D == 128 || d.D == 256, UVX_ERR_UNSUPPORTED, "attention_f32: head_dim %d not supported", d.D);
   UVX_CHECK(d.v != nullptr, UVX_ERR_INVALID, "attention_f32: needs the natural-layout V");
   AArgs a = mk(d);
   const long long n = (long long)d.B * d.Hq * d.T;
   dim3 grid(cdiv(n, 4));
   if (d.D == 64) hipLaunchKernelGGL(attn_fwd_f32_k<64>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(attn_fwd_f32_k<128>, grid, dim3(256), 0, st, a);
+  else if (d.D == 128) hipLaunchKernelGGL(attn_fwd_f32_k<128>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(attn_fwd_f32_k<256>, grid, dim3(256), 0, st, a);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
 
 int attention_bwd_f32(hipStream_t st, const AttnBwdDesc& bd) {
   const AttnDesc& d = bd.f;
-  UVX_CHECK(d.D == 64 || d.D == 128, UVX_ERR_UNSUPPORTED, "attention_f32: head_dim %d not supported", d.D);
+  UVX_CHECK(d.D == 64 || d.D == 128 || d.D == 256, UVX_ERR_UNSUPPORTED, "attention_f32: head_dim %d not supported", d.D);
   AArgs a = mk(d);
   a.dout = (const float*)bd.dout; a.delta = bd.delta; a.delta_in = bd.delta;
   a.dq = (float*)bd.dq; a.dk = (float*)bd.dk; a.dv = (float*)bd.dv; a.lddq = bd.lddq; a.lddk = bd.lddk; a.lddv = bd.lddv;
@@ -178,9 +179,12 @@ int attention_bwd_f32(hipStream_t st, const AttnBwdDesc& bd) {
   if (d.D == 64) {
     hipLaunchKernelGGL(attn_bwd_dq_f32_k<64>, dim3(cdiv(nq, 4)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dkdv_f32_k<64>, dim3(cdiv(nk, 4)), dim3(256), 0, st, a);
-  } else {
+  } else if (d.D == 128) {
     hipLaunchKernelGGL(attn_bwd_dq_f32_k<128>, dim3(cdiv(nq, 4)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dkdv_f32_k<128>, dim3(cdiv(nk, 4)), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_f32_k<256>, dim3(cdiv(nq, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_f32_k<256>, dim3(cdiv(nk, 4)), dim3(256), 0, st, a);
   }
   UVX_LAUNCH_CHECK();
   return UVX_OK;

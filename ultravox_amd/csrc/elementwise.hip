@@ -10,7 +10,40 @@
 
 namespace {
 
+// GLU activations.  ACT 0: silu(g) = g * sigmoid(g); ACT 1: [3P] gelu_pytorch_tanh(g) = 0.5 g (1 + tanh(k (g + 0.044715 g^3))),
+// k = sqrt(2 / pi) - Gemma's hidden_act.  dact = d act / d g.
+template <int ACT>
+__device__ __forceinline__ float glu_act(float g) {
+  if (ACT == 0) return g / (1.0f + expf(-g));
+  const float u = 0.7978845608028654f * (g + 0.044715f * g * g * g);
+  return 0.5f * g * (1.0f + tanhf(u));
+}
+template <int ACT>
+__device__ __forceinline__ void glu_act_grad(float g, float& a, float& da) {
+  if (ACT == 0) {
+    const float s = 1.0f / (1.0f + expf(-g));
+    a = g * s;
+    da = s * (1.0f + g * (1.0f - s));
+  } else {
+    const float u = 0.7978845608028654f * (g + 0.044715f * g * g * g);
+    const float t = tanhf(u);
+    a = 0.5f * g * (1.0f + t);
+    da = 0.5f * (1.0f + t) + 0.5f * g * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * g * g);
+  }
+}
+
 template <typename T>
+__global__ void scale_k(T* __restrict__ x, long long n8, float s) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float v[8];
+  ld8<T>(x + i * 8, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] *= s;
+  st8<T>(x + i * 8, v);
+}
+
+template <typename T, int ACT>
 __global__ void swiglu_fwd_k(const T* __restrict__ in, T* __restrict__ out, long long n8, int half, int gate_first) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
@@ -24,11 +57,11 @@ __global__ void swiglu_fwd_k(const T* __restrict__ in, T* __restrict__ out, long
   ld8<T>(r + voff, a);   // value / up
   ld8<T>(r + goff, g);   // gate
 #pragma unroll
-  for (int k = 0; k < 8; ++k) o[k] = rnd<T>(g[k] / (1.0f + expf(-g[k]))) * a[k];
+  for (int k = 0; k < 8; ++k) o[k] = rnd<T>(glu_act<ACT>(g[k])) * a[k];
   st8<T>(out + row * half + c, o);
 }
 
-template <typename T>
+template <typename T, int ACT>
 __global__ void swiglu_bwd_k(const T* __restrict__ dout, const T* __restrict__ in, T* __restrict__ din,
                              long long n8, int half, int gate_first) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,10 +79,10 @@ __global__ void swiglu_bwd_k(const T* __restrict__ dout, const T* __restrict__ i
   ld8<T>(dout + row * half + c, d);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const float s = 1.0f / (1.0f + expf(-g[k]));
-    const float silu = g[k] * s;
-    da[k] = d[k] * rnd<T>(silu);
-    dg[k] = d[k] * a[k] * (s * (1.0f + g[k] * (1.0f - s)));
+    float act, dact;
+    glu_act_grad<ACT>(g[k], act, dact);
+    da[k] = d[k] * rnd<T>(act);
+    dg[k] = d[k] * a[k] * dact;
   }
   st8<T>(dr + voff, da);
   st8<T>(dr + goff, dg);
@@ -326,27 +359,38 @@ inline int grid1d(long long n, int th) { return (int)((n + th - 1) / th); }
 
 namespace uvx {
 
-int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first) {
+int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first, int act) {
   UVX_CHECK(half % 8 == 0 && (gate_first != 2 || half % 16 == 0), UVX_ERR_SHAPE, "swiglu: half=%d must be a multiple of 8 (16 when interleaved)", half);
+  UVX_CHECK(act == 0 || act == 1, UVX_ERR_INVALID, "swiglu: unknown activation %d", act);
   const long long n8 = (long long)rows * half / 8;
   if (n8 == 0) return UVX_OK;
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(swiglu_fwd_k<bf16_t>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, n8, half, gate_first);
-  else
-    hipLaunchKernelGGL(swiglu_fwd_k<float>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const float*)in, (float*)out, n8, half, gate_first);
+#define L(T, A) hipLaunchKernelGGL((swiglu_fwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)in, (T*)out, n8, half, gate_first)
+  if (dtype == DT_BF16) { if (act) L(bf16_t, 1); else L(bf16_t, 0); }
+  else { if (act) L(float, 1); else L(float, 0); }
+#undef L
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
 
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
-               int gate_first) {
+               int gate_first, int act) {
   UVX_CHECK(half % 8 == 0, UVX_ERR_SHAPE, "swiglu_bwd: half=%d must be a multiple of 8", half);
+  UVX_CHECK(act == 0 || act == 1, UVX_ERR_INVALID, "swiglu_bwd: unknown activation %d", act);
   const long long n8 = (long long)rows * half / 8;
   if (n8 == 0) return UVX_OK;
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(swiglu_bwd_k<bf16_t>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, n8, half, gate_first);
-  else
-    hipLaunchKernelGGL(swiglu_bwd_k<float>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const float*)dout, (const float*)in, (float*)din, n8, half, gate_first);
+#define L(T, A) hipLaunchKernelGGL((swiglu_bwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)din, n8, half, gate_first)
+  if (dtype == DT_BF16) { if (act) L(bf16_t, 1); else L(bf16_t, 0); }
+  else { if (act) L(float, 1); else L(float, 0); }
+#undef L
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int scale_inplace(hipStream_t st, int dtype, void* x, long long n, float s) {
+  UVX_CHECK(n % 8 == 0, UVX_ERR_SHAPE, "scale: n=%lld must be a multiple of 8", n);
+  if (n == 0) return UVX_OK;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(scale_k<bf16_t>, dim3(grid1d(n / 8, 256)), dim3(256), 0, st, (bf16_t*)x, n / 8, s);
+  else hipLaunchKernelGGL(scale_k<float>, dim3(grid1d(n / 8, 256)), dim3(256), 0, st, (float*)x, n / 8, s);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

@@ -311,6 +311,8 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
                                    int32_t* next_pos, int32_t* kv_start, void* logits_last, void* workspace, size_t ws_bytes) {
   UVX_CHECK(cfg && w && inputs_embeds && kv_cache && next_pos && kv_start && logits_last && workspace, UVX_ERR_INVALID,
             "llm_prefill: null argument");
+  UVX_CHECK(cfg->llm_flavor == UVX_LLM_LLAMA, UVX_ERR_UNSUPPORTED,
+            "generate(): the KV-cache prefill / decode kernels are built for the Llama family only (llm_flavor %d)", cfg->llm_flavor);
   const uvx_config_t& c = *cfg;
   UVX_CHECK(T >= 1 && T <= Tmax, UVX_ERR_SHAPE, "llm_prefill: prompt length %d exceeds the cache length %d", T, Tmax);
   UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
@@ -390,6 +392,8 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
                                          size_t ws_bytes) {
   UVX_CHECK(cfg && w && inputs_embeds && kv_cache && positions0 && logits_last && workspace, UVX_ERR_INVALID,
             "llm_prefill_chunk: null argument");
+  UVX_CHECK(cfg->llm_flavor == UVX_LLM_LLAMA, UVX_ERR_UNSUPPORTED,
+            "generate(): the KV-cache prefill / decode kernels are built for the Llama family only (llm_flavor %d)", cfg->llm_flavor);
   const uvx_config_t& c = *cfg;
   const int Tf = cur_len + Tn;
   UVX_CHECK(Tn >= 1 && cur_len >= 0 && Tf <= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: %d cached + %d new positions exceed the cache length %d",
@@ -451,6 +455,8 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
                                   const int32_t* positions, const int32_t* kv_start, void* kv_cache, int32_t Tmax,
                                   int32_t cur_len, int32_t B, void* logits, void* workspace, size_t ws_bytes) {
   UVX_CHECK(cfg && w && token_embeds && positions && kv_cache && logits && workspace, UVX_ERR_INVALID, "llm_decode: null argument");
+  UVX_CHECK(cfg->llm_flavor == UVX_LLM_LLAMA, UVX_ERR_UNSUPPORTED,
+            "generate(): the KV-cache prefill / decode kernels are built for the Llama family only (llm_flavor %d)", cfg->llm_flavor);
   const uvx_config_t& c = *cfg;
   UVX_CHECK(cur_len >= 0 && cur_len < Tmax, UVX_ERR_SHAPE, "llm_decode: cache full (%d of %d)", cur_len, Tmax);
   hipStream_t st = (hipStream_t)stream;

@@ -67,21 +67,26 @@ inline int gemm(hipStream_t st, int dtype, const GemmDesc& d) {
 int layernorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, const void* b, void* y,
                   int rows, int cols, float eps);
 // y = rmsnorm(x) * w ; optionally stores rstd[rows] (f32) for backward
+// flavor 0 = LlamaRMSNorm: w * round(x * rstd) (two roundings, as HF computes it); flavor 1 = GemmaRMSNorm: the whole of
+// x * rstd * (1 + w) in f32, ONE rounding ([3P] modeling_gemma.py GemmaRMSNorm.forward).
 int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, float* rstd,
-                int rows, int cols, float eps);
+                int rows, int cols, float eps, int flavor = 0);
 // dx = d(rmsnorm)/dx (+ dx_add if given: residual-stream gradient), optional dw partial accumulation
 // (f32 [cols], atomically accumulated; must be zeroed by the caller).
 int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w,
-                const void* dx_add, void* dx, float* dw, int rows, int cols, float eps);
+                const void* dx_add, void* dx, float* dw, int rows, int cols, float eps, int flavor = 0);
 // StackAudioFrames + RMSNorm (ultravox_model.py:722-730, 791): x [B, T, C] -> y [B, Tp/S, C*S]
 int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked,
                       int B, int T, int C, int S, float eps);
 
 // ---- elementwise.hip ----
 // layout: 0 = [value | gate] halves (UltravoxProjector), 1 = [gate | up] halves, 2 = 16-wide gate/up blocks interleaved
-int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first);
+// act: 0 = SiLU (SwiGLU: Llama MLP, UltravoxProjector), 1 = tanh-GELU (GeGLU: Gemma MLP, hidden_act gelu_pytorch_tanh)
+int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first, int act = 0);
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
-               int gate_first);
+               int gate_first, int act = 0);
+// x[i] = round(x[i] * s) in place over n elements (Gemma: inputs_embeds * sqrt(hidden_size), and its gradient)
+int scale_inplace(hipStream_t st, int dtype, void* x, long long n, float s);
 int rope_inplace(hipStream_t st, int dtype, void* qkv, const float* cos_sin, const int32_t* pos, int rows,
                  int T, int n_heads_rot, int head_dim, int ld, int inverse);
 int embed_gather(hipStream_t st, int dtype, const void* table, const int64_t* ids, void* out, int rows,

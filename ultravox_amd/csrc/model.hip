@@ -259,7 +259,15 @@ LlmLayerStash llm_layer(const LlmWs& w, int slot) {
 int check_cfg(const uvx_config_t* c) {
   UVX_CHECK(c != nullptr, UVX_ERR_INVALID, "null config");
   UVX_CHECK(c->dtype == DT_BF16 || c->dtype == DT_F32, UVX_ERR_INVALID, "bad dtype %d", c->dtype);
+  UVX_CHECK(c->llm_flavor == UVX_LLM_LLAMA || c->llm_flavor == UVX_LLM_GEMMA, UVX_ERR_INVALID, "bad llm_flavor %d", c->llm_flavor);
   return UVX_OK;
+}
+
+// [3P] transformers 4.51.3 GemmaModel.forward: normalizer = torch.tensor(hidden_size ** 0.5, dtype=hidden_states.dtype) -
+// the square root is ROUNDED to the model dtype before it multiplies (55.5 for hidden_size 3072 in bf16)
+float gemma_normalizer(const uvx_config_t& c) {
+  const float n = sqrtf((float)c.llm_d);
+  return c.dtype == DT_BF16 ? bf2f(f2bf(n)) : n;
 }
 
 GemmDesc lin(const void* A, const void* W, void* C, int M, int N, int K) {
@@ -646,11 +654,13 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   const int32_t *kvs = s.kvs, *kvl = s.kvl;
   LlmLayerStash cur = llm_layer(s, 0);
   UVX_HIP(hipMemcpyAsync(cur.x_in, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+  const int fl = c.llm_flavor;   // 0 Llama, 1 Gemma (norm flavour, GLU activation, embedding scale)
+  if (fl == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, cur.x_in, (long long)M * D, gemma_normalizer(c)));
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     const bool last = l + 1 == c.llm_layers;
     void* x_out = last ? s.x_final : llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1)).x_in;
-    RC(rmsnorm_fwd(st, dt, cur.x_in, L.ln1, s.n, nullptr, M, D, c.rms_eps));
+    RC(rmsnorm_fwd(st, dt, cur.x_in, L.ln1, s.n, nullptr, M, D, c.rms_eps, fl));
     RC(gemm(st, dt, lin(s.n, L.wqkv, cur.qkv, M, s.QKV, D)));
     if (lora) {   // peft LoRA on q_proj / k_proj (text_model_lora_config): added to the projections, before RoPE
       const uvx_enc_lora_layer_t& R = lora->layers[l];
@@ -676,12 +686,13 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       g.residual = cur.x_in; g.ldr = D;
       RC(gemm(st, dt, g));
     }
-    RC(rmsnorm_fwd(st, dt, cur.x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps));
+    RC(rmsnorm_fwd(st, dt, cur.x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps, fl));
     {  // gate|up projection; wgu rows are packed as alternating 16-row gate / up blocks (weights.py)
       GemmDesc g = lin(s.n, L.wgu, cur.gu, M, 2 * c.llm_inter, D);
-      if (dt == DT_BF16) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }   // SwiGLU fused into the epilogue
+      const bool fused = dt == DT_BF16 && fl == UVX_LLM_LLAMA;   // SwiGLU fused into the epilogue (GeGLU: separate kernel)
+      if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
       RC(gemm(st, dt, g));
-      if (dt != DT_BF16) RC(swiglu_fwd(st, dt, cur.gu, s.act, M, c.llm_inter, /*layout=*/2));
+      if (!fused) RC(swiglu_fwd(st, dt, cur.gu, s.act, M, c.llm_inter, /*layout=*/2, /*act=*/fl == UVX_LLM_GEMMA));
     }
     {
       GemmDesc g = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
@@ -690,7 +701,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     }
     if (!last) cur = llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1));
   }
-  RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps));
+  RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps, fl));
   if (rows) {
     UVX_CHECK(dt == DT_BF16, UVX_ERR_UNSUPPORTED, "llm_fwd_rows: bf16 only");
     UVX_CHECK(n_rows >= 0 && n_rows <= M, UVX_ERR_SHAPE, "llm_fwd_rows: %d rows of %d", n_rows, M);
@@ -823,22 +834,23 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     if (labels) RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale));
     RC(gemm(st, dt, lin(s.logits, w->lm_head_t, s.d_hn, M, D, c.vocab)));
   }
-  RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps));
+  const int fl = c.llm_flavor;
+  RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl));
   for (int l = c.llm_layers - 1; l >= 0; --l) {
     const uvx_llm_layer_t& L = w->layers[l];
     UVX_CHECK(L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t, UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
     LlmLayerStash cur = llm_layer(s, l);
     // MLP
-    if (dt == DT_BF16 && g_options[2]) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
+    if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
       GemmDesc g = lin(s.dx, L.wd_t, s.d_gu, M, c.llm_inter, D);
       g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2;
       RC(gemm(st, dt, g));
     } else {
       RC(gemm(st, dt, lin(s.dx, L.wd_t, s.d_act, M, c.llm_inter, D)));
-      RC(swiglu_bwd(st, dt, s.d_act, cur.gu, s.d_gu, M, c.llm_inter, /*layout=*/2));
+      RC(swiglu_bwd(st, dt, s.d_act, cur.gu, s.d_gu, M, c.llm_inter, /*layout=*/2, /*act=*/fl == UVX_LLM_GEMMA));
     }
     RC(gemm(st, dt, lin(s.d_gu, L.wgu_t, s.d_n, M, D, 2 * c.llm_inter)));
-    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_mid, L.ln2, s.dx, s.dx, nullptr, M, D, c.rms_eps));
+    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_mid, L.ln2, s.dx, s.dx, nullptr, M, D, c.rms_eps, fl));
     // attention
     RC(gemm(st, dt, lin(s.dx, L.wo_t, s.d_o, M, s.OD, D)));
     RC(heads_transpose(st, dt, cur.qkv, s.qT, B, T, s.Tp, Hq, dh, s.QKV));
@@ -865,7 +877,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       void* dk = at(s.d_qkv, (size_t)qc, dt);
       RC(lora_down(st, dt, s.d_qkv, s.QKV, cur.bqT, 0, s.lu, 128, M, qc, r, lora->scaling));
       RC(lora_down(st, dt, dk, s.QKV, cur.bkT, 0, at(s.lu, 64, dt), 128, M, kc, r, lora->scaling));
-      RC(rmsnorm_fwd(st, dt, cur.x_in, L.ln1, s.n, nullptr, M, D, c.rms_eps));        // n1 recomputed
+      RC(rmsnorm_fwd(st, dt, cur.x_in, L.ln1, s.n, nullptr, M, D, c.rms_eps, fl));        // n1 recomputed
       RC(lora_wgrad(st, dt, s.n, D, s.lu, 128, G.q.a, M, D, r, 0, 1.0f, s.lwg));
       RC(lora_wgrad(st, dt, s.n, D, at(s.lu, 64, dt), 128, G.k.a, M, D, r, 0, 1.0f, s.lwg));
       RC(lora_wgrad(st, dt, s.d_qkv, s.QKV, cur.t, 128, G.q.b, M, qc, r, 1, lora->scaling, s.lwg));
@@ -873,8 +885,9 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       RC(lora_up(st, dt, s.lu, 128, R.q.a, 1, s.d_n, D, M, D, r, 1.0f, 1));
       RC(lora_up(st, dt, at(s.lu, 64, dt), 128, R.k.a, 1, s.d_n, D, M, D, r, 1.0f, 1));
     }
-    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_in, L.ln1, s.dx, l == 0 ? d_inputs_embeds : s.dx, nullptr, M, D, c.rms_eps));
+    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_in, L.ln1, s.dx, l == 0 ? d_inputs_embeds : s.dx, nullptr, M, D, c.rms_eps, fl));
   }
+  if (fl == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, d_inputs_embeds, (long long)M * D, gemma_normalizer(c)));   // d (x * normalizer)
   return UVX_OK;
 }
 

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_wave_k(const bf16_t* __rest
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_wave_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, float* __restrict__ rstd_out,
-                                                          long long rows, float eps) {
+                                                          long long rows, float eps, int flavor) {
   constexpr int cols = NV * 512;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_wave_k(const bf16_t* __restri
     xv[k].get(v);
     ld8<bf16_t>(w + c, wv);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = wv[i] * rnd<bf16_t>(v[i] * rstd);
+    for (int i = 0; i < 8; ++i) o[i] = flavor ? (v[i] * rstd) * (1.0f + wv[i]) : wv[i] * rnd<bf16_t>(v[i] * rstd);
     st8<bf16_t>(y + row * cols + c, o);
   }
 }
@@ -213,7 +213,7 @@ __device__ __forceinline__ void row_span(const RowMap& m, long long row, int col
 template <typename T>
 __global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y,
                               T* __restrict__ stacked, float* __restrict__ rstd_out, int cols, float eps,
-                              RowMap map) {
+                              RowMap map, int flavor) {
   __shared__ float red[16];
   const long long row = blockIdx.x;
   long long base; int valid;
@@ -238,7 +238,7 @@ __global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, 
     }
     ld8<T>(w + c, wv);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = wv[i] * rnd<T>(v[i] * rstd);
+    for (int i = 0; i < 8; ++i) o[i] = flavor ? (v[i] * rstd) * (1.0f + wv[i]) : wv[i] * rnd<T>(v[i] * rstd);
     st8<T>(yr + c, o);
     if (stacked) st8<T>(stacked + row * cols + c, v);
   }
@@ -249,7 +249,9 @@ __global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, 
 template <typename T, bool WANT_DX, bool WANT_DW>
 __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
                               const T* __restrict__ dx_add, T* __restrict__ dx, float* __restrict__ dw,
-                              int rows, int cols, float eps, int rpb) {
+                              int rows, int cols, float eps, int rpb, int flavor) {
+  // flavor 1 (Gemma): y = x_hat * (1 + w) with no intermediate rounding -> the effective weight is 1 + w and
+  // d w gets the UNROUNDED x_hat
   __shared__ float red[16];
   __shared__ float red2[16];
   float dwacc[MAXV][8];
@@ -282,7 +284,7 @@ __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
       xr8.get(xv); gr8.get(gv);
       ld8<T>(w + c, wv);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { s1 += xv[i] * xv[i]; s2 += gv[i] * wv[i] * xv[i]; }
+      for (int i = 0; i < 8; ++i) { s1 += xv[i] * xv[i]; s2 += gv[i] * (flavor ? 1.0f + wv[i] : wv[i]) * xv[i]; }
     }
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red2);
@@ -304,12 +306,12 @@ __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
           for (int i = 0; i < 8; ++i) o[i] = 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] += r * gv[i] * wv[i] - xv[i] * coef;
+        for (int i = 0; i < 8; ++i) o[i] += r * gv[i] * (flavor ? 1.0f + wv[i] : wv[i]) - xv[i] * coef;
         st8<T>(dx + (long long)row * cols + c, o);
       }
       if (WANT_DW) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dwacc[j][i] += gv[i] * rnd<T>(xv[i] * r);
+        for (int i = 0; i < 8; ++i) dwacc[j][i] += gv[i] * (flavor ? xv[i] * r : rnd<T>(xv[i] * r));
       }
     }
   }
@@ -369,29 +371,29 @@ int layernorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, cons
 }
 
 static int rms_launch(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked,
-                      float* rstd, long long rows, int cols, float eps, RowMap map) {
+                      float* rstd, long long rows, int cols, float eps, RowMap map, int flavor = 0) {
   UVX_CHECK(cols % 8 == 0, UVX_ERR_SHAPE, "rmsnorm: cols=%d must be a multiple of 8", cols);
   if (rows == 0) return UVX_OK;
   const int th = norm_threads(cols);
   // (at 4096 columns the block kernel is as fast - 11.5 vs 12.4 us at 2528 rows - and has 4x the blocks: keep it)
   if (dtype == DT_BF16 && map.S == 0 && !stacked && (cols == 512 || cols == 1024 || cols == 2048)) {
     const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
-#define LW(NV) hipLaunchKernelGGL(rmsnorm_fwd_wave_k<NV>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, eps)
+#define LW(NV) hipLaunchKernelGGL(rmsnorm_fwd_wave_k<NV>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, eps, flavor)
     if (cols == 512) LW(1); else if (cols == 1024) LW(2); else LW(4);
 #undef LW
   } else if (dtype == DT_BF16)
     hipLaunchKernelGGL(rmsnorm_fwd_k<bf16_t>, dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w,
-                       (bf16_t*)y, (bf16_t*)stacked, rstd, cols, eps, map);
+                       (bf16_t*)y, (bf16_t*)stacked, rstd, cols, eps, map, flavor);
   else
     hipLaunchKernelGGL(rmsnorm_fwd_k<float>, dim3(rows), dim3(th), 0, st, (const float*)x, (const float*)w,
-                       (float*)y, (float*)stacked, rstd, cols, eps, map);
+                       (float*)y, (float*)stacked, rstd, cols, eps, map, flavor);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
 
 int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, float* rstd, int rows,
-                int cols, float eps) {
-  return rms_launch(st, dtype, x, w, y, nullptr, rstd, rows, cols, eps, RowMap{0, 0, 0, 0});
+                int cols, float eps, int flavor) {
+  return rms_launch(st, dtype, x, w, y, nullptr, rstd, rows, cols, eps, RowMap{0, 0, 0, 0}, flavor);
 }
 
 int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked, int B,
@@ -403,7 +405,7 @@ int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, v
 
 template <typename T>
 static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const void* w, const void* dx_add,
-                          void* dx, float* dw, int rows, int cols, float eps) {
+                          void* dx, float* dw, int rows, int cols, float eps, int flavor) {
   const int th = 256;
   UVX_CHECK(cols % 8 == 0 && cols <= th * 8 * MAXV, UVX_ERR_SHAPE, "rmsnorm_bwd: cols=%d unsupported", cols);
   if (rows == 0) return UVX_OK;
@@ -411,7 +413,7 @@ static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const v
   const int grid = (rows + rpb - 1) / rpb;
 #define L(DX, DW)                                                                                         \
   hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x, \
-                     (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb)
+                     (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor)
   if (dx && dw) L(true, true);
   else if (dx) L(true, false);
   else if (dw) L(false, true);
@@ -421,9 +423,9 @@ static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const v
 }
 
 int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w, const void* dx_add,
-                void* dx, float* dw, int rows, int cols, float eps) {
-  return dtype == DT_BF16 ? rms_bwd_launch<bf16_t>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps)
-                          : rms_bwd_launch<float>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps);
+                void* dx, float* dw, int rows, int cols, float eps, int flavor) {
+  return dtype == DT_BF16 ? rms_bwd_launch<bf16_t>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor)
+                          : rms_bwd_launch<float>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor);
 }
 
 }  // namespace uvx

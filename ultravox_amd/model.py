@@ -241,6 +241,7 @@ class UltravoxModel:
         c.stack_factor, c.proj_hidden, c.proj_ln_mid, c.proj_eps = cfg.stack_factor, cfg.hidden_size, int(cfg.projector_ln_mid), 1e-6
         c.llm_layers, c.llm_d, c.llm_heads, c.llm_kv_heads = t.num_hidden_layers, t.hidden_size, t.num_attention_heads, t.num_key_value_heads
         c.llm_head_dim, c.llm_inter, c.vocab, c.rms_eps = t.head_dim, t.intermediate_size, t.vocab_size, t.rms_norm_eps
+        c.llm_flavor = 1 if t.is_gemma else 0      # UVX_LLM_GEMMA / UVX_LLM_LLAMA (include/uvx.h)
         self._c = c
 
         e = self._enc
@@ -681,6 +682,9 @@ class UltravoxModel:
             warnings.warn(f"generate(): these arguments have no effect here: {sorted(ignored)}")
         if past is not None and not isinstance(past, KVState):
             raise TypeError("past_key_values must be the KVState a previous generate(return_dict_in_generate=True) returned")
+        if getattr(self.config.text_config, "is_gemma", False):
+            raise NotImplementedError("generate() is built for the Llama family; the Gemma backbone (BASELINE config 5) covers the "
+                                      "adapter-training path: forward, loss, backward")
         if self.text_lora_r > 0:
             raise NotImplementedError("generate() with an un-merged LLM LoRA adapter is not built: call merge_and_unload() first "
                                       "(as the reference does before inference, ultravox_model.py:528-559)")

@@ -90,7 +90,14 @@ def random_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32, d
         sd[L + "mlp.up_proj.weight"] = rn(I, D, s=1.0 / math.sqrt(D))
         sd[L + "mlp.down_proj.weight"] = rn(D, I, s=1.0 / math.sqrt(I))
     sd[P + "norm.weight"] = near_one(D)
-    sd["language_model.lm_head.weight"] = rn(t.vocab_size, D, s=1.0 / math.sqrt(D))
+    if getattr(t, "is_gemma", False):
+        # Gemma: norm weights are stored zero-centred (the norm multiplies by 1 + w), the embedding is divided by the
+        # sqrt(hidden) the model multiplies back in, and the head is the embedding matrix (tied: no lm_head key)
+        for k in [k for k in sd if k.startswith(P) and k.endswith(("layernorm.weight", "model.norm.weight"))]:
+            sd[k] = (sd[k].float() - 1.0).to(dtype)
+        sd[P + "embed_tokens.weight"] = (sd[P + "embed_tokens.weight"].float() / math.sqrt(D)).to(dtype)
+    else:
+        sd["language_model.lm_head.weight"] = rn(t.vocab_size, D, s=1.0 / math.sqrt(D))
     return sd
 
 
@@ -209,8 +216,11 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
     if prefix + "model.embed_tokens.weight" not in sd and prefix + "base_model.model.model.embed_tokens.weight" in sd:
         prefix = prefix + "base_model.model."          # a peft-wrapped LLM (LoRA checkpoints)
     P = prefix + "model."
-    out = {"embed": cv(sd[P + "embed_tokens.weight"]), "norm": cv(sd[P + "norm.weight"]),
-           "lm_head": cv(sd[prefix + "lm_head.weight"]), "layers": []}
+    out = {"embed": cv(sd[P + "embed_tokens.weight"]), "norm": cv(sd[P + "norm.weight"]), "layers": []}
+    # tied head (Gemma; HF tie_word_embeddings): lm_head IS the embedding matrix - one tensor, two uses
+    out["lm_head"] = cv(sd[prefix + "lm_head.weight"]) if prefix + "lm_head.weight" in sd else out["embed"]
+    if prefix + "lm_head.weight" not in sd and not getattr(t, "is_gemma", False):
+        raise KeyError(f"{prefix}lm_head.weight is missing (only the Gemma family ties the head to embed_tokens)")
     out["lm_head_t"] = tr(out["lm_head"])
     for i in range(t.num_hidden_layers):
         L = f"{P}layers.{i}."
