@@ -43,6 +43,9 @@ WORKLOADS = {
     # selectable for the DP-8 run (`--gpus 8 --workload c3`)
     "c3": dict(name="Llama-3-8B (frozen) + whisper-large-v3, bs=8x30s clips per GPU, adapter train",
                audio="openai/whisper-large-v3", text="meta-llama/Meta-Llama-3-8B-Instruct", B=8, seconds=30.0),
+    # BASELINE.json configs[4] per-rank shapes (alt encoder / backbone; the reference quotes it at DP = 4): not the quoted configuration
+    "c5": dict(name="Gemma-7B (frozen) + wav2vec2-large (frozen), bs=8x30s clips per GPU, adapter train",
+               audio="facebook/wav2vec2-large-960h", text="google/gemma-7b", B=8, seconds=30.0),
     # BASELINE.json configs[0] shapes (plumbing-sized), for quick checks
     "c1": dict(name="TinyLlama-1.1B + whisper-tiny, 1x4s clip, adapter train",
                audio="openai/whisper-tiny", text="TinyLlama/TinyLlama-1.1B-Chat-v1.0", B=1, seconds=4.0),
@@ -60,6 +63,17 @@ def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int =
     T = n_text + Na
     d, Le, ffn = a.d_model, a.encoder_layers, a.encoder_ffn_dim
     E = 2 * F * a.num_mel_bins * 3 * d + 2 * Te * d * 3 * d + Le * (8 * Te * d * d + 4 * Te * Te * d + 4 * Te * d * ffn)
+    if getattr(a, "is_wav2vec2", False):      # conv stack + feature projection + grouped positional conv + post-LN layers
+        n, Cc, E, cin = int(seconds * 16000), a.conv_dim[0], 0, 1
+        for k, st in zip(a.conv_kernel, a.conv_stride):
+            n = (n - k) // st + 1
+            E += 2 * n * Cc * k * cin
+            cin = Cc
+        Te = n
+        Na = -(-Te // cfg.stack_factor)
+        T = n_text + Na
+        E += 2 * Te * Cc * d + 2 * Te * d * a.num_conv_pos_embeddings * (d // a.num_conv_pos_embedding_groups)
+        E += Le * (8 * Te * d * d + 4 * Te * Te * d + 4 * Te * d * ffn)
     H, D = cfg.hidden_size, t.hidden_size
     P = 2 * Na * (8 * d * H + (H // 2) * D)
     h, kv, dh, I, V, L = t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.intermediate_size, t.vocab_size, t.num_hidden_layers
@@ -322,7 +336,7 @@ def main():
         from ultravox_amd.parallel import UvxComm
         comm = UvxComm.from_torch_distributed()
     trainer = UltravoxTrainer(model, lr=2e-3, max_grad_norm=1.0, overlap_comm=world > 1 and not args.no_overlap, comm=comm)
-    fe = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins, device=str(dev))
+    fe = None if cfg.audio_config.is_wav2vec2 else WhisperFeatureExtractor(cfg.audio_config.num_mel_bins, device=str(dev))
     batch = synthetic_batch(cfg, B, wl["seconds"], n_text=128, audio_start=16, n_supervised=32, rank=rank)
     pcm = batch.pop("pcm").to(dev)
     if args.loss == "kl":
@@ -338,7 +352,14 @@ def main():
     batch = {k: v.to(dev) for k, v in batch.items()}
     T = batch["input_ids"].shape[1]
 
+    if cfg.audio_config.is_wav2vec2:
+        # raw-waveform tower: the feature extractor's per-clip normalisation (host arithmetic in the reference's data loader)
+        # is applied once, outside the timed region; the step starts from input_values resident in HBM
+        values = ((pcm - pcm.mean(-1, keepdim=True)) / torch.sqrt(pcm.var(-1, unbiased=False, keepdim=True) + 1e-7)).contiguous()
+
     def step():
+        if cfg.audio_config.is_wav2vec2:
+            return trainer.train_step(audio_values=values, **batch)
         mel = fe.logmel_device(pcm)                        # K1 on device, inside the step
         return trainer.train_step(audio_values=mel, **batch)
 

@@ -164,6 +164,37 @@ int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const uvx_encoder
                         const void* d_out, const int64_t* audio_lens, int32_t B, int32_t F,
                         const uvx_encoder_lora_grads_t* grads, void* workspace, size_t ws_bytes);
 
+/* Alt audio tower (BASELINE.json config 5): [3P] transformers Wav2Vec2Model.forward, the AutoModel branch of
+ * UltravoxModel._create_audio_tower (ultravox_model.py:460-467, :476-485), for the facebook/wav2vec2-large-960h family
+ * (GroupNorm after the first conv layer, bias-free convs, post-LN encoder).  Frozen tower: forward only.
+ * input_values [B, L] (f32 if values_is_f32 else cfg dtype): the zero-mean / unit-variance waveform of the `input_values`
+ * fallback (ultravox_processing.py:308); out [B, frames, d] with frames = uvx_wav2vec2_frames(cfg, L).  No attention mask
+ * (group-norm wav2vec2 models are used without one).
+ * Weight packing (host, once): conv0_w [C, 64] = conv_layers.0.conv.weight[:, 0, k] in column k, zero padded;
+ * conv_w[i] (i >= 1) [C, k_i C] with column k C + c = conv_layers.i.conv.weight[:, c, k];  pos_w [G][d/G, K d/G] with
+ * column k d/G + c = (weight-normed) pos_conv_embed.conv.weight[g d/G + o, c, k];  layers[] reuse uvx_enc_layer_t:
+ * wqkv = [q_proj * head_dim^-0.5 ; k_proj ; v_proj], bqkv likewise, ln1 = layers.N.layer_norm, ln2 = final_layer_norm. */
+typedef struct {
+  int32_t dtype;
+  int32_t n_conv, conv_dim;
+  int32_t conv_kernel[8], conv_stride[8];
+  int32_t d, heads, ffn, layers;
+  int32_t pos_k, pos_groups;
+  float ln_eps;
+} uvx_w2v_config_t;
+typedef struct {
+  const void *conv0_w, *gn_w, *gn_b;
+  const void* conv_w[8];
+  const void *fp_ln_w, *fp_ln_b, *fp_w, *fp_b;
+  const void *pos_w, *pos_b;
+  const void *ln_w, *ln_b;
+  const uvx_enc_layer_t* layers; /* HOST array [layers] */
+} uvx_w2v_weights_t;
+int32_t uvx_wav2vec2_frames(const uvx_w2v_config_t* cfg, int32_t L); /* [3P] _get_feat_extract_output_lengths; -1 if too short */
+size_t uvx_wav2vec2_ws_bytes(const uvx_w2v_config_t* cfg, int32_t B, int32_t L);
+int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_weights_t* w, const void* input_values,
+                         int32_t values_is_f32, int32_t B, int32_t L, void* out, void* workspace, size_t ws_bytes);
+
 /* embed_tokens + the in-place audio overwrite loop (ultravox_model.py:314-316, :390-394, :259-275).
  * input_ids [B, T] int64; audio_embeds [n_items, Na, D]; audio_batch_size [B] int64;
  * audio_token_start_idx [n_items] int64; audio_token_len [n_items] int32.  Later items overwrite earlier

@@ -268,6 +268,70 @@ def whisper_encoder_ref(sd: Dict[str, torch.Tensor], cfg, input_features: torch.
 
 
 # ----------------------------------------------------------------------------------------------
+# Alt audio tower (BASELINE.json config 5): [3P] transformers Wav2Vec2Model.forward, the AutoModel branch of
+# UltravoxModel._create_audio_tower (ultravox_model.py:460-467, :476-485).  In this reference snapshot that branch cannot
+# run end to end (max_context_length / audio_len / hop_length exist only for the Whisper tower - SURVEY.md §8f-4), so the
+# contract is the third-party module's: input_values [B, L] (zero-mean / unit-variance waveform, the `input_values` fallback
+# of ultravox_processing.py:308) -> last_hidden_state [B, frames, hidden], no attention mask (wav2vec2-large-960h is a
+# feat_extract_norm="group" model: trained and used without one).  Pinned against the installed HF Wav2Vec2Model.
+# ----------------------------------------------------------------------------------------------
+def wav2vec2_normalize_ref(pcm: torch.Tensor) -> torch.Tensor:
+    """[3P] Wav2Vec2FeatureExtractor.zero_mean_unit_var_norm for equal-length clips [B, L]: (x - mean) / sqrt(var + 1e-7)."""
+    return (pcm - pcm.mean(-1, keepdim=True)) / torch.sqrt(pcm.var(-1, unbiased=False, keepdim=True) + 1e-7)
+
+
+def pos_conv_weight_ref(sd: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
+    """weight_norm(conv, dim=2): w = g * v / ||v|| with the norm over (out, in) per kernel position; torch's parametrization
+    names (original0 = g, original1 = v) or the older weight_g / weight_v."""
+    P = prefix + "encoder.pos_conv_embed.conv."
+    if P + "parametrizations.weight.original0" in sd:
+        g, v = sd[P + "parametrizations.weight.original0"], sd[P + "parametrizations.weight.original1"]
+    else:
+        g, v = sd[P + "weight_g"], sd[P + "weight_v"]
+    return v * (g / v.float().norm(dim=(0, 1), keepdim=True).to(v.dtype))
+
+
+def wav2vec2_encoder_ref(sd: Dict[str, torch.Tensor], cfg, input_values: torch.Tensor, prefix: str = "audio_tower.") -> torch.Tensor:
+    a = cfg.audio_config
+    dt = input_values.dtype
+    W = lambda k: sd[prefix + k].to(dt)
+    H, d = a.encoder_attention_heads, a.d_model
+    dh = d // H
+    x = input_values[:, None]                                                     # Wav2Vec2FeatureEncoder
+    for i, (k, st) in enumerate(zip(a.conv_kernel, a.conv_stride)):
+        x = F.conv1d(x, W(f"feature_extractor.conv_layers.{i}.conv.weight"), stride=st)
+        if i == 0:      # Wav2Vec2GroupNormConvLayer: GroupNorm(num_groups = channels) = per-channel statistics over time
+            C = x.shape[1]
+            x = F.group_norm(x, C, W("feature_extractor.conv_layers.0.layer_norm.weight"),
+                             W("feature_extractor.conv_layers.0.layer_norm.bias"), 1e-5)
+        x = F.gelu(x)
+    x = x.transpose(1, 2)                                                         # [B, T, conv_dim]
+    C = x.shape[-1]
+    x = F.layer_norm(x, (C,), W("feature_projection.layer_norm.weight"), W("feature_projection.layer_norm.bias"), a.layer_norm_eps)
+    x = F.linear(x, W("feature_projection.projection.weight"), W("feature_projection.projection.bias"))
+    K, G = a.num_conv_pos_embeddings, a.num_conv_pos_embedding_groups             # Wav2Vec2PositionalConvEmbedding
+    pos = F.conv1d(x.transpose(1, 2), pos_conv_weight_ref(sd, prefix).to(dt), W("encoder.pos_conv_embed.conv.bias"), padding=K // 2, groups=G)
+    if K % 2 == 0:
+        pos = pos[:, :, :-1]                                                      # Wav2Vec2SamePadLayer
+    x = x + F.gelu(pos).transpose(1, 2)
+    x = F.layer_norm(x, (d,), W("encoder.layer_norm.weight"), W("encoder.layer_norm.bias"), a.layer_norm_eps)
+    B, S, _ = x.shape
+    for i in range(a.encoder_layers):                                             # Wav2Vec2EncoderLayer (post-LN)
+        L = f"encoder.layers.{i}."
+        q = F.linear(x, W(L + "attention.q_proj.weight"), W(L + "attention.q_proj.bias")) * dh ** -0.5
+        k = F.linear(x, W(L + "attention.k_proj.weight"), W(L + "attention.k_proj.bias"))
+        v = F.linear(x, W(L + "attention.v_proj.weight"), W(L + "attention.v_proj.bias"))
+        q, k, v = (t.view(B, S, H, dh).transpose(1, 2) for t in (q, k, v))
+        o = _attend(q, k, v, None, 1.0).transpose(1, 2).reshape(B, S, d)
+        x = x + F.linear(o, W(L + "attention.out_proj.weight"), W(L + "attention.out_proj.bias"))
+        x = F.layer_norm(x, (d,), W(L + "layer_norm.weight"), W(L + "layer_norm.bias"), a.layer_norm_eps)
+        h = F.gelu(F.linear(x, W(L + "feed_forward.intermediate_dense.weight"), W(L + "feed_forward.intermediate_dense.bias")))
+        x = x + F.linear(h, W(L + "feed_forward.output_dense.weight"), W(L + "feed_forward.output_dense.bias"))
+        x = F.layer_norm(x, (d,), W(L + "final_layer_norm.weight"), W(L + "final_layer_norm.bias"), a.layer_norm_eps)
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
 # Projector — StackAudioFrames / RMSNorm / SwiGLU / UltravoxProjector, ultravox_model.py:712-800.
 # ----------------------------------------------------------------------------------------------
 def rmsnorm_ref(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
@@ -460,6 +524,10 @@ class OracleModel:
         return {k[len(P):]: self.sd[k] for k in self.trainable if k.startswith(P)}
 
     def audio_embeds(self, audio_values, audio_lens):
+        if getattr(self.cfg.audio_config, "is_wav2vec2", False):
+            with torch.no_grad():                                                          # frozen tower (apply_lora r = 0)
+                tower = wav2vec2_encoder_ref(self.sd, self.cfg, audio_values.to(self.dtype))
+            return tower, projector_ref(self.projector_params(), self.cfg, tower.to(self.dtype))
         with torch.set_grad_enabled(self.lora is not None and torch.is_grad_enabled()):   # frozen tower unless LoRA-adapted
             tower = whisper_encoder_ref(self.sd, self.cfg, audio_values.to(self.dtype), audio_lens, lora=self.lora)   # :382-385
         return tower, projector_ref(self.projector_params(), self.cfg, tower.to(self.dtype))        # :386-387
@@ -537,6 +605,9 @@ def synthetic_batch(cfg, B: int, seconds: float, n_text: int = 128, audio_start:
     pcm = (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
     Fm = L // HOP
     Na = -(-Fm // (2 * cfg.stack_factor))
+    if getattr(cfg.audio_config, "is_wav2vec2", False):     # raw-waveform tower: audio_lens = encoder frames, no 2x factor
+        Fm = cfg.audio_config.feat_extract_output_length(L)
+        Na = -(-Fm // cfg.stack_factor)
     g2 = torch.Generator().manual_seed(4321 + rank)
     V = cfg.text_config.vocab_size
     text = torch.randint(0, V - 1, (B, n_text), generator=g2)

@@ -135,7 +135,18 @@ def test_configs_outside_the_built_arithmetic_are_refused_not_run_as_llama():
         with pytest.raises(ValueError):
             UltravoxConfig(text_config={**ok_text, **bad})
     with pytest.raises(ValueError, match="model_type"):
-        UltravoxConfig(audio_config={"model_type": "wav2vec2", "d_model": 64})
+        UltravoxConfig(audio_config={"model_type": "hubert", "d_model": 64})
+    # the families that ARE built (BASELINE config 5): Gemma backbone, wav2vec2-large-960h-style tower - and their unbuilt variants
+    g = UltravoxConfig(text_config={**ok_text, "model_type": "gemma", "head_dim": 32, "tie_word_embeddings": True}).text_config
+    assert g.is_gemma and g.hidden_act == "gelu_pytorch_tanh" and g.head_dim == 32
+    w = UltravoxConfig(audio_config={"model_type": "wav2vec2", "hidden_size": 64, "num_hidden_layers": 2, "num_attention_heads": 2,
+                                     "intermediate_size": 128, "conv_dim": [64] * 7}).audio_config
+    assert w.is_wav2vec2 and (w.d_model, w.encoder_layers, w.encoder_ffn_dim) == (64, 2, 128) and w.feat_extract_output_length(16000) == 49
+    for bad in ({"feat_extract_norm": "layer"}, {"do_stable_layer_norm": True}, {"conv_bias": True}):
+        with pytest.raises(ValueError, match="960h"):
+            UltravoxConfig(audio_config={"model_type": "wav2vec2", "hidden_size": 64, **bad})
+    with pytest.raises(ValueError, match="hidden_act"):
+        UltravoxConfig(text_config={**ok_text, "model_type": "gemma", "hidden_act": "silu"})
     # apply_lora with r = 0 + unfreeze_layers (ultravox_model.py:694-703) is not built: refused, not silently frozen
     for r in (0, 8):
         with pytest.raises(ValueError, match="unfreeze_layers"):

@@ -356,3 +356,46 @@ def test_gemma_backbone_matches_hf_blocks():
     np.testing.assert_allclose(loss.item(), out.loss.item(), rtol=1e-5)
     # bf16: the normalizer is rounded to the model dtype before it multiplies (4.51.3: torch.tensor(sqrt(H), dtype=...))
     assert float(torch.tensor(3072 ** 0.5, dtype=torch.bfloat16)) == 55.5
+
+
+W2V_TINY = {"model_type": "wav2vec2", "hidden_size": 64, "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 128,
+            "conv_dim": [64] * 7, "num_conv_pos_embeddings": 16, "num_conv_pos_embedding_groups": 4}
+
+
+def test_wav2vec2_tower_matches_hf_model():
+    """BASELINE config 5's tower.  [3P] check: the restated Wav2Vec2Model.forward (GroupNorm conv stem, feature projection,
+    weight-normed grouped positional conv, post-LN layers) == the installed HF Wav2Vec2Model on the same weights."""
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    cfg = UltravoxConfig(audio_config=W2V_TINY, text_config=TINY["text_config"], hidden_size=64)
+    a = cfg.audio_config
+    hf = Wav2Vec2Model(Wav2Vec2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                                      conv_dim=[64] * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4,
+                                      feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False,
+                                      attn_implementation="eager")).eval()
+    sd = random_state_dict(cfg, seed=2)
+    missing, unexpected = hf.load_state_dict({k[len("audio_tower."):]: v for k, v in sd.items() if k.startswith("audio_tower.")}, strict=False)
+    assert not unexpected and missing == ["masked_spec_embed"]
+    torch.manual_seed(1)
+    x = O.wav2vec2_normalize_ref(torch.randn(2, 6000) * 0.1 + 0.02)
+    with torch.no_grad():
+        want = hf(x).last_hidden_state
+        got = O.wav2vec2_encoder_ref(sd, cfg, x)
+    assert got.shape == want.shape == (2, a.feat_extract_output_length(6000), 64)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    assert hf._get_feat_extract_output_lengths(480000) == a.feat_extract_output_length(480000) == 1499
+
+
+def test_wav2vec2_feature_extractor_contract_matches_hf():
+    from transformers import Wav2Vec2FeatureExtractor as HF
+    from ultravox_amd.frontend import Wav2Vec2FeatureExtractor
+    rng = np.random.RandomState(3)
+    clips = [rng.randn(4000).astype(np.float32) * 0.3 + 0.1, rng.randn(2500).astype(np.float32)]
+    want = HF(feature_size=1, sampling_rate=16000, padding_value=0.0, do_normalize=True, return_attention_mask=True)(
+        clips, sampling_rate=16000, padding="longest", return_attention_mask=True, return_tensors="pt")
+    got = Wav2Vec2FeatureExtractor()(clips, sampling_rate=16000, padding="longest", return_attention_mask=True)
+    np.testing.assert_allclose(got["input_values"].numpy(), want["input_values"].numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(got["attention_mask"].long(), want["attention_mask"].long())
+    np.testing.assert_allclose(O.wav2vec2_normalize_ref(torch.from_numpy(clips[0])[None]).numpy(), want["input_values"][:1].numpy(),
+                               rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError, match="sampling rate"):
+        Wav2Vec2FeatureExtractor()(clips, sampling_rate=8000)

@@ -118,3 +118,40 @@ def test_collator_right_and_left_padding(golden):
                 assert list(batch[k].shape) == v
             else:
                 assert batch[k].tolist() == v, (side, k)
+
+
+def test_raw_waveform_tower_branch_of_the_processor():
+    """BASELINE config 5 (wav2vec2): the `input_values` fallback (ultravox_processing.py:308).  The reference cannot execute it
+    (feature_extractor.hop_length, :284), so this pins OUR contract: one un-chunked item per audio, audio_lens = encoder frames,
+    audio_token_len = ceil(frames / stack_factor) = the projector's rows, placeholders expanded and collated as for Whisper."""
+    import numpy as np
+    from fake_tokenizer import FakeTokenizer
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.frontend import Wav2Vec2FeatureExtractor
+    from ultravox_amd.processing import DataCollatorForSeq2SeqWithAudio, UltravoxProcessor
+    cfg = UltravoxConfig(audio_model_id="facebook/wav2vec2-large-960h", text_model_id="google/gemma-7b")
+    tok = FakeTokenizer()
+    proc = UltravoxProcessor(Wav2Vec2FeatureExtractor(), tok, stack_factor=8, audio_frames_fn=cfg.audio_config.feat_extract_output_length)
+    rng = np.random.RandomState(0)
+    a30, a1 = rng.randn(480000).astype(np.float32), rng.randn(16000).astype(np.float32)
+    out = proc(text="Listen <|audio|> and <|audio|> done", audios=[a30, a1], sampling_rate=16000, include_audio_num_chunks=True)
+    assert tuple(out["audio_values"].shape) == (2, 480000) and out["audio_values"].dtype == torch.float32
+    assert out["audio_lens"].tolist() == [1499, 49] and out["audio_token_len"].tolist() == [188, 7]
+    assert out["audio_batch_size"].tolist() == [2] and out["audio_num_chunks"].tolist() == [1, 1]
+    ids = out["input_ids"][0].tolist()
+    s0, s1 = out["audio_token_start_idx"].tolist()
+    eos = tok.eos_token_id
+    assert ids[s0:s0 + 188] == [eos] * 188 and ids[s1:s1 + 7] == [eos] * 7 and s1 > s0 + 188
+    assert abs(float(out["audio_values"][1, :16000].mean())) < 1e-5 and float(out["audio_values"][1, 16000:].abs().max()) == 0.0
+    with pytest.raises(ValueError, match="audio placeholders"):
+        proc(text="only one <|audio|>", audios=[a1, a1], sampling_rate=16000)
+    with pytest.raises(ValueError, match="receptive field"):
+        proc(text="<|audio|>", audios=[a1[:300]], sampling_rate=16000)
+    # collation: the waveforms are right-padded to the longest one
+    one = proc(text="<|audio|> hi", audios=[a1], sampling_rate=16000)
+    feats = [{k: (v[0] if k in ("input_ids", "attention_mask") else v) for k, v in f.items()} for f in (out, one)]
+    for f in feats:
+        f.pop("audio_num_chunks", None)
+    batch = DataCollatorForSeq2SeqWithAudio(tok)(feats)
+    assert tuple(batch["audio_values"].shape) == (3, 480000) and batch["audio_lens"].tolist() == [1499, 49, 49]
+    assert batch["audio_batch_size"].reshape(-1).tolist() == [2, 1]

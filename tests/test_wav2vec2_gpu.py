@@ -1,0 +1,104 @@
+"""BASELINE.json config 5's audio tower (wav2vec2) on the GPU through uvx_wav2vec2_fwd: the conv stem as strided-view GEMMs,
+GroupNorm over time, the grouped positional conv, the post-LN encoder - against the oracle's restatement, which
+tests/test_oracle_pinning.py pins to the installed HF Wav2Vec2Model.  f32 mode tight, bf16 at the per-stage bf16-vs-f32 bar;
+then the whole C5 pairing (wav2vec2-large WIDTH + Gemma-7B WIDTH, reduced depth) through one adapter-train step."""
+import pytest
+import torch
+
+from parity_util import oracle_threads, record, rel_l2, stage_errors
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+W2V_SMALL = {"model_type": "wav2vec2", "hidden_size": 128, "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 256,
+             "conv_dim": [64] * 7, "num_conv_pos_embeddings": 16, "num_conv_pos_embedding_groups": 4}
+TEXT_SMALL = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                  vocab_size=512, eos_token_id=2)
+
+
+def _cfg(audio=W2V_SMALL, text=TEXT_SMALL, **kw):
+    from ultravox_amd.config import UltravoxConfig
+    return UltravoxConfig(audio_config=audio, text_config=text, hidden_size=256, projector_ln_mid=True, **kw)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
+def test_wav2vec2_tower_matches_oracle(dtype, tol):
+    from oracle.reference_cpu import wav2vec2_encoder_ref, wav2vec2_normalize_ref
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = _cfg()
+    sd = {k: v.to(dtype) for k, v in random_state_dict(cfg, seed=5).items()}
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    torch.manual_seed(2)
+    x = wav2vec2_normalize_ref(0.1 * torch.randn(3, 9000) + 0.01)                 # 9000 samples -> 27 frames
+    got = model.audio_tower_forward(x.to(DEV), None)
+    with torch.no_grad():
+        want = wav2vec2_encoder_ref({k: v.float() for k, v in sd.items()}, cfg, x.to(dtype).float())
+    assert got.shape == want.shape == (3, cfg.audio_config.feat_extract_output_length(9000), 128)
+    err = stage_errors(got, want)
+    record(f"wav2vec2_small_{'f32' if dtype == torch.float32 else 'bf16'}", err)
+    assert err["rel_l2"] < tol, err
+    with pytest.raises(ValueError, match="receptive field"):
+        model.audio_tower_forward(x[:, :300].to(DEV), None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wav2vec2_llama_train_step_matches_oracle(dtype):
+    """The alt tower in front of the (Llama) LLM: one adapter-train step, loss + projector gradients vs the oracle."""
+    from oracle.reference_cpu import OracleModel, synthetic_batch, wav2vec2_normalize_ref
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = _cfg()
+    sd = {k: v.to(dtype) for k, v in random_state_dict(cfg, seed=6).items()}
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    b = synthetic_batch(cfg, 2, 2.0, n_text=24, audio_start=5, n_supervised=8)        # 32000 samples -> 99 frames -> 13 tokens
+    assert int(b["audio_lens"][0]) == 99 and int(b["audio_token_len"][0]) == 13
+    b["audio_values"] = wav2vec2_normalize_ref(b.pop("pcm")).to(dtype)
+    ref, grads, _ = oracle.train_step({**b, "audio_values": b["audio_values"].float()})
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    out = model.forward(**gb)
+    model.train()
+    loss = model.forward_backward(**gb)
+    mine = model.projector_grads()
+    f32 = dtype == torch.float32
+    assert rel_l2(out.logits, ref["logits"]) < (1e-4 if f32 else 3e-2)
+    assert abs(loss.item() - ref["loss"].item()) < (1e-4 if f32 else 2e-2) * abs(ref["loss"].item())
+    for k, g in grads.items():
+        assert rel_l2(mine[k], g) < (2e-3 if f32 else 8e-2), k
+
+
+def test_c5_wav2vec2_large_gemma_7b_width_train_step():
+    """C5 at full WIDTH, reduced depth: wav2vec2-large (conv 512 x 7 on 30 s = 95 999 -> 1 499 frames, d 1024, pos-conv k 128 g 16,
+    2 of 24 layers) + Gemma-7B (3072 / 24576 / 16 x 256 / 256000, 1 of 28 layers), 2 x 30 s clips + 128 text tokens."""
+    from oracle.reference_cpu import OracleModel, synthetic_batch, wav2vec2_normalize_ref
+    from ultravox_amd.config import AUDIO_PRESETS, TEXT_PRESETS, UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    tc = dict(TEXT_PRESETS["google/gemma-7b"], num_hidden_layers=1)
+    ac = dict(AUDIO_PRESETS["facebook/wav2vec2-large-960h"], encoder_layers=2)
+    cfg = UltravoxConfig(text_config=tc, audio_config=ac, hidden_size=4096, stack_factor=8, projector_ln_mid=True, torch_dtype="bfloat16")
+    sd = random_state_dict(cfg, seed=3, dtype=torch.bfloat16, device="cuda")
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16, rope_len=512)
+    oracle = OracleModel(cfg, {k: v.cpu() for k, v in sd.items()}, dtype=torch.float32)
+    b = synthetic_batch(cfg, 2, 30.0, n_text=128, audio_start=16, n_supervised=32)
+    assert int(b["audio_lens"][0]) == 1499 and int(b["audio_token_len"][0]) == 188 and b["input_ids"].shape[1] == 316
+    vals = wav2vec2_normalize_ref(b.pop("pcm")).bfloat16()
+    b["audio_values"] = vals
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    oracle_threads()
+    with torch.no_grad():
+        tower_ref, _ = oracle.audio_embeds(vals.float(), None)
+    ref, grads, _ = oracle.train_step({**b, "audio_values": vals.float()})
+    rec = {"tower": stage_errors(model.audio_tower_forward(gb["audio_values"], None), tower_ref)}
+    out = model.forward(**gb)
+    model.train()
+    loss = model.forward_backward(**gb)
+    mine = model.projector_grads()
+    rec.update({"logits": stage_errors(out.logits, ref["logits"]), "loss": [loss.item(), ref["loss"].item()],
+                "grads": {k: rel_l2(mine[k], g) for k, g in grads.items()}})
+    record("c5_wav2vec2_large_gemma_7b_width", rec)
+    assert rec["tower"]["rel_l2"] < 2e-2 and rec["logits"]["rel_l2"] < 3e-2, rec
+    assert abs(loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
+    for k, v in rec["grads"].items():
+        assert v < 8e-2, (k, v)

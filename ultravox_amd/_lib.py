@@ -112,6 +112,20 @@ class EncoderWeights(C.Structure):
                 ("pos", C.c_void_p), ("layers", C.POINTER(EncLayer)), ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p)]
 
 
+class W2vConfig(C.Structure):      # uvx_w2v_config_t
+    _fields_ = [("dtype", C.c_int32), ("n_conv", C.c_int32), ("conv_dim", C.c_int32),
+                ("conv_kernel", C.c_int32 * 8), ("conv_stride", C.c_int32 * 8),
+                ("d", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32), ("layers", C.c_int32),
+                ("pos_k", C.c_int32), ("pos_groups", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class W2vWeights(C.Structure):     # uvx_w2v_weights_t
+    _fields_ = [("conv0_w", C.c_void_p), ("gn_w", C.c_void_p), ("gn_b", C.c_void_p), ("conv_w", C.c_void_p * 8),
+                ("fp_ln_w", C.c_void_p), ("fp_ln_b", C.c_void_p), ("fp_w", C.c_void_p), ("fp_b", C.c_void_p),
+                ("pos_w", C.c_void_p), ("pos_b", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
+                ("layers", C.POINTER(EncLayer))]
+
+
 class LoraProj(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p)]
 
@@ -168,13 +182,15 @@ EXPORTS = [
     "uvx_llm_prefill", "uvx_llm_prefill_chunk", "uvx_llm_prefill_chunk_ws_bytes", "uvx_llm_decode", "uvx_argmax", "uvx_llm_kl_loss", "uvx_kl_loss", "uvx_gemm_override_variant", "uvx_gemm_pick_variant", "uvx_set_option",
     "uvx_encoder_train_ws_bytes", "uvx_encoder_fwd_train", "uvx_encoder_bwd", "uvx_layernorm_bwd", "uvx_gelu", "uvx_gelu_bwd",
     "uvx_llm_fwd_rows", "uvx_llm_kl_loss_rows", "uvx_llm_bwd_rows", "uvx_llm_fwd_lora", "uvx_llm_bwd_lora",
+    "uvx_wav2vec2_frames", "uvx_wav2vec2_ws_bytes", "uvx_wav2vec2_fwd",
     "uvx_comm_unique_id", "uvx_comm_init", "uvx_comm_world_size", "uvx_comm_version", "uvx_comm_allreduce_f32", "uvx_comm_destroy",
 ]
 
 
 def _declare(l: C.CDLL) -> None:
     for name in ("uvx_encoder_ws_bytes", "uvx_projector_ws_bytes", "uvx_llm_ws_bytes", "uvx_attention_ws_bytes",
-                 "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes", "uvx_llm_prefill_chunk_ws_bytes", "uvx_encoder_train_ws_bytes"):
+                 "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes", "uvx_llm_prefill_chunk_ws_bytes", "uvx_encoder_train_ws_bytes",
+                 "uvx_wav2vec2_ws_bytes"):
         getattr(l, name).restype = C.c_size_t
     for name in EXPORTS:
         f = getattr(l, name)

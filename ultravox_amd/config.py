@@ -55,10 +55,49 @@ class AudioConfig:
     num_mel_bins: int = 80
     max_source_positions: int = 1500
     layer_norm_eps: float = 1e-5
+    # model_type "wav2vec2" (BASELINE.json config 5, the AutoModel branch of _create_audio_tower, ultravox_model.py:460-467,
+    # :476-485): d_model / encoder_layers / encoder_attention_heads / encoder_ffn_dim carry Wav2Vec2Config's hidden_size /
+    # num_hidden_layers / num_attention_heads / intermediate_size; the fields below are Wav2Vec2Config's own names.
+    # Built: the wav2vec2-large-960h family (GroupNorm on the first conv layer, bias-free convs, post-LN encoder).
+    conv_dim: Optional[List[int]] = None
+    conv_kernel: Optional[List[int]] = None
+    conv_stride: Optional[List[int]] = None
+    conv_bias: bool = False
+    feat_extract_norm: str = "group"
+    do_stable_layer_norm: bool = False
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+
+    def __post_init__(self):
+        if self.model_type not in ("whisper", "wav2vec2"):
+            raise ValueError(f"audio_config.model_type {self.model_type!r} is not built (whisper, wav2vec2)")
+        if self.is_wav2vec2:
+            self.conv_dim = list(self.conv_dim or (512,) * 7)
+            self.conv_kernel = list(self.conv_kernel or (10, 3, 3, 3, 3, 2, 2))
+            self.conv_stride = list(self.conv_stride or (5, 2, 2, 2, 2, 2, 2))
+            if not (len(self.conv_dim) == len(self.conv_kernel) == len(self.conv_stride)):
+                raise ValueError("audio_config: conv_dim / conv_kernel / conv_stride must have one entry per conv layer")
+            if self.feat_extract_norm != "group" or self.conv_bias or self.do_stable_layer_norm:
+                raise ValueError("audio_config: only the wav2vec2-large-960h family is built (feat_extract_norm='group', "
+                                 "conv_bias=False, do_stable_layer_norm=False); the -lv60 layer-norm variants are not")
+            if len(set(self.conv_dim)) != 1 or self.conv_dim[0] % 64 or self.d_model % self.num_conv_pos_embedding_groups:
+                raise ValueError("audio_config: conv_dim must be one multiple of 64 for all layers; hidden size divisible by the "
+                                 "positional-conv groups")
+
+    @property
+    def is_wav2vec2(self) -> bool:
+        return self.model_type == "wav2vec2"
 
     @property
     def hidden_size(self) -> int:  # WhisperConfig.hidden_size aliases d_model (used at ultravox_model.py:750)
         return self.d_model
+
+    def feat_extract_output_length(self, n_samples: int) -> int:
+        """[3P] Wav2Vec2Model._get_feat_extract_output_lengths: frames the conv stack produces from n_samples."""
+        n = int(n_samples)
+        for k, st in zip(self.conv_kernel, self.conv_stride):
+            n = (n - k) // st + 1
+        return n
 
 
 @dataclasses.dataclass
@@ -100,6 +139,11 @@ class TextConfig:
 
 
 AUDIO_PRESETS: Dict[str, Dict[str, Any]] = {
+    # conv feature encoder 512 x 7, kernels (10,3,3,3,3,2,2), strides (5,2,2,2,2,2,2) = 320x
+    "facebook/wav2vec2-large-960h": dict(model_type="wav2vec2", d_model=1024, encoder_layers=24, encoder_attention_heads=16,
+                                         encoder_ffn_dim=4096, layer_norm_eps=1e-5),
+    "facebook/wav2vec2-base-960h": dict(model_type="wav2vec2", d_model=768, encoder_layers=12, encoder_attention_heads=12,
+                                        encoder_ffn_dim=3072, layer_norm_eps=1e-5),
     "openai/whisper-tiny": dict(d_model=384, encoder_layers=4, encoder_attention_heads=6, encoder_ffn_dim=1536, num_mel_bins=80),
     "openai/whisper-small": dict(d_model=768, encoder_layers=12, encoder_attention_heads=12, encoder_ffn_dim=3072, num_mel_bins=80),
     "openai/whisper-medium": dict(d_model=1024, encoder_layers=24, encoder_attention_heads=16, encoder_ffn_dim=4096, num_mel_bins=80),
@@ -147,15 +191,20 @@ def _mk(cls, value, presets, model_id):
     names = {f.name for f in dataclasses.fields(cls)}
     get = (lambda k: value.get(k)) if isinstance(value, dict) else (lambda k: getattr(value, k, None))   # dict or HF config object
     _check_supported(cls, get)
-    if isinstance(value, dict):
-        return cls(**{k: v for k, v in value.items() if k in names})
-    return cls(**{k: getattr(value, k) for k in names if hasattr(value, k)})
+    kw = ({k: v for k, v in value.items() if k in names} if isinstance(value, dict)
+          else {k: getattr(value, k) for k in names if hasattr(value, k)})
+    if cls is AudioConfig and get("model_type") == "wav2vec2":        # Wav2Vec2Config's names for the transformer dimensions
+        for mine, theirs in (("d_model", "hidden_size"), ("encoder_layers", "num_hidden_layers"),
+                             ("encoder_attention_heads", "num_attention_heads"), ("encoder_ffn_dim", "intermediate_size")):
+            if get(theirs) is not None and mine not in (value if isinstance(value, dict) else ()):
+                kw[mine] = get(theirs)
+    return cls(**kw)
 
 
 def _check_supported(cls, get) -> None:
     """Fields outside the dataclass are dropped by _mk, so anything that would change the arithmetic must be refused here:
     a Qwen2 (q/k/v biases), Mistral (sliding window) or Gemma config would otherwise run silently as a bias-free Llama."""
-    want = ("llama", "gemma") if cls is TextConfig else (cls.__dataclass_fields__["model_type"].default,)
+    want = ("llama", "gemma") if cls is TextConfig else ("whisper", "wav2vec2")
     mt = get("model_type")
     if mt is not None and mt not in want:
         raise ValueError(f"{cls.__name__}: model_type {mt!r} is not built (this path implements {', '.join(want)})")

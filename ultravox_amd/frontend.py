@@ -146,3 +146,44 @@ class WhisperFeatureExtractor:
             fmask = fmask[:, :-1]
         out = {"input_features": feats, "attention_mask": torch.from_numpy(np.ascontiguousarray(fmask))}
         return out
+
+
+class Wav2Vec2FeatureExtractor:
+    """Call contract of the [3P] transformers Wav2Vec2FeatureExtractor (feature_size 1, do_normalize True) for the raw-waveform
+    tower of BASELINE.json config 5: every clip is normalised to zero mean / unit variance over its OWN samples
+    (zero_mean_unit_var_norm: (x - mean) / sqrt(var + 1e-7)), padded with zeros to the longest clip, and returned as
+    `input_values` [B, L] f32 - what ultravox_processing.py:308 falls back to when there is no `input_features`.
+    wav2vec2-large-960h is a feat_extract_norm="group" model: `return_attention_mask` defaults to False there and the model
+    runs without a mask; the sample-count mask is still returned on request because the processor needs the lengths.
+    Host arithmetic (a mean and a variance per clip); no device work."""
+
+    model_input_names = ["input_values", "attention_mask"]
+
+    def __init__(self, sampling_rate: int = 16000, padding_value: float = 0.0, do_normalize: bool = True):
+        self.sampling_rate, self.padding_value, self.do_normalize, self.feature_size = sampling_rate, padding_value, do_normalize, 1
+
+    @property
+    def feature_extractor(self):
+        return self
+
+    def __call__(self, raw_speech, sampling_rate: Optional[int] = None, padding="longest", pad_to_multiple_of: Optional[int] = None,
+                 truncation: bool = False, return_attention_mask: bool = False, return_tensors=None, **kwargs):
+        import torch
+        if sampling_rate is not None and sampling_rate != self.sampling_rate:
+            raise ValueError(f"The model corresponding to this feature extractor was trained using a sampling rate of "
+                             f"{self.sampling_rate}. Please make sure that the provided `raw_speech` input was sampled with "
+                             f"{self.sampling_rate} and not {sampling_rate}.")
+        clips = [np.asarray(x, dtype=np.float32).reshape(-1) for x in (raw_speech if isinstance(raw_speech, (list, tuple)) else [raw_speech])]
+        lens = [len(x) for x in clips]
+        width = max(lens)
+        if pad_to_multiple_of:
+            width = -(-width // pad_to_multiple_of) * pad_to_multiple_of
+        out = np.full((len(clips), width), self.padding_value, dtype=np.float32)
+        for i, x in enumerate(clips):
+            if self.do_normalize:
+                x = (x - x.mean()) / np.sqrt(x.var() + 1e-7)
+            out[i, : len(x)] = x
+        data = {"input_values": torch.from_numpy(out)}
+        if return_attention_mask:
+            data["attention_mask"] = torch.from_numpy((np.arange(width)[None, :] < np.asarray(lens)[:, None]).astype(np.int32))
+        return data

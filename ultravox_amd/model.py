@@ -19,7 +19,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .config import LossConfig, LossFunction, UltravoxConfig
-from .weights import (LORA_TARGETS, init_lora_state_dict, llm_lora_key, lora_key, pack_encoder, pack_llm,
+from .weights import (LORA_TARGETS, init_lora_state_dict, llm_lora_key, lora_key, pack_encoder, pack_llm, pack_wav2vec2,
                       random_state_dict)
 
 
@@ -163,7 +163,13 @@ class UltravoxModel:
         cfg, dev, dt = self.config, self.device, self.dtype
         a, t = cfg.audio_config, cfg.text_config
         self.lora_r = int(cfg.audio_model_lora_config.get("r", 0) or 0)      # encoder LoRA rank (0: frozen tower)
-        self._enc = pack_encoder(sd, cfg, dt, dev, with_transposes=self.lora_r > 0 and self.with_backward)
+        self.is_wav2vec2 = bool(getattr(a, "is_wav2vec2", False))
+        if self.is_wav2vec2:
+            if self.lora_r > 0:
+                raise ValueError("audio_model_lora_config.r > 0 is built for the Whisper tower only (the wav2vec2 tower is frozen)")
+            self._enc = pack_wav2vec2(sd, cfg, dt, dev)
+        else:
+            self._enc = pack_encoder(sd, cfg, dt, dev, with_transposes=self.lora_r > 0 and self.with_backward)
         self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=self.with_backward, rope_len=rope_len,
                              consume=getattr(self, "_consume_sd", False))
         # projector: one flat trainable bucket with views (ln_pre | linear_1 | ln_mid/ln_post | linear_2)
@@ -249,11 +255,26 @@ class UltravoxModel:
         for i, L in enumerate(e["layers"]):
             for n in _lib._ENC_LAYER_FIELDS:
                 setattr(self._enc_layers[i], n, 0 if L.get(n) is None else L[n].data_ptr())
-        ew = _lib.EncoderWeights()
-        for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "pos", "lnf_w", "lnf_b"):
-            setattr(ew, n, e[n].data_ptr())
-        ew.layers = self._enc_layers
-        self._ew = ew
+        if self.is_wav2vec2:
+            wc = _lib.W2vConfig()
+            wc.dtype, wc.n_conv, wc.conv_dim = self.code, len(a.conv_kernel), a.conv_dim[0]
+            for i, (k, st) in enumerate(zip(a.conv_kernel, a.conv_stride)):
+                wc.conv_kernel[i], wc.conv_stride[i] = k, st
+            wc.d, wc.heads, wc.ffn, wc.layers = a.d_model, a.encoder_attention_heads, a.encoder_ffn_dim, a.encoder_layers
+            wc.pos_k, wc.pos_groups, wc.ln_eps = a.num_conv_pos_embeddings, a.num_conv_pos_embedding_groups, a.layer_norm_eps
+            ww = _lib.W2vWeights()
+            for n in ("conv0_w", "gn_w", "gn_b", "fp_ln_w", "fp_ln_b", "fp_w", "fp_b", "pos_w", "pos_b", "ln_w", "ln_b"):
+                setattr(ww, n, e[n].data_ptr())
+            for i, t_ in enumerate(e["conv_w"]):
+                ww.conv_w[i] = 0 if t_ is None else t_.data_ptr()
+            ww.layers = self._enc_layers
+            self._w2v_cfg, self._w2v_w, self._ew = wc, ww, None
+        else:
+            ew = _lib.EncoderWeights()
+            for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "pos", "lnf_w", "lnf_b"):
+                setattr(ew, n, e[n].data_ptr())
+            ew.layers = self._enc_layers
+            self._ew = ew
 
         pw = _lib.ProjectorWeights()
         pw.ln_pre = self._proj_views["ln_pre"].data_ptr()
@@ -435,6 +456,8 @@ class UltravoxModel:
     def audio_tower_forward(self, audio_values: torch.Tensor, audio_len: Optional[torch.Tensor]) -> torch.Tensor:
         """ModifiedWhisperEncoder.forward(input_features, audio_len) -> last_hidden_state [A, Te, d]."""
         l = _lib.lib()
+        if self.is_wav2vec2:
+            return self._wav2vec2_forward(audio_values)
         A, n_mels, F = audio_values.shape
         if F > self.audio_tower_context_length:
             raise ValueError(
@@ -461,6 +484,27 @@ class UltravoxModel:
         ws = self._workspace("enc", nb)
         check(l.uvx_encoder_fwd(stream_ptr(), C.byref(self._c), C.byref(self._ew), ptr(audio_values), int(is_f32),
                                 ptr(lens), A, F, ptr(out), ptr(ws), C.c_size_t(nb)), "uvx_encoder_fwd")
+        return out
+
+    def _wav2vec2_forward(self, input_values: torch.Tensor) -> torch.Tensor:
+        """AutoModel branch of the audio tower (ultravox_model.py:460-467, :476-485): Wav2Vec2Model(input_values).last_hidden_state,
+        input_values [A, L] = the normalised waveform (the `input_values` fallback, ultravox_processing.py:308); no mask."""
+        l = _lib.lib()
+        if input_values.dim() != 2:
+            raise ValueError(f"the wav2vec2 tower takes input_values [n_audio, n_samples], got shape {tuple(input_values.shape)}")
+        A, L = input_values.shape
+        is_f32 = input_values.dtype == torch.float32
+        if not is_f32 and input_values.dtype != self.dtype:
+            input_values = input_values.to(self.dtype)
+        input_values = input_values.contiguous()
+        Tn = l.uvx_wav2vec2_frames(C.byref(self._w2v_cfg), L)
+        if Tn <= 0:
+            raise ValueError(f"{L} samples are shorter than the wav2vec2 feature encoder's receptive field")
+        out = torch.empty((A, Tn, self.config.audio_config.d_model), device=self.device, dtype=self.dtype)
+        nb = l.uvx_wav2vec2_ws_bytes(C.byref(self._w2v_cfg), A, L)
+        ws = self._workspace("enc", nb)
+        check(l.uvx_wav2vec2_fwd(stream_ptr(), C.byref(self._w2v_cfg), C.byref(self._w2v_w), ptr(input_values), int(is_f32), A, L,
+                                 ptr(out), ptr(ws), C.c_size_t(nb)), "uvx_wav2vec2_fwd")
         return out
 
     def multi_modal_projector_forward(self, audio_features: torch.Tensor) -> torch.Tensor:

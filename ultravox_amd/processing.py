@@ -54,7 +54,10 @@ class UltravoxProcessor:
 
     def __init__(self, audio_processor=None, tokenizer=None, audio_padding: str = "longest",
                  encoder_ds_factor: int = 2, stack_factor: int = 8, audio_placeholder: str = AUDIO_PLACEHOLDER,
-                 audio_context_size: Optional[int] = 3000):
+                 audio_context_size: Optional[int] = 3000, audio_frames_fn=None):
+        """audio_frames_fn (not in the reference): samples -> encoder frames for a RAW-WAVEFORM tower (wav2vec2, BASELINE
+        config 5), e.g. `config.audio_config.feat_extract_output_length`; default = wav2vec2's conv stack."""
+        self.audio_frames_fn = audio_frames_fn or _wav2vec2_frames
         self.audio_padding = audio_padding
         self.encoder_ds_factor = encoder_ds_factor
         self.stack_factor = stack_factor
@@ -119,6 +122,25 @@ class UltravoxProcessor:
         is_cont: Sequence[bool] = []
         if len(audios) > 0:
             audios = [x.numpy() if isinstance(x, torch.Tensor) else x for x in audios]
+        if len(audios) > 0 and getattr(self.audio_processor.feature_extractor, "hop_length", None) is None:
+            # Raw-waveform tower (the `input_values` fallback of :308).  The reference cannot run this branch - it reads
+            # feature_extractor.hop_length unconditionally (:284) and chunks [B, mels, F] features - so the contract is the
+            # third-party module's: one un-chunked item per audio, audio_lens = ENCODER frames, audio_token_len =
+            # ceil(frames / stack_factor) = the rows the projector produces for it.
+            feats = self.audio_processor(audios, sampling_rate=sampling_rate, padding="longest", truncation=False,
+                                         return_attention_mask=True, **kwargs)
+            n_samples = torch.as_tensor(feats["attention_mask"]).sum(-1).tolist()
+            frames = torch.tensor([self.audio_frames_fn(int(n)) for n in n_samples], dtype=torch.int64)
+            if int(frames.min()) <= 0:
+                raise ValueError("an audio clip is shorter than the encoder's receptive field")
+            data["audio_values"] = torch.as_tensor(feats["input_values"])
+            data["audio_lens"] = frames
+            data["audio_batch_size"] = torch.tensor([len(audios)])
+            if include_audio_num_chunks:
+                data["audio_num_chunks"] = torch.ones(len(audios), dtype=torch.int64)
+            is_cont = [False] * len(audios)
+            data["audio_token_len"] = torch.ceil(frames / self.stack_factor).to(dtype=torch.int)
+        elif len(audios) > 0:
             hop = self.audio_processor.feature_extractor.hop_length
             # at least two hops of samples, the feature extractor's minimum (:283-292)
             audios = [np.pad(x, (0, 2 * hop - len(x)), mode="constant") if len(x) < 2 * hop else x for x in audios]
@@ -169,6 +191,14 @@ class UltravoxProcessor:
     @property
     def model_input_names(self):
         return list(set(self.tokenizer.model_input_names + self.audio_processor.model_input_names))
+
+
+def _wav2vec2_frames(n_samples: int) -> int:
+    """[3P] Wav2Vec2Model._get_feat_extract_output_lengths for the standard conv stack (kernels 10,3,3,3,3,2,2; strides 5,2,...)."""
+    n = int(n_samples)
+    for k, st in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
+        n = (n - k) // st + 1
+    return n
 
 
 def _pad_1d(seqs: List[Any], value: int, side: str) -> torch.Tensor:

@@ -18,6 +18,9 @@ def synthetic_batch(cfg, B: int, seconds: float, n_text: int = 128, audio_start:
     pcm = (0.1 * torch.randn(B, L, generator=g)).clamp_(-1, 1)
     frames = L // HOP
     n_audio = -(-frames // (2 * cfg.stack_factor))  # ceil(frames / (encoder_ds_factor * stack_factor))
+    if getattr(cfg.audio_config, "is_wav2vec2", False):     # raw-waveform tower: audio_lens = encoder frames, no 2x factor
+        frames = cfg.audio_config.feat_extract_output_length(L)
+        n_audio = -(-frames // cfg.stack_factor)
     g2 = torch.Generator().manual_seed(4321 + rank)
     V = cfg.text_config.vocab_size
     text = torch.randint(0, V - 1, (B, n_text), generator=g2)

@@ -42,6 +42,52 @@ def random_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32, d
 
     d = a.d_model
     P = "audio_tower."
+    if getattr(a, "is_wav2vec2", False):
+        _random_wav2vec2(sd, a, rn, near_one, P)
+    else:
+        _random_whisper(sd, a, rn, near_one, P, device, dtype)
+    _random_rest(sd, cfg, rn, near_one, device, dtype)
+    return sd
+
+
+def _random_wav2vec2(sd, a, rn, near_one, P):
+    """HF Wav2Vec2Model key names (wav2vec2-large-960h family: GroupNorm after the first conv, bias-free convs, post-LN)."""
+    d, Cc = a.d_model, a.conv_dim[0]
+    cin = 1
+    for i, k in enumerate(a.conv_kernel):
+        sd[P + f"feature_extractor.conv_layers.{i}.conv.weight"] = rn(Cc, cin, k, s=1.6 / math.sqrt(cin * k))
+        cin = Cc
+    sd[P + "feature_extractor.conv_layers.0.layer_norm.weight"] = near_one(Cc)
+    sd[P + "feature_extractor.conv_layers.0.layer_norm.bias"] = rn(Cc)
+    sd[P + "feature_projection.layer_norm.weight"] = near_one(Cc)
+    sd[P + "feature_projection.layer_norm.bias"] = rn(Cc)
+    sd[P + "feature_projection.projection.weight"] = rn(d, Cc, s=1.0 / math.sqrt(Cc))
+    sd[P + "feature_projection.projection.bias"] = rn(d)
+    K, G = a.num_conv_pos_embeddings, a.num_conv_pos_embedding_groups
+    sd[P + "encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = rn(d, d // G, K, s=1.0 / math.sqrt(K * d // G))
+    sd[P + "encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = (
+        sd[P + "encoder.pos_conv_embed.conv.parametrizations.weight.original1"].float().norm(dim=(0, 1), keepdim=True) * 1.1).to(
+        sd[P + "encoder.pos_conv_embed.conv.parametrizations.weight.original1"].dtype)
+    sd[P + "encoder.pos_conv_embed.conv.bias"] = rn(d)
+    sd[P + "encoder.layer_norm.weight"] = near_one(d)
+    sd[P + "encoder.layer_norm.bias"] = rn(d)
+    for i in range(a.encoder_layers):
+        L = f"{P}encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[L + f"attention.{nm}.weight"] = rn(d, d, s=1.0 / math.sqrt(d))
+            sd[L + f"attention.{nm}.bias"] = rn(d)
+        sd[L + "layer_norm.weight"] = near_one(d)
+        sd[L + "layer_norm.bias"] = rn(d)
+        sd[L + "feed_forward.intermediate_dense.weight"] = rn(a.encoder_ffn_dim, d, s=1.0 / math.sqrt(d))
+        sd[L + "feed_forward.intermediate_dense.bias"] = rn(a.encoder_ffn_dim)
+        sd[L + "feed_forward.output_dense.weight"] = rn(d, a.encoder_ffn_dim, s=1.0 / math.sqrt(a.encoder_ffn_dim))
+        sd[L + "feed_forward.output_dense.bias"] = rn(d)
+        sd[L + "final_layer_norm.weight"] = near_one(d)
+        sd[L + "final_layer_norm.bias"] = rn(d)
+
+
+def _random_whisper(sd, a, rn, near_one, P, device, dtype):
+    d = a.d_model
     sd[P + "conv1.weight"] = rn(d, a.num_mel_bins, 3, s=1.0 / math.sqrt(3 * a.num_mel_bins))
     sd[P + "conv1.bias"] = rn(d)
     sd[P + "conv2.weight"] = rn(d, d, 3, s=1.0 / math.sqrt(3 * d))
@@ -64,6 +110,10 @@ def random_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32, d
     sd[P + "layer_norm.weight"] = near_one(d)
     sd[P + "layer_norm.bias"] = rn(d)
 
+
+def _random_rest(sd, cfg, rn, near_one, device, dtype):
+    a, t = cfg.audio_config, cfg.text_config
+    d = a.d_model
     # projector (ultravox_model.py:745-766): RMSNorm weights start at norm_init (0.4)
     P = "multi_modal_projector."
     dim_in, H, D = d * cfg.stack_factor, cfg.hidden_size, t.hidden_size
@@ -161,6 +211,53 @@ def init_lora_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32
     for i in range(t.num_hidden_layers if rt else 0):
         add(llm_lora_key, i, "q_proj", rt, t.hidden_size, t.num_attention_heads * t.head_dim)
         add(llm_lora_key, i, "k_proj", rt, t.hidden_size, t.num_key_value_heads * t.head_dim)
+    return out
+
+
+def pack_wav2vec2(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.") -> Dict[str, object]:
+    """HF Wav2Vec2Model weights -> the operands of csrc/wav2vec2.hip (layouts: include/uvx.h, uvx_w2v_weights_t)."""
+    a = cfg.audio_config
+    d, H, Cc = a.d_model, a.encoder_attention_heads, a.conv_dim[0]
+    scale = (d // H) ** -0.5
+    cv = lambda x: x.to(device=device, dtype=dtype).contiguous()
+    W = lambda k: sd[prefix + k]
+    w0 = W("feature_extractor.conv_layers.0.conv.weight")                       # [C, 1, k0]
+    conv0 = torch.zeros(Cc, 64, dtype=w0.dtype, device=w0.device)
+    conv0[:, : w0.shape[-1]] = w0[:, 0, :]
+    out = {"conv0_w": cv(conv0), "gn_w": cv(W("feature_extractor.conv_layers.0.layer_norm.weight")),
+           "gn_b": cv(W("feature_extractor.conv_layers.0.layer_norm.bias")), "conv_w": [None]}
+    for i in range(1, len(a.conv_kernel)):
+        w = W(f"feature_extractor.conv_layers.{i}.conv.weight")                  # [C, C, k] -> [C, k*C], column k*C + c
+        out["conv_w"].append(cv(w.permute(0, 2, 1).reshape(Cc, -1)))
+    out["fp_ln_w"], out["fp_ln_b"] = cv(W("feature_projection.layer_norm.weight")), cv(W("feature_projection.layer_norm.bias"))
+    out["fp_w"], out["fp_b"] = cv(W("feature_projection.projection.weight")), cv(W("feature_projection.projection.bias"))
+    # positional conv: weight norm (dim = 2) folded in the SOURCE dtype, as torch's parametrization evaluates it
+    P = prefix + "encoder.pos_conv_embed.conv."
+    if P + "parametrizations.weight.original0" in sd:
+        g, v = sd[P + "parametrizations.weight.original0"], sd[P + "parametrizations.weight.original1"]
+    elif P + "weight_g" in sd:
+        g, v = sd[P + "weight_g"], sd[P + "weight_v"]
+    else:
+        g, v = None, sd[P + "weight"]
+    wpos = v if g is None else v * (g / v.float().norm(dim=(0, 1), keepdim=True).to(v.dtype))      # [d, d/G, K]
+    G, K = a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
+    dg = d // G
+    out["pos_w"] = cv(wpos.to(dtype).view(G, dg, dg, K).permute(0, 1, 3, 2).reshape(G, dg, K * dg))   # [g][o][k*dg + c]
+    out["pos_b"] = cv(sd[P + "bias"])
+    out["ln_w"], out["ln_b"] = cv(W("encoder.layer_norm.weight")), cv(W("encoder.layer_norm.bias"))
+    out["layers"] = []
+    for i in range(a.encoder_layers):
+        L = f"encoder.layers.{i}."
+        wqkv = torch.cat([W(L + "attention.q_proj.weight") * scale, W(L + "attention.k_proj.weight"), W(L + "attention.v_proj.weight")], 0)
+        bqkv = torch.cat([W(L + "attention.q_proj.bias") * scale, W(L + "attention.k_proj.bias"), W(L + "attention.v_proj.bias")], 0)
+        out["layers"].append({
+            "ln1_w": cv(W(L + "layer_norm.weight")), "ln1_b": cv(W(L + "layer_norm.bias")),
+            "wqkv": cv(wqkv), "bqkv": cv(bqkv),
+            "wo": cv(W(L + "attention.out_proj.weight")), "bo": cv(W(L + "attention.out_proj.bias")),
+            "ln2_w": cv(W(L + "final_layer_norm.weight")), "ln2_b": cv(W(L + "final_layer_norm.bias")),
+            "fc1_w": cv(W(L + "feed_forward.intermediate_dense.weight")), "fc1_b": cv(W(L + "feed_forward.intermediate_dense.bias")),
+            "fc2_w": cv(W(L + "feed_forward.output_dense.weight")), "fc2_b": cv(W(L + "feed_forward.output_dense.bias")),
+        })
     return out
 
 
