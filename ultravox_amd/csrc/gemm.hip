@@ -29,8 +29,8 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // (-0.5 ms/step at C2), 2 = row-contiguous through LDS (default), [2] SwiGLU backward fused into the
 // dgrad GEMM (off: measured neutral at C2 - the separate elementwise kernel runs at 6.7 TB/s, the fused epilogue is
 // serialised behind each tile's main loop), [3] loss head on the supervised rows only (on), [4] weight-streaming kernel for
-// M <= 16 (on)
-int g_options[8] = {0, 2, 0, 1, 1, 0, 0, 0};
+// M <= 16 (on), [5] residual rows of a wave tile fetched up front in the GEMM epilogue (on)
+int g_options[8] = {0, 2, 0, 1, 1, 1, 0, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -52,6 +52,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   bf16_t* C2;      // swiglu mode: activation output [M, N/2]
   int ldc2;
+  int res_prefetch;  // fetch the residual rows of the wave tile up front (option 5; 0 = in-loop loads, for A/B runs)
   int swiglu;      // 1: columns alternate 16-wide gate / up blocks; also write silu(gate) * up to C2
   int wide_io;     // 16-byte epilogue loads / stores (probe switch; on by default)
   const int32_t* m_dev;  // device-side row count (nullptr: M is exact)
@@ -131,6 +132,22 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
         for (int e = 0; e < 4; ++e) bv[j][e] = bf2f(b4[e]);
       }
     }
+    // Residual rows of the whole wave tile are fetched UP FRONT, unconditionally (row / column clamped, out-of-range results
+    // are never stored): issued before the accumulators go through LDS, their L2 / HBM latency (~0.4 us each, 2 * MI of them
+    // per lane) overlaps the staging pass instead of being paid load -> wait -> add -> store, one row group after the other
+    // (conditional loads cannot be batched by the compiler).  The accumulators' registers are free by the time these are
+    // consumed.  Single-pass tiles only (GI == MI); the 16-row passes of the persistent probes keep the in-loop load.
+    constexpr bool PREFETCH_RES = GI == MI;
+    uint4 rres[PREFETCH_RES ? (GI * 16) / 8 : 1];
+    if (PREFETCH_RES && p.residual && p.res_prefetch) {
+      const int c8 = lane & 7, n8c = min(n_base + c8 * 8, p.N - 8);
+#pragma unroll
+      for (int it = 0; it < (GI * 16) / 8; ++it) {
+        const int m = min(m_base + it * 8 + (lane >> 3), p.M - 1);
+        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+        rres[it] = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8c);
+      }
+    }
 #pragma unroll
     for (int i0 = 0; i0 < MI; i0 += GI) {
       if (i0 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads are done (WAR on the slice)
@@ -160,7 +177,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
           if (m < p.M && n8 < p.N) {
             if (p.residual) {
               const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
-              const uint4 r = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
+              const uint4 r = (PREFETCH_RES && p.res_prefetch) ? rres[it] : *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
               o.x = pack2(unpack_lo(o.x) + unpack_lo(r.x), unpack_hi(o.x) + unpack_hi(r.x));
               o.y = pack2(unpack_lo(o.y) + unpack_lo(r.y), unpack_hi(o.y) + unpack_hi(r.y));
               o.z = pack2(unpack_lo(o.z) + unpack_lo(r.z), unpack_hi(o.z) + unpack_hi(r.z));
@@ -1010,6 +1027,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.act = d.act; a.out_f32 = d.out_f32; a.accumulate = d.accumulate; a.alpha = d.alpha;
   a.C2 = (bf16_t*)d.C2; a.ldc2 = d.ldc2; a.swiglu = d.swiglu;
   a.wide_io = uvx::g_options[1];
+  a.res_prefetch = uvx::g_options[5];
   a.m_dev = d.m_dev; a.m_dev_off = d.m_dev_off;
   UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
