@@ -573,8 +573,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 // drops 47.5 -> 39.6 us, +0.5...1.5 % on the multi-round shapes - far less than the 33 us a free epilogue would give
 // (MODE 3 probe): all CUs finish a round together, so the 30-50 MB of output per round is one HBM-write burst that
 // throttles store ISSUE on every CU at once, overlapped or not.  Kept as probe variants (23..26), not selected."
-template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false>
+// PH = phases per K-tile.  4: the schedule above.  2 ("four-phase" kernel, round 2): phases 1+2 and 3+4 merged - [read XA, WA,
+// WB | 32 MFMAs: XA x WA, XA x WB] and [read XB | 32 MFMAs: XB x WB, XB x WA].  Why: with 16 MFMAs per section (256 cycles) the
+// LOAD section of the other wave row is the longer one (phase 1 reads 12 fragments per wave = 48 KB per row through a
+// 256 B/clk LDS, plus 2 LDS-DMA issues, plus the barrier hand-off: ~380 cycles), so the matrix pipe waits for loads and the
+// K-tile costs ~3000 cycles against the 2048 of its 128 MFMAs per SIMD (profiles/r02_gemm_timeline.txt: 8 hand-offs per
+// K-tile at ~60 cycles, phase-1 excess, MFMA sections at 280).  With 32 MFMAs per section (512 cycles) every load section
+// (<= 16 fragment reads + <= 6 DMA issues) hides under the other row's MFMAs and there are 4 hand-offs per K-tile.
+// DMA schedule (NS = 2): XB(t+1) is issued in the first load section of tile t, [XA | WA | WB](t+2) in the second;
+// each load section ends with ONE counted wait that leaves exactly one XB piece set and one REST piece set in flight, i.e.
+// retires what was issued a whole K-tile earlier (XB(t) before the section that reads it next; REST(t+1) before tile t+1).
+// RAW / WAR: same rules as above - a region is read one section after the wait + barrier that retired it, and restaged
+// no earlier than two sections after its last read by EITHER row (XB(t-1)'s set: read in the second load section of tile
+// t-1, restaged in the first of tile t; [XA | WA | WB](t): read in the first load section of tile t, restaged in the second).
+template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false, int PH = 4>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
+  static_assert(PH == 4 || (PH == 2 && NS == 2 && MODE == 0 && !PERSIST), "the merged-phase schedule is written for two buffer sets");
   constexpr int BNW = 256;
   constexpr int MI = BM / 32, MA = (MI + 1) / 2, MB = MI - MA;
   constexpr int XA_ROWS = 2 * MA * 16, XB_ROWS = 2 * MB * 16;
@@ -740,6 +754,67 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     const char* set = lds + cs * SET;
     const int ps = cs == 0 ? NS - 1 : cs - 1;   // (t + NS - 1) % NS
     bf16x8_t xa[MA][2], wa[2][2], wb[2][2];
+    if (PH == 2) {
+      // ---- section A: read XA, WA, WB; DMA: XB of tile t+1; wait: XB(t) (issued one K-tile ago) ----
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          wa[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + O_WA + wo[kh] + j * 16 * 128);
+          wb[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + O_WB + wo[kh] + j * 16 * 128);
+        }
+#pragma unroll
+      for (int i = 0; i < MA; ++i)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xa_base + xo[kh] + i * 16 * 128);
+      if (t + 1 < nk) {
+#pragma unroll
+        for (int k = 0; k < N1; ++k) dma(sxb[k], t + 1, ps);
+        UVX_VMCNT(N234 + N1);
+      } else {
+        UVX_VMCNT(0);
+      }
+      UVX_PHASE_SYNC();
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < MA; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][i], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < MA; ++i) acc[2 + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][i], 0, 0, 0);
+      }
+      UVX_PHASE_END();
+      // ---- section B: read XB (WA, WB stay in registers); DMA: [XA | WA | WB] of tile t+2; wait: REST(t+1) ----
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xb_base + xo[kh] + i * 16 * 128);
+      if (t + 2 < nk) {
+#pragma unroll
+        for (int k = 0; k < N234; ++k) dma(srest[k], t + 2, cs);
+        UVX_VMCNT(N234 + N1);
+      } else {
+        UVX_VMCNT(0);
+      }
+      UVX_PHASE_SYNC();
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < MB; ++i) acc[2 + j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][kh], xa[i][kh], acc[2 + j][MA + i], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < MB; ++i) acc[j][MA + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][kh], xa[i][kh], acc[j][MA + i], 0, 0, 0);
+      }
+      UVX_PHASE_END();
+      cs = cs == NS - 1 ? 0 : cs + 1;
+      continue;
+    }
     // ---- phase 1: XA x WA; DMA: XB of tile t+1 ----
     UVX_TL_FLUSH(t - 1, 3);
     UVX_TL_TAKE(0);
@@ -908,7 +983,7 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 31;
+constexpr int kNumVariants = 35;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
@@ -917,11 +992,12 @@ const Variant kVariants[kNumVariants] = {
     {160, 256, 1245., 9.},  {128, 256, 0., 6.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   {256, 256, 0., 9.},   // 20..22 = probe modes of 11
     {256, 256, 0., 4.},     {192, 256, 0., 6.},     {160, 256, 0., 5.},     {128, 256, 0., 4.},
     {256, 256, 0., 9.},    // 27 = timeline probe of 11 (MODE 4)
-    {256, 256, 0., 9.},     {256, 256, 0., 9.},     {256, 256, 0., 9.}};   // 28..30 = issue-priority probes of 11 (MODE 5..7: none / load section / MFMA section at priority 1)
+    {256, 256, 0., 9.},     {256, 256, 0., 9.},     {256, 256, 0., 9.},    // 28..30 = issue-priority probes of 11 (MODE 5..7: none / load section / MFMA section at priority 1)
+    {256, 256, 0., 8.5},    {192, 256, 0., 12.},    {160, 256, 0., 9.},     {128, 256, 0., 6.}};   // 31..34 = merged-phase (PH = 2) {256,192,160,128} x 256
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
-constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19); }
+constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34); }
 bool variant_available(int v) {
 #ifdef UVX_PROBES
   return v >= 0 && v < kNumVariants;
@@ -969,6 +1045,10 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 17: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<128>, grid, dim3(512), 0, st, a); break;
     case 18: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 3>), grid, dim3(512), 0, st, a); break;
     case 19: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 3>), grid, dim3(512), 0, st, a); break;
+    case 31: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2>), grid, dim3(512), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2>), grid, dim3(512), 0, st, a); break;
+    case 33: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2>), grid, dim3(512), 0, st, a); break;
+    case 34: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2>), grid, dim3(512), 0, st, a); break;
 #ifdef UVX_PROBES
     case 1: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<128>, grid, dim3(512), 0, st, a); break;
     case 2: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<160>, grid, dim3(512), 0, st, a); break;
