@@ -29,8 +29,9 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // (-0.5 ms/step at C2), 2 = row-contiguous through LDS (default), [2] SwiGLU backward fused into the
 // dgrad GEMM (off: measured neutral at C2 - the separate elementwise kernel runs at 6.7 TB/s, the fused epilogue is
 // serialised behind each tile's main loop), [3] loss head on the supervised rows only (on), [4] weight-streaming kernel for
-// M <= 16 (on), [5] residual rows of a wave tile fetched up front in the GEMM epilogue (on)
-int g_options[8] = {0, 2, 0, 1, 1, 1, 0, 0};
+// M <= 16 (on), [5] residual rows of a wave tile fetched up front in the GEMM epilogue (off: same-box A/B at C2, round 2:
+// 98.2 / 98.6 ms per step with it, 97.5 / 97.6 without - the 2 * MI extra live uint4 per lane cost more than the hidden latency)
+int g_options[8] = {0, 2, 0, 1, 1, 0, 0, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -132,11 +133,8 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
         for (int e = 0; e < 4; ++e) bv[j][e] = bf2f(b4[e]);
       }
     }
-    // Residual rows of the whole wave tile are fetched UP FRONT, unconditionally (row / column clamped, out-of-range results
-    // are never stored): issued before the accumulators go through LDS, their L2 / HBM latency (~0.4 us each, 2 * MI of them
-    // per lane) overlaps the staging pass instead of being paid load -> wait -> add -> store, one row group after the other
-    // (conditional loads cannot be batched by the compiler).  The accumulators' registers are free by the time these are
-    // consumed.  Single-pass tiles only (GI == MI); the 16-row passes of the persistent probes keep the in-loop load.
+    // Probe (option 5, default off): residual rows of the whole wave tile fetched up front, unconditionally (row / column
+    // clamped), so that their latency overlaps the staging pass.  Measured slower in situ (see g_options) - kept switchable.
     constexpr bool PREFETCH_RES = GI == MI;
     uint4 rres[PREFETCH_RES ? (GI * 16) / 8 : 1];
     if (PREFETCH_RES && p.residual && p.res_prefetch) {
