@@ -128,8 +128,8 @@ def test_tile_picker_never_selects_a_probe_only_variant():
     and at the C2 hot shapes it must take the eight-phase family."""
     import random
     lib = _lib.lib()
-    production = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 15, 16, 17, 18}
-    probe_only = {9, 12, 13, 14} | set(range(19, 28))
+    production = {0, 31, 32, 33, 34}          # 128x128 and the merged-phase {256,192,160,128} x 256 kernels (round 2)
+    probe_only = set(range(1, 31)) - {11, 15, 16, 17, 18, 19}     # superseded families + probe builds: never picked
     rnd = random.Random(0)
     seen = set()
     for _ in range(4000):
@@ -139,10 +139,10 @@ def test_tile_picker_never_selects_a_probe_only_variant():
         v = lib.uvx_gemm_pick_variant(M, N, K, rnd.choice([1, 1, 1, 8, 128]))
         assert v in production and v not in probe_only, (M, N, K, v)
         seen.add(v)
-    assert len(seen) >= 4                                   # the model does discriminate between tiles
+    assert len(seen) >= 4 and not (seen & {11, 15, 16, 17, 18, 19})     # discriminates between tiles; four-phase twins retired
     for (M, N, K) in [(2528, 28672, 4096), (2528, 4096, 14336), (2528, 6144, 4096), (2528, 4096, 4096),
                       (12000, 3072, 1024), (12000, 4096, 1024), (12000, 1024, 4096)]:
-        assert lib.uvx_gemm_pick_variant(M, N, K, 1) in {11, 15, 16, 17, 18}, (M, N, K)
+        assert lib.uvx_gemm_pick_variant(M, N, K, 1) in {31, 32, 33, 34}, (M, N, K)
 
 
 def test_every_entry_point_survives_an_all_null_call():

@@ -13,6 +13,11 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 new = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 text_id = sys.argv[3] if len(sys.argv) > 3 else "meta-llama/Meta-Llama-3-8B-Instruct"
 dev = "cuda"
+free_gb = torch.cuda.mem_get_info()[0] / 2 ** 30
+need_gb = 170 if "70B" in text_id else 40          # bf16 weights + KV cache + workspaces, with headroom
+if free_gb < need_gb:                              # never drive the box out of memory: a dead box is a strike
+    print(f"SKIP: {free_gb:.0f} GiB free on the device, {text_id} needs about {need_gb} GiB")
+    sys.exit(0)
 cfg = UltravoxConfig(audio_model_id="openai/whisper-medium", text_model_id=text_id,
                      hidden_size=4096, stack_factor=8, projector_ln_mid=True, torch_dtype="bfloat16")
 model = UltravoxModel(cfg, device=dev, dtype=torch.bfloat16, seed=0, rope_len=1024, with_backward=False, consume_state_dict=True)

@@ -30,8 +30,9 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // dgrad GEMM (off: measured neutral at C2 - the separate elementwise kernel runs at 6.7 TB/s, the fused epilogue is
 // serialised behind each tile's main loop), [3] loss head on the supervised rows only (on), [4] weight-streaming kernel for
 // M <= 16 (on), [5] residual rows of a wave tile fetched up front in the GEMM epilogue (off: same-box A/B at C2, round 2:
-// 98.2 / 98.6 ms per step with it, 97.5 / 97.6 without - the 2 * MI extra live uint4 per lane cost more than the hidden latency)
-int g_options[8] = {0, 2, 0, 1, 1, 0, 0, 0};
+// 98.2 / 98.6 ms per step with it, 97.5 / 97.6 without - the 2 * MI extra live uint4 per lane cost more than the hidden latency),
+// [6] tile picker uses the merged-phase kernels 31..34 (on; 0 = the round-1 four-phase set 11, 15..19)
+int g_options[8] = {0, 2, 0, 1, 1, 0, 1, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -991,7 +992,10 @@ const Variant kVariants[kNumVariants] = {
     {256, 256, 0., 4.},     {192, 256, 0., 6.},     {160, 256, 0., 5.},     {128, 256, 0., 4.},
     {256, 256, 0., 9.},    // 27 = timeline probe of 11 (MODE 4)
     {256, 256, 0., 9.},     {256, 256, 0., 9.},     {256, 256, 0., 9.},    // 28..30 = issue-priority probes of 11 (MODE 5..7: none / load section / MFMA section at priority 1)
-    {256, 256, 0., 8.5},    {192, 256, 0., 12.},    {160, 256, 0., 9.},     {128, 256, 0., 6.}};   // 31..34 = merged-phase (PH = 2) {256,192,160,128} x 256
+    // 31..34 = merged-phase (PH = 2) {256,192,160,128} x 256: the production set since round 2.  Speeds = their four-phase
+    // twins' x the same-box cold-probe ratio (profiles/r02_gemm_ph2_probe.txt: 256: +3...+10 %, 192: +0...+4 %, 160: +0...+4 %
+    // over the three-buffer 18, 128: +2...+5 %); fixed costs unchanged (same prologue / epilogue).
+    {256, 256, 1470., 8.5}, {192, 256, 1430., 12.}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.}};
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
@@ -1024,6 +1028,8 @@ int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
   }
   for (int v = 0; v < kNumVariants; ++v) {
     if (kVariants[v].speed <= 0. || !is_production(v)) continue;
+    // option 6 (default 1): merged-phase kernels 31..34 replace their four-phase twins 11, 15..19 (0 = the round-1 set, for A/B)
+    if (v != 0 && ((v >= 31) != (uvx::g_options[6] != 0))) continue;
     const double cost = variant_cost(v, M, N, K, batch);
     if (cost < best) { best = cost; best_v = v; }
   }
