@@ -994,8 +994,9 @@ const Variant kVariants[kNumVariants] = {
     {256, 256, 0., 9.},     {256, 256, 0., 9.},     {256, 256, 0., 9.},    // 28..30 = issue-priority probes of 11 (MODE 5..7: none / load section / MFMA section at priority 1)
     // 31..34 = merged-phase (PH = 2) {256,192,160,128} x 256: the production set since round 2.  Speeds = their four-phase
     // twins' x the same-box cold-probe ratio (profiles/r02_gemm_ph2_probe.txt: 256: +3...+10 %, 192: +0...+4 %, 160: +0...+4 %
-    // over the three-buffer 18, 128: +2...+5 %); fixed costs unchanged (same prologue / epilogue).
-    {256, 256, 1470., 8.5}, {192, 256, 1430., 12.}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.}};
+    // over the three-buffer 18, 128: +2...+5 %); fixed costs as the twins' except 192 (10.5 instead of 12: the in-situ table of the
+    // first merged-phase run had 12000 x 3072 x 1024 on the 256 tile at 108 us where the 192 tile takes 87).
+    {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.}};
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
