@@ -1,9 +1,10 @@
 #!/bin/bash
-# rocprofv3 PMC passes on the PRODUCTION eight-phase GEMM (tile variant 11, static issue priority) and its round-1 form
-# (variant 30: MFMA section at s_setprio 1), shape 2528 x 28672 x 4096 (gate|up projection, C2).  Separate passes: the SQ block
+# rocprofv3 PMC passes on the PRODUCTION GEMM (tile variant 31: merged-phase 256x256, static issue priority) and the kernel it
+# replaced (variant 11: four phases per K-tile; VARS="11 30" PYVARS="11, 30" compares the issue-priority policies instead),
+# shape 2528 x 28672 x 4096 (gate|up projection, C2).  Separate passes: the SQ block
 # has 8 slots.  Counters only with --kernel-trace (no other trace domains).  Summary -> gpurun_out/pmc_prod/summary.txt
 R=$PWD; OUT=$R/gpurun_out/pmc_prod; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R
-for V in 11 30; do
+for V in ${VARS:-31 11}; do
   timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $OUT/sq_v$V -o p --output-format csv -- python $R/tools/gpu_gemm_pmc.py $V 2528 28672 4096 > $OUT/sq_v$V.log 2>&1
   timeout 120 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/lds_v$V -o p --output-format csv -- python $R/tools/gpu_gemm_pmc.py $V 2528 28672 4096 > $OUT/lds_v$V.log 2>&1
 done
@@ -11,10 +12,10 @@ python - <<PY > $OUT/summary.txt
 import csv, collections, glob, os
 out = "$OUT"
 print("# rocprofv3 --pmc on gemm_nt_bf16_ph8_kernel<256,2,*> at 2528 x 28672 x 4096 bf16 (1120 tiles of 256x256, 64 K-tiles), 4 launches averaged")
-print("# v11 = production (static issue priority, MODE 0); v30 = round-1 form (MFMA section at s_setprio 1, MODE 7)")
+print("# v31 = production (merged-phase: 2 sections of 32 MFMAs per K-tile); v11 = four-phase kernel (static issue priority); v30 = v11 with the round-1 priority policy")
 print("# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over all waves; SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES in cycles;")
 print("# GRBM_GUI_ACTIVE summed over the 8 XCDs (per XCD / kernel duration = shader clock, here 1.9 GHz).  MFMA pipe utilisation is taken per RESIDENT wave pair: while a tile is resident 8 waves share 4 SIMDs.")
-for v in (11, 30):
+for v in (${PYVARS:-31, 11}):
     vals = collections.defaultdict(list); dur = []
     for d in ("sq", "lds"):
         for f in glob.glob(os.path.join(out, f"{d}_v{v}", "**", "*counter_collection.csv"), recursive=True):
