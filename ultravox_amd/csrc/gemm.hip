@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 // t-1, restaged in the first of tile t; [XA | WA | WB](t): read in the first load section of tile t, restaged in the second).
 template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false, int PH = 4>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
-  static_assert(PH == 4 || (PH == 2 && NS == 2 && MODE == 0 && !PERSIST), "the merged-phase schedule is written for two buffer sets");
+  static_assert(PH == 4 || (PH == 2 && NS == 2 && MODE == 0), "the merged-phase schedule is written for two buffer sets");
   constexpr int BNW = 256;
   constexpr int MI = BM / 32, MA = (MI + 1) / 2, MB = MI - MA;
   constexpr int XA_ROWS = 2 * MA * 16, XB_ROWS = 2 * MB * 16;
@@ -982,7 +982,7 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 35;
+constexpr int kNumVariants = 39;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
@@ -996,7 +996,8 @@ const Variant kVariants[kNumVariants] = {
     // twins' x the same-box cold-probe ratio (profiles/r02_gemm_ph2_probe.txt: 256: +3...+10 %, 192: +0...+4 %, 160: +0...+4 %
     // over the three-buffer 18, 128: +2...+5 %); fixed costs as the twins' except 192 (10.5 instead of 12: the in-situ table of the
     // first merged-phase run had 12000 x 3072 x 1024 on the 256 tile at 108 us where the 192 tile takes 87).
-    {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.}};
+    {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.},
+    {256, 256, 0., 6.},     {192, 256, 0., 8.},      {160, 256, 0., 7.},     {128, 256, 0., 5.}};   // 35..38 = PERSISTENT merged-phase (probe)
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
@@ -1072,6 +1073,15 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 28: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 5>), grid, dim3(512), 0, st, a); break;
     case 29: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 6>), grid, dim3(512), 0, st, a); break;
     case 30: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 7>), grid, dim3(512), 0, st, a); break;
+    case 35: case 36: case 37: case 38: {   // persistent merged-phase: next tile's pipeline fill under the epilogue
+      if (batch != 1) { launch_variant(st, variant - 4, a, M, N, batch); return; }
+      const dim3 pgrid(a.tiles_m * a.tiles_n < 256 ? a.tiles_m * a.tiles_n : 256);
+      if (variant == 35) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 0, true, 2>), pgrid, dim3(512), 0, st, a);
+      else if (variant == 36) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<192, 2, 0, true, 2>), pgrid, dim3(512), 0, st, a);
+      else if (variant == 37) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 2, 0, true, 2>), pgrid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 2, 0, true, 2>), pgrid, dim3(512), 0, st, a);
+      break;
+    }
     case 23: case 24: case 25: case 26: {
       // persistent: one block per CU walks the tiles (batched problems use the plain kernels: grid.y would oversubscribe)
       if (batch != 1) { launch_variant(st, variant == 23 ? 11 : variant == 24 ? 16 : variant == 25 ? 15 : 17, a, M, N, batch); return; }
