@@ -1,9 +1,9 @@
 """GPU probe: bf16 GEMM tile variants with COLD weights.  Inside the training step every weight matrix is read once
 per launch from HBM (16 GB of frozen weights per pass), while a back-to-back probe on one weight buffer keeps it in
 the 256 MB Infinity Cache and overstates every variant differently.  Here each launch takes the next weight matrix
+from a pool of > 1 GB, activations stay warm (they were just written by the previous kernel in the real step)."""
 import os
 os.environ.setdefault("UVX_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ultravox_amd", "libuvx_probes.so"))  # probe tile variants live in the probes build
-from a pool of > 1 GB, activations stay warm (they were just written by the previous kernel in the real step)."""
 import sys
 import torch
 from ultravox_amd import ops, _lib

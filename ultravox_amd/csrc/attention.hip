@@ -314,24 +314,6 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   }
 }
 
-// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
-__global__ void attn_delta_k(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ o, float* __restrict__ delta,
-                             int B, int T, int Hq, int D, int ldo) {
-  const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per (b,q,h)
-  const int lane = threadIdx.x & 63;
-  if (i >= (long long)B * T * Hq) return;
-  const int h = (int)(i % Hq);
-  const long long bq = i / Hq;
-  const long long off = bq * ldo + h * D;
-  float s = 0.f;
-  for (int c = lane * 2; c < D; c += 128) s += bf2f(dout[off + c]) * bf2f(o[off + c]) + bf2f(dout[off + c + 1]) * bf2f(o[off + c + 1]);
-  s = wave_sum(s);
-  if (lane == 0) {
-    const int b = (int)(bq / T), q = (int)(bq % T);
-    delta[((long long)b * Hq + h) * T + q] = s;
-  }
-}
-
 // =================================== backward: dK, dV ===================================
 // Block = (key block of 64, kv head, batch); wave w owns keys kb0 + w*16 .. +16.  Loops over the
 // query heads of the GQA group and over 32-query steps.
@@ -504,19 +486,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
 
+  // delta[q] = sum_d dO[q, d] * O[q, d] is computed HERE (this kernel runs first): the four lanes that share a query row hold
+  // its dO fragments, so the row dot product costs one extra O load per fragment and two shuffles - and the separate
+  // delta kernel (one launch per layer, 20 us at T = 316) is gone.  The result is also written out for the dK/dV kernel.
   bf16x8_t qf[KS], dof[KS];
+  float dl = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
+    u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0}, o8 = {0, 0, 0, 0, 0, 0, 0, 0};
     if (q < p.T) {
       a = *reinterpret_cast<const u16x8_t*>(p.q + ((long long)b * p.T + q) * p.ldq + h * D + ks * 32 + g * 8);
       c = *reinterpret_cast<const u16x8_t*>(p.dout + ((long long)b * p.T + q) * p.ldo + h * D + ks * 32 + g * 8);
+      o8 = *reinterpret_cast<const u16x8_t*>(p.o + ((long long)b * p.T + q) * p.ldo + h * D + ks * 32 + g * 8);
     }
     qf[ks] = __builtin_bit_cast(bf16x8_t, a);
     dof[ks] = __builtin_bit_cast(bf16x8_t, c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += bf2f(c[e]) * bf2f(o8[e]);
   }
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
+  if (g == 0 && q < p.T) p.delta[((long long)b * p.Hq + h) * p.T + q] = dl;
   const float lse = q < p.T ? p.lse[((long long)b * p.Hq + h) * p.T + q] : __builtin_huge_valf();
-  const float dl = q < p.T ? p.delta[((long long)b * p.Hq + h) * p.T + q] : 0.f;
 
   f32x4_t acc[DT];
 #pragma unroll
@@ -686,20 +677,18 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   a.delta = d.delta; a.dq = (bf16_t*)d.dq; a.dk = (bf16_t*)d.dk; a.dv = (bf16_t*)d.dv;
   a.lddq = d.lddq; a.lddk = d.lddk; a.lddv = d.lddv;
   a.dkv_part = (d.f.Hq != d.f.Hkv) ? d.dkv_part : nullptr;
-  const long long nw = (long long)d.f.B * d.f.T * d.f.Hq;
-  hipLaunchKernelGGL(attn_delta_k, dim3(cdiv(nw, 4)), dim3(256), 0, st, a.dout, (const bf16_t*)d.f.o, a.delta, d.f.B, d.f.T,
-                     d.f.Hq, d.f.D, d.f.ldo);
-  UVX_LAUNCH_CHECK();
+  a.o = (bf16_t*)d.f.o;
+  // dQ first: it computes delta = rowsum(dO * O) on the fly and leaves it in d.delta for the dK/dV kernel
   dim3 gk(cdiv(d.f.T, 64), a.dkv_part ? d.f.Hq : d.f.Hkv, d.f.B), gq(cdiv(d.f.T, 64), d.f.Hq, d.f.B);
   if (d.f.D == 64) {
-    hipLaunchKernelGGL(attn_bwd_dkdv_k<64>, gk, dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dq_k<64>, gq, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<64>, gk, dim3(256), 0, st, a);
   } else if (d.f.D == 128) {
-    hipLaunchKernelGGL(attn_bwd_dkdv_k<128>, gk, dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dq_k<128>, gq, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<128>, gk, dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dkdv_k<256>, gk, dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_dq_k<256>, gq, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_k<256>, gk, dim3(256), 0, st, a);
   }
   if (a.dkv_part) {
     const long long n4 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 4);
