@@ -31,8 +31,9 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // serialised behind each tile's main loop), [3] loss head on the supervised rows only (on), [4] weight-streaming kernel for
 // M <= 16 (on), [5] residual rows of a wave tile fetched up front in the GEMM epilogue (off: same-box A/B at C2, round 2:
 // 98.2 / 98.6 ms per step with it, 97.5 / 97.6 without - the 2 * MI extra live uint4 per lane cost more than the hidden latency),
-// [6] tile picker uses the merged-phase kernels 31..34 (on; 0 = the round-1 four-phase set 11, 15..19)
-int g_options[8] = {0, 2, 0, 1, 1, 0, 1, 0};
+// [6] tile picker uses the merged-phase kernels 31..34 (on; 0 = the round-1 four-phase set 11, 15..19),
+// [7] m-major tile order when the activation matrix is the larger operand (M > N: the encoder's GEMMs; on)
+int g_options[8] = {0, 2, 0, 1, 1, 0, 1, 1};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -54,6 +55,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   bf16_t* C2;      // swiglu mode: activation output [M, N/2]
   int ldc2;
+  int m_major;       // XCD-contiguous tile runs share an activation panel instead of a weight panel (option 7, M > N)
   int res_prefetch;  // fetch the residual rows of the wave tile up front (option 5; 0 = in-loop loads, for A/B runs)
   int swiglu;      // 1: columns alternate 16-wide gate / up blocks; also write silu(gate) * up to C2
   int wide_io;     // 16-byte epilogue loads / stores (probe switch; on by default)
@@ -617,7 +619,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     if (o >= ntiles) return false;
     const int xcd = o & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (o >> 3);
-    m0_ = (wg % p.tiles_m) * BM; n0_ = (wg / p.tiles_m) * BNW;
+    // which operand an XCD's contiguous run of tiles SHARES: n-major (default: consecutive tiles walk the M panels of one
+    // weight panel - every XCD streams its own weights once and re-fetches the activations) or m-major (p.m_major: the
+    // activation panel is the big operand - encoder GEMMs, M = 12000 rows against 1024...4096 weight rows - so consecutive
+    // tiles walk the weight panels of one activation panel and it is the small weight matrix that gets re-fetched per XCD)
+    if (p.m_major) { m0_ = (wg / p.tiles_n) * BM; n0_ = (wg % p.tiles_n) * BNW; }
+    else { m0_ = (wg % p.tiles_m) * BM; n0_ = (wg / p.tiles_m) * BNW; }
     return true;
   };
   // first / next tile with rows to compute (tiles beyond a device-side row count are skipped); uniform over the block
@@ -1123,6 +1130,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.C2 = (bf16_t*)d.C2; a.ldc2 = d.ldc2; a.swiglu = d.swiglu;
   a.wide_io = uvx::g_options[1];
   a.res_prefetch = uvx::g_options[5];
+  a.m_major = uvx::g_options[7] && d.M > d.N && (d.batch <= 1);
   a.m_dev = d.m_dev; a.m_dev_off = d.m_dev_off;
   UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
