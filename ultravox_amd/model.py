@@ -606,8 +606,17 @@ class UltravoxModel:
                 audio_batch_size: Optional[torch.Tensor] = None, past_key_values=None, alt_input_ids=None,
                 alt_attention_mask=None, alt_labels=None, return_logits: bool = True, _save_for_bwd: bool = False,
                 **kwargs) -> CausalLMOutputWithPast:
+        """UltravoxModel.forward (ultravox_model.py:277-352).  `attention_mask` rows must keep ONE contiguous run of positions
+        (right or left padding, what DataCollatorForSeq2SeqWithAudio produces): the device path turns each row into a
+        [start, end) key range, so a mask with holes would be honoured only at its outer edges.  A CPU mask is checked here
+        (a device mask is not: the check would cost a host synchronisation per step)."""
         if past_key_values is not None:
             raise NotImplementedError("forward() with an external KV cache is not built; use generate() (prefill + decode)")
+        if attention_mask is not None and not attention_mask.is_cuda:
+            m = attention_mask != 0
+            if bool(((m[:, 1:] != m[:, :-1]).sum(-1) > 2).any()) or bool(((m[:, 1:] != m[:, :-1]).sum(-1) == 2).__and__(m[:, 0]).any()):
+                raise ValueError("attention_mask rows must keep one contiguous run of positions (padding on one side or both), "
+                                 "masks with holes are not supported")
         use_kl = False
         if self.training and self.loss_config.loss_function != LossFunction.CrossEntropy:
             if self.loss_config.loss_function != LossFunction.KL_Divergence:
