@@ -90,12 +90,39 @@ def test_gemma_train_step_bf16(head_dim):
         assert v < 8e-2, (k, v)
 
 
-def test_gemma_generate_is_refused_not_wrong():
+@pytest.mark.parametrize("head_dim", [64, 256])
+def test_gemma_generate_token_exact_in_f32(head_dim):
+    """generate() on the Gemma backbone: prefill + KV-cache decode (head_dim-256 decode attention, GeGLU, GemmaRMSNorm, the
+    embedding scale on prompt AND decoded-token embeddings) - token-exact against the oracle's cache-free greedy search in
+    f32, with audio and a left-padded prompt; bf16: decode vs the model's own teacher-forced forward."""
+    from oracle.reference_cpu import OracleModel, logmel_ref, synthetic_batch
     from ultravox_amd.model import UltravoxModel
-    cfg = _cfg(64)
-    model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=1)
-    with pytest.raises(NotImplementedError, match="Llama family"):
-        model.generate(torch.randint(3, 500, (1, 8), device=DEV), max_new_tokens=2)
+    from ultravox_amd.weights import random_state_dict
+    cfg = _cfg(head_dim)
+    sd = random_state_dict(cfg, seed=41)
+    sd["language_model.model.embed_tokens.weight"] = sd["language_model.model.embed_tokens.weight"] * 3.0     # well separated logits
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32, with_backward=False)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    b = synthetic_batch(cfg, 2, 2.0, n_text=20, audio_start=4, n_supervised=4)
+    b.pop("labels")
+    b["audio_values"] = logmel_ref(b.pop("pcm"), 80)
+    b["attention_mask"][1, :3] = 0                      # left padding on one prompt (before the audio at position 4)
+    b["input_ids"][1, :3] = 1
+    N = 5
+    got = model.generate(max_new_tokens=N, eos_token_id=-1, **{k: v.to(DEV) for k, v in b.items()}).cpu()
+    want = oracle.generate_greedy(N, -1, pad_token_id=0, **b)
+    assert torch.equal(got, want)
+    # bf16: the decode path agrees with the teacher-forced forward wherever the arg-max is not a rounding coin toss
+    m16 = UltravoxModel(cfg, state_dict={k: v.bfloat16() for k, v in sd.items()}, device=DEV, dtype=torch.bfloat16, with_backward=False)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    out = m16.generate(max_new_tokens=N, eos_token_id=-1, **gb)
+    T = b["input_ids"].shape[1]
+    am = torch.cat([gb["attention_mask"], torch.ones(2, N, dtype=torch.long, device=DEV)], 1)
+    logits = m16.forward(input_ids=out, attention_mask=am, **{k: v for k, v in gb.items() if k.startswith("audio")}).logits.float()
+    top2 = logits.topk(2, -1).values
+    margin, pred = top2[..., 0] - top2[..., 1], logits.argmax(-1)
+    for t in range(T - 1, T + N - 1):
+        assert bool(((pred[:, t] == out[:, t + 1]) | (margin[:, t] < 5e-2)).all()), t
 
 
 def test_c5_gemma_7b_width_train_step_matches_oracle():

@@ -102,3 +102,24 @@ def test_c5_wav2vec2_large_gemma_7b_width_train_step():
     assert abs(loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
     for k, v in rec["grads"].items():
         assert v < 8e-2, (k, v)
+
+
+def test_c5_pairing_generates_token_exact_in_f32():
+    """wav2vec2 tower + Gemma backbone (BASELINE config 5's pairing, small sizes) through generate(): audio merged once, prefill,
+    KV-cache decode - token for token the oracle's cache-free greedy search, in f32."""
+    from oracle.reference_cpu import OracleModel, synthetic_batch, wav2vec2_normalize_ref
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    gemma = dict(model_type="gemma", hidden_size=192, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                 num_key_value_heads=2, head_dim=64, vocab_size=512, rms_norm_eps=1e-6, eos_token_id=1)
+    cfg = _cfg(text=gemma)
+    sd = random_state_dict(cfg, seed=43)
+    sd["language_model.model.embed_tokens.weight"] = sd["language_model.model.embed_tokens.weight"] * 3.0
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32, with_backward=False)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    b = synthetic_batch(cfg, 2, 1.0, n_text=16, audio_start=3, n_supervised=4)
+    b.pop("labels")
+    b["audio_values"] = wav2vec2_normalize_ref(b.pop("pcm"))
+    got = model.generate(max_new_tokens=5, eos_token_id=-1, **{k: v.to(DEV) for k, v in b.items()}).cpu()
+    want = oracle.generate_greedy(5, -1, pad_token_id=0, **b)
+    assert torch.equal(got, want)

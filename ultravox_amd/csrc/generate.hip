@@ -271,6 +271,13 @@ __global__ void argmax_k(const T* __restrict__ logits, int64_t* __restrict__ out
   if (threadIdx.x == 0) out[blockIdx.x] = bi[0] == 0x7fffffff ? 0 : bi[0];   // nothing above -inf: index 0, like torch.argmax
 }
 
+// [3P] transformers 4.51.3 GemmaModel.forward: hidden_states * tensor(hidden_size ** 0.5, dtype) - the normaliser is rounded
+// to the model dtype first (same helper as model.hip)
+float gemma_normalizer(const uvx_config_t& c) {
+  const float n = sqrtf((float)c.llm_d);
+  return c.dtype == DT_BF16 ? bf2f(f2bf(n)) : n;
+}
+
 GemmDesc lin(const void* A, const void* W, void* C, int M, int N, int K) {
   GemmDesc g;
   g.A = A; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
@@ -282,11 +289,12 @@ struct LayerIO { void *x_in, *x_mid; };
 
 int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, void* x_mid, void* x_out) {
   const int dt = c.dtype, D = c.llm_d;
-  RC(rmsnorm_fwd(st, dt, x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps));
+  RC(rmsnorm_fwd(st, dt, x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
   GemmDesc g = lin(s.n, L.wgu, s.gu, M, 2 * c.llm_inter, D);
-  if (dt == DT_BF16) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
+  const bool fused = dt == DT_BF16 && c.llm_flavor == UVX_LLM_LLAMA;   // SwiGLU in the epilogue; Gemma's GeGLU: separate kernel
+  if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
   RC(gemm(st, dt, g));
-  if (dt != DT_BF16) RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2));
+  if (!fused) RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2, c.llm_flavor == UVX_LLM_GEMMA));
   GemmDesc d = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
   d.residual = x_mid; d.ldr = D;
   return gemm(st, dt, d);
@@ -311,8 +319,6 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
                                    int32_t* next_pos, int32_t* kv_start, void* logits_last, void* workspace, size_t ws_bytes) {
   UVX_CHECK(cfg && w && inputs_embeds && kv_cache && next_pos && kv_start && logits_last && workspace, UVX_ERR_INVALID,
             "llm_prefill: null argument");
-  UVX_CHECK(cfg->llm_flavor == UVX_LLM_LLAMA, UVX_ERR_UNSUPPORTED,
-            "generate(): the KV-cache prefill / decode kernels are built for the Llama family only (llm_flavor %d)", cfg->llm_flavor);
   const uvx_config_t& c = *cfg;
   UVX_CHECK(T >= 1 && T <= Tmax, UVX_ERR_SHAPE, "llm_prefill: prompt length %d exceeds the cache length %d", T, Tmax);
   UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
@@ -325,10 +331,11 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   hipLaunchKernelGGL(mask_positions_k, dim3(B), dim3(64), 0, st, attention_mask, s.pos, kv_start, s.kvl, next_pos, T);
   UVX_LAUNCH_CHECK();
   UVX_HIP(hipMemcpyAsync(s.x, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+  if (c.llm_flavor == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, s.x, (long long)M * D, gemma_normalizer(c)));   // 4.51.3: inside the model
   const size_t layer_stride = (size_t)2 * B * Tmax * KVD;  // elements
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
-    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps));
+    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
     RC(gemm(st, dt, lin(s.n, L.wqkv, s.qkv, M, s.QKV, D)));
     RC(rope_inplace(st, dt, s.qkv, w->rope_cos_sin, s.pos, M, T, Hq + Hkv, dh, s.QKV, 0));
     {
@@ -356,7 +363,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   // logits of the LAST position of every sequence only (what generate() consumes)
   UVX_HIP(hipMemcpy2DAsync(s.last, (size_t)D * es, at(s.x, (size_t)(T - 1) * D, dt), (size_t)T * D * es, (size_t)D * es, B,
                            hipMemcpyDeviceToDevice, st));
-  RC(rmsnorm_fwd(st, dt, s.last, w->norm, s.hn, nullptr, B, D, c.rms_eps));
+  RC(rmsnorm_fwd(st, dt, s.last, w->norm, s.hn, nullptr, B, D, c.rms_eps, c.llm_flavor));
   return gemm(st, dt, lin(s.hn, w->lm_head, logits_last, B, c.vocab, D));
 }
 
@@ -392,8 +399,6 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
                                          size_t ws_bytes) {
   UVX_CHECK(cfg && w && inputs_embeds && kv_cache && positions0 && logits_last && workspace, UVX_ERR_INVALID,
             "llm_prefill_chunk: null argument");
-  UVX_CHECK(cfg->llm_flavor == UVX_LLM_LLAMA, UVX_ERR_UNSUPPORTED,
-            "generate(): the KV-cache prefill / decode kernels are built for the Llama family only (llm_flavor %d)", cfg->llm_flavor);
   const uvx_config_t& c = *cfg;
   const int Tf = cur_len + Tn;
   UVX_CHECK(Tn >= 1 && cur_len >= 0 && Tf <= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: %d cached + %d new positions exceed the cache length %d",
@@ -409,11 +414,12 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
   hipLaunchKernelGGL(chunk_positions_k, dim3(cdiv(M, 256)), dim3(256), 0, st, positions0, s.pos, B, Tn);
   UVX_LAUNCH_CHECK();
   UVX_HIP(hipMemcpyAsync(s.x, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+  if (c.llm_flavor == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, s.x, (long long)M * D, gemma_normalizer(c)));
   UVX_HIP(hipMemsetAsync(k.fq, 0, (size_t)B * Tf * s.QKV * es, st));   // the prefix rows' (skipped) query part stays defined
   const size_t layer_stride = (size_t)2 * B * Tmax * KVD;  // elements
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
-    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps));
+    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
     RC(gemm(st, dt, lin(s.n, L.wqkv, s.qkv, M, s.QKV, D)));
     RC(rope_inplace(st, dt, s.qkv, w->rope_cos_sin, s.pos, M, Tn, Hq + Hkv, dh, s.QKV, 0));
     char* ck = at(kv_cache, l * layer_stride, dt);
@@ -447,7 +453,7 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
   }
   UVX_HIP(hipMemcpy2DAsync(s.last, (size_t)D * es, at(s.x, (size_t)(Tn - 1) * D, dt), (size_t)Tn * D * es, (size_t)D * es, B,
                            hipMemcpyDeviceToDevice, st));
-  RC(rmsnorm_fwd(st, dt, s.last, w->norm, s.hn, nullptr, B, D, c.rms_eps));
+  RC(rmsnorm_fwd(st, dt, s.last, w->norm, s.hn, nullptr, B, D, c.rms_eps, c.llm_flavor));
   return gemm(st, dt, lin(s.hn, w->lm_head, logits_last, B, c.vocab, D));
 }
 
@@ -455,8 +461,6 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
                                   const int32_t* positions, const int32_t* kv_start, void* kv_cache, int32_t Tmax,
                                   int32_t cur_len, int32_t B, void* logits, void* workspace, size_t ws_bytes) {
   UVX_CHECK(cfg && w && token_embeds && positions && kv_cache && logits && workspace, UVX_ERR_INVALID, "llm_decode: null argument");
-  UVX_CHECK(cfg->llm_flavor == UVX_LLM_LLAMA, UVX_ERR_UNSUPPORTED,
-            "generate(): the KV-cache prefill / decode kernels are built for the Llama family only (llm_flavor %d)", cfg->llm_flavor);
   const uvx_config_t& c = *cfg;
   UVX_CHECK(cur_len >= 0 && cur_len < Tmax, UVX_ERR_SHAPE, "llm_decode: cache full (%d of %d)", cur_len, Tmax);
   hipStream_t st = (hipStream_t)stream;
@@ -464,14 +468,15 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
   InferWs s = carve(a, c, B, 1);
   UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_decode: workspace %zu < %zu bytes", ws_bytes, a.off);
   const int dt = c.dtype, D = c.llm_d, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads, KVD = Hkv * dh;
-  UVX_CHECK(dh == 64 || dh == 128, UVX_ERR_UNSUPPORTED, "llm_decode: head_dim %d not supported", dh);
+  UVX_CHECK(dh == 64 || dh == 128 || dh == 256, UVX_ERR_UNSUPPORTED, "llm_decode: head_dim %d not supported", dh);
   const size_t es = esz(dt);
   UVX_HIP(hipMemcpyAsync(s.x, token_embeds, (size_t)B * D * es, hipMemcpyDeviceToDevice, st));
+  if (c.llm_flavor == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, s.x, (long long)B * D, gemma_normalizer(c)));
   const size_t layer_stride = (size_t)2 * B * Tmax * KVD;
   const float scale = 1.0f / sqrtf((float)dh);
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
-    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps));
+    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
     RC(gemm(st, dt, lin(s.n, L.wqkv, s.qkv, B, s.QKV, D)));
     RC(rope_inplace(st, dt, s.qkv, w->rope_cos_sin, positions, B, 1, Hq + Hkv, dh, s.QKV, 0));
     char* ck = at(kv_cache, l * layer_stride, dt);
@@ -491,11 +496,13 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
       else if (sh <= 48 * 1024 && dh == 64 && G == 2) UVX_DEC(64, 2);
       else if (sh <= 48 * 1024 && dh == 64 && G == 1) UVX_DEC(64, 1);
 #undef UVX_DEC
+      else if (dh == 256) hipLaunchKernelGGL((attn_decode_k<bf16_t, 256>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
       else if (dh == 64) hipLaunchKernelGGL((attn_decode_k<bf16_t, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
       else hipLaunchKernelGGL((attn_decode_k<bf16_t, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
     } else {
       hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
-      if (dh == 64) hipLaunchKernelGGL((attn_decode_k<float, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
+      if (dh == 256) hipLaunchKernelGGL((attn_decode_k<float, 256>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
+      else if (dh == 64) hipLaunchKernelGGL((attn_decode_k<float, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
       else hipLaunchKernelGGL((attn_decode_k<float, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
     }
     UVX_LAUNCH_CHECK();
@@ -504,7 +511,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
     RC(gemm(st, dt, g));
     RC(mlp_block(st, c, L, s, B, s.x2, s.x));
   }
-  RC(rmsnorm_fwd(st, dt, s.x, w->norm, s.hn, nullptr, B, D, c.rms_eps));
+  RC(rmsnorm_fwd(st, dt, s.x, w->norm, s.hn, nullptr, B, D, c.rms_eps, c.llm_flavor));
   return gemm(st, dt, lin(s.hn, w->lm_head, logits, B, c.vocab, D));
 }
 

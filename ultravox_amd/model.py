@@ -735,9 +735,6 @@ class UltravoxModel:
             warnings.warn(f"generate(): these arguments have no effect here: {sorted(ignored)}")
         if past is not None and not isinstance(past, KVState):
             raise TypeError("past_key_values must be the KVState a previous generate(return_dict_in_generate=True) returned")
-        if getattr(self.config.text_config, "is_gemma", False):
-            raise NotImplementedError("generate() is built for the Llama family; the Gemma backbone (BASELINE config 5) covers the "
-                                      "adapter-training path: forward, loss, backward")
         if self.text_lora_r > 0:
             raise NotImplementedError("generate() with an un-merged LLM LoRA adapter is not built: call merge_and_unload() first "
                                       "(as the reference does before inference, ultravox_model.py:528-559)")
