@@ -55,7 +55,8 @@ WORKLOADS = {
 def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int = 32):
     """Algorithmic FLOPs of one sample: matmul [m,k]x[k,n] = 2mkn, causal attention = 1/2.  The LM head
     is counted on the supervised positions only (the rows that enter the loss; the other rows of the logits have zero
-    weight and zero gradient, and the training step does not compute them) - `step_full_head` keeps the all-rows count."""
+    weight and zero gradient, and the training step does not compute them), and so is the last LLM layer's o_proj + MLP -
+    `step_full_head` keeps the all-rows count."""
     a, t = cfg.audio_config, cfg.text_config
     F = int(seconds * 100)
     Te = F // 2
@@ -80,9 +81,11 @@ def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int =
     attn = L * 2 * T * T * h * dh
     body = L * (2 * T * (2 * D * h * dh + 2 * D * kv * dh) + 6 * T * D * I) + attn
     head, head_full = 2 * n_supervised * D * V, 2 * T * D * V
-    M = body + head
+    # the last layer's o_proj + MLP (row-wise, after the last position mixing) likewise run on the supervised rows only
+    top_skip = (T - n_supervised) * (2 * D * h * dh + 6 * D * I)
+    M = body + head - top_skip
     step = E + 3 * P + M + (M + attn)
-    return dict(encoder=E, projector=P, llm_fwd=M, step=step, step_full_head=step + 2 * (head_full - head))
+    return dict(encoder=E, projector=P, llm_fwd=M, step=step, step_full_head=step + 2 * (head_full - head) + 2 * top_skip)
 
 
 def cpu_baseline(cfg, seconds: float, n_text: int = 128):

@@ -222,6 +222,15 @@ int32_t uvx_llm_fwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights
  * d loss / d inputs_embeds [B, T, D], loss scaled by grad_scale (1 / gradient_accumulation_steps). */
 int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
                     int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes);
+/* The adapter-training step's own pair: the same loss and gradients as uvx_llm_fwd(labels, logits = NULL, save_for_bwd = 1) +
+ * uvx_llm_bwd, but the LAST layer's o_proj, MLP and final norm (and their gradients) are evaluated on the supervised rows
+ * only - nothing downstream of the last attention mixes positions, and only positions whose next token is labelled enter
+ * ForCausalLMLoss.  bf16 only; the two calls must be used together (the last layer's stash is row-compacted). */
+int32_t uvx_llm_fwd_train(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                          const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T, float* loss,
+                          void* workspace, size_t ws_bytes);
+int32_t uvx_llm_bwd_train(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels, int32_t B,
+                          int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes);
 /* labels == NULL: the saved logits already hold d loss / d logits (see uvx_llm_kl_loss). */
 
 /* KL-distillation loss: UltravoxModel._compute_kl_loss (ultravox_model.py:200-256) with the

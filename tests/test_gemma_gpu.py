@@ -100,7 +100,9 @@ def test_gemma_generate_token_exact_in_f32(head_dim):
     from ultravox_amd.weights import random_state_dict
     cfg = _cfg(head_dim)
     sd = random_state_dict(cfg, seed=41)
-    sd["language_model.model.embed_tokens.weight"] = sd["language_model.model.embed_tokens.weight"] * 3.0     # well separated logits
+    # an explicit (untied) head for this test only: with random weights a TIED head makes every step copy the last token
+    # (its own embedding dominates the residual stream), which would check nothing about the decode arithmetic
+    sd["language_model.lm_head.weight"] = 0.3 * torch.randn(512, 192, generator=torch.Generator().manual_seed(7))
     model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32, with_backward=False)
     oracle = OracleModel(cfg, sd, dtype=torch.float32)
     b = synthetic_batch(cfg, 2, 2.0, n_text=20, audio_start=4, n_supervised=4)

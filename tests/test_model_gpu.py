@@ -194,10 +194,7 @@ def test_llm_input_gradient_matches_oracle():
     out = model.language_model_forward(emb.to(DEV), labels=labels.to(DEV), want_logits=False, save_for_bwd=True)
     import ctypes as C
     from ultravox_amd import _lib
-    d = torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16)
-    Bc, Tc, nb, lab = model._llm_ctx
-    _lib.check(_lib.lib().uvx_llm_bwd(_lib.stream_ptr(), C.byref(model._c), C.byref(model._lw), _lib.ptr(lab), B, T,
-                                      C.c_float(1.0), _lib.ptr(d), _lib.ptr(model._ws["llm"]), C.c_size_t(nb)))
+    d = model.language_model_backward(1.0)        # uvx_llm_bwd_train: pairs with the forward above
     e = emb.float().requires_grad_(True)
     loss = causal_lm_loss_ref(llama_ref(oracle.sd, cfg, e, None), labels)
     loss.backward()
@@ -287,10 +284,7 @@ def test_loss_head_on_supervised_rows_split_k(T, first_label):
     out = model.language_model_forward(emb.to(DEV), labels=labels.to(DEV), want_logits=False, save_for_bwd=True)
     import ctypes as C
     from ultravox_amd import _lib
-    d = torch.empty(B, T, D, device=DEV, dtype=torch.bfloat16)
-    Bc, Tc, nb, lab = model._llm_ctx
-    _lib.check(_lib.lib().uvx_llm_bwd(_lib.stream_ptr(), C.byref(model._c), C.byref(model._lw), _lib.ptr(lab), B, T,
-                                      C.c_float(1.0), _lib.ptr(d), _lib.ptr(model._ws["llm"]), C.c_size_t(nb)))
+    d = model.language_model_backward(1.0)        # uvx_llm_bwd_train: pairs with the forward above
     e = emb.float().requires_grad_(True)
     loss = causal_lm_loss_ref(llama_ref(oracle.sd, cfg, e, None), labels)
     loss.backward()
@@ -300,10 +294,24 @@ def test_loss_head_on_supervised_rows_split_k(T, first_label):
     _lib.lib().uvx_set_option(3, 0)
     try:
         out2 = model.language_model_forward(emb.to(DEV), labels=labels.to(DEV), want_logits=False, save_for_bwd=True)
-        d2 = torch.empty_like(d)
-        _lib.check(_lib.lib().uvx_llm_bwd(_lib.stream_ptr(), C.byref(model._c), C.byref(model._lw), _lib.ptr(lab), B, T,
-                                          C.c_float(1.0), _lib.ptr(d2), _lib.ptr(model._ws["llm"]), C.c_size_t(nb)))
+        d2 = model.language_model_backward(1.0)
     finally:
         _lib.lib().uvx_set_option(3, 1)
     assert abs(out2.loss.item() - out.loss.item()) < 1e-6 * out.loss.item()   # same per-row losses; the f32 row sum groups differently
     assert rel_l2(d, d2) < 5e-3
+    # ... and so does the plain uvx_llm_fwd / uvx_llm_bwd pair (supervised-rows head, but the last layer on every row):
+    # the training pair (uvx_llm_fwd_train / uvx_llm_bwd_train) evaluates the same per-row arithmetic on fewer rows
+    model.top_layer_supervised_rows = False
+    try:
+        out3 = model.language_model_forward(emb.to(DEV), labels=labels.to(DEV), want_logits=False, save_for_bwd=True)
+        assert not model._llm_train_pair
+        d3 = model.language_model_backward(1.0)
+    finally:
+        model.top_layer_supervised_rows = True
+    assert out3.loss.item() == out.loss.item()
+    sup = torch.zeros(B, T, dtype=torch.bool); sup[:, :-1] = labels[:, 1:] != -100
+    assert rel_l2(d, d3) < 5e-3
+    # rows after the last supervised position of a sequence get no gradient at all, in either pair
+    last = [int(sup[b].nonzero().max()) for b in range(B)]
+    for b in range(B):
+        assert float(d[b, last[b] + 1:].float().abs().max() if last[b] + 1 < T else 0.0) == 0.0

@@ -114,7 +114,9 @@ def test_c5_pairing_generates_token_exact_in_f32():
                  num_key_value_heads=2, head_dim=64, vocab_size=512, rms_norm_eps=1e-6, eos_token_id=1)
     cfg = _cfg(text=gemma)
     sd = random_state_dict(cfg, seed=43)
-    sd["language_model.model.embed_tokens.weight"] = sd["language_model.model.embed_tokens.weight"] * 3.0
+    # an explicit (untied) head for this test only: with random weights a TIED head makes every step copy the last token
+    # (its own embedding dominates the residual stream), which would check nothing about the decode arithmetic
+    sd["language_model.lm_head.weight"] = 0.3 * torch.randn(512, 192, generator=torch.Generator().manual_seed(7))
     model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32, with_backward=False)
     oracle = OracleModel(cfg, sd, dtype=torch.float32)
     b = synthetic_batch(cfg, 2, 1.0, n_text=16, audio_start=3, n_supervised=4)

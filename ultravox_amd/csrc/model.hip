@@ -633,7 +633,7 @@ __global__ void set_i32_k(int32_t* p, int32_t v) { *p = v; }
 static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
                        const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T, void* logits,
                        float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes, const int32_t* rows,
-                       int32_t n_rows, void* logits_rows, const uvx_encoder_lora_t* lora = nullptr) {
+                       int32_t n_rows, void* logits_rows, const uvx_encoder_lora_t* lora = nullptr, bool top_rows = false) {
   RC(check_cfg(cfg));
   UVX_CHECK(w && inputs_embeds && workspace, UVX_ERR_INVALID, "llm_fwd: null argument");
   UVX_CHECK(!labels || loss, UVX_ERR_INVALID, "llm_fwd: labels given but no loss output");
@@ -652,6 +652,13 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   else hipLaunchKernelGGL(full_range_k, dim3(cdiv(B, 64)), dim3(64), 0, st, s.kvs, s.kvl, B, T);
   UVX_LAUNCH_CHECK();
   const int32_t *kvs = s.kvs, *kvl = s.kvl;
+  // top_rows (uvx_llm_fwd_train): only the supervised positions enter the loss, and in the LAST layer nothing downstream of
+  // its attention mixes positions any more - o_proj, the MLP and the final norm are row-wise.  Their results are needed
+  // (and have a gradient) on the supervised rows alone, so the last layer's post-attention half runs on the compacted
+  // rows (device-side list, no host sync; GEMMs clamp to the device count).  Same loss, same gradients.
+  UVX_CHECK(!top_rows || (labels && loss && dt == DT_BF16 && save_for_bwd && !logits && !rows), UVX_ERR_INVALID,
+            "llm_fwd_train: labels and a loss output are required, bf16 only");
+  const bool tc = top_rows && g_options[3];   // (tuning option 3 off: the plain full-row path, in both calls of the pair)
   LlmLayerStash cur = llm_layer(s, 0);
   UVX_HIP(hipMemcpyAsync(cur.x_in, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
   const int fl = c.llm_flavor;   // 0 Llama, 1 Gemma (norm flavour, GLU activation, embedding scale)
@@ -681,9 +688,16 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
     ad.scale = 1.0f / sqrtf((float)dh);
     RC(attention_fwd(st, dt, ad));
+    const bool compact = tc && last;
+    const int32_t* mdev = compact ? s.sup + M : nullptr;
+    if (compact) {   // gather the supervised rows of the attention output and of the residual stream (backward scratch is free here)
+      RC(sup_rows(st, labels, s.sup, B, T, c.vocab));
+      RC(gather_rows(st, dt, cur.o, s.sup, M, s.d_o, s.OD));
+      RC(gather_rows(st, dt, cur.x_in, s.sup, M, s.dx, D));
+    }
     {
-      GemmDesc g = lin(cur.o, L.wo, cur.x_mid, M, D, s.OD);
-      g.residual = cur.x_in; g.ldr = D;
+      GemmDesc g = lin(compact ? s.d_o : cur.o, L.wo, cur.x_mid, M, D, s.OD);
+      g.residual = compact ? s.dx : cur.x_in; g.ldr = D; g.m_dev = mdev;
       RC(gemm(st, dt, g));
     }
     RC(rmsnorm_fwd(st, dt, cur.x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps, fl));
@@ -691,12 +705,13 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       GemmDesc g = lin(s.n, L.wgu, cur.gu, M, 2 * c.llm_inter, D);
       const bool fused = dt == DT_BF16 && fl == UVX_LLM_LLAMA;   // SwiGLU fused into the epilogue (GeGLU: separate kernel)
       if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
+      g.m_dev = mdev;
       RC(gemm(st, dt, g));
       if (!fused) RC(swiglu_fwd(st, dt, cur.gu, s.act, M, c.llm_inter, /*layout=*/2, /*act=*/fl == UVX_LLM_GEMMA));
     }
     {
       GemmDesc g = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
-      g.residual = cur.x_mid; g.ldr = D;
+      g.residual = cur.x_mid; g.ldr = D; g.m_dev = mdev;
       RC(gemm(st, dt, g));
     }
     if (!last) cur = llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1));
@@ -720,9 +735,11 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     // head dgrad run on the compacted rows - identical loss and gradients, ~T / n_supervised less head work.  The
     // row list is built on the device (no host sync): GEMMs are launched for M rows and clamp to the device count.
     if (logits) RC(gemm(st, dt, lin(s.hn, w->lm_head, logits, M, c.vocab, D)));   // the caller's full logits, if asked
-    RC(sup_rows(st, labels, s.sup, B, T, c.vocab));
-    RC(gather_rows(st, dt, s.hn, s.sup, M, s.n, D));
-    GemmDesc g = lin(s.n, w->lm_head, s.logits, M, c.vocab, D);
+    if (!tc) {   // (top_rows: the last layer already left s.hn compact, in the order of the row list)
+      RC(sup_rows(st, labels, s.sup, B, T, c.vocab));
+      RC(gather_rows(st, dt, s.hn, s.sup, M, s.n, D));
+    }
+    GemmDesc g = lin(tc ? s.hn : s.n, w->lm_head, s.logits, M, c.vocab, D);
     g.m_dev = s.sup + M;
     RC(gemm(st, dt, g));
     RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, loss, s.ce_scratch, nullptr, B, T, c.vocab, c.vocab, 1.0f, s.sup));
@@ -786,7 +803,7 @@ extern "C" int32_t uvx_llm_kl_loss(void* stream, const uvx_config_t* cfg, const 
 static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
                         int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes,
                         bool compact_in_place, const uvx_encoder_lora_t* lora = nullptr,
-                        const uvx_encoder_lora_grads_t* lgrads = nullptr) {
+                        const uvx_encoder_lora_grads_t* lgrads = nullptr, bool top_rows = false) {
   RC(check_cfg(cfg));
   UVX_CHECK(w && d_inputs_embeds && workspace, UVX_ERR_INVALID, "llm_bwd: null argument");
   const uvx_config_t& c = *cfg;
@@ -835,24 +852,54 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     RC(gemm(st, dt, lin(s.logits, w->lm_head_t, s.d_hn, M, D, c.vocab)));
   }
   const int fl = c.llm_flavor;
-  RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl));
+  // top_rows (uvx_llm_bwd_train, after uvx_llm_fwd_train): the last layer's stash (x_final, x_mid, gate|up) holds the
+  // supervised rows only; its MLP / o_proj gradients run on those rows and are scattered back before the attention backward
+  UVX_CHECK(!top_rows || (!compact_in_place && labels && dt == DT_BF16), UVX_ERR_INVALID, "llm_bwd_train: labels are required, bf16 only");
+  const bool tc = top_rows && g_options[3];
+  const int32_t* mdev_top = tc ? s.sup + M : nullptr;
+  const void* dx_resid = s.dx;     // gradient of the residual stream entering the layer being processed
+  if (tc) {
+    RC(gather_rows(st, dt, s.d_hn, s.sup, M, s.d_n, D));                 // d_hn was scattered to full rows: back to compact
+    RC(rmsnorm_bwd(st, dt, s.d_n, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl));
+  } else {
+    RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl));
+  }
   for (int l = c.llm_layers - 1; l >= 0; --l) {
     const uvx_llm_layer_t& L = w->layers[l];
     UVX_CHECK(L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t, UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
     LlmLayerStash cur = llm_layer(s, l);
+    const bool compact = tc && l == c.llm_layers - 1;
+    const int32_t* mdev = compact ? mdev_top : nullptr;
     // MLP
     if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
       GemmDesc g = lin(s.dx, L.wd_t, s.d_gu, M, c.llm_inter, D);
-      g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2;
+      g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2; g.m_dev = mdev;
       RC(gemm(st, dt, g));
     } else {
-      RC(gemm(st, dt, lin(s.dx, L.wd_t, s.d_act, M, c.llm_inter, D)));
+      GemmDesc g = lin(s.dx, L.wd_t, s.d_act, M, c.llm_inter, D);
+      g.m_dev = mdev;
+      RC(gemm(st, dt, g));
       RC(swiglu_bwd(st, dt, s.d_act, cur.gu, s.d_gu, M, c.llm_inter, /*layout=*/2, /*act=*/fl == UVX_LLM_GEMMA));
     }
-    RC(gemm(st, dt, lin(s.d_gu, L.wgu_t, s.d_n, M, D, 2 * c.llm_inter)));
+    {
+      GemmDesc g = lin(s.d_gu, L.wgu_t, s.d_n, M, D, 2 * c.llm_inter);
+      g.m_dev = mdev;
+      RC(gemm(st, dt, g));
+    }
     RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_mid, L.ln2, s.dx, s.dx, nullptr, M, D, c.rms_eps, fl));
     // attention
-    RC(gemm(st, dt, lin(s.dx, L.wo_t, s.d_o, M, s.OD, D)));
+    if (compact) {   // d o on the compact rows, then both it and the residual-stream gradient go back to their full rows
+      GemmDesc g = lin(s.dx, L.wo_t, s.doT, M, s.OD, D);        // doT ([B, Hq, Tp, dh] >= M * OD) is free until the transpose below
+      g.m_dev = mdev;
+      RC(gemm(st, dt, g));
+      UVX_HIP(hipMemsetAsync(s.d_o, 0, (size_t)M * s.OD * esz(dt), st));
+      RC(scatter_rows(st, dt, s.doT, s.sup, M, s.d_o, s.OD));
+      UVX_HIP(hipMemsetAsync(s.d_hn, 0, (size_t)M * D * esz(dt), st));
+      RC(scatter_rows(st, dt, s.dx, s.sup, M, s.d_hn, D));
+      dx_resid = s.d_hn;
+    } else {
+      RC(gemm(st, dt, lin(s.dx, L.wo_t, s.d_o, M, s.OD, D)));
+    }
     RC(heads_transpose(st, dt, cur.qkv, s.qT, B, T, s.Tp, Hq, dh, s.QKV));
     RC(heads_transpose(st, dt, at(cur.qkv, (size_t)Hq * dh, dt), s.kT, B, T, s.Tp, Hkv, dh, s.QKV));
     RC(heads_transpose(st, dt, s.d_o, s.doT, B, T, s.Tp, Hq, dh, s.OD));
@@ -885,7 +932,8 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       RC(lora_up(st, dt, s.lu, 128, R.q.a, 1, s.d_n, D, M, D, r, 1.0f, 1));
       RC(lora_up(st, dt, at(s.lu, 64, dt), 128, R.k.a, 1, s.d_n, D, M, D, r, 1.0f, 1));
     }
-    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_in, L.ln1, s.dx, l == 0 ? d_inputs_embeds : s.dx, nullptr, M, D, c.rms_eps, fl));
+    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_in, L.ln1, dx_resid, l == 0 ? d_inputs_embeds : s.dx, nullptr, M, D, c.rms_eps, fl));
+    dx_resid = s.dx;
   }
   if (fl == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, d_inputs_embeds, (long long)M * D, gemma_normalizer(c)));   // d (x * normalizer)
   return UVX_OK;
@@ -895,6 +943,20 @@ extern "C" int32_t uvx_llm_bwd(void* stream, const uvx_config_t* cfg, const uvx_
                                int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace,
                                size_t ws_bytes) {
   return llm_backward(stream, cfg, w, labels, B, T, grad_scale, d_inputs_embeds, workspace, ws_bytes, false);
+}
+
+// The adapter-training step's own pair (include/uvx.h): identical loss and gradients to uvx_llm_fwd(save_for_bwd = 1, logits =
+// NULL) + uvx_llm_bwd, with the last layer's o_proj / MLP / final norm and their gradients on the supervised rows only.
+extern "C" int32_t uvx_llm_fwd_train(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                                     const int64_t* attention_mask, const int64_t* labels, int32_t B, int32_t T, float* loss,
+                                     void* workspace, size_t ws_bytes) {
+  return llm_forward(stream, cfg, w, inputs_embeds, attention_mask, labels, B, T, nullptr, loss, 1, workspace, ws_bytes, nullptr, 0,
+                     nullptr, nullptr, true);
+}
+extern "C" int32_t uvx_llm_bwd_train(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
+                                     int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace,
+                                     size_t ws_bytes) {
+  return llm_backward(stream, cfg, w, labels, B, T, grad_scale, d_inputs_embeds, workspace, ws_bytes, false, nullptr, nullptr, true);
 }
 
 // LLM under LoRA training (text_model_lora_config.r > 0, apply_lora on the language model, ultravox_model.py:500-526):

@@ -10,6 +10,7 @@ step (loss -> backward -> DP mean of projector grads -> clip 1.0 -> AdamW), SURV
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 import dataclasses
 from typing import Dict, List, Optional
@@ -137,6 +138,8 @@ class UltravoxModel:
         self.dtype = _torch_dtype(config, dtype)
         self.code = _lib.dtype_code(self.dtype)
         self.training = False
+        # training step: last layer's o_proj / MLP on the supervised rows only (uvx_llm_fwd_train); A/B switch for the probes
+        self.top_layer_supervised_rows = os.environ.get("UVX_TOP_LAYER_ROWS", "1") != "0"
         self._kl_grad_scale = 1.0
         self._before_projector = None
         self.keep_params = set()                 # ultravox_model.py:59
@@ -587,7 +590,13 @@ class UltravoxModel:
         loss = torch.zeros(1, device=dev, dtype=torch.float32) if labels is not None else None
         lab = None if labels is None else labels.to(device=dev, dtype=torch.int64).contiguous()
         am = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
-        if self.text_lora_r > 0:
+        # the training step's pair (uvx_llm_fwd_train / uvx_llm_bwd_train): last layer's row-wise half on the supervised rows
+        train_pair = (save_for_bwd and not want_logits and lab is not None and self.dtype == torch.bfloat16
+                      and self.text_lora_r == 0 and self.top_layer_supervised_rows)
+        if train_pair:
+            check(l.uvx_llm_fwd_train(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(am),
+                                      ptr(lab), B, T, ptr(loss), ptr(ws), C.c_size_t(nb)), "uvx_llm_fwd_train")
+        elif self.text_lora_r > 0:
             check(l.uvx_llm_fwd_lora(stream_ptr(), C.byref(self._c), C.byref(self._lw), C.byref(self._tlora),
                                      ptr(inputs_embeds.contiguous()), ptr(am), ptr(lab), B, T, ptr(logits), ptr(loss),
                                      int(save_for_bwd), ptr(ws), C.c_size_t(nb)), "uvx_llm_fwd_lora")
@@ -596,7 +605,30 @@ class UltravoxModel:
                                 ptr(lab), B, T, ptr(logits), ptr(loss), int(save_for_bwd), ptr(ws), C.c_size_t(nb)),
                   "uvx_llm_fwd")
         self._llm_ctx = (B, T, nb, lab)
+        self._llm_train_pair = bool(train_pair)
         return CausalLMOutputWithPast(loss=None if loss is None else loss[0], logits=logits)
+
+    def language_model_backward(self, grad_scale: float = 1.0) -> torch.Tensor:
+        """d loss / d inputs_embeds of the last ``language_model_forward(save_for_bwd=True)`` (or KL forward): the uvx_llm_bwd*
+        entry point that pairs with the forward that ran.  LoRA gradients (text_model_lora_config) land in their buffers."""
+        l = _lib.lib()
+        B, T, nb, lab = self._llm_ctx
+        D = self.config.text_config.hidden_size
+        d_embeds = torch.empty((B, T, D), device=self.device, dtype=self.dtype)
+        if isinstance(lab, str):      # "rows": the compact KL path left d logits for its row list in the workspace
+            check(l.uvx_llm_bwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), B, T, ptr(d_embeds),
+                                     ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_rows")
+        elif self.text_lora_r > 0:
+            check(l.uvx_llm_bwd_lora(stream_ptr(), C.byref(self._c), C.byref(self._lw), C.byref(self._tlora), ptr(lab), B, T,
+                                     C.c_float(grad_scale), ptr(d_embeds), C.byref(self._tlora_grads), ptr(self._ws["llm"]),
+                                     C.c_size_t(nb)), "uvx_llm_bwd_lora")
+        elif getattr(self, "_llm_train_pair", False):
+            check(l.uvx_llm_bwd_train(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, C.c_float(grad_scale),
+                                      ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_train")
+        else:
+            check(l.uvx_llm_bwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, C.c_float(grad_scale),
+                                ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd")
+        return d_embeds
 
     # ------------------------------------------------------------------ reference API
     def forward(self, input_ids: Optional[torch.Tensor] = None, audio_values: Optional[torch.Tensor] = None,
@@ -877,20 +909,9 @@ class UltravoxModel:
         self._kl_grad_scale = grad_scale
         out = self.forward(return_logits=False, _save_for_bwd=True, **batch)
         self._kl_grad_scale = 1.0
+        d_embeds = self.language_model_backward(grad_scale)
         l = _lib.lib()
-        B, T, nb, lab = self._llm_ctx
         D = self.config.text_config.hidden_size
-        d_embeds = torch.empty((B, T, D), device=self.device, dtype=self.dtype)
-        if isinstance(lab, str):      # "rows": the compact KL path left d logits for its row list in the workspace
-            check(l.uvx_llm_bwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), B, T, ptr(d_embeds),
-                                     ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_rows")
-        elif self.text_lora_r > 0:
-            check(l.uvx_llm_bwd_lora(stream_ptr(), C.byref(self._c), C.byref(self._lw), C.byref(self._tlora), ptr(lab), B, T,
-                                     C.c_float(grad_scale), ptr(d_embeds), C.byref(self._tlora_grads), ptr(self._ws["llm"]),
-                                     C.c_size_t(nb)), "uvx_llm_bwd_lora")
-        else:
-            check(l.uvx_llm_bwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, C.c_float(grad_scale),
-                                ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd")
         st, tl, B, T, n_items, Na, scratch = self._merge_ctx
         if n_items == 0:     # text-only batch: no gradient reaches the projector / the encoder adapters
             if self.text_lora_r > 0:
