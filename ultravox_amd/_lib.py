@@ -182,7 +182,7 @@ EXPORTS = [
     "uvx_llm_prefill", "uvx_llm_prefill_chunk", "uvx_llm_prefill_chunk_ws_bytes", "uvx_llm_decode", "uvx_argmax", "uvx_llm_kl_loss", "uvx_kl_loss", "uvx_gemm_override_variant", "uvx_gemm_pick_variant", "uvx_set_option",
     "uvx_encoder_train_ws_bytes", "uvx_encoder_fwd_train", "uvx_encoder_bwd", "uvx_layernorm_bwd", "uvx_gelu", "uvx_gelu_bwd",
     "uvx_llm_fwd_rows", "uvx_llm_kl_loss_rows", "uvx_llm_bwd_rows", "uvx_llm_fwd_lora", "uvx_llm_bwd_lora",
-    "uvx_llm_fwd_train", "uvx_llm_bwd_train",
+    "uvx_llm_fwd_train", "uvx_llm_bwd_train", "uvx_gemm_streamk_timeouts",
     "uvx_wav2vec2_frames", "uvx_wav2vec2_ws_bytes", "uvx_wav2vec2_fwd",
     "uvx_comm_unique_id", "uvx_comm_init", "uvx_comm_world_size", "uvx_comm_version", "uvx_comm_allreduce_f32", "uvx_comm_destroy",
 ]

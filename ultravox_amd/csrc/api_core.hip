@@ -26,11 +26,12 @@ extern "C" int32_t uvx_gemm_force_variant(int32_t v) {
 }
 
 extern "C" int32_t uvx_set_option(int32_t key, int32_t value) {
-  UVX_CHECK(key > 0 && key < 8, UVX_ERR_INVALID, "uvx_set_option: unknown key %d", key);
+  UVX_CHECK(key > 0 && key < 12, UVX_ERR_INVALID, "uvx_set_option: unknown key %d", key);
   uvx::g_options[key] = value;
   return UVX_OK;
 }
 
+extern "C" int32_t uvx_gemm_streamk_timeouts(void) { return uvx::gemm_streamk_timeouts(); }
 extern "C" int32_t uvx_gemm_pick_variant(int32_t M, int32_t N, int32_t K, int32_t batch) { return uvx::gemm_pick_variant(M, N, K, batch); }
 
 extern "C" int32_t uvx_gemm_override_variant(int32_t M, int32_t N, int32_t K, int32_t variant) {

@@ -17,7 +17,9 @@
 // (rows = 4 consecutive n per lane, col = m) stores 4 consecutive output columns per lane: 8-byte
 // bf16x4 / 16-byte f32x4 stores, bias as one vector load.
 #include <math.h>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 #include "common.h"
 #include "kernels.h"
 
@@ -33,7 +35,9 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // 98.2 / 98.6 ms per step with it, 97.5 / 97.6 without - the 2 * MI extra live uint4 per lane cost more than the hidden latency),
 // [6] tile picker uses the merged-phase kernels 31..34 (on; 0 = the round-1 four-phase set 11, 15..19),
 // [7] m-major tile order when the activation matrix is the larger operand (M > N: the encoder's GEMMs; on)
-int g_options[8] = {0, 2, 0, 1, 1, 0, 1, 1};
+// [8] stream-K scheduling for the merged-phase kernels where the cost model prefers it (variants 39..42, see the kernel),
+// [9] stream-K flavour: data-parallel rounds before the stream-K part: 1 = all but the last full round ("two-tile"), 0 = none
+int g_options[12] = {0, 2, 0, 1, 1, 0, 1, 1, 0, 1, 0, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -61,6 +65,12 @@ struct GemmArgs {
   int wide_io;     // 16-byte epilogue loads / stores (probe switch; on by default)
   const int32_t* m_dev;  // device-side row count (nullptr: M is exact)
   int m_dev_off;         // rows of the compact list handled by earlier launches
+  // stream-K launches (SK kernels): data-parallel rounds before the stream-K part, partial-accumulator slots
+  // (one per block), publish flags (one per block, + a timeout counter at [gridDim.x]) and this launch's flag value
+  int sk_full;
+  float* sk_ws;
+  unsigned* sk_flags;
+  unsigned sk_epoch;
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -587,9 +597,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 // RAW / WAR: same rules as above - a region is read one section after the wait + barrier that retired it, and restaged
 // no earlier than two sections after its last read by EITHER row (XB(t-1)'s set: read in the second load section of tile
 // t-1, restaged in the first of tile t; [XA | WA | WB](t): read in the first load section of tile t, restaged in the second).
-template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false, int PH = 4>
+// SK (stream-K, round 2): the grid is one block per CU (a multiple of 8) and the launch's work - tiles x K-tiles - is cut
+// into equal shares instead of whole tiles.  Block b (XCD b & 7 under round-robin dispatch, local index b >> 3) first
+// computes p.sk_full whole tiles like a persistent data-parallel kernel (tile b + r * grid: the K loops of a round stay
+// aligned across the chip, which is what lets concurrent tiles share operand panels in L2), then its 1/32 of the K-tiles
+// of the tiles its XCD has left: a contiguous range that starts and ends anywhere inside a tile.  A piece that does
+// not start at K-tile 0 ("contributor": at most one per block, and it is the block's FIRST stream-K piece) is written as
+// f32 accumulators to the block's slot and published with a release store of the launch's epoch; the block that owns the
+// tile's first K-tile ("owner": its LAST piece) adds the slots of the blocks that continue the tile, in a fixed order, and
+// runs the normal epilogue.  Every block gets the same number of K-tiles (+-1), so no CU idles through a partial last
+// round (2528 x 4096 x 28672: 160 tiles of 256 x 256 on 256 CUs; 2528 x 28672 x 4096: 4.375 rounds) - the chip is
+// power-limited, so the gain is a fraction of the idle share it removes (measured: profiles/r02_gemm_streamk_probe.txt).
+// Progress: owners wait only on blocks of higher index, a contribution never waits, and blocks are dispatched in index
+// order, so the wait ends as soon as the needed blocks are resident; a bounded spin (then a counted timeout and a wrong
+// tile, never a hung queue) guards the case of a device with < 9 free CUs.  Deterministic: fixed ranges, fixed sum order.
+template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false, int PH = 4, bool SK = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   static_assert(PH == 4 || (PH == 2 && NS == 2 && MODE == 0), "the merged-phase schedule is written for two buffer sets");
+  static_assert(!SK || (PH == 2 && !PERSIST), "stream-K is built on the merged-phase kernel");
   constexpr int BNW = 256;
   constexpr int MI = BM / 32, MA = (MI + 1) / 2, MB = MI - MA;
   constexpr int XA_ROWS = 2 * MA * 16, XB_ROWS = 2 * MB * 16;
@@ -636,8 +661,35 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       o += gridDim.x;
     }
   };
+  const int nk = p.K / BK;
+  int kbase = 0, nks = nk;        // this piece: K-tiles [kbase, kbase + nks) of the tile at (m0, n0)  (SK only: else the whole K)
+  // stream-K work list of this block (see the template comment)
+  const int sk_x = blockIdx.x & 7, sk_wl = blockIdx.x >> 3, sk_per = gridDim.x >> 3;   // XCD, index / blocks within the XCD
+  int sk_round = 0, sk_it = 0, sk_hi = 0, sk_lt = 0, sk_I = 0;
+  if (SK) {
+    const int n_x = (ntiles >> 3) + (sk_x < (ntiles & 7));       // tiles in this XCD's run of the dispatch order
+    sk_I = (n_x - p.sk_full * sk_per) * nk;                        // K-tiles left to this XCD after the data-parallel rounds
+    sk_it = (int)((long long)sk_wl * sk_I / sk_per);
+    sk_hi = (int)((long long)(sk_wl + 1) * sk_I / sk_per);
+  }
+  auto sk_next = [&]() {          // next piece of this block: sets m0, n0, kbase, nks
+    if (sk_round < p.sk_full) {
+      kbase = 0; nks = nk;
+      tile_origin(sk_round * (int)gridDim.x + (int)blockIdx.x, m0, n0);
+      ++sk_round;
+      return true;
+    }
+    if (sk_it >= sk_hi) return false;
+    sk_lt = sk_it / nk;
+    kbase = sk_it - sk_lt * nk;
+    nks = min(nk - kbase, sk_hi - sk_it);
+    sk_it += nks;
+    tile_origin(((p.sk_full * sk_per + sk_lt) << 3) + sk_x, m0, n0);
+    return true;
+  };
   int orig = blockIdx.x;
-  if (!next_tile(orig, m0, n0)) return;   // (before any barrier)
+  if (SK) { if (!sk_next()) return; }
+  else if (!next_tile(orig, m0, n0)) return;   // (before any barrier)
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -684,7 +736,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 
   auto dma = [&](const Slot& sl, int t, int set_idx) {   // set_idx = t % NS, tracked by the caller
     if (MODE == 2 && t >= NS) return;
-    glds16(sl.g + t * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_idx * SET));
+    glds16(sl.g + (SK ? kbase + t : t) * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_idx * SET));
   };
 #define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 // PRIO: who gets issue priority on a SIMD shared by a wave in its MFMA section and one in its load section.
@@ -717,12 +769,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   if (PRIO == 2) __builtin_amdgcn_s_setprio(1);            \
   __builtin_amdgcn_sched_barrier(0)
 
-  const int nk = p.K / BK;
   // prologue: REST(0), XB(0), REST(1), XB(1), ..., REST(NS-1)  (the steady-state issue order)
   auto issue_prologue = [&](const Slot (&sxb_)[N1], const Slot (&srest_)[N234]) {
 #pragma unroll
     for (int tt = 0; tt < NS; ++tt) {
-      if (tt < nk) {
+      if (tt < nks) {
 #pragma unroll
         for (int k = 0; k < N234; ++k) dma(srest_[k], tt, tt);
         if (tt < NS - 1) {
@@ -737,7 +788,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   for (;;) {   // one iteration per output tile (exactly one unless PERSIST)
   // K-tile 0 has landed when at most INFLIGHT DMA instructions are outstanding (in PERSIST mode the previous tile's
   // output stores sit in the same counter behind them: the bound on the total still bounds the loads)
-  if (nk >= NS) UVX_VMCNT(INFLIGHT);
+  if (nks >= NS) UVX_VMCNT(INFLIGHT);
   else UVX_VMCNT(0);
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
@@ -756,7 +807,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   typedef __attribute__((address_space(3))) unsigned lds_u32;
   unsigned long long tl[3] = {0ull, 0ull, 0ull};
   lds_u32* tl_base = (lds_u32*)(lds + O_STAGE + (PERSIST ? 8 * 2048 : 0) + w * TL_WAVE);
-  for (int t = 0; t < nk; ++t) {
+  for (int t = 0; t < nks; ++t) {
     const char* set = lds + cs * SET;
     const int ps = cs == 0 ? NS - 1 : cs - 1;   // (t + NS - 1) % NS
     bf16x8_t xa[MA][2], wa[2][2], wb[2][2];
@@ -773,7 +824,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int i = 0; i < MA; ++i)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xa_base + xo[kh] + i * 16 * 128);
-      if (t + 1 < nk) {
+      if (t + 1 < nks) {
 #pragma unroll
         for (int k = 0; k < N1; ++k) dma(sxb[k], t + 1, ps);
         UVX_VMCNT(N234 + N1);
@@ -798,7 +849,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xb_base + xo[kh] + i * 16 * 128);
-      if (t + 2 < nk) {
+      if (t + 2 < nks) {
 #pragma unroll
         for (int k = 0; k < N234; ++k) dma(srest[k], t + 2, cs);
         UVX_VMCNT(N234 + N1);
@@ -946,6 +997,56 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     if (t == 12345.678f) *reinterpret_cast<float*>(p.C) = t;
     return;
   }
+  if (SK) {
+    constexpr int SLOT_V4 = 4 * MI * 512;                       // float4 per block slot: [j][i][thread]
+    float4* slots = reinterpret_cast<float4*>(p.sk_ws);
+    if (kbase != 0) {   // contributor: partial sums to this block's slot, then publish
+      float4* slot = slots + (size_t)blockIdx.x * SLOT_V4 + tid;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) slot[(j * MI + i) * 512] = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+      __threadfence();                                            // each thread's stores are visible device-wide ...
+      __syncthreads();                                            // ... before thread 0 says so
+      if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, p.sk_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (nks != nk) {  // owner of a split tile: the blocks that continue it are the next ones of this XCD's list
+        const int tile_end = (sk_lt + 1) * nk;
+        for (int c = sk_wl + 1; c < sk_per; ++c) {
+          const int clo = (int)((long long)c * sk_I / sk_per), chi = (int)((long long)(c + 1) * sk_I / sk_per);
+          if (clo >= tile_end) break;
+          if (chi == clo) continue;                               // (an empty share contributes nothing)
+          const int g = (c << 3) + sk_x;
+          if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(p.sk_flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins > (1 << 21)) { atomicAdd(p.sk_flags + gridDim.x, 1u); break; }   // ~1 s: count it, do not hang
+            }
+          }
+          __syncthreads();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every wave: nothing below is served from a stale line
+          const float4* slot = slots + (size_t)g * SLOT_V4 + tid;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              const float4 v = slot[(j * MI + i) * 512];
+              acc[j][i][0] += v.x; acc[j][i][1] += v.y; acc[j][i][2] += v.z; acc[j][i][3] += v.w;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // MI loads in flight at a time: the accumulators already fill half the file
+          }
+        }
+      }
+      __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
+      store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
+    }
+    if (!sk_next()) break;
+    __syncthreads();     // the output stage is the next piece's operand buffer
+    fill_slots(sxb, srest);
+    issue_prologue(sxb, srest);
+    continue;
+  }
   if (!PERSIST) {
     __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
     store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
@@ -989,7 +1090,7 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 39;
+constexpr int kNumVariants = 43;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
@@ -1004,11 +1105,14 @@ const Variant kVariants[kNumVariants] = {
     // over the three-buffer 18, 128: +2...+5 %); fixed costs as the twins' except 192 (10.5 instead of 12: the in-situ table of the
     // first merged-phase run had 12000 x 3072 x 1024 on the 256 tile at 108 us where the 192 tile takes 87).
     {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.},
-    {256, 256, 0., 6.},     {192, 256, 0., 8.},      {160, 256, 0., 7.},     {128, 256, 0., 5.}};   // 35..38 = PERSISTENT merged-phase (probe)
+    {256, 256, 0., 6.},     {192, 256, 0., 8.},      {160, 256, 0., 7.},     {128, 256, 0., 5.},    // 35..38 = PERSISTENT merged-phase (probe)
+    // 39..42 = STREAM-K merged-phase {256,192,160,128} x 256 (see the kernel).  Cost: sk_cost() below, not variant_cost().
+    {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.}};
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
-constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34); }
+constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34) || (v >= 39 && v <= 42); }
+constexpr bool is_streamk(int v) { return v >= 39 && v <= 42; }
 bool variant_available(int v) {
 #ifdef UVX_PROBES
   return v >= 0 && v < kNumVariants;
@@ -1025,6 +1129,33 @@ double variant_cost(int v, int M, int N, int K, int batch) {
   const double rounds = floor(r) + (frac > 0. ? fmax(0.55, pow(frac, 0.6)) : 0.);
   return rounds * kVariants[v].bm * kVariants[v].bn * (K / 64.0 + kVariants[v].c) / kVariants[v].speed;
 }
+// Stream-K launch geometry: one block per CU; `full` data-parallel rounds, the rest of the tiles shared out by K-tiles.
+int sk_grid() {
+  static int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  return cus >= 64 && cus % 8 == 0 ? cus : 0;     // 0: stream-K unavailable (the XCD-local work lists need a multiple of 8)
+}
+int sk_full_rounds(long long tiles, int grid) {
+  if (tiles < grid) return 0;
+  const int rounds = (int)(tiles / grid);
+  return uvx::g_options[9] ? rounds - 1 : 0;
+}
+// time ~ (every block's share of the K-tiles + per-piece fixed costs) x tile area / speed.  A block runs `full` whole
+// tiles plus a share that touches 2 (sometimes 3) tiles: one more pipeline fill than the data-parallel kernel, plus writing /
+// re-reading one f32 partial (~2.5 K-tiles' worth of time on a 256 x 256 tile).  `kSkSlow`: with every CU busy the chip
+// clocks lower than through a partly filled round (power limit) - fitted to profiles/r02_gemm_streamk_probe.txt.
+constexpr double kSkSlow = 1.06, kSkFix = 2.5;
+double sk_cost(int v, int M, int N, int K, int grid) {
+  const Variant& V = kVariants[v];
+  const double tiles = (double)cdiv(M, V.bm) * cdiv(N, V.bn), nk = K / 64.0;
+  const double full = sk_full_rounds((long long)tiles, grid);
+  const double share = (tiles - full * grid) * nk / grid;          // K-tiles of the stream-K part, per block
+  const double pieces = share / nk + 1.0;                          // ~ pieces per block in the stream-K part
+  return (full * (nk + V.c) + share + pieces * V.c + kSkFix) * V.bm * V.bn / V.speed * kSkSlow;
+}
 int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
   int forced = uvx::g_gemm_variant;
   for (int i = 0; i < uvx::g_gemm_ovr_n; ++i)
@@ -1035,21 +1166,65 @@ int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
     if (cost_out) *cost_out = kVariants[forced].speed > 0. ? variant_cost(forced, M, N, K, batch) : 0.;
     return forced;
   }
+  const int skg = batch == 1 && uvx::g_options[8] && uvx::g_options[6] ? sk_grid() : 0;
   for (int v = 0; v < kNumVariants; ++v) {
     if (kVariants[v].speed <= 0. || !is_production(v)) continue;
     // option 6 (default 1): merged-phase kernels 31..34 replace their four-phase twins 11, 15..19 (0 = the round-1 set, for A/B)
     if (v != 0 && ((v >= 31) != (uvx::g_options[6] != 0))) continue;
-    const double cost = variant_cost(v, M, N, K, batch);
+    double cost;
+    if (is_streamk(v)) {
+      // (a launch whose tiles fill whole rounds has nothing to share out; tiny launches stay data-parallel)
+      const long long tiles = (long long)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn);
+      if (!skg || tiles % skg == 0 || tiles * (K / 64) < 4LL * skg) continue;
+      cost = sk_cost(v, M, N, K, skg);
+    } else {
+      cost = variant_cost(v, M, N, K, batch);
+    }
     if (cost < best) { best = cost; best_v = v; }
   }
   if (cost_out) *cost_out = best;
   return best_v;
 }
 
+// Stream-K scratch: per stream (launches on one stream are ordered, so one set of slots per stream is enough; two streams
+// never share one), allocated on first use and kept: grid x 512 threads x 128 f32 of partial sums (64 MB at 256 CUs) and
+// grid + 1 flags.  `epoch` is the value a contributor publishes in its flag: one per launch, never reused on the stream.
+struct SkScratch { float* ws = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; };
+std::mutex g_sk_mu;
+std::unordered_map<hipStream_t, SkScratch> g_sk_scratch;
+bool sk_acquire(hipStream_t st, int grid, GemmArgs& a) {
+  std::lock_guard<std::mutex> lock(g_sk_mu);
+  SkScratch& sc = g_sk_scratch[st];
+  if (!sc.ws) {
+    const size_t slot_bytes = (size_t)512 * 128 * sizeof(float);
+    void *w = nullptr, *f = nullptr;
+    if (hipMalloc(&w, slot_bytes * grid) != hipSuccess) return false;
+    if (hipMalloc(&f, sizeof(unsigned) * (grid + 1)) != hipSuccess || hipMemset(f, 0, sizeof(unsigned) * (grid + 1)) != hipSuccess) {
+      (void)hipFree(w);
+      return false;
+    }
+    sc.ws = (float*)w; sc.flags = (unsigned*)f;
+  }
+  a.sk_ws = sc.ws; a.sk_flags = sc.flags; a.sk_epoch = ++sc.epoch;
+  return true;
+}
+
 void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int batch) {
   a.M = M; a.N = N;
   a.tiles_m = cdiv(M, kVariants[variant].bm); a.tiles_n = cdiv(N, kVariants[variant].bn);
   dim3 grid(a.tiles_m * a.tiles_n, batch);
+  if (is_streamk(variant)) {
+    const int g = sk_grid();
+    // not a stream-K case after all (batched, device-side row count, no scratch): the data-parallel twin
+    if (batch != 1 || a.m_dev || !g || !sk_acquire(st, g, a)) { launch_variant(st, variant - 8, a, M, N, batch); return; }
+    a.sk_full = sk_full_rounds((long long)a.tiles_m * a.tiles_n, g);
+    const dim3 sgrid(g);
+    if (variant == 39) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2, true>), sgrid, dim3(512), 0, st, a);
+    else if (variant == 40) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2, true>), sgrid, dim3(512), 0, st, a);
+    else if (variant == 41) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2, true>), sgrid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2, true>), sgrid, dim3(512), 0, st, a);
+    return;
+  }
   switch (variant) {
     case 0: hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, st, a); break;
     case 11: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<256>, grid, dim3(512), 0, st, a); break;
@@ -1109,6 +1284,24 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
 
 }  // namespace
 
+// Stream-K spin waits that gave up (see the kernel), summed over every stream's scratch; synchronises the device.  0 on a
+// healthy run - anything else means wrong output tiles in some stream-K launch since the last call (the counters are reset).
+int uvx::gemm_streamk_timeouts() {
+  std::lock_guard<std::mutex> lock(g_sk_mu);
+  const int g = sk_grid();
+  long long total = 0;
+  if (!g || g_sk_scratch.empty()) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  for (auto& kv : g_sk_scratch) {
+    unsigned n = 0;
+    if (!kv.second.flags) continue;
+    if (hipMemcpy(&n, kv.second.flags + g, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (n && hipMemset(kv.second.flags + g, 0, sizeof(n)) != hipSuccess) return -1;
+    total += n;
+  }
+  return (int)(total > 0x7fffffff ? 0x7fffffff : total);
+}
+
 int uvx::gemm_pick_variant(int M, int N, int K, int batch) { return pick_variant(M, N, K, batch > 0 ? batch : 1); }
 
 int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
@@ -1132,6 +1325,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.res_prefetch = uvx::g_options[5];
   a.m_major = uvx::g_options[7] && d.M > d.N && (d.batch <= 1);
   a.m_dev = d.m_dev; a.m_dev_off = d.m_dev_off;
+  a.sk_full = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0;
   UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
   UVX_CHECK(d.swiglu != 2 || (d.N % 16 == 0 && d.ldc >= 2 * d.N && d.ldc2 >= 2 * d.N), UVX_ERR_INVALID,
@@ -1150,7 +1344,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   const int tm = cdiv(d.M, V.bm), tn = cdiv(d.N, V.bn);
   const long long tiles = (long long)tm * tn;
   int n_main = d.N, tail_variant = -1;
-  if (batch == 1 && uvx::g_gemm_split && tiles > 256 && tiles % 256 != 0) {
+  if (batch == 1 && uvx::g_gemm_split && !is_streamk(variant) && tiles > 256 && tiles % 256 != 0) {
     const int full_rounds = (int)(tiles / 256);
     const int main_panels = (int)((full_rounds * 256LL) / tm);           // whole weight panels in the full rounds
     const int tail_n = d.N - main_panels * V.bn;

@@ -47,8 +47,9 @@ struct GemmDesc {
 
 extern int g_gemm_variant;
 extern int g_gemm_split;
-extern int g_options[8];
+extern int g_options[12];
 int gemm_pick_variant(int M, int N, int K, int batch);  // host only: the tile variant the cost model picks
+int gemm_streamk_timeouts();   // stream-K waits that gave up since the last call (0 = healthy); synchronises
 extern int g_gemm_ovr_n;
 extern int g_gemm_ovr[32][4];
 // bf16 operands, f32 accumulate (MFMA 16x16x32).
