@@ -3,6 +3,8 @@
 flavours (option 9), bit-identical repeats (fixed ranges and a fixed order of partial sums), bit-identical or 1-ulp
 agreement with the data-parallel twin, and the give-up counter at zero.
 usage: gpu_gemm_streamk_check.py [variants, default 39,40,41,42]"""
+import os
+os.environ.setdefault("UVX_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ultravox_amd", "libuvx_probes.so"))  # probe tile variants live in the probes build
 import sys
 import torch
 from ultravox_amd import ops, _lib

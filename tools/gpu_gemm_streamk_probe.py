@@ -1,6 +1,8 @@
 """GPU probe: stream-K variants (39..42) next to their data-parallel twins (31..34) and torch (hipBLASLt), cold weights
 (same method as gpu_gemm_cold_probe.py: every launch reads the next weight matrix of a > 1 GB pool).  TF/s.
 usage: gpu_gemm_streamk_probe.py [llm|enc]"""
+import os
+os.environ.setdefault("UVX_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ultravox_amd", "libuvx_probes.so"))  # probe tile variants live in the probes build
 import sys
 import torch
 from ultravox_amd import ops, _lib

@@ -35,7 +35,7 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // 98.2 / 98.6 ms per step with it, 97.5 / 97.6 without - the 2 * MI extra live uint4 per lane cost more than the hidden latency),
 // [6] tile picker uses the merged-phase kernels 31..34 (on; 0 = the round-1 four-phase set 11, 15..19),
 // [7] m-major tile order when the activation matrix is the larger operand (M > N: the encoder's GEMMs; on)
-// [8] stream-K scheduling for the merged-phase kernels where the cost model prefers it (variants 39..42, see the kernel),
+// [8] (probe builds) let the picker choose the stream-K variants 39..42 (off: measured slower, see the kernel),
 // [9] stream-K flavour: data-parallel rounds before the stream-K part: 1 = all but the last full round ("two-tile"), 0 = none
 int g_options[12] = {0, 2, 0, 1, 1, 0, 1, 1, 0, 1, 0, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
@@ -607,7 +607,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 // tile's first K-tile ("owner": its LAST piece) adds the slots of the blocks that continue the tile, in a fixed order, and
 // runs the normal epilogue.  Every block gets the same number of K-tiles (+-1), so no CU idles through a partial last
 // round (2528 x 4096 x 28672: 160 tiles of 256 x 256 on 256 CUs; 2528 x 28672 x 4096: 4.375 rounds) - the chip is
-// power-limited, so the gain is a fraction of the idle share it removes (measured: profiles/r02_gemm_streamk_probe.txt).
+// power-limited, so the gain could only be a fraction of the idle share it removes.
+// MEASURED (profiles/r02_gemm_streamk_probe.txt): correct and deterministic, but 5...55 % SLOWER than the data-parallel twin
+// on every C2 shape, so these are probe builds (39..42, libuvx_probes.so), never picked.  Two costs the model above leaves
+// out: (1) blocks whose K loops are not aligned stop sharing operand panels in L2 - a 256 x 256 tile has 128 flop per
+// operand byte, i.e. 10 TB/s at 1.3 PFLOP/s unless concurrent tiles hit each other's panels; (2) every block writes and
+// another re-reads a 256 KB f32 partial through device-scope release / acquire (L2 write-back + invalidate): 128 MB per
+// launch, six times the output of 2528 x 4096.
 // Progress: owners wait only on blocks of higher index, a contribution never waits, and blocks are dispatched in index
 // order, so the wait ends as soon as the needed blocks are resident; a bounded spin (then a counted timeout and a wrong
 // tile, never a hung queue) guards the case of a device with < 9 free CUs.  Deterministic: fixed ranges, fixed sum order.
@@ -1106,12 +1112,12 @@ const Variant kVariants[kNumVariants] = {
     // first merged-phase run had 12000 x 3072 x 1024 on the 256 tile at 108 us where the 192 tile takes 87).
     {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.},
     {256, 256, 0., 6.},     {192, 256, 0., 8.},      {160, 256, 0., 7.},     {128, 256, 0., 5.},    // 35..38 = PERSISTENT merged-phase (probe)
-    // 39..42 = STREAM-K merged-phase {256,192,160,128} x 256 (see the kernel).  Cost: sk_cost() below, not variant_cost().
+    // 39..42 = STREAM-K merged-phase {256,192,160,128} x 256 (probe builds; see the kernel).  Cost: sk_cost() below.
     {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.}};
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
-constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34) || (v >= 39 && v <= 42); }
+constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34); }
 constexpr bool is_streamk(int v) { return v >= 39 && v <= 42; }
 bool variant_available(int v) {
 #ifdef UVX_PROBES
@@ -1166,9 +1172,13 @@ int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
     if (cost_out) *cost_out = kVariants[forced].speed > 0. ? variant_cost(forced, M, N, K, batch) : 0.;
     return forced;
   }
+#ifdef UVX_PROBES
   const int skg = batch == 1 && uvx::g_options[8] && uvx::g_options[6] ? sk_grid() : 0;
+#else
+  const int skg = 0;
+#endif
   for (int v = 0; v < kNumVariants; ++v) {
-    if (kVariants[v].speed <= 0. || !is_production(v)) continue;
+    if (kVariants[v].speed <= 0. || !(is_production(v) || (skg && is_streamk(v)))) continue;
     // option 6 (default 1): merged-phase kernels 31..34 replace their four-phase twins 11, 15..19 (0 = the round-1 set, for A/B)
     if (v != 0 && ((v >= 31) != (uvx::g_options[6] != 0))) continue;
     double cost;
@@ -1213,6 +1223,7 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
   a.M = M; a.N = N;
   a.tiles_m = cdiv(M, kVariants[variant].bm); a.tiles_n = cdiv(N, kVariants[variant].bn);
   dim3 grid(a.tiles_m * a.tiles_n, batch);
+#ifdef UVX_PROBES
   if (is_streamk(variant)) {
     const int g = sk_grid();
     // not a stream-K case after all (batched, device-side row count, no scratch): the data-parallel twin
@@ -1225,6 +1236,7 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     else hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2, true>), sgrid, dim3(512), 0, st, a);
     return;
   }
+#endif
   switch (variant) {
     case 0: hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, st, a); break;
     case 11: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<256>, grid, dim3(512), 0, st, a); break;
