@@ -254,6 +254,34 @@ def test_attention_backward(D, Hq, Hkv, T, causal, block):
         assert dk[1, int(kv_len[1]):].abs().max().item() == 0 and dv[1, int(kv_len[1]):].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("T,Hq,Hkv", [(316, 8, 2), (200, 4, 4), (129, 4, 1)])
+def test_attention_backward_causal_left_and_right_padding(T, Hq, Hkv):
+    """The LLM's backward kernels (head_dim 128: 128 keys / 128 queries per block, two-deep prefetch) with the collator's
+    padding on both sides: sequence 1 starts at key 23 (left padding) and sequence 2 ends 41 keys early (right padding);
+    block edges at 128 fall inside all three lengths.  Keys outside the valid range get exactly zero gradient."""
+    torch.manual_seed(17)
+    B, D = 3, 128
+    q = bf(torch.randn(B, T, Hq, D, device=DEV))
+    k = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    v = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    do = bf(torch.randn(B, T, Hq * D, device=DEV))
+    kv_start = torch.tensor([0, 23, 0], device=DEV, dtype=torch.int32)
+    kv_len = torch.tensor([T, T, T - 41], device=DEV, dtype=torch.int32)
+    o, lse = ops().attention(q, k, v, causal=True, kv_start=kv_start, kv_len=kv_len)
+    dq, dk, dv = ops().attention_bwd(q, k, v, o, lse, do, causal=True, kv_start=kv_start, kv_len=kv_len)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref, ok = sdpa_ref(qr, kr, vr, True, 0, D ** -0.5, kv_start=kv_start, kv_len=kv_len)
+    valid = ok.any(-1)[:, 0]                                        # query rows that see at least one key
+    m = valid[:, :, None].expand(B, T, Hq * D)
+    ref.backward(do.float() * m)         # (rows that see no key: the kernels' output there is unspecified, as in SDPA)
+    dqm = dq.float() * valid[:, :, None, None]
+    assert rel_l2(dqm, qr.grad) < 2e-2 and rel_l2(dk, kr.grad) < 2e-2 and rel_l2(dv, vr.grad) < 2e-2
+    assert dk[1, :23].abs().max().item() == 0 and dv[1, :23].abs().max().item() == 0
+    assert dk[2, T - 41:].abs().max().item() == 0 and dv[2, T - 41:].abs().max().item() == 0
+    again = ops().attention_bwd(q, k, v, o, lse, do, causal=True, kv_start=kv_start, kv_len=kv_len)
+    assert all(torch.equal(a, b) for a, b in zip((dq, dk, dv), again))          # fixed reduction order
+
+
 # ------------------------------------------------------------------ loss / optimizer / merge
 def test_ce_loss_and_gradient():
     torch.manual_seed(8)

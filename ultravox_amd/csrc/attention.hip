@@ -58,10 +58,11 @@ __device__ __forceinline__ bf16x8_t pack8(const float* lo, const float* hi) {
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
+// (bitwise, not short-circuit: hipcc then emits compares + selects instead of a chain of exec-mask branches per element;
+// the latency-block test - two integer divisions - sits behind a wave-uniform branch)
 __device__ __forceinline__ bool key_ok(int key, int q, int k_lo, int k_hi, int causal, int block) {
-  bool ok = key >= k_lo && key < k_hi;
-  if (causal) ok = ok && key <= q;
-  if (block > 0) ok = ok && (key / block) <= (q / block);
+  bool ok = (key >= k_lo) & (key < k_hi) & ((causal == 0) | (key <= q));
+  if (block > 0) ok = ok & ((key / block) <= (q / block));
   return ok;
 }
 
@@ -87,47 +88,49 @@ __device__ __forceinline__ int tr_off8(int row, int c8) {
 // of tile j and written to the other LDS buffer after it, so HBM/L2 latency hides under compute and
 // there is one barrier per tile.
 // natural tile: rows [r0, r0+R) of a [*, ld] matrix, D columns (rows clamped to rmax-1).
-template <int D, int R>
-struct NatRegs { u16x8_t v[R * (D / 8) / 256]; };
-template <int D, int R>
-__device__ __forceinline__ void load_nat(NatRegs<D, R>& g, const bf16_t* base, long long ld, int r0, int rmax, int tid) {
-  constexpr int NCH = D / 8, N = R * NCH / 256;
+template <int D, int R, int NT = 256>
+struct NatRegs { u16x8_t v[R * (D / 8) / NT]; };
+template <int D, int R, int NT = 256>
+__device__ __forceinline__ void load_nat(NatRegs<D, R, NT>& g, const bf16_t* base, long long ld, int r0, int rmax, int tid) {
+  constexpr int NCH = D / 8, N = R * NCH / NT;
+  static_assert(N >= 1 && N * NT == R * NCH, "tile does not divide over the block's threads");
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const int i = tid + k * 256, r = i / NCH, c = i % NCH;
+    const int i = tid + k * NT, r = i / NCH, c = i % NCH;
     // UNCONDITIONAL load of a clamped row: a fixed number of VMEM ops per iteration lets hipcc place counted
     // s_waitcnt vmcnt(N) instead of draining the prefetch with vmcnt(0); rows >= rmax repeat row rmax-1 and are
     // always masked out by the callers (they are finite, so 0 * x stays 0)
     g.v[k] = *reinterpret_cast<const u16x8_t*>(base + (long long)min(r0 + r, rmax - 1) * ld + c * 8);
   }
 }
-template <int D, int R>
-__device__ __forceinline__ void store_nat(char* lds, const NatRegs<D, R>& g, int tid) {
-  constexpr int NCH = D / 8, N = R * NCH / 256;
+template <int D, int R, int NT = 256>
+__device__ __forceinline__ void store_nat(char* lds, const NatRegs<D, R, NT>& g, int tid) {
+  constexpr int NCH = D / 8, N = R * NCH / NT;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const int i = tid + k * 256, r = i / NCH, c = i % NCH;
+    const int i = tid + k * NT, r = i / NCH, c = i % NCH;
     *reinterpret_cast<u16x8_t*>(lds + nat_off<D>(r, c)) = g.v[k];
   }
 }
 // transposed tile: D rows, W keys starting at t0 of a [D, Tp] matrix (zero padded in memory).
-template <int D, int W>
-struct TrRegs { u16x8_t v[D * (W / 8) / 256]; };
-template <int D, int W>
-__device__ __forceinline__ void load_tr(TrRegs<D, W>& g, const bf16_t* base, int Tp, int t0, int tid) {
-  constexpr int NC = W / 8, N = D * NC / 256;
+template <int D, int W, int NT = 256>
+struct TrRegs { u16x8_t v[D * (W / 8) / NT]; };
+template <int D, int W, int NT = 256>
+__device__ __forceinline__ void load_tr(TrRegs<D, W, NT>& g, const bf16_t* base, int Tp, int t0, int tid) {
+  constexpr int NC = W / 8, N = D * NC / NT;
+  static_assert(N >= 1 && N * NT == D * NC, "tile does not divide over the block's threads");
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const int i = tid + k * 256, r = i / NC, c = i % NC;
+    const int i = tid + k * NT, r = i / NC, c = i % NC;
     g.v[k] = *reinterpret_cast<const u16x8_t*>(base + (long long)r * Tp + t0 + c * 8);
   }
 }
-template <int D, int W>
-__device__ __forceinline__ void store_tr(char* lds, const TrRegs<D, W>& g, int tid) {
-  constexpr int NC = W / 8, N = D * NC / 256;
+template <int D, int W, int NT = 256>
+__device__ __forceinline__ void store_tr(char* lds, const TrRegs<D, W, NT>& g, int tid) {
+  constexpr int NC = W / 8, N = D * NC / NT;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const int i = tid + k * 256, r = i / NC, c = i % NC;
+    const int i = tid + k * NT, r = i / NC, c = i % NC;
     const int sw = tr_sw<W>(r);
     u16x8_t v = g.v[k];
     if (sw & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
@@ -315,10 +318,14 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 }
 
 // =================================== backward: dK, dV ===================================
-// Block = (key block of 64, kv head, batch); wave w owns keys kb0 + w*16 .. +16.  Loops over the
-// query heads of the GQA group and over 32-query steps.
-template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
+// Block = (key block of NT/4, kv head, batch): NT/64 waves, wave w owns keys kb0 + w*16 .. +16.  Loops over the
+// query heads of the GQA group and over 32-query steps.  NT = 512 (head_dim 128: the LLM) halves the staging traffic and
+// the number of steps per MFMA - every staged Q / dO tile feeds 128 keys instead of 64 - and halves the staging registers
+// per thread, which is what makes room for the second prefetch set below; 8 waves per CU either way.
+template <int D, int NT>
+__global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
+  constexpr bool DEEP = D <= 128;   // two-deep prefetch (head_dim 256 has no registers left for a second staging set)
+  constexpr int KB = NT / 4;        // keys per block
   constexpr int KS = D / 32, DT = D / 16;
   constexpr int TILE = 32 * D * 2;
   __shared__ __attribute__((aligned(16))) char ldsAll[8 * TILE + 2 * 64 * 4];  // [buf][Q | dO | Q^T | dO^T], then [buf][lse | delta]
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
   // writes f32 partials that gqa_reduce_k sums in a fixed order; without it the block loops over its group.
   const int grp_all = p.Hq / p.Hkv;
   const bool split = p.dkv_part != nullptr;
-  const int b = blockIdx.z, kb0 = blockIdx.x * 64;
+  const int b = blockIdx.z, kb0 = blockIdx.x * KB;
   const int hk = split ? blockIdx.y / grp_all : blockIdx.y;
   const int h_first = split ? blockIdx.y : hk * grp_all;
   const int grp = split ? 1 : grp_all;
@@ -359,89 +366,121 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
   if (p.block > 0) q_begin = max(q_begin, (kb0 / p.block) * p.block);
   q_begin = (q_begin / 32) * 32;
 
-  // flattened (head-in-group, 32-query step) iteration space, software pipelined like the forward
+  // flattened (head-in-group, 32-query step) iteration space, software pipelined TWO steps deep: the global loads of step
+  // it + 2 are issued before the MFMA work of step it and written to LDS after the work of step it + 1 (two register
+  // sets, alternating), so a load has two whole steps to land - one step (~0.5 us of issue) does not cover an L2 / HBM
+  // round trip at T = 316, and the kernel was measured latency-bound (4.7 us per step at 2 blocks per CU).
   const int nq = q_begin < p.T ? (p.T - q_begin + 31) / 32 : 0;
   const int n_it = grp * nq;
-  NatRegs<D, 32> qreg, doreg;
-  TrRegs<D, 32> qtreg, dotreg;
-  float lreg = 0.f, dlreg = 0.f;
-  auto issue = [&](int it) {
+  struct StepRegs { NatRegs<D, 32, NT> q, d_o; TrRegs<D, 32, NT> qt, dot; float l, dl; };
+  StepRegs r0, r1;
+  auto issue = [&](StepRegs& r, int it) {
+    it = min(it, n_it - 1);      // past the end: re-load the last step (branch-free, static VMEM count; never committed to a live buffer)
     const int h = h_first + it / nq, qs = q_begin + (it % nq) * 32;
-    load_nat<D, 32>(qreg, p.q + (long long)b * p.T * p.ldq + h * D, p.ldq, qs, p.T, tid);
-    load_nat<D, 32>(doreg, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
-    load_tr<D, 32>(qtreg, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
-    load_tr<D, 32>(dotreg, p.dot + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
+    load_nat<D, 32, NT>(r.q, p.q + (long long)b * p.T * p.ldq + h * D, p.ldq, qs, p.T, tid);
+    load_nat<D, 32, NT>(r.d_o, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
+    load_tr<D, 32, NT>(r.qt, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
+    load_tr<D, 32, NT>(r.dot, p.dot + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
     {  // every thread loads (clamped index, branch-free: keeps the per-iteration VMEM count static);
        // queries >= T are masked by the consumers
       const int q = min(qs + (tid & 31), p.T - 1);
-      lreg = p.lse[((long long)b * p.Hq + h) * p.T + q];
-      dlreg = p.delta[((long long)b * p.Hq + h) * p.T + q];
+      r.l = p.lse[((long long)b * p.Hq + h) * p.T + q];
+      r.dl = p.delta[((long long)b * p.Hq + h) * p.T + q];
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](const StepRegs& r, int buf) {
     char* base = ldsAll + buf * 4 * TILE;
-    store_nat<D, 32>(base, qreg, tid);
-    store_nat<D, 32>(base + TILE, doreg, tid);
-    store_tr<D, 32>(base + 2 * TILE, qtreg, tid);
-    store_tr<D, 32>(base + 3 * TILE, dotreg, tid);
-    if (tid < 32) { ldsStat[buf * 64 + tid] = lreg; ldsStat[buf * 64 + 32 + tid] = dlreg; }
+    store_nat<D, 32, NT>(base, r.q, tid);
+    store_nat<D, 32, NT>(base + TILE, r.d_o, tid);
+    store_tr<D, 32, NT>(base + 2 * TILE, r.qt, tid);
+    store_tr<D, 32, NT>(base + 3 * TILE, r.dot, tid);
+    if (tid < 32) { ldsStat[buf * 64 + tid] = r.l; ldsStat[buf * 64 + 32 + tid] = r.dl; }
   };
-  if (n_it > 0) { issue(0); commit(0); }
-  __syncthreads();
-  {
-    for (int it = 0; it < n_it; ++it) {
-      const int cur = it & 1;
-      const int qs = q_begin + (it % nq) * 32;
-      const char* ldsQ = ldsAll + cur * 4 * TILE;
-      const char* ldsDO = ldsQ + TILE;
-      const char* ldsQT = ldsQ + 2 * TILE;
-      const char* ldsDOT = ldsQ + 3 * TILE;
-      const float* ldsL = ldsStat + cur * 64;
-      const float* ldsDl = ldsL + 32;
-      issue(it + 1 < n_it ? it + 1 : it);
-
-      // S[q][key] and dP[q][key] for the two 16-query tiles: A = Q / dO rows, B = K / V fragments
-      f32x4_t s[2], dp[2];
+  auto compute = [&](int it, int cur) {
+    const int qs = q_begin + (it % nq) * 32;
+    const char* ldsQ = ldsAll + cur * 4 * TILE;
+    const char* ldsDO = ldsQ + TILE;
+    const char* ldsQT = ldsQ + 2 * TILE;
+    const char* ldsDOT = ldsQ + 3 * TILE;
+    const float* ldsL = ldsStat + cur * 64;
+    const float* ldsDl = ldsL + 32;
+    // S[q][key] and dP[q][key] for the two 16-query tiles: A = Q / dO rows, B = K / V fragments
+    f32x4_t s[2], dp[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 2; ++t) {
+      s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8_t a = lds_b128(ldsQ + nat_off<D>(t * 16 + fr, ks * 4 + g));
-          const bf16x8_t c = lds_b128(ldsDO + nat_off<D>(t * 16 + fr, ks * 4 + g));
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kf[ks], s[t], 0, 0, 0);
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, vf[ks], dp[t], 0, 0, 0);
-        }
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t a = lds_b128(ldsQ + nat_off<D>(t * 16 + fr, ks * 4 + g));
+        const bf16x8_t c = lds_b128(ldsDO + nat_off<D>(t * 16 + fr, ks * 4 + g));
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kf[ks], s[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, vf[ks], dp[t], 0, 0, 0);
       }
-      // accumulator element e of tile t: q = qs + t*16 + g*4 + e, key = this lane's key
-      float pr[2][4], ds[2][4];
-      const int key_w0 = kb0 + w * 16;  // this wave's 16 keys
-      bool need_mask = key_w0 < k_lo || key_w0 + 16 > k_hi || qs + 32 > p.T;
-      if (p.causal) need_mask = need_mask || key_w0 + 15 > qs;
-      if (p.block > 0) need_mask = need_mask || (key_w0 + 15) / p.block > qs / p.block;
+    }
+    // accumulator element e of tile t: q = qs + t*16 + g*4 + e, key = this lane's key
+    float pr[2][4], ds[2][4];
+    const int key_w0 = kb0 + w * 16;  // this wave's 16 keys
+    bool need_mask = key_w0 < k_lo || key_w0 + 16 > k_hi || qs + 32 > p.T;
+    if (p.causal) need_mask = need_mask || key_w0 + 15 > qs;
+    if (p.block > 0) need_mask = need_mask || (key_w0 + 15) / p.block > qs / p.block;
+    unsigned okbits = 0xffu;          // bit t*4 + e: the (query, key) pair of that accumulator element takes part
+    if (need_mask) {
+      okbits = 0u;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int ql = t * 16 + g * 4 + e;
-          const int q = qs + ql;
-          bool ok = true;
-          if (need_mask) ok = q < p.T && key_ok(key, q, k_lo, k_hi, p.causal, p.block);
-          const float pv = ok ? __builtin_amdgcn_exp2f(s[t][e] * p.sc - ldsL[ql]) : 0.f;
-          pr[t][e] = pv;
-          ds[t][e] = pv * (dp[t][e] - ldsDl[ql]);
+          const int q = qs + t * 16 + g * 4 + e;
+          okbits |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block)) << (t * 4 + e);
         }
-      const bf16x8_t pB = pack8(pr[0], pr[1]);   // B operand: slot (g, s) <-> q = qs + 16*(s>>2) + 4*g + (s&3)
-      const bf16x8_t dsB = pack8(ds[0], ds[1]);
+    }
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const int row = d * 16 + fr;
-        const bf16x8_t a = lds_2xb64(ldsDOT + tr_off8<32>(row, g), ldsDOT + tr_off8<32>(row, 4 + g));
-        const bf16x8_t c = lds_2xb64(ldsQT + tr_off8<32>(row, g), ldsQT + tr_off8<32>(row, 4 + g));
-        acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB, acc_dv[d], 0, 0, 0);
-        acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB, acc_dk[d], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) {
+      const float4 l4 = *reinterpret_cast<const float4*>(ldsL + t * 16 + g * 4);      // this lane's four queries of the tile
+      const float4 d4 = *reinterpret_cast<const float4*>(ldsDl + t * 16 + g * 4);
+      const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ev = __builtin_amdgcn_exp2f(s[t][e] * p.sc - lq[e]);
+        const float pv = (okbits >> (t * 4 + e)) & 1u ? ev : 0.f;
+        pr[t][e] = pv;
+        ds[t][e] = pv * (dp[t][e] - dq[e]);
       }
-      commit(cur ^ 1);
+    }
+    const bf16x8_t pB = pack8(pr[0], pr[1]);   // B operand: slot (g, s) <-> q = qs + 16*(s>>2) + 4*g + (s&3)
+    const bf16x8_t dsB = pack8(ds[0], ds[1]);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const int row = d * 16 + fr;
+      const bf16x8_t a = lds_2xb64(ldsDOT + tr_off8<32>(row, g), ldsDOT + tr_off8<32>(row, 4 + g));
+      const bf16x8_t c = lds_2xb64(ldsQT + tr_off8<32>(row, g), ldsQT + tr_off8<32>(row, 4 + g));
+      acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB, acc_dv[d], 0, 0, 0);
+      acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB, acc_dk[d], 0, 0, 0);
+    }
+  };
+  if (n_it > 0) {
+    issue(r0, 0);
+    commit(r0, 0);
+    if (DEEP) issue(r1, 1);
+  }
+  __syncthreads();
+  if (DEEP) {
+    for (int it = 0; it < n_it; it += 2) {
+      issue(r0, it + 2);           // buffer 0 holds step it; r1 holds step it + 1 (in flight)
+      compute(it, 0);
+      commit(r1, 1);
+      __syncthreads();
+      if (it + 1 >= n_it) break;
+      issue(r1, it + 3);           // buffer 1 holds step it + 1; r0 holds step it + 2 (in flight)
+      compute(it + 1, 1);
+      commit(r0, 0);
+      __syncthreads();
+    }
+  } else {                         // head_dim 256: one register set, one step ahead
+    for (int it = 0; it < n_it; ++it) {
+      issue(r0, it + 1);
+      compute(it, it & 1);
+      commit(r0, (it & 1) ^ 1);
       __syncthreads();
     }
   }
@@ -471,9 +510,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_k(AttnArgs p) {
 }
 
 // =================================== backward: dQ ===================================
-// Block = (query block of 64, head, batch); wave w owns queries qb0 + w*16 .. +16; loops over 32-key steps.
-template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
+// Block = (query block of NT/4, head, batch): NT/64 waves, wave w owns queries qb0 + w*16 .. +16; loops over 32-key steps.
+// (NT = 512 for head_dim 128, as in the dK/dV kernel: every staged K / V tile feeds 128 queries.)
+template <int D, int NT>
+__global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
+  constexpr bool DEEP = D <= 128;
+  constexpr int QB = NT / 4;        // queries per block
   constexpr int KS = D / 32, DT = D / 16;
   constexpr int TILE = 32 * D * 2;
   __shared__ __attribute__((aligned(16))) char ldsAll[6 * TILE];  // [buf][K | V | K^T]
@@ -481,7 +523,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
-  const int qb0 = blockIdx.x * 64;
+  const int qb0 = blockIdx.x * QB;
   const int q = qb0 + w * 16 + fr;
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
@@ -514,34 +556,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
   for (int d = 0; d < DT; ++d) acc[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   int kend = p.T;
-  if (p.causal) kend = min(kend, qb0 + 64);
-  if (p.block > 0) kend = min(kend, ((qb0 + 63) / p.block + 1) * p.block);
+  if (p.causal) kend = min(kend, qb0 + QB);
+  if (p.block > 0) kend = min(kend, ((qb0 + QB - 1) / p.block + 1) * p.block);
   kend = min(kend, k_hi);
   const bf16_t* kbase = p.k + (long long)b * p.T * p.ldk + hk * D;
   const bf16_t* vbase = p.v + (long long)b * p.T * p.ldv + hk * D;
   const bf16_t* ktbase = p.kt + ((long long)b * p.Hkv + hk) * D * p.Tp;
 
-  NatRegs<D, 32> kreg, vreg;
-  TrRegs<D, 32> ktreg;
+  // key steps of 32, software pipelined two steps deep like the dK/dV kernel (two register sets, alternating)
+  struct StepRegs { NatRegs<D, 32, NT> k, v; TrRegs<D, 32, NT> kt; };
+  StepRegs r0, r1;
   const int k_begin = (k_lo / 32) * 32;
-  auto issue = [&](int ks0) {
-    load_nat<D, 32>(kreg, kbase, p.ldk, ks0, p.T, tid);
-    load_nat<D, 32>(vreg, vbase, p.ldv, ks0, p.T, tid);
-    load_tr<D, 32>(ktreg, ktbase, p.Tp, ks0, tid);
+  const int n_it = k_begin < kend ? (kend - k_begin + 31) / 32 : 0;
+  auto issue = [&](StepRegs& r, int it) {
+    const int ks0 = k_begin + min(it, n_it - 1) * 32;   // past the end: re-load the last step (static VMEM count)
+    load_nat<D, 32, NT>(r.k, kbase, p.ldk, ks0, p.T, tid);
+    load_nat<D, 32, NT>(r.v, vbase, p.ldv, ks0, p.T, tid);
+    load_tr<D, 32, NT>(r.kt, ktbase, p.Tp, ks0, tid);
   };
-  auto commit = [&](int buf) {
-    store_nat<D, 32>(ldsAll + buf * 3 * TILE, kreg, tid);
-    store_nat<D, 32>(ldsAll + buf * 3 * TILE + TILE, vreg, tid);
-    store_tr<D, 32>(ldsAll + buf * 3 * TILE + 2 * TILE, ktreg, tid);
+  auto commit = [&](const StepRegs& r, int buf) {
+    store_nat<D, 32, NT>(ldsAll + buf * 3 * TILE, r.k, tid);
+    store_nat<D, 32, NT>(ldsAll + buf * 3 * TILE + TILE, r.v, tid);
+    store_tr<D, 32, NT>(ldsAll + buf * 3 * TILE + 2 * TILE, r.kt, tid);
   };
-  if (k_begin < kend) { issue(k_begin); commit(0); }
-  __syncthreads();
-  int cur = 0;
-  for (int ks0 = k_begin; ks0 < kend; ks0 += 32, cur ^= 1) {
+  auto compute = [&](int it, int cur) {
+    const int ks0 = k_begin + it * 32;
     const char* ldsK = ldsAll + cur * 3 * TILE;
     const char* ldsV = ldsK + TILE;
     const char* ldsKT = ldsK + 2 * TILE;
-    issue(ks0 + 32 < kend ? ks0 + 32 : ks0);
     f32x4_t s[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -559,14 +601,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
     bool need_mask = ks0 < k_lo || ks0 + 32 > k_hi || q_w0 + 16 > p.T;
     if (p.causal) need_mask = need_mask || ks0 + 31 > q_w0;
     if (p.block > 0) need_mask = need_mask || (ks0 + 31) / p.block > q_w0 / p.block;
+    unsigned okbits = 0xffu;          // bit t*4 + e: the (key, query) pair of that accumulator element takes part
+    if (need_mask) {
+      okbits = 0u;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = ks0 + t * 16 + g * 4 + e;
+          okbits |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block)) << (t * 4 + e);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int key = ks0 + t * 16 + g * 4 + e;
-        bool ok = true;
-        if (need_mask) ok = q < p.T && key_ok(key, q, k_lo, k_hi, p.causal, p.block);
-        const float pv = ok ? __builtin_amdgcn_exp2f(s[t][e] * p.sc - lse) : 0.f;
+        const float ev = __builtin_amdgcn_exp2f(s[t][e] * p.sc - lse);
+        const float pv = (okbits >> (t * 4 + e)) & 1u ? ev : 0.f;
         ds[t][e] = pv * (dp[t][e] - dl);
       }
     const bf16x8_t dsB = pack8(ds[0], ds[1]);
@@ -576,8 +627,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(AttnArgs p) {
       const bf16x8_t a = lds_2xb64(ldsKT + tr_off8<32>(row, g), ldsKT + tr_off8<32>(row, 4 + g));
       acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB, acc[d], 0, 0, 0);  // dQ^T[d][q]
     }
-    commit(cur ^ 1);
-    __syncthreads();
+  };
+  if (n_it > 0) {
+    issue(r0, 0);
+    commit(r0, 0);
+    if (DEEP) issue(r1, 1);
+  }
+  __syncthreads();
+  if (DEEP) {
+    for (int it = 0; it < n_it; it += 2) {
+      issue(r0, it + 2);           // buffer 0 holds step it; r1 holds step it + 1 (in flight)
+      compute(it, 0);
+      commit(r1, 1);
+      __syncthreads();
+      if (it + 1 >= n_it) break;
+      issue(r1, it + 3);           // buffer 1 holds step it + 1; r0 holds step it + 2 (in flight)
+      compute(it + 1, 1);
+      commit(r0, 0);
+      __syncthreads();
+    }
+  } else {                         // head_dim 256: one register set, one step ahead
+    for (int it = 0; it < n_it; ++it) {
+      issue(r0, it + 1);
+      compute(it, it & 1);
+      commit(r0, (it & 1) ^ 1);
+      __syncthreads();
+    }
   }
   if (q < p.T) {
     bf16_t* dqrow = p.dq + ((long long)b * p.T + q) * p.lddq + h * D;
@@ -679,16 +754,17 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   a.dkv_part = (d.f.Hq != d.f.Hkv) ? d.dkv_part : nullptr;
   a.o = (bf16_t*)d.f.o;
   // dQ first: it computes delta = rowsum(dO * O) on the fly and leaves it in d.delta for the dK/dV kernel
-  dim3 gk(cdiv(d.f.T, 64), a.dkv_part ? d.f.Hq : d.f.Hkv, d.f.B), gq(cdiv(d.f.T, 64), d.f.Hq, d.f.B);
+  const int kv_heads = a.dkv_part ? d.f.Hq : d.f.Hkv;
+  dim3 gk(cdiv(d.f.T, 64), kv_heads, d.f.B), gk128(cdiv(d.f.T, 128), kv_heads, d.f.B), gq(cdiv(d.f.T, 64), d.f.Hq, d.f.B);
   if (d.f.D == 64) {
-    hipLaunchKernelGGL(attn_bwd_dq_k<64>, gq, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkdv_k<64>, gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_k<64, 256>), gq, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_k<64, 256>), gk, dim3(256), 0, st, a);
   } else if (d.f.D == 128) {
-    hipLaunchKernelGGL(attn_bwd_dq_k<128>, gq, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkdv_k<128>, gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_k<128, 512>), dim3(cdiv(d.f.T, 128), d.f.Hq, d.f.B), dim3(512), 0, st, a);   // 128 queries per block
+    hipLaunchKernelGGL((attn_bwd_dkdv_k<128, 512>), gk128, dim3(512), 0, st, a);   // 128 keys per block, 8 waves
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_k<256>, gq, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkdv_k<256>, gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_k<256, 256>), gq, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_k<256, 256>), gk, dim3(256), 0, st, a);
   }
   if (a.dkv_part) {
     const long long n4 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 4);
