@@ -337,9 +337,12 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   // writes f32 partials that gqa_reduce_k sums in a fixed order; without it the block loops over its group.
   const int grp_all = p.Hq / p.Hkv;
   const bool split = p.dkv_part != nullptr;
-  const int b = blockIdx.z, kb0 = blockIdx.x * KB;
-  const int hk = split ? blockIdx.y / grp_all : blockIdx.y;
-  const int h_first = split ? blockIdx.y : hk * grp_all;
+  // grid = (heads, batch, key blocks): the key block is the SLOWEST index, so under a causal mask the blocks with the most
+  // query steps (key block 0 sees every query) are dispatched first and the short ones fill the tail (longest-first; with
+  // the key block fastest a CU could draw two 10-step blocks and the launch ran 28 steps deep instead of 18)
+  const int b = blockIdx.y, kb0 = blockIdx.z * KB;
+  const int hk = split ? blockIdx.x / grp_all : blockIdx.x;
+  const int h_first = split ? blockIdx.x : hk * grp_all;
   const int grp = split ? 1 : grp_all;
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
@@ -374,9 +377,16 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   const int n_it = grp * nq;
   struct StepRegs { NatRegs<D, 32, NT> q, d_o; TrRegs<D, 32, NT> qt, dot; float l, dl; };
   StepRegs r0, r1;
-  auto issue = [&](StepRegs& r, int it) {
-    it = min(it, n_it - 1);      // past the end: re-load the last step (branch-free, static VMEM count; never committed to a live buffer)
-    const int h = h_first + it / nq, qs = q_begin + (it % nq) * 32;
+  // (head, query step) cursors advance by increments: an integer division per step is ~25 scalar instructions, and the
+  // kernel is issue-bound (PMC, round 2: ~480 instructions per wave and step for 32 MFMAs, 13 cycles each)
+  const int q_last = q_begin + (nq - 1) * 32, h_last = h_first + grp - 1;
+  int ih = h_first, iqs = q_begin;     // next step to load
+  int cqs = q_begin;                   // step being computed
+  auto issue = [&](StepRegs& r) {
+    const int h = ih, qs = iqs;
+    // advance; past the end: stay on the last step (re-loaded branch-free, static VMEM count; never committed to a live buffer)
+    if (iqs < q_last) iqs += 32;
+    else if (ih < h_last) { iqs = q_begin; ++ih; }
     load_nat<D, 32, NT>(r.q, p.q + (long long)b * p.T * p.ldq + h * D, p.ldq, qs, p.T, tid);
     load_nat<D, 32, NT>(r.d_o, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
     load_tr<D, 32, NT>(r.qt, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
@@ -396,8 +406,13 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     store_tr<D, 32, NT>(base + 3 * TILE, r.dot, tid);
     if (tid < 32) { ldsStat[buf * 64 + tid] = r.l; ldsStat[buf * 64 + 32 + tid] = r.dl; }
   };
-  auto compute = [&](int it, int cur) {
-    const int qs = q_begin + (it % nq) * 32;
+  auto compute = [&](int cur) {
+    const int qs = cqs;
+    cqs = cqs < q_last ? cqs + 32 : q_begin;
+    const int key_w0 = kb0 + w * 16;  // this wave's 16 keys
+    // nothing to add when every (query, key) pair of this wave's tile is masked: its keys lie after the step's last query
+    // (the first steps of a causal block: half of the 8 waves on average) or outside the valid key range
+    if ((p.causal && key_w0 > qs + 31) || key_w0 >= k_hi || key_w0 + 16 <= k_lo) return;
     const char* ldsQ = ldsAll + cur * 4 * TILE;
     const char* ldsDO = ldsQ + TILE;
     const char* ldsQT = ldsQ + 2 * TILE;
@@ -419,7 +434,6 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     }
     // accumulator element e of tile t: q = qs + t*16 + g*4 + e, key = this lane's key
     float pr[2][4], ds[2][4];
-    const int key_w0 = kb0 + w * 16;  // this wave's 16 keys
     bool need_mask = key_w0 < k_lo || key_w0 + 16 > k_hi || qs + 32 > p.T;
     if (p.causal) need_mask = need_mask || key_w0 + 15 > qs;
     if (p.block > 0) need_mask = need_mask || (key_w0 + 15) / p.block > qs / p.block;
@@ -459,27 +473,27 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     }
   };
   if (n_it > 0) {
-    issue(r0, 0);
+    issue(r0);
     commit(r0, 0);
-    if (DEEP) issue(r1, 1);
+    if (DEEP) issue(r1);
   }
   __syncthreads();
   if (DEEP) {
     for (int it = 0; it < n_it; it += 2) {
-      issue(r0, it + 2);           // buffer 0 holds step it; r1 holds step it + 1 (in flight)
-      compute(it, 0);
+      issue(r0);                   // buffer 0 holds step it; r1 holds step it + 1 (in flight); r0 <- step it + 2
+      compute(0);
       commit(r1, 1);
       __syncthreads();
       if (it + 1 >= n_it) break;
-      issue(r1, it + 3);           // buffer 1 holds step it + 1; r0 holds step it + 2 (in flight)
-      compute(it + 1, 1);
+      issue(r1);                   // buffer 1 holds step it + 1; r0 holds step it + 2 (in flight); r1 <- step it + 3
+      compute(1);
       commit(r0, 0);
       __syncthreads();
     }
   } else {                         // head_dim 256: one register set, one step ahead
     for (int it = 0; it < n_it; ++it) {
-      issue(r0, it + 1);
-      compute(it, it & 1);
+      issue(r0);
+      compute(it & 1);
       commit(r0, (it & 1) ^ 1);
       __syncthreads();
     }
@@ -522,8 +536,10 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
-  const int qb0 = blockIdx.x * QB;
+  // grid = (heads, batch, query blocks), the query block slowest and - under a causal mask - the LAST one first: it has
+  // the most key steps (longest-first dispatch, as in the dK/dV kernel)
+  const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);
+  const int qb0 = (p.causal ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z) * QB;
   const int q = qb0 + w * 16 + fr;
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
@@ -568,8 +584,11 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   StepRegs r0, r1;
   const int k_begin = (k_lo / 32) * 32;
   const int n_it = k_begin < kend ? (kend - k_begin + 31) / 32 : 0;
-  auto issue = [&](StepRegs& r, int it) {
-    const int ks0 = k_begin + min(it, n_it - 1) * 32;   // past the end: re-load the last step (static VMEM count)
+  int iks = k_begin, cks = k_begin;    // next key step to load / key step being computed
+  const int k_last = k_begin + (n_it - 1) * 32;
+  auto issue = [&](StepRegs& r) {
+    const int ks0 = iks;
+    if (iks < k_last) iks += 32;                        // past the end: re-load the last step (static VMEM count)
     load_nat<D, 32, NT>(r.k, kbase, p.ldk, ks0, p.T, tid);
     load_nat<D, 32, NT>(r.v, vbase, p.ldv, ks0, p.T, tid);
     load_tr<D, 32, NT>(r.kt, ktbase, p.Tp, ks0, tid);
@@ -579,8 +598,12 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
     store_nat<D, 32, NT>(ldsAll + buf * 3 * TILE + TILE, r.v, tid);
     store_tr<D, 32, NT>(ldsAll + buf * 3 * TILE + 2 * TILE, r.kt, tid);
   };
-  auto compute = [&](int it, int cur) {
-    const int ks0 = k_begin + it * 32;
+  auto compute = [&](int cur) {
+    const int ks0 = cks;
+    cks += 32;
+    const int q_w0 = qb0 + w * 16;  // this wave's 16 queries
+    // every pair of this wave's tile masked (its queries lie before the step's first key, or past the sequence): nothing to add
+    if ((p.causal && ks0 > q_w0 + 15) || q_w0 >= p.T) return;
     const char* ldsK = ldsAll + cur * 3 * TILE;
     const char* ldsV = ldsK + TILE;
     const char* ldsKT = ldsK + 2 * TILE;
@@ -597,7 +620,6 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
       }
     }
     float ds[2][4];
-    const int q_w0 = qb0 + w * 16;  // this wave's 16 queries
     bool need_mask = ks0 < k_lo || ks0 + 32 > k_hi || q_w0 + 16 > p.T;
     if (p.causal) need_mask = need_mask || ks0 + 31 > q_w0;
     if (p.block > 0) need_mask = need_mask || (ks0 + 31) / p.block > q_w0 / p.block;
@@ -629,27 +651,27 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
     }
   };
   if (n_it > 0) {
-    issue(r0, 0);
+    issue(r0);
     commit(r0, 0);
-    if (DEEP) issue(r1, 1);
+    if (DEEP) issue(r1);
   }
   __syncthreads();
   if (DEEP) {
     for (int it = 0; it < n_it; it += 2) {
-      issue(r0, it + 2);           // buffer 0 holds step it; r1 holds step it + 1 (in flight)
-      compute(it, 0);
+      issue(r0);                   // buffer 0 holds step it; r1 holds step it + 1 (in flight); r0 <- step it + 2
+      compute(0);
       commit(r1, 1);
       __syncthreads();
       if (it + 1 >= n_it) break;
-      issue(r1, it + 3);           // buffer 1 holds step it + 1; r0 holds step it + 2 (in flight)
-      compute(it + 1, 1);
+      issue(r1);                   // buffer 1 holds step it + 1; r0 holds step it + 2 (in flight); r1 <- step it + 3
+      compute(1);
       commit(r0, 0);
       __syncthreads();
     }
   } else {                         // head_dim 256: one register set, one step ahead
     for (int it = 0; it < n_it; ++it) {
-      issue(r0, it + 1);
-      compute(it, it & 1);
+      issue(r0);
+      compute(it & 1);
       commit(r0, (it & 1) ^ 1);
       __syncthreads();
     }
@@ -755,12 +777,12 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   a.o = (bf16_t*)d.f.o;
   // dQ first: it computes delta = rowsum(dO * O) on the fly and leaves it in d.delta for the dK/dV kernel
   const int kv_heads = a.dkv_part ? d.f.Hq : d.f.Hkv;
-  dim3 gk(cdiv(d.f.T, 64), kv_heads, d.f.B), gk128(cdiv(d.f.T, 128), kv_heads, d.f.B), gq(cdiv(d.f.T, 64), d.f.Hq, d.f.B);
+  dim3 gk(kv_heads, d.f.B, cdiv(d.f.T, 64)), gk128(kv_heads, d.f.B, cdiv(d.f.T, 128)), gq(d.f.Hq, d.f.B, cdiv(d.f.T, 64));
   if (d.f.D == 64) {
     hipLaunchKernelGGL((attn_bwd_dq_k<64, 256>), gq, dim3(256), 0, st, a);
     hipLaunchKernelGGL((attn_bwd_dkdv_k<64, 256>), gk, dim3(256), 0, st, a);
   } else if (d.f.D == 128) {
-    hipLaunchKernelGGL((attn_bwd_dq_k<128, 512>), dim3(cdiv(d.f.T, 128), d.f.Hq, d.f.B), dim3(512), 0, st, a);   // 128 queries per block
+    hipLaunchKernelGGL((attn_bwd_dq_k<128, 512>), dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), dim3(512), 0, st, a);   // 128 queries per block
     hipLaunchKernelGGL((attn_bwd_dkdv_k<128, 512>), gk128, dim3(512), 0, st, a);   // 128 keys per block, 8 waves
   } else {
     hipLaunchKernelGGL((attn_bwd_dq_k<256, 256>), gq, dim3(256), 0, st, a);
