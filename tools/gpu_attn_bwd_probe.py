@@ -21,6 +21,6 @@ for name, (B, Hq, Hkv, T, D, causal) in {"llm": (8, 32, 8, 316, 128, True), "enc
     do = torch.randn(B, T, Hq * D, device=dev).bfloat16()
     o, lse = ops.attention(q, k, v, causal=causal)
     f = timeit(lambda: ops.attention(q, k, v, causal=causal))
-    b = timeit(lambda: ops.attention_bwd(q, k, v, o, lse, do, causal=causal))
     fl = 4.0 * B * Hq * T * T * D * (0.5 if causal else 1.0)
+    b = timeit(lambda: ops.attention_bwd(q, k, v, o, lse, do, causal=causal))
     print(f"{name}: fwd {f:7.1f} us ({fl / f / 1e6:6.1f} TF/s)   bwd {b:7.1f} us ({2.5 * fl / b / 1e6:6.1f} TF/s)", flush=True)

@@ -38,7 +38,7 @@ struct AttnArgs {
   bf16_t* dq; bf16_t* dk; bf16_t* dv;
   int lddq, lddk, lddv;
   float scale;
-  float* dkv_part;  // [2][B, T, Hq, D] f32 per-query-head partials (GQA) or null
+  float* dkv_part;  // scratch for [2][B, T, Hq, D] per-query-head results (GQA; stored as bf16) or null
 };
 
 __device__ __forceinline__ bf16x8_t lds_b128(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
@@ -318,28 +318,29 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 }
 
 // =================================== backward: dK, dV ===================================
-// Block = (key block of NT/4, kv head, batch): NT/64 waves, wave w owns keys kb0 + w*16 .. +16.  Loops over the
-// query heads of the GQA group and over 32-query steps.  NT = 512 (head_dim 128: the LLM) halves the staging traffic and
-// the number of steps per MFMA - every staged Q / dO tile feeds 128 keys instead of 64 - and halves the staging registers
-// per thread, which is what makes room for the second prefetch set below; 8 waves per CU either way.
-template <int D, int NT>
+// Block = (key block of NT/4, kv head, batch): NT/64 waves, wave w owns keys kb0 + w*16 .. +16.  Loops over the query
+// heads of the GQA group and over ST-query steps (ST = 32 or 64).  NT = 512 (head_dim 128: the LLM): every staged Q / dO
+// tile feeds 128 keys instead of 64.  ST = 64 halves the number of steps: a step is a chain of dependent latencies (LDS
+// reads -> 16 MFMAs -> exp / pack -> LDS reads -> 16 MFMAs -> staging stores -> barrier) that two waves per SIMD do not
+// hide (PMC, round 2: 8 000 wave cycles per 32-query step for ~400 instructions), so the fixed part is paid half as often.
+// DEEP: two-deep register prefetch (two staging sets, alternating) instead of one step ahead.
+template <int D, int NT, int ST, bool DEEP>
 __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
-  constexpr bool DEEP = D <= 128;   // two-deep prefetch (head_dim 256 has no registers left for a second staging set)
   constexpr int KB = NT / 4;        // keys per block
-  constexpr int KS = D / 32, DT = D / 16;
-  constexpr int TILE = 32 * D * 2;
-  __shared__ __attribute__((aligned(16))) char ldsAll[8 * TILE + 2 * 64 * 4];  // [buf][Q | dO | Q^T | dO^T], then [buf][lse | delta]
+  constexpr int KS = D / 32, DT = D / 16, QT = ST / 16, KP = ST / 32;
+  constexpr int TILE = ST * D * 2;
+  __shared__ __attribute__((aligned(16))) char ldsAll[8 * TILE + 4 * ST * 4];  // [buf][Q | dO | Q^T | dO^T], then [buf][lse | delta]
   float* ldsStat = reinterpret_cast<float*>(ldsAll + 8 * TILE);
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  // With `dkv_part` every block handles ONE query head (grid.y = Hq: 4x the parallelism under GQA) and
+  // With `dkv_part` every block handles ONE query head (grid.x = Hq: 4x the parallelism under GQA) and
   // writes f32 partials that gqa_reduce_k sums in a fixed order; without it the block loops over its group.
   const int grp_all = p.Hq / p.Hkv;
   const bool split = p.dkv_part != nullptr;
   // grid = (heads, batch, key blocks): the key block is the SLOWEST index, so under a causal mask the blocks with the most
   // query steps (key block 0 sees every query) are dispatched first and the short ones fill the tail (longest-first; with
-  // the key block fastest a CU could draw two 10-step blocks and the launch ran 28 steps deep instead of 18)
+  // the key block fastest a CU could draw two of the longest blocks and the launch ran 28 steps deep instead of 18)
   const int b = blockIdx.y, kb0 = blockIdx.z * KB;
   const int hk = split ? blockIdx.x / grp_all : blockIdx.x;
   const int h_first = split ? blockIdx.x : hk * grp_all;
@@ -367,62 +368,59 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   int q_begin = 0;
   if (p.causal) q_begin = kb0;
   if (p.block > 0) q_begin = max(q_begin, (kb0 / p.block) * p.block);
-  q_begin = (q_begin / 32) * 32;
+  q_begin = (q_begin / ST) * ST;
 
-  // flattened (head-in-group, 32-query step) iteration space, software pipelined TWO steps deep: the global loads of step
-  // it + 2 are issued before the MFMA work of step it and written to LDS after the work of step it + 1 (two register
-  // sets, alternating), so a load has two whole steps to land - one step (~0.5 us of issue) does not cover an L2 / HBM
-  // round trip at T = 316, and the kernel was measured latency-bound (4.7 us per step at 2 blocks per CU).
-  const int nq = q_begin < p.T ? (p.T - q_begin + 31) / 32 : 0;
+  // flattened (head-in-group, ST-query step) iteration space, software pipelined: the global loads of a later step are
+  // issued before the MFMA work of the current one and written to the other LDS buffer after it (one barrier per step)
+  const int nq = q_begin < p.T ? (p.T - q_begin + ST - 1) / ST : 0;
   const int n_it = grp * nq;
-  struct StepRegs { NatRegs<D, 32, NT> q, d_o; TrRegs<D, 32, NT> qt, dot; float l, dl; };
+  struct StepRegs { NatRegs<D, ST, NT> q, d_o; TrRegs<D, ST, NT> qt, dot; float l, dl; };
   StepRegs r0, r1;
-  // (head, query step) cursors advance by increments: an integer division per step is ~25 scalar instructions, and the
-  // kernel is issue-bound (PMC, round 2: ~480 instructions per wave and step for 32 MFMAs, 13 cycles each)
-  const int q_last = q_begin + (nq - 1) * 32, h_last = h_first + grp - 1;
+  // (head, query step) cursors advance by increments: an integer division per step is ~25 scalar instructions
+  const int q_last = q_begin + (nq - 1) * ST, h_last = h_first + grp - 1;
   int ih = h_first, iqs = q_begin;     // next step to load
   int cqs = q_begin;                   // step being computed
   auto issue = [&](StepRegs& r) {
     const int h = ih, qs = iqs;
     // advance; past the end: stay on the last step (re-loaded branch-free, static VMEM count; never committed to a live buffer)
-    if (iqs < q_last) iqs += 32;
+    if (iqs < q_last) iqs += ST;
     else if (ih < h_last) { iqs = q_begin; ++ih; }
-    load_nat<D, 32, NT>(r.q, p.q + (long long)b * p.T * p.ldq + h * D, p.ldq, qs, p.T, tid);
-    load_nat<D, 32, NT>(r.d_o, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
-    load_tr<D, 32, NT>(r.qt, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
-    load_tr<D, 32, NT>(r.dot, p.dot + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
+    load_nat<D, ST, NT>(r.q, p.q + (long long)b * p.T * p.ldq + h * D, p.ldq, qs, p.T, tid);
+    load_nat<D, ST, NT>(r.d_o, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
+    load_tr<D, ST, NT>(r.qt, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
+    load_tr<D, ST, NT>(r.dot, p.dot + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
     {  // every thread loads (clamped index, branch-free: keeps the per-iteration VMEM count static);
        // queries >= T are masked by the consumers
-      const int q = min(qs + (tid & 31), p.T - 1);
+      const int q = min(qs + (tid & (ST - 1)), p.T - 1);
       r.l = p.lse[((long long)b * p.Hq + h) * p.T + q];
       r.dl = p.delta[((long long)b * p.Hq + h) * p.T + q];
     }
   };
   auto commit = [&](const StepRegs& r, int buf) {
     char* base = ldsAll + buf * 4 * TILE;
-    store_nat<D, 32, NT>(base, r.q, tid);
-    store_nat<D, 32, NT>(base + TILE, r.d_o, tid);
-    store_tr<D, 32, NT>(base + 2 * TILE, r.qt, tid);
-    store_tr<D, 32, NT>(base + 3 * TILE, r.dot, tid);
-    if (tid < 32) { ldsStat[buf * 64 + tid] = r.l; ldsStat[buf * 64 + 32 + tid] = r.dl; }
+    store_nat<D, ST, NT>(base, r.q, tid);
+    store_nat<D, ST, NT>(base + TILE, r.d_o, tid);
+    store_tr<D, ST, NT>(base + 2 * TILE, r.qt, tid);
+    store_tr<D, ST, NT>(base + 3 * TILE, r.dot, tid);
+    if (tid < ST) { ldsStat[buf * 2 * ST + tid] = r.l; ldsStat[buf * 2 * ST + ST + tid] = r.dl; }
   };
   auto compute = [&](int cur) {
     const int qs = cqs;
-    cqs = cqs < q_last ? cqs + 32 : q_begin;
+    cqs = cqs < q_last ? cqs + ST : q_begin;
     const int key_w0 = kb0 + w * 16;  // this wave's 16 keys
     // nothing to add when every (query, key) pair of this wave's tile is masked: its keys lie after the step's last query
-    // (the first steps of a causal block: half of the 8 waves on average) or outside the valid key range
-    if ((p.causal && key_w0 > qs + 31) || key_w0 >= k_hi || key_w0 + 16 <= k_lo) return;
+    // (the first steps of a causal block) or outside the valid key range
+    if ((p.causal && key_w0 > qs + ST - 1) || key_w0 >= k_hi || key_w0 + 16 <= k_lo) return;
     const char* ldsQ = ldsAll + cur * 4 * TILE;
     const char* ldsDO = ldsQ + TILE;
     const char* ldsQT = ldsQ + 2 * TILE;
     const char* ldsDOT = ldsQ + 3 * TILE;
-    const float* ldsL = ldsStat + cur * 64;
-    const float* ldsDl = ldsL + 32;
-    // S[q][key] and dP[q][key] for the two 16-query tiles: A = Q / dO rows, B = K / V fragments
-    f32x4_t s[2], dp[2];
+    const float* ldsL = ldsStat + cur * 2 * ST;
+    const float* ldsDl = ldsL + ST;
+    // S[q][key] and dP[q][key] for the QT 16-query tiles: A = Q / dO rows, B = K / V fragments
+    f32x4_t s[QT], dp[QT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < QT; ++t) {
       s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -433,15 +431,15 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
       }
     }
     // accumulator element e of tile t: q = qs + t*16 + g*4 + e, key = this lane's key
-    float pr[2][4], ds[2][4];
-    bool need_mask = key_w0 < k_lo || key_w0 + 16 > k_hi || qs + 32 > p.T;
+    float pr[QT][4], ds[QT][4];
+    bool need_mask = key_w0 < k_lo || key_w0 + 16 > k_hi || qs + ST > p.T;
     if (p.causal) need_mask = need_mask || key_w0 + 15 > qs;
     if (p.block > 0) need_mask = need_mask || (key_w0 + 15) / p.block > qs / p.block;
-    unsigned okbits = 0xffu;          // bit t*4 + e: the (query, key) pair of that accumulator element takes part
+    unsigned okbits = 0xffffu;        // bit t*4 + e: the (query, key) pair of that accumulator element takes part
     if (need_mask) {
       okbits = 0u;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < QT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int q = qs + t * 16 + g * 4 + e;
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
         }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < QT; ++t) {
       const float4 l4 = *reinterpret_cast<const float4*>(ldsL + t * 16 + g * 4);      // this lane's four queries of the tile
       const float4 d4 = *reinterpret_cast<const float4*>(ldsDl + t * 16 + g * 4);
       const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -461,15 +459,20 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
         ds[t][e] = pv * (dp[t][e] - dq[e]);
       }
     }
-    const bf16x8_t pB = pack8(pr[0], pr[1]);   // B operand: slot (g, s) <-> q = qs + 16*(s>>2) + 4*g + (s&3)
-    const bf16x8_t dsB = pack8(ds[0], ds[1]);
+    // B operands per 32-query chunk kp: slot (g, s) <-> q = qs + 32*kp + 16*(s>>2) + 4*g + (s&3)
+    bf16x8_t pB[KP], dsB[KP];
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) { pB[kp] = pack8(pr[2 * kp], pr[2 * kp + 1]); dsB[kp] = pack8(ds[2 * kp], ds[2 * kp + 1]); }
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       const int row = d * 16 + fr;
-      const bf16x8_t a = lds_2xb64(ldsDOT + tr_off8<32>(row, g), ldsDOT + tr_off8<32>(row, 4 + g));
-      const bf16x8_t c = lds_2xb64(ldsQT + tr_off8<32>(row, g), ldsQT + tr_off8<32>(row, 4 + g));
-      acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB, acc_dv[d], 0, 0, 0);
-      acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB, acc_dk[d], 0, 0, 0);
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) {
+        const bf16x8_t a = lds_2xb64(ldsDOT + tr_off8<ST>(row, kp * 8 + g), ldsDOT + tr_off8<ST>(row, kp * 8 + 4 + g));
+        const bf16x8_t c = lds_2xb64(ldsQT + tr_off8<ST>(row, kp * 8 + g), ldsQT + tr_off8<ST>(row, kp * 8 + 4 + g));
+        acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB[kp], acc_dv[d], 0, 0, 0);
+        acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB[kp], acc_dk[d], 0, 0, 0);
+      }
     }
   };
   if (n_it > 0) {
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
       commit(r0, 0);
       __syncthreads();
     }
-  } else {                         // head_dim 256: one register set, one step ahead
+  } else {                         // one register set, one step ahead
     for (int it = 0; it < n_it; ++it) {
       issue(r0);
       compute(it & 1);
@@ -500,13 +503,18 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   }
   // accumulators hold dV^T / dK^T: row d = dt*16 + g*4 + e, col key = fr
   if (split) {
+    // per-query-head dK / dV, rounded to bf16 like the un-grouped result below: that is where the reference rounds too (SDPA
+    // returns bf16 gradients for the repeat_kv-expanded heads and autograd sums the group afterwards) - and half the bytes
     if (key < p.T) {
-      float* dkp = p.dkv_part + (((long long)b * p.T + key) * p.Hq + h_first) * D;
-      float* dvp = dkp + (long long)p.B * p.T * p.Hq * D;
+      bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dkv_part) + (((long long)b * p.T + key) * p.Hq + h_first) * D;
+      bf16_t* dvp = dkp + (long long)p.B * p.T * p.Hq * D;
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        *reinterpret_cast<float4*>(dkp + d * 16 + g * 4) = make_float4(acc_dk[d][0] * p.scale, acc_dk[d][1] * p.scale, acc_dk[d][2] * p.scale, acc_dk[d][3] * p.scale);
-        *reinterpret_cast<float4*>(dvp + d * 16 + g * 4) = make_float4(acc_dv[d][0], acc_dv[d][1], acc_dv[d][2], acc_dv[d][3]);
+        u16x4_t a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = f2bf(acc_dk[d][e] * p.scale); c[e] = f2bf(acc_dv[d][e]); }
+        *reinterpret_cast<u16x4_t*>(dkp + d * 16 + g * 4) = a;
+        *reinterpret_cast<u16x4_t*>(dvp + d * 16 + g * 4) = c;
       }
     }
   } else if (key < p.T) {
@@ -524,14 +532,13 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
 }
 
 // =================================== backward: dQ ===================================
-// Block = (query block of NT/4, head, batch): NT/64 waves, wave w owns queries qb0 + w*16 .. +16; loops over 32-key steps.
-// (NT = 512 for head_dim 128, as in the dK/dV kernel: every staged K / V tile feeds 128 queries.)
-template <int D, int NT>
+// Block = (query block of NT/4, head, batch): NT/64 waves, wave w owns queries qb0 + w*16 .. +16; loops over ST-key steps
+// (NT, ST, DEEP as in the dK/dV kernel).
+template <int D, int NT, int ST, bool DEEP>
 __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
-  constexpr bool DEEP = D <= 128;
   constexpr int QB = NT / 4;        // queries per block
-  constexpr int KS = D / 32, DT = D / 16;
-  constexpr int TILE = 32 * D * 2;
+  constexpr int KS = D / 32, DT = D / 16, KT = ST / 16, KP = ST / 32;
+  constexpr int TILE = ST * D * 2;
   __shared__ __attribute__((aligned(16))) char ldsAll[6 * TILE];  // [buf][K | V | K^T]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -579,37 +586,37 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   const bf16_t* vbase = p.v + (long long)b * p.T * p.ldv + hk * D;
   const bf16_t* ktbase = p.kt + ((long long)b * p.Hkv + hk) * D * p.Tp;
 
-  // key steps of 32, software pipelined two steps deep like the dK/dV kernel (two register sets, alternating)
-  struct StepRegs { NatRegs<D, 32, NT> k, v; TrRegs<D, 32, NT> kt; };
+  // key steps of ST, software pipelined like the dK/dV kernel
+  struct StepRegs { NatRegs<D, ST, NT> k, v; TrRegs<D, ST, NT> kt; };
   StepRegs r0, r1;
-  const int k_begin = (k_lo / 32) * 32;
-  const int n_it = k_begin < kend ? (kend - k_begin + 31) / 32 : 0;
+  const int k_begin = (k_lo / ST) * ST;
+  const int n_it = k_begin < kend ? (kend - k_begin + ST - 1) / ST : 0;
   int iks = k_begin, cks = k_begin;    // next key step to load / key step being computed
-  const int k_last = k_begin + (n_it - 1) * 32;
+  const int k_last = k_begin + (n_it - 1) * ST;
   auto issue = [&](StepRegs& r) {
     const int ks0 = iks;
-    if (iks < k_last) iks += 32;                        // past the end: re-load the last step (static VMEM count)
-    load_nat<D, 32, NT>(r.k, kbase, p.ldk, ks0, p.T, tid);
-    load_nat<D, 32, NT>(r.v, vbase, p.ldv, ks0, p.T, tid);
-    load_tr<D, 32, NT>(r.kt, ktbase, p.Tp, ks0, tid);
+    if (iks < k_last) iks += ST;                        // past the end: re-load the last step (static VMEM count)
+    load_nat<D, ST, NT>(r.k, kbase, p.ldk, ks0, p.T, tid);
+    load_nat<D, ST, NT>(r.v, vbase, p.ldv, ks0, p.T, tid);
+    load_tr<D, ST, NT>(r.kt, ktbase, p.Tp, ks0, tid);
   };
   auto commit = [&](const StepRegs& r, int buf) {
-    store_nat<D, 32, NT>(ldsAll + buf * 3 * TILE, r.k, tid);
-    store_nat<D, 32, NT>(ldsAll + buf * 3 * TILE + TILE, r.v, tid);
-    store_tr<D, 32, NT>(ldsAll + buf * 3 * TILE + 2 * TILE, r.kt, tid);
+    store_nat<D, ST, NT>(ldsAll + buf * 3 * TILE, r.k, tid);
+    store_nat<D, ST, NT>(ldsAll + buf * 3 * TILE + TILE, r.v, tid);
+    store_tr<D, ST, NT>(ldsAll + buf * 3 * TILE + 2 * TILE, r.kt, tid);
   };
   auto compute = [&](int cur) {
     const int ks0 = cks;
-    cks += 32;
+    cks += ST;
     const int q_w0 = qb0 + w * 16;  // this wave's 16 queries
     // every pair of this wave's tile masked (its queries lie before the step's first key, or past the sequence): nothing to add
     if ((p.causal && ks0 > q_w0 + 15) || q_w0 >= p.T) return;
     const char* ldsK = ldsAll + cur * 3 * TILE;
     const char* ldsV = ldsK + TILE;
     const char* ldsKT = ldsK + 2 * TILE;
-    f32x4_t s[2], dp[2];
+    f32x4_t s[KT], dp[KT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < KT; ++t) {
       s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -619,15 +626,15 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
         dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dof[ks], dp[t], 0, 0, 0);  // dP^T[key][q]
       }
     }
-    float ds[2][4];
-    bool need_mask = ks0 < k_lo || ks0 + 32 > k_hi || q_w0 + 16 > p.T;
-    if (p.causal) need_mask = need_mask || ks0 + 31 > q_w0;
-    if (p.block > 0) need_mask = need_mask || (ks0 + 31) / p.block > q_w0 / p.block;
-    unsigned okbits = 0xffu;          // bit t*4 + e: the (key, query) pair of that accumulator element takes part
+    float ds[KT][4];
+    bool need_mask = ks0 < k_lo || ks0 + ST > k_hi || q_w0 + 16 > p.T;
+    if (p.causal) need_mask = need_mask || ks0 + ST - 1 > q_w0;
+    if (p.block > 0) need_mask = need_mask || (ks0 + ST - 1) / p.block > q_w0 / p.block;
+    unsigned okbits = 0xffffu;        // bit t*4 + e: the (key, query) pair of that accumulator element takes part
     if (need_mask) {
       okbits = 0u;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int key = ks0 + t * 16 + g * 4 + e;
@@ -635,19 +642,24 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
         }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < KT; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float ev = __builtin_amdgcn_exp2f(s[t][e] * p.sc - lse);
         const float pv = (okbits >> (t * 4 + e)) & 1u ? ev : 0.f;
         ds[t][e] = pv * (dp[t][e] - dl);
       }
-    const bf16x8_t dsB = pack8(ds[0], ds[1]);
+    bf16x8_t dsB[KP];
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) dsB[kp] = pack8(ds[2 * kp], ds[2 * kp + 1]);
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       const int row = d * 16 + fr;
-      const bf16x8_t a = lds_2xb64(ldsKT + tr_off8<32>(row, g), ldsKT + tr_off8<32>(row, 4 + g));
-      acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB, acc[d], 0, 0, 0);  // dQ^T[d][q]
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) {
+        const bf16x8_t a = lds_2xb64(ldsKT + tr_off8<ST>(row, kp * 8 + g), ldsKT + tr_off8<ST>(row, kp * 8 + 4 + g));
+        acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB[kp], acc[d], 0, 0, 0);  // dQ^T[d][q]
+      }
     }
   };
   if (n_it > 0) {
@@ -668,7 +680,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
       commit(r0, 0);
       __syncthreads();
     }
-  } else {                         // head_dim 256: one register set, one step ahead
+  } else {                         // one register set, one step ahead
     for (int it = 0; it < n_it; ++it) {
       issue(r0);
       compute(it & 1);
@@ -688,28 +700,30 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   }
 }
 
-// dk/dv[b, t, hk, :] = sum over the GQA group (fixed order) of the f32 per-query-head partials
-__global__ void gqa_reduce_k(const float* __restrict__ part, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int B, int T,
+// dk/dv[b, t, hk, :] = sum over the GQA group (fixed order, f32) of the bf16 per-query-head results
+__global__ void gqa_reduce_k(const bf16_t* __restrict__ part, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int B, int T,
                              int Hq, int Hkv, int D, int lddk, int lddv) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of one (b, t, hk)
-  const int dv4 = D / 4;
-  const long long n = (long long)B * T * Hkv * dv4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // 8 columns of one (b, t, hk)
+  const int dv8 = D / 8;
+  const long long n = (long long)B * T * Hkv * dv8;
   if (i >= n) return;
-  const int c = (int)(i % dv4) * 4, hk = (int)((i / dv4) % Hkv);
-  const long long bt = i / ((long long)dv4 * Hkv);
+  const int c = (int)(i % dv8) * 8, hk = (int)((i / dv8) % Hkv);
+  const long long bt = i / ((long long)dv8 * Hkv);
   const int grp = Hq / Hkv;
   const long long half = (long long)B * T * Hq * D;
-  float4 sk = make_float4(0.f, 0.f, 0.f, 0.f), sv = sk;
+  float sk[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int gq = 0; gq < grp; ++gq) {
-    const float* pk = part + (bt * Hq + hk * grp + gq) * D + c;
-    const float4 a = *reinterpret_cast<const float4*>(pk);
-    const float4 v = *reinterpret_cast<const float4*>(pk + half);
-    sk.x += a.x; sk.y += a.y; sk.z += a.z; sk.w += a.w;
-    sv.x += v.x; sv.y += v.y; sv.z += v.z; sv.w += v.w;
+    const bf16_t* pk = part + (bt * Hq + hk * grp + gq) * D + c;
+    const u16x8_t a = *reinterpret_cast<const u16x8_t*>(pk);
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(pk + half);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sk[e] += bf2f(a[e]); sv[e] += bf2f(v[e]); }
   }
-  u16x4_t ok = {f2bf(sk.x), f2bf(sk.y), f2bf(sk.z), f2bf(sk.w)}, ov = {f2bf(sv.x), f2bf(sv.y), f2bf(sv.z), f2bf(sv.w)};
-  *reinterpret_cast<u16x4_t*>(dk + bt * lddk + hk * D + c) = ok;
-  *reinterpret_cast<u16x4_t*>(dv + bt * lddv + hk * D + c) = ov;
+  u16x8_t ok, ov;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ok[e] = f2bf(sk[e]); ov[e] = f2bf(sv[e]); }
+  *reinterpret_cast<u16x8_t*>(dk + bt * lddk + hk * D + c) = ok;
+  *reinterpret_cast<u16x8_t*>(dv + bt * lddv + hk * D + c) = ov;
 }
 
 AttnArgs make_args(const uvx::AttnDesc& d) {
@@ -773,24 +787,28 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   a.dout = (const bf16_t*)d.dout; a.qt = (const bf16_t*)d.qt; a.kt = (const bf16_t*)d.kt; a.dot = (const bf16_t*)d.dot;
   a.delta = d.delta; a.dq = (bf16_t*)d.dq; a.dk = (bf16_t*)d.dk; a.dv = (bf16_t*)d.dv;
   a.lddq = d.lddq; a.lddk = d.lddk; a.lddv = d.lddv;
+  UVX_CHECK(d.lddq % 8 == 0 && d.lddk % 8 == 0 && d.lddv % 8 == 0, UVX_ERR_SHAPE, "attention_bwd: gradient row strides must be multiples of 8");
   a.dkv_part = (d.f.Hq != d.f.Hkv) ? d.dkv_part : nullptr;
   a.o = (bf16_t*)d.f.o;
   // dQ first: it computes delta = rowsum(dO * O) on the fly and leaves it in d.delta for the dK/dV kernel
   const int kv_heads = a.dkv_part ? d.f.Hq : d.f.Hkv;
   dim3 gk(kv_heads, d.f.B, cdiv(d.f.T, 64)), gk128(kv_heads, d.f.B, cdiv(d.f.T, 128)), gq(d.f.Hq, d.f.B, cdiv(d.f.T, 64));
+  // head_dim 128 (the LLM): 128 queries / keys per block (8 waves), 32-row steps, two-deep prefetch.  64-row steps (ST = 64,
+  // with or without the second staging set) were measured within 3 % of this at the C2 shape and are not instantiated
+  // (profiles/r02_attn_bwd.txt).
   if (d.f.D == 64) {
-    hipLaunchKernelGGL((attn_bwd_dq_k<64, 256>), gq, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_k<64, 256>), gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_k<64, 256, 32, true>), gq, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_k<64, 256, 32, true>), gk, dim3(256), 0, st, a);
   } else if (d.f.D == 128) {
-    hipLaunchKernelGGL((attn_bwd_dq_k<128, 512>), dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), dim3(512), 0, st, a);   // 128 queries per block
-    hipLaunchKernelGGL((attn_bwd_dkdv_k<128, 512>), gk128, dim3(512), 0, st, a);   // 128 keys per block, 8 waves
+    hipLaunchKernelGGL((attn_bwd_dq_k<128, 512, 32, true>), dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_k<128, 512, 32, true>), gk128, dim3(512), 0, st, a);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_k<256, 256>), gq, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_k<256, 256>), gk, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_k<256, 256, 32, false>), gq, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_dkdv_k<256, 256, 32, false>), gk, dim3(256), 0, st, a);
   }
   if (a.dkv_part) {
-    const long long n4 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 4);
-    hipLaunchKernelGGL(gqa_reduce_k, dim3(cdiv(n4, 256)), dim3(256), 0, st, a.dkv_part, a.dk, a.dv, d.f.B, d.f.T, d.f.Hq,
+    const long long n8 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 8);
+    hipLaunchKernelGGL(gqa_reduce_k, dim3(cdiv(n8, 256)), dim3(256), 0, st, (const bf16_t*)a.dkv_part, a.dk, a.dv, d.f.B, d.f.T, d.f.Hq,
                        d.f.Hkv, d.f.D, a.lddk, a.lddv);
   }
   UVX_LAUNCH_CHECK();

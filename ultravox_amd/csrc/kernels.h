@@ -150,7 +150,7 @@ struct AttnBwdDesc {
   const void* kt = nullptr;    // [B, Hkv, D, Tp]
   const void* dot = nullptr;   // [B, Hq, D, Tp]
   float* delta = nullptr;      // [B, Hq, T] scratch
-  float* dkv_part = nullptr;   // optional [2, B, T, Hq, D] f32 scratch: per-query-head dK/dV partials (GQA)
+  float* dkv_part = nullptr;   // optional scratch (sized for [2, B, T, Hq, D] f32; the bf16 kernels store bf16): per-query-head dK/dV (GQA)
   void* dq = nullptr; void* dk = nullptr; void* dv = nullptr;  // same layouts/strides as q,k,v
   int lddq = 0, lddk = 0, lddv = 0;
 };
