@@ -149,8 +149,10 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
-  const int qb0 = blockIdx.x * BQ;
+  // grid = (heads, batch, query blocks): the query block is the slowest index and, under a causal mask, the LAST block -
+  // the one with the most key tiles - is dispatched first (longest-first: the short blocks fill the tail of the launch)
+  const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);
+  const int qb0 = (p.causal ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z) * BQ;
   if (qb0 + BQ <= p.q_begin) return;   // chunked prefill: these query rows belong to the cached prefix (block-uniform exit)
   const int q0 = qb0 + w * QT * 16;
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
@@ -762,7 +764,7 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
   // q rows per block = 64 * QT.  Long sequences (the encoder's 1500 frames) want QT = 2 for K/V reuse; short
   // ones (the LLM's few hundred tokens) are latency-bound and want more, smaller blocks and fewer registers.
   const int qt = uvx::g_attn_qt > 0 ? uvx::g_attn_qt : (d.T >= 1024 ? 2 : 1);
-  dim3 grid(cdiv(d.T, 4 * qt * 16), d.Hq, d.B);
+  dim3 grid(d.Hq, d.B, cdiv(d.T, 4 * qt * 16));
   if (d.D == 64) {
     if (qt == 4) hipLaunchKernelGGL((attn_fwd_k<64, 4>), grid, dim3(256), 0, st, a);
     else if (qt == 3) hipLaunchKernelGGL((attn_fwd_k<64, 3>), grid, dim3(256), 0, st, a);
@@ -772,7 +774,7 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
     if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<128, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_k<128, 1>), grid, dim3(256), 0, st, a);
   } else {   // head_dim 256 (Gemma): one q tile per wave keeps the O accumulators (64 registers) + Q fragments in budget
-    hipLaunchKernelGGL((attn_fwd_k<256, 1>), dim3(cdiv(d.T, 64), d.Hq, d.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_fwd_k<256, 1>), dim3(d.Hq, d.B, cdiv(d.T, 64)), dim3(256), 0, st, a);
   }
   UVX_LAUNCH_CHECK();
   return UVX_OK;
