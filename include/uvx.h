@@ -354,9 +354,10 @@ int32_t uvx_gemm_force_variant(int32_t variant);
  * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
  * problems of at most 16 rows (the decode step; default 1) */
 int32_t uvx_set_option(int32_t key, int32_t value);
-/* Diagnostic for the stream-K GEMM launches: blocks that wait for another block's partial sums spin for a bounded time
- * (~1 s) and then give up rather than hang the queue.  Returns how many did since the last call (0 on a healthy run; a
- * non-zero count means wrong output tiles), -1 on a HIP error.  Synchronises the device. */
+/* Diagnostic for the stream-K GEMM launches (probe builds only - libuvx_probes.so; the production picker never selects
+ * them and this returns 0): blocks that wait for another block's partial sums spin for a bounded time (~1 s) and then give
+ * up rather than hang the queue.  Returns how many did since the last call (0 on a healthy run; a non-zero count means
+ * wrong output tiles), -1 on a HIP error.  Synchronises the device. */
 int32_t uvx_gemm_streamk_timeouts(void);
 /* host only (no GPU work): the bf16 GEMM tile variant the cost model picks for this problem */
 int32_t uvx_gemm_pick_variant(int32_t M, int32_t N, int32_t K, int32_t batch);

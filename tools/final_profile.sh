@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round-end evidence run on the GPU box: tests, bench JSON, rocprofv3 kernel stats, PMC traffic passes.
 R=$PWD; OUT=$R/gpurun_out/final; mkdir -p $OUT
-python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
-python bench.py --steps 5 --warmup 2 --gemm-table $OUT/gemm_table.txt > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-300
+timeout 1200 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+timeout 600 python bench.py --steps 5 --warmup 2 --gemm-table $OUT/gemm_table.txt > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-300
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_write.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- timeout 300 python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_stats.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p --output-format csv -- timeout 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_fetch.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o p --output-format csv -- timeout 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_write.log 2>&1
 ls $OUT/stats $OUT/fetch $OUT/write | head -30
 # keep only what is needed (the merged-back directory is capped at 64 MiB)
 python - <<PY

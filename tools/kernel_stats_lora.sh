@@ -2,6 +2,6 @@
 # rocprofv3 --kernel-trace --stats over a short bench.py run with encoder LoRA (the release recipe)
 R=$PWD; OUT=$R/gpurun_out/stats_lora; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT -o s --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --audio-lora-r 8 > $OUT/log.txt 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats -d $OUT -o s --output-format csv -- timeout 300 python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --audio-lora-r 8 > $OUT/log.txt 2>&1
 tail -1 $OUT/log.txt | cut -c1-200
 rm -f $OUT/*kernel_trace.csv

@@ -5,8 +5,8 @@
 # has 8 slots.  Counters only with --kernel-trace (no other trace domains).  Summary -> gpurun_out/pmc_prod/summary.txt
 R=$PWD; OUT=$R/gpurun_out/pmc_prod; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp; export PYTHONPATH=$R
 for V in ${VARS:-31 11}; do
-  timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $OUT/sq_v$V -o p --output-format csv -- python $R/tools/gpu_gemm_pmc.py $V 2528 28672 4096 > $OUT/sq_v$V.log 2>&1
-  timeout 120 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/lds_v$V -o p --output-format csv -- python $R/tools/gpu_gemm_pmc.py $V 2528 28672 4096 > $OUT/lds_v$V.log 2>&1
+  timeout 120 timeout 420 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $OUT/sq_v$V -o p --output-format csv -- timeout 300 python $R/tools/gpu_gemm_pmc.py $V 2528 28672 4096 > $OUT/sq_v$V.log 2>&1
+  timeout 120 timeout 420 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/lds_v$V -o p --output-format csv -- timeout 300 python $R/tools/gpu_gemm_pmc.py $V 2528 28672 4096 > $OUT/lds_v$V.log 2>&1
 done
 python - <<PY > $OUT/summary.txt
 import csv, collections, glob, os

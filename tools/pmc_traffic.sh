@@ -2,8 +2,8 @@
 # HBM traffic of every kernel of the C2 step from the memory-side PMC counters (separate passes: FETCH_SIZE uses 3
 # of the 4 TCC slots, WRITE_SIZE 2).  Output: gpurun_out/final/pmc_traffic.json {pass: {kernel: [launches, sum]}}.
 R=$PWD; OUT=$R/gpurun_out/final; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_write.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p --output-format csv -- timeout 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_fetch.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o p --output-format csv -- timeout 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_write.log 2>&1
 python - <<PY
 import csv, collections, json, os
 out = "$OUT"
