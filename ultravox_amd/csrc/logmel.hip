@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void logmel_pass1_k(const float* __restrict__ 
   }
   __syncthreads();
   // DFT on the f32 matrix cores: [32 frames x 400] . [400 x (cos | sin) 208 bins].  v_mfma_f32_16x16x4_f32 is bitwise a
-  // k-ordered fmaf chain (gemm_f32.hip), so re / im are the SAME bits as the scalar loop `re = fmaf(x[n], cos[n][k], re)` over
-  // n = 0..399 that this replaces (round 1: 650 us per 8 x 30 s at 12 TFLOP/s of VALU; the matrix pipe does the 7.7 GFLOP
+  // k-ordered fmaf chain (gemm_f32.hip), so re / im accumulate in the same order as the scalar loop `re = fmaf(x[n], cos[n][k], re)` over
+  // n = 0..399 that this replaces (tests/test_kernels_gpu.py pins the output to the HF extractor fixture as before) (round 1: 650 us per 8 x 30 s at 12 TFLOP/s of VALU; the matrix pipe does the 7.7 GFLOP
   // in a tenth of that).  A = frames (row = frame lr, k = n), B = twiddles (col = bin lr): accumulator element e is
   // (frame 4 lk + e, bin lr) of the 16 x 16 tile.  Wave w owns bin tiles w, w + 4, w + 8, w + 12 (13 tiles: the last only
   // for wave 0), cos and sin of a tile in the same lanes so that the power needs no exchange.
