@@ -19,6 +19,8 @@ What is recorded
                     package: its real one needs librosa / soundfile) over the reference processor and FakeChatTokenizer:
                     input_ids / labels / alt_* for every loss-mask type, alt fields, response truncation, inference mode.
   logmel.npz      — HF WhisperFeatureExtractor (the [3P] K1 arithmetic) on seeded PCM, 80 and 128 mels.
+  config.json     — the REFERENCE UltravoxConfig (ultravox_config.py:56-203) for keyword sets that need no network: every field the
+                    hot path reads, the [3P] family defaults a partial sub-config dict resolves to, the to_diff_dict key set.
   lora_reference.npz / .json — the REFERENCE apply_lora (ultravox_model.py:690-709) run on an installed-HF WhisperEncoder and
                     LlamaForCausalLM with the reference's own LoraConfigSimplified defaults, through tests/peft_stub.py
                     (peft itself is not installable here: the stub restates peft 0.11.1's LoRA Linear and says so): adapted
@@ -450,7 +452,67 @@ def lora_cases():
     print("lora_reference:", meta["encoder"]["adapted"], meta["llm"]["adapted"])
 
 
+CONFIG_SCALARS = ["ignore_index", "audio_model_id", "text_model_id", "audio_token_index", "hidden_size", "stack_factor", "norm_init",
+                  "projector_act", "projector_ln_mid", "llm_only_training", "audio_latency_block_size", "vocab_size", "initializer_range"]
+CONFIG_TEXT = ["model_type", "hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "intermediate_size",
+               "vocab_size", "rms_norm_eps", "head_dim", "max_position_embeddings", "initializer_range", "tie_word_embeddings"]
+CONFIG_AUDIO = ["model_type", "d_model", "encoder_layers", "encoder_attention_heads", "encoder_ffn_dim", "num_mel_bins",
+                "max_source_positions", "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
+                "conv_dim", "conv_stride", "conv_kernel", "num_conv_pos_embeddings", "num_conv_pos_embedding_groups"]
+
+
+def config_summary(c):
+    """What the hot path reads from an UltravoxConfig - the same function runs on the REFERENCE object here and on
+    ultravox_amd.config.UltravoxConfig in tests/test_checkpoint_cpu.py (attributes a class does not have are skipped there)."""
+    out = {k: getattr(c, k) for k in CONFIG_SCALARS}
+    for name in ("text_model_lora_config", "audio_model_lora_config"):
+        v = getattr(c, name)
+        out[name] = dataclasses.asdict(v) if dataclasses.is_dataclass(v) else v
+    out["loss"] = None
+    out["text"] = {k: getattr(c.text_config, k) for k in CONFIG_TEXT if hasattr(c.text_config, k)}
+    out["audio"] = {k: list(v) if isinstance(v, tuple) else v
+                    for k in CONFIG_AUDIO if (v := getattr(c.audio_config, k, None)) is not None}
+    out["diff_keys"] = sorted(k for k in c.to_diff_dict() if k not in ("transformers_version", "torch_dtype"))
+    return out
+
+
+def config_cases():
+    """The REFERENCE UltravoxConfig (ultravox_config.py:56-203) built from keyword sets that need no network (sub-configs
+    as dicts: AutoConfig.for_model fills the [3P] family defaults), including partial dicts - what a missing field means."""
+    llama_small = {"model_type": "llama", "hidden_size": 256, "intermediate_size": 512, "num_hidden_layers": 2,
+                   "num_attention_heads": 4, "num_key_value_heads": 2, "vocab_size": 512}
+    whisper_small = {"model_type": "whisper", "d_model": 128, "encoder_layers": 2, "encoder_attention_heads": 4,
+                     "encoder_ffn_dim": 256, "num_mel_bins": 80, "max_source_positions": 1500}
+    cases = {
+        "defaults": {},
+        "small_dicts": dict(text_config=llama_small, audio_config=whisper_small, hidden_size=384, stack_factor=4,
+                            projector_ln_mid=True, audio_latency_block_size=50),
+        "partial_text_dict": dict(text_config={"model_type": "llama", "hidden_size": 256, "vocab_size": 512},
+                                  audio_model_lora_config={"r": 8, "lora_alpha": 16}, text_model_lora_config={"r": 4}),
+        "projector_variants": dict(text_config=llama_small, audio_config=whisper_small, projector_act="swiglu", norm_init=0.4,
+                                   projector_ln_mid=False, stack_factor=8, audio_token_index=32000, ignore_index=-100),
+        "gemma_wav2vec2": dict(text_config={"model_type": "gemma", "hidden_size": 192, "head_dim": 32, "vocab_size": 512,
+                                            "num_hidden_layers": 2, "num_attention_heads": 4, "num_key_value_heads": 4,
+                                            "intermediate_size": 384},
+                               audio_config={"model_type": "wav2vec2", "hidden_size": 64, "num_hidden_layers": 2,
+                                             "num_attention_heads": 2, "intermediate_size": 128}),
+        "partial_gemma_dict": dict(text_config={"model_type": "gemma", "vocab_size": 512}),
+        "llm_only": dict(text_config=llama_small, llm_only_training=True),
+    }
+    out = {}
+    for name, kw in cases.items():
+        c = ultravox_config.UltravoxConfig(**json.loads(json.dumps(kw)))
+        out[name] = {"kwargs": kw, "expect": config_summary(c)}
+    lc = ultravox_config.LossConfig()
+    out["_loss_config_defaults"] = {"loss_function": str(lc.loss_function.value), "kl_temperature": lc.kl_temperature,
+                                    "requires_alt_fields": lc.requires_alt_fields}
+    with open(os.path.join(HERE, "config.json"), "w") as f:
+        json.dump(out, f, indent=1, default=str)
+    print("config:", sorted(out))
+
+
 if __name__ == "__main__":
+    config_cases()
     lora_cases()
     processor_cases()
     projector_cases()

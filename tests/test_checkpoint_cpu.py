@@ -170,3 +170,48 @@ def test_from_pretrained_base_gets_adapter_keys_before_the_checkpoint_is_merged(
         seeded.setdefault(k, v)
     merged, keep = checkpoint.merge_state_dict(seeded, ckpt)
     assert keep == set(ckpt) and all(torch.equal(merged[k], ckpt[k]) for k in ckpt)
+
+
+def test_config_matches_the_reference_config_fixture():
+    """UltravoxConfig against tests/golden/config.json, recorded from the IMPORTED reference UltravoxConfig
+    (ultravox_config.py:56-203; tests/golden/make_golden.py `config_cases`): every field the hot path reads, the [3P] family
+    defaults that a PARTIAL text_config / audio_config dict resolves to (a config.json that omits rms_norm_eps means 1e-6 to
+    LlamaConfig, not the 1e-5 Llama-3 checkpoints happen to carry), LoRA sub-configs, and the to_diff_dict key set."""
+    import dataclasses
+    import json
+    import os
+    from ultravox_amd.config import LossConfig, UltravoxConfig
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config.json")))
+    alias = {"hidden_size": "d_model", "num_hidden_layers": "encoder_layers", "num_attention_heads": "encoder_attention_heads",
+             "intermediate_size": "encoder_ffn_dim"}          # Wav2Vec2Config / WhisperConfig names for the same four numbers
+    n = 0
+    for name, case in fx.items():
+        if name.startswith("_"):
+            continue
+        cfg, exp = UltravoxConfig(**json.loads(json.dumps(case["kwargs"]))), case["expect"]
+        for k, v in exp.items():
+            if k in ("text", "audio", "diff_keys", "loss"):
+                continue
+            got = getattr(cfg, k)
+            got = dataclasses.asdict(got) if dataclasses.is_dataclass(got) else got
+            assert got == v, (name, k, got, v)
+            n += 1
+        for k, v in exp["text"].items():
+            assert getattr(cfg.text_config, k) == v, (name, "text." + k, getattr(cfg.text_config, k), v)
+            n += 1
+        for k, v in exp["audio"].items():
+            mine = k if hasattr(cfg.audio_config, k) else alias.get(k)
+            if mine is None or not hasattr(cfg.audio_config, mine):
+                continue                                        # (fields the device path does not read)
+            got = getattr(cfg.audio_config, mine)
+            got = list(got) if isinstance(got, tuple) else got
+            if got is None:
+                continue                                        # whisper: no conv stack
+            assert got == v, (name, "audio." + k, got, v)
+            n += 1
+        # same keys in the saved config (torch_dtype aside: this framework always records the dtype it runs in)
+        assert sorted(k for k in cfg.to_diff_dict() if k not in ("transformers_version", "torch_dtype")) == exp["diff_keys"], name
+    assert n > 150
+    lc, ref = LossConfig(), fx["_loss_config_defaults"]
+    assert lc.loss_function.value == ref["loss_function"] and lc.kl_temperature == ref["kl_temperature"]
+    assert lc.requires_alt_fields == ref["requires_alt_fields"]

@@ -107,25 +107,43 @@ class TextConfig:
     (hidden_act gelu_pytorch_tanh), sqrt(hidden_size) embedding scale, explicit head_dim, lm_head tied to embed_tokens."""
     model_type: str = "llama"
     hidden_act: Optional[str] = None            # None = the family's own: silu (llama), gelu_pytorch_tanh (gemma)
-    hidden_size: int = 2048
-    intermediate_size: int = 5632
-    num_hidden_layers: int = 22
-    num_attention_heads: int = 32
-    num_key_value_heads: int = 4
+    # None = the family's [3P] default (transformers LlamaConfig / GemmaConfig), so that a config.json that leaves a field
+    # out means here what it means to the reference's AutoConfig (pinned against the imported reference config:
+    # tests/golden/config.json)
+    hidden_size: Optional[int] = None
+    intermediate_size: Optional[int] = None
+    num_hidden_layers: Optional[int] = None
+    num_attention_heads: Optional[int] = None
+    num_key_value_heads: Optional[int] = None
     head_dim: Optional[int] = None
-    vocab_size: int = 32000
-    rms_norm_eps: float = 1e-5
+    vocab_size: Optional[int] = None
+    rms_norm_eps: Optional[float] = None
     rope_theta: float = 10000.0
     rope_scaling: Optional[Dict[str, Any]] = None
-    max_position_embeddings: int = 2048
+    max_position_embeddings: Optional[int] = None
     initializer_range: float = 0.02
-    eos_token_id: int = 2
+    eos_token_id: Optional[int] = None
+    tie_word_embeddings: Optional[bool] = None
+
+    _FAMILY_DEFAULTS = {
+        "llama": dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                      vocab_size=32000, rms_norm_eps=1e-6, max_position_embeddings=2048, eos_token_id=2,
+                      tie_word_embeddings=False),
+        "gemma": dict(hidden_size=3072, intermediate_size=24576, num_hidden_layers=28, num_attention_heads=16,
+                      num_key_value_heads=16, head_dim=256, vocab_size=256000, rms_norm_eps=1e-6,
+                      max_position_embeddings=8192, eos_token_id=1, tie_word_embeddings=True),
+    }
 
     def __post_init__(self):
-        if self.head_dim is None:
-            self.head_dim = self.hidden_size // self.num_attention_heads
         if self.model_type not in ("llama", "gemma"):
             raise ValueError(f"text_config.model_type {self.model_type!r} is not built (llama, gemma)")
+        for k, v in self._FAMILY_DEFAULTS[self.model_type].items():
+            if getattr(self, k) is None:
+                setattr(self, k, v)
+        if self.num_key_value_heads is None:     # LlamaConfig: defaults to num_attention_heads (no GQA)
+            self.num_key_value_heads = self.num_attention_heads
+        if self.head_dim is None:
+            self.head_dim = self.hidden_size // self.num_attention_heads
         want = "silu" if self.model_type == "llama" else "gelu_pytorch_tanh"
         if self.hidden_act is None:
             self.hidden_act = want
@@ -155,18 +173,20 @@ _LLAMA3_SCALING = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high
 TEXT_PRESETS: Dict[str, Dict[str, Any]] = {
     "TinyLlama/TinyLlama-1.1B-Chat-v1.0": dict(hidden_size=2048, intermediate_size=5632, num_hidden_layers=22,
                                                num_attention_heads=32, num_key_value_heads=4, vocab_size=32000,
-                                               rope_theta=10000.0, max_position_embeddings=2048, eos_token_id=2),
+                                               rope_theta=10000.0, max_position_embeddings=2048, eos_token_id=2,
+                                               rms_norm_eps=1e-5),
     "meta-llama/Meta-Llama-3-8B-Instruct": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
                                                 num_attention_heads=32, num_key_value_heads=8, vocab_size=128256,
-                                                rope_theta=500000.0, max_position_embeddings=8192, eos_token_id=128009),
+                                                rope_theta=500000.0, max_position_embeddings=8192, eos_token_id=128009,
+                                                rms_norm_eps=1e-5),
     "meta-llama/Llama-3.1-8B-Instruct": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
                                              num_attention_heads=32, num_key_value_heads=8, vocab_size=128256,
                                              rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING,
-                                             max_position_embeddings=131072, eos_token_id=128009),
+                                             max_position_embeddings=131072, eos_token_id=128009, rms_norm_eps=1e-5),
     "meta-llama/Llama-3.3-70B-Instruct": dict(hidden_size=8192, intermediate_size=28672, num_hidden_layers=80,
                                               num_attention_heads=64, num_key_value_heads=8, vocab_size=128256,
                                               rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING,
-                                              max_position_embeddings=131072, eos_token_id=128009),
+                                              max_position_embeddings=131072, eos_token_id=128009, rms_norm_eps=1e-5),
 }
 # Gemma-1 (C5).  head_dim 256 is NOT hidden_size / heads for the 7B model (3072 / 16 = 192)
 TEXT_PRESETS["google/gemma-7b"] = dict(model_type="gemma", hidden_size=3072, intermediate_size=24576, num_hidden_layers=28,
