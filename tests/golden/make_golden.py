@@ -372,7 +372,8 @@ def lora_cases():
     tiny = dict(audio_config=dict(d_model=64, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=128, num_mel_bins=80,
                                   max_source_positions=1500),
                 text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
-                                 num_key_value_heads=2, vocab_size=256, rope_theta=10000.0, max_position_embeddings=512),
+                                 num_key_value_heads=2, vocab_size=256, rope_theta=10000.0, max_position_embeddings=512,
+                                 rms_norm_eps=1e-5),
                 hidden_size=128, stack_factor=8, projector_ln_mid=True)
     cfg = UltravoxConfig(**tiny)
     a, t = cfg.audio_config, cfg.text_config
