@@ -1,0 +1,40 @@
+"""Seeded weights / inputs shared by tests/golden/make_golden.py `forward_cases` (which fills the REFERENCE UltravoxModel with
+them and records its outputs in tests/golden/forward_reference.npz) and the tests that replay the same case through the
+oracle and the HIP path.  Every tensor is a function of its NAME and shape only (torch CPU randn with a crc32 seed), so the
+fixture stores outputs, not megabytes of weights.  Dimensions are the smallest the HIP kernels take (head_dim 64, GEMM K % 64)."""
+import zlib
+
+import torch
+
+TEXT = {"model_type": "llama", "hidden_size": 256, "intermediate_size": 512, "num_hidden_layers": 2, "num_attention_heads": 4,
+        "num_key_value_heads": 2, "vocab_size": 512, "rms_norm_eps": 1e-5, "max_position_embeddings": 256, "rope_theta": 10000.0}
+AUDIO = {"model_type": "whisper", "d_model": 64, "encoder_layers": 2, "encoder_attention_heads": 2, "encoder_ffn_dim": 128,
+         "num_mel_bins": 80, "max_source_positions": 1500}
+N_AUDIO, B, T = 4, 3, 44
+
+
+def config_kwargs(ln_mid: bool) -> dict:
+    return dict(text_config=dict(TEXT), audio_config=dict(AUDIO), hidden_size=256, stack_factor=8, projector_ln_mid=ln_mid)
+
+
+def param(name: str, shape) -> torch.Tensor:
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    w = torch.randn(tuple(shape), generator=g) * (0.05 if len(shape) > 1 else 0.02)
+    return w + 1.0 if (name.endswith("weight") and len(shape) == 1) else w      # norm weights around 1
+
+
+def tower_output() -> torch.Tensor:
+    return torch.randn(N_AUDIO, 1500, AUDIO["d_model"], generator=torch.Generator().manual_seed(5)) * 0.5
+
+
+def batch() -> dict:
+    ids = torch.randint(3, TEXT["vocab_size"], (B, T), generator=torch.Generator().manual_seed(3))
+    labels = ids.clone()
+    labels[:, :24] = -100
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, 38:] = 0                      # right padding (sample 1), labels ignored there
+    labels[1, 38:] = -100
+    mask[2, :5] = 0                       # left padding (sample 2)
+    return dict(input_ids=ids, labels=labels, attention_mask=mask,
+                audio_token_start_idx=torch.tensor([2, 13, 3, 8]), audio_token_len=torch.tensor([6, 5, 7, 9]),
+                audio_lens=torch.tensor([3000, 2600, 2000, 2999]), audio_batch_size=torch.tensor([2, 1, 1]))

@@ -19,6 +19,10 @@ What is recorded
                     package: its real one needs librosa / soundfile) over the reference processor and FakeChatTokenizer:
                     input_ids / labels / alt_* for every loss-mask type, alt fields, response truncation, inference mode.
   logmel.npz      — HF WhisperFeatureExtractor (the [3P] K1 arithmetic) on seeded PCM, 80 and 128 mels.
+  forward_reference.npz / .json — the REFERENCE UltravoxModel.forward + loss.backward() end to end (ultravox_model.py:277-396:
+                    _prepare_audio_embeds, _audio_iter, projector, merge loop, HF Llama + ForCausalLMLoss) on tiny random towers,
+                    the audio tower stubbed by recorded hidden states; both projector variants, two items in one sample,
+                    left and right padding: weights, inputs, logits, loss, projector gradients.
   config.json     — the REFERENCE UltravoxConfig (ultravox_config.py:56-203) for keyword sets that need no network: every field the
                     hot path reads, the [3P] family defaults a partial sub-config dict resolves to, the to_diff_dict key set.
   lora_reference.npz / .json — the REFERENCE apply_lora (ultravox_model.py:690-709) run on an installed-HF WhisperEncoder and
@@ -512,7 +516,55 @@ def config_cases():
     print("config:", sorted(out))
 
 
+def forward_cases():
+    """The REFERENCE UltravoxModel.forward (ultravox_model.py:277-396) END TO END on CPU: its own _prepare_audio_embeds,
+    _audio_iter, UltravoxProjector, the in-place merge loop, the installed-HF LlamaForCausalLM + ForCausalLMLoss, and
+    loss.backward() into the projector - with random tiny towers built from dict configs (no network) and the audio tower's
+    forward replaced by recorded hidden states (the installed transformers 5.x encoder layer no longer takes the 4.51.3
+    mask the reference's ModifiedWhisperEncoder.forward builds; the tower itself is pinned separately, against HF blocks).
+    Weights and inputs are the seeded tensors of tests/forward_fixture_util.py (functions of name and shape), so only the
+    outputs are stored.  Compatibility shims, all outside the arithmetic: transformers.modeling_utils._init_weights (removed
+    in 5.x: the reference reads it at :447), tie_weights(**kwargs), rotary inv_freq recomputed after to_empty()."""
+    import forward_fixture_util as U
+    transformers.modeling_utils._init_weights = True
+    tw = ultravox_model.UltravoxModel.tie_weights
+    ultravox_model.UltravoxModel.tie_weights = lambda self, *a, **k: tw(self)
+    arrays, meta = {}, {"cases": {}}
+    for name, ln_mid in (("ln_mid", True), ("ln_post", False)):
+        kw = U.config_kwargs(ln_mid)
+        kw["audio_config"].update({"_name_or_path": "random/whisper-nano", "decoder_layers": 1, "decoder_attention_heads": 2,
+                                   "decoder_ffn_dim": 64, "vocab_size": 100, "pad_token_id": 0, "bos_token_id": 1,
+                                   "eos_token_id": 2, "decoder_start_token_id": 1})
+        m = ultravox_model.UltravoxModel(ultravox_config.UltravoxConfig(**json.loads(json.dumps(kw)))).to_empty(device="cpu")
+        n_w = 0
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                p.copy_(U.param(n, p.shape))
+                n_w += n.startswith(("multi_modal_projector.", "language_model."))
+        m.float()
+        dim = U.TEXT["hidden_size"] // U.TEXT["num_attention_heads"]
+        inv = 1.0 / (U.TEXT["rope_theta"] ** (torch.arange(0, dim, 2).float() / dim))
+        m.language_model.model.rotary_emb.inv_freq = inv
+        m.language_model.model.rotary_emb.original_inv_freq = inv.clone()
+        enc = U.tower_output()
+        m.audio_tower.forward = lambda audio_values, audio_len=None, **k: transformers.modeling_outputs.BaseModelOutput(
+            last_hidden_state=enc[: audio_values.shape[0]])
+        out = m(audio_values=torch.zeros(U.N_AUDIO, 80, 3000), **U.batch())
+        out.loss.backward()
+        for n, p in m.multi_modal_projector.named_parameters():
+            arrays[f"{name}.g.multi_modal_projector.{n}"] = p.grad.numpy()
+        arrays[f"{name}.logits"] = out.logits.detach().numpy()
+        arrays[f"{name}.loss"] = np.array(out.loss.item(), np.float64)
+        meta["cases"][name] = {"loss": out.loss.item(), "n_weights": int(n_w),
+                               "weight_names": [n for n, _ in m.named_parameters() if n.startswith(("multi_modal_projector.", "language_model."))]}
+    np.savez_compressed(os.path.join(HERE, "forward_reference.npz"), **arrays)
+    with open(os.path.join(HERE, "forward_reference.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("forward_reference:", {k: v["loss"] for k, v in meta["cases"].items()})
+
+
 if __name__ == "__main__":
+    forward_cases()
     config_cases()
     lora_cases()
     processor_cases()

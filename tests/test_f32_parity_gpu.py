@@ -108,3 +108,34 @@ def test_c1_tinyllama_whisper_tiny_train_step():
     new = model.projector_state_dict()
     for k in oracle.trainable:
         assert rel_l2(new[k], oracle.sd[k].detach()) < 1e-4, k
+
+
+@pytest.mark.parametrize("name", ["ln_mid", "ln_post"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_matches_the_reference_forward_fixture(name, dtype):
+    """The HIP path against the REFERENCE UltravoxModel.forward + loss.backward() itself (tests/golden/forward_reference.npz:
+    the imported reference run end to end on tiny random towers, its audio tower stubbed by recorded hidden states - the
+    tower is stubbed here the same way): two audio items merged into one sample, token_len truncation, left and right
+    padding, ForCausalLMLoss, projector gradients.  f32 compute mode: north_star's 1e-3 on the logits; bf16: the usual bars."""
+    from test_oracle_pinning import load_forward_fixture
+    from ultravox_amd.model import UltravoxModel
+    cfg, sd, batch, enc, exp = load_forward_fixture(name)
+    model = UltravoxModel(cfg, state_dict={k: v.to(dtype) for k, v in sd.items()}, device=DEV, dtype=dtype)
+    tower = enc.to(DEV, dtype)
+    model.audio_tower_forward = lambda audio_values, audio_len: tower[: audio_values.shape[0]]
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    mel = torch.zeros(len(enc), 80, 3000, device=DEV, dtype=dtype)
+    out = model.forward(audio_values=mel, **gb)
+    keep = batch["attention_mask"].bool()
+    logits = out.logits.float().cpu()
+    if dtype == torch.float32:
+        assert (logits[keep] - exp["logits"][keep]).abs().max().item() < 1e-3
+        assert abs(out.loss.item() - exp["loss"]) < 1e-4
+    else:
+        assert rel_l2(logits[keep], exp["logits"][keep]) < 3e-2
+        assert abs(out.loss.item() - exp["loss"]) < 2e-2 * exp["loss"]
+    model.train()
+    model.forward_backward(audio_values=mel, **gb)
+    mine = model.projector_grads()
+    for k, g in exp["grads"].items():
+        assert rel_l2(mine[k], g) < (1e-3 if dtype == torch.float32 else 8e-2), k

@@ -399,3 +399,42 @@ def test_wav2vec2_feature_extractor_contract_matches_hf():
                                rtol=1e-5, atol=1e-6)
     with pytest.raises(ValueError, match="sampling rate"):
         Wav2Vec2FeatureExtractor()(clips, sampling_rate=8000)
+
+
+def load_forward_fixture(name):
+    """tests/golden/forward_reference.npz (outputs of the REFERENCE forward) + the seeded weights / inputs it was run on
+    (tests/forward_fixture_util.py) -> (cfg, state dict incl. a random audio tower, batch, tower output, expected)."""
+    import json
+    import os
+    import forward_fixture_util as U
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import random_state_dict
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(here, "forward_reference.npz"))
+    meta = json.load(open(os.path.join(here, "forward_reference.json")))["cases"][name]
+    cfg = UltravoxConfig(**U.config_kwargs(name == "ln_mid"))
+    sd = random_state_dict(cfg, seed=1)
+    for key in meta["weight_names"]:          # the reference's parameter names ARE this framework's state-dict keys
+        assert key in sd, key
+        sd[key] = U.param(key, sd[key].shape)
+    assert {k for k in sd if k.startswith(("multi_modal_projector.", "language_model."))} == set(meta["weight_names"])
+    exp = {"logits": torch.from_numpy(z[f"{name}.logits"]), "loss": float(z[f"{name}.loss"]),
+           "grads": {k[len(name) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + ".g.")}}
+    return cfg, sd, U.batch(), U.tower_output(), exp
+
+
+@pytest.mark.parametrize("name", ["ln_mid", "ln_post"])
+def test_oracle_forward_matches_the_reference_forward_end_to_end(name):
+    """OracleModel.forward + backward against the REFERENCE UltravoxModel.forward run end to end (fixture: make_golden.py
+    `forward_cases`): merge of two audio items into one sample, token_len truncation, left / right padding, loss shift and
+    ignore index, projector gradients - the glue the piecewise fixtures do not cover."""
+    from oracle import reference_cpu as O
+    cfg, sd, batch, enc, exp = load_forward_fixture(name)
+    oracle = O.OracleModel(cfg, sd)
+    out = oracle.forward(audio_values=torch.zeros(len(enc), 80, 3000), tower_output=enc, **batch)
+    keep = batch["attention_mask"].bool()
+    assert (out["logits"].detach()[keep] - exp["logits"][keep]).abs().max().item() < 2e-5
+    assert abs(out["loss"].item() - exp["loss"]) < 1e-6
+    out["loss"].backward()
+    for k, g in exp["grads"].items():
+        np.testing.assert_allclose(oracle.sd[k].grad.numpy(), g.numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
