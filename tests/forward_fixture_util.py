@@ -38,3 +38,15 @@ def batch() -> dict:
     return dict(input_ids=ids, labels=labels, attention_mask=mask,
                 audio_token_start_idx=torch.tensor([2, 13, 3, 8]), audio_token_len=torch.tensor([6, 5, 7, 9]),
                 audio_lens=torch.tensor([3000, 2600, 2000, 2999]), audio_batch_size=torch.tensor([2, 1, 1]))
+
+
+def generate_batch() -> dict:
+    """Prompts for generate(): samples 0 (no padding, two audio items) and 2 (left padded, one item) of `batch()`."""
+    b = batch()
+    sel = [0, 2]
+    return dict(input_ids=b["input_ids"][sel], attention_mask=b["attention_mask"][sel],
+                audio_token_start_idx=torch.tensor([2, 13, 8]), audio_token_len=torch.tensor([6, 5, 9]),
+                audio_lens=torch.tensor([3000, 2600, 2999]), audio_batch_size=torch.tensor([2, 1]))
+
+
+GEN_AUDIO_ROWS = [0, 1, 3]        # rows of tower_output() behind generate_batch()'s three audio items

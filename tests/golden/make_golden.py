@@ -23,6 +23,8 @@ What is recorded
                     _prepare_audio_embeds, _audio_iter, projector, merge loop, HF Llama + ForCausalLMLoss) on tiny random towers,
                     the audio tower stubbed by recorded hidden states; both projector variants, two items in one sample,
                     left and right padding: weights, inputs, logits, loss, projector gradients.
+  generate_reference.json — the REFERENCE UltravoxModel.generate (greedy, HF GenerationMixin) on the same seeded tiny model:
+                    new tokens for an unpadded and a left-padded prompt, without EOS and with an EOS that stops one row early.
   config.json     — the REFERENCE UltravoxConfig (ultravox_config.py:56-203) for keyword sets that need no network: every field the
                     hot path reads, the [3P] family defaults a partial sub-config dict resolves to, the to_diff_dict key set.
   lora_reference.npz / .json — the REFERENCE apply_lora (ultravox_model.py:690-709) run on an installed-HF WhisperEncoder and
@@ -563,7 +565,49 @@ def forward_cases():
     print("forward_reference:", {k: v["loss"] for k, v in meta["cases"].items()})
 
 
+def generate_cases():
+    """The REFERENCE UltravoxModel.generate (ultravox_model.py:398-426 -> [3P] GenerationMixin greedy search) on the seeded
+    tiny model of forward_cases: audio merged once before the prefill, a left-padded prompt next to an unpadded one,
+    (a) 10 new tokens with no EOS, (b) the same with an EOS id chosen so that row 0 stops after 3 tokens and is padded."""
+    import forward_fixture_util as U
+    transformers.modeling_utils._init_weights = True
+    if not getattr(ultravox_model.UltravoxModel.tie_weights, "_shimmed", False):
+        tw = ultravox_model.UltravoxModel.tie_weights
+        f = lambda self, *a, **k: tw(self)
+        f._shimmed = True
+        ultravox_model.UltravoxModel.tie_weights = f
+    kw = U.config_kwargs(True)
+    kw["audio_config"].update({"_name_or_path": "random/whisper-nano", "decoder_layers": 1, "decoder_attention_heads": 2,
+                               "decoder_ffn_dim": 64, "vocab_size": 100, "pad_token_id": 0, "bos_token_id": 1,
+                               "eos_token_id": 2, "decoder_start_token_id": 1})
+    m = ultravox_model.UltravoxModel(ultravox_config.UltravoxConfig(**json.loads(json.dumps(kw)))).to_empty(device="cpu")
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(U.param(n, p.shape))
+    m.float().eval()
+    dim = U.TEXT["hidden_size"] // U.TEXT["num_attention_heads"]
+    inv = 1.0 / (U.TEXT["rope_theta"] ** (torch.arange(0, dim, 2).float() / dim))
+    m.language_model.model.rotary_emb.inv_freq = inv
+    m.language_model.model.rotary_emb.original_inv_freq = inv.clone()
+    enc = U.tower_output()[U.GEN_AUDIO_ROWS]
+    m.audio_tower.forward = lambda audio_values, audio_len=None, **k: transformers.modeling_outputs.BaseModelOutput(
+        last_hidden_state=enc[: audio_values.shape[0]])
+    b = U.generate_batch()
+    T = b["input_ids"].shape[1]
+    free = m.generate(audio_values=torch.zeros(3, 80, 3000), max_new_tokens=10, do_sample=False, pad_token_id=0,
+                      eos_token_id=None, **b)
+    eos = int(free[0, T + 2])
+    assert eos not in free[0, T:T + 2].tolist() and eos not in free[1, T:].tolist()
+    stop = m.generate(audio_values=torch.zeros(3, 80, 3000), max_new_tokens=10, do_sample=False, pad_token_id=0,
+                      eos_token_id=eos, **b)
+    out = {"prompt_len": T, "free": free[:, T:].tolist(), "eos": eos, "with_eos": stop[:, T:].tolist(), "pad_token_id": 0}
+    with open(os.path.join(HERE, "generate_reference.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("generate_reference:", out)
+
+
 if __name__ == "__main__":
+    generate_cases()
     forward_cases()
     config_cases()
     lora_cases()

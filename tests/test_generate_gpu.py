@@ -226,3 +226,27 @@ def test_longest_common_prefix_reuse_on_the_device(dtype):
     assert rel_l2(rows(got.past_key_values), rows(fresh.past_key_values)) < (1e-5 if dtype == torch.float32 else 2e-2)
     if dtype == torch.float32:
         assert torch.equal(got.sequences, fresh.sequences)
+
+
+def test_f32_generate_matches_the_reference_generate_fixture():
+    """generate() against the REFERENCE UltravoxModel.generate itself (tests/golden/generate_reference.json: the imported
+    reference + HF greedy search on the seeded tiny model, audio tower stubbed by recorded hidden states): new tokens of an
+    unpadded prompt with two audio items and a left-padded prompt, without EOS and with an EOS that stops one row early."""
+    import json
+    import os
+    import forward_fixture_util as U
+    from test_oracle_pinning import load_forward_fixture
+    from ultravox_amd.model import UltravoxModel
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "generate_reference.json")))
+    cfg, sd, _, enc, _ = load_forward_fixture("ln_mid")
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32, rope_len=512)
+    tower = enc[U.GEN_AUDIO_ROWS].to(DEV)
+    model.audio_tower_forward = lambda audio_values, audio_len: tower[: audio_values.shape[0]]
+    b = {k: v.to(DEV) for k, v in U.generate_batch().items()}
+    mel = torch.zeros(3, 80, 3000, device=DEV)
+    T = fx["prompt_len"]
+    free = model.generate(audio_values=mel, max_new_tokens=10, eos_token_id=None, pad_token_id=fx["pad_token_id"], **b).cpu()
+    assert free[:, T:].tolist() == fx["free"]
+    stop = model.generate(audio_values=mel, max_new_tokens=10, eos_token_id=fx["eos"], pad_token_id=fx["pad_token_id"], **b).cpu()
+    got = stop[:, T:].tolist()
+    assert [r + [fx["pad_token_id"]] * (10 - len(r)) for r in got] == fx["with_eos"]

@@ -438,3 +438,25 @@ def test_oracle_forward_matches_the_reference_forward_end_to_end(name):
     out["loss"].backward()
     for k, g in exp["grads"].items():
         np.testing.assert_allclose(oracle.sd[k].grad.numpy(), g.numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_oracle_generate_matches_the_reference_generate():
+    """OracleModel.generate_greedy against the REFERENCE UltravoxModel.generate (fixture generate_reference.json: HF greedy
+    search on the seeded tiny model): audio merged once, a left-padded prompt next to an unpadded one (mask-based position
+    ids), EOS stops one row early and pads it."""
+    import json
+    import os
+    import forward_fixture_util as U
+    from oracle import reference_cpu as O
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "generate_reference.json")))
+    cfg, sd, _, enc, _ = load_forward_fixture("ln_mid")
+    oracle = O.OracleModel(cfg, sd)
+    b = U.generate_batch()
+    T = fx["prompt_len"]
+    kw = dict(audio_values=torch.zeros(3, 80, 3000), tower_output=enc[U.GEN_AUDIO_ROWS], **b)
+    free = oracle.generate_greedy(10, eos_token_id=-1, pad_token_id=fx["pad_token_id"], **kw)
+    assert free[:, T:].tolist() == fx["free"]
+    stop = oracle.generate_greedy(10, eos_token_id=fx["eos"], pad_token_id=fx["pad_token_id"], **kw)
+    got = stop[:, T:].tolist()
+    want = [row[: len(got[0])] for row in fx["with_eos"]]      # (the oracle may stop the loop once every row has finished)
+    assert [r + [fx["pad_token_id"]] * (10 - len(r)) for r in got] == fx["with_eos"] and want == got
