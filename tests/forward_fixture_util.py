@@ -50,3 +50,17 @@ def generate_batch() -> dict:
 
 
 GEN_AUDIO_ROWS = [0, 1, 3]        # rows of tower_output() behind generate_batch()'s three audio items
+
+
+def alt_batch() -> dict:
+    """The text-only (teacher) fields of the KL-distillation step for `batch()`: same number of supervised tokens per row as
+    `labels` (20, 14, 20), a shorter sequence, row 1 right padded."""
+    Ta = 36
+    ids = torch.randint(3, TEXT["vocab_size"], (B, Ta), generator=torch.Generator().manual_seed(9))
+    mask = torch.ones(B, Ta, dtype=torch.long)
+    labels = torch.full((B, Ta), -100, dtype=torch.long)
+    labels[0, 16:] = ids[0, 16:]
+    labels[1, 18:32] = ids[1, 18:32]
+    mask[1, 32:] = 0
+    labels[2, 16:] = ids[2, 16:]
+    return dict(alt_input_ids=ids, alt_attention_mask=mask, alt_labels=labels)

@@ -23,6 +23,8 @@ What is recorded
                     _prepare_audio_embeds, _audio_iter, projector, merge loop, HF Llama + ForCausalLMLoss) on tiny random towers,
                     the audio tower stubbed by recorded hidden states; both projector variants, two items in one sample,
                     left and right padding: weights, inputs, logits, loss, projector gradients.
+  kl_forward_reference.npz / .json — the REFERENCE forward in training mode under LossFunction.KL_Divergence (teacher pass +
+                    _compute_kl_loss inside the model) on the same seeded tiny model: loss and projector gradients, two settings.
   generate_reference.json — the REFERENCE UltravoxModel.generate (greedy, HF GenerationMixin) on the same seeded tiny model:
                     new tokens for an unpadded and a left-padded prompt, without EOS and with an EOS that stops one row early.
   config.json     — the REFERENCE UltravoxConfig (ultravox_config.py:56-203) for keyword sets that need no network: every field the
@@ -565,6 +567,60 @@ def forward_cases():
     print("forward_reference:", {k: v["loss"] for k, v in meta["cases"].items()})
 
 
+def _seeded_reference_model(ln_mid=True, extra=None):
+    """The reference UltravoxModel on the seeded tiny towers of tests/forward_fixture_util.py, audio tower stubbed."""
+    import forward_fixture_util as U
+    transformers.modeling_utils._init_weights = True
+    if not getattr(ultravox_model.UltravoxModel.tie_weights, "_shimmed", False):
+        tw = ultravox_model.UltravoxModel.tie_weights
+        f = lambda self, *a, **k: tw(self)
+        f._shimmed = True
+        ultravox_model.UltravoxModel.tie_weights = f
+    kw = U.config_kwargs(ln_mid)
+    kw["audio_config"].update({"_name_or_path": "random/whisper-nano", "decoder_layers": 1, "decoder_attention_heads": 2,
+                               "decoder_ffn_dim": 64, "vocab_size": 100, "pad_token_id": 0, "bos_token_id": 1,
+                               "eos_token_id": 2, "decoder_start_token_id": 1})
+    kw.update(extra or {})
+    m = ultravox_model.UltravoxModel(ultravox_config.UltravoxConfig(**json.loads(json.dumps(kw)))).to_empty(device="cpu")
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(U.param(n, p.shape))
+    m.float()
+    dim = U.TEXT["hidden_size"] // U.TEXT["num_attention_heads"]
+    inv = 1.0 / (U.TEXT["rope_theta"] ** (torch.arange(0, dim, 2).float() / dim))
+    rot = m.language_model.model.rotary_emb if hasattr(m.language_model, "model") else None
+    for mod in m.language_model.modules():
+        if hasattr(mod, "inv_freq"):
+            mod.inv_freq = inv
+            mod.original_inv_freq = inv.clone()
+    return m
+
+
+def kl_forward_cases():
+    """The REFERENCE UltravoxModel.forward in TRAINING mode with LossFunction.KL_Divergence (ultravox_model.py:335-351 ->
+    _compute_kl_loss :200-256): text-only teacher pass of the same LM over alt_* without gradient, student = the audio path,
+    KL over the prediction positions + the end-of-turn term; loss and projector gradients on the seeded tiny model."""
+    import forward_fixture_util as U
+    arrays, meta = {}, {}
+    for tag, lc in (("t2_eot1", dict(kl_temperature=2.0, eot_loss_weight=1.0)), ("t1_eot0", dict(kl_temperature=1.0, eot_loss_weight=0.0))):
+        m = _seeded_reference_model(True)
+        m.set_loss_config(ultravox_config.LossConfig(loss_function=ultravox_config.LossFunction.KL_Divergence, **lc))
+        m.train()
+        enc = U.tower_output()
+        m.audio_tower.forward = lambda audio_values, audio_len=None, **k: transformers.modeling_outputs.BaseModelOutput(
+            last_hidden_state=enc[: audio_values.shape[0]])
+        out = m(audio_values=torch.zeros(U.N_AUDIO, 80, 3000), **U.batch(), **U.alt_batch())
+        out.loss.backward()
+        for n, p in m.multi_modal_projector.named_parameters():
+            arrays[f"{tag}.g.multi_modal_projector.{n}"] = p.grad.numpy()
+        arrays[f"{tag}.loss"] = np.array(out.loss.item(), np.float64)
+        meta[tag] = {"loss": out.loss.item(), **lc}
+    np.savez_compressed(os.path.join(HERE, "kl_forward_reference.npz"), **arrays)
+    with open(os.path.join(HERE, "kl_forward_reference.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("kl_forward_reference:", meta)
+
+
 def generate_cases():
     """The REFERENCE UltravoxModel.generate (ultravox_model.py:398-426 -> [3P] GenerationMixin greedy search) on the seeded
     tiny model of forward_cases: audio merged once before the prefill, a left-padded prompt next to an unpadded one,
@@ -607,6 +663,7 @@ def generate_cases():
 
 
 if __name__ == "__main__":
+    kl_forward_cases()
     generate_cases()
     forward_cases()
     config_cases()

@@ -127,3 +127,36 @@ def test_kl_requires_alt_fields():
     ids = torch.randint(0, 100, (1, 8), device=DEV)
     with pytest.raises(ValueError):
         model.forward(input_ids=ids, labels=ids)
+
+
+@pytest.mark.parametrize("tag", ["t2_eot1", "t1_eot0"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_kl_step_matches_the_reference_forward_fixture(tag, dtype):
+    """The KL-distillation step of the HIP path against the REFERENCE forward in training mode itself (fixture
+    kl_forward_reference.npz: imported reference on the seeded tiny model, audio tower stubbed): loss and projector
+    gradients, with and without the end-of-turn term.  bf16 runs the rows-only heads (uvx_llm_fwd_rows / kl_loss_rows)."""
+    import json
+    import os
+    import numpy as np
+    import forward_fixture_util as U
+    from test_oracle_pinning import load_forward_fixture
+    from ultravox_amd.config import LossConfig, LossFunction
+    from ultravox_amd.model import UltravoxModel
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(here, "kl_forward_reference.npz"))
+    meta = json.load(open(os.path.join(here, "kl_forward_reference.json")))[tag]
+    cfg, sd, batch, enc, _ = load_forward_fixture("ln_mid")
+    model = UltravoxModel(cfg, state_dict={k: v.to(dtype) for k, v in sd.items()}, device=DEV, dtype=dtype)
+    model.set_loss_config(LossConfig(loss_function=LossFunction.KL_Divergence, kl_temperature=meta["kl_temperature"],
+                                     eot_loss_weight=meta["eot_loss_weight"]))
+    tower = enc.to(DEV, dtype)
+    model.audio_tower_forward = lambda audio_values, audio_len: tower[: audio_values.shape[0]]
+    gb = {k: v.to(DEV) for k, v in {**batch, **U.alt_batch()}.items()}
+    model.train()
+    loss = model.forward_backward(audio_values=torch.zeros(len(enc), 80, 3000, device=DEV, dtype=dtype), **gb)
+    want = float(z[f"{tag}.loss"])
+    assert abs(loss.item() - want) < (1e-5 + 1e-4 * want if dtype == torch.float32 else 0.05 * want + 1e-4)
+    mine = model.projector_grads()
+    for k in z.files:
+        if k.startswith(tag + ".g."):
+            assert rel_l2(mine[k[len(tag) + 3:]], torch.from_numpy(z[k])) < (1e-3 if dtype == torch.float32 else 0.1), k

@@ -460,3 +460,25 @@ def test_oracle_generate_matches_the_reference_generate():
     got = stop[:, T:].tolist()
     want = [row[: len(got[0])] for row in fx["with_eos"]]      # (the oracle may stop the loop once every row has finished)
     assert [r + [fx["pad_token_id"]] * (10 - len(r)) for r in got] == fx["with_eos"] and want == got
+
+
+@pytest.mark.parametrize("tag", ["t2_eot1", "t1_eot0"])
+def test_oracle_kl_step_matches_the_reference_forward_in_training_mode(tag):
+    """OracleModel.forward(kl=...) + backward against the REFERENCE forward in training mode under KL_Divergence (fixture
+    kl_forward_reference.npz): the teacher pass over alt_* inside the model, prediction / end-of-turn masks, batchmean."""
+    import json
+    import os
+    import forward_fixture_util as U
+    from oracle import reference_cpu as O
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(here, "kl_forward_reference.npz"))
+    meta = json.load(open(os.path.join(here, "kl_forward_reference.json")))[tag]
+    cfg, sd, batch, enc, _ = load_forward_fixture("ln_mid")
+    oracle = O.OracleModel(cfg, sd)
+    out = oracle.forward(audio_values=torch.zeros(len(enc), 80, 3000), tower_output=enc, **batch, **U.alt_batch(),
+                         kl={"temperature": meta["kl_temperature"], "eot_loss_weight": meta["eot_loss_weight"]})
+    assert abs(out["loss"].item() - float(z[f"{tag}.loss"])) < 1e-6
+    out["loss"].backward()
+    for k in z.files:
+        if k.startswith(tag + ".g."):
+            np.testing.assert_allclose(oracle.sd[k[len(tag) + 3:]].grad.numpy(), z[k], rtol=3e-4, atol=1e-7, err_msg=k)
