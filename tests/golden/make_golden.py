@@ -25,6 +25,8 @@ What is recorded
                     left and right padding: weights, inputs, logits, loss, projector gradients.
   kl_forward_reference.npz / .json — the REFERENCE forward in training mode under LossFunction.KL_Divergence (teacher pass +
                     _compute_kl_loss inside the model) on the same seeded tiny model: loss and projector gradients, two settings.
+  lora_forward_reference.npz / .json — the REFERENCE model with text_model_lora_config r = 4 (apply_lora via tests/peft_stub.py),
+                    forward + backward with non-zero adapters: loss, logits, projector and adapter gradients.
   generate_reference.json — the REFERENCE UltravoxModel.generate (greedy, HF GenerationMixin) on the same seeded tiny model:
                     new tokens for an unpadded and a left-padded prompt, without EOS and with an EOS that stops one row early.
   config.json     — the REFERENCE UltravoxConfig (ultravox_config.py:56-203) for keyword sets that need no network: every field the
@@ -621,6 +623,31 @@ def kl_forward_cases():
     print("kl_forward_reference:", meta)
 
 
+def lora_forward_cases():
+    """The REFERENCE UltravoxModel with text_model_lora_config r = 4 (apply_lora through tests/peft_stub.py on the LLM's q_proj /
+    k_proj, ultravox_model.py:499-526, 690-709), forward + backward on the seeded tiny model with NON-ZERO lora_B: loss, logits
+    and the gradients of the projector and of every adapter matrix.  Parameter names are recorded: the base weights sit under
+    peft's `base_model.model.` / `.base_layer` names there and are seeded by those names."""
+    import forward_fixture_util as U
+    m = _seeded_reference_model(True, extra={"text_model_lora_config": dataclasses.asdict(ultravox_config.LoraConfigSimplified(r=4))})
+    enc = U.tower_output()
+    m.audio_tower.forward = lambda audio_values, audio_len=None, **k: transformers.modeling_outputs.BaseModelOutput(
+        last_hidden_state=enc[: audio_values.shape[0]])
+    out = m(audio_values=torch.zeros(U.N_AUDIO, 80, 3000), **U.batch())
+    out.loss.backward()
+    arrays = {"logits": out.logits.detach().numpy(), "loss": np.array(out.loss.item(), np.float64)}
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            arrays["g." + n] = p.grad.numpy()
+    meta = {"loss": out.loss.item(), "trainable": trainable, "lora_config": dataclasses.asdict(ultravox_config.LoraConfigSimplified(r=4)),
+            "weight_names": [n for n, _ in m.named_parameters() if n.startswith(("multi_modal_projector.", "language_model."))]}
+    np.savez_compressed(os.path.join(HERE, "lora_forward_reference.npz"), **arrays)
+    with open(os.path.join(HERE, "lora_forward_reference.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("lora_forward_reference:", meta["loss"], len(trainable))
+
+
 def generate_cases():
     """The REFERENCE UltravoxModel.generate (ultravox_model.py:398-426 -> [3P] GenerationMixin greedy search) on the seeded
     tiny model of forward_cases: audio merged once before the prefill, a left-padded prompt next to an unpadded one,
@@ -663,6 +690,7 @@ def generate_cases():
 
 
 if __name__ == "__main__":
+    lora_forward_cases()
     kl_forward_cases()
     generate_cases()
     forward_cases()

@@ -182,3 +182,33 @@ def test_merge_and_unload_matches_adapter_forward(dtype):
     gen = {k: v for k, v in gb.items() if k != "labels"}
     out = model.generate(audio_values=mel, max_new_tokens=4, eos_token_id=-1, **gen)
     assert out.shape[1] == gb["input_ids"].shape[1] + 4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_llm_lora_step_matches_the_reference_model_fixture(dtype):
+    """uvx_llm_fwd_lora / uvx_llm_bwd_lora inside a whole training step against the REFERENCE model with
+    text_model_lora_config r = 4 itself (fixture lora_forward_reference.npz: imported reference, apply_lora through
+    tests/peft_stub.py, seeded tiny model with non-zero adapters, audio tower stubbed): loss, logits, the projector's and
+    every adapter matrix's gradient."""
+    from test_oracle_pinning import load_lora_forward_fixture
+    from ultravox_amd.model import UltravoxModel
+    cfg, sd, batch, enc, exp = load_lora_forward_fixture()
+    model = UltravoxModel(cfg, state_dict={k: v.to(dtype) for k, v in sd.items()}, device=DEV, dtype=dtype)
+    tower = enc.to(DEV, dtype)
+    model.audio_tower_forward = lambda audio_values, audio_len: tower[: audio_values.shape[0]]
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    mel = torch.zeros(len(enc), 80, 3000, device=DEV, dtype=dtype)
+    out = model.forward(audio_values=mel, **gb)
+    keep = batch["attention_mask"].bool()
+    logits = out.logits.float().cpu()
+    if dtype == torch.float32:
+        assert (logits[keep] - exp["logits"][keep]).abs().max().item() < 1e-3
+        assert abs(out.loss.item() - exp["loss"]) < 1e-4
+    else:
+        assert rel_l2(logits[keep], exp["logits"][keep]) < 3e-2
+    model.train()
+    model.forward_backward(audio_values=mel, **gb)
+    mine = model.projector_grads()
+    assert sorted(mine) == sorted(exp["grads"])
+    for k, g in exp["grads"].items():
+        assert rel_l2(mine[k], g) < (2e-3 if dtype == torch.float32 else 0.1), k

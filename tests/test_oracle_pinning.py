@@ -482,3 +482,47 @@ def test_oracle_kl_step_matches_the_reference_forward_in_training_mode(tag):
     for k in z.files:
         if k.startswith(tag + ".g."):
             np.testing.assert_allclose(oracle.sd[k[len(tag) + 3:]].grad.numpy(), z[k], rtol=3e-4, atol=1e-7, err_msg=k)
+
+
+def load_lora_forward_fixture():
+    """tests/golden/lora_forward_reference.* + the seeded weights (by the REFERENCE's parameter names: under peft the base
+    weights are `language_model.base_model.model.<...>.base_layer.weight`; this framework keeps HF names for them)."""
+    import json
+    import os
+    import forward_fixture_util as U
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import random_state_dict
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(here, "lora_forward_reference.npz"))
+    meta = json.load(open(os.path.join(here, "lora_forward_reference.json")))
+    from ultravox_amd.weights import init_lora_state_dict
+    cfg = UltravoxConfig(**U.config_kwargs(True), text_model_lora_config=meta["lora_config"])
+    sd = random_state_dict(cfg, seed=1)
+    sd.update(init_lora_state_dict(cfg))          # peft's key names for the adapter matrices (pinned by lora_reference.json)
+    seen = set()
+    for ref in meta["weight_names"]:
+        key = ref if ".lora_" in ref else ref.replace("language_model.base_model.model.", "language_model.").replace(".base_layer", "")
+        assert key in sd, (ref, key)
+        sd[key] = U.param(ref, sd[key].shape)
+        seen.add(key)
+    assert {k for k in sd if k.startswith(("multi_modal_projector.", "language_model."))} == seen
+    exp = {"logits": torch.from_numpy(z["logits"]), "loss": float(z["loss"]),
+           "grads": {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g.")}}
+    assert sorted(exp["grads"]) == sorted(meta["trainable"])
+    return cfg, sd, U.batch(), U.tower_output(), exp
+
+
+def test_oracle_llm_lora_step_matches_the_reference_model_with_text_lora():
+    """OracleModel (text_model_lora_config r = 4) against the REFERENCE model with apply_lora on the LLM (fixture
+    lora_forward_reference.npz, peft restated by tests/peft_stub.py): logits, loss, projector and adapter gradients."""
+    from oracle import reference_cpu as O
+    cfg, sd, batch, enc, exp = load_lora_forward_fixture()
+    oracle = O.OracleModel(cfg, sd)
+    assert sorted(oracle.trainable) == sorted(exp["grads"])
+    out = oracle.forward(audio_values=torch.zeros(len(enc), 80, 3000), tower_output=enc, **batch)
+    keep = batch["attention_mask"].bool()
+    assert (out["logits"].detach()[keep] - exp["logits"][keep]).abs().max().item() < 3e-5
+    assert abs(out["loss"].item() - exp["loss"]) < 1e-6
+    out["loss"].backward()
+    for k, g in exp["grads"].items():
+        np.testing.assert_allclose(oracle.sd[k].grad.numpy(), g.numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
