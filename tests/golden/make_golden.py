@@ -27,6 +27,9 @@ What is recorded
                     _compute_kl_loss inside the model) on the same seeded tiny model: loss and projector gradients, two settings.
   lora_forward_reference.npz / .json — the REFERENCE model with text_model_lora_config r = 4 (apply_lora via tests/peft_stub.py),
                     forward + backward with non-zero adapters: loss, logits, projector and adapter gradients.
+  (No Gemma-backbone run of the reference model: the installed transformers 5.x moved Gemma's sqrt(hidden) scale into the
+   embedding module, i.e. it no longer scales the MERGED inputs_embeds as the reference's pinned 4.51.3 does - a fixture
+   generated here would pin the wrong semantics.  The Gemma blocks are pinned against HF with the scale applied explicitly.)
   generate_reference.json — the REFERENCE UltravoxModel.generate (greedy, HF GenerationMixin) on the same seeded tiny model:
                     new tokens for an unpadded and a left-padded prompt, without EOS and with an EOS that stops one row early.
   config.json     — the REFERENCE UltravoxConfig (ultravox_config.py:56-203) for keyword sets that need no network: every field the
@@ -569,7 +572,7 @@ def forward_cases():
     print("forward_reference:", {k: v["loss"] for k, v in meta["cases"].items()})
 
 
-def _seeded_reference_model(ln_mid=True, extra=None):
+def _seeded_reference_model(ln_mid=True, extra=None, base_kwargs=None):
     """The reference UltravoxModel on the seeded tiny towers of tests/forward_fixture_util.py, audio tower stubbed."""
     import forward_fixture_util as U
     transformers.modeling_utils._init_weights = True
@@ -578,7 +581,7 @@ def _seeded_reference_model(ln_mid=True, extra=None):
         f = lambda self, *a, **k: tw(self)
         f._shimmed = True
         ultravox_model.UltravoxModel.tie_weights = f
-    kw = U.config_kwargs(ln_mid)
+    kw = base_kwargs if base_kwargs is not None else U.config_kwargs(ln_mid)
     kw["audio_config"].update({"_name_or_path": "random/whisper-nano", "decoder_layers": 1, "decoder_attention_heads": 2,
                                "decoder_ffn_dim": 64, "vocab_size": 100, "pad_token_id": 0, "bos_token_id": 1,
                                "eos_token_id": 2, "decoder_start_token_id": 1})
@@ -588,9 +591,11 @@ def _seeded_reference_model(ln_mid=True, extra=None):
         for n, p in m.named_parameters():
             p.copy_(U.param(n, p.shape))
     m.float()
-    dim = U.TEXT["hidden_size"] // U.TEXT["num_attention_heads"]
-    inv = 1.0 / (U.TEXT["rope_theta"] ** (torch.arange(0, dim, 2).float() / dim))
-    rot = m.language_model.model.rotary_emb if hasattr(m.language_model, "model") else None
+    tc = kw["text_config"]
+    if tc.get("tie_word_embeddings"):      # to_empty() + per-name seeding broke the tie: share the tensor again (HF tie_weights)
+        m.language_model.lm_head.weight = m.language_model.model.embed_tokens.weight
+    dim = tc.get("head_dim") or tc["hidden_size"] // tc["num_attention_heads"]
+    inv = 1.0 / (tc["rope_theta"] ** (torch.arange(0, dim, 2).float() / dim))
     for mod in m.language_model.modules():
         if hasattr(mod, "inv_freq"):
             mod.inv_freq = inv
