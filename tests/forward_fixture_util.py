@@ -27,7 +27,8 @@ def tower_output() -> torch.Tensor:
     return torch.randn(N_AUDIO, 1500, AUDIO["d_model"], generator=torch.Generator().manual_seed(5)) * 0.5
 
 
-def batch() -> dict:
+def batch(mixed: bool = False) -> dict:
+    """mixed: sample 0 is text-only, sample 1 carries three audio items, sample 2 one (audio_batch_size [0, 3, 1])."""
     ids = torch.randint(3, TEXT["vocab_size"], (B, T), generator=torch.Generator().manual_seed(3))
     labels = ids.clone()
     labels[:, :24] = -100
@@ -35,6 +36,10 @@ def batch() -> dict:
     mask[1, 38:] = 0                      # right padding (sample 1), labels ignored there
     labels[1, 38:] = -100
     mask[2, :5] = 0                       # left padding (sample 2)
+    if mixed:
+        return dict(input_ids=ids, labels=labels, attention_mask=mask,
+                    audio_token_start_idx=torch.tensor([2, 12, 20, 8]), audio_token_len=torch.tensor([6, 5, 4, 9]),
+                    audio_lens=torch.tensor([3000, 2600, 2000, 2999]), audio_batch_size=torch.tensor([0, 3, 1]))
     return dict(input_ids=ids, labels=labels, attention_mask=mask,
                 audio_token_start_idx=torch.tensor([2, 13, 3, 8]), audio_token_len=torch.tensor([6, 5, 7, 9]),
                 audio_lens=torch.tensor([3000, 2600, 2000, 2999]), audio_batch_size=torch.tensor([2, 1, 1]))

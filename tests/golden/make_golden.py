@@ -21,8 +21,8 @@ What is recorded
   logmel.npz      — HF WhisperFeatureExtractor (the [3P] K1 arithmetic) on seeded PCM, 80 and 128 mels.
   forward_reference.npz / .json — the REFERENCE UltravoxModel.forward + loss.backward() end to end (ultravox_model.py:277-396:
                     _prepare_audio_embeds, _audio_iter, projector, merge loop, HF Llama + ForCausalLMLoss) on tiny random towers,
-                    the audio tower stubbed by recorded hidden states; both projector variants, two items in one sample,
-                    left and right padding: weights, inputs, logits, loss, projector gradients.
+                    the audio tower stubbed by recorded hidden states; both projector variants, two / three items in one
+                    sample, a text-only sample in the batch, left and right padding: logits, loss, projector gradients.
   kl_forward_reference.npz / .json — the REFERENCE forward in training mode under LossFunction.KL_Divergence (teacher pass +
                     _compute_kl_loss inside the model) on the same seeded tiny model: loss and projector gradients, two settings.
   lora_forward_reference.npz / .json — the REFERENCE model with text_model_lora_config r = 4 (apply_lora via tests/peft_stub.py),
@@ -539,7 +539,7 @@ def forward_cases():
     tw = ultravox_model.UltravoxModel.tie_weights
     ultravox_model.UltravoxModel.tie_weights = lambda self, *a, **k: tw(self)
     arrays, meta = {}, {"cases": {}}
-    for name, ln_mid in (("ln_mid", True), ("ln_post", False)):
+    for name, ln_mid in (("ln_mid", True), ("ln_post", False), ("ln_mid_mixed", True)):
         kw = U.config_kwargs(ln_mid)
         kw["audio_config"].update({"_name_or_path": "random/whisper-nano", "decoder_layers": 1, "decoder_attention_heads": 2,
                                    "decoder_ffn_dim": 64, "vocab_size": 100, "pad_token_id": 0, "bos_token_id": 1,
@@ -558,7 +558,7 @@ def forward_cases():
         enc = U.tower_output()
         m.audio_tower.forward = lambda audio_values, audio_len=None, **k: transformers.modeling_outputs.BaseModelOutput(
             last_hidden_state=enc[: audio_values.shape[0]])
-        out = m(audio_values=torch.zeros(U.N_AUDIO, 80, 3000), **U.batch())
+        out = m(audio_values=torch.zeros(U.N_AUDIO, 80, 3000), **U.batch(mixed=name.endswith("_mixed")))
         out.loss.backward()
         for n, p in m.multi_modal_projector.named_parameters():
             arrays[f"{name}.g.multi_modal_projector.{n}"] = p.grad.numpy()

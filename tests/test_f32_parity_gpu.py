@@ -110,7 +110,7 @@ def test_c1_tinyllama_whisper_tiny_train_step():
         assert rel_l2(new[k], oracle.sd[k].detach()) < 1e-4, k
 
 
-@pytest.mark.parametrize("name", ["ln_mid", "ln_post"])
+@pytest.mark.parametrize("name", ["ln_mid", "ln_post", "ln_mid_mixed"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_forward_matches_the_reference_forward_fixture(name, dtype):
     """The HIP path against the REFERENCE UltravoxModel.forward + loss.backward() itself (tests/golden/forward_reference.npz:

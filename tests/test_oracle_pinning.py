@@ -412,7 +412,7 @@ def load_forward_fixture(name):
     here = os.path.join(os.path.dirname(__file__), "golden")
     z = np.load(os.path.join(here, "forward_reference.npz"))
     meta = json.load(open(os.path.join(here, "forward_reference.json")))["cases"][name]
-    cfg = UltravoxConfig(**U.config_kwargs(name == "ln_mid"))
+    cfg = UltravoxConfig(**U.config_kwargs(name.startswith("ln_mid")))
     sd = random_state_dict(cfg, seed=1)
     for key in meta["weight_names"]:          # the reference's parameter names ARE this framework's state-dict keys
         assert key in sd, key
@@ -420,10 +420,10 @@ def load_forward_fixture(name):
     assert {k for k in sd if k.startswith(("multi_modal_projector.", "language_model."))} == set(meta["weight_names"])
     exp = {"logits": torch.from_numpy(z[f"{name}.logits"]), "loss": float(z[f"{name}.loss"]),
            "grads": {k[len(name) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + ".g.")}}
-    return cfg, sd, U.batch(), U.tower_output(), exp
+    return cfg, sd, U.batch(mixed=name.endswith("_mixed")), U.tower_output(), exp
 
 
-@pytest.mark.parametrize("name", ["ln_mid", "ln_post"])
+@pytest.mark.parametrize("name", ["ln_mid", "ln_post", "ln_mid_mixed"])
 def test_oracle_forward_matches_the_reference_forward_end_to_end(name):
     """OracleModel.forward + backward against the REFERENCE UltravoxModel.forward run end to end (fixture: make_golden.py
     `forward_cases`): merge of two audio items into one sample, token_len truncation, left / right padding, loss shift and
