@@ -1110,7 +1110,10 @@ const Variant kVariants[kNumVariants] = {
     // twins' x the same-box cold-probe ratio (profiles/r02_gemm_ph2_probe.txt: 256: +3...+10 %, 192: +0...+4 %, 160: +0...+4 %
     // over the three-buffer 18, 128: +2...+5 %); fixed costs as the twins' except 192 (10.5 instead of 12: the in-situ table of the
     // first merged-phase run had 12000 x 3072 x 1024 on the 256 tile at 108 us where the 192 tile takes 87).
-    {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.},
+    // (160-row tile: 1285 -> 1305 after the in-situ A/B of profiles/r02_gemm_k28672_tile_ab.txt - at 2528 x 4096 x 28672 the model
+    //  had the 192-row tile (224 tiles, a 7/8-filled round) 0.1 % ahead, in the step the 160-row tile (256 tiles) is 10 % faster
+    //  on that shape: 91.75 -> 90.2 ms per step; the nudge flips only the K >= 24576 dgrad shapes of C2 / C4 / C5)
+    {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1305., 9.},  {128, 256, 1160., 6.},
     {256, 256, 0., 6.},     {192, 256, 0., 8.},      {160, 256, 0., 7.},     {128, 256, 0., 5.},    // 35..38 = PERSISTENT merged-phase (probe)
     // 39..42 = STREAM-K merged-phase {256,192,160,128} x 256 (probe builds; see the kernel).  Cost: sk_cost() below.
     {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.}};
