@@ -36,6 +36,7 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // [6] tile picker uses the merged-phase kernels 31..34 (on; 0 = the round-1 four-phase set 11, 15..19),
 // [7] m-major tile order when the activation matrix is the larger operand (M > N: the encoder's GEMMs; on)
 // [8] (probe builds) let the picker choose the stream-K variants 39..42 (off: measured slower, see the kernel),
+// [10] tail-split threshold in per cent of the whole launch's modelled cost (0 = 88),
 // [9] stream-K flavour: data-parallel rounds before the stream-K part: 1 = all but the last full round ("two-tile"), 0 = none
 int g_options[12] = {0, 2, 0, 1, 1, 0, 1, 1, 0, 1, 0, 0};
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
@@ -1368,7 +1369,9 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
       const int tv = pick_variant(d.M, tail_n, d.K, 1, &cost_tail);
       const double cost_split = variant_cost(variant, d.M, main_panels * V.bn, d.K, 1) + cost_tail;
       // (the second launch costs a round of its own plus a launch gap: only worth it for a clear modelled win)
-      if (cost_split < 0.88 * cost_whole) { n_main = main_panels * V.bn; tail_variant = tv; }
+      // (probe option 10: the threshold in per cent, 0 = the default 88)
+      const double thr = uvx::g_options[10] > 0 ? uvx::g_options[10] / 100.0 : 0.88;
+      if (cost_split < thr * cost_whole) { n_main = main_panels * V.bn; tail_variant = tv; }
     }
   }
   if (uvx::g_prof_on && !d.m_dev) uvx::prof_tag(d.M, d.N, d.K, batch, tail_variant >= 0 ? 100 + variant : variant);
