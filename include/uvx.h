@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 7
+#define UVX_ABI_VERSION 8
 #define UVX_BF16 0
 #define UVX_F32 1
 

@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 7   # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+ABI_VERSION = 8   # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
 
 
 def lib() -> C.CDLL:
