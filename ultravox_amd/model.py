@@ -140,6 +140,7 @@ class UltravoxModel:
         self.training = False
         # training step: last layer's o_proj / MLP on the supervised rows only (uvx_llm_fwd_train); A/B switch for the probes
         self.top_layer_supervised_rows = os.environ.get("UVX_TOP_LAYER_ROWS", "1") != "0"
+        self._llm_train_pair = False             # which uvx_llm_bwd* entry point pairs with the last language_model_forward
         self._kl_grad_scale = 1.0
         self._before_projector = None
         self.keep_params = set()                 # ultravox_model.py:59
@@ -622,7 +623,7 @@ class UltravoxModel:
             check(l.uvx_llm_bwd_lora(stream_ptr(), C.byref(self._c), C.byref(self._lw), C.byref(self._tlora), ptr(lab), B, T,
                                      C.c_float(grad_scale), ptr(d_embeds), C.byref(self._tlora_grads), ptr(self._ws["llm"]),
                                      C.c_size_t(nb)), "uvx_llm_bwd_lora")
-        elif getattr(self, "_llm_train_pair", False):
+        elif self._llm_train_pair:
             check(l.uvx_llm_bwd_train(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, C.c_float(grad_scale),
                                       ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_train")
         else:
