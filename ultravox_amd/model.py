@@ -741,6 +741,7 @@ class UltravoxModel:
                                      C.c_float(self.loss_config.kl_temperature), C.c_float(self._kl_grad_scale), ptr(loss),
                                      ptr(ws), C.c_size_t(nb)), "uvx_llm_kl_loss_rows")
         self._llm_ctx = (B, T, nb, "rows")        # forward_backward: uvx_llm_bwd_rows
+        self._llm_train_pair = False
         return CausalLMOutputWithPast(loss=loss[0], logits=None)
 
     @torch.no_grad()
