@@ -11,6 +11,16 @@ TEXT = {"model_type": "llama", "hidden_size": 256, "intermediate_size": 512, "nu
 AUDIO = {"model_type": "whisper", "d_model": 64, "encoder_layers": 2, "encoder_attention_heads": 2, "encoder_ffn_dim": 128,
          "num_mel_bins": 80, "max_source_positions": 1500}
 N_AUDIO, B, T = 4, 3, 44
+# The REAL-tower fixtures (tests/golden/real_tower_reference.npz: the reference's own ModifiedWhisperEncoder.forward) use an
+# encoder the HIP kernels accept (head_dim 64); everything else as above.
+AUDIO_REAL = {"model_type": "whisper", "d_model": 128, "encoder_layers": 2, "encoder_attention_heads": 2, "encoder_ffn_dim": 256,
+              "num_mel_bins": 80, "max_source_positions": 1500}
+ENCODER_CASES = {            # name -> (mel frames, audio_len or None, audio_latency_block_size or None)
+    "key_padding": (400, [400, 123, 250], None),
+    "latency_and_padding": (400, [400, 123, 250], 50),
+    "latency_only": (300, None, 100),
+    "odd_frames": (77, [77, 40, 1], None),
+}
 
 
 def config_kwargs(ln_mid: bool) -> dict:
@@ -21,6 +31,18 @@ def param(name: str, shape) -> torch.Tensor:
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
     w = torch.randn(tuple(shape), generator=g) * (0.05 if len(shape) > 1 else 0.02)
     return w + 1.0 if (name.endswith("weight") and len(shape) == 1) else w      # norm weights around 1
+
+
+def real_config_kwargs(ln_mid: bool = True, latency=None) -> dict:
+    kw = dict(text_config=dict(TEXT), audio_config=dict(AUDIO_REAL), hidden_size=256, stack_factor=8, projector_ln_mid=ln_mid)
+    if latency is not None:
+        kw["audio_latency_block_size"] = latency
+    return kw
+
+
+def mel(n: int, frames: int, seed: int = 21) -> torch.Tensor:
+    """Seeded stand-in for log-mel features (the Whisper range is roughly [-1, 1.5])."""
+    return torch.randn(n, 80, frames, generator=torch.Generator().manual_seed(seed)) * 0.6
 
 
 def tower_output() -> torch.Tensor:

@@ -694,7 +694,82 @@ def generate_cases():
     print("generate_reference:", out)
 
 
+class _TupleLayer(torch.nn.Module):
+    """Adapter between the reference's ModifiedWhisperEncoder.forward (written for transformers 4.51.3: it calls
+    `encoder_layer(hidden, mask, layer_head_mask=..., output_attentions=...)` and indexes the result with [0],
+    ultravox_model.py:966-975) and the installed 5.x WhisperEncoderLayer (no layer_head_mask, returns the tensor).  It touches
+    no arithmetic: the mask the REFERENCE built (:915-936) is handed to the layer unchanged."""
+
+    def __init__(self, layer):
+        super().__init__()
+        self.layer = layer
+
+    def forward(self, hidden_states, attention_mask, layer_head_mask=None, output_attentions=False):
+        assert layer_head_mask is None and not output_attentions
+        out = self.layer(hidden_states, attention_mask)
+        return out if isinstance(out, tuple) else (out,)
+
+
+def _wrap_encoder_layers(enc):
+    enc.layers = torch.nn.ModuleList([_TupleLayer(l) for l in enc.layers])
+    return enc
+
+
+def real_tower_cases():
+    """The REFERENCE ModifiedWhisperEncoder.forward ITSELF (ultravox_model.py:865-994: conv stem, positional slice, the
+    audio_len key-padding mask :915-926, the latency mask of init_latency_mask :834-863 merged at :928-936, the layer loop,
+    final LayerNorm) on seeded tiny weights, and the REFERENCE UltravoxModel.forward + loss.backward() with that tower in place
+    (nothing stubbed: mel -> tower -> projector -> merge -> Llama -> loss).  Only shim: _TupleLayer above."""
+    import forward_fixture_util as U
+    arrays, meta = {}, {"encoder_cases": {}, "model_cases": {}}
+    wcfg = transformers.WhisperConfig(**{k: v for k, v in U.AUDIO_REAL.items() if k != "model_type"}, attn_implementation="eager")
+    for name, (frames, audio_len, block) in U.ENCODER_CASES.items():
+        enc = ultravox_model.ModifiedWhisperEncoder(wcfg).eval()
+        names = sorted("audio_tower." + n for n, _ in enc.named_parameters())      # incl. embed_positions.weight
+        with torch.no_grad():
+            for n, p in enc.named_parameters():
+                p.copy_(U.param("audio_tower." + n, p.shape))
+        enc.init_latency_mask(block, torch.float32)
+        _wrap_encoder_layers(enc)
+        n_items = 3 if audio_len is None else len(audio_len)
+        x = U.mel(n_items, frames)
+        with torch.no_grad():
+            out = enc(x, audio_len=None if audio_len is None else torch.tensor(audio_len)).last_hidden_state
+        arrays[f"enc.{name}"] = out.numpy()
+        meta["encoder_cases"][name] = {"frames": frames, "audio_len": audio_len, "audio_latency_block_size": block,
+                                       "weight_names": names}
+    for name, ln_mid, latency in (("real_tower", True, None), ("real_tower_latency", True, 100)):
+        kw = U.real_config_kwargs(ln_mid, latency)
+        kw["torch_dtype"] = "float32"           # init_latency_mask reads config.torch_dtype (ultravox_model.py:472-475)
+        m = _seeded_reference_model(ln_mid, base_kwargs=kw)
+        names = sorted(n for n, _ in m.named_parameters())
+        assert isinstance(m.audio_tower, ultravox_model.ModifiedWhisperEncoder)
+        assert (m.audio_tower.audio_streaming_mask is None) == (latency is None)
+        if latency is not None:     # _seeded_reference_model's to_empty() wiped the (non-persistent) mask buffer: let the
+            del m.audio_tower.audio_streaming_mask          # reference build it again
+            m.audio_tower.init_latency_mask(latency, torch.float32)
+        _wrap_encoder_layers(m.audio_tower)
+        b = U.batch()
+        melx = U.mel(U.N_AUDIO, 3000)
+        out = m(audio_values=melx, **b)
+        out.loss.backward()
+        for n, p in m.multi_modal_projector.named_parameters():
+            arrays[f"{name}.g.multi_modal_projector.{n}"] = p.grad.numpy()
+        arrays[f"{name}.logits"] = out.logits.detach().numpy()
+        arrays[f"{name}.loss"] = np.array(out.loss.item(), np.float64)
+        with torch.no_grad():
+            tower = m.audio_tower(melx, audio_len=b["audio_lens"]).last_hidden_state
+        arrays[f"{name}.tower_rows"] = tower[:, :80].numpy()          # the rows the projector's first 10 outputs read
+        meta["model_cases"][name] = {"loss": out.loss.item(), "audio_latency_block_size": latency,
+                                     "weight_names": names}
+    np.savez_compressed(os.path.join(HERE, "real_tower_reference.npz"), **arrays)
+    with open(os.path.join(HERE, "real_tower_reference.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("real_tower_reference:", {k: v["loss"] for k, v in meta["model_cases"].items()}, list(meta["encoder_cases"]))
+
+
 if __name__ == "__main__":
+    real_tower_cases()
     lora_forward_cases()
     kl_forward_cases()
     generate_cases()

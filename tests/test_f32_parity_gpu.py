@@ -139,3 +139,61 @@ def test_forward_matches_the_reference_forward_fixture(name, dtype):
     mine = model.projector_grads()
     for k, g in exp["grads"].items():
         assert rel_l2(mine[k], g) < (1e-3 if dtype == torch.float32 else 8e-2), k
+
+
+@pytest.mark.parametrize("name", ["key_padding", "latency_and_padding", "latency_only", "odd_frames"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_matches_the_reference_encoder_forward_fixture(name, dtype):
+    """uvx_encoder_fwd against a RUN OF THE REFERENCE's ModifiedWhisperEncoder.forward (ultravox_model.py:865-994; fixture
+    tests/golden/real_tower_reference.npz, generator make_golden.py `real_tower_cases`): the key-padding mask from audio_len
+    (:915-926), the latency mask (:834-863) and their merge (:928-936) are the reference's own.  f32 mode: 1e-3 absolute."""
+    import forward_fixture_util as U
+    from test_oracle_pinning import load_real_tower_fixture
+    from ultravox_amd.model import UltravoxModel
+    z, meta, make = load_real_tower_fixture()
+    case = meta["encoder_cases"][name]
+    cfg, sd = make(case["weight_names"], case["audio_latency_block_size"])
+    model = UltravoxModel(cfg, state_dict={k: v.to(dtype) for k, v in sd.items()}, device=DEV, dtype=dtype)
+    n = 3 if case["audio_len"] is None else len(case["audio_len"])
+    lens = None if case["audio_len"] is None else torch.tensor(case["audio_len"], device=DEV)
+    got = model.audio_tower_forward(U.mel(n, case["frames"]).to(DEV, dtype), lens).float().cpu()
+    want = torch.from_numpy(z[f"enc.{name}"])
+    assert got.shape == want.shape
+    if dtype == torch.float32:
+        assert (got - want).abs().max().item() < 1e-3
+    else:
+        assert rel_l2(got, want) < 2e-2
+
+
+@pytest.mark.parametrize("name", ["real_tower", "real_tower_latency"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_matches_the_reference_forward_with_its_own_tower(name, dtype):
+    """The whole HIP path (mel -> encoder -> projector -> merge -> Llama -> loss -> projector gradients) against the REFERENCE
+    UltravoxModel.forward + loss.backward() with nothing stubbed - the reference's ModifiedWhisperEncoder.forward included."""
+    import forward_fixture_util as U
+    from test_oracle_pinning import load_real_tower_fixture
+    from ultravox_amd.model import UltravoxModel
+    z, meta, make = load_real_tower_fixture()
+    case = meta["model_cases"][name]
+    cfg, sd = make(case["weight_names"], case["audio_latency_block_size"])
+    model = UltravoxModel(cfg, state_dict={k: v.to(dtype) for k, v in sd.items()}, device=DEV, dtype=dtype)
+    batch = U.batch()
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    mel = U.mel(U.N_AUDIO, 3000).to(DEV, dtype)
+    out = model.forward(audio_values=mel, **gb)
+    keep = batch["attention_mask"].bool()
+    logits, want = out.logits.float().cpu(), torch.from_numpy(z[f"{name}.logits"])
+    loss = float(z[f"{name}.loss"])
+    if dtype == torch.float32:
+        assert (logits[keep] - want[keep]).abs().max().item() < 1e-3
+        assert abs(out.loss.item() - loss) < 1e-4
+    else:
+        assert rel_l2(logits[keep], want[keep]) < 3e-2
+        assert abs(out.loss.item() - loss) < 2e-2 * loss
+    model.train()
+    model.forward_backward(audio_values=mel, **gb)
+    mine = model.projector_grads()
+    for k in z.files:
+        if k.startswith(name + ".g."):
+            key = k[len(name) + 3:]
+            assert rel_l2(mine[key], torch.from_numpy(z[k])) < (1e-3 if dtype == torch.float32 else 8e-2), key

@@ -423,6 +423,73 @@ def load_forward_fixture(name):
     return cfg, sd, U.batch(mixed=name.endswith("_mixed")), U.tower_output(), exp
 
 
+def load_real_tower_fixture():
+    """tests/golden/real_tower_reference.npz: outputs of the REFERENCE ModifiedWhisperEncoder.forward itself
+    (ultravox_model.py:865-994, masks :915-936 built by the reference, latency mask by its init_latency_mask :834-863) and of
+    the REFERENCE UltravoxModel.forward + backward with that tower in place; weights / inputs are the seeded tensors of
+    tests/forward_fixture_util.py.  -> (arrays, meta, make(kind, latency) -> (cfg, state dict))."""
+    import json
+    import os
+    import forward_fixture_util as U
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import random_state_dict
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(here, "real_tower_reference.npz"))
+    meta = json.load(open(os.path.join(here, "real_tower_reference.json")))
+
+    def make(names, latency):
+        cfg = UltravoxConfig(**U.real_config_kwargs(True, latency))
+        sd = random_state_dict(cfg, seed=1)
+        for key in names:                         # the reference's parameter names ARE this framework's state-dict keys
+            assert key in sd, key
+            sd[key] = U.param(key, sd[key].shape)
+        return cfg, sd
+    return z, meta, make
+
+
+@pytest.mark.parametrize("name", ["key_padding", "latency_and_padding", "latency_only", "odd_frames"])
+def test_oracle_encoder_matches_the_reference_encoder_forward(name):
+    """whisper_encoder_ref against a RUN OF THE REFERENCE's ModifiedWhisperEncoder.forward (fixture: make_golden.py
+    `real_tower_cases`) - conv stem, positional slice, the reference-built key-padding mask, its latency mask, the merge of
+    the two, final LayerNorm.  Rows of padded keys are compared too: with a finite finfo.min mask they are well defined."""
+    import forward_fixture_util as U
+    from oracle import reference_cpu as O
+    z, meta, make = load_real_tower_fixture()
+    case = meta["encoder_cases"][name]
+    cfg, sd = make(case["weight_names"], case["audio_latency_block_size"])
+    assert set(case["weight_names"]) == {k for k in sd if k.startswith("audio_tower.")}
+    n = 3 if case["audio_len"] is None else len(case["audio_len"])
+    lens = None if case["audio_len"] is None else torch.tensor(case["audio_len"])
+    got = O.whisper_encoder_ref(sd, cfg, U.mel(n, case["frames"]), lens)
+    np.testing.assert_allclose(got.numpy(), z[f"enc.{name}"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["real_tower", "real_tower_latency"])
+def test_oracle_forward_matches_the_reference_forward_with_its_own_tower(name):
+    """OracleModel end to end (mel -> encoder -> projector -> merge -> Llama -> loss -> projector gradients) against the
+    REFERENCE UltravoxModel.forward + loss.backward() with NOTHING stubbed (its ModifiedWhisperEncoder.forward included)."""
+    import forward_fixture_util as U
+    from oracle import reference_cpu as O
+    z, meta, make = load_real_tower_fixture()
+    case = meta["model_cases"][name]
+    cfg, sd = make(case["weight_names"], case["audio_latency_block_size"])
+    assert set(case["weight_names"]) == set(sd)
+    batch = U.batch()
+    oracle = O.OracleModel(cfg, sd)
+    mel = U.mel(U.N_AUDIO, 3000)
+    tower = O.whisper_encoder_ref(sd, cfg, mel, batch["audio_lens"])
+    np.testing.assert_allclose(tower[:, :80].numpy(), z[f"{name}.tower_rows"], rtol=1e-4, atol=2e-5)
+    out = oracle.forward(audio_values=mel, **batch)
+    keep = batch["attention_mask"].bool()
+    assert (out["logits"].detach()[keep] - torch.from_numpy(z[f"{name}.logits"])[keep]).abs().max().item() < 2e-5
+    assert abs(out["loss"].item() - float(z[f"{name}.loss"])) < 1e-6
+    out["loss"].backward()
+    for k in z.files:
+        if k.startswith(name + ".g."):
+            key = k[len(name) + 3:]
+            np.testing.assert_allclose(oracle.sd[key].grad.numpy(), z[k], rtol=2e-4, atol=2e-6, err_msg=key)
+
+
 @pytest.mark.parametrize("name", ["ln_mid", "ln_post", "ln_mid_mixed"])
 def test_oracle_forward_matches_the_reference_forward_end_to_end(name):
     """OracleModel.forward + backward against the REFERENCE UltravoxModel.forward run end to end (fixture: make_golden.py
