@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 8
+#define UVX_ABI_VERSION 9
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -61,7 +61,13 @@ typedef struct {
    * multiplied by sqrt(hidden_size) in the model dtype INSIDE the model (transformers 4.51.3 GemmaModel.forward: text and
    * merged audio rows alike), head_dim independent of hidden_size / heads (256), lm_head tied to embed_tokens by the host. */
   int32_t llm_flavor;
+  /* activation of the gated MLP ([3P] ACT2FN[text_config.hidden_act]): UVX_ACT_SILU (Llama), UVX_ACT_GELU_TANH
+   * (gelu_pytorch_tanh, Gemma's default), UVX_ACT_GELU_ERF (exact GELU: Gemma checkpoints whose config says "gelu") */
+  int32_t llm_act;
 } uvx_config_t;
+#define UVX_ACT_SILU 0
+#define UVX_ACT_GELU_TANH 1
+#define UVX_ACT_GELU_ERF 2
 #define UVX_LLM_LLAMA 0
 #define UVX_LLM_GEMMA 1
 
@@ -352,7 +358,11 @@ int32_t uvx_gemm_force_variant(int32_t variant);
 /* probes (same-box A/B inside bench.py): key 1 = 16-byte epilogue loads/stores (default 1), key 2 = SwiGLU backward fused
  * into the down-projection dgrad GEMM (default 0: measured neutral), key 3 = LM head / CE / head dgrad on the supervised
  * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
- * problems of at most 16 rows (the decode step; default 1) */
+ * problems of at most 16 rows (the decode step; default 1), key 11 = LLM layer chains of the two batch halves on two
+ * streams (2 = on, the default; 0 = one chain on the caller's stream; uvx_llm_fwd* / uvx_llm_bwd*: same kernels on the same rows, bit-identical results; the side stream is
+ * forked from and joined into the caller's stream by events, so the call stays stream-ordered for the caller), key 12 = bf16
+ * attention kernels read V^T / Q^T / K^T / dO^T out of the natural tiles with the transposing LDS read instead of from
+ * transposed copies in global memory (default 1; 0 restores the copies: heads_transpose + the *_t staging) */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* Diagnostic for the stream-K GEMM launches (probe builds only - libuvx_probes.so; the production picker never selects
  * them and this returns 0): blocks that wait for another block's partial sums spin for a bounded time (~1 s) and then give
@@ -363,6 +373,10 @@ int32_t uvx_gemm_streamk_timeouts(void);
 int32_t uvx_gemm_pick_variant(int32_t M, int32_t N, int32_t K, int32_t batch);
 /* probes: use `variant` for problems of exactly this shape (in-situ A/B inside bench.py); variant < 0 clears the table */
 int32_t uvx_gemm_override_variant(int32_t M, int32_t N, int32_t K, int32_t variant);
+/* probe of the gfx950 transposing LDS read (ds_read_b64_tr_b16) that the bf16 attention kernels rely on for their transposed
+ * operands: one wave; lane l supplies the BYTE offset addr[l] (8-byte aligned, < 8184) into an LDS image whose 16-bit element e
+ * holds the value e; out[4 l + j] = element j the instruction returned to lane l.  tests/test_kernels_gpu.py pins the semantics. */
+int32_t uvx_probe_lds_tr(void* stream, const int32_t* addr, int32_t* out);
 /* probes: force the attention forward q-tile count per wave (1 or 2; 0 = automatic) */
 int32_t uvx_attention_force_qt(int32_t qt);
 
@@ -414,6 +428,10 @@ int32_t uvx_kl_loss(void* stream, int32_t dtype, const void* student_logits, con
  * for class 0 = bf16 MFMA GEMM (classes 1.. reserved) and synchronises on the recorded events. */
 int32_t uvx_prof_begin(void);
 int32_t uvx_prof_end(double* out, int32_t n_classes);
+/* wall time (ms) during which at least one launch of the class was executing: the union of the event intervals (= the summed
+ * durations on one stream; with the two-stream LLM schedule, uvx_set_option(11, 2), launches of the two chains overlap).
+ * Call before uvx_prof_end; negative on error. */
+double uvx_prof_union_ms(int32_t cls);
 /* per-launch GEMM records of the region (call before uvx_prof_end): out[i*6 + {M,N,K,batch,variant,ms}] */
 int32_t uvx_prof_records(double* out, int32_t max_records);
 

@@ -40,12 +40,13 @@ def test_attention_head_dim_256_forward_backward(Hq, Hkv, T, causal):
     assert rel_l2(dqf, qr.grad) < 1e-5 and rel_l2(dkf, kr.grad) < 1e-5 and rel_l2(dvf, vr.grad) < 1e-5
 
 
-def _cfg(head_dim, **kw):
+def _cfg(head_dim, hidden_act=None, **kw):
     from ultravox_amd.config import UltravoxConfig
     return UltravoxConfig(
         audio_config=dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256),
         text_config=dict(model_type="gemma", hidden_size=192, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
-                         num_key_value_heads=2, head_dim=head_dim, vocab_size=512, rms_norm_eps=1e-6, eos_token_id=1),
+                         num_key_value_heads=2, head_dim=head_dim, vocab_size=512, rms_norm_eps=1e-6, eos_token_id=1,
+                         **({"hidden_act": hidden_act} if hidden_act else {})),
         hidden_size=256, projector_ln_mid=True, **kw)
 
 
@@ -75,6 +76,20 @@ def test_gemma_train_step_f32_within_1e3(head_dim):
     mine = model.projector_grads()
     for k, g in grads.items():
         assert rel_l2(mine[k], g) < 2e-3, k
+
+
+def test_gemma_hidden_act_gelu_is_the_exact_erf_gelu():
+    """A Gemma checkpoint whose config says hidden_act = "gelu" runs the exact erf GELU in [3P] GemmaMLP (ACT2FN[hidden_act]);
+    UVX_ACT_GELU_ERF follows it (forward, backward, f32 at 1e-3) - and differs measurably from the tanh approximation."""
+    model, out, loss, ref, grads = _step(_cfg(64, hidden_act="gelu"), torch.float32, 33)
+    assert model._c.llm_act == 2
+    assert (out.logits.cpu() - ref["logits"]).abs().max().item() < 1e-3
+    assert abs(out.loss.item() - ref["loss"].item()) < 1e-4 and abs(loss.item() - ref["loss"].item()) < 1e-4
+    mine = model.projector_grads()
+    for k, g in grads.items():
+        assert rel_l2(mine[k], g) < 2e-3, k
+    model_b, out_b, loss_b, ref_b, grads_b = _step(_cfg(64, hidden_act="gelu"), torch.bfloat16, 33)
+    assert rel_l2(out_b.logits, ref_b["logits"]) < 3e-2 and abs(loss_b.item() - ref_b["loss"].item()) < 2e-2 * abs(ref_b["loss"].item())
 
 
 @pytest.mark.parametrize("head_dim", [64, 256])

@@ -470,3 +470,54 @@ def test_gemm_few_rows_weight_streaming_kernel(M, N, K):
         finally:
             L.uvx_set_option(4, 1)
         assert rel_l2(gu, gu_t) < 3e-3 and rel_l2(act, act_t) < 6e-3
+
+
+def test_lds_transpose_read_semantics():
+    """ds_read_b64_tr_b16 (gfx950), the instruction the bf16 attention kernels use to read V^T / Q^T / K^T / dO^T out of the
+    natural [row][d] LDS tiles: every lane supplies the address of one 8-byte chunk; within each group of 16 lanes, result
+    element j of lane i is element (i & 3) of the chunk supplied by lane 4*j + (i >> 2).  Pinned for distinct, permuted and
+    strided per-lane addresses (uvx_probe_lds_tr: the LDS image holds value e at 16-bit element e)."""
+    import ctypes as C
+    from ultravox_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    cases = [torch.arange(64, dtype=torch.int32) * 8,                                   # consecutive chunks
+             torch.randperm(64, generator=g).to(torch.int32) * 8,                       # any chunk per lane
+             (torch.arange(64, dtype=torch.int32) // 4) * 256 + (torch.arange(64, dtype=torch.int32) % 4) * 8 + 1024]   # rows of a 256-byte-pitch tile
+    for addr in cases:
+        a = addr.to(DEV)
+        out = torch.zeros(256, dtype=torch.int32, device=DEV)
+        _lib.check(L.uvx_probe_lds_tr(None, C.c_void_p(a.data_ptr()), C.c_void_p(out.data_ptr())), "uvx_probe_lds_tr")
+        torch.cuda.synchronize()
+        got = out.cpu().view(64, 4)
+        want = torch.empty(64, 4, dtype=torch.int32)
+        for lane in range(64):
+            grp, i = lane // 16 * 16, lane % 16
+            for j in range(4):
+                want[lane, j] = addr[grp + 4 * j + (i >> 2)] // 2 + (i & 3)
+        assert torch.equal(got, want), (addr[:8], got[:4], want[:4])
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,T,causal,block", [(128, 8, 2, 316, True, 0), (64, 3, 3, 700, False, 50), (256, 2, 1, 150, True, 0)])
+def test_attention_transposing_lds_reads_equal_the_transposed_copies(D, Hq, Hkv, T, causal, block):
+    """Option 12 (default on): natural tiles + ds_read_b64_tr_b16 instead of V^T / Q^T / K^T / dO^T copies in global memory.
+    Same operands in the same contraction order: forward output, log-sum-exp and all three gradients are bit-identical."""
+    from ultravox_amd import _lib
+    torch.manual_seed(11)
+    B = 2
+    q = bf(torch.randn(B, T, Hq, D, device=DEV)); k = bf(torch.randn(B, T, Hkv, D, device=DEV)); v = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    do = bf(torch.randn(B, T, Hq * D, device=DEV))
+    kv_len = torch.tensor([T, T - 29], device=DEV, dtype=torch.int32)
+
+    def run():
+        o, lse = ops().attention(q, k, v, causal=causal, block=block, kv_len=kv_len)
+        return (o, lse) + tuple(ops().attention_bwd(q, k, v, o, lse, do, causal=causal, block=block, kv_len=kv_len))
+
+    new = run()
+    _lib.lib().uvx_set_option(12, 0)
+    try:
+        old = run()
+    finally:
+        _lib.lib().uvx_set_option(12, 1)
+    for a, b in zip(new, old):
+        assert torch.equal(a, b)

@@ -315,3 +315,40 @@ def test_loss_head_on_supervised_rows_split_k(T, first_label):
     last = [int(sup[b].nonzero().max()) for b in range(B)]
     for b in range(B):
         assert float(d[b, last[b] + 1:].float().abs().max() if last[b] + 1 < T else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("B,T", [(2, 48), (5, 70), (8, 316)])
+def test_two_stream_llm_schedule_is_bit_identical(B, T):
+    """uvx_set_option(11, 2) (the default): the LLM layer chains of the two batch halves run on two streams (the caller's and one forked
+    from / joined into it by events).  Same kernels on the same rows: loss, full logits and d loss / d inputs_embeds must be
+    BIT-identical to the one-stream schedule - for the plain pair (full logits), the training pair (last layer and head on the
+    supervised rows), an odd batch (halves of 3 and 2) and with left / right padding in the attention mask."""
+    from ultravox_amd import _lib
+    tc = dict(SMALL["text_config"], num_hidden_layers=3)
+    cfg, sd, model, oracle = build(13, text_config=tc)
+    torch.manual_seed(5)
+    emb = (torch.randn(B, T, 256) * 0.5).bfloat16().to(DEV)
+    labels = torch.randint(0, 512, (B, T)); labels[:, : T // 2] = -100
+    mask = torch.ones(B, T, dtype=torch.long); mask[0, :3] = 0; mask[B - 1, T - 4:] = 0
+    labels[B - 1, T - 4:] = -100
+    labels, mask = labels.to(DEV), mask.to(DEV)
+
+    def run():
+        full = model.language_model_forward(emb, labels=labels, attention_mask=mask, want_logits=True, save_for_bwd=True)
+        d_full = model.language_model_backward(1.0).clone()
+        tr = model.language_model_forward(emb, labels=labels, attention_mask=mask, want_logits=False, save_for_bwd=True)
+        assert model._llm_train_pair
+        d_tr = model.language_model_backward(1.0).clone()
+        torch.cuda.synchronize()
+        return full.logits.clone(), full.loss.clone(), d_full, tr.loss.clone(), d_tr
+
+    _lib.lib().uvx_set_option(11, 0)
+    try:
+        one = run()
+    finally:
+        _lib.lib().uvx_set_option(11, 2)       # the default
+    two = run()
+    two_again = run()
+    for a, b, c in zip(one, two, two_again):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.isfinite(one[2].float()).all() and one[2].float().abs().max() > 0

@@ -319,21 +319,27 @@ def test_lora_restatement_matches_reference_apply_lora_fixture(golden_dir):
         np.testing.assert_allclose(sd["language_model." + n].grad.numpy(), z["llm.g." + n], rtol=2e-4, atol=2e-5, err_msg=n)
 
 
-def test_gemma_backbone_matches_hf_blocks():
-    """BASELINE config 5's backbone.  [3P] check: the oracle's Gemma flavour (GemmaRMSNorm, GeGLU, head_dim from the config,
+@pytest.mark.parametrize("hidden_act", ["gelu_pytorch_tanh", "gelu"])
+def test_gemma_backbone_matches_hf_blocks(hidden_act):
+    """hidden_act "gelu": [3P] GemmaMLP applies ACT2FN[config.hidden_act], so a checkpoint whose config.json says "gelu" runs the
+    EXACT erf GELU (not the tanh approximation) - the oracle and the HIP path (UVX_ACT_GELU_ERF) follow the config.
+    BASELINE config 5's backbone.  [3P] check: the oracle's Gemma flavour (GemmaRMSNorm, GeGLU, head_dim from the config,
     tied head, sqrt(hidden) embedding scale) == the installed HF GemmaForCausalLM.  The reference pins transformers 4.51.3,
     whose GemmaModel.forward multiplies whatever inputs_embeds it receives by the normalizer; the installed 5.x moved that
     scale into the embedding module, so the installed stack is fed PRE-SCALED embeddings."""
     from transformers import GemmaConfig, GemmaForCausalLM
     cfg = UltravoxConfig(audio_config=TINY["audio_config"], hidden_size=64,
                          text_config=dict(model_type="gemma", hidden_size=96, intermediate_size=256, num_hidden_layers=2,
-                                          num_attention_heads=4, num_key_value_heads=2, head_dim=32, vocab_size=160, rms_norm_eps=1e-6))
+                                          num_attention_heads=4, num_key_value_heads=2, head_dim=32, vocab_size=160, rms_norm_eps=1e-6,
+                                          **({} if hidden_act == "gelu_pytorch_tanh" else {"hidden_act": hidden_act})))
     t = cfg.text_config
-    assert t.is_gemma and t.hidden_act == "gelu_pytorch_tanh" and t.head_dim * t.num_attention_heads != t.hidden_size
+    assert t.is_gemma and t.hidden_act == hidden_act and t.head_dim * t.num_attention_heads != t.hidden_size
     hf = GemmaForCausalLM(GemmaConfig(hidden_size=96, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
                                       num_key_value_heads=2, head_dim=32, vocab_size=160, rms_norm_eps=1e-6, rope_theta=t.rope_theta,
-                                      max_position_embeddings=t.max_position_embeddings, hidden_activation="gelu_pytorch_tanh",
+                                      max_position_embeddings=t.max_position_embeddings, hidden_act=hidden_act,
                                       attn_implementation="eager")).eval()
+    assert type(hf.model.layers[0].mlp.act_fn).__name__ == ("GELUTanh" if hidden_act == "gelu_pytorch_tanh" else "GELUActivation"), \
+        type(hf.model.layers[0].mlp.act_fn)
     sd = random_state_dict(cfg, seed=4)
     assert "language_model.lm_head.weight" not in sd                      # tied: the head is the embedding matrix
     llm_sd = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}

@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 8   # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+ABI_VERSION = 9   # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
 
 
 def lib() -> C.CDLL:
@@ -95,7 +95,7 @@ class Config(C.Structure):
         ("proj_eps", C.c_float),
         ("llm_layers", C.c_int32), ("llm_d", C.c_int32), ("llm_heads", C.c_int32), ("llm_kv_heads", C.c_int32),
         ("llm_head_dim", C.c_int32), ("llm_inter", C.c_int32), ("vocab", C.c_int32), ("rms_eps", C.c_float),
-        ("llm_flavor", C.c_int32),
+        ("llm_flavor", C.c_int32), ("llm_act", C.c_int32),
     ]
 
 
@@ -178,7 +178,7 @@ EXPORTS = [
     "uvx_projector_ws_bytes", "uvx_projector_fwd", "uvx_projector_bwd", "uvx_embed_merge", "uvx_merge_embeds_bwd",
     "uvx_llm_ws_bytes", "uvx_llm_fwd", "uvx_llm_bwd", "uvx_adamw_clip_step", "uvx_gemm", "uvx_layernorm",
     "uvx_rmsnorm", "uvx_rmsnorm_bwd", "uvx_swiglu", "uvx_swiglu_bwd", "uvx_rope", "uvx_attention_ws_bytes",
-    "uvx_attention_fwd", "uvx_attention_bwd", "uvx_ce_loss", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records", "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes",
+    "uvx_attention_fwd", "uvx_attention_bwd", "uvx_ce_loss", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records", "uvx_prof_union_ms", "uvx_probe_lds_tr", "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes",
     "uvx_llm_prefill", "uvx_llm_prefill_chunk", "uvx_llm_prefill_chunk_ws_bytes", "uvx_llm_decode", "uvx_argmax", "uvx_llm_kl_loss", "uvx_kl_loss", "uvx_gemm_override_variant", "uvx_gemm_pick_variant", "uvx_set_option",
     "uvx_encoder_train_ws_bytes", "uvx_encoder_fwd_train", "uvx_encoder_bwd", "uvx_layernorm_bwd", "uvx_gelu", "uvx_gelu_bwd",
     "uvx_llm_fwd_rows", "uvx_llm_kl_loss_rows", "uvx_llm_bwd_rows", "uvx_llm_fwd_lora", "uvx_llm_bwd_lora",
@@ -196,5 +196,8 @@ def _declare(l: C.CDLL) -> None:
     for name in EXPORTS:
         f = getattr(l, name)
         if name.endswith("_bytes") or name in ("uvx_last_error", "uvx_abi_version"):
+            continue
+        if name == "uvx_prof_union_ms":
+            f.restype, f.argtypes = C.c_double, [C.c_int32]
             continue
         f.restype = C.c_int32

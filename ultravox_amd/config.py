@@ -147,7 +147,8 @@ class TextConfig:
         want = "silu" if self.model_type == "llama" else "gelu_pytorch_tanh"
         if self.hidden_act is None:
             self.hidden_act = want
-        # [3P] GemmaConfig: "gelu" in old checkpoints is the same tanh approximation (hidden_activation defaults to it)
+        # [3P] GemmaMLP applies ACT2FN[config.hidden_act] (transformers 4.51.3 and the installed 5.x alike): "gelu" in a Gemma
+        # checkpoint's config.json is the EXACT erf GELU, not the tanh approximation - built as its own GLU activation
         if self.hidden_act != want and not (self.model_type == "gemma" and self.hidden_act == "gelu"):
             raise ValueError(f"text_config.hidden_act {self.hidden_act!r} is not built for {self.model_type} ({want})")
 

@@ -26,9 +26,14 @@ extern "C" int32_t uvx_gemm_force_variant(int32_t v) {
 }
 
 extern "C" int32_t uvx_set_option(int32_t key, int32_t value) {
-  UVX_CHECK(key > 0 && key < 12, UVX_ERR_INVALID, "uvx_set_option: unknown key %d", key);
+  UVX_CHECK(key > 0 && key < 16, UVX_ERR_INVALID, "uvx_set_option: unknown key %d", key);
   uvx::g_options[key] = value;
   return UVX_OK;
+}
+
+extern "C" int32_t uvx_probe_lds_tr(void* stream, const int32_t* addr, int32_t* out) {
+  UVX_CHECK(addr && out, UVX_ERR_INVALID, "uvx_probe_lds_tr: null argument");
+  return uvx::lds_tr_probe((hipStream_t)stream, addr, out);
 }
 
 extern "C" int32_t uvx_gemm_streamk_timeouts(void) { return uvx::gemm_streamk_timeouts(); }
@@ -143,8 +148,10 @@ extern "C" int32_t uvx_attention_fwd(void* stream, int32_t dtype, const uvx_attn
   AttnWs w = attn_carve((char*)workspace, dtype, *d, 0);
   UVX_CHECK(w.bytes <= ws_bytes + 256, UVX_ERR_WORKSPACE, "attention_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  int rc = uvx::heads_transpose(st, dtype, d->v, w.vt, d->B, d->T, w.Tp, d->Hkv, d->D, d->ldv);
-  if (rc) return rc;
+  if (uvx::attention_needs_transposed_copies(dtype)) {
+    int rc = uvx::heads_transpose(st, dtype, d->v, w.vt, d->B, d->T, w.Tp, d->Hkv, d->D, d->ldv);
+    if (rc) return rc;
+  }
   return uvx::attention_fwd(st, dtype, to_desc(*d, w));
 }
 extern "C" int32_t uvx_attention_bwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d, void* workspace,
@@ -154,9 +161,11 @@ extern "C" int32_t uvx_attention_bwd(void* stream, int32_t dtype, const uvx_attn
   UVX_CHECK(w.bytes <= ws_bytes + 256, UVX_ERR_WORKSPACE, "attention_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if ((rc = uvx::heads_transpose(st, dtype, d->q, w.qt, d->B, d->T, w.Tp, d->Hq, d->D, d->ldq))) return rc;
-  if ((rc = uvx::heads_transpose(st, dtype, d->k, w.kt, d->B, d->T, w.Tp, d->Hkv, d->D, d->ldk))) return rc;
-  if ((rc = uvx::heads_transpose(st, dtype, d->dout, w.dot, d->B, d->T, w.Tp, d->Hq, d->D, d->ldo))) return rc;
+  if (uvx::attention_needs_transposed_copies(dtype)) {
+    if ((rc = uvx::heads_transpose(st, dtype, d->q, w.qt, d->B, d->T, w.Tp, d->Hq, d->D, d->ldq))) return rc;
+    if ((rc = uvx::heads_transpose(st, dtype, d->k, w.kt, d->B, d->T, w.Tp, d->Hkv, d->D, d->ldk))) return rc;
+    if ((rc = uvx::heads_transpose(st, dtype, d->dout, w.dot, d->B, d->T, w.Tp, d->Hq, d->D, d->ldo))) return rc;
+  }
   uvx::AttnBwdDesc b;
   b.f = to_desc(*d, w);
   b.dout = d->dout; b.qt = w.qt; b.kt = w.kt; b.dot = w.dot; b.delta = w.delta; b.dkv_part = w.part;

@@ -84,6 +84,28 @@ __device__ __forceinline__ int tr_off8(int row, int c8) {
   constexpr int M8 = W / 4 - 1;  // chunk index mask
   return row * (W * 2) + (((c8 ^ tr_sw<W>(row)) & M8) << 3);
 }
+// A-operand fragment [row = d0 + (lane & 15)][k-slot (g, s)] of the TRANSPOSE of a natural tile (rows = contraction index r,
+// columns = d), with the permuted contraction order used throughout this file: slot (g, s) <-> r = r0 + 16*(s>>2) + 4*g + (s&3).
+// gfx950's transposing LDS read (ds_read_b64_tr_b16) makes the transposed global copies (V^T, Q^T, K^T, dO^T: four HBM round
+// trips per layer) unnecessary: every lane supplies the address of ONE 8-byte chunk (4 consecutive d of one row), and within
+// each group of 16 lanes result element j of lane i is element (i & 3) of the chunk supplied by lane 4*j + (i >> 2).  So
+// lane i points at row r0 + 4*g + (i >> 2), columns d0 + 4*(i & 3) ..+3, and receives rows r0 + 4*g + j (j = 0..3) of column
+// d0 + i; a second read 16 rows further down completes the 8-slot fragment.  (Semantics pinned on the GPU by
+// tests/test_kernels_gpu.py::test_lds_transpose_read_semantics through uvx_probe_lds_tr.)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ s16x4_t lds_tr_b64(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+template <int D>
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int r0, int d0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int row = r0 + 4 * g + (i >> 2), col = d0 + 4 * (i & 3);
+  const char* p0 = tile + nat_off<D>(row, col >> 3) + ((col & 4) << 1);
+  const char* p1 = tile + nat_off<D>(row + 16, col >> 3) + ((col & 4) << 1);
+  const s16x4_t a = lds_tr_b64(p0), b = lds_tr_b64(p1);
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // Register-staged tiles (async-STAGE split): the global loads of tile j+1 are ISSUED before the MFMA work
 // of tile j and written to the other LDS buffer after it, so HBM/L2 latency hides under compute and
 // there is one barrier per tile.
@@ -139,7 +161,8 @@ __device__ __forceinline__ void store_tr(char* lds, const TrRegs<D, W, NT>& g, i
 }
 
 // =================================== forward ===================================
-template <int D, int QT>
+// TR: V is staged in its natural [key][d] layout and read through the transposing LDS read (no V^T copy in global memory)
+template <int D, int QT, bool TR>
 __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   constexpr int BQ = 4 * QT * 16;
   constexpr int KS = D / 32;   // k-steps of the QK^T product
@@ -185,16 +208,23 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   if (p.block > 0) kb_end = min(kb_end, ((qb0 + BQ - 1) / p.block + 1) * p.block);
   kb_end = min(kb_end, k_hi);
   const bf16_t* kbase = p.k + (long long)b * p.T * p.ldk + hk * D;
-  const bf16_t* vtbase = p.vt + ((long long)b * p.Hkv + hk) * D * p.Tp;
+  const bf16_t* vtbase = TR ? nullptr : p.vt + ((long long)b * p.Hkv + hk) * D * p.Tp;
+  const bf16_t* vbase = TR ? p.v + (long long)b * p.T * p.ldv + hk * D : nullptr;
 
   NatRegs<D, 64> kreg;
-  TrRegs<D, 64> vreg;
+  TrRegs<D, 64> vreg;      // (!TR)
+  NatRegs<D, 64> vnreg;    // (TR)
   const int kb_begin = (k_lo / 64) * 64;
   if (kb_begin < kb_end) {
     load_nat<D, 64>(kreg, kbase, p.ldk, kb_begin, p.T, tid);
-    load_tr<D, 64>(vreg, vtbase, p.Tp, kb_begin, tid);
     store_nat<D, 64>(ldsKV, kreg, tid);
-    store_tr<D, 64>(ldsKV + TILE, vreg, tid);
+    if constexpr (TR) {
+      load_nat<D, 64>(vnreg, vbase, p.ldv, kb_begin, p.T, tid);
+      store_nat<D, 64>(ldsKV + TILE, vnreg, tid);
+    } else {
+      load_tr<D, 64>(vreg, vtbase, p.Tp, kb_begin, tid);
+      store_tr<D, 64>(ldsKV + TILE, vreg, tid);
+    }
   }
   __syncthreads();
   int cur = 0;
@@ -205,7 +235,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
     // its own tile: branch-free, so the VMEM count per iteration is static)
     const int kn = kb + 64 < kb_end ? kb + 64 : kb;
     load_nat<D, 64>(kreg, kbase, p.ldk, kn, p.T, tid);
-    load_tr<D, 64>(vreg, vtbase, p.Tp, kn, tid);
+    if constexpr (TR) load_nat<D, 64>(vnreg, vbase, p.ldv, kn, p.T, tid);
+    else load_tr<D, 64>(vreg, vtbase, p.Tp, kn, tid);
 
     // ---- S^T = K . Q^T ----
     f32x4_t s[QT][4];
@@ -288,13 +319,16 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 #pragma unroll
       for (int kp = 0; kp < 2; ++kp) {
         const int row = d * 16 + fr;
-        const bf16x8_t vf = lds_2xb64(ldsV + tr_off8<64>(row, kp * 8 + g), ldsV + tr_off8<64>(row, kp * 8 + 4 + g));
+        bf16x8_t vf;
+        if constexpr (TR) vf = tr_frag<D>(ldsV, kp * 32, d * 16, lane);
+        else vf = lds_2xb64(ldsV + tr_off8<64>(row, kp * 8 + g), ldsV + tr_off8<64>(row, kp * 8 + 4 + g));
 #pragma unroll
         for (int t = 0; t < QT; ++t) acc_o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][kp], acc_o[t][d], 0, 0, 0);
       }
     // the other buffer was last read one iteration ago, before the previous barrier
     store_nat<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE, kreg, tid);
-    store_tr<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE + TILE, vreg, tid);
+    if constexpr (TR) store_nat<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE + TILE, vnreg, tid);
+    else store_tr<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE + TILE, vreg, tid);
     __syncthreads();
   }
 
@@ -326,13 +360,15 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 // reads -> 16 MFMAs -> exp / pack -> LDS reads -> 16 MFMAs -> staging stores -> barrier) that two waves per SIMD do not
 // hide (PMC, round 2: 8 000 wave cycles per 32-query step for ~400 instructions), so the fixed part is paid half as often.
 // DEEP: two-deep register prefetch (two staging sets, alternating) instead of one step ahead.
-template <int D, int NT, int ST, bool DEEP>
+// TR: only the natural Q / dO tiles are staged; their transposes come from the transposing LDS read (no Q^T / dO^T copies).
+template <int D, int NT, int ST, bool DEEP, bool TR>
 __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   constexpr int KB = NT / 4;        // keys per block
   constexpr int KS = D / 32, DT = D / 16, QT = ST / 16, KP = ST / 32;
   constexpr int TILE = ST * D * 2;
-  __shared__ __attribute__((aligned(16))) char ldsAll[8 * TILE + 4 * ST * 4];  // [buf][Q | dO | Q^T | dO^T], then [buf][lse | delta]
-  float* ldsStat = reinterpret_cast<float*>(ldsAll + 8 * TILE);
+  constexpr int NTILE = TR ? 2 : 4;   // tiles per buffer
+  __shared__ __attribute__((aligned(16))) char ldsAll[2 * NTILE * TILE + 4 * ST * 4];  // [buf][Q | dO (| Q^T | dO^T)], then [buf][lse | delta]
+  float* ldsStat = reinterpret_cast<float*>(ldsAll + 2 * NTILE * TILE);
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -376,7 +412,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   // issued before the MFMA work of the current one and written to the other LDS buffer after it (one barrier per step)
   const int nq = q_begin < p.T ? (p.T - q_begin + ST - 1) / ST : 0;
   const int n_it = grp * nq;
-  struct StepRegs { NatRegs<D, ST, NT> q, d_o; TrRegs<D, ST, NT> qt, dot; float l, dl; };
+  struct StepRegs { NatRegs<D, ST, NT> q, d_o; TrRegs<D, TR ? 8 * NT / D : ST, NT> qt, dot; float l, dl; };   // (TR: qt / dot unused, minimal)
   StepRegs r0, r1;
   // (head, query step) cursors advance by increments: an integer division per step is ~25 scalar instructions
   const int q_last = q_begin + (nq - 1) * ST, h_last = h_first + grp - 1;
@@ -389,8 +425,10 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     else if (ih < h_last) { iqs = q_begin; ++ih; }
     load_nat<D, ST, NT>(r.q, p.q + (long long)b * p.T * p.ldq + h * D, p.ldq, qs, p.T, tid);
     load_nat<D, ST, NT>(r.d_o, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
-    load_tr<D, ST, NT>(r.qt, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
-    load_tr<D, ST, NT>(r.dot, p.dot + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
+    if constexpr (!TR) {
+      load_tr<D, ST, NT>(r.qt, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
+      load_tr<D, ST, NT>(r.dot, p.dot + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
+    }
     {  // every thread loads (clamped index, branch-free: keeps the per-iteration VMEM count static);
        // queries >= T are masked by the consumers
       const int q = min(qs + (tid & (ST - 1)), p.T - 1);
@@ -399,11 +437,13 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     }
   };
   auto commit = [&](const StepRegs& r, int buf) {
-    char* base = ldsAll + buf * 4 * TILE;
+    char* base = ldsAll + buf * NTILE * TILE;
     store_nat<D, ST, NT>(base, r.q, tid);
     store_nat<D, ST, NT>(base + TILE, r.d_o, tid);
-    store_tr<D, ST, NT>(base + 2 * TILE, r.qt, tid);
-    store_tr<D, ST, NT>(base + 3 * TILE, r.dot, tid);
+    if constexpr (!TR) {
+      store_tr<D, ST, NT>(base + 2 * TILE, r.qt, tid);
+      store_tr<D, ST, NT>(base + 3 * TILE, r.dot, tid);
+    }
     if (tid < ST) { ldsStat[buf * 2 * ST + tid] = r.l; ldsStat[buf * 2 * ST + ST + tid] = r.dl; }
   };
   auto compute = [&](int cur) {
@@ -413,10 +453,10 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     // nothing to add when every (query, key) pair of this wave's tile is masked: its keys lie after the step's last query
     // (the first steps of a causal block) or outside the valid key range
     if ((p.causal && key_w0 > qs + ST - 1) || key_w0 >= k_hi || key_w0 + 16 <= k_lo) return;
-    const char* ldsQ = ldsAll + cur * 4 * TILE;
+    const char* ldsQ = ldsAll + cur * NTILE * TILE;
     const char* ldsDO = ldsQ + TILE;
-    const char* ldsQT = ldsQ + 2 * TILE;
-    const char* ldsDOT = ldsQ + 3 * TILE;
+    const char* ldsQT = ldsQ + 2 * TILE;      // (!TR)
+    const char* ldsDOT = ldsQ + 3 * TILE;     // (!TR)
     const float* ldsL = ldsStat + cur * 2 * ST;
     const float* ldsDl = ldsL + ST;
     // S[q][key] and dP[q][key] for the QT 16-query tiles: A = Q / dO rows, B = K / V fragments
@@ -470,8 +510,14 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
       const int row = d * 16 + fr;
 #pragma unroll
       for (int kp = 0; kp < KP; ++kp) {
-        const bf16x8_t a = lds_2xb64(ldsDOT + tr_off8<ST>(row, kp * 8 + g), ldsDOT + tr_off8<ST>(row, kp * 8 + 4 + g));
-        const bf16x8_t c = lds_2xb64(ldsQT + tr_off8<ST>(row, kp * 8 + g), ldsQT + tr_off8<ST>(row, kp * 8 + 4 + g));
+        bf16x8_t a, c;
+        if constexpr (TR) {
+          a = tr_frag<D>(ldsDO, kp * 32, d * 16, lane);
+          c = tr_frag<D>(ldsQ, kp * 32, d * 16, lane);
+        } else {
+          a = lds_2xb64(ldsDOT + tr_off8<ST>(row, kp * 8 + g), ldsDOT + tr_off8<ST>(row, kp * 8 + 4 + g));
+          c = lds_2xb64(ldsQT + tr_off8<ST>(row, kp * 8 + g), ldsQT + tr_off8<ST>(row, kp * 8 + 4 + g));
+        }
         acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB[kp], acc_dv[d], 0, 0, 0);
         acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB[kp], acc_dk[d], 0, 0, 0);
       }
@@ -536,12 +582,13 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
 // =================================== backward: dQ ===================================
 // Block = (query block of NT/4, head, batch): NT/64 waves, wave w owns queries qb0 + w*16 .. +16; loops over ST-key steps
 // (NT, ST, DEEP as in the dK/dV kernel).
-template <int D, int NT, int ST, bool DEEP>
+template <int D, int NT, int ST, bool DEEP, bool TR>
 __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   constexpr int QB = NT / 4;        // queries per block
   constexpr int KS = D / 32, DT = D / 16, KT = ST / 16, KP = ST / 32;
   constexpr int TILE = ST * D * 2;
-  __shared__ __attribute__((aligned(16))) char ldsAll[6 * TILE];  // [buf][K | V | K^T]
+  constexpr int NTILE = TR ? 2 : 3;   // tiles per buffer
+  __shared__ __attribute__((aligned(16))) char ldsAll[2 * NTILE * TILE];  // [buf][K | V (| K^T)]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -586,10 +633,10 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   kend = min(kend, k_hi);
   const bf16_t* kbase = p.k + (long long)b * p.T * p.ldk + hk * D;
   const bf16_t* vbase = p.v + (long long)b * p.T * p.ldv + hk * D;
-  const bf16_t* ktbase = p.kt + ((long long)b * p.Hkv + hk) * D * p.Tp;
+  const bf16_t* ktbase = TR ? nullptr : p.kt + ((long long)b * p.Hkv + hk) * D * p.Tp;
 
   // key steps of ST, software pipelined like the dK/dV kernel
-  struct StepRegs { NatRegs<D, ST, NT> k, v; TrRegs<D, ST, NT> kt; };
+  struct StepRegs { NatRegs<D, ST, NT> k, v; TrRegs<D, TR ? 8 * NT / D : ST, NT> kt; };   // (TR: kt unused, minimal)
   StepRegs r0, r1;
   const int k_begin = (k_lo / ST) * ST;
   const int n_it = k_begin < kend ? (kend - k_begin + ST - 1) / ST : 0;
@@ -600,12 +647,12 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
     if (iks < k_last) iks += ST;                        // past the end: re-load the last step (static VMEM count)
     load_nat<D, ST, NT>(r.k, kbase, p.ldk, ks0, p.T, tid);
     load_nat<D, ST, NT>(r.v, vbase, p.ldv, ks0, p.T, tid);
-    load_tr<D, ST, NT>(r.kt, ktbase, p.Tp, ks0, tid);
+    if constexpr (!TR) load_tr<D, ST, NT>(r.kt, ktbase, p.Tp, ks0, tid);
   };
   auto commit = [&](const StepRegs& r, int buf) {
-    store_nat<D, ST, NT>(ldsAll + buf * 3 * TILE, r.k, tid);
-    store_nat<D, ST, NT>(ldsAll + buf * 3 * TILE + TILE, r.v, tid);
-    store_tr<D, ST, NT>(ldsAll + buf * 3 * TILE + 2 * TILE, r.kt, tid);
+    store_nat<D, ST, NT>(ldsAll + buf * NTILE * TILE, r.k, tid);
+    store_nat<D, ST, NT>(ldsAll + buf * NTILE * TILE + TILE, r.v, tid);
+    if constexpr (!TR) store_tr<D, ST, NT>(ldsAll + buf * NTILE * TILE + 2 * TILE, r.kt, tid);
   };
   auto compute = [&](int cur) {
     const int ks0 = cks;
@@ -613,9 +660,9 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
     const int q_w0 = qb0 + w * 16;  // this wave's 16 queries
     // every pair of this wave's tile masked (its queries lie before the step's first key, or past the sequence): nothing to add
     if ((p.causal && ks0 > q_w0 + 15) || q_w0 >= p.T) return;
-    const char* ldsK = ldsAll + cur * 3 * TILE;
+    const char* ldsK = ldsAll + cur * NTILE * TILE;
     const char* ldsV = ldsK + TILE;
-    const char* ldsKT = ldsK + 2 * TILE;
+    const char* ldsKT = ldsK + 2 * TILE;      // (!TR)
     f32x4_t s[KT], dp[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -659,7 +706,9 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
       const int row = d * 16 + fr;
 #pragma unroll
       for (int kp = 0; kp < KP; ++kp) {
-        const bf16x8_t a = lds_2xb64(ldsKT + tr_off8<ST>(row, kp * 8 + g), ldsKT + tr_off8<ST>(row, kp * 8 + 4 + g));
+        bf16x8_t a;
+        if constexpr (TR) a = tr_frag<D>(ldsK, kp * 32, d * 16, lane);
+        else a = lds_2xb64(ldsKT + tr_off8<ST>(row, kp * 8 + g), ldsKT + tr_off8<ST>(row, kp * 8 + 4 + g));
         acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB[kp], acc[d], 0, 0, 0);  // dQ^T[d][q]
       }
     }
@@ -728,6 +777,17 @@ __global__ void gqa_reduce_k(const bf16_t* __restrict__ part, bf16_t* __restrict
   *reinterpret_cast<u16x8_t*>(dv + bt * lddv + hk * D + c) = ov;
 }
 
+// probe: out[lane*4 + j] = element j that ds_read_b64_tr_b16 returns to `lane` when lane l supplies the byte address addr[l] of
+// an LDS image whose 16-bit element e holds the value e (pins the semantics tr_frag relies on)
+__global__ void lds_tr_probe_k(const int32_t* __restrict__ addr, int32_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned short img[4096];
+  for (int e = threadIdx.x; e < 4096; e += 64) img[e] = (unsigned short)e;
+  __syncthreads();
+  const s16x4_t v = lds_tr_b64(reinterpret_cast<const char*>(img) + addr[threadIdx.x]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (int32_t)(unsigned short)v[j];
+}
+
 AttnArgs make_args(const uvx::AttnDesc& d) {
   AttnArgs a = {};
   a.q = (const bf16_t*)d.q; a.k = (const bf16_t*)d.k; a.v = (const bf16_t*)d.v; a.vt = (const bf16_t*)d.vt;
@@ -752,6 +812,10 @@ int check_desc(const uvx::AttnDesc& d) {
 namespace uvx {
 
 int g_attn_qt = 0;  // probes: force the forward kernel's q-tile count (0 = automatic)
+// bf16 kernels read transposed operands out of the NATURAL tiles with ds_read_b64_tr_b16 (tuning option 12, default on):
+// callers then skip heads_transpose and may leave vt / qt / kt / dot null
+bool attention_tr_reads(int dtype) { return dtype == DT_BF16 && g_options[12] != 0; }
+bool attention_needs_transposed_copies(int dtype) { return dtype == DT_BF16 && g_options[12] == 0; }
 int attention_fwd_f32(hipStream_t st, const AttnDesc& d);
 int attention_bwd_f32(hipStream_t st, const AttnBwdDesc& d);
 
@@ -765,17 +829,29 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
   // ones (the LLM's few hundred tokens) are latency-bound and want more, smaller blocks and fewer registers.
   const int qt = uvx::g_attn_qt > 0 ? uvx::g_attn_qt : (d.T >= 1024 ? 2 : 1);
   dim3 grid(d.Hq, d.B, cdiv(d.T, 4 * qt * 16));
+  const bool tr = attention_tr_reads(dtype);   // V natural + transposing LDS reads (no V^T copy) - tuning option 12
+  UVX_CHECK(tr ? d.v != nullptr : d.vt != nullptr, UVX_ERR_INVALID, "attention_fwd: %s is null", tr ? "v" : "vt");
+#define FWD(DD, Q) do { if (tr) hipLaunchKernelGGL((attn_fwd_k<DD, Q, true>), grid, dim3(256), 0, st, a); \
+                        else hipLaunchKernelGGL((attn_fwd_k<DD, Q, false>), grid, dim3(256), 0, st, a); } while (0)
   if (d.D == 64) {
-    if (qt == 4) hipLaunchKernelGGL((attn_fwd_k<64, 4>), grid, dim3(256), 0, st, a);
-    else if (qt == 3) hipLaunchKernelGGL((attn_fwd_k<64, 3>), grid, dim3(256), 0, st, a);
-    else if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<64, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_k<64, 1>), grid, dim3(256), 0, st, a);
+    if (qt == 4) FWD(64, 4);
+    else if (qt == 3) FWD(64, 3);
+    else if (qt == 2) FWD(64, 2);
+    else FWD(64, 1);
   } else if (d.D == 128) {
-    if (qt == 2) hipLaunchKernelGGL((attn_fwd_k<128, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_k<128, 1>), grid, dim3(256), 0, st, a);
+    if (qt == 2) FWD(128, 2);
+    else FWD(128, 1);
   } else {   // head_dim 256 (Gemma): one q tile per wave keeps the O accumulators (64 registers) + Q fragments in budget
-    hipLaunchKernelGGL((attn_fwd_k<256, 1>), dim3(d.Hq, d.B, cdiv(d.T, 64)), dim3(256), 0, st, a);
+    grid = dim3(d.Hq, d.B, cdiv(d.T, 64));
+    FWD(256, 1);
   }
+#undef FWD
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int lds_tr_probe(hipStream_t st, const int32_t* addr, int32_t* out) {
+  hipLaunchKernelGGL(lds_tr_probe_k, dim3(1), dim3(64), 0, st, addr, out);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
@@ -798,16 +874,18 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   // head_dim 128 (the LLM): 128 queries / keys per block (8 waves), 32-row steps, two-deep prefetch.  64-row steps (ST = 64,
   // with or without the second staging set) were measured within 3 % of this at the C2 shape and are not instantiated
   // (profiles/r02_attn_bwd.txt).
-  if (d.f.D == 64) {
-    hipLaunchKernelGGL((attn_bwd_dq_k<64, 256, 32, true>), gq, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_k<64, 256, 32, true>), gk, dim3(256), 0, st, a);
-  } else if (d.f.D == 128) {
-    hipLaunchKernelGGL((attn_bwd_dq_k<128, 512, 32, true>), dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), dim3(512), 0, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_k<128, 512, 32, true>), gk128, dim3(512), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((attn_bwd_dq_k<256, 256, 32, false>), gq, dim3(256), 0, st, a);
-    hipLaunchKernelGGL((attn_bwd_dkdv_k<256, 256, 32, false>), gk, dim3(256), 0, st, a);
-  }
+  const bool tr = attention_tr_reads(dtype);   // natural tiles + transposing LDS reads (no Q^T / K^T / dO^T copies) - option 12
+  UVX_CHECK(tr || (d.qt && d.kt && d.dot), UVX_ERR_INVALID, "attention_bwd: transposed operand copies are null");
+  UVX_CHECK(d.f.v != nullptr, UVX_ERR_INVALID, "attention_bwd: v is null");
+#define BWD(DD, NTH, DEEP, GQ, GK) do { \
+    if (tr) { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, 32, DEEP, true>), GQ, dim3(NTH), 0, st, a); \
+              hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, 32, DEEP, true>), GK, dim3(NTH), 0, st, a); } \
+    else { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, 32, DEEP, false>), GQ, dim3(NTH), 0, st, a); \
+           hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, 32, DEEP, false>), GK, dim3(NTH), 0, st, a); } } while (0)
+  if (d.f.D == 64) BWD(64, 256, true, gq, gk);
+  else if (d.f.D == 128) BWD(128, 512, true, dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), gk128);
+  else BWD(256, 256, false, gq, gk);
+#undef BWD
   if (a.dkv_part) {
     const long long n8 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 8);
     hipLaunchKernelGGL(gqa_reduce_k, dim3(cdiv(n8, 256)), dim3(256), 0, st, (const bf16_t*)a.dkv_part, a.dk, a.dv, d.f.B, d.f.T, d.f.Hq,

@@ -11,10 +11,12 @@
 namespace {
 
 // GLU activations.  ACT 0: silu(g) = g * sigmoid(g); ACT 1: [3P] gelu_pytorch_tanh(g) = 0.5 g (1 + tanh(k (g + 0.044715 g^3))),
-// k = sqrt(2 / pi) - Gemma's hidden_act.  dact = d act / d g.
+// k = sqrt(2 / pi) - Gemma's hidden_act; ACT 2: exact GELU 0.5 g (1 + erf(g / sqrt 2)) - what ACT2FN["gelu"] is, i.e. what a
+// Gemma checkpoint whose config.json says hidden_act = "gelu" computes ([3P] GemmaMLP reads config.hidden_act).  dact = d act / d g.
 template <int ACT>
 __device__ __forceinline__ float glu_act(float g) {
   if (ACT == 0) return g / (1.0f + expf(-g));
+  if (ACT == 2) return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
   const float u = 0.7978845608028654f * (g + 0.044715f * g * g * g);
   return 0.5f * g * (1.0f + tanhf(u));
 }
@@ -24,6 +26,10 @@ __device__ __forceinline__ void glu_act_grad(float g, float& a, float& da) {
     const float s = 1.0f / (1.0f + expf(-g));
     a = g * s;
     da = s * (1.0f + g * (1.0f - s));
+  } else if (ACT == 2) {
+    const float cdf = 0.5f * (1.0f + erff(g * 0.70710678118654752440f));
+    a = g * cdf;
+    da = cdf + g * 0.3989422804014327f * expf(-0.5f * g * g);      // Phi(g) + g phi(g)
   } else {
     const float u = 0.7978845608028654f * (g + 0.044715f * g * g * g);
     const float t = tanhf(u);
@@ -361,12 +367,12 @@ namespace uvx {
 
 int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first, int act) {
   UVX_CHECK(half % 8 == 0 && (gate_first != 2 || half % 16 == 0), UVX_ERR_SHAPE, "swiglu: half=%d must be a multiple of 8 (16 when interleaved)", half);
-  UVX_CHECK(act == 0 || act == 1, UVX_ERR_INVALID, "swiglu: unknown activation %d", act);
+  UVX_CHECK(act >= 0 && act <= 2, UVX_ERR_INVALID, "swiglu: unknown activation %d", act);
   const long long n8 = (long long)rows * half / 8;
   if (n8 == 0) return UVX_OK;
 #define L(T, A) hipLaunchKernelGGL((swiglu_fwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)in, (T*)out, n8, half, gate_first)
-  if (dtype == DT_BF16) { if (act) L(bf16_t, 1); else L(bf16_t, 0); }
-  else { if (act) L(float, 1); else L(float, 0); }
+  if (dtype == DT_BF16) { if (act == 2) L(bf16_t, 2); else if (act) L(bf16_t, 1); else L(bf16_t, 0); }
+  else { if (act == 2) L(float, 2); else if (act) L(float, 1); else L(float, 0); }
 #undef L
   UVX_LAUNCH_CHECK();
   return UVX_OK;
@@ -375,12 +381,12 @@ int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, i
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
                int gate_first, int act) {
   UVX_CHECK(half % 8 == 0, UVX_ERR_SHAPE, "swiglu_bwd: half=%d must be a multiple of 8", half);
-  UVX_CHECK(act == 0 || act == 1, UVX_ERR_INVALID, "swiglu_bwd: unknown activation %d", act);
+  UVX_CHECK(act >= 0 && act <= 2, UVX_ERR_INVALID, "swiglu_bwd: unknown activation %d", act);
   const long long n8 = (long long)rows * half / 8;
   if (n8 == 0) return UVX_OK;
 #define L(T, A) hipLaunchKernelGGL((swiglu_bwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)din, n8, half, gate_first)
-  if (dtype == DT_BF16) { if (act) L(bf16_t, 1); else L(bf16_t, 0); }
-  else { if (act) L(float, 1); else L(float, 0); }
+  if (dtype == DT_BF16) { if (act == 2) L(bf16_t, 2); else if (act) L(bf16_t, 1); else L(bf16_t, 0); }
+  else { if (act == 2) L(float, 2); else if (act) L(float, 1); else L(float, 0); }
 #undef L
   UVX_LAUNCH_CHECK();
   return UVX_OK;

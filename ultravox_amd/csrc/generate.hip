@@ -294,7 +294,7 @@ int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, I
   const bool fused = dt == DT_BF16 && c.llm_flavor == UVX_LLM_LLAMA;   // SwiGLU in the epilogue; Gemma's GeGLU: separate kernel
   if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
   RC(gemm(st, dt, g));
-  if (!fused) RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2, c.llm_flavor == UVX_LLM_GEMMA));
+  if (!fused) RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2, c.llm_act));
   GemmDesc d = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
   d.residual = x_mid; d.ldr = D;
   return gemm(st, dt, d);
@@ -348,7 +348,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
         hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, T, Tmax, 0, s.QKV, Hq * dh, KVD);
       UVX_LAUNCH_CHECK();
     }
-    RC(heads_transpose(st, dt, at(s.qkv, (size_t)(Hq + Hkv) * dh, dt), s.vt, B, T, s.Tp, Hkv, dh, s.QKV));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(s.qkv, (size_t)(Hq + Hkv) * dh, dt), s.vt, B, T, s.Tp, Hkv, dh, s.QKV));
     AttnDesc ad;
     ad.q = s.qkv; ad.k = at(s.qkv, (size_t)Hq * dh, dt); ad.v = at(s.qkv, (size_t)(Hq + Hkv) * dh, dt);
     ad.vt = s.vt; ad.o = s.o; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = s.kvl;
@@ -436,7 +436,7 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
     for (int b = 0; b < B; ++b)   // the new rows' queries into their place in the full-length layout
       UVX_HIP(hipMemcpy2DAsync(at(k.fq, ((size_t)b * Tf + cur_len) * s.QKV, dt), (size_t)s.QKV * es, at(s.qkv, (size_t)b * Tn * s.QKV, dt),
                                (size_t)s.QKV * es, (size_t)Hq * dh * es, Tn, hipMemcpyDeviceToDevice, st));
-    RC(heads_transpose(st, dt, at(k.fq, (size_t)(Hq + Hkv) * dh, dt), k.fvt, B, Tf, k.Tfp, Hkv, dh, s.QKV));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(k.fq, (size_t)(Hq + Hkv) * dh, dt), k.fvt, B, Tf, k.Tfp, Hkv, dh, s.QKV));
     AttnDesc ad;
     ad.q = k.fq; ad.k = at(k.fq, (size_t)Hq * dh, dt); ad.v = at(k.fq, (size_t)(Hq + Hkv) * dh, dt);
     ad.vt = k.fvt; ad.o = k.fo; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = nullptr;

@@ -47,7 +47,7 @@ struct GemmDesc {
 
 extern int g_gemm_variant;
 extern int g_gemm_split;
-extern int g_options[12];
+extern int g_options[16];
 int gemm_pick_variant(int M, int N, int K, int batch);  // host only: the tile variant the cost model picks
 int gemm_streamk_timeouts();   // stream-K waits that gave up since the last call (0 = healthy); synchronises
 extern int g_gemm_ovr_n;
@@ -82,7 +82,8 @@ int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, v
 
 // ---- elementwise.hip ----
 // layout: 0 = [value | gate] halves (UltravoxProjector), 1 = [gate | up] halves, 2 = 16-wide gate/up blocks interleaved
-// act: 0 = SiLU (SwiGLU: Llama MLP, UltravoxProjector), 1 = tanh-GELU (GeGLU: Gemma MLP, hidden_act gelu_pytorch_tanh)
+// act: 0 = SiLU (SwiGLU: Llama MLP, UltravoxProjector), 1 = tanh-GELU (GeGLU: Gemma MLP, hidden_act gelu_pytorch_tanh),
+// 2 = exact erf GELU (Gemma checkpoints whose config says hidden_act "gelu")
 int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first, int act = 0);
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
                int gate_first, int act = 0);
@@ -155,6 +156,11 @@ struct AttnBwdDesc {
   int lddq = 0, lddk = 0, lddv = 0;
 };
 int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d);
+// true: the attention kernels of this dtype read vt / qt / kt / dot (callers run heads_transpose first); false (bf16 with tuning
+// option 12, the default): they read the natural q / k / v / dout through the transposing LDS read and ignore those pointers
+bool attention_needs_transposed_copies(int dtype);
+bool attention_tr_reads(int dtype);
+int lds_tr_probe(hipStream_t st, const int32_t* addr /*[64] byte offsets*/, int32_t* out /*[256]*/);
 // [B, T, H, D] (row stride ld) -> [B, H, D, Tp], zero padded in T
 int heads_transpose(hipStream_t st, int dtype, const void* in, void* out, int B, int T, int Tp, int H,
                     int D, int ld);

@@ -1,5 +1,6 @@
 // Host-side orchestration of the hot path behind the C ABI (include/uvx.h): which kernels run, in
 // what order, on which slices of the caller's workspace.  No device allocation, no synchronisation.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 #include "../../include/uvx.h"
@@ -256,10 +257,60 @@ LlmLayerStash llm_layer(const LlmWs& w, int slot) {
   return s;
 }
 
+// Batch slice [b0, b0 + nb) of the carved LLM workspace: every buffer is batch-major at the top level ([B*T, ld] rows or
+// [B, ...]), so a slice is the same record with its pointers advanced.  Used by the two-stream schedule below.
+LlmWs llm_view(const LlmWs& w, const uvx_config_t& c, int b0, int nb, int T) {
+  LlmWs v = w;
+  if (b0 == 0 && nb * T == w.M) return v;
+  const size_t es = esz(c.dtype), r0 = (size_t)b0 * T, D = c.llm_d, I = c.llm_inter;
+  auto adv = [](auto& p, size_t bytes) { if (p) p = (typename std::remove_reference<decltype(p)>::type)((char*)p + bytes); };
+  v.M = nb * T;
+  LlmLayerStash& s = v.ls[0];
+  adv(s.x_in, r0 * D * es); adv(s.qkv, r0 * w.QKV * es); adv(s.o, r0 * w.OD * es); adv(s.x_mid, r0 * D * es);
+  adv(s.gu, r0 * 2 * I * es); adv(s.lse, sizeof(float) * (size_t)b0 * c.llm_heads * T); adv(s.t, r0 * 128 * es);
+  adv(v.x_final, r0 * D * es); adv(v.hn, r0 * D * es); adv(v.n, r0 * D * es); adv(v.act, r0 * I * es);
+  adv(v.vt, (size_t)b0 * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
+  adv(v.logits, r0 * c.vocab * es);
+  adv(v.kvs, sizeof(int32_t) * (size_t)b0); adv(v.kvl, sizeof(int32_t) * (size_t)b0);
+  adv(v.dx, r0 * D * es); adv(v.d_hn, r0 * D * es); adv(v.d_act, r0 * I * es); adv(v.d_gu, r0 * 2 * I * es);
+  adv(v.d_n, r0 * D * es); adv(v.d_o, r0 * w.OD * es); adv(v.d_qkv, r0 * w.QKV * es);
+  adv(v.qT, (size_t)b0 * c.llm_heads * c.llm_head_dim * w.Tp * es);
+  adv(v.kT, (size_t)b0 * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
+  adv(v.doT, (size_t)b0 * c.llm_heads * c.llm_head_dim * w.Tp * es);
+  adv(v.delta, sizeof(float) * (size_t)b0 * c.llm_heads * T);
+  adv(v.dkv_part, sizeof(float) * 2 * r0 * w.OD);
+  return v;
+}
+
+// Two-stream schedule (tuning option 11 = 2): the batch is cut in two halves whose layer chains are independent (frozen
+// LLM: no weight gradient couples them), and the halves run on the caller's stream and on one side stream.  Every kernel
+// of a chain depends on its predecessor, so on ONE stream the tail of each GEMM (a partly filled last round of tiles: 1120
+// tiles = 4.4 rounds of 256 CUs at N = 28672, 560 = 2.2 at N = 14336) and every HBM-bound elementwise kernel leave CUs
+// idle; with two chains in flight the other half's kernel takes those CUs.  Same kernels on the same rows: results are
+// bit-identical to the one-stream schedule.  Fork / join by events (legal under stream capture as well).
+struct Fork {
+  hipStream_t side = nullptr;
+  hipEvent_t e_fork = nullptr, e_join = nullptr;
+};
+Fork* fork_for_device() {
+  static Fork forks[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  Fork& f = forks[dev];
+  if (!f.side) {
+    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) { f.side = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&f.e_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&f.e_join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &f;
+}
+
 int check_cfg(const uvx_config_t* c) {
   UVX_CHECK(c != nullptr, UVX_ERR_INVALID, "null config");
   UVX_CHECK(c->dtype == DT_BF16 || c->dtype == DT_F32, UVX_ERR_INVALID, "bad dtype %d", c->dtype);
   UVX_CHECK(c->llm_flavor == UVX_LLM_LLAMA || c->llm_flavor == UVX_LLM_GEMMA, UVX_ERR_INVALID, "bad llm_flavor %d", c->llm_flavor);
+  UVX_CHECK(c->llm_act >= UVX_ACT_SILU && c->llm_act <= UVX_ACT_GELU_ERF && (c->llm_flavor == UVX_LLM_GEMMA) == (c->llm_act != UVX_ACT_SILU),
+            UVX_ERR_INVALID, "llm_act %d does not fit llm_flavor %d (Llama: SiLU; Gemma: tanh- or erf-GELU)", c->llm_act, c->llm_flavor);
   return UVX_OK;
 }
 
@@ -363,7 +414,7 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
       RC(lora_up(st, dt, S.t, 128, S.bqT, 1, qkv, 3 * d, M, d, r, lora->scaling * qscale, 1));
       RC(lora_up(st, dt, at(S.t, 64, dt), 128, S.bkT, 1, at(qkv, d, dt), 3 * d, M, d, r, lora->scaling, 1));
     }
-    RC(heads_transpose(st, dt, at(qkv, 2 * d, dt), s.vt, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(qkv, 2 * d, dt), s.vt, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
     AttnDesc ad;
     ad.q = qkv; ad.k = at(qkv, d, dt); ad.v = at(qkv, 2 * d, dt); ad.vt = s.vt; ad.o = o; ad.lse = train ? S.lse : nullptr;
     ad.kv_len = kvlen; ad.B = B; ad.T = Te; ad.Tp = s.Tp; ad.Hq = c.enc_heads; ad.Hkv = c.enc_heads; ad.D = dh;
@@ -449,9 +500,9 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     RC(layernorm_bwd(st, dt, s.d_n, S.x_mid, L.ln2_w, s.dx, s.dx, M, d, c.ln_eps));
     // ---- attention: x_mid = x_in + wo(attn(q, k, v)) ----
     RC(gemm(st, dt, lin(s.dx, L.wo_t, s.d_o, M, d, d)));
-    RC(heads_transpose(st, dt, S.qkv, s.qT, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
-    RC(heads_transpose(st, dt, at(S.qkv, d, dt), s.kT, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
-    RC(heads_transpose(st, dt, s.d_o, s.doT, B, Te, s.Tp, c.enc_heads, dh, d));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, S.qkv, s.qT, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(S.qkv, d, dt), s.kT, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, s.d_o, s.doT, B, Te, s.Tp, c.enc_heads, dh, d));
     AttnBwdDesc bd;
     AttnDesc& ad = bd.f;
     ad.q = S.qkv; ad.k = at(S.qkv, d, dt); ad.v = at(S.qkv, 2 * d, dt); ad.o = S.o; ad.lse = S.lse;
@@ -651,7 +702,6 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   if (attention_mask) hipLaunchKernelGGL(mask_range_k, dim3(B), dim3(256), 0, st, attention_mask, s.kvs, s.kvl, T);
   else hipLaunchKernelGGL(full_range_k, dim3(cdiv(B, 64)), dim3(64), 0, st, s.kvs, s.kvl, B, T);
   UVX_LAUNCH_CHECK();
-  const int32_t *kvs = s.kvs, *kvl = s.kvl;
   // top_rows (uvx_llm_fwd_train): only the supervised positions enter the loss, and in the LAST layer nothing downstream of
   // its attention mixes positions any more - o_proj, the MLP and the final norm are row-wise.  Their results are needed
   // (and have a gradient) on the supervised rows alone, so the last layer's post-attention half runs on the compacted
@@ -659,63 +709,99 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   UVX_CHECK(!top_rows || (labels && loss && dt == DT_BF16 && save_for_bwd && !logits && !rows), UVX_ERR_INVALID,
             "llm_fwd_train: labels and a loss output are required, bf16 only");
   const bool tc = top_rows && g_options[3];   // (tuning option 3 off: the plain full-row path, in both calls of the pair)
-  LlmLayerStash cur = llm_layer(s, 0);
-  UVX_HIP(hipMemcpyAsync(cur.x_in, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
   const int fl = c.llm_flavor;   // 0 Llama, 1 Gemma (norm flavour, GLU activation, embedding scale)
-  if (fl == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, cur.x_in, (long long)M * D, gemma_normalizer(c)));
-  for (int l = 0; l < c.llm_layers; ++l) {
+  {
+    LlmLayerStash l0 = llm_layer(s, 0);
+    UVX_HIP(hipMemcpyAsync(l0.x_in, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
+    if (fl == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, l0.x_in, (long long)M * D, gemma_normalizer(c)));
+  }
+  auto slot_of = [&](int l) { return save_for_bwd ? l : (l & 1); };
+  // first half of a layer, rows of the view v (a batch slice): norm, q|k|v projection, RoPE, V^T, causal GQA flash attention
+  auto layer_attn = [&](hipStream_t sx, const LlmWs& v, int Bv, int l) -> int {
     const uvx_llm_layer_t& L = w->layers[l];
-    const bool last = l + 1 == c.llm_layers;
-    void* x_out = last ? s.x_final : llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1)).x_in;
-    RC(rmsnorm_fwd(st, dt, cur.x_in, L.ln1, s.n, nullptr, M, D, c.rms_eps, fl));
-    RC(gemm(st, dt, lin(s.n, L.wqkv, cur.qkv, M, s.QKV, D)));
+    LlmLayerStash cur = llm_layer(v, slot_of(l));
+    const int Mv = v.M;
+    RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, v.n, nullptr, Mv, D, c.rms_eps, fl));
+    RC(gemm(sx, dt, lin(v.n, L.wqkv, cur.qkv, Mv, s.QKV, D)));
     if (lora) {   // peft LoRA on q_proj / k_proj (text_model_lora_config): added to the projections, before RoPE
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r, qc = Hq * dh, kc = Hkv * dh;
-      RC(lora_transpose(st, dt, R.q.b, cur.bqT, qc, r));
-      RC(lora_transpose(st, dt, R.k.b, cur.bkT, kc, r));
-      RC(lora_down(st, dt, s.n, D, R.q.a, 0, cur.t, 128, M, D, r, 1.0f));
-      RC(lora_down(st, dt, s.n, D, R.k.a, 0, at(cur.t, 64, dt), 128, M, D, r, 1.0f));
-      RC(lora_up(st, dt, cur.t, 128, cur.bqT, 1, cur.qkv, s.QKV, M, qc, r, lora->scaling, 1));
-      RC(lora_up(st, dt, at(cur.t, 64, dt), 128, cur.bkT, 1, at(cur.qkv, (size_t)qc, dt), s.QKV, M, kc, r, lora->scaling, 1));
+      RC(lora_transpose(sx, dt, R.q.b, cur.bqT, qc, r));
+      RC(lora_transpose(sx, dt, R.k.b, cur.bkT, kc, r));
+      RC(lora_down(sx, dt, v.n, D, R.q.a, 0, cur.t, 128, Mv, D, r, 1.0f));
+      RC(lora_down(sx, dt, v.n, D, R.k.a, 0, at(cur.t, 64, dt), 128, Mv, D, r, 1.0f));
+      RC(lora_up(sx, dt, cur.t, 128, cur.bqT, 1, cur.qkv, s.QKV, Mv, qc, r, lora->scaling, 1));
+      RC(lora_up(sx, dt, at(cur.t, 64, dt), 128, cur.bkT, 1, at(cur.qkv, (size_t)qc, dt), s.QKV, Mv, kc, r, lora->scaling, 1));
     }
-    RC(rope_inplace(st, dt, cur.qkv, w->rope_cos_sin, nullptr, M, T, Hq + Hkv, dh, s.QKV, 0));
-    RC(heads_transpose(st, dt, at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt), s.vt, B, T, s.Tp, Hkv, dh, s.QKV));
+    RC(rope_inplace(sx, dt, cur.qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 0));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt), v.vt, Bv, T, s.Tp, Hkv, dh, s.QKV));
     AttnDesc ad;
     ad.q = cur.qkv; ad.k = at(cur.qkv, (size_t)Hq * dh, dt); ad.v = at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt);
-    ad.vt = s.vt; ad.o = cur.o; ad.lse = cur.lse; ad.kv_start = kvs; ad.kv_len = kvl;
-    ad.B = B; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
+    ad.vt = v.vt; ad.o = cur.o; ad.lse = cur.lse; ad.kv_start = v.kvs; ad.kv_len = v.kvl;
+    ad.B = Bv; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
     ad.scale = 1.0f / sqrtf((float)dh);
-    RC(attention_fwd(st, dt, ad));
-    const bool compact = tc && last;
-    const int32_t* mdev = compact ? s.sup + M : nullptr;
+    return attention_fwd(sx, dt, ad);
+  };
+  // second half: o_proj + residual, norm, gate|up (+ SwiGLU), down + residual.  compact (last layer of the training pair,
+  // whole batch only): on the supervised rows gathered into the idle backward scratch.
+  auto layer_mlp = [&](hipStream_t sx, const LlmWs& v, int l, bool compact) -> int {
+    const uvx_llm_layer_t& L = w->layers[l];
+    const bool last = l + 1 == c.llm_layers;
+    LlmLayerStash cur = llm_layer(v, slot_of(l));
+    void* x_out = last ? v.x_final : llm_layer(v, slot_of(l + 1)).x_in;
+    const int Mv = v.M;
+    const int32_t* mdev = compact ? v.sup + Mv : nullptr;
     if (compact) {   // gather the supervised rows of the attention output and of the residual stream (backward scratch is free here)
-      RC(sup_rows(st, labels, s.sup, B, T, c.vocab));
-      RC(gather_rows(st, dt, cur.o, s.sup, M, s.d_o, s.OD));
-      RC(gather_rows(st, dt, cur.x_in, s.sup, M, s.dx, D));
+      RC(sup_rows(sx, labels, v.sup, B, T, c.vocab));
+      RC(gather_rows(sx, dt, cur.o, v.sup, Mv, v.d_o, s.OD));
+      RC(gather_rows(sx, dt, cur.x_in, v.sup, Mv, v.dx, D));
     }
     {
-      GemmDesc g = lin(compact ? s.d_o : cur.o, L.wo, cur.x_mid, M, D, s.OD);
-      g.residual = compact ? s.dx : cur.x_in; g.ldr = D; g.m_dev = mdev;
-      RC(gemm(st, dt, g));
+      GemmDesc g = lin(compact ? v.d_o : cur.o, L.wo, cur.x_mid, Mv, D, s.OD);
+      g.residual = compact ? v.dx : cur.x_in; g.ldr = D; g.m_dev = mdev;
+      RC(gemm(sx, dt, g));
     }
-    RC(rmsnorm_fwd(st, dt, cur.x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps, fl));
+    RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, v.n, nullptr, Mv, D, c.rms_eps, fl));
     {  // gate|up projection; wgu rows are packed as alternating 16-row gate / up blocks (weights.py)
-      GemmDesc g = lin(s.n, L.wgu, cur.gu, M, 2 * c.llm_inter, D);
+      GemmDesc g = lin(v.n, L.wgu, cur.gu, Mv, 2 * c.llm_inter, D);
       const bool fused = dt == DT_BF16 && fl == UVX_LLM_LLAMA;   // SwiGLU fused into the epilogue (GeGLU: separate kernel)
-      if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
+      if (fused) { g.C2 = v.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
       g.m_dev = mdev;
-      RC(gemm(st, dt, g));
-      if (!fused) RC(swiglu_fwd(st, dt, cur.gu, s.act, M, c.llm_inter, /*layout=*/2, /*act=*/fl == UVX_LLM_GEMMA));
+      RC(gemm(sx, dt, g));
+      if (!fused) RC(swiglu_fwd(sx, dt, cur.gu, v.act, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
     }
     {
-      GemmDesc g = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
+      GemmDesc g = lin(v.act, L.wd, x_out, Mv, D, c.llm_inter);
       g.residual = cur.x_mid; g.ldr = D; g.m_dev = mdev;
-      RC(gemm(st, dt, g));
+      RC(gemm(sx, dt, g));
     }
-    if (!last) cur = llm_layer(s, save_for_bwd ? l + 1 : ((l + 1) & 1));
+    return UVX_OK;
+  };
+  // schedule: one chain on the caller's stream, or (option 11) two batch halves on two streams - see Fork above
+  Fork* fk = (g_options[11] >= 2 && B >= 2 && dt == DT_BF16 && !lora) ? fork_for_device() : nullptr;
+  const int nh = fk ? 2 : 1;
+  const int hb[3] = {0, fk ? (B + 1) / 2 : B, B};
+  LlmWs hv[2] = {llm_view(s, c, 0, hb[1], T), fk ? llm_view(s, c, hb[1], B - hb[1], T) : s};
+  hipStream_t hs[2] = {st, fk ? fk->side : st};
+  if (fk) {
+    UVX_HIP(hipEventRecord(fk->e_fork, st));
+    UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
   }
+  int rc_layers = UVX_OK;
+  for (int l = 0; l < c.llm_layers && rc_layers == UVX_OK; ++l) {
+    const bool compact = tc && l + 1 == c.llm_layers;
+    for (int h = 0; h < nh && rc_layers == UVX_OK; ++h) {
+      rc_layers = layer_attn(hs[h], hv[h], hb[h + 1] - hb[h], l);
+      if (rc_layers == UVX_OK && !compact) rc_layers = layer_mlp(hs[h], hv[h], l, false);
+    }
+  }
+  if (fk) {   // join (also on an error above: the side stream must not be left forked)
+    UVX_HIP(hipEventRecord(fk->e_join, fk->side));
+    UVX_HIP(hipStreamWaitEvent(st, fk->e_join, 0));
+  }
+  RC(rc_layers);
+  if (tc) RC(layer_mlp(st, s, c.llm_layers - 1, true));
   RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps, fl));
   if (rows) {
     UVX_CHECK(dt == DT_BF16, UVX_ERR_UNSUPPORTED, "llm_fwd_rows: bf16 only");
@@ -857,84 +943,119 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   UVX_CHECK(!top_rows || (!compact_in_place && labels && dt == DT_BF16), UVX_ERR_INVALID, "llm_bwd_train: labels are required, bf16 only");
   const bool tc = top_rows && g_options[3];
   const int32_t* mdev_top = tc ? s.sup + M : nullptr;
-  const void* dx_resid = s.dx;     // gradient of the residual stream entering the layer being processed
   if (tc) {
     RC(gather_rows(st, dt, s.d_hn, s.sup, M, s.d_n, D));                 // d_hn was scattered to full rows: back to compact
     RC(rmsnorm_bwd(st, dt, s.d_n, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl));
   } else {
     RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl));
   }
-  for (int l = c.llm_layers - 1; l >= 0; --l) {
+  const size_t es = esz(dt);
+  // MLP half of a layer's backward on the rows of the view v: v.dx (gradient of the layer's output) -> v.dx (gradient of
+  // x_mid: residual + norm branch).  compact: the supervised rows of the last layer (whole batch, device-side count).
+  auto layer_mlp_bwd = [&](hipStream_t sx, const LlmWs& v, int l, bool compact) -> int {
     const uvx_llm_layer_t& L = w->layers[l];
-    UVX_CHECK(L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t, UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
-    LlmLayerStash cur = llm_layer(s, l);
-    const bool compact = tc && l == c.llm_layers - 1;
-    const int32_t* mdev = compact ? mdev_top : nullptr;
-    // MLP
+    LlmLayerStash cur = llm_layer(v, l);
+    const int Mv = v.M;
+    const int32_t* mdev = compact ? v.sup + Mv : nullptr;
     if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
-      GemmDesc g = lin(s.dx, L.wd_t, s.d_gu, M, c.llm_inter, D);
+      GemmDesc g = lin(v.dx, L.wd_t, v.d_gu, Mv, c.llm_inter, D);
       g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2; g.m_dev = mdev;
-      RC(gemm(st, dt, g));
+      RC(gemm(sx, dt, g));
     } else {
-      GemmDesc g = lin(s.dx, L.wd_t, s.d_act, M, c.llm_inter, D);
+      GemmDesc g = lin(v.dx, L.wd_t, v.d_act, Mv, c.llm_inter, D);
       g.m_dev = mdev;
-      RC(gemm(st, dt, g));
-      RC(swiglu_bwd(st, dt, s.d_act, cur.gu, s.d_gu, M, c.llm_inter, /*layout=*/2, /*act=*/fl == UVX_LLM_GEMMA));
+      RC(gemm(sx, dt, g));
+      RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
     }
     {
-      GemmDesc g = lin(s.d_gu, L.wgu_t, s.d_n, M, D, 2 * c.llm_inter);
+      GemmDesc g = lin(v.d_gu, L.wgu_t, v.d_n, Mv, D, 2 * c.llm_inter);
       g.m_dev = mdev;
-      RC(gemm(st, dt, g));
+      RC(gemm(sx, dt, g));
     }
-    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_mid, L.ln2, s.dx, s.dx, nullptr, M, D, c.rms_eps, fl));
-    // attention
-    if (compact) {   // d o on the compact rows, then both it and the residual-stream gradient go back to their full rows
-      GemmDesc g = lin(s.dx, L.wo_t, s.doT, M, s.OD, D);        // doT ([B, Hq, Tp, dh] >= M * OD) is free until the transpose below
-      g.m_dev = mdev;
-      RC(gemm(st, dt, g));
-      UVX_HIP(hipMemsetAsync(s.d_o, 0, (size_t)M * s.OD * esz(dt), st));
-      RC(scatter_rows(st, dt, s.doT, s.sup, M, s.d_o, s.OD));
-      UVX_HIP(hipMemsetAsync(s.d_hn, 0, (size_t)M * D * esz(dt), st));
-      RC(scatter_rows(st, dt, s.dx, s.sup, M, s.d_hn, D));
-      dx_resid = s.d_hn;
-    } else {
-      RC(gemm(st, dt, lin(s.dx, L.wo_t, s.d_o, M, s.OD, D)));
-    }
-    RC(heads_transpose(st, dt, cur.qkv, s.qT, B, T, s.Tp, Hq, dh, s.QKV));
-    RC(heads_transpose(st, dt, at(cur.qkv, (size_t)Hq * dh, dt), s.kT, B, T, s.Tp, Hkv, dh, s.QKV));
-    RC(heads_transpose(st, dt, s.d_o, s.doT, B, T, s.Tp, Hq, dh, s.OD));
+    return rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl);
+  };
+  // attention half: v.dx (gradient of x_mid) -> dx_out (gradient of the layer's input).  d_o_ready: v.d_o and the residual
+  // gradient `resid` were already produced for the whole batch (compact last layer), else d_o = dx . W_o^T here.
+  auto layer_attn_bwd = [&](hipStream_t sx, const LlmWs& v, int Bv, int l, bool d_o_ready, const void* resid, void* dx_out) -> int {
+    const uvx_llm_layer_t& L = w->layers[l];
+    LlmLayerStash cur = llm_layer(v, l);
+    const int Mv = v.M;
+    if (!d_o_ready) RC(gemm(sx, dt, lin(v.dx, L.wo_t, v.d_o, Mv, s.OD, D)));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, cur.qkv, v.qT, Bv, T, s.Tp, Hq, dh, s.QKV));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, at(cur.qkv, (size_t)Hq * dh, dt), v.kT, Bv, T, s.Tp, Hkv, dh, s.QKV));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, v.d_o, v.doT, Bv, T, s.Tp, Hq, dh, s.OD));
     AttnBwdDesc bd;
     AttnDesc& ad = bd.f;
     ad.q = cur.qkv; ad.k = at(cur.qkv, (size_t)Hq * dh, dt); ad.v = at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt);
     ad.o = cur.o; ad.lse = cur.lse;
-    ad.kv_start = s.kvs; ad.kv_len = s.kvl;  // written by the forward pass
-    ad.B = B; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
+    ad.kv_start = v.kvs; ad.kv_len = v.kvl;  // written by the forward pass
+    ad.B = Bv; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
     ad.scale = 1.0f / sqrtf((float)dh);
-    bd.dout = s.d_o; bd.qt = s.qT; bd.kt = s.kT; bd.dot = s.doT; bd.delta = s.delta; bd.dkv_part = s.dkv_part;
-    bd.dq = s.d_qkv; bd.dk = at(s.d_qkv, (size_t)Hq * dh, dt); bd.dv = at(s.d_qkv, (size_t)(Hq + Hkv) * dh, dt);
+    bd.dout = v.d_o; bd.qt = v.qT; bd.kt = v.kT; bd.dot = v.doT; bd.delta = v.delta; bd.dkv_part = v.dkv_part;
+    bd.dq = v.d_qkv; bd.dk = at(v.d_qkv, (size_t)Hq * dh, dt); bd.dv = at(v.d_qkv, (size_t)(Hq + Hkv) * dh, dt);
     bd.lddq = bd.lddk = bd.lddv = s.QKV;
-    RC(attention_bwd(st, dt, bd));
-    RC(rope_inplace(st, dt, s.d_qkv, w->rope_cos_sin, nullptr, M, T, Hq + Hkv, dh, s.QKV, 1));
-    RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, D, s.QKV)));
+    RC(attention_bwd(sx, dt, bd));
+    RC(rope_inplace(sx, dt, v.d_qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
+    RC(gemm(sx, dt, lin(v.d_qkv, L.wqkv_t, v.d_n, Mv, D, s.QKV)));
     if (lora) {   // LoRA gradients of q_proj / k_proj and their contribution to d n1 (rank-r products, lora.hip)
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const uvx_enc_lora_layer_grads_t& G = lgrads->layers[l];
       const int r = lora->r, qc = Hq * dh, kc = Hkv * dh;
-      void* dk = at(s.d_qkv, (size_t)qc, dt);
-      RC(lora_down(st, dt, s.d_qkv, s.QKV, cur.bqT, 0, s.lu, 128, M, qc, r, lora->scaling));
-      RC(lora_down(st, dt, dk, s.QKV, cur.bkT, 0, at(s.lu, 64, dt), 128, M, kc, r, lora->scaling));
-      RC(rmsnorm_fwd(st, dt, cur.x_in, L.ln1, s.n, nullptr, M, D, c.rms_eps, fl));        // n1 recomputed
-      RC(lora_wgrad(st, dt, s.n, D, s.lu, 128, G.q.a, M, D, r, 0, 1.0f, s.lwg));
-      RC(lora_wgrad(st, dt, s.n, D, at(s.lu, 64, dt), 128, G.k.a, M, D, r, 0, 1.0f, s.lwg));
-      RC(lora_wgrad(st, dt, s.d_qkv, s.QKV, cur.t, 128, G.q.b, M, qc, r, 1, lora->scaling, s.lwg));
-      RC(lora_wgrad(st, dt, dk, s.QKV, at(cur.t, 64, dt), 128, G.k.b, M, kc, r, 1, lora->scaling, s.lwg));
-      RC(lora_up(st, dt, s.lu, 128, R.q.a, 1, s.d_n, D, M, D, r, 1.0f, 1));
-      RC(lora_up(st, dt, at(s.lu, 64, dt), 128, R.k.a, 1, s.d_n, D, M, D, r, 1.0f, 1));
+      void* dk = at(v.d_qkv, (size_t)qc, dt);
+      RC(lora_down(sx, dt, v.d_qkv, s.QKV, cur.bqT, 0, v.lu, 128, Mv, qc, r, lora->scaling));
+      RC(lora_down(sx, dt, dk, s.QKV, cur.bkT, 0, at(v.lu, 64, dt), 128, Mv, kc, r, lora->scaling));
+      RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, v.n, nullptr, Mv, D, c.rms_eps, fl));        // n1 recomputed
+      RC(lora_wgrad(sx, dt, v.n, D, v.lu, 128, G.q.a, Mv, D, r, 0, 1.0f, v.lwg));
+      RC(lora_wgrad(sx, dt, v.n, D, at(v.lu, 64, dt), 128, G.k.a, Mv, D, r, 0, 1.0f, v.lwg));
+      RC(lora_wgrad(sx, dt, v.d_qkv, s.QKV, cur.t, 128, G.q.b, Mv, qc, r, 1, lora->scaling, v.lwg));
+      RC(lora_wgrad(sx, dt, dk, s.QKV, at(cur.t, 64, dt), 128, G.k.b, Mv, kc, r, 1, lora->scaling, v.lwg));
+      RC(lora_up(sx, dt, v.lu, 128, R.q.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
+      RC(lora_up(sx, dt, at(v.lu, 64, dt), 128, R.k.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
     }
-    RC(rmsnorm_bwd(st, dt, s.d_n, cur.x_in, L.ln1, dx_resid, l == 0 ? d_inputs_embeds : s.dx, nullptr, M, D, c.rms_eps, fl));
-    dx_resid = s.dx;
+    return rmsnorm_bwd(sx, dt, v.d_n, cur.x_in, L.ln1, resid, dx_out, nullptr, Mv, D, c.rms_eps, fl);
+  };
+  for (int l = 0; l < c.llm_layers; ++l) {
+    const uvx_llm_layer_t& L = w->layers[l];
+    UVX_CHECK(L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t, UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
   }
+  const int top = c.llm_layers - 1;
+  if (tc) {   // last layer of the training pair: MLP and o_proj gradients on the compact supervised rows (whole batch, this
+              // stream), then d o and the residual-stream gradient go back to their full rows for the attention backward
+    RC(layer_mlp_bwd(st, s, top, true));
+    GemmDesc g = lin(s.dx, w->layers[top].wo_t, s.doT, M, s.OD, D);     // doT ([B, Hq, Tp, dh] >= M * OD) is free until the transpose
+    g.m_dev = mdev_top;
+    RC(gemm(st, dt, g));
+    UVX_HIP(hipMemsetAsync(s.d_o, 0, (size_t)M * s.OD * es, st));
+    RC(scatter_rows(st, dt, s.doT, s.sup, M, s.d_o, s.OD));
+    UVX_HIP(hipMemsetAsync(s.d_hn, 0, (size_t)M * D * es, st));
+    RC(scatter_rows(st, dt, s.dx, s.sup, M, s.d_hn, D));
+  }
+  // schedule: one chain on the caller's stream, or (option 11) two batch halves on two streams - see Fork above
+  Fork* fk = (g_options[11] >= 2 && B >= 2 && dt == DT_BF16 && !lora) ? fork_for_device() : nullptr;
+  const int nh = fk ? 2 : 1;
+  const int hb[3] = {0, fk ? (B + 1) / 2 : B, B};
+  LlmWs hv[2] = {llm_view(s, c, 0, hb[1], T), fk ? llm_view(s, c, hb[1], B - hb[1], T) : s};
+  hipStream_t hs[2] = {st, fk ? fk->side : st};
+  if (fk) {
+    UVX_HIP(hipEventRecord(fk->e_fork, st));
+    UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
+  }
+  int rc_layers = UVX_OK;
+  for (int l = top; l >= 0 && rc_layers == UVX_OK; --l) {
+    const bool compact = tc && l == top;
+    for (int h = 0; h < nh && rc_layers == UVX_OK; ++h) {
+      const LlmWs& v = hv[h];
+      if (!compact) rc_layers = layer_mlp_bwd(hs[h], v, l, false);
+      void* dx_out = l == 0 ? (void*)((char*)d_inputs_embeds + (size_t)hb[h] * T * D * es) : v.dx;
+      if (rc_layers == UVX_OK) rc_layers = layer_attn_bwd(hs[h], v, hb[h + 1] - hb[h], l, compact, compact ? v.d_hn : v.dx, dx_out);
+    }
+  }
+  if (fk) {   // join (also on an error above: the side stream must not be left forked)
+    UVX_HIP(hipEventRecord(fk->e_join, fk->side));
+    UVX_HIP(hipStreamWaitEvent(st, fk->e_join, 0));
+  }
+  RC(rc_layers);
   if (fl == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, d_inputs_embeds, (long long)M * D, gemma_normalizer(c)));   // d (x * normalizer)
   return UVX_OK;
 }

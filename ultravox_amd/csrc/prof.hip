@@ -1,6 +1,8 @@
 // Live kernel timing for bench.py: HIP events recorded on the SAME stream as the kernel, immediately
 // around the launch (torch.cuda.Event would only see torch's current stream).  Off by default; costs
 // nothing when off.  One pool of event pairs, reused between uvx_prof_begin / uvx_prof_end.
+#include <algorithm>
+#include <utility>
 #include <vector>
 #include "common.h"
 #include "kernels.h"
@@ -53,6 +55,35 @@ extern "C" int32_t uvx_prof_records(double* out, int32_t max_records) {
     ++n;
   }
   return n;
+}
+
+// Wall time during which at least one launch of class `cls` was executing (union of the [begin, end] event intervals), in ms.
+// Equals the summed durations when every launch is on one stream; with the two-stream schedule (tuning option 11) launches of
+// the two chains overlap, each one's own interval includes the time it shared the chip, and the union is the honest
+// denominator for an aggregate rate.  Call BEFORE uvx_prof_end.  Negative on error.
+extern "C" double uvx_prof_union_ms(int32_t cls) {
+  std::vector<std::pair<float, float>> iv;
+  hipEvent_t ref = nullptr;
+  for (size_t i = 0; i < uvx::g_used; ++i) {
+    auto& r = uvx::g_pool[i];
+    if (hipEventSynchronize(r.b) != hipSuccess) return -1.0;
+    if (!ref) ref = r.a;
+    if (r.cls != cls) continue;
+    float ta = 0.f, tb = 0.f;
+    if (hipEventElapsedTime(&ta, ref, r.a) != hipSuccess || hipEventElapsedTime(&tb, ref, r.b) != hipSuccess) return -1.0;
+    iv.emplace_back(ta, tb);
+  }
+  std::sort(iv.begin(), iv.end());
+  double total = 0.0;
+  float lo = 0.f, hi = 0.f;
+  bool open = false;
+  for (auto& x : iv) {
+    if (open && x.first <= hi) { hi = std::max(hi, x.second); continue; }
+    if (open) total += hi - lo;
+    lo = x.first; hi = x.second; open = true;
+  }
+  if (open) total += hi - lo;
+  return total;
 }
 
 // out[cls] = {launches, total_ms, total_flops, total_bytes}; synchronises on the recorded events.

@@ -321,7 +321,7 @@ extern "C" int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, c
       g.bias = Lw.bqkv;
       RC(gemm(st, dt, g));
     }
-    RC(heads_transpose(st, dt, at(s.qkv, 2 * d, dt), s.vt, B, Tn, s.Tp, c.heads, dh, 3 * d));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(s.qkv, 2 * d, dt), s.vt, B, Tn, s.Tp, c.heads, dh, 3 * d));
     AttnDesc ad;
     ad.q = s.qkv; ad.k = at(s.qkv, d, dt); ad.v = at(s.qkv, 2 * d, dt); ad.vt = s.vt; ad.o = s.o;
     ad.B = B; ad.T = Tn; ad.Tp = s.Tp; ad.Hq = c.heads; ad.Hkv = c.heads; ad.D = dh;

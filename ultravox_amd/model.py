@@ -252,6 +252,7 @@ class UltravoxModel:
         c.llm_layers, c.llm_d, c.llm_heads, c.llm_kv_heads = t.num_hidden_layers, t.hidden_size, t.num_attention_heads, t.num_key_value_heads
         c.llm_head_dim, c.llm_inter, c.vocab, c.rms_eps = t.head_dim, t.intermediate_size, t.vocab_size, t.rms_norm_eps
         c.llm_flavor = 1 if t.is_gemma else 0      # UVX_LLM_GEMMA / UVX_LLM_LLAMA (include/uvx.h)
+        c.llm_act = {"silu": 0, "gelu_pytorch_tanh": 1, "gelu": 2}[t.hidden_act]      # UVX_ACT_* : [3P] ACT2FN[hidden_act]
         self._c = c
 
         e = self._enc
