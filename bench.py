@@ -237,6 +237,14 @@ def pmc_traffic_per_launch(profiles_dir=None):
         return None
 
 
+def _opt_get(opt: str, key: int, default: int) -> int:
+    """value of `key` in a --opt 'k=v,...' string (the library's default otherwise)"""
+    for item in (opt or "").split(","):
+        if "=" in item and int(item.split("=")[0]) == key:
+            return int(item.split("=")[1])
+    return default
+
+
 def self_launch(n: int) -> int:
     """Re-execute this command line as n ranks of one node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n
     --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`."""
@@ -374,6 +382,7 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     trainer.flush()
+    trainer.measure_comm = world > 1 and trainer.overlap_comm
     barrier()
     prof = (C.c_double * 12)()
     if not args.no_prof:
@@ -398,10 +407,17 @@ def main():
         gemm_union_ms = float(_lib.lib().uvx_prof_union_ms(0))      # wall time with >= 1 GEMM executing (= the sum on one stream)
         _lib.check(_lib.lib().uvx_prof_end(prof, 3), "uvx_prof_end")
     loss_val = float(loss.item())
-    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+    # per-rank diagnostics for the scaling runs: every rank's own wall time over the timed region and the time its compute
+    # stream waited for the (overlapped) gradient all-reduce - so that a poor 1 -> N line can be read (a slow rank? an exposed
+    # collective?) and not just observed
+    mine = torch.tensor([dt, trainer.comm_exposed_ms() if trainer.measure_comm else 0.0], device=dev, dtype=torch.float64)
+    per_rank = [mine]
     if world > 1:
-        torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t_max.item())
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(per_rank, mine)
+    rank_s = [float(t[0].item()) for t in per_rank]
+    exposed_ms = [float(t[1].item()) / args.steps for t in per_rank]
+    dt = max(rank_s)                                        # the contract: MAX over ranks
 
     if rank == 0:
         fl = flops_per_sample(cfg, wl["seconds"])
@@ -426,6 +442,13 @@ def main():
             "mfu": fl["step"] * B * world * args.steps / dt / (PEAK_BF16_TFLOPS * 1e12 * world),
             "loss": loss_val,
             "world_size": world,
+            "per_rank_ms": {"min": min(rank_s) / args.steps * 1e3, "max": max(rank_s) / args.steps * 1e3,
+                            "all": [round(t / args.steps * 1e3, 3) for t in rank_s]},
+            "allreduce_exposed_ms_per_step": (None if world == 1 else
+                                              {"max": max(exposed_ms), "all": [round(x, 4) for x in exposed_ms],
+                                               "note": "time the compute stream waited for the deferred all-reduce" if trainer.overlap_comm
+                                                       else "sequential schedule: the collective is on the compute stream, not timed separately"}),
+            "llm_streams": 2 if (B >= 2 and not args.audio_lora_r and _opt_get(args.opt, 11, 2) >= 2) else 1,
             "collective": (None if world == 1 else "gloo (shared-GPU test mode)" if share_gpu
                            else "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + (" via uvx_comm_* (C ABI)" if comm else " via torch.distributed")
                                 + " all-reduce(sum) of one flat f32 bucket, "

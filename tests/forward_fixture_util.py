@@ -91,3 +91,30 @@ def alt_batch() -> dict:
     mask[1, 32:] = 0
     labels[2, 16:] = ids[2, 16:]
     return dict(alt_input_ids=ids, alt_attention_mask=mask, alt_labels=labels)
+
+
+def speech_like_pcm(seconds: float = 30.0, seed: int = 77):
+    """A 30 s harmonic, speech-like test signal for the log-mel frontend (white noise hides the accuracy of the bins near the
+    per-clip `max - 8` floor: tonal audio has 6-8 decades of dynamic range between a harmonic and the gaps next to it):
+    a glottal-like harmonic series (f0 gliding 90-220 Hz with vibrato, 1 / h roll-off up to 4 kHz) through three moving
+    formant-like gains, syllable-rate amplitude modulation, pauses of exact silence, a faint noise floor in the voiced parts.
+    float64 arithmetic from a seeded generator, rounded to float32 - reproducible, so fixtures store outputs only."""
+    import numpy as np
+    n = int(seconds * 16000)
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    rng = np.random.RandomState(seed)
+    f0 = 150.0 + 60.0 * np.sin(2 * np.pi * 0.31 * t) + 6.0 * np.sin(2 * np.pi * 5.3 * t)
+    phase = 2 * np.pi * np.cumsum(f0) / 16000.0
+    formants = [(500 + 250 * np.sin(2 * np.pi * 0.7 * t), 90.0), (1500 + 500 * np.sin(2 * np.pi * 0.43 * t + 1.0), 140.0),
+                (2600 + 300 * np.sin(2 * np.pi * 0.2 * t + 2.0), 200.0)]
+    x = np.zeros(n)
+    for h in range(1, 27):
+        fh = h * f0
+        gain = sum(np.exp(-0.5 * ((fh - fc) / bw) ** 2) for fc, bw in formants) + 0.02
+        x += np.where(fh < 4000.0, gain / h, 0.0) * np.sin(h * phase)
+    env = np.clip(np.sin(2 * np.pi * 1.9 * t) * 1.5 + 0.4, 0.0, 1.0) ** 2
+    x = x * env + 1e-4 * rng.randn(n) * (env > 0)
+    for a, b in ((2.0, 2.6), (9.5, 10.4), (17.0, 17.3), (28.5, 30.0)):        # pauses: exact zeros
+        x[int(a * 16000): int(b * 16000)] = 0.0
+    x = 0.6 * x / np.abs(x).max()
+    return x.astype(np.float32)

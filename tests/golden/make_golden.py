@@ -230,6 +230,25 @@ def logmel_cases():
     print("logmel.npz written")
 
 
+def logmel_speech_cases():
+    """HF WhisperFeatureExtractor on a 30 s harmonic, speech-like clip (tests/forward_fixture_util.py speech_like_pcm): every
+    4th frame of the 80 x 3000 log-mel is kept (240 KB instead of 960 KB), plus the clip statistics the floor depends on."""
+    import forward_fixture_util as U
+    pcm = U.speech_like_pcm()
+    rec = {}
+    for n_mels in (80, 128):
+        fe = transformers.WhisperFeatureExtractor(feature_size=n_mels)
+        out = fe([pcm], sampling_rate=16000, padding="longest", pad_to_multiple_of=160, truncation=False,
+                 return_attention_mask=True, return_tensors="np")["input_features"][0].astype(np.float32)
+        assert out.shape == (n_mels, 3000)
+        rec[f"mel_{n_mels}_every4"] = out[:, ::4]
+        rec[f"max_{n_mels}"] = np.float32(out.max())
+        rec[f"n_floor_{n_mels}"] = np.int64((out == out.min()).sum())
+    rec["pcm_checksum"] = np.float64(np.abs(pcm.astype(np.float64)).sum())
+    np.savez_compressed(os.path.join(HERE, "logmel_speech.npz"), **rec)
+    print("logmel_speech.npz written; floor fraction", float(rec["n_floor_80"]) / (80 * 3000))
+
+
 def kl_cases():
     """Reference KL loss on seeded logits.  `self` is a stub: get_input_embeddings().forward -> passthrough,
     language_model.forward -> the recorded teacher logits."""
@@ -780,6 +799,7 @@ if __name__ == "__main__":
     projector_cases()
     latency_mask_cases()
     logmel_cases()
+    logmel_speech_cases()
     kl_cases()
     diff_state_dict_cases()
     dataproc_cases()

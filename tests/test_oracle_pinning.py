@@ -60,6 +60,20 @@ def test_logmel_matches_hf_fixture(golden_dir, n_mels):
     np.testing.assert_allclose(mel, z[f"mel_{n_mels}"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_logmel_matches_hf_on_speech_like_audio(golden_dir, n_mels):
+    """30 s of harmonic, speech-like audio with pauses (forward_fixture_util.speech_like_pcm): most bins sit at or near the
+    per-clip `max - 8` floor, which white noise never reaches.  Fixture: the installed HF WhisperFeatureExtractor."""
+    import forward_fixture_util as U
+    z = np.load(os.path.join(golden_dir, "logmel_speech.npz"))
+    pcm = U.speech_like_pcm()
+    assert abs(float(np.abs(pcm.astype(np.float64)).sum()) - float(z["pcm_checksum"])) < 1e-6 * float(z["pcm_checksum"])
+    mel = O.logmel_ref(torch.from_numpy(pcm)[None], n_mels)[0].numpy()
+    assert mel.shape == (n_mels, 3000)
+    np.testing.assert_allclose(mel[:, ::4], z[f"mel_{n_mels}_every4"], rtol=0, atol=5e-5)
+    assert abs(float(mel.max()) - float(z[f"max_{n_mels}"])) < 1e-5
+
+
 def test_feature_extractor_contract_matches_hf():
     import transformers
     rng = np.random.RandomState(3)

@@ -964,6 +964,10 @@ class UltravoxTrainer:
         self.world = comm.world if comm is not None else (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1)
         self._comm_stream = torch.cuda.Stream(device=dev) if comm is not None else None
         self._pending = None
+        # diagnostics for the scaling runs (bench.py --gpus N): time the compute stream spent WAITING for the deferred
+        # all-reduce in flush() (the exposed part of the collective), from event pairs around the wait
+        self.measure_comm = False
+        self._comm_waits = []
 
     def save_checkpoint(self, directory: str) -> None:
         """checkpoint-N/ of the HF Trainer: the model's diff state dict + optimizer moments + step."""
@@ -1071,9 +1075,26 @@ class UltravoxTrainer:
         if self._pending is None:
             return
         work, self._pending = self._pending, None
+        if self.measure_comm:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self.comm is not None:
             torch.cuda.current_stream().wait_event(work)   # uvx_comm_allreduce_f32 already applied the 1 / world
         else:
             work.wait()                                    # the compute stream waits for the collective
+        if self.measure_comm:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._comm_waits.append((e0, e1))
+        if self.comm is None:
             self.model.proj_grad.mul_(1.0 / self.world)    # DDP: sum, then divide by the world size
         self.optimizer_step()
+
+    def comm_exposed_ms(self, reset: bool = True) -> float:
+        """Sum over the flushes since the last call of the time the compute stream waited for the deferred all-reduce
+        (measure_comm = True).  Synchronises."""
+        torch.cuda.synchronize()
+        total = sum(a.elapsed_time(b) for a, b in self._comm_waits)
+        if reset:
+            self._comm_waits = []
+        return float(total)
