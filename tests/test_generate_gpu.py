@@ -250,3 +250,44 @@ def test_f32_generate_matches_the_reference_generate_fixture():
     stop = model.generate(audio_values=mel, max_new_tokens=10, eos_token_id=fx["eos"], pad_token_id=fx["pad_token_id"], **b).cpu()
     got = stop[:, T:].tolist()
     assert [r + [fx["pad_token_id"]] * (10 - len(r)) for r in got] == fx["with_eos"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_with_past_key_values_drives_a_decode_loop(dtype):
+    """forward(input_ids=new tokens, past_key_values=KVState) - the call the reference forwards to the language model
+    (ultravox_model.py:328-334) and HF's generation loop issues every step: a hand-rolled greedy loop over it reproduces
+    generate() token for token (f32), appends to / grows the cache, and returns [B, 1, V] logits + the extended state; a
+    multi-token continuation needs logits_to_keep=1 (HF's own prefill setting)."""
+    cfg, model, _ = _build(dtype, 37)
+    torch.manual_seed(3)
+    B, T = 2, 40
+    ids = torch.randint(3, 512, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, :4] = 0
+    ids[am == 0] = 2
+    n_new = 9
+    want = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=n_new, eos_token_id=-1).cpu()
+    # prompt -> cache (one generated token), then step by step through forward()
+    first = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=1, eos_token_id=-1, return_dict_in_generate=True)
+    state, seq = first.past_key_values, first.sequences
+    assert state.cur_len == T and state.Tmax == T + 1
+    for step in range(n_new - 1):
+        out = model.forward(input_ids=seq[:, -1:], past_key_values=state)
+        assert tuple(out.logits.shape) == (B, 1, 512) and out.past_key_values.cur_len == T + 1 + step
+        state = out.past_key_values
+        seq = torch.cat([seq, out.logits[:, 0].float().argmax(-1, keepdim=True)], 1)
+    assert state.Tmax >= T + n_new - 1                       # grown past the buffer generate() sized for one token
+    if dtype == torch.float32:
+        assert torch.equal(seq.cpu(), want)
+    else:
+        assert (seq.cpu() == want).float().mean().item() > 0.9
+    # several new tokens at once: last-position logits only, on request
+    with pytest.raises(NotImplementedError, match="logits_to_keep=1"):
+        model.forward(input_ids=want[:, T:T + 3].to(DEV), past_key_values=first.past_key_values)
+    again = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=1, eos_token_id=-1, return_dict_in_generate=True)
+    out3 = model.forward(input_ids=want[:, T:T + 3].to(DEV), past_key_values=again.past_key_values, logits_to_keep=1)
+    assert out3.past_key_values.cur_len == T + 3
+    if dtype == torch.float32:
+        assert torch.equal(out3.logits[:, 0].float().argmax(-1).cpu(), want[:, T + 3])
+    with pytest.raises(ValueError, match="inference call"):
+        model.forward(input_ids=seq[:, -1:], past_key_values=state, labels=seq[:, -1:])

@@ -349,6 +349,11 @@ def test_two_stream_llm_schedule_is_bit_identical(B, T):
         _lib.lib().uvx_set_option(11, 2)       # the default
     two = run()
     two_again = run()
-    for a, b, c in zip(one, two, two_again):
-        assert torch.equal(a, b) and torch.equal(a, c)
+    _lib.lib().uvx_set_option(11, 3)           # side chain half a layer behind
+    try:
+        staggered = run()
+    finally:
+        _lib.lib().uvx_set_option(11, 2)
+    for a, b, c, d in zip(one, two, two_again, staggered):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
     assert torch.isfinite(one[2].float()).all() and one[2].float().abs().max() > 0

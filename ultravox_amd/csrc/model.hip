@@ -292,6 +292,10 @@ struct Fork {
   hipStream_t side = nullptr;
   hipEvent_t e_fork = nullptr, e_join = nullptr;
 };
+// Option 11 = 3: the side chain starts half a layer late (it waits for the first chain's first half-layer instead of for the
+// fork point).  Two chains that start together run in lockstep - GEMM beside GEMM, elementwise beside elementwise, both tails
+// at the same moment; offset by half a layer one chain's GEMMs run beside the other's attention / norms / activation kernels.
+inline bool fork_staggered() { return g_options[11] >= 3; }
 Fork* fork_for_device() {
   static Fork forks[16];
   int dev = 0;
@@ -784,7 +788,8 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   const int hb[3] = {0, fk ? (B + 1) / 2 : B, B};
   LlmWs hv[2] = {llm_view(s, c, 0, hb[1], T), fk ? llm_view(s, c, hb[1], B - hb[1], T) : s};
   hipStream_t hs[2] = {st, fk ? fk->side : st};
-  if (fk) {
+  const bool stagger = fk && fork_staggered();
+  if (fk && !stagger) {
     UVX_HIP(hipEventRecord(fk->e_fork, st));
     UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
   }
@@ -793,6 +798,10 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     const bool compact = tc && l + 1 == c.llm_layers;
     for (int h = 0; h < nh && rc_layers == UVX_OK; ++h) {
       rc_layers = layer_attn(hs[h], hv[h], hb[h + 1] - hb[h], l);
+      if (l == 0 && h == 0 && stagger) {   // the side chain may start now: half a layer behind
+        UVX_HIP(hipEventRecord(fk->e_fork, st));
+        UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
+      }
       if (rc_layers == UVX_OK && !compact) rc_layers = layer_mlp(hs[h], hv[h], l, false);
     }
   }
@@ -1037,7 +1046,8 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   const int hb[3] = {0, fk ? (B + 1) / 2 : B, B};
   LlmWs hv[2] = {llm_view(s, c, 0, hb[1], T), fk ? llm_view(s, c, hb[1], B - hb[1], T) : s};
   hipStream_t hs[2] = {st, fk ? fk->side : st};
-  if (fk) {
+  const bool stagger = fk && fork_staggered();
+  if (fk && !stagger) {
     UVX_HIP(hipEventRecord(fk->e_fork, st));
     UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
   }
@@ -1047,6 +1057,15 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     for (int h = 0; h < nh && rc_layers == UVX_OK; ++h) {
       const LlmWs& v = hv[h];
       if (!compact) rc_layers = layer_mlp_bwd(hs[h], v, l, false);
+      if (l == top && h == 0 && stagger) {   // the side chain starts half a layer behind (see fork_staggered)
+        if (compact) {   // (training pair: the top layer has no per-half MLP part; offset by the first chain's attention half instead)
+          void* dx0 = l == 0 ? d_inputs_embeds : v.dx;
+          if (rc_layers == UVX_OK) rc_layers = layer_attn_bwd(hs[0], v, hb[1] - hb[0], l, true, v.d_hn, dx0);
+        }
+        UVX_HIP(hipEventRecord(fk->e_fork, st));
+        UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
+        if (compact) continue;
+      }
       void* dx_out = l == 0 ? (void*)((char*)d_inputs_embeds + (size_t)hb[h] * T * D * es) : v.dx;
       if (rc_layers == UVX_OK) rc_layers = layer_attn_bwd(hs[h], v, hb[h + 1] - hb[h], l, compact, compact ? v.d_hn : v.dx, dx_out);
     }

@@ -645,7 +645,9 @@ class UltravoxModel:
         [start, end) key range, so a mask with holes would be honoured only at its outer edges.  A CPU mask is checked here
         (a device mask is not: the check would cost a host synchronisation per step)."""
         if past_key_values is not None:
-            raise NotImplementedError("forward() with an external KV cache is not built; use generate() (prefill + decode)")
+            return self._forward_with_cache(past_key_values, input_ids, inputs_embeds, audio_values, audio_token_start_idx,
+                                            audio_lens, audio_token_len, audio_batch_size, labels, attention_mask,
+                                            kwargs.get("logits_to_keep", kwargs.get("num_logits_to_keep", 0)))
         if attention_mask is not None and not attention_mask.is_cuda:
             m = attention_mask != 0
             if bool(((m[:, 1:] != m[:, :-1]).sum(-1) > 2).any()) or bool(((m[:, 1:] != m[:, :-1]).sum(-1) == 2).__and__(m[:, 0]).any()):
@@ -669,6 +671,59 @@ class UltravoxModel:
                                 return_logits)
 
     __call__ = forward
+
+    def _forward_with_cache(self, past, input_ids, inputs_embeds, audio_values, audio_token_start_idx, audio_lens, audio_token_len,
+                            audio_batch_size, labels, attention_mask, logits_to_keep) -> CausalLMOutputWithPast:
+        """forward(..., past_key_values=KVState) - what the reference forwards to the language model (ultravox_model.py:328-334)
+        and HF's generation loop calls every step: `input_ids` / `inputs_embeds` hold only the NEW positions (HF's contract for
+        a cache handed to forward), their keys / values are appended to the cache (uvx_llm_prefill_chunk) and the logits of
+        the last new position come back as [B, 1, V] - HF's `logits_to_keep=1`, what its generate() asks for; one new token
+        (the decode step) needs no flag.  The returned `past_key_values` is the extended state (the one handed in is consumed,
+        as HF's in-place caches are)."""
+        if not isinstance(past, KVState):
+            raise TypeError("past_key_values must be a KVState (generate(return_dict_in_generate=True).past_key_values)")
+        if labels is not None:
+            raise ValueError("forward() with a KV cache is an inference call: labels are not supported")
+        if self.text_lora_r > 0:
+            raise NotImplementedError("forward() with a KV cache and an un-merged LLM LoRA adapter: call merge_and_unload() first")
+        l = _lib.lib()
+        dev = self.device
+        if audio_values is not None and len(audio_values) > 0:
+            inputs_embeds = self._prepare_audio_embeds(inputs_embeds, input_ids, audio_values, audio_token_start_idx,
+                                                       audio_lens, audio_token_len, audio_batch_size)
+        elif inputs_embeds is None:
+            inputs_embeds = self._embed_merge(None, input_ids, None, None, None, None, *input_ids.shape)
+        B, Tn, D = inputs_embeds.shape
+        if B != past.tokens.shape[0]:
+            raise ValueError(f"batch size {B} does not match the cache ({past.tokens.shape[0]})")
+        if Tn > 1 and int(logits_to_keep or 0) != 1:
+            raise NotImplementedError("forward() with a KV cache returns the logits of the last new position only: pass "
+                                      "logits_to_keep=1 (as HF's generate does) or feed one token per call")
+        if attention_mask is not None and not bool(torch.as_tensor(attention_mask)[:, -Tn:].to("cpu").bool().all()):
+            raise ValueError("padding inside the new positions of a cached sequence is not supported")
+        P, V = past.cur_len, self.config.vocab_size
+        if P + Tn > self._llm["rope_len"]:
+            raise ValueError(f"cache + new tokens = {P + Tn} exceeds the RoPE table ({self._llm['rope_len']})")
+        cache, Tmax = past.cache, past.Tmax
+        if Tmax < P + Tn:                      # grow: rows [0, P) of every (layer, k|v, sequence) plane move over
+            new_T = max(P + Tn, 2 * Tmax)
+            nbytes = l.uvx_kv_cache_bytes(C.byref(self._c), B, new_T)
+            grown = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            planes = self._c.llm_layers * 2 * B
+            row = nbytes // (planes * new_T)
+            grown[:nbytes].view(planes, new_T, row)[:, :P].copy_(cache[:planes * Tmax * row].view(planes, Tmax, row)[:, :P])
+            cache, Tmax = grown, new_T
+        nb = l.uvx_llm_prefill_chunk_ws_bytes(C.byref(self._c), B, Tn, P)
+        ws = self._workspace("infer", nb)
+        logits = torch.empty(B, V, device=dev, dtype=self.dtype)
+        pos0 = past.pos_next.to(torch.int32).contiguous()
+        check(l.uvx_llm_prefill_chunk(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), B, Tn,
+                                      ptr(cache), Tmax, P, ptr(pos0), ptr(past.kv_start), ptr(logits), ptr(ws), C.c_size_t(nb)),
+              "uvx_llm_prefill_chunk")
+        new_ids = (input_ids.to(dev) if input_ids is not None else torch.full((B, Tn), -1, device=dev, dtype=torch.int64))
+        state = KVState(cache=cache, Tmax=Tmax, cur_len=P + Tn, pos_next=(pos0 + Tn).contiguous(), kv_start=past.kv_start,
+                        tokens=torch.cat([past.tokens, new_ids.to(torch.int64)], dim=1), partial_ok=past.partial_ok)
+        return CausalLMOutputWithPast(loss=None, logits=logits[:, None, :], past_key_values=state)
 
     def _kl_forward(self, inputs_embeds, labels, attention_mask, alt_input_ids, alt_attention_mask, alt_labels,
                     return_logits) -> CausalLMOutputWithPast:
