@@ -448,7 +448,7 @@ def main():
                                               {"max": max(exposed_ms), "all": [round(x, 4) for x in exposed_ms],
                                                "note": "time the compute stream waited for the deferred all-reduce" if trainer.overlap_comm
                                                        else "sequential schedule: the collective is on the compute stream, not timed separately"}),
-            "llm_streams": 2 if (B >= 2 and not args.audio_lora_r and _opt_get(args.opt, 11, 2) >= 2) else 1,
+            "llm_streams": max(1, min(B, 4, _opt_get(args.opt, 11, 2))),
             "collective": (None if world == 1 else "gloo (shared-GPU test mode)" if share_gpu
                            else "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + (" via uvx_comm_* (C ABI)" if comm else " via torch.distributed")
                                 + " all-reduce(sum) of one flat f32 bucket, "

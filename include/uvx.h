@@ -358,11 +358,13 @@ int32_t uvx_gemm_force_variant(int32_t variant);
 /* probes (same-box A/B inside bench.py): key 1 = 16-byte epilogue loads/stores (default 1), key 2 = SwiGLU backward fused
  * into the down-projection dgrad GEMM (default 0: measured neutral), key 3 = LM head / CE / head dgrad on the supervised
  * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
- * problems of at most 16 rows (the decode step; default 1), key 11 = LLM layer chains of the two batch halves on two
- * streams (2 = on, the default; 0 = one chain on the caller's stream; uvx_llm_fwd* / uvx_llm_bwd*: same kernels on the same rows, bit-identical results; the side stream is
+ * problems of at most 16 rows (the decode step; default 1), key 11 = number of LLM layer chains: the batch
+ * is cut into that many slices whose layer chains run on as many streams (default 2, at most 4; 0 / 1 = one chain on the
+ * caller's stream; uvx_llm_fwd* / uvx_llm_bwd*: same kernels on the same rows, bit-identical results; the side streams are
  * forked from and joined into the caller's stream by events, so the call stays stream-ordered for the caller), key 12 = bf16
  * attention kernels read V^T / Q^T / K^T / dO^T out of the natural tiles with the transposing LDS read instead of from
- * transposed copies in global memory (default 1; 0 restores the copies: heads_transpose + the *_t staging) */
+ * transposed copies in global memory (default 1; 0 restores the copies: heads_transpose + the *_t staging), key 14 = the LLM's attention backward writes dq / dk
+ * RoPE-inverted from its own epilogues instead of a separate pass over d_qkv (default 1; bit-identical) */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* Diagnostic for the stream-K GEMM launches (probe builds only - libuvx_probes.so; the production picker never selects
  * them and this returns 0): blocks that wait for another block's partial sums spin for a bounded time (~1 s) and then give

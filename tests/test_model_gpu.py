@@ -319,8 +319,8 @@ def test_loss_head_on_supervised_rows_split_k(T, first_label):
 
 @pytest.mark.parametrize("B,T", [(2, 48), (5, 70), (8, 316)])
 def test_two_stream_llm_schedule_is_bit_identical(B, T):
-    """uvx_set_option(11, 2) (the default): the LLM layer chains of the two batch halves run on two streams (the caller's and one forked
-    from / joined into it by events).  Same kernels on the same rows: loss, full logits and d loss / d inputs_embeds must be
+    """uvx_set_option(11, 2) (the default): the LLM layer chains of the batch slices run on several streams (the caller's and side streams
+    forked from / joined into it by events; option value = number of chains).  Same kernels on the same rows: loss, full logits and d loss / d inputs_embeds must be
     BIT-identical to the one-stream schedule - for the plain pair (full logits), the training pair (last layer and head on the
     supervised rows), an odd batch (halves of 3 and 2) and with left / right padding in the attention mask."""
     from ultravox_amd import _lib
@@ -349,11 +349,43 @@ def test_two_stream_llm_schedule_is_bit_identical(B, T):
         _lib.lib().uvx_set_option(11, 2)       # the default
     two = run()
     two_again = run()
-    _lib.lib().uvx_set_option(11, 3)           # side chain half a layer behind
-    try:
-        staggered = run()
-    finally:
-        _lib.lib().uvx_set_option(11, 2)
-    for a, b, c, d in zip(one, two, two_again, staggered):
-        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    more = []
+    for n in (3, 4):                           # three / four chains (B = 2: capped at two; B = 5: slices of 2, 1, 1, 1)
+        _lib.lib().uvx_set_option(11, n)
+        try:
+            more.append(run())
+        finally:
+            _lib.lib().uvx_set_option(11, 2)
+    for i, a in enumerate(one):
+        for other in (two, two_again, *more):
+            assert torch.equal(a, other[i])
     assert torch.isfinite(one[2].float()).all() and one[2].float().abs().max() > 0
+
+
+def test_fused_inverse_rope_in_the_attention_backward_is_bit_identical():
+    """Option 14 (default on): dq / dk leave the LLM's attention backward already RoPE-inverted (epilogue of the dQ kernel, the
+    GQA group reduction) instead of a separate rope pass over d_qkv.  Same arithmetic and rounding points: d inputs_embeds is
+    bit-identical - GQA (4 : 2 heads) and, with kv heads = heads, the un-grouped dK epilogue."""
+    from ultravox_amd import _lib
+    for kv in (2, 4):
+        tc = dict(SMALL["text_config"], num_hidden_layers=2, num_key_value_heads=kv)
+        cfg, sd, model, oracle = build(14, text_config=tc)
+        torch.manual_seed(6)
+        B, T = 3, 77
+        emb = (torch.randn(B, T, 256) * 0.5).bfloat16().to(DEV)
+        labels = torch.randint(0, 512, (B, T)); labels[:, :30] = -100
+        mask = torch.ones(B, T, dtype=torch.long); mask[1, :6] = 0
+
+        def run():
+            model.language_model_forward(emb, labels=labels.to(DEV), attention_mask=mask.to(DEV), want_logits=False, save_for_bwd=True)
+            d = model.language_model_backward(1.0).clone()
+            torch.cuda.synchronize()
+            return d
+
+        fused = run()
+        _lib.lib().uvx_set_option(14, 0)
+        try:
+            separate = run()
+        finally:
+            _lib.lib().uvx_set_option(14, 1)
+        assert torch.equal(fused, separate) and fused.float().abs().max() > 0

@@ -39,7 +39,31 @@ struct AttnArgs {
   int lddq, lddk, lddv;
   float scale;
   float* dkv_part;  // scratch for [2][B, T, Hq, D] per-query-head results (GQA; stored as bf16) or null
+  const float* rope;  // backward: [T_table, D/2, 2] f32 cos / sin - dQ and dK leave the kernels RoPE-INVERTED (the gradient of q, k
+                      // before the rotary embedding), position = the row's index in its sequence; null = none
 };
+
+// Inverse rotary embedding of one gradient row held as DT accumulator tiles (element e of tile dt <-> d = 16 dt + 4 g + e):
+// the pair (d, d + D/2) sits in tiles dt and dt + DT/2 of the same lane.  Same arithmetic and rounding points as rope_k
+// (elementwise.hip) applied to the bf16-rounded gradient: every product rounded to bf16, the sum rounded by the store.
+template <int DT>
+__device__ __forceinline__ void rope_inverse_tiles(float (&v)[DT][4], const float* __restrict__ cs, int pos, int g) {
+  constexpr int HALF = DT / 2;
+  const float* t = cs + (long long)pos * (HALF * 16) * 2;
+#pragma unroll
+  for (int dt = 0; dt < HALF; ++dt) {
+    const float4 a = *reinterpret_cast<const float4*>(t + (dt * 16 + 4 * g) * 2);
+    const float4 b = *reinterpret_cast<const float4*>(t + (dt * 16 + 4 * g) * 2 + 4);
+    const float co[4] = {a.x, a.z, b.x, b.z}, si[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float c = bf2f(f2bf(co[e])), sn = -bf2f(f2bf(si[e]));
+      const float lo = v[dt][e], hi = v[dt + HALF][e];
+      v[dt][e] = bf2f(f2bf(lo * c)) + bf2f(f2bf(-hi * sn));
+      v[dt + HALF][e] = bf2f(f2bf(hi * c)) + bf2f(f2bf(lo * sn));
+    }
+  }
+}
 
 __device__ __forceinline__ bf16x8_t lds_b128(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
@@ -568,11 +592,17 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   } else if (key < p.T) {
     bf16_t* dkrow = p.dk + ((long long)b * p.T + key) * p.lddk + hk * D;
     bf16_t* dvrow = p.dv + ((long long)b * p.T + key) * p.lddv + hk * D;
+    float dkv[DT][4];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dkv[d][e] = bf2f(f2bf(acc_dk[d][e] * p.scale));
+    if (p.rope) rope_inverse_tiles<DT>(dkv, p.rope, key, g);
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       u16x4_t a, c;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a[e] = f2bf(acc_dk[d][e] * p.scale); c[e] = f2bf(acc_dv[d][e]); }
+      for (int e = 0; e < 4; ++e) { a[e] = f2bf(dkv[d][e]); c[e] = f2bf(acc_dv[d][e]); }
       *reinterpret_cast<u16x4_t*>(dkrow + d * 16 + g * 4) = a;
       *reinterpret_cast<u16x4_t*>(dvrow + d * 16 + g * 4) = c;
     }
@@ -741,40 +771,72 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   }
   if (q < p.T) {
     bf16_t* dqrow = p.dq + ((long long)b * p.T + q) * p.lddq + h * D;
+    float dqv[DT][4];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dqv[d][e] = bf2f(f2bf(acc[d][e] * p.scale));
+    if (p.rope) rope_inverse_tiles<DT>(dqv, p.rope, q, g);
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       u16x4_t a;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] = f2bf(acc[d][e] * p.scale);
+      for (int e = 0; e < 4; ++e) a[e] = f2bf(dqv[d][e]);
       *reinterpret_cast<u16x4_t*>(dqrow + d * 16 + g * 4) = a;
     }
   }
 }
 
-// dk/dv[b, t, hk, :] = sum over the GQA group (fixed order, f32) of the bf16 per-query-head results
+// dk/dv[b, t, hk, :] = sum over the GQA group (fixed order, f32) of the bf16 per-query-head results; with `rope` the summed dK is
+// then RoPE-inverted (same arithmetic as rope_k on the bf16-rounded sum).  One thread = 8 columns c..c+7 of the first half of
+// the head AND their partners c + D/2.. (the rotary pairs) of one (b, t, hk).
 __global__ void gqa_reduce_k(const bf16_t* __restrict__ part, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int B, int T,
-                             int Hq, int Hkv, int D, int lddk, int lddv) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // 8 columns of one (b, t, hk)
-  const int dv8 = D / 8;
-  const long long n = (long long)B * T * Hkv * dv8;
+                             int Hq, int Hkv, int D, int lddk, int lddv, const float* __restrict__ rope) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int dv16 = D / 16;
+  const long long n = (long long)B * T * Hkv * dv16;
   if (i >= n) return;
-  const int c = (int)(i % dv8) * 8, hk = (int)((i / dv8) % Hkv);
-  const long long bt = i / ((long long)dv8 * Hkv);
-  const int grp = Hq / Hkv;
+  const int c = (int)(i % dv16) * 8, hk = (int)((i / dv16) % Hkv);
+  const long long bt = i / ((long long)dv16 * Hkv);
+  const int grp = Hq / Hkv, half_d = D / 2;
   const long long half = (long long)B * T * Hq * D;
-  float sk[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float sk[2][8], sv[2][8];
+#pragma unroll
+  for (int z = 0; z < 2; ++z)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sk[z][e] = 0.f; sv[z][e] = 0.f; }
   for (int gq = 0; gq < grp; ++gq) {
     const bf16_t* pk = part + (bt * Hq + hk * grp + gq) * D + c;
-    const u16x8_t a = *reinterpret_cast<const u16x8_t*>(pk);
-    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(pk + half);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sk[e] += bf2f(a[e]); sv[e] += bf2f(v[e]); }
+    for (int z = 0; z < 2; ++z) {
+      const u16x8_t a = *reinterpret_cast<const u16x8_t*>(pk + z * half_d);
+      const u16x8_t v = *reinterpret_cast<const u16x8_t*>(pk + z * half_d + half);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sk[z][e] += bf2f(a[e]); sv[z][e] += bf2f(v[e]); }
+    }
   }
-  u16x8_t ok, ov;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { ok[e] = f2bf(sk[e]); ov[e] = f2bf(sv[e]); }
-  *reinterpret_cast<u16x8_t*>(dk + bt * lddk + hk * D + c) = ok;
-  *reinterpret_cast<u16x8_t*>(dv + bt * lddv + hk * D + c) = ov;
+  for (int z = 0; z < 2; ++z)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sk[z][e] = bf2f(f2bf(sk[z][e]));
+  if (rope) {
+    const float* t = rope + ((long long)(bt % T) * half_d + c) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float co = bf2f(f2bf(t[2 * e])), sn = -bf2f(f2bf(t[2 * e + 1]));
+      const float lo = sk[0][e], hi = sk[1][e];
+      sk[0][e] = bf2f(f2bf(lo * co)) + bf2f(f2bf(-hi * sn));
+      sk[1][e] = bf2f(f2bf(hi * co)) + bf2f(f2bf(lo * sn));
+    }
+  }
+#pragma unroll
+  for (int z = 0; z < 2; ++z) {
+    u16x8_t ok, ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ok[e] = f2bf(sk[z][e]); ov[e] = f2bf(sv[z][e]); }
+    *reinterpret_cast<u16x8_t*>(dk + bt * lddk + hk * D + z * half_d + c) = ok;
+    *reinterpret_cast<u16x8_t*>(dv + bt * lddv + hk * D + z * half_d + c) = ov;
+  }
 }
 
 // probe: out[lane*4 + j] = element j that ds_read_b64_tr_b16 returns to `lane` when lane l supplies the byte address addr[l] of
@@ -868,28 +930,29 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   UVX_CHECK(d.lddq % 8 == 0 && d.lddk % 8 == 0 && d.lddv % 8 == 0, UVX_ERR_SHAPE, "attention_bwd: gradient row strides must be multiples of 8");
   a.dkv_part = (d.f.Hq != d.f.Hkv) ? d.dkv_part : nullptr;
   a.o = (bf16_t*)d.f.o;
+  a.rope = d.rope_cos_sin;
   // dQ first: it computes delta = rowsum(dO * O) on the fly and leaves it in d.delta for the dK/dV kernel
   const int kv_heads = a.dkv_part ? d.f.Hq : d.f.Hkv;
   dim3 gk(kv_heads, d.f.B, cdiv(d.f.T, 64)), gk128(kv_heads, d.f.B, cdiv(d.f.T, 128)), gq(d.f.Hq, d.f.B, cdiv(d.f.T, 64));
   // head_dim 128 (the LLM): 128 queries / keys per block (8 waves), 32-row steps, two-deep prefetch.  64-row steps (ST = 64,
-  // with or without the second staging set) were measured within 3 % of this at the C2 shape and are not instantiated
-  // (profiles/r02_attn_bwd.txt).
+  // with or without the second staging set) were measured within 3 % of this at the C2 shape in round 2 and again on the
+  // transposing-read kernels in round 3 (85.15 vs 84.96 ms per step, profiles/r03_call5_ab.txt): not instantiated.
   const bool tr = attention_tr_reads(dtype);   // natural tiles + transposing LDS reads (no Q^T / K^T / dO^T copies) - option 12
   UVX_CHECK(tr || (d.qt && d.kt && d.dot), UVX_ERR_INVALID, "attention_bwd: transposed operand copies are null");
   UVX_CHECK(d.f.v != nullptr, UVX_ERR_INVALID, "attention_bwd: v is null");
-#define BWD(DD, NTH, DEEP, GQ, GK) do { \
-    if (tr) { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, 32, DEEP, true>), GQ, dim3(NTH), 0, st, a); \
-              hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, 32, DEEP, true>), GK, dim3(NTH), 0, st, a); } \
-    else { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, 32, DEEP, false>), GQ, dim3(NTH), 0, st, a); \
-           hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, 32, DEEP, false>), GK, dim3(NTH), 0, st, a); } } while (0)
-  if (d.f.D == 64) BWD(64, 256, true, gq, gk);
-  else if (d.f.D == 128) BWD(128, 512, true, dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), gk128);
-  else BWD(256, 256, false, gq, gk);
+#define BWD(DD, NTH, STEP, DEEP, GQ, GK) do { \
+    if (tr) { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, STEP, DEEP, true>), GQ, dim3(NTH), 0, st, a); \
+              hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, true>), GK, dim3(NTH), 0, st, a); } \
+    else { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, STEP, DEEP, false>), GQ, dim3(NTH), 0, st, a); \
+           hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, false>), GK, dim3(NTH), 0, st, a); } } while (0)
+  if (d.f.D == 64) BWD(64, 256, 32, true, gq, gk);
+  else if (d.f.D == 128) BWD(128, 512, 32, true, dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), gk128);
+  else BWD(256, 256, 32, false, gq, gk);
 #undef BWD
   if (a.dkv_part) {
-    const long long n8 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 8);
-    hipLaunchKernelGGL(gqa_reduce_k, dim3(cdiv(n8, 256)), dim3(256), 0, st, (const bf16_t*)a.dkv_part, a.dk, a.dv, d.f.B, d.f.T, d.f.Hq,
-                       d.f.Hkv, d.f.D, a.lddk, a.lddv);
+    const long long n16 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 16);
+    hipLaunchKernelGGL(gqa_reduce_k, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const bf16_t*)a.dkv_part, a.dk, a.dv, d.f.B, d.f.T, d.f.Hq,
+                       d.f.Hkv, d.f.D, a.lddk, a.lddv, a.rope);
   }
   UVX_LAUNCH_CHECK();
   return UVX_OK;

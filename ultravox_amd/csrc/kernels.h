@@ -154,7 +154,11 @@ struct AttnBwdDesc {
   float* dkv_part = nullptr;   // optional scratch (sized for [2, B, T, Hq, D] f32; the bf16 kernels store bf16): per-query-head dK/dV (GQA)
   void* dq = nullptr; void* dk = nullptr; void* dv = nullptr;  // same layouts/strides as q,k,v
   int lddq = 0, lddk = 0, lddv = 0;
+  // bf16 kernels only (attention_bwd_fuses_rope): [T_table, D/2, 2] f32 cos / sin of the rotary embedding that produced q and k -
+  // dq and dk are then written RoPE-INVERTED (gradients of the projections' outputs), saving the separate inverse-RoPE pass
+  const float* rope_cos_sin = nullptr;
 };
+inline bool attention_bwd_fuses_rope(int dtype) { return dtype == DT_BF16; }
 int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d);
 // true: the attention kernels of this dtype read vt / qt / kt / dot (callers run heads_transpose first); false (bf16 with tuning
 // option 12, the default): they read the natural q / k / v / dout through the transposing LDS read and ignore those pointers

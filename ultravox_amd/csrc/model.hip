@@ -282,31 +282,65 @@ LlmWs llm_view(const LlmWs& w, const uvx_config_t& c, int b0, int nb, int T) {
   return v;
 }
 
-// Two-stream schedule (tuning option 11 = 2): the batch is cut in two halves whose layer chains are independent (frozen
-// LLM: no weight gradient couples them), and the halves run on the caller's stream and on one side stream.  Every kernel
+// Multi-stream schedule (tuning option 11 = number of chains, default 2): the batch is cut into slices whose layer chains are
+// independent (frozen LLM: no weight gradient couples them); they run on the caller's stream and on side streams.  Every kernel
 // of a chain depends on its predecessor, so on ONE stream the tail of each GEMM (a partly filled last round of tiles: 1120
 // tiles = 4.4 rounds of 256 CUs at N = 28672, 560 = 2.2 at N = 14336) and every HBM-bound elementwise kernel leave CUs
 // idle; with two chains in flight the other half's kernel takes those CUs.  Same kernels on the same rows: results are
 // bit-identical to the one-stream schedule.  Fork / join by events (legal under stream capture as well).
 struct Fork {
-  hipStream_t side = nullptr;
-  hipEvent_t e_fork = nullptr, e_join = nullptr;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t e_fork = nullptr, e_join[3] = {nullptr, nullptr, nullptr};
+  bool ok = false;
 };
-// Option 11 = 3: the side chain starts half a layer late (it waits for the first chain's first half-layer instead of for the
-// fork point).  Two chains that start together run in lockstep - GEMM beside GEMM, elementwise beside elementwise, both tails
-// at the same moment; offset by half a layer one chain's GEMMs run beside the other's attention / norms / activation kernels.
-inline bool fork_staggered() { return g_options[11] >= 3; }
 Fork* fork_for_device() {
   static Fork forks[16];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   Fork& f = forks[dev];
-  if (!f.side) {
-    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) { f.side = nullptr; return nullptr; }
-    if (hipEventCreateWithFlags(&f.e_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&f.e_join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (!f.ok) {
+    if (hipEventCreateWithFlags(&f.e_fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < 3; ++i)
+      if (hipStreamCreateWithFlags(&f.side[i], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&f.e_join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    f.ok = true;
   }
   return &f;
+}
+// The chains of one call: batch slices [b0[i], b0[i + 1]) with their workspace views and streams (chain 0 = the caller's).
+// Option 11 = number of chains (2 by default, up to 4; 0 / 1 = one chain); a chain needs at least one sequence.
+struct Chains {
+  int n = 1;
+  int b0[5] = {0, 0, 0, 0, 0};
+  LlmWs v[4];
+  hipStream_t st[4];
+  Fork* fk = nullptr;
+};
+Chains make_chains(hipStream_t st, const LlmWs& s, const uvx_config_t& c, int B, int T, bool allowed) {
+  Chains ch;
+  int want = g_options[11] < 2 ? 1 : (g_options[11] > 4 ? 4 : g_options[11]);
+  if (want > B) want = B;
+  ch.fk = (allowed && want >= 2) ? fork_for_device() : nullptr;
+  ch.n = ch.fk ? want : 1;
+  for (int i = 0; i <= ch.n; ++i) ch.b0[i] = (int)(((long long)B * i + ch.n - 1) / ch.n);   // sizes differ by at most one, larger first
+  for (int i = 0; i < ch.n; ++i) {
+    ch.v[i] = ch.n == 1 ? s : llm_view(s, c, ch.b0[i], ch.b0[i + 1] - ch.b0[i], T);
+    ch.st[i] = i == 0 ? st : ch.fk->side[i - 1];
+  }
+  return ch;
+}
+int chains_fork(const Chains& ch) {
+  if (ch.n < 2) return UVX_OK;
+  UVX_HIP(hipEventRecord(ch.fk->e_fork, ch.st[0]));
+  for (int i = 1; i < ch.n; ++i) UVX_HIP(hipStreamWaitEvent(ch.st[i], ch.fk->e_fork, 0));
+  return UVX_OK;
+}
+int chains_join(const Chains& ch) {
+  for (int i = 1; i < ch.n; ++i) {
+    UVX_HIP(hipEventRecord(ch.fk->e_join[i - 1], ch.st[i]));
+    UVX_HIP(hipStreamWaitEvent(ch.st[0], ch.fk->e_join[i - 1], 0));
+  }
+  return UVX_OK;
 }
 
 int check_cfg(const uvx_config_t* c) {
@@ -782,33 +816,20 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     }
     return UVX_OK;
   };
-  // schedule: one chain on the caller's stream, or (option 11) two batch halves on two streams - see Fork above
-  Fork* fk = (g_options[11] >= 2 && B >= 2 && dt == DT_BF16 && !lora) ? fork_for_device() : nullptr;
-  const int nh = fk ? 2 : 1;
-  const int hb[3] = {0, fk ? (B + 1) / 2 : B, B};
-  LlmWs hv[2] = {llm_view(s, c, 0, hb[1], T), fk ? llm_view(s, c, hb[1], B - hb[1], T) : s};
-  hipStream_t hs[2] = {st, fk ? fk->side : st};
-  const bool stagger = fk && fork_staggered();
-  if (fk && !stagger) {
-    UVX_HIP(hipEventRecord(fk->e_fork, st));
-    UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
-  }
+  // schedule: one chain on the caller's stream, or (option 11) the batch slices on several streams - see Fork above.  The
+  // chains advance in lockstep (same kernel at the same time): a staggered start was measured 3.3 ms per step slower
+  // (profiles/r03_two_stream_stagger_and_tiles_ab.txt).
+  const Chains ch = make_chains(st, s, c, B, T, dt == DT_BF16 && !lora);
+  RC(chains_fork(ch));
   int rc_layers = UVX_OK;
   for (int l = 0; l < c.llm_layers && rc_layers == UVX_OK; ++l) {
     const bool compact = tc && l + 1 == c.llm_layers;
-    for (int h = 0; h < nh && rc_layers == UVX_OK; ++h) {
-      rc_layers = layer_attn(hs[h], hv[h], hb[h + 1] - hb[h], l);
-      if (l == 0 && h == 0 && stagger) {   // the side chain may start now: half a layer behind
-        UVX_HIP(hipEventRecord(fk->e_fork, st));
-        UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
-      }
-      if (rc_layers == UVX_OK && !compact) rc_layers = layer_mlp(hs[h], hv[h], l, false);
+    for (int h = 0; h < ch.n && rc_layers == UVX_OK; ++h) {
+      rc_layers = layer_attn(ch.st[h], ch.v[h], ch.b0[h + 1] - ch.b0[h], l);
+      if (rc_layers == UVX_OK && !compact) rc_layers = layer_mlp(ch.st[h], ch.v[h], l, false);
     }
   }
-  if (fk) {   // join (also on an error above: the side stream must not be left forked)
-    UVX_HIP(hipEventRecord(fk->e_join, fk->side));
-    UVX_HIP(hipStreamWaitEvent(st, fk->e_join, 0));
-  }
+  RC(chains_join(ch));   // (also after an error above: the side streams must not be left forked)
   RC(rc_layers);
   if (tc) RC(layer_mlp(st, s, c.llm_layers - 1, true));
   RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps, fl));
@@ -1004,8 +1025,11 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     bd.dout = v.d_o; bd.qt = v.qT; bd.kt = v.kT; bd.dot = v.doT; bd.delta = v.delta; bd.dkv_part = v.dkv_part;
     bd.dq = v.d_qkv; bd.dk = at(v.d_qkv, (size_t)Hq * dh, dt); bd.dv = at(v.d_qkv, (size_t)(Hq + Hkv) * dh, dt);
     bd.lddq = bd.lddk = bd.lddv = s.QKV;
+    // the bf16 kernels write dq / dk RoPE-inverted (epilogue of the dQ kernel, GQA group reduction): no separate pass
+    const bool rope_fused = attention_bwd_fuses_rope(dt) && g_options[14];
+    if (rope_fused) bd.rope_cos_sin = w->rope_cos_sin;
     RC(attention_bwd(sx, dt, bd));
-    RC(rope_inplace(sx, dt, v.d_qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
+    if (!rope_fused) RC(rope_inplace(sx, dt, v.d_qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
     RC(gemm(sx, dt, lin(v.d_qkv, L.wqkv_t, v.d_n, Mv, D, s.QKV)));
     if (lora) {   // LoRA gradients of q_proj / k_proj and their contribution to d n1 (rank-r products, lora.hip)
       const uvx_enc_lora_layer_t& R = lora->layers[l];
@@ -1040,40 +1064,20 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     UVX_HIP(hipMemsetAsync(s.d_hn, 0, (size_t)M * D * es, st));
     RC(scatter_rows(st, dt, s.dx, s.sup, M, s.d_hn, D));
   }
-  // schedule: one chain on the caller's stream, or (option 11) two batch halves on two streams - see Fork above
-  Fork* fk = (g_options[11] >= 2 && B >= 2 && dt == DT_BF16 && !lora) ? fork_for_device() : nullptr;
-  const int nh = fk ? 2 : 1;
-  const int hb[3] = {0, fk ? (B + 1) / 2 : B, B};
-  LlmWs hv[2] = {llm_view(s, c, 0, hb[1], T), fk ? llm_view(s, c, hb[1], B - hb[1], T) : s};
-  hipStream_t hs[2] = {st, fk ? fk->side : st};
-  const bool stagger = fk && fork_staggered();
-  if (fk && !stagger) {
-    UVX_HIP(hipEventRecord(fk->e_fork, st));
-    UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
-  }
+  // schedule: one chain on the caller's stream, or (option 11) the batch slices on several streams - see Fork above
+  const Chains ch = make_chains(st, s, c, B, T, dt == DT_BF16 && !lora);
+  RC(chains_fork(ch));
   int rc_layers = UVX_OK;
   for (int l = top; l >= 0 && rc_layers == UVX_OK; --l) {
     const bool compact = tc && l == top;
-    for (int h = 0; h < nh && rc_layers == UVX_OK; ++h) {
-      const LlmWs& v = hv[h];
-      if (!compact) rc_layers = layer_mlp_bwd(hs[h], v, l, false);
-      if (l == top && h == 0 && stagger) {   // the side chain starts half a layer behind (see fork_staggered)
-        if (compact) {   // (training pair: the top layer has no per-half MLP part; offset by the first chain's attention half instead)
-          void* dx0 = l == 0 ? d_inputs_embeds : v.dx;
-          if (rc_layers == UVX_OK) rc_layers = layer_attn_bwd(hs[0], v, hb[1] - hb[0], l, true, v.d_hn, dx0);
-        }
-        UVX_HIP(hipEventRecord(fk->e_fork, st));
-        UVX_HIP(hipStreamWaitEvent(fk->side, fk->e_fork, 0));
-        if (compact) continue;
-      }
-      void* dx_out = l == 0 ? (void*)((char*)d_inputs_embeds + (size_t)hb[h] * T * D * es) : v.dx;
-      if (rc_layers == UVX_OK) rc_layers = layer_attn_bwd(hs[h], v, hb[h + 1] - hb[h], l, compact, compact ? v.d_hn : v.dx, dx_out);
+    for (int h = 0; h < ch.n && rc_layers == UVX_OK; ++h) {
+      const LlmWs& v = ch.v[h];
+      if (!compact) rc_layers = layer_mlp_bwd(ch.st[h], v, l, false);
+      void* dx_out = l == 0 ? (void*)((char*)d_inputs_embeds + (size_t)ch.b0[h] * T * D * es) : v.dx;
+      if (rc_layers == UVX_OK) rc_layers = layer_attn_bwd(ch.st[h], v, ch.b0[h + 1] - ch.b0[h], l, compact, compact ? v.d_hn : v.dx, dx_out);
     }
   }
-  if (fk) {   // join (also on an error above: the side stream must not be left forked)
-    UVX_HIP(hipEventRecord(fk->e_join, fk->side));
-    UVX_HIP(hipStreamWaitEvent(st, fk->e_join, 0));
-  }
+  RC(chains_join(ch));   // (also after an error above: the side streams must not be left forked)
   RC(rc_layers);
   if (fl == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, d_inputs_embeds, (long long)M * D, gemma_normalizer(c)));   // d (x * normalizer)
   return UVX_OK;
