@@ -356,7 +356,8 @@ int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* desc);
 /* probes/tests: force the bf16 GEMM tile variant (-1 auto, 0 = 128x128, 1..4 = {128,160,192,256} x 256) */
 int32_t uvx_gemm_force_variant(int32_t variant);
 /* probes (same-box A/B inside bench.py): key 1 = 16-byte epilogue loads/stores (default 1), key 2 = SwiGLU backward fused
- * into the down-projection dgrad GEMM (default 0: measured neutral), key 3 = LM head / CE / head dgrad on the supervised
+ * into the down-projection dgrad GEMM (0 = separate kernel, 1 = round 2's fragment-layout epilogue (measured neutral),
+ * 2 = whole-line epilogue through the LDS stage (round 3)), key 3 = LM head / CE / head dgrad on the supervised
  * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
  * problems of at most 16 rows (the decode step; default 1), key 11 = number of LLM layer chains: the batch
  * is cut into that many slices whose layer chains run on as many streams (default 2, at most 4; 0 / 1 = one chain on the
@@ -364,7 +365,10 @@ int32_t uvx_gemm_force_variant(int32_t variant);
  * forked from and joined into the caller's stream by events, so the call stays stream-ordered for the caller), key 12 = bf16
  * attention kernels read V^T / Q^T / K^T / dO^T out of the natural tiles with the transposing LDS read instead of from
  * transposed copies in global memory (default 1; 0 restores the copies: heads_transpose + the *_t staging), key 14 = the LLM's attention backward writes dq / dk
- * RoPE-inverted from its own epilogues instead of a separate pass over d_qkv (default 1; bit-identical) */
+ * RoPE-inverted from its own epilogues instead of a separate pass over d_qkv (default 1; bit-identical), key 15 = TIMING
+ * PROBE ONLY (default 0): bit mask of kernel classes that are not launched (results are garbage; what the class costs inside
+ * the overlapped schedule): 1 LLM attention backward, 2 LLM attention forward, 4 SwiGLU backward, 8 RMSNorm backward,
+ * 16 RMSNorm forward, 32 RoPE forward, 64 encoder attention, 128 encoder LayerNorm */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* Diagnostic for the stream-K GEMM launches (probe builds only - libuvx_probes.so; the production picker never selects
  * them and this returns 0): blocks that wait for another block's partial sums spin for a bounded time (~1 s) and then give

@@ -57,3 +57,20 @@ def test_gpus_n_without_torchrun_becomes_the_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_ranks_synthesise_distinct_shards():
+    """bench.py --gpus N: every rank builds its OWN shard (seeded by its rank) - a weak-scaling run whose ranks all train on
+    the same clips would still print a plausible line."""
+    import torch
+    from ultravox_amd.synthetic import synthetic_batch
+    cfg = UltravoxConfig(audio_config=dict(d_model=128, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=256),
+                         text_config=dict(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=4,
+                                          num_key_value_heads=2, vocab_size=512, eos_token_id=2), hidden_size=256)
+    shards = [synthetic_batch(cfg, 2, 1.0, n_text=16, audio_start=4, n_supervised=4, rank=r) for r in range(4)]
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert not torch.equal(shards[i]["pcm"], shards[j]["pcm"]) and not torch.equal(shards[i]["input_ids"], shards[j]["input_ids"])
+    again = synthetic_batch(cfg, 2, 1.0, n_text=16, audio_start=4, n_supervised=4, rank=2)
+    assert torch.equal(again["pcm"], shards[2]["pcm"]) and torch.equal(again["input_ids"], shards[2]["input_ids"])
+    assert all(s["input_ids"].shape == shards[0]["input_ids"].shape for s in shards)        # weak scaling: same shapes per rank

@@ -389,3 +389,26 @@ def test_fused_inverse_rope_in_the_attention_backward_is_bit_identical():
         finally:
             _lib.lib().uvx_set_option(14, 1)
         assert torch.equal(fused, separate) and fused.float().abs().max() > 0
+
+
+def test_attention_masks_with_holes_are_rejected_on_host_and_device():
+    """The device path reduces a mask row to its [first, last] key range, so a mask with holes must not get through silently:
+    host masks are checked on the spot, a device mask synchronously the first time its shape is seen, later ones through a
+    device flag read at the next synchronisation point (raise_pending_errors) - no per-step host sync."""
+    cfg, sd, model, oracle = build(4)
+    B, T = 2, 24
+    ids = torch.randint(0, 512, (B, T))
+    ok = torch.ones(B, T, dtype=torch.long); ok[0, :3] = 0; ok[1, 20:] = 0            # left and right padding: fine
+    both = torch.ones(B, T, dtype=torch.long); both[0, :3] = 0; both[0, 21:] = 0       # padding on both sides of one row: fine
+    holes = ok.clone(); holes[1, 7:9] = 0
+    model.forward(input_ids=ids.to(DEV), attention_mask=ok)                            # host mask
+    model.forward(input_ids=ids.to(DEV), attention_mask=both)
+    with pytest.raises(ValueError, match="contiguous run"):
+        model.forward(input_ids=ids.to(DEV), attention_mask=holes)
+    model.forward(input_ids=ids.to(DEV), attention_mask=ok.to(DEV))                    # device mask, first time this shape: sync check
+    model.forward(input_ids=ids.to(DEV), attention_mask=holes.to(DEV))                 # same shape again: deferred
+    with pytest.raises(ValueError, match="earlier call"):
+        model.raise_pending_errors()
+    model.raise_pending_errors()                                                       # flag consumed
+    with pytest.raises(ValueError, match="contiguous run"):                            # a NEW shape with holes: caught at once
+        model.forward(input_ids=ids[:, :20].to(DEV), attention_mask=holes[:, :20].to(DEV))

@@ -63,6 +63,7 @@ struct GemmArgs {
   int m_major;       // XCD-contiguous tile runs share an activation panel instead of a weight panel (option 7, M > N)
   int res_prefetch;  // fetch the residual rows of the wave tile up front (option 5; 0 = in-loop loads, for A/B runs)
   int swiglu;      // 1: columns alternate 16-wide gate / up blocks; also write silu(gate) * up to C2
+  int sw_stage;    // swiglu == 2: whole-line epilogue through the LDS stage (0 = the fragment-layout form)
   int wide_io;     // 16-byte epilogue loads / stores (probe switch; on by default)
   const int32_t* m_dev;  // device-side row count (nullptr: M is exact)
   int m_dev_off;         // rows of the compact list handled by earlier launches
@@ -129,6 +130,63 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
                                            int fg, long long z, char* stage = nullptr) {
   const bool bf16_out = !p.out_f32;
   const int lane = fg * 16 + frow;
+  if (NJ == 4 && stage && p.wide_io == 2 && bf16_out && p.swiglu == 2 && p.sw_stage && (p.N & 15) == 0 && (p.ldc & 7) == 0 &&
+      (p.ldc2 & 7) == 0 && ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.C2 & 15) == 0) {
+    // Fused SwiGLU BACKWARD through the LDS stage (round 3): the tile is d act = dY . W_down^T.  Pass 1 parks the bf16 d act
+    // rows in this wave's slice; pass 2 walks the matching rows of gate|up / d gate|d up - 256 contiguous bytes per wave-tile
+    // row in the interleaved layout [g0 (16 cols) | u0 | g1 | u1 | ...] - with SIXTEEN lanes per row, so every load and store
+    // instruction moves whole 128-byte lines (the fragment-layout version below moves half lines and measured neutral
+    // against the separate swiglu_bwd kernel).  A lane owns one 16-byte chunk: gate or up columns 8 h .. 8 h + 7 of block b;
+    // the other kind comes from lane ^ 2 by a cross-lane exchange; each lane then produces its own kind of gradient (the
+    // sigmoid is evaluated by both partners: VALU is idle here).  Arithmetic and rounding points of swiglu_bwd_k, bit for bit.
+    constexpr int ROWS = GI * 16;
+    static_assert(MI % GI == 0, "row fragments per pass must divide the wave tile");
+    const int c16 = lane & 15, blk = c16 >> 2, is_up = (c16 >> 1) & 1, hf = c16 & 1;
+#pragma unroll
+    for (int i0 = 0; i0 < MI; i0 += GI) {
+      if (i0 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads are done (WAR on the slice)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int ii = 0; ii < GI; ++ii) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[j][i0 + ii][e] * p.alpha;
+          *reinterpret_cast<uint2*>(stage_slot<ROWS, 8>(stage, ii * 16 + frow, 2 * j + (fg >> 1)) + (fg & 1) * 8) =
+              make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int n16 = n_base + blk * 16;                                   // first d-act column of this lane's block
+      const long long goff = (long long)(n16 >> 4) * 32 + is_up * 16 + hf * 8;   // the lane's chunk in the interleaved row
+#pragma unroll 2     // (fully unrolled, hipcc hoists every iteration's loads and spills around the 128 live accumulators)
+      for (int it = 0; it < ROWS / 4; ++it) {
+        const int row = it * 4 + (lane >> 4), m = m_base + i0 * 16 + row;
+        const uint4 dv = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 8>(stage, row, blk * 2 + hf));
+        const bool ok = m < p.M && n16 < p.N;
+        uint4 mine = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) mine = *reinterpret_cast<const uint4*>(p.C2 + (long long)m * p.ldc2 + goff);
+        uint4 other;
+        other.x = __shfl_xor(mine.x, 2, 64); other.y = __shfl_xor(mine.y, 2, 64);
+        other.z = __shfl_xor(mine.z, 2, 64); other.w = __shfl_xor(mine.w, 2, 64);
+        const uint4 gq = is_up ? other : mine, uq = is_up ? mine : other;
+        const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, gw[4] = {gq.x, gq.y, gq.z, gq.w}, uw[4] = {uq.x, uq.y, uq.z, uq.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (e & 1) ? unpack_hi(dw[e >> 1]) : unpack_lo(dw[e >> 1]);
+          const float g = (e & 1) ? unpack_hi(gw[e >> 1]) : unpack_lo(gw[e >> 1]);
+          const float u = (e & 1) ? unpack_hi(uw[e >> 1]) : unpack_lo(uw[e >> 1]);
+          const float sg = 1.0f / (1.0f + expf(-g));
+          o[e] = is_up ? d * bf2f(f2bf(g * sg)) : d * u * (sg * (1.0f + g * (1.0f - sg)));
+        }
+        if (ok)
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + goff) =
+              make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
+      }
+    }
+    return;
+  }
   if (NJ == 4 && stage && p.wide_io == 2 && bf16_out && p.swiglu != 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.sC & 7) == 0 &&
       ((uintptr_t)p.C & 15) == 0 &&
       (p.swiglu == 0 || ((p.ldc2 & 7) == 0 && ((uintptr_t)p.C2 & 15) == 0)) &&
@@ -147,19 +205,9 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
         for (int e = 0; e < 4; ++e) bv[j][e] = bf2f(b4[e]);
       }
     }
-    // Probe (option 5, default off): residual rows of the whole wave tile fetched up front, unconditionally (row / column
-    // clamped), so that their latency overlaps the staging pass.  Measured slower in situ (see g_options) - kept switchable.
-    constexpr bool PREFETCH_RES = GI == MI;
-    uint4 rres[PREFETCH_RES ? (GI * 16) / 8 : 1];
-    if (PREFETCH_RES && p.residual && p.res_prefetch) {
-      const int c8 = lane & 7, n8c = min(n_base + c8 * 8, p.N - 8);
-#pragma unroll
-      for (int it = 0; it < (GI * 16) / 8; ++it) {
-        const int m = min(m_base + it * 8 + (lane >> 3), p.M - 1);
-        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
-        rres[it] = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8c);
-      }
-    }
+    // (round 2's option 5 - the residual rows of the whole wave tile prefetched into a register array ahead of the staging
+    // pass - measured slower in situ and was removed in round 3: its dynamically indexed array also gave every kernel of the
+    // family a private (scratch) segment, used or not)
 #pragma unroll
     for (int i0 = 0; i0 < MI; i0 += GI) {
       if (i0 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads are done (WAR on the slice)
@@ -189,7 +237,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
           if (m < p.M && n8 < p.N) {
             if (p.residual) {
               const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
-              const uint4 r = (PREFETCH_RES && p.res_prefetch) ? rres[it] : *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
+              const uint4 r = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
               o.x = pack2(unpack_lo(o.x) + unpack_lo(r.x), unpack_hi(o.x) + unpack_hi(r.x));
               o.y = pack2(unpack_lo(o.y) + unpack_lo(r.y), unpack_hi(o.y) + unpack_hi(r.y));
               o.z = pack2(unpack_lo(o.z) + unpack_lo(r.z), unpack_hi(o.z) + unpack_hi(r.z));
@@ -1339,6 +1387,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.C2 = (bf16_t*)d.C2; a.ldc2 = d.ldc2; a.swiglu = d.swiglu;
   a.wide_io = uvx::g_options[1];
   a.res_prefetch = uvx::g_options[5];
+  a.sw_stage = uvx::g_options[2] != 1;     // SwiGLU-backward epilogue through the LDS stage (option 2 = 1: the round-2 fragment-layout form)
   a.m_major = uvx::g_options[7] && d.M > d.N && (d.batch <= 1);
   a.m_dev = d.m_dev; a.m_dev_off = d.m_dev_off;
   a.sk_full = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0;

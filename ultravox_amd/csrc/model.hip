@@ -257,6 +257,12 @@ LlmLayerStash llm_layer(const LlmWs& w, int slot) {
   return s;
 }
 
+// Timing probe (tuning option 15, default 0): bit mask of kernel classes NOT launched - the step's results are then garbage, its
+// time says what that class costs inside the overlapped schedule (bench.py --opt 15=<mask>; never set by the product).
+// 1 LLM attention backward, 2 LLM attention forward, 4 SwiGLU backward, 8 RMSNorm backward, 16 RMSNorm forward, 32 RoPE forward,
+// 64 encoder attention, 128 encoder LayerNorm
+inline bool probe_skip(int bit) { return (g_options[15] & bit) != 0; }
+
 // Batch slice [b0, b0 + nb) of the carved LLM workspace: every buffer is batch-major at the top level ([B*T, ld] rows or
 // [B, ...]), so a slice is the same record with its pointers advanced.  Used by the two-stream schedule below.
 LlmWs llm_view(const LlmWs& w, const uvx_config_t& c, int b0, int nb, int T) {
@@ -433,7 +439,7 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     void* o = train ? S.o : s.o;
     void* x_mid = train ? S.x_mid : x;            // inference: the residual stream is updated in place
     void* x_out = !train ? x : (l + 1 < c.enc_layers ? enc_layer(s, l + 1).x_in : s.x);
-    RC(layernorm_fwd(st, dt, x, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));
+    if (!probe_skip(128)) RC(layernorm_fwd(st, dt, x, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));
     {
       GemmDesc g = lin(s.n, L.wqkv, qkv, M, 3 * d, d);
       g.bias = L.bqkv;
@@ -458,13 +464,13 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     ad.kv_len = kvlen; ad.B = B; ad.T = Te; ad.Tp = s.Tp; ad.Hq = c.enc_heads; ad.Hkv = c.enc_heads; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = 3 * d; ad.ldo = d; ad.causal = 0; ad.block = c.enc_block;
     ad.scale = 1.0f;  // q_proj is pre-scaled by head_dim^-0.5 at pack time (exact in bf16 for dh = 64)
-    RC(attention_fwd(st, dt, ad));
+    if (!probe_skip(64)) RC(attention_fwd(st, dt, ad));
     {
       GemmDesc g = lin(o, L.wo, x_mid, M, d, d);
       g.bias = L.bo; g.residual = x; g.ldr = d;
       RC(gemm(st, dt, g));
     }
-    RC(layernorm_fwd(st, dt, x_mid, L.ln2_w, L.ln2_b, s.n, M, d, c.ln_eps));
+    if (!probe_skip(128)) RC(layernorm_fwd(st, dt, x_mid, L.ln2_w, L.ln2_b, s.n, M, d, c.ln_eps));
     if (train) {   // keep the fc1 pre-activation for the GELU backward
       GemmDesc g = lin(s.n, L.fc1_w, S.pre, M, c.enc_ffn, d);
       g.bias = L.fc1_b;
@@ -759,7 +765,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     const uvx_llm_layer_t& L = w->layers[l];
     LlmLayerStash cur = llm_layer(v, slot_of(l));
     const int Mv = v.M;
-    RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, v.n, nullptr, Mv, D, c.rms_eps, fl));
+    if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, v.n, nullptr, Mv, D, c.rms_eps, fl));
     RC(gemm(sx, dt, lin(v.n, L.wqkv, cur.qkv, Mv, s.QKV, D)));
     if (lora) {   // peft LoRA on q_proj / k_proj (text_model_lora_config): added to the projections, before RoPE
       const uvx_enc_lora_layer_t& R = lora->layers[l];
@@ -771,7 +777,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       RC(lora_up(sx, dt, cur.t, 128, cur.bqT, 1, cur.qkv, s.QKV, Mv, qc, r, lora->scaling, 1));
       RC(lora_up(sx, dt, at(cur.t, 64, dt), 128, cur.bkT, 1, at(cur.qkv, (size_t)qc, dt), s.QKV, Mv, kc, r, lora->scaling, 1));
     }
-    RC(rope_inplace(sx, dt, cur.qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 0));
+    if (!probe_skip(32)) RC(rope_inplace(sx, dt, cur.qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 0));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt), v.vt, Bv, T, s.Tp, Hkv, dh, s.QKV));
     AttnDesc ad;
     ad.q = cur.qkv; ad.k = at(cur.qkv, (size_t)Hq * dh, dt); ad.v = at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt);
@@ -779,7 +785,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     ad.B = Bv; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
     ad.scale = 1.0f / sqrtf((float)dh);
-    return attention_fwd(sx, dt, ad);
+    return probe_skip(2) ? UVX_OK : attention_fwd(sx, dt, ad);
   };
   // second half: o_proj + residual, norm, gate|up (+ SwiGLU), down + residual.  compact (last layer of the training pair,
   // whole batch only): on the supervised rows gathered into the idle backward scratch.
@@ -800,7 +806,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       g.residual = compact ? v.dx : cur.x_in; g.ldr = D; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
-    RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, v.n, nullptr, Mv, D, c.rms_eps, fl));
+    if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, v.n, nullptr, Mv, D, c.rms_eps, fl));
     {  // gate|up projection; wgu rows are packed as alternating 16-row gate / up blocks (weights.py)
       GemmDesc g = lin(v.n, L.wgu, cur.gu, Mv, 2 * c.llm_inter, D);
       const bool fused = dt == DT_BF16 && fl == UVX_LLM_LLAMA;   // SwiGLU fused into the epilogue (GeGLU: separate kernel)
@@ -995,14 +1001,14 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       GemmDesc g = lin(v.dx, L.wd_t, v.d_act, Mv, c.llm_inter, D);
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
-      RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
+      if (!probe_skip(4)) RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
     }
     {
       GemmDesc g = lin(v.d_gu, L.wgu_t, v.d_n, Mv, D, 2 * c.llm_inter);
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
-    return rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl);
+    return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl);
   };
   // attention half: v.dx (gradient of x_mid) -> dx_out (gradient of the layer's input).  d_o_ready: v.d_o and the residual
   // gradient `resid` were already produced for the whole batch (compact last layer), else d_o = dx . W_o^T here.
@@ -1028,7 +1034,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     // the bf16 kernels write dq / dk RoPE-inverted (epilogue of the dQ kernel, GQA group reduction): no separate pass
     const bool rope_fused = attention_bwd_fuses_rope(dt) && g_options[14];
     if (rope_fused) bd.rope_cos_sin = w->rope_cos_sin;
-    RC(attention_bwd(sx, dt, bd));
+    if (!probe_skip(1)) RC(attention_bwd(sx, dt, bd));
     if (!rope_fused) RC(rope_inplace(sx, dt, v.d_qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
     RC(gemm(sx, dt, lin(v.d_qkv, L.wqkv_t, v.d_n, Mv, D, s.QKV)));
     if (lora) {   // LoRA gradients of q_proj / k_proj and their contribution to d n1 (rank-r products, lora.hip)
@@ -1046,7 +1052,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       RC(lora_up(sx, dt, v.lu, 128, R.q.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
       RC(lora_up(sx, dt, at(v.lu, 64, dt), 128, R.k.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
     }
-    return rmsnorm_bwd(sx, dt, v.d_n, cur.x_in, L.ln1, resid, dx_out, nullptr, Mv, D, c.rms_eps, fl);
+    return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_in, L.ln1, resid, dx_out, nullptr, Mv, D, c.rms_eps, fl);
   };
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];

@@ -642,17 +642,14 @@ class UltravoxModel:
                 **kwargs) -> CausalLMOutputWithPast:
         """UltravoxModel.forward (ultravox_model.py:277-352).  `attention_mask` rows must keep ONE contiguous run of positions
         (right or left padding, what DataCollatorForSeq2SeqWithAudio produces): the device path turns each row into a
-        [start, end) key range, so a mask with holes would be honoured only at its outer edges.  A CPU mask is checked here
-        (a device mask is not: the check would cost a host synchronisation per step)."""
+        [start, end) key range, so a mask with holes would be honoured only at its outer edges.  A CPU mask is checked here;
+        a device mask is checked synchronously the first time its shape is seen and asynchronously afterwards (`_check_mask`)."""
         if past_key_values is not None:
             return self._forward_with_cache(past_key_values, input_ids, inputs_embeds, audio_values, audio_token_start_idx,
                                             audio_lens, audio_token_len, audio_batch_size, labels, attention_mask,
                                             kwargs.get("logits_to_keep", kwargs.get("num_logits_to_keep", 0)))
-        if attention_mask is not None and not attention_mask.is_cuda:
-            m = attention_mask != 0
-            if bool(((m[:, 1:] != m[:, :-1]).sum(-1) > 2).any()) or bool(((m[:, 1:] != m[:, :-1]).sum(-1) == 2).__and__(m[:, 0]).any()):
-                raise ValueError("attention_mask rows must keep one contiguous run of positions (padding on one side or both), "
-                                 "masks with holes are not supported")
+        if attention_mask is not None:
+            self._check_mask(attention_mask)
         use_kl = False
         if self.training and self.loss_config.loss_function != LossFunction.CrossEntropy:
             if self.loss_config.loss_function != LossFunction.KL_Divergence:
@@ -671,6 +668,41 @@ class UltravoxModel:
                                 return_logits)
 
     __call__ = forward
+
+    _MASK_MSG = ("attention_mask rows must keep one contiguous run of positions (padding on one side or both), "
+                 "masks with holes are not supported")
+
+    @staticmethod
+    def _mask_has_holes(mask: torch.Tensor) -> torch.Tensor:
+        m = mask != 0
+        flips = (m[:, 1:] != m[:, :-1]).sum(-1)
+        return ((flips > 2) | ((flips == 2) & m[:, 0])).any()
+
+    def _check_mask(self, mask: torch.Tensor) -> None:
+        """Host masks: checked on the spot.  Device masks: a host synchronisation per step would serialise the pipeline, so the
+        verdict is read synchronously only the FIRST time a mask shape is seen; later masks of that shape fold theirs into a
+        device flag that is read at the next natural synchronisation point (`raise_pending_errors`, called by
+        `UltravoxTrainer.flush / grad_norm / save_checkpoint` and by the next first-time shape)."""
+        bad = self._mask_has_holes(mask)
+        if not mask.is_cuda:
+            if bool(bad):
+                raise ValueError(self._MASK_MSG)
+            return
+        seen = self.__dict__.setdefault("_mask_shapes_seen", set())
+        if tuple(mask.shape) not in seen:
+            seen.add(tuple(mask.shape))
+            self.raise_pending_errors()
+            if bool(bad):
+                raise ValueError(self._MASK_MSG)
+            return
+        flag = self.__dict__.get("_mask_err")
+        self._mask_err = bad if flag is None else torch.logical_or(flag, bad)
+
+    def raise_pending_errors(self) -> None:
+        """Reads (synchronously) the device-side verdict of the attention masks checked asynchronously since the last call."""
+        flag = self.__dict__.pop("_mask_err", None)
+        if flag is not None and bool(flag):
+            raise ValueError(self._MASK_MSG + " (detected on a device mask of an earlier call)")
 
     def _forward_with_cache(self, past, input_ids, inputs_embeds, audio_values, audio_token_start_idx, audio_lens, audio_token_len,
                             audio_batch_size, labels, attention_mask, logits_to_keep) -> CausalLMOutputWithPast:
@@ -1028,6 +1060,7 @@ class UltravoxTrainer:
         """checkpoint-N/ of the HF Trainer: the model's diff state dict + optimizer moments + step."""
         from . import checkpoint
         self.flush()
+        self.model.raise_pending_errors()
         self.model.save_pretrained(directory)
         checkpoint.save_trainer_state(directory, self.step_count,
                                       {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "master": self.master},
@@ -1074,6 +1107,7 @@ class UltravoxTrainer:
 
     def grad_norm(self) -> torch.Tensor:
         self.flush()
+        self.model.raise_pending_errors()
         return self.scratch[0].sqrt()
 
     def train_step(self, **batch) -> torch.Tensor:
