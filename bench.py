@@ -274,6 +274,8 @@ def main():
     ap.add_argument("--opt", default=None, help="probe: 'key=value,...' for uvx_set_option")
     ap.add_argument("--gemm-override", default=None, help="probe: 'MxNxK=variant,...' tile-variant overrides")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table (from the HIP events) here")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="keep the library's default LLM schedule instead of letting the trainer pick the chain count during the warm-up")
     ap.add_argument("--probe-skip", type=int, default=0,
                     help="TIMING PROBE: uvx_set_option(15, mask) after the warm-up - the masked kernel classes are not launched in the "
                          "timed steps (garbage results; the line is marked invalid): what a class costs inside the overlapped schedule")
@@ -372,6 +374,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # the warm-up steps double as the schedule tuner's trial steps (1 throw-away + 2 per candidate when there are >= 5; with fewer
+    # the tuner simply finishes during the first timed steps - it only reads event timers)
+    tune = not args.no_autotune and _opt_get(args.opt, 11, -1) < 0 and B >= 2 and not args.audio_lora_r
+    if tune:
+        trainer.autotune_schedule()
     for _ in range(args.warmup):
         loss = step()
     trainer.flush()
@@ -444,7 +451,10 @@ def main():
                                               {"max": max(exposed_ms), "all": [round(x, 4) for x in exposed_ms],
                                                "note": "time the compute stream waited for the deferred all-reduce" if trainer.overlap_comm
                                                        else "sequential schedule: the collective is on the compute stream, not timed separately"}),
-            "llm_streams": max(1, min(B, 4, _opt_get(args.opt, 11, 2))),
+            "llm_streams": (trainer.schedule_chains if tune and getattr(trainer, "schedule_chains", None)
+                            else max(1, min(B, 4, _opt_get(args.opt, 11, 2)))),
+            "llm_streams_autotuned_ms": ({str(k): round(v, 3) for k, v in trainer.schedule_timings.items()}
+                                         if tune and getattr(trainer, "schedule_chains", None) else None),
             "collective": (None if world == 1 else "gloo (shared-GPU test mode)" if share_gpu
                            else "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + (" via uvx_comm_* (C ABI)" if comm else " via torch.distributed")
                                 + " all-reduce(sum) of one flat f32 bucket, "

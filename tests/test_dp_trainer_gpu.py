@@ -150,3 +150,33 @@ def test_uvx_comm_one_rank_rccl_group_and_trainer_route():
         results.append(trainer.master.clone())
     assert torch.equal(results[0], results[1]) and torch.equal(results[0], results[2])
     comm.close()
+
+
+def test_schedule_autotuner_picks_a_chain_count_and_changes_no_result():
+    """UltravoxTrainer.autotune_schedule(): the first steps alternate between the candidate LLM chain counts (timed with events)
+    and the faster one stays set; every candidate computes bit-identical results, so a tuned run equals an untuned one."""
+    import torch
+    from test_model_gpu import build, batch_for
+    from ultravox_amd import _lib
+    from ultravox_amd.model import UltravoxTrainer
+
+    def run(tuned):
+        cfg, sd, model, oracle = build(21)
+        tr = UltravoxTrainer(model, lr=1e-3)
+        if tuned:
+            tr.autotune_schedule(candidates=(2, 1), rounds=2)
+        b = {k: v.to("cuda") for k, v in batch_for(cfg, B=4, seconds=2.0).items()}
+        losses = [tr.train_step(**b).item() for _ in range(7)]
+        tr.flush()
+        return tr, losses, model.projector_state_dict()
+
+    try:
+        tr, losses, params = run(True)
+        assert tr.schedule_chains in (1, 2) and set(tr.schedule_timings) == {1, 2} and tr._tune is None
+        _lib.lib().uvx_set_option(11, 2)
+        _, losses0, params0 = run(False)
+    finally:
+        _lib.lib().uvx_set_option(11, 2)
+    assert losses == losses0
+    for k in params:
+        assert torch.equal(params[k], params0[k]), k

@@ -1055,6 +1055,13 @@ class UltravoxTrainer:
         # all-reduce in flush() (the exposed part of the collective), from event pairs around the wait
         self.measure_comm = False
         self._comm_waits = []
+        # Schedule auto-tuning (autotune_schedule()): the number of LLM layer chains (uvx_set_option 11) that is faster depends
+        # on the box (one chain won by 3 ms per step on one MI355X, two chains by 0.7-3.6 ms on others - profiles/r03_*):
+        # the first steps try the candidates in turn, timed with events, and the trainer keeps the faster one.  Results are
+        # bit-identical under every candidate, so tuning never changes what is trained.
+        self._tune = None
+        self.schedule_chains = None           # the tuner's verdict (None: not tuned - the library default applies)
+        self.schedule_timings = {}
 
     def save_checkpoint(self, directory: str) -> None:
         """checkpoint-N/ of the HF Trainer: the model's diff state dict + optimizer moments + step."""
@@ -1110,7 +1117,53 @@ class UltravoxTrainer:
         self.model.raise_pending_errors()
         return self.scratch[0].sqrt()
 
+    def autotune_schedule(self, candidates=(2, 1), rounds: int = 2) -> None:
+        """Arms the tuner: the next 1 + rounds * len(candidates) calls of train_step (one throw-away step first) alternate
+        between the candidate chain counts; afterwards the fastest (by its best step) stays set.  `self.schedule_chains` holds
+        the verdict (None while tuning)."""
+        self._tune = {"plan": [None] + [c for _ in range(rounds) for c in candidates], "i": 0, "t": {}, "pending": None}
+        self.schedule_chains = None
+
+    def _tune_begin(self) -> None:
+        tn = self._tune
+        if tn["pending"] is not None:            # the previous tuned step: read its time (it has finished long ago, or we wait)
+            cand, e0, e1 = tn["pending"]
+            e1.synchronize()
+            if cand is not None:
+                tn["t"].setdefault(cand, []).append(e0.elapsed_time(e1))
+            tn["pending"] = None
+        if tn["i"] >= len(tn["plan"]):
+            best = min(tn["t"], key=lambda c: min(tn["t"][c]))
+            _lib.lib().uvx_set_option(11, int(best))
+            self.schedule_chains, self.schedule_timings, self._tune = int(best), {c: min(v) for c, v in tn["t"].items()}, None
+            return
+        cand = tn["plan"][tn["i"]]
+        tn["i"] += 1
+        if cand is not None:
+            _lib.lib().uvx_set_option(11, int(cand))
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tn["pending"] = (cand, e0, None)
+
+    def _tune_end(self) -> None:
+        tn = self._tune
+        if tn is not None and tn["pending"] is not None and tn["pending"][2] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            tn["pending"] = (tn["pending"][0], tn["pending"][1], e1)
+
     def train_step(self, **batch) -> torch.Tensor:
+        if self._tune is not None:
+            self.flush()
+            self._tune_begin()
+        try:
+            return self._train_step(**batch)
+        finally:
+            if self._tune is not None:
+                self.flush()                     # a tuned step includes its own (otherwise deferred) exchange + update
+                self._tune_end()
+
+    def _train_step(self, **batch) -> torch.Tensor:
         """One optimizer step.  With `overlap_comm` (and more than one rank) the gradient all-reduce is launched
         asynchronously after the backward pass and waited for - together with clip + AdamW - only when the NEXT step
         reaches the projector: the next step's log-mel and frozen-encoder forward, which do not read the trainable
