@@ -382,20 +382,21 @@ def test_logmel_matches_hf_fixture(golden_dir, n_mels):
     want = z[f"mel_{n_mels}"]
     assert got.shape == want.shape
     # dense f32 DFT (a fixed-order fmaf chain on the f32 matrix cores) vs HF's FFT: a numpy emulation of the same chain agrees
-    # with the fixture to 1e-5 on every clip, the tonal one included; the device is held to 1e-3 / 2e-4 and the measured
-    # numbers are recorded (gpurun_out/parity/logmel_fixture_errors_*.json)
+    # with the fixture to 1e-5 on every clip, the tonal one included, and so does the device (measured on MI355X, round 3:
+    # 2.5e-6 / 1.7e-6 on the noise clips, 1.3e-5 on the tonal clip at 80 mels; 4.4e-6 / 2.6e-6 / 2.2e-5 at 128 -
+    # profiles/r03_parity/logmel_fixture_errors_*.json).  Round 2's 5e-3 bound on the tonal clip was slack, not error.
     from parity_util import record
     errs = [float(np.abs(got[i] - want[i]).max()) for i in range(3)]
     record(f"logmel_fixture_errors_{n_mels}", {"max_abs_noise": errs[0], "max_abs_quiet_noise": errs[1], "max_abs_tonal": errs[2]})
-    assert max(errs[:2]) < 2e-4
-    assert errs[2] < 1e-3, errs
+    assert max(errs[:2]) < 5e-5
+    assert errs[2] < 1e-4, errs
     assert out["attention_mask"].sum(-1).tolist() == [200, 200, 200]
 
 
 @pytest.mark.parametrize("n_mels", [80, 128])
 def test_logmel_speech_like_audio_within_1e3(golden_dir, n_mels):
     """The clip class speech belongs to: 30 s of harmonics with pauses (62 % of the bins at the per-clip floor, the rest spread
-    over 8 decades) against the installed HF extractor (tests/golden/logmel_speech.npz) - 1e-3 absolute on every bin."""
+    over 8 decades) against the installed HF extractor (tests/golden/logmel_speech.npz) - 2e-4 absolute on every bin (north_star asks 1e-3)."""
     import os
     import forward_fixture_util as U
     from parity_util import record
@@ -408,7 +409,7 @@ def test_logmel_speech_like_audio_within_1e3(golden_dir, n_mels):
     record(f"logmel_speech_errors_{n_mels}", {"max_abs": float(d.max()), "mean_abs": float(d.mean()),
                                               "frac_above_1e-4": float((d > 1e-4).mean()), "floor_frac": float((want == want.min()).mean())})
     assert got.shape == (n_mels, 3000)
-    assert d.max() < 1e-3, float(d.max())
+    assert d.max() < 2e-4, float(d.max())            # measured 2.1e-5 (80 mels) / 3.7e-5 (128 mels)
 
 
 def test_logmel_full_size_properties():
