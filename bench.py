@@ -376,9 +376,9 @@ def main():
 
     # the warm-up steps double as the schedule tuner's trial steps (1 throw-away + 2 per candidate when there are >= 5; with fewer
     # the tuner simply finishes during the first timed steps - it only reads event timers)
-    tune = not args.no_autotune and _opt_get(args.opt, 11, -1) < 0 and B >= 2 and not args.audio_lora_r
+    tune = not args.no_autotune and _opt_get(args.opt, 11, -1) < 0 and _opt_get(args.opt, 13, -1) < 0 and B >= 2 and not args.audio_lora_r
     if tune:
-        trainer.autotune_schedule()
+        trainer.autotune_schedule(rounds=2 if args.warmup >= 5 else 1)
     for _ in range(args.warmup):
         loss = step()
     trainer.flush()
@@ -451,10 +451,11 @@ def main():
                                               {"max": max(exposed_ms), "all": [round(x, 4) for x in exposed_ms],
                                                "note": "time the compute stream waited for the deferred all-reduce" if trainer.overlap_comm
                                                        else "sequential schedule: the collective is on the compute stream, not timed separately"}),
-            "llm_streams": (trainer.schedule_chains if tune and getattr(trainer, "schedule_chains", None)
-                            else max(1, min(B, 4, _opt_get(args.opt, 11, 2)))),
-            "llm_streams_autotuned_ms": ({str(k): round(v, 3) for k, v in trainer.schedule_timings.items()}
-                                         if tune and getattr(trainer, "schedule_chains", None) else None),
+            "llm_schedule": ({"chosen": {str(k): v for k, v in trainer.llm_schedule.items()}, "trial_ms": {k: round(v, 3) for k, v in trainer.schedule_timings.items()},
+                              "note": "uvx_set_option keys: 11 = LLM layer chains (streams), 13 = fused attention backward; picked "
+                                      "from timed warm-up steps, results are bit-identical within a chain count"}
+                             if tune and trainer.llm_schedule else
+                             {"chosen": {"11": _opt_get(args.opt, 11, 1), "13": _opt_get(args.opt, 13, 1)}, "trial_ms": None}),
             "collective": (None if world == 1 else "gloo (shared-GPU test mode)" if share_gpu
                            else "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + (" via uvx_comm_* (C ABI)" if comm else " via torch.distributed")
                                 + " all-reduce(sum) of one flat f32 bucket, "

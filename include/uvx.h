@@ -360,11 +360,12 @@ int32_t uvx_gemm_force_variant(int32_t variant);
  * 2 = whole-line epilogue through the LDS stage (round 3)), key 3 = LM head / CE / head dgrad on the supervised
  * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
  * problems of at most 16 rows (the decode step; default 1), key 11 = number of LLM layer chains: the batch
- * is cut into that many slices whose layer chains run on as many streams (default 2, at most 4; 0 / 1 = one chain on the
- * caller's stream; uvx_llm_fwd* / uvx_llm_bwd*: same kernels on the same rows, bit-identical results; the side streams are
+ * is cut into that many slices whose layer chains run on as many streams (default 1 = one chain on the caller's stream, at most 4; which of 1 / 2 is
+ * faster depends on the box: UltravoxTrainer.autotune_schedule times both; uvx_llm_fwd* / uvx_llm_bwd*: same kernels on the same rows, bit-identical results; the side streams are
  * forked from and joined into the caller's stream by events, so the call stays stream-ordered for the caller), key 12 = bf16
  * attention kernels read V^T / Q^T / K^T / dO^T out of the natural tiles with the transposing LDS read instead of from
- * transposed copies in global memory (default 1; 0 restores the copies: heads_transpose + the *_t staging), key 14 = the LLM's attention backward writes dq / dk
+ * transposed copies in global memory (default 1; 0 restores the copies: heads_transpose + the *_t staging), key 13 = the fused attention backward
+ * kernel for head_dim 128 / causal / at most 320 positions (default 1; 0 = the dQ + dK/dV kernel pair), key 14 = the LLM's attention backward writes dq / dk
  * RoPE-inverted from its own epilogues instead of a separate pass over d_qkv (default 1; bit-identical), key 15 = TIMING
  * PROBE ONLY (default 0): bit mask of kernel classes that are not launched (results are garbage; what the class costs inside
  * the overlapped schedule): 1 LLM attention backward, 2 LLM attention forward, 4 SwiGLU backward, 8 RMSNorm backward,

@@ -152,9 +152,11 @@ def test_uvx_comm_one_rank_rccl_group_and_trainer_route():
     comm.close()
 
 
-def test_schedule_autotuner_picks_a_chain_count_and_changes_no_result():
-    """UltravoxTrainer.autotune_schedule(): the first steps alternate between the candidate LLM chain counts (timed with events)
-    and the faster one stays set; every candidate computes bit-identical results, so a tuned run equals an untuned one."""
+def test_schedule_autotuner_picks_a_schedule_and_changes_no_result():
+    """UltravoxTrainer.autotune_schedule(): the first steps alternate between candidate schedules (uvx_set_option dicts: LLM
+    chain count, here) timed with events, and the faster one stays set; chain counts compute bit-identical results, so a tuned
+    run equals an untuned one.  (The default candidates also switch the attention-backward kernel, whose two forms agree to
+    rounding only - they are exercised by bench.py.)"""
     import torch
     from test_model_gpu import build, batch_for
     from ultravox_amd import _lib
@@ -164,7 +166,7 @@ def test_schedule_autotuner_picks_a_chain_count_and_changes_no_result():
         cfg, sd, model, oracle = build(21)
         tr = UltravoxTrainer(model, lr=1e-3)
         if tuned:
-            tr.autotune_schedule(candidates=(2, 1), rounds=2)
+            tr.autotune_schedule(candidates=[{11: 2}, {11: 1}], rounds=2)
         b = {k: v.to("cuda") for k, v in batch_for(cfg, B=4, seconds=2.0).items()}
         losses = [tr.train_step(**b).item() for _ in range(7)]
         tr.flush()
@@ -172,11 +174,12 @@ def test_schedule_autotuner_picks_a_chain_count_and_changes_no_result():
 
     try:
         tr, losses, params = run(True)
-        assert tr.schedule_chains in (1, 2) and set(tr.schedule_timings) == {1, 2} and tr._tune is None
-        _lib.lib().uvx_set_option(11, 2)
+        assert tr.llm_schedule in ({11: 1}, {11: 2}) and len(tr.schedule_timings) == 2 and tr._tune is None
+        assert tr.schedule_chains == tr.llm_schedule[11]
+        _lib.lib().uvx_set_option(11, 1)
         _, losses0, params0 = run(False)
     finally:
-        _lib.lib().uvx_set_option(11, 2)
+        _lib.lib().uvx_set_option(11, 1)
     assert losses == losses0
     for k in params:
         assert torch.equal(params[k], params0[k]), k

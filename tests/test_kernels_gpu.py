@@ -537,11 +537,55 @@ def test_attention_transposing_lds_reads_equal_the_transposed_copies(D, Hq, Hkv,
         o, lse = ops().attention(q, k, v, causal=causal, block=block, kv_len=kv_len)
         return (o, lse) + tuple(ops().attention_bwd(q, k, v, o, lse, do, causal=causal, block=block, kv_len=kv_len))
 
-    new = run()
-    _lib.lib().uvx_set_option(12, 0)
+    _lib.lib().uvx_set_option(13, 0)          # the kernel PAIR on both sides (the fused backward sums in another order)
     try:
-        old = run()
+        new = run()
+        _lib.lib().uvx_set_option(12, 0)
+        try:
+            old = run()
+        finally:
+            _lib.lib().uvx_set_option(12, 1)
     finally:
-        _lib.lib().uvx_set_option(12, 1)
+        _lib.lib().uvx_set_option(13, 1)
     for a, b in zip(new, old):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("T,Hq,Hkv,pad", [(316, 8, 2, False), (320, 4, 4, False), (17, 4, 1, False), (129, 4, 2, True), (300, 2, 2, True), (64, 2, 1, True)])
+def test_fused_attention_backward_matches_reference_and_the_kernel_pair(T, Hq, Hkv, pad):
+    """attn_bwd_fused_k (head_dim 128, causal, T <= 320: one block per (batch, query head), S / dP once, dS through LDS) against
+    the f32 reference and against the dQ + dK/dV kernel pair it replaces (option 13 = 0): same per-element arithmetic, another
+    summation order - agreement to bf16 rounding of the outputs; left / right padding; zero gradient for padded keys;
+    repeated launches bit-identical."""
+    from ultravox_amd import _lib
+    torch.manual_seed(23)
+    B, D = 3, 128
+    q = bf(torch.randn(B, T, Hq, D, device=DEV)); k = bf(torch.randn(B, T, Hkv, D, device=DEV)); v = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    do = bf(torch.randn(B, T, Hq * D, device=DEV))
+    kv_start = kv_len = None
+    if pad:
+        kv_start = torch.tensor([0, min(23, T // 3), 0], device=DEV, dtype=torch.int32)
+        kv_len = torch.tensor([T, T, T - min(41, T // 2)], device=DEV, dtype=torch.int32)
+    o, lse = ops().attention(q, k, v, causal=True, kv_start=kv_start, kv_len=kv_len)
+    fused = ops().attention_bwd(q, k, v, o, lse, do, causal=True, kv_start=kv_start, kv_len=kv_len)
+    again = ops().attention_bwd(q, k, v, o, lse, do, causal=True, kv_start=kv_start, kv_len=kv_len)
+    assert all(torch.equal(a, b) for a, b in zip(fused, again))
+    _lib.lib().uvx_set_option(13, 0)
+    try:
+        pair = ops().attention_bwd(q, k, v, o, lse, do, causal=True, kv_start=kv_start, kv_len=kv_len)
+    finally:
+        _lib.lib().uvx_set_option(13, 1)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref, ok = sdpa_ref(qr, kr, vr, True, 0, D ** -0.5, kv_start=kv_start, kv_len=kv_len)
+    valid = ok.any(-1)[:, 0]
+    ref.backward(do.float() * valid[:, :, None].expand(B, T, Hq * D))
+    for name, got, old, want in zip(("dq", "dk", "dv"), fused, pair, (qr.grad, kr.grad, vr.grad)):
+        if name == "dq":
+            got, old = got.float() * valid[:, :, None, None], old.float() * valid[:, :, None, None]
+        assert rel_l2(got, want) < 2e-2, name
+        assert rel_l2(got, old) < 6e-3, name                     # two bf16 roundings of the same sums apart
+        assert rel_l2(got, want) < 1.1 * rel_l2(old, want) + 1e-4, name
+    if pad:
+        s1, e2 = int(kv_start[1]), int(kv_len[2])
+        assert fused[1][1, :s1].abs().max().item() == 0 and fused[2][1, :s1].abs().max().item() == 0
+        assert fused[1][2, e2:].abs().max().item() == 0 and fused[2][2, e2:].abs().max().item() == 0

@@ -319,7 +319,7 @@ def test_loss_head_on_supervised_rows_split_k(T, first_label):
 
 @pytest.mark.parametrize("B,T", [(2, 48), (5, 70), (8, 316)])
 def test_two_stream_llm_schedule_is_bit_identical(B, T):
-    """uvx_set_option(11, 2) (the default): the LLM layer chains of the batch slices run on several streams (the caller's and side streams
+    """uvx_set_option(11, n): the LLM layer chains of the batch slices run on several streams (the caller's and side streams
     forked from / joined into it by events; option value = number of chains).  Same kernels on the same rows: loss, full logits and d loss / d inputs_embeds must be
     BIT-identical to the one-stream schedule - for the plain pair (full logits), the training pair (last layer and head on the
     supervised rows), an odd batch (halves of 3 and 2) and with left / right padding in the attention mask."""
@@ -342,20 +342,19 @@ def test_two_stream_llm_schedule_is_bit_identical(B, T):
         torch.cuda.synchronize()
         return full.logits.clone(), full.loss.clone(), d_full, tr.loss.clone(), d_tr
 
-    _lib.lib().uvx_set_option(11, 0)
+    L = _lib.lib()
     try:
+        L.uvx_set_option(11, 1)
         one = run()
-    finally:
-        _lib.lib().uvx_set_option(11, 2)       # the default
-    two = run()
-    two_again = run()
-    more = []
-    for n in (3, 4):                           # three / four chains (B = 2: capped at two; B = 5: slices of 2, 1, 1, 1)
-        _lib.lib().uvx_set_option(11, n)
-        try:
+        L.uvx_set_option(11, 2)
+        two = run()
+        two_again = run()
+        more = []
+        for n in (3, 4):                           # three / four chains (B = 2: capped at two; B = 5: slices of 2, 1, 1, 1)
+            L.uvx_set_option(11, n)
             more.append(run())
-        finally:
-            _lib.lib().uvx_set_option(11, 2)
+    finally:
+        L.uvx_set_option(11, 1)                    # the default
     for i, a in enumerate(one):
         for other in (two, two_again, *more):
             assert torch.equal(a, other[i])

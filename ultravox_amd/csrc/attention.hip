@@ -787,6 +787,251 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   }
 }
 
+// =================================== backward, fused (short causal sequences) ===================================
+// One block = ONE (batch, query head): the whole S = Q K^T triangle of a sequence of at most TMAX positions is worked off on one
+// CU, so S and dP are computed ONCE (5 matrix products instead of the 7 of the dQ + dK/dV kernel pair), and the pair's second
+// launch, its second staging stream and the `delta` round trip through global memory disappear.
+//   prologue  delta[q] = rowsum(dO * O) and the saved log-sum-exp into LDS.
+//   phase 1   waves own 16-key tiles (K / V fragments in registers, dK^T / dV^T accumulators in registers); the Q / dO rows arrive
+//             in 64-query chunks (natural layout, staged once per pass for all eight waves).  Per (32 queries x 16 keys):
+//             S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS (transposed operands by ds_read_b64_tr_b16) - and dS goes, as
+//             bf16, into a triangular LDS array of 16 x 16 tiles [q][key] (105 KB at 320 positions).
+//   phase 2   waves own 16-query tiles (dQ^T accumulators in registers); K arrives in 64-key chunks (double buffered):
+//             dQ^T += K^T dS^T with dS^T read back as the B operand (8 bytes per lane and tile).
+// Key tiles are dealt to the waves in three passes (j = w, 15 - w, 16 + w) - one key tile's accumulators at a time fit the
+// register file; a pass only walks the query chunks at or below its first key (causality).  Same arithmetic per element as
+// the kernel pair (P and dS rounded to bf16 at the same points, f32 accumulation); the summation ORDER over queries / keys
+// differs, so results agree to rounding, not bitwise.  Fixed order: repeated launches are bit-identical.
+template <int D, int TMAX>
+__global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
+  constexpr int KS = D / 32, DT = D / 16, NT16 = TMAX / 16;
+  constexpr int CH = 64;                          // rows per staged chunk
+  constexpr int TILE = CH * D * 2;                // bytes of one staged chunk
+  constexpr int DS_BYTES = NT16 * (NT16 + 1) / 2 * 512;
+  static_assert(TMAX % 64 == 0 && NT16 <= 20, "three passes of eight key tiles cover at most 20 tiles (the last pass takes four)");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsDS = smem;                              // [tile (i, j <= i)][q 16][key 16] bf16
+  char* ldsBuf = smem + DS_BYTES;                  // phase 1: [Q chunk | dO chunk]; phase 2: [K chunk] x 2
+  float* ldsLse = reinterpret_cast<float*>(smem + DS_BYTES + 2 * TILE);
+  float* ldsDl = ldsLse + TMAX;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y, grp = p.Hq / p.Hkv, hk = h / grp;
+  const int T = p.T;
+  const int k_lo = p.kv_start ? p.kv_start[b] : 0;
+  const int k_hi = p.kv_len ? min(p.kv_len[b], T) : T;
+  const bf16_t* qbase = p.q + (long long)b * T * p.ldq + h * D;
+  const bf16_t* dobase = p.dout + (long long)b * T * p.ldo + h * D;
+  const bf16_t* obase = p.o + (long long)b * T * p.ldo + h * D;
+  const bf16_t* kbase = p.k + (long long)b * T * p.ldk + hk * D;
+  const bf16_t* vbase = p.v + (long long)b * T * p.ldv + hk * D;
+  const int nch = (T + CH - 1) / CH;               // query / key chunks that hold rows
+  const int nt = (T + 15) / 16;                    // 16-row tiles that hold rows
+
+  // ---- prologue: delta and log-sum-exp ----
+  for (int r0 = 0; r0 < TMAX; r0 += 32) {
+    const int row = r0 + (tid >> 4), c = (tid & 15) * (D / 16);
+    float dl = 0.f;
+    if (row < T) {
+#pragma unroll
+      for (int c8 = 0; c8 < D / 16; c8 += 8) {
+        const u16x8_t a = *reinterpret_cast<const u16x8_t*>(dobase + (long long)row * p.ldo + c + c8);
+        const u16x8_t o8 = *reinterpret_cast<const u16x8_t*>(obase + (long long)row * p.ldo + c + c8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += bf2f(a[e]) * bf2f(o8[e]);
+      }
+    }
+    dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64); dl += __shfl_xor(dl, 8, 64);
+    if ((tid & 15) == 0) ldsDl[row] = dl;
+  }
+  for (int r = tid; r < TMAX; r += 512) ldsLse[r] = r < T ? p.lse[((long long)b * p.Hq + h) * T + r] : __builtin_huge_valf();
+
+  // ---- phase 1: dK, dV, dS ----
+  NatRegs<D, CH, 512> rq, rdo;
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    const int j = pass == 0 ? w : (pass == 1 ? 15 - w : 16 + w);          // this wave's key tile
+    const bool have = j < nt && (pass < 2 || w < 4) && j * 16 < k_hi && j * 16 + 16 > k_lo;
+    const int j_min = pass == 0 ? 0 : (pass == 1 ? 8 : 16);                // first key tile of the pass (block-uniform)
+    if (j_min >= nt) break;
+    const int key = j * 16 + fr;
+    bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (have && key < T) {
+        a = *reinterpret_cast<const u16x8_t*>(kbase + (long long)key * p.ldk + ks * 32 + g * 8);
+        c = *reinterpret_cast<const u16x8_t*>(vbase + (long long)key * p.ldv + ks * 32 + g * 8);
+      }
+      kf[ks] = __builtin_bit_cast(bf16x8_t, a);
+      vf[ks] = __builtin_bit_cast(bf16x8_t, c);
+    }
+    f32x4_t acc_dk[DT], acc_dv[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { acc_dk[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc_dv[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const int c_first = (j_min * 16) / CH;         // causal: queries below the pass's first key see none of its keys
+    load_nat<D, CH, 512>(rq, qbase, p.ldq, c_first * CH, T, tid);
+    load_nat<D, CH, 512>(rdo, dobase, p.ldo, c_first * CH, T, tid);
+#pragma unroll 1
+    for (int c = c_first; c < nch; ++c) {
+      __syncthreads();                              // every wave is done with the previous chunk (and, first, the prologue)
+      store_nat<D, CH, 512>(ldsBuf, rq, tid);
+      store_nat<D, CH, 512>(ldsBuf + TILE, rdo, tid);
+      __syncthreads();
+      if (c + 1 < nch) {                            // next chunk's loads fly under this chunk's products
+        load_nat<D, CH, 512>(rq, qbase, p.ldq, (c + 1) * CH, T, tid);
+        load_nat<D, CH, 512>(rdo, dobase, p.ldo, (c + 1) * CH, T, tid);
+      }
+      if (!have) continue;
+#pragma unroll 1
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int qs = c * CH + t2 * 32;            // 32 queries: tiles i0, i0 + 1
+        if (qs + 31 < j * 16 || qs >= T) continue;  // wholly above the diagonal / past the sequence (wave-uniform)
+        const char* ldsQ = ldsBuf + 0;
+        const char* ldsDO = ldsBuf + TILE;
+        f32x4_t s[2], dp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t a = lds_b128(ldsQ + nat_off<D>(t2 * 32 + t * 16 + fr, ks * 4 + g));
+            const bf16x8_t cc = lds_b128(ldsDO + nat_off<D>(t2 * 32 + t * 16 + fr, ks * 4 + g));
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kf[ks], s[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cc, vf[ks], dp[t], 0, 0, 0);
+          }
+        }
+        // accumulator element e of tile t: q = qs + t*16 + g*4 + e, key = this lane's key
+        float pr[2][4], ds[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float4 l4 = *reinterpret_cast<const float4*>(ldsLse + qs + t * 16 + g * 4);
+          const float4 d4 = *reinterpret_cast<const float4*>(ldsDl + qs + t * 16 + g * 4);
+          const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int q = qs + t * 16 + g * 4 + e;
+            const bool ok = (q < T) & (key >= k_lo) & (key < k_hi) & (key <= q);
+            const float ev = __builtin_amdgcn_exp2f(s[t][e] * p.sc - lq[e]);
+            const float pv = ok ? ev : 0.f;
+            pr[t][e] = pv;
+            ds[t][e] = pv * (dp[t][e] - dq4[e]);
+          }
+          const int i = (qs >> 4) + t;              // query tile; stored only on / below the diagonal (the rest is never read)
+          if (i >= j && i < NT16) {
+            bf16_t* tile = reinterpret_cast<bf16_t*>(ldsDS + (i * (i + 1) / 2 + j) * 512);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(g * 4 + e) * 16 + fr] = f2bf(ds[t][e]);
+          }
+        }
+        const bf16x8_t pB = pack8(pr[0], pr[1]), dsB = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const bf16x8_t a = tr_frag<D>(ldsDO, t2 * 32, d * 16, lane);
+          const bf16x8_t cc = tr_frag<D>(ldsQ, t2 * 32, d * 16, lane);
+          acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB, acc_dv[d], 0, 0, 0);
+          acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cc, dsB, acc_dk[d], 0, 0, 0);
+        }
+      }
+    }
+    // dK^T / dV^T of this wave's key tile: row d = dt*16 + g*4 + e, col key = fr (per query head under GQA: gqa_reduce_k sums)
+    if (j < nt && (pass < 2 || w < 4) && key < T) {
+      if (p.dkv_part) {
+        bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dkv_part) + (((long long)b * T + key) * p.Hq + h) * D;
+        bf16_t* dvp = dkp + (long long)p.B * T * p.Hq * D;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          u16x4_t a, c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[e] = f2bf(acc_dk[d][e] * p.scale); c[e] = f2bf(acc_dv[d][e]); }
+          *reinterpret_cast<u16x4_t*>(dkp + d * 16 + g * 4) = a;
+          *reinterpret_cast<u16x4_t*>(dvp + d * 16 + g * 4) = c;
+        }
+      } else {
+        bf16_t* dkrow = p.dk + ((long long)b * T + key) * p.lddk + hk * D;
+        bf16_t* dvrow = p.dv + ((long long)b * T + key) * p.lddv + hk * D;
+        float dkv[DT][4];
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dkv[d][e] = bf2f(f2bf(acc_dk[d][e] * p.scale));
+        if (p.rope) rope_inverse_tiles<DT>(dkv, p.rope, key, g);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          u16x4_t a, c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[e] = f2bf(dkv[d][e]); c[e] = f2bf(acc_dv[d][e]); }
+          *reinterpret_cast<u16x4_t*>(dkrow + d * 16 + g * 4) = a;
+          *reinterpret_cast<u16x4_t*>(dvrow + d * 16 + g * 4) = c;
+        }
+      }
+    }
+  }
+
+  // ---- phase 2: dQ ----
+  // query tiles of this wave: w, 19 - w and (w < 4) 8 + w  ->  slots 0..2
+  int qi[3] = {w, NT16 - 1 - w, w < 4 ? 8 + w : NT16};
+  f32x4_t acc[3][DT];
+#pragma unroll
+  for (int z = 0; z < 3; ++z)
+#pragma unroll
+    for (int d = 0; d < DT; ++d) acc[z][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  NatRegs<D, CH, 512> rk;
+  load_nat<D, CH, 512>(rk, kbase, p.ldk, 0, T, tid);
+  __syncthreads();                                  // phase 1 is over: its chunk buffer is free, every dS tile is written
+  store_nat<D, CH, 512>(ldsBuf, rk, tid);
+#pragma unroll 1
+  for (int kc = 0; kc < nch; ++kc) {
+    const char* ldsK = ldsBuf + (kc & 1) * TILE;
+    if (kc + 1 < nch) load_nat<D, CH, 512>(rk, kbase, p.ldk, (kc + 1) * CH, T, tid);
+    __syncthreads();                                // chunk kc is in place (and chunk kc - 1's buffer is no longer read)
+#pragma unroll
+    for (int z = 0; z < 3; ++z) {
+      const int i = qi[z];
+      if (i >= nt) continue;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int j0 = kc * 4 + k2 * 2;             // key tiles j0, j0 + 1 (32 keys)
+        if (j0 > i) continue;
+        typedef __attribute__((ext_vector_type(4))) unsigned short u16x4v;
+        // (a key tile wholly outside the valid key range was never visited in phase 1: its dS tiles do not exist - zeros)
+        const bool ok0 = j0 * 16 < k_hi && j0 * 16 + 16 > k_lo, ok1 = j0 + 1 <= i && (j0 + 1) * 16 < k_hi && (j0 + 1) * 16 + 16 > k_lo;
+        if (!ok0 && !ok1) continue;
+        u16x4v lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (ok0) lo = *reinterpret_cast<const u16x4v*>(ldsDS + (i * (i + 1) / 2 + j0) * 512 + fr * 32 + g * 8);
+        if (ok1) hi = *reinterpret_cast<const u16x4v*>(ldsDS + (i * (i + 1) / 2 + j0 + 1) * 512 + fr * 32 + g * 8);
+        const bf16x8_t dsB = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const bf16x8_t a = tr_frag<D>(ldsK, k2 * 32, d * 16, lane);
+          acc[z][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB, acc[z][d], 0, 0, 0);   // dQ^T[d][q]
+        }
+      }
+    }
+    if (kc + 1 < nch) store_nat<D, CH, 512>(ldsBuf + ((kc + 1) & 1) * TILE, rk, tid);
+  }
+#pragma unroll
+  for (int z = 0; z < 3; ++z) {
+    const int q = qi[z] * 16 + fr;
+    if (qi[z] >= nt || q >= T) continue;
+    bf16_t* dqrow = p.dq + ((long long)b * T + q) * p.lddq + h * D;
+    float dqv[DT][4];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dqv[d][e] = bf2f(f2bf(acc[z][d][e] * p.scale));
+    if (p.rope) rope_inverse_tiles<DT>(dqv, p.rope, q, g);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      u16x4_t a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = f2bf(dqv[d][e]);
+      *reinterpret_cast<u16x4_t*>(dqrow + d * 16 + g * 4) = a;
+    }
+  }
+}
+
 // dk/dv[b, t, hk, :] = sum over the GQA group (fixed order, f32) of the bf16 per-query-head results; with `rope` the summed dK is
 // then RoPE-inverted (same arithmetic as rope_k on the bf16-rounded sum).  One thread = 8 columns c..c+7 of the first half of
 // the head AND their partners c + D/2.. (the rotary pairs) of one (b, t, hk).
@@ -945,7 +1190,20 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
               hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, true>), GK, dim3(NTH), 0, st, a); } \
     else { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, STEP, DEEP, false>), GQ, dim3(NTH), 0, st, a); \
            hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, false>), GK, dim3(NTH), 0, st, a); } } while (0)
-  if (d.f.D == 64) BWD(64, 256, 32, true, gq, gk);
+  // head_dim 128, causal, at most 320 positions (the LLM's training sequences): ONE fused kernel per (batch, query head) -
+  // S and dP once, dS through LDS (tuning option 13, default on)
+  constexpr int FUSED_TMAX = 320;
+  const bool fused = tr && d.f.D == 128 && d.f.causal && d.f.block == 0 && d.f.T <= FUSED_TMAX && g_options[13];
+  if (fused) {
+    constexpr int smem = (FUSED_TMAX / 16) * (FUSED_TMAX / 16 + 1) / 2 * 512 + 2 * 64 * 128 * 2 + 2 * FUSED_TMAX * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      UVX_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_k<128, FUSED_TMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_fused_k<128, FUSED_TMAX>), dim3(d.f.Hq, d.f.B), dim3(512), smem, st, a);
+  }
+  else if (d.f.D == 64) BWD(64, 256, 32, true, gq, gk);
   else if (d.f.D == 128) BWD(128, 512, 32, true, dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), gk128);
   else BWD(256, 256, 32, false, gq, gk);
 #undef BWD

@@ -13,6 +13,7 @@ from __future__ import annotations
 import os
 import ctypes as C
 import dataclasses
+import json
 from typing import Dict, List, Optional
 
 import torch
@@ -1060,7 +1061,8 @@ class UltravoxTrainer:
         # the first steps try the candidates in turn, timed with events, and the trainer keeps the faster one.  Results are
         # bit-identical under every candidate, so tuning never changes what is trained.
         self._tune = None
-        self.schedule_chains = None           # the tuner's verdict (None: not tuned - the library default applies)
+        self.llm_schedule = None              # the tuner's verdict (None: not tuned - the library defaults apply)
+        self.schedule_chains = None
         self.schedule_timings = {}
 
     def save_checkpoint(self, directory: str) -> None:
@@ -1117,12 +1119,23 @@ class UltravoxTrainer:
         self.model.raise_pending_errors()
         return self.scratch[0].sqrt()
 
-    def autotune_schedule(self, candidates=(2, 1), rounds: int = 2) -> None:
+    # the two schedules worth trying (profiles/r03_*): ONE layer chain with the fused attention backward (fewer, longer kernels;
+    # wins by 1-4 ms per step on the faster MI355X boxes) and TWO chains with the dQ + dK/dV kernel pair (the chains fill each
+    # other's GEMM tail rounds; wins by up to 3 ms on the slower ones).  Keys are uvx_set_option keys.
+    SCHEDULES = ({11: 1, 13: 1}, {11: 2, 13: 0})
+
+    def autotune_schedule(self, candidates=None, rounds: int = 2) -> None:
         """Arms the tuner: the next 1 + rounds * len(candidates) calls of train_step (one throw-away step first) alternate
-        between the candidate chain counts; afterwards the fastest (by its best step) stays set.  `self.schedule_chains` holds
-        the verdict (None while tuning)."""
-        self._tune = {"plan": [None] + [c for _ in range(rounds) for c in candidates], "i": 0, "t": {}, "pending": None}
-        self.schedule_chains = None
+        between the candidate schedules (dicts of uvx_set_option key -> value); afterwards the fastest (by its best step) stays
+        set.  `self.llm_schedule` holds the verdict (None while tuning), `self.schedule_timings` the best step time of each."""
+        cands = [dict(c) for c in (candidates or self.SCHEDULES)]
+        self._tune = {"cands": cands, "plan": [None] + [i for _ in range(rounds) for i in range(len(cands))], "i": 0, "t": {},
+                      "pending": None}
+        self.llm_schedule = None
+
+    def _apply_schedule(self, sched: dict) -> None:
+        for k, v in sched.items():
+            _lib.lib().uvx_set_option(int(k), int(v))
 
     def _tune_begin(self) -> None:
         tn = self._tune
@@ -1134,13 +1147,16 @@ class UltravoxTrainer:
             tn["pending"] = None
         if tn["i"] >= len(tn["plan"]):
             best = min(tn["t"], key=lambda c: min(tn["t"][c]))
-            _lib.lib().uvx_set_option(11, int(best))
-            self.schedule_chains, self.schedule_timings, self._tune = int(best), {c: min(v) for c, v in tn["t"].items()}, None
+            self._apply_schedule(tn["cands"][best])
+            self.llm_schedule = dict(tn["cands"][best])
+            self.schedule_chains = int(self.llm_schedule.get(11, 0)) or None
+            self.schedule_timings = {json.dumps(tn["cands"][c], sort_keys=True): min(v) for c, v in tn["t"].items()}
+            self._tune = None
             return
         cand = tn["plan"][tn["i"]]
         tn["i"] += 1
         if cand is not None:
-            _lib.lib().uvx_set_option(11, int(cand))
+            self._apply_schedule(tn["cands"][cand])
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
         tn["pending"] = (cand, e0, None)
