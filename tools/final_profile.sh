@@ -3,7 +3,9 @@
 R=$PWD; OUT=$R/gpurun_out/final; mkdir -p $OUT
 timeout 1200 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
-timeout 600 python bench.py --steps 5 --warmup 2 --gemm-table $OUT/gemm_table.txt > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-300
+timeout 900 python bench.py --steps 20 --warmup 5 --gemm-table $OUT/gemm_table.txt > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-300
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --autotune > $OUT/bench_autotune.log 2>&1; tail -1 $OUT/bench_autotune.log | cut -c1-200
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --opt 11=2,13=0 > $OUT/bench_two_chains.log 2>&1; tail -1 $OUT/bench_two_chains.log | cut -c1-200
 cd /tmp; export TMPDIR=/tmp
 timeout 420 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- timeout 300 python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_stats.log 2>&1
 timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p --output-format csv -- timeout 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/rocprof_fetch.log 2>&1

@@ -802,9 +802,11 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
 // register file; a pass only walks the query chunks at or below its first key (causality).  Same arithmetic per element as
 // the kernel pair (P and dS rounded to bf16 at the same points, f32 accumulation); the summation ORDER over queries / keys
 // differs, so results agree to rounding, not bitwise.  Fixed order: repeated launches are bit-identical.
-template <int D, int TMAX>
+template <int D, int TMAX, int NQT>
 __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
   constexpr int KS = D / 32, DT = D / 16, NT16 = TMAX / 16;
+  constexpr int QS = NQT * 16;                    // queries per step (32 or 64): one dependent LDS -> MFMA -> exp -> MFMA chain per step
+  static_assert(NQT == 2 || NQT == 4, "a step covers one or two 32-query contraction chunks");
   constexpr int CH = 64;                          // rows per staged chunk
   constexpr int TILE = CH * D * 2;                // bytes of one staged chunk
   constexpr int DS_BYTES = NT16 * (NT16 + 1) / 2 * 512;
@@ -885,27 +887,27 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
       }
       if (!have) continue;
 #pragma unroll 1
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const int qs = c * CH + t2 * 32;            // 32 queries: tiles i0, i0 + 1
-        if (qs + 31 < j * 16 || qs >= T) continue;  // wholly above the diagonal / past the sequence (wave-uniform)
+      for (int t2 = 0; t2 < CH / QS; ++t2) {
+        const int qs = c * CH + t2 * QS;            // QS queries: tiles i0 .. i0 + NQT - 1
+        if (qs + QS - 1 < j * 16 || qs >= T) continue;  // wholly above the diagonal / past the sequence (wave-uniform)
         const char* ldsQ = ldsBuf + 0;
         const char* ldsDO = ldsBuf + TILE;
-        f32x4_t s[2], dp[2];
+        f32x4_t s[NQT], dp[NQT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NQT; ++t) {
           s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t a = lds_b128(ldsQ + nat_off<D>(t2 * 32 + t * 16 + fr, ks * 4 + g));
-            const bf16x8_t cc = lds_b128(ldsDO + nat_off<D>(t2 * 32 + t * 16 + fr, ks * 4 + g));
+            const bf16x8_t a = lds_b128(ldsQ + nat_off<D>(t2 * QS + t * 16 + fr, ks * 4 + g));
+            const bf16x8_t cc = lds_b128(ldsDO + nat_off<D>(t2 * QS + t * 16 + fr, ks * 4 + g));
             s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kf[ks], s[t], 0, 0, 0);
             dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cc, vf[ks], dp[t], 0, 0, 0);
           }
         }
         // accumulator element e of tile t: q = qs + t*16 + g*4 + e, key = this lane's key
-        float pr[2][4], ds[2][4];
+        float pr[NQT][4], ds[NQT][4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NQT; ++t) {
           const float4 l4 = *reinterpret_cast<const float4*>(ldsLse + qs + t * 16 + g * 4);
           const float4 d4 = *reinterpret_cast<const float4*>(ldsDl + qs + t * 16 + g * 4);
           const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -925,13 +927,16 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
             for (int e = 0; e < 4; ++e) tile[(g * 4 + e) * 16 + fr] = f2bf(ds[t][e]);
           }
         }
-        const bf16x8_t pB = pack8(pr[0], pr[1]), dsB = pack8(ds[0], ds[1]);
 #pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          const bf16x8_t a = tr_frag<D>(ldsDO, t2 * 32, d * 16, lane);
-          const bf16x8_t cc = tr_frag<D>(ldsQ, t2 * 32, d * 16, lane);
-          acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB, acc_dv[d], 0, 0, 0);
-          acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cc, dsB, acc_dk[d], 0, 0, 0);
+        for (int kp = 0; kp < NQT / 2; ++kp) {
+          const bf16x8_t pB = pack8(pr[2 * kp], pr[2 * kp + 1]), dsB = pack8(ds[2 * kp], ds[2 * kp + 1]);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const bf16x8_t a = tr_frag<D>(ldsDO, t2 * QS + kp * 32, d * 16, lane);
+            const bf16x8_t cc = tr_frag<D>(ldsQ, t2 * QS + kp * 32, d * 16, lane);
+            acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB, acc_dv[d], 0, 0, 0);
+            acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cc, dsB, acc_dk[d], 0, 0, 0);
+          }
         }
       }
     }
@@ -1134,7 +1139,8 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
   AttnArgs a = make_args(d);
   // q rows per block = 64 * QT.  Long sequences (the encoder's 1500 frames) want QT = 2 for K/V reuse; short
   // ones (the LLM's few hundred tokens) are latency-bound and want more, smaller blocks and fewer registers.
-  const int qt = uvx::g_attn_qt > 0 ? uvx::g_attn_qt : (d.T >= 1024 ? 2 : 1);
+  // (the probe override applies to the head_dim-64 kernels only - the encoder's; the others have one or two instantiations)
+  const int qt = (uvx::g_attn_qt > 0 && d.D == 64) ? (uvx::g_attn_qt > 4 ? 4 : uvx::g_attn_qt) : (d.T >= 1024 ? 2 : 1);
   dim3 grid(d.Hq, d.B, cdiv(d.T, 4 * qt * 16));
   const bool tr = attention_tr_reads(dtype);   // V natural + transposing LDS reads (no V^T copy) - tuning option 12
   UVX_CHECK(tr ? d.v != nullptr : d.vt != nullptr, UVX_ERR_INVALID, "attention_fwd: %s is null", tr ? "v" : "vt");
@@ -1198,10 +1204,11 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
     constexpr int smem = (FUSED_TMAX / 16) * (FUSED_TMAX / 16 + 1) / 2 * 512 + 2 * 64 * 128 * 2 + 2 * FUSED_TMAX * 4;
     static bool attr_set = false;
     if (!attr_set) {
-      UVX_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_k<128, FUSED_TMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      UVX_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_k<128, FUSED_TMAX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
       attr_set = true;
     }
-    hipLaunchKernelGGL((attn_bwd_fused_k<128, FUSED_TMAX>), dim3(d.f.Hq, d.f.B), dim3(512), smem, st, a);
+    // (64-query steps, NQT = 4: 87.9 vs 87.5 ms per step - profiles/r03_call13_probes.txt - not instantiated)
+    hipLaunchKernelGGL((attn_bwd_fused_k<128, FUSED_TMAX, 2>), dim3(d.f.Hq, d.f.B), dim3(512), smem, st, a);
   }
   else if (d.f.D == 64) BWD(64, 256, 32, true, gq, gk);
   else if (d.f.D == 128) BWD(128, 512, 32, true, dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), gk128);
