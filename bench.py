@@ -52,11 +52,12 @@ WORKLOADS = {
 }
 
 
-def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int = 32):
+def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int = 32, top_rows: bool = True):
     """Algorithmic FLOPs of one sample: matmul [m,k]x[k,n] = 2mkn, causal attention = 1/2.  The LM head
     is counted on the supervised positions only (the rows that enter the loss; the other rows of the logits have zero
     weight and zero gradient, and the training step does not compute them), and so is the last LLM layer's o_proj + MLP -
-    `step_full_head` keeps the all-rows count."""
+    `step_full_head` keeps the all-rows count.  top_rows = False: the step flavours that DO run the last layer on every row
+    (KL distillation, LLM LoRA, UVX_TOP_LAYER_ROWS=0: model._llm_train_pair is false) - nothing is subtracted for them."""
     a, t = cfg.audio_config, cfg.text_config
     F = int(seconds * 100)
     Te = F // 2
@@ -82,7 +83,7 @@ def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int =
     body = L * (2 * T * (2 * D * h * dh + 2 * D * kv * dh) + 6 * T * D * I) + attn
     head, head_full = 2 * n_supervised * D * V, 2 * T * D * V
     # the last layer's o_proj + MLP (row-wise, after the last position mixing) likewise run on the supervised rows only
-    top_skip = (T - n_supervised) * (2 * D * h * dh + 6 * D * I)
+    top_skip = (T - n_supervised) * (2 * D * h * dh + 6 * D * I) if top_rows else 0
     M = body + head - top_skip
     step = E + 3 * P + M + (M + attn)
     return dict(encoder=E, projector=P, llm_fwd=M, step=step, step_full_head=step + 2 * (head_full - head) + 2 * top_skip)
@@ -427,7 +428,7 @@ def main():
     dt = max(rank_s)                                        # the contract: MAX over ranks
 
     if rank == 0:
-        fl = flops_per_sample(cfg, wl["seconds"])
+        fl = flops_per_sample(cfg, wl["seconds"], top_rows=bool(model._llm_train_pair))    # what the measured step really skipped
         audio_s = B * world * wl["seconds"] * args.steps
         ms = dt / args.steps * 1e3
         out = {

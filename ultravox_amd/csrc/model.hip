@@ -1,6 +1,8 @@
 // Host-side orchestration of the hot path behind the C ABI (include/uvx.h): which kernels run, in
 // what order, on which slices of the caller's workspace.  No device allocation, no synchronisation.
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 #include "common.h"
 #include "kernels.h"
 #include "../../include/uvx.h"
@@ -255,6 +257,21 @@ LlmLayerStash llm_layer(const LlmWs& w, int slot) {
   s.x_mid = (char*)s.x_mid + d; s.gu = (char*)s.gu + d; s.lse = (float*)((char*)s.lse + d);
   s.t = (char*)s.t + d; s.bqT = (char*)s.bqT + d; s.bkT = (char*)s.bkT + d;
   return s;
+}
+
+// What uvx_llm_fwd_train left in a workspace (host-side note keyed by the workspace address): whether the last layer's stash is
+// row-compacted.  uvx_llm_bwd_train re-derives that from tuning option 3; if the option changed in between it would misread the
+// stash silently - now it is an error.
+std::mutex g_pair_mu;
+std::unordered_map<const void*, bool> g_pair_compact;
+void note_pair(const void* ws, bool compact) { std::lock_guard<std::mutex> l(g_pair_mu); g_pair_compact[ws] = compact; }
+int check_pair(const void* ws, bool compact) {
+  std::lock_guard<std::mutex> l(g_pair_mu);
+  auto it = g_pair_compact.find(ws);
+  UVX_CHECK(it == g_pair_compact.end() || it->second == compact, UVX_ERR_INVALID,
+            "llm_bwd_train: the forward pass left a %s last-layer stash in this workspace, the backward expects %s (uvx_set_option(3, ..) "
+            "changed between uvx_llm_fwd_train and uvx_llm_bwd_train)", it->second ? "row-compacted" : "full-row", compact ? "row-compacted" : "full-row");
+  return UVX_OK;
 }
 
 // Timing probe (tuning option 15, default 0): bit mask of kernel classes NOT launched - the step's results are then garbage, its
@@ -753,6 +770,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   UVX_CHECK(!top_rows || (labels && loss && dt == DT_BF16 && save_for_bwd && !logits && !rows), UVX_ERR_INVALID,
             "llm_fwd_train: labels and a loss output are required, bf16 only");
   const bool tc = top_rows && g_options[3];   // (tuning option 3 off: the plain full-row path, in both calls of the pair)
+  if (top_rows) note_pair(workspace, tc);
   const int fl = c.llm_flavor;   // 0 Llama, 1 Gemma (norm flavour, GLU activation, embedding scale)
   {
     LlmLayerStash l0 = llm_layer(s, 0);
@@ -978,6 +996,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   // supervised rows only; its MLP / o_proj gradients run on those rows and are scattered back before the attention backward
   UVX_CHECK(!top_rows || (!compact_in_place && labels && dt == DT_BF16), UVX_ERR_INVALID, "llm_bwd_train: labels are required, bf16 only");
   const bool tc = top_rows && g_options[3];
+  if (top_rows) RC(check_pair(workspace, tc));
   const int32_t* mdev_top = tc ? s.sup + M : nullptr;
   if (tc) {
     RC(gather_rows(st, dt, s.d_hn, s.sup, M, s.d_n, D));                 // d_hn was scattered to full rows: back to compact

@@ -320,15 +320,22 @@ class UltravoxModel:
     def trainable_parameter_names(self):
         return list(self.projector_state_dict().keys())
 
-    def _full_state_dict(self) -> Dict[str, torch.Tensor]:
+    def _full_state_dict(self, strict: bool = False) -> Dict[str, torch.Tensor]:
         """What can be saved from this model: the trainable tensors plus the frozen-tower tensors a loaded checkpoint carried
-        (`keep_params`, retained on the host by from_pretrained).  A keep_param with no tensor behind it would silently drop
-        out of the next save - the reload would then revert that tower to its base model id - so it raises instead."""
+        (`keep_params`, retained on the host by from_pretrained).  Deviation from the reference, stated: there `keep_params`
+        may name ANY key of the module's state dict (ultravox_model.py:59, :565-584: the whole model lives in one nn.Module);
+        here the frozen towers exist only as packed device weights, so a keep_param without a retained tensor cannot be
+        re-saved.  Such keys are reported with a warning and left out (the reload then takes that tower from its base model
+        id, which is what the key said anyway unless the tower had been modified); strict=True raises instead."""
         sd = {**getattr(self, "_kept_tensors", {}), **self.projector_state_dict()}
         lost = sorted(k for k in self.keep_params if k not in sd)
         if lost:
-            raise KeyError(f"keep_params names {len(lost)} tensor(s) this model cannot re-save (e.g. {lost[:3]}): frozen-tower keys "
-                           "are only retained when they arrive through from_pretrained")
+            msg = (f"keep_params names {len(lost)} tensor(s) this model cannot re-save (e.g. {lost[:3]}): frozen-tower keys are only "
+                   "retained when they arrive through from_pretrained")
+            if strict:
+                raise KeyError(msg)
+            import warnings
+            warnings.warn(msg + "; they are left out of the saved state dict")
         return sd
 
     def diff_state_dict(self, state_dict: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
@@ -556,6 +563,13 @@ class UltravoxModel:
         if self._before_projector is not None:   # the trainer's deferred all-reduce + optimizer step (overlapped with the
             self._before_projector()             # frozen encoder above, which does not read the trainable weights)
         audio_embeds = self.multi_modal_projector_forward(tower)
+        if self.is_wav2vec2 and not audio_token_len.is_cuda:
+            # raw-waveform tower: audio_token_len comes from the PROCESSOR's frame formula (its audio_frames_fn defaults to the
+            # standard 7-layer conv stack); a tower with other conv_kernel / conv_stride values would silently disagree with the
+            # rows the projector really produced - checked here when the lengths live on the host (no synchronisation)
+            assert int(audio_token_len.max()) <= audio_embeds.shape[1], (
+                f"audio_token_len {int(audio_token_len.max())} exceeds the {audio_embeds.shape[1]} rows the projector produced: the "
+                "processor's audio_frames_fn does not match audio_config.conv_kernel / conv_stride")
         return self._embed_merge(inputs_embeds, input_ids, audio_embeds, audio_token_start_idx, audio_token_len,
                                  audio_batch_size, B, T)
 
