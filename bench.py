@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--opt", default=None, help="probe: 'key=value,...' for uvx_set_option")
     ap.add_argument("--gemm-override", default=None, help="probe: 'MxNxK=variant,...' tile-variant overrides")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table (from the HIP events) here")
+    ap.add_argument("--gemm-raw", default=None, help="probe: write every GEMM launch of the timed region, in issue order (M N K variant us)")
     ap.add_argument("--attn-qt", type=int, default=0, help="probe: uvx_attention_force_qt (query tiles per wave of the attention forward)")
     ap.add_argument("--autotune", action="store_true",
                     help="let the trainer pick the LLM schedule ({one chain, fused attention backward} or {two chains, kernel pair}) from "
@@ -403,9 +404,13 @@ def main():
     dt = time.perf_counter() - t0
     shapes = None
     if not args.no_prof:
-        if args.gemm_table and rank == 0:
+        if (args.gemm_table or args.gemm_raw) and rank == 0:
             buf = (C.c_double * (6 * 20000))()
             n = _lib.lib().uvx_prof_records(buf, 20000)
+            if args.gemm_raw:
+                with open(args.gemm_raw, "w") as f:
+                    for i in range(n):
+                        f.write("%d %d %d %d %d %.2f\n" % (buf[i * 6], buf[i * 6 + 1], buf[i * 6 + 2], buf[i * 6 + 3], buf[i * 6 + 4], buf[i * 6 + 5] * 1e3))
             agg = {}
             for i in range(n):
                 key = tuple(int(buf[i * 6 + j]) for j in range(5))
