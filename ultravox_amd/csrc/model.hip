@@ -783,7 +783,8 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     const uvx_llm_layer_t& L = w->layers[l];
     LlmLayerStash cur = llm_layer(v, slot_of(l));
     const int Mv = v.M;
-    if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, v.n, nullptr, Mv, D, c.rms_eps, fl));
+    // (probe bit 256: the kernel runs but writes elsewhere - the GEMM then reads a buffer nobody has just written)
+    if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, probe_skip(256) && save_for_bwd ? v.d_n : v.n, nullptr, Mv, D, c.rms_eps, fl));
     RC(gemm(sx, dt, lin(v.n, L.wqkv, cur.qkv, Mv, s.QKV, D)));
     if (lora) {   // peft LoRA on q_proj / k_proj (text_model_lora_config): added to the projections, before RoPE
       const uvx_enc_lora_layer_t& R = lora->layers[l];
@@ -824,7 +825,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       g.residual = compact ? v.dx : cur.x_in; g.ldr = D; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
-    if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, v.n, nullptr, Mv, D, c.rms_eps, fl));
+    if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, probe_skip(256) && save_for_bwd ? v.d_n : v.n, nullptr, Mv, D, c.rms_eps, fl));
     {  // gate|up projection; wgu rows are packed as alternating 16-row gate / up blocks (weights.py)
       GemmDesc g = lin(v.n, L.wgu, cur.gu, Mv, 2 * c.llm_inter, D);
       const bool fused = dt == DT_BF16 && fl == UVX_LLM_LLAMA;   // SwiGLU fused into the epilogue (GeGLU: separate kernel)
