@@ -386,6 +386,12 @@ int32_t uvx_gemm_override_variant(int32_t M, int32_t N, int32_t K, int32_t varia
 int32_t uvx_probe_lds_tr(void* stream, const int32_t* addr, int32_t* out);
 /* probes: force the attention forward q-tile count per wave (1 or 2; 0 = automatic) */
 int32_t uvx_attention_force_qt(int32_t qt);
+/* probes (libuvx_probes.so; UVX_ERR_UNSUPPORTED in libuvx.so): while `stamps` is non-null, every wave of the fused attention
+ * backward kernel writes a 16 x u64 record of cycle-counter stamps into stamps[((b * Hq + h) * 8 + wave) * 16 + slot]: 0 start,
+ * 1 prologue done, 2 + 2 p / 3 + 2 p pass p of phase 1 done / its dK, dV stored, 8 phase 2 done, 9 dQ stored, 10 cycles inside
+ * phase-1 steps, 11 cycles at phase-1 barriers + staging stores, 12 steps taken, 13 cycles inside phase-2 products.
+ * tools/gpu_attn_timeline.py prints the breakdown.  null switches the stamps off. */
+int32_t uvx_probe_attn_timeline(void* stamps);
 
 int32_t uvx_layernorm(void* stream, int32_t dtype, const void* x, const void* w, const void* b, void* y, int32_t rows,
                       int32_t cols, float eps);

@@ -22,7 +22,7 @@ CSRC = PKG / "csrc"
 OBJ = CSRC / "build"
 LIB = PKG / "libuvx.so"
 LIB_PROBES = PKG / "libuvx_probes.so"
-PROBE_SOURCES = ("gemm.hip",)          # the only sources that read UVX_PROBES
+PROBE_SOURCES = ("gemm.hip", "attention.hip", "api_core.hip")   # the sources that read UVX_PROBES
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 # per-file extras.  attention: keep MFMA results in VGPRs (gfx950 has a unified 512-entry file): the softmax

@@ -17,8 +17,17 @@ extern "C" void uvx_set_error(const char* fmt, ...) {
 
 extern "C" const char* uvx_last_error(void) { return g_err; }
 extern "C" int32_t uvx_abi_version(void) { return UVX_ABI_VERSION; }
-namespace uvx { extern int g_attn_qt; }
+namespace uvx { extern int g_attn_qt; extern void* g_attn_tl; }
 extern "C" int32_t uvx_attention_force_qt(int32_t qt) { uvx::g_attn_qt = qt; return UVX_OK; }
+extern "C" int32_t uvx_probe_attn_timeline(void* stamps) {
+#ifdef UVX_PROBES
+  uvx::g_attn_tl = stamps;
+  return UVX_OK;
+#else
+  (void)stamps;
+  UVX_CHECK(false, UVX_ERR_UNSUPPORTED, "uvx_probe_attn_timeline: the stamps exist in libuvx_probes.so only (built with -DUVX_PROBES)");
+#endif
+}
 extern "C" int32_t uvx_gemm_force_variant(int32_t v) {
   if (v <= -2) { uvx::g_gemm_variant = -1; uvx::g_gemm_split = 0; }  // -2: automatic variant, tail split off (A/B probes)
   else { uvx::g_gemm_variant = v; uvx::g_gemm_split = 1; }

@@ -41,7 +41,18 @@ struct AttnArgs {
   float* dkv_part;  // scratch for [2][B, T, Hq, D] per-query-head results (GQA; stored as bf16) or null
   const float* rope;  // backward: [T_table, D/2, 2] f32 cos / sin - dQ and dK leave the kernels RoPE-INVERTED (the gradient of q, k
                       // before the rotary embedding), position = the row's index in its sequence; null = none
+  unsigned long long* tl;  // probes build: per-wave s_memtime stamps of the fused backward kernel (uvx_probe_attn_timeline); else null
 };
+// Timeline stamps (libuvx_probes.so only): lane 0 of every wave writes slot `s` of its 16-slot record.
+#ifdef UVX_PROBES
+#define TL_STAMP(s) do { if (p.tl && lane == 0) p.tl[((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * 16 + (s)] = __builtin_readcyclecounter(); } while (0)
+#define TL_NOW() (p.tl ? __builtin_readcyclecounter() : 0ULL)
+#define TL_PUT(s, v) do { if (p.tl && lane == 0) p.tl[((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * 16 + (s)] = (v); } while (0)
+#else
+#define TL_STAMP(s) do {} while (0)
+#define TL_NOW() 0ULL
+#define TL_PUT(s, v) do {} while (0)
+#endif
 
 // Inverse rotary embedding of one gradient row held as DT accumulator tiles (element e of tile dt <-> d = 16 dt + 4 g + e):
 // the pair (d, d + D/2) sits in tiles dt and dt + DT/2 of the same lane.  Same arithmetic and rounding points as rope_k
@@ -181,6 +192,47 @@ __device__ __forceinline__ void store_tr(char* lds, const TrRegs<D, W, NT>& g, i
     u16x8_t v = g.v[k];
     if (sw & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
     *reinterpret_cast<u16x8_t*>(lds + r * (W * 2) + (((c ^ (sw >> 1)) & (NC - 1)) << 4)) = v;
+  }
+}
+
+// Stores of DT accumulator tiles held "transposed" (element e of tile dt <-> column 16 dt + 4 g + e of row fr = lane & 15).
+// Written as they are, every store instruction touches 16 rows with 32 contiguous bytes each - partial lines, measured at ~5
+// cycles per 32-byte piece in the fused backward kernel (a quarter of its run time went into issuing its dK / dV / dQ stores,
+// profiles/r03_attn_timeline.txt).  store_rows_staged passes them through a 16 x (64 + 8)-column bf16 LDS tile of the wave, 64
+// columns at a time, so that a row leaves as 128 contiguous bytes from four lanes: head_dim 128 kernels 7 - 15 % faster at the
+// LLM's shape; at head_dim 64 (128-byte rows) it is neutral (forward) to 4 % slower (backward pair), so store_rows keeps the direct
+// form there (profiles/r03_attn_staged_stores_ab.txt).  rows r >= rows_valid are not written.
+constexpr int STAGE_ROW = 144, STAGE_BYTES = 16 * STAGE_ROW;
+template <int DT>
+__device__ __forceinline__ void store_rows_staged(char* stage, const u16x4_t (&v)[DT], bf16_t* row0, long long ld, int rows_valid, int lane) {
+  static_assert(DT % 4 == 0, "64 columns per round");
+  const int fr = lane & 15, g = lane >> 4, r = lane >> 2, seg = lane & 3;
+#pragma unroll
+  for (int h = 0; h < DT / 4; ++h) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<u16x4_t*>(stage + fr * STAGE_ROW + (dt * 16 + g * 4) * 2) = v[h * 4 + dt];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u16x8_t a = *reinterpret_cast<const u16x8_t*>(stage + r * STAGE_ROW + seg * 32);
+    const u16x8_t b = *reinterpret_cast<const u16x8_t*>(stage + r * STAGE_ROW + seg * 32 + 16);
+    if (r < rows_valid) {
+      *reinterpret_cast<u16x8_t*>(row0 + (long long)r * ld + h * 64 + seg * 16) = a;
+      *reinterpret_cast<u16x8_t*>(row0 + (long long)r * ld + h * 64 + seg * 16 + 8) = b;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+template <int DT>
+__device__ __forceinline__ void store_rows(char* stage, const u16x4_t (&v)[DT], bf16_t* row0, long long ld, int rows_valid, int lane) {
+  if constexpr (DT >= 8) {
+    store_rows_staged<DT>(stage, v, row0, ld, rows_valid, lane);
+  } else {
+    const int fr = lane & 15, g = lane >> 4;
+    if (fr < rows_valid) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) *reinterpret_cast<u16x4_t*>(row0 + (long long)fr * ld + d * 16 + g * 4) = v[d];
+    }
   }
 }
 
@@ -357,23 +409,25 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   }
 
   // ---- epilogue ----
+  // (after the loop's last barrier nobody reads the K / V tiles any more: each wave stages its O rows through a private piece
+  //  of them and stores whole 128-byte row segments - store_rows_staged)
+  char* stage = ldsKV + w * STAGE_BYTES;
+  static_assert(4 * STAGE_BYTES <= 4 * TILE, "stage fits the tile buffers");
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int q = q0 + t * 16 + fr;
     float l = l_run[t];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    if (q >= p.T) continue;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    bf16_t* orow = p.o + ((long long)b * p.T + q) * p.ldo + h * D;
+    u16x4_t o4[DT];
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      u16x4_t o4;
+    for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o4[e] = f2bf(acc_o[t][d][e] * inv);
-      *reinterpret_cast<u16x4_t*>(orow + d * 16 + g * 4) = o4;
-    }
-    if (p.lse && g == 0) p.lse[((long long)b * p.Hq + h) * p.T + q] = l > 0.f ? m_run[t] + log2f(l) : __builtin_huge_valf();
+      for (int e = 0; e < 4; ++e) o4[d][e] = f2bf(acc_o[t][d][e] * inv);
+    if (q0 + t * 16 < p.T)   // wave-uniform
+      store_rows<DT>(stage, o4, p.o + ((long long)b * p.T + q0 + t * 16) * p.ldo + h * D, p.ldo, p.T - (q0 + t * 16), lane);
+    if (p.lse && g == 0 && q < p.T) p.lse[((long long)b * p.Hq + h) * p.T + q] = l > 0.f ? m_run[t] + log2f(l) : __builtin_huge_valf();
   }
 }
 
@@ -573,38 +627,37 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
       __syncthreads();
     }
   }
-  // accumulators hold dV^T / dK^T: row d = dt*16 + g*4 + e, col key = fr
-  if (split) {
-    // per-query-head dK / dV, rounded to bf16 like the un-grouped result below: that is where the reference rounds too (SDPA
-    // returns bf16 gradients for the repeat_kv-expanded heads and autograd sums the group afterwards) - and half the bytes
-    if (key < p.T) {
-      bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dkv_part) + (((long long)b * p.T + key) * p.Hq + h_first) * D;
+  // accumulators hold dV^T / dK^T: row d = dt*16 + g*4 + e, col key = fr.  After the loop's last barrier the staging buffers are
+  // free: every wave passes its rows through a private piece of them and stores whole 128-byte segments (store_rows_staged).
+  char* stage = ldsAll + w * STAGE_BYTES;
+  static_assert((NT / 64) * STAGE_BYTES <= 2 * NTILE * TILE, "stage fits the staging buffers");
+  const int key0 = kb0 + w * 16;
+  if (key0 < p.T) {    // wave-uniform
+    u16x4_t ok[DT], ov[DT];
+    if (split) {
+      // per-query-head dK / dV, rounded to bf16 like the un-grouped result below: that is where the reference rounds too (SDPA
+      // returns bf16 gradients for the repeat_kv-expanded heads and autograd sums the group afterwards) - and half the bytes
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(acc_dk[d][e] * p.scale); ov[d][e] = f2bf(acc_dv[d][e]); }
+      bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dkv_part) + (((long long)b * p.T + key0) * p.Hq + h_first) * D;
       bf16_t* dvp = dkp + (long long)p.B * p.T * p.Hq * D;
+      store_rows<DT>(stage, ok, dkp, (long long)p.Hq * D, p.T - key0, lane);
+      store_rows<DT>(stage, ov, dvp, (long long)p.Hq * D, p.T - key0, lane);
+    } else {
+      float dkv[DT][4];
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        u16x4_t a, c;
+      for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] = f2bf(acc_dk[d][e] * p.scale); c[e] = f2bf(acc_dv[d][e]); }
-        *reinterpret_cast<u16x4_t*>(dkp + d * 16 + g * 4) = a;
-        *reinterpret_cast<u16x4_t*>(dvp + d * 16 + g * 4) = c;
-      }
-    }
-  } else if (key < p.T) {
-    bf16_t* dkrow = p.dk + ((long long)b * p.T + key) * p.lddk + hk * D;
-    bf16_t* dvrow = p.dv + ((long long)b * p.T + key) * p.lddv + hk * D;
-    float dkv[DT][4];
+        for (int e = 0; e < 4; ++e) dkv[d][e] = bf2f(f2bf(acc_dk[d][e] * p.scale));
+      if (p.rope) rope_inverse_tiles<DT>(dkv, p.rope, min(key, p.T - 1), g);
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+      for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dkv[d][e] = bf2f(f2bf(acc_dk[d][e] * p.scale));
-    if (p.rope) rope_inverse_tiles<DT>(dkv, p.rope, key, g);
-#pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      u16x4_t a, c;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { a[e] = f2bf(dkv[d][e]); c[e] = f2bf(acc_dv[d][e]); }
-      *reinterpret_cast<u16x4_t*>(dkrow + d * 16 + g * 4) = a;
-      *reinterpret_cast<u16x4_t*>(dvrow + d * 16 + g * 4) = c;
+        for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(dkv[d][e]); ov[d][e] = f2bf(acc_dv[d][e]); }
+      store_rows<DT>(stage, ok, p.dk + ((long long)b * p.T + key0) * p.lddk + hk * D, p.lddk, p.T - key0, lane);
+      store_rows<DT>(stage, ov, p.dv + ((long long)b * p.T + key0) * p.lddv + hk * D, p.lddv, p.T - key0, lane);
     }
   }
 }
@@ -769,21 +822,20 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
       __syncthreads();
     }
   }
-  if (q < p.T) {
-    bf16_t* dqrow = p.dq + ((long long)b * p.T + q) * p.lddq + h * D;
+  if (qb0 + w * 16 < p.T) {   // wave-uniform; rows leave through the (now free) staging buffers as 128-byte segments
+    char* stage = ldsAll + w * STAGE_BYTES;
     float dqv[DT][4];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int e = 0; e < 4; ++e) dqv[d][e] = bf2f(f2bf(acc[d][e] * p.scale));
-    if (p.rope) rope_inverse_tiles<DT>(dqv, p.rope, q, g);
+    if (p.rope) rope_inverse_tiles<DT>(dqv, p.rope, min(q, p.T - 1), g);
+    u16x4_t oq[DT];
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      u16x4_t a;
+    for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] = f2bf(dqv[d][e]);
-      *reinterpret_cast<u16x4_t*>(dqrow + d * 16 + g * 4) = a;
-    }
+      for (int e = 0; e < 4; ++e) oq[d][e] = f2bf(dqv[d][e]);
+    store_rows<DT>(stage, oq, p.dq + ((long long)b * p.T + qb0 + w * 16) * p.lddq + h * D, p.lddq, p.T - (qb0 + w * 16), lane);
   }
 }
 
@@ -816,6 +868,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
   char* ldsBuf = smem + DS_BYTES;                  // phase 1: [Q chunk | dO chunk]; phase 2: [K chunk] x 2
   float* ldsLse = reinterpret_cast<float*>(smem + DS_BYTES + 2 * TILE);
   float* ldsDl = ldsLse + TMAX;
+  char* ldsStage = smem + DS_BYTES + 2 * TILE + 2 * TMAX * 4;   // [wave][16 rows][64 + 8 columns] bf16: store_rows_staged
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -823,6 +876,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
   const int T = p.T;
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], T) : T;
+  char* stage = ldsStage + w * STAGE_BYTES;
   const bf16_t* qbase = p.q + (long long)b * T * p.ldq + h * D;
   const bf16_t* dobase = p.dout + (long long)b * T * p.ldo + h * D;
   const bf16_t* obase = p.o + (long long)b * T * p.ldo + h * D;
@@ -831,24 +885,36 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
   const int nch = (T + CH - 1) / CH;               // query / key chunks that hold rows
   const int nt = (T + 15) / 16;                    // 16-row tiles that hold rows
 
+  TL_STAMP(0);
+  unsigned long long tl_step = 0, tl_wait = 0, tl_n = 0, tl_p2 = 0;
+  (void)tl_step; (void)tl_wait; (void)tl_n; (void)tl_p2;
   // ---- prologue: delta and log-sum-exp ----
-  for (int r0 = 0; r0 < TMAX; r0 += 32) {
-    const int row = r0 + (tid >> 4), c = (tid & 15) * (D / 16);
-    float dl = 0.f;
-    if (row < T) {
+  // (every load of the prologue is issued before the first is used: ten dependent round trips to HBM, one per 32 rows, were 14 % of
+  //  the kernel - profiles/r03_attn_timeline.txt; rows >= T repeat row T - 1 and are discarded)
+  {
+    static_assert(D / 16 == 8, "one 16-byte load per thread and row");
+    constexpr int NIT = TMAX / 32;
+    u16x8_t pa[NIT], po[NIT];
+    const int c = (tid & 15) * 8;
 #pragma unroll
-      for (int c8 = 0; c8 < D / 16; c8 += 8) {
-        const u16x8_t a = *reinterpret_cast<const u16x8_t*>(dobase + (long long)row * p.ldo + c + c8);
-        const u16x8_t o8 = *reinterpret_cast<const u16x8_t*>(obase + (long long)row * p.ldo + c + c8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += bf2f(a[e]) * bf2f(o8[e]);
-      }
+    for (int it = 0; it < NIT; ++it) {
+      const int row = min(it * 32 + (tid >> 4), T - 1);
+      pa[it] = *reinterpret_cast<const u16x8_t*>(dobase + (long long)row * p.ldo + c);
+      po[it] = *reinterpret_cast<const u16x8_t*>(obase + (long long)row * p.ldo + c);
     }
-    dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64); dl += __shfl_xor(dl, 8, 64);
-    if ((tid & 15) == 0) ldsDl[row] = dl;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      float dl = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += bf2f(pa[it][e]) * bf2f(po[it][e]);
+      dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64); dl += __shfl_xor(dl, 8, 64);
+      const int row = it * 32 + (tid >> 4);
+      if ((tid & 15) == 0) ldsDl[row] = row < T ? dl : 0.f;
+    }
   }
   for (int r = tid; r < TMAX; r += 512) ldsLse[r] = r < T ? p.lse[((long long)b * p.Hq + h) * T + r] : __builtin_huge_valf();
 
+  TL_STAMP(1);
   // ---- phase 1: dK, dV, dS ----
   NatRegs<D, CH, 512> rq, rdo;
 #pragma unroll 1
@@ -877,10 +943,12 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
     load_nat<D, CH, 512>(rdo, dobase, p.ldo, c_first * CH, T, tid);
 #pragma unroll 1
     for (int c = c_first; c < nch; ++c) {
+      const unsigned long long tl_a = TL_NOW();
       __syncthreads();                              // every wave is done with the previous chunk (and, first, the prologue)
       store_nat<D, CH, 512>(ldsBuf, rq, tid);
       store_nat<D, CH, 512>(ldsBuf + TILE, rdo, tid);
       __syncthreads();
+      tl_wait += TL_NOW() - tl_a;
       if (c + 1 < nch) {                            // next chunk's loads fly under this chunk's products
         load_nat<D, CH, 512>(rq, qbase, p.ldq, (c + 1) * CH, T, tid);
         load_nat<D, CH, 512>(rdo, dobase, p.ldo, (c + 1) * CH, T, tid);
@@ -890,6 +958,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
       for (int t2 = 0; t2 < CH / QS; ++t2) {
         const int qs = c * CH + t2 * QS;            // QS queries: tiles i0 .. i0 + NQT - 1
         if (qs + QS - 1 < j * 16 || qs >= T) continue;  // wholly above the diagonal / past the sequence (wave-uniform)
+        const unsigned long long tl_b = TL_NOW();
         const char* ldsQ = ldsBuf + 0;
         const char* ldsDO = ldsBuf + TILE;
         f32x4_t s[NQT], dp[NQT];
@@ -938,40 +1007,39 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
             acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cc, dsB, acc_dk[d], 0, 0, 0);
           }
         }
+        tl_step += TL_NOW() - tl_b; tl_n += 1;
       }
     }
-    // dK^T / dV^T of this wave's key tile: row d = dt*16 + g*4 + e, col key = fr (per query head under GQA: gqa_reduce_k sums)
-    if (j < nt && (pass < 2 || w < 4) && key < T) {
+    TL_STAMP(2 + 2 * pass);
+    // dK^T / dV^T of this wave's key tile: row d = dt*16 + g*4 + e, col key = fr (per query head under GQA: gqa_reduce_k sums);
+    // stored through the wave's LDS stage as whole 128-byte row segments
+    if (j < nt && (pass < 2 || w < 4)) {
+      u16x4_t ok[DT], ov[DT];
       if (p.dkv_part) {
-        bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dkv_part) + (((long long)b * T + key) * p.Hq + h) * D;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(acc_dk[d][e] * p.scale); ov[d][e] = f2bf(acc_dv[d][e]); }
+        bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dkv_part) + (((long long)b * T + j * 16) * p.Hq + h) * D;
         bf16_t* dvp = dkp + (long long)p.B * T * p.Hq * D;
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          u16x4_t a, c;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { a[e] = f2bf(acc_dk[d][e] * p.scale); c[e] = f2bf(acc_dv[d][e]); }
-          *reinterpret_cast<u16x4_t*>(dkp + d * 16 + g * 4) = a;
-          *reinterpret_cast<u16x4_t*>(dvp + d * 16 + g * 4) = c;
-        }
+        store_rows_staged<DT>(stage, ok, dkp, (long long)p.Hq * D, T - j * 16, lane);
+        store_rows_staged<DT>(stage, ov, dvp, (long long)p.Hq * D, T - j * 16, lane);
       } else {
-        bf16_t* dkrow = p.dk + ((long long)b * T + key) * p.lddk + hk * D;
-        bf16_t* dvrow = p.dv + ((long long)b * T + key) * p.lddv + hk * D;
         float dkv[DT][4];
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
           for (int e = 0; e < 4; ++e) dkv[d][e] = bf2f(f2bf(acc_dk[d][e] * p.scale));
-        if (p.rope) rope_inverse_tiles<DT>(dkv, p.rope, key, g);
+        if (p.rope) rope_inverse_tiles<DT>(dkv, p.rope, min(key, T - 1), g);
 #pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          u16x4_t a, c;
+        for (int d = 0; d < DT; ++d)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { a[e] = f2bf(dkv[d][e]); c[e] = f2bf(acc_dv[d][e]); }
-          *reinterpret_cast<u16x4_t*>(dkrow + d * 16 + g * 4) = a;
-          *reinterpret_cast<u16x4_t*>(dvrow + d * 16 + g * 4) = c;
-        }
+          for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(dkv[d][e]); ov[d][e] = f2bf(acc_dv[d][e]); }
+        store_rows_staged<DT>(stage, ok, p.dk + ((long long)b * T + j * 16) * p.lddk + hk * D, p.lddk, T - j * 16, lane);
+        store_rows_staged<DT>(stage, ov, p.dv + ((long long)b * T + j * 16) * p.lddv + hk * D, p.lddv, T - j * 16, lane);
       }
     }
+    TL_STAMP(3 + 2 * pass);
   }
 
   // ---- phase 2: dQ ----
@@ -991,6 +1059,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
     const char* ldsK = ldsBuf + (kc & 1) * TILE;
     if (kc + 1 < nch) load_nat<D, CH, 512>(rk, kbase, p.ldk, (kc + 1) * CH, T, tid);
     __syncthreads();                                // chunk kc is in place (and chunk kc - 1's buffer is no longer read)
+    const unsigned long long tl_c = TL_NOW();
 #pragma unroll
     for (int z = 0; z < 3; ++z) {
       const int i = qi[z];
@@ -1014,27 +1083,29 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
         }
       }
     }
+    tl_p2 += TL_NOW() - tl_c;
     if (kc + 1 < nch) store_nat<D, CH, 512>(ldsBuf + ((kc + 1) & 1) * TILE, rk, tid);
   }
+  TL_STAMP(8);
 #pragma unroll
   for (int z = 0; z < 3; ++z) {
+    if (qi[z] >= nt) continue;                      // wave-uniform
     const int q = qi[z] * 16 + fr;
-    if (qi[z] >= nt || q >= T) continue;
-    bf16_t* dqrow = p.dq + ((long long)b * T + q) * p.lddq + h * D;
     float dqv[DT][4];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int e = 0; e < 4; ++e) dqv[d][e] = bf2f(f2bf(acc[z][d][e] * p.scale));
-    if (p.rope) rope_inverse_tiles<DT>(dqv, p.rope, q, g);
+    if (p.rope) rope_inverse_tiles<DT>(dqv, p.rope, min(q, T - 1), g);
+    u16x4_t oq[DT];
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      u16x4_t a;
+    for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] = f2bf(dqv[d][e]);
-      *reinterpret_cast<u16x4_t*>(dqrow + d * 16 + g * 4) = a;
-    }
+      for (int e = 0; e < 4; ++e) oq[d][e] = f2bf(dqv[d][e]);
+    store_rows_staged<DT>(stage, oq, p.dq + ((long long)b * T + qi[z] * 16) * p.lddq + h * D, p.lddq, T - qi[z] * 16, lane);
   }
+  TL_STAMP(9);
+  TL_PUT(10, tl_step); TL_PUT(11, tl_wait); TL_PUT(12, tl_n); TL_PUT(13, tl_p2);
 }
 
 // dk/dv[b, t, hk, :] = sum over the GQA group (fixed order, f32) of the bf16 per-query-head results; with `rope` the summed dK is
@@ -1124,6 +1195,7 @@ int check_desc(const uvx::AttnDesc& d) {
 namespace uvx {
 
 int g_attn_qt = 0;  // probes: force the forward kernel's q-tile count (0 = automatic)
+void* g_attn_tl = nullptr;  // probes build: stamp buffer of the fused backward kernel (uvx_probe_attn_timeline)
 // bf16 kernels read transposed operands out of the NATURAL tiles with ds_read_b64_tr_b16 (tuning option 12, default on):
 // callers then skip heads_transpose and may leave vt / qt / kt / dot null
 bool attention_tr_reads(int dtype) { return dtype == DT_BF16 && g_options[12] != 0; }
@@ -1182,6 +1254,7 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   a.dkv_part = (d.f.Hq != d.f.Hkv) ? d.dkv_part : nullptr;
   a.o = (bf16_t*)d.f.o;
   a.rope = d.rope_cos_sin;
+  a.tl = (unsigned long long*)g_attn_tl;
   // dQ first: it computes delta = rowsum(dO * O) on the fly and leaves it in d.delta for the dK/dV kernel
   const int kv_heads = a.dkv_part ? d.f.Hq : d.f.Hkv;
   dim3 gk(kv_heads, d.f.B, cdiv(d.f.T, 64)), gk128(kv_heads, d.f.B, cdiv(d.f.T, 128)), gq(d.f.Hq, d.f.B, cdiv(d.f.T, 64));
@@ -1201,7 +1274,8 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   constexpr int FUSED_TMAX = 320;
   const bool fused = tr && d.f.D == 128 && d.f.causal && d.f.block == 0 && d.f.T <= FUSED_TMAX && g_options[13];
   if (fused) {
-    constexpr int smem = (FUSED_TMAX / 16) * (FUSED_TMAX / 16 + 1) / 2 * 512 + 2 * 64 * 128 * 2 + 2 * FUSED_TMAX * 4;
+    constexpr int smem = (FUSED_TMAX / 16) * (FUSED_TMAX / 16 + 1) / 2 * 512 + 2 * 64 * 128 * 2 + 2 * FUSED_TMAX * 4 + 8 * STAGE_BYTES;
+    static_assert(smem <= 160 * 1024, "LDS of one CU");
     static bool attr_set = false;
     if (!attr_set) {
       UVX_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_k<128, FUSED_TMAX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
