@@ -48,7 +48,10 @@ struct AttnArgs {
 #define TL_STAMP(s) do { if (p.tl && lane == 0) p.tl[((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * 16 + (s)] = __builtin_readcyclecounter(); } while (0)
 #define TL_NOW() (p.tl ? __builtin_readcyclecounter() : 0ULL)
 #define TL_PUT(s, v) do { if (p.tl && lane == 0) p.tl[((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * 16 + (s)] = (v); } while (0)
+#define TLF_IDX ((((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + w) * 16
+#define TLF_PUT(s, v) do { if (p.tl && lane == 0) p.tl[TLF_IDX + (s)] = (v); } while (0)
 #else
+#define TLF_PUT(s, v) do {} while (0)
 #define TL_STAMP(s) do {} while (0)
 #define TL_NOW() 0ULL
 #define TL_PUT(s, v) do {} while (0)
@@ -257,6 +260,9 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
 
+  const unsigned long long tlf0 = TL_NOW();
+  unsigned long long tl_s = 0, tl_sm = 0, tl_pv = 0, tl_cm = 0, tl_it = 0;
+  (void)tlf0; (void)tl_s; (void)tl_sm; (void)tl_pv; (void)tl_cm; (void)tl_it;
   // Q fragments (B operand): Q[q = fr][d = ks*32 + g*8 ..]
   bf16x8_t qf[QT][KS];
 #pragma unroll
@@ -303,8 +309,11 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
     }
   }
   __syncthreads();
+  const unsigned long long tlf1 = TL_NOW();
+  (void)tlf1;
   int cur = 0;
   for (int kb = kb_begin; kb < kb_end; kb += 64, cur ^= 1) {
+    const unsigned long long tla = TL_NOW();
     const char* ldsK = ldsKV + cur * 2 * TILE;
     const char* ldsV = ldsK + TILE;
     // issue the next tile's global loads now; they land while this tile computes (the last iteration re-loads
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
         for (int t = 0; t < QT; ++t) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[t][kt], 0, 0, 0);
       }
 
+    const unsigned long long tlb = TL_NOW();
     // ---- online softmax (per lane: q = fr; keys kb + kt*16 + g*4 + e) ----
     // A tile needs per-element masking only at the edges (padding, diagonal, latency-block boundary); the
     // test is wave-uniform, so interior tiles skip all of the integer mask arithmetic.
@@ -375,6 +385,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
           s[t][kt][e] = pv;
           ps += pv;
         }
+      // (the two-wide forms of this scale + row sum - v_pk_fma_f32 / v_pk_add_f32, 29 VALU instructions fewer per 64-key tile - were
+      //  measured neutral on the encoder shape: profiles/r03_attn_fwd_timeline.txt)
       l_run[t] = l_run[t] * alpha + ps;
       if (__any(changed)) {  // wave-uniform: once the running max has settled the O rescale is skipped (alpha == 1 exactly)
 #pragma unroll
@@ -389,6 +401,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
       }
     }
 
+    const unsigned long long tlc = TL_NOW();
     // ---- O^T += V^T . P^T ----
 #pragma unroll
     for (int d = 0; d < DT; ++d)
@@ -401,12 +414,17 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) acc_o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][kp], acc_o[t][d], 0, 0, 0);
       }
+    const unsigned long long tld = TL_NOW();
     // the other buffer was last read one iteration ago, before the previous barrier
     store_nat<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE, kreg, tid);
     if constexpr (TR) store_nat<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE + TILE, vnreg, tid);
     else store_tr<D, 64>(ldsKV + (cur ^ 1) * 2 * TILE + TILE, vreg, tid);
     __syncthreads();
+    const unsigned long long tle = TL_NOW();
+    tl_s += tlb - tla; tl_sm += tlc - tlb; tl_pv += tld - tlc; tl_cm += tle - tld; tl_it += 1;
   }
+  const unsigned long long tlf2 = TL_NOW();
+  (void)tlf2;
 
   // ---- epilogue ----
   // (after the loop's last barrier nobody reads the K / V tiles any more: each wave stages its O rows through a private piece
@@ -429,6 +447,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
       store_rows<DT>(stage, o4, p.o + ((long long)b * p.T + q0 + t * 16) * p.ldo + h * D, p.ldo, p.T - (q0 + t * 16), lane);
     if (p.lse && g == 0 && q < p.T) p.lse[((long long)b * p.Hq + h) * p.T + q] = l > 0.f ? m_run[t] + log2f(l) : __builtin_huge_valf();
   }
+  TLF_PUT(0, tlf0); TLF_PUT(1, tlf1); TLF_PUT(2, tlf2); TLF_PUT(3, TL_NOW());
+  TLF_PUT(4, tl_s); TLF_PUT(5, tl_sm); TLF_PUT(6, tl_pv); TLF_PUT(7, tl_cm); TLF_PUT(8, tl_it);
 }
 
 // =================================== backward: dK, dV ===================================
@@ -1209,6 +1229,7 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
   int rc = check_desc(d);
   if (rc) return rc;
   AttnArgs a = make_args(d);
+  a.tl = (unsigned long long*)g_attn_tl;
   // q rows per block = 64 * QT.  Long sequences (the encoder's 1500 frames) want QT = 2 for K/V reuse; short
   // ones (the LLM's few hundred tokens) are latency-bound and want more, smaller blocks and fewer registers.
   // (the probe override applies to the head_dim-64 kernels only - the encoder's; the others have one or two instantiations)
