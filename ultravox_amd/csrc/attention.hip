@@ -908,35 +908,15 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
   TL_STAMP(0);
   unsigned long long tl_step = 0, tl_wait = 0, tl_n = 0, tl_p2 = 0;
   (void)tl_step; (void)tl_wait; (void)tl_n; (void)tl_p2;
-  // ---- prologue: delta and log-sum-exp ----
-  // (every load of the prologue is issued before the first is used: ten dependent round trips to HBM, one per 32 rows, were 14 % of
-  //  the kernel - profiles/r03_attn_timeline.txt; rows >= T repeat row T - 1 and are discarded)
-  {
-    static_assert(D / 16 == 8, "one 16-byte load per thread and row");
-    constexpr int NIT = TMAX / 32;
-    u16x8_t pa[NIT], po[NIT];
-    const int c = (tid & 15) * 8;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = min(it * 32 + (tid >> 4), T - 1);
-      pa[it] = *reinterpret_cast<const u16x8_t*>(dobase + (long long)row * p.ldo + c);
-      po[it] = *reinterpret_cast<const u16x8_t*>(obase + (long long)row * p.ldo + c);
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      float dl = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dl += bf2f(pa[it][e]) * bf2f(po[it][e]);
-      dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64); dl += __shfl_xor(dl, 8, 64);
-      const int row = it * 32 + (tid >> 4);
-      if ((tid & 15) == 0) ldsDl[row] = row < T ? dl : 0.f;
-    }
-  }
+  // ---- prologue: the saved log-sum-exp.  delta[q] = rowsum(dO * O) is computed chunk by chunk while pass 0 stages its Q / dO
+  // chunks (the O rows ride along with that prefetch): as a prologue of its own it cost 12-20K cycles of pure HBM time - every
+  // block of the launch asking for its 160 KB of dO and O at once (profiles/r03_attn_timeline.txt)
   for (int r = tid; r < TMAX; r += 512) ldsLse[r] = r < T ? p.lse[((long long)b * p.Hq + h) * T + r] : __builtin_huge_valf();
 
   TL_STAMP(1);
   // ---- phase 1: dK, dV, dS ----
-  NatRegs<D, CH, 512> rq, rdo;
+  NatRegs<D, CH, 512> rq, rdo, ro;
+  static_assert(sizeof(rdo.v) / sizeof(rdo.v[0]) == 2 && D / 8 == 16, "delta: a row's 16 chunks sit in 16 consecutive threads");
 #pragma unroll 1
   for (int pass = 0; pass < 3; ++pass) {
     const int j = pass == 0 ? w : (pass == 1 ? 15 - w : 16 + w);          // this wave's key tile
@@ -961,17 +941,30 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
     const int c_first = (j_min * 16) / CH;         // causal: queries below the pass's first key see none of its keys
     load_nat<D, CH, 512>(rq, qbase, p.ldq, c_first * CH, T, tid);
     load_nat<D, CH, 512>(rdo, dobase, p.ldo, c_first * CH, T, tid);
+    if (pass == 0) load_nat<D, CH, 512>(ro, obase, p.ldo, 0, T, tid);
 #pragma unroll 1
     for (int c = c_first; c < nch; ++c) {
       const unsigned long long tl_a = TL_NOW();
       __syncthreads();                              // every wave is done with the previous chunk (and, first, the prologue)
       store_nat<D, CH, 512>(ldsBuf, rq, tid);
       store_nat<D, CH, 512>(ldsBuf + TILE, rdo, tid);
+      if (pass == 0) {                              // delta of this chunk's rows (pass 0 visits every chunk)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          float dl = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dl += bf2f(rdo.v[k][e]) * bf2f(ro.v[k][e]);
+          dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64); dl += __shfl_xor(dl, 8, 64);
+          const int row = c * CH + (tid >> 4) + 32 * k;
+          if ((tid & 15) == 0) ldsDl[row] = row < T ? dl : 0.f;   // (rows >= T were loaded as copies of row T - 1)
+        }
+      }
       __syncthreads();
       tl_wait += TL_NOW() - tl_a;
       if (c + 1 < nch) {                            // next chunk's loads fly under this chunk's products
         load_nat<D, CH, 512>(rq, qbase, p.ldq, (c + 1) * CH, T, tid);
         load_nat<D, CH, 512>(rdo, dobase, p.ldo, (c + 1) * CH, T, tid);
+        if (pass == 0) load_nat<D, CH, 512>(ro, obase, p.ldo, (c + 1) * CH, T, tid);
       }
       if (!have) continue;
 #pragma unroll 1
