@@ -165,6 +165,8 @@ def test_every_entry_point_survives_an_all_null_call():
         f.restype = ctypes.c_int32
         rc = f(*([ctypes.c_void_p(0)] * 24))
         assert rc in (0, -1, -2), (name, rc)
+        if name == "uvx_probe_attn_timeline":          # probes-build feature: the product library refuses a stamp buffer
+            assert f(ctypes.c_void_p(64)) == -4 and b"libuvx_probes.so" in lib.uvx_last_error()
         if rc != 0:
             rejected += 1
             assert lib.uvx_last_error(), name

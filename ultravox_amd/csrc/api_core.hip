@@ -24,7 +24,7 @@ extern "C" int32_t uvx_probe_attn_timeline(void* stamps) {
   uvx::g_attn_tl = stamps;
   return UVX_OK;
 #else
-  (void)stamps;
+  if (!stamps) return UVX_OK;   // "off" is what this build always is
   UVX_CHECK(false, UVX_ERR_UNSUPPORTED, "uvx_probe_attn_timeline: the stamps exist in libuvx_probes.so only (built with -DUVX_PROBES)");
 #endif
 }
