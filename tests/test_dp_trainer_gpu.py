@@ -124,7 +124,7 @@ def test_bench_self_launches_two_ranks():
     # the diagnostics a first real N > 1 run needs: every rank's own time, the exposed part of the all-reduce per rank
     pr, ex = out["per_rank_ms"], out["allreduce_exposed_ms_per_step"]
     assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - out["ms_per_step"]) < 1e-6 * out["ms_per_step"] + 1e-9
-    assert len(ex["all"]) == 2 and all(x >= 0.0 for x in ex["all"]) and ex["max"] == max(ex["all"])
+    assert len(ex["all"]) == 2 and all(x >= 0.0 for x in ex["all"]) and abs(ex["max"] - max(ex["all"])) < 1e-3   # (the list is rounded)
 
 
 def test_uvx_comm_one_rank_rccl_group_and_trainer_route():
