@@ -246,7 +246,9 @@ __global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, 
 
 // One block handles `rpb` consecutive rows; each thread owns fixed columns so the weight gradient
 // is accumulated in registers and flushed with one atomicAdd per column per block.
-template <typename T, bool WANT_DX, bool WANT_DW>
+// MV: 8-element vectors per thread (static trip count; the launcher picks the smallest that covers the row - at the LLM's 4096
+// columns MV = 2 needs half the registers of MV = 6 and twice as many rows are in flight per CU)
+template <typename T, bool WANT_DX, bool WANT_DW, int MV>
 __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
                               const T* __restrict__ dx_add, T* __restrict__ dx, float* __restrict__ dw,
                               int rows, int cols, float eps, int rpb, int flavor) {
@@ -254,10 +256,10 @@ __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
   // d w gets the UNROUNDED x_hat
   __shared__ float red[16];
   __shared__ float red2[16];
-  float dwacc[MAXV][8];
+  float dwacc[MV][8];
   if (WANT_DW) {
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j)
+    for (int j = 0; j < MV; ++j)
 #pragma unroll
       for (int i = 0; i < 8; ++i) dwacc[j][i] = 0.f;
   }
@@ -268,12 +270,12 @@ __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
     const T* dyr = dy + (long long)row * cols;
     float s1 = 0.f, s2 = 0.f;
     // the row is read from global memory ONCE: x, dy and w stay in registers between the reduction and the update
-    // (static trip count MAXV; the launcher guarantees cols <= MAXV * blockDim.x * 8)
+    // (static trip count MV; the launcher guarantees cols <= MV * blockDim.x * 8)
     // (only where it fits the register budget: bf16 without the weight-gradient accumulators - the hot, frozen-LLM case)
     constexpr bool CACHE = sizeof(T) == 2 && !WANT_DW;
-    Raw8<T> xc[CACHE ? MAXV : 1], gc[CACHE ? MAXV : 1];   // raw storage type: 4 registers per 8 bf16
+    Raw8<T> xc[CACHE ? MV : 1], gc[CACHE ? MV : 1];   // raw storage type: 4 registers per 8 bf16
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
+    for (int j = 0; j < MV; ++j) {
       const int c = (j * blockDim.x + threadIdx.x) * 8;
       if (c >= cols) continue;
       Raw8<T> xr8, gr8;
@@ -291,7 +293,7 @@ __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
     const float r = rsqrtf(s1 / cols + eps);
     const float coef = r * r * r * s2 / cols;
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {  // static trip count: dwacc[j] must stay in registers
+    for (int j = 0; j < MV; ++j) {  // static trip count: dwacc[j] must stay in registers
       const int c = (j * blockDim.x + threadIdx.x) * 8;
       if (c >= cols) continue;
       float xv[8], gv[8], wv[8];
@@ -317,7 +319,7 @@ __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
   }
   if (WANT_DW) {
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
+    for (int j = 0; j < MV; ++j) {
       const int c = (j * blockDim.x + threadIdx.x) * 8;
       if (c >= cols) continue;
 #pragma unroll
@@ -406,14 +408,23 @@ int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, v
 template <typename T>
 static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const void* w, const void* dx_add,
                           void* dx, float* dw, int rows, int cols, float eps, int flavor) {
-  const int th = 256;
+  const int th = 256;   // (512 threads with one vector each: 20.4 vs 17.7 us at 2528 x 4096 - profiles/r03_rmsnorm_bwd_variants.txt)
   UVX_CHECK(cols % 8 == 0 && cols <= th * 8 * MAXV, UVX_ERR_SHAPE, "rmsnorm_bwd: cols=%d unsupported", cols);
   if (rows == 0) return UVX_OK;
   const int rpb = dw ? 16 : 1;
   const int grid = (rows + rpb - 1) / rpb;
-#define L(DX, DW)                                                                                         \
-  hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x, \
-                     (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor)
+#define L(DX, DW)                                                                                                 \
+  do {                                                                                                            \
+    if (cols <= th * 8)                                                                                           \
+      hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, 1>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x,   \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor);               \
+    else if (cols <= th * 8 * 2)                                                                                  \
+      hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, 2>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x,   \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor);               \
+    else                                                                                                          \
+      hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, MAXV>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x, \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor);               \
+  } while (0)
   if (dx && dw) L(true, true);
   else if (dx) L(true, false);
   else if (dw) L(false, true);
