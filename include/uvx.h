@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 9
+#define UVX_ABI_VERSION 10
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -64,6 +64,10 @@ typedef struct {
   /* activation of the gated MLP ([3P] ACT2FN[text_config.hidden_act]): UVX_ACT_SILU (Llama), UVX_ACT_GELU_TANH
    * (gelu_pytorch_tanh, Gemma's default), UVX_ACT_GELU_ERF (exact GELU: Gemma checkpoints whose config says "gelu") */
   int32_t llm_act;
+  /* Qwen3 (the reference's v0.6 recipe trains on Qwen/Qwen3-32B, ultravox/training/configs/v0.6_config_qwen3_32b.yaml): q_norm /
+   * k_norm, an RMSNorm over head_dim on every head of q and k BEFORE the rotary embedding ([3P] modeling_qwen3.py Qwen3Attention).
+   * Non-zero: uvx_llm_layer_t.q_norm / k_norm must be set, and training workspaces keep the un-normalised q | k rows per layer. */
+  int32_t llm_qk_norm;
 } uvx_config_t;
 #define UVX_ACT_SILU 0
 #define UVX_ACT_GELU_TANH 1
@@ -116,6 +120,9 @@ typedef struct {
 typedef struct {
   const void *ln1, *wqkv, *wo, *ln2, *wgu, *wd;
   const void *wqkv_t, *wo_t, *wgu_t, *wd_t;
+  /* family extras, NULL when the family has none.  bqkv: [q;k;v] projection biases [(H+2Hkv)*dh] (Qwen2: q_proj / k_proj / v_proj
+   * carry a bias, o_proj does not - [3P] modeling_qwen2.py Qwen2Attention); q_norm, k_norm: [dh] (Qwen3, see llm_qk_norm). */
+  const void *bqkv, *q_norm, *k_norm;
 } uvx_llm_layer_t;
 typedef struct {
   const void* embed;             /* [vocab, D] */
@@ -404,6 +411,14 @@ int32_t uvx_swiglu_bwd(void* stream, int32_t dtype, const void* dout, const void
                        int32_t half, int32_t gate_first);
 int32_t uvx_rope(void* stream, int32_t dtype, void* x, const float* cos_sin, int32_t rows, int32_t T, int32_t n_heads,
                  int32_t head_dim, int32_t ld, int32_t inverse);
+/* Qwen3 q_norm / k_norm + rotary embedding in one pass, in place on the q | k columns of qkv [rows, ld] (heads of width head_dim:
+ * Hq query heads, then Hkv key heads; position of row r = r % T); wq / wk [head_dim]; raw = NULL or [rows, (Hq + Hkv) * head_dim],
+ * receives the un-normalised q | k rows.  uvx_qk_norm_bwd: d_qkv's q | k columns hold the gradient of the normalised (pre-rotary)
+ * rows on entry and the gradient of the raw rows on return. */
+int32_t uvx_qk_norm_rope(void* stream, int32_t dtype, void* qkv, const void* wq, const void* wk, void* raw, const float* cos_sin,
+                         int32_t rows, int32_t T, int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t ld, float eps);
+int32_t uvx_qk_norm_bwd(void* stream, int32_t dtype, void* d_qkv, const void* raw, const void* wq, const void* wk, int32_t rows,
+                        int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t ld, float eps);
 
 typedef struct {
   const void *q, *k, *v; /* [B, T, H, D] views with token strides ldq/ldk/ldv (elements) */

@@ -130,10 +130,21 @@ def test_configs_outside_the_built_arithmetic_are_refused_not_run_as_llama():
     from ultravox_amd.config import UltravoxConfig
     ok_text = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1, vocab_size=128)
     UltravoxConfig(text_config={**ok_text, "model_type": "llama", "attention_bias": False, "tie_word_embeddings": False})
-    for bad in ({"model_type": "qwen2"}, {"attention_bias": True}, {"mlp_bias": True}, {"sliding_window": 4096},
-                {"tie_word_embeddings": True}, {"hidden_act": "gelu_pytorch_tanh"}):
+    for bad in ({"model_type": "mistral"}, {"attention_bias": True}, {"mlp_bias": True}, {"sliding_window": 4096},
+                {"tie_word_embeddings": True}, {"hidden_act": "gelu_pytorch_tanh"},
+                {"model_type": "qwen2", "sliding_window": 4096, "use_sliding_window": True}, {"model_type": "qwen3", "attention_bias": True},
+                {"model_type": "qwen3", "layer_types": ["sliding_attention"]}):
         with pytest.raises(ValueError):
             UltravoxConfig(text_config={**ok_text, **bad})
+    # the Qwen families (the reference's v0.6 recipe: Qwen/Qwen3-32B): built; their configs always carry a sliding_window VALUE,
+    # which is live only with use_sliding_window
+    q3 = UltravoxConfig(text_config={**ok_text, "model_type": "qwen3", "head_dim": 64, "sliding_window": 4096, "use_sliding_window": False,
+                                     "layer_types": ["full_attention"]}).text_config
+    assert q3.has_qk_norm and not q3.has_qkv_bias and q3.head_dim == 64 and q3.hidden_act == "silu" and not q3.ties_head
+    q2 = UltravoxConfig(text_config={**ok_text, "model_type": "qwen2", "tie_word_embeddings": True}).text_config
+    assert q2.has_qkv_bias and not q2.has_qk_norm and q2.ties_head and q2.head_dim == 32
+    big = UltravoxConfig(text_model_id="Qwen/Qwen3-32B").text_config
+    assert (big.hidden_size, big.num_attention_heads, big.num_key_value_heads, big.head_dim, big.intermediate_size) == (5120, 64, 8, 128, 25600)
     with pytest.raises(ValueError, match="model_type"):
         UltravoxConfig(audio_config={"model_type": "hubert", "d_model": 64})
     # the families that ARE built (BASELINE config 5): Gemma backbone, wav2vec2-large-960h-style tower - and their unbuilt variants

@@ -378,6 +378,50 @@ def test_gemma_backbone_matches_hf_blocks(hidden_act):
     assert float(torch.tensor(3072 ** 0.5, dtype=torch.bfloat16)) == 55.5
 
 
+@pytest.mark.parametrize("family", ["qwen3", "qwen2"])
+def test_qwen_backbones_match_hf_blocks(family):
+    """The reference's v0.6 recipe trains on Qwen/Qwen3-32B (ultravox/training/configs/v0.6_config_qwen3_32b.yaml), reached through
+    the same AutoModelForCausalLM call as Llama (ultravox_model.py:499-526).  [3P] check: the oracle's qwen3 flavour (RMSNorm over
+    head_dim on every q / k head before RoPE, head_dim independent of hidden_size / heads) and qwen2 flavour (q / k / v biases)
+    == the installed HF Qwen3ForCausalLM / Qwen2ForCausalLM on the same weights: logits, loss, and the gradient that reaches
+    inputs_embeds (what the adapter-training path back-propagates through the frozen LLM)."""
+    import transformers
+    kw = dict(hidden_size=96, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+              vocab_size=160, rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=512)
+    if family == "qwen3":
+        kw["head_dim"] = 32
+    cfg = UltravoxConfig(audio_config=TINY["audio_config"], hidden_size=64, text_config=dict(model_type=family, **kw))
+    t = cfg.text_config
+    assert t.has_qk_norm == (family == "qwen3") and t.has_qkv_bias == (family == "qwen2") and t.hidden_act == "silu"
+    assert (t.head_dim * t.num_attention_heads != t.hidden_size) == (family == "qwen3")
+    Cfg, LM = ((transformers.Qwen3Config, transformers.Qwen3ForCausalLM) if family == "qwen3"
+               else (transformers.Qwen2Config, transformers.Qwen2ForCausalLM))
+    hf = LM(Cfg(**kw, tie_word_embeddings=False, attn_implementation="eager")).eval()
+    sd = random_state_dict(cfg, seed=6)
+    llm_sd = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}
+    missing, unexpected = hf.load_state_dict(llm_sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    extra = [k for k in llm_sd if k.endswith(("q_norm.weight", "k_norm.weight", "_proj.bias"))]
+    assert len(extra) == (4 if family == "qwen3" else 6)                  # the family's extras exist and were consumed
+    torch.manual_seed(0)
+    B, T = 2, 19
+    labels = torch.randint(0, 160, (B, T))
+    labels[:, :9] = -100
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, -4:] = 0
+    emb_hf = (torch.randn(B, T, 96) * 0.1).requires_grad_(True)
+    emb_or = emb_hf.detach().clone().requires_grad_(True)
+    out = hf(inputs_embeds=emb_hf, attention_mask=am, labels=labels)
+    out.loss.backward()
+    logits = O.llama_ref(sd, cfg, emb_or, am)
+    loss = O.causal_lm_loss_ref(logits, labels)
+    loss.backward()
+    keep = am.bool()
+    np.testing.assert_allclose(logits.detach()[keep].numpy(), out.logits.detach()[keep].numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(loss.item(), out.loss.item(), rtol=1e-5)
+    np.testing.assert_allclose(emb_or.grad[keep].numpy(), emb_hf.grad[keep].numpy(), rtol=2e-4, atol=1e-7)
+
+
 W2V_TINY = {"model_type": "wav2vec2", "hidden_size": 64, "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 128,
             "conv_dim": [64] * 7, "num_conv_pos_embeddings": 16, "num_conv_pos_embedding_groups": 4}
 

@@ -102,9 +102,12 @@ class AudioConfig:
 
 @dataclasses.dataclass
 class TextConfig:
-    """Field names of transformers.LlamaConfig / GemmaConfig that the LLM path reads.  model_type "llama" (default) or "gemma"
-    (BASELINE.json config 5, the alt backbone behind AutoModelForCausalLM, ultravox_model.py:499-526): GemmaRMSNorm, GeGLU
-    (hidden_act gelu_pytorch_tanh), sqrt(hidden_size) embedding scale, explicit head_dim, lm_head tied to embed_tokens."""
+    """Field names of transformers.LlamaConfig / GemmaConfig / Qwen2Config / Qwen3Config that the LLM path reads.  model_type
+    "llama" (default); "gemma" (BASELINE.json config 5, the alt backbone behind AutoModelForCausalLM, ultravox_model.py:499-526):
+    GemmaRMSNorm, GeGLU (hidden_act gelu_pytorch_tanh), sqrt(hidden_size) embedding scale, explicit head_dim, lm_head tied to
+    embed_tokens; "qwen3" (the reference's v0.6 recipe, ultravox/training/configs/v0.6_config_qwen3_32b.yaml: text_model
+    Qwen/Qwen3-32B): a Llama block with an RMSNorm over head_dim on every q / k head before RoPE, explicit head_dim; "qwen2": a
+    Llama block whose q / k / v projections carry biases."""
     model_type: str = "llama"
     hidden_act: Optional[str] = None            # None = the family's own: silu (llama), gelu_pytorch_tanh (gemma)
     # None = the family's [3P] default (transformers LlamaConfig / GemmaConfig), so that a config.json that leaves a field
@@ -132,11 +135,19 @@ class TextConfig:
         "gemma": dict(hidden_size=3072, intermediate_size=24576, num_hidden_layers=28, num_attention_heads=16,
                       num_key_value_heads=16, head_dim=256, vocab_size=256000, rms_norm_eps=1e-6,
                       max_position_embeddings=8192, eos_token_id=1, tie_word_embeddings=True),
+        # [3P] transformers Qwen2Config / Qwen3Config defaults
+        "qwen2": dict(hidden_size=4096, intermediate_size=22016, num_hidden_layers=32, num_attention_heads=32,
+                      num_key_value_heads=32, vocab_size=151936, rms_norm_eps=1e-6, max_position_embeddings=32768,
+                      tie_word_embeddings=False),
+        "qwen3": dict(hidden_size=4096, intermediate_size=22016, num_hidden_layers=32, num_attention_heads=32,
+                      num_key_value_heads=32, head_dim=128, vocab_size=151936, rms_norm_eps=1e-6,
+                      max_position_embeddings=32768, tie_word_embeddings=False),
     }
+    FAMILIES = ("llama", "gemma", "qwen2", "qwen3")
 
     def __post_init__(self):
-        if self.model_type not in ("llama", "gemma"):
-            raise ValueError(f"text_config.model_type {self.model_type!r} is not built (llama, gemma)")
+        if self.model_type not in self.FAMILIES:
+            raise ValueError(f"text_config.model_type {self.model_type!r} is not built ({', '.join(self.FAMILIES)})")
         for k, v in self._FAMILY_DEFAULTS[self.model_type].items():
             if getattr(self, k) is None:
                 setattr(self, k, v)
@@ -144,7 +155,7 @@ class TextConfig:
             self.num_key_value_heads = self.num_attention_heads
         if self.head_dim is None:
             self.head_dim = self.hidden_size // self.num_attention_heads
-        want = "silu" if self.model_type == "llama" else "gelu_pytorch_tanh"
+        want = "gelu_pytorch_tanh" if self.model_type == "gemma" else "silu"
         if self.hidden_act is None:
             self.hidden_act = want
         # [3P] GemmaMLP applies ACT2FN[config.hidden_act] (transformers 4.51.3 and the installed 5.x alike): "gelu" in a Gemma
@@ -155,6 +166,18 @@ class TextConfig:
     @property
     def is_gemma(self) -> bool:
         return self.model_type == "gemma"
+
+    @property
+    def has_qk_norm(self) -> bool:     # Qwen3Attention.q_norm / k_norm
+        return self.model_type == "qwen3"
+
+    @property
+    def has_qkv_bias(self) -> bool:    # Qwen2Attention: q_proj / k_proj / v_proj with bias, o_proj without
+        return self.model_type == "qwen2"
+
+    @property
+    def ties_head(self) -> bool:       # lm_head IS embed_tokens (Gemma always; Qwen checkpoints that say so)
+        return self.model_type == "gemma" or (self.model_type in ("qwen2", "qwen3") and bool(self.tie_word_embeddings))
 
 
 AUDIO_PRESETS: Dict[str, Dict[str, Any]] = {
@@ -196,6 +219,18 @@ TEXT_PRESETS["google/gemma-7b"] = dict(model_type="gemma", hidden_size=3072, int
 TEXT_PRESETS["google/gemma-2b"] = dict(model_type="gemma", hidden_size=2048, intermediate_size=16384, num_hidden_layers=18,
                                        num_attention_heads=8, num_key_value_heads=1, head_dim=256, vocab_size=256000,
                                        rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=8192, eos_token_id=1)
+# Qwen (public config.json values; the reference's v0.6 recipe names Qwen/Qwen3-32B).  head_dim 128 is NOT hidden_size / heads for
+# Qwen3-32B (5120 / 64 = 80)
+TEXT_PRESETS["Qwen/Qwen3-32B"] = dict(model_type="qwen3", hidden_size=5120, intermediate_size=25600, num_hidden_layers=64,
+                                      num_attention_heads=64, num_key_value_heads=8, head_dim=128, vocab_size=151936,
+                                      rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=40960, eos_token_id=151645)
+TEXT_PRESETS["Qwen/Qwen3-8B"] = dict(model_type="qwen3", hidden_size=4096, intermediate_size=12288, num_hidden_layers=36,
+                                     num_attention_heads=32, num_key_value_heads=8, head_dim=128, vocab_size=151936,
+                                     rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=40960, eos_token_id=151645)
+TEXT_PRESETS["Qwen/Qwen2.5-7B-Instruct"] = dict(model_type="qwen2", hidden_size=3584, intermediate_size=18944, num_hidden_layers=28,
+                                                num_attention_heads=28, num_key_value_heads=4, vocab_size=152064,
+                                                rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=32768,
+                                                eos_token_id=151645)
 TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat"] = TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat-v1.0"]
 TEXT_PRESETS["meta-llama/Meta-Llama-3-8B"] = TEXT_PRESETS["meta-llama/Meta-Llama-3-8B-Instruct"]
 
@@ -225,17 +260,21 @@ def _mk(cls, value, presets, model_id):
 def _check_supported(cls, get) -> None:
     """Fields outside the dataclass are dropped by _mk, so anything that would change the arithmetic must be refused here:
     a Qwen2 (q/k/v biases), Mistral (sliding window) or Gemma config would otherwise run silently as a bias-free Llama."""
-    want = ("llama", "gemma") if cls is TextConfig else ("whisper", "wav2vec2")
+    want = TextConfig.FAMILIES if cls is TextConfig else ("whisper", "wav2vec2")
     mt = get("model_type")
     if mt is not None and mt not in want:
         raise ValueError(f"{cls.__name__}: model_type {mt!r} is not built (this path implements {', '.join(want)})")
     if cls is TextConfig:
         for flag in ("attention_bias", "mlp_bias"):
             if get(flag):
-                raise ValueError(f"text_config.{flag} = True is not built (the LLM kernels are bias-free, as Llama is)")
-        if get("sliding_window"):
+                raise ValueError(f"text_config.{flag} = True is not built (only Qwen2's own q / k / v biases are; o_proj and the MLP "
+                                 "are bias-free in every family here)")
+        # Qwen2 / Qwen3 configs always carry a sliding_window VALUE; it is live only with use_sliding_window ([3P] Qwen2Config:
+        # "sliding_window if use_sliding_window else None") - layer_types other than full attention likewise
+        live_window = get("sliding_window") and (mt not in ("qwen2", "qwen3") or get("use_sliding_window"))
+        if live_window or any(lt != "full_attention" for lt in (get("layer_types") or ())):
             raise ValueError("text_config.sliding_window is not built (full causal attention only)")
-        if get("tie_word_embeddings") and mt != "gemma":     # Gemma ties by definition: the packer uses embed_tokens as the head
+        if get("tie_word_embeddings") and mt not in ("gemma", "qwen2", "qwen3"):     # Gemma ties by definition; Qwen: ties_head
             raise ValueError("text_config.tie_word_embeddings = True: pass the embedding matrix as lm_head.weight "
                              "(checkpoint.language_model_state_dict does this for tied checkpoints) and leave the flag unset")
 

@@ -121,6 +121,83 @@ __global__ void rope_k(T* __restrict__ x, const float* __restrict__ cs, const in
   st8<T>(base + D / 2 + c, ohi);
 }
 
+// Qwen3: per-head RMSNorm of q and k ([3P] transformers modeling_qwen3.py Qwen3Attention: q_norm / k_norm = Qwen3RMSNorm(head_dim)
+// on the projections viewed as [.., heads, head_dim], BEFORE the rotary embedding; Qwen3RMSNorm == LlamaRMSNorm: w * round(x_hat)),
+// fused with rope_k's rotary embedding (same arithmetic and rounding points as rmsnorm_fwd_k followed by rope_k: the normalised
+// row is rounded to the storage type before it is rotated).  One thread = the 8-column chunk c of the first half of a head and
+// its rotary partner c + D/2; the D/16 threads of a head share the sum of squares through wave shuffles.  raw != null: the
+// un-normalised q | k rows are kept ([rows, (Hq + Hkv) * D], the backward needs them); v is untouched.
+template <typename T>
+__global__ void qk_norm_rope_k(T* __restrict__ x, const T* __restrict__ wq, const T* __restrict__ wk, T* __restrict__ raw,
+                               const float* __restrict__ cs, const int32_t* __restrict__ pos, long long n_items, int Tlen, int Hq,
+                               int Hkv, int D, int ld, float eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;      // (whole heads: n_items is a multiple of D/16, a power of two that divides the block)
+  const int per_head = D / 16, H = Hq + Hkv;
+  const int per_row = H * per_head;
+  const long long row = i / per_row;
+  const int rem = (int)(i % per_row);
+  const int h = rem / per_head, c = (rem % per_head) * 8;
+  const int p = pos ? pos[row] : (int)(row % Tlen);
+  T* base = x + row * ld + h * D;
+  const T* w = h < Hq ? wq : wk;
+  float lo[8], hi[8], wl[8], wh[8], olo[8], ohi[8];
+  ld8<T>(base + c, lo);
+  ld8<T>(base + D / 2 + c, hi);
+  if (raw) {
+    T* r = raw + (row * H + h) * D;
+    st8<T>(r + c, lo);
+    st8<T>(r + D / 2 + c, hi);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ss += lo[k] * lo[k] + hi[k] * hi[k];
+  for (int m = 1; m < per_head; m <<= 1) ss += __shfl_xor(ss, m, 64);
+  const float rstd = rsqrtf(ss / D + eps);
+  ld8<T>(w + c, wl);
+  ld8<T>(w + D / 2 + c, wh);
+  const float* t = cs + ((long long)p * (D / 2) + c) * 2;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float nl = rnd<T>(wl[k] * rnd<T>(lo[k] * rstd)), nh = rnd<T>(wh[k] * rnd<T>(hi[k] * rstd));
+    const float co = rnd<T>(t[2 * k]), si = rnd<T>(t[2 * k + 1]);
+    olo[k] = rnd<T>(nl * co) + rnd<T>(-nh * si);
+    ohi[k] = rnd<T>(nh * co) + rnd<T>(nl * si);
+  }
+  st8<T>(base + c, olo);
+  st8<T>(base + D / 2 + c, ohi);
+}
+
+// Backward of the per-head norm (frozen weights: activation gradient only), in place on the q | k columns of d_qkv: dy = the
+// gradient of the NORMALISED rows (the attention backward's RoPE-inverted dq / dk), x = the raw rows the forward kept.
+// rmsnorm_bwd_k's arithmetic per row of D: r = rsqrt(mean(x^2) + eps), dx = r dy w - x r^3 mean(dy w x).  One thread = 8 columns.
+template <typename T>
+__global__ void qk_norm_bwd_k(T* __restrict__ dqk, const T* __restrict__ raw, const T* __restrict__ wq, const T* __restrict__ wk,
+                              long long n_items, int Hq, int Hkv, int D, int ld, float eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  const int per_head = D / 8, H = Hq + Hkv;
+  const int per_row = H * per_head;
+  const long long row = i / per_row;
+  const int rem = (int)(i % per_row);
+  const int h = rem / per_head, c = (rem % per_head) * 8;
+  T* g = dqk + row * ld + h * D + c;
+  const T* w = (h < Hq ? wq : wk) + c;
+  float xv[8], gv[8], wv[8], o[8];
+  ld8<T>(raw + (row * H + h) * D + c, xv);
+  ld8<T>(g, gv);
+  ld8<T>(w, wv);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1 += xv[k] * xv[k]; s2 += gv[k] * wv[k] * xv[k]; }
+  for (int m = 1; m < per_head; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  const float r = rsqrtf(s1 / D + eps);
+  const float coef = r * r * r * s2 / D;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = r * gv[k] * wv[k] - xv[k] * coef;
+  st8<T>(g, o);
+}
+
 template <typename T>
 __global__ void embed_gather_k(const T* __restrict__ table, const int64_t* __restrict__ ids, T* __restrict__ out,
                                long long n8, int D, int vocab) {
@@ -411,6 +488,40 @@ int rope_inplace(hipStream_t st, int dtype, void* x, const float* cos_sin, const
     hipLaunchKernelGGL(rope_k<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, (bf16_t*)x, cos_sin, pos, n, T, n_heads_rot, head_dim, ld, sgn);
   else
     hipLaunchKernelGGL(rope_k<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, (float*)x, cos_sin, pos, n, T, n_heads_rot, head_dim, ld, sgn);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int qk_norm_rope(hipStream_t st, int dtype, void* qkv, const void* wq, const void* wk, void* raw, const float* cos_sin,
+                 const int32_t* pos, int rows, int T, int Hq, int Hkv, int head_dim, int ld, float eps) {
+  UVX_CHECK((head_dim == 64 || head_dim == 128 || head_dim == 256) && ld % 8 == 0, UVX_ERR_SHAPE,
+            "qk_norm_rope: head_dim=%d ld=%d unsupported (64, 128 or 256; row stride a multiple of 8)", head_dim, ld);
+  UVX_CHECK(qkv && wq && wk && cos_sin, UVX_ERR_INVALID, "qk_norm_rope: null argument");
+  const long long n = (long long)rows * (Hq + Hkv) * (head_dim / 16);
+  if (n == 0) return UVX_OK;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(qk_norm_rope_k<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, (bf16_t*)qkv, (const bf16_t*)wq, (const bf16_t*)wk,
+                       (bf16_t*)raw, cos_sin, pos, n, T, Hq, Hkv, head_dim, ld, eps);
+  else
+    hipLaunchKernelGGL(qk_norm_rope_k<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, (float*)qkv, (const float*)wq, (const float*)wk,
+                       (float*)raw, cos_sin, pos, n, T, Hq, Hkv, head_dim, ld, eps);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int qk_norm_bwd(hipStream_t st, int dtype, void* d_qkv, const void* raw, const void* wq, const void* wk, int rows, int Hq, int Hkv,
+                int head_dim, int ld, float eps) {
+  UVX_CHECK((head_dim == 64 || head_dim == 128 || head_dim == 256) && ld % 8 == 0, UVX_ERR_SHAPE,
+            "qk_norm_bwd: head_dim=%d ld=%d unsupported", head_dim, ld);
+  UVX_CHECK(d_qkv && raw && wq && wk, UVX_ERR_INVALID, "qk_norm_bwd: null argument");
+  const long long n = (long long)rows * (Hq + Hkv) * (head_dim / 8);
+  if (n == 0) return UVX_OK;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(qk_norm_bwd_k<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, (bf16_t*)d_qkv, (const bf16_t*)raw, (const bf16_t*)wq,
+                       (const bf16_t*)wk, n, Hq, Hkv, head_dim, ld, eps);
+  else
+    hipLaunchKernelGGL(qk_norm_bwd_k<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, (float*)d_qkv, (const float*)raw, (const float*)wq,
+                       (const float*)wk, n, Hq, Hkv, head_dim, ld, eps);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

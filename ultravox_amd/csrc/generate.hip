@@ -300,6 +300,20 @@ int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, I
   return gemm(st, dt, d);
 }
 
+// q | k | v projection of a layer (+ Qwen2's biases), then the rotary embedding - for Qwen3 behind its per-head q_norm / k_norm
+int qkv_rope(hipStream_t st, const uvx_config_t& c, const uvx_llm_weights_t* w, const uvx_llm_layer_t& L, const void* n, void* qkv,
+             const int32_t* pos, int rows, int T, int QKV) {
+  const int dt = c.dtype, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads;
+  GemmDesc g = lin(n, L.wqkv, qkv, rows, QKV, c.llm_d);
+  g.bias = L.bqkv;
+  RC(gemm(st, dt, g));
+  if (c.llm_qk_norm) {
+    UVX_CHECK(L.q_norm && L.k_norm, UVX_ERR_INVALID, "llm: llm_qk_norm is set but a layer has no q_norm / k_norm");
+    return qk_norm_rope(st, dt, qkv, L.q_norm, L.k_norm, nullptr, w->rope_cos_sin, pos, rows, T, Hq, Hkv, dh, QKV, c.rms_eps);
+  }
+  return rope_inplace(st, dt, qkv, w->rope_cos_sin, pos, rows, T, Hq + Hkv, dh, QKV, 0);
+}
+
 }  // namespace
 
 extern "C" size_t uvx_kv_cache_bytes(const uvx_config_t* cfg, int32_t B, int32_t Tmax) {
@@ -336,8 +350,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
-    RC(gemm(st, dt, lin(s.n, L.wqkv, s.qkv, M, s.QKV, D)));
-    RC(rope_inplace(st, dt, s.qkv, w->rope_cos_sin, s.pos, M, T, Hq + Hkv, dh, s.QKV, 0));
+    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, T, s.QKV));
     {
       char* ck = at(kv_cache, l * layer_stride, dt);
       char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
@@ -420,8 +433,7 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
-    RC(gemm(st, dt, lin(s.n, L.wqkv, s.qkv, M, s.QKV, D)));
-    RC(rope_inplace(st, dt, s.qkv, w->rope_cos_sin, s.pos, M, Tn, Hq + Hkv, dh, s.QKV, 0));
+    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, Tn, s.QKV));
     char* ck = at(kv_cache, l * layer_stride, dt);
     char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
     const long long na = (long long)M * (KVD / 8), ng = (long long)B * Tf * (KVD / 8);
@@ -477,8 +489,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
-    RC(gemm(st, dt, lin(s.n, L.wqkv, s.qkv, B, s.QKV, D)));
-    RC(rope_inplace(st, dt, s.qkv, w->rope_cos_sin, positions, B, 1, Hq + Hkv, dh, s.QKV, 0));
+    RC(qkv_rope(st, c, w, L, s.n, s.qkv, positions, B, 1, s.QKV));
     char* ck = at(kv_cache, l * layer_stride, dt);
     char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
     const long long n = (long long)B * (KVD / 8);

@@ -91,6 +91,13 @@ int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void
 int scale_inplace(hipStream_t st, int dtype, void* x, long long n, float s);
 int rope_inplace(hipStream_t st, int dtype, void* qkv, const float* cos_sin, const int32_t* pos, int rows,
                  int T, int n_heads_rot, int head_dim, int ld, int inverse);
+// Qwen3 q_norm / k_norm (per-head RMSNorm, weights [head_dim]) fused with the rotary embedding, in place on the q | k columns of a
+// [rows, ld] q|k|v buffer; raw (or null) receives the un-normalised q | k rows [rows, (Hq + Hkv) * head_dim] for qk_norm_bwd,
+// which turns the gradient of the normalised rows (q | k columns of d_qkv) into the gradient of the raw ones, in place.
+int qk_norm_rope(hipStream_t st, int dtype, void* qkv, const void* wq, const void* wk, void* raw, const float* cos_sin,
+                 const int32_t* pos, int rows, int T, int Hq, int Hkv, int head_dim, int ld, float eps);
+int qk_norm_bwd(hipStream_t st, int dtype, void* d_qkv, const void* raw, const void* wq, const void* wk, int rows, int Hq, int Hkv,
+                int head_dim, int ld, float eps);
 int embed_gather(hipStream_t st, int dtype, const void* table, const int64_t* ids, void* out, int rows,
                  int D, int vocab);
 // owner[B*T] / item_batch[n_items] are int32 scratch filled by merge_owner and reused by the backward.

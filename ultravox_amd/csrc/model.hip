@@ -173,6 +173,7 @@ struct LlmLayerStash {
   void *x_in, *qkv, *o, *x_mid, *gu;
   float* lse;
   void *t, *bqT, *bkT;   // LLM LoRA (text_model_lora_config): [lora_A_q(n) | lora_A_k(n)] [M, 128]; lora_B^T of q / k
+  void* qk_raw;          // Qwen3 (llm_qk_norm): the q | k projections before q_norm / k_norm [M, (Hq + Hkv) * dh]
 };
 struct LlmWs {
   LlmLayerStash ls[1];   // layer-0 slot; slot i starts slot_bytes * i later
@@ -203,6 +204,7 @@ void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
   s.t = a.take(M * 128 * es);
   s.bqT = a.take((size_t)64 * c.llm_heads * c.llm_head_dim * es);
   s.bkT = a.take((size_t)64 * c.llm_kv_heads * c.llm_head_dim * es);
+  s.qk_raw = a.take(c.llm_qk_norm ? M * (c.llm_heads + c.llm_kv_heads) * c.llm_head_dim * es : 0);
 }
 LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
   LlmWs w;
@@ -255,7 +257,7 @@ LlmLayerStash llm_layer(const LlmWs& w, int slot) {
   const size_t d = w.slot_bytes * slot;
   s.x_in = (char*)s.x_in + d; s.qkv = (char*)s.qkv + d; s.o = (char*)s.o + d;
   s.x_mid = (char*)s.x_mid + d; s.gu = (char*)s.gu + d; s.lse = (float*)((char*)s.lse + d);
-  s.t = (char*)s.t + d; s.bqT = (char*)s.bqT + d; s.bkT = (char*)s.bkT + d;
+  s.t = (char*)s.t + d; s.bqT = (char*)s.bqT + d; s.bkT = (char*)s.bkT + d; s.qk_raw = (char*)s.qk_raw + d;
   return s;
 }
 
@@ -291,6 +293,7 @@ LlmWs llm_view(const LlmWs& w, const uvx_config_t& c, int b0, int nb, int T) {
   LlmLayerStash& s = v.ls[0];
   adv(s.x_in, r0 * D * es); adv(s.qkv, r0 * w.QKV * es); adv(s.o, r0 * w.OD * es); adv(s.x_mid, r0 * D * es);
   adv(s.gu, r0 * 2 * I * es); adv(s.lse, sizeof(float) * (size_t)b0 * c.llm_heads * T); adv(s.t, r0 * 128 * es);
+  if (c.llm_qk_norm) adv(s.qk_raw, r0 * (c.llm_heads + c.llm_kv_heads) * c.llm_head_dim * es);
   adv(v.x_final, r0 * D * es); adv(v.hn, r0 * D * es); adv(v.n, r0 * D * es); adv(v.act, r0 * I * es);
   adv(v.vt, (size_t)b0 * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
   adv(v.logits, r0 * c.vocab * es);
@@ -372,6 +375,8 @@ int check_cfg(const uvx_config_t* c) {
   UVX_CHECK(c->llm_flavor == UVX_LLM_LLAMA || c->llm_flavor == UVX_LLM_GEMMA, UVX_ERR_INVALID, "bad llm_flavor %d", c->llm_flavor);
   UVX_CHECK(c->llm_act >= UVX_ACT_SILU && c->llm_act <= UVX_ACT_GELU_ERF && (c->llm_flavor == UVX_LLM_GEMMA) == (c->llm_act != UVX_ACT_SILU),
             UVX_ERR_INVALID, "llm_act %d does not fit llm_flavor %d (Llama: SiLU; Gemma: tanh- or erf-GELU)", c->llm_act, c->llm_flavor);
+  UVX_CHECK(c->llm_qk_norm == 0 || (c->llm_qk_norm == 1 && c->llm_flavor == UVX_LLM_LLAMA), UVX_ERR_INVALID,
+            "llm_qk_norm %d: 0 or 1, and only with the Llama-flavoured norms (Qwen3)", c->llm_qk_norm);
   return UVX_OK;
 }
 
@@ -735,6 +740,9 @@ static int llm_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int T) {
   UVX_CHECK(c.llm_heads % c.llm_kv_heads == 0, UVX_ERR_SHAPE, "llm: heads %d not a multiple of kv heads %d", c.llm_heads, c.llm_kv_heads);
   UVX_CHECK(c.llm_inter % 16 == 0, UVX_ERR_SHAPE, "llm: intermediate size %d must be a multiple of 16", c.llm_inter);
   UVX_CHECK(w->rope_len >= T, UVX_ERR_SHAPE, "llm: rope table (%d) shorter than sequence (%d)", w->rope_len, T);
+  if (c.llm_qk_norm)
+    for (int l = 0; l < c.llm_layers; ++l)
+      UVX_CHECK(w->layers[l].q_norm && w->layers[l].k_norm, UVX_ERR_INVALID, "llm: llm_qk_norm is set but layer %d has no q_norm / k_norm", l);
   return UVX_OK;
 }
 
@@ -785,7 +793,11 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     const int Mv = v.M;
     // (probe bit 256: the kernel runs but writes elsewhere - the GEMM then reads a buffer nobody has just written)
     if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, probe_skip(256) && save_for_bwd ? v.d_n : v.n, nullptr, Mv, D, c.rms_eps, fl));
-    RC(gemm(sx, dt, lin(v.n, L.wqkv, cur.qkv, Mv, s.QKV, D)));
+    {
+      GemmDesc g = lin(v.n, L.wqkv, cur.qkv, Mv, s.QKV, D);
+      g.bias = L.bqkv;     // Qwen2: q / k / v projection biases (null otherwise)
+      RC(gemm(sx, dt, g));
+    }
     if (lora) {   // peft LoRA on q_proj / k_proj (text_model_lora_config): added to the projections, before RoPE
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r, qc = Hq * dh, kc = Hkv * dh;
@@ -796,7 +808,10 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       RC(lora_up(sx, dt, cur.t, 128, cur.bqT, 1, cur.qkv, s.QKV, Mv, qc, r, lora->scaling, 1));
       RC(lora_up(sx, dt, at(cur.t, 64, dt), 128, cur.bkT, 1, at(cur.qkv, (size_t)qc, dt), s.QKV, Mv, kc, r, lora->scaling, 1));
     }
-    if (!probe_skip(32)) RC(rope_inplace(sx, dt, cur.qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 0));
+    if (c.llm_qk_norm)   // Qwen3: q_norm / k_norm per head, then RoPE - one pass; the raw rows stay for the backward
+      RC(qk_norm_rope(sx, dt, cur.qkv, L.q_norm, L.k_norm, save_for_bwd ? cur.qk_raw : nullptr, w->rope_cos_sin, nullptr, Mv, T, Hq, Hkv,
+                      dh, s.QKV, c.rms_eps));
+    else if (!probe_skip(32)) RC(rope_inplace(sx, dt, cur.qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 0));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt), v.vt, Bv, T, s.Tp, Hkv, dh, s.QKV));
     AttnDesc ad;
     ad.q = cur.qkv; ad.k = at(cur.qkv, (size_t)Hq * dh, dt); ad.v = at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt);
@@ -1056,6 +1071,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     if (rope_fused) bd.rope_cos_sin = w->rope_cos_sin;
     if (!probe_skip(1)) RC(attention_bwd(sx, dt, bd));
     if (!rope_fused) RC(rope_inplace(sx, dt, v.d_qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
+    if (c.llm_qk_norm) RC(qk_norm_bwd(sx, dt, v.d_qkv, cur.qk_raw, L.q_norm, L.k_norm, Mv, Hq, Hkv, dh, s.QKV, c.rms_eps));
     RC(gemm(sx, dt, lin(v.d_qkv, L.wqkv_t, v.d_n, Mv, D, s.QKV)));
     if (lora) {   // LoRA gradients of q_proj / k_proj and their contribution to d n1 (rank-r products, lora.hip)
       const uvx_enc_lora_layer_t& R = lora->layers[l];

@@ -254,6 +254,7 @@ class UltravoxModel:
         c.llm_head_dim, c.llm_inter, c.vocab, c.rms_eps = t.head_dim, t.intermediate_size, t.vocab_size, t.rms_norm_eps
         c.llm_flavor = 1 if t.is_gemma else 0      # UVX_LLM_GEMMA / UVX_LLM_LLAMA (include/uvx.h)
         c.llm_act = {"silu": 0, "gelu_pytorch_tanh": 1, "gelu": 2}[t.hidden_act]      # UVX_ACT_* : [3P] ACT2FN[hidden_act]
+        c.llm_qk_norm = int(t.has_qk_norm)         # Qwen3: per-head q_norm / k_norm before RoPE
         self._c = c
 
         e = self._enc
@@ -298,7 +299,7 @@ class UltravoxModel:
         self._llm_layers = (_lib.LlmLayer * t.num_hidden_layers)()
         for i, L in enumerate(m["layers"]):
             for n in _lib._LLM_LAYER_FIELDS:
-                setattr(self._llm_layers[i], n, 0 if L[n] is None else L[n].data_ptr())
+                setattr(self._llm_layers[i], n, 0 if L.get(n) is None else L[n].data_ptr())
         lw = _lib.LlmWeights()
         lw.embed, lw.norm, lw.lm_head = m["embed"].data_ptr(), m["norm"].data_ptr(), m["lm_head"].data_ptr()
         lw.lm_head_t = 0 if m["lm_head_t"] is None else m["lm_head_t"].data_ptr()

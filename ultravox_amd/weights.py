@@ -139,6 +139,12 @@ def _random_rest(sd, cfg, rn, near_one, device, dtype):
         sd[L + "mlp.gate_proj.weight"] = rn(I, D, s=1.0 / math.sqrt(D))
         sd[L + "mlp.up_proj.weight"] = rn(I, D, s=1.0 / math.sqrt(D))
         sd[L + "mlp.down_proj.weight"] = rn(D, I, s=1.0 / math.sqrt(I))
+        if getattr(t, "has_qkv_bias", False):      # Qwen2Attention: biases on q / k / v only
+            for n, rows in (("q", Hq * dh), ("k", Hkv * dh), ("v", Hkv * dh)):
+                sd[L + f"self_attn.{n}_proj.bias"] = rn(rows, s=0.5)
+        if getattr(t, "has_qk_norm", False):       # Qwen3Attention.q_norm / k_norm: RMSNorm weights over head_dim
+            sd[L + "self_attn.q_norm.weight"] = near_one(dh)
+            sd[L + "self_attn.k_norm.weight"] = near_one(dh)
     sd[P + "norm.weight"] = near_one(D)
     if getattr(t, "is_gemma", False):
         # Gemma: norm weights are stored zero-centred (the norm multiplies by 1 + w), the embedding is divided by the
@@ -146,7 +152,7 @@ def _random_rest(sd, cfg, rn, near_one, device, dtype):
         for k in [k for k in sd if k.startswith(P) and k.endswith(("layernorm.weight", "model.norm.weight"))]:
             sd[k] = (sd[k].float() - 1.0).to(dtype)
         sd[P + "embed_tokens.weight"] = (sd[P + "embed_tokens.weight"].float() / math.sqrt(D)).to(dtype)
-    else:
+    elif not getattr(t, "ties_head", False):
         sd["language_model.lm_head.weight"] = rn(t.vocab_size, D, s=1.0 / math.sqrt(D))
     return sd
 
@@ -316,8 +322,9 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
     out = {"embed": cv(sd[P + "embed_tokens.weight"]), "norm": cv(sd[P + "norm.weight"]), "layers": []}
     # tied head (Gemma; HF tie_word_embeddings): lm_head IS the embedding matrix - one tensor, two uses
     out["lm_head"] = cv(sd[prefix + "lm_head.weight"]) if prefix + "lm_head.weight" in sd else out["embed"]
-    if prefix + "lm_head.weight" not in sd and not getattr(t, "is_gemma", False):
-        raise KeyError(f"{prefix}lm_head.weight is missing (only the Gemma family ties the head to embed_tokens)")
+    if prefix + "lm_head.weight" not in sd and not getattr(t, "ties_head", getattr(t, "is_gemma", False)):
+        raise KeyError(f"{prefix}lm_head.weight is missing (only Gemma, and Qwen configs with tie_word_embeddings, tie the head to "
+                       "embed_tokens)")
     out["lm_head_t"] = tr(out["lm_head"])
     for i in range(t.num_hidden_layers):
         L = f"{P}layers.{i}."
@@ -333,7 +340,17 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
             for key in [L + f"self_attn.{n}_proj.weight" for n in "qkv"] + [L + "mlp.gate_proj.weight", L + "mlp.up_proj.weight"]:
                 sd.pop(key)
         wo, wd = cv(sd[L + "self_attn.o_proj.weight"]), cv(sd[L + "mlp.down_proj.weight"])
+        extras = {}      # family extras: present only where the family has them (uvx_llm_layer_t.bqkv / q_norm / k_norm, else NULL)
+        if getattr(t, "has_qkv_bias", False):
+            extras["bqkv"] = cv(torch.cat([sd[L + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0))
+        elif any(L + f"self_attn.{n}_proj.bias" in sd for n in "qkvo"):
+            raise ValueError(f"{L}self_attn.*_proj.bias present: attention biases are built for the qwen2 family only")
+        if getattr(t, "has_qk_norm", False):
+            extras["q_norm"], extras["k_norm"] = cv(sd[L + "self_attn.q_norm.weight"]), cv(sd[L + "self_attn.k_norm.weight"])
+        elif L + "self_attn.q_norm.weight" in sd:
+            raise ValueError(f"{L}self_attn.q_norm.weight present: per-head q / k norms are built for the qwen3 family only")
         out["layers"].append({
+            **extras,
             "ln1": cv(sd[L + "input_layernorm.weight"]), "ln2": cv(sd[L + "post_attention_layernorm.weight"]),
             "wqkv": wqkv, "wo": wo, "wgu": wgu, "wd": wd,
             "wqkv_t": tr(wqkv), "wo_t": tr(wo), "wgu_t": tr(wgu), "wd_t": tr(wd),
