@@ -46,6 +46,10 @@ WORKLOADS = {
     # BASELINE.json configs[4] per-rank shapes (alt encoder / backbone; the reference quotes it at DP = 4): not the quoted configuration
     "c5": dict(name="Gemma-7B (frozen) + wav2vec2-large (frozen), bs=8x30s clips per GPU, adapter train",
                audio="facebook/wav2vec2-large-960h", text="google/gemma-7b", B=8, seconds=30.0),
+    # not a BASELINE.json configuration: the reference's v0.6 recipe (ultravox/training/configs/v0.6_config_qwen3_32b.yaml: Qwen/Qwen3-32B
+    # behind whisper-large-v3-turbo), per-rank shapes as c2 / c3.  64 GB of frozen bf16 weights + their transposed copies on one GPU.
+    "q3": dict(name="Qwen3-32B (frozen) + whisper-large-v3-turbo, bs=8x30s clips per GPU, adapter train",
+               audio="openai/whisper-large-v3-turbo", text="Qwen/Qwen3-32B", B=8, seconds=30.0),
     # BASELINE.json configs[0] shapes (plumbing-sized), for quick checks
     "c1": dict(name="TinyLlama-1.1B + whisper-tiny, 1x4s clip, adapter train",
                audio="openai/whisper-tiny", text="TinyLlama/TinyLlama-1.1B-Chat-v1.0", B=1, seconds=4.0),
