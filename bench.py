@@ -50,6 +50,11 @@ WORKLOADS = {
     # behind whisper-large-v3-turbo), per-rank shapes as c2 / c3.  64 GB of frozen bf16 weights + their transposed copies on one GPU.
     "q3": dict(name="Qwen3-32B (frozen) + whisper-large-v3-turbo, bs=8x30s clips per GPU, adapter train",
                audio="openai/whisper-large-v3-turbo", text="Qwen/Qwen3-32B", B=8, seconds=30.0),
+    # not a BASELINE.json configuration (its configs[3] is 70B INFERENCE): the reference's 70B TRAINING recipes
+    # (v0.6_config_llama3_70b.yaml: Llama-3.3-70B behind whisper-large-v3-turbo), per-rank shapes as c2.  141 GB of frozen bf16 weights
+    # on ONE 288 GB GPU - possible because the backward's transposed copies are streamed (uvx_config_t.llm_wt_stream), not resident
+    "l70": dict(name="Llama-3.3-70B (frozen) + whisper-large-v3-turbo, bs=8x30s clips per GPU, adapter train",
+               audio="openai/whisper-large-v3-turbo", text="meta-llama/Llama-3.3-70B-Instruct", B=8, seconds=30.0),
     # BASELINE.json configs[0] shapes (plumbing-sized), for quick checks
     "c1": dict(name="TinyLlama-1.1B + whisper-tiny, 1x4s clip, adapter train",
                audio="openai/whisper-tiny", text="TinyLlama/TinyLlama-1.1B-Chat-v1.0", B=1, seconds=4.0),
@@ -261,6 +266,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--stream-wt", default="auto", choices=["auto", "on", "off"],
+                    help="transposed weight copies of the frozen LLM for the backward pass: made on the fly on a side stream (on), resident (off), "
+                         "or resident unless the LLM exceeds a third of the GPU's memory (auto, the model's default)")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", default=None, metavar="OUT.json",
@@ -347,7 +355,8 @@ def main():
     cfg = UltravoxConfig(audio_model_id=wl["audio"], text_model_id=wl["text"], hidden_size=4096, stack_factor=8,
                          projector_ln_mid=True, torch_dtype="bfloat16",
                          audio_model_lora_config={"r": args.audio_lora_r} if args.audio_lora_r else None)
-    model = UltravoxModel(cfg, device=str(dev), dtype=torch.bfloat16, seed=0, rope_len=1024)
+    model = UltravoxModel(cfg, device=str(dev), dtype=torch.bfloat16, seed=0, rope_len=1024,
+                          stream_weight_transposes={"auto": None, "on": True, "off": False}[args.stream_wt])
     comm = None
     if args.comm == "abi" and world > 1 and not share_gpu:
         from ultravox_amd.parallel import UvxComm

@@ -68,6 +68,11 @@ typedef struct {
    * k_norm, an RMSNorm over head_dim on every head of q and k BEFORE the rotary embedding ([3P] modeling_qwen3.py Qwen3Attention).
    * Non-zero: uvx_llm_layer_t.q_norm / k_norm must be set, and training workspaces keep the un-normalised q | k rows per layer. */
   int32_t llm_qk_norm;
+  /* Non-zero: uvx_llm_bwd* make the transposed weight copies they need ([K_in, N_out] of wqkv / wo / wgu / wd and of lm_head) ON
+   * THE FLY, one layer ahead of the layer being differentiated, on an internal side stream into two alternating workspace
+   * buffers - uvx_llm_layer_t.*_t and lm_head_t may then be NULL.  Halves the resident weight bytes (a 70B-parameter LLM then
+   * trains on one 288 GB GPU: 141 GB of weights instead of 282) for one extra read + write of the weights per step. */
+  int32_t llm_wt_stream;
 } uvx_config_t;
 #define UVX_ACT_SILU 0
 #define UVX_ACT_GELU_TANH 1

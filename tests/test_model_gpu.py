@@ -361,6 +361,53 @@ def test_two_stream_llm_schedule_is_bit_identical(B, T):
     assert torch.isfinite(one[2].float()).all() and one[2].float().abs().max() > 0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_streamed_weight_transposes_are_bit_identical(dtype):
+    """uvx_config_t.llm_wt_stream (UltravoxModel(stream_weight_transposes=True)): the backward's transposed weight copies are
+    made on the fly - lm_head first, then one layer ahead of the layer being differentiated, on a side stream into two
+    alternating workspace buffers - instead of being resident (a 70B-parameter LLM then fits one GPU).  Same GEMMs on the
+    same operands: loss and d loss / d inputs_embeds BIT-identical to the resident-copy build for the plain pair, the training
+    pair and repeated calls (the buffers are reused across calls), and a whole train step gives identical projector gradients."""
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    tc = dict(SMALL["text_config"], num_hidden_layers=5)           # odd depth: both buffers, both parities of the top layer
+    cfg = UltravoxConfig(**{**SMALL, "text_config": tc})
+    sd = {k: v.to(dtype) for k, v in random_state_dict(cfg, seed=21).items()}
+    resident = UltravoxModel(cfg, state_dict=dict(sd), device=DEV, dtype=dtype, stream_weight_transposes=False)
+    streamed = UltravoxModel(cfg, state_dict=dict(sd), device=DEV, dtype=dtype, stream_weight_transposes=True)
+    assert streamed._c.llm_wt_stream == 1 and resident._c.llm_wt_stream == 0
+    assert streamed._llm["lm_head_t"] is None and all(L["wqkv_t"] is None and L["wd_t"] is None for L in streamed._llm["layers"])
+    torch.manual_seed(6)
+    B, T = 3, 40
+    emb = (torch.randn(B, T, 256) * 0.5).to(dtype).to(DEV)
+    labels = torch.randint(0, 512, (B, T)); labels[:, : T // 2] = -100
+    mask = torch.ones(B, T, dtype=torch.long); mask[0, :3] = 0
+    labels, mask = labels.to(DEV), mask.to(DEV)
+
+    def run(m):
+        full = m.language_model_forward(emb, labels=labels, attention_mask=mask, want_logits=True, save_for_bwd=True)
+        d_full = m.language_model_backward(1.0).clone()
+        tr = m.language_model_forward(emb, labels=labels, attention_mask=mask, want_logits=False, save_for_bwd=True)
+        d_tr = m.language_model_backward(1.0).clone()
+        torch.cuda.synchronize()
+        return full.loss.clone(), d_full, tr.loss.clone(), d_tr
+
+    a, b, b2 = run(resident), run(streamed), run(streamed)
+    for x, y, z in zip(a, b, b2):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    assert a[1].float().abs().max() > 0
+    batch = {k: v.to(DEV) for k, v in batch_for(cfg).items()}
+    batch["audio_values"] = batch["audio_values"].to(dtype)
+    for m in (resident, streamed):
+        m.train()
+    la, lb = resident.forward_backward(**batch), streamed.forward_backward(**batch)
+    assert torch.equal(la, lb)
+    ga, gb = resident.projector_grads(), streamed.projector_grads()
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+
+
 def test_fused_inverse_rope_in_the_attention_backward_is_bit_identical():
     """Option 14 (default on): dq / dk leave the LLM's attention backward already RoPE-inverted (epilogue of the dQ kernel, the
     GQA group reduction) instead of a separate rope pass over d_qkv.  Same arithmetic and rounding points: d inputs_embeds is

@@ -95,7 +95,7 @@ class Config(C.Structure):
         ("proj_eps", C.c_float),
         ("llm_layers", C.c_int32), ("llm_d", C.c_int32), ("llm_heads", C.c_int32), ("llm_kv_heads", C.c_int32),
         ("llm_head_dim", C.c_int32), ("llm_inter", C.c_int32), ("vocab", C.c_int32), ("rms_eps", C.c_float),
-        ("llm_flavor", C.c_int32), ("llm_act", C.c_int32), ("llm_qk_norm", C.c_int32),
+        ("llm_flavor", C.c_int32), ("llm_act", C.c_int32), ("llm_qk_norm", C.c_int32), ("llm_wt_stream", C.c_int32),
     ]
 
 

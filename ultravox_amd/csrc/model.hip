@@ -189,8 +189,14 @@ struct LlmWs {
   float* dkv_part;
   void* lu;      // LoRA backward: u = [dq . B_q | dk . B_k] [M, 128]
   float* lwg;    // lora_wgrad scratch
+  void *wt[2], *head_t;   // llm_wt_stream: two alternating sets of one layer's transposed weights, and lm_head^T
   int M, Tp, QKV, OD;
 };
+// elements of one layer's four transposed matrices (wqkv_t | wo_t | wgu_t | wd_t, in this order)
+inline size_t layer_wt_elems(const uvx_config_t& c) {
+  const size_t QKV = (size_t)(c.llm_heads + 2 * c.llm_kv_heads) * c.llm_head_dim, OD = (size_t)c.llm_heads * c.llm_head_dim;
+  return (QKV + OD + 3 * (size_t)c.llm_inter) * c.llm_d;
+}
 void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
   const size_t es = esz(c.dtype);
   const size_t M = (size_t)B * T;
@@ -248,6 +254,9 @@ LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
     w.dkv_part = (float*)a.take(sizeof(float) * 2 * M * w.OD);
     w.lu = a.take(M * 128 * es);
     w.lwg = (float*)a.take(sizeof(float) * (size_t)lora_wgrad_scratch_floats(w.M, c.llm_d > w.OD ? c.llm_d : w.OD, 64));
+    w.wt[0] = a.take(c.llm_wt_stream ? layer_wt_elems(c) * es : 0);
+    w.wt[1] = a.take(c.llm_wt_stream ? layer_wt_elems(c) * es : 0);
+    w.head_t = a.take(c.llm_wt_stream ? (size_t)c.vocab * c.llm_d * es : 0);
   }
   return w;
 }
@@ -333,6 +342,26 @@ Fork* fork_for_device() {
   }
   return &f;
 }
+// llm_wt_stream: the side stream that transposes layer l - 1's weights while layer l is differentiated, and its events
+struct WtStream {
+  hipStream_t side = nullptr;
+  hipEvent_t e_start = nullptr, e_head = nullptr, e_ready[2] = {nullptr, nullptr}, e_free[2] = {nullptr, nullptr};
+  bool ok = false;
+};
+WtStream* wt_stream_for_device() {
+  static WtStream all[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  WtStream& f = all[dev];
+  if (!f.ok) {
+    hipEvent_t* ev[6] = {&f.e_start, &f.e_head, &f.e_ready[0], &f.e_ready[1], &f.e_free[0], &f.e_free[1]};
+    for (hipEvent_t* e : ev)
+      if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    f.ok = true;
+  }
+  return &f;
+}
 // The chains of one call: batch slices [b0[i], b0[i + 1]) with their workspace views and streams (chain 0 = the caller's).
 // Option 11 = number of chains (2 by default, up to 4; 0 / 1 = one chain); a chain needs at least one sequence.
 struct Chains {
@@ -375,6 +404,7 @@ int check_cfg(const uvx_config_t* c) {
   UVX_CHECK(c->llm_flavor == UVX_LLM_LLAMA || c->llm_flavor == UVX_LLM_GEMMA, UVX_ERR_INVALID, "bad llm_flavor %d", c->llm_flavor);
   UVX_CHECK(c->llm_act >= UVX_ACT_SILU && c->llm_act <= UVX_ACT_GELU_ERF && (c->llm_flavor == UVX_LLM_GEMMA) == (c->llm_act != UVX_ACT_SILU),
             UVX_ERR_INVALID, "llm_act %d does not fit llm_flavor %d (Llama: SiLU; Gemma: tanh- or erf-GELU)", c->llm_act, c->llm_flavor);
+  UVX_CHECK(c->llm_wt_stream == 0 || c->llm_wt_stream == 1, UVX_ERR_INVALID, "llm_wt_stream %d: 0 or 1", c->llm_wt_stream);
   UVX_CHECK(c->llm_qk_norm == 0 || (c->llm_qk_norm == 1 && c->llm_flavor == UVX_LLM_LLAMA), UVX_ERR_INVALID,
             "llm_qk_norm %d: 0 or 1, and only with the Llama-flavoured norms (Qwen3)", c->llm_qk_norm);
   return UVX_OK;
@@ -964,13 +994,50 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   UVX_CHECK(w && d_inputs_embeds && workspace, UVX_ERR_INVALID, "llm_bwd: null argument");
   const uvx_config_t& c = *cfg;
   RC(llm_check(c, w, T));
-  UVX_CHECK(w->lm_head_t != nullptr, UVX_ERR_INVALID, "llm_bwd: transposed weights (lm_head_t, *_t) are required");
+  const bool wts = c.llm_wt_stream != 0;      // transposed weights made on the fly (include/uvx.h)
+  UVX_CHECK(wts || w->lm_head_t != nullptr, UVX_ERR_INVALID, "llm_bwd: transposed weights (lm_head_t, *_t) are required (or llm_wt_stream)");
   hipStream_t st = (hipStream_t)stream;
   if (B == 0 || T == 0) return UVX_OK;
   Arena a(workspace, ws_bytes);
   LlmWs s = llm_carve(a, c, B, T, 1);
   UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_bwd: workspace %zu < %zu bytes", ws_bytes, a.off);
   const int dt = c.dtype, D = c.llm_d, M = s.M, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads;
+
+  // llm_wt_stream: a side stream transposes lm_head and then, one layer ahead of the layer being differentiated, each layer's
+  // four matrices into the alternating buffers s.wt[l & 1]; e_ready[b] = buffer b holds its layer, e_free[b] = the caller's stream
+  // is done with buffer b.  (One chain only: the chains' side streams would each need the same waits.)
+  struct LayerT { const void *wqkv_t, *wo_t, *wgu_t, *wd_t; };
+  WtStream* wt = nullptr;
+  auto layer_t = [&](int l) -> LayerT {
+    const uvx_llm_layer_t& L = w->layers[l];
+    if (!wts) return LayerT{L.wqkv_t, L.wo_t, L.wgu_t, L.wd_t};
+    const size_t es_ = esz(dt), nq = (size_t)s.QKV * D, no = (size_t)s.OD * D, ng = (size_t)2 * c.llm_inter * D;
+    char* b = (char*)s.wt[l & 1];
+    return LayerT{b, b + nq * es_, b + (nq + no) * es_, b + (nq + no + ng) * es_};
+  };
+  auto issue_layer_t = [&](int l) -> int {      // on the side stream: W^T of layer l into its buffer
+    const uvx_llm_layer_t& L = w->layers[l];
+    const LayerT t = layer_t(l);
+    UVX_HIP(hipStreamWaitEvent(wt->side, wt->e_free[l & 1], 0));
+    RC(transpose2d(wt->side, dt, L.wqkv, const_cast<void*>(t.wqkv_t), s.QKV, D, D, s.QKV, 1, 0, 0));
+    RC(transpose2d(wt->side, dt, L.wo, const_cast<void*>(t.wo_t), D, s.OD, s.OD, D, 1, 0, 0));
+    RC(transpose2d(wt->side, dt, L.wgu, const_cast<void*>(t.wgu_t), 2 * c.llm_inter, D, D, 2 * c.llm_inter, 1, 0, 0));
+    RC(transpose2d(wt->side, dt, L.wd, const_cast<void*>(t.wd_t), D, c.llm_inter, c.llm_inter, D, 1, 0, 0));
+    UVX_HIP(hipEventRecord(wt->e_ready[l & 1], wt->side));
+    return UVX_OK;
+  };
+  const void* head_t = w->lm_head_t;
+  if (wts) {
+    wt = wt_stream_for_device();
+    UVX_CHECK(wt != nullptr, UVX_ERR_RUNTIME, "llm_bwd: could not create the weight-transpose stream");
+    UVX_HIP(hipEventRecord(wt->e_start, st));                 // everything issued before (an earlier backward's reads of the buffers)
+    UVX_HIP(hipStreamWaitEvent(wt->side, wt->e_start, 0));
+    RC(transpose2d(wt->side, dt, w->lm_head, s.head_t, c.vocab, D, D, c.vocab, 1, 0, 0));
+    UVX_HIP(hipEventRecord(wt->e_head, wt->side));
+    RC(issue_layer_t(c.llm_layers - 1));
+    UVX_HIP(hipStreamWaitEvent(st, wt->e_head, 0));
+    head_t = s.head_t;
+  }
 
   // d logits (in place over the saved logits), then the frozen head: d_hn = dlogits . W_head
   // (labels == NULL: uvx_llm_kl_loss already replaced the saved logits by their gradient)
@@ -990,7 +1057,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     if (nsplit > 1) {
       float* partial = (float*)s.d_gu;
       const int Kc = c.vocab / nsplit;
-      GemmDesc g = lin(s.logits, w->lm_head_t, partial, cap, D, Kc);
+      GemmDesc g = lin(s.logits, head_t, partial, cap, D, Kc);
       g.lda = c.vocab; g.ldb = c.vocab; g.batch = nsplit; g.sA = Kc; g.sB = Kc; g.sC = (long long)cap * D; g.out_f32 = 1;
       g.m_dev = s.sup + M;
       RC(gemm(st, dt, g));
@@ -998,14 +1065,14 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     }
     const int first = nsplit > 1 ? cap : 0;
     if (M > first) {
-      GemmDesc g = lin(at(s.logits, (size_t)first * c.vocab, dt), w->lm_head_t, s.d_n, M - first, D, c.vocab);
+      GemmDesc g = lin(at(s.logits, (size_t)first * c.vocab, dt), head_t, s.d_n, M - first, D, c.vocab);
       g.m_dev = s.sup + M; g.m_dev_off = first;
       RC(gemm(st, dt, g));
       RC(scatter_rows(st, dt, s.d_n, s.sup, M, s.d_hn, D, first));
     }
   } else {
     if (labels) RC(ce_loss_fwd_bwd(st, dt, s.logits, labels, nullptr, s.ce_scratch, s.logits, B, T, c.vocab, c.vocab, grad_scale));
-    RC(gemm(st, dt, lin(s.logits, w->lm_head_t, s.d_hn, M, D, c.vocab)));
+    RC(gemm(st, dt, lin(s.logits, head_t, s.d_hn, M, D, c.vocab)));
   }
   const int fl = c.llm_flavor;
   // top_rows (uvx_llm_bwd_train, after uvx_llm_fwd_train): the last layer's stash (x_final, x_mid, gate|up) holds the
@@ -1029,17 +1096,17 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     const int Mv = v.M;
     const int32_t* mdev = compact ? v.sup + Mv : nullptr;
     if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
-      GemmDesc g = lin(v.dx, L.wd_t, v.d_gu, Mv, c.llm_inter, D);
+      GemmDesc g = lin(v.dx, layer_t(l).wd_t, v.d_gu, Mv, c.llm_inter, D);
       g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     } else {
-      GemmDesc g = lin(v.dx, L.wd_t, v.d_act, Mv, c.llm_inter, D);
+      GemmDesc g = lin(v.dx, layer_t(l).wd_t, v.d_act, Mv, c.llm_inter, D);
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
       if (!probe_skip(4)) RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
     }
     {
-      GemmDesc g = lin(v.d_gu, L.wgu_t, v.d_n, Mv, D, 2 * c.llm_inter);
+      GemmDesc g = lin(v.d_gu, layer_t(l).wgu_t, v.d_n, Mv, D, 2 * c.llm_inter);
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
@@ -1051,7 +1118,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     const uvx_llm_layer_t& L = w->layers[l];
     LlmLayerStash cur = llm_layer(v, l);
     const int Mv = v.M;
-    if (!d_o_ready) RC(gemm(sx, dt, lin(v.dx, L.wo_t, v.d_o, Mv, s.OD, D)));
+    if (!d_o_ready) RC(gemm(sx, dt, lin(v.dx, layer_t(l).wo_t, v.d_o, Mv, s.OD, D)));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, cur.qkv, v.qT, Bv, T, s.Tp, Hq, dh, s.QKV));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, at(cur.qkv, (size_t)Hq * dh, dt), v.kT, Bv, T, s.Tp, Hkv, dh, s.QKV));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, v.d_o, v.doT, Bv, T, s.Tp, Hq, dh, s.OD));
@@ -1072,7 +1139,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     if (!probe_skip(1)) RC(attention_bwd(sx, dt, bd));
     if (!rope_fused) RC(rope_inplace(sx, dt, v.d_qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
     if (c.llm_qk_norm) RC(qk_norm_bwd(sx, dt, v.d_qkv, cur.qk_raw, L.q_norm, L.k_norm, Mv, Hq, Hkv, dh, s.QKV, c.rms_eps));
-    RC(gemm(sx, dt, lin(v.d_qkv, L.wqkv_t, v.d_n, Mv, D, s.QKV)));
+    RC(gemm(sx, dt, lin(v.d_qkv, layer_t(l).wqkv_t, v.d_n, Mv, D, s.QKV)));
     if (lora) {   // LoRA gradients of q_proj / k_proj and their contribution to d n1 (rank-r products, lora.hip)
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const uvx_enc_lora_layer_grads_t& G = lgrads->layers[l];
@@ -1092,13 +1159,14 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   };
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
-    UVX_CHECK(L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t, UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
+    UVX_CHECK(wts || (L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t), UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
   }
   const int top = c.llm_layers - 1;
+  if (wts) UVX_HIP(hipStreamWaitEvent(st, wt->e_ready[top & 1], 0));
   if (tc) {   // last layer of the training pair: MLP and o_proj gradients on the compact supervised rows (whole batch, this
               // stream), then d o and the residual-stream gradient go back to their full rows for the attention backward
     RC(layer_mlp_bwd(st, s, top, true));
-    GemmDesc g = lin(s.dx, w->layers[top].wo_t, s.doT, M, s.OD, D);     // doT ([B, Hq, Tp, dh] >= M * OD) is free until the transpose
+    GemmDesc g = lin(s.dx, layer_t(top).wo_t, s.doT, M, s.OD, D);     // doT ([B, Hq, Tp, dh] >= M * OD) is free until the transpose
     g.m_dev = mdev_top;
     RC(gemm(st, dt, g));
     UVX_HIP(hipMemsetAsync(s.d_o, 0, (size_t)M * s.OD * es, st));
@@ -1107,17 +1175,22 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     RC(scatter_rows(st, dt, s.dx, s.sup, M, s.d_hn, D));
   }
   // schedule: one chain on the caller's stream, or (option 11) the batch slices on several streams - see Fork above
-  const Chains ch = make_chains(st, s, c, B, T, dt == DT_BF16 && !lora);
+  const Chains ch = make_chains(st, s, c, B, T, dt == DT_BF16 && !lora && !wts);
   RC(chains_fork(ch));
   int rc_layers = UVX_OK;
   for (int l = top; l >= 0 && rc_layers == UVX_OK; --l) {
     const bool compact = tc && l == top;
+    if (wts) {      // this layer's W^T must have landed; the next one's is started now, into the buffer layer l + 1 has released
+      if (l != top && hipStreamWaitEvent(st, wt->e_ready[l & 1], 0) != hipSuccess) rc_layers = UVX_ERR_RUNTIME;
+      if (l > 0 && rc_layers == UVX_OK) rc_layers = issue_layer_t(l - 1);
+    }
     for (int h = 0; h < ch.n && rc_layers == UVX_OK; ++h) {
       const LlmWs& v = ch.v[h];
       if (!compact) rc_layers = layer_mlp_bwd(ch.st[h], v, l, false);
       void* dx_out = l == 0 ? (void*)((char*)d_inputs_embeds + (size_t)ch.b0[h] * T * D * es) : v.dx;
       if (rc_layers == UVX_OK) rc_layers = layer_attn_bwd(ch.st[h], v, ch.b0[h + 1] - ch.b0[h], l, compact, compact ? v.d_hn : v.dx, dx_out);
     }
+    if (wts && hipEventRecord(wt->e_free[l & 1], st) != hipSuccess && rc_layers == UVX_OK) rc_layers = UVX_ERR_RUNTIME;
   }
   RC(chains_join(ch));   // (also after an error above: the side streams must not be left forked)
   RC(rc_layers);

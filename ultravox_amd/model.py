@@ -126,9 +126,14 @@ class UltravoxModel:
 
     def __init__(self, config: UltravoxConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  device: str = "cuda", dtype: Optional[torch.dtype] = None, seed: int = 0,
-                 with_backward: bool = True, rope_len: Optional[int] = None, consume_state_dict: bool = False):
+                 with_backward: bool = True, rope_len: Optional[int] = None, consume_state_dict: bool = False,
+                 stream_weight_transposes: Optional[bool] = None):
         """consume_state_dict: pop the LLM's q/k/v/gate/up tensors from `state_dict` as they are packed (the dict is left
-        without them) so that loading peaks at one copy of the model plus a layer - for the 70B-parameter LLM (C4)."""
+        without them) so that loading peaks at one copy of the model plus a layer - for the 70B-parameter LLM (C4).
+        stream_weight_transposes: the backward pass needs the frozen LLM's weights transposed; True = made on the fly, one layer
+        ahead, on a side stream (uvx_config_t.llm_wt_stream: half the resident weight bytes for one extra read + write of the
+        weights per step), False = resident copies, None = resident unless the LLM's weights exceed a third of the GPU's memory
+        (a 70B-parameter LLM: 141 GB of 288)."""
         _lib.lib()  # fail loudly if the HIP library is missing
         if not torch.cuda.is_available():
             raise _lib.UvxError("UltravoxModel needs a GPU (MI355X / gfx950); there is no CPU path")
@@ -156,8 +161,16 @@ class UltravoxModel:
         if state_dict is None:
             gen_dev = "cuda" if t.num_hidden_layers * t.hidden_size > 64 * 1024 else "cpu"
             state_dict = random_state_dict(config, seed=seed, dtype=self.dtype, device=gen_dev)
+            consume_state_dict = True              # nobody else holds this dict: let the packer free its sources as it goes
         self.with_backward = with_backward
         self._consume_sd = bool(consume_state_dict)
+        if stream_weight_transposes is None:
+            per_layer = ((t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim * t.hidden_size
+                         + t.num_attention_heads * t.head_dim * t.hidden_size + 3 * t.intermediate_size * t.hidden_size)
+            llm_bytes = (per_layer * t.num_hidden_layers + 2 * t.vocab_size * t.hidden_size) * (2 if self.dtype == torch.bfloat16 else 4)
+            total = torch.cuda.get_device_properties(self.device).total_memory
+            stream_weight_transposes = llm_bytes > total / 3
+        self.stream_weight_transposes = bool(stream_weight_transposes) and with_backward
         self._load(state_dict, rope_len)
         self._ws: Dict[str, torch.Tensor] = {}
         self._proj_ctx = None
@@ -175,7 +188,7 @@ class UltravoxModel:
             self._enc = pack_wav2vec2(sd, cfg, dt, dev)
         else:
             self._enc = pack_encoder(sd, cfg, dt, dev, with_transposes=self.lora_r > 0 and self.with_backward)
-        self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=self.with_backward, rope_len=rope_len,
+        self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=self.with_backward and not self.stream_weight_transposes, rope_len=rope_len,
                              consume=getattr(self, "_consume_sd", False))
         # projector: one flat trainable bucket with views (ln_pre | linear_1 | ln_mid/ln_post | linear_2)
         P = "multi_modal_projector."
@@ -255,6 +268,7 @@ class UltravoxModel:
         c.llm_flavor = 1 if t.is_gemma else 0      # UVX_LLM_GEMMA / UVX_LLM_LLAMA (include/uvx.h)
         c.llm_act = {"silu": 0, "gelu_pytorch_tanh": 1, "gelu": 2}[t.hidden_act]      # UVX_ACT_* : [3P] ACT2FN[hidden_act]
         c.llm_qk_norm = int(t.has_qk_norm)         # Qwen3: per-head q_norm / k_norm before RoPE
+        c.llm_wt_stream = int(self.stream_weight_transposes)
         self._c = c
 
         e = self._enc
