@@ -371,7 +371,8 @@ int32_t uvx_gemm_force_variant(int32_t variant);
  * into the down-projection dgrad GEMM (0 = separate kernel, 1 = round 2's fragment-layout epilogue (measured neutral),
  * 2 = whole-line epilogue through the LDS stage (round 3)), key 3 = LM head / CE / head dgrad on the supervised
  * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
- * problems of at most 16 rows (the decode step; default 1), key 11 = number of LLM layer chains: the batch
+ * problems of at most 16 rows (the decode step; default 1), key 5 = the streamed weight transposes (llm_wt_stream) use plain instead of
+ * non-temporal loads / stores (default 0), key 11 = number of LLM layer chains: the batch
  * is cut into that many slices whose layer chains run on as many streams (default 1 = one chain on the caller's stream, at most 4; which of 1 / 2 is
  * faster depends on the box: UltravoxTrainer.autotune_schedule times both; uvx_llm_fwd* / uvx_llm_bwd*: same kernels on the same rows, bit-identical results; the side streams are
  * forked from and joined into the caller's stream by events, so the call stays stream-ordered for the caller), key 12 = bf16

@@ -293,6 +293,9 @@ __global__ void transpose_k(const T* __restrict__ in, T* __restrict__ out, int r
 // bf16, 16-byte global access on both sides (ld_in, ld_out, cols and all strides multiples of 8, 16-byte aligned bases):
 // 2 loads + 2 stores per thread for a 64 x 64 tile instead of 16 + 16 two-byte ones; the transposition itself is done
 // with 2-byte LDS accesses on a 65-element row stride (conflict-free for both the row-wise writes and the column gathers).
+// NT: non-temporal loads and stores - a stream of weights that is transposed once per step (llm_wt_stream) and far exceeds the
+// caches should not evict the GEMM operands that live there
+template <bool NT>
 __global__ void transpose_bf16_v8_k(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols, int ld_in,
                                     int ld_out, int nzi, long long s_in_o, long long s_in_i, long long s_out) {
   __shared__ bf16_t tile[64][65];
@@ -305,7 +308,10 @@ __global__ void transpose_bf16_v8_k(const bf16_t* __restrict__ in, bf16_t* __res
     const int idx = threadIdx.x + k * 256, rr = idx >> 3, ch = idx & 7;
     const int r = r0 + rr, c = c0 + ch * 8;
     u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r < rows && c < cols) v = *reinterpret_cast<const u16x8_t*>(ib + (long long)r * ld_in + c);
+    if (r < rows && c < cols) {
+      const u16x8_t* src = reinterpret_cast<const u16x8_t*>(ib + (long long)r * ld_in + c);
+      v = NT ? __builtin_nontemporal_load(src) : *src;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) tile[rr][ch * 8 + e] = v[e];
   }
@@ -318,7 +324,9 @@ __global__ void transpose_bf16_v8_k(const bf16_t* __restrict__ in, bf16_t* __res
       u16x8_t v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = tile[r8 * 8 + e][cc];
-      *reinterpret_cast<u16x8_t*>(ob + (long long)c * ld_out + r) = v;
+      u16x8_t* dst = reinterpret_cast<u16x8_t*>(ob + (long long)c * ld_out + r);
+      if (NT) __builtin_nontemporal_store(v, dst);
+      else *dst = v;
     }
   }
 }
@@ -565,14 +573,16 @@ int merge_audio(hipStream_t st, int dtype, void* embeds, const void* audio, void
 }
 
 static int transpose_launch(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in,
-                            int ld_out, int nzo, int nzi, long long s_in_o, long long s_in_i, long long s_out) {
+                            int ld_out, int nzo, int nzi, long long s_in_o, long long s_in_i, long long s_out, bool nt = false) {
   if (rows == 0 || cols == 0 || nzo * nzi == 0) return UVX_OK;
   // the zero padded region out[:, rows..ld_out) is written too (the GEMM K dimension must be 64-aligned)
   dim3 grid(cdiv(ld_out, 64), cdiv(cols, 64), nzo * nzi);
   const bool v8 = dtype == DT_BF16 && ((ld_in | ld_out | cols) & 7) == 0 && ((s_in_o | s_in_i | s_out) & 7) == 0 &&
                   (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
-  if (v8)
-    hipLaunchKernelGGL(transpose_bf16_v8_k, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, nzi, s_in_o, s_in_i, s_out);
+  if (v8 && nt)
+    hipLaunchKernelGGL(transpose_bf16_v8_k<true>, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, nzi, s_in_o, s_in_i, s_out);
+  else if (v8)
+    hipLaunchKernelGGL(transpose_bf16_v8_k<false>, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, nzi, s_in_o, s_in_i, s_out);
   else if (dtype == DT_BF16)
     hipLaunchKernelGGL(transpose_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out, nzi, s_in_o, s_in_i, s_out);
   else
@@ -584,6 +594,10 @@ static int transpose_launch(hipStream_t st, int dtype, const void* in, void* out
 int transpose2d(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in, int ld_out,
                 int batch, long long s_in, long long s_out) {
   return transpose_launch(st, dtype, in, out, rows, cols, ld_in, ld_out, batch, 1, s_in, 0, s_out);
+}
+
+int transpose2d_streaming(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in, int ld_out) {
+  return transpose_launch(st, dtype, in, out, rows, cols, ld_in, ld_out, 1, 1, 0, 0, 0, g_options[5] == 0);   // (probe option 5 = 1: plain accesses, for A/B)
 }
 
 int heads_transpose(hipStream_t st, int dtype, const void* in, void* out, int B, int T, int Tp, int H, int D, int ld) {

@@ -61,7 +61,6 @@ struct GemmArgs {
   bf16_t* C2;      // swiglu mode: activation output [M, N/2]
   int ldc2;
   int m_major;       // XCD-contiguous tile runs share an activation panel instead of a weight panel (option 7, M > N)
-  int res_prefetch;  // fetch the residual rows of the wave tile up front (option 5; 0 = in-loop loads, for A/B runs)
   int swiglu;      // 1: columns alternate 16-wide gate / up blocks; also write silu(gate) * up to C2
   int sw_stage;    // swiglu == 2: whole-line epilogue through the LDS stage (0 = the fragment-layout form)
   int wide_io;     // 16-byte epilogue loads / stores (probe switch; on by default)
@@ -1386,7 +1385,6 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.act = d.act; a.out_f32 = d.out_f32; a.accumulate = d.accumulate; a.alpha = d.alpha;
   a.C2 = (bf16_t*)d.C2; a.ldc2 = d.ldc2; a.swiglu = d.swiglu;
   a.wide_io = uvx::g_options[1];
-  a.res_prefetch = uvx::g_options[5];
   a.sw_stage = uvx::g_options[2] != 1;     // SwiGLU-backward epilogue through the LDS stage (option 2 = 1: the round-2 fragment-layout form)
   a.m_major = uvx::g_options[7] && d.M > d.N && (d.batch <= 1);
   a.m_dev = d.m_dev; a.m_dev_off = d.m_dev_off;

@@ -109,6 +109,8 @@ int merge_audio(hipStream_t st, int dtype, void* embeds, const void* audio, void
                 int Na, int bwd);
 int transpose2d(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in,
                 int ld_out, int batch, long long s_in, long long s_out);
+// the same for one matrix that is read and written once and is much larger than the caches (non-temporal accesses)
+int transpose2d_streaming(hipStream_t st, int dtype, const void* in, void* out, int rows, int cols, int ld_in, int ld_out);
 int im2col_conv1(hipStream_t st, int dtype, const void* mel, int mel_is_f32, void* out, int B, int n_mels,
                  int F, int F_stride, int Kp);
 int add_rows(hipStream_t st, int dtype, const void* a, const void* b, void* out, long long n);

@@ -1019,10 +1019,10 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     const uvx_llm_layer_t& L = w->layers[l];
     const LayerT t = layer_t(l);
     UVX_HIP(hipStreamWaitEvent(wt->side, wt->e_free[l & 1], 0));
-    RC(transpose2d(wt->side, dt, L.wqkv, const_cast<void*>(t.wqkv_t), s.QKV, D, D, s.QKV, 1, 0, 0));
-    RC(transpose2d(wt->side, dt, L.wo, const_cast<void*>(t.wo_t), D, s.OD, s.OD, D, 1, 0, 0));
-    RC(transpose2d(wt->side, dt, L.wgu, const_cast<void*>(t.wgu_t), 2 * c.llm_inter, D, D, 2 * c.llm_inter, 1, 0, 0));
-    RC(transpose2d(wt->side, dt, L.wd, const_cast<void*>(t.wd_t), D, c.llm_inter, c.llm_inter, D, 1, 0, 0));
+    RC(transpose2d_streaming(wt->side, dt, L.wqkv, const_cast<void*>(t.wqkv_t), s.QKV, D, D, s.QKV));
+    RC(transpose2d_streaming(wt->side, dt, L.wo, const_cast<void*>(t.wo_t), D, s.OD, s.OD, D));
+    RC(transpose2d_streaming(wt->side, dt, L.wgu, const_cast<void*>(t.wgu_t), 2 * c.llm_inter, D, D, 2 * c.llm_inter));
+    RC(transpose2d_streaming(wt->side, dt, L.wd, const_cast<void*>(t.wd_t), D, c.llm_inter, c.llm_inter, D));
     UVX_HIP(hipEventRecord(wt->e_ready[l & 1], wt->side));
     return UVX_OK;
   };
@@ -1032,7 +1032,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     UVX_CHECK(wt != nullptr, UVX_ERR_RUNTIME, "llm_bwd: could not create the weight-transpose stream");
     UVX_HIP(hipEventRecord(wt->e_start, st));                 // everything issued before (an earlier backward's reads of the buffers)
     UVX_HIP(hipStreamWaitEvent(wt->side, wt->e_start, 0));
-    RC(transpose2d(wt->side, dt, w->lm_head, s.head_t, c.vocab, D, D, c.vocab, 1, 0, 0));
+    RC(transpose2d_streaming(wt->side, dt, w->lm_head, s.head_t, c.vocab, D, D, c.vocab));
     UVX_HIP(hipEventRecord(wt->e_head, wt->side));
     RC(issue_layer_t(c.llm_layers - 1));
     UVX_HIP(hipStreamWaitEvent(st, wt->e_head, 0));
