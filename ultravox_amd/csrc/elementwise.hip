@@ -50,11 +50,13 @@ __global__ void scale_k(T* __restrict__ x, long long n8, float s) {
 }
 
 template <typename T, int ACT>
-__global__ void swiglu_fwd_k(const T* __restrict__ in, T* __restrict__ out, long long n8, int half, int gate_first) {
+__global__ void swiglu_fwd_k(const T* __restrict__ in, T* __restrict__ out, long long n8, int half, int gate_first,
+                             const int32_t* __restrict__ rows_dev) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   const int hv = half / 8;
   const long long row = i / hv;
+  if (rows_dev && row >= *rows_dev) return;    // device-side row count (compacted supervised rows): the tail holds no data
   const int c = (int)(i % hv) * 8;
   const T* r = in + row * 2 * half;
   float a[8], g[8], o[8];
@@ -69,11 +71,12 @@ __global__ void swiglu_fwd_k(const T* __restrict__ in, T* __restrict__ out, long
 
 template <typename T, int ACT>
 __global__ void swiglu_bwd_k(const T* __restrict__ dout, const T* __restrict__ in, T* __restrict__ din,
-                             long long n8, int half, int gate_first) {
+                             long long n8, int half, int gate_first, const int32_t* __restrict__ rows_dev) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   const int hv = half / 8;
   const long long row = i / hv;
+  if (rows_dev && row >= *rows_dev) return;
   const int c = (int)(i % hv) * 8;
   const T* r = in + row * 2 * half;
   T* dr = din + row * 2 * half;
@@ -450,12 +453,12 @@ inline int grid1d(long long n, int th) { return (int)((n + th - 1) / th); }
 
 namespace uvx {
 
-int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first, int act) {
+int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first, int act, const int32_t* rows_dev) {
   UVX_CHECK(half % 8 == 0 && (gate_first != 2 || half % 16 == 0), UVX_ERR_SHAPE, "swiglu: half=%d must be a multiple of 8 (16 when interleaved)", half);
   UVX_CHECK(act >= 0 && act <= 2, UVX_ERR_INVALID, "swiglu: unknown activation %d", act);
   const long long n8 = (long long)rows * half / 8;
   if (n8 == 0) return UVX_OK;
-#define L(T, A) hipLaunchKernelGGL((swiglu_fwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)in, (T*)out, n8, half, gate_first)
+#define L(T, A) hipLaunchKernelGGL((swiglu_fwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)in, (T*)out, n8, half, gate_first, rows_dev)
   if (dtype == DT_BF16) { if (act == 2) L(bf16_t, 2); else if (act) L(bf16_t, 1); else L(bf16_t, 0); }
   else { if (act == 2) L(float, 2); else if (act) L(float, 1); else L(float, 0); }
 #undef L
@@ -464,12 +467,12 @@ int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, i
 }
 
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
-               int gate_first, int act) {
+               int gate_first, int act, const int32_t* rows_dev) {
   UVX_CHECK(half % 8 == 0, UVX_ERR_SHAPE, "swiglu_bwd: half=%d must be a multiple of 8", half);
   UVX_CHECK(act >= 0 && act <= 2, UVX_ERR_INVALID, "swiglu_bwd: unknown activation %d", act);
   const long long n8 = (long long)rows * half / 8;
   if (n8 == 0) return UVX_OK;
-#define L(T, A) hipLaunchKernelGGL((swiglu_bwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)din, n8, half, gate_first)
+#define L(T, A) hipLaunchKernelGGL((swiglu_bwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)din, n8, half, gate_first, rows_dev)
   if (dtype == DT_BF16) { if (act == 2) L(bf16_t, 2); else if (act) L(bf16_t, 1); else L(bf16_t, 0); }
   else { if (act == 2) L(float, 2); else if (act) L(float, 1); else L(float, 0); }
 #undef L

@@ -71,11 +71,12 @@ int layernorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, const
 // flavor 0 = LlamaRMSNorm: w * round(x * rstd) (two roundings, as HF computes it); flavor 1 = GemmaRMSNorm: the whole of
 // x * rstd * (1 + w) in f32, ONE rounding ([3P] modeling_gemma.py GemmaRMSNorm.forward).
 int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, float* rstd,
-                int rows, int cols, float eps, int flavor = 0);
+                int rows, int cols, float eps, int flavor = 0, const int32_t* rows_dev = nullptr);
 // dx = d(rmsnorm)/dx (+ dx_add if given: residual-stream gradient), optional dw partial accumulation
 // (f32 [cols], atomically accumulated; must be zeroed by the caller).
 int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w,
-                const void* dx_add, void* dx, float* dw, int rows, int cols, float eps, int flavor = 0);
+                const void* dx_add, void* dx, float* dw, int rows, int cols, float eps, int flavor = 0,
+                const int32_t* rows_dev = nullptr);
 // StackAudioFrames + RMSNorm (ultravox_model.py:722-730, 791): x [B, T, C] -> y [B, Tp/S, C*S]
 int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked,
                       int B, int T, int C, int S, float eps);
@@ -84,9 +85,12 @@ int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, v
 // layout: 0 = [value | gate] halves (UltravoxProjector), 1 = [gate | up] halves, 2 = 16-wide gate/up blocks interleaved
 // act: 0 = SiLU (SwiGLU: Llama MLP, UltravoxProjector), 1 = tanh-GELU (GeGLU: Gemma MLP, hidden_act gelu_pytorch_tanh),
 // 2 = exact erf GELU (Gemma checkpoints whose config says hidden_act "gelu")
-int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first, int act = 0);
+// rows_dev (here and in the rmsnorm entry points): device-side row count - rows at or beyond *rows_dev are skipped (the row-compacted last
+// layer of the training pair: `rows` is only the launch bound)
+int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first, int act = 0,
+               const int32_t* rows_dev = nullptr);
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
-               int gate_first, int act = 0);
+               int gate_first, int act = 0, const int32_t* rows_dev = nullptr);
 // x[i] = round(x[i] * s) in place over n elements (Gemma: inputs_embeds * sqrt(hidden_size), and its gradient)
 int scale_inplace(hipStream_t st, int dtype, void* x, long long n, float s);
 int rope_inplace(hipStream_t st, int dtype, void* qkv, const float* cos_sin, const int32_t* pos, int rows,

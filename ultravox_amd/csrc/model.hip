@@ -870,14 +870,14 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       g.residual = compact ? v.dx : cur.x_in; g.ldr = D; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
-    if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, probe_skip(256) && save_for_bwd ? v.d_n : v.n, nullptr, Mv, D, c.rms_eps, fl));
+    if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, probe_skip(256) && save_for_bwd ? v.d_n : v.n, nullptr, Mv, D, c.rms_eps, fl, mdev));
     {  // gate|up projection; wgu rows are packed as alternating 16-row gate / up blocks (weights.py)
       GemmDesc g = lin(v.n, L.wgu, cur.gu, Mv, 2 * c.llm_inter, D);
       const bool fused = dt == DT_BF16 && fl == UVX_LLM_LLAMA;   // SwiGLU fused into the epilogue (GeGLU: separate kernel)
       if (fused) { g.C2 = v.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
-      if (!fused) RC(swiglu_fwd(sx, dt, cur.gu, v.act, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
+      if (!fused) RC(swiglu_fwd(sx, dt, cur.gu, v.act, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act, mdev));
     }
     {
       GemmDesc g = lin(v.act, L.wd, x_out, Mv, D, c.llm_inter);
@@ -902,7 +902,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   RC(chains_join(ch));   // (also after an error above: the side streams must not be left forked)
   RC(rc_layers);
   if (tc) RC(layer_mlp(st, s, c.llm_layers - 1, true));
-  RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps, fl));
+  RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps, fl, tc ? s.sup + M : nullptr));   // (compact last layer: its rows only)
   if (rows) {
     UVX_CHECK(dt == DT_BF16, UVX_ERR_UNSUPPORTED, "llm_fwd_rows: bf16 only");
     UVX_CHECK(n_rows >= 0 && n_rows <= M, UVX_ERR_SHAPE, "llm_fwd_rows: %d rows of %d", n_rows, M);
@@ -1083,7 +1083,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   const int32_t* mdev_top = tc ? s.sup + M : nullptr;
   if (tc) {
     RC(gather_rows(st, dt, s.d_hn, s.sup, M, s.d_n, D));                 // d_hn was scattered to full rows: back to compact
-    RC(rmsnorm_bwd(st, dt, s.d_n, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl));
+    RC(rmsnorm_bwd(st, dt, s.d_n, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl, mdev_top));
   } else {
     RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl));
   }
@@ -1103,14 +1103,14 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       GemmDesc g = lin(v.dx, layer_t(l).wd_t, v.d_act, Mv, c.llm_inter, D);
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
-      if (!probe_skip(4)) RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
+      if (!probe_skip(4)) RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act, mdev));
     }
     {
       GemmDesc g = lin(v.d_gu, layer_t(l).wgu_t, v.d_n, Mv, D, 2 * c.llm_inter);
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
-    return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl);
+    return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl, mdev);
   };
   // attention half: v.dx (gradient of x_mid) -> dx_out (gradient of the layer's input).  d_o_ready: v.d_o and the residual
   // gradient `resid` were already produced for the whole batch (compact last layer), else d_o = dx . W_o^T here.

@@ -213,9 +213,10 @@ __device__ __forceinline__ void row_span(const RowMap& m, long long row, int col
 template <typename T>
 __global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y,
                               T* __restrict__ stacked, float* __restrict__ rstd_out, int cols, float eps,
-                              RowMap map, int flavor) {
+                              RowMap map, int flavor, const int32_t* __restrict__ rows_dev) {
   __shared__ float red[16];
   const long long row = blockIdx.x;
+  if (rows_dev && row >= *rows_dev) return;     // block-uniform: the tail of a row-compacted buffer holds no data
   long long base; int valid;
   row_span(map, row, cols, base, valid);
   const T* xr = x + base;
@@ -251,7 +252,8 @@ __global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, 
 template <typename T, bool WANT_DX, bool WANT_DW, int MV>
 __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
                               const T* __restrict__ dx_add, T* __restrict__ dx, float* __restrict__ dw,
-                              int rows, int cols, float eps, int rpb, int flavor) {
+                              int rows, int cols, float eps, int rpb, int flavor, const int32_t* __restrict__ rows_dev) {
+  if (rows_dev) rows = min(rows, *rows_dev);     // device-side row count (row-compacted buffers)
   // flavor 1 (Gemma): y = x_hat * (1 + w) with no intermediate rounding -> the effective weight is 1 + w and
   // d w gets the UNROUNDED x_hat
   __shared__ float red[16];
@@ -373,29 +375,29 @@ int layernorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, cons
 }
 
 static int rms_launch(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked,
-                      float* rstd, long long rows, int cols, float eps, RowMap map, int flavor = 0) {
+                      float* rstd, long long rows, int cols, float eps, RowMap map, int flavor = 0, const int32_t* rows_dev = nullptr) {
   UVX_CHECK(cols % 8 == 0, UVX_ERR_SHAPE, "rmsnorm: cols=%d must be a multiple of 8", cols);
   if (rows == 0) return UVX_OK;
   const int th = norm_threads(cols);
   // (at 4096 columns the block kernel is as fast - 11.5 vs 12.4 us at 2528 rows - and has 4x the blocks: keep it)
-  if (dtype == DT_BF16 && map.S == 0 && !stacked && (cols == 512 || cols == 1024 || cols == 2048)) {
+  if (dtype == DT_BF16 && map.S == 0 && !stacked && !rows_dev && (cols == 512 || cols == 1024 || cols == 2048)) {
     const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
 #define LW(NV) hipLaunchKernelGGL(rmsnorm_fwd_wave_k<NV>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, eps, flavor)
     if (cols == 512) LW(1); else if (cols == 1024) LW(2); else LW(4);
 #undef LW
   } else if (dtype == DT_BF16)
     hipLaunchKernelGGL(rmsnorm_fwd_k<bf16_t>, dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w,
-                       (bf16_t*)y, (bf16_t*)stacked, rstd, cols, eps, map, flavor);
+                       (bf16_t*)y, (bf16_t*)stacked, rstd, cols, eps, map, flavor, rows_dev);
   else
     hipLaunchKernelGGL(rmsnorm_fwd_k<float>, dim3(rows), dim3(th), 0, st, (const float*)x, (const float*)w,
-                       (float*)y, (float*)stacked, rstd, cols, eps, map, flavor);
+                       (float*)y, (float*)stacked, rstd, cols, eps, map, flavor, rows_dev);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
 
 int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, float* rstd, int rows,
-                int cols, float eps, int flavor) {
-  return rms_launch(st, dtype, x, w, y, nullptr, rstd, rows, cols, eps, RowMap{0, 0, 0, 0}, flavor);
+                int cols, float eps, int flavor, const int32_t* rows_dev) {
+  return rms_launch(st, dtype, x, w, y, nullptr, rstd, rows, cols, eps, RowMap{0, 0, 0, 0}, flavor, rows_dev);
 }
 
 int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked, int B,
@@ -407,7 +409,7 @@ int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, v
 
 template <typename T>
 static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const void* w, const void* dx_add,
-                          void* dx, float* dw, int rows, int cols, float eps, int flavor) {
+                          void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev) {
   const int th = 256;   // (512 threads with one vector each: 20.4 vs 17.7 us at 2528 x 4096 - profiles/r03_rmsnorm_bwd_variants.txt)
   UVX_CHECK(cols % 8 == 0 && cols <= th * 8 * MAXV, UVX_ERR_SHAPE, "rmsnorm_bwd: cols=%d unsupported", cols);
   if (rows == 0) return UVX_OK;
@@ -417,13 +419,13 @@ static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const v
   do {                                                                                                            \
     if (cols <= th * 8)                                                                                           \
       hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, 1>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x,   \
-                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor);               \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev);     \
     else if (cols <= th * 8 * 2)                                                                                  \
       hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, 2>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x,   \
-                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor);               \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev);     \
     else                                                                                                          \
       hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, MAXV>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x, \
-                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor);               \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev);     \
   } while (0)
   if (dx && dw) L(true, true);
   else if (dx) L(true, false);
@@ -434,9 +436,9 @@ static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const v
 }
 
 int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w, const void* dx_add,
-                void* dx, float* dw, int rows, int cols, float eps, int flavor) {
-  return dtype == DT_BF16 ? rms_bwd_launch<bf16_t>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor)
-                          : rms_bwd_launch<float>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor);
+                void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev) {
+  return dtype == DT_BF16 ? rms_bwd_launch<bf16_t>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev)
+                          : rms_bwd_launch<float>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev);
 }
 
 }  // namespace uvx
