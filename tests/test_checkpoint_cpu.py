@@ -164,6 +164,25 @@ def test_configs_outside_the_built_arithmetic_are_refused_not_run_as_llama():
             UltravoxConfig(audio_model_lora_config={"r": r, "unfreeze_layers": ["layers.3"]})
 
 
+def test_rope_parameters_of_newer_transformers_configs_are_read():
+    """transformers 5.x keeps rope_theta / scaling in `rope_parameters`; the reference's pin (4.51.3) has top-level rope_theta /
+    rope_scaling.  Both spellings must give the same TextConfig - never the silent 10000 default."""
+    import transformers
+    from ultravox_amd.config import UltravoxConfig
+    ok_text = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=1, num_key_value_heads=1, vocab_size=128)
+    scaling = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)
+    old = UltravoxConfig(text_config={**ok_text, "rope_theta": 500000.0, "rope_scaling": scaling}).text_config
+    new = UltravoxConfig(text_config={**ok_text, "rope_parameters": {"rope_theta": 500000.0, **scaling}}).text_config
+    assert old.rope_theta == new.rope_theta == 500000.0 and old.rope_scaling == new.rope_scaling == scaling
+    plain = UltravoxConfig(text_config={**ok_text, "rope_parameters": {"rope_theta": 1000000.0, "rope_type": "default"}}).text_config
+    assert plain.rope_theta == 1000000.0 and plain.rope_scaling is None
+    hf = transformers.Qwen3Config(**ok_text, head_dim=64, rope_theta=1000000.0)              # whatever the installed version stores
+    got = UltravoxConfig(text_config=hf).text_config
+    assert got.model_type == "qwen3" and got.rope_theta == 1000000.0 and got.head_dim == 64
+    got = UltravoxConfig(text_config=hf.to_dict()).text_config
+    assert got.rope_theta == 1000000.0
+
+
 def test_from_pretrained_base_gets_adapter_keys_before_the_checkpoint_is_merged():
     """The merge refuses unknown keys; a LoRA checkpoint's adapter keys must therefore already exist in the base."""
     from ultravox_amd import checkpoint

@@ -249,6 +249,16 @@ def _mk(cls, value, presets, model_id):
     _check_supported(cls, get)
     kw = ({k: v for k, v in value.items() if k in names} if isinstance(value, dict)
           else {k: getattr(value, k) for k in names if hasattr(value, k)})
+    if cls is TextConfig:
+        # transformers 5.x moved rope_theta / rope_scaling into one `rope_parameters` dict (the reference pins 4.51.3, whose configs
+        # carry the two top-level fields): read both spellings - a config object or config.json saved by a newer transformers must not
+        # fall back to the dataclass default of 10000 (Llama-3: 500000, Qwen: 1000000)
+        rp = get("rope_parameters")
+        if isinstance(rp, dict):
+            if rp.get("rope_theta") is not None and get("rope_theta") is None:
+                kw["rope_theta"] = float(rp["rope_theta"])
+            if rp.get("rope_type", rp.get("type", "default")) != "default" and get("rope_scaling") is None:
+                kw["rope_scaling"] = {k: v for k, v in rp.items() if k != "rope_theta"}
     if cls is AudioConfig and get("model_type") == "wav2vec2":        # Wav2Vec2Config's names for the transformer dimensions
         for mine, theirs in (("d_model", "hidden_size"), ("encoder_layers", "num_hidden_layers"),
                              ("encoder_attention_heads", "num_attention_heads"), ("encoder_ffn_dim", "intermediate_size")):
