@@ -131,7 +131,7 @@ def test_configs_outside_the_built_arithmetic_are_refused_not_run_as_llama():
     ok_text = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1, vocab_size=128)
     UltravoxConfig(text_config={**ok_text, "model_type": "llama", "attention_bias": False, "tie_word_embeddings": False})
     for bad in ({"model_type": "mistral"}, {"attention_bias": True}, {"mlp_bias": True}, {"sliding_window": 4096},
-                {"tie_word_embeddings": True}, {"hidden_act": "gelu_pytorch_tanh"},
+                {"hidden_act": "gelu_pytorch_tanh"},
                 {"model_type": "qwen2", "sliding_window": 4096, "use_sliding_window": True}, {"model_type": "qwen3", "attention_bias": True},
                 {"model_type": "qwen3", "layer_types": ["sliding_attention"]}):
         with pytest.raises(ValueError):
@@ -143,6 +143,19 @@ def test_configs_outside_the_built_arithmetic_are_refused_not_run_as_llama():
     assert q3.has_qk_norm and not q3.has_qkv_bias and q3.head_dim == 64 and q3.hidden_act == "silu" and not q3.ties_head
     q2 = UltravoxConfig(text_config={**ok_text, "model_type": "qwen2", "tie_word_embeddings": True}).text_config
     assert q2.has_qkv_bias and not q2.has_qk_norm and q2.ties_head and q2.head_dim == 32
+    tied = UltravoxConfig(text_config={**ok_text, "tie_word_embeddings": True}).text_config          # Llama-3.2-1B / 3B style
+    assert tied.model_type == "llama" and tied.ties_head
+    from ultravox_amd.weights import pack_llm, random_state_dict
+    import torch
+    cfg_t = UltravoxConfig(text_config={**ok_text, "tie_word_embeddings": True})
+    sd_t = random_state_dict(cfg_t, seed=1)
+    assert "language_model.lm_head.weight" not in sd_t
+    packed = pack_llm(sd_t, cfg_t, torch.float32, "cpu")
+    assert packed["lm_head"] is packed["embed"] and torch.equal(packed["lm_head_t"], packed["embed"].t())
+    cfg_u = UltravoxConfig(text_config=ok_text)
+    sd_u = {k: v for k, v in random_state_dict(cfg_u, seed=1).items() if k != "language_model.lm_head.weight"}
+    with pytest.raises(KeyError, match="tie"):
+        pack_llm(sd_u, cfg_u, torch.float32, "cpu")
     big = UltravoxConfig(text_model_id="Qwen/Qwen3-32B").text_config
     assert (big.hidden_size, big.num_attention_heads, big.num_key_value_heads, big.head_dim, big.intermediate_size) == (5120, 64, 8, 128, 25600)
     with pytest.raises(ValueError, match="model_type"):

@@ -176,8 +176,8 @@ class TextConfig:
         return self.model_type == "qwen2"
 
     @property
-    def ties_head(self) -> bool:       # lm_head IS embed_tokens (Gemma always; Qwen checkpoints that say so)
-        return self.model_type == "gemma" or (self.model_type in ("qwen2", "qwen3") and bool(self.tie_word_embeddings))
+    def ties_head(self) -> bool:       # lm_head IS embed_tokens (Gemma always; any checkpoint whose config says tie_word_embeddings)
+        return self.model_type == "gemma" or bool(self.tie_word_embeddings)      # e.g. Llama-3.2-1B / 3B, the small Qwen models
 
 
 AUDIO_PRESETS: Dict[str, Dict[str, Any]] = {
@@ -284,9 +284,6 @@ def _check_supported(cls, get) -> None:
         live_window = get("sliding_window") and (mt not in ("qwen2", "qwen3") or get("use_sliding_window"))
         if live_window or any(lt != "full_attention" for lt in (get("layer_types") or ())):
             raise ValueError("text_config.sliding_window is not built (full causal attention only)")
-        if get("tie_word_embeddings") and mt not in ("gemma", "qwen2", "qwen3"):     # Gemma ties by definition; Qwen: ties_head
-            raise ValueError("text_config.tie_word_embeddings = True: pass the embedding matrix as lm_head.weight "
-                             "(checkpoint.language_model_state_dict does this for tied checkpoints) and leave the flag unset")
 
 
 class UltravoxConfig:

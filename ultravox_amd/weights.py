@@ -321,10 +321,12 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
     P = prefix + "model."
     out = {"embed": cv(sd[P + "embed_tokens.weight"]), "norm": cv(sd[P + "norm.weight"]), "layers": []}
     # tied head (Gemma; HF tie_word_embeddings): lm_head IS the embedding matrix - one tensor, two uses
-    out["lm_head"] = cv(sd[prefix + "lm_head.weight"]) if prefix + "lm_head.weight" in sd else out["embed"]
+    head = sd.get(prefix + "lm_head.weight")
+    # (checkpoint.language_model_state_dict hands a tied checkpoint's embedding over under both names: still one device tensor)
+    out["lm_head"] = out["embed"] if head is None or head is sd[P + "embed_tokens.weight"] else cv(head)
     if prefix + "lm_head.weight" not in sd and not getattr(t, "ties_head", getattr(t, "is_gemma", False)):
-        raise KeyError(f"{prefix}lm_head.weight is missing (only Gemma, and Qwen configs with tie_word_embeddings, tie the head to "
-                       "embed_tokens)")
+        raise KeyError(f"{prefix}lm_head.weight is missing and the config does not tie the head to embed_tokens "
+                       "(tie_word_embeddings; Gemma always ties)")
     out["lm_head_t"] = tr(out["lm_head"])
     for i in range(t.num_hidden_layers):
         L = f"{P}layers.{i}."
