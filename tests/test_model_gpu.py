@@ -408,6 +408,32 @@ def test_streamed_weight_transposes_are_bit_identical(dtype):
         assert torch.equal(ga[k], gb[k]), k
 
 
+def test_tied_head_llama_train_step_f32_within_1e3():
+    """tie_word_embeddings (Llama-3.2-1B / 3B in the reference's recipes): no lm_head.weight - the head IS embed_tokens (one device
+    tensor, its transpose made from it); loss, logits and projector gradients against the oracle in f32."""
+    from oracle.reference_cpu import OracleModel
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = UltravoxConfig(**{**SMALL, "text_config": dict(SMALL["text_config"], tie_word_embeddings=True)})
+    sd = random_state_dict(cfg, seed=17)
+    assert cfg.text_config.ties_head and "language_model.lm_head.weight" not in sd
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32)
+    assert model._llm["lm_head"] is model._llm["embed"]
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    b = batch_for(cfg)
+    ref, grads, _ = oracle.train_step(b)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    out = model.forward(**gb)
+    model.train()
+    loss = model.forward_backward(**gb)
+    assert (out.logits.cpu() - ref["logits"]).abs().max().item() < 1e-3
+    assert abs(loss.item() - ref["loss"].item()) < 1e-4
+    mine = model.projector_grads()
+    for k, g in grads.items():
+        assert rel_l2(mine[k], g) < 2e-3, k
+
+
 def test_fused_inverse_rope_in_the_attention_backward_is_bit_identical():
     """Option 14 (default on): dq / dk leave the LLM's attention backward already RoPE-inverted (epilogue of the dQ kernel, the
     GQA group reduction) instead of a separate rope pass over d_qkv.  Same arithmetic and rounding points: d inputs_embeds is

@@ -231,6 +231,15 @@ TEXT_PRESETS["Qwen/Qwen2.5-7B-Instruct"] = dict(model_type="qwen2", hidden_size=
                                                 num_attention_heads=28, num_key_value_heads=4, vocab_size=152064,
                                                 rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=32768,
                                                 eos_token_id=151645)
+# the other ids the reference's recipes name (ultravox/training/configs/*.yaml)
+TEXT_PRESETS["meta-llama/Llama-3.2-1B-Instruct"] = dict(hidden_size=2048, intermediate_size=8192, num_hidden_layers=16,
+                                                        num_attention_heads=32, num_key_value_heads=8, head_dim=64, vocab_size=128256,
+                                                        rope_theta=500000.0, rope_scaling=dict(_LLAMA3_SCALING, factor=32.0),
+                                                        max_position_embeddings=131072, eos_token_id=128009, rms_norm_eps=1e-5,
+                                                        tie_word_embeddings=True)
+TEXT_PRESETS["meta-llama/Meta-Llama-3.1-8B-Instruct"] = TEXT_PRESETS["meta-llama/Llama-3.1-8B-Instruct"]
+TEXT_PRESETS["meta-llama/Meta-Llama-3.1-70B-Instruct"] = TEXT_PRESETS["meta-llama/Llama-3.3-70B-Instruct"]      # same architecture
+TEXT_PRESETS["meta-llama/Llama-3-8B-Instruct"] = TEXT_PRESETS["meta-llama/Meta-Llama-3-8B-Instruct"]
 TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat"] = TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat-v1.0"]
 TEXT_PRESETS["meta-llama/Meta-Llama-3-8B"] = TEXT_PRESETS["meta-llama/Meta-Llama-3-8B-Instruct"]
 
