@@ -422,6 +422,59 @@ def test_qwen_backbones_match_hf_blocks(family):
     np.testing.assert_allclose(emb_or.grad[keep].numpy(), emb_hf.grad[keep].numpy(), rtol=2e-4, atol=1e-7)
 
 
+def test_gemma3_backbone_matches_hf_blocks():
+    """The reference's other v0.6 recipe trains on google/gemma-3-27b-it (ultravox/training/configs/v0.6_config_gemma3_27b.yaml).
+    [3P] check: the oracle's gemma3 flavour - four Gemma norms per layer (post-norms before each residual add), q / k norms over
+    head_dim, query_pre_attn_scalar scaling, sliding-window layers with their own un-scaled rotary table and the global layers with
+    linear rope scaling, GeGLU, tied head, the sqrt(hidden) scale inside the EMBEDDING module - == the installed HF
+    Gemma3ForCausalLM on the same weights, with a window shorter than the sequence: logits, loss, the gradient reaching
+    inputs_embeds, and the scaled embedding lookup."""
+    import transformers
+    kw = dict(hidden_size=96, intermediate_size=256, num_hidden_layers=7, num_attention_heads=4, num_key_value_heads=2, head_dim=32,
+              vocab_size=160, rms_norm_eps=1e-6, query_pre_attn_scalar=24, sliding_window=8, max_position_embeddings=512)
+    hfc = transformers.Gemma3TextConfig(**kw, rope_parameters={"sliding_attention": {"rope_type": "default", "rope_theta": 10000.0},
+                                                               "full_attention": {"rope_type": "linear", "factor": 8.0, "rope_theta": 1000000.0}},
+                                        attn_implementation="eager")
+    cfg = UltravoxConfig(audio_config=TINY["audio_config"], hidden_size=64, text_config=hfc)
+    t = cfg.text_config
+    assert t.is_gemma3 and t.has_qk_norm and t.ties_head and t.rope_scaling == {"rope_type": "linear", "factor": 8.0}
+    assert t.rope_local_base_freq == 10000.0 and t.layer_types.count("full_attention") == 1 and t.sliding_window == 8
+    hf = transformers.Gemma3ForCausalLM(hfc).eval()
+    sd = random_state_dict(cfg, seed=8)
+    llm_sd = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}
+    missing, unexpected = hf.load_state_dict(llm_sd, strict=False)
+    assert not unexpected and missing == ["lm_head.weight"]
+    hf.tie_weights()
+    torch.manual_seed(0)
+    B, T = 2, 21                                        # > sliding_window: the local layers really mask
+    labels = torch.randint(0, 160, (B, T))
+    labels[:, :9] = -100
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, -4:] = 0
+    emb_hf = (torch.randn(B, T, 96) * 0.1).requires_grad_(True)
+    emb_or = emb_hf.detach().clone().requires_grad_(True)
+    out = hf(inputs_embeds=emb_hf, attention_mask=am, labels=labels)
+    out.loss.backward()
+    logits = O.llama_ref(sd, cfg, emb_or, am)
+    loss = O.causal_lm_loss_ref(logits, labels)
+    loss.backward()
+    keep = am.bool()
+    np.testing.assert_allclose(logits.detach()[keep].numpy(), out.logits.detach()[keep].numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(loss.item(), out.loss.item(), rtol=1e-5)
+    np.testing.assert_allclose(emb_or.grad[keep].numpy(), emb_hf.grad[keep].numpy(), rtol=2e-4, atol=1e-7)
+    ids = torch.randint(0, 160, (2, 5))
+    np.testing.assert_allclose(O.OracleModel(cfg, sd, dtype=torch.float32).embed(ids).numpy(), hf.get_input_embeddings()(ids).detach().numpy(), rtol=1e-6)
+    # a window that covers the sequence is plain causal attention (what the HIP training path requires: T <= sliding_window)
+    wide = UltravoxConfig(audio_config=TINY["audio_config"], hidden_size=64, text_config=dict(hfc.to_dict(), sliding_window=64))
+    with torch.no_grad():
+        a = O.llama_ref(sd, wide, emb_or.detach(), am)
+        hf_w = transformers.Gemma3ForCausalLM(transformers.Gemma3TextConfig(**{**kw, "sliding_window": 64}, rope_parameters=hfc.rope_parameters,
+                                                                            attn_implementation="eager")).eval()
+        hf_w.load_state_dict(llm_sd, strict=False); hf_w.tie_weights()
+        b = hf_w(inputs_embeds=emb_or.detach(), attention_mask=am).logits
+    np.testing.assert_allclose(a[keep].numpy(), b[keep].numpy(), rtol=1e-4, atol=2e-5)
+
+
 W2V_TINY = {"model_type": "wav2vec2", "hidden_size": 64, "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 128,
             "conv_dim": [64] * 7, "num_conv_pos_embeddings": 16, "num_conv_pos_embedding_groups": 4}
 

@@ -127,6 +127,14 @@ class TextConfig:
     initializer_range: float = 0.02
     eos_token_id: Optional[int] = None
     tie_word_embeddings: Optional[bool] = None
+    # gemma3 only ([3P] Gemma3TextConfig): attention scale = query_pre_attn_scalar ** -0.5; every layer whose type is
+    # "sliding_attention" attends to the last `sliding_window` positions and rotates with rope_local_base_freq (no scaling), the
+    # "full_attention" layers (every sliding_window_pattern-th) with rope_theta / rope_scaling (linear)
+    query_pre_attn_scalar: Optional[float] = None
+    sliding_window: Optional[int] = None
+    sliding_window_pattern: Optional[int] = None
+    layer_types: Optional[List[str]] = None
+    rope_local_base_freq: Optional[float] = None
 
     _FAMILY_DEFAULTS = {
         "llama": dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
@@ -142,10 +150,17 @@ class TextConfig:
         "qwen3": dict(hidden_size=4096, intermediate_size=22016, num_hidden_layers=32, num_attention_heads=32,
                       num_key_value_heads=32, head_dim=128, vocab_size=151936, rms_norm_eps=1e-6,
                       max_position_embeddings=32768, tie_word_embeddings=False),
+        # [3P] Gemma3TextConfig defaults (the 4B text stack); google/gemma-3-27b-it is a preset
+        "gemma3": dict(hidden_size=2304, intermediate_size=9216, num_hidden_layers=26, num_attention_heads=8, num_key_value_heads=4,
+                       head_dim=256, vocab_size=262208, rms_norm_eps=1e-6, max_position_embeddings=131072, eos_token_id=1,
+                       tie_word_embeddings=True, query_pre_attn_scalar=256, sliding_window=4096, sliding_window_pattern=6,
+                       rope_local_base_freq=10000.0),
     }
-    FAMILIES = ("llama", "gemma", "qwen2", "qwen3")
+    FAMILIES = ("llama", "gemma", "qwen2", "qwen3", "gemma3")
 
     def __post_init__(self):
+        if self.model_type == "gemma3_text":        # the text stack of a Gemma3ForConditionalGeneration checkpoint
+            self.model_type = "gemma3"
         if self.model_type not in self.FAMILIES:
             raise ValueError(f"text_config.model_type {self.model_type!r} is not built ({', '.join(self.FAMILIES)})")
         for k, v in self._FAMILY_DEFAULTS[self.model_type].items():
@@ -155,21 +170,34 @@ class TextConfig:
             self.num_key_value_heads = self.num_attention_heads
         if self.head_dim is None:
             self.head_dim = self.hidden_size // self.num_attention_heads
-        want = "gelu_pytorch_tanh" if self.model_type == "gemma" else "silu"
+        want = "gelu_pytorch_tanh" if self.model_type in ("gemma", "gemma3") else "silu"
         if self.hidden_act is None:
             self.hidden_act = want
         # [3P] GemmaMLP applies ACT2FN[config.hidden_act] (transformers 4.51.3 and the installed 5.x alike): "gelu" in a Gemma
         # checkpoint's config.json is the EXACT erf GELU, not the tanh approximation - built as its own GLU activation
         if self.hidden_act != want and not (self.model_type == "gemma" and self.hidden_act == "gelu"):
             raise ValueError(f"text_config.hidden_act {self.hidden_act!r} is not built for {self.model_type} ({want})")
+        if self.model_type == "gemma3":
+            if self.layer_types is None:      # [3P] Gemma3TextConfig: every sliding_window_pattern-th layer is global
+                self.layer_types = ["full_attention" if (i + 1) % self.sliding_window_pattern == 0 else "sliding_attention"
+                                    for i in range(self.num_hidden_layers)]
+            if len(self.layer_types) != self.num_hidden_layers or set(self.layer_types) - {"full_attention", "sliding_attention"}:
+                raise ValueError(f"text_config.layer_types {self.layer_types} does not fit {self.num_hidden_layers} gemma3 layers")
+            rs = self.rope_scaling
+            if rs and rs.get("rope_type", rs.get("type", "default")) not in ("default", "linear"):
+                raise ValueError(f"gemma3 rope_scaling {rs}: default or linear (the global layers) are built")
 
     @property
-    def is_gemma(self) -> bool:
+    def is_gemma(self) -> bool:        # Gemma-1: GemmaRMSNorm, GeGLU, the embedding scale applied INSIDE the model (4.51.3)
         return self.model_type == "gemma"
 
     @property
-    def has_qk_norm(self) -> bool:     # Qwen3Attention.q_norm / k_norm
-        return self.model_type == "qwen3"
+    def is_gemma3(self) -> bool:       # Gemma-3 text stack: Gemma norms, GeGLU, four norms per layer, q / k norms, local / global layers
+        return self.model_type == "gemma3"
+
+    @property
+    def has_qk_norm(self) -> bool:     # Qwen3Attention / Gemma3Attention q_norm / k_norm
+        return self.model_type in ("qwen3", "gemma3")
 
     @property
     def has_qkv_bias(self) -> bool:    # Qwen2Attention: q_proj / k_proj / v_proj with bias, o_proj without
@@ -177,7 +205,7 @@ class TextConfig:
 
     @property
     def ties_head(self) -> bool:       # lm_head IS embed_tokens (Gemma always; any checkpoint whose config says tie_word_embeddings)
-        return self.model_type == "gemma" or bool(self.tie_word_embeddings)      # e.g. Llama-3.2-1B / 3B, the small Qwen models
+        return self.model_type == "gemma" or bool(self.tie_word_embeddings)      # e.g. Llama-3.2-1B / 3B, the small Qwen models, Gemma-3
 
 
 AUDIO_PRESETS: Dict[str, Dict[str, Any]] = {
@@ -240,6 +268,12 @@ TEXT_PRESETS["meta-llama/Llama-3.2-1B-Instruct"] = dict(hidden_size=2048, interm
 TEXT_PRESETS["meta-llama/Meta-Llama-3.1-8B-Instruct"] = TEXT_PRESETS["meta-llama/Llama-3.1-8B-Instruct"]
 TEXT_PRESETS["meta-llama/Meta-Llama-3.1-70B-Instruct"] = TEXT_PRESETS["meta-llama/Llama-3.3-70B-Instruct"]      # same architecture
 TEXT_PRESETS["meta-llama/Llama-3-8B-Instruct"] = TEXT_PRESETS["meta-llama/Meta-Llama-3-8B-Instruct"]
+# the reference's other v0.6 backbone (v0.6_config_gemma3_27b.yaml): the text stack of google/gemma-3-27b-it (public config.json)
+TEXT_PRESETS["google/gemma-3-27b-it"] = dict(model_type="gemma3", hidden_size=5376, intermediate_size=21504, num_hidden_layers=62,
+                                             num_attention_heads=32, num_key_value_heads=16, head_dim=128, vocab_size=262208,
+                                             rms_norm_eps=1e-6, rope_theta=1000000.0, rope_scaling=dict(rope_type="linear", factor=8.0),
+                                             rope_local_base_freq=10000.0, query_pre_attn_scalar=168, sliding_window=1024,
+                                             sliding_window_pattern=6, max_position_embeddings=131072, eos_token_id=1)
 TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat"] = TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat-v1.0"]
 TEXT_PRESETS["meta-llama/Meta-Llama-3-8B"] = TEXT_PRESETS["meta-llama/Meta-Llama-3-8B-Instruct"]
 
@@ -255,6 +289,11 @@ def _mk(cls, value, presets, model_id):
         return value
     names = {f.name for f in dataclasses.fields(cls)}
     get = (lambda k: value.get(k)) if isinstance(value, dict) else (lambda k: getattr(value, k, None))   # dict or HF config object
+    if cls is TextConfig and get("model_type") == "gemma3" and get("text_config") is not None:
+        # google/gemma-3-*-it are Gemma3ForConditionalGeneration checkpoints: AutoModelForCausalLM (ultravox_model.py:507-523) loads
+        # the whole model and the LLM path runs its text stack - the nested text_config
+        value = get("text_config")
+        get = (lambda k: value.get(k)) if isinstance(value, dict) else (lambda k: getattr(value, k, None))
     _check_supported(cls, get)
     kw = ({k: v for k, v in value.items() if k in names} if isinstance(value, dict)
           else {k: getattr(value, k) for k in names if hasattr(value, k)})
@@ -263,11 +302,21 @@ def _mk(cls, value, presets, model_id):
         # carry the two top-level fields): read both spellings - a config object or config.json saved by a newer transformers must not
         # fall back to the dataclass default of 10000 (Llama-3: 500000, Qwen: 1000000)
         rp = get("rope_parameters")
+        if isinstance(rp, dict) and isinstance(rp.get("full_attention"), dict):      # gemma3 in transformers 5.x: one entry per layer type
+            if get("rope_local_base_freq") is None and isinstance(rp.get("sliding_attention"), dict):
+                kw["rope_local_base_freq"] = float(rp["sliding_attention"].get("rope_theta", 10000.0))
+            rp = rp["full_attention"]
         if isinstance(rp, dict):
             if rp.get("rope_theta") is not None and get("rope_theta") is None:
                 kw["rope_theta"] = float(rp["rope_theta"])
             if rp.get("rope_type", rp.get("type", "default")) != "default" and get("rope_scaling") is None:
                 kw["rope_scaling"] = {k: v for k, v in rp.items() if k != "rope_theta"}
+        rs = kw.get("rope_scaling")      # (5.x config objects alias rope_scaling to the rope_parameters dict)
+        if isinstance(rs, dict) and isinstance(rs.get("full_attention"), dict):
+            rs = rs["full_attention"]
+        if isinstance(rs, dict):
+            rs = {k: v for k, v in rs.items() if k != "rope_theta"}
+            kw["rope_scaling"] = None if rs.get("rope_type", rs.get("type", "default")) == "default" else rs
     if cls is AudioConfig and get("model_type") == "wav2vec2":        # Wav2Vec2Config's names for the transformer dimensions
         for mine, theirs in (("d_model", "hidden_size"), ("encoder_layers", "num_hidden_layers"),
                              ("encoder_attention_heads", "num_attention_heads"), ("encoder_ffn_dim", "intermediate_size")):
@@ -279,7 +328,7 @@ def _mk(cls, value, presets, model_id):
 def _check_supported(cls, get) -> None:
     """Fields outside the dataclass are dropped by _mk, so anything that would change the arithmetic must be refused here:
     a Qwen2 (q/k/v biases), Mistral (sliding window) or Gemma config would otherwise run silently as a bias-free Llama."""
-    want = TextConfig.FAMILIES if cls is TextConfig else ("whisper", "wav2vec2")
+    want = (*TextConfig.FAMILIES, "gemma3_text") if cls is TextConfig else ("whisper", "wav2vec2")
     mt = get("model_type")
     if mt is not None and mt not in want:
         raise ValueError(f"{cls.__name__}: model_type {mt!r} is not built (this path implements {', '.join(want)})")
@@ -290,6 +339,11 @@ def _check_supported(cls, get) -> None:
                                  "are bias-free in every family here)")
         # Qwen2 / Qwen3 configs always carry a sliding_window VALUE; it is live only with use_sliding_window ([3P] Qwen2Config:
         # "sliding_window if use_sliding_window else None") - layer_types other than full attention likewise
+        if mt in ("gemma3", "gemma3_text"):      # Gemma-3: the local layers' window is part of the family (model.py checks T against it)
+            for flag in ("attn_logit_softcapping", "final_logit_softcapping", "use_bidirectional_attention"):
+                if get(flag):
+                    raise ValueError(f"text_config.{flag} is not built")
+            return
         live_window = get("sliding_window") and (mt not in ("qwen2", "qwen3") or get("use_sliding_window"))
         if live_window or any(lt != "full_attention" for lt in (get("layer_types") or ())):
             raise ValueError("text_config.sliding_window is not built (full causal attention only)")

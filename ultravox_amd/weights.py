@@ -142,14 +142,17 @@ def _random_rest(sd, cfg, rn, near_one, device, dtype):
         if getattr(t, "has_qkv_bias", False):      # Qwen2Attention: biases on q / k / v only
             for n, rows in (("q", Hq * dh), ("k", Hkv * dh), ("v", Hkv * dh)):
                 sd[L + f"self_attn.{n}_proj.bias"] = rn(rows, s=0.5)
-        if getattr(t, "has_qk_norm", False):       # Qwen3Attention.q_norm / k_norm: RMSNorm weights over head_dim
+        if getattr(t, "has_qk_norm", False):       # Qwen3Attention / Gemma3Attention q_norm / k_norm: RMSNorm weights over head_dim
             sd[L + "self_attn.q_norm.weight"] = near_one(dh)
             sd[L + "self_attn.k_norm.weight"] = near_one(dh)
+        if getattr(t, "is_gemma3", False):         # Gemma3DecoderLayer: four norms (HF names; post_attention_layernorm is a POST norm here)
+            sd[L + "pre_feedforward_layernorm.weight"] = near_one(D)
+            sd[L + "post_feedforward_layernorm.weight"] = near_one(D)
     sd[P + "norm.weight"] = near_one(D)
-    if getattr(t, "is_gemma", False):
+    if getattr(t, "is_gemma", False) or getattr(t, "is_gemma3", False):
         # Gemma: norm weights are stored zero-centred (the norm multiplies by 1 + w), the embedding is divided by the
         # sqrt(hidden) the model multiplies back in, and the head is the embedding matrix (tied: no lm_head key)
-        for k in [k for k in sd if k.startswith(P) and k.endswith(("layernorm.weight", "model.norm.weight"))]:
+        for k in [k for k in sd if k.startswith(P) and k.endswith(("layernorm.weight", "model.norm.weight", "q_norm.weight", "k_norm.weight"))]:
             sd[k] = (sd[k].float() - 1.0).to(dtype)
         sd[P + "embed_tokens.weight"] = (sd[P + "embed_tokens.weight"].float() / math.sqrt(D)).to(dtype)
     elif not getattr(t, "ties_head", False):
@@ -157,12 +160,15 @@ def _random_rest(sd, cfg, rn, near_one, device, dtype):
     return sd
 
 
-def rope_inv_freq(tc) -> torch.Tensor:
-    """[3P] LlamaRotaryEmbedding: default and "llama3" rope_scaling (Llama-3.1/3.3)."""
+def rope_inv_freq(tc, local: bool = False) -> torch.Tensor:
+    """[3P] LlamaRotaryEmbedding: default, "llama3" (Llama-3.1/3.3) and "linear" (Gemma-3's global layers) rope_scaling.
+    local: the table of Gemma-3's sliding-window layers (rope_local_base_freq, never scaled)."""
     dh = tc.head_dim
-    inv = 1.0 / (tc.rope_theta ** (torch.arange(0, dh, 2, dtype=torch.int64).float() / dh))
-    rs = tc.rope_scaling
-    if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+    inv = 1.0 / ((tc.rope_local_base_freq if local else tc.rope_theta) ** (torch.arange(0, dh, 2, dtype=torch.int64).float() / dh))
+    rs = None if local else tc.rope_scaling
+    if rs and rs.get("rope_type", rs.get("type")) == "linear":
+        inv = inv / rs["factor"]
+    elif rs and rs.get("rope_type", rs.get("type")) == "llama3":
         factor, lo, hi = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"]
         old = rs["original_max_position_embeddings"]
         wavelen = 2 * math.pi / inv
@@ -176,8 +182,8 @@ def rope_inv_freq(tc) -> torch.Tensor:
     return inv
 
 
-def rope_table(tc, length: int, device) -> torch.Tensor:
-    inv = rope_inv_freq(tc)
+def rope_table(tc, length: int, device, local: bool = False) -> torch.Tensor:
+    inv = rope_inv_freq(tc, local)
     freqs = torch.arange(length, dtype=torch.float32)[:, None] * inv[None, :]
     return torch.stack([freqs.cos(), freqs.sin()], dim=-1).contiguous().to(device)  # [len, dh/2, 2]
 
@@ -350,13 +356,21 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
         if getattr(t, "has_qk_norm", False):
             extras["q_norm"], extras["k_norm"] = cv(sd[L + "self_attn.q_norm.weight"]), cv(sd[L + "self_attn.k_norm.weight"])
         elif L + "self_attn.q_norm.weight" in sd:
-            raise ValueError(f"{L}self_attn.q_norm.weight present: per-head q / k norms are built for the qwen3 family only")
+            raise ValueError(f"{L}self_attn.q_norm.weight present: per-head q / k norms are built for the qwen3 / gemma3 families only")
+        ln2_key = "post_attention_layernorm.weight"
+        if getattr(t, "is_gemma3", False):      # four norms: ln1 | ln1_post (HF post_attention_layernorm) | ln2 (pre_feedforward) | ln2_post
+            extras["ln1_post"] = cv(sd[L + "post_attention_layernorm.weight"])
+            extras["ln2_post"] = cv(sd[L + "post_feedforward_layernorm.weight"])
+            ln2_key = "pre_feedforward_layernorm.weight"
         out["layers"].append({
             **extras,
-            "ln1": cv(sd[L + "input_layernorm.weight"]), "ln2": cv(sd[L + "post_attention_layernorm.weight"]),
+            "ln1": cv(sd[L + "input_layernorm.weight"]), "ln2": cv(sd[L + ln2_key]),
             "wqkv": wqkv, "wo": wo, "wgu": wgu, "wd": wd,
             "wqkv_t": tr(wqkv), "wo_t": tr(wo), "wgu_t": tr(wgu), "wd_t": tr(wd),
         })
     out["rope_len"] = rope_len or min(t.max_position_embeddings, 8192)
     out["rope"] = rope_table(t, out["rope_len"], device)
+    if getattr(t, "is_gemma3", False):          # second table + per-layer flags for the sliding-window layers
+        out["rope_local"] = rope_table(t, out["rope_len"], device, local=True)
+        out["layer_local"] = [int(lt == "sliding_attention") for lt in t.layer_types]
     return out
