@@ -50,6 +50,9 @@ WORKLOADS = {
     # behind whisper-large-v3-turbo), per-rank shapes as c2 / c3.  64 GB of frozen bf16 weights + their transposed copies on one GPU.
     "q3": dict(name="Qwen3-32B (frozen) + whisper-large-v3-turbo, bs=8x30s clips per GPU, adapter train",
                audio="openai/whisper-large-v3-turbo", text="Qwen/Qwen3-32B", B=8, seconds=30.0),
+    # the reference's other v0.6 recipe (v0.6_config_gemma3_27b.yaml): the text stack of google/gemma-3-27b-it
+    "g3": dict(name="Gemma-3-27B (frozen) + whisper-large-v3-turbo, bs=8x30s clips per GPU, adapter train",
+               audio="openai/whisper-large-v3-turbo", text="google/gemma-3-27b-it", B=8, seconds=30.0),
     # not a BASELINE.json configuration (its configs[3] is 70B INFERENCE): the reference's 70B TRAINING recipes
     # (v0.6_config_llama3_70b.yaml: Llama-3.3-70B behind whisper-large-v3-turbo), per-rank shapes as c2.  141 GB of frozen bf16 weights
     # on ONE 288 GB GPU - possible because the backward's transposed copies are streamed (uvx_config_t.llm_wt_stream), not resident

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 10
+#define UVX_ABI_VERSION 11
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -73,12 +73,23 @@ typedef struct {
    * buffers - uvx_llm_layer_t.*_t and lm_head_t may then be NULL.  Halves the resident weight bytes (a 70B-parameter LLM then
    * trains on one 288 GB GPU: 141 GB of weights instead of 282) for one extra read + write of the weights per step. */
   int32_t llm_wt_stream;
+  /* UVX_LLM_GEMMA3 (the reference's v0.6_config_gemma3_27b.yaml: the text stack of google/gemma-3-27b-it, [3P] modeling_gemma3.py):
+   * llm_attn_scale = query_pre_attn_scalar ** -0.5 (0 = head_dim ** -0.5, every other family); llm_window = sliding_window of the
+   * layers flagged in uvx_llm_weights_t.layer_local - sequences (and caches) longer than it are refused, so those layers run as
+   * plain causal attention with their own rotary table. */
+  float llm_attn_scale;
+  int32_t llm_window;
 } uvx_config_t;
 #define UVX_ACT_SILU 0
 #define UVX_ACT_GELU_TANH 1
 #define UVX_ACT_GELU_ERF 2
 #define UVX_LLM_LLAMA 0
 #define UVX_LLM_GEMMA 1
+/* Gemma-3 text stack: Gemma norms and GeGLU as UVX_LLM_GEMMA, plus a POST norm on each branch before its residual add
+ * (uvx_llm_layer_t.ln1_post / ln2_post), q_norm / k_norm in the Gemma flavour (llm_qk_norm = 1), a second rotary table for the
+ * sliding-window layers, llm_attn_scale; the sqrt(hidden) embedding scale is applied to the LOOKED-UP rows only (uvx_embed_merge:
+ * [3P] Gemma3TextScaledWordEmbedding), never to inputs_embeds inside the model; head tied by the host. */
+#define UVX_LLM_GEMMA3 2
 
 /* Encoder weights.  Names follow the HF WhisperEncoder state dict; packing done once at
  * load time by the host:  wqkv = [q_proj*head_dim^-0.5 ; k_proj ; v_proj] ([3d, d]), bqkv likewise with a
@@ -128,6 +139,8 @@ typedef struct {
   /* family extras, NULL when the family has none.  bqkv: [q;k;v] projection biases [(H+2Hkv)*dh] (Qwen2: q_proj / k_proj / v_proj
    * carry a bias, o_proj does not - [3P] modeling_qwen2.py Qwen2Attention); q_norm, k_norm: [dh] (Qwen3, see llm_qk_norm). */
   const void *bqkv, *q_norm, *k_norm;
+  /* Gemma-3: post_attention_layernorm / post_feedforward_layernorm [D] (ln2 is then pre_feedforward_layernorm) */
+  const void *ln1_post, *ln2_post;
 } uvx_llm_layer_t;
 typedef struct {
   const void* embed;             /* [vocab, D] */
@@ -137,6 +150,10 @@ typedef struct {
   const void* lm_head_t;         /* [D, vocab] or NULL */
   const float* rope_cos_sin;     /* [rope_len, head_dim/2, 2] f32 (cos, sin), built by the host */
   int32_t rope_len;
+  /* Gemma-3 (else NULL): the rotary table of the sliding-window layers (rope_local_base_freq, same shape) and a HOST array
+   * [llm_layers] of flags: 1 = sliding-window ("local") layer */
+  const float* rope_cos_sin_local;
+  const int32_t* layer_local;
 } uvx_llm_weights_t;
 
 /* ============================== hot-path entry points ============================== */
@@ -421,10 +438,11 @@ int32_t uvx_rope(void* stream, int32_t dtype, void* x, const float* cos_sin, int
  * Hq query heads, then Hkv key heads; position of row r = r % T); wq / wk [head_dim]; raw = NULL or [rows, (Hq + Hkv) * head_dim],
  * receives the un-normalised q | k rows.  uvx_qk_norm_bwd: d_qkv's q | k columns hold the gradient of the normalised (pre-rotary)
  * rows on entry and the gradient of the raw rows on return. */
+/* flavor: 0 = w * round(x_hat) (Qwen3RMSNorm == LlamaRMSNorm), 1 = x_hat * (1 + w) in f32 with one rounding (Gemma3RMSNorm) */
 int32_t uvx_qk_norm_rope(void* stream, int32_t dtype, void* qkv, const void* wq, const void* wk, void* raw, const float* cos_sin,
-                         int32_t rows, int32_t T, int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t ld, float eps);
+                         int32_t rows, int32_t T, int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t ld, float eps, int32_t flavor);
 int32_t uvx_qk_norm_bwd(void* stream, int32_t dtype, void* d_qkv, const void* raw, const void* wq, const void* wk, int32_t rows,
-                        int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t ld, float eps);
+                        int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t ld, float eps, int32_t flavor);
 
 typedef struct {
   const void *q, *k, *v; /* [B, T, H, D] views with token strides ldq/ldk/ldv (elements) */

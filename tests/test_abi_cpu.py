@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in header_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in include/uvx.h but not exported by libuvx.so: {missing}"
     assert set(_lib.EXPORTS) == set(header_functions())
-    assert lib.uvx_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.uvx_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_struct_mirrors_match_header_sizes():
@@ -39,7 +39,7 @@ def test_struct_mirrors_match_header_sizes():
     n_fields = sum(len(decl.split(",")) for decl in re.findall(r"(?:int32_t|float)\s+([^;]+);", body))
     assert n_fields == len(_lib.Config._fields_)
     assert ctypes.sizeof(_lib.Config) == 4 * n_fields
-    assert ctypes.sizeof(_lib.EncLayer) == 8 * 16 and ctypes.sizeof(_lib.LlmLayer) == 8 * 13
+    assert ctypes.sizeof(_lib.EncLayer) == 8 * 16 and ctypes.sizeof(_lib.LlmLayer) == 8 * 15
     assert ctypes.sizeof(_lib.EncLoraLayer) == 32 and ctypes.sizeof(_lib.EncoderLora) == 16
 
 

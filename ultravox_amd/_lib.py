@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 10  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+ABI_VERSION = 11  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
 
 
 def lib() -> C.CDLL:
@@ -96,6 +96,7 @@ class Config(C.Structure):
         ("llm_layers", C.c_int32), ("llm_d", C.c_int32), ("llm_heads", C.c_int32), ("llm_kv_heads", C.c_int32),
         ("llm_head_dim", C.c_int32), ("llm_inter", C.c_int32), ("vocab", C.c_int32), ("rms_eps", C.c_float),
         ("llm_flavor", C.c_int32), ("llm_act", C.c_int32), ("llm_qk_norm", C.c_int32), ("llm_wt_stream", C.c_int32),
+        ("llm_attn_scale", C.c_float), ("llm_window", C.c_int32),
     ]
 
 
@@ -151,7 +152,8 @@ class ProjectorGrads(C.Structure):
 
 
 _LLM_LAYER_FIELDS = ["ln1", "wqkv", "wo", "ln2", "wgu", "wd", "wqkv_t", "wo_t", "wgu_t", "wd_t",
-                     "bqkv", "q_norm", "k_norm"]     # family extras (Qwen2 biases, Qwen3 per-head norms): null when absent
+                     "bqkv", "q_norm", "k_norm",     # family extras (Qwen2 biases, Qwen3 / Gemma-3 per-head norms): null when absent
+                     "ln1_post", "ln2_post"]         # Gemma-3's post norms
 
 
 class LlmLayer(C.Structure):
@@ -161,7 +163,7 @@ class LlmLayer(C.Structure):
 class LlmWeights(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("layers", C.POINTER(LlmLayer)), ("norm", C.c_void_p),
                 ("lm_head", C.c_void_p), ("lm_head_t", C.c_void_p), ("rope_cos_sin", C.c_void_p),
-                ("rope_len", C.c_int32)]
+                ("rope_len", C.c_int32), ("rope_cos_sin_local", C.c_void_p), ("layer_local", C.POINTER(C.c_int32))]
 
 
 class AttnDesc(C.Structure):

@@ -97,12 +97,12 @@ extern "C" int32_t uvx_rope(void* stream, int32_t dtype, void* x, const float* c
 }
 extern "C" int32_t uvx_qk_norm_rope(void* stream, int32_t dtype, void* qkv, const void* wq, const void* wk, void* raw,
                                     const float* cos_sin, int32_t rows, int32_t T, int32_t Hq, int32_t Hkv, int32_t head_dim,
-                                    int32_t ld, float eps) {
-  return uvx::qk_norm_rope((hipStream_t)stream, dtype, qkv, wq, wk, raw, cos_sin, nullptr, rows, T, Hq, Hkv, head_dim, ld, eps);
+                                    int32_t ld, float eps, int32_t flavor) {
+  return uvx::qk_norm_rope((hipStream_t)stream, dtype, qkv, wq, wk, raw, cos_sin, nullptr, rows, T, Hq, Hkv, head_dim, ld, eps, flavor);
 }
 extern "C" int32_t uvx_qk_norm_bwd(void* stream, int32_t dtype, void* d_qkv, const void* raw, const void* wq, const void* wk,
-                                   int32_t rows, int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t ld, float eps) {
-  return uvx::qk_norm_bwd((hipStream_t)stream, dtype, d_qkv, raw, wq, wk, rows, Hq, Hkv, head_dim, ld, eps);
+                                   int32_t rows, int32_t Hq, int32_t Hkv, int32_t head_dim, int32_t ld, float eps, int32_t flavor) {
+  return uvx::qk_norm_bwd((hipStream_t)stream, dtype, d_qkv, raw, wq, wk, rows, Hq, Hkv, head_dim, ld, eps, flavor);
 }
 extern "C" int32_t uvx_ce_loss(void* stream, int32_t dtype, const void* logits, const int64_t* labels, float* loss,
                                void* dlogits, int32_t B, int32_t T, int32_t V, int32_t ld, float grad_scale,

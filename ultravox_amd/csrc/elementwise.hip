@@ -133,7 +133,7 @@ __global__ void rope_k(T* __restrict__ x, const float* __restrict__ cs, const in
 template <typename T>
 __global__ void qk_norm_rope_k(T* __restrict__ x, const T* __restrict__ wq, const T* __restrict__ wk, T* __restrict__ raw,
                                const float* __restrict__ cs, const int32_t* __restrict__ pos, long long n_items, int Tlen, int Hq,
-                               int Hkv, int D, int ld, float eps) {
+                               int Hkv, int D, int ld, float eps, int flavor) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;      // (whole heads: n_items is a multiple of D/16, a power of two that divides the block)
   const int per_head = D / 16, H = Hq + Hkv;
@@ -162,7 +162,9 @@ __global__ void qk_norm_rope_k(T* __restrict__ x, const T* __restrict__ wq, cons
   const float* t = cs + ((long long)p * (D / 2) + c) * 2;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const float nl = rnd<T>(wl[k] * rnd<T>(lo[k] * rstd)), nh = rnd<T>(wh[k] * rnd<T>(hi[k] * rstd));
+    // flavor 1 (Gemma-3's Gemma3RMSNorm): x_hat * (1 + w) in f32, one rounding; 0 (Qwen3): w * round(x_hat)
+    const float nl = flavor ? rnd<T>((lo[k] * rstd) * (1.0f + wl[k])) : rnd<T>(wl[k] * rnd<T>(lo[k] * rstd));
+    const float nh = flavor ? rnd<T>((hi[k] * rstd) * (1.0f + wh[k])) : rnd<T>(wh[k] * rnd<T>(hi[k] * rstd));
     const float co = rnd<T>(t[2 * k]), si = rnd<T>(t[2 * k + 1]);
     olo[k] = rnd<T>(nl * co) + rnd<T>(-nh * si);
     ohi[k] = rnd<T>(nh * co) + rnd<T>(nl * si);
@@ -176,7 +178,7 @@ __global__ void qk_norm_rope_k(T* __restrict__ x, const T* __restrict__ wq, cons
 // rmsnorm_bwd_k's arithmetic per row of D: r = rsqrt(mean(x^2) + eps), dx = r dy w - x r^3 mean(dy w x).  One thread = 8 columns.
 template <typename T>
 __global__ void qk_norm_bwd_k(T* __restrict__ dqk, const T* __restrict__ raw, const T* __restrict__ wq, const T* __restrict__ wk,
-                              long long n_items, int Hq, int Hkv, int D, int ld, float eps) {
+                              long long n_items, int Hq, int Hkv, int D, int ld, float eps, int flavor) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const int per_head = D / 8, H = Hq + Hkv;
@@ -190,6 +192,10 @@ __global__ void qk_norm_bwd_k(T* __restrict__ dqk, const T* __restrict__ raw, co
   ld8<T>(raw + (row * H + h) * D + c, xv);
   ld8<T>(g, gv);
   ld8<T>(w, wv);
+  if (flavor) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wv[k] += 1.0f;      // Gemma: the effective weight is 1 + w
+  }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) { s1 += xv[k] * xv[k]; s2 += gv[k] * wv[k] * xv[k]; }
@@ -504,7 +510,7 @@ int rope_inplace(hipStream_t st, int dtype, void* x, const float* cos_sin, const
 }
 
 int qk_norm_rope(hipStream_t st, int dtype, void* qkv, const void* wq, const void* wk, void* raw, const float* cos_sin,
-                 const int32_t* pos, int rows, int T, int Hq, int Hkv, int head_dim, int ld, float eps) {
+                 const int32_t* pos, int rows, int T, int Hq, int Hkv, int head_dim, int ld, float eps, int flavor) {
   UVX_CHECK((head_dim == 64 || head_dim == 128 || head_dim == 256) && ld % 8 == 0, UVX_ERR_SHAPE,
             "qk_norm_rope: head_dim=%d ld=%d unsupported (64, 128 or 256; row stride a multiple of 8)", head_dim, ld);
   UVX_CHECK(qkv && wq && wk && cos_sin, UVX_ERR_INVALID, "qk_norm_rope: null argument");
@@ -512,16 +518,16 @@ int qk_norm_rope(hipStream_t st, int dtype, void* qkv, const void* wq, const voi
   if (n == 0) return UVX_OK;
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(qk_norm_rope_k<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, (bf16_t*)qkv, (const bf16_t*)wq, (const bf16_t*)wk,
-                       (bf16_t*)raw, cos_sin, pos, n, T, Hq, Hkv, head_dim, ld, eps);
+                       (bf16_t*)raw, cos_sin, pos, n, T, Hq, Hkv, head_dim, ld, eps, flavor);
   else
     hipLaunchKernelGGL(qk_norm_rope_k<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, (float*)qkv, (const float*)wq, (const float*)wk,
-                       (float*)raw, cos_sin, pos, n, T, Hq, Hkv, head_dim, ld, eps);
+                       (float*)raw, cos_sin, pos, n, T, Hq, Hkv, head_dim, ld, eps, flavor);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
 
 int qk_norm_bwd(hipStream_t st, int dtype, void* d_qkv, const void* raw, const void* wq, const void* wk, int rows, int Hq, int Hkv,
-                int head_dim, int ld, float eps) {
+                int head_dim, int ld, float eps, int flavor) {
   UVX_CHECK((head_dim == 64 || head_dim == 128 || head_dim == 256) && ld % 8 == 0, UVX_ERR_SHAPE,
             "qk_norm_bwd: head_dim=%d ld=%d unsupported", head_dim, ld);
   UVX_CHECK(d_qkv && raw && wq && wk, UVX_ERR_INVALID, "qk_norm_bwd: null argument");
@@ -529,10 +535,10 @@ int qk_norm_bwd(hipStream_t st, int dtype, void* d_qkv, const void* raw, const v
   if (n == 0) return UVX_OK;
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(qk_norm_bwd_k<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, (bf16_t*)d_qkv, (const bf16_t*)raw, (const bf16_t*)wq,
-                       (const bf16_t*)wk, n, Hq, Hkv, head_dim, ld, eps);
+                       (const bf16_t*)wk, n, Hq, Hkv, head_dim, ld, eps, flavor);
   else
     hipLaunchKernelGGL(qk_norm_bwd_k<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, (float*)d_qkv, (const float*)raw, (const float*)wq,
-                       (const float*)wk, n, Hq, Hkv, head_dim, ld, eps);
+                       (const float*)wk, n, Hq, Hkv, head_dim, ld, eps, flavor);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

@@ -290,6 +290,12 @@ struct LayerIO { void *x_in, *x_mid; };
 int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, void* x_mid, void* x_out) {
   const int dt = c.dtype, D = c.llm_d;
   RC(rmsnorm_fwd(st, dt, x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
+  if (c.llm_flavor == UVX_LLM_GEMMA3) {      // x_out = x_mid + post_feedforward_norm(mlp(pre_feedforward_norm(x_mid)))
+    RC(gemm(st, dt, lin(s.n, L.wgu, s.gu, M, 2 * c.llm_inter, D)));
+    RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2, c.llm_act));
+    RC(gemm(st, dt, lin(s.act, L.wd, s.n, M, D, c.llm_inter)));        // (s.n is free again: the gate|up GEMM has consumed it)
+    return rmsnorm_fwd(st, dt, s.n, L.ln2_post, x_out, nullptr, M, D, c.rms_eps, c.llm_flavor, nullptr, x_mid);
+  }
   GemmDesc g = lin(s.n, L.wgu, s.gu, M, 2 * c.llm_inter, D);
   const bool fused = dt == DT_BF16 && c.llm_flavor == UVX_LLM_LLAMA;   // SwiGLU in the epilogue; Gemma's GeGLU: separate kernel
   if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
@@ -300,18 +306,48 @@ int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, I
   return gemm(st, dt, d);
 }
 
-// q | k | v projection of a layer (+ Qwen2's biases), then the rotary embedding - for Qwen3 behind its per-head q_norm / k_norm
+// x_out = x + o_proj(o)  -  Gemma-3: x + post_attention_norm(o_proj(o))
+int attn_out(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, const void* o, int OD, const void* x, void* x_out) {
+  const int dt = c.dtype, D = c.llm_d;
+  if (c.llm_flavor == UVX_LLM_GEMMA3) {
+    RC(gemm(st, dt, lin(o, L.wo, s.n, M, D, OD)));                    // (s.n is free: the q|k|v GEMM has consumed it)
+    return rmsnorm_fwd(st, dt, s.n, L.ln1_post, x_out, nullptr, M, D, c.rms_eps, c.llm_flavor, nullptr, x);
+  }
+  GemmDesc g = lin(o, L.wo, x_out, M, D, OD);
+  g.residual = x; g.ldr = D;
+  return gemm(st, dt, g);
+}
+float attn_scale_of(const uvx_config_t& c) { return c.llm_attn_scale > 0.f ? c.llm_attn_scale : 1.0f / sqrtf((float)c.llm_head_dim); }
+// Gemma-3: post norms present, a local rotary table where layers are flagged, and the cache within the sliding window (a local layer
+// over at most `window` positions is plain causal attention; longer caches are not built)
+int g3_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int Tmax) {
+  if (c.llm_flavor != UVX_LLM_GEMMA3) return UVX_OK;
+  bool any_local = false;
+  for (int l = 0; l < c.llm_layers; ++l) {
+    UVX_CHECK(w->layers[l].ln1_post && w->layers[l].ln2_post, UVX_ERR_INVALID, "llm: Gemma-3 layer %d has no post norms", l);
+    any_local = any_local || (w->layer_local && w->layer_local[l]);
+  }
+  UVX_CHECK(!any_local || w->rope_cos_sin_local, UVX_ERR_INVALID, "llm: Gemma-3 sliding-window layers need rope_cos_sin_local");
+  UVX_CHECK(!any_local || c.llm_window <= 0 || Tmax <= c.llm_window, UVX_ERR_UNSUPPORTED,
+            "llm: a cache of %d positions exceeds Gemma-3's sliding window (%d): windowed attention over longer sequences is not built", Tmax, c.llm_window);
+  return UVX_OK;
+}
+
+// q | k | v projection of a layer (+ Qwen2's biases), then the rotary embedding - for Qwen3 / Gemma-3 behind the per-head q_norm / k_norm
+// (l: the layer index - Gemma-3's sliding-window layers rotate with their own table)
 int qkv_rope(hipStream_t st, const uvx_config_t& c, const uvx_llm_weights_t* w, const uvx_llm_layer_t& L, const void* n, void* qkv,
-             const int32_t* pos, int rows, int T, int QKV) {
+             const int32_t* pos, int rows, int T, int QKV, int l) {
   const int dt = c.dtype, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads;
+  const bool g3 = c.llm_flavor == UVX_LLM_GEMMA3;
+  const float* rope = g3 && w->layer_local && w->layer_local[l] ? w->rope_cos_sin_local : w->rope_cos_sin;
   GemmDesc g = lin(n, L.wqkv, qkv, rows, QKV, c.llm_d);
   g.bias = L.bqkv;
   RC(gemm(st, dt, g));
   if (c.llm_qk_norm) {
     UVX_CHECK(L.q_norm && L.k_norm, UVX_ERR_INVALID, "llm: llm_qk_norm is set but a layer has no q_norm / k_norm");
-    return qk_norm_rope(st, dt, qkv, L.q_norm, L.k_norm, nullptr, w->rope_cos_sin, pos, rows, T, Hq, Hkv, dh, QKV, c.rms_eps);
+    return qk_norm_rope(st, dt, qkv, L.q_norm, L.k_norm, nullptr, rope, pos, rows, T, Hq, Hkv, dh, QKV, c.rms_eps, g3 ? 1 : 0);
   }
-  return rope_inplace(st, dt, qkv, w->rope_cos_sin, pos, rows, T, Hq + Hkv, dh, QKV, 0);
+  return rope_inplace(st, dt, qkv, rope, pos, rows, T, Hq + Hkv, dh, QKV, 0);
 }
 
 }  // namespace
@@ -336,6 +372,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   const uvx_config_t& c = *cfg;
   UVX_CHECK(T >= 1 && T <= Tmax, UVX_ERR_SHAPE, "llm_prefill: prompt length %d exceeds the cache length %d", T, Tmax);
   UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
+  RC(g3_check(c, w, Tmax));
   hipStream_t st = (hipStream_t)stream;
   Arena a(workspace, ws_bytes);
   InferWs s = carve(a, c, B, T);
@@ -350,7 +387,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
-    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, T, s.QKV));
+    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, T, s.QKV, l));
     {
       char* ck = at(kv_cache, l * layer_stride, dt);
       char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
@@ -366,11 +403,9 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
     ad.q = s.qkv; ad.k = at(s.qkv, (size_t)Hq * dh, dt); ad.v = at(s.qkv, (size_t)(Hq + Hkv) * dh, dt);
     ad.vt = s.vt; ad.o = s.o; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = s.kvl;
     ad.B = B; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
-    ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.scale = 1.0f / sqrtf((float)dh);
+    ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.scale = attn_scale_of(c);
     RC(attention_fwd(st, dt, ad));
-    GemmDesc g = lin(s.o, L.wo, s.x2, M, D, s.OD);
-    g.residual = s.x; g.ldr = D;
-    RC(gemm(st, dt, g));
+    RC(attn_out(st, c, L, s, M, s.o, s.OD, s.x, s.x2));
     RC(mlp_block(st, c, L, s, M, s.x2, s.x));
   }
   // logits of the LAST position of every sequence only (what generate() consumes)
@@ -417,6 +452,7 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
   UVX_CHECK(Tn >= 1 && cur_len >= 0 && Tf <= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: %d cached + %d new positions exceed the cache length %d",
             cur_len, Tn, Tmax);
   UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
+  RC(g3_check(c, w, Tmax));
   hipStream_t st = (hipStream_t)stream;
   Arena a(workspace, ws_bytes);
   ChunkWs k;
@@ -433,7 +469,7 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
-    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, Tn, s.QKV));
+    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, Tn, s.QKV, l));
     char* ck = at(kv_cache, l * layer_stride, dt);
     char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
     const long long na = (long long)M * (KVD / 8), ng = (long long)B * Tf * (KVD / 8);
@@ -453,14 +489,12 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
     ad.q = k.fq; ad.k = at(k.fq, (size_t)Hq * dh, dt); ad.v = at(k.fq, (size_t)(Hq + Hkv) * dh, dt);
     ad.vt = k.fvt; ad.o = k.fo; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = nullptr;
     ad.B = B; ad.T = Tf; ad.Tp = k.Tfp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
-    ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.q_begin = cur_len; ad.scale = 1.0f / sqrtf((float)dh);
+    ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.q_begin = cur_len; ad.scale = attn_scale_of(c);
     RC(attention_fwd(st, dt, ad));
     for (int b = 0; b < B; ++b)
       UVX_HIP(hipMemcpyAsync(at(s.o, (size_t)b * Tn * s.OD, dt), at(k.fo, ((size_t)b * Tf + cur_len) * s.OD, dt), (size_t)Tn * s.OD * es,
                              hipMemcpyDeviceToDevice, st));
-    GemmDesc g = lin(s.o, L.wo, s.x2, M, D, s.OD);
-    g.residual = s.x; g.ldr = D;
-    RC(gemm(st, dt, g));
+    RC(attn_out(st, c, L, s, M, s.o, s.OD, s.x, s.x2));
     RC(mlp_block(st, c, L, s, M, s.x2, s.x));
   }
   UVX_HIP(hipMemcpy2DAsync(s.last, (size_t)D * es, at(s.x, (size_t)(Tn - 1) * D, dt), (size_t)Tn * D * es, (size_t)D * es, B,
@@ -481,15 +515,16 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
   UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_decode: workspace %zu < %zu bytes", ws_bytes, a.off);
   const int dt = c.dtype, D = c.llm_d, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads, KVD = Hkv * dh;
   UVX_CHECK(dh == 64 || dh == 128 || dh == 256, UVX_ERR_UNSUPPORTED, "llm_decode: head_dim %d not supported", dh);
+  RC(g3_check(c, w, cur_len + 1));
   const size_t es = esz(dt);
   UVX_HIP(hipMemcpyAsync(s.x, token_embeds, (size_t)B * D * es, hipMemcpyDeviceToDevice, st));
   if (c.llm_flavor == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, s.x, (long long)B * D, gemma_normalizer(c)));
   const size_t layer_stride = (size_t)2 * B * Tmax * KVD;
-  const float scale = 1.0f / sqrtf((float)dh);
+  const float scale = attn_scale_of(c);
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
-    RC(qkv_rope(st, c, w, L, s.n, s.qkv, positions, B, 1, s.QKV));
+    RC(qkv_rope(st, c, w, L, s.n, s.qkv, positions, B, 1, s.QKV, l));
     char* ck = at(kv_cache, l * layer_stride, dt);
     char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
     const long long n = (long long)B * (KVD / 8);
@@ -517,9 +552,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
       else hipLaunchKernelGGL((attn_decode_k<float, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
     }
     UVX_LAUNCH_CHECK();
-    GemmDesc g = lin(s.o, L.wo, s.x2, B, D, s.OD);
-    g.residual = s.x; g.ldr = D;
-    RC(gemm(st, dt, g));
+    RC(attn_out(st, c, L, s, B, s.o, s.OD, s.x, s.x2));
     RC(mlp_block(st, c, L, s, B, s.x2, s.x));
   }
   RC(rmsnorm_fwd(st, dt, s.x, w->norm, s.hn, nullptr, B, D, c.rms_eps, c.llm_flavor));

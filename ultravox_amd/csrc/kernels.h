@@ -71,7 +71,8 @@ int layernorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, const
 // flavor 0 = LlamaRMSNorm: w * round(x * rstd) (two roundings, as HF computes it); flavor 1 = GemmaRMSNorm: the whole of
 // x * rstd * (1 + w) in f32, ONE rounding ([3P] modeling_gemma.py GemmaRMSNorm.forward).
 int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, float* rstd,
-                int rows, int cols, float eps, int flavor = 0, const int32_t* rows_dev = nullptr);
+                int rows, int cols, float eps, int flavor = 0, const int32_t* rows_dev = nullptr, const void* resid = nullptr);
+// (resid: y = round(rmsnorm(x)) + resid - Gemma-3's post norms feed the residual add directly)
 // dx = d(rmsnorm)/dx (+ dx_add if given: residual-stream gradient), optional dw partial accumulation
 // (f32 [cols], atomically accumulated; must be zeroed by the caller).
 int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w,
@@ -99,9 +100,9 @@ int rope_inplace(hipStream_t st, int dtype, void* qkv, const float* cos_sin, con
 // [rows, ld] q|k|v buffer; raw (or null) receives the un-normalised q | k rows [rows, (Hq + Hkv) * head_dim] for qk_norm_bwd,
 // which turns the gradient of the normalised rows (q | k columns of d_qkv) into the gradient of the raw ones, in place.
 int qk_norm_rope(hipStream_t st, int dtype, void* qkv, const void* wq, const void* wk, void* raw, const float* cos_sin,
-                 const int32_t* pos, int rows, int T, int Hq, int Hkv, int head_dim, int ld, float eps);
+                 const int32_t* pos, int rows, int T, int Hq, int Hkv, int head_dim, int ld, float eps, int flavor = 0);
 int qk_norm_bwd(hipStream_t st, int dtype, void* d_qkv, const void* raw, const void* wq, const void* wk, int rows, int Hq, int Hkv,
-                int head_dim, int ld, float eps);
+                int head_dim, int ld, float eps, int flavor = 0);
 int embed_gather(hipStream_t st, int dtype, const void* table, const int64_t* ids, void* out, int rows,
                  int D, int vocab);
 // owner[B*T] / item_batch[n_items] are int32 scratch filled by merge_owner and reused by the backward.

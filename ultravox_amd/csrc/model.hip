@@ -173,7 +173,8 @@ struct LlmLayerStash {
   void *x_in, *qkv, *o, *x_mid, *gu;
   float* lse;
   void *t, *bqT, *bkT;   // LLM LoRA (text_model_lora_config): [lora_A_q(n) | lora_A_k(n)] [M, 128]; lora_B^T of q / k
-  void* qk_raw;          // Qwen3 (llm_qk_norm): the q | k projections before q_norm / k_norm [M, (Hq + Hkv) * dh]
+  void* qk_raw;          // Qwen3 / Gemma-3 (llm_qk_norm): the q | k projections before q_norm / k_norm [M, (Hq + Hkv) * dh]
+  void *o_pre, *m_pre;   // Gemma-3: o_proj / down_proj outputs BEFORE their post norms [M, D] (the post norms' backward needs them)
 };
 struct LlmWs {
   LlmLayerStash ls[1];   // layer-0 slot; slot i starts slot_bytes * i later
@@ -211,6 +212,8 @@ void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
   s.bqT = a.take((size_t)64 * c.llm_heads * c.llm_head_dim * es);
   s.bkT = a.take((size_t)64 * c.llm_kv_heads * c.llm_head_dim * es);
   s.qk_raw = a.take(c.llm_qk_norm ? M * (c.llm_heads + c.llm_kv_heads) * c.llm_head_dim * es : 0);
+  s.o_pre = a.take(c.llm_flavor == UVX_LLM_GEMMA3 ? M * c.llm_d * es : 0);
+  s.m_pre = a.take(c.llm_flavor == UVX_LLM_GEMMA3 ? M * c.llm_d * es : 0);
 }
 LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
   LlmWs w;
@@ -267,6 +270,7 @@ LlmLayerStash llm_layer(const LlmWs& w, int slot) {
   s.x_in = (char*)s.x_in + d; s.qkv = (char*)s.qkv + d; s.o = (char*)s.o + d;
   s.x_mid = (char*)s.x_mid + d; s.gu = (char*)s.gu + d; s.lse = (float*)((char*)s.lse + d);
   s.t = (char*)s.t + d; s.bqT = (char*)s.bqT + d; s.bkT = (char*)s.bkT + d; s.qk_raw = (char*)s.qk_raw + d;
+  s.o_pre = (char*)s.o_pre + d; s.m_pre = (char*)s.m_pre + d;
   return s;
 }
 
@@ -303,6 +307,7 @@ LlmWs llm_view(const LlmWs& w, const uvx_config_t& c, int b0, int nb, int T) {
   adv(s.x_in, r0 * D * es); adv(s.qkv, r0 * w.QKV * es); adv(s.o, r0 * w.OD * es); adv(s.x_mid, r0 * D * es);
   adv(s.gu, r0 * 2 * I * es); adv(s.lse, sizeof(float) * (size_t)b0 * c.llm_heads * T); adv(s.t, r0 * 128 * es);
   if (c.llm_qk_norm) adv(s.qk_raw, r0 * (c.llm_heads + c.llm_kv_heads) * c.llm_head_dim * es);
+  if (c.llm_flavor == UVX_LLM_GEMMA3) { adv(s.o_pre, r0 * D * es); adv(s.m_pre, r0 * D * es); }
   adv(v.x_final, r0 * D * es); adv(v.hn, r0 * D * es); adv(v.n, r0 * D * es); adv(v.act, r0 * I * es);
   adv(v.vt, (size_t)b0 * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
   adv(v.logits, r0 * c.vocab * es);
@@ -401,12 +406,14 @@ int chains_join(const Chains& ch) {
 int check_cfg(const uvx_config_t* c) {
   UVX_CHECK(c != nullptr, UVX_ERR_INVALID, "null config");
   UVX_CHECK(c->dtype == DT_BF16 || c->dtype == DT_F32, UVX_ERR_INVALID, "bad dtype %d", c->dtype);
-  UVX_CHECK(c->llm_flavor == UVX_LLM_LLAMA || c->llm_flavor == UVX_LLM_GEMMA, UVX_ERR_INVALID, "bad llm_flavor %d", c->llm_flavor);
-  UVX_CHECK(c->llm_act >= UVX_ACT_SILU && c->llm_act <= UVX_ACT_GELU_ERF && (c->llm_flavor == UVX_LLM_GEMMA) == (c->llm_act != UVX_ACT_SILU),
+  UVX_CHECK(c->llm_flavor >= UVX_LLM_LLAMA && c->llm_flavor <= UVX_LLM_GEMMA3, UVX_ERR_INVALID, "bad llm_flavor %d", c->llm_flavor);
+  UVX_CHECK(c->llm_act >= UVX_ACT_SILU && c->llm_act <= UVX_ACT_GELU_ERF && (c->llm_flavor != UVX_LLM_LLAMA) == (c->llm_act != UVX_ACT_SILU),
             UVX_ERR_INVALID, "llm_act %d does not fit llm_flavor %d (Llama: SiLU; Gemma: tanh- or erf-GELU)", c->llm_act, c->llm_flavor);
   UVX_CHECK(c->llm_wt_stream == 0 || c->llm_wt_stream == 1, UVX_ERR_INVALID, "llm_wt_stream %d: 0 or 1", c->llm_wt_stream);
-  UVX_CHECK(c->llm_qk_norm == 0 || (c->llm_qk_norm == 1 && c->llm_flavor == UVX_LLM_LLAMA), UVX_ERR_INVALID,
-            "llm_qk_norm %d: 0 or 1, and only with the Llama-flavoured norms (Qwen3)", c->llm_qk_norm);
+  UVX_CHECK(c->llm_qk_norm == 0 || (c->llm_qk_norm == 1 && c->llm_flavor != UVX_LLM_GEMMA), UVX_ERR_INVALID,
+            "llm_qk_norm %d: 0 or 1 (Qwen3: Llama-flavoured; Gemma-3: Gemma-flavoured)", c->llm_qk_norm);
+  UVX_CHECK((c->llm_flavor == UVX_LLM_GEMMA3) == (c->llm_qk_norm == 1 && c->llm_flavor == UVX_LLM_GEMMA3) && c->llm_attn_scale >= 0.f &&
+            c->llm_window >= 0, UVX_ERR_INVALID, "Gemma-3 needs llm_qk_norm = 1; llm_attn_scale / llm_window must not be negative");
   return UVX_OK;
 }
 
@@ -734,6 +741,9 @@ extern "C" int32_t uvx_embed_merge(void* stream, const uvx_config_t* cfg, const 
   hipStream_t st = (hipStream_t)stream;
   const uvx_config_t& c = *cfg;
   if (input_ids) RC(embed_gather(st, c.dtype, embed_table, input_ids, inputs_embeds, B * T, c.llm_d, c.vocab));
+  // Gemma-3: the embedding MODULE scales its rows ([3P] Gemma3TextScaledWordEmbedding: lookup * sqrt(hidden) in the table's dtype);
+  // the audio rows merged over them below are not scaled
+  if (input_ids && c.llm_flavor == UVX_LLM_GEMMA3) RC(scale_inplace(st, c.dtype, inputs_embeds, (long long)B * T * c.llm_d, gemma_normalizer(c)));
   int32_t* owner = scratch;
   int32_t* item_batch = scratch + (size_t)B * T;
   if (n_items > 0) {
@@ -773,6 +783,17 @@ static int llm_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int T) {
   if (c.llm_qk_norm)
     for (int l = 0; l < c.llm_layers; ++l)
       UVX_CHECK(w->layers[l].q_norm && w->layers[l].k_norm, UVX_ERR_INVALID, "llm: llm_qk_norm is set but layer %d has no q_norm / k_norm", l);
+  if (c.llm_flavor == UVX_LLM_GEMMA3) {
+    bool any_local = false;
+    for (int l = 0; l < c.llm_layers; ++l) {
+      UVX_CHECK(w->layers[l].ln1_post && w->layers[l].ln2_post, UVX_ERR_INVALID, "llm: Gemma-3 layer %d has no post norms", l);
+      any_local = any_local || (w->layer_local && w->layer_local[l]);
+    }
+    UVX_CHECK(!any_local || w->rope_cos_sin_local, UVX_ERR_INVALID, "llm: Gemma-3 sliding-window layers need rope_cos_sin_local");
+    // a sliding-window layer over at most `window` positions IS plain causal attention; longer sequences are not built
+    UVX_CHECK(!any_local || c.llm_window <= 0 || T <= c.llm_window, UVX_ERR_UNSUPPORTED,
+              "llm: %d positions exceed Gemma-3's sliding window (%d): windowed attention over longer sequences is not built", T, c.llm_window);
+  }
   return UVX_OK;
 }
 
@@ -807,9 +828,11 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   // rows (device-side list, no host sync; GEMMs clamp to the device count).  Same loss, same gradients.
   UVX_CHECK(!top_rows || (labels && loss && dt == DT_BF16 && save_for_bwd && !logits && !rows), UVX_ERR_INVALID,
             "llm_fwd_train: labels and a loss output are required, bf16 only");
-  const bool tc = top_rows && g_options[3];   // (tuning option 3 off: the plain full-row path, in both calls of the pair)
+  const int fl = c.llm_flavor;   // 0 Llama, 1 Gemma, 2 Gemma-3 (norm flavour - any non-zero value is Gemma's -, GLU activation, embedding scale)
+  const bool g3 = fl == UVX_LLM_GEMMA3;
+  const bool tc = top_rows && g_options[3] && !g3;   // (tuning option 3 off, or Gemma-3's post norms: the plain full-row path, in both calls of the pair)
   if (top_rows) note_pair(workspace, tc);
-  const int fl = c.llm_flavor;   // 0 Llama, 1 Gemma (norm flavour, GLU activation, embedding scale)
+  const float attn_scale = c.llm_attn_scale > 0.f ? c.llm_attn_scale : 1.0f / sqrtf((float)dh);
   {
     LlmLayerStash l0 = llm_layer(s, 0);
     UVX_HIP(hipMemcpyAsync(l0.x_in, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
@@ -838,17 +861,19 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       RC(lora_up(sx, dt, cur.t, 128, cur.bqT, 1, cur.qkv, s.QKV, Mv, qc, r, lora->scaling, 1));
       RC(lora_up(sx, dt, at(cur.t, 64, dt), 128, cur.bkT, 1, at(cur.qkv, (size_t)qc, dt), s.QKV, Mv, kc, r, lora->scaling, 1));
     }
-    if (c.llm_qk_norm)   // Qwen3: q_norm / k_norm per head, then RoPE - one pass; the raw rows stay for the backward
-      RC(qk_norm_rope(sx, dt, cur.qkv, L.q_norm, L.k_norm, save_for_bwd ? cur.qk_raw : nullptr, w->rope_cos_sin, nullptr, Mv, T, Hq, Hkv,
-                      dh, s.QKV, c.rms_eps));
-    else if (!probe_skip(32)) RC(rope_inplace(sx, dt, cur.qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 0));
+    // (Gemma-3: the sliding-window layers rotate with their own table)
+    const float* rope = g3 && w->layer_local && w->layer_local[l] ? w->rope_cos_sin_local : w->rope_cos_sin;
+    if (c.llm_qk_norm)   // Qwen3 / Gemma-3: q_norm / k_norm per head, then RoPE - one pass; the raw rows stay for the backward
+      RC(qk_norm_rope(sx, dt, cur.qkv, L.q_norm, L.k_norm, save_for_bwd ? cur.qk_raw : nullptr, rope, nullptr, Mv, T, Hq, Hkv,
+                      dh, s.QKV, c.rms_eps, g3 ? 1 : 0));
+    else if (!probe_skip(32)) RC(rope_inplace(sx, dt, cur.qkv, rope, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 0));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt), v.vt, Bv, T, s.Tp, Hkv, dh, s.QKV));
     AttnDesc ad;
     ad.q = cur.qkv; ad.k = at(cur.qkv, (size_t)Hq * dh, dt); ad.v = at(cur.qkv, (size_t)(Hq + Hkv) * dh, dt);
     ad.vt = v.vt; ad.o = cur.o; ad.lse = cur.lse; ad.kv_start = v.kvs; ad.kv_len = v.kvl;
     ad.B = Bv; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
-    ad.scale = 1.0f / sqrtf((float)dh);
+    ad.scale = attn_scale;
     return probe_skip(2) ? UVX_OK : attention_fwd(sx, dt, ad);
   };
   // second half: o_proj + residual, norm, gate|up (+ SwiGLU), down + residual.  compact (last layer of the training pair,
@@ -860,6 +885,17 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     void* x_out = last ? v.x_final : llm_layer(v, slot_of(l + 1)).x_in;
     const int Mv = v.M;
     const int32_t* mdev = compact ? v.sup + Mv : nullptr;
+    if (g3) {
+      // Gemma3DecoderLayer: x_mid = x_in + post_attention_norm(o_proj(o));  x_out = x_mid + post_feedforward_norm(mlp(pre_feedforward_norm(x_mid)))
+      // (the branch outputs before their post norms stay in the stash for the backward: o_pre, m_pre)
+      RC(gemm(sx, dt, lin(cur.o, L.wo, cur.o_pre, Mv, D, s.OD)));
+      RC(rmsnorm_fwd(sx, dt, cur.o_pre, L.ln1_post, cur.x_mid, nullptr, Mv, D, c.rms_eps, fl, nullptr, cur.x_in));
+      RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, v.n, nullptr, Mv, D, c.rms_eps, fl));
+      RC(gemm(sx, dt, lin(v.n, L.wgu, cur.gu, Mv, 2 * c.llm_inter, D)));
+      RC(swiglu_fwd(sx, dt, cur.gu, v.act, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
+      RC(gemm(sx, dt, lin(v.act, L.wd, cur.m_pre, Mv, D, c.llm_inter)));
+      return rmsnorm_fwd(sx, dt, cur.m_pre, L.ln2_post, x_out, nullptr, Mv, D, c.rms_eps, fl, nullptr, cur.x_mid);
+    }
     if (compact) {   // gather the supervised rows of the attention output and of the residual stream (backward scratch is free here)
       RC(sup_rows(sx, labels, v.sup, B, T, c.vocab));
       RC(gather_rows(sx, dt, cur.o, v.sup, Mv, v.d_o, s.OD));
@@ -1075,10 +1111,12 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     RC(gemm(st, dt, lin(s.logits, head_t, s.d_hn, M, D, c.vocab)));
   }
   const int fl = c.llm_flavor;
+  const bool g3 = fl == UVX_LLM_GEMMA3;
+  const float attn_scale = c.llm_attn_scale > 0.f ? c.llm_attn_scale : 1.0f / sqrtf((float)dh);
   // top_rows (uvx_llm_bwd_train, after uvx_llm_fwd_train): the last layer's stash (x_final, x_mid, gate|up) holds the
   // supervised rows only; its MLP / o_proj gradients run on those rows and are scattered back before the attention backward
   UVX_CHECK(!top_rows || (!compact_in_place && labels && dt == DT_BF16), UVX_ERR_INVALID, "llm_bwd_train: labels are required, bf16 only");
-  const bool tc = top_rows && g_options[3];
+  const bool tc = top_rows && g_options[3] && !g3;
   if (top_rows) RC(check_pair(workspace, tc));
   const int32_t* mdev_top = tc ? s.sup + M : nullptr;
   if (tc) {
@@ -1095,6 +1133,14 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     LlmLayerStash cur = llm_layer(v, l);
     const int Mv = v.M;
     const int32_t* mdev = compact ? v.sup + Mv : nullptr;
+    if (g3) {
+      // x_out = x_mid + post_ffw_norm(m_pre): d m_pre = norm'(dx) -> d act -> d gate|up -> d n2; d x_mid = dx + pre_ffw_norm'(d n2)
+      RC(rmsnorm_bwd(sx, dt, v.dx, cur.m_pre, L.ln2_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
+      RC(gemm(sx, dt, lin(v.d_n, layer_t(l).wd_t, v.d_act, Mv, c.llm_inter, D)));
+      RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
+      RC(gemm(sx, dt, lin(v.d_gu, layer_t(l).wgu_t, v.d_n, Mv, D, 2 * c.llm_inter)));
+      return rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl);
+    }
     if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
       GemmDesc g = lin(v.dx, layer_t(l).wd_t, v.d_gu, Mv, c.llm_inter, D);
       g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2; g.m_dev = mdev;
@@ -1118,7 +1164,10 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     const uvx_llm_layer_t& L = w->layers[l];
     LlmLayerStash cur = llm_layer(v, l);
     const int Mv = v.M;
-    if (!d_o_ready) RC(gemm(sx, dt, lin(v.dx, layer_t(l).wo_t, v.d_o, Mv, s.OD, D)));
+    if (g3) {      // x_mid = x_in + post_attention_norm(o_pre): d o_pre = norm'(d x_mid), then the o_proj dgrad
+      RC(rmsnorm_bwd(sx, dt, v.dx, cur.o_pre, L.ln1_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
+      RC(gemm(sx, dt, lin(v.d_n, layer_t(l).wo_t, v.d_o, Mv, s.OD, D)));
+    } else if (!d_o_ready) RC(gemm(sx, dt, lin(v.dx, layer_t(l).wo_t, v.d_o, Mv, s.OD, D)));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, cur.qkv, v.qT, Bv, T, s.Tp, Hq, dh, s.QKV));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, at(cur.qkv, (size_t)Hq * dh, dt), v.kT, Bv, T, s.Tp, Hkv, dh, s.QKV));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, v.d_o, v.doT, Bv, T, s.Tp, Hq, dh, s.OD));
@@ -1129,16 +1178,17 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     ad.kv_start = v.kvs; ad.kv_len = v.kvl;  // written by the forward pass
     ad.B = Bv; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
-    ad.scale = 1.0f / sqrtf((float)dh);
+    ad.scale = attn_scale;
     bd.dout = v.d_o; bd.qt = v.qT; bd.kt = v.kT; bd.dot = v.doT; bd.delta = v.delta; bd.dkv_part = v.dkv_part;
     bd.dq = v.d_qkv; bd.dk = at(v.d_qkv, (size_t)Hq * dh, dt); bd.dv = at(v.d_qkv, (size_t)(Hq + Hkv) * dh, dt);
     bd.lddq = bd.lddk = bd.lddv = s.QKV;
     // the bf16 kernels write dq / dk RoPE-inverted (epilogue of the dQ kernel, GQA group reduction): no separate pass
     const bool rope_fused = attention_bwd_fuses_rope(dt) && g_options[14];
-    if (rope_fused) bd.rope_cos_sin = w->rope_cos_sin;
+    const float* rope = g3 && w->layer_local && w->layer_local[l] ? w->rope_cos_sin_local : w->rope_cos_sin;
+    if (rope_fused) bd.rope_cos_sin = rope;
     if (!probe_skip(1)) RC(attention_bwd(sx, dt, bd));
-    if (!rope_fused) RC(rope_inplace(sx, dt, v.d_qkv, w->rope_cos_sin, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
-    if (c.llm_qk_norm) RC(qk_norm_bwd(sx, dt, v.d_qkv, cur.qk_raw, L.q_norm, L.k_norm, Mv, Hq, Hkv, dh, s.QKV, c.rms_eps));
+    if (!rope_fused) RC(rope_inplace(sx, dt, v.d_qkv, rope, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
+    if (c.llm_qk_norm) RC(qk_norm_bwd(sx, dt, v.d_qkv, cur.qk_raw, L.q_norm, L.k_norm, Mv, Hq, Hkv, dh, s.QKV, c.rms_eps, g3 ? 1 : 0));
     RC(gemm(sx, dt, lin(v.d_qkv, layer_t(l).wqkv_t, v.d_n, Mv, D, s.QKV)));
     if (lora) {   // LoRA gradients of q_proj / k_proj and their contribution to d n1 (rank-r products, lora.hip)
       const uvx_enc_lora_layer_t& R = lora->layers[l];

@@ -213,7 +213,7 @@ __device__ __forceinline__ void row_span(const RowMap& m, long long row, int col
 template <typename T>
 __global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y,
                               T* __restrict__ stacked, float* __restrict__ rstd_out, int cols, float eps,
-                              RowMap map, int flavor, const int32_t* __restrict__ rows_dev) {
+                              RowMap map, int flavor, const int32_t* __restrict__ rows_dev, const T* __restrict__ resid) {
   __shared__ float red[16];
   const long long row = blockIdx.x;
   if (rows_dev && row >= *rows_dev) return;     // block-uniform: the tail of a row-compacted buffer holds no data
@@ -240,6 +240,12 @@ __global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, 
     ld8<T>(w + c, wv);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = flavor ? (v[i] * rstd) * (1.0f + wv[i]) : wv[i] * rnd<T>(v[i] * rstd);
+    if (resid) {      // the norm's output is a tensor of its own (rounded) before the residual add
+      float rv[8];
+      ld8<T>(resid + row * cols + c, rv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = rnd<T>(o[i]) + rv[i];
+    }
     st8<T>(yr + c, o);
     if (stacked) st8<T>(stacked + row * cols + c, v);
   }
@@ -375,29 +381,30 @@ int layernorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, cons
 }
 
 static int rms_launch(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked,
-                      float* rstd, long long rows, int cols, float eps, RowMap map, int flavor = 0, const int32_t* rows_dev = nullptr) {
+                      float* rstd, long long rows, int cols, float eps, RowMap map, int flavor = 0, const int32_t* rows_dev = nullptr,
+                      const void* resid = nullptr) {
   UVX_CHECK(cols % 8 == 0, UVX_ERR_SHAPE, "rmsnorm: cols=%d must be a multiple of 8", cols);
   if (rows == 0) return UVX_OK;
   const int th = norm_threads(cols);
   // (at 4096 columns the block kernel is as fast - 11.5 vs 12.4 us at 2528 rows - and has 4x the blocks: keep it)
-  if (dtype == DT_BF16 && map.S == 0 && !stacked && !rows_dev && (cols == 512 || cols == 1024 || cols == 2048)) {
+  if (dtype == DT_BF16 && map.S == 0 && !stacked && !rows_dev && !resid && (cols == 512 || cols == 1024 || cols == 2048)) {
     const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
 #define LW(NV) hipLaunchKernelGGL(rmsnorm_fwd_wave_k<NV>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, eps, flavor)
     if (cols == 512) LW(1); else if (cols == 1024) LW(2); else LW(4);
 #undef LW
   } else if (dtype == DT_BF16)
     hipLaunchKernelGGL(rmsnorm_fwd_k<bf16_t>, dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w,
-                       (bf16_t*)y, (bf16_t*)stacked, rstd, cols, eps, map, flavor, rows_dev);
+                       (bf16_t*)y, (bf16_t*)stacked, rstd, cols, eps, map, flavor, rows_dev, (const bf16_t*)resid);
   else
     hipLaunchKernelGGL(rmsnorm_fwd_k<float>, dim3(rows), dim3(th), 0, st, (const float*)x, (const float*)w,
-                       (float*)y, (float*)stacked, rstd, cols, eps, map, flavor, rows_dev);
+                       (float*)y, (float*)stacked, rstd, cols, eps, map, flavor, rows_dev, (const float*)resid);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
 
 int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, float* rstd, int rows,
-                int cols, float eps, int flavor, const int32_t* rows_dev) {
-  return rms_launch(st, dtype, x, w, y, nullptr, rstd, rows, cols, eps, RowMap{0, 0, 0, 0}, flavor, rows_dev);
+                int cols, float eps, int flavor, const int32_t* rows_dev, const void* resid) {
+  return rms_launch(st, dtype, x, w, y, nullptr, rstd, rows, cols, eps, RowMap{0, 0, 0, 0}, flavor, rows_dev, resid);
 }
 
 int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked, int B,

@@ -265,7 +265,10 @@ class UltravoxModel:
         c.stack_factor, c.proj_hidden, c.proj_ln_mid, c.proj_eps = cfg.stack_factor, cfg.hidden_size, int(cfg.projector_ln_mid), 1e-6
         c.llm_layers, c.llm_d, c.llm_heads, c.llm_kv_heads = t.num_hidden_layers, t.hidden_size, t.num_attention_heads, t.num_key_value_heads
         c.llm_head_dim, c.llm_inter, c.vocab, c.rms_eps = t.head_dim, t.intermediate_size, t.vocab_size, t.rms_norm_eps
-        c.llm_flavor = 1 if t.is_gemma else 0      # UVX_LLM_GEMMA / UVX_LLM_LLAMA (include/uvx.h)
+        c.llm_flavor = 2 if t.is_gemma3 else (1 if t.is_gemma else 0)      # UVX_LLM_GEMMA3 / UVX_LLM_GEMMA / UVX_LLM_LLAMA (include/uvx.h)
+        if t.is_gemma3:      # [3P] Gemma3Attention: scaling = query_pre_attn_scalar ** -0.5; sliding-window layers (window checked per call)
+            c.llm_attn_scale = float(t.query_pre_attn_scalar) ** -0.5
+            c.llm_window = int(t.sliding_window or 0)
         c.llm_act = {"silu": 0, "gelu_pytorch_tanh": 1, "gelu": 2}[t.hidden_act]      # UVX_ACT_* : [3P] ACT2FN[hidden_act]
         c.llm_qk_norm = int(t.has_qk_norm)         # Qwen3: per-head q_norm / k_norm before RoPE
         c.llm_wt_stream = int(self.stream_weight_transposes)
@@ -319,6 +322,9 @@ class UltravoxModel:
         lw.lm_head_t = 0 if m["lm_head_t"] is None else m["lm_head_t"].data_ptr()
         lw.layers = self._llm_layers
         lw.rope_cos_sin, lw.rope_len = m["rope"].data_ptr(), m["rope_len"]
+        if m.get("rope_local") is not None:        # Gemma-3: the sliding-window layers' table and the per-layer flags (host array)
+            self._layer_local = (C.c_int32 * t.num_hidden_layers)(*m["layer_local"])
+            lw.rope_cos_sin_local, lw.layer_local = m["rope_local"].data_ptr(), self._layer_local
         self._lw = lw
 
     def projector_state_dict(self) -> Dict[str, torch.Tensor]:

@@ -75,20 +75,20 @@ def rmsnorm_bwd(dy, x, w, eps=1e-6, dx_add=None, want_dx=True, want_dw=False):
     return dx, dw
 
 
-def qk_norm_rope_(qkv, wq, wk, cos_sin, T, Hq, Hkv, head_dim, eps=1e-6, keep_raw=False):
+def qk_norm_rope_(qkv, wq, wk, cos_sin, T, Hq, Hkv, head_dim, eps=1e-6, keep_raw=False, flavor=0):
     """Qwen3 q_norm / k_norm + RoPE in place on the q | k columns of qkv [rows, ld]; -> the raw q | k rows when keep_raw."""
     rows = qkv.numel() // qkv.shape[-1]
     raw = torch.empty(rows, (Hq + Hkv) * head_dim, device=qkv.device, dtype=qkv.dtype) if keep_raw else None
     check(_lib.lib().uvx_qk_norm_rope(stream_ptr(), _code(qkv), ptr(qkv), ptr(wq), ptr(wk), ptr(raw), ptr(cos_sin), rows, T, Hq, Hkv,
-                                      head_dim, qkv.shape[-1], C.c_float(eps)), "uvx_qk_norm_rope")
+                                      head_dim, qkv.shape[-1], C.c_float(eps), flavor), "uvx_qk_norm_rope")
     return raw
 
 
-def qk_norm_bwd_(d_qkv, raw, wq, wk, Hq, Hkv, head_dim, eps=1e-6):
+def qk_norm_bwd_(d_qkv, raw, wq, wk, Hq, Hkv, head_dim, eps=1e-6, flavor=0):
     """In place on the q | k columns of d_qkv [rows, ld]: gradient of the normalised rows -> gradient of the raw rows."""
     rows = d_qkv.numel() // d_qkv.shape[-1]
     check(_lib.lib().uvx_qk_norm_bwd(stream_ptr(), _code(d_qkv), ptr(d_qkv), ptr(raw), ptr(wq), ptr(wk), rows, Hq, Hkv, head_dim,
-                                     d_qkv.shape[-1], C.c_float(eps)), "uvx_qk_norm_bwd")
+                                     d_qkv.shape[-1], C.c_float(eps), flavor), "uvx_qk_norm_bwd")
     return d_qkv
 
 
