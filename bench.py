@@ -14,7 +14,10 @@ checkpoints offline); data: synthetic.  Weak scaling: per-GPU w
 
 The JSON line also carries
   roofline     — the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs of every launch / its duration,
-                 timed live with HIP events on the launch stream inside the timed region, vs 2.5 PFLOP/s;
+                 timed live with HIP events on the launch stream inside the timed region, vs 2.5 PFLOP/s.  The events
+                 are attached to the GEMM dispatches themselves (hipExtLaunchKernelGGL) of every 4th timed step
+                 (--prof-every; `roofline.profiled_steps`): a timed dispatch costs ~1.4 us, and the steps in between
+                 run exactly as a training step does;
   cpu_baseline — the CPU oracle (oracle/reference_cpu.py, a port of the reference path) timed on this box's
                  host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -287,6 +290,8 @@ def main():
     ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
                     help="N > 1: gradient exchange through torch.distributed (RCCL; default) or through libuvx.so's own RCCL "
                          "communicator (uvx_comm_*: the C-ABI route, torch.distributed only hands the 128-byte id around)")
+    ap.add_argument("--prof-every", type=int, default=4,
+                    help="HIP events (roofline) on the GEMM launches of every N-th timed step (1 = every step); the others run un-instrumented")
     ap.add_argument("--opt", default=None, help="probe: 'key=value,...' for uvx_set_option")
     ap.add_argument("--gemm-override", default=None, help="probe: 'MxNxK=variant,...' tile-variant overrides")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM time table (from the HIP events) here")
@@ -413,7 +418,12 @@ def main():
     if not args.no_prof:
         _lib.lib().uvx_prof_begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    profiled_steps = 0
+    for i in range(args.steps):
+        if not args.no_prof:   # the GEMM launches of every N-th timed step carry HIP events (a timed dispatch costs ~1.4 us: profiles/r03_prof_event_overhead.txt)
+            on = i % max(1, args.prof_every) == 0
+            _lib.lib().uvx_prof_enable(int(on))
+            profiled_steps += int(on)
         loss = step()
     trainer.flush()            # the last step's deferred all-reduce + optimizer step belong to the timed region
     barrier()
@@ -500,8 +510,9 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_* (all tile variants)", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": prof[3] / prof[0],
-                               "launches_per_step": prof[0] / args.steps, "gemm_ms_per_step": gemm_ms / args.steps,
-                               "gemm_ms_per_step_summed_intervals": prof[1] / args.steps,
+                               "launches_per_step": prof[0] / profiled_steps, "gemm_ms_per_step": gemm_ms / profiled_steps,
+                               "gemm_ms_per_step_summed_intervals": prof[1] / profiled_steps,
+                               "profiled_steps": f"{profiled_steps} of the {args.steps} timed steps (every {max(1, args.prof_every)}th; HIP events attached to every GEMM dispatch of those steps)",
                                "avg_launch_us": gemm_ms / prof[0] * 1e3,
                                "algorithmic_gflop_per_launch": prof[2] / prof[0] / 1e9}
         if world == 1 and not args.no_cpu_baseline:
@@ -523,7 +534,7 @@ def main():
                 f.write("# per-shape bf16 GEMM time inside the timed region (HIP events), C2 step\n")
                 f.write(f"# {'M':>6s} {'N':>7s} {'K':>7s} {'batch':>5s} {'var':>3s} {'calls/step':>10s} {'ms/step':>9s} {'avg_us':>9s} {'TF/s':>8s}\n")
                 for (m, n, k, bt, v), c, ms in shapes:
-                    f.write(f"  {m:6d} {n:7d} {k:7d} {bt:5d} {v:3d} {c / args.steps:10.1f} {ms / args.steps:9.3f} "
+                    f.write(f"  {m:6d} {n:7d} {k:7d} {bt:5d} {v:3d} {c / profiled_steps:10.1f} {ms / profiled_steps:9.3f} "
                             f"{ms / c * 1e3:9.1f} {2.0 * m * n * k * bt * c / ms / 1e9:8.1f}\n")
         print(json.dumps(out))
     if world > 1:

@@ -479,6 +479,7 @@ int32_t uvx_kl_loss(void* stream, int32_t dtype, const void* student_logits, con
  * uvx_prof_end fills out[class*4 + {0: launches, 1: total ms, 2: algorithmic FLOPs, 3: algorithmic bytes}]
  * for class 0 = bf16 MFMA GEMM (classes 1.. reserved) and synchronises on the recorded events. */
 int32_t uvx_prof_begin(void);
+int32_t uvx_prof_enable(int32_t on); /* pause (0) / resume (1) the recording inside a region; the records so far are kept */
 int32_t uvx_prof_end(double* out, int32_t n_classes);
 /* wall time (ms) during which at least one launch of the class was executing: the union of the event intervals (= the summed
  * durations on one stream; with the two-stream LLM schedule, uvx_set_option(11, 2), launches of the two chains overlap).

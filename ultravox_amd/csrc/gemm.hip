@@ -20,6 +20,7 @@
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
+#include <hip/hip_ext.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -1270,6 +1271,19 @@ bool sk_acquire(hipStream_t st, int grid, GemmArgs& a) {
   return true;
 }
 
+// bench.py's live timing (prof.hip): the start / stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL) instead of
+// being recorded as two extra barrier packets around it - separate hipEventRecord calls cost ~2.8 us each on the stream, 2 ms per C2
+// step for its 354 GEMM launches (profiles/r03_prof_event_overhead.txt).  Set by gemm_nt around launch_variant; null = plain launch.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
+thread_local LaunchEvents g_launch_ev;
+#define UVX_GEMM_LAUNCH(KERNEL, GRID, BLOCK, ST, ARG)                                                                      \
+  do {                                                                                                                      \
+    if (g_launch_ev.start || g_launch_ev.stop)                                                                              \
+      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, ST, g_launch_ev.start, g_launch_ev.stop, 0, ARG);                       \
+    else                                                                                                                    \
+      hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, ST, ARG);                                                                  \
+  } while (0)
+
 void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int batch) {
   a.M = M; a.N = N;
   a.tiles_m = cdiv(M, kVariants[variant].bm); a.tiles_n = cdiv(N, kVariants[variant].bn);
@@ -1281,65 +1295,65 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     if (batch != 1 || a.m_dev || !g || !sk_acquire(st, g, a)) { launch_variant(st, variant - 8, a, M, N, batch); return; }
     a.sk_full = sk_full_rounds((long long)a.tiles_m * a.tiles_n, g);
     const dim3 sgrid(g);
-    if (variant == 39) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2, true>), sgrid, dim3(512), 0, st, a);
-    else if (variant == 40) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2, true>), sgrid, dim3(512), 0, st, a);
-    else if (variant == 41) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2, true>), sgrid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2, true>), sgrid, dim3(512), 0, st, a);
+    if (variant == 39) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2, true>), sgrid, dim3(512), st, a);
+    else if (variant == 40) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2, true>), sgrid, dim3(512), st, a);
+    else if (variant == 41) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2, true>), sgrid, dim3(512), st, a);
+    else UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2, true>), sgrid, dim3(512), st, a);
     return;
   }
 #endif
   switch (variant) {
-    case 0: hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(256), 0, st, a); break;
-    case 11: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<256>, grid, dim3(512), 0, st, a); break;
-    case 15: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<160>, grid, dim3(512), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<192>, grid, dim3(512), 0, st, a); break;
-    case 17: hipLaunchKernelGGL(gemm_nt_bf16_ph8_kernel<128>, grid, dim3(512), 0, st, a); break;
-    case 18: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 3>), grid, dim3(512), 0, st, a); break;
-    case 19: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 3>), grid, dim3(512), 0, st, a); break;
-    case 31: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2>), grid, dim3(512), 0, st, a); break;
-    case 32: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2>), grid, dim3(512), 0, st, a); break;
-    case 33: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2>), grid, dim3(512), 0, st, a); break;
-    case 34: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2>), grid, dim3(512), 0, st, a); break;
+    case 0: UVX_GEMM_LAUNCH(gemm_nt_bf16_kernel, grid, dim3(256), st, a); break;
+    case 11: UVX_GEMM_LAUNCH(gemm_nt_bf16_ph8_kernel<256>, grid, dim3(512), st, a); break;
+    case 15: UVX_GEMM_LAUNCH(gemm_nt_bf16_ph8_kernel<160>, grid, dim3(512), st, a); break;
+    case 16: UVX_GEMM_LAUNCH(gemm_nt_bf16_ph8_kernel<192>, grid, dim3(512), st, a); break;
+    case 17: UVX_GEMM_LAUNCH(gemm_nt_bf16_ph8_kernel<128>, grid, dim3(512), st, a); break;
+    case 18: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 3>), grid, dim3(512), st, a); break;
+    case 19: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 3>), grid, dim3(512), st, a); break;
+    case 31: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2>), grid, dim3(512), st, a); break;
+    case 32: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2>), grid, dim3(512), st, a); break;
+    case 33: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2>), grid, dim3(512), st, a); break;
+    case 34: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2>), grid, dim3(512), st, a); break;
 #ifdef UVX_PROBES
-    case 1: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<128>, grid, dim3(512), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<160>, grid, dim3(512), 0, st, a); break;
-    case 3: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<192>, grid, dim3(512), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(gemm_nt_bf16_wide_kernel<256>, grid, dim3(512), 0, st, a); break;
-    case 5: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<128>, grid, dim3(512), 0, st, a); break;
-    case 6: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<160>, grid, dim3(512), 0, st, a); break;
-    case 7: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<192>, grid, dim3(512), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), 0, st, a); break;
-    case 9: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<128>, grid, dim3(512), 0, st, a); break;
-    case 10: hipLaunchKernelGGL(gemm_nt_bf16_wide3_kernel<160>, grid, dim3(512), 0, st, a); break;
-    case 20: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 1>), grid, dim3(512), 0, st, a); break;   // operand delivery only
-    case 21: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 2>), grid, dim3(512), 0, st, a); break;   // arithmetic only
-    case 22: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 3>), grid, dim3(512), 0, st, a); break;   // no epilogue
-    case 27: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 4>), grid, dim3(512), 0, st, a); break;   // s_memtime timeline
-    case 28: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 5>), grid, dim3(512), 0, st, a); break;
-    case 29: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 6>), grid, dim3(512), 0, st, a); break;
-    case 30: hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 7>), grid, dim3(512), 0, st, a); break;
+    case 1: UVX_GEMM_LAUNCH(gemm_nt_bf16_wide_kernel<128>, grid, dim3(512), st, a); break;
+    case 2: UVX_GEMM_LAUNCH(gemm_nt_bf16_wide_kernel<160>, grid, dim3(512), st, a); break;
+    case 3: UVX_GEMM_LAUNCH(gemm_nt_bf16_wide_kernel<192>, grid, dim3(512), st, a); break;
+    case 4: UVX_GEMM_LAUNCH(gemm_nt_bf16_wide_kernel<256>, grid, dim3(512), st, a); break;
+    case 5: UVX_GEMM_LAUNCH(gemm_nt_bf16_pp_kernel<128>, grid, dim3(512), st, a); break;
+    case 6: UVX_GEMM_LAUNCH(gemm_nt_bf16_pp_kernel<160>, grid, dim3(512), st, a); break;
+    case 7: UVX_GEMM_LAUNCH(gemm_nt_bf16_pp_kernel<192>, grid, dim3(512), st, a); break;
+    case 8: UVX_GEMM_LAUNCH(gemm_nt_bf16_pp_kernel<256>, grid, dim3(512), st, a); break;
+    case 9: UVX_GEMM_LAUNCH(gemm_nt_bf16_wide3_kernel<128>, grid, dim3(512), st, a); break;
+    case 10: UVX_GEMM_LAUNCH(gemm_nt_bf16_wide3_kernel<160>, grid, dim3(512), st, a); break;
+    case 20: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 1>), grid, dim3(512), st, a); break;   // operand delivery only
+    case 21: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 2>), grid, dim3(512), st, a); break;   // arithmetic only
+    case 22: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 3>), grid, dim3(512), st, a); break;   // no epilogue
+    case 27: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 4>), grid, dim3(512), st, a); break;   // s_memtime timeline
+    case 28: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 5>), grid, dim3(512), st, a); break;
+    case 29: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 6>), grid, dim3(512), st, a); break;
+    case 30: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 7>), grid, dim3(512), st, a); break;
     case 35: case 36: case 37: case 38: {   // persistent merged-phase: next tile's pipeline fill under the epilogue
       if (batch != 1) { launch_variant(st, variant - 4, a, M, N, batch); return; }
       const dim3 pgrid(a.tiles_m * a.tiles_n < 256 ? a.tiles_m * a.tiles_n : 256);
-      if (variant == 35) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 0, true, 2>), pgrid, dim3(512), 0, st, a);
-      else if (variant == 36) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<192, 2, 0, true, 2>), pgrid, dim3(512), 0, st, a);
-      else if (variant == 37) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 2, 0, true, 2>), pgrid, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 2, 0, true, 2>), pgrid, dim3(512), 0, st, a);
+      if (variant == 35) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 0, true, 2>), pgrid, dim3(512), st, a);
+      else if (variant == 36) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<192, 2, 0, true, 2>), pgrid, dim3(512), st, a);
+      else if (variant == 37) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 2, 0, true, 2>), pgrid, dim3(512), st, a);
+      else UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, true, 2>), pgrid, dim3(512), st, a);
       break;
     }
     case 23: case 24: case 25: case 26: {
       // persistent: one block per CU walks the tiles (batched problems use the plain kernels: grid.y would oversubscribe)
       if (batch != 1) { launch_variant(st, variant == 23 ? 11 : variant == 24 ? 16 : variant == 25 ? 15 : 17, a, M, N, batch); return; }
       const dim3 pgrid(a.tiles_m * a.tiles_n < 256 ? a.tiles_m * a.tiles_n : 256);
-      if (variant == 23) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<256, 2, 0, true>), pgrid, dim3(512), 0, st, a);
-      else if (variant == 24) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<192, 2, 0, true>), pgrid, dim3(512), 0, st, a);
-      else if (variant == 25) hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<160, 2, 0, true>), pgrid, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((gemm_nt_bf16_ph8_kernel<128, 2, 0, true>), pgrid, dim3(512), 0, st, a);
+      if (variant == 23) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 0, true>), pgrid, dim3(512), st, a);
+      else if (variant == 24) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<192, 2, 0, true>), pgrid, dim3(512), st, a);
+      else if (variant == 25) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 2, 0, true>), pgrid, dim3(512), st, a);
+      else UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, true>), pgrid, dim3(512), st, a);
       break;
     }
-    case 12: hipLaunchKernelGGL(gemm_nt_bf16_q4_kernel, grid, dim3(256), 0, st, a); break;
-    case 13: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 1>), grid, dim3(512), 0, st, a); break;   // probe: delivery only
-    case 14: hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<256, 2>), grid, dim3(512), 0, st, a); break;   // probe: arithmetic only
+    case 12: UVX_GEMM_LAUNCH(gemm_nt_bf16_q4_kernel, grid, dim3(256), st, a); break;
+    case 13: UVX_GEMM_LAUNCH((gemm_nt_bf16_pp_kernel<256, 1>), grid, dim3(512), st, a); break;   // probe: delivery only
+    case 14: UVX_GEMM_LAUNCH((gemm_nt_bf16_pp_kernel<256, 2>), grid, dim3(512), st, a); break;   // probe: arithmetic only
 #endif
     default: break;   // unavailable variants are rejected in gemm_nt before any launch
   }
@@ -1398,9 +1412,12 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   const int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole);
   UVX_CHECK(variant_available(variant), UVX_ERR_INVALID,
             "gemm: tile variant %d is not in this build (probe variants live in libuvx_probes.so, built with -DUVX_PROBES)", variant);
-  uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K * batch,
-                      ((double)d.M * d.K + (double)d.N * d.K) * 2.0 * batch + (double)d.M * d.N * batch * (d.out_f32 ? 4.0 : 2.0),
-                      /*enable=*/d.m_dev == nullptr);   // device-side row count: the true work is unknown here, leave it out
+  // (device-side row count: the true work is unknown here, such launches are left out of the timing)
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  const bool timed = uvx::g_prof_on && d.m_dev == nullptr &&
+                     uvx::prof_take(uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K * batch,
+                                    ((double)d.M * d.K + (double)d.N * d.K) * 2.0 * batch + (double)d.M * d.N * batch * (d.out_f32 ? 4.0 : 2.0),
+                                    &ev_a, &ev_b);
   // Tail split (tile-quantisation fix): when the last round of big tiles would leave most CUs idle, the
   // trailing weight panels (a column range of C) are computed by a second launch with its own best variant.
   const Variant& V = kVariants[variant];
@@ -1421,8 +1438,10 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
       if (cost_split < thr * cost_whole) { n_main = main_panels * V.bn; tail_variant = tv; }
     }
   }
-  if (uvx::g_prof_on && !d.m_dev) uvx::prof_tag(d.M, d.N, d.K, batch, tail_variant >= 0 ? 100 + variant : variant);
+  if (timed) uvx::prof_tag(d.M, d.N, d.K, batch, tail_variant >= 0 ? 100 + variant : variant);
+  g_launch_ev = LaunchEvents{ev_a, tail_variant >= 0 ? nullptr : ev_b};     // start on the (first) launch, stop on the last one
   launch_variant(st, variant, a, d.M, n_main, batch);
+  g_launch_ev = LaunchEvents{};
   if (tail_variant >= 0) {
     GemmArgs t = a;
     t.B = a.B + (long long)n_main * a.ldb;
@@ -1431,8 +1450,11 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
     if (a.swiglu == 1) t.C2 = a.C2 + n_main / 2;
     t.C = a.out_f32 ? (void*)((float*)a.C + n_main) : (void*)((bf16_t*)a.C + n_main);
     if (a.swiglu == 2) { t.C2 = a.C2 + 2 * n_main; t.C = (void*)((bf16_t*)a.C + 2 * n_main); }   // [M, 2N] operands
+    g_launch_ev = LaunchEvents{nullptr, ev_b};
     launch_variant(st, tail_variant, t, d.M, d.N - n_main, 1);
+    g_launch_ev = LaunchEvents{};
   }
+  if (timed) uvx::prof_commit();
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

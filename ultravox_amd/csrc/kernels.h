@@ -13,6 +13,8 @@ enum ProfClass { PROF_GEMM = 0, PROF_ATTN = 1, PROF_OTHER = 2, PROF_NCLASS = 3 }
 void prof_record_begin(hipStream_t st, int cls, double flops, double bytes);
 void prof_record_end(hipStream_t st);
 void prof_tag(int m, int n, int k, int batch, int variant);
+bool prof_take(int cls, double flops, double bytes, hipEvent_t* a, hipEvent_t* b);
+void prof_commit();
 extern bool g_prof_on;
 struct ProfScope {
   hipStream_t st; bool on;
