@@ -110,7 +110,7 @@ __global__ void chunk_positions_k(const int32_t* __restrict__ pos0, int32_t* __r
 template <typename T, int D>
 __global__ void attn_decode_k(const T* __restrict__ qkv, const T* __restrict__ cache_k, const T* __restrict__ cache_v,
                               T* __restrict__ out, const int32_t* __restrict__ kv_start, int B, int Hq, int Hkv, int Tmax,
-                              int len, int QKV, float scale) {
+                              int len, int QKV, float scale, int lo_clamp) {
   const int wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (wid >= B * Hq) return;
   const int b = wid / Hq, h = wid % Hq, hk = h / (Hq / Hkv);
@@ -120,7 +120,8 @@ __global__ void attn_decode_k(const T* __restrict__ qkv, const T* __restrict__ c
   for (int e = 0; e < E; ++e) { q[e] = ldf<T>(qkv + (long long)b * QKV + h * D + lane + 64 * e); acc[e] = 0.f; }
   const int KVD = Hkv * D;
   float m = -__builtin_huge_valf(), l = 0.f;
-  for (int j = kv_start ? kv_start[b] : 0; j < len; ++j) {
+  // (lo_clamp: Gemma-3's sliding-window layers see the last `window` cache slots only)
+  for (int j = max(kv_start ? kv_start[b] : 0, lo_clamp); j < len; ++j) {
     const T* kr = cache_k + ((long long)b * Tmax + j) * KVD + hk * D;
     const T* vr = cache_v + ((long long)b * Tmax + j) * KVD + hk * D;
     float s = 0.f;
@@ -147,7 +148,7 @@ template <typename T, int D, int G>
 __global__ __launch_bounds__(256) void attn_decode_grp_k(const T* __restrict__ qkv, const T* __restrict__ cache_k,
                                                          const T* __restrict__ cache_v, T* __restrict__ out,
                                                          const int32_t* __restrict__ kv_start, int Hq, int Hkv, int Tmax,
-                                                         int len, int QKV, float scale) {
+                                                         int len, int QKV, float scale, int lo_clamp) {
   extern __shared__ float sc[];                 // [G][len]
   __shared__ float qs[G][D];
   __shared__ float red[4][G][D];
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_decode_grp_k(const T* __restrict__ q
   constexpr int KL = 256 / CH;                  // keys in flight per pass
   const int b = blockIdx.x / Hkv, hk = blockIdx.x % Hkv;
   const int tid = threadIdx.x, ch = tid % CH, kl = tid / CH, lane = tid & 63, w = tid >> 6;
-  const int j0 = kv_start ? kv_start[b] : 0;
+  const int j0 = max(kv_start ? kv_start[b] : 0, lo_clamp);
   const int KVD = Hkv * D;
   const T* kbase = cache_k + (long long)b * Tmax * KVD + hk * D + ch * 8;
   const T* vbase = cache_v + (long long)b * Tmax * KVD + hk * D + ch * 8;
@@ -329,7 +330,7 @@ int g3_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int Tmax) {
   }
   UVX_CHECK(!any_local || w->rope_cos_sin_local, UVX_ERR_INVALID, "llm: Gemma-3 sliding-window layers need rope_cos_sin_local");
   UVX_CHECK(!any_local || c.llm_window <= 0 || Tmax <= c.llm_window, UVX_ERR_UNSUPPORTED,
-            "llm: a cache of %d positions exceeds Gemma-3's sliding window (%d): windowed attention over longer sequences is not built", Tmax, c.llm_window);
+            "llm: %d positions in one pass exceed Gemma-3's sliding window (%d): windowed attention over longer prompts / chunks is not built", Tmax, c.llm_window);
   return UVX_OK;
 }
 
@@ -372,7 +373,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   const uvx_config_t& c = *cfg;
   UVX_CHECK(T >= 1 && T <= Tmax, UVX_ERR_SHAPE, "llm_prefill: prompt length %d exceeds the cache length %d", T, Tmax);
   UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
-  RC(g3_check(c, w, Tmax));
+  RC(g3_check(c, w, T));          // (the PROMPT must fit the sliding window; the decode steps clamp their key range)
   hipStream_t st = (hipStream_t)stream;
   Arena a(workspace, ws_bytes);
   InferWs s = carve(a, c, B, T);
@@ -452,7 +453,7 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
   UVX_CHECK(Tn >= 1 && cur_len >= 0 && Tf <= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: %d cached + %d new positions exceed the cache length %d",
             cur_len, Tn, Tmax);
   UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
-  RC(g3_check(c, w, Tmax));
+  RC(g3_check(c, w, cur_len + Tn));   // (a multi-token chunk attends to the whole cache: cache + chunk must fit the window)
   hipStream_t st = (hipStream_t)stream;
   Arena a(workspace, ws_bytes);
   ChunkWs k;
@@ -515,7 +516,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
   UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "llm_decode: workspace %zu < %zu bytes", ws_bytes, a.off);
   const int dt = c.dtype, D = c.llm_d, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads, KVD = Hkv * dh;
   UVX_CHECK(dh == 64 || dh == 128 || dh == 256, UVX_ERR_UNSUPPORTED, "llm_decode: head_dim %d not supported", dh);
-  RC(g3_check(c, w, cur_len + 1));
+  RC(g3_check(c, w, 0));          // (weights / tables only: the sliding-window layers clamp their key range below)
   const size_t es = esz(dt);
   UVX_HIP(hipMemcpyAsync(s.x, token_embeds, (size_t)B * D * es, hipMemcpyDeviceToDevice, st));
   if (c.llm_flavor == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, s.x, (long long)B * D, gemma_normalizer(c)));
@@ -525,6 +526,9 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
     RC(qkv_rope(st, c, w, L, s.n, s.qkv, positions, B, 1, s.QKV, l));
+    // Gemma-3 sliding-window layer: the new token attends to the last `window` positions = cache slots (the slots of a sequence are
+    // contiguous, so the window is a clamp of the first visible slot)
+    const int lo = (c.llm_flavor == UVX_LLM_GEMMA3 && c.llm_window > 0 && w->layer_local && w->layer_local[l]) ? max(0, cur_len + 1 - c.llm_window) : 0;
     char* ck = at(kv_cache, l * layer_stride, dt);
     char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
     const long long n = (long long)B * (KVD / 8);
@@ -533,7 +537,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
       hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
       const int G = Hq / Hkv, len = cur_len + 1;
       const size_t sh = sizeof(float) * (size_t)G * len;
-#define UVX_DEC(DD, GG) hipLaunchKernelGGL((attn_decode_grp_k<bf16_t, DD, GG>), dim3(B * Hkv), dim3(256), sh, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale)
+#define UVX_DEC(DD, GG) hipLaunchKernelGGL((attn_decode_grp_k<bf16_t, DD, GG>), dim3(B * Hkv), dim3(256), sh, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale, lo)
       if (sh <= 48 * 1024 && dh == 128 && G == 4) UVX_DEC(128, 4);
       else if (sh <= 48 * 1024 && dh == 128 && G == 8) UVX_DEC(128, 8);
       else if (sh <= 48 * 1024 && dh == 128 && G == 2) UVX_DEC(128, 2);
@@ -542,14 +546,14 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
       else if (sh <= 48 * 1024 && dh == 64 && G == 2) UVX_DEC(64, 2);
       else if (sh <= 48 * 1024 && dh == 64 && G == 1) UVX_DEC(64, 1);
 #undef UVX_DEC
-      else if (dh == 256) hipLaunchKernelGGL((attn_decode_k<bf16_t, 256>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
-      else if (dh == 64) hipLaunchKernelGGL((attn_decode_k<bf16_t, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
-      else hipLaunchKernelGGL((attn_decode_k<bf16_t, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
+      else if (dh == 256) hipLaunchKernelGGL((attn_decode_k<bf16_t, 256>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale, lo);
+      else if (dh == 64) hipLaunchKernelGGL((attn_decode_k<bf16_t, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale, lo);
+      else hipLaunchKernelGGL((attn_decode_k<bf16_t, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale, lo);
     } else {
       hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
-      if (dh == 256) hipLaunchKernelGGL((attn_decode_k<float, 256>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
-      else if (dh == 64) hipLaunchKernelGGL((attn_decode_k<float, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
-      else hipLaunchKernelGGL((attn_decode_k<float, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale);
+      if (dh == 256) hipLaunchKernelGGL((attn_decode_k<float, 256>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale, lo);
+      else if (dh == 64) hipLaunchKernelGGL((attn_decode_k<float, 64>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale, lo);
+      else hipLaunchKernelGGL((attn_decode_k<float, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale, lo);
     }
     UVX_LAUNCH_CHECK();
     RC(attn_out(st, c, L, s, B, s.o, s.OD, s.x, s.x2));
