@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 11
+#define UVX_ABI_VERSION 12
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -453,6 +453,7 @@ typedef struct {
   float scale;
   /* backward only */
   const void* dout; void *dq, *dk, *dv; int32_t lddq, lddk, lddv;
+  int32_t window; /* > 0 with causal: sliding window, a query sees keys in (q - window, q] only; 0 = none */
 } uvx_attn_desc_t;
 size_t uvx_attention_ws_bytes(int32_t dtype, const uvx_attn_desc_t* d, int32_t backward);
 int32_t uvx_attention_fwd(void* stream, int32_t dtype, const uvx_attn_desc_t* d, void* workspace, size_t ws_bytes);

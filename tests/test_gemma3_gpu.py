@@ -107,19 +107,32 @@ def test_gemma3_train_step_bf16(head_dim):
         assert v < 8e-2, (k, v)
 
 
-def test_gemma3_sequences_beyond_the_sliding_window_are_refused():
-    """A sliding-window layer over at most `window` positions is plain causal attention - what is built; longer sequences raise
-    (UVX_ERR_UNSUPPORTED) instead of silently attending to everything."""
-    from oracle.reference_cpu import logmel_ref, synthetic_batch
-    from ultravox_amd import _lib
-    from ultravox_amd.model import UltravoxModel
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemma3_sequences_beyond_the_sliding_window(dtype):
+    """Sequences LONGER than the sliding window: the local layers run the windowed attention kernels (forward, dK/dV, dQ skip what
+    no pair can see and mask the boundary), the global layers plain causal attention - whole train step against the oracle, which
+    masks the window in full (window 16, 37 positions)."""
+    cfg = _cfg(64, layers=4, window=16)
+    model, out, loss, ref, grads, b = _step(cfg, dtype, 63)
+    assert b["input_ids"].shape[1] == 37 and sum(model._llm["layer_local"]) == 3
+    keep = b["attention_mask"].bool()
+    mine = model.projector_grads()
+    if dtype == torch.float32:
+        assert (out.logits.cpu() - ref["logits"])[keep].abs().max().item() < 1e-3
+        assert abs(loss.item() - ref["loss"].item()) < 1e-4
+        for k, g in grads.items():
+            assert rel_l2(mine[k], g) < 2e-3, k
+    else:
+        assert rel_l2(out.logits.cpu()[keep], ref["logits"][keep]) < 3e-2
+        assert abs(loss.item() - ref["loss"].item()) < 2e-2 * abs(ref["loss"].item())
+        for k, g in grads.items():
+            assert rel_l2(mine[k], g) < 8e-2, k
+    # the window matters here: a model whose window covers the sequence gives other logits
+    from oracle.reference_cpu import OracleModel
     from ultravox_amd.weights import random_state_dict
-    cfg = _cfg(64, layers=3, window=32)
-    model = UltravoxModel(cfg, state_dict=random_state_dict(cfg, seed=63), device=DEV, dtype=torch.float32)
-    b = synthetic_batch(cfg, 1, 2.0, n_text=40, audio_start=5, n_supervised=8)          # 40 + 7 audio tokens > 32
-    b["audio_values"] = logmel_ref(b.pop("pcm"), 80)
-    with pytest.raises((_lib.UvxError, RuntimeError), match="sliding window"):
-        model.forward(**{k: v.to(DEV) for k, v in b.items()})
+    sd = {k: v.to(dtype) for k, v in random_state_dict(cfg, seed=63).items()}
+    wide = OracleModel(_cfg(64, layers=4, window=512), sd, dtype=torch.float32)
+    assert (wide.forward(**{**b, "audio_values": b["audio_values"].float()})["logits"] - ref["logits"])[keep].abs().max().item() > 1e-2
 
 
 @pytest.mark.parametrize("head_dim", [64, 128])
@@ -145,13 +158,22 @@ def test_gemma3_generate_token_exact_in_f32(head_dim):
 
 
 def test_gemma3_decode_runs_past_the_sliding_window():
-    """The PROMPT has to fit the sliding window (one-pass windowed attention is not built), the decode steps do not: a
-    sliding-window layer clamps the first visible cache slot to the last `window` positions.  window = 40, prompt = 33 positions,
-    12 new tokens (45 positions) - token-exact against the oracle, which masks the window in full."""
+    """Generation across the sliding window: the prompt (33 positions) is prefilled with the windowed attention kernel where it is
+    longer than the window, every decode step clamps the first visible cache slot of a sliding-window layer to the last `window`
+    positions.  Token-exact against the oracle, which masks the window in full - window 40 (crossed while decoding) and window
+    24 (crossed inside the prompt)."""
     from oracle.reference_cpu import OracleModel, logmel_ref, synthetic_batch
     from ultravox_amd.model import UltravoxModel
     from ultravox_amd.weights import random_state_dict
-    cfg = _cfg(64, layers=4, window=40)
+    _run_decode_window(40)
+    _run_decode_window(24)
+
+
+def _run_decode_window(window):
+    from oracle.reference_cpu import OracleModel, logmel_ref, synthetic_batch
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = _cfg(64, layers=4, window=window)
     sd = random_state_dict(cfg, seed=69)
     sd["language_model.lm_head.weight"] = 0.3 * torch.randn(512, 192, generator=torch.Generator().manual_seed(9))
     model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32, with_backward=False)

@@ -175,7 +175,7 @@ def test_rope_forward_and_inverse():
 
 
 # ------------------------------------------------------------------ attention
-def sdpa_ref(q, k, v, causal, block, scale, kv_start=None, kv_len=None):
+def sdpa_ref(q, k, v, causal, block, scale, kv_start=None, kv_len=None, window=0):
     B, T, Hq, D = q.shape
     Hkv = k.shape[2]
     qf, kf, vf = (t.float().transpose(1, 2) for t in (q, k, v))
@@ -188,6 +188,8 @@ def sdpa_ref(q, k, v, causal, block, scale, kv_start=None, kv_len=None):
         ok = ok & (idx[None, :] <= idx[:, None])[None, None]
     if block:
         ok = ok & ((idx[None, :] // block) <= (idx[:, None] // block))[None, None]
+    if window:
+        ok = ok & (idx[None, :] > idx[:, None] - window)[None, None]
     if kv_len is not None:
         ok = ok & (idx[None, None, None, :] < kv_len.view(-1, 1, 1, 1))
     if kv_start is not None:
@@ -196,6 +198,31 @@ def sdpa_ref(q, k, v, causal, block, scale, kv_start=None, kv_len=None):
     p = torch.softmax(s, -1)
     p = torch.nan_to_num(p, 0.0)
     return (p @ vf).transpose(1, 2).reshape(B, T, Hq * D), ok
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("D,Hq,Hkv,T,window", [(128, 4, 2, 700, 128), (128, 4, 1, 330, 100), (64, 4, 4, 513, 64), (256, 2, 2, 300, 77),
+                                                (128, 8, 2, 316, 400)])
+def test_sliding_window_attention_forward_backward(dtype, D, Hq, Hkv, T, window):
+    """Causal attention with a sliding window (Gemma-3's local layers: a query sees keys in (q - window, q]) - forward and both
+    backward kernels skip the key / query ranges no pair of which is visible and mask the boundary tiles; with left padding; a
+    window that covers the sequence (last case) takes the plain-causal paths (incl. the fused backward)."""
+    from ultravox_amd import ops
+    torch.manual_seed(11)
+    B = 2
+    q, k, v = ((torch.randn(B, T, h, D, device=DEV)).to(dtype) for h in (Hq, Hkv, Hkv))
+    do = torch.randn(B, T, Hq * D, device=DEV).to(dtype)
+    kv_start = torch.tensor([0, 37], device=DEV, dtype=torch.int32)
+    o, lse = ops.attention(q, k, v, causal=True, kv_start=kv_start, window=window)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref, ok = sdpa_ref(qr, kr, vr, True, 0, D ** -0.5, kv_start=kv_start, window=window)
+    rows = ok.any(-1)[:, 0]                                   # rows with at least one visible key (left-padded rows have none)
+    bf = dtype == torch.bfloat16
+    assert rel_l2(o[rows], ref.detach()[rows]) < (8e-3 if bf else 1e-5)
+    dq, dk, dv = ops.attention_bwd(q, k, v, o, lse, do, causal=True, kv_start=kv_start, window=window)
+    (ref * rows[..., None]).backward(do.float() * rows[..., None])
+    tol = 2e-2 if bf else 2e-5
+    assert rel_l2(dq[rows], qr.grad[rows]) < tol and rel_l2(dk, kr.grad) < tol and rel_l2(dv, vr.grad) < tol
 
 
 @pytest.mark.parametrize("D,Hq,Hkv,T,causal,block", [(64, 4, 4, 200, False, 0), (64, 2, 2, 333, False, 50),

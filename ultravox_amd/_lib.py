@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 11  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+ABI_VERSION = 12  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
 
 
 def lib() -> C.CDLL:
@@ -173,7 +173,7 @@ class AttnDesc(C.Structure):
                 ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
                 ("causal", C.c_int32), ("block", C.c_int32), ("scale", C.c_float),
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
-                ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32)]
+                ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32), ("window", C.c_int32)]
 
 
 EXPORTS = [

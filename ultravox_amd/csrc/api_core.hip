@@ -152,7 +152,7 @@ uvx::AttnDesc to_desc(const uvx_attn_desc_t& d, const AttnWs& w) {
   uvx::AttnDesc a;
   a.q = d.q; a.k = d.k; a.v = d.v; a.vt = w.vt; a.o = d.o; a.lse = d.lse; a.kv_start = d.kv_start; a.kv_len = d.kv_len;
   a.B = d.B; a.T = d.T; a.Tp = w.Tp; a.Hq = d.Hq; a.Hkv = d.Hkv; a.D = d.D;
-  a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo; a.causal = d.causal; a.block = d.block; a.scale = d.scale;
+  a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo; a.causal = d.causal; a.block = d.block; a.window = d.window; a.scale = d.scale;
   return a;
 }
 }  // namespace

@@ -31,6 +31,7 @@ struct AttnArgs {
   int B, T, Tp, Hq, Hkv;
   int ldq, ldk, ldv, ldo;
   int causal, block, q_begin;
+  int window;   // > 0 (with causal): a query sees the last `window` positions only, key > q - window (Gemma-3's sliding-window layers)
   float sc;  // softmax scale * log2(e)
   // backward
   const bf16_t* dout; const bf16_t* qt; const bf16_t* kt; const bf16_t* dot;
@@ -98,8 +99,8 @@ __device__ __forceinline__ bf16x8_t pack8(const float* lo, const float* hi) {
 
 // (bitwise, not short-circuit: hipcc then emits compares + selects instead of a chain of exec-mask branches per element;
 // the latency-block test - two integer divisions - sits behind a wave-uniform branch)
-__device__ __forceinline__ bool key_ok(int key, int q, int k_lo, int k_hi, int causal, int block) {
-  bool ok = (key >= k_lo) & (key < k_hi) & ((causal == 0) | (key <= q));
+__device__ __forceinline__ bool key_ok(int key, int q, int k_lo, int k_hi, int causal, int block, int window = 0) {
+  bool ok = (key >= k_lo) & (key < k_hi) & ((causal == 0) | (key <= q)) & ((window <= 0) | (key > q - window));
   if (block > 0) ok = ok & ((key / block) <= (q / block));
   return ok;
 }
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   NatRegs<D, 64> kreg;
   TrRegs<D, 64> vreg;      // (!TR)
   NatRegs<D, 64> vnreg;    // (TR)
-  const int kb_begin = (k_lo / 64) * 64;
+  // (sliding window: the block's first query sees nothing before qb0 - window + 1)
+  const int kb_begin = (max(k_lo, p.window > 0 ? qb0 - p.window + 1 : 0) / 64) * 64;
   if (kb_begin < kb_end) {
     load_nat<D, 64>(kreg, kbase, p.ldk, kb_begin, p.T, tid);
     store_nat<D, 64>(ldsKV, kreg, tid);
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
     bool need_mask = kb < k_lo || kb + 64 > k_hi;
     if (p.causal) need_mask = need_mask || kb + 63 > q0;
     if (p.block > 0) need_mask = need_mask || (kb + 63) / p.block > q0 / p.block;
+    if (p.window > 0) need_mask = need_mask || kb <= q0 + QT * 16 - 1 - p.window;    // the tile's first key lies outside some row's window
     bf16x8_t pf[QT][2];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int key = kb + kt * 16 + g * 4 + e;
-            const float v = key_ok(key, q, k_lo, k_hi, p.causal, p.block) ? s[t][kt][e] : NEG_INF;
+            const float v = key_ok(key, q, k_lo, k_hi, p.causal, p.block, p.window) ? s[t][kt][e] : NEG_INF;
             s[t][kt][e] = v;
             mx = fmaxf(mx, v);
           }
@@ -505,10 +508,12 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   if (p.causal) q_begin = kb0;
   if (p.block > 0) q_begin = max(q_begin, (kb0 / p.block) * p.block);
   q_begin = (q_begin / ST) * ST;
+  // (sliding window: the block's last key is seen by queries up to kb0 + KB - 1 + window - 1)
+  const int q_stop = p.window > 0 ? min(p.T, kb0 + KB - 1 + p.window) : p.T;
 
   // flattened (head-in-group, ST-query step) iteration space, software pipelined: the global loads of a later step are
   // issued before the MFMA work of the current one and written to the other LDS buffer after it (one barrier per step)
-  const int nq = q_begin < p.T ? (p.T - q_begin + ST - 1) / ST : 0;
+  const int nq = q_begin < q_stop ? (q_stop - q_begin + ST - 1) / ST : 0;
   const int n_it = grp * nq;
   struct StepRegs { NatRegs<D, ST, NT> q, d_o; TrRegs<D, TR ? 8 * NT / D : ST, NT> qt, dot; float l, dl; };   // (TR: qt / dot unused, minimal)
   StepRegs r0, r1;
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     const int key_w0 = kb0 + w * 16;  // this wave's 16 keys
     // nothing to add when every (query, key) pair of this wave's tile is masked: its keys lie after the step's last query
     // (the first steps of a causal block) or outside the valid key range
-    if ((p.causal && key_w0 > qs + ST - 1) || key_w0 >= k_hi || key_w0 + 16 <= k_lo) return;
+    if ((p.causal && key_w0 > qs + ST - 1) || key_w0 >= k_hi || key_w0 + 16 <= k_lo || (p.window > 0 && key_w0 + 15 <= qs - p.window)) return;
     const char* ldsQ = ldsAll + cur * NTILE * TILE;
     const char* ldsDO = ldsQ + TILE;
     const char* ldsQT = ldsQ + 2 * TILE;      // (!TR)
@@ -575,6 +580,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     bool need_mask = key_w0 < k_lo || key_w0 + 16 > k_hi || qs + ST > p.T;
     if (p.causal) need_mask = need_mask || key_w0 + 15 > qs;
     if (p.block > 0) need_mask = need_mask || (key_w0 + 15) / p.block > qs / p.block;
+    if (p.window > 0) need_mask = need_mask || key_w0 <= qs + ST - 1 - p.window;
     unsigned okbits = 0xffffu;        // bit t*4 + e: the (query, key) pair of that accumulator element takes part
     if (need_mask) {
       okbits = 0u;
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int q = qs + t * 16 + g * 4 + e;
-          okbits |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block)) << (t * 4 + e);
+          okbits |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block, p.window)) << (t * 4 + e);
         }
     }
 #pragma unroll
@@ -741,7 +747,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   // key steps of ST, software pipelined like the dK/dV kernel
   struct StepRegs { NatRegs<D, ST, NT> k, v; TrRegs<D, TR ? 8 * NT / D : ST, NT> kt; };   // (TR: kt unused, minimal)
   StepRegs r0, r1;
-  const int k_begin = (k_lo / ST) * ST;
+  const int k_begin = (max(k_lo, p.window > 0 ? qb0 - p.window + 1 : 0) / ST) * ST;     // (sliding window: nothing before the block's first query's window)
   const int n_it = k_begin < kend ? (kend - k_begin + ST - 1) / ST : 0;
   int iks = k_begin, cks = k_begin;    // next key step to load / key step being computed
   const int k_last = k_begin + (n_it - 1) * ST;
@@ -762,7 +768,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
     cks += ST;
     const int q_w0 = qb0 + w * 16;  // this wave's 16 queries
     // every pair of this wave's tile masked (its queries lie before the step's first key, or past the sequence): nothing to add
-    if ((p.causal && ks0 > q_w0 + 15) || q_w0 >= p.T) return;
+    if ((p.causal && ks0 > q_w0 + 15) || q_w0 >= p.T || (p.window > 0 && ks0 + ST - 1 <= q_w0 - p.window)) return;
     const char* ldsK = ldsAll + cur * NTILE * TILE;
     const char* ldsV = ldsK + TILE;
     const char* ldsKT = ldsK + 2 * TILE;      // (!TR)
@@ -782,6 +788,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
     bool need_mask = ks0 < k_lo || ks0 + ST > k_hi || q_w0 + 16 > p.T;
     if (p.causal) need_mask = need_mask || ks0 + ST - 1 > q_w0;
     if (p.block > 0) need_mask = need_mask || (ks0 + ST - 1) / p.block > q_w0 / p.block;
+    if (p.window > 0) need_mask = need_mask || ks0 <= q_w0 + 15 - p.window;
     unsigned okbits = 0xffffu;        // bit t*4 + e: the (key, query) pair of that accumulator element takes part
     if (need_mask) {
       okbits = 0u;
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int key = ks0 + t * 16 + g * 4 + e;
-          okbits |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block)) << (t * 4 + e);
+          okbits |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block, p.window)) << (t * 4 + e);
         }
     }
 #pragma unroll
@@ -1190,7 +1197,7 @@ AttnArgs make_args(const uvx::AttnDesc& d) {
   a.o = (bf16_t*)d.o; a.lse = d.lse; a.kv_start = d.kv_start; a.kv_len = d.kv_len;
   a.B = d.B; a.T = d.T; a.Tp = d.Tp; a.Hq = d.Hq; a.Hkv = d.Hkv;
   a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo;
-  a.causal = d.causal; a.block = d.block; a.q_begin = d.q_begin;
+  a.causal = d.causal; a.block = d.block; a.q_begin = d.q_begin; a.window = d.causal ? d.window : 0;
   a.sc = d.scale * LOG2E; a.scale = d.scale;
   return a;
 }
@@ -1286,7 +1293,8 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   // head_dim 128, causal, at most 320 positions (the LLM's training sequences): ONE fused kernel per (batch, query head) -
   // S and dP once, dS through LDS (tuning option 13, default on)
   constexpr int FUSED_TMAX = 320;
-  const bool fused = tr && d.f.D == 128 && d.f.causal && d.f.block == 0 && d.f.T <= FUSED_TMAX && g_options[13];
+  const bool fused = tr && d.f.D == 128 && d.f.causal && d.f.block == 0 && d.f.T <= FUSED_TMAX && g_options[13] &&
+                     (d.f.window <= 0 || d.f.window >= d.f.T);   // (a window that covers the sequence is plain causal attention)
   if (fused) {
     constexpr int smem = (FUSED_TMAX / 16) * (FUSED_TMAX / 16 + 1) / 2 * 512 + 2 * 64 * 128 * 2 + 2 * FUSED_TMAX * 4 + 8 * STAGE_BYTES;
     static_assert(smem <= 160 * 1024, "LDS of one CU");

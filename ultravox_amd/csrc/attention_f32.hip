@@ -9,14 +9,15 @@ namespace {
 struct AArgs {
   const float *q, *k, *v; float* o; float* lse;
   const int32_t *kv_start, *kv_len;
-  int B, T, Hq, Hkv, D, ldq, ldk, ldv, ldo, causal, block;
+  int B, T, Hq, Hkv, D, ldq, ldk, ldv, ldo, causal, block, window;
   float scale;
   const float* dout; const float* delta_in; float* delta; float *dq, *dk, *dv; int lddq, lddk, lddv;
 };
 
-__device__ __forceinline__ bool ok_key(int key, int q, int lo, int hi, int causal, int block) {
+__device__ __forceinline__ bool ok_key(int key, int q, int lo, int hi, int causal, int block, int window = 0) {
   bool ok = key >= lo && key < hi;
   if (causal) ok = ok && key <= q;
+  if (window > 0) ok = ok && key > q - window;      // sliding window (Gemma-3's local layers)
   if (block > 0) ok = ok && (key / block) <= (q / block);
   return ok;
 }
@@ -46,7 +47,7 @@ __global__ void attn_fwd_f32_k(AArgs p) {
   // pass 1: row max;  pass 2: exp-sum and P.V  (two passes keep the arithmetic identical to softmax())
   float mx = -__builtin_huge_valf();
   for (int key = 0; key < p.T; ++key) {
-    if (!ok_key(key, q, lo, hi, p.causal, p.block)) continue;
+    if (!ok_key(key, q, lo, hi, p.causal, p.block, p.window)) continue;
     const float* kr = p.k + ((long long)b * p.T + key) * p.ldk + hk * D;
     float s = 0.f;
 #pragma unroll
@@ -56,7 +57,7 @@ __global__ void attn_fwd_f32_k(AArgs p) {
   }
   float l = 0.f;
   for (int key = 0; key < p.T; ++key) {
-    if (!ok_key(key, q, lo, hi, p.causal, p.block)) continue;
+    if (!ok_key(key, q, lo, hi, p.causal, p.block, p.window)) continue;
     const float* kr = p.k + ((long long)b * p.T + key) * p.ldk + hk * D;
     const float* vr = p.v + ((long long)b * p.T + key) * p.ldv + hk * D;
     float s = 0.f;
@@ -95,7 +96,7 @@ __global__ void attn_bwd_dq_f32_k(AArgs p) {  // also writes delta[b,h,q]
 #pragma unroll
   for (int e = 0; e < E; ++e) acc[e] = 0.f;
   for (int key = 0; key < p.T; ++key) {
-    if (!ok_key(key, q, lo, hi, p.causal, p.block)) continue;
+    if (!ok_key(key, q, lo, hi, p.causal, p.block, p.window)) continue;
     const float* kr = p.k + ((long long)b * p.T + key) * p.ldk + hk * D;
     const float* vr = p.v + ((long long)b * p.T + key) * p.ldv + hk * D;
     const float s = wdot<D>(qr, kr, lane) * p.scale;
@@ -126,7 +127,7 @@ __global__ void attn_bwd_dkdv_f32_k(AArgs p) {  // one wave per (b, kv head, key
   for (int hh = 0; hh < grp; ++hh) {
     const int h = hk * grp + hh;
     for (int q = 0; q < p.T; ++q) {
-      if (!ok_key(key, q, lo, hi, p.causal, p.block)) continue;
+      if (!ok_key(key, q, lo, hi, p.causal, p.block, p.window)) continue;
       const float* qr = p.q + ((long long)b * p.T + q) * p.ldq + h * D;
       const float* dor = p.dout + ((long long)b * p.T + q) * p.ldo + h * D;
       const float lse = p.lse[((long long)b * p.Hq + h) * p.T + q] * 0.6931471805599453f;
@@ -148,7 +149,7 @@ AArgs mk(const uvx::AttnDesc& d) {
   a.q = (const float*)d.q; a.k = (const float*)d.k; a.v = (const float*)d.v; a.o = (float*)d.o; a.lse = d.lse;
   a.kv_start = d.kv_start; a.kv_len = d.kv_len;
   a.B = d.B; a.T = d.T; a.Hq = d.Hq; a.Hkv = d.Hkv; a.D = d.D;
-  a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo; a.causal = d.causal; a.block = d.block; a.scale = d.scale;
+  a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.ldo = d.ldo; a.causal = d.causal; a.block = d.block; a.window = d.window; a.scale = d.scale;
   return a;
 }
 

@@ -319,8 +319,7 @@ int attn_out(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, In
   return gemm(st, dt, g);
 }
 float attn_scale_of(const uvx_config_t& c) { return c.llm_attn_scale > 0.f ? c.llm_attn_scale : 1.0f / sqrtf((float)c.llm_head_dim); }
-// Gemma-3: post norms present, a local rotary table where layers are flagged, and the cache within the sliding window (a local layer
-// over at most `window` positions is plain causal attention; longer caches are not built)
+// Gemma-3: post norms present and a local rotary table where layers are flagged
 int g3_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int Tmax) {
   if (c.llm_flavor != UVX_LLM_GEMMA3) return UVX_OK;
   bool any_local = false;
@@ -329,8 +328,7 @@ int g3_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int Tmax) {
     any_local = any_local || (w->layer_local && w->layer_local[l]);
   }
   UVX_CHECK(!any_local || w->rope_cos_sin_local, UVX_ERR_INVALID, "llm: Gemma-3 sliding-window layers need rope_cos_sin_local");
-  UVX_CHECK(!any_local || c.llm_window <= 0 || Tmax <= c.llm_window, UVX_ERR_UNSUPPORTED,
-            "llm: %d positions in one pass exceed Gemma-3's sliding window (%d): windowed attention over longer prompts / chunks is not built", Tmax, c.llm_window);
+  (void)Tmax;
   return UVX_OK;
 }
 
@@ -405,6 +403,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
     ad.vt = s.vt; ad.o = s.o; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = s.kvl;
     ad.B = B; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.scale = attn_scale_of(c);
+    ad.window = c.llm_flavor == UVX_LLM_GEMMA3 && c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
     RC(attention_fwd(st, dt, ad));
     RC(attn_out(st, c, L, s, M, s.o, s.OD, s.x, s.x2));
     RC(mlp_block(st, c, L, s, M, s.x2, s.x));
@@ -491,6 +490,7 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
     ad.vt = k.fvt; ad.o = k.fo; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = nullptr;
     ad.B = B; ad.T = Tf; ad.Tp = k.Tfp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.q_begin = cur_len; ad.scale = attn_scale_of(c);
+    ad.window = c.llm_flavor == UVX_LLM_GEMMA3 && c.llm_window > 0 && Tf > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
     RC(attention_fwd(st, dt, ad));
     for (int b = 0; b < B; ++b)
       UVX_HIP(hipMemcpyAsync(at(s.o, (size_t)b * Tn * s.OD, dt), at(k.fo, ((size_t)b * Tf + cur_len) * s.OD, dt), (size_t)Tn * s.OD * es,

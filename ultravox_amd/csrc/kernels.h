@@ -156,6 +156,7 @@ struct AttnDesc {
   int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
   int causal = 0;
   int block = 0;  // >0: block-causal "latency" mask, block size in positions
+  int window = 0; // >0 (causal): sliding window - a query sees keys in (q - window, q] only (Gemma-3's local layers)
   int q_begin = 0;  // forward only: query rows below this are not needed (chunked prefill over a cached prefix); blocks wholly below it exit
   float scale = 1.0f;
 };

@@ -790,9 +790,6 @@ static int llm_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int T) {
       any_local = any_local || (w->layer_local && w->layer_local[l]);
     }
     UVX_CHECK(!any_local || w->rope_cos_sin_local, UVX_ERR_INVALID, "llm: Gemma-3 sliding-window layers need rope_cos_sin_local");
-    // a sliding-window layer over at most `window` positions IS plain causal attention; longer sequences are not built
-    UVX_CHECK(!any_local || c.llm_window <= 0 || T <= c.llm_window, UVX_ERR_UNSUPPORTED,
-              "llm: %d positions exceed Gemma-3's sliding window (%d): windowed attention over longer sequences is not built", T, c.llm_window);
   }
   return UVX_OK;
 }
@@ -874,6 +871,8 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     ad.B = Bv; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
     ad.scale = attn_scale;
+    // Gemma-3 sliding-window layer over a sequence LONGER than the window (up to the window it is plain causal attention)
+    ad.window = g3 && c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
     return probe_skip(2) ? UVX_OK : attention_fwd(sx, dt, ad);
   };
   // second half: o_proj + residual, norm, gate|up (+ SwiGLU), down + residual.  compact (last layer of the training pair,
@@ -1179,6 +1178,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     ad.B = Bv; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
     ad.scale = attn_scale;
+    ad.window = g3 && c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
     bd.dout = v.d_o; bd.qt = v.qT; bd.kt = v.kT; bd.dot = v.doT; bd.delta = v.delta; bd.dkv_part = v.dkv_part;
     bd.dq = v.d_qkv; bd.dk = at(v.d_qkv, (size_t)Hq * dh, dt); bd.dv = at(v.d_qkv, (size_t)(Hq + Hkv) * dh, dt);
     bd.lddq = bd.lddk = bd.lddv = s.QKV;

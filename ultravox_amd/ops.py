@@ -116,7 +116,7 @@ def rope_(x, cos_sin, T, n_heads, head_dim, inverse=False):
     return x
 
 
-def _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len):
+def _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len, window=0):
     B, T, Hq, D = q.shape
     d = _lib.AttnDesc()
     d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
@@ -125,28 +125,28 @@ def _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len):
     d.kv_len = 0 if kv_len is None else kv_len.data_ptr()
     d.B, d.T, d.Hq, d.Hkv, d.D = B, T, Hq, k.shape[2], D
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
-    d.causal, d.block, d.scale = int(causal), int(block), scale
+    d.causal, d.block, d.scale, d.window = int(causal), int(block), scale, int(window)
     return d
 
 
-def attention(q, k, v, causal=False, block=0, scale=None, kv_start=None, kv_len=None, need_lse=True):
+def attention(q, k, v, causal=False, block=0, scale=None, kv_start=None, kv_len=None, need_lse=True, window=0):
     """q [B,T,Hq,D], k/v [B,T,Hkv,D] (last two dims contiguous, token stride free) -> o [B,T,Hq*D], lse."""
     B, T, Hq, D = q.shape
     scale = D ** -0.5 if scale is None else scale
     o = torch.empty(B, T, Hq * D, device=q.device, dtype=q.dtype)
     lse = torch.empty(B, Hq, T, device=q.device, dtype=torch.float32) if need_lse else None
-    d = _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len)
+    d = _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len, window)
     nb = _lib.lib().uvx_attention_ws_bytes(_code(q), C.byref(d), 0)
     ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
     check(_lib.lib().uvx_attention_fwd(stream_ptr(), _code(q), C.byref(d), ptr(ws), C.c_size_t(nb)), "uvx_attention_fwd")
     return o, lse
 
 
-def attention_bwd(q, k, v, o, lse, dout, causal=False, block=0, scale=None, kv_start=None, kv_len=None):
+def attention_bwd(q, k, v, o, lse, dout, causal=False, block=0, scale=None, kv_start=None, kv_len=None, window=0):
     B, T, Hq, D = q.shape
     scale = D ** -0.5 if scale is None else scale
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    d = _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len)
+    d = _attn_desc(q, k, v, o, lse, causal, block, scale, kv_start, kv_len, window)
     d.dout, d.dq, d.dk, d.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     d.lddq, d.lddk, d.lddv = dq.stride(1), dk.stride(1), dv.stride(1)
     nb = _lib.lib().uvx_attention_ws_bytes(_code(q), C.byref(d), 1)
