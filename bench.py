@@ -459,7 +459,7 @@ def main():
     dt = max(rank_s)                                        # the contract: MAX over ranks
 
     if rank == 0:
-        fl = flops_per_sample(cfg, wl["seconds"], top_rows=bool(model._llm_train_pair))    # what the measured step really skipped
+        fl = flops_per_sample(cfg, wl["seconds"], top_rows=bool(model._llm_top_rows))    # what the measured step really skipped
         audio_s = B * world * wl["seconds"] * args.steps
         ms = dt / args.steps * 1e3
         out = {

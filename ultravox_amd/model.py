@@ -147,6 +147,7 @@ class UltravoxModel:
         # training step: last layer's o_proj / MLP on the supervised rows only (uvx_llm_fwd_train); A/B switch for the probes
         self.top_layer_supervised_rows = os.environ.get("UVX_TOP_LAYER_ROWS", "1") != "0"
         self._llm_train_pair = False             # which uvx_llm_bwd* entry point pairs with the last language_model_forward
+        self._llm_top_rows = False
         self._kl_grad_scale = 1.0
         self._before_projector = None
         self.keep_params = set()                 # ultravox_model.py:59
@@ -644,6 +645,8 @@ class UltravoxModel:
                   "uvx_llm_fwd")
         self._llm_ctx = (B, T, nb, lab)
         self._llm_train_pair = bool(train_pair)
+        # (what the pair really skipped: Gemma-3's post norms keep its last layer on all rows - bench.py's FLOP count reads this)
+        self._llm_top_rows = bool(train_pair) and not self.config.text_config.is_gemma3
         return CausalLMOutputWithPast(loss=None if loss is None else loss[0], logits=logits)
 
     def language_model_backward(self, grad_scale: float = 1.0) -> torch.Tensor:
@@ -866,6 +869,7 @@ class UltravoxModel:
                                      ptr(ws), C.c_size_t(nb)), "uvx_llm_kl_loss_rows")
         self._llm_ctx = (B, T, nb, "rows")        # forward_backward: uvx_llm_bwd_rows
         self._llm_train_pair = False
+        self._llm_top_rows = False
         return CausalLMOutputWithPast(loss=loss[0], logits=None)
 
     @torch.no_grad()
