@@ -162,9 +162,6 @@ def test_gemma3_decode_runs_past_the_sliding_window():
     longer than the window, every decode step clamps the first visible cache slot of a sliding-window layer to the last `window`
     positions.  Token-exact against the oracle, which masks the window in full - window 40 (crossed while decoding) and window
     24 (crossed inside the prompt)."""
-    from oracle.reference_cpu import OracleModel, logmel_ref, synthetic_batch
-    from ultravox_amd.model import UltravoxModel
-    from ultravox_amd.weights import random_state_dict
     _run_decode_window(40)
     _run_decode_window(24)
 
