@@ -20,6 +20,7 @@
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
+#include <utility>
 #include <hip/hip_ext.h>
 #include "common.h"
 #include "kernels.h"
@@ -1128,6 +1129,288 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 #undef UVX_TL_FLUSH
 }
 
+// ------------------------------------------------------------------------------------------------
+// Four-wave kernel with a hand-scheduled K loop (round 4): (32 MI) x 256 x 64 tile, 256 threads = 4 waves as 2 x 2, one wave
+// per SIMD, (16 MI) x 128 per wave = 8 x MI accumulator fragments in AGPRs (a[0 : 32 MI)), all 160 KiB of LDS as a ring of
+// five 32 KiB operand slots filled by LDS-DMA.  The whole K loop - pipeline fill, steady state, tails, drain - is ONE
+// inline-asm statement generated by tools/gen_gemm_a4.py (gemm_a4_loop.inc): the 8-wave kernels above spend ~2800 cycles
+// per K-tile against the 2048 of its MFMAs because each wave's load section (fragment reads + DMA issue + barrier hand-off)
+// has to hide under 32 MFMAs of its SIMD partner; here a wave reads (MI + 8) x 2 fragments for 16 MI MFMAs (half the LDS
+// bytes per MFMA of the 2 x 4 geometry), every ds_read / DMA issue sits in an MFMA's shadow by construction, and there is one
+// barrier per K-tile.  hipcc cannot schedule this loop (the q4 probe kernel: 570 TF/s, 256 accumulators shuffled through
+// v_accvgpr moves), hence the asm.  Same MFMA, operand roles, swizzle and k order as the rest of the family: results are
+// bit-identical across tile variants.  What stays in C++: tile mapping, address set-up, and the epilogue, which reads the
+// accumulators out of the named AGPRs (a4_acc) in passes of two row fragments through a per-wave LDS stage.
+// The asm addresses LDS absolutely: the kernel's single __shared__ array is the ring (its base is folded into the operands).
+#include "gemm_a4_loop.inc"
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// accumulator fragment at a[R : R + 3] (the K loop's literal registers; volatile keeps the reads behind the loop statement)
+template <int R>
+__device__ __forceinline__ f32x4_t a4_acc() {
+  float x, y, z, w;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+               : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
+  return f32x4_t{x, y, z, w};
+}
+
+// Epilogue of the hand-scheduled kernels: NJ x MI fragments per wave, fragment (j, i) = output columns n_base + 16 j + 4 fg .. + 3,
+// output row m_base + 16 i + frow (the family's convention, store_tile), accumulators read out of the AGPRs two row fragments at
+// a time.  bf16 output goes through the wave's LDS stage (32 rows x 32 NJ bytes): fragments in (16-byte chunks XOR-swizzled by
+// row), whole rows out - 2 NJ lanes = one row of the wave tile, contiguous in memory - with the residual added on the way; rounding
+// points as store_tile (after bias, after the activation, after the residual add).  The host side (a4_applicable) only routes
+// launches here whose pointers / strides allow the 16-byte accesses.
+template <int NJ, int MI>
+__device__ __forceinline__ void store_tile_a4(const GemmArgs& p, int m_base, int n_base, int lane, long long z, char* stage) {
+  constexpr int CH = 2 * NJ, RPI = 64 / CH;     // 16-byte chunks per stage row; rows per read instruction
+  const int frow = lane & 15, fg = lane >> 4;
+  if (p.out_f32) {     // f32 (wgrad / split-K partials): fragment layout is already 16 bytes per lane
+    static_for<NJ>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      const int n = n_base + j * 16 + fg * 4;
+      static_for<MI>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const f32x4_t a = a4_acc<(j * MI + i) * 4>();
+        const int m = m_base + i * 16 + frow;
+        if (m < p.M && n < p.N) {
+          float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + z * p.sC + (long long)m * p.ldc + n);
+          float4 v = make_float4(a[0] * p.alpha, a[1] * p.alpha, a[2] * p.alpha, a[3] * p.alpha);
+          if (p.accumulate) { const float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+          *dst = v;
+        }
+      });
+    });
+    return;
+  }
+  float bv[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n_base + j * 16 + fg * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[j][e] = 0.f;
+    if (p.bias && n < p.N) {
+      const u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[j][e] = bf2f(b4[e]);
+    }
+  }
+  constexpr int NP = (MI + 1) / 2;
+  static_for<NP>([&](auto P) {
+    constexpr int i0 = 2 * decltype(P)::value;
+    constexpr int gi = (MI - i0) < 2 ? (MI - i0) : 2;            // row fragments in this pass
+    if (i0 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads are done (WAR on the stage)
+    // ---- pass 1: [16 gi x 16 NJ] of C into the stage ----
+    static_for<NJ>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      static_for<gi>([&](auto II) {
+        constexpr int ii = decltype(II)::value;
+        const f32x4_t a = a4_acc<(j * MI + i0 + ii) * 4>();
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = bf2f(f2bf(a[e] * p.alpha + bv[j][e]));
+          if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));
+          v[e] = t;
+        }
+        *reinterpret_cast<uint2*>(stage_slot<32, CH>(stage, ii * 16 + frow, 2 * j + (fg >> 1)) + (fg & 1) * 8) =
+            make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+      });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const int cc = lane & (CH - 1), n8 = n_base + cc * 8;
+#pragma unroll
+      for (int it = 0; it < gi * 16 / RPI; ++it) {
+        const int row = it * RPI + lane / CH, m = m_base + i0 * 16 + row;
+        uint4 o = *reinterpret_cast<const uint4*>(stage_slot<32, CH>(stage, row, cc));
+        if (m < p.M && n8 < p.N) {
+          if (p.residual) {
+            const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+            const uint4 r = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
+            o.x = pack2(unpack_lo(o.x) + unpack_lo(r.x), unpack_hi(o.x) + unpack_hi(r.x));
+            o.y = pack2(unpack_lo(o.y) + unpack_lo(r.y), unpack_hi(o.y) + unpack_hi(r.y));
+            o.z = pack2(unpack_lo(o.z) + unpack_lo(r.z), unpack_hi(o.z) + unpack_hi(r.z));
+            o.w = pack2(unpack_lo(o.w) + unpack_lo(r.w), unpack_hi(o.w) + unpack_hi(r.w));
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n8) = o;
+        }
+      }
+    }
+    if (p.swiglu == 1) {
+      // ---- pass 2 (fused SwiGLU): act = round(silu(gate)) * up, [16 gi x 8 NJ] -> C2; gate = fragment j (even), up = j + 1 ----
+      constexpr int CH2 = NJ, RPI2 = 64 / CH2;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pass-1 reads done before the stage is overwritten
+      static_for<NJ / 2>([&](auto J2) {
+        constexpr int j = 2 * decltype(J2)::value;
+        static_for<gi>([&](auto II) {
+          constexpr int ii = decltype(II)::value;
+          const f32x4_t ag = a4_acc<(j * MI + i0 + ii) * 4>();
+          const f32x4_t au = a4_acc<((j + 1) * MI + i0 + ii) * 4>();
+          float a[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = bf2f(f2bf(ag[e] * p.alpha));
+            a[e] = bf2f(f2bf(g / (1.0f + __expf(-g)))) * bf2f(f2bf(au[e] * p.alpha));
+          }
+          *reinterpret_cast<uint2*>(stage_slot<32, CH2>(stage, ii * 16 + frow, j + (fg >> 1)) + (fg & 1) * 8) =
+              make_uint2(pack2(a[0], a[1]), pack2(a[2], a[3]));
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int cc = lane & (CH2 - 1), n8 = n_base / 2 + cc * 8;
+#pragma unroll
+      for (int it = 0; it < gi * 16 / RPI2; ++it) {
+        const int row = it * RPI2 + lane / CH2, m = m_base + i0 * 16 + row;
+        const uint4 o = *reinterpret_cast<const uint4*>(stage_slot<32, CH2>(stage, row, cc));
+        if (m < p.M && 2 * n8 < p.N) *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc2 + n8) = o;
+      }
+    }
+  });
+}
+
+#define UVX_A4_OPERANDS                                                                                                      \
+  [xo0] "v"(xo[0]), [xo1] "v"(xo[1]), [xo2] "v"(xo[2]), [xo3] "v"(xo[3]), [xo4] "v"(xo[4]), [xo5] "v"(xo[5]),                 \
+  [xo6] "v"(xo[6]), [xo7] "v"(xo[7]), [wo0] "v"(wo[0]), [wo1] "v"(wo[1]), [wo2] "v"(wo[2]), [wo3] "v"(wo[3]),                 \
+  [wo4] "v"(wo[4]), [wo5] "v"(wo[5]), [wo6] "v"(wo[6]), [wo7] "v"(wo[7]), [sAlo] "s"(a_lo), [sAhi] "s"(a_hi),                 \
+  [sBlo] "s"(b_lo), [sBhi] "s"(b_hi), [nk] "s"(nk), [vx0] "v"(vx[0]), [vx1] "v"(vx[1]), [vw0] "v"(vw[0]), [vw1] "v"(vw[1]),   \
+  [wofs] "s"(wofs)
+#define UVX_A8_OPERANDS                                                                                                      \
+  [xo0] "v"(xo[0]), [xo1] "v"(xo[1]), [xo2] "v"(xo[2]), [xo3] "v"(xo[3]), [wo0] "v"(wo[0]), [wo1] "v"(wo[1]),                 \
+  [wo2] "v"(wo[2]), [wo3] "v"(wo[3]), [sAlo] "s"(a_lo), [sAhi] "s"(a_hi),                                                     \
+  [sBlo] "s"(b_lo), [sBhi] "s"(b_hi), [nk] "s"(nk), [vx0] "v"(vx[0]), [vx1] "v"(vx[1]), [vw0] "v"(vw[0]), [vw1] "v"(vw[1]),   \
+  [wofs] "s"(wofs)
+
+// NWN = waves along N: 2 = four waves (one per SIMD, (16 MI) x 128 each), 4 = eight waves (two per SIMD, (16 MI) x 64 each).
+// SCHED selects the generated interleave (gemm_a4_loop.inc; 0 = production, others: probe builds).
+template <int NWN, int MI, int SCHED = 0>
+__global__ __launch_bounds__(128 * NWN, NWN / 2) void gemm_nt_bf16_a4_kernel(GemmArgs p) {
+  static_assert(MI == 8 && (NWN == 2 || NWN == 4), "generated loops exist for MI = 8");
+  constexpr int BMT = 32 * MI, BNW = 256, WAVES = 2 * NWN, NJ = 16 / NWN, NX = 4 * MI / WAVES, NW = 32 / WAVES;
+  __shared__ __attribute__((aligned(16))) char lds[5 * 32768];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w / NWN, wc = w % NWN;
+  if (p.m_dev) p.M = min(p.M, max(*p.m_dev - p.m_dev_off, 0));   // rows known only on the device: clamp M
+  // XCD-aware bijective remap of the dispatch order (see the eight-phase kernel's tile_origin)
+  const int ntiles = p.tiles_m * p.tiles_n, o = blockIdx.x;
+  const int xcd = o & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (o >> 3);
+  int m0, n0;
+  if (p.m_major) { m0 = (wg / p.tiles_n) * BMT; n0 = (wg % p.tiles_n) * BNW; }
+  else { m0 = (wg % p.tiles_m) * BMT; n0 = (wg / p.tiles_m) * BNW; }
+  if (m0 >= p.M) return;   // (before any barrier)
+  const long long z = blockIdx.y;
+  const char* A = reinterpret_cast<const char*>(p.A + z * p.sA + (long long)m0 * p.lda);
+  const char* B = reinterpret_cast<const char*>(p.B + z * p.sB + (long long)n0 * p.ldb);
+  const unsigned a_lo = (unsigned)(uintptr_t)A, a_hi = (unsigned)((uintptr_t)A >> 32);
+  const unsigned b_lo = (unsigned)(uintptr_t)B, b_hi = (unsigned)((uintptr_t)B >> 32);
+
+  // DMA instruction i of wave w covers unit rows 8 (w + WAVES i) .. + 7: lane -> row + (lane >> 3), LDS chunk position lane & 7
+  // holds source chunk (lane & 7) ^ (row & 7); rows past the matrix edge re-read its last row (results are masked at the store)
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  unsigned xo[NX], wo[NW];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xo[i] = (unsigned)min(8 * (w + WAVES * i) + srow, p.M - 1 - m0) * (unsigned)(p.lda * 2) + schunk * 16;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) wo[i] = (unsigned)min(8 * (w + WAVES * i) + srow, p.N - 1 - n0) * (unsigned)(p.ldb * 2) + schunk * 16;
+  // fragment reads: X fragment i = slot + vx[kh] + 2048 i, W fragment j = slot + vw[kh] + 2048 j
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const int frow = lane & 15, fg = lane >> 4;
+  unsigned vx[2], vw[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const unsigned c = ((fg + 4 * kh) ^ (frow & 7)) * 16;
+    vx[kh] = lds_base + (wr * (16 * MI) + frow) * 128 + c;
+    vw[kh] = lds_base + (wc * (16 * NJ) + frow) * 128 + c;
+  }
+  const unsigned wofs = lds_base + w * 1024;
+  const int nk = p.K / 64;
+#define UVX_AX_LOOP(G, S) asm volatile(UVX_##G##_MI8_LOOP_S##S : : UVX_##G##_OPERANDS : UVX_##G##_MI8_CLOBBER)
+  if constexpr (NWN == 2) {
+    if constexpr (SCHED == 0) UVX_AX_LOOP(A4, 1);
+#ifdef UVX_PROBES
+    if constexpr (SCHED == 1) UVX_AX_LOOP(A4, 0);
+    if constexpr (SCHED == 2) UVX_AX_LOOP(A4, 2);
+    if constexpr (SCHED == 3) UVX_AX_LOOP(A4, 3);
+    if constexpr (SCHED == 4) UVX_AX_LOOP(A4, 4);
+    if constexpr (SCHED == 5) UVX_AX_LOOP(A4, 5);
+#endif
+  } else {
+    if constexpr (SCHED == 0) UVX_AX_LOOP(A8, 0);
+#ifdef UVX_PROBES
+    if constexpr (SCHED == 1) UVX_AX_LOOP(A8, 1);
+    if constexpr (SCHED == 2) UVX_AX_LOOP(A8, 2);
+    if constexpr (SCHED == 3) UVX_AX_LOOP(A8, 3);
+    if constexpr (SCHED == 4) UVX_AX_LOOP(A8, 4);
+    if constexpr (SCHED == 5) UVX_AX_LOOP(A8, 5);
+#endif
+  }
+#undef UVX_AX_LOOP
+  store_tile_a4<NJ, MI>(p, m0 + wr * (16 * MI), n0 + wc * (16 * NJ), lane, z, lds + w * (32 * 32 * NJ));
+}
+
+// Eight waves, ping-pong by wave row (gen_gemm_a4.py "a8pp"): same tile / ring / fragments as the eight-wave kernel above, but a
+// wave alternates a PURE MFMA phase (64 MFMAs = one K-tile, fragments of the whole K-tile in registers) with a load phase (24
+// fragment reads + 8 LDS-DMA instructions), the two waves of a SIMD run half a period apart, and the DMA is split by operand:
+// wave row 0 issues the activation units, wave row 1 the weight units.  One barrier per K-tile.
+template <int SCHED = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_a8pp_kernel(GemmArgs p) {
+  constexpr int MI = 8, NJ = 4, BMT = 256, BNW = 256;
+  __shared__ __attribute__((aligned(16))) char lds[5 * 32768];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  if (p.m_dev) p.M = min(p.M, max(*p.m_dev - p.m_dev_off, 0));   // rows known only on the device: clamp M
+  const int ntiles = p.tiles_m * p.tiles_n, o = blockIdx.x;
+  const int xcd = o & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (o >> 3);
+  int m0, n0;
+  if (p.m_major) { m0 = (wg / p.tiles_n) * BMT; n0 = (wg % p.tiles_n) * BNW; }
+  else { m0 = (wg % p.tiles_m) * BMT; n0 = (wg / p.tiles_m) * BNW; }
+  if (m0 >= p.M) return;   // (before any barrier)
+  const long long z = blockIdx.y;
+  // this wave row's DMA operand: row 0 = activations (A rows m0 ..), row 1 = weights (B rows n0 ..)
+  const char* G = wr == 0 ? reinterpret_cast<const char*>(p.A + z * p.sA + (long long)m0 * p.lda)
+                          : reinterpret_cast<const char*>(p.B + z * p.sB + (long long)n0 * p.ldb);
+  const unsigned gp_lo = (unsigned)(uintptr_t)G, gp_hi = (unsigned)((uintptr_t)G >> 32);
+  const int lim = wr == 0 ? p.M - 1 - m0 : p.N - 1 - n0;
+  const unsigned ldg = (unsigned)((wr == 0 ? p.lda : p.ldb) * 2);
+  // DMA instruction i of wave wc (of its row) covers unit rows 8 (wc + 4 i) .. + 7 (see the four-wave kernel)
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  unsigned go[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) go[i] = (unsigned)min(8 * (wc + 4 * i) + srow, lim) * ldg + schunk * 16;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const int frow = lane & 15, fg = lane >> 4;
+  unsigned vx[2], vw[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const unsigned c = ((fg + 4 * kh) ^ (frow & 7)) * 16;
+    vx[kh] = lds_base + (wr * 128 + frow) * 128 + c;
+    vw[kh] = lds_base + (wc * 64 + frow) * 128 + c;
+  }
+  const unsigned wofs = lds_base + wc * 1024;
+  const int nk = p.K / 64;
+#define UVX_PP_LOOP(S)                                                                                                         \
+  asm volatile(UVX_A8PP_MI8_LOOP_S##S : : [go0] "v"(go[0]), [go1] "v"(go[1]), [go2] "v"(go[2]), [go3] "v"(go[3]), [go4] "v"(go[4]), \
+               [go5] "v"(go[5]), [go6] "v"(go[6]), [go7] "v"(go[7]), [gplo] "s"(gp_lo), [gphi] "s"(gp_hi), [nk] "s"(nk),       \
+               [vx0] "v"(vx[0]), [vx1] "v"(vx[1]), [vw0] "v"(vw[0]), [vw1] "v"(vw[1]), [wofs] "s"(wofs), [wr] "s"(wr)            \
+               : UVX_A8PP_MI8_CLOBBER)
+  if constexpr (SCHED == 0) UVX_PP_LOOP(0);
+#ifdef UVX_PROBES
+  if constexpr (SCHED == 1) UVX_PP_LOOP(1);
+  if constexpr (SCHED == 2) UVX_PP_LOOP(2);
+  if constexpr (SCHED == 3) UVX_PP_LOOP(3);
+#endif
+#undef UVX_PP_LOOP
+  store_tile_a4<NJ, MI>(p, m0 + wr * 128, n0 + wc * 64, lane, z, lds + w * 4096);
+}
+
 // Tile choice.  Every CU works through ~tiles/256 rounds of tiles (see variant_cost for the partial last
 // round); a tile costs BM x BN / speed(variant), speeds measured on
 // MI355X (profiles/r01_gemm_variants.txt).  variant 0 = 128x128 narrow; 1..4 = {128,160,192,256} x 256 wide.
@@ -1145,7 +1428,7 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 43;
+constexpr int kNumVariants = 59;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
@@ -1165,11 +1448,22 @@ const Variant kVariants[kNumVariants] = {
     {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1305., 9.},  {128, 256, 1160., 6.},
     {256, 256, 0., 6.},     {192, 256, 0., 8.},      {160, 256, 0., 7.},     {128, 256, 0., 5.},    // 35..38 = PERSISTENT merged-phase (probe)
     // 39..42 = STREAM-K merged-phase {256,192,160,128} x 256 (probe builds; see the kernel).  Cost: sk_cost() below.
-    {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.}};
+    {256, 256, 1470., 8.5}, {192, 256, 1430., 10.5}, {160, 256, 1285., 9.},  {128, 256, 1160., 6.},
+    // 43 = FOUR-WAVE kernel with the hand-scheduled K loop, 256 x 256 (round 4; see gemm_nt_bf16_a4_kernel); 44, 45 = other
+    // interleaves of the same loop (probe builds)
+    {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},
+    {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},    // 46..48 = timing probes of 43: no in-loop DMA / nor fragment reads / no MFMAs
+    // 49 = EIGHT-WAVE kernel with the hand-scheduled K loop (two free-running waves per SIMD), 256 x 256; 50, 51 = other interleaves;
+    // 52..54 = its timing probes
+    {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},
+    {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},
+    // 55 = eight waves, PING-PONG by wave row (pure MFMA phase / load phase, DMA split by operand); 56..58 = its timing probes
+    {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},     {256, 256, 0., 7.}};
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
-constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34); }
+constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34) || v == 43 || v == 49 || v == 55; }
+constexpr bool is_a4(int v) { return v >= 43 && v <= 58; }
 constexpr bool is_streamk(int v) { return v >= 39 && v <= 42; }
 bool variant_available(int v) {
 #ifdef UVX_PROBES
@@ -1314,7 +1608,23 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 32: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2>), grid, dim3(512), st, a); break;
     case 33: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2>), grid, dim3(512), st, a); break;
     case 34: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2>), grid, dim3(512), st, a); break;
+    case 43: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<2, 8, 0>), grid, dim3(256), st, a); break;
+    case 49: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<4, 8, 0>), grid, dim3(512), st, a); break;
+    case 55: UVX_GEMM_LAUNCH((gemm_nt_bf16_a8pp_kernel<0>), grid, dim3(512), st, a); break;
 #ifdef UVX_PROBES
+    case 56: UVX_GEMM_LAUNCH((gemm_nt_bf16_a8pp_kernel<1>), grid, dim3(512), st, a); break;
+    case 57: UVX_GEMM_LAUNCH((gemm_nt_bf16_a8pp_kernel<2>), grid, dim3(512), st, a); break;
+    case 58: UVX_GEMM_LAUNCH((gemm_nt_bf16_a8pp_kernel<3>), grid, dim3(512), st, a); break;
+    case 44: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<2, 8, 1>), grid, dim3(256), st, a); break;
+    case 45: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<2, 8, 2>), grid, dim3(256), st, a); break;
+    case 46: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<2, 8, 3>), grid, dim3(256), st, a); break;
+    case 47: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<2, 8, 4>), grid, dim3(256), st, a); break;
+    case 48: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<2, 8, 5>), grid, dim3(256), st, a); break;
+    case 50: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<4, 8, 1>), grid, dim3(512), st, a); break;
+    case 51: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<4, 8, 2>), grid, dim3(512), st, a); break;
+    case 52: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<4, 8, 3>), grid, dim3(512), st, a); break;
+    case 53: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<4, 8, 4>), grid, dim3(512), st, a); break;
+    case 54: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<4, 8, 5>), grid, dim3(512), st, a); break;
     case 1: UVX_GEMM_LAUNCH(gemm_nt_bf16_wide_kernel<128>, grid, dim3(512), st, a); break;
     case 2: UVX_GEMM_LAUNCH(gemm_nt_bf16_wide_kernel<160>, grid, dim3(512), st, a); break;
     case 3: UVX_GEMM_LAUNCH(gemm_nt_bf16_wide_kernel<192>, grid, dim3(512), st, a); break;
@@ -1379,6 +1689,17 @@ int uvx::gemm_streamk_timeouts() {
   return (int)(total > 0x7fffffff ? 0x7fffffff : total);
 }
 
+// launches the four-wave kernel's epilogue can serve (16-byte accesses on every operand it touches; no SwiGLU-backward fusion)
+static bool a4_applicable(const uvx::GemmDesc& d) {
+  if (d.swiglu == 2) return false;
+  if (d.out_f32) return true;
+  const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  if ((d.N & 7) || (d.ldc & 7) || (d.sC & 7) || !al16(d.C)) return false;
+  if (d.residual && ((d.ldr & 7) || (d.sR & 7) || !al16(d.residual))) return false;
+  if (d.swiglu == 1 && ((d.ldc2 & 7) || !al16(d.C2))) return false;
+  return true;
+}
+
 int uvx::gemm_pick_variant(int M, int N, int K, int batch) { return pick_variant(M, N, K, batch > 0 ? batch : 1); }
 
 int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
@@ -1409,7 +1730,8 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
             "gemm: swiglu-backward epilogue writes [M, 2N]: ldc=%d / ldc2=%d too small for N=%d", d.ldc, d.ldc2, d.N);
   const int batch = d.batch > 0 ? d.batch : 1;
   double cost_whole = 0.;
-  const int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole);
+  int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole);
+  if (is_a4(variant) && !a4_applicable(d)) variant = 31;     // (the eight-wave 256 x 256 kernel takes any alignment)
   UVX_CHECK(variant_available(variant), UVX_ERR_INVALID,
             "gemm: tile variant %d is not in this build (probe variants live in libuvx_probes.so, built with -DUVX_PROBES)", variant);
   // (device-side row count: the true work is unknown here, such launches are left out of the timing)
