@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 12
+#define UVX_ABI_VERSION 13
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -335,6 +335,11 @@ size_t uvx_llm_prefill_chunk_ws_bytes(const uvx_config_t* cfg, int32_t B, int32_
 int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
                               int32_t B, int32_t Tn, void* kv_cache, int32_t Tmax, int32_t cur_len, const int32_t* positions0,
                               const int32_t* kv_start, void* logits_last, void* workspace, size_t ws_bytes);
+/* The same with the logits of EVERY new position, logits_all [B, Tn, vocab]: what the language model returns for
+ * forward(past_key_values=...) without logits_to_keep (ultravox_model.py:328-334 -> [3P] LlamaForCausalLM.forward). */
+int32_t uvx_llm_prefill_chunk_logits(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                                     int32_t B, int32_t Tn, void* kv_cache, int32_t Tmax, int32_t cur_len, const int32_t* positions0,
+                                     const int32_t* kv_start, void* logits_all, void* workspace, size_t ws_bytes);
 /* out[r] = argmax_v logits[r, v] (lowest index on ties, like torch.argmax) */
 int32_t uvx_argmax(void* stream, int32_t dtype, const void* logits, int32_t rows, int32_t V, int64_t* out);
 

@@ -27,6 +27,8 @@ What is recorded
                     _compute_kl_loss inside the model) on the same seeded tiny model: loss and projector gradients, two settings.
   lora_forward_reference.npz / .json — the REFERENCE model with text_model_lora_config r = 4 (apply_lora via tests/peft_stub.py),
                     forward + backward with non-zero adapters: loss, logits, projector and adapter gradients.
+  kl_lora_forward_reference.npz / .json — the same model in training mode under KL_Divergence: teacher and student both run the
+                    ADAPTED language model (ultravox_model.py:212-222); loss, projector and adapter gradients.
   (No Gemma-backbone run of the reference model: the installed transformers 5.x moved Gemma's sqrt(hidden) scale into the
    embedding module, i.e. it no longer scales the MERGED inputs_embeds as the reference's pinned 4.51.3 does - a fixture
    generated here would pin the wrong semantics.  The Gemma blocks are pinned against HF with the scale applied explicitly.)
@@ -672,6 +674,34 @@ def lora_forward_cases():
     print("lora_forward_reference:", meta["loss"], len(trainable))
 
 
+def kl_lora_forward_cases():
+    """The REFERENCE model with text_model_lora_config r = 4 in TRAINING mode under LossFunction.KL_Divergence: the teacher pass of
+    _compute_kl_loss goes through the SAME self.language_model (ultravox_model.py:212-222), i.e. with the adapters ACTIVE, under
+    no_grad; the student is the audio path through the same adapted model.  Loss, projector and adapter gradients, non-zero lora_B."""
+    import forward_fixture_util as U
+    lcfg = dataclasses.asdict(ultravox_config.LoraConfigSimplified(r=4))
+    m = _seeded_reference_model(True, extra={"text_model_lora_config": lcfg})
+    lc = dict(kl_temperature=2.0, eot_loss_weight=1.0)
+    m.set_loss_config(ultravox_config.LossConfig(loss_function=ultravox_config.LossFunction.KL_Divergence, **lc))
+    m.train()
+    enc = U.tower_output()
+    m.audio_tower.forward = lambda audio_values, audio_len=None, **k: transformers.modeling_outputs.BaseModelOutput(
+        last_hidden_state=enc[: audio_values.shape[0]])
+    out = m(audio_values=torch.zeros(U.N_AUDIO, 80, 3000), **U.batch(), **U.alt_batch())
+    out.loss.backward()
+    arrays = {"loss": np.array(out.loss.item(), np.float64)}
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            arrays["g." + n] = p.grad.numpy()
+    meta = {"loss": out.loss.item(), "trainable": trainable, "lora_config": lcfg, **lc,
+            "weight_names": [n for n, _ in m.named_parameters() if n.startswith(("multi_modal_projector.", "language_model."))]}
+    np.savez_compressed(os.path.join(HERE, "kl_lora_forward_reference.npz"), **arrays)
+    with open(os.path.join(HERE, "kl_lora_forward_reference.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("kl_lora_forward_reference:", meta["loss"], len(trainable))
+
+
 def generate_cases():
     """The REFERENCE UltravoxModel.generate (ultravox_model.py:398-426 -> [3P] GenerationMixin greedy search) on the seeded
     tiny model of forward_cases: audio merged once before the prefill, a left-padded prompt next to an unpadded one,
@@ -788,7 +818,12 @@ def real_tower_cases():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # python make_golden.py kl_lora_forward_cases ...: only the named generators
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     real_tower_cases()
+    kl_lora_forward_cases()
     lora_forward_cases()
     kl_forward_cases()
     generate_cases()

@@ -196,6 +196,32 @@ def test_rope_parameters_of_newer_transformers_configs_are_read():
     assert got.rope_theta == 1000000.0
 
 
+def test_a_text_config_without_rope_theta_takes_its_familys_default():
+    """a 4.51.3-style gemma3 text_config dict (the published google/gemma-3-27b-it config.json leaves rope_theta out)
+    must build the global layers' rotary table with Gemma3TextConfig's 1e6, not a flat 1e4; every family is pinned against the
+    installed transformers config class."""
+    import transformers
+    from ultravox_amd.config import UltravoxConfig
+    small = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=6, num_attention_heads=2, num_key_value_heads=1, vocab_size=128)
+
+    def hf_theta(cfg):
+        rp = getattr(cfg, "rope_parameters", None)
+        if isinstance(rp, dict):
+            rp = rp.get("full_attention", rp)
+            return float(rp["rope_theta"])
+        return float(cfg.rope_theta)
+
+    for mt, cls in (("gemma3_text", transformers.Gemma3TextConfig), ("llama", transformers.LlamaConfig), ("gemma", transformers.GemmaConfig),
+                    ("qwen2", transformers.Qwen2Config), ("qwen3", transformers.Qwen3Config)):
+        got = UltravoxConfig(text_config={"model_type": mt, **small}).text_config
+        assert got.rope_theta == hf_theta(cls()), mt
+    g3 = UltravoxConfig(text_config={"model_type": "gemma3_text", **small}).text_config
+    assert g3.rope_theta == 1000000.0 and g3.rope_local_base_freq == 10000.0
+    nested = UltravoxConfig(text_config={"model_type": "gemma3", "text_config": {"model_type": "gemma3_text", **small}}).text_config
+    assert nested.rope_theta == 1000000.0
+    assert UltravoxConfig(text_config={"model_type": "gemma3_text", **small, "rope_theta": 5000.0}).text_config.rope_theta == 5000.0
+
+
 def test_from_pretrained_base_gets_adapter_keys_before_the_checkpoint_is_merged():
     """The merge refuses unknown keys; a LoRA checkpoint's adapter keys must therefore already exist in the base."""
     from ultravox_amd import checkpoint

@@ -256,8 +256,8 @@ def test_f32_generate_matches_the_reference_generate_fixture():
 def test_forward_with_past_key_values_drives_a_decode_loop(dtype):
     """forward(input_ids=new tokens, past_key_values=KVState) - the call the reference forwards to the language model
     (ultravox_model.py:328-334) and HF's generation loop issues every step: a hand-rolled greedy loop over it reproduces
-    generate() token for token (f32), appends to / grows the cache, and returns [B, 1, V] logits + the extended state; a
-    multi-token continuation needs logits_to_keep=1 (HF's own prefill setting)."""
+    generate() token for token (f32), appends to / grows the cache, and returns [B, Tn, V] logits + the extended state
+    ([B, 1, V] with logits_to_keep=1, HF's own prefill setting)."""
     cfg, model, _ = _build(dtype, 37)
     torch.manual_seed(3)
     B, T = 2, 40
@@ -281,12 +281,24 @@ def test_forward_with_past_key_values_drives_a_decode_loop(dtype):
         assert torch.equal(seq.cpu(), want)
     else:
         assert (seq.cpu() == want).float().mean().item() > 0.9
-    # several new tokens at once: last-position logits only, on request
-    with pytest.raises(NotImplementedError, match="logits_to_keep=1"):
-        model.forward(input_ids=want[:, T:T + 3].to(DEV), past_key_values=first.past_key_values)
+    # several new tokens at once: logits of EVERY new position [B, Tn, V] as from the HF language model (ultravox_model.py:328-334)
+    # - against the teacher-forced forward over the whole sequence - or the last one only on request (logits_to_keep=1)
+    full = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=1, eos_token_id=-1, return_dict_in_generate=True)
+    outN = model.forward(input_ids=want[:, T:T + 3].to(DEV), past_key_values=full.past_key_values)
+    assert tuple(outN.logits.shape) == (B, 3, 512) and outN.past_key_values.cur_len == T + 3
+    am_full = torch.cat([am, torch.ones(B, 3, dtype=torch.long)], 1)
+    tf = model.forward(input_ids=want[:, :T + 3].to(DEV), attention_mask=am_full.to(DEV)).logits[:, T:T + 3].float()
+    if dtype == torch.float32:
+        assert (outN.logits.float() - tf).abs().max().item() < 1e-4
+        assert torch.equal(outN.logits.float().argmax(-1).cpu(), want[:, T + 1:T + 4])
+    else:
+        assert rel_l2(outN.logits.float(), tf) < 2e-2
+    with pytest.raises(NotImplementedError, match="logits_to_keep=2"):
+        model.forward(input_ids=want[:, T:T + 3].to(DEV), past_key_values=outN.past_key_values, logits_to_keep=2)
     again = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=1, eos_token_id=-1, return_dict_in_generate=True)
     out3 = model.forward(input_ids=want[:, T:T + 3].to(DEV), past_key_values=again.past_key_values, logits_to_keep=1)
-    assert out3.past_key_values.cur_len == T + 3
+    assert out3.past_key_values.cur_len == T + 3 and tuple(out3.logits.shape) == (B, 1, 512)
+    assert torch.equal(out3.logits[:, 0], outN.logits[:, -1]) or rel_l2(out3.logits[:, 0].float(), outN.logits[:, -1].float()) < 1e-2
     if dtype == torch.float32:
         assert torch.equal(out3.logits[:, 0].float().argmax(-1).cpu(), want[:, T + 3])
     with pytest.raises(ValueError, match="inference call"):

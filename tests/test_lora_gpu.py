@@ -212,3 +212,30 @@ def test_llm_lora_step_matches_the_reference_model_fixture(dtype):
     assert sorted(mine) == sorted(exp["grads"])
     for k, g in exp["grads"].items():
         assert rel_l2(mine[k], g) < (2e-3 if dtype == torch.float32 else 0.1), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_kl_step_under_llm_lora_matches_the_reference_model_fixture(dtype):
+    """KL distillation WITH an LLM LoRA adapter: the reference's teacher pass is `self.language_model.forward`
+    (ultravox_model.py:212-222) - the same adapted model, adapters active, no_grad - so both passes run uvx_llm_fwd_lora.  Fixture
+    kl_lora_forward_reference.npz is the imported reference in training mode (text_model_lora_config r = 4, KL_Divergence,
+    non-zero lora_B): loss, projector and adapter gradients."""
+    import forward_fixture_util as U
+    from test_oracle_pinning import load_lora_forward_fixture
+    from ultravox_amd.config import LossConfig, LossFunction
+    from ultravox_amd.model import UltravoxModel
+    cfg, sd, batch, enc, exp = load_lora_forward_fixture("kl_lora_forward_reference")
+    model = UltravoxModel(cfg, state_dict={k: v.to(dtype) for k, v in sd.items()}, device=DEV, dtype=dtype)
+    model.set_loss_config(LossConfig(loss_function=LossFunction.KL_Divergence, kl_temperature=exp["meta"]["kl_temperature"],
+                                     eot_loss_weight=exp["meta"]["eot_loss_weight"]))
+    tower = enc.to(DEV, dtype)
+    model.audio_tower_forward = lambda audio_values, audio_len: tower[: audio_values.shape[0]]
+    gb = {k: v.to(DEV) for k, v in {**batch, **U.alt_batch()}.items()}
+    model.train()
+    loss = model.forward_backward(audio_values=torch.zeros(len(enc), 80, 3000, device=DEV, dtype=dtype), **gb)
+    want = exp["loss"]
+    assert abs(loss.item() - want) < (1e-5 + 1e-4 * want if dtype == torch.float32 else 0.05 * want + 1e-4)
+    mine = model.projector_grads()
+    assert sorted(mine) == sorted(exp["grads"])
+    for k, g in exp["grads"].items():
+        assert rel_l2(mine[k], g) < (2e-3 if dtype == torch.float32 else 0.1), k

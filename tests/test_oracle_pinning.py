@@ -668,8 +668,8 @@ def test_oracle_kl_step_matches_the_reference_forward_in_training_mode(tag):
             np.testing.assert_allclose(oracle.sd[k[len(tag) + 3:]].grad.numpy(), z[k], rtol=3e-4, atol=1e-7, err_msg=k)
 
 
-def load_lora_forward_fixture():
-    """tests/golden/lora_forward_reference.* + the seeded weights (by the REFERENCE's parameter names: under peft the base
+def load_lora_forward_fixture(stem="lora_forward_reference"):
+    """tests/golden/lora_forward_reference.* (or kl_lora_forward_reference.*) + the seeded weights (by the REFERENCE's parameter names: under peft the base
     weights are `language_model.base_model.model.<...>.base_layer.weight`; this framework keeps HF names for them)."""
     import json
     import os
@@ -677,8 +677,8 @@ def load_lora_forward_fixture():
     from ultravox_amd.config import UltravoxConfig
     from ultravox_amd.weights import random_state_dict
     here = os.path.join(os.path.dirname(__file__), "golden")
-    z = np.load(os.path.join(here, "lora_forward_reference.npz"))
-    meta = json.load(open(os.path.join(here, "lora_forward_reference.json")))
+    z = np.load(os.path.join(here, stem + ".npz"))
+    meta = json.load(open(os.path.join(here, stem + ".json")))
     from ultravox_amd.weights import init_lora_state_dict
     cfg = UltravoxConfig(**U.config_kwargs(True), text_model_lora_config=meta["lora_config"])
     sd = random_state_dict(cfg, seed=1)
@@ -690,7 +690,7 @@ def load_lora_forward_fixture():
         sd[key] = U.param(ref, sd[key].shape)
         seen.add(key)
     assert {k for k in sd if k.startswith(("multi_modal_projector.", "language_model."))} == seen
-    exp = {"logits": torch.from_numpy(z["logits"]), "loss": float(z["loss"]),
+    exp = {"logits": torch.from_numpy(z["logits"]) if "logits" in z.files else None, "loss": float(z["loss"]), "meta": meta,
            "grads": {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g.")}}
     assert sorted(exp["grads"]) == sorted(meta["trainable"])
     return cfg, sd, U.batch(), U.tower_output(), exp
@@ -710,3 +710,23 @@ def test_oracle_llm_lora_step_matches_the_reference_model_with_text_lora():
     out["loss"].backward()
     for k, g in exp["grads"].items():
         np.testing.assert_allclose(oracle.sd[k].grad.numpy(), g.numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
+
+
+def test_oracle_kl_step_under_llm_lora_runs_the_teacher_through_the_adapted_model():
+    """KL distillation with text_model_lora_config r = 4 against the REFERENCE (fixture kl_lora_forward_reference.npz): the teacher
+    pass of _compute_kl_loss is `self.language_model.forward` (ultravox_model.py:212-222) - the peft-wrapped model, adapters
+    ACTIVE, no_grad.  A teacher with the adapters switched off gives a different loss (asserted: the fixture tells them apart)."""
+    import forward_fixture_util as U
+    from oracle import reference_cpu as O
+    cfg, sd, batch, enc, exp = load_lora_forward_fixture("kl_lora_forward_reference")
+    kl = {"temperature": exp["meta"]["kl_temperature"], "eot_loss_weight": exp["meta"]["eot_loss_weight"]}
+    oracle = O.OracleModel(cfg, sd)
+    out = oracle.forward(audio_values=torch.zeros(len(enc), 80, 3000), tower_output=enc, **batch, **U.alt_batch(), kl=kl)
+    assert abs(out["loss"].item() - exp["loss"]) < 1e-6
+    out["loss"].backward()
+    for k, g in exp["grads"].items():
+        np.testing.assert_allclose(oracle.sd[k].grad.numpy(), g.numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
+    plain_teacher = O.llama_ref(oracle.sd, cfg, oracle.embed(U.alt_batch()["alt_input_ids"]), U.alt_batch()["alt_attention_mask"])
+    wrong = O.kl_loss_ref(out["logits"].detach(), batch["labels"], plain_teacher.detach(), U.alt_batch()["alt_labels"],
+                          kl["temperature"], kl["eot_loss_weight"])
+    assert abs(wrong.item() - exp["loss"]) > 1e-4

@@ -121,7 +121,7 @@ class TextConfig:
     head_dim: Optional[int] = None
     vocab_size: Optional[int] = None
     rms_norm_eps: Optional[float] = None
-    rope_theta: float = 10000.0
+    rope_theta: Optional[float] = None          # None = the family's default (llama / gemma / qwen: 1e4, gemma3: 1e6)
     rope_scaling: Optional[Dict[str, Any]] = None
     max_position_embeddings: Optional[int] = None
     initializer_range: float = 0.02
@@ -139,22 +139,23 @@ class TextConfig:
     _FAMILY_DEFAULTS = {
         "llama": dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
                       vocab_size=32000, rms_norm_eps=1e-6, max_position_embeddings=2048, eos_token_id=2,
-                      tie_word_embeddings=False),
+                      tie_word_embeddings=False, rope_theta=10000.0),
         "gemma": dict(hidden_size=3072, intermediate_size=24576, num_hidden_layers=28, num_attention_heads=16,
                       num_key_value_heads=16, head_dim=256, vocab_size=256000, rms_norm_eps=1e-6,
-                      max_position_embeddings=8192, eos_token_id=1, tie_word_embeddings=True),
+                      max_position_embeddings=8192, eos_token_id=1, tie_word_embeddings=True, rope_theta=10000.0),
         # [3P] transformers Qwen2Config / Qwen3Config defaults
         "qwen2": dict(hidden_size=4096, intermediate_size=22016, num_hidden_layers=32, num_attention_heads=32,
                       num_key_value_heads=32, vocab_size=151936, rms_norm_eps=1e-6, max_position_embeddings=32768,
-                      tie_word_embeddings=False),
+                      tie_word_embeddings=False, rope_theta=10000.0),
         "qwen3": dict(hidden_size=4096, intermediate_size=22016, num_hidden_layers=32, num_attention_heads=32,
                       num_key_value_heads=32, head_dim=128, vocab_size=151936, rms_norm_eps=1e-6,
-                      max_position_embeddings=32768, tie_word_embeddings=False),
+                      max_position_embeddings=32768, tie_word_embeddings=False, rope_theta=10000.0),
         # [3P] Gemma3TextConfig defaults (the 4B text stack); google/gemma-3-27b-it is a preset
         "gemma3": dict(hidden_size=2304, intermediate_size=9216, num_hidden_layers=26, num_attention_heads=8, num_key_value_heads=4,
                        head_dim=256, vocab_size=262208, rms_norm_eps=1e-6, max_position_embeddings=131072, eos_token_id=1,
                        tie_word_embeddings=True, query_pre_attn_scalar=256, sliding_window=4096, sliding_window_pattern=6,
-                       rope_local_base_freq=10000.0),
+                       rope_local_base_freq=10000.0, rope_theta=1000000.0),     # Gemma3TextConfig: 1e6 (the published
+                       # google/gemma-3-27b-it config.json leaves the field out)
     }
     FAMILIES = ("llama", "gemma", "qwen2", "qwen3", "gemma3")
 

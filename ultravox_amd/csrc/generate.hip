@@ -441,10 +441,12 @@ extern "C" size_t uvx_llm_prefill_chunk_ws_bytes(const uvx_config_t* cfg, int32_
 // kernel over the whole [B, cur_len + Tn] key range with the query blocks of the prefix skipped (AttnDesc::q_begin): K / V
 // of the prefix are gathered from the cache into the kernel's row layout (a few MB per layer against the GBs of weights
 // the layer streams), the new rows are appended to the cache first so one gather serves both.
-extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
-                                         int32_t B, int32_t Tn, void* kv_cache, int32_t Tmax, int32_t cur_len,
-                                         const int32_t* positions0, const int32_t* kv_start, void* logits_last, void* workspace,
-                                         size_t ws_bytes) {
+// `all_rows`: logits of every new position [B, Tn, vocab] (what HF's forward returns for a cached call without logits_to_keep,
+// ultravox_model.py:328-334) instead of the last one [B, vocab].
+static int32_t prefill_chunk_impl(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                                  int32_t B, int32_t Tn, void* kv_cache, int32_t Tmax, int32_t cur_len,
+                                  const int32_t* positions0, const int32_t* kv_start, void* logits_last, void* workspace,
+                                  size_t ws_bytes, bool all_rows) {
   UVX_CHECK(cfg && w && inputs_embeds && kv_cache && positions0 && logits_last && workspace, UVX_ERR_INVALID,
             "llm_prefill_chunk: null argument");
   const uvx_config_t& c = *cfg;
@@ -498,10 +500,29 @@ extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, 
     RC(attn_out(st, c, L, s, M, s.o, s.OD, s.x, s.x2));
     RC(mlp_block(st, c, L, s, M, s.x2, s.x));
   }
+  if (all_rows) {      // final norm and LM head on the B * Tn new rows (x2 is free after the last layer)
+    RC(rmsnorm_fwd(st, dt, s.x, w->norm, s.x2, nullptr, M, D, c.rms_eps, c.llm_flavor));
+    return gemm(st, dt, lin(s.x2, w->lm_head, logits_last, M, c.vocab, D));
+  }
   UVX_HIP(hipMemcpy2DAsync(s.last, (size_t)D * es, at(s.x, (size_t)(Tn - 1) * D, dt), (size_t)Tn * D * es, (size_t)D * es, B,
                            hipMemcpyDeviceToDevice, st));
   RC(rmsnorm_fwd(st, dt, s.last, w->norm, s.hn, nullptr, B, D, c.rms_eps, c.llm_flavor));
   return gemm(st, dt, lin(s.hn, w->lm_head, logits_last, B, c.vocab, D));
+}
+
+extern "C" int32_t uvx_llm_prefill_chunk(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                                         int32_t B, int32_t Tn, void* kv_cache, int32_t Tmax, int32_t cur_len,
+                                         const int32_t* positions0, const int32_t* kv_start, void* logits_last, void* workspace,
+                                         size_t ws_bytes) {
+  return prefill_chunk_impl(stream, cfg, w, inputs_embeds, B, Tn, kv_cache, Tmax, cur_len, positions0, kv_start, logits_last, workspace,
+                            ws_bytes, false);
+}
+extern "C" int32_t uvx_llm_prefill_chunk_logits(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
+                                                int32_t B, int32_t Tn, void* kv_cache, int32_t Tmax, int32_t cur_len,
+                                                const int32_t* positions0, const int32_t* kv_start, void* logits_all, void* workspace,
+                                                size_t ws_bytes) {
+  return prefill_chunk_impl(stream, cfg, w, inputs_embeds, B, Tn, kv_cache, Tmax, cur_len, positions0, kv_start, logits_all, workspace,
+                            ws_bytes, true);
 }
 
 extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* token_embeds,

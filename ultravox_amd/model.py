@@ -747,9 +747,9 @@ class UltravoxModel:
                             audio_batch_size, labels, attention_mask, logits_to_keep) -> CausalLMOutputWithPast:
         """forward(..., past_key_values=KVState) - what the reference forwards to the language model (ultravox_model.py:328-334)
         and HF's generation loop calls every step: `input_ids` / `inputs_embeds` hold only the NEW positions (HF's contract for
-        a cache handed to forward), their keys / values are appended to the cache (uvx_llm_prefill_chunk) and the logits of
-        the last new position come back as [B, 1, V] - HF's `logits_to_keep=1`, what its generate() asks for; one new token
-        (the decode step) needs no flag.  The returned `past_key_values` is the extended state (the one handed in is consumed,
+        a cache handed to forward), their keys / values are appended to the cache (uvx_llm_prefill_chunk*) and the logits of
+        EVERY new position come back, [B, Tn, V], as from the HF language model; with `logits_to_keep=1` (what HF's generate()
+        asks for) only the last position's, [B, 1, V].  The returned `past_key_values` is the extended state (the one handed in is consumed,
         as HF's in-place caches are)."""
         if not isinstance(past, KVState):
             raise TypeError("past_key_values must be a KVState (generate(return_dict_in_generate=True).past_key_values)")
@@ -767,9 +767,11 @@ class UltravoxModel:
         B, Tn, D = inputs_embeds.shape
         if B != past.tokens.shape[0]:
             raise ValueError(f"batch size {B} does not match the cache ({past.tokens.shape[0]})")
-        if Tn > 1 and int(logits_to_keep or 0) != 1:
-            raise NotImplementedError("forward() with a KV cache returns the logits of the last new position only: pass "
-                                      "logits_to_keep=1 (as HF's generate does) or feed one token per call")
+        keep = int(logits_to_keep or 0)
+        if keep not in (0, 1) and keep < Tn:
+            raise NotImplementedError(f"logits_to_keep={keep}: 0 (every new position, HF's default) and 1 (the last one, what its "
+                                      "generate() asks for) are built")
+        all_rows = Tn > 1 and keep != 1
         if attention_mask is not None and not bool(torch.as_tensor(attention_mask)[:, -Tn:].to("cpu").bool().all()):
             raise ValueError("padding inside the new positions of a cached sequence is not supported")
         P, V = past.cur_len, self.config.vocab_size
@@ -786,23 +788,22 @@ class UltravoxModel:
             cache, Tmax = grown, new_T
         nb = l.uvx_llm_prefill_chunk_ws_bytes(C.byref(self._c), B, Tn, P)
         ws = self._workspace("infer", nb)
-        logits = torch.empty(B, V, device=dev, dtype=self.dtype)
+        logits = torch.empty((B, Tn, V) if all_rows else (B, 1, V), device=dev, dtype=self.dtype)
         pos0 = past.pos_next.to(torch.int32).contiguous()
-        check(l.uvx_llm_prefill_chunk(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), B, Tn,
-                                      ptr(cache), Tmax, P, ptr(pos0), ptr(past.kv_start), ptr(logits), ptr(ws), C.c_size_t(nb)),
-              "uvx_llm_prefill_chunk")
+        entry = l.uvx_llm_prefill_chunk_logits if all_rows else l.uvx_llm_prefill_chunk      # [B, Tn, V] / the last position's [B, V]
+        check(entry(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), B, Tn,
+                    ptr(cache), Tmax, P, ptr(pos0), ptr(past.kv_start), ptr(logits), ptr(ws), C.c_size_t(nb)),
+              "uvx_llm_prefill_chunk_logits" if all_rows else "uvx_llm_prefill_chunk")
         new_ids = (input_ids.to(dev) if input_ids is not None else torch.full((B, Tn), -1, device=dev, dtype=torch.int64))
         state = KVState(cache=cache, Tmax=Tmax, cur_len=P + Tn, pos_next=(pos0 + Tn).contiguous(), kv_start=past.kv_start,
                         tokens=torch.cat([past.tokens, new_ids.to(torch.int64)], dim=1), partial_ok=past.partial_ok)
-        return CausalLMOutputWithPast(loss=None, logits=logits[:, None, :], past_key_values=state)
+        return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=state)
 
     def _kl_forward(self, inputs_embeds, labels, attention_mask, alt_input_ids, alt_attention_mask, alt_labels,
                     return_logits) -> CausalLMOutputWithPast:
         """LossFunction.KL_Divergence (ultravox_model.py:335-345 -> _compute_kl_loss :200-256): a text-only teacher
         pass of the same frozen LLM over alt_input_ids (no_grad), then KL(teacher || student) at kl_temperature over
         the prediction positions plus eot_loss_weight x the end-of-turn positions."""
-        if self.text_lora_r > 0:
-            raise NotImplementedError("KL distillation with an LLM LoRA adapter is not built (the teacher pass would need the adapter disabled)")
         if labels is None:
             raise ValueError("labels must be provided")          # _get_prediction_mask, :178-179
         if alt_input_ids is None or alt_labels is None:
@@ -811,7 +812,9 @@ class UltravoxModel:
         dev = self.device
         V = self.config.vocab_size
         pair_row, pair_w, n_pred = kl_row_pairs(labels, alt_labels, self.loss_config.eot_loss_weight)
-        if self.dtype == torch.bfloat16 and not return_logits and n_pred > 0:
+        # (under text_model_lora_config the teacher is the SAME adapted model, adapters active, no_grad - `self.language_model.forward`,
+        #  ultravox_model.py:212-222 - so both passes go through uvx_llm_fwd_lora; the compact-rows entry points are frozen-LLM only)
+        if self.dtype == torch.bfloat16 and not return_logits and n_pred > 0 and self.text_lora_r == 0:
             return self._kl_forward_rows(inputs_embeds, attention_mask, alt_input_ids, alt_attention_mask, pair_row, pair_w)
         # teacher (its own workspace: the student's holds the activations for the backward pass)
         Bt, Tt = alt_input_ids.shape
@@ -822,8 +825,12 @@ class UltravoxModel:
         wst = self._workspace("llm_teacher", nbt)
         t_logits = self._workspace("teacher_logits", Bt * Tt * V * self.proj_flat.element_size()).view(self.dtype)[: Bt * Tt * V]
         am = None if alt_attention_mask is None else alt_attention_mask.to(device=dev, dtype=torch.int64).contiguous()
-        check(l.uvx_llm_fwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(alt_embeds.contiguous()), ptr(am), None,
-                            Bt, Tt, ptr(t_logits), None, 0, ptr(wst), C.c_size_t(nbt)), "uvx_llm_fwd")
+        if self.text_lora_r > 0:
+            check(l.uvx_llm_fwd_lora(stream_ptr(), C.byref(self._c), C.byref(self._lw), C.byref(self._tlora), ptr(alt_embeds.contiguous()),
+                                     ptr(am), None, Bt, Tt, ptr(t_logits), None, 0, ptr(wst), C.c_size_t(nbt)), "uvx_llm_fwd_lora")
+        else:
+            check(l.uvx_llm_fwd(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(alt_embeds.contiguous()), ptr(am), None,
+                                Bt, Tt, ptr(t_logits), None, 0, ptr(wst), C.c_size_t(nbt)), "uvx_llm_fwd")
         # student: activations kept for the backward pass; logits stay in the workspace
         out = self.language_model_forward(inputs_embeds, labels=None, attention_mask=attention_mask,
                                           want_logits=return_logits, save_for_bwd=True)
