@@ -61,10 +61,107 @@ WORKLOADS = {
     # on ONE 288 GB GPU - possible because the backward's transposed copies are streamed (uvx_config_t.llm_wt_stream), not resident
     "l70": dict(name="Llama-3.3-70B (frozen) + whisper-large-v3-turbo, bs=8x30s clips per GPU, adapter train",
                audio="openai/whisper-large-v3-turbo", text="meta-llama/Llama-3.3-70B-Instruct", B=8, seconds=30.0),
+    # BASELINE.json configs[3]: 70B INFERENCE, one replica per GPU (TP = 1; the reference's x8 is eight independent replicas = --gpus 8):
+    # `--workload c4` times generate() = encoder + projector + LLM prefill over 30 s audio + 128 text tokens, then `new_tokens` greedy
+    # decode steps; value = decoded tokens / s, roofline = weight bytes streamed per decoded token against HBM (run_inference below)
+    "c4": dict(name="Llama-3.3-70B (frozen, bf16) + whisper-medium, inference prefill+decode, TP=1 per replica",
+               audio="openai/whisper-medium", text="meta-llama/Llama-3.3-70B-Instruct", B=1, seconds=30.0, inference=True, new_tokens=32),
+    # the same loop on the C2 model (8B): a quick check of the inference path, not a BASELINE.json configuration
+    "c4s": dict(name="Llama-3-8B (frozen, bf16) + whisper-medium, inference prefill+decode",
+                audio="openai/whisper-medium", text="meta-llama/Meta-Llama-3-8B-Instruct", B=1, seconds=30.0, inference=True, new_tokens=32),
     # BASELINE.json configs[0] shapes (plumbing-sized), for quick checks
     "c1": dict(name="TinyLlama-1.1B + whisper-tiny, 1x4s clip, adapter train",
                audio="openai/whisper-tiny", text="TinyLlama/TinyLlama-1.1B-Chat-v1.0", B=1, seconds=4.0),
 }
+
+
+PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy, 7.0-7.1 TB/s non-temporal read stream)
+
+
+def llm_weight_bytes(cfg) -> float:
+    """bf16 bytes of the frozen LLM that ONE decode step streams: every layer's q|k|v, o, gate|up, down matrices + the LM head
+    (the embedding table is a gather of B rows; norms are negligible)."""
+    t = cfg.text_config
+    D, I, L, V = t.hidden_size, t.intermediate_size, t.num_hidden_layers, t.vocab_size
+    qkv = (t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim * D
+    o = t.num_attention_heads * t.head_dim * D
+    return 2.0 * (L * (qkv + o + 3 * D * I) + V * D)
+
+
+def run_inference(args, wl, dev) -> None:
+    """`--workload c4 / c4s`: a "step" = one generate() call (encoder + projector + prefill + new_tokens greedy decode steps) on B
+    prompts resident in HBM.  Prefill is also timed alone (max_new_tokens = 1) so that decode ms/token = (whole - prefill) / (new - 1).
+    N > 1 = N independent replicas (replicas only: no collective on this path); rank 0 reports N x its own rate (weak scaling)."""
+    from ultravox_amd import _lib
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.synthetic import synthetic_batch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.opt:
+        for item in args.opt.split(","):
+            k, v = item.split("=")
+            _lib.lib().uvx_set_option(int(k), int(v))
+    B, new = args.batch or wl["B"], wl["new_tokens"]
+    free_gb = torch.cuda.mem_get_info()[0] / 2 ** 30
+    need_gb = 170 if "70B" in wl["text"] else 40
+    if free_gb < need_gb:          # never drive the box out of memory
+        raise SystemExit(f"bench.py --workload {args.workload}: {free_gb:.0f} GiB free on the device, about {need_gb} GiB needed")
+    cfg = UltravoxConfig(audio_model_id=wl["audio"], text_model_id=wl["text"], hidden_size=4096, stack_factor=8,
+                         projector_ln_mid=True, torch_dtype="bfloat16")
+    model = UltravoxModel(cfg, device=str(dev), dtype=torch.bfloat16, seed=0, rope_len=1024, with_backward=False, consume_state_dict=True)
+    fe = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins, device=str(dev))
+    batch = synthetic_batch(cfg, B, wl["seconds"], n_text=128, audio_start=16, n_supervised=32, rank=rank)
+    pcm = batch.pop("pcm").to(dev)
+    batch.pop("labels")
+    gb = {k: v.to(dev) for k, v in batch.items()}
+    T = gb["input_ids"].shape[1]
+
+    def gen(n):
+        mel = fe.logmel_device(pcm)                       # K1 on device, inside the step
+        return model.generate(audio_values=mel, max_new_tokens=n, eos_token_id=-1, **gb)
+
+    def timed(n, reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = gen(n)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, out
+
+    for _ in range(max(1, args.warmup)):
+        gen(new)
+    if world > 1:
+        torch.distributed.barrier()
+    t_prefill, _ = timed(1, max(2, args.steps))
+    if world > 1:
+        torch.distributed.barrier()
+    t_all, out = timed(new, args.steps)
+    mine = torch.tensor([t_all], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(mine, op=torch.distributed.ReduceOp.MAX)
+    t_all_max = float(mine.item())
+    if rank != 0:
+        return
+    ms_tok = (t_all - t_prefill) / (new - 1) * 1e3
+    wbytes = llm_weight_bytes(cfg)
+    ach = wbytes / (ms_tok * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "decoded tokens/sec, prefill + decode (Whisper-med + Llama-3.3-70B inference)" if args.workload == "c4" else "decoded tokens/sec, prefill + decode",
+        "value": B * world * new / t_all_max, "unit": "tokens/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": t_all_max * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (seeded PCM + token ids; seeded random-init weights)",
+        "config": {"workload": wl["name"], "prompts_per_gpu": B, "clip_seconds": wl["seconds"], "text_tokens": 128, "prompt_len": T,
+                   "new_tokens": new, "parallelism": f"{world} independent replica(s), TP=1 (replicas only: no collective on this path)",
+                   "audio_model": wl["audio"], "text_model": wl["text"], "decoding": "greedy, KV cache, no early stop"},
+        "prefill_ms": t_prefill * 1e3, "decode_ms_per_token": ms_tok, "decode_tokens_per_sec": B * world / (ms_tok * 1e-3),
+        "resident_gib": torch.cuda.memory_allocated() / 2 ** 30,
+        "roofline": {"bound": "hbm", "kernel": "decode step: gemv_rows_bf16_k / gemm_skinny_bf16_k weight streaming (all layers + LM head)",
+                     "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                     "algorithmic_bytes_per_token": wbytes,
+                     "note": "achieved = LLM weight bytes / WHOLE decode step time (attention, norms, RoPE, sampling included in the time, not in the bytes)"},
+        "output_shape": list(out.shape)}))
 
 
 def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int = 32, top_rows: bool = True):
@@ -340,6 +437,12 @@ def main():
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    if WORKLOADS[args.workload].get("inference"):
+        run_inference(args, WORKLOADS[args.workload], dev)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     from ultravox_amd import _lib
     from ultravox_amd.config import UltravoxConfig

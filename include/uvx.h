@@ -75,8 +75,9 @@ typedef struct {
   int32_t llm_wt_stream;
   /* UVX_LLM_GEMMA3 (the reference's v0.6_config_gemma3_27b.yaml: the text stack of google/gemma-3-27b-it, [3P] modeling_gemma3.py):
    * llm_attn_scale = query_pre_attn_scalar ** -0.5 (0 = head_dim ** -0.5, every other family); llm_window = sliding_window of the
-   * layers flagged in uvx_llm_weights_t.layer_local - sequences (and caches) longer than it are refused, so those layers run as
-   * plain causal attention with their own rotary table. */
+   * layers flagged in uvx_llm_weights_t.layer_local (their own rotary table).  Sequences of at most llm_window positions run those layers
+   * as plain causal attention (incl. the fused backward); longer ones run the WINDOWED forms of the same kernels (a query sees the keys
+   * in (q - window, q]: forward, dQ + dK/dV pair, chunked prefill), and the decode steps clamp the first visible cache slot. */
   float llm_attn_scale;
   int32_t llm_window;
 } uvx_config_t;
@@ -393,7 +394,8 @@ int32_t uvx_gemm_force_variant(int32_t variant);
  * into the down-projection dgrad GEMM (0 = separate kernel, 1 = round 2's fragment-layout epilogue (measured neutral),
  * 2 = whole-line epilogue through the LDS stage (round 3)), key 3 = LM head / CE / head dgrad on the supervised
  * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
- * problems of at most 16 rows (the decode step; default 1), key 5 = the streamed weight transposes (llm_wt_stream) use plain instead of
+ * problems of at most 16 rows (the decode step; default 1: row-streaming kernel for M <= 4, MFMA mapping for 5..16; 2 = MFMA mapping for
+ * every M <= 16, the round-2 kernel, for A/B; 0 = the tiled kernels), key 5 = the streamed weight transposes (llm_wt_stream) use plain instead of
  * non-temporal loads / stores (default 0), key 11 = number of LLM layer chains: the batch
  * is cut into that many slices whose layer chains run on as many streams (default 1 = one chain on the caller's stream, at most 4; which of 1 / 2 is
  * faster depends on the box: UltravoxTrainer.autotune_schedule times both; uvx_llm_fwd* / uvx_llm_bwd*: same kernels on the same rows, bit-identical results; the side streams are

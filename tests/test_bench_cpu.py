@@ -74,3 +74,16 @@ def test_ranks_synthesise_distinct_shards():
     again = synthetic_batch(cfg, 2, 1.0, n_text=16, audio_start=4, n_supervised=4, rank=2)
     assert torch.equal(again["pcm"], shards[2]["pcm"]) and torch.equal(again["input_ids"], shards[2]["input_ids"])
     assert all(s["input_ids"].shape == shards[0]["input_ids"].shape for s in shards)        # weak scaling: same shapes per rank
+
+
+def test_decode_roofline_numerator_is_the_llm_weight_stream():
+    """`bench.py --workload c4`: bytes one decode step must stream = every layer's q|k|v, o, gate|up, down + the LM head in bf16
+    (Llama-3.3-70B: 69.5 B parameters -> 139 GB; at 8 TB/s a 17.4 ms floor per token)."""
+    import bench
+    from ultravox_amd.config import UltravoxConfig
+    wl = bench.WORKLOADS["c4"]
+    assert wl["inference"] and wl["B"] == 1 and wl["new_tokens"] == 32
+    cfg = UltravoxConfig(audio_model_id=wl["audio"], text_model_id=wl["text"], hidden_size=4096, stack_factor=8, projector_ln_mid=True)
+    b = bench.llm_weight_bytes(cfg)
+    assert abs(b - 2 * (80 * ((64 + 16) * 128 * 8192 + 8192 * 8192 + 3 * 8192 * 28672) + 128256 * 8192)) < 1
+    assert 138e9 < b < 140e9

@@ -7,7 +7,7 @@ and the same inputs.  Bars (round 4: 1.5 x what round 3 recorded at this depth, 
 loss within 0.2 %, encoder output <= 1.5e-2 (C3 1.8e-2), audio embeddings <= 2.2e-2 (C3 2.5e-2), argmax agreement on the supervised
 rows >= 0.9 (C2; 0.85 elsewhere: 32 rows, one row = 3 %).  CALIBRATION at this depth: the same restatement run by torch-ROCm in
 bf16 ON THE GPU (flash-rounded attention) is the second opinion - the HIP path's distance to the f32 oracle must be <= 1.25 x torch's
-own bf16 distance to it, for logits, audio embeddings and every projector gradient.  Per-stage errors are recorded to
+own bf16 distance to it, for the tower output, logits, audio embeddings and every projector gradient (C5: 1.5 x, see below).  Per-stage errors are recorded to
 gpurun_out/parity/ (committed as profiles/rNN_parity/*_full_depth.json).  Needs ~45 GB of host memory for the f32 oracle weights:
 skipped below 48 GB.
 
@@ -28,7 +28,7 @@ DEV = "cuda"
 BARS = {
     "c2": dict(encoder_out=1.5e-2, audio_embeds=2.2e-2, logits=2.8e-2, grads=3.6e-2, loss=2e-3, argmax=0.9),
     "c3": dict(encoder_out=1.8e-2, audio_embeds=2.5e-2, logits=3.2e-2, grads=3.6e-2, loss=2e-3, argmax=0.85),
-    "c5": dict(encoder_out=2.0e-2, audio_embeds=2.5e-2, logits=3.2e-2, grads=4.5e-2, loss=3e-3, argmax=0.85),
+    "c5": dict(encoder_out=2.2e-2, audio_embeds=3.4e-2, logits=4.2e-2, grads=7.3e-2, loss=2e-3, argmax=0.9),
 }
 
 
@@ -106,14 +106,15 @@ def test_full_depth_train_step_matches_oracle(workload):
     # ---- second opinion: the same restatement in torch-ROCm bf16 on the GPU (flash-rounded attention), whole step ----
     t0 = time.perf_counter()
     with torch.device(DEV), fused_attention():
-        # (C5: the conv tower of the second opinion would go through MIOpen's first-use kernel search on a fresh box; it gets the
-        #  f32 oracle's tower output instead, so its calibration covers the projector and the Gemma stack)
-        r16 = second.forward(audio_values=vals.bfloat16(), tower_output=tower_ref.to(DEV, torch.bfloat16) if w2v else None, **gb)
+        r16 = second.forward(audio_values=vals.bfloat16(), **gb)      # its own tower (C5: conv feature encoder through MIOpen)
         r16["loss"].backward()
+        with torch.no_grad():
+            tower16, _ = second.audio_embeds(vals.bfloat16(), None if w2v else gb["audio_lens"])
     torch.cuda.synchronize()
     rec["torch_bf16_gpu_step_s"] = time.perf_counter() - t0
     cal = {"logits": (out.logits, r16["logits"].detach().cpu(), ref["logits"].detach()),
            "audio_embeds": (emb[:, :Na], r16["audio_embeds"].detach()[:, :Na].cpu(), ref["audio_embeds"].detach()[:, :Na])}
+    cal["encoder_out"] = (tower, tower16.cpu(), tower_ref)
     cal.update({"grad." + k.split(".", 1)[1]: (mine[k], second.sd[k].grad.cpu(), g) for k, g in grads.items()})
     rec["calibration"] = {k: {"hip_vs_f32": rel_l2(h, f), "torch_bf16_vs_f32": rel_l2(t16, f), "hip_vs_torch_bf16": rel_l2(h, t16)}
                           for k, (h, t16, f) in cal.items()}
@@ -129,9 +130,13 @@ def test_full_depth_train_step_matches_oracle(workload):
     for k, e in rec["grads_rel_l2"].items():
         assert e < bars["grads"], (k, e)
     assert agree >= bars["argmax"], (agree, rec["argmax_agreement_all_rows"])
+    # C5: 1.5 instead of 1.25 - measured 1.15-1.24 (profiles/r04_parity/c5_full_depth.json): the wav2vec2 conv stem runs as im2col
+    # GEMMs with a bf16 rounding per layer where torch goes through MIOpen, whose algorithm choice (and with it torch's own distance)
+    # may differ from box to box; the Gemma stack alone is calibrated at 1.00 (profiles/r04_parity/c5_text_only_calibration_probe.txt)
+    factor = 1.5 if w2v else 1.25
     for k, v in rec["calibration"].items():
         if k != "loss":
-            assert v["hip_vs_f32"] <= 1.25 * v["torch_bf16_vs_f32"] + 1e-4, (k, v)
+            assert v["hip_vs_f32"] <= factor * v["torch_bf16_vs_f32"] + 1e-4, (k, v)
 
 
 def test_c2_width_f32_mode_logits_within_1e3():

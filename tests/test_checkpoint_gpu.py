@@ -190,11 +190,13 @@ def test_tower_keys_carried_by_a_checkpoint_are_re_saved(tmp_path):
     m.save_pretrained(str(tmp_path / "again"))
     _, again = checkpoint.load_pretrained(str(tmp_path / "again"))
     assert set(again) == set(carried) and all(torch.equal(again[k], carried[k]) for k in carried)
-    # a keep_param with no tensor behind it (reference-style code adds names by hand, ultravox_model.py:59): reported and left
-    # out of the save rather than aborting it; strict=True raises
+    # a keep_param with no tensor behind it (reference-style code adds names by hand, ultravox_model.py:59): the save is refused
+    # (a checkpoint must not lose tensors silently); strict=False reports it and leaves the key out
     m.keep_params.add("audio_tower.layers.1.fc2.weight")
+    with pytest.raises(KeyError, match="cannot re-save"):
+        m.save_pretrained(str(tmp_path / "refused"))
     with pytest.warns(UserWarning, match="cannot re-save"):
-        m.save_pretrained(str(tmp_path / "partial"))
+        m.save_pretrained(str(tmp_path / "partial"), strict=False)
     _, partial = checkpoint.load_pretrained(str(tmp_path / "partial"))
     assert set(partial) == set(carried)
     with pytest.raises(KeyError, match="cannot re-save"):

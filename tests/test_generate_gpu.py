@@ -303,3 +303,36 @@ def test_forward_with_past_key_values_drives_a_decode_loop(dtype):
         assert torch.equal(out3.logits[:, 0].float().argmax(-1).cpu(), want[:, T + 3])
     with pytest.raises(ValueError, match="inference call"):
         model.forward(input_ids=seq[:, -1:], past_key_values=state, labels=seq[:, -1:])
+
+
+@pytest.mark.parametrize("heads,kv_heads,head_dim,T", [(8, 1, 128, 1400), (8, 2, 64, 700), (4, 4, 128, 300)])
+def test_bf16_decode_attention_over_long_caches_and_group_sizes(heads, kv_heads, head_dim, T):
+    """The grouped decode-attention kernel (one block of 1024 threads per sequence and KV head; scores in dynamic LDS next to ~36 KB of
+    static LDS) at the edges of its launch conditions: 8 query heads per KV head over 1400 cached keys (45 KB of scores), head_dim 64,
+    no grouping; left padding in one row.  Decode logits against the teacher-forced forward of the same model."""
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    cfg = UltravoxConfig(
+        audio_config=dict(d_model=128, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=256),
+        text_config=dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=heads,
+                         num_key_value_heads=kv_heads, head_dim=head_dim, vocab_size=512, eos_token_id=2, max_position_embeddings=4096),
+        hidden_size=256, projector_ln_mid=True)
+    model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=5, rope_len=2048)
+    torch.manual_seed(9)
+    B = 2
+    ids = torch.randint(3, 512, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, :37] = 0
+    ids[am == 0] = 2
+    new = 5
+    seq = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=new, eos_token_id=-1)
+    am_full = torch.cat([am, torch.ones(B, new, dtype=torch.long)], 1).to(DEV)
+    tf = model.forward(input_ids=seq, attention_mask=am_full).logits.float()
+    # step by step through the cache: the logits that produced each new token
+    first = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=1, eos_token_id=-1, return_dict_in_generate=True)
+    state = first.past_key_values
+    for step in range(new - 1):
+        out = model.forward(input_ids=seq[:, T + step:T + step + 1], past_key_values=state)
+        state = out.past_key_values
+        got, want = out.logits[:, 0].float(), tf[:, T + step]
+        assert rel_l2(got, want) < 3e-2, (step, rel_l2(got, want))

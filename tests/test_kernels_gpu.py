@@ -490,10 +490,12 @@ def test_gemm_fused_swiglu_epilogues_match_unfused_path(M, I, K):
     assert torch.equal(dgu, dgu_ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 6144, 4096), (5, 100, 64), (16, 1028, 14336), (3, 32, 128)])
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 6144, 4096), (5, 100, 64), (16, 1028, 14336), (3, 32, 128),
+                                   (2, 8192, 28672), (4, 4096, 14336), (1, 57344, 8192), (3, 96, 576), (7, 96, 576), (9, 64, 1024)])
 def test_gemm_few_rows_weight_streaming_kernel(M, N, K):
-    """M <= 16 (the decode step) runs the weight-streaming kernel (csrc/gemm_skinny.hip): against torch and against the
-    tiled kernels (option 4 off) with every epilogue the decode path uses."""
+    """M <= 16 (the decode step) runs the weight-streaming kernels (csrc/gemm_skinny.hip: the row-streaming kernel for M <= 4, the
+    MFMA mapping for 5..16): against torch, against the tiled kernels (option 4 off) and against each other (option 4 = 2) with every
+    epilogue the decode path uses; K that is not a multiple of the 512-element step, ragged N, the 70B shapes."""
     from ultravox_amd import _lib
     g = torch.Generator(device=DEV).manual_seed(11)
     a = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
@@ -511,6 +513,11 @@ def test_gemm_few_rows_weight_streaming_kernel(M, N, K):
     ref = F.gelu((a.float() @ b.float().t() + bias.float()).bfloat16().float()).bfloat16().float() + resid.float()
     assert rel_l2(out, ref) < 5e-3 and rel_l2(out, tiled) < 5e-3
     assert rel_l2(ops().gemm(a, b), plain_tiled) < 3e-3
+    L.uvx_set_option(4, 2)          # the MFMA mapping for every M <= 16
+    try:
+        assert rel_l2(out, ops().gemm(a, b, bias=bias, residual=resid, act="gelu")) < 5e-3
+    finally:
+        L.uvx_set_option(4, 1)
     if N % 32 == 0:     # fused SwiGLU epilogue (interleaved gate / up packing)
         act = torch.empty(M, N // 2, device=DEV, dtype=torch.bfloat16)
         gu = ops().gemm(a, b, epilogue=1, c2=act)

@@ -57,6 +57,24 @@ for (M, N, K) in shapes:
     print(f"{M} x {N} x {K}: {tiles} tiles, main {main_panels} panels ({main_panels * tm} tiles), tail {tail_n} columns ({tail_tiles} tiles)", flush=True)
     t_whole = run(whole)
     print(f"  whole                      {t_whole:8.1f} us  {2.0 * M * N * K / t_whole / 1e6:7.1f} TF/s", flush=True)
+    # the trailing panels as a second plain launch with a smaller tile (what gemm_nt's tail split does when its cost model agrees)
+    L.uvx_gemm_force_variant(-2)          # automatic variant, the library's own tail split off: the arms below split by hand
+    for tv in (0, 34, 33, 31):
+        def main2(w):
+            d = desc(a, w, out, M, n_main, K)
+            check(L.uvx_gemm(stream_ptr(), BF, C.byref(d)), "uvx_gemm")
+
+        def tail2(w):
+            L.uvx_gemm_force_variant(tv)
+            d = desc(a, w[n_main:], out[:, n_main:], M, tail_n, K)
+            check(L.uvx_gemm(stream_ptr(), BF, C.byref(d)), "uvx_gemm")
+            L.uvx_gemm_force_variant(-2)
+
+        def both(w):
+            main2(w); tail2(w)
+
+        t_both, t_tail = run(both), run(tail2)
+        print(f"  main + tail via variant {tv:2d}   {t_both:8.1f} us  {2.0 * M * N * K / t_both / 1e6:7.1f} TF/s   tail alone {t_tail:6.1f}", flush=True)
     for s in (2, 4, 8):
         if (K // 64) % s or tail_tiles * s > 320:
             continue
@@ -84,4 +102,5 @@ for (M, N, K) in shapes:
         t_split, t_main, t_tail, t_red = run(split), run(main), run(tail), run(reduce)
         print(f"  split-K {s} tail ({tail_tiles * s:3d} blocks) {t_split:8.1f} us  {2.0 * M * N * K / t_split / 1e6:7.1f} TF/s   "
               f"main {t_main:7.1f}  tail {t_tail:6.1f}  reduce(torch) {t_red:5.1f}   rel-L2 vs whole {err:.1e}", flush=True)
+    L.uvx_gemm_force_variant(-1)
     del ws

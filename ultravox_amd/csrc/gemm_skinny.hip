@@ -35,14 +35,19 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
   f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
   const int nchunk = p.K / 32;
-  int i = w;
+  // Which k32 chunks a wave takes.  Round 4: contiguous SPANS (wave w: chunks [w * n/8, (w + 1) * n/8)) instead of the interleave
+  // w, w + 8, ...: every wave then walks its 16 rows front to back, which streams at 6.0 instead of 4.9 TB/s on the 70B gate|up
+  // matrix (profiles/r04_hbm_stream_patterns.txt, patterns 4 / 1).  The interleave remains for K that does not split evenly.
+  const bool span = nchunk % 8 == 0;
+  const int stride = span ? 1 : 8, end = span ? (w + 1) * (nchunk / 8) : nchunk;
+  int i = span ? w * (nchunk / 8) : w;
   // UN chunks per iteration: 2-3 x UN independent 16-byte loads in flight per lane (the kernel lives on memory-level parallelism)
   constexpr int UN = TILES == 2 ? 4 : 8;
-  for (; i + 8 * (UN - 1) < nchunk; i += 8 * UN) {
+  for (; i + stride * (UN - 1) < end; i += stride * UN) {
     bf16x8_t x[UN], u[UN], v[UN];
 #pragma unroll
     for (int t = 0; t < UN; ++t) {
-      const int kk = (i + 8 * t) * 32;
+      const int kk = (i + stride * t) * 32;
       u[t] = *reinterpret_cast<const bf16x8_t*>(b0 + kk);
       if (TILES == 2) v[t] = *reinterpret_cast<const bf16x8_t*>(b1 + kk);
       x[t] = *reinterpret_cast<const bf16x8_t*>(a0 + kk);
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
       if (TILES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v[t], xx, acc1, 0, 0, 0);
     }
   }
-  for (; i < nchunk; i += 8) {
+  for (; i < end; i += stride) {
     const int kk = i * 32;
     const bf16x8_t u = *reinterpret_cast<const bf16x8_t*>(b0 + kk);
     bf16x8_t v = zero;
@@ -122,6 +127,105 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
   }
 }
 
+
+// ---- round 4: row-streaming kernel for M <= 4 (the decode step at batch 1..4) ----
+// The MFMA mapping above reads 16 weight rows x 64 bytes per wave instruction (row stride K * 2 bytes): on Llama-3.3-70B's
+// gate|up matrix (940 MB) that pattern streams at 4.8 TB/s, while the same bytes read as whole rows - 1 KiB contiguous per wave
+// instruction, non-temporal - stream at 6.5-7.1 TB/s (tools/probes/hbm_stream_probe.hip, profiles/r04_hbm_stream_patterns.txt).
+// Here a block of 8 waves owns RB consecutive weight rows and walks them R at a time; for each row the 8 waves together read
+// 8 KiB contiguous per step (wave w takes the 512-element steps w, w + 8, ...), so a block streams its RB x K region front to back.
+// A lane holds 8 consecutive k of a row; the matching 8 k of each of the M activation rows come from L1 / L2 (M x K x 2 bytes
+// in all, re-read per R rows); products are exact (bf16 x bf16 in f32), accumulation f32 (v_dot2c_f32_bf16), lanes and waves are
+// folded in a fixed order.  Epilogue arithmetic and rounding points as the kernel above.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// (the components are copied to scalars first: __builtin_bit_cast applied directly to a vector-element lvalue - bit_cast(a.y) -
+//  reads element 0 for every component under hipcc 7.2, which also shrinks the 16-byte loads to 4 bytes)
+__device__ __forceinline__ float dot2(unsigned a, unsigned b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+__device__ __forceinline__ float dot8(const u32x4_t a, const u32x4_t b, float c) {
+  const unsigned a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+  return dot2(a3, b3, dot2(a2, b2, dot2(a1, b1, dot2(a0, b0, c))));
+}
+
+template <int MB /*activation rows served: 1, 2, 4*/, int R /*weight rows in flight per wave*/, int RB /*weight rows per block: 16 or 32*/>
+__global__ __launch_bounds__(512) void gemv_rows_bf16_k(SkinnyArgs p) {
+  __shared__ float part[8][RB][MB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * RB;
+  const int nsteps = (p.K + 511) / 512;
+  const u32x4_t zero = {0u, 0u, 0u, 0u};
+  const bf16_t* arow[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) arow[m] = p.A + (long long)min(m, p.M - 1) * p.lda + lane * 8;
+  for (int rb = 0; rb < RB; rb += R) {
+    float acc[R][MB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+    const bf16_t* brow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) brow[r] = p.B + (long long)min(n0 + rb + r, p.N - 1) * p.ldb + lane * 8;
+    // two k-steps per trip: 2 R weight loads (HBM, non-temporal) + 2 MB activation loads (cache) in flight per lane
+    for (int j = w; j < nsteps; j += 16) {
+      const int k0 = j * 512, k1 = (j + 8) * 512;
+      const bool ok0 = k0 + lane * 8 < p.K, ok1 = j + 8 < nsteps && k1 + lane * 8 < p.K;
+      u32x4_t wv0[R], wv1[R], xv0[MB], xv1[MB];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        wv0[r] = ok0 ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(brow[r] + k0)) : zero;
+        wv1[r] = ok1 ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(brow[r] + k1)) : zero;
+      }
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        xv0[m] = ok0 ? *reinterpret_cast<const u32x4_t*>(arow[m] + k0) : zero;
+        xv1[m] = ok1 ? *reinterpret_cast<const u32x4_t*>(arow[m] + k1) : zero;
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[r][m] = dot8(wv1[r], xv1[m], dot8(wv0[r], xv0[m], acc[r][m]));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const float t = wave_sum(acc[r][m]);
+        if (lane == 0) part[w][rb + r][m] = t;
+      }
+  }
+  __syncthreads();
+  // ---- epilogue (one thread per output element; the sums over the waves in a fixed order) ----
+  const int t = threadIdx.x;
+  if (p.swiglu) {      // RB = 32: rows 0..15 = gate block, 16..31 = the matching up block (interleaved packing, weights.py)
+    const int m = t / 16, c = t % 16;
+    if (m >= p.M || m >= MB || n0 + c >= p.N) return;
+    float g = 0.f, u = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) { g += part[ww][c][m]; u += part[ww][16 + c][m]; }
+    const bf16_t og = f2bf(g * p.alpha), ou = f2bf(u * p.alpha);
+    const float gf = bf2f(og);
+    bf16_t* crow = p.C + (long long)m * p.ldc + n0;
+    crow[c] = og;
+    crow[16 + c] = ou;
+    p.C2[(long long)m * p.ldc2 + n0 / 2 + c] = f2bf(bf2f(f2bf(gf / (1.0f + __expf(-gf)))) * bf2f(ou));
+    return;
+  }
+  const int m = t / RB, c = t % RB, n = n0 + c;
+  if (m >= p.M || m >= MB || n >= p.N) return;
+  float v = 0.f;
+#pragma unroll
+  for (int ww = 0; ww < 8; ++ww) v += part[ww][c][m];
+  v = v * p.alpha + (p.bias ? bf2f(p.bias[n]) : 0.f);
+  v = bf2f(f2bf(v));
+  if (p.act == 1) v = bf2f(f2bf(gelu_fast(v)));
+  if (p.residual) v += bf2f(p.residual[(long long)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr + n]);
+  p.C[(long long)m * p.ldc + n] = f2bf(v);
+}
+
 }  // namespace
 
 namespace uvx {
@@ -141,6 +245,19 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 + (double)d.M * d.N * 2.0);
   if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, 1, 200);
+  // M <= 8: the row-streaming kernel (option 4 = 2 keeps the MFMA mapping for every M: same-box A/B)
+  // (M = 5..8 would need 8 activation vectors per weight vector from L1 - measured slower than the MFMA mapping at M = 8: 53 vs 36 ms per
+  //  70B token - so the row-streaming kernel serves M <= 4)
+  if (d.M <= 4 && uvx::g_options[4] != 2 && d.K % 8 == 0 && (!d.swiglu || d.N % 32 == 0)) {
+    const bool rb32 = d.swiglu || d.N >= 16384;
+    const dim3 grid(rb32 ? (d.N + 31) / 32 : (d.N + 15) / 16);
+#define UVX_GEMV(MB) do { if (rb32) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 32>), grid, dim3(512), 0, st, a); \
+                          else hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 16>), grid, dim3(512), 0, st, a); } while (0)
+    if (d.M == 1) UVX_GEMV(1); else if (d.M == 2) UVX_GEMV(2); else UVX_GEMV(4);
+#undef UVX_GEMV
+    UVX_LAUNCH_CHECK();
+    return UVX_OK;
+  }
   if (d.swiglu || d.N >= 16384) hipLaunchKernelGGL(gemm_skinny_bf16_k<2>, dim3((d.N + 31) / 32), dim3(512), 0, st, a);
   else hipLaunchKernelGGL(gemm_skinny_bf16_k<1>, dim3((d.N + 15) / 16), dim3(512), 0, st, a);
   UVX_LAUNCH_CHECK();

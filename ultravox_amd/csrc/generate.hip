@@ -141,50 +141,65 @@ __global__ void attn_decode_k(const T* __restrict__ qkv, const T* __restrict__ c
 }
 
 // One block per (sequence, KV head): the G query heads that share the KV head are served together (K and V rows are read
-// once), the keys are spread over the block - thread = (key lane, 8-dim chunk) - instead of being walked serially by one
-// wave (255 us per layer at 320 keys; this: a few us).  Three phases: scores -> LDS, softmax statistics, P . V.
-// sc: dynamic LDS, G * len floats.  Probabilities are rounded to the storage type before P . V like the tiled kernels.
-template <typename T, int D, int G>
-__global__ __launch_bounds__(256) void attn_decode_grp_k(const T* __restrict__ qkv, const T* __restrict__ cache_k,
+// once from HBM / L2).  Round 4: 1024 threads (was 256: 55 us per layer at 332 keys on Llama-3.3-70B, 12 % of a decoded token -
+// a latency chain on 8 of 256 CUs, profiles/r04_decode70_kernel_stats.txt).
+//   phase 1  scores: thread = (key lane, 16-byte chunk of the head dimension), NTH / (D / 8) keys in flight per pass, the chunk
+//            partial sums of a key folded by shuffles -> LDS sc[g][key]
+//   phase 2  softmax statistics: one wave per query head; probabilities rounded to the storage type (as the tiled kernels do)
+//   phase 3  P . V: thread = (key residue class, query head, 8 output dimensions): 16-byte V loads, four keys in flight, the residue
+//            classes folded through LDS in a fixed order.
+// sc: dynamic LDS, G * len floats.
+template <typename T, int D, int G, int NTH>
+__global__ __launch_bounds__(NTH) void attn_decode_grp_k(const T* __restrict__ qkv, const T* __restrict__ cache_k,
                                                          const T* __restrict__ cache_v, T* __restrict__ out,
                                                          const int32_t* __restrict__ kv_start, int Hq, int Hkv, int Tmax,
                                                          int len, int QKV, float scale, int lo_clamp) {
   extern __shared__ float sc[];                 // [G][len]
   __shared__ float qs[G][D];
-  __shared__ float red[4][G][D];
-  __shared__ float stat[2][G];
+  __shared__ float red[NTH * 8];                // phase 3 partial sums: [residue class][query head][dimension]
+  __shared__ float stat[G];
   constexpr int CH = D / 8;                     // 16-byte chunks per row
-  constexpr int KL = 256 / CH;                  // keys in flight per pass
+  constexpr int KL = NTH / CH;                  // keys in flight per pass
+  constexpr int NW = NTH / 64;
+  constexpr int ITEMS = G * D / 8;              // (query head, 8-dimension chunk) pairs of the block
+  constexpr int KS = NTH / ITEMS;               // key residue classes in phase 3
+  static_assert(NTH % ITEMS == 0 && ITEMS <= NTH, "block size vs outputs");
   const int b = blockIdx.x / Hkv, hk = blockIdx.x % Hkv;
   const int tid = threadIdx.x, ch = tid % CH, kl = tid / CH, lane = tid & 63, w = tid >> 6;
   const int j0 = max(kv_start ? kv_start[b] : 0, lo_clamp);
   const int KVD = Hkv * D;
   const T* kbase = cache_k + (long long)b * Tmax * KVD + hk * D + ch * 8;
-  const T* vbase = cache_v + (long long)b * Tmax * KVD + hk * D + ch * 8;
-  for (int i = tid; i < G * D; i += 256) qs[i / D][i % D] = ldf<T>(qkv + (long long)b * QKV + (hk * G + i / D) * D + i % D);
+  const T* vbase = cache_v + (long long)b * Tmax * KVD + hk * D;
+  for (int i = tid; i < G * D; i += NTH) qs[i / D][i % D] = ldf<T>(qkv + (long long)b * QKV + (hk * G + i / D) * D + i % D);
   __syncthreads();
-  float q[G][8];
+  // ---- phase 1: scores (two passes of keys in flight per trip) ----
+  {
+    float q[G][8];
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) q[g][e] = qs[g][ch * 8 + e];
-  // ---- phase 1: scores ----
-  for (int j = j0 + kl; j < len; j += KL) {
-    float kv[8];
-    ld8<T>(kbase + (long long)j * KVD, kv);
+      for (int e = 0; e < 8; ++e) q[g][e] = qs[g][ch * 8 + e];
+    for (int j = j0 + kl; j < len; j += 2 * KL) {
+      float kv[2][8];
+      const bool two = j + KL < len;
+      ld8<T>(kbase + (long long)j * KVD, kv[0]);
+      ld8<T>(kbase + (long long)(two ? j + KL : j) * KVD, kv[1]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float s = 0.f;
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += q[g][e] * kv[e];
+        for (int g = 0; g < G; ++g) {
+          float s = 0.f;
 #pragma unroll
-      for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o, 64);      // the CH threads of a key are consecutive lanes
-      if (ch == 0) sc[g * len + j] = s * scale;
+          for (int e = 0; e < 8; ++e) s += q[g][e] * kv[u][e];
+#pragma unroll
+          for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o, 64);      // the CH threads of a key are consecutive lanes
+          if (ch == 0 && (u == 0 || two)) sc[g * len + j + u * KL] = s * scale;
+        }
     }
   }
   __syncthreads();
   // ---- phase 2: softmax statistics (one wave per head, heads round-robin) ----
-  for (int g = w; g < G; g += 4) {
+  for (int g = w; g < G; g += NW) {
     float m = -__builtin_huge_valf();
     for (int j = j0 + lane; j < len; j += 64) m = fmaxf(m, sc[g * len + j]);
     m = wave_max(m);
@@ -195,48 +210,62 @@ __global__ __launch_bounds__(256) void attn_decode_grp_k(const T* __restrict__ q
       l += p;
     }
     l = wave_sum(l);
-    if (lane == 0) stat[0][g] = l;
+    if (lane == 0) stat[g] = l;
   }
   __syncthreads();
   // ---- phase 3: P . V ----
-  float acc[G][8];
+  // thread = (key residue class `part`, query head g, 8 output dimensions): 16-byte V loads, four keys in flight per trip, KS classes
+  // walk the keys in parallel (the first version - one thread per (g, dimension) over ALL keys - was a chain of ~40 dependent
+  // load batches: 30 us per layer)
+  const int i = tid % ITEMS, part = tid / ITEMS;
+  const int g = (i * 8) / D, dd = (i * 8) % D;
+  const T* vp = vbase + dd;
+  const float* pg = sc + g * len;
+  float acc[8];
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  int j = j0 + part;
+  for (; j + 3 * KS < len; j += 4 * KS) {
+    float v[4][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-  for (int j = j0 + kl; j < len; j += KL) {
-    float vv[8];
-    ld8<T>(vbase + (long long)j * KVD, vv);
+    for (int u = 0; u < 4; ++u) ld8<T>(vp + (long long)(j + u * KS) * KVD, v[u]);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float p = sc[g * len + j];
+    for (int u = 0; u < 4; ++u) {
+      const float pj = pg[j + u * KS];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[g][e] += p * vv[e];
+      for (int e = 0; e < 8; ++e) acc[e] += pj * v[u][e];
     }
   }
-  // fold the key lanes: within a wave (64 / CH key lanes), then across the 4 waves through LDS
+  for (; j < len; j += KS) {
+    float v[8];
+    ld8<T>(vp + (long long)j * KVD, v);
+    const float pj = pg[j];
 #pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = acc[g][e];
-#pragma unroll
-      for (int o = CH; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-      acc[g][e] = v;
-    }
-  if (lane < CH) {
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) red[w][g][lane * 8 + e] = acc[g][e];
+    for (int e = 0; e < 8; ++e) acc[e] += pj * v[e];
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[(part * ITEMS + i) * 8 + e] = acc[e];
   __syncthreads();
-  for (int i = tid; i < G * D; i += 256) {
-    const int g = i / D, dd = i % D;
-    const float l = stat[0][g];
-    const float o = red[0][g][dd] + red[1][g][dd] + red[2][g][dd] + red[3][g][dd];
-    stf<T>(out + (long long)b * Hq * D + (hk * G + g) * D + dd, l > 0.f ? o / l : 0.f);
+  for (int o = tid; o < G * D; o += NTH) {       // fold the residue classes in a fixed order
+    float t = 0.f;
+    for (int q2 = 0; q2 < KS; ++q2) t += red[q2 * ITEMS * 8 + o];
+    const float l = stat[o / D];
+    stf<T>(out + (long long)b * Hq * D + hk * G * D + o, l > 0.f ? t / l : 0.f);
   }
+}
+
+// launch helper: static LDS (~36 KB) + the dynamic score array (<= 48 KB) exceed the 64 KB a launch gets by default
+template <int DD, int GG>
+int launch_decode_grp(hipStream_t st, size_t sh, int blocks, const bf16_t* qkv, const bf16_t* ck, const bf16_t* cv, bf16_t* o,
+                      const int32_t* kv_start, int Hq, int Hkv, int Tmax, int len, int QKV, float scale, int lo) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    UVX_HIP(hipFuncSetAttribute((const void*)attn_decode_grp_k<bf16_t, DD, GG, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_decode_grp_k<bf16_t, DD, GG, 1024>), dim3(blocks), dim3(1024), sh, st, qkv, ck, cv, o, kv_start, Hq, Hkv, Tmax, len,
+                     QKV, scale, lo);
+  return UVX_OK;
 }
 
 template <typename T>
@@ -558,7 +587,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
       hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
       const int G = Hq / Hkv, len = cur_len + 1;
       const size_t sh = sizeof(float) * (size_t)G * len;
-#define UVX_DEC(DD, GG) hipLaunchKernelGGL((attn_decode_grp_k<bf16_t, DD, GG>), dim3(B * Hkv), dim3(256), sh, st, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale, lo)
+#define UVX_DEC(DD, GG) RC((launch_decode_grp<DD, GG>(st, sh, B * Hkv, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale, lo)))
       if (sh <= 48 * 1024 && dh == 128 && G == 4) UVX_DEC(128, 4);
       else if (sh <= 48 * 1024 && dh == 128 && G == 8) UVX_DEC(128, 8);
       else if (sh <= 48 * 1024 && dh == 128 && G == 2) UVX_DEC(128, 2);

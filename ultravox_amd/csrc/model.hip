@@ -322,7 +322,7 @@ LlmWs llm_view(const LlmWs& w, const uvx_config_t& c, int b0, int nb, int T) {
   return v;
 }
 
-// Multi-stream schedule (tuning option 11 = number of chains, default 2): the batch is cut into slices whose layer chains are
+// Multi-stream schedule (tuning option 11 = number of chains, default 1 = one chain on the caller's stream): the batch is cut into slices whose layer chains are
 // independent (frozen LLM: no weight gradient couples them); they run on the caller's stream and on side streams.  Every kernel
 // of a chain depends on its predecessor, so on ONE stream the tail of each GEMM (a partly filled last round of tiles: 1120
 // tiles = 4.4 rounds of 256 CUs at N = 28672, 560 = 2.2 at N = 14336) and every HBM-bound elementwise kernel leave CUs
@@ -338,11 +338,25 @@ Fork* fork_for_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   Fork& f = forks[dev];
+  // One set of side streams / events per DEVICE, created once (under a lock: two host threads may make their first call together).
+  // The set is shared by every call on the device: calls that use it must be issued from one stream at a time (the trainer's
+  // usage); a partly failed creation is torn down so that a retry starts clean.
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   if (!f.ok) {
-    if (hipEventCreateWithFlags(&f.e_fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    for (int i = 0; i < 3; ++i)
-      if (hipStreamCreateWithFlags(&f.side[i], hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&f.e_join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    bool good = hipEventCreateWithFlags(&f.e_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 3 && good; ++i)
+      good = hipStreamCreateWithFlags(&f.side[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&f.e_join[i], hipEventDisableTiming) == hipSuccess;
+    if (!good) {
+      if (f.e_fork) (void)hipEventDestroy(f.e_fork);
+      for (int i = 0; i < 3; ++i) {
+        if (f.side[i]) (void)hipStreamDestroy(f.side[i]);
+        if (f.e_join[i]) (void)hipEventDestroy(f.e_join[i]);
+      }
+      f = Fork{};
+      return nullptr;
+    }
     f.ok = true;
   }
   return &f;
@@ -358,11 +372,20 @@ WtStream* wt_stream_for_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   WtStream& f = all[dev];
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   if (!f.ok) {
     hipEvent_t* ev[6] = {&f.e_start, &f.e_head, &f.e_ready[0], &f.e_ready[1], &f.e_free[0], &f.e_free[1]};
-    for (hipEvent_t* e : ev)
-      if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    bool good = true;
+    for (hipEvent_t* e : ev) good = good && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    good = good && hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess;
+    if (!good) {      // tear down what exists: a retry starts clean
+      for (hipEvent_t* e : ev)
+        if (*e) (void)hipEventDestroy(*e);
+      if (f.side) (void)hipStreamDestroy(f.side);
+      f = WtStream{};
+      return nullptr;
+    }
     f.ok = true;
   }
   return &f;

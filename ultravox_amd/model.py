@@ -347,8 +347,8 @@ class UltravoxModel:
         (`keep_params`, retained on the host by from_pretrained).  Deviation from the reference, stated: there `keep_params`
         may name ANY key of the module's state dict (ultravox_model.py:59, :565-584: the whole model lives in one nn.Module);
         here the frozen towers exist only as packed device weights, so a keep_param without a retained tensor cannot be
-        re-saved.  Such keys are reported with a warning and left out (the reload then takes that tower from its base model
-        id, which is what the key said anyway unless the tower had been modified); strict=True raises instead."""
+        re-saved.  strict=True (what save_pretrained / save_checkpoint use by default) raises; otherwise such keys are reported with
+        a warning and left out (the reload then takes that tower from its base model id)."""
         sd = {**getattr(self, "_kept_tensors", {}), **self.projector_state_dict()}
         lost = sorted(k for k in self.keep_params if k not in sd)
         if lost:
@@ -366,9 +366,11 @@ class UltravoxModel:
         sd = self._full_state_dict() if state_dict is None else state_dict
         return checkpoint.diff_state_dict(sd, self.trainable_parameter_names(), self.keep_params)
 
-    def save_pretrained(self, save_directory: str, state_dict: Optional[Dict[str, torch.Tensor]] = None):
+    def save_pretrained(self, save_directory: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, strict: bool = True):
+        """strict (default): a keep_param this model cannot re-save ABORTS the save - a checkpoint that silently lost the frozen-tower
+        tensors the reference would have kept reloads with the base model's instead.  strict=False: warn and leave them out."""
         from . import checkpoint
-        sd = self._full_state_dict() if state_dict is None else state_dict
+        sd = self._full_state_dict(strict=strict) if state_dict is None else state_dict
         return checkpoint.save_pretrained(save_directory, self.config, sd, self.trainable_parameter_names(), self.keep_params)
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = False):
@@ -779,7 +781,7 @@ class UltravoxModel:
             raise ValueError(f"cache + new tokens = {P + Tn} exceeds the RoPE table ({self._llm['rope_len']})")
         cache, Tmax = past.cache, past.Tmax
         if Tmax < P + Tn:                      # grow: rows [0, P) of every (layer, k|v, sequence) plane move over
-            new_T = max(P + Tn, 2 * Tmax)
+            new_T = min(max(P + Tn, 2 * Tmax), self._llm["rope_len"])     # (doubling, but never past the RoPE table the kernels check)
             nbytes = l.uvx_kv_cache_bytes(C.byref(self._c), B, new_T)
             grown = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             planes = self._c.llm_layers * 2 * B
@@ -1120,7 +1122,10 @@ class UltravoxTrainer:
         checkpoint.save_trainer_state(directory, self.step_count,
                                       {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "master": self.master},
                                       {"lr": self.lr, "betas": list(self.betas), "eps": self.eps, "weight_decay": self.wd,
-                                       "max_grad_norm": self.max_grad_norm})
+                                       "max_grad_norm": self.max_grad_norm,
+                                       # the tuner's verdict (uvx_set_option keys): a resumed trainer re-applies it, so that the
+                                       # attention backward keeps the summation order the run has been using
+                                       "llm_schedule": None if not self.llm_schedule else {str(k): int(v) for k, v in self.llm_schedule.items()}})
 
     def load_checkpoint(self, directory: str) -> None:
         """resume_from_checkpoint: restores projector weights, AdamW moments, master weights and the step counter,
@@ -1128,8 +1133,11 @@ class UltravoxTrainer:
         from . import checkpoint
         _, ckpt = checkpoint.load_pretrained(directory)
         self.model.load_state_dict(ckpt)
-        step, t, _ = checkpoint.load_trainer_state(directory)
+        step, t, extra = checkpoint.load_trainer_state(directory)
         self.step_count = step
+        if (extra or {}).get("llm_schedule"):
+            self.llm_schedule = {int(k): int(v) for k, v in extra["llm_schedule"].items()}
+            self._apply_schedule(self.llm_schedule)
         self.exp_avg.copy_(t["exp_avg"].to(self.exp_avg.device))
         self.exp_avg_sq.copy_(t["exp_avg_sq"].to(self.exp_avg_sq.device))
         if self.master is not None:
@@ -1173,7 +1181,12 @@ class UltravoxTrainer:
     def autotune_schedule(self, candidates=None, rounds: int = 2) -> None:
         """Arms the tuner: the next 1 + rounds * len(candidates) calls of train_step (one throw-away step first) alternate
         between the candidate schedules (dicts of uvx_set_option key -> value); afterwards the fastest (by its best step) stays
-        set.  `self.llm_schedule` holds the verdict (None while tuning), `self.schedule_timings` the best step time of each."""
+        set.  `self.llm_schedule` holds the verdict (None while tuning), `self.schedule_timings` the best step time of each.
+        NOT bit-neutral across candidates: the default pair also switches the attention backward (option 13), whose fused form sums
+        in another order than the dQ + dK/dV pair - results agree to rounding, and a run that tunes may round differently from box to
+        box.  For reproducible runs / bit-exact resume keep the library default (do not call this) or pass candidates that differ in
+        option 11 only (bit-identical); the verdict is saved by `save_checkpoint` and re-applied by `load_checkpoint`.  The options
+        are process-global: tuning one trainer sets the schedule of every model in the process."""
         cands = [dict(c) for c in (candidates or self.SCHEDULES)]
         self._tune = {"cands": cands, "plan": [None] + [i for _ in range(rounds) for i in range(len(cands))], "i": 0, "t": {},
                       "pending": None}
