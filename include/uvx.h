@@ -390,11 +390,17 @@ typedef struct {
 int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* desc);
 /* probes/tests: force the bf16 GEMM tile variant (-1 auto, 0 = 128x128, 1..4 = {128,160,192,256} x 256) */
 int32_t uvx_gemm_force_variant(int32_t variant);
+/* C = epilogue(RMSNorm(A; norm_w, eps) . B^T) - LlamaRMSNorm (flavor 0) / GemmaRMSNorm (1) feeding an nn.Linear, the pair the
+ * decode step runs twice per layer ([3P] LlamaDecoderLayer: input_layernorm -> q|k|v, post_attention_layernorm -> gate|up).  bf16 with
+ * at most 2 rows (and K <= 16384): ONE launch, the norm applied while the activation rows are staged; anything else: the two launches
+ * it replaces (norm_out [M, K] is the scratch for that case, may be NULL when the fused kernel is known to apply).  lda must equal K. */
+int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, const void* norm_w, float eps, int32_t flavor,
+                         void* norm_out);
 /* probes (same-box A/B inside bench.py): key 1 = 16-byte epilogue loads/stores (default 1), key 2 = SwiGLU backward fused
  * into the down-projection dgrad GEMM (0 = separate kernel, 1 = round 2's fragment-layout epilogue (measured neutral),
  * 2 = whole-line epilogue through the LDS stage (round 3)), key 3 = LM head / CE / head dgrad on the supervised
  * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
- * problems of at most 16 rows (the decode step; default 1: row-streaming kernel for M <= 4, MFMA mapping for 5..16; 2 = MFMA mapping for
+ * problems of at most 16 rows (the decode step; default 1: row-streaming kernel for M <= 2, MFMA mapping for 3..16; 2 = MFMA mapping for
  * every M <= 16, the round-2 kernel, for A/B; 0 = the tiled kernels), key 5 = the streamed weight transposes (llm_wt_stream) use plain instead of
  * non-temporal loads / stores (default 0), key 11 = number of LLM layer chains: the batch
  * is cut into that many slices whose layer chains run on as many streams (default 1 = one chain on the caller's stream, at most 4; which of 1 / 2 is

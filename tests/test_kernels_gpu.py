@@ -493,8 +493,8 @@ def test_gemm_fused_swiglu_epilogues_match_unfused_path(M, I, K):
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 6144, 4096), (5, 100, 64), (16, 1028, 14336), (3, 32, 128),
                                    (2, 8192, 28672), (4, 4096, 14336), (1, 57344, 8192), (3, 96, 576), (7, 96, 576), (9, 64, 1024)])
 def test_gemm_few_rows_weight_streaming_kernel(M, N, K):
-    """M <= 16 (the decode step) runs the weight-streaming kernels (csrc/gemm_skinny.hip: the row-streaming kernel for M <= 4, the
-    MFMA mapping for 5..16): against torch, against the tiled kernels (option 4 off) and against each other (option 4 = 2) with every
+    """M <= 16 (the decode step) runs the weight-streaming kernels (csrc/gemm_skinny.hip: the row-streaming kernel for M <= 2, the
+    MFMA mapping for 3..16): against torch, against the tiled kernels (option 4 off) and against each other (option 4 = 2) with every
     epilogue the decode path uses; K that is not a multiple of the 512-element step, ragged N, the 70B shapes."""
     from ultravox_amd import _lib
     g = torch.Generator(device=DEV).manual_seed(11)
@@ -528,6 +528,40 @@ def test_gemm_few_rows_weight_streaming_kernel(M, N, K):
         finally:
             L.uvx_set_option(4, 1)
         assert rel_l2(gu, gu_t) < 3e-3 and rel_l2(act, act_t) < 6e-3
+
+
+@pytest.mark.parametrize("M,N,K,flavor,swiglu", [(1, 10240, 8192, 0, False), (4, 6144, 4096, 0, False), (2, 28672, 4096, 0, True),
+                                                  (1, 57344, 8192, 0, True), (2, 4096, 3072, 1, False), (3, 4096, 3072, 1, False), (8, 6144, 4096, 0, False),
+                                                  (4, 1024, 8192, 0, False)])
+def test_gemm_with_fused_rmsnorm_matches_the_two_launches(M, N, K, flavor, swiglu):
+    """uvx_gemm_rmsnorm (the decode step's input_layernorm -> q|k|v and post_attention_layernorm -> gate|up in one launch, M <= 2) against
+    rmsnorm + gemm as two launches: the same rounding points, so the outputs agree to the last-bit noise of a differently ordered sum of
+    squares (rel-L2 < 2e-3, almost every element identical); M = 3, 4, 8 take the two-launch fallback inside the entry point."""
+    g = torch.Generator(device=DEV).manual_seed(13)
+    a = (torch.randn(M, K, device=DEV, generator=g) * 1.7).bfloat16()
+    w = (1.0 + 0.2 * torch.randn(K, device=DEV, generator=g)).bfloat16()
+    b = (torch.randn(N, K, device=DEV, generator=g) * 0.05).bfloat16()
+    eps = 1e-5
+    if flavor:      # GemmaRMSNorm (x_hat * (1 + w), one rounding) is not among the single-op wrappers: restated in f32
+        x = a.float()
+        normed = ((x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)) * (1.0 + w.float())).bfloat16()
+    else:
+        normed = ops().rmsnorm(a, w, eps=eps)
+    if swiglu:
+        act2 = torch.empty(M, N // 2, device=DEV, dtype=torch.bfloat16)
+        want = ops().gemm(normed, b, epilogue=1, c2=act2)
+        act1 = torch.empty_like(act2)
+        got = ops().gemm_rmsnorm(a, w, b, eps=eps, flavor=flavor, epilogue=1, c2=act1)
+        assert rel_l2(act1, act2) < 4e-3
+    else:
+        bias = torch.randn(N, device=DEV, generator=g).bfloat16()
+        want = ops().gemm(normed, b, bias=bias)
+        got = ops().gemm_rmsnorm(a, w, b, eps=eps, flavor=flavor, bias=bias)
+    assert rel_l2(got, want) < 2e-3, rel_l2(got, want)
+    assert (got == want).float().mean().item() > (0.9 if flavor == 0 else 0.6)
+    ref = normed.float() @ b.float().t()
+    if not swiglu:
+        assert rel_l2(got, (ref + bias.float())) < 5e-3
 
 
 def test_lds_transpose_read_semantics():

@@ -70,6 +70,32 @@ extern "C" int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* 
   return uvx::gemm((hipStream_t)stream, dtype, d);
 }
 
+// C = epilogue(RMSNorm(A; norm_w) . B^T): the decode step's fused norm + weight-streaming GEMV (bf16, at most 2 rows); any other
+// problem runs as the two launches it replaces (norm_out: M x K scratch for that case).
+extern "C" int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, const void* norm_w, float eps, int32_t flavor,
+                                    void* norm_out) {
+  UVX_CHECK(g != nullptr && norm_w != nullptr, UVX_ERR_INVALID, "uvx_gemm_rmsnorm: null argument");
+  uvx::GemmDesc d;
+  d.A = g->A; d.B = g->B; d.C = g->C; d.bias = g->bias; d.residual = g->residual;
+  d.M = g->M; d.N = g->N; d.K = g->K;
+  d.lda = g->lda; d.ldb = g->ldb; d.ldc = g->ldc; d.ldr = g->ldr;
+  d.res_mod = g->res_mod; d.batch = g->batch;
+  d.sA = g->stride_a; d.sB = g->stride_b; d.sC = g->stride_c; d.sR = g->stride_r;
+  d.act = g->act; d.out_f32 = g->out_f32; d.accumulate = g->accumulate; d.alpha = g->alpha;
+  d.C2 = g->C2; d.ldc2 = g->ldc2; d.swiglu = g->epilogue;
+  UVX_CHECK(g->epilogue == 0 || dtype == uvx::DT_BF16, UVX_ERR_UNSUPPORTED, "uvx_gemm_rmsnorm: fused SwiGLU epilogues are bf16 only");
+  UVX_CHECK(d.lda == d.K, UVX_ERR_SHAPE, "uvx_gemm_rmsnorm: A rows must be contiguous (lda = K)");
+  if (dtype == uvx::DT_BF16) {
+    const int rc = uvx::gemm_skinny_rmsnorm_bf16((hipStream_t)stream, d, norm_w, eps, flavor);
+    if (rc != UVX_ERR_UNSUPPORTED) return rc;
+  }
+  UVX_CHECK(norm_out != nullptr, UVX_ERR_INVALID, "uvx_gemm_rmsnorm: this problem runs as two launches and needs norm_out [M, K]");
+  const int rc_norm = uvx::rmsnorm_fwd((hipStream_t)stream, dtype, d.A, norm_w, norm_out, nullptr, d.M, d.K, eps, flavor);
+  if (rc_norm != UVX_OK) return rc_norm;
+  d.A = norm_out;
+  return uvx::gemm((hipStream_t)stream, dtype, d);
+}
+
 // ---- thin single-op wrappers ----
 extern "C" int32_t uvx_layernorm(void* stream, int32_t dtype, const void* x, const void* w, const void* b, void* y,
                                  int32_t rows, int32_t cols, float eps) {

@@ -18,6 +18,8 @@ struct SkinnyArgs {
   const bf16_t* A; const bf16_t* B; bf16_t* C; const bf16_t* bias; const bf16_t* residual; bf16_t* C2;
   int M, N, K, lda, ldb, ldc, ldr, ldc2, res_mod, act, swiglu;
   float alpha;
+  // gemv_rows_bf16_k<.., NORM = true>: A is the RAW residual-stream row; RMSNorm(A; norm_w) is applied on the way in
+  const bf16_t* norm_w; float norm_eps; int norm_flavor;
 };
 
 // TILES = 16-column MFMA tiles per block: 2 (needed by the fused SwiGLU: gate block + up block) or 1 (twice the blocks:
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
 }
 
 
-// ---- round 4: row-streaming kernel for M <= 4 (the decode step at batch 1..4) ----
+// ---- round 4: row-streaming kernel for M <= 2 (the decode step at batch 1 and 2) ----
 // The MFMA mapping above reads 16 weight rows x 64 bytes per wave instruction (row stride K * 2 bytes): on Llama-3.3-70B's
 // gate|up matrix (940 MB) that pattern streams at 4.8 TB/s, while the same bytes read as whole rows - 1 KiB contiguous per wave
 // instruction, non-temporal - stream at 6.5-7.1 TB/s (tools/probes/hbm_stream_probe.hip, profiles/r04_hbm_stream_patterns.txt).
@@ -150,16 +152,60 @@ __device__ __forceinline__ float dot8(const u32x4_t a, const u32x4_t b, float c)
   return dot2(a3, b3, dot2(a2, b2, dot2(a1, b1, dot2(a0, b0, c))));
 }
 
-template <int MB /*activation rows served: 1, 2, 4*/, int R /*weight rows in flight per wave*/, int RB /*weight rows per block: 16 or 32*/>
+// NORM: the activation rows are RMS-normalised on the way in (the decode step's input_layernorm -> q|k|v and post_attention_layernorm ->
+// gate|up: the separate rmsnorm_fwd_k launch on ONE row of 8192 elements cost 6.2 us, 161 of them 1.0 ms of a 26 ms 70B token).  Every
+// block normalises the M rows itself - they are M x K x 2 bytes, read by every block anyway - into LDS (xs, dynamic: MB x K bf16) with
+// rmsnorm_fwd_k's arithmetic and rounding points (flavor 0: w * round(x * rstd); 1, Gemma: (x * rstd) * (1 + w)), and the main loop reads
+// its activation vectors from there.  The sum of squares is folded in this block's own order (per-thread strided partial sums, wave
+// butterfly, waves in order): rstd may differ from the separate kernel's in the last bit.
+template <int MB /*activation rows served: 1, 2*/, int R /*weight rows in flight per wave*/, int RB /*weight rows per block: 16 or 32*/,
+          bool NORM = false>
 __global__ __launch_bounds__(512) void gemv_rows_bf16_k(SkinnyArgs p) {
   __shared__ float part[8][RB][MB];
+  __shared__ float nred[16];
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs_raw[];      // NORM: [MB][K] bf16
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n0 = blockIdx.x * RB;
   const int nsteps = (p.K + 511) / 512;
   const u32x4_t zero = {0u, 0u, 0u, 0u};
   const bf16_t* arow[MB];
+  if (NORM) {
+    bf16_t* xs = reinterpret_cast<bf16_t*>(xs_raw);
+    constexpr int MAXV = 4;                       // 8-element vectors per thread: K <= 512 * 8 * MAXV = 16384
 #pragma unroll
-  for (int m = 0; m < MB; ++m) arow[m] = p.A + (long long)min(m, p.M - 1) * p.lda + lane * 8;
+    for (int m = 0; m < MB; ++m) {
+      const bf16_t* xr = p.A + (long long)min(m, p.M - 1) * p.lda;
+      float v[MAXV][8];
+      float ss = 0.f;
+#pragma unroll
+      for (int q = 0; q < MAXV; ++q) {
+        const int c = (threadIdx.x + q * 512) * 8;
+        if (c < p.K) {
+          ld8<bf16_t>(xr + c, v[q]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += v[q][e] * v[q][e];
+        }
+      }
+      const float rstd = rsqrtf(block_sum(ss, nred) / p.K + p.norm_eps);
+#pragma unroll
+      for (int q = 0; q < MAXV; ++q) {
+        const int c = (threadIdx.x + q * 512) * 8;
+        if (c < p.K) {
+          float wv[8], o[8];
+          ld8<bf16_t>(p.norm_w + c, wv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = p.norm_flavor ? (v[q][e] * rstd) * (1.0f + wv[e]) : wv[e] * rnd<bf16_t>(v[q][e] * rstd);
+          st8<bf16_t>(xs + (long long)m * p.K + c, o);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MB; ++m) arow[m] = xs + (long long)m * p.K + lane * 8;
+  } else {
+#pragma unroll
+    for (int m = 0; m < MB; ++m) arow[m] = p.A + (long long)min(m, p.M - 1) * p.lda + lane * 8;
+  }
   for (int rb = 0; rb < RB; rb += R) {
     float acc[R][MB];
 #pragma unroll
@@ -230,6 +276,59 @@ __global__ __launch_bounds__(512) void gemv_rows_bf16_k(SkinnyArgs p) {
 
 namespace uvx {
 
+// Weight rows per block: 32 for the SwiGLU epilogue (a gate block + its up block); otherwise whichever of 32 / 16 / 8 spreads the blocks most
+// evenly over the CUs by more than 5 % (q|k|v of Llama-3.3-70B, N = 10240: 640 blocks of 16 rows = 2.5 per CU - some CUs stream 3 blocks while others
+// stream 2 - against 1280 blocks of 8 rows = 5 per CU); ties go to the larger block (fewer re-reads of the activation rows).
+static int gemv_rows_per_block(const uvx::GemmDesc& d) {
+  if (d.swiglu) return 32;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  int best = 32;
+  double best_cost = 1e30;
+  for (int rb : {32, 16, 8}) {
+    const int blocks = (d.N + rb - 1) / rb;
+    if (rb == 32 && d.N < 16384) continue;              // (few large blocks leave CUs idle at the small N of the attention projections)
+    const double per_cu = (double)blocks / cus, cost = ceil(per_cu) / per_cu;
+    if (cost < 0.95 * best_cost) { best_cost = cost; best = rb; }      // a smaller block only for a clear (> 5 %) balance gain
+  }
+  return best;
+}
+
+// C = epilogue(RMSNorm(A; norm_w, eps, flavor) . B^T) for the decode step's few rows: one launch instead of rmsnorm_fwd + gemm.
+// Returns UVX_ERR_UNSUPPORTED (no launch, no error text) when the fused kernel does not serve the problem: the caller then runs the two.
+int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm_w, float eps, int flavor) {
+  const bool ok = d.M > 0 && d.M <= 2 && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 && d.K % 8 == 0 &&
+                  d.K <= 16384 && d.lda % 8 == 0 && d.ldb % 8 == 0 && (!d.swiglu || (d.N % 32 == 0 && d.C2)) && norm_w &&
+                  (size_t)d.M * d.K * 2 <= 64 * 1024 && uvx::g_options[4] == 1;
+  if (!ok) return UVX_ERR_UNSUPPORTED;
+  SkinnyArgs a;
+  a.A = (const bf16_t*)d.A; a.B = (const bf16_t*)d.B; a.C = (bf16_t*)d.C; a.bias = (const bf16_t*)d.bias;
+  a.residual = (const bf16_t*)d.residual; a.C2 = (bf16_t*)d.C2;
+  a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr; a.ldc2 = d.ldc2;
+  a.res_mod = d.res_mod; a.act = d.act; a.swiglu = d.swiglu; a.alpha = d.alpha;
+  a.norm_w = (const bf16_t*)norm_w; a.norm_eps = eps; a.norm_flavor = flavor;
+  uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K,
+                      ((double)d.M * d.K + (double)d.N * d.K) * 2.0 + (double)d.M * d.N * 2.0);
+  if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, 1, 201);
+  const int rb = gemv_rows_per_block(d);
+  const dim3 grid((d.N + rb - 1) / rb);
+  const int mb = d.M;
+  const size_t sh = (size_t)mb * d.K * 2;
+#define UVX_GEMVN(MB, RBV) do { \
+    static bool attr = false; \
+    if (!attr) { UVX_HIP(hipFuncSetAttribute((const void*)gemv_rows_bf16_k<MB, 4, RBV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr = true; } \
+    hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, RBV, true>), grid, dim3(512), sh, st, a); } while (0)
+  if (rb == 32) { if (mb == 1) UVX_GEMVN(1, 32); else UVX_GEMVN(2, 32); }
+  else if (rb == 16) { if (mb == 1) UVX_GEMVN(1, 16); else UVX_GEMVN(2, 16); }
+  else { if (mb == 1) UVX_GEMVN(1, 8); else UVX_GEMVN(2, 8); }
+#undef UVX_GEMVN
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
 bool gemm_skinny_applicable(const GemmDesc& d) {
   return d.M > 0 && d.M <= 16 && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 &&
          d.K % 32 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.N % 4 == 0 && d.ldc % 4 == 0 &&
@@ -242,18 +341,21 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
   a.residual = (const bf16_t*)d.residual; a.C2 = (bf16_t*)d.C2;
   a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr; a.ldc2 = d.ldc2;
   a.res_mod = d.res_mod; a.act = d.act; a.swiglu = d.swiglu; a.alpha = d.alpha;
+  a.norm_w = nullptr; a.norm_eps = 0.f; a.norm_flavor = 0;
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 + (double)d.M * d.N * 2.0);
   if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, 1, 200);
   // M <= 8: the row-streaming kernel (option 4 = 2 keeps the MFMA mapping for every M: same-box A/B)
-  // (M = 5..8 would need 8 activation vectors per weight vector from L1 - measured slower than the MFMA mapping at M = 8: 53 vs 36 ms per
-  //  70B token - so the row-streaming kernel serves M <= 4)
-  if (d.M <= 4 && uvx::g_options[4] != 2 && d.K % 8 == 0 && (!d.swiglu || d.N % 32 == 0)) {
-    const bool rb32 = d.swiglu || d.N >= 16384;
-    const dim3 grid(rb32 ? (d.N + 31) / 32 : (d.N + 15) / 16);
-#define UVX_GEMV(MB) do { if (rb32) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 32>), grid, dim3(512), 0, st, a); \
-                          else hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 16>), grid, dim3(512), 0, st, a); } while (0)
-    if (d.M == 1) UVX_GEMV(1); else if (d.M == 2) UVX_GEMV(2); else UVX_GEMV(4);
+  // (more activation rows cost more than the mapping gains - every weight vector then needs M activation vectors from L1 / LDS and the
+  //  registers halve the occupancy: 70B decode, ms per token, row kernel / MFMA mapping: B = 2: 27.0 / 28.8, B = 3: 34.1 / 29.1,
+  //  B = 4: 34.4 / 29.3, B = 8: 53 / 31 - profiles/r04_decode_gemv_batch_ab.txt - so the row-streaming kernel serves M <= 2)
+  if (d.M <= 2 && uvx::g_options[4] != 2 && d.K % 8 == 0 && (!d.swiglu || d.N % 32 == 0)) {
+    const int rb = gemv_rows_per_block(d);
+    const dim3 grid((d.N + rb - 1) / rb);
+#define UVX_GEMV(MB) do { if (rb == 32) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 32>), grid, dim3(512), 0, st, a); \
+                          else if (rb == 16) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 16>), grid, dim3(512), 0, st, a); \
+                          else hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 8>), grid, dim3(512), 0, st, a); } while (0)
+    if (d.M == 1) UVX_GEMV(1); else UVX_GEMV(2);
 #undef UVX_GEMV
     UVX_LAUNCH_CHECK();
     return UVX_OK;

@@ -81,6 +81,48 @@ __global__ void kv_append_k(const T* __restrict__ qkv, T* __restrict__ cache_k, 
   st8<T>(cache_v + dst, v);
 }
 
+// The decode step's rotary embedding and cache append in ONE launch (round 4: rope_k + kv_append_k were two 4.6 us launches per layer,
+// 0.7 ms of a 26 ms Llama-3.3-70B token): one new position per sequence; q heads are rotated in place, k heads are rotated and written to
+// cache row t0 (and back to the qkv row, as rope_k does), v heads are copied to the cache.  Same arithmetic and rounding points as rope_k.
+// item = (sequence, head of q | k, 8-column chunk of the first half of the head) or (sequence, 8-column chunk of v).
+template <typename T>
+__global__ void rope_kv_append_k(T* __restrict__ qkv, const float* __restrict__ cs, const int32_t* __restrict__ pos, T* __restrict__ cache_k,
+                                 T* __restrict__ cache_v, int B, int Tmax, int t0, int Hq, int Hkv, int D, int QKV) {
+  const int per_head = D / 16, KVD = Hkv * D;
+  const int rope_items = (Hq + Hkv) * per_head, v_items = KVD / 8, per_row = rope_items + v_items;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * per_row) return;
+  const int b = (int)(i / per_row), rem = (int)(i % per_row);
+  T* row = qkv + (long long)b * QKV;
+  const long long crow = ((long long)b * Tmax + t0) * KVD;
+  if (rem >= rope_items) {                      // v: copy
+    const int c = (rem - rope_items) * 8;
+    float v[8];
+    ld8<T>(row + (Hq + Hkv) * D + c, v);
+    st8<T>(cache_v + crow + c, v);
+    return;
+  }
+  const int h = rem / per_head, c = (rem % per_head) * 8;
+  T* base = row + h * D;
+  const float* t = cs + ((long long)pos[b] * (D / 2) + c) * 2;
+  float lo[8], hi[8], olo[8], ohi[8];
+  ld8<T>(base + c, lo);
+  ld8<T>(base + D / 2 + c, hi);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float co = rnd<T>(t[2 * k]), si = rnd<T>(t[2 * k + 1]);
+    olo[k] = rnd<T>(lo[k] * co) + rnd<T>(-hi[k] * si);
+    ohi[k] = rnd<T>(hi[k] * co) + rnd<T>(lo[k] * si);
+  }
+  st8<T>(base + c, olo);
+  st8<T>(base + D / 2 + c, ohi);
+  if (h >= Hq) {                                // k: the rotated row is the cache row
+    T* kc = cache_k + crow + (h - Hq) * D;
+    st8<T>(kc + c, olo);
+    st8<T>(kc + D / 2 + c, ohi);
+  }
+}
+
 // full[b][t][koff + c] = cache_k[b][t][c], full[b][t][koff + KVD + c] = cache_v[b][t][c] for t < Tf: the cached keys / values
 // laid back into the [B, Tf, QKV] row format the prefill attention reads (chunked prefill over a cached prefix)
 template <typename T>
@@ -319,6 +361,19 @@ struct LayerIO { void *x_in, *x_mid; };
 
 int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, void* x_mid, void* x_out) {
   const int dt = c.dtype, D = c.llm_d;
+  if (dt == DT_BF16 && M <= 2 && c.llm_flavor != UVX_LLM_GEMMA3) {     // decode: post_attention_layernorm inside the gate|up GEMV
+    GemmDesc g = lin(x_mid, L.wgu, s.gu, M, 2 * c.llm_inter, D);
+    const bool fused = c.llm_flavor == UVX_LLM_LLAMA;
+    if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
+    const int rc = gemm_skinny_rmsnorm_bf16(st, g, L.ln2, c.rms_eps, c.llm_flavor);
+    if (rc != UVX_ERR_UNSUPPORTED) {
+      RC(rc);
+      if (!fused) RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2, c.llm_act));
+      GemmDesc d = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
+      d.residual = x_mid; d.ldr = D;
+      return gemm(st, dt, d);
+    }
+  }
   RC(rmsnorm_fwd(st, dt, x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
   if (c.llm_flavor == UVX_LLM_GEMMA3) {      // x_out = x_mid + post_feedforward_norm(mlp(pre_feedforward_norm(x_mid)))
     RC(gemm(st, dt, lin(s.n, L.wgu, s.gu, M, 2 * c.llm_inter, D)));
@@ -574,8 +629,23 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
   const float scale = attn_scale_of(c);
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
-    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
-    RC(qkv_rope(st, c, w, L, s.n, s.qkv, positions, B, 1, s.QKV, l));
+    const bool fuse_rope_append = dt == DT_BF16 && !c.llm_qk_norm;     // (Qwen3 / Gemma-3: q_norm / k_norm + RoPE is its own kernel)
+    if (fuse_rope_append) {
+      // input_layernorm inside the q|k|v GEMV (B <= 2); otherwise the two launches
+      GemmDesc g = lin(s.x, L.wqkv, s.qkv, B, s.QKV, D);
+      g.bias = L.bqkv;
+      const int rc = gemm_skinny_rmsnorm_bf16(st, g, L.ln1, c.rms_eps, c.llm_flavor);
+      if (rc == UVX_ERR_UNSUPPORTED) {
+        RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
+        g.A = s.n;
+        RC(gemm(st, dt, g));
+      } else {
+        RC(rc);
+      }
+    } else {
+      RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
+      RC(qkv_rope(st, c, w, L, s.n, s.qkv, positions, B, 1, s.QKV, l));
+    }
     // Gemma-3 sliding-window layer: the new token attends to the last `window` positions = cache slots (the slots of a sequence are
     // contiguous, so the window is a clamp of the first visible slot)
     const int lo = (c.llm_flavor == UVX_LLM_GEMMA3 && c.llm_window > 0 && w->layer_local && w->layer_local[l]) ? max(0, cur_len + 1 - c.llm_window) : 0;
@@ -584,7 +654,13 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
     const long long n = (long long)B * (KVD / 8);
     const int nw = B * Hq;
     if (dt == DT_BF16) {
-      hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
+      if (fuse_rope_append) {
+        const long long items = (long long)B * ((Hq + Hkv) * (dh / 16) + KVD / 8);
+        hipLaunchKernelGGL(rope_kv_append_k<bf16_t>, dim3(cdiv(items, 256)), dim3(256), 0, st, (bf16_t*)s.qkv, w->rope_cos_sin, positions,
+                           (bf16_t*)ck, (bf16_t*)cv, B, Tmax, cur_len, Hq, Hkv, dh, s.QKV);
+      } else {
+        hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
+      }
       const int G = Hq / Hkv, len = cur_len + 1;
       const size_t sh = sizeof(float) * (size_t)G * len;
 #define UVX_DEC(DD, GG) RC((launch_decode_grp<DD, GG>(st, sh, B * Hkv, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale, lo)))

@@ -59,6 +59,8 @@ int gemm_nt(hipStream_t st, const GemmDesc& d);
 // gemm_skinny.hip: weight-streaming kernel for M <= 16 rows (the decode step); gemm_nt dispatches to it
 bool gemm_skinny_applicable(const GemmDesc& d);
 int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d);
+// decode step: RMSNorm fused into the row-streaming kernel's input (M <= 2); UVX_ERR_UNSUPPORTED (nothing launched) when it does not apply
+int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm_w, float eps, int flavor);
 // f32 operands/outputs (parity mode; MFMA 16x16x4 f32).
 int gemm_nt_f32(hipStream_t st, const GemmDesc& d);
 // dispatch on dtype

@@ -46,6 +46,25 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_rmsnorm(a: torch.Tensor, norm_w: torch.Tensor, b: torch.Tensor, *, eps: float = 1e-5, flavor: int = 0,
+                 bias: Optional[torch.Tensor] = None, epilogue: int = 0, c2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epilogue(RMSNorm(a; norm_w) @ b[N,K]^T + bias) through uvx_gemm_rmsnorm (the decode step's fused norm + GEMV)."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    scratch = torch.empty_like(a)
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    d.bias = 0 if bias is None else bias.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = a.stride(0), b.stride(0), out.stride(0)
+    d.batch, d.alpha, d.epilogue = 1, 1.0, epilogue
+    d.C2, d.ldc2 = (0, 0) if c2 is None else (c2.data_ptr(), c2.stride(0))
+    check(_lib.lib().uvx_gemm_rmsnorm(stream_ptr(), dtype_code(a.dtype), C.byref(d), ptr(norm_w), C.c_float(eps), int(flavor), ptr(scratch)),
+          "uvx_gemm_rmsnorm")
+    return out
+
+
 def _code(t: torch.Tensor) -> int:
     return dtype_code(t.dtype)
 
