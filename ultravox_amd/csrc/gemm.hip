@@ -1472,14 +1472,19 @@ bool variant_available(int v) {
   return v >= 0 && v < kNumVariants && is_production(v);
 #endif
 }
-double variant_cost(int v, int M, int N, int K, int batch) {
+// `gelu`: the launch carries the bias + GELU epilogue (the encoder's fc1).  Its cost grows with the tile's area and is paid by every CU at
+// the same time; in situ the 192-row tile is 13 % faster than the 256-row tile on 12000 x 4096 x 1024 (128 vs 147-150 us, and the fc2 GEMM
+// behind it 86 vs 97 us; whole step -0.6 ms: profiles/r04_gemm_fc1_tile_ab.txt) where the plain model had the 256-row tile 10 % ahead:
+// three more K-tiles of fixed cost for the 256-row tiles under that epilogue.
+double variant_cost(int v, int M, int N, int K, int batch, bool gelu = false) {
   const double tiles = (double)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * batch;
   // Rounds of tiles over the 256 CUs.  A partly filled last round is cheaper than a full one (the kernels are bound
   // by operand delivery through the shared L2 / fabric, so fewer active CUs each run faster) but never cheaper
   // than ~0.55 of one: measured behaviour is well described by max(0.55, frac^0.6).
   const double r = tiles / 256.0, frac = r - floor(r);
   const double rounds = floor(r) + (frac > 0. ? fmax(0.55, pow(frac, 0.6)) : 0.);
-  return rounds * kVariants[v].bm * kVariants[v].bn * (K / 64.0 + kVariants[v].c) / kVariants[v].speed;
+  const double c = kVariants[v].c + (gelu && kVariants[v].bm == 256 ? 3.0 : 0.0);
+  return rounds * kVariants[v].bm * kVariants[v].bn * (K / 64.0 + c) / kVariants[v].speed;
 }
 // Stream-K launch geometry: one block per CU; `full` data-parallel rounds, the rest of the tiles shared out by K-tiles.
 int sk_grid() {
@@ -1508,14 +1513,14 @@ double sk_cost(int v, int M, int N, int K, int grid) {
   const double pieces = share / nk + 1.0;                          // ~ pieces per block in the stream-K part
   return (full * (nk + V.c) + share + pieces * V.c + kSkFix) * V.bm * V.bn / V.speed * kSkSlow;
 }
-int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
+int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr, bool gelu = false) {
   int forced = uvx::g_gemm_variant;
   for (int i = 0; i < uvx::g_gemm_ovr_n; ++i)
     if (uvx::g_gemm_ovr[i][0] == M && uvx::g_gemm_ovr[i][1] == N && uvx::g_gemm_ovr[i][2] == K) forced = uvx::g_gemm_ovr[i][3];
   double best = 1e30;
   int best_v = 0;
   if (forced >= 0 && forced < kNumVariants) {   // probe-only variants carry speed 0: never let the cost model veto them
-    if (cost_out) *cost_out = kVariants[forced].speed > 0. ? variant_cost(forced, M, N, K, batch) : 0.;
+    if (cost_out) *cost_out = kVariants[forced].speed > 0. ? variant_cost(forced, M, N, K, batch, gelu) : 0.;
     return forced;
   }
 #ifdef UVX_PROBES
@@ -1534,7 +1539,7 @@ int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr) {
       if (!skg || tiles % skg == 0 || tiles * (K / 64) < 4LL * skg) continue;
       cost = sk_cost(v, M, N, K, skg);
     } else {
-      cost = variant_cost(v, M, N, K, batch);
+      cost = variant_cost(v, M, N, K, batch, gelu);
     }
     if (cost < best) { best = cost; best_v = v; }
   }
@@ -1730,7 +1735,8 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
             "gemm: swiglu-backward epilogue writes [M, 2N]: ldc=%d / ldc2=%d too small for N=%d", d.ldc, d.ldc2, d.N);
   const int batch = d.batch > 0 ? d.batch : 1;
   double cost_whole = 0.;
-  int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole);
+  const bool gelu = d.act == 1;
+  int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole, gelu);
   if (is_a4(variant) && !a4_applicable(d)) variant = 31;     // (the eight-wave 256 x 256 kernel takes any alignment)
   UVX_CHECK(variant_available(variant), UVX_ERR_INVALID,
             "gemm: tile variant %d is not in this build (probe variants live in libuvx_probes.so, built with -DUVX_PROBES)", variant);
@@ -1752,8 +1758,8 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
     const int tail_n = d.N - main_panels * V.bn;
     if (main_panels > 0 && tail_n > 0) {
       double cost_tail = 0.;
-      const int tv = pick_variant(d.M, tail_n, d.K, 1, &cost_tail);
-      const double cost_split = variant_cost(variant, d.M, main_panels * V.bn, d.K, 1) + cost_tail;
+      const int tv = pick_variant(d.M, tail_n, d.K, 1, &cost_tail, gelu);
+      const double cost_split = variant_cost(variant, d.M, main_panels * V.bn, d.K, 1, gelu) + cost_tail;
       // (the second launch costs a round of its own plus a launch gap: only worth it for a clear modelled win)
       // (probe option 10: the threshold in per cent, 0 = the default 88)
       const double thr = uvx::g_options[10] > 0 ? uvx::g_options[10] / 100.0 : 0.88;

@@ -52,6 +52,57 @@ __global__ __launch_bounds__(256) void lora_down_k(const T* __restrict__ X, long
   }
 }
 
+// The same for r <= 8, W [r][C] and C = 512 * NCH (the encoder's 1024 columns), bf16: a wave keeps ITS slice of W in registers (8 x NCH
+// packed 16-byte vectors per lane) and walks RPW rows, two at a time - the kernel above re-reads W through L1 for every row (9 vector
+// loads per 64 FMAs: 19 us for a 24.6 MB activation matrix whose HBM time is 5 us).  Exact bf16 products, f32 accumulation
+// (v_dot2c_f32_bf16 over the lane's column pairs in ascending order, butterfly over the lanes), the same rounding of the result.
+typedef unsigned int lu32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 lbf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ldot2(unsigned a, unsigned b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(lbf16x2_t, a), __builtin_bit_cast(lbf16x2_t, b), c, false);
+}
+__device__ __forceinline__ float ldot8(const lu32x4_t a, const lu32x4_t b, float c) {     // (components through scalars: see gemm_skinny.hip)
+  const unsigned a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+  return ldot2(a3, b3, ldot2(a2, b2, ldot2(a1, b1, ldot2(a0, b0, c))));
+}
+template <int NCH>
+__global__ __launch_bounds__(256) void lora_down_reg_k(const bf16_t* __restrict__ X, long long ldx, const bf16_t* __restrict__ W,
+                                                       bf16_t* __restrict__ Y, long long ldy, long long M, int C, int r, float alpha, int rpw) {
+  const int lane = threadIdx.x & 63;
+  const long long m0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;
+  if (m0 >= M) return;
+  const lu32x4_t zero = {0u, 0u, 0u, 0u};
+  lu32x4_t wv[8][NCH];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+      wv[jj][ch] = jj < r ? *reinterpret_cast<const lu32x4_t*>(W + (long long)jj * C + ch * 512 + lane * 8) : zero;
+  const long long m1 = min(M, m0 + rpw);
+  for (long long m = m0; m < m1; m += 2) {
+    const bool two = m + 1 < m1;
+    lu32x4_t xa[NCH], xb[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      xa[ch] = *reinterpret_cast<const lu32x4_t*>(X + m * ldx + ch * 512 + lane * 8);
+      xb[ch] = *reinterpret_cast<const lu32x4_t*>(X + (two ? m + 1 : m) * ldx + ch * 512 + lane * 8);
+    }
+    float oa[8], ob[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) { sa = ldot8(xa[ch], wv[jj][ch], sa); sb = ldot8(xb[ch], wv[jj][ch], sb); }
+      oa[jj] = wave_sum(sa) * alpha;
+      ob[jj] = wave_sum(sb) * alpha;
+    }
+    if (lane == 0) {
+      st8<bf16_t>(Y + m * ldy, oa);
+      if (two) st8<bf16_t>(Y + (m + 1) * ldy, ob);
+    }
+  }
+}
+
 // Z[m, c] = round(Z[m, c] + round(alpha * sum_j Y[m, j] * W[c, j]))   (accumulate = false: Z = round(alpha * ...))
 // W_RC: W is stored [r][C] (lora_A used as an up-projection in the backward pass) instead of [C][r]
 template <typename T, bool ACC, bool W_RC>
@@ -63,10 +114,33 @@ __global__ void lora_up_k(const T* __restrict__ Y, long long ldy, const T* __res
   const long long m = i / cv;
   const int c = (int)(i % cv) * 8;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int j = 0; j < r; ++j) {
-    const float y = ldf<T>(Y + m * ldy + j);
+  if (r <= 8 && (W_RC || r == 8)) {
+    // ranks up to 8 (the reference's r = 8): Y rows are written in whole groups of 8 (zeros beyond r) and the narrow operand comes in
+    // 16-byte vectors - r (W [r][C]) or 8 (W [C][8]) loads per thread instead of 8 r two-byte loads (round 4: 18 us -> the HBM time of Z)
+    float y[8];
+    ld8<T>(Y + m * ldy, y);
+    if (W_RC) {
+      for (int j = 0; j < r; ++j) {
+        float wv[8];
+        ld8<T>(W + (long long)j * C + c, wv);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += y * ldf<T>(W_RC ? W + (long long)j * C + c + k : W + (long long)(c + k) * r + j);
+        for (int k = 0; k < 8; ++k) acc[k] += y[j] * wv[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float wv[8];
+        ld8<T>(W + (long long)(c + k) * 8, wv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k] += y[j] * wv[j];
+      }
+    }
+  } else {
+    for (int j = 0; j < r; ++j) {
+      const float y = ldf<T>(Y + m * ldy + j);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += y * ldf<T>(W_RC ? W + (long long)j * C + c + k : W + (long long)(c + k) * r + j);
+    }
   }
   float z[8];
   if (ACC) ld8<T>(Z + m * ldz + c, z);
@@ -80,7 +154,7 @@ __global__ void lora_up_k(const T* __restrict__ Y, long long ldy, const T* __res
 // (column vector 0..7): 8 lanes read one 128-byte piece of a row, the 8 row lanes take consecutive rows, the 4 waves
 // interleave further.  Each lane keeps acc[8 j][8 c]; row lanes are folded with shuffles, waves through LDS.
 // partial[chunk][j][c]; lora_wgrad_reduce_k sums the few chunks in a fixed order.
-constexpr int RCH = 1024;
+constexpr int RCH = 256;      // (round 4: 1024 gave 16 x 12 = 192 blocks at the encoder's 12000 x 1024 - fewer than CUs; 256 -> 752 blocks)
 template <typename T>
 __global__ __launch_bounds__(256) void lora_wgrad_k(const T* __restrict__ X, long long ldx, const T* __restrict__ Y, long long ldy,
                                                     float* __restrict__ partial, long long M, int C, int r, int j0) {
@@ -156,6 +230,14 @@ int lora_down(hipStream_t st, int dtype, const void* X, long long ldx, const voi
               long long M, int C, int r, float alpha) {
   UVX_CHECK(C % 8 == 0 && ldx % 8 == 0 && r > 0 && r <= RMAX, UVX_ERR_SHAPE, "lora_down: C=%d r=%d unsupported", C, r);
   if (M == 0) return UVX_OK;
+  if (dtype == DT_BF16 && !w_is_cr && r <= 8 && (C == 512 || C == 1024) && M >= 1024) {      // W in registers, 8 rows per wave
+    const int rpw = 8;
+    const dim3 g2((unsigned)((M + 4 * rpw - 1) / (4 * rpw)));
+    if (C == 512) hipLaunchKernelGGL((lora_down_reg_k<1>), g2, dim3(256), 0, st, (const bf16_t*)X, ldx, (const bf16_t*)W, (bf16_t*)Y, ldy, M, C, r, alpha, rpw);
+    else hipLaunchKernelGGL((lora_down_reg_k<2>), g2, dim3(256), 0, st, (const bf16_t*)X, ldx, (const bf16_t*)W, (bf16_t*)Y, ldy, M, C, r, alpha, rpw);
+    UVX_LAUNCH_CHECK();
+    return UVX_OK;
+  }
   const dim3 grid((unsigned)((M + 3) / 4));
 #define L(T, F) hipLaunchKernelGGL((lora_down_k<T, F>), grid, dim3(256), 0, st, (const T*)X, ldx, (const T*)W, (T*)Y, ldy, M, C, r, alpha)
   if (dtype == DT_BF16) { if (w_is_cr) L(bf16_t, true); else L(bf16_t, false); }
