@@ -69,6 +69,9 @@ WORKLOADS = {
     # the same loop on the C2 model (8B): a quick check of the inference path, not a BASELINE.json configuration
     "c4s": dict(name="Llama-3-8B (frozen, bf16) + whisper-medium, inference prefill+decode",
                 audio="openai/whisper-medium", text="meta-llama/Meta-Llama-3-8B-Instruct", B=1, seconds=30.0, inference=True, new_tokens=32),
+    # plumbing-sized inference loop (TinyLlama + whisper-tiny, 4 s clips): what the 2-rank replica test runs
+    "c4t": dict(name="TinyLlama-1.1B + whisper-tiny, inference prefill+decode (plumbing check)",
+                audio="openai/whisper-tiny", text="TinyLlama/TinyLlama-1.1B-Chat-v1.0", B=1, seconds=4.0, inference=True, new_tokens=8),
     # BASELINE.json configs[0] shapes (plumbing-sized), for quick checks
     "c1": dict(name="TinyLlama-1.1B + whisper-tiny, 1x4s clip, adapter train",
                audio="openai/whisper-tiny", text="TinyLlama/TinyLlama-1.1B-Chat-v1.0", B=1, seconds=4.0),
@@ -105,7 +108,7 @@ def run_inference(args, wl, dev) -> None:
             _lib.lib().uvx_set_option(int(k), int(v))
     B, new = args.batch or wl["B"], wl["new_tokens"]
     free_gb = torch.cuda.mem_get_info()[0] / 2 ** 30
-    need_gb = 170 if "70B" in wl["text"] else 40
+    need_gb = 170 if "70B" in wl["text"] else 40 if "8B" in wl["text"] else 6
     if free_gb < need_gb:          # never drive the box out of memory
         raise SystemExit(f"bench.py --workload {args.workload}: {free_gb:.0f} GiB free on the device, about {need_gb} GiB needed")
     cfg = UltravoxConfig(audio_model_id=wl["audio"], text_model_id=wl["text"], hidden_size=4096, stack_factor=8,

@@ -127,6 +127,24 @@ def test_bench_self_launches_two_ranks():
     assert len(ex["all"]) == 2 and all(x >= 0.0 for x in ex["all"]) and abs(ex["max"] - max(ex["all"])) < 1e-3   # (the list is rounded)
 
 
+def test_bench_inference_workload_runs_as_independent_replicas():
+    """`python bench.py --gpus 2 --workload c4t`: the inference line (BASELINE config 4's shape of run: prefill + decode, one replica
+    per rank, no collective on the data path) from two self-launched ranks - value = both replicas' tokens over the slower one's time."""
+    env = dict(os.environ, UVX_BENCH_SHARE_GPU="1", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "c4t"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["unit"] == "tokens/sec" and out["scaling"] == "weak" and out["value"] > 0
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1 and out["config"]["new_tokens"] == 8
+    assert out["output_shape"][1] == out["config"]["prompt_len"] + 8
+    assert abs(out["value"] - 2 * 8 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+
+
 def test_uvx_comm_one_rank_rccl_group_and_trainer_route():
     """The C-ABI exchange (uvx_comm_*) on a real RCCL communicator - a 1-rank group is all one GPU allows: sum over one rank x
     scale; and UltravoxTrainer(comm=UvxComm) - sequential and overlapped - reproduces the torch.distributed-free trainer bit
