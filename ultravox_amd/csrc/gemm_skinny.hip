@@ -152,14 +152,40 @@ __device__ __forceinline__ float dot8(const u32x4_t a, const u32x4_t b, float c)
   return dot2(a3, b3, dot2(a2, b2, dot2(a1, b1, dot2(a0, b0, c))));
 }
 
+// Sums NV per-lane values over the 64 lanes in NV - 1 + (6 - log2 NV) shuffles instead of 6 NV: at every stage a lane keeps one half of
+// its values and hands the other half to its partner (xor 32, 16, ...), until one value is left, which the remaining butterfly stages
+// finish.  Afterwards v[0] of lane L is the total of value index idx(L) = the top log2(NV) bits of L read as a number (bit 5 = the index's
+// most significant bit); all 64 >> log2(NV) lanes of a group hold the same total.  Fixed order: deterministic.
+template <int NV>
+__device__ __forceinline__ void wave_sum_multi(float (&v)[NV], int lane) {
+  static_assert(NV >= 1 && NV <= 64 && (NV & (NV - 1)) == 0, "power of two");
+  int d = 32;
+#pragma unroll
+  for (int h = NV / 2; h >= 1; h /= 2, d >>= 1) {
+    const bool upper = (lane & d) != 0;
+#pragma unroll
+    for (int i = 0; i < h; ++i) {
+      const float keep = upper ? v[h + i] : v[i], send = upper ? v[i] : v[h + i];
+      v[i] = keep + __shfl_xor(send, d, 64);
+    }
+  }
+#pragma unroll
+  for (; d >= 1; d >>= 1) v[0] += __shfl_xor(v[0], d, 64);
+}
+template <int NV> __device__ __forceinline__ int wave_sum_multi_index(int lane) {
+  int bits = 0;
+  for (int n = NV; n > 1; n >>= 1) ++bits;
+  return bits == 0 ? 0 : (lane >> (6 - bits));
+}
+
 // NORM: the activation rows are RMS-normalised on the way in (the decode step's input_layernorm -> q|k|v and post_attention_layernorm ->
 // gate|up: the separate rmsnorm_fwd_k launch on ONE row of 8192 elements cost 6.2 us, 161 of them 1.0 ms of a 26 ms 70B token).  Every
 // block normalises the M rows itself - they are M x K x 2 bytes, read by every block anyway - into LDS (xs, dynamic: MB x K bf16) with
 // rmsnorm_fwd_k's arithmetic and rounding points (flavor 0: w * round(x * rstd); 1, Gemma: (x * rstd) * (1 + w)), and the main loop reads
 // its activation vectors from there.  The sum of squares is folded in this block's own order (per-thread strided partial sums, wave
 // butterfly, waves in order): rstd may differ from the separate kernel's in the last bit.
-template <int MB /*activation rows served: 1, 2*/, int R /*weight rows in flight per wave*/, int RB /*weight rows per block: 16 or 32*/,
-          bool NORM = false>
+template <int MB /*activation rows served: 1, 2*/, int R /*weight rows in flight per wave*/, int RB /*weight rows per block: 8, 16 or 32*/,
+          bool NORM = false, int KSTEPS = (MB <= 2 ? 2 : 1) /*512-element k-steps in flight per trip*/>
 __global__ __launch_bounds__(512) void gemv_rows_bf16_k(SkinnyArgs p) {
   __shared__ float part[8][RB][MB];
   __shared__ float nred[16];
@@ -215,33 +241,36 @@ __global__ __launch_bounds__(512) void gemv_rows_bf16_k(SkinnyArgs p) {
     const bf16_t* brow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) brow[r] = p.B + (long long)min(n0 + rb + r, p.N - 1) * p.ldb + lane * 8;
-    // two k-steps per trip: 2 R weight loads (HBM, non-temporal) + 2 MB activation loads (cache) in flight per lane
-    for (int j = w; j < nsteps; j += 16) {
-      const int k0 = j * 512, k1 = (j + 8) * 512;
-      const bool ok0 = k0 + lane * 8 < p.K, ok1 = j + 8 < nsteps && k1 + lane * 8 < p.K;
-      u32x4_t wv0[R], wv1[R], xv0[MB], xv1[MB];
+    // KSTEPS k-steps per trip: KSTEPS x R weight loads (HBM, non-temporal) + KSTEPS x MB activation loads (cache / LDS) in flight per lane
+    for (int j = w; j < nsteps; j += 8 * KSTEPS) {
+      u32x4_t wv[KSTEPS][R], xv[KSTEPS][MB];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        wv0[r] = ok0 ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(brow[r] + k0)) : zero;
-        wv1[r] = ok1 ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(brow[r] + k1)) : zero;
+      for (int q = 0; q < KSTEPS; ++q) {
+        const int kq = (j + 8 * q) * 512;
+        const bool ok = j + 8 * q < nsteps && kq + lane * 8 < p.K;
+#pragma unroll
+        for (int r = 0; r < R; ++r) wv[q][r] = ok ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(brow[r] + kq)) : zero;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) xv[q][m] = ok ? *reinterpret_cast<const u32x4_t*>(arow[m] + kq) : zero;
       }
 #pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        xv0[m] = ok0 ? *reinterpret_cast<const u32x4_t*>(arow[m] + k0) : zero;
-        xv1[m] = ok1 ? *reinterpret_cast<const u32x4_t*>(arow[m] + k1) : zero;
-      }
+      for (int q = 0; q < KSTEPS; ++q)
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) acc[r][m] = dot8(wv1[r], xv1[m], dot8(wv0[r], xv0[m], acc[r][m]));
+          for (int m = 0; m < MB; ++m) acc[r][m] = dot8(wv[q][r], xv[q][m], acc[r][m]);
     }
+    // fold the lanes: all R x MB values in one halving butterfly (value index = r * MB + m)
+    float flat[R * MB];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        const float t = wave_sum(acc[r][m]);
-        if (lane == 0) part[w][rb + r][m] = t;
-      }
+      for (int m = 0; m < MB; ++m) flat[r * MB + m] = acc[r][m];
+    wave_sum_multi<R * MB>(flat, lane);
+    if ((lane & (64 / (R * MB) - 1)) == 0) {
+      const int idx = wave_sum_multi_index<R * MB>(lane);
+      part[w][rb + idx / MB][idx % MB] = flat[0];
+    }
   }
   __syncthreads();
   // ---- epilogue (one thread per output element; the sums over the waves in a fixed order) ----
@@ -348,14 +377,15 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
   // M <= 8: the row-streaming kernel (option 4 = 2 keeps the MFMA mapping for every M: same-box A/B)
   // (more activation rows cost more than the mapping gains - every weight vector then needs M activation vectors from L1 / LDS and the
   //  registers halve the occupancy: 70B decode, ms per token, row kernel / MFMA mapping: B = 2: 27.0 / 28.8, B = 3: 34.1 / 29.1,
-  //  B = 4: 34.4 / 29.3, B = 8: 53 / 31 - profiles/r04_decode_gemv_batch_ab.txt - so the row-streaming kernel serves M <= 2)
+  //  B = 4: 34.4 / 29.3, B = 8: 53 / 31 - profiles/r04_decode_gemv_batch_ab.txt - so the row-streaming kernel serves M <= 2.
+  //  With the halving-butterfly lane reduction and one k-step per trip the picture is the same: B = 4: 37.4 / 29.3, B = 8: 89 / 30.6.)
   if (d.M <= 2 && uvx::g_options[4] != 2 && d.K % 8 == 0 && (!d.swiglu || d.N % 32 == 0)) {
     const int rb = gemv_rows_per_block(d);
     const dim3 grid((d.N + rb - 1) / rb);
-#define UVX_GEMV(MB) do { if (rb == 32) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 32>), grid, dim3(512), 0, st, a); \
-                          else if (rb == 16) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 16>), grid, dim3(512), 0, st, a); \
-                          else hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, 8>), grid, dim3(512), 0, st, a); } while (0)
-    if (d.M == 1) UVX_GEMV(1); else UVX_GEMV(2);
+#define UVX_GEMV(MB, RR) do { if (rb == 32) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, RR, 32>), grid, dim3(512), 0, st, a); \
+                          else if (rb == 16) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, RR, 16>), grid, dim3(512), 0, st, a); \
+                          else hipLaunchKernelGGL((gemv_rows_bf16_k<MB, RR, 8>), grid, dim3(512), 0, st, a); } while (0)
+    if (d.M == 1) UVX_GEMV(1, 4); else UVX_GEMV(2, 4);
 #undef UVX_GEMV
     UVX_LAUNCH_CHECK();
     return UVX_OK;
