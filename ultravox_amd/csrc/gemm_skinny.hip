@@ -24,9 +24,18 @@ struct SkinnyArgs {
 
 // TILES = 16-column MFMA tiles per block: 2 (needed by the fused SwiGLU: gate block + up block) or 1 (twice the blocks:
 // N = 4096 gives 256 blocks instead of 128, one per CU)
-template <int TILES>
+// STAGE (round 4, M = 3..16): the weights reach the MFMA fragments through a wave-private LDS tile.  A fragment load straight from global
+// memory touches 16 rows x 64 bytes; here a wave instruction reads 2 rows x 512 contiguous bytes (non-temporal), eight of them bring
+// 16 rows x 256 k into the wave's own [16][256 + 8] bf16 tile, and the eight k32 fragments are read back from there - the HBM side sees
+// the row-streaming pattern (profiles/r04_hbm_stream_patterns.txt), LDS traffic is twice the weight bytes (a few per cent of its bandwidth).
+// The next step's loads are issued right after the tile has been written, so they fly during the fragment reads and MFMAs; no block
+// barrier (LDS operations of one wave execute in order).  Needs K % 2048 == 0 (each wave's K span in whole 256-element steps).
+constexpr int SKS_PITCH = 528;                    // bytes per staged row: 256 bf16 + 16 bytes of padding
+template <int TILES, bool STAGE = false>
 __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
-  __shared__ float red[8][2][64][4];
+  extern __shared__ __attribute__((aligned(16))) unsigned char sk_dyn[];      // STAGE: 8 waves x 16 x SKS_PITCH bytes (then the reduction)
+  __shared__ float red_static[STAGE ? 1 : 8 * 2 * 64 * 4];
+  float (*red)[2][64][4] = reinterpret_cast<float (*)[2][64][4]>(STAGE ? reinterpret_cast<float*>(sk_dyn) : red_static);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int frow = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.x * (16 * TILES);
@@ -40,8 +49,43 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
   // Which k32 chunks a wave takes.  Round 4: contiguous SPANS (wave w: chunks [w * n/8, (w + 1) * n/8)) instead of the interleave
   // w, w + 8, ...: every wave then walks its 16 rows front to back, which streams at 6.0 instead of 4.9 TB/s on the 70B gate|up
   // matrix (profiles/r04_hbm_stream_patterns.txt, patterns 4 / 1).  The interleave remains for K that does not split evenly.
+  if constexpr (STAGE) {
+    typedef unsigned int su32x4_t __attribute__((ext_vector_type(4)));
+    unsigned char* buf = sk_dyn + w * (16 * SKS_PITCH);
+    const int kspan = p.K / 8, k_begin = w * kspan, nst = kspan / 256;
+    const int lrow = lane >> 5, lk = (lane & 31) * 8;            // load mapping: instruction i brings rows 2 i + lrow, elements lk .. lk + 7
+    // one (step, tile) pair at a time: its 8 row-pair loads were issued while the previous pair was being multiplied
+    su32x4_t ld[8];
+    auto issue = [&](int q) {
+      const int st = q / TILES, t = q % TILES;
+#pragma unroll
+      for (int i8 = 0; i8 < 8; ++i8) {
+        const bf16_t* src = p.B + (long long)min(n0 + 16 * t + 2 * i8 + lrow, p.N - 1) * p.ldb + k_begin + st * 256 + lk;
+        ld[i8] = __builtin_nontemporal_load(reinterpret_cast<const su32x4_t*>(src));
+      }
+    };
+    issue(0);
+    bf16x8_t xf[8];
+    for (int q = 0; q < nst * TILES; ++q) {
+      const int st = q / TILES, t = q % TILES, k0 = k_begin + st * 256;
+      if (t == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xf[c] = m_ok ? *reinterpret_cast<const bf16x8_t*>(a0 + k0 + c * 32) : zero;
+      }
+#pragma unroll
+      for (int i8 = 0; i8 < 8; ++i8) *reinterpret_cast<su32x4_t*>(buf + (2 * i8 + lrow) * SKS_PITCH + lk * 2) = ld[i8];
+      if (q + 1 < nst * TILES) issue(q + 1);      // the registers are free again
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(buf + frow * SKS_PITCH + c * 64 + fg * 16);
+        if (t == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[c], acc0, 0, 0, 0);
+        else acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[c], acc1, 0, 0, 0);
+      }
+    }
+    __syncthreads();            // every wave is done with its tile: the buffer becomes the reduction array
+  }
   const bool span = nchunk % 8 == 0;
-  const int stride = span ? 1 : 8, end = span ? (w + 1) * (nchunk / 8) : nchunk;
+  const int stride = span ? 1 : 8, end = STAGE ? 0 : (span ? (w + 1) * (nchunk / 8) : nchunk);
   int i = span ? w * (nchunk / 8) : w;
   // UN chunks per iteration: 2-3 x UN independent 16-byte loads in flight per lane (the kernel lives on memory-level parallelism)
   constexpr int UN = TILES == 2 ? 4 : 8;
@@ -390,8 +434,21 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
     UVX_LAUNCH_CHECK();
     return UVX_OK;
   }
-  if (d.swiglu || d.N >= 16384) hipLaunchKernelGGL(gemm_skinny_bf16_k<2>, dim3((d.N + 31) / 32), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL(gemm_skinny_bf16_k<1>, dim3((d.N + 15) / 16), dim3(512), 0, st, a);
+  if (d.K % 2048 == 0 && uvx::g_options[4] != 2) {      // weights through a wave-private LDS tile (option 4 = 2: straight fragment loads, A/B)
+    constexpr size_t sh = 8 * 16 * SKS_PITCH;             // 67.6 KB: two blocks per CU
+    static bool attr = false;
+    if (!attr) {
+      UVX_HIP(hipFuncSetAttribute((const void*)gemm_skinny_bf16_k<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+      UVX_HIP(hipFuncSetAttribute((const void*)gemm_skinny_bf16_k<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+      attr = true;
+    }
+    if (d.swiglu || d.N >= 16384) hipLaunchKernelGGL((gemm_skinny_bf16_k<2, true>), dim3((d.N + 31) / 32), dim3(512), sh, st, a);
+    else hipLaunchKernelGGL((gemm_skinny_bf16_k<1, true>), dim3((d.N + 15) / 16), dim3(512), sh, st, a);
+    UVX_LAUNCH_CHECK();
+    return UVX_OK;
+  }
+  if (d.swiglu || d.N >= 16384) hipLaunchKernelGGL((gemm_skinny_bf16_k<2, false>), dim3((d.N + 31) / 32), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((gemm_skinny_bf16_k<1, false>), dim3((d.N + 15) / 16), dim3(512), 0, st, a);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
