@@ -92,9 +92,13 @@ def test_c4_width_generate_matches_oracle_and_teacher_forcing():
         logits = model.forward(input_ids=out, attention_mask=am_full).logits.float()
         top2 = logits.topk(2, -1).values
         margin, pred = top2[..., 0] - top2[..., 1], logits.argmax(-1)
-        # decode (KV cache, skinny GEMMs) vs the model's own teacher-forced forward, wherever the arg-max is not a bf16 coin toss
+        # decode (KV cache, skinny GEMMs) vs the model's own teacher-forced forward, wherever the arg-max is not a bf16 coin toss.
+        # Margin 8e-2 (round 4; was 5e-2): the teacher-forced pass (M = 48 / 384 rows) now ALSO runs on weight-streaming kernels
+        # (staged MFMA GEMV for M <= 64) whose K split differs from the decode step's row kernel - two bf16 pipelines with different
+        # summation orders; logits of magnitude 2-4 have a bf16 spacing of 0.016-0.03, so a margin of 0.0625 is 2-4 ulps
+        # (observed: one flip at margin 0.0625).  The rel-L2 bars against the f32 oracle below are unchanged.
         for t in range(T - 1, T + N - 1):
-            assert bool(((pred[:, t] == out[:, t + 1]) | (margin[:, t] < 5e-2)).all()), (B, t)
+            assert bool(((pred[:, t] == out[:, t + 1]) | (margin[:, t] < 8e-2)).all()), (B, t)
         with torch.no_grad():
             ref = oracle.forward(input_ids=ids, attention_mask=am)["logits"]
         keep = am.bool()

@@ -491,10 +491,11 @@ def test_gemm_fused_swiglu_epilogues_match_unfused_path(M, I, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 6144, 4096), (5, 100, 64), (16, 1028, 14336), (3, 32, 128),
-                                   (2, 8192, 28672), (4, 4096, 14336), (1, 57344, 8192), (3, 96, 576), (7, 96, 576), (9, 64, 1024)])
+                                   (2, 8192, 28672), (4, 4096, 14336), (1, 57344, 8192), (3, 96, 576), (7, 96, 576), (9, 64, 1024),
+                                   (24, 6144, 4096), (33, 1028, 14336), (64, 4096, 8192), (17, 64, 2048)])
 def test_gemm_few_rows_weight_streaming_kernel(M, N, K):
-    """M <= 16 (the decode step) runs the weight-streaming kernels (csrc/gemm_skinny.hip: the row-streaming kernel for M <= 2, the
-    MFMA mapping for 3..16): against torch, against the tiled kernels (option 4 off) and against each other (option 4 = 2) with every
+    """Few rows (the decode step) run the weight-streaming kernels (csrc/gemm_skinny.hip: the row-streaming kernel for M <= 2, the
+    MFMA mapping for 3..16 - and, with the weights staged through LDS, up to 64 rows when K % 2048 == 0): against torch, against the tiled kernels (option 4 off) and against each other (option 4 = 2) with every
     epilogue the decode path uses; K that is not a multiple of the 512-element step, ragged N, the 70B shapes."""
     from ultravox_amd import _lib
     g = torch.Generator(device=DEV).manual_seed(11)

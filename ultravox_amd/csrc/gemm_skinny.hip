@@ -31,11 +31,16 @@ struct SkinnyArgs {
 // The next step's loads are issued right after the tile has been written, so they fly during the fragment reads and MFMAs; no block
 // barrier (LDS operations of one wave execute in order).  Needs K % 2048 == 0 (each wave's K span in whole 256-element steps).
 constexpr int SKS_PITCH = 528;                    // bytes per staged row: 256 bf16 + 16 bytes of padding
-template <int TILES, bool STAGE = false>
+// MT (STAGE only): 16-row tiles of the ACTIVATION matrix served by one block - M <= 16 MT.  Every staged weight fragment is multiplied with
+// MT activation fragments, so batches up to 64 (M = 17..64 used to fall to the 128-row tiled kernels: a handful of active CUs at N = 8192)
+// stream the weights once at the same rate.
+template <int TILES, bool STAGE = false, int MT = 1>
 __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
+  static_assert(STAGE || MT == 1, "several activation row tiles: staged kernel only");
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_dyn[];      // STAGE: 8 waves x 16 x SKS_PITCH bytes (then the reduction)
   __shared__ float red_static[STAGE ? 1 : 8 * 2 * 64 * 4];
-  float (*red)[2][64][4] = reinterpret_cast<float (*)[2][64][4]>(STAGE ? reinterpret_cast<float*>(sk_dyn) : red_static);
+  float (*red)[2][MT][64][4] = reinterpret_cast<float (*)[2][MT][64][4]>(STAGE ? reinterpret_cast<float*>(sk_dyn) : red_static);
+  static_assert(!STAGE || 8 * 2 * MT * 64 * 4 * 4 <= 8 * 16 * SKS_PITCH, "reduction array fits the staging buffer");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int frow = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.x * (16 * TILES);
@@ -43,7 +48,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
   const bf16_t* b1 = p.B + (long long)min(n0 + 16 + frow, p.N - 1) * p.ldb + fg * 8;
   const bool m_ok = frow < p.M;
   const bf16_t* a0 = p.A + (long long)(m_ok ? frow : 0) * p.lda + fg * 8;
-  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
   const int nchunk = p.K / 32;
   // Which k32 chunks a wave takes.  Round 4: contiguous SPANS (wave w: chunks [w * n/8, (w + 1) * n/8)) instead of the interleave
@@ -56,36 +63,56 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
     const int lrow = lane >> 5, lk = (lane & 31) * 8;            // load mapping: instruction i brings rows 2 i + lrow, elements lk .. lk + 7
     // one (step, tile) pair at a time: its 8 row-pair loads were issued while the previous pair was being multiplied
     su32x4_t ld[8];
-    auto issue = [&](int q) {
-      const int st = q / TILES, t = q % TILES;
+    auto issue = [&](int st, int t) {
 #pragma unroll
       for (int i8 = 0; i8 < 8; ++i8) {
         const bf16_t* src = p.B + (long long)min(n0 + 16 * t + 2 * i8 + lrow, p.N - 1) * p.ldb + k_begin + st * 256 + lk;
         ld[i8] = __builtin_nontemporal_load(reinterpret_cast<const su32x4_t*>(src));
       }
     };
-    issue(0);
-    bf16x8_t xf[8];
-    for (int q = 0; q < nst * TILES; ++q) {
-      const int st = q / TILES, t = q % TILES, k0 = k_begin + st * 256;
-      if (t == 0) {
+    issue(0, 0);
+    // activation fragments: MT <= 2: the 8 chunks of a step stay in registers for both weight tiles; MT = 4: four chunks at a time,
+    // re-read (L1 / L2) for the second weight tile
+    constexpr int CH = MT <= 2 ? 8 : 4;
+    const bf16_t* am[MT];
+    bool mok[MT];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) xf[c] = m_ok ? *reinterpret_cast<const bf16x8_t*>(a0 + k0 + c * 32) : zero;
-      }
+    for (int mt = 0; mt < MT; ++mt) {
+      mok[mt] = mt * 16 + frow < p.M;
+      am[mt] = p.A + (long long)(mok[mt] ? mt * 16 + frow : 0) * p.lda + fg * 8;
+    }
+    bf16x8_t xf[MT][CH];
+    for (int st = 0; st < nst; ++st) {
+      const int k0 = k_begin + st * 256;
 #pragma unroll
-      for (int i8 = 0; i8 < 8; ++i8) *reinterpret_cast<su32x4_t*>(buf + (2 * i8 + lrow) * SKS_PITCH + lk * 2) = ld[i8];
-      if (q + 1 < nst * TILES) issue(q + 1);      // the registers are free again
+      for (int t = 0; t < TILES; ++t) {          // (compile-time tile index: the accumulators are addressed statically)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(buf + frow * SKS_PITCH + c * 64 + fg * 16);
-        if (t == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[c], acc0, 0, 0, 0);
-        else acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[c], acc1, 0, 0, 0);
+        for (int i8 = 0; i8 < 8; ++i8) *reinterpret_cast<su32x4_t*>(buf + (2 * i8 + lrow) * SKS_PITCH + lk * 2) = ld[i8];
+        // the registers are free again: the next pair's rows
+        if (t + 1 < TILES) issue(st, t + 1);
+        else if (st + 1 < nst) issue(st + 1, 0);
+#pragma unroll
+        for (int h = 0; h < 8 / CH; ++h) {
+          if (CH == 4 || t == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int c = 0; c < CH; ++c) xf[mt][c] = mok[mt] ? *reinterpret_cast<const bf16x8_t*>(am[mt] + k0 + (h * CH + c) * 32) : zero;
+          }
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(buf + frow * SKS_PITCH + (h * CH + c) * 64 + fg * 16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mt][c], acc[mt][t], 0, 0, 0);
+          }
+        }
       }
     }
     __syncthreads();            // every wave is done with its tile: the buffer becomes the reduction array
   }
+  if constexpr (!STAGE) {
   const bool span = nchunk % 8 == 0;
-  const int stride = span ? 1 : 8, end = STAGE ? 0 : (span ? (w + 1) * (nchunk / 8) : nchunk);
+  const int stride = span ? 1 : 8, end = span ? (w + 1) * (nchunk / 8) : nchunk;
   int i = span ? w * (nchunk / 8) : w;
   // UN chunks per iteration: 2-3 x UN independent 16-byte loads in flight per lane (the kernel lives on memory-level parallelism)
   constexpr int UN = TILES == 2 ? 4 : 8;
@@ -101,8 +128,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
 #pragma unroll
     for (int t = 0; t < UN; ++t) {
       const bf16x8_t xx = m_ok ? x[t] : zero;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[t], xx, acc0, 0, 0, 0);
-      if (TILES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v[t], xx, acc1, 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[t], xx, acc[0][0], 0, 0, 0);
+      if (TILES == 2) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v[t], xx, acc[0][1], 0, 0, 0);
     }
   }
   for (; i < end; i += stride) {
@@ -112,13 +139,17 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
     if (TILES == 2) v = *reinterpret_cast<const bf16x8_t*>(b1 + kk);
     const bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(a0 + kk);
     const bf16x8_t xx = m_ok ? x : zero;
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u, xx, acc0, 0, 0, 0);
-    if (TILES == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, xx, acc1, 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u, xx, acc[0][0], 0, 0, 0);
+    if (TILES == 2) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, xx, acc[0][1], 0, 0, 0);
+  }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { red[w][0][lane][e] = acc0[e]; red[w][1][lane][e] = acc1[e]; }
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[w][0][mt][lane][e] = acc[mt][0][e]; red[w][1][mt][lane][e] = acc[mt][1][e]; }
   __syncthreads();
-  if (w != 0) return;
+  if (w >= MT) return;          // wave mt finishes activation row tile mt
+  const int mt = w;
   float s[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -126,10 +157,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
     for (int e = 0; e < 4; ++e) {
       float t = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < 8; ++ww) t += red[ww][j][lane][e];     // fixed order: deterministic
+      for (int ww = 0; ww < 8; ++ww) t += red[ww][j][mt][lane][e];     // fixed order: deterministic
       s[j][e] = t * p.alpha;
     }
-  const int m = frow;
+  const int m = mt * 16 + frow;
   if (m >= p.M) return;
   if (p.swiglu) {    // tile 0 = 16 gate columns, tile 1 = the matching up columns (interleaved packing, weights.py)
     const int n = n0 + fg * 4;
@@ -403,7 +434,9 @@ int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm
 }
 
 bool gemm_skinny_applicable(const GemmDesc& d) {
-  return d.M > 0 && d.M <= 16 && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 &&
+  // (M = 17..64: only the staged kernel serves several activation row tiles)
+  const bool rows_ok = d.M <= 16 || (d.M <= 64 && d.K % 2048 == 0 && uvx::g_options[4] != 2);
+  return d.M > 0 && rows_ok && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 &&
          d.K % 32 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.N % 4 == 0 && d.ldc % 4 == 0 &&
          (!d.swiglu || (d.N % 32 == 0 && d.ldc2 % 4 == 0)) && (!d.residual || d.ldr % 4 == 0) && uvx::g_options[4];
 }
@@ -436,14 +469,16 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
   }
   if (d.K % 2048 == 0 && uvx::g_options[4] != 2) {      // weights through a wave-private LDS tile (option 4 = 2: straight fragment loads, A/B)
     constexpr size_t sh = 8 * 16 * SKS_PITCH;             // 67.6 KB: two blocks per CU
-    static bool attr = false;
-    if (!attr) {
-      UVX_HIP(hipFuncSetAttribute((const void*)gemm_skinny_bf16_k<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-      UVX_HIP(hipFuncSetAttribute((const void*)gemm_skinny_bf16_k<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-      attr = true;
-    }
-    if (d.swiglu || d.N >= 16384) hipLaunchKernelGGL((gemm_skinny_bf16_k<2, true>), dim3((d.N + 31) / 32), dim3(512), sh, st, a);
-    else hipLaunchKernelGGL((gemm_skinny_bf16_k<1, true>), dim3((d.N + 15) / 16), dim3(512), sh, st, a);
+    const bool two = d.swiglu || d.N >= 16384;
+    const dim3 grid(two ? (d.N + 31) / 32 : (d.N + 15) / 16);
+#define UVX_SKS(TT, MTT) do { \
+      static bool attr2 = false; \
+      if (!attr2) { UVX_HIP(hipFuncSetAttribute((const void*)gemm_skinny_bf16_k<TT, true, MTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); attr2 = true; } \
+      hipLaunchKernelGGL((gemm_skinny_bf16_k<TT, true, MTT>), grid, dim3(512), sh, st, a); } while (0)
+    if (d.M <= 16) { if (two) UVX_SKS(2, 1); else UVX_SKS(1, 1); }
+    else if (d.M <= 32) { if (two) UVX_SKS(2, 2); else UVX_SKS(1, 2); }
+    else { if (two) UVX_SKS(2, 4); else UVX_SKS(1, 4); }
+#undef UVX_SKS
     UVX_LAUNCH_CHECK();
     return UVX_OK;
   }
