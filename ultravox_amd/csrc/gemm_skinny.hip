@@ -72,7 +72,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
     };
     issue(0, 0);
     // activation fragments: MT <= 2: the 8 chunks of a step stay in registers for both weight tiles; MT = 4: four chunks at a time,
-    // re-read (L1 / L2) for the second weight tile
+    // re-read (L1 / L2) for the second weight tile.  (Two chunks at a time at MT = 2 - 126 instead of 164 VGPRs, two blocks per CU - was
+    // measured SLOWER: 44.3 vs 39.6 ms per 70B token at B = 32: the re-reads cost more than the occupancy buys.)
     constexpr int CH = MT <= 2 ? 8 : 4;
     const bf16_t* am[MT];
     bool mok[MT];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
         else if (st + 1 < nst) issue(st + 1, 0);
 #pragma unroll
         for (int h = 0; h < 8 / CH; ++h) {
-          if (CH == 4 || t == 0) {
+          if (CH < 8 || t == 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
