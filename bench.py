@@ -386,6 +386,9 @@ def main():
     ap.add_argument("--loss", default="ce", choices=["ce", "kl"],
                     help="ce = the BASELINE.json configuration; kl = LossFunction.KL_Divergence (the reference's meta_config.yaml "
                          "default): a text-only teacher pass over alt_input_ids (audio replaced by a 48-token transcript)")
+    ap.add_argument("--no-kl-side-stream", action="store_true",
+                    help="--loss kl: keep the text-only teacher pass on the step's own stream (default: a side stream next to the encoder and the "
+                         "student forward - same kernels, identical results; A/B switch)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: sequential all-reduce + optimizer step (no overlap)")
     ap.add_argument("--comm", default="torch", choices=["torch", "abi"],
                     help="N > 1: gradient exchange through torch.distributed (RCCL; default) or through libuvx.so's own RCCL "
@@ -482,6 +485,7 @@ def main():
     if args.loss == "kl":
         from ultravox_amd.config import LossConfig, LossFunction
         model.set_loss_config(LossConfig(loss_function=LossFunction.KL_Divergence))
+        model.kl_teacher_side_stream = not args.no_kl_side_stream
         ids, Na = batch["input_ids"], int(batch["audio_token_len"][0])
         g = torch.Generator().manual_seed(777 + rank)
         tr = torch.randint(0, cfg.text_config.vocab_size - 1, (B, 48), generator=g)

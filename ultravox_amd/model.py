@@ -10,8 +10,9 @@ step (loss -> backward -> DP mean of projector grads -> clip 1.0 -> AdamW), SURV
 """
 from __future__ import annotations
 
-import os
+import contextlib
 import ctypes as C
+import os
 import dataclasses
 import json
 from typing import Dict, List, Optional
@@ -696,12 +697,21 @@ class UltravoxModel:
             if self.loss_config.loss_function != LossFunction.KL_Divergence:
                 raise ValueError(f"Unsupported loss function: {self.loss_config.loss_function}")
             use_kl = True
+        kl_ctx = None
+        if (use_kl and getattr(self, "kl_teacher_side_stream", True) and self.device.type == "cuda" and self.dtype == torch.bfloat16
+                and not return_logits and self.text_lora_r == 0 and labels is not None and alt_input_ids is not None and alt_labels is not None):
+            # the teacher pass depends on the text-only view alone: it starts NOW, on a side stream, next to the encoder, the projector
+            # and the student forward (see _kl_teacher_launch)
+            kl_ctx = self._kl_teacher_launch(labels, alt_input_ids, alt_attention_mask, alt_labels)
         if audio_values is not None and len(audio_values) > 0:
             inputs_embeds = self._prepare_audio_embeds(inputs_embeds, input_ids, audio_values, audio_token_start_idx,
                                                        audio_lens, audio_token_len, audio_batch_size)
         elif inputs_embeds is None:
             B, T = input_ids.shape
             inputs_embeds = self._embed_merge(None, input_ids, None, None, None, None, B, T)
+        if kl_ctx is not None:
+            return self._kl_forward_rows(inputs_embeds, attention_mask, alt_input_ids, alt_attention_mask, kl_ctx["pair_row"],
+                                         kl_ctx["pair_w"], teacher=kl_ctx)
         if not use_kl:
             return self.language_model_forward(inputs_embeds, labels=labels, attention_mask=attention_mask,
                                                want_logits=return_logits, save_for_bwd=_save_for_bwd)
@@ -847,31 +857,55 @@ class UltravoxModel:
         self._llm_ctx = (B, T, nb, None)     # uvx_llm_bwd(labels = NULL): gradient already in place of the logits
         return CausalLMOutputWithPast(loss=loss[0], logits=out.logits)
 
-    def _kl_forward_rows(self, inputs_embeds, attention_mask, alt_input_ids, alt_attention_mask, pair_row, pair_w):
-        """The KL step with both LM heads restricted to the rows that enter the loss (prediction / end-of-turn positions):
-        identical loss and gradients, ~10x less head and KL-kernel work than full [B, T, V] logits for teacher and student."""
+    def _kl_teacher_launch(self, labels, alt_input_ids, alt_attention_mask, alt_labels, pair=None) -> Optional[dict]:
+        """The teacher half of the compact-rows KL step: host row pairs, the text-only embedding lookup and uvx_llm_fwd_rows(teacher).
+        The teacher pass is independent of the student's (frozen LLM, no gradient) and of the audio path: with kl_teacher_side_stream
+        (default) it is issued on a side stream - as early as forward() can, before the encoder - and its GEMMs (1408 rows at C2: 96-176
+        tiles, less than one round of the 256 CUs) fill the CUs the other stream's partly filled rounds leave idle: -6.5 ms per C2 step
+        (profiles/r04_kl_side_stream_ab.txt).  Same kernels in the same order per stream: identical results.  None: nothing to pair."""
         l = _lib.lib()
         dev = self.device
         V = self.config.vocab_size
+        pair_row, pair_w, n_pred = pair if pair is not None else kl_row_pairs(labels, alt_labels, self.loss_config.eot_loss_weight)
+        if n_pred == 0:
+            return None
         rows_s, rows_t, pair_c, pw = kl_compact_pairs(pair_row, pair_w)
         ns, nt = int(rows_s.numel()), int(rows_t.numel())
         rows_s, rows_t, pair_c, pw = rows_s.to(dev), rows_t.to(dev), pair_c.to(dev), pw.to(dev)
         Bt, Tt = alt_input_ids.shape
-        student_merge = self._merge_ctx
-        alt_embeds = self._embed_merge(None, alt_input_ids, None, None, None, None, Bt, Tt)
-        self._merge_ctx = student_merge
+        student_merge = self.__dict__.get("_merge_ctx")
+        alt_embeds = self._embed_merge(None, alt_input_ids, None, None, None, None, Bt, Tt).contiguous()
+        self._merge_ctx = student_merge          # the teacher's plain embedding lookup must not replace the student's merge context
         nbt = l.uvx_llm_ws_bytes(C.byref(self._c), Bt, Tt, 0)
         wst = self._workspace("llm_teacher", nbt)
         t_logits = self._workspace("teacher_logits", nt * V * 2).view(self.dtype)[: nt * V]
         am = None if alt_attention_mask is None else alt_attention_mask.to(device=dev, dtype=torch.int64).contiguous()
-        check(l.uvx_llm_fwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(alt_embeds.contiguous()), ptr(am), Bt, Tt,
-                                 ptr(rows_t), nt, ptr(t_logits), 0, ptr(wst), C.c_size_t(nbt)), "uvx_llm_fwd_rows")
+        side = None
+        if getattr(self, "kl_teacher_side_stream", True) and dev.type == "cuda":
+            side = self.__dict__.setdefault("_kl_side", torch.cuda.Stream(device=dev))
+            side.wait_stream(torch.cuda.current_stream(dev))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            check(l.uvx_llm_fwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(alt_embeds), ptr(am), Bt, Tt,
+                                     ptr(rows_t), nt, ptr(t_logits), 0, ptr(wst), C.c_size_t(nbt)), "uvx_llm_fwd_rows")
+        return dict(pair_row=pair_row, pair_w=pair_w, rows_s=rows_s, ns=ns, pair_c=pair_c, pw=pw, t_logits=t_logits, side=side,
+                    keep=(alt_embeds, am, rows_t))       # (tensors the side stream reads stay referenced until the join)
+
+    def _kl_forward_rows(self, inputs_embeds, attention_mask, alt_input_ids, alt_attention_mask, pair_row, pair_w, teacher=None):
+        """The KL step with both LM heads restricted to the rows that enter the loss (prediction / end-of-turn positions):
+        identical loss and gradients, ~10x less head and KL-kernel work than full [B, T, V] logits for teacher and student."""
+        l = _lib.lib()
+        dev = self.device
+        if teacher is None:
+            teacher = self._kl_teacher_launch(None, alt_input_ids, alt_attention_mask, None, pair=(pair_row, pair_w, 1))
+        rows_s, ns, pair_c, pw, t_logits, side = (teacher[k] for k in ("rows_s", "ns", "pair_c", "pw", "t_logits", "side"))
         B, T, D = inputs_embeds.shape
         nb = l.uvx_llm_ws_bytes(C.byref(self._c), B, T, 1)
         ws = self._workspace("llm", nb)
         ams = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         check(l.uvx_llm_fwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(ams), B, T,
                                  ptr(rows_s), ns, None, 1, ptr(ws), C.c_size_t(nb)), "uvx_llm_fwd_rows")
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
         loss = torch.zeros(1, device=dev, dtype=torch.float32)
         check(l.uvx_llm_kl_loss_rows(stream_ptr(), C.byref(self._c), ptr(t_logits), ptr(pair_c), ptr(pw), B, T, ns,
                                      C.c_float(self.loss_config.kl_temperature), C.c_float(self._kl_grad_scale), ptr(loss),
