@@ -565,6 +565,39 @@ def test_gemm_with_fused_rmsnorm_matches_the_two_launches(M, N, K, flavor, swigl
         assert rel_l2(got, (ref + bias.float())) < 5e-3
 
 
+@pytest.mark.parametrize("variant", [43, 49, 55])
+def test_hand_scheduled_gemm_loops_are_bit_identical_to_the_production_kernel(variant):
+    """Round 4's inline-asm K loops (43 = four waves x 128 x 128, 49 = eight free-running waves, 55 = eight waves ping-pong; generated by
+    tools/gen_gemm_a4.py) share the production kernel's MFMA, operand roles and k order: every epilogue they serve is BIT-identical to the
+    merged-phase 256 x 256 kernel (variant 31) on ragged / one-K-tile / deep-K shapes, and repeated launches are bit-identical (the
+    full screen, 12 shapes x 7 epilogues x 30 repeats, is tools/gpu_gemm_a4_check.py)."""
+    from ultravox_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(variant)
+
+    def run(v, fn):
+        L.uvx_gemm_force_variant(v)
+        try:
+            return fn()
+        finally:
+            L.uvx_gemm_force_variant(-1)
+
+    for (M, N, K) in [(256, 256, 64), (300, 520, 192), (2528, 4096, 256), (1000, 1032, 640), (2528, 6144, 4096)]:
+        a = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+        b = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
+        bias = torch.randn(N, device=DEV, generator=g).bfloat16()
+        resid = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+        modes = {"plain": lambda: ops().gemm(a, b), "bias+res": lambda: ops().gemm(a, b, bias=bias, residual=resid),
+                 "bias+gelu": lambda: ops().gemm(a, b, bias=bias, act="gelu"), "f32": lambda: ops().gemm(a, b, out_f32=True)}
+        for name, fn in modes.items():
+            want, got = run(31, fn), run(variant, fn)
+            assert torch.equal(got, want), (variant, (M, N, K), name, int((got != want).sum()))
+        first = run(variant, modes["plain"])
+        for _ in range(5):
+            assert torch.equal(run(variant, modes["plain"]), first), (variant, (M, N, K), "repeat")
+        assert rel_l2(first, a.float() @ b.float().t()) < 5e-3
+
+
 def test_lds_transpose_read_semantics():
     """ds_read_b64_tr_b16 (gfx950), the instruction the bf16 attention kernels use to read V^T / Q^T / K^T / dO^T out of the
     natural [row][d] LDS tiles: every lane supplies the address of one 8-byte chunk; within each group of 16 lanes, result
