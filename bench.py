@@ -91,6 +91,17 @@ def llm_weight_bytes(cfg) -> float:
     return 2.0 * (L * (qkv + o + 3 * D * I) + V * D)
 
 
+def pmc_decode_traffic_per_token(profiles_dir=None):
+    """roofline.traffic of `--workload c4`: memory-side read bytes of the decode GEMVs per token from the newest committed PMC summary
+    (profiles/rNN_pmc_decode_traffic.json, written from tools/pmc_decode_traffic.sh's separate FETCH_SIZE pass), or None."""
+    d = profiles_dir or os.path.join(ROOT, "profiles")
+    try:
+        names = sorted(n for n in os.listdir(d) if n.startswith("r") and n.endswith("_pmc_decode_traffic.json"))
+        return json.load(open(os.path.join(d, names[-1]))).get("traffic_bytes_per_token") if names else None
+    except (OSError, ValueError):
+        return None
+
+
 def run_inference(args, wl, dev) -> None:
     """`--workload c4 / c4s`: a "step" = one generate() call (encoder + projector + prefill + new_tokens greedy decode steps) on B
     prompts resident in HBM.  Prefill is also timed alone (max_new_tokens = 1) so that decode ms/token = (whole - prefill) / (new - 1).
@@ -161,7 +172,8 @@ def run_inference(args, wl, dev) -> None:
         "prefill_ms": t_prefill * 1e3, "decode_ms_per_token": ms_tok, "decode_tokens_per_sec": B * world / (ms_tok * 1e-3),
         "resident_gib": torch.cuda.memory_allocated() / 2 ** 30,
         "roofline": {"bound": "hbm", "kernel": "decode step: gemv_rows_bf16_k / gemm_skinny_bf16_k weight streaming (all layers + LM head)",
-                     "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                     "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                     "traffic": pmc_decode_traffic_per_token() if args.workload == "c4" and B == 1 else None,
                      "algorithmic_bytes_per_token": wbytes,
                      "note": "achieved = LLM weight bytes / WHOLE decode step time (attention, norms, RoPE, sampling included in the time, not in the bytes)"},
         "output_shape": list(out.shape)}))
