@@ -3,7 +3,7 @@
 //   M <= 2            gemv_rows_bf16_k       row streaming (1 KiB contiguous non-temporal weight reads), v_dot2c arithmetic, optional fused RMSNorm
 //   M = 3..64         gemm_skinny_bf16_k<.., STAGE>  MFMA, weights through a wave-private LDS tile (K % 2048 == 0)
 //   otherwise M <= 16 gemm_skinny_bf16_k     MFMA, fragments straight from global memory (round 2's kernel, K-span mapping since round 4)
-// Measured on Llama-3.3-70B's decode step (ms per token, B = 1 / 8 / 32): 36.0 / 37.9 / 87 before round 4, 24.1 / 26.4 / 39.6 after.
+// Measured on Llama-3.3-70B's decode step (ms per token, B = 1 / 8 / 32): 36.0 / 37.9 / 87 before round 4, 23.0 / 25.6 / 39.6 after.
 //
 // C[M, N] = epilogue(A[M, K] . B[N, K]^T).  With so few rows the product is weight streaming: every element of B is read
 // once and multiplied by M values, so the kernel is HBM-bound and the tiled kernels (128-row tiles, a handful of active

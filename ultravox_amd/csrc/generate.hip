@@ -195,7 +195,9 @@ template <typename T, int D, int G, int NTH>
 __global__ __launch_bounds__(NTH) void attn_decode_grp_k(const T* __restrict__ qkv, const T* __restrict__ cache_k,
                                                          const T* __restrict__ cache_v, T* __restrict__ out,
                                                          const int32_t* __restrict__ kv_start, int Hq, int Hkv, int Tmax,
-                                                         int len, int QKV, float scale, int lo_clamp) {
+                                                         int len, int QKV, float scale, int lo_clamp, int hsplit) {
+  // hsplit: the query heads of a KV head are dealt to `hsplit` blocks of G heads each (G = group size / hsplit): at batch 1 a 70B
+  // decode step had 8 blocks of 8 heads - 20 us of latency on 8 of 256 CUs; 64 blocks of one head re-read K / V from L2 and finish sooner
   extern __shared__ float sc[];                 // [G][len]
   __shared__ float qs[G][D];
   __shared__ float red[NTH * 8];                // phase 3 partial sums: [residue class][query head][dimension]
@@ -206,13 +208,13 @@ __global__ __launch_bounds__(NTH) void attn_decode_grp_k(const T* __restrict__ q
   constexpr int ITEMS = G * D / 8;              // (query head, 8-dimension chunk) pairs of the block
   constexpr int KS = NTH / ITEMS;               // key residue classes in phase 3
   static_assert(NTH % ITEMS == 0 && ITEMS <= NTH, "block size vs outputs");
-  const int b = blockIdx.x / Hkv, hk = blockIdx.x % Hkv;
+  const int b = blockIdx.x / (Hkv * hsplit), hq0 = (blockIdx.x % (Hkv * hsplit)) * G, hk = hq0 / (G * hsplit);   // first query head, KV head
   const int tid = threadIdx.x, ch = tid % CH, kl = tid / CH, lane = tid & 63, w = tid >> 6;
   const int j0 = max(kv_start ? kv_start[b] : 0, lo_clamp);
   const int KVD = Hkv * D;
   const T* kbase = cache_k + (long long)b * Tmax * KVD + hk * D + ch * 8;
   const T* vbase = cache_v + (long long)b * Tmax * KVD + hk * D;
-  for (int i = tid; i < G * D; i += NTH) qs[i / D][i % D] = ldf<T>(qkv + (long long)b * QKV + (hk * G + i / D) * D + i % D);
+  for (int i = tid; i < G * D; i += NTH) qs[i / D][i % D] = ldf<T>(qkv + (long long)b * QKV + (hq0 + i / D) * D + i % D);
   __syncthreads();
   // ---- phase 1: scores (two passes of keys in flight per trip) ----
   {
@@ -292,21 +294,21 @@ __global__ __launch_bounds__(NTH) void attn_decode_grp_k(const T* __restrict__ q
     float t = 0.f;
     for (int q2 = 0; q2 < KS; ++q2) t += red[q2 * ITEMS * 8 + o];
     const float l = stat[o / D];
-    stf<T>(out + (long long)b * Hq * D + hk * G * D + o, l > 0.f ? t / l : 0.f);
+    stf<T>(out + (long long)b * Hq * D + hq0 * D + o, l > 0.f ? t / l : 0.f);
   }
 }
 
 // launch helper: static LDS (~36 KB) + the dynamic score array (<= 48 KB) exceed the 64 KB a launch gets by default
 template <int DD, int GG>
 int launch_decode_grp(hipStream_t st, size_t sh, int blocks, const bf16_t* qkv, const bf16_t* ck, const bf16_t* cv, bf16_t* o,
-                      const int32_t* kv_start, int Hq, int Hkv, int Tmax, int len, int QKV, float scale, int lo) {
+                      const int32_t* kv_start, int Hq, int Hkv, int Tmax, int len, int QKV, float scale, int lo, int hsplit) {
   static bool attr_set = false;
   if (!attr_set) {
     UVX_HIP(hipFuncSetAttribute((const void*)attn_decode_grp_k<bf16_t, DD, GG, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL((attn_decode_grp_k<bf16_t, DD, GG, 1024>), dim3(blocks), dim3(1024), sh, st, qkv, ck, cv, o, kv_start, Hq, Hkv, Tmax, len,
-                     QKV, scale, lo);
+                     QKV, scale, lo, hsplit);
   return UVX_OK;
 }
 
@@ -661,9 +663,13 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
       } else {
         hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
       }
-      const int G = Hq / Hkv, len = cur_len + 1;
+      const int Gall = Hq / Hkv, len = cur_len + 1;
+      // query heads of a KV head per block: split the group until ~256 blocks are in flight (powers of two that divide the group)
+      int hsplit = 1;
+      while (hsplit * 2 <= Gall && Gall % (hsplit * 2) == 0 && B * Hkv * hsplit < 256) hsplit *= 2;
+      const int G = Gall / hsplit;
       const size_t sh = sizeof(float) * (size_t)G * len;
-#define UVX_DEC(DD, GG) RC((launch_decode_grp<DD, GG>(st, sh, B * Hkv, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale, lo)))
+#define UVX_DEC(DD, GG) RC((launch_decode_grp<DD, GG>(st, sh, B * Hkv * hsplit, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale, lo, hsplit)))
       if (sh <= 48 * 1024 && dh == 128 && G == 4) UVX_DEC(128, 4);
       else if (sh <= 48 * 1024 && dh == 128 && G == 8) UVX_DEC(128, 8);
       else if (sh <= 48 * 1024 && dh == 128 && G == 2) UVX_DEC(128, 2);
