@@ -87,3 +87,17 @@ def test_decode_roofline_numerator_is_the_llm_weight_stream():
     b = bench.llm_weight_bytes(cfg)
     assert abs(b - 2 * (80 * ((64 + 16) * 128 * 8192 + 8192 * 8192 + 3 * 8192 * 28672) + 128256 * 8192)) < 1
     assert 138e9 < b < 140e9
+
+
+def test_decode_traffic_lookup_reads_the_committed_pmc_summary(tmp_path):
+    """`bench.py --workload c4` reports roofline.traffic from the newest profiles/rNN_pmc_decode_traffic.json and never raises."""
+    import json
+    import bench
+    assert bench.pmc_decode_traffic_per_token(str(tmp_path)) is None
+    (tmp_path / "r03_pmc_decode_traffic.json").write_text(json.dumps({"traffic_bytes_per_token": 1.0}))
+    (tmp_path / "r04_pmc_decode_traffic.json").write_text(json.dumps({"traffic_bytes_per_token": 2.5}))
+    assert bench.pmc_decode_traffic_per_token(str(tmp_path)) == 2.5
+    (tmp_path / "r05_pmc_decode_traffic.json").write_text("not json")
+    assert bench.pmc_decode_traffic_per_token(str(tmp_path)) is None
+    got = bench.pmc_decode_traffic_per_token()          # the committed record: within 1 % of the weight bytes of Llama-3.3-70B
+    assert got is not None and abs(got / 139003428864.0 - 1.0) < 0.01
