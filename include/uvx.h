@@ -399,9 +399,10 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
 /* probes (same-box A/B inside bench.py): key 1 = 16-byte epilogue loads/stores (default 1), key 2 = SwiGLU backward fused
  * into the down-projection dgrad GEMM (0 = separate kernel, 1 = round 2's fragment-layout epilogue (measured neutral),
  * 2 = whole-line epilogue through the LDS stage (round 3)), key 3 = LM head / CE / head dgrad on the supervised
- * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernel for
- * problems of at most 16 rows (the decode step; default 1: row-streaming kernel for M <= 2, MFMA mapping for 3..16; 2 = MFMA mapping with straight fragment loads for
- * every M <= 16, the round-2 kernel, for A/B; 0 = the tiled kernels), key 5 = the streamed weight transposes (llm_wt_stream) use plain instead of
+ * rows only (default 1; must not change between uvx_llm_fwd and uvx_llm_bwd), key 4 = weight-streaming GEMM kernels for
+ * few-row problems (the decode step; default 1: row-streaming kernel for M <= 2, MFMA kernel with the weights staged through LDS for
+ * M = 3..64 when K % 2048 == 0, straight fragment loads for other M <= 16; 2 = straight fragment loads for every M <= 16 - round 2's
+ * kernel - and the tiled kernels above, for A/B; 0 = the tiled kernels), key 5 = the streamed weight transposes (llm_wt_stream) use plain instead of
  * non-temporal loads / stores (default 0), key 11 = number of LLM layer chains: the batch
  * is cut into that many slices whose layer chains run on as many streams (default 1 = one chain on the caller's stream, at most 4; which of 1 / 2 is
  * faster depends on the box: UltravoxTrainer.autotune_schedule times both; uvx_llm_fwd* / uvx_llm_bwd*: same kernels on the same rows, bit-identical results; the side streams are
