@@ -221,7 +221,7 @@ def cpu_baseline(cfg, seconds: float, n_text: int = 128):
     log-mel + conv stem + 2 encoder layers, the projector, 1 LLM layer (fwd + bwd) and the lm_head + CE
     (fwd + bwd); per-layer times are scaled to the real layer counts."""
     from oracle import reference_cpu as O
-    from ultravox_amd.config import AudioConfig, TextConfig, UltravoxConfig
+    from ultravox_amd.config import UltravoxConfig
     import dataclasses
 
     # Thread count: the GPU boxes expose 256 hardware threads, but torch's CPU GEMM peaks far below that

@@ -14,7 +14,6 @@ import math
 import sys
 import types
 
-import torch
 from torch import nn
 
 

@@ -1,7 +1,6 @@
 """bench.py's host-side definitions, checked without a GPU: the algorithmic FLOP count against SURVEY.md §8(d)'s figures
 for C2 / C3 and the lookup of the committed PMC traffic summary."""
 import json
-import os
 
 import pytest
 

@@ -13,7 +13,6 @@ skipped below 48 GB.
 
 Second test: the f32 compute mode (north_star's "logits within 1e-3") at the C2 WIDTH - the real tile shapes of the exact-f32
 matrix-core GEMM (K = 4096 / 14336, N = 128256) - at depth 2."""
-import os
 import time
 
 import pytest

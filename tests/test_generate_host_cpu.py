@@ -3,7 +3,6 @@ streamer protocol, repetition penalty — exercised on the CPU against a tiny SI
 makes are replaced by torch stand-ins whose "logits" depend on every cached row, its position and the left padding, so a
 row that is missing, misplaced or stale changes the generated tokens.  (This is a test double for the library, not a
 fallback: the product never runs without libuvx; the device kernels themselves are checked in tests/test_generate_gpu.py.)"""
-import ctypes as C
 import types
 
 import pytest

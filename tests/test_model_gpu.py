@@ -282,7 +282,6 @@ def test_loss_head_on_supervised_rows_split_k(T, first_label):
     labels = torch.randint(0, 4096, (B, T)); labels[:, :first_label] = -100
     labels[1, T - 5:] = -100                                   # ragged supervision
     out = model.language_model_forward(emb.to(DEV), labels=labels.to(DEV), want_logits=False, save_for_bwd=True)
-    import ctypes as C
     from ultravox_amd import _lib
     d = model.language_model_backward(1.0)        # uvx_llm_bwd_train: pairs with the forward above
     e = emb.float().requires_grad_(True)

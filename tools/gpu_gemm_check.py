@@ -1,7 +1,7 @@
 """GPU probe: GEMM correctness (transpose-detecting, asymmetric data) + throughput on hot-path shapes."""
 import os
 os.environ.setdefault("UVX_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ultravox_amd", "libuvx_probes.so"))  # probe tile variants live in the probes build
-import json, sys, time
+import json
 import torch
 from ultravox_amd import ops
 

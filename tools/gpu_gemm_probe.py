@@ -2,7 +2,7 @@
 hot-path shapes, interleaved in one process (within-probe A/B)."""
 import os
 os.environ.setdefault("UVX_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ultravox_amd", "libuvx_probes.so"))  # probe tile variants live in the probes build
-import json, sys
+import json
 import torch
 from ultravox_amd import ops, _lib
 

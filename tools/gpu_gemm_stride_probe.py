@@ -2,7 +2,7 @@
 Same GEMM, weight (and/or activation) rows padded by a few hundred bytes."""
 import os
 os.environ.setdefault("UVX_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ultravox_amd", "libuvx_probes.so"))  # probe tile variants live in the probes build
-import torch, json
+import torch
 from ultravox_amd import ops, _lib
 L = _lib.lib(); dev = "cuda"
 def timeit(fn, iters=10):

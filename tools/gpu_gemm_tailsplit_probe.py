@@ -6,9 +6,9 @@ Arms, cold weights (a pool of weight matrices, as tools/gpu_gemm_cold_probe.py):
            s ways into f32 partials (s x tail tiles ~ one round) + a reduction (here torch's sum + cast as a stand-in for a fused kernel)
   main / tail / reduce - the three parts alone."""
 import ctypes as C
-import sys
+
 import torch
-from ultravox_amd import _lib, ops
+from ultravox_amd import _lib
 from ultravox_amd._lib import check
 from ultravox_amd.ops import stream_ptr
 

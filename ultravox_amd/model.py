@@ -15,7 +15,7 @@ import ctypes as C
 import os
 import dataclasses
 import json
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 

@@ -10,7 +10,7 @@ GPU; any object with the HF feature-extractor call contract works).
 from __future__ import annotations
 
 import math
-from typing import Any, Dict, List, Optional, Sequence, Union
+from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
