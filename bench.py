@@ -1,6 +1,6 @@
 """bench.py — adapter-train step of the Ultravox audio->LLM hot path on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py                                         # = --gpus 1 --steps 10 --warmup 5
     python bench.py --gpus 8 --steps 20 --warmup 5          # launches its own 8 ranks (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -381,8 +381,10 @@ def self_launch(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5,
+                    help="untimed steps first; fewer than ~4 leave the clock / power ramp of a just-initialised GPU inside the timed region "
+                         "(5 timed + 2 warm-up steps read 10-25 %% slow, profiles/r04_bench_short_run_bias.txt)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--stream-wt", default="auto", choices=["auto", "on", "off"],
                     help="transposed weight copies of the frozen LLM for the backward pass: made on the fly on a side stream (on), resident (off), "
