@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 13
+#define UVX_ABI_VERSION 14
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -388,6 +388,19 @@ typedef struct {
 } uvx_gemm_desc_t;
 /* C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual — torch.nn.Linear semantics. */
 int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* desc);
+/* uvx_gemm for problems of a few hundred rows (round 5: the prefill of generate() - one or two prompts of 30 s of audio + text are
+ * 316 / 632 rows, [3P] language_model.generate's first forward, ultravox_model.py:398-426): with 160- / 256-row tiles such a problem has
+ * fewer tiles than the chip has CUs, so the K loop of every tile is cut over `s` blocks (tiles x s ~ one round of the 256 CUs) that
+ * write f32 partial tiles into `workspace`, and one more kernel sums them in a fixed order (bit-reproducible) and applies the epilogue
+ * with uvx_gemm's arithmetic and rounding points.  Results agree with uvx_gemm to f32 summation order.  bf16, batch 1, N % 8 == 0 and
+ * 16-byte-aligned operands; anything else (and every problem the cost model would not split) runs exactly as uvx_gemm.
+ * force_split: 0 = the cost model decides, 1 = never split, s > 1 = split by s (tests / probes).  workspace: uvx_gemm_splitk_ws_bytes(M, N)
+ * bytes (at most 128 MiB), caller-owned, free for reuse once the call's work has run.  uvx_llm_prefill* take theirs from their workspace. */
+size_t uvx_gemm_splitk_ws_bytes(int32_t M, int32_t N);
+int32_t uvx_gemm_splitk(void* stream, int32_t dtype, const uvx_gemm_desc_t* desc, void* workspace, size_t ws_bytes, int32_t force_split);
+/* host only (no GPU work): the split factor (1 = none) the cost model picks for a bf16 problem with `ws_bytes` of scratch; *variant
+ * (may be NULL) receives the tile variant */
+int32_t uvx_gemm_pick_split(int32_t M, int32_t N, int32_t K, size_t ws_bytes, int32_t* variant);
 /* probes/tests: force the bf16 GEMM tile variant (-1 auto, 0 = 128x128, 1..4 = {128,160,192,256} x 256) */
 int32_t uvx_gemm_force_variant(int32_t variant);
 /* C = epilogue(RMSNorm(A; norm_w, eps) . B^T) - LlamaRMSNorm (flavor 0) / GemmaRMSNorm (1) feeding an nn.Linear, the pair the

@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 13  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+ABI_VERSION = 14  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
 
 
 def lib() -> C.CDLL:
@@ -187,6 +187,7 @@ EXPORTS = [
     "uvx_llm_fwd_rows", "uvx_llm_kl_loss_rows", "uvx_llm_bwd_rows", "uvx_llm_fwd_lora", "uvx_llm_bwd_lora",
     "uvx_llm_fwd_train", "uvx_llm_bwd_train", "uvx_gemm_streamk_timeouts",
     "uvx_wav2vec2_frames", "uvx_wav2vec2_ws_bytes", "uvx_wav2vec2_fwd",
+    "uvx_gemm_splitk_ws_bytes", "uvx_gemm_splitk", "uvx_gemm_pick_split",
     "uvx_comm_unique_id", "uvx_comm_init", "uvx_comm_world_size", "uvx_comm_version", "uvx_comm_allreduce_f32", "uvx_comm_destroy",
 ]
 
@@ -194,7 +195,7 @@ EXPORTS = [
 def _declare(l: C.CDLL) -> None:
     for name in ("uvx_encoder_ws_bytes", "uvx_projector_ws_bytes", "uvx_llm_ws_bytes", "uvx_attention_ws_bytes",
                  "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes", "uvx_llm_prefill_chunk_ws_bytes", "uvx_encoder_train_ws_bytes",
-                 "uvx_wav2vec2_ws_bytes"):
+                 "uvx_wav2vec2_ws_bytes", "uvx_gemm_splitk_ws_bytes"):
         getattr(l, name).restype = C.c_size_t
     for name in EXPORTS:
         f = getattr(l, name)

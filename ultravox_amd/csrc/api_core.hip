@@ -70,6 +70,30 @@ extern "C" int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* 
   return uvx::gemm((hipStream_t)stream, dtype, d);
 }
 
+// uvx_gemm with split-K scratch (the prefill's few-hundred-row GEMMs; gemm.hip "Split-K"): same result contract as uvx_gemm
+extern "C" size_t uvx_gemm_splitk_ws_bytes(int32_t M, int32_t N) { return M > 0 && N > 0 ? uvx::gemm_splitk_ws_bytes(M, N) : 0; }
+extern "C" int32_t uvx_gemm_pick_split(int32_t M, int32_t N, int32_t K, size_t ws_bytes, int32_t* variant) {
+  int v = 0;
+  const int s = uvx::gemm_pick_split(M, N, K, ws_bytes, &v);
+  if (variant) *variant = v;
+  return s;
+}
+extern "C" int32_t uvx_gemm_splitk(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, void* workspace, size_t ws_bytes, int32_t force_split) {
+  UVX_CHECK(g != nullptr, UVX_ERR_INVALID, "uvx_gemm_splitk: null descriptor");
+  UVX_CHECK(force_split >= 0, UVX_ERR_INVALID, "uvx_gemm_splitk: force_split %d (0 = automatic, 1 = never, s = that factor)", force_split);
+  uvx::GemmDesc d;
+  d.A = g->A; d.B = g->B; d.C = g->C; d.bias = g->bias; d.residual = g->residual;
+  d.M = g->M; d.N = g->N; d.K = g->K;
+  d.lda = g->lda; d.ldb = g->ldb; d.ldc = g->ldc; d.ldr = g->ldr;
+  d.res_mod = g->res_mod; d.batch = g->batch;
+  d.sA = g->stride_a; d.sB = g->stride_b; d.sC = g->stride_c; d.sR = g->stride_r;
+  d.act = g->act; d.out_f32 = g->out_f32; d.accumulate = g->accumulate; d.alpha = g->alpha;
+  d.C2 = g->C2; d.ldc2 = g->ldc2; d.swiglu = g->epilogue;
+  d.splitk_ws = workspace; d.splitk_ws_bytes = workspace ? ws_bytes : 0; d.splitk_force = force_split;
+  UVX_CHECK(g->epilogue == 0 || dtype == uvx::DT_BF16, UVX_ERR_UNSUPPORTED, "uvx_gemm_splitk: fused SwiGLU epilogues are bf16 only");
+  return uvx::gemm((hipStream_t)stream, dtype, d);
+}
+
 // C = epilogue(RMSNorm(A; norm_w) . B^T): the decode step's fused norm + weight-streaming GEMV (bf16, at most 2 rows); any other
 // problem runs as the two launches it replaces (norm_out: M x K scratch for that case).
 extern "C" int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, const void* norm_w, float eps, int32_t flavor,

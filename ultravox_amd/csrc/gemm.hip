@@ -74,6 +74,9 @@ struct GemmArgs {
   float* sk_ws;
   unsigned* sk_flags;
   unsigned sk_epoch;
+  // split-K launches (round 5): blockIdx.y = z of ksplit takes K-tiles [z nk / ksplit, (z + 1) nk / ksplit) and writes its f32 partial
+  // tile to slab z of C (stride sC); sA = sB = 0.  splitk_reduce_k sums the slabs in a fixed order and runs the epilogue.
+  int ksplit;
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -274,6 +277,31 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
           const uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 4>(stage, row, c4));
           if (m < p.M && 2 * n8 < p.N) *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc2 + n8) = o;
         }
+      }
+    }
+    return;
+  }
+  if (NJ == 4 && GI == MI && stage && p.wide_io == 2 && p.out_f32 && !p.accumulate && !p.bias && !p.residual && p.act == 0 && p.swiglu == 0 &&
+      (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.sC & 3) == 0 && ((uintptr_t)p.C & 15) == 0) {
+    // f32 output through the stage (round 5: the split-K partial tiles - twice the bytes of a bf16 tile, and in fragment layout a store
+    // instruction would touch 16 rows x 64 bytes).  One row fragment per pass: the wave parks 16 rows x 64 columns x 4 bytes = 4 KiB
+    // (256-byte rows, 16-byte chunks XOR-swizzled by row) in its slice, reads them back with SIXTEEN lanes per row and stores two whole
+    // 128-byte lines per row.  Same values as the fragment-layout path below.
+    float* Cf = reinterpret_cast<float*>(p.C) + z * p.sC;
+    const int c16 = lane & 15, n4 = n_base + c16 * 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (i > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads are done (WAR on the slice)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        *reinterpret_cast<float4*>(stage + frow * 256 + (((j * 4 + fg) ^ frow) << 4)) =
+            make_float4(acc[j][i][0] * p.alpha, acc[j][i][1] * p.alpha, acc[j][i][2] * p.alpha, acc[j][i][3] * p.alpha);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 4 + (lane >> 4), m = m_base + i * 16 + row;
+        const float4 o = *reinterpret_cast<const float4*>(stage + row * 256 + ((c16 ^ row) << 4));
+        if (m < p.M && n4 < p.N) *reinterpret_cast<float4*>(Cf + (long long)m * p.ldc + n4) = o;
       }
     }
     return;
@@ -523,6 +551,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
+  int k_len = p.K;
+  if (p.ksplit > 1) {   // this block's K range (whole K-tiles; the ranges differ by at most one K-tile)
+    const int nk = p.K / BK, kb = (int)(z * nk / p.ksplit), ke = (int)((z + 1) * nk / p.ksplit);
+    A += kb * BK; B += kb * BK; k_len = (ke - kb) * BK;
+  }
 
   // ---- staging addresses: wave w issues instructions (i*4 + w), each covering 8 tile rows ----
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
@@ -553,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < p.K; k0 += BK) {
+  for (int k0 = 0; k0 < k_len; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       glds16(ap[i] + k0, ldsX + (i * 4 + w) * 1024);
@@ -717,7 +750,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       o += gridDim.x;
     }
   };
-  const int nk = p.K / BK;
+  int nk = p.K / BK;
+  int ks_first = 0;               // split-K launch (p.ksplit > 1): first K-tile of this block's range; folded into A / B below
+  if (!SK && p.ksplit > 1) {
+    ks_first = (int)((long long)blockIdx.y * nk / p.ksplit);
+    nk = (int)((long long)(blockIdx.y + 1) * nk / p.ksplit) - ks_first;
+  }
   int kbase = 0, nks = nk;        // this piece: K-tiles [kbase, kbase + nks) of the tile at (m0, n0)  (SK only: else the whole K)
   // stream-K work list of this block (see the template comment)
   const int sk_x = blockIdx.x & 7, sk_wl = blockIdx.x >> 3, sk_per = gridDim.x >> 3;   // XCD, index / blocks within the XCD
@@ -747,8 +785,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   if (SK) { if (!sk_next()) return; }
   else if (!next_tile(orig, m0, n0)) return;   // (before any barrier)
   const long long z = blockIdx.y;
-  const bf16_t* A = p.A + z * p.sA;
-  const bf16_t* B = p.B + z * p.sB;
+  const bf16_t* A = p.A + z * p.sA + ks_first * BK;
+  const bf16_t* B = p.B + z * p.sB + ks_first * BK;
 
   // one DMA instruction = rows 8q .. 8q+7 of a region; lane -> row 8q + (lane >> 3), LDS chunk position lane & 7
   // holds source chunk (lane & 7) ^ (row & 7)
@@ -1129,6 +1167,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 #undef UVX_TL_FLUSH
 }
 
+#ifdef UVX_PROBES
 // ------------------------------------------------------------------------------------------------
 // Four-wave kernel with a hand-scheduled K loop (round 4): (32 MI) x 256 x 64 tile, 256 threads = 4 waves as 2 x 2, one wave
 // per SIMD, (16 MI) x 128 per wave = 8 x MI accumulator fragments in AGPRs (a[0 : 32 MI)), all 160 KiB of LDS as a ring of
@@ -1410,6 +1449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_a8pp_kernel(GemmArgs p) {
 #undef UVX_PP_LOOP
   store_tile_a4<NJ, MI>(p, m0 + wr * 128, n0 + wc * 64, lane, z, lds + w * 4096);
 }
+#endif  // UVX_PROBES (hand-scheduled K loops: a record of round 4, never picked; the product library does not carry them)
 
 // Tile choice.  Every CU works through ~tiles/256 rounds of tiles (see variant_cost for the partial last
 // round); a tile costs BM x BN / speed(variant), speeds measured on
@@ -1462,7 +1502,7 @@ const Variant kVariants[kNumVariants] = {
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
-constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34) || v == 43 || v == 49 || v == 55; }
+constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34); }
 constexpr bool is_a4(int v) { return v >= 43 && v <= 58; }
 constexpr bool is_streamk(int v) { return v >= 39 && v <= 42; }
 bool variant_available(int v) {
@@ -1513,10 +1553,15 @@ double sk_cost(int v, int M, int N, int K, int grid) {
   const double pieces = share / nk + 1.0;                          // ~ pieces per block in the stream-K part
   return (full * (nk + V.c) + share + pieces * V.c + kSkFix) * V.bm * V.bn / V.speed * kSkSlow;
 }
-int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr, bool gelu = false) {
+// probes: the tile variant forced for this shape (uvx_gemm_force_variant / uvx_gemm_override_variant), or -1
+int forced_variant(int M, int N, int K) {
   int forced = uvx::g_gemm_variant;
   for (int i = 0; i < uvx::g_gemm_ovr_n; ++i)
     if (uvx::g_gemm_ovr[i][0] == M && uvx::g_gemm_ovr[i][1] == N && uvx::g_gemm_ovr[i][2] == K) forced = uvx::g_gemm_ovr[i][3];
+  return forced;
+}
+int pick_variant(int M, int N, int K, int batch, double* cost_out = nullptr, bool gelu = false) {
+  const int forced = forced_variant(M, N, K);
   double best = 1e30;
   int best_v = 0;
   if (forced >= 0 && forced < kNumVariants) {   // probe-only variants carry speed 0: never let the cost model veto them
@@ -1613,10 +1658,10 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 32: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2>), grid, dim3(512), st, a); break;
     case 33: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2>), grid, dim3(512), st, a); break;
     case 34: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2>), grid, dim3(512), st, a); break;
+#ifdef UVX_PROBES
     case 43: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<2, 8, 0>), grid, dim3(256), st, a); break;
     case 49: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<4, 8, 0>), grid, dim3(512), st, a); break;
     case 55: UVX_GEMM_LAUNCH((gemm_nt_bf16_a8pp_kernel<0>), grid, dim3(512), st, a); break;
-#ifdef UVX_PROBES
     case 56: UVX_GEMM_LAUNCH((gemm_nt_bf16_a8pp_kernel<1>), grid, dim3(512), st, a); break;
     case 57: UVX_GEMM_LAUNCH((gemm_nt_bf16_a8pp_kernel<2>), grid, dim3(512), st, a); break;
     case 58: UVX_GEMM_LAUNCH((gemm_nt_bf16_a8pp_kernel<3>), grid, dim3(512), st, a); break;
@@ -1674,7 +1719,121 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-K (round 5).  The prefill of generate() runs the LLM's linears on M = 64 ... ~700 rows (one or two prompts of 30 s of audio +
+// text: 316 positions each).  With 160 / 256-row tiles that is 2-4 row tiles x N / 256 weight panels - 64 tiles at N = 8192 on a chip of
+// 256 CUs - and the 128 x 128 fallback re-reads the weights per row tile at a third of the big tiles' rate: Llama-3.3-70B's B = 1 prefill
+// sat at 0.17 of EITHER roofline (round 4: 102 ms for 44.6 TFLOP / 139 GB).  A tile's K loop is therefore cut over `s` blocks
+// (grid.y = s; block z runs K-tiles [z nk / s, (z + 1) nk / s) of its tile through the unchanged main loop and writes an f32 partial tile
+// to slab z of the caller's scratch), so tiles x s ~ one full round of the 256 CUs, every weight byte still leaves HBM once (the row
+// tiles that share a weight panel and K range sit in the same XCD's L2), and splitk_reduce_k sums the slabs in slab order - fixed, hence
+// bit-reproducible - and applies the epilogue with store_tile's arithmetic and rounding points.
+// Why not a block that owns all M rows and a narrow N slice with the K split over its waves: its activation traffic.  Per K-tile a
+// 320 x 32 block pulls 40 KB of activations + 4 KB of weights from L2 for 1.3 MFLOP, a 160 x 256 tile 53 KB for 5.2 MFLOP - and
+// the wide tile's main loop is already bounded by that L2 -> LDS stream (DESIGN 3.1, round 4 probes).  Splitting K over CUs keeps the
+// wide tile's bytes per flop and pays s x M x N x 4 bytes of partials through the L2 / Infinity Cache instead.
+struct ReduceArgs {
+  const float* P; long long slab; int s, ldp;
+  bf16_t* C; int ldc; const bf16_t* bias; const bf16_t* residual; int ldr, res_mod;
+  int M, N, act; float alpha; bf16_t* C2; int ldc2, swiglu;
+};
+// one thread = 8 consecutive output columns of a row (SwiGLU epilogue: 8 gate columns of a 16-column block and the matching 8 up columns)
+__global__ __launch_bounds__(256) void splitk_reduce_k(ReduceArgs p) {
+  const int per_row = p.swiglu ? p.N / 16 : p.N / 8;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)p.M * per_row) return;
+  const int m = (int)(idx / per_row), c = (int)(idx % per_row);
+  const int n0 = p.swiglu ? (c >> 1) * 32 + (c & 1) * 8 : c * 8;       // first (gate) column
+  const float* src = p.P + (long long)m * p.ldp + n0;
+  float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int z = 0; z < p.s; ++z) {                                       // slab order: the sum is the same on every run
+    const float4 a = *reinterpret_cast<const float4*>(src + z * p.slab), b = *reinterpret_cast<const float4*>(src + z * p.slab + 4);
+    g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
+    if (p.swiglu) {
+      const float4 e = *reinterpret_cast<const float4*>(src + z * p.slab + 16), f = *reinterpret_cast<const float4*>(src + z * p.slab + 20);
+      u[0] += e.x; u[1] += e.y; u[2] += e.z; u[3] += e.w; u[4] += f.x; u[5] += f.y; u[6] += f.z; u[7] += f.w;
+    }
+  }
+  uint32_t o[4];
+  if (p.swiglu) {   // C = gate|up pre-activations (interleaved 16-column blocks), C2 = round(silu(round(gate))) * round(up)
+    uint32_t ou[4], oa[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a2[2];
+      o[e] = pack2(g[2 * e] * p.alpha, g[2 * e + 1] * p.alpha);
+      ou[e] = pack2(u[2 * e] * p.alpha, u[2 * e + 1] * p.alpha);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float gg = h ? unpack_hi(o[e]) : unpack_lo(o[e]), uu = h ? unpack_hi(ou[e]) : unpack_lo(ou[e]);
+        a2[h] = bf2f(f2bf(gg / (1.0f + __expf(-gg)))) * uu;
+      }
+      oa[e] = pack2(a2[0], a2[1]);
+    }
+    bf16_t* crow = p.C + (long long)m * p.ldc + n0;
+    *reinterpret_cast<uint4*>(crow) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(crow + 16) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+    *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc2 + (c >> 1) * 16 + (c & 1) * 8) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+    return;
+  }
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const uint4 b4 = *reinterpret_cast<const uint4*>(p.bias + n0);
+    bv[0] = unpack_lo(b4.x); bv[1] = unpack_hi(b4.x); bv[2] = unpack_lo(b4.y); bv[3] = unpack_hi(b4.y);
+    bv[4] = unpack_lo(b4.z); bv[5] = unpack_hi(b4.z); bv[6] = unpack_lo(b4.w); bv[7] = unpack_hi(b4.w);
+  }
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float t = bf2f(f2bf(g[e] * p.alpha + bv[e]));
+    if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));
+    v[e] = t;
+  }
+  if (p.residual) {
+    const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+    const uint4 r = *reinterpret_cast<const uint4*>(p.residual + (long long)rm * p.ldr + n0);
+    v[0] += unpack_lo(r.x); v[1] += unpack_hi(r.x); v[2] += unpack_lo(r.y); v[3] += unpack_hi(r.y);
+    v[4] += unpack_lo(r.z); v[5] += unpack_hi(r.z); v[6] += unpack_lo(r.w); v[7] += unpack_hi(r.w);
+  }
+  *reinterpret_cast<uint4*>(p.C + (long long)m * p.ldc + n0) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
+// Which (tile variant, split factor).  Modelled time in us: the tile model above (cost units x kCostUs) on tiles x s blocks of K / s
+// each, plus what the partials cost: the f32 tile written by the GEMM and read back by the reduce kernel (through L2 / Infinity Cache:
+// kSplitBytesPerUs), the reduce launch itself (kSplitFixUs).  Constants fitted to tools/gpu_gemm_splitk_probe.py (profiles/r05_gemm_splitk_probe.txt).
+constexpr double kCostUs = 128.0 * 256.0 / 1e6;       // variant_cost units -> microseconds (2 x 64 flop per tile element and K-tile, 256 CUs, speed in TF/s)
+constexpr double kSplitFixUs = 4.0, kSplitBytesPerUs = 2.2e6;
+constexpr int kSplitMinKTiles = 8, kSplitMax = 16;
+struct SplitPick { int variant, s; double us; };
+SplitPick pick_split(int M, int N, int K, size_t ws_bytes, bool gelu, int force_s) {
+  double c0 = 0.;
+  const int v0 = pick_variant(M, N, K, 1, &c0, gelu);                    // (honours a forced variant / per-shape overrides)
+  SplitPick best{v0, 1, c0 * kCostUs};
+  if (force_s == 1) return best;
+  const int nk = K / 64;
+  const bool v_forced = forced_variant(M, N, K) >= 0;
+  bool have = false;
+  for (int v : {0, 34, 33, 32, 31}) {
+    if (v_forced ? v != v0 : (!uvx::g_options[6] && v != 0)) continue;   // (option 6 = 0, the round-1 four-phase set: A/B builds, never split)
+    const long long tiles = (long long)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn);
+    for (int s = 2; s <= kSplitMax; ++s) {
+      if (force_s > 1 && s != force_s) continue;
+      if (nk / s < 1 || (size_t)s * M * N * 4 > ws_bytes) break;
+      if (force_s <= 1 && (nk / s < kSplitMinKTiles || tiles * s > 640)) break;   // (> ~2.5 rounds of blocks: nothing left to fill)
+      const double us = variant_cost(v, M, N, cdiv(nk, s) * 64, s, false) * kCostUs + kSplitFixUs + (double)s * M * N * 4.0 / kSplitBytesPerUs;
+      if ((force_s > 1 && !have) || us < best.us) { best = SplitPick{v, s, us}; have = true; }
+    }
+  }
+  return best;
+}
+
 }  // namespace
+
+size_t uvx::gemm_splitk_ws_bytes(int M, int N) {
+  // enough for one full round of the largest tiles' f32 partials and never more than 16 slabs of the problem
+  const size_t cap = (size_t)256 * 256 * 256 * 4 * 2, want = (size_t)kSplitMax * (size_t)M * N * 4;
+  return want < cap ? want : cap;
+}
 
 // Stream-K spin waits that gave up (see the kernel), summed over every stream's scratch; synchronises the device.  0 on a
 // healthy run - anything else means wrong output tiles in some stream-K launch since the last call (the counters are reset).
@@ -1706,6 +1865,11 @@ static bool a4_applicable(const uvx::GemmDesc& d) {
 }
 
 int uvx::gemm_pick_variant(int M, int N, int K, int batch) { return pick_variant(M, N, K, batch > 0 ? batch : 1); }
+int uvx::gemm_pick_split(int M, int N, int K, size_t ws_bytes, int* variant) {
+  const SplitPick sp = pick_split(M, N, K, ws_bytes, false, 0);
+  if (variant) *variant = sp.variant;
+  return sp.s;
+}
 
 int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   UVX_CHECK(d.M > 0 && d.N > 0 && d.K > 0, UVX_ERR_SHAPE, "gemm: empty problem %dx%dx%d", d.M, d.N, d.K);
@@ -1728,7 +1892,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.sw_stage = uvx::g_options[2] != 1;     // SwiGLU-backward epilogue through the LDS stage (option 2 = 1: the round-2 fragment-layout form)
   a.m_major = uvx::g_options[7] && d.M > d.N && (d.batch <= 1);
   a.m_dev = d.m_dev; a.m_dev_off = d.m_dev_off;
-  a.sk_full = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0;
+  a.sk_full = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0; a.ksplit = 1;
   UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
   UVX_CHECK(d.swiglu != 2 || (d.N % 16 == 0 && d.ldc >= 2 * d.N && d.ldc2 >= 2 * d.N), UVX_ERR_INVALID,
@@ -1736,6 +1900,39 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   const int batch = d.batch > 0 ? d.batch : 1;
   double cost_whole = 0.;
   const bool gelu = d.act == 1;
+  // split-K (see splitk_reduce_k): only where the caller lent scratch for the partial tiles and the reduce kernel's 16-byte accesses apply
+  if (d.splitk_ws && batch == 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
+      ((uintptr_t)d.C & 15) == 0 && ((uintptr_t)d.splitk_ws & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
+      (!d.residual || (d.ldr % 8 == 0 && ((uintptr_t)d.residual & 15) == 0)) &&
+      (!d.swiglu || (d.ldc2 % 8 == 0 && ((uintptr_t)d.C2 & 15) == 0))) {
+    const SplitPick sp = pick_split(d.M, d.N, d.K, d.splitk_ws_bytes, gelu, d.splitk_force);
+    if (sp.s > 1) {
+      UVX_CHECK(variant_available(sp.variant), UVX_ERR_INVALID, "gemm: tile variant %d is not in this build", sp.variant);
+      hipEvent_t ev_a = nullptr, ev_b = nullptr;
+      const bool timed = uvx::g_prof_on &&
+                         uvx::prof_take(uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K,
+                                        ((double)d.M * d.K + (double)d.N * d.K) * 2.0 + (double)d.M * d.N * 2.0, &ev_a, &ev_b);
+      if (timed) uvx::prof_tag(d.M, d.N, d.K, sp.s, 300 + sp.variant);   // (records: batch = split factor, variant = 300 + tile)
+      GemmArgs g = a;
+      g.C = d.splitk_ws; g.ldc = d.N; g.sA = 0; g.sB = 0; g.sC = (long long)d.M * d.N; g.out_f32 = 1; g.accumulate = 0;
+      g.bias = nullptr; g.residual = nullptr; g.act = 0; g.alpha = 1.0f; g.swiglu = 0; g.C2 = nullptr; g.ksplit = sp.s;
+      g.m_major = 0;
+      g_launch_ev = LaunchEvents{ev_a, nullptr};
+      launch_variant(st, sp.variant, g, d.M, d.N, sp.s);
+      g_launch_ev = LaunchEvents{};
+      ReduceArgs r;
+      r.P = (const float*)d.splitk_ws; r.slab = (long long)d.M * d.N; r.s = sp.s; r.ldp = d.N;
+      r.C = (bf16_t*)d.C; r.ldc = d.ldc; r.bias = a.bias; r.residual = a.residual; r.ldr = d.ldr; r.res_mod = d.res_mod;
+      r.M = d.M; r.N = d.N; r.act = d.act; r.alpha = d.alpha; r.C2 = a.C2; r.ldc2 = d.ldc2; r.swiglu = d.swiglu;
+      const long long items = (long long)d.M * (d.swiglu ? d.N / 16 : d.N / 8);
+      const dim3 rgrid((unsigned)((items + 255) / 256));
+      if (ev_b) hipExtLaunchKernelGGL(splitk_reduce_k, rgrid, dim3(256), 0, st, nullptr, ev_b, 0, r);
+      else hipLaunchKernelGGL(splitk_reduce_k, rgrid, dim3(256), 0, st, r);
+      if (timed) uvx::prof_commit();
+      UVX_LAUNCH_CHECK();
+      return UVX_OK;
+    }
+  }
   int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole, gelu);
   if (is_a4(variant) && !a4_applicable(d)) variant = 31;     // (the eight-wave 256 x 256 kernel takes any alignment)
   UVX_CHECK(variant_available(variant), UVX_ERR_INVALID,

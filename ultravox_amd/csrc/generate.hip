@@ -9,6 +9,7 @@
 // its own kernels: gemm_skinny.hip (M <= 16) and attn_decode_grp_k below (one block per sequence and KV head).  A further
 // chunk of tokens on top of a filled cache (conversation turns) goes through uvx_llm_prefill_chunk.
 // KV cache layout: [layer][k | v][B][Tmax][kv_heads * head_dim], caller-owned.
+#include <algorithm>
 #include "common.h"
 #include "kernels.h"
 #include "../../include/uvx.h"
@@ -30,6 +31,7 @@ struct InferWs {
   void *x, *x2, *n, *qkv, *vt, *o, *gu, *act, *last, *hn;
   int32_t *kvs, *kvl, *pos;
   int M, Tp, QKV, OD;
+  void* sk; size_t sk_bytes;     // split-K scratch of the GEMMs (bf16 prefill of a few hundred rows; gemm.hip "Split-K"), or null
 };
 InferWs carve(Arena& a, const uvx_config_t& c, int B, int T) {
   InferWs w;
@@ -44,8 +46,13 @@ InferWs carve(Arena& a, const uvx_config_t& c, int B, int T) {
   w.last = a.take((size_t)B * c.llm_d * es); w.hn = a.take((size_t)B * c.llm_d * es);
   w.kvs = (int32_t*)a.take(sizeof(int32_t) * B); w.kvl = (int32_t*)a.take(sizeof(int32_t) * B);
   w.pos = (int32_t*)a.take(sizeof(int32_t) * M);
+  // one or two prompts' worth of rows: too many for the weight-streaming kernels (M <= 64), too few tiles for the 256 CUs
+  w.sk_bytes = c.dtype == DT_BF16 && M > 64 && M <= 1536 ? gemm_splitk_ws_bytes((int)M, std::max(std::max(w.QKV, 2 * c.llm_inter), c.llm_d)) : 0;
+  w.sk = w.sk_bytes ? a.take(w.sk_bytes) : nullptr;
   return w;
 }
+// lends the split-K scratch to a GEMM of the layer loop
+GemmDesc sk(GemmDesc g, const InferWs& s) { g.splitk_ws = s.sk; g.splitk_ws_bytes = s.sk_bytes; return g; }
 
 // position ids + valid key range from the attention mask (HF prepare_inputs_for_generation semantics)
 __global__ void mask_positions_k(const int64_t* __restrict__ mask, int32_t* __restrict__ pos, int32_t* __restrict__ kv_start,
@@ -378,31 +385,31 @@ int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, I
   }
   RC(rmsnorm_fwd(st, dt, x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
   if (c.llm_flavor == UVX_LLM_GEMMA3) {      // x_out = x_mid + post_feedforward_norm(mlp(pre_feedforward_norm(x_mid)))
-    RC(gemm(st, dt, lin(s.n, L.wgu, s.gu, M, 2 * c.llm_inter, D)));
+    RC(gemm(st, dt, sk(lin(s.n, L.wgu, s.gu, M, 2 * c.llm_inter, D), s)));
     RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2, c.llm_act));
-    RC(gemm(st, dt, lin(s.act, L.wd, s.n, M, D, c.llm_inter)));        // (s.n is free again: the gate|up GEMM has consumed it)
+    RC(gemm(st, dt, sk(lin(s.act, L.wd, s.n, M, D, c.llm_inter), s)));        // (s.n is free again: the gate|up GEMM has consumed it)
     return rmsnorm_fwd(st, dt, s.n, L.ln2_post, x_out, nullptr, M, D, c.rms_eps, c.llm_flavor, nullptr, x_mid);
   }
   GemmDesc g = lin(s.n, L.wgu, s.gu, M, 2 * c.llm_inter, D);
   const bool fused = dt == DT_BF16 && c.llm_flavor == UVX_LLM_LLAMA;   // SwiGLU in the epilogue; Gemma's GeGLU: separate kernel
   if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
-  RC(gemm(st, dt, g));
+  RC(gemm(st, dt, sk(g, s)));
   if (!fused) RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2, c.llm_act));
   GemmDesc d = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
   d.residual = x_mid; d.ldr = D;
-  return gemm(st, dt, d);
+  return gemm(st, dt, sk(d, s));
 }
 
 // x_out = x + o_proj(o)  -  Gemma-3: x + post_attention_norm(o_proj(o))
 int attn_out(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, const void* o, int OD, const void* x, void* x_out) {
   const int dt = c.dtype, D = c.llm_d;
   if (c.llm_flavor == UVX_LLM_GEMMA3) {
-    RC(gemm(st, dt, lin(o, L.wo, s.n, M, D, OD)));                    // (s.n is free: the q|k|v GEMM has consumed it)
+    RC(gemm(st, dt, sk(lin(o, L.wo, s.n, M, D, OD), s)));             // (s.n is free: the q|k|v GEMM has consumed it)
     return rmsnorm_fwd(st, dt, s.n, L.ln1_post, x_out, nullptr, M, D, c.rms_eps, c.llm_flavor, nullptr, x);
   }
   GemmDesc g = lin(o, L.wo, x_out, M, D, OD);
   g.residual = x; g.ldr = D;
-  return gemm(st, dt, g);
+  return gemm(st, dt, sk(g, s));
 }
 float attn_scale_of(const uvx_config_t& c) { return c.llm_attn_scale > 0.f ? c.llm_attn_scale : 1.0f / sqrtf((float)c.llm_head_dim); }
 // Gemma-3: post norms present and a local rotary table where layers are flagged
@@ -421,13 +428,13 @@ int g3_check(const uvx_config_t& c, const uvx_llm_weights_t* w, int Tmax) {
 // q | k | v projection of a layer (+ Qwen2's biases), then the rotary embedding - for Qwen3 / Gemma-3 behind the per-head q_norm / k_norm
 // (l: the layer index - Gemma-3's sliding-window layers rotate with their own table)
 int qkv_rope(hipStream_t st, const uvx_config_t& c, const uvx_llm_weights_t* w, const uvx_llm_layer_t& L, const void* n, void* qkv,
-             const int32_t* pos, int rows, int T, int QKV, int l) {
+             const int32_t* pos, int rows, int T, int QKV, int l, const InferWs* ws = nullptr) {
   const int dt = c.dtype, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads;
   const bool g3 = c.llm_flavor == UVX_LLM_GEMMA3;
   const float* rope = g3 && w->layer_local && w->layer_local[l] ? w->rope_cos_sin_local : w->rope_cos_sin;
   GemmDesc g = lin(n, L.wqkv, qkv, rows, QKV, c.llm_d);
   g.bias = L.bqkv;
-  RC(gemm(st, dt, g));
+  RC(gemm(st, dt, ws ? sk(g, *ws) : g));
   if (c.llm_qk_norm) {
     UVX_CHECK(L.q_norm && L.k_norm, UVX_ERR_INVALID, "llm: llm_qk_norm is set but a layer has no q_norm / k_norm");
     return qk_norm_rope(st, dt, qkv, L.q_norm, L.k_norm, nullptr, rope, pos, rows, T, Hq, Hkv, dh, QKV, c.rms_eps, g3 ? 1 : 0);
@@ -472,7 +479,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
-    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, T, s.QKV, l));
+    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, T, s.QKV, l, &s));
     {
       char* ck = at(kv_cache, l * layer_stride, dt);
       char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
@@ -557,7 +564,7 @@ static int32_t prefill_chunk_impl(void* stream, const uvx_config_t* cfg, const u
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
-    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, Tn, s.QKV, l));
+    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, Tn, s.QKV, l, &s));
     char* ck = at(kv_cache, l * layer_stride, dt);
     char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
     const long long na = (long long)M * (KVD / 8), ng = (long long)B * Tf * (KVD / 8);

@@ -45,7 +45,15 @@ struct GemmDesc {
   // device-side row count: effective M = min(M, *m_dev) (tiles beyond it exit at once); M stays the launch bound
   const int32_t* m_dev = nullptr;
   int m_dev_off = 0;   // effective M = clamp(*m_dev - m_dev_off, 0, M): this launch covers compact rows [m_dev_off, ...)
+  // split-K (round 5, bf16 path; gemm.hip "Split-K"): scratch the caller lends for f32 partial tiles (gemm_splitk_ws_bytes).  With it,
+  // gemm_nt cuts a tile's K loop over several blocks when the tile count would leave most of the CUs idle (the prefill's M = 64..700
+  // rows) and a reduce kernel runs the epilogue; null = never split.  splitk_force: 0 = the cost model decides, 1 = never, s > 1 = that factor.
+  void* splitk_ws = nullptr;
+  size_t splitk_ws_bytes = 0;
+  int splitk_force = 0;
 };
+size_t gemm_splitk_ws_bytes(int M, int N);   // enough scratch for any split gemm_nt picks on an M x N output
+int gemm_pick_split(int M, int N, int K, size_t ws_bytes, int* variant);   // host only: split factor (1 = none) and tile the model picks
 
 extern int g_gemm_variant;
 extern int g_gemm_split;

@@ -46,6 +46,32 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_splitk(a: torch.Tensor, b: torch.Tensor, *, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                act: str = "none", epilogue: int = 0, c2: Optional[torch.Tensor] = None, alpha: float = 1.0, res_mod: int = 0,
+                force_split: int = 0, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uvx_gemm_splitk: gemm() with split-K scratch (the prefill's few-hundred-row problems); force_split 0 = the cost model decides."""
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    if workspace is None:
+        workspace = torch.empty(int(_lib.lib().uvx_gemm_splitk_ws_bytes(M, N)), device=a.device, dtype=torch.uint8)
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    d.bias = 0 if bias is None else bias.data_ptr()
+    d.residual = 0 if residual is None else residual.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = a.stride(0), b.stride(0), out.stride(0)
+    d.ldr = 0 if residual is None else residual.stride(0)
+    d.res_mod, d.batch, d.alpha = res_mod, 1, alpha
+    d.act = {"none": 0, "gelu": 1}[act]
+    d.epilogue = epilogue
+    d.C2, d.ldc2 = (0, 0) if c2 is None else (c2.data_ptr(), c2.stride(0))
+    check(_lib.lib().uvx_gemm_splitk(stream_ptr(), dtype_code(a.dtype), C.byref(d), ptr(workspace), C.c_size_t(workspace.numel()),
+                                     int(force_split)), "uvx_gemm_splitk")
+    return out
+
+
 def gemm_rmsnorm(a: torch.Tensor, norm_w: torch.Tensor, b: torch.Tensor, *, eps: float = 1e-5, flavor: int = 0,
                  bias: Optional[torch.Tensor] = None, epilogue: int = 0, c2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = epilogue(RMSNorm(a; norm_w) @ b[N,K]^T + bias) through uvx_gemm_rmsnorm (the decode step's fused norm + GEMV)."""
