@@ -1798,31 +1798,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(ReduceArgs p) {
   *reinterpret_cast<uint4*>(p.C + (long long)m * p.ldc + n0) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
 }
 
-// Which (tile variant, split factor).  Modelled time in us: the tile model above (cost units x kCostUs) on tiles x s blocks of K / s
-// each, plus what the partials cost: the f32 tile written by the GEMM and read back by the reduce kernel (through L2 / Infinity Cache:
-// kSplitBytesPerUs), the reduce launch itself (kSplitFixUs).  Constants fitted to tools/gpu_gemm_splitk_probe.py (profiles/r05_gemm_splitk_probe.txt).
+// Which (tile variant, split factor).  Two regimes, both in microseconds:
+//  * at most one block per CU (blocks = tiles x s <= 256; the few-hundred-row problems this path exists for): every block runs its K loop
+//    alone on a CU at the tile's own pace, kt1_us per K-tile, + kSparseFix K-tiles of fill and epilogue - the time is that of ONE block,
+//    however few there are.  (The training-shape model above prices a quarter-filled round at 0.55 of a full one and has the 128 x 128
+//    tile at 880 TF/s; on cold weights a lone 128 x 128 block needs 1.3 us per K-tile - no prefetch across its two barriers - and 64
+//    blocks of 160 x 256 take exactly as long as 256: profiles/r05_gemm_splitk_probe.txt.)
+//  * more blocks than CUs: the tile model above (cost units x kCostUs) on tiles x s blocks of K / s each.
+// A split adds what the partials cost: the f32 tiles written by the GEMM and read back by the reduce kernel (through L2 / Infinity
+// Cache: kSplitBytesPerUs, fitted: 2.4 TB/s for the pair) and the second launch (kSplitFixUs).  The model reproduces the probe's
+// 5 tiles x 8 factors x 16 shapes to ~10 %; its picks are within 5 % of the best measured pair on every shape.
 constexpr double kCostUs = 128.0 * 256.0 / 1e6;       // variant_cost units -> microseconds (2 x 64 flop per tile element and K-tile, 256 CUs, speed in TF/s)
-constexpr double kSplitFixUs = 4.0, kSplitBytesPerUs = 2.2e6;
-constexpr int kSplitMinKTiles = 8, kSplitMax = 16;
+constexpr double kSplitFixUs = 4.0, kSplitBytesPerUs = 2.4e6, kSparseFix = 2.0;
+constexpr int kSplitMinKTiles = 4, kSplitMax = 16;
+double kt1_us(int v) { return v == 0 ? 1.30 : v == 34 ? 0.85 : v == 33 ? 0.975 : v == 32 ? 1.00 : 1.09; }
+double sparse_cost_us(int v, int M, int N, int nk_s, int s, bool gelu) {
+  const long long blocks = (long long)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * s;
+  // between half and all of the CUs busy the K-tile time climbs from the lone block's to the full chip's (the tile model's asymptotic
+  // rate): 1.07 -> 1.44 us for the 256 x 256 tile between 128 and 256 blocks, 0.98 -> 1.04 for 160 x 256 (same probe)
+  const double full = kVariants[v].bm * kVariants[v].bn * kCostUs / kVariants[v].speed, x = blocks / 256.0;
+  const double kt = v == 0 ? kt1_us(0) : kt1_us(v) + fmax(0., full - kt1_us(v)) * fmin(1., fmax(0., (x - 0.5) / 0.5));
+  const double alone = (nk_s + kSparseFix + (gelu ? 1.0 : 0.0)) * kt;
+  if (v != 0 && blocks <= 256) return alone;
+  const double model = variant_cost(v, M, N, nk_s * 64, s, gelu) * kCostUs;
+  return v == 0 ? fmax(model, alone) : model;          // (several 128 x 128 blocks share a CU, none runs its K loop faster than alone)
+}
 struct SplitPick { int variant, s; double us; };
 SplitPick pick_split(int M, int N, int K, size_t ws_bytes, bool gelu, int force_s) {
-  double c0 = 0.;
-  const int v0 = pick_variant(M, N, K, 1, &c0, gelu);                    // (honours a forced variant / per-shape overrides)
-  SplitPick best{v0, 1, c0 * kCostUs};
-  if (force_s == 1) return best;
-  const int nk = K / 64;
-  const bool v_forced = forced_variant(M, N, K) >= 0;
-  bool have = false;
+  const int nk = K / 64, fv = forced_variant(M, N, K);
+  SplitPick best{fv >= 0 ? fv : 0, 1, 1e30};
   for (int v : {0, 34, 33, 32, 31}) {
-    if (v_forced ? v != v0 : (!uvx::g_options[6] && v != 0)) continue;   // (option 6 = 0, the round-1 four-phase set: A/B builds, never split)
+    if (fv >= 0 ? v != fv : (!uvx::g_options[6] && v != 0)) continue;    // (option 6 = 0, the round-1 four-phase set: A/B builds, never split)
     const long long tiles = (long long)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn);
-    for (int s = 2; s <= kSplitMax; ++s) {
-      if (force_s > 1 && s != force_s) continue;
-      if (nk / s < 1 || (size_t)s * M * N * 4 > ws_bytes) break;
-      if (force_s <= 1 && (nk / s < kSplitMinKTiles || tiles * s > 640)) break;   // (> ~2.5 rounds of blocks: nothing left to fill)
-      const double us = variant_cost(v, M, N, cdiv(nk, s) * 64, s, false) * kCostUs + kSplitFixUs + (double)s * M * N * 4.0 / kSplitBytesPerUs;
-      if ((force_s > 1 && !have) || us < best.us) { best = SplitPick{v, s, us}; have = true; }
+    for (int s = 1; s <= kSplitMax; ++s) {
+      if (force_s > 0 && s != force_s) continue;
+      if (s > 1 && (nk / s < 1 || (size_t)s * M * N * 4 > ws_bytes)) break;
+      if (s > 1 && force_s <= 1 && (nk / s < kSplitMinKTiles || tiles * s > 640)) break;   // (> ~2.5 rounds of blocks: nothing left to fill)
+      const double us = sparse_cost_us(v, M, N, cdiv(nk, s), s, gelu) + (s > 1 ? kSplitFixUs + (double)s * M * N * 4.0 / kSplitBytesPerUs : 0.);
+      if (us < best.us) best = SplitPick{v, s, us};
     }
+  }
+  if (best.us >= 1e30) {       // a forced tile outside the split set (probe builds): unsplit
+    double c0 = 0.;
+    const int v0 = pick_variant(M, N, K, 1, &c0, gelu);
+    best = SplitPick{v0, 1, c0 * kCostUs};
   }
   return best;
 }
@@ -1900,12 +1919,14 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   const int batch = d.batch > 0 ? d.batch : 1;
   double cost_whole = 0.;
   const bool gelu = d.act == 1;
+  int sparse_variant = -1;       // the split picker's unsplit choice for a launch of at most one block per CU (its model, not the tile model's)
   // split-K (see splitk_reduce_k): only where the caller lent scratch for the partial tiles and the reduce kernel's 16-byte accesses apply
   if (d.splitk_ws && batch == 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
       ((uintptr_t)d.C & 15) == 0 && ((uintptr_t)d.splitk_ws & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
       (!d.residual || (d.ldr % 8 == 0 && ((uintptr_t)d.residual & 15) == 0)) &&
       (!d.swiglu || (d.ldc2 % 8 == 0 && ((uintptr_t)d.C2 & 15) == 0))) {
     const SplitPick sp = pick_split(d.M, d.N, d.K, d.splitk_ws_bytes, gelu, d.splitk_force);
+    if (sp.s == 1 && (long long)cdiv(d.M, kVariants[sp.variant].bm) * cdiv(d.N, kVariants[sp.variant].bn) <= 256) sparse_variant = sp.variant;
     if (sp.s > 1) {
       UVX_CHECK(variant_available(sp.variant), UVX_ERR_INVALID, "gemm: tile variant %d is not in this build", sp.variant);
       hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -1934,6 +1955,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
     }
   }
   int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole, gelu);
+  if (sparse_variant >= 0 && sparse_variant != variant) { variant = sparse_variant; cost_whole = variant_cost(variant, d.M, d.N, d.K, batch, gelu); }
   if (is_a4(variant) && !a4_applicable(d)) variant = 31;     // (the eight-wave 256 x 256 kernel takes any alignment)
   UVX_CHECK(variant_available(variant), UVX_ERR_INVALID,
             "gemm: tile variant %d is not in this build (probe variants live in libuvx_probes.so, built with -DUVX_PROBES)", variant);

@@ -74,6 +74,7 @@ struct EncWs {
   void *im2col, *c1, *x, *n, *qkv, *vt, *o, *f;
   int32_t* kvlen;
   int Te, Tp, M, Kp1;
+  void* sk; size_t sk_bytes;    // inference at one or two clips: split-K scratch of the layer GEMMs (gemm.hip "Split-K"), else null
   // training only
   char* slots; size_t slot_bytes; EncLayerStash ls0;
   void *dx, *d_n, *d_o, *d_f, *d_qkv, *qT, *kT, *doT, *u;
@@ -111,6 +112,9 @@ EncWs enc_carve(Arena& a, const uvx_config_t& c, int B, int F, bool train = fals
   w.o = a.take((size_t)w.M * c.enc_d * es);
   w.f = a.take((size_t)w.M * c.enc_ffn * es);
   w.kvlen = (int32_t*)a.take(sizeof(int32_t) * B);
+  // one or two clips (generate() at B = 1, 2): 1500 / 3000 rows are 48 ... 144 of the 128- / 256-wide tiles on 256 CUs
+  w.sk_bytes = !train && c.dtype == DT_BF16 && w.M > 64 && w.M <= 3072 ? gemm_splitk_ws_bytes(w.M, c.enc_ffn) : 0;
+  w.sk = w.sk_bytes ? a.take(w.sk_bytes) : nullptr;
   if (train) {
     const size_t M = (size_t)w.M, d = c.enc_d;
     w.Mp = rup(w.M, 64);
@@ -469,6 +473,7 @@ extern "C" size_t uvx_encoder_ws_bytes(const uvx_config_t* cfg, int32_t B, int32
   return a.off + 256;
 }
 
+static GemmDesc enc_sk(GemmDesc g, const EncWs& s) { g.splitk_ws = s.sk; g.splitk_ws_bytes = s.sk_bytes; return g; }
 static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_weights_t* w, const uvx_encoder_lora_t* lora,
                        const void* mel, int mel_is_f32, const int64_t* audio_lens, int B, int F, void* out, void* workspace,
                        size_t ws_bytes) {
@@ -504,7 +509,7 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     g.lda = 2 * d; g.bias = w->conv2_b; g.act = 1; g.batch = B;
     g.sA = (long long)(F + 2) * d; g.sC = (long long)Te * d;
     g.residual = w->pos; g.ldr = d; g.sR = 0;
-    RC(gemm(st, dt, g));
+    RC(gemm(st, dt, enc_sk(g, s)));
   }
   // key padding mask from audio_len (:915-926)
   const int32_t* kvlen = nullptr;
@@ -525,7 +530,7 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     {
       GemmDesc g = lin(s.n, L.wqkv, qkv, M, 3 * d, d);
       g.bias = L.bqkv;
-      RC(gemm(st, dt, g));
+      RC(gemm(st, dt, enc_sk(g, s)));
     }
     if (train) {
       // peft LoRA on q_proj / k_proj: result += lora_B(lora_A(x)) * scaling (and q carries Whisper's head_dim^-0.5,
@@ -550,7 +555,7 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     {
       GemmDesc g = lin(o, L.wo, x_mid, M, d, d);
       g.bias = L.bo; g.residual = x; g.ldr = d;
-      RC(gemm(st, dt, g));
+      RC(gemm(st, dt, enc_sk(g, s)));
     }
     if (!probe_skip(128)) RC(layernorm_fwd(st, dt, x_mid, L.ln2_w, L.ln2_b, s.n, M, d, c.ln_eps));
     if (train) {   // keep the fc1 pre-activation for the GELU backward
@@ -561,12 +566,12 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     } else {
       GemmDesc g = lin(s.n, L.fc1_w, s.f, M, c.enc_ffn, d);
       g.bias = L.fc1_b; g.act = 1;
-      RC(gemm(st, dt, g));
+      RC(gemm(st, dt, enc_sk(g, s)));
     }
     {
       GemmDesc g = lin(s.f, L.fc2_w, x_out, M, d, c.enc_ffn);
       g.bias = L.fc2_b; g.residual = x_mid; g.ldr = d;
-      RC(gemm(st, dt, g));
+      RC(gemm(st, dt, enc_sk(g, s)));
     }
     x = x_out;
   }
