@@ -281,7 +281,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
     }
     return;
   }
-  if (NJ == 4 && GI == MI && stage && p.wide_io == 2 && p.out_f32 && !p.accumulate && !p.bias && !p.residual && p.act == 0 && p.swiglu == 0 &&
+  if (NJ == 4 && GI >= 2 && stage && p.wide_io == 2 && p.out_f32 && !p.accumulate && !p.bias && !p.residual && p.act == 0 && p.swiglu == 0 &&
       (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.sC & 3) == 0 && ((uintptr_t)p.C & 15) == 0) {
     // f32 output through the stage (round 5: the split-K partial tiles - twice the bytes of a bf16 tile, and in fragment layout a store
     // instruction would touch 16 rows x 64 bytes).  One row fragment per pass: the wave parks 16 rows x 64 columns x 4 bytes = 4 KiB
@@ -1499,6 +1499,10 @@ const Variant kVariants[kNumVariants] = {
     {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},
     // 55 = eight waves, PING-PONG by wave row (pure MFMA phase / load phase, DMA split by operand); 56..58 = its timing probes
     {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},     {256, 256, 0., 7.}};
+// (round 5, tried: the merged-phase kernel at 320 x 256 - both 160-row tiles of a 316-row prompt in ONE block, every weight byte staged once
+//  per K-tile for all rows.  160 accumulator + 72 fragment registers per wave leave hipcc 35 spills at two waves per SIMD, and the spilled
+//  registers are the DMA source pointers: each reload sits behind an s_waitcnt vmcnt(0) inside the K loop, which drains the LDS-DMA
+//  pipeline the kernel lives on.  Not built.)
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
