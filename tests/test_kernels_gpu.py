@@ -657,7 +657,7 @@ def test_splitk_gemm_prefill_shapes_match_the_f32_product(M, N, K):
 
 
 @pytest.mark.parametrize("s", [2, 3, 5, 8, 16])
-@pytest.mark.parametrize("variant", [0, 31, 32, 33, 34])
+@pytest.mark.parametrize("variant", [0, 31, 32, 33, 34, 59, 60])
 def test_splitk_gemm_every_tile_and_factor(variant, s):
     """Every production tile x forced split factors (incl. factors that do not divide the K-tile count: the ranges then differ by one
     K-tile) x every epilogue the reduce kernel restates (bias, GELU, residual, positional residual, alpha, fused SwiGLU) on a ragged
@@ -695,6 +695,39 @@ def test_splitk_gemm_every_tile_and_factor(variant, s):
         assert torch.equal(act_s, ops().swiglu(gu_s, gate_first=2))       # the activation is exactly that of the stored pre-activations
     finally:
         L.uvx_gemm_force_variant(-1)
+
+
+@pytest.mark.parametrize("variant,twin", [(59, 33), (60, 34)])
+def test_three_buffer_merged_phase_kernels_are_bit_identical_to_their_twins(variant, twin):
+    """Round 5: the merged-phase kernel with THREE LDS buffer sets (59 = 160 x 256, 60 = 128 x 256: twice the DMA look-ahead, for the
+    prefill's HBM-fed problems) issues the same MFMAs on the same operands in the same k order as its two-set twin: bit-identical on
+    one-, two-, three-K-tile loops (shorter than the pipeline), ragged shapes, deep K, every epilogue; 20 repeats bit-identical (race screen)."""
+    from ultravox_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(variant)
+
+    def run(v, fn):
+        L.uvx_gemm_force_variant(v)
+        try:
+            return fn()
+        finally:
+            L.uvx_gemm_force_variant(-1)
+
+    for (M, N, K) in [(160, 256, 64), (316, 520, 128), (300, 256, 192), (316, 1032, 256), (632, 4096, 4096), (316, 8192, 8192), (188, 768, 28672)]:
+        a = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+        b = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
+        bias = torch.randn(N, device=DEV, generator=g).bfloat16()
+        resid = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+        modes = {"plain": lambda: ops().gemm(a, b), "bias+res": lambda: ops().gemm(a, b, bias=bias, residual=resid),
+                 "bias+gelu": lambda: ops().gemm(a, b, bias=bias, act="gelu"), "f32": lambda: ops().gemm(a, b, out_f32=True),
+                 "split3": lambda: ops().gemm_splitk(a, b, residual=resid, force_split=3 if K >= 192 else 1)}
+        for name, fn in modes.items():
+            want, got = run(twin, fn), run(variant, fn)
+            assert torch.equal(got, want), (variant, (M, N, K), name, int((got != want).sum()))
+        first = run(variant, modes["plain"])
+        for _ in range(20):
+            assert torch.equal(run(variant, modes["plain"]), first), (variant, (M, N, K), "repeat")
+        assert rel_l2(first, a.float() @ b.float().t()) < 5e-3
 
 
 def test_splitk_gemm_falls_back_to_the_plain_kernel():

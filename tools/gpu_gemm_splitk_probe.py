@@ -1,7 +1,7 @@
 """GPU probe (round 5): split-K of the prefill's GEMMs with COLD weights (every launch reads the next weight matrix of a > 1 GB pool, as
 the prefill does: 139 GB of weights per pass).  For each (M, N, K): every production tile x split factor through uvx_gemm_splitk
 (force_split), the cost model's own pick, and the unsplit pick; prints microseconds per launch (GEMM + reduce) and TF/s.
-usage: gpu_gemm_splitk_probe.py [70b|8b|all] [M,M,...]"""
+usage: gpu_gemm_splitk_probe.py [70b|8b|all] [M,M,...] [variant,variant,...]"""
 import ctypes as C
 import sys
 import torch
@@ -14,7 +14,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "all"
 Ms = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [316, 632]
 NK = {"70b": [(10240, 8192), (8192, 8192), (57344, 8192), (8192, 28672)], "8b": [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)]}
 shapes = [(m, n, k) for key in (["70b", "8b"] if which == "all" else [which]) for m in Ms for (n, k) in NK[key]]
-VARIANTS = [0, 34, 33, 32, 31]
+VARIANTS = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0, 34, 33, 32, 31]
 SPLITS = [1, 2, 3, 4, 6, 8, 12, 16]
 for (M, N, K) in shapes:
     npool = min(48, max(2, -(-(1200 << 20) // (N * K * 2))))

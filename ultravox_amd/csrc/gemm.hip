@@ -677,6 +677,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 // DMA schedule (NS = 2): XB(t+1) is issued in the first load section of tile t, [XA | WA | WB](t+2) in the second;
 // each load section ends with ONE counted wait that leaves exactly one XB piece set and one REST piece set in flight, i.e.
 // retires what was issued a whole K-tile earlier (XB(t) before the section that reads it next; REST(t+1) before tile t+1).
+// Three buffer sets (NS = 3, round 5; BM <= 160): XB(t + 2) is issued in the first load section of tile t, [XA | WA | WB](t + 3) in the second,
+// and each counted wait leaves TWO XB and TWO REST piece sets in flight - a piece has two K-tile times to arrive instead of one.  For the
+// prefill's few-hundred-row problems every weight byte comes from HBM (a panel is shared by two row tiles, not sixteen) and one K-tile
+// time (~1 us) does not cover that latency; the last NS - 1 tiles drain with vmcnt(0).
 // RAW / WAR: same rules as above - a region is read one section after the wait + barrier that retired it, and restaged
 // no earlier than two sections after its last read by EITHER row (XB(t-1)'s set: read in the second load section of tile
 // t-1, restaged in the first of tile t; [XA | WA | WB](t): read in the first load section of tile t, restaged in the second).
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 // tile, never a hung queue) guards the case of a device with < 9 free CUs.  Deterministic: fixed ranges, fixed sum order.
 template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false, int PH = 4, bool SK = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
-  static_assert(PH == 4 || (PH == 2 && NS == 2 && MODE == 0), "the merged-phase schedule is written for two buffer sets");
+  static_assert(PH == 4 || (PH == 2 && (NS == 2 || NS == 3) && MODE == 0), "the merged-phase schedule: two or three buffer sets");
   static_assert(!SK || (PH == 2 && !PERSIST), "stream-K is built on the merged-phase kernel");
   constexpr int BNW = 256;
   constexpr int MI = BM / 32, MA = (MI + 1) / 2, MB = MI - MA;
@@ -918,10 +922,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int i = 0; i < MA; ++i)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xa_base + xo[kh] + i * 16 * 128);
-      if (t + 1 < nks) {
+      if (t + NS - 1 < nks) {
 #pragma unroll
-        for (int k = 0; k < N1; ++k) dma(sxb[k], t + 1, ps);
-        UVX_VMCNT(N234 + N1);
+        for (int k = 0; k < N1; ++k) dma(sxb[k], t + NS - 1, ps);
+        UVX_VMCNT((NS - 1) * (N234 + N1));
       } else {
         UVX_VMCNT(0);
       }
@@ -943,10 +947,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) xa[i][kh] = *reinterpret_cast<const bf16x8_t*>(set + xb_base + xo[kh] + i * 16 * 128);
-      if (t + 2 < nks) {
+      if (t + NS < nks) {
 #pragma unroll
-        for (int k = 0; k < N234; ++k) dma(srest[k], t + 2, cs);
-        UVX_VMCNT(N234 + N1);
+        for (int k = 0; k < N234; ++k) dma(srest[k], t + NS, cs);
+        UVX_VMCNT((NS - 1) * (N234 + N1));
       } else {
         UVX_VMCNT(0);
       }
@@ -1468,7 +1472,7 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 59;
+constexpr int kNumVariants = 61;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
@@ -1498,7 +1502,10 @@ const Variant kVariants[kNumVariants] = {
     {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},
     {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},
     // 55 = eight waves, PING-PONG by wave row (pure MFMA phase / load phase, DMA split by operand); 56..58 = its timing probes
-    {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},     {256, 256, 0., 7.}};
+    {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},     {256, 256, 0., 7.},
+    // 59, 60 = merged-phase {160,128} x 256 with THREE buffer sets (round 5): twice the DMA look-ahead, for problems whose weights all come
+    // from HBM (the prefill).  Speed 0: the training-shape picker never takes them; pick_split does (kt1_us).
+    {160, 256, 0., 9.},     {128, 256, 0., 6.}};
 // (round 5, tried: the merged-phase kernel at 320 x 256 - both 160-row tiles of a 316-row prompt in ONE block, every weight byte staged once
 //  per K-tile for all rows.  160 accumulator + 72 fragment registers per wave leave hipcc 35 spills at two waves per SIMD, and the spilled
 //  registers are the DMA source pointers: each reload sits behind an s_waitcnt vmcnt(0) inside the K loop, which drains the LDS-DMA
@@ -1506,7 +1513,7 @@ const Variant kVariants[kNumVariants] = {
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
-constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34); }
+constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34) || v == 59 || v == 60; }
 constexpr bool is_a4(int v) { return v >= 43 && v <= 58; }
 constexpr bool is_streamk(int v) { return v >= 39 && v <= 42; }
 bool variant_available(int v) {
@@ -1528,7 +1535,7 @@ double variant_cost(int v, int M, int N, int K, int batch, bool gelu = false) {
   const double r = tiles / 256.0, frac = r - floor(r);
   const double rounds = floor(r) + (frac > 0. ? fmax(0.55, pow(frac, 0.6)) : 0.);
   const double c = kVariants[v].c + (gelu && kVariants[v].bm == 256 ? 3.0 : 0.0);
-  return rounds * kVariants[v].bm * kVariants[v].bn * (K / 64.0 + c) / kVariants[v].speed;
+  return rounds * kVariants[v].bm * kVariants[v].bn * (K / 64.0 + c) / (kVariants[v].speed > 0. ? kVariants[v].speed : 1300.);   // (speed 0: forced probe tiles)
 }
 // Stream-K launch geometry: one block per CU; `full` data-parallel rounds, the rest of the tiles shared out by K-tiles.
 int sk_grid() {
@@ -1662,6 +1669,8 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 32: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2>), grid, dim3(512), st, a); break;
     case 33: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2>), grid, dim3(512), st, a); break;
     case 34: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2>), grid, dim3(512), st, a); break;
+    case 59: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 3, 0, false, 2>), grid, dim3(512), st, a); break;
+    case 60: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 3, 0, false, 2>), grid, dim3(512), st, a); break;
 #ifdef UVX_PROBES
     case 43: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<2, 8, 0>), grid, dim3(256), st, a); break;
     case 49: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<4, 8, 0>), grid, dim3(512), st, a); break;
@@ -1815,12 +1824,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(ReduceArgs p) {
 constexpr double kCostUs = 128.0 * 256.0 / 1e6;       // variant_cost units -> microseconds (2 x 64 flop per tile element and K-tile, 256 CUs, speed in TF/s)
 constexpr double kSplitFixUs = 4.0, kSplitBytesPerUs = 2.4e6, kSparseFix = 2.0;
 constexpr int kSplitMinKTiles = 4, kSplitMax = 16;
-double kt1_us(int v) { return v == 0 ? 1.30 : v == 34 ? 0.85 : v == 33 ? 0.975 : v == 32 ? 1.00 : 1.09; }
+double kt1_us(int v) { return v == 0 ? 1.30 : v == 34 ? 0.85 : v == 33 ? 0.975 : v == 32 ? 1.00 : v == 31 ? 1.09 : kVariants[v].bm * kVariants[v].bn * kCostUs / 1300.; }
 double sparse_cost_us(int v, int M, int N, int nk_s, int s, bool gelu) {
   const long long blocks = (long long)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn) * s;
   // between half and all of the CUs busy the K-tile time climbs from the lone block's to the full chip's (the tile model's asymptotic
   // rate): 1.07 -> 1.44 us for the 256 x 256 tile between 128 and 256 blocks, 0.98 -> 1.04 for 160 x 256 (same probe)
-  const double full = kVariants[v].bm * kVariants[v].bn * kCostUs / kVariants[v].speed, x = blocks / 256.0;
+  const double full = kVariants[v].bm * kVariants[v].bn * kCostUs / (kVariants[v].speed > 0. ? kVariants[v].speed : 1300.), x = blocks / 256.0;
   const double kt = v == 0 ? kt1_us(0) : kt1_us(v) + fmax(0., full - kt1_us(v)) * fmin(1., fmax(0., (x - 0.5) / 0.5));
   const double alone = (nk_s + kSparseFix + (gelu ? 1.0 : 0.0)) * kt;
   if (v != 0 && blocks <= 256) return alone;
@@ -1831,8 +1840,9 @@ struct SplitPick { int variant, s; double us; };
 SplitPick pick_split(int M, int N, int K, size_t ws_bytes, bool gelu, int force_s) {
   const int nk = K / 64, fv = forced_variant(M, N, K);
   SplitPick best{fv >= 0 ? fv : 0, 1, 1e30};
-  for (int v : {0, 34, 33, 32, 31}) {
-    if (fv >= 0 ? v != fv : (!uvx::g_options[6] && v != 0)) continue;    // (option 6 = 0, the round-1 four-phase set: A/B builds, never split)
+  for (int v : {0, 34, 33, 32, 31, 59, 60, 18, 19, 11, 15, 16, 17}) {
+    if (fv >= 0 ? v != fv : (v > 34 || v < 31) && v != 0) continue;      // (outside the merged-phase set: only when forced - probes)
+    if (fv < 0 && !uvx::g_options[6] && v != 0) continue;                // (option 6 = 0, the round-1 four-phase set: A/B builds, never split)
     const long long tiles = (long long)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn);
     for (int s = 1; s <= kSplitMax; ++s) {
       if (force_s > 0 && s != force_s) continue;

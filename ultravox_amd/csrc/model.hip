@@ -691,13 +691,19 @@ extern "C" int32_t uvx_projector_fwd(void* stream, const uvx_config_t* cfg, cons
   const int dt = c.dtype;
   // _pad_and_stack + ln_pre (:790-791)
   RC(stack_rmsnorm_fwd(st, dt, enc_out, w->ln_pre, s.xn, s.stacked, B, Te, c.enc_d, c.stack_factor, c.proj_eps));
-  RC(gemm(st, dt, lin(s.xn, w->w1, s.h1, s.R, s.H, s.C8)));                 // linear_1 (:793)
+  // a few clips (generate(): 188 rows per 30 s): the two linears are 2 x 16 tiles - split-K (gemm.hip) with the backward's W1^T buffer,
+  // idle during any forward, as the scratch for the partial tiles.  Larger batches (training at C2: 1504 rows) keep the plain path.
+  auto psk = [&](GemmDesc g) {
+    if (dt == DT_BF16 && s.R > 64 && s.R <= 1024) { g.splitk_ws = s.w1T; g.splitk_ws_bytes = (size_t)s.C8 * s.H * esz(dt); }
+    return g;
+  };
+  RC(gemm(st, dt, psk(lin(s.xn, w->w1, s.h1, s.R, s.H, s.C8))));            // linear_1 (:793)
   RC(swiglu_fwd(st, dt, s.h1, s.a, s.R, s.Hh, /*gate_first=*/0));           // SwiGLU (:739-742, :795)
   if (c.proj_ln_mid) {
     RC(rmsnorm_fwd(st, dt, s.a, w->ln_mid, s.an, nullptr, s.R, s.Hh, c.proj_eps));  // ln_mid (:796)
-    RC(gemm(st, dt, lin(s.an, w->w2, out, s.R, s.D, s.Hh)));                        // linear_2 (:798)
+    RC(gemm(st, dt, psk(lin(s.an, w->w2, out, s.R, s.D, s.Hh))));                   // linear_2 (:798)
   } else {
-    RC(gemm(st, dt, lin(s.a, w->w2, s.ypre, s.R, s.D, s.Hh)));
+    RC(gemm(st, dt, psk(lin(s.a, w->w2, s.ypre, s.R, s.D, s.Hh))));
     RC(rmsnorm_fwd(st, dt, s.ypre, w->ln_post, out, nullptr, s.R, s.D, c.proj_eps));  // ln_post (:799)
   }
   return UVX_OK;
