@@ -428,6 +428,8 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
  * the overlapped schedule): 1 LLM attention backward, 2 LLM attention forward, 4 SwiGLU backward, 8 RMSNorm backward,
  * 16 RMSNorm forward, 32 RoPE forward, 64 encoder attention, 128 encoder LayerNorm */
 int32_t uvx_set_option(int32_t key, int32_t value);
+/* the current value of a tuning option (-1: unknown key) */
+int32_t uvx_get_option(int32_t key);
 /* Diagnostic for the stream-K GEMM launches (probe builds only - libuvx_probes.so; the production picker never selects
  * them and this returns 0): blocks that wait for another block's partial sums spin for a bounded time (~1 s) and then give
  * up rather than hang the queue.  Returns how many did since the last call (0 on a healthy run; a non-zero count means

@@ -150,7 +150,7 @@ def test_every_entry_point_survives_an_all_null_call():
     status-returning entry point either reports an argument / shape error through uvx_last_error or is a no-op on the empty
     problem — before any GPU work, so this runs without a device."""
     lib = _lib.lib()
-    skip = {"uvx_last_error", "uvx_abi_version", "uvx_set_option", "uvx_gemm_pick_variant", "uvx_gemm_pick_split", "uvx_gemm_override_variant",
+    skip = {"uvx_last_error", "uvx_abi_version", "uvx_set_option", "uvx_get_option", "uvx_gemm_pick_variant", "uvx_gemm_pick_split", "uvx_gemm_override_variant",
             "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_prof_begin", "uvx_prof_end", "uvx_prof_records", "uvx_prof_union_ms",
             "uvx_comm_world_size", "uvx_comm_version"}         # value-returning queries, not status codes
     rejected = 0

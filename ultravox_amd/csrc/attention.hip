@@ -1298,11 +1298,8 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   if (fused) {
     constexpr int smem = (FUSED_TMAX / 16) * (FUSED_TMAX / 16 + 1) / 2 * 512 + 2 * 64 * 128 * 2 + 2 * FUSED_TMAX * 4 + 8 * STAGE_BYTES;
     static_assert(smem <= 160 * 1024, "LDS of one CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-      UVX_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_k<128, FUSED_TMAX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-      attr_set = true;
-    }
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) UVX_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_k<128, FUSED_TMAX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     // (64-query steps, NQT = 4: 87.9 vs 87.5 ms per step - profiles/r03_call13_probes.txt - not instantiated)
     hipLaunchKernelGGL((attn_bwd_fused_k<128, FUSED_TMAX, 2>), dim3(d.f.Hq, d.f.B), dim3(512), smem, st, a);
   }

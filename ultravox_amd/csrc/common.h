@@ -154,3 +154,19 @@ __device__ __forceinline__ float gelu_fast(float x) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: one of these per call site remembers which
+// devices have had it set (bit d of the mask; ADVICE r4: a process-wide `static bool` would leave a second device of the same process
+// at the 64 KB default).  Two threads may both see "not yet" and both set it - harmless, the call is idempotent.
+#include <atomic>
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool need() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return true;
+    const unsigned long long bit = 1ull << (d & 63);
+    if (mask.load(std::memory_order_relaxed) & bit) return false;
+    mask.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+  }
+};

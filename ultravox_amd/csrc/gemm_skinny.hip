@@ -428,8 +428,8 @@ int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm
   const int mb = d.M;
   const size_t sh = (size_t)mb * d.K * 2;
 #define UVX_GEMVN(MB, RBV) do { \
-    static bool attr = false; \
-    if (!attr) { UVX_HIP(hipFuncSetAttribute((const void*)gemv_rows_bf16_k<MB, 4, RBV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr = true; } \
+    static PerDeviceOnce attr; \
+    if (attr.need()) UVX_HIP(hipFuncSetAttribute((const void*)gemv_rows_bf16_k<MB, 4, RBV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
     hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, RBV, true>), grid, dim3(512), sh, st, a); } while (0)
   if (rb == 32) { if (mb == 1) UVX_GEMVN(1, 32); else UVX_GEMVN(2, 32); }
   else if (rb == 16) { if (mb == 1) UVX_GEMVN(1, 16); else UVX_GEMVN(2, 16); }
@@ -478,8 +478,8 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
     const bool two = d.swiglu || d.N >= 16384;
     const dim3 grid(two ? (d.N + 31) / 32 : (d.N + 15) / 16);
 #define UVX_SKS(TT, MTT) do { \
-      static bool attr2 = false; \
-      if (!attr2) { UVX_HIP(hipFuncSetAttribute((const void*)gemm_skinny_bf16_k<TT, true, MTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); attr2 = true; } \
+      static PerDeviceOnce attr2; \
+      if (attr2.need()) UVX_HIP(hipFuncSetAttribute((const void*)gemm_skinny_bf16_k<TT, true, MTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
       hipLaunchKernelGGL((gemm_skinny_bf16_k<TT, true, MTT>), grid, dim3(512), sh, st, a); } while (0)
     if (d.M <= 16) { if (two) UVX_SKS(2, 1); else UVX_SKS(1, 1); }
     else if (d.M <= 32) { if (two) UVX_SKS(2, 2); else UVX_SKS(1, 2); }

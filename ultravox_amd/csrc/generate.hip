@@ -309,11 +309,8 @@ __global__ __launch_bounds__(NTH) void attn_decode_grp_k(const T* __restrict__ q
 template <int DD, int GG>
 int launch_decode_grp(hipStream_t st, size_t sh, int blocks, const bf16_t* qkv, const bf16_t* ck, const bf16_t* cv, bf16_t* o,
                       const int32_t* kv_start, int Hq, int Hkv, int Tmax, int len, int QKV, float scale, int lo, int hsplit) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    UVX_HIP(hipFuncSetAttribute((const void*)attn_decode_grp_k<bf16_t, DD, GG, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
-  }
+  static PerDeviceOnce attr_set;
+  if (attr_set.need()) UVX_HIP(hipFuncSetAttribute((const void*)attn_decode_grp_k<bf16_t, DD, GG, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   hipLaunchKernelGGL((attn_decode_grp_k<bf16_t, DD, GG, 1024>), dim3(blocks), dim3(1024), sh, st, qkv, ck, cv, o, kv_start, Hq, Hkv, Tmax, len,
                      QKV, scale, lo, hsplit);
   return UVX_OK;
@@ -464,7 +461,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   const uvx_config_t& c = *cfg;
   UVX_CHECK(T >= 1 && T <= Tmax, UVX_ERR_SHAPE, "llm_prefill: prompt length %d exceeds the cache length %d", T, Tmax);
   UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
-  RC(g3_check(c, w, T));          // (the PROMPT must fit the sliding window; the decode steps clamp their key range)
+  RC(g3_check(c, w, T));          // (Gemma-3: post norms + local rotary table present; prompts beyond the window run the WINDOWED kernels)
   hipStream_t st = (hipStream_t)stream;
   Arena a(workspace, ws_bytes);
   InferWs s = carve(a, c, B, T);
@@ -547,7 +544,7 @@ static int32_t prefill_chunk_impl(void* stream, const uvx_config_t* cfg, const u
   UVX_CHECK(Tn >= 1 && cur_len >= 0 && Tf <= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: %d cached + %d new positions exceed the cache length %d",
             cur_len, Tn, Tmax);
   UVX_CHECK(w->rope_len >= Tmax, UVX_ERR_SHAPE, "llm_prefill_chunk: rope table (%d) shorter than the cache (%d)", w->rope_len, Tmax);
-  RC(g3_check(c, w, cur_len + Tn));   // (a multi-token chunk attends to the whole cache: cache + chunk must fit the window)
+  RC(g3_check(c, w, cur_len + Tn));   // (Gemma-3 weight check; cache + chunk beyond the window run the windowed kernels)
   hipStream_t st = (hipStream_t)stream;
   Arena a(workspace, ws_bytes);
   ChunkWs k;

@@ -143,7 +143,8 @@ int layernorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, cons
 // Y[M, r] = round(alpha * sum_c X[m, c] * W(j, c));  W stored [r][C] (w_is_cr = 0) or [C][r] (1)
 int lora_down(hipStream_t st, int dtype, const void* X, long long ldx, const void* W, int w_is_cr, void* Y, long long ldy,
               long long M, int C, int r, float alpha);
-// Z[M, C] (+)= round(alpha * sum_j Y[m, j] * W(c, j));  W stored [C][r] (w_is_rc = 0) or [r][C] (1)
+// Z[M, C] (+)= round(alpha * sum_j Y[m, j] * W(c, j));  W stored [C][r] (w_is_rc = 0) or [r][C] (1).  r <= 8: Y rows must be padded to 8
+// columns (zeros beyond r, as lora_down leaves them) with ldy % 8 == 0 and 16-byte-aligned Y / W / Z - checked.
 int lora_up(hipStream_t st, int dtype, const void* Y, long long ldy, const void* W, int w_is_rc, void* Z, long long ldz,
             long long M, int C, int r, float alpha, int accumulate);
 // out = alpha * Y[M, r]^T . X[M, C]  as [r][C] or, transpose_out, [C][r]  (f32; scratch: lora_wgrad_scratch_floats)

@@ -180,11 +180,8 @@ int logmel(hipStream_t st, const float* pcm, const float* window, const float* t
   if (B == 0) return UVX_OK;
   const int nblk = cdiv(F, FR);
   const size_t sh = sizeof(float) * (FR * XS + FR * PS);
-  static bool attr_set = false;
-  if (!attr_set) {
-    UVX_HIP(hipFuncSetAttribute((const void*)logmel_pass1_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    attr_set = true;
-  }
+  static PerDeviceOnce attr_set;
+  if (attr_set.need()) UVX_HIP(hipFuncSetAttribute((const void*)logmel_pass1_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
   hipLaunchKernelGGL(logmel_pass1_k, dim3(nblk, B), dim3(256), sh, st, pcm, window, tw_cos, tw_sin, mel_fb, out, scratch,
                      L, n_mels, F, F_stride);
   hipLaunchKernelGGL(logmel_pass2_k, dim3(32, B), dim3(256), 0, st, out, scratch, nblk, n_mels, F, F_stride);

@@ -250,6 +250,11 @@ int lora_down(hipStream_t st, int dtype, const void* X, long long ldx, const voi
 int lora_up(hipStream_t st, int dtype, const void* Y, long long ldy, const void* W, int w_is_rc, void* Z, long long ldz,
             long long M, int C, int r, float alpha, int accumulate) {
   UVX_CHECK(C % 8 == 0 && ldz % 8 == 0 && r > 0 && r <= RMAX, UVX_ERR_SHAPE, "lora_up: C=%d r=%d unsupported", C, r);
+  // the r <= 8 path reads Y rows as one 16-byte vector: rows padded to 8 columns (zeros beyond r - lora_down writes them so), ldy % 8 == 0 and
+  // 16-byte-aligned Y / W / Z (enforced here, not assumed)
+  const size_t esz_ = dtype == DT_BF16 ? 2 : 4;
+  UVX_CHECK(r > 8 || (ldy % 8 == 0 && ((uintptr_t)Y % (8 * esz_)) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)Z % 16) == 0), UVX_ERR_SHAPE,
+            "lora_up: rank %d <= 8 needs Y rows padded to 8 columns with ldy %% 8 == 0 (ldy = %lld) and 16-byte-aligned operands", r, ldy);
   if (M == 0) return UVX_OK;
   const long long n = M * (C / 8);
   const dim3 grid((unsigned)((n + 255) / 256));

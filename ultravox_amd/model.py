@@ -53,6 +53,7 @@ class KVState:
 class GenerateOutput:
     sequences: torch.Tensor
     past_key_values: Optional[KVState] = None
+    logits: Optional[tuple] = None      # output_logits=True: one [B, vocab] tensor of raw next-token logits per generated token (HF's field)
 
 
 @dataclasses.dataclass
@@ -881,8 +882,13 @@ class UltravoxModel:
         t_logits = self._workspace("teacher_logits", nt * V * 2).view(self.dtype)[: nt * V]
         am = None if alt_attention_mask is None else alt_attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         side = None
-        if getattr(self, "kl_teacher_side_stream", True) and dev.type == "cuda":
-            side = self.__dict__.setdefault("_kl_side", torch.cuda.Stream(device=dev))
+        # With several LLM layer chains (uvx_set_option(11, n >= 2)) every uvx_llm_fwd* call forks the device's ONE set of side streams
+        # and events; two calls issued from two streams would share it (ordering held only because one host thread issues
+        # everything, and the chains of the two calls serialised on the same side streams) - the teacher then runs on the caller's stream.
+        if getattr(self, "kl_teacher_side_stream", True) and dev.type == "cuda" and l.uvx_get_option(11) < 2:
+            if "_kl_side" not in self.__dict__:
+                self._kl_side = torch.cuda.Stream(device=dev)
+            side = self._kl_side
             side.wait_stream(torch.cuda.current_stream(dev))
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             check(l.uvx_llm_fwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(alt_embeds), ptr(am), Bt, Tt,
@@ -934,7 +940,9 @@ class UltravoxModel:
         rep = None if rep is None or float(rep) == 1.0 else float(rep)
         if rep is not None and not rep > 0:
             raise ValueError(f"`repetition_penalty` has to be a strictly positive float, but is {rep}")
-        ignored = set(kwargs) - {"past_key_values", "return_dict_in_generate", "repetition_penalty", "num_beams", "use_cache"}
+        want_logits = bool(kwargs.get("output_logits", False)) and return_dict      # HF: only reported in the dict form
+        step_logits = []
+        ignored = set(kwargs) - {"past_key_values", "return_dict_in_generate", "repetition_penalty", "num_beams", "use_cache", "output_logits"}
         if ignored:
             import warnings
             warnings.warn(f"generate(): these arguments have no effect here: {sorted(ignored)}")
@@ -1016,6 +1024,8 @@ class UltravoxModel:
         unfinished = torch.ones(B, device=dev, dtype=torch.bool)
         n_decoded = 0
         for step in range(max_new_tokens):
+            if want_logits:
+                step_logits.append(logits.clone())
             if rep is not None:      # HF order: logits processors on f32 scores first, then the warpers / argmax
                 scores = self._repetition_penalty(logits.float(), torch.cat(out, dim=1), rep)
                 nxt = self._sample(scores, temperature, top_k, top_p, generator) if do_sample else torch.argmax(scores, dim=-1)
@@ -1046,7 +1056,7 @@ class UltravoxModel:
         state = KVState(cache=cache, Tmax=Tmax, cur_len=T + n_decoded, pos_next=(next_pos + n_decoded).to(torch.int32).contiguous(),
                         kv_start=kv_start, tokens=sequences[:, :T + n_decoded].contiguous(),
                         partial_ok=bool(past is not None and past.partial_ok))
-        return GenerateOutput(sequences=sequences, past_key_values=state)
+        return GenerateOutput(sequences=sequences, past_key_values=state, logits=tuple(step_logits) if want_logits else None)
 
     @staticmethod
     def _repetition_penalty(scores: torch.Tensor, seen_ids: torch.Tensor, penalty: float) -> torch.Tensor:
