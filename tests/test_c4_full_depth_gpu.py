@@ -81,6 +81,7 @@ def test_c4_llama70b_generate_full_depth_matches_torch_bf16_teacher_forced():
            "token_agreement_per_row": agree.mean(1).tolist(),
            "top5_contains_hip_token": (ref.topk(5, -1).indices == seq[:, T:, None]).any(-1).float().mean().item()}
     record("c4_full_depth", rec)
-    assert rec["prefill_logits_hip_vs_torch_bf16"] < 6e-2, rec
-    assert rec["decode_logits_worst"] < 6e-2, rec
+    # bars = 1.5 x the first record (profiles/r05_parity/c4_full_depth.json: prefill 2.38e-2, decode steps <= 2.46e-2, 29 of 32 tokens, top-5 32 of 32)
+    assert rec["prefill_logits_hip_vs_torch_bf16"] < 3.6e-2, rec
+    assert rec["decode_logits_worst"] < 3.7e-2, rec
     assert rec["token_agreement_teacher_forced"] >= 0.8 and rec["top5_contains_hip_token"] >= 0.95, rec

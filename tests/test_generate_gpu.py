@@ -336,3 +336,38 @@ def test_bf16_decode_attention_over_long_caches_and_group_sizes(heads, kv_heads,
         state = out.past_key_values
         got, want = out.logits[:, 0].float(), tf[:, T + step]
         assert rel_l2(got, want) < 3e-2, (step, rel_l2(got, want))
+
+
+@pytest.mark.parametrize("B", [17, 40, 64])
+def test_bf16_decode_batches_beyond_16_rows_take_the_tiled_split_path(B):
+    """Round 5: a decode batch of more than 16 sequences runs its linears on the tiled kernels with split-K (the weight-streaming
+    kernels serve 16-row tiles one after the other; gemm.hip gemm_nt) - Llama-shaped layers wide enough for the split to engage
+    (K = 1024 / 2816: 16 / 44 K-tiles), left padding in some rows.  Every decode step's logits (generate(output_logits=True)) against the
+    teacher-forced forward of the same model, and the greedy tokens they imply; a B = 16 batch (weight-streaming kernels) of the same
+    prompts gives the same tokens wherever the two paths' logits are not within rounding of a tie."""
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    cfg = UltravoxConfig(
+        audio_config=dict(d_model=128, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=256),
+        text_config=dict(hidden_size=1024, intermediate_size=2816, num_hidden_layers=3, num_attention_heads=8,
+                         num_key_value_heads=2, head_dim=128, vocab_size=2048, eos_token_id=2, max_position_embeddings=1024),
+        hidden_size=256, projector_ln_mid=True)
+    model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=7, rope_len=256)
+    torch.manual_seed(B)
+    T, new = 41, 6
+    ids = torch.randint(3, 2048, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    for r in range(1, B, 3):
+        am[r, :r % 11 + 1] = 0
+    ids[am == 0] = 2
+    out = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=new, eos_token_id=-1, return_dict_in_generate=True, output_logits=True)
+    seq = out.sequences
+    assert len(out.logits) == new and tuple(out.logits[0].shape) == (B, 2048)
+    am_full = torch.cat([am, torch.ones(B, new, dtype=torch.long)], 1).to(DEV)
+    tf = model.forward(input_ids=seq, attention_mask=am_full).logits.float()
+    for step in range(new):
+        got, want = out.logits[step].float(), tf[:, T - 1 + step]
+        assert rel_l2(got, want) < 3e-2, (step, rel_l2(got, want))
+        assert torch.equal(got.argmax(-1), seq[:, T + step])
+    small = model.generate(ids[:16].to(DEV), attention_mask=am[:16].to(DEV), max_new_tokens=new, eos_token_id=-1)
+    assert (small[:, T:] == seq[:16, T:]).float().mean().item() > 0.9

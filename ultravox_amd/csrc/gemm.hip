@@ -1911,7 +1911,14 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   UVX_CHECK(d.lda % 8 == 0 && d.ldb % 8 == 0, UVX_ERR_SHAPE, "gemm: lda=%d / ldb=%d must be multiples of 8", d.lda, d.ldb);
   UVX_CHECK(!d.residual || d.ldr % 4 == 0, UVX_ERR_SHAPE, "gemm: ldr=%d must be a multiple of 4", d.ldr);
   UVX_CHECK(!d.accumulate || d.out_f32, UVX_ERR_INVALID, "gemm: accumulate needs f32 output");
-  if (uvx::g_gemm_variant < 0 && uvx::gemm_skinny_applicable(d)) return uvx::gemm_skinny_bf16(st, d);   // few rows: stream the weights
+  // few rows: stream the weights.  Beyond 16 rows the weight-streaming kernels serve 16-row tiles one after the other (MT = 2, 4) and lose to a
+  // 128 x 256 tile whose K loop is cut over 6-8 blocks wherever the caller lent split-K scratch (Llama-3.3-70B's four linears, us per
+  // launch, staged kernel / tiled split-K: 32 rows 447 / 345, 64 rows 871 / 358 - profiles/r05_gemm_splitk_decode_rows.txt)
+  const bool split_ok = d.splitk_ws && d.batch <= 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
+      ((uintptr_t)d.C & 15) == 0 && ((uintptr_t)d.splitk_ws & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
+      (!d.residual || (d.ldr % 8 == 0 && ((uintptr_t)d.residual & 15) == 0)) &&
+      (!d.swiglu || (d.ldc2 % 8 == 0 && ((uintptr_t)d.C2 & 15) == 0));      // (the reduce kernel's 16-byte accesses apply)
+  if (uvx::g_gemm_variant < 0 && !(split_ok && d.M > 16) && uvx::gemm_skinny_applicable(d)) return uvx::gemm_skinny_bf16(st, d);
   GemmArgs a;
   a.A = (const bf16_t*)d.A; a.B = (const bf16_t*)d.B; a.C = d.C;
   a.bias = (const bf16_t*)d.bias; a.residual = (const bf16_t*)d.residual;
@@ -1935,10 +1942,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   const bool gelu = d.act == 1;
   int sparse_variant = -1;       // the split picker's unsplit choice for a launch of at most one block per CU (its model, not the tile model's)
   // split-K (see splitk_reduce_k): only where the caller lent scratch for the partial tiles and the reduce kernel's 16-byte accesses apply
-  if (d.splitk_ws && batch == 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
-      ((uintptr_t)d.C & 15) == 0 && ((uintptr_t)d.splitk_ws & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
-      (!d.residual || (d.ldr % 8 == 0 && ((uintptr_t)d.residual & 15) == 0)) &&
-      (!d.swiglu || (d.ldc2 % 8 == 0 && ((uintptr_t)d.C2 & 15) == 0))) {
+  if (split_ok) {
     const SplitPick sp = pick_split(d.M, d.N, d.K, d.splitk_ws_bytes, gelu, d.splitk_force);
     if (sp.s == 1 && (long long)cdiv(d.M, kVariants[sp.variant].bm) * cdiv(d.N, kVariants[sp.variant].bn) <= 256) sparse_variant = sp.variant;
     if (sp.s > 1) {

@@ -46,8 +46,9 @@ InferWs carve(Arena& a, const uvx_config_t& c, int B, int T) {
   w.last = a.take((size_t)B * c.llm_d * es); w.hn = a.take((size_t)B * c.llm_d * es);
   w.kvs = (int32_t*)a.take(sizeof(int32_t) * B); w.kvl = (int32_t*)a.take(sizeof(int32_t) * B);
   w.pos = (int32_t*)a.take(sizeof(int32_t) * M);
-  // one or two prompts' worth of rows: too many for the weight-streaming kernels (M <= 64), too few tiles for the 256 CUs
-  w.sk_bytes = c.dtype == DT_BF16 && M > 64 && M <= 1536 ? gemm_splitk_ws_bytes((int)M, std::max(std::max(w.QKV, 2 * c.llm_inter), c.llm_d)) : 0;
+  // a decode batch beyond 16 sequences, or one or two prompts' worth of rows: too many rows for the weight-streaming kernels (the staged
+  // MFMA kernel serves 16-row tiles: B = 32 runs at 0.44, B = 64 at 0.23 of the HBM roofline), too few tiles for the 256 CUs
+  w.sk_bytes = c.dtype == DT_BF16 && M > 16 && M <= 1536 ? gemm_splitk_ws_bytes((int)M, std::max(std::max(w.QKV, 2 * c.llm_inter), c.llm_d)) : 0;
   w.sk = w.sk_bytes ? a.take(w.sk_bytes) : nullptr;
   return w;
 }
@@ -644,13 +645,13 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
       if (rc == UVX_ERR_UNSUPPORTED) {
         RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
         g.A = s.n;
-        RC(gemm(st, dt, g));
+        RC(gemm(st, dt, sk(g, s)));
       } else {
         RC(rc);
       }
     } else {
       RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
-      RC(qkv_rope(st, c, w, L, s.n, s.qkv, positions, B, 1, s.QKV, l));
+      RC(qkv_rope(st, c, w, L, s.n, s.qkv, positions, B, 1, s.QKV, l, &s));
     }
     // Gemma-3 sliding-window layer: the new token attends to the last `window` positions = cache slots (the slots of a sequence are
     // contiguous, so the window is a clamp of the first visible slot)
@@ -696,7 +697,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
     RC(mlp_block(st, c, L, s, B, s.x2, s.x));
   }
   RC(rmsnorm_fwd(st, dt, s.x, w->norm, s.hn, nullptr, B, D, c.rms_eps, c.llm_flavor));
-  return gemm(st, dt, lin(s.hn, w->lm_head, logits, B, c.vocab, D));
+  return gemm(st, dt, sk(lin(s.hn, w->lm_head, logits, B, c.vocab, D), s));
 }
 
 extern "C" int32_t uvx_argmax(void* stream, int32_t dtype, const void* logits, int32_t rows, int32_t V, int64_t* out) {
