@@ -369,5 +369,17 @@ def test_bf16_decode_batches_beyond_16_rows_take_the_tiled_split_path(B):
         got, want = out.logits[step].float(), tf[:, T - 1 + step]
         assert rel_l2(got, want) < 3e-2, (step, rel_l2(got, want))
         assert torch.equal(got.argmax(-1), seq[:, T + step])
+    # The two paths round differently (split-K partial sums vs one f32 chain), so a row may part ways at a near-tie and then - fed its own
+    # token - stay apart: compare each row up to its first differing token only, and require that token to BE a near-tie in this path's
+    # logits (the two candidates closer than the bf16 logit spacing the 3e-2 bar above allows).
     small = model.generate(ids[:16].to(DEV), attention_mask=am[:16].to(DEV), max_new_tokens=new, eos_token_id=-1)
-    assert (small[:, T:] == seq[:16, T:]).float().mean().item() > 0.9
+    same = small[:, T:] == seq[:16, T:]
+    assert same[:, 0].float().mean().item() >= 0.75
+    for r in range(16):
+        miss = (~same[r]).nonzero()
+        if miss.numel() == 0:
+            continue
+        step = int(miss[0])
+        row = out.logits[step][r].float()
+        gap = (row[seq[r, T + step]] - row[small[r, T + step]]).abs().item()
+        assert gap <= 3e-2 * row.norm().item() / row.numel() ** 0.5 * 4, (r, step, gap)
