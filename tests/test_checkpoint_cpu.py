@@ -284,3 +284,38 @@ def test_config_matches_the_reference_config_fixture():
     lc, ref = LossConfig(), fx["_loss_config_defaults"]
     assert lc.loss_function.value == ref["loss_function"] and lc.kl_temperature == ref["kl_temperature"]
     assert lc.requires_alt_fields == ref["requires_alt_fields"]
+
+
+@pytest.mark.parametrize("family", ["llama", "qwen2", "qwen3", "gemma", "gemma3"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_unpack_inverts_the_packed_tower_layouts(family, dtype):
+    """weights.unpack_encoder / unpack_llm (what re-exports a merged tower, ultravox_model.py:528-559 + :565-591): the packed
+    device layouts (fused q|k|v with the pre-scaled q rows, 16-row interleaved gate|up, im2col conv weights, family extras) go
+    back to the reference's checkpoint names bit for bit - every tower key, nothing else."""
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import pack_encoder, pack_llm, random_state_dict, unpack_encoder, unpack_llm
+    text = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                head_dim=32, vocab_size=256)
+    if family != "llama":
+        text["model_type"] = {"gemma3": "gemma3_text"}.get(family, family)
+    if family == "gemma3":
+        text.update(sliding_window=64, query_pre_attn_scalar=32, layer_types=["sliding_attention", "full_attention"])
+    cfg = UltravoxConfig(audio_config=dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256),
+                         text_config=text, hidden_size=128)
+    sd = random_state_dict(cfg, seed=3, dtype=dtype)
+    back = {**unpack_encoder(pack_encoder(sd, cfg, dtype, "cpu"), cfg), **unpack_llm(pack_llm(sd, cfg, dtype, "cpu", with_transposes=False), cfg)}
+    towers = {k for k in sd if not k.startswith("multi_modal_projector.")}
+    assert set(back) == towers
+    for k in sorted(towers):
+        assert back[k].dtype == dtype and back[k].shape == sd[k].shape and torch.equal(back[k], sd[k]), k
+
+
+def test_unpack_refuses_a_scale_it_cannot_undo_exactly():
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import pack_encoder, random_state_dict, unpack_encoder
+    cfg = UltravoxConfig(audio_config=dict(d_model=96, encoder_layers=1, encoder_attention_heads=3, encoder_ffn_dim=128),
+                         text_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                          num_key_value_heads=2, head_dim=32, vocab_size=64), hidden_size=64)
+    sd = random_state_dict(cfg, seed=3, dtype=torch.float32)
+    with pytest.raises(ValueError, match="power of two"):
+        unpack_encoder(pack_encoder(sd, cfg, torch.float32, "cpu"), cfg)      # head_dim 32: scale 2^-2.5

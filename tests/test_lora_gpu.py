@@ -152,8 +152,20 @@ def test_llm_and_encoder_lora_train_step_matches_oracle(dtype):
     mine = model.projector_grads()
     assert mine["multi_modal_projector.linear_1.weight"].abs().max().item() == 0
     assert mine["language_model.base_model.model.model.layers.0.self_attn.q_proj.lora_B.default.weight"].abs().max().item() > 0
-    with pytest.raises(NotImplementedError):
-        model.generate(input_ids=gb["input_ids"], max_new_tokens=2)
+    # generate() under the un-merged LLM adapter (the reference's peft-wrapped LLM decodes with the adapters active): the q / k rows
+    # are folded for the call and put back bit for bit; the tokens are those of the merged model (same folded weights)
+    rows_before = [L["wqkv"].clone() for L in model._llm["layers"]]
+    gen = {k: v for k, v in gb.items() if k != "labels"}
+    model.eval()
+    out = model.generate(audio_values=mel, max_new_tokens=4, eos_token_id=-1, return_dict_in_generate=True, **gen)
+    assert model.text_lora_r == cfg.text_model_lora_config["r"]
+    assert all(torch.equal(L["wqkv"], w) for L, w in zip(model._llm["layers"], rows_before))
+    step = model.forward(input_ids=out.sequences[:, -1:], past_key_values=out.past_key_values)      # the cache path folds per call
+    assert all(torch.equal(L["wqkv"], w) for L, w in zip(model._llm["layers"], rows_before))
+    model.merge_and_unload()
+    merged = model.generate(audio_values=mel, max_new_tokens=5, eos_token_id=-1, return_dict_in_generate=True, output_logits=True, **gen)
+    assert torch.equal(merged.sequences[:, :-1], out.sequences)
+    assert rel_l2(step.logits[:, -1], merged.logits[4]) < (1e-4 if dtype == torch.float32 else 3e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -182,6 +194,21 @@ def test_merge_and_unload_matches_adapter_forward(dtype):
     gen = {k: v for k, v in gb.items() if k != "labels"}
     out = model.generate(audio_values=mel, max_new_tokens=4, eos_token_id=-1, **gen)
     assert out.shape[1] == gb["input_ids"].shape[1] + 4
+    # the reference's book-keeping of a merged model (ultravox_model.py:528-559): base ids cleared, LoRA configs gone, every tower
+    # parameter a keep_param - and the export that follows from it: save_pretrained writes the merged towers whole (read back from
+    # the packed device weights), a reload from that directory ALONE computes the same logits bit for bit
+    import tempfile
+    from ultravox_amd.weights import random_state_dict as rsd
+    assert model.config.audio_model_id is None and model.config.text_model_id is None
+    assert not hasattr(model.config, "audio_model_lora_config") and not hasattr(model.config, "text_model_lora_config")
+    towers = {k for k in rsd(cfg, seed=0, dtype=dtype) if not k.startswith("multi_modal_projector.")}
+    assert towers <= model.keep_params and not any("lora_" in k for k in model.keep_params)
+    with tempfile.TemporaryDirectory() as d:
+        saved = model.save_pretrained(d)
+        assert set(saved) == towers | set(model.projector_state_dict())
+        again = UltravoxModel.from_pretrained(d, device=DEV, dtype=dtype, seed=999)      # (a different seed: nothing may come from the random base)
+    assert again.lora_r == 0 and again.text_lora_r == 0
+    assert torch.equal(again.forward(audio_values=mel, **gb).logits, model.forward(audio_values=mel, **gb).logits)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -23,6 +23,7 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .config import LossConfig, LossFunction, UltravoxConfig
 from .weights import (LORA_TARGETS, init_lora_state_dict, llm_lora_key, lora_key, pack_encoder, pack_llm, pack_wav2vec2,
+                      unpack_encoder, unpack_llm,
                       random_state_dict)
 
 
@@ -183,7 +184,7 @@ class UltravoxModel:
     def _load(self, sd, rope_len):
         cfg, dev, dt = self.config, self.device, self.dtype
         a, t = cfg.audio_config, cfg.text_config
-        self.lora_r = int(cfg.audio_model_lora_config.get("r", 0) or 0)      # encoder LoRA rank (0: frozen tower)
+        self.lora_r = int((getattr(cfg, "audio_model_lora_config", None) or {}).get("r", 0) or 0)      # encoder LoRA rank (0: frozen tower)
         self.is_wav2vec2 = bool(getattr(a, "is_wav2vec2", False))
         if self.is_wav2vec2:
             if self.lora_r > 0:
@@ -202,7 +203,7 @@ class UltravoxModel:
         # encoder LoRA: lora_A / lora_B of q_proj and k_proj of every layer join the SAME flat trainable bucket (one
         # all-reduce, one AdamW launch); missing keys get peft's initialisation (A kaiming-uniform, B zero)
         self._lora_names = []
-        self.text_lora_r = int(cfg.text_model_lora_config.get("r", 0) or 0)   # LLM LoRA rank (0: frozen LLM)
+        self.text_lora_r = int((getattr(cfg, "text_model_lora_config", None) or {}).get("r", 0) or 0)   # LLM LoRA rank (0: frozen LLM)
         if self.lora_r > 0 or self.text_lora_r > 0:
             init = init_lora_state_dict(cfg, seed=0, dtype=dt)
             todo = [(lora_key, a.encoder_layers)] * (self.lora_r > 0) + [(llm_lora_key, t.num_hidden_layers)] * (self.text_lora_r > 0)
@@ -348,10 +349,18 @@ class UltravoxModel:
         """What can be saved from this model: the trainable tensors plus the frozen-tower tensors a loaded checkpoint carried
         (`keep_params`, retained on the host by from_pretrained).  Deviation from the reference, stated: there `keep_params`
         may name ANY key of the module's state dict (ultravox_model.py:59, :565-584: the whole model lives in one nn.Module);
-        here the frozen towers exist only as packed device weights, so a keep_param without a retained tensor cannot be
-        re-saved.  strict=True (what save_pretrained / save_checkpoint use by default) raises; otherwise such keys are reported with
-        a warning and left out (the reload then takes that tower from its base model id)."""
+        here the frozen towers exist as packed device weights: a keep_param nobody retained on the host is read back from them
+        under its plain HF name (weights.unpack_encoder / unpack_llm).  What still cannot be re-saved: wav2vec2 tower keys, and
+        tower keys while that tower's adapters are un-merged (peft then nests the base weights under other names).
+        strict=True (what save_pretrained / save_checkpoint use by default) raises for those; otherwise they are reported with a
+        warning and left out (the reload then takes that tower from its base model id)."""
         sd = {**getattr(self, "_kept_tensors", {}), **self.projector_state_dict()}
+        # frozen-tower keys nobody retained on the host are read back from the packed device weights (exact inverses of the
+        # packing: weights.unpack_*) - the merged towers after merge_and_unload, or keep_params a caller added by name
+        for prefix, ok, unpack, packed in (("audio_tower.", not self.is_wav2vec2 and self.lora_r == 0, unpack_encoder, self._enc),
+                                           ("language_model.", self.text_lora_r == 0, unpack_llm, self._llm)):
+            if ok and any(k.startswith(prefix) and k not in sd for k in self.keep_params):
+                sd = {**unpack(packed, self.config, prefix), **sd}
         lost = sorted(k for k in self.keep_params if k not in sd)
         if lost:
             msg = (f"keep_params names {len(lost)} tensor(s) this model cannot re-save (e.g. {lost[:3]}): frozen-tower keys are only "
@@ -432,11 +441,13 @@ class UltravoxModel:
     @torch.no_grad()
     def merge_and_unload(self) -> None:
         """UltravoxModel.merge_and_unload (ultravox_model.py:528-559; peft's merge): fold every LoRA adapter into the packed
-        base weights, W += scaling * B @ A, and drop the adapters - afterwards the towers run their plain (frozen) kernels, so
-        generate() and the KL teacher pass work on a LoRA-trained model.  The merged towers are not exported back to
-        checkpoint form (the reference then saves them whole via keep_params); inference only."""
+        base weights, W += scaling * B @ A, and drop the adapters - afterwards the towers run their plain (frozen) kernels.
+        As in the reference, a tower that carried adapters can no longer be re-created from its base model id: the id is
+        cleared, every parameter of that tower joins keep_params (the next save_pretrained writes the merged tower whole, read
+        back from the packed device weights - weights.unpack_encoder / unpack_llm) and the two LoRA configs leave the config."""
         def fold(w_rows: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scale: float) -> None:
             w_rows.copy_((w_rows.float() + scale * (B.float() @ A.float())).to(w_rows.dtype))
+        kept = getattr(self, "_kept_tensors", {})
         if self.lora_r > 0:
             d = self.config.audio_config.d_model
             qs = (d // self.config.audio_config.encoder_attention_heads) ** -0.5      # folded into the packed q rows
@@ -447,6 +458,7 @@ class UltravoxModel:
                 if L.get("wqkv_t") is not None:
                     L["wqkv_t"].copy_(L["wqkv"].t())
             self.lora_r = 0
+            self._merged_tower("audio_tower.", "audio_model_id", kept)
         if self.text_lora_r > 0:
             t = self.config.text_config
             qc, kc = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim
@@ -457,7 +469,28 @@ class UltravoxModel:
                 if L.get("wqkv_t") is not None:
                     L["wqkv_t"].copy_(L["wqkv"].t())
             self.text_lora_r = 0
-        self._lora_names = []        # the adapters are gone: only the projector remains trainable / saved
+            self._merged_tower("language_model.", "text_model_id", kept)
+        self._lora_names = []        # the adapters are gone: only the projector remains trainable
+        for param in ("text_model_lora_config", "audio_model_lora_config"):      # ultravox_model.py:555-557
+            if hasattr(self.config, param):
+                delattr(self.config, param)
+
+    def _merged_tower(self, prefix: str, id_attr: str, kept: Dict[str, torch.Tensor]) -> None:
+        """Book-keeping of a merged tower (ultravox_model.py:529-553): the base id no longer describes the weights, every tower
+        parameter is kept; adapter keys and host copies of pre-merge tensors a loaded checkpoint carried are stale and go."""
+        setattr(self.config, id_attr, None)
+        self.keep_params = {k for k in self.keep_params if not k.startswith(prefix)}
+        for k in [k for k in kept if k.startswith(prefix)]:
+            del kept[k]
+        self.keep_params.update(self._tower_param_names(prefix))
+
+    def _tower_param_names(self, prefix: str):
+        """named_parameters() of a (plain, un-wrapped) tower under the reference's key names."""
+        if prefix == "audio_tower.":
+            if self.is_wav2vec2:
+                raise ValueError("the wav2vec2 tower carries no adapters and is never re-exported")
+            return list(unpack_encoder(self._enc, self.config, prefix, device="meta"))
+        return list(unpack_llm(self._llm, self.config, prefix, device="meta"))
 
     def projector_grads(self) -> Dict[str, torch.Tensor]:
         P = "multi_modal_projector."
@@ -688,9 +721,10 @@ class UltravoxModel:
         [start, end) key range, so a mask with holes would be honoured only at its outer edges.  A CPU mask is checked here;
         a device mask is checked synchronously the first time its shape is seen and asynchronously afterwards (`_check_mask`)."""
         if past_key_values is not None:
-            return self._forward_with_cache(past_key_values, input_ids, inputs_embeds, audio_values, audio_token_start_idx,
-                                            audio_lens, audio_token_len, audio_batch_size, labels, attention_mask,
-                                            kwargs.get("logits_to_keep", kwargs.get("num_logits_to_keep", 0)))
+            with self._llm_adapters_folded():      # (an un-merged LLM LoRA adapter is folded per call: see generate())
+                return self._forward_with_cache(past_key_values, input_ids, inputs_embeds, audio_values, audio_token_start_idx,
+                                                audio_lens, audio_token_len, audio_batch_size, labels, attention_mask,
+                                                kwargs.get("logits_to_keep", kwargs.get("num_logits_to_keep", 0)))
         if attention_mask is not None:
             self._check_mask(attention_mask)
         use_kl = False
@@ -768,8 +802,6 @@ class UltravoxModel:
             raise TypeError("past_key_values must be a KVState (generate(return_dict_in_generate=True).past_key_values)")
         if labels is not None:
             raise ValueError("forward() with a KV cache is an inference call: labels are not supported")
-        if self.text_lora_r > 0:
-            raise NotImplementedError("forward() with a KV cache and an un-merged LLM LoRA adapter: call merge_and_unload() first")
         l = _lib.lib()
         dev = self.device
         if audio_values is not None and len(audio_values) > 0:
@@ -930,6 +962,55 @@ class UltravoxModel:
                  do_sample: bool = False, temperature: float = 1.0, top_k: Optional[int] = None,
                  top_p: Optional[float] = None, generator: Optional[torch.Generator] = None, streamer=None,
                  **kwargs) -> torch.Tensor:
+        """UltravoxModel.generate (ultravox_model.py:398-426).  With an un-merged LLM LoRA adapter (text_model_lora_config.r > 0)
+        the reference's peft-wrapped LLM decodes with the adapters active; here the decode kernels know plain weights only, so the
+        adapters are folded into copies-on-the-side of the q / k rows for the duration of the call and the original rows put back
+        afterwards (_llm_adapters_folded): W + scaling * B A applied as one matrix instead of base(x) + scaling * B(A(x)) - the
+        same function to bf16 rounding."""
+        with self._llm_adapters_folded():
+            return self._generate(input_ids, audio_values=audio_values, inputs_embeds=inputs_embeds,
+                                  audio_token_start_idx=audio_token_start_idx, audio_lens=audio_lens, audio_token_len=audio_token_len,
+                                  audio_batch_size=audio_batch_size, attention_mask=attention_mask, max_new_tokens=max_new_tokens,
+                                  eos_token_id=eos_token_id, pad_token_id=pad_token_id, do_sample=do_sample, temperature=temperature,
+                                  top_k=top_k, top_p=top_p, generator=generator, streamer=streamer, **kwargs)
+
+    @contextlib.contextmanager
+    def _llm_adapters_folded(self):
+        """Inference under an un-merged LLM LoRA adapter: q / k rows of every layer's packed wqkv <- W + scaling * B A for the body of
+        the `with`, the saved rows restored on exit (training continues on the un-merged pair; (Hq + Hkv) * dh * D elements per layer
+        of scratch: 1.3 GB for Llama-3-8B).  No-op without adapters."""
+        r = self.text_lora_r
+        if r == 0:
+            yield
+            return
+        t = self.config.text_config
+        qc, kc = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim
+        sc = float(self._tlora.scaling)
+        saved = []
+        try:
+            with torch.no_grad():
+                for i, L in enumerate(self._llm["layers"]):
+                    rows = L["wqkv"][:qc + kc]
+                    saved.append(rows.clone())
+                    for lo, hi, pj in ((0, qc, "q_proj"), (qc, qc + kc, "k_proj")):
+                        A, B = self._proj_views[llm_lora_key(i, pj, "A")], self._proj_views[llm_lora_key(i, pj, "B")]
+                        rows[lo:hi].copy_((rows[lo:hi].float() + sc * (B.float() @ A.float())).to(rows.dtype))
+            self.text_lora_r = 0
+            yield
+        finally:
+            self.text_lora_r = r
+            with torch.no_grad():
+                for L, rows in zip(self._llm["layers"], saved):
+                    L["wqkv"][:qc + kc].copy_(rows)
+
+    def _generate(self, input_ids: torch.Tensor, audio_values: Optional[torch.Tensor] = None,
+                 inputs_embeds: Optional[torch.Tensor] = None, audio_token_start_idx: Optional[torch.Tensor] = None,
+                 audio_lens: Optional[torch.Tensor] = None, audio_token_len: Optional[torch.Tensor] = None,
+                 audio_batch_size: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 max_new_tokens: int = 20, eos_token_id=None, pad_token_id: Optional[int] = None,
+                 do_sample: bool = False, temperature: float = 1.0, top_k: Optional[int] = None,
+                 top_p: Optional[float] = None, generator: Optional[torch.Generator] = None, streamer=None,
+                 **kwargs) -> torch.Tensor:
         """UltravoxModel.generate (ultravox_model.py:398-426): merged embeddings built ONCE, then the LLM's
         prefill + KV-cache decode loop (greedy or sampling).  Returns prompt + generated ids, [B, T + n_new], finished
         sequences padded with pad_token_id like HF's GenerationMixin.  `eos_token_id` may be one id or a list of
@@ -948,9 +1029,6 @@ class UltravoxModel:
             warnings.warn(f"generate(): these arguments have no effect here: {sorted(ignored)}")
         if past is not None and not isinstance(past, KVState):
             raise TypeError("past_key_values must be the KVState a previous generate(return_dict_in_generate=True) returned")
-        if self.text_lora_r > 0:
-            raise NotImplementedError("generate() with an un-merged LLM LoRA adapter is not built: call merge_and_unload() first "
-                                      "(as the reference does before inference, ultravox_model.py:528-559)")
         if kwargs.get("num_beams", 1) != 1:
             raise NotImplementedError("beam search is not built (greedy and sampling are)")
         if do_sample and not temperature > 0:

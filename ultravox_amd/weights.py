@@ -374,3 +374,85 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
         out["rope_local"] = rope_table(t, out["rope_len"], device, local=True)
         out["layer_local"] = [int(lt == "sliding_attention") for lt in t.layer_types]
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Packed device operands -> the reference's checkpoint names again.  What UltravoxModel.merge_and_unload needs to re-export a
+# tower whose LoRA adapters were folded into the packed weights (ultravox_model.py:528-559: after the merge every tower
+# parameter joins keep_params and the next save_pretrained writes the towers whole), and what lets ANY keep_param be re-saved
+# from the tensors the kernels actually run on.  Exact inverses of pack_encoder / pack_llm: a split, a de-interleave, a
+# power-of-two scale - no arithmetic that rounds.
+
+def unpack_encoder(enc: Dict[str, object], cfg: UltravoxConfig, prefix: str = "audio_tower.", device="cpu") -> Dict[str, torch.Tensor]:
+    """pack_encoder's operands -> HF WhisperEncoder names under `prefix` (no peft infix: a merged tower is a plain module).
+    q_proj's weight and bias were stored pre-multiplied by head_dim^-0.5; Whisper's head_dim is 64 for every released size,
+    so the division is exact (a non power-of-two scale raises rather than round a second time).  k_proj has no bias in
+    Whisper: the zero block of bqkv is not exported."""
+    a = cfg.audio_config
+    d, H = a.d_model, a.encoder_attention_heads
+    dh = d // H
+    if dh & (dh - 1) or (dh.bit_length() - 1) % 2:
+        raise ValueError(f"encoder head_dim {dh}: head_dim^-0.5 is not a power of two, the packed q_proj cannot be unscaled exactly")
+    inv = float(dh) ** 0.5
+    cv = lambda x: x.detach().to(device).contiguous()
+    nm = a.num_mel_bins
+    out = {
+        prefix + "conv1.weight": cv(enc["conv1_w"][:, : 3 * nm].reshape(d, 3, nm).permute(0, 2, 1)),
+        prefix + "conv1.bias": cv(enc["conv1_b"]),
+        prefix + "conv2.weight": cv(enc["conv2_w"].reshape(d, 3, d).permute(0, 2, 1)),
+        prefix + "conv2.bias": cv(enc["conv2_b"]),
+        prefix + "embed_positions.weight": cv(enc["pos"]),
+        prefix + "layer_norm.weight": cv(enc["lnf_w"]), prefix + "layer_norm.bias": cv(enc["lnf_b"]),
+    }
+    for i, lay in enumerate(enc["layers"]):
+        L = f"{prefix}layers.{i}."
+        w, b = lay["wqkv"], lay["bqkv"]
+        out[L + "self_attn.q_proj.weight"] = cv(w[:d] * inv)
+        out[L + "self_attn.k_proj.weight"] = cv(w[d:2 * d])
+        out[L + "self_attn.v_proj.weight"] = cv(w[2 * d:])
+        out[L + "self_attn.q_proj.bias"] = cv(b[:d] * inv)
+        out[L + "self_attn.v_proj.bias"] = cv(b[2 * d:])
+        out[L + "self_attn.out_proj.weight"], out[L + "self_attn.out_proj.bias"] = cv(lay["wo"]), cv(lay["bo"])
+        out[L + "self_attn_layer_norm.weight"], out[L + "self_attn_layer_norm.bias"] = cv(lay["ln1_w"]), cv(lay["ln1_b"])
+        out[L + "final_layer_norm.weight"], out[L + "final_layer_norm.bias"] = cv(lay["ln2_w"]), cv(lay["ln2_b"])
+        out[L + "fc1.weight"], out[L + "fc1.bias"] = cv(lay["fc1_w"]), cv(lay["fc1_b"])
+        out[L + "fc2.weight"], out[L + "fc2.bias"] = cv(lay["fc2_w"]), cv(lay["fc2_b"])
+    return out
+
+
+def unpack_llm(llm: Dict[str, object], cfg: UltravoxConfig, prefix: str = "language_model.", device="cpu") -> Dict[str, torch.Tensor]:
+    """pack_llm's operands -> HF causal-LM names under `prefix`: q/k/v split out of wqkv, gate/up de-interleaved (16-row
+    blocks), the family extras (Qwen2 biases, Qwen3 / Gemma-3 q_norm / k_norm, Gemma-3's four norms) under their HF names.  A tied
+    head (lm_head IS embed_tokens, one tensor) is exported once, as embed_tokens - what named_parameters() lists."""
+    t = cfg.text_config
+    dh, Hq, Hkv, I = t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size
+    qc, kc = Hq * dh, Hkv * dh
+    cv = lambda x: x.detach().to(device).contiguous()
+    P = prefix + "model."
+    out = {P + "embed_tokens.weight": cv(llm["embed"]), P + "norm.weight": cv(llm["norm"])}
+    if llm["lm_head"] is not llm["embed"]:
+        out[prefix + "lm_head.weight"] = cv(llm["lm_head"])
+    g3 = bool(getattr(t, "is_gemma3", False))
+    for i, lay in enumerate(llm["layers"]):
+        L = f"{P}layers.{i}."
+        w = lay["wqkv"]
+        out[L + "self_attn.q_proj.weight"], out[L + "self_attn.k_proj.weight"] = cv(w[:qc]), cv(w[qc:qc + kc])
+        out[L + "self_attn.v_proj.weight"] = cv(w[qc + kc:])
+        out[L + "self_attn.o_proj.weight"] = cv(lay["wo"])
+        gu = lay["wgu"].reshape(I // 16, 2, 16, -1)
+        out[L + "mlp.gate_proj.weight"], out[L + "mlp.up_proj.weight"] = cv(gu[:, 0].reshape(I, -1)), cv(gu[:, 1].reshape(I, -1))
+        out[L + "mlp.down_proj.weight"] = cv(lay["wd"])
+        out[L + "input_layernorm.weight"] = cv(lay["ln1"])
+        if g3:
+            out[L + "post_attention_layernorm.weight"] = cv(lay["ln1_post"])
+            out[L + "pre_feedforward_layernorm.weight"] = cv(lay["ln2"])
+            out[L + "post_feedforward_layernorm.weight"] = cv(lay["ln2_post"])
+        else:
+            out[L + "post_attention_layernorm.weight"] = cv(lay["ln2"])
+        if lay.get("bqkv") is not None:
+            b = lay["bqkv"]
+            out[L + "self_attn.q_proj.bias"], out[L + "self_attn.k_proj.bias"], out[L + "self_attn.v_proj.bias"] = (
+                cv(b[:qc]), cv(b[qc:qc + kc]), cv(b[qc + kc:]))
+        if lay.get("q_norm") is not None:
+            out[L + "self_attn.q_norm.weight"], out[L + "self_attn.k_norm.weight"] = cv(lay["q_norm"]), cv(lay["k_norm"])
+    return out
