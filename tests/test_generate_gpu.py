@@ -383,3 +383,43 @@ def test_bf16_decode_batches_beyond_16_rows_take_the_tiled_split_path(B):
         row = out.logits[step][r].float()
         gap = (row[seq[r, T + step]] - row[small[r, T + step]]).abs().item()
         assert gap <= 3e-2 * row.norm().item() / row.numel() ** 0.5 * 4, (r, step, gap)
+
+
+@pytest.mark.parametrize("family", ["llama", "qwen2"])
+def test_prefill_rope_and_cache_append_in_one_launch_is_bit_identical(family):
+    """Round 5: the prefill (and the chunked prefill behind forward(past_key_values)) rotate q / k and write the new cache rows in
+    one launch per layer (rope_kv_append_k with Tn positions per sequence; option 16) instead of rope_k + kv_append_k: same
+    arithmetic, so tokens, every step's logits and the cache itself are bit-identical.  Left padding, GQA; qwen2 adds q / k / v biases."""
+    from ultravox_amd import _lib
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    text = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, head_dim=64,
+                vocab_size=512, eos_token_id=2, max_position_embeddings=512)
+    if family == "qwen2":
+        text["model_type"] = "qwen2"
+    cfg = UltravoxConfig(audio_config=dict(d_model=128, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=256),
+                         text_config=text, hidden_size=256, projector_ln_mid=True)
+    model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=11, rope_len=256)
+    torch.manual_seed(3)
+    B, T, new = 3, 37, 4
+    ids = torch.randint(3, 512, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, :9] = 0
+    am[2, :2] = 0
+    ids[am == 0] = 2
+    L = _lib.lib()
+    runs = []
+    try:
+        for opt in (1, 0):
+            L.uvx_set_option(16, opt)
+            out = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=new, eos_token_id=-1, return_dict_in_generate=True,
+                                 output_logits=True)
+            cache = out.past_key_values.cache.clone()
+            more = model.forward(input_ids=torch.randint(3, 512, (B, 5), generator=torch.Generator().manual_seed(5)).to(DEV),
+                                 past_key_values=out.past_key_values)      # chunked prefill: five new positions per sequence
+            runs.append((out.sequences, torch.stack(out.logits), cache, more.logits, more.past_key_values.cache.clone()))
+    finally:
+        L.uvx_set_option(16, 1)
+    assert L.uvx_get_option(16) == 1
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)

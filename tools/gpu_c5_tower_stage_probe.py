@@ -1,0 +1,112 @@
+"""Where does the wav2vec2 tower's bf16 distance to f32 come from?  (the C5 calibration factor was loosened to 1.5 x
+because HIP sat 1.15-1.24 x further from the f32 oracle than torch-ROCm's own bf16 run; the stem was blamed without a measurement.)
+
+For the wav2vec2-large tower at depth n in DEPTHS, on the same bf16-rounded weights and the same normalised PCM:
+  hip      uvx_wav2vec2_fwd (bf16)
+  torch    the oracle restatement in torch-ROCm bf16 on the GPU (F.conv1d -> MIOpen), flash-rounded attention
+  im2col   the same restatement with the conv stem written as unfold + matmul in bf16 (the algorithm of the HIP stem:
+           one f32-accumulated GEMM per layer, one rounding) - separates "MIOpen's conv algorithm" from "everything else"
+  f32      the restatement in f32 on the GPU
+and prints each pipeline's rel-L2 distance to f32 plus hip / torch.  Depth 1 isolates stem + feature projection + positional conv."""
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from oracle import reference_cpu as O      # noqa: E402  (checker only: this is a probe, not the product)
+from parity_util import rel_l2, width_config      # noqa: E402
+from ultravox_amd.model import UltravoxModel      # noqa: E402
+from ultravox_amd.weights import random_state_dict      # noqa: E402
+
+DEV = "cuda"
+DEPTHS = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,4,12,24").split(",")]
+SECONDS = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+
+
+def stem_im2col(sd, cfg, x, prefix="audio_tower."):
+    """Wav2Vec2FeatureEncoder with every conv as unfold + matmul in x.dtype -> [B, T, C] (what wav2vec2_encoder_ref feeds its LayerNorm)."""
+    a = cfg.audio_config
+    W = lambda k: sd[prefix + k].to(x.dtype)
+    h = x[:, :, None]                                        # [B, L, 1] time-major
+    for i, (k, st) in enumerate(zip(a.conv_kernel, a.conv_stride)):
+        w = W(f"feature_extractor.conv_layers.{i}.conv.weight")      # [C, Cin, k]
+        cols = h.unfold(1, k, st)                            # [B, T, Cin, k]
+        cols = cols.permute(0, 1, 3, 2).reshape(h.shape[0], cols.shape[1], -1)      # tap-major, channel-minor
+        h = cols @ w.permute(0, 2, 1).reshape(w.shape[0], -1).t()
+        if i == 0:
+            C = h.shape[-1]
+            h = F.group_norm(h.transpose(1, 2), C, W("feature_extractor.conv_layers.0.layer_norm.weight"),
+                             W("feature_extractor.conv_layers.0.layer_norm.bias"), 1e-5).transpose(1, 2)
+        h = F.gelu(h)
+    return h
+
+
+def tower_after_stem(sd, cfg, h, prefix="audio_tower."):
+    """wav2vec2_encoder_ref from the feature projection on (same code path: the stem is swapped by monkey-patching F.conv1d away)."""
+    a = cfg.audio_config
+    W = lambda k: sd[prefix + k].to(h.dtype)
+    Hh, d = a.encoder_attention_heads, a.d_model
+    dh = d // Hh
+    x = F.layer_norm(h, (h.shape[-1],), W("feature_projection.layer_norm.weight"), W("feature_projection.layer_norm.bias"), a.layer_norm_eps)
+    x = F.linear(x, W("feature_projection.projection.weight"), W("feature_projection.projection.bias"))
+    K, G = a.num_conv_pos_embeddings, a.num_conv_pos_embedding_groups
+    pos = F.conv1d(x.transpose(1, 2), O.pos_conv_weight_ref(sd, prefix).to(h.dtype), W("encoder.pos_conv_embed.conv.bias"), padding=K // 2, groups=G)
+    if K % 2 == 0:
+        pos = pos[:, :, :-1]
+    x = x + F.gelu(pos).transpose(1, 2)
+    x = F.layer_norm(x, (d,), W("encoder.layer_norm.weight"), W("encoder.layer_norm.bias"), a.layer_norm_eps)
+    B, S, _ = x.shape
+    for i in range(a.encoder_layers):
+        L = f"encoder.layers.{i}."
+        q = F.linear(x, W(L + "attention.q_proj.weight"), W(L + "attention.q_proj.bias")) * dh ** -0.5
+        k = F.linear(x, W(L + "attention.k_proj.weight"), W(L + "attention.k_proj.bias"))
+        v = F.linear(x, W(L + "attention.v_proj.weight"), W(L + "attention.v_proj.bias"))
+        q, k, v = (t.view(B, S, Hh, dh).transpose(1, 2) for t in (q, k, v))
+        o = O._attend(q, k, v, None, 1.0).transpose(1, 2).reshape(B, S, d)
+        x = x + F.linear(o, W(L + "attention.out_proj.weight"), W(L + "attention.out_proj.bias"))
+        x = F.layer_norm(x, (d,), W(L + "layer_norm.weight"), W(L + "layer_norm.bias"), a.layer_norm_eps)
+        hh = F.gelu(F.linear(x, W(L + "feed_forward.intermediate_dense.weight"), W(L + "feed_forward.intermediate_dense.bias")))
+        x = x + F.linear(hh, W(L + "feed_forward.output_dense.weight"), W(L + "feed_forward.output_dense.bias"))
+        x = F.layer_norm(x, (d,), W(L + "final_layer_norm.weight"), W(L + "final_layer_norm.bias"), a.layer_norm_eps)
+    return x
+
+
+def main():
+    torch.manual_seed(0)
+    print(f"# wav2vec2-large tower, B = 2 x {SECONDS:g} s, rel-L2 of each bf16 pipeline's output to the f32 restatement (same bf16-rounded weights / input)")
+    print("depth   hip      torch(MIOpen)  torch(im2col stem)   hip/torch  hip/im2col   | stem only: torch-conv vs f32, im2col vs f32, im2col vs torch-conv")
+    for depth in DEPTHS:
+        cfg = width_config("google/gemma-2b", "facebook/wav2vec2-large-960h", 1, depth)
+        sd = random_state_dict(cfg, seed=7, dtype=torch.bfloat16, device=DEV)
+        model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16, rope_len=256, with_backward=False)
+        b = O.synthetic_batch(cfg, 2, SECONDS, n_text=16, audio_start=4, n_supervised=4)
+        vals = O.wav2vec2_normalize_ref(b["pcm"]).bfloat16().to(DEV)
+        with torch.no_grad(), O.fused_attention():
+            hip = model.audio_tower_forward(vals, None).float()
+            f32 = O.wav2vec2_encoder_ref(sd, cfg, vals.float())
+            t16 = O.wav2vec2_encoder_ref(sd, cfg, vals).float()
+            stem16 = stem_im2col(sd, cfg, vals)
+            i16 = tower_after_stem(sd, cfg, stem16).float()
+            # the stems alone
+            x = vals[:, None]
+            a = cfg.audio_config
+            xf = vals.float()[:, None]
+            for i, (k, st) in enumerate(zip(a.conv_kernel, a.conv_stride)):
+                w = sd[f"audio_tower.feature_extractor.conv_layers.{i}.conv.weight"]
+                x, xf = F.conv1d(x, w, stride=st), F.conv1d(xf, w.float(), stride=st)
+                if i == 0:
+                    gw, gb = sd["audio_tower.feature_extractor.conv_layers.0.layer_norm.weight"], sd["audio_tower.feature_extractor.conv_layers.0.layer_norm.bias"]
+                    x, xf = F.group_norm(x, x.shape[1], gw, gb, 1e-5), F.group_norm(xf, xf.shape[1], gw.float(), gb.float(), 1e-5)
+                x, xf = F.gelu(x), F.gelu(xf)
+            s_conv, s_f32 = x.transpose(1, 2).float(), xf.transpose(1, 2)
+        eh, et, ei = rel_l2(hip, f32), rel_l2(t16, f32), rel_l2(i16, f32)
+        print(f"{depth:5d}   {eh:.5f}  {et:.5f}        {ei:.5f}              {eh / et:.3f}      {eh / ei:.3f}       | "
+              f"{rel_l2(s_conv, s_f32):.5f}  {rel_l2(stem16.float(), s_f32):.5f}  {rel_l2(stem16.float(), s_conv):.5f}", flush=True)
+        del model, sd
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

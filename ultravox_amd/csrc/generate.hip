@@ -89,20 +89,24 @@ __global__ void kv_append_k(const T* __restrict__ qkv, T* __restrict__ cache_k, 
   st8<T>(cache_v + dst, v);
 }
 
-// The decode step's rotary embedding and cache append in ONE launch (round 4: rope_k + kv_append_k were two 4.6 us launches per layer,
-// 0.7 ms of a 26 ms Llama-3.3-70B token): one new position per sequence; q heads are rotated in place, k heads are rotated and written to
-// cache row t0 (and back to the qkv row, as rope_k does), v heads are copied to the cache.  Same arithmetic and rounding points as rope_k.
-// item = (sequence, head of q | k, 8-column chunk of the first half of the head) or (sequence, 8-column chunk of v).
+// Rotary embedding and cache append in ONE launch (round 4, decode: rope_k + kv_append_k were two 4.6 us launches per layer, 0.7 ms of a
+// 26 ms Llama-3.3-70B token; round 5: the prefill's Tn new positions per sequence go the same way - the pair re-read the k rows it had
+// just written).  Row r = b Tn + t of qkv sits at position pos[r] and goes to cache row t0 + t of sequence b: q heads are rotated in
+// place, k heads are rotated and written to the cache row (and back to the qkv row, as rope_k does - the prefill's attention reads them
+// there), v heads are copied to the cache.  Same arithmetic and rounding points as rope_k.
+// item = (row, head of q | k, 8-column chunk of the first half of the head) or (row, 8-column chunk of v).
 template <typename T>
 __global__ void rope_kv_append_k(T* __restrict__ qkv, const float* __restrict__ cs, const int32_t* __restrict__ pos, T* __restrict__ cache_k,
-                                 T* __restrict__ cache_v, int B, int Tmax, int t0, int Hq, int Hkv, int D, int QKV) {
+                                 T* __restrict__ cache_v, int B, int Tn, int Tmax, int t0, int Hq, int Hkv, int D, int QKV) {
   const int per_head = D / 16, KVD = Hkv * D;
   const int rope_items = (Hq + Hkv) * per_head, v_items = KVD / 8, per_row = rope_items + v_items;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)B * per_row) return;
-  const int b = (int)(i / per_row), rem = (int)(i % per_row);
-  T* row = qkv + (long long)b * QKV;
-  const long long crow = ((long long)b * Tmax + t0) * KVD;
+  if (i >= (long long)B * Tn * per_row) return;
+  const long long r = i / per_row;
+  const int rem = (int)(i % per_row);
+  const int b = (int)(r / Tn), tq = (int)(r % Tn);
+  T* row = qkv + r * QKV;
+  const long long crow = ((long long)b * Tmax + t0 + tq) * KVD;
   if (rem >= rope_items) {                      // v: copy
     const int c = (rem - rope_items) * 8;
     float v[8];
@@ -112,7 +116,7 @@ __global__ void rope_kv_append_k(T* __restrict__ qkv, const float* __restrict__ 
   }
   const int h = rem / per_head, c = (rem % per_head) * 8;
   T* base = row + h * D;
-  const float* t = cs + ((long long)pos[b] * (D / 2) + c) * 2;
+  const float* t = cs + ((long long)pos[r] * (D / 2) + c) * 2;
   float lo[8], hi[8], olo[8], ohi[8];
   ld8<T>(base + c, lo);
   ld8<T>(base + D / 2 + c, hi);
@@ -129,6 +133,14 @@ __global__ void rope_kv_append_k(T* __restrict__ qkv, const float* __restrict__ 
     st8<T>(kc + c, olo);
     st8<T>(kc + D / 2 + c, ohi);
   }
+}
+// q | k | v projection, rotary embedding and cache append of Tn new positions per sequence (prefill, chunked prefill).  bf16 without
+// per-head q / k norms: the projection, then rope_kv_append_k; otherwise qkv_rope + kv_append_k (option 15 = 0 forces that pair: A/B)
+template <typename T>
+void launch_rope_kv_append(hipStream_t st, void* qkv, const float* cs, const int32_t* pos, void* ck, void* cv, int B, int Tn, int Tmax, int t0,
+                           int Hq, int Hkv, int dh, int QKV) {
+  const long long items = (long long)B * Tn * ((Hq + Hkv) * (dh / 16) + Hkv * dh / 8);
+  hipLaunchKernelGGL(rope_kv_append_k<T>, dim3(cdiv(items, 256)), dim3(256), 0, st, (T*)qkv, cs, pos, (T*)ck, (T*)cv, B, Tn, Tmax, t0, Hq, Hkv, dh, QKV);
 }
 
 // full[b][t][koff + c] = cache_k[b][t][c], full[b][t][koff + KVD + c] = cache_v[b][t][c] for t < Tf: the cached keys / values
@@ -440,6 +452,32 @@ int qkv_rope(hipStream_t st, const uvx_config_t& c, const uvx_llm_weights_t* w, 
   return rope_inplace(st, dt, qkv, rope, pos, rows, T, Hq + Hkv, dh, QKV, 0);
 }
 
+// q | k | v projection, rotary embedding and cache append of Tn new positions per sequence (rows b Tn + t at positions pos[row] -> cache
+// rows t0 + t): bf16 without per-head q / k norms runs the projection and then ONE launch that rotates q / k and writes the cache rows
+// (rope_kv_append_k); everything else - and tuning option 16 = 0, for A/B - runs qkv_rope and kv_append_k.  Same values either way.
+int qkv_rope_append(hipStream_t st, const uvx_config_t& c, const uvx_llm_weights_t* w, const uvx_llm_layer_t& L, const InferWs& s, const void* n,
+                    const int32_t* pos, int B, int Tn, int Tmax, int t0, void* ck, void* cv, int l) {
+  const int dt = c.dtype, dh = c.llm_head_dim, Hq = c.llm_heads, Hkv = c.llm_kv_heads, KVD = Hkv * dh, rows = B * Tn;
+  if (dt == DT_BF16 && !c.llm_qk_norm && uvx::g_options[16]) {
+    GemmDesc g = lin(n, L.wqkv, s.qkv, rows, s.QKV, c.llm_d);
+    g.bias = L.bqkv;
+    RC(gemm(st, dt, sk(g, s)));
+    const bool g3 = c.llm_flavor == UVX_LLM_GEMMA3;
+    launch_rope_kv_append<bf16_t>(st, s.qkv, g3 && w->layer_local && w->layer_local[l] ? w->rope_cos_sin_local : w->rope_cos_sin, pos, ck, cv,
+                                  B, Tn, Tmax, t0, Hq, Hkv, dh, s.QKV);
+    UVX_LAUNCH_CHECK();
+    return UVX_OK;
+  }
+  RC(qkv_rope(st, c, w, L, n, s.qkv, pos, rows, Tn, s.QKV, l, &s));
+  const long long na = (long long)rows * (KVD / 8);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(na, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, Tn, Tmax, t0, s.QKV, Hq * dh, KVD);
+  else
+    hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(na, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, Tn, Tmax, t0, s.QKV, Hq * dh, KVD);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
 }  // namespace
 
 extern "C" size_t uvx_kv_cache_bytes(const uvx_config_t* cfg, int32_t B, int32_t Tmax) {
@@ -477,16 +515,10 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
-    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, T, s.QKV, l, &s));
     {
       char* ck = at(kv_cache, l * layer_stride, dt);
       char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
-      const long long n = (long long)M * (KVD / 8);
-      if (dt == DT_BF16)
-        hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, T, Tmax, 0, s.QKV, Hq * dh, KVD);
-      else
-        hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, T, Tmax, 0, s.QKV, Hq * dh, KVD);
-      UVX_LAUNCH_CHECK();
+      RC(qkv_rope_append(st, c, w, L, s, s.n, s.pos, B, T, Tmax, 0, ck, cv, l));
     }
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(s.qkv, (size_t)(Hq + Hkv) * dh, dt), s.vt, B, T, s.Tp, Hkv, dh, s.QKV));
     AttnDesc ad;
@@ -562,17 +594,14 @@ static int32_t prefill_chunk_impl(void* stream, const uvx_config_t* cfg, const u
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
-    RC(qkv_rope(st, c, w, L, s.n, s.qkv, s.pos, M, Tn, s.QKV, l, &s));
     char* ck = at(kv_cache, l * layer_stride, dt);
     char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
-    const long long na = (long long)M * (KVD / 8), ng = (long long)B * Tf * (KVD / 8);
-    if (dt == DT_BF16) {
-      hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(na, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, Tn, Tmax, cur_len, s.QKV, Hq * dh, KVD);
+    RC(qkv_rope_append(st, c, w, L, s, s.n, s.pos, B, Tn, Tmax, cur_len, ck, cv, l));
+    const long long ng = (long long)B * Tf * (KVD / 8);
+    if (dt == DT_BF16)
       hipLaunchKernelGGL(kv_gather_k<bf16_t>, dim3(cdiv(ng, 256)), dim3(256), 0, st, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)k.fq, B, Tf, Tmax, s.QKV, Hq * dh, KVD);
-    } else {
-      hipLaunchKernelGGL(kv_append_k<float>, dim3(cdiv(na, 256)), dim3(256), 0, st, (const float*)s.qkv, (float*)ck, (float*)cv, B, Tn, Tmax, cur_len, s.QKV, Hq * dh, KVD);
+    else
       hipLaunchKernelGGL(kv_gather_k<float>, dim3(cdiv(ng, 256)), dim3(256), 0, st, (const float*)ck, (const float*)cv, (float*)k.fq, B, Tf, Tmax, s.QKV, Hq * dh, KVD);
-    }
     UVX_LAUNCH_CHECK();
     for (int b = 0; b < B; ++b)   // the new rows' queries into their place in the full-length layout
       UVX_HIP(hipMemcpy2DAsync(at(k.fq, ((size_t)b * Tf + cur_len) * s.QKV, dt), (size_t)s.QKV * es, at(s.qkv, (size_t)b * Tn * s.QKV, dt),
@@ -662,9 +691,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
     const int nw = B * Hq;
     if (dt == DT_BF16) {
       if (fuse_rope_append) {
-        const long long items = (long long)B * ((Hq + Hkv) * (dh / 16) + KVD / 8);
-        hipLaunchKernelGGL(rope_kv_append_k<bf16_t>, dim3(cdiv(items, 256)), dim3(256), 0, st, (bf16_t*)s.qkv, w->rope_cos_sin, positions,
-                           (bf16_t*)ck, (bf16_t*)cv, B, Tmax, cur_len, Hq, Hkv, dh, s.QKV);
+        launch_rope_kv_append<bf16_t>(st, s.qkv, w->rope_cos_sin, positions, ck, cv, B, 1, Tmax, cur_len, Hq, Hkv, dh, s.QKV);
       } else {
         hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
       }
