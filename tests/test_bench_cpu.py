@@ -100,3 +100,21 @@ def test_decode_traffic_lookup_reads_the_committed_pmc_summary(tmp_path):
     assert bench.pmc_decode_traffic_per_token(str(tmp_path)) is None
     got = bench.pmc_decode_traffic_per_token()          # the committed record: within 1 % of the weight bytes of Llama-3.3-70B
     assert got is not None and abs(got / 139003428864.0 - 1.0) < 0.01
+
+
+def test_parity_object_cites_the_newest_committed_full_depth_record(tmp_path):
+    """bench.py's `parity` object (say in the line what the bf16 path's distance to the oracle is instead of leaving
+    north_star's 1e-3 implicit): read from profiles/rNN_parity/<workload>_full_depth.json, newest round first, never raises."""
+    import bench
+    assert bench.parity_record("c2", str(tmp_path)) is None and bench.parity_record("c2", "/nonexistent") is None
+    for rnd, v in (("r03", 0.5), ("r11", 0.25)):
+        (tmp_path / f"{rnd}_parity").mkdir()
+        (tmp_path / f"{rnd}_parity" / "c2_full_depth.json").write_text(json.dumps(
+            {"stages": {"logits": {"rel_l2": v, "max_abs": 1.0, "ref_rms": 1.0}}, "grads_rel_l2": {"a": 0.1, "b": 0.2}}))
+    (tmp_path / "r12_parity").mkdir()          # a newer round without this workload's record: the older record still answers
+    got = bench.parity_record("c2", str(tmp_path))
+    assert got["logits_rel_l2_vs_f32_oracle"] == 0.25 and got["projector_grads_rel_l2_vs_f32_oracle_max"] == 0.2 and "r11_parity" in got["source"]
+    (tmp_path / "r12_parity" / "c2_full_depth.json").write_text("{not json")
+    assert bench.parity_record("c2", str(tmp_path)) is None
+    committed = bench.parity_record("c2")
+    assert committed is not None and 1e-3 < committed["logits_rel_l2_vs_f32_oracle"] < 2.8e-2      # the bar of tests/test_c2_full_depth_gpu.py
