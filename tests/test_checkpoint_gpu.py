@@ -190,14 +190,22 @@ def test_tower_keys_carried_by_a_checkpoint_are_re_saved(tmp_path):
     m.save_pretrained(str(tmp_path / "again"))
     _, again = checkpoint.load_pretrained(str(tmp_path / "again"))
     assert set(again) == set(carried) and all(torch.equal(again[k], carried[k]) for k in carried)
-    # a keep_param with no tensor behind it (reference-style code adds names by hand, ultravox_model.py:59): the save is refused
-    # (a checkpoint must not lose tensors silently); strict=False reports it and leaves the key out
+    # a keep_param added by NAME (reference-style code does that, ultravox_model.py:59): the tensor is read back from the packed device
+    # weights under its checkpoint name (round 5: weights.unpack_*) - here a frozen-tower matrix nobody retained on the host
     m.keep_params.add("audio_tower.layers.1.fc2.weight")
+    m.save_pretrained(str(tmp_path / "named"))
+    _, named = checkpoint.load_pretrained(str(tmp_path / "named"))
+    assert set(named) == set(carried) | {"audio_tower.layers.1.fc2.weight"}
+    assert torch.equal(named["audio_tower.layers.1.fc2.weight"], base["audio_tower.layers.1.fc2.weight"])
+    assert all(torch.equal(named[k], carried[k]) for k in carried)          # retained originals still win over the read-back
+    # a keep_param with no tensor behind it at all: the save is refused (a checkpoint must not lose tensors silently);
+    # strict=False reports it and leaves the key out
+    m.keep_params.add("audio_tower.layers.1.fc2.no_such_tensor")
     with pytest.raises(KeyError, match="cannot re-save"):
         m.save_pretrained(str(tmp_path / "refused"))
     with pytest.warns(UserWarning, match="cannot re-save"):
         m.save_pretrained(str(tmp_path / "partial"), strict=False)
     _, partial = checkpoint.load_pretrained(str(tmp_path / "partial"))
-    assert set(partial) == set(carried)
+    assert set(partial) == set(named)
     with pytest.raises(KeyError, match="cannot re-save"):
         m._full_state_dict(strict=True)

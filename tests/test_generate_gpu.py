@@ -414,10 +414,13 @@ def test_prefill_rope_and_cache_append_in_one_launch_is_bit_identical(family):
             L.uvx_set_option(16, opt)
             out = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=new, eos_token_id=-1, return_dict_in_generate=True,
                                  output_logits=True)
-            cache = out.past_key_values.cache.clone()
+            def rows(state):      # the cache rows written so far ([L][2][B][Tmax][kv_heads * head_dim]; rows >= cur_len were never written)
+                kvd = text["num_key_value_heads"] * text["head_dim"]
+                return state.cache.view(torch.bfloat16).view(text["num_hidden_layers"], 2, B, state.Tmax, kvd)[:, :, :, :state.cur_len].clone()
+            cache = rows(out.past_key_values)
             more = model.forward(input_ids=torch.randint(3, 512, (B, 5), generator=torch.Generator().manual_seed(5)).to(DEV),
                                  past_key_values=out.past_key_values)      # chunked prefill: five new positions per sequence
-            runs.append((out.sequences, torch.stack(out.logits), cache, more.logits, more.past_key_values.cache.clone()))
+            runs.append((out.sequences, torch.stack(out.logits), cache, more.logits, rows(more.past_key_values)))
     finally:
         L.uvx_set_option(16, 1)
     assert L.uvx_get_option(16) == 1

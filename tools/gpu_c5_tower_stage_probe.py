@@ -83,7 +83,7 @@ def main():
         model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16, rope_len=256, with_backward=False)
         b = O.synthetic_batch(cfg, 2, SECONDS, n_text=16, audio_start=4, n_supervised=4)
         vals = O.wav2vec2_normalize_ref(b["pcm"]).bfloat16().to(DEV)
-        with torch.no_grad(), O.fused_attention():
+        with torch.no_grad(), torch.device(DEV), O.fused_attention():      # (torch.device: the oracle's flash loop allocates its running max / sum)
             hip = model.audio_tower_forward(vals, None).float()
             f32 = O.wav2vec2_encoder_ref(sd, cfg, vals.float())
             t16 = O.wav2vec2_encoder_ref(sd, cfg, vals).float()

@@ -363,8 +363,8 @@ class UltravoxModel:
                 sd = {**unpack(packed, self.config, prefix), **sd}
         lost = sorted(k for k in self.keep_params if k not in sd)
         if lost:
-            msg = (f"keep_params names {len(lost)} tensor(s) this model cannot re-save (e.g. {lost[:3]}): frozen-tower keys are only "
-                   "retained when they arrive through from_pretrained")
+            msg = (f"keep_params names {len(lost)} tensor(s) this model cannot re-save (e.g. {lost[:3]}): not a trainable key, not retained "
+                   "from a loaded checkpoint and not a parameter of a plain (adapter-free) Whisper tower / LLM under its checkpoint name")
             if strict:
                 raise KeyError(msg)
             import warnings
