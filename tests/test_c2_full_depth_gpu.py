@@ -129,9 +129,12 @@ def test_full_depth_train_step_matches_oracle(workload):
     for k, e in rec["grads_rel_l2"].items():
         assert e < bars["grads"], (k, e)
     assert agree >= bars["argmax"], (agree, rec["argmax_agreement_all_rows"])
-    # C5: 1.5 instead of 1.25 - measured 1.15-1.24 (profiles/r04_parity/c5_full_depth.json): the wav2vec2 conv stem runs as im2col
-    # GEMMs with a bf16 rounding per layer where torch goes through MIOpen, whose algorithm choice (and with it torch's own distance)
-    # may differ from box to box; the Gemma stack alone is calibrated at 1.00 (profiles/r04_parity/c5_text_only_calibration_probe.txt)
+    # C5: 1.5 instead of 1.25.  This test sees ONE 30 s clip, and at depth 24 the wav2vec2 tower's hip / torch distance ratio is a sample
+    # of a quantity that scatters 0.84 ... 1.14 from clip to clip (round 5, profiles/r05_c5_tower_stage_probe.txt: the post-LN stack doubles
+    # the error between layers 12 and 24; this seed's clip reads 1.14-1.19, the mean over 8 clips 0.97, at every depth and batch size HIP is
+    # at or below torch's distance on average - the stem's rounding, blamed in round 4, measures 0.87-0.96 at depth 1).  The calibrated bar
+    # on the tower is tests/test_wav2vec2_gpu.py::test_wav2vec2_large_tower_bf16_distance_is_calibrated_over_clips (mean over clips <= 1.08);
+    # the Gemma stack alone is calibrated at 1.00 (profiles/r04_parity/c5_text_only_calibration_probe.txt).
     factor = 1.5 if w2v else 1.25
     for k, v in rec["calibration"].items():
         if k != "loss":

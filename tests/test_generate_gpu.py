@@ -426,3 +426,54 @@ def test_prefill_rope_and_cache_append_in_one_launch_is_bit_identical(family):
     assert L.uvx_get_option(16) == 1
     for a, b in zip(*runs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("family", ["llama", "gemma", "qwen3"])
+def test_rmsnorm_inside_the_splitk_reduce_is_bit_identical(family):
+    """Round 5: where a linear of generate() is split over K, the RMSNorm that follows it (o_proj -> post_attention_layernorm,
+    down_proj -> the next layer's input_layernorm) is computed by the reduce kernel (splitk_reduce_norm_k, option 17) with
+    rmsnorm_fwd_k's thread mapping and summation order: tokens, logits and cache rows are bit-identical to the separate launches.
+    Layers wide enough for the split to engage at these row counts (K = 1024 / 2816; uvx_gemm_pick_split says so below): a prefill of
+    240 rows, decode steps of 20 rows (beyond 16: the tiled path), a chunked prefill; Gemma = the (1 + w) flavour, Qwen3 = q / k norms."""
+    import ctypes as C
+    from ultravox_amd import _lib
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    text = dict(hidden_size=1024, intermediate_size=2816, num_hidden_layers=3, num_attention_heads=8, num_key_value_heads=2, head_dim=128,
+                vocab_size=2048, eos_token_id=2, max_position_embeddings=1024)
+    if family != "llama":
+        text["model_type"] = family
+    cfg = UltravoxConfig(audio_config=dict(d_model=128, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=256),
+                         text_config=text, hidden_size=256, projector_ln_mid=True)
+    model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=13, rope_len=256)
+    L = _lib.lib()
+    L.uvx_gemm_pick_split.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.POINTER(C.c_int32)]
+    L.uvx_gemm_splitk_ws_bytes.restype = C.c_size_t
+    for M in (240, 20, 100):          # the o / down projections of the three phases below are split
+        for K in (1024, 2816):
+            assert L.uvx_gemm_pick_split(M, 1024, K, L.uvx_gemm_splitk_ws_bytes(M, 1024), None) > 1, (M, K)
+    torch.manual_seed(4)
+    B, T, new = 20, 12, 3
+    ids = torch.randint(3, 2048, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    for r in range(1, B, 4):
+        am[r, :r % 5 + 1] = 0
+    ids[am == 0] = 2
+    more_ids = torch.randint(3, 2048, (B, 5), generator=torch.Generator().manual_seed(6)).to(DEV)
+    runs = []
+    try:
+        for opt in (1, 0):
+            L.uvx_set_option(17, opt)
+            out = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=new, eos_token_id=-1, return_dict_in_generate=True,
+                                 output_logits=True)
+            st = out.past_key_values
+            kvd = text["num_key_value_heads"] * text["head_dim"]
+            rows = lambda s_: s_.cache.view(torch.bfloat16).view(3, 2, B, s_.Tmax, kvd)[:, :, :, :s_.cur_len].clone()
+            cache = rows(st)
+            more = model.forward(input_ids=more_ids, past_key_values=st)      # chunked prefill: 100 rows
+            runs.append((out.sequences, torch.stack(out.logits), cache, more.logits, rows(more.past_key_values)))
+    finally:
+        L.uvx_set_option(17, 1)
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(runs[0][1].float()).all()

@@ -23,6 +23,7 @@ from ultravox_amd.weights import random_state_dict      # noqa: E402
 DEV = "cuda"
 DEPTHS = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,4,12,24").split(",")]
 SECONDS = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+CLIPS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 
 
 def stem_im2col(sd, cfg, x, prefix="audio_tower."):
@@ -75,13 +76,13 @@ def tower_after_stem(sd, cfg, h, prefix="audio_tower."):
 
 def main():
     torch.manual_seed(0)
-    print(f"# wav2vec2-large tower, B = 2 x {SECONDS:g} s, rel-L2 of each bf16 pipeline's output to the f32 restatement (same bf16-rounded weights / input)")
+    print(f"# wav2vec2-large tower, B = {CLIPS} x {SECONDS:g} s, rel-L2 of each bf16 pipeline's output to the f32 restatement (same bf16-rounded weights / input)")
     print("depth   hip      torch(MIOpen)  torch(im2col stem)   hip/torch  hip/im2col   | stem only: torch-conv vs f32, im2col vs f32, im2col vs torch-conv")
     for depth in DEPTHS:
         cfg = width_config("google/gemma-2b", "facebook/wav2vec2-large-960h", 1, depth)
         sd = random_state_dict(cfg, seed=7, dtype=torch.bfloat16, device=DEV)
         model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16, rope_len=256, with_backward=False)
-        b = O.synthetic_batch(cfg, 2, SECONDS, n_text=16, audio_start=4, n_supervised=4)
+        b = O.synthetic_batch(cfg, CLIPS, SECONDS, n_text=16, audio_start=4, n_supervised=4)
         vals = O.wav2vec2_normalize_ref(b["pcm"]).bfloat16().to(DEV)
         with torch.no_grad(), torch.device(DEV), O.fused_attention():      # (torch.device: the oracle's flash loop allocates its running max / sum)
             hip = model.audio_tower_forward(vals, None).float()
@@ -104,6 +105,9 @@ def main():
         eh, et, ei = rel_l2(hip, f32), rel_l2(t16, f32), rel_l2(i16, f32)
         print(f"{depth:5d}   {eh:.5f}  {et:.5f}        {ei:.5f}              {eh / et:.3f}      {eh / ei:.3f}       | "
               f"{rel_l2(s_conv, s_f32):.5f}  {rel_l2(stem16.float(), s_f32):.5f}  {rel_l2(stem16.float(), s_conv):.5f}", flush=True)
+        if CLIPS > 1:      # per clip: is a ratio away from 1 a property of the kernels or of the sample?
+            per = [(rel_l2(hip[i], f32[i]), rel_l2(t16[i], f32[i])) for i in range(CLIPS)]
+            print("        per clip hip / torch: " + "  ".join(f"{a / b:.3f}" for a, b in per) + "   (hip: " + " ".join(f"{a:.5f}" for a, _ in per) + ")", flush=True)
         del model, sd
         torch.cuda.empty_cache()
 

@@ -40,7 +40,7 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // [8] (probe builds) let the picker choose the stream-K variants 39..42 (off: measured slower, see the kernel),
 // [10] tail-split threshold in per cent of the whole launch's modelled cost (0 = 88),
 // [9] stream-K flavour: data-parallel rounds before the stream-K part: 1 = all but the last full round ("two-tile"), 0 = none
-int g_options[24] = {0, 2, 0, 1, 1, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, /*16*/ 1, 0, 0, 0, 0, 0, 0, 0};   // keys: include/uvx.h uvx_set_option
+int g_options[24] = {0, 2, 0, 1, 1, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, /*16*/ 1, 1, 0, 0, 0, 0, 0, 0};   // keys: include/uvx.h uvx_set_option
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {
@@ -1811,6 +1811,78 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(ReduceArgs p) {
   *reinterpret_cast<uint4*>(p.C + (long long)m * p.ldc + n0) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
 }
 
+// The reduce with the RMSNorm that FOLLOWS the linear fused in (round 5): in the decoder stack every o_proj / down_proj (+ residual) is
+// followed by post_attention_layernorm / the next layer's input_layernorm over the row it has just completed - a separate launch of 8-14 us on
+// a few hundred rows (160 of them per 70B prefill, 160 per decode step of a batch beyond 16 rows).  One block per output row, the
+// thread -> column mapping and the summation order of rmsnorm_fwd_k (norms.hip: norm_threads(N) threads, 8-column chunks strided by the block,
+// block_sum), so C is what splitk_reduce_k writes and Y is bit for bit what rmsnorm_fwd_k would compute from it: y = w * round(x * rstd)
+// (flavor 0, LlamaRMSNorm) or (x * rstd) * (1 + w) (flavor 1, GemmaRMSNorm), x = the bf16-rounded C row.  No SwiGLU form (never followed by a norm).
+struct ReduceNormArgs { ReduceArgs r; const bf16_t* norm_w; bf16_t* Y; int ldy; float eps; int flavor; };
+constexpr int kReduceNormMaxChunks = 8;      // 8-column chunks per thread: N <= 256 * 8 * 8 = 16384
+__global__ __launch_bounds__(256) void splitk_reduce_norm_k(ReduceNormArgs q) {
+  __shared__ float red[16];
+  const ReduceArgs& p = q.r;
+  const int m = blockIdx.x;
+  const float* src = p.P + (long long)m * p.ldp;
+  const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+  uint4 xo[kReduceNormMaxChunks];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < kReduceNormMaxChunks; ++k) {
+    const int n0 = (threadIdx.x + k * blockDim.x) * 8;
+    if (n0 >= p.N) break;
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int z = 0; z < p.s; ++z) {                                     // slab order: the sum is the same on every run
+      const float4 a = *reinterpret_cast<const float4*>(src + z * p.slab + n0), b = *reinterpret_cast<const float4*>(src + z * p.slab + n0 + 4);
+      g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
+    }
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      const uint4 b4 = *reinterpret_cast<const uint4*>(p.bias + n0);
+      bv[0] = unpack_lo(b4.x); bv[1] = unpack_hi(b4.x); bv[2] = unpack_lo(b4.y); bv[3] = unpack_hi(b4.y);
+      bv[4] = unpack_lo(b4.z); bv[5] = unpack_hi(b4.z); bv[6] = unpack_lo(b4.w); bv[7] = unpack_hi(b4.w);
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = bf2f(f2bf(g[e] * p.alpha + bv[e]));
+      if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));
+      v[e] = t;
+    }
+    if (p.residual) {
+      const uint4 r = *reinterpret_cast<const uint4*>(p.residual + (long long)rm * p.ldr + n0);
+      v[0] += unpack_lo(r.x); v[1] += unpack_hi(r.x); v[2] += unpack_lo(r.y); v[3] += unpack_hi(r.y);
+      v[4] += unpack_lo(r.z); v[5] += unpack_hi(r.z); v[6] += unpack_lo(r.w); v[7] += unpack_hi(r.w);
+    }
+    xo[k] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    *reinterpret_cast<uint4*>(p.C + (long long)m * p.ldc + n0) = xo[k];
+    const uint32_t xw[4] = {xo[k].x, xo[k].y, xo[k].z, xo[k].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float lo = unpack_lo(xw[e]), hi = unpack_hi(xw[e]); ss += lo * lo; ss += hi * hi; }
+  }
+  const float rstd = rsqrtf(block_sum(ss, red) / p.N + q.eps);
+#pragma unroll
+  for (int k = 0; k < kReduceNormMaxChunks; ++k) {
+    const int n0 = (threadIdx.x + k * blockDim.x) * 8;
+    if (n0 >= p.N) break;
+    const uint4 w4 = *reinterpret_cast<const uint4*>(q.norm_w + n0);
+    const uint32_t xw[4] = {xo[k].x, xo[k].y, xo[k].z, xo[k].w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xl = unpack_lo(xw[e]), xh = unpack_hi(xw[e]), wl = unpack_lo(ww[e]), wh = unpack_hi(ww[e]);
+      o[e] = q.flavor ? pack2((xl * rstd) * (1.0f + wl), (xh * rstd) * (1.0f + wh))
+                      : pack2(wl * bf2f(f2bf(xl * rstd)), wh * bf2f(f2bf(xh * rstd)));
+    }
+    *reinterpret_cast<uint4*>(q.Y + (long long)m * q.ldy + n0) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+int reduce_norm_threads(int cols) {      // == norm_threads(cols) of norms.hip (the summation order depends on it)
+  const int t = ((cols / 8) + 63) / 64 * 64;
+  return t < 64 ? 64 : (t > 256 ? 256 : t);
+}
+
 // Which (tile variant, split factor).  Two regimes, both in microseconds:
 //  * at most one block per CU (blocks = tiles x s <= 256; the few-hundred-row problems this path exists for): every block runs its K loop
 //    alone on a CU at the tile's own pace, kt1_us per K-tile, + kSparseFix K-tiles of fill and epilogue - the time is that of ONE block,
@@ -1965,7 +2037,16 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
       r.M = d.M; r.N = d.N; r.act = d.act; r.alpha = d.alpha; r.C2 = a.C2; r.ldc2 = d.ldc2; r.swiglu = d.swiglu;
       const long long items = (long long)d.M * (d.swiglu ? d.N / 16 : d.N / 8);
       const dim3 rgrid((unsigned)((items + 255) / 256));
-      if (ev_b) hipExtLaunchKernelGGL(splitk_reduce_k, rgrid, dim3(256), 0, st, nullptr, ev_b, 0, r);
+      // the RMSNorm that follows this linear, in the same launch (one block per row), where the caller asked for it
+      const bool with_norm = d.norm_w && d.norm_out && !d.swiglu && uvx::g_options[17] && d.N <= 256 * 8 * kReduceNormMaxChunks &&
+                             d.norm_ld % 8 == 0 && ((uintptr_t)d.norm_w & 15) == 0 && ((uintptr_t)d.norm_out & 15) == 0;
+      if (with_norm) {
+        ReduceNormArgs q{r, (const bf16_t*)d.norm_w, (bf16_t*)d.norm_out, d.norm_ld, d.norm_eps, d.norm_flavor};
+        const dim3 ngrid((unsigned)d.M), nblk((unsigned)reduce_norm_threads(d.N));
+        if (ev_b) hipExtLaunchKernelGGL(splitk_reduce_norm_k, ngrid, nblk, 0, st, nullptr, ev_b, 0, q);
+        else hipLaunchKernelGGL(splitk_reduce_norm_k, ngrid, nblk, 0, st, q);
+        if (d.norm_done) *d.norm_done = true;
+      } else if (ev_b) hipExtLaunchKernelGGL(splitk_reduce_k, rgrid, dim3(256), 0, st, nullptr, ev_b, 0, r);
       else hipLaunchKernelGGL(splitk_reduce_k, rgrid, dim3(256), 0, st, r);
       if (timed) uvx::prof_commit();
       UVX_LAUNCH_CHECK();

@@ -378,9 +378,13 @@ GemmDesc lin(const void* A, const void* W, void* C, int M, int N, int K) {
 // one decoder layer on M = B*T rows; attention supplied by the caller
 struct LayerIO { void *x_in, *x_mid; };
 
-int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, void* x_mid, void* x_out) {
+// n_ready: s.n already holds post_attention_layernorm(x_mid) (attn_out's split-K reduce wrote it).  next_ln1 / next_ready: the NEXT
+// layer's input_layernorm is asked of the down projection's reduce (GemmDesc::norm_*); *next_ready says whether s.n holds it on return.
+int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, void* x_mid, void* x_out,
+              bool n_ready = false, const void* next_ln1 = nullptr, bool* next_ready = nullptr) {
   const int dt = c.dtype, D = c.llm_d;
-  if (dt == DT_BF16 && M <= 2 && c.llm_flavor != UVX_LLM_GEMMA3) {     // decode: post_attention_layernorm inside the gate|up GEMV
+  if (next_ready) *next_ready = false;
+  if (!n_ready && dt == DT_BF16 && M <= 2 && c.llm_flavor != UVX_LLM_GEMMA3) {     // decode: post_attention_layernorm inside the gate|up GEMV
     GemmDesc g = lin(x_mid, L.wgu, s.gu, M, 2 * c.llm_inter, D);
     const bool fused = c.llm_flavor == UVX_LLM_LLAMA;
     if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
@@ -393,7 +397,7 @@ int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, I
       return gemm(st, dt, d);
     }
   }
-  RC(rmsnorm_fwd(st, dt, x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
+  if (!n_ready) RC(rmsnorm_fwd(st, dt, x_mid, L.ln2, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
   if (c.llm_flavor == UVX_LLM_GEMMA3) {      // x_out = x_mid + post_feedforward_norm(mlp(pre_feedforward_norm(x_mid)))
     RC(gemm(st, dt, sk(lin(s.n, L.wgu, s.gu, M, 2 * c.llm_inter, D), s)));
     RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2, c.llm_act));
@@ -407,18 +411,27 @@ int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, I
   if (!fused) RC(swiglu_fwd(st, dt, s.gu, s.act, M, c.llm_inter, 2, c.llm_act));
   GemmDesc d = lin(s.act, L.wd, x_out, M, D, c.llm_inter);
   d.residual = x_mid; d.ldr = D;
+  if (dt == DT_BF16 && next_ln1 && next_ready) {      // (s.n is free: the gate|up GEMM has consumed it)
+    d.norm_w = next_ln1; d.norm_out = s.n; d.norm_ld = D; d.norm_eps = c.rms_eps; d.norm_flavor = c.llm_flavor; d.norm_done = next_ready;
+  }
   return gemm(st, dt, sk(d, s));
 }
 
 // x_out = x + o_proj(o)  -  Gemma-3: x + post_attention_norm(o_proj(o))
-int attn_out(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, const void* o, int OD, const void* x, void* x_out) {
+// n_ready (may be null): set when s.n holds post_attention_layernorm(x_out) on return (written by the o projection's split-K reduce)
+int attn_out(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, InferWs& s, int M, const void* o, int OD, const void* x, void* x_out,
+             bool* n_ready = nullptr) {
   const int dt = c.dtype, D = c.llm_d;
+  if (n_ready) *n_ready = false;
   if (c.llm_flavor == UVX_LLM_GEMMA3) {
     RC(gemm(st, dt, sk(lin(o, L.wo, s.n, M, D, OD), s)));             // (s.n is free: the q|k|v GEMM has consumed it)
     return rmsnorm_fwd(st, dt, s.n, L.ln1_post, x_out, nullptr, M, D, c.rms_eps, c.llm_flavor, nullptr, x);
   }
   GemmDesc g = lin(o, L.wo, x_out, M, D, OD);
   g.residual = x; g.ldr = D;
+  if (dt == DT_BF16 && n_ready) {      // (s.n is free: the q|k|v GEMM has consumed it)
+    g.norm_w = L.ln2; g.norm_out = s.n; g.norm_ld = D; g.norm_eps = c.rms_eps; g.norm_flavor = c.llm_flavor; g.norm_done = n_ready;
+  }
   return gemm(st, dt, sk(g, s));
 }
 float attn_scale_of(const uvx_config_t& c) { return c.llm_attn_scale > 0.f ? c.llm_attn_scale : 1.0f / sqrtf((float)c.llm_head_dim); }
@@ -512,9 +525,10 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
   UVX_HIP(hipMemcpyAsync(s.x, inputs_embeds, (size_t)M * D * es, hipMemcpyDeviceToDevice, st));
   if (c.llm_flavor == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, s.x, (long long)M * D, gemma_normalizer(c)));   // 4.51.3: inside the model
   const size_t layer_stride = (size_t)2 * B * Tmax * KVD;  // elements
+  bool n1_ready = false, n2_ready = false;      // s.n already holds this layer's input_layernorm / post_attention_layernorm (fused reduces)
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
-    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
+    if (!n1_ready) RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
     {
       char* ck = at(kv_cache, l * layer_stride, dt);
       char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
@@ -528,8 +542,8 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.scale = attn_scale_of(c);
     ad.window = c.llm_flavor == UVX_LLM_GEMMA3 && c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
     RC(attention_fwd(st, dt, ad));
-    RC(attn_out(st, c, L, s, M, s.o, s.OD, s.x, s.x2));
-    RC(mlp_block(st, c, L, s, M, s.x2, s.x));
+    RC(attn_out(st, c, L, s, M, s.o, s.OD, s.x, s.x2, &n2_ready));
+    RC(mlp_block(st, c, L, s, M, s.x2, s.x, n2_ready, l + 1 < c.llm_layers ? w->layers[l + 1].ln1 : nullptr, &n1_ready));
   }
   // logits of the LAST position of every sequence only (what generate() consumes)
   UVX_HIP(hipMemcpy2DAsync(s.last, (size_t)D * es, at(s.x, (size_t)(T - 1) * D, dt), (size_t)T * D * es, (size_t)D * es, B,
@@ -591,9 +605,10 @@ static int32_t prefill_chunk_impl(void* stream, const uvx_config_t* cfg, const u
   if (c.llm_flavor == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, s.x, (long long)M * D, gemma_normalizer(c)));
   UVX_HIP(hipMemsetAsync(k.fq, 0, (size_t)B * Tf * s.QKV * es, st));   // the prefix rows' (skipped) query part stays defined
   const size_t layer_stride = (size_t)2 * B * Tmax * KVD;  // elements
+  bool n1_ready = false, n2_ready = false;
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
-    RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
+    if (!n1_ready) RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, M, D, c.rms_eps, c.llm_flavor));
     char* ck = at(kv_cache, l * layer_stride, dt);
     char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
     RC(qkv_rope_append(st, c, w, L, s, s.n, s.pos, B, Tn, Tmax, cur_len, ck, cv, l));
@@ -617,8 +632,8 @@ static int32_t prefill_chunk_impl(void* stream, const uvx_config_t* cfg, const u
     for (int b = 0; b < B; ++b)
       UVX_HIP(hipMemcpyAsync(at(s.o, (size_t)b * Tn * s.OD, dt), at(k.fo, ((size_t)b * Tf + cur_len) * s.OD, dt), (size_t)Tn * s.OD * es,
                              hipMemcpyDeviceToDevice, st));
-    RC(attn_out(st, c, L, s, M, s.o, s.OD, s.x, s.x2));
-    RC(mlp_block(st, c, L, s, M, s.x2, s.x));
+    RC(attn_out(st, c, L, s, M, s.o, s.OD, s.x, s.x2, &n2_ready));
+    RC(mlp_block(st, c, L, s, M, s.x2, s.x, n2_ready, l + 1 < c.llm_layers ? w->layers[l + 1].ln1 : nullptr, &n1_ready));
   }
   if (all_rows) {      // final norm and LM head on the B * Tn new rows (x2 is free after the last layer)
     RC(rmsnorm_fwd(st, dt, s.x, w->norm, s.x2, nullptr, M, D, c.rms_eps, c.llm_flavor));
@@ -663,6 +678,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
   if (c.llm_flavor == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, s.x, (long long)B * D, gemma_normalizer(c)));
   const size_t layer_stride = (size_t)2 * B * Tmax * KVD;
   const float scale = attn_scale_of(c);
+  bool n1_ready = false, n2_ready = false;      // batches beyond 16 rows (tiled split-K linears): the norms ride in the reduce kernels
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
     const bool fuse_rope_append = dt == DT_BF16 && !c.llm_qk_norm;     // (Qwen3 / Gemma-3: q_norm / k_norm + RoPE is its own kernel)
@@ -670,16 +686,16 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
       // input_layernorm inside the q|k|v GEMV (B <= 2); otherwise the two launches
       GemmDesc g = lin(s.x, L.wqkv, s.qkv, B, s.QKV, D);
       g.bias = L.bqkv;
-      const int rc = gemm_skinny_rmsnorm_bf16(st, g, L.ln1, c.rms_eps, c.llm_flavor);
+      const int rc = n1_ready ? UVX_ERR_UNSUPPORTED : gemm_skinny_rmsnorm_bf16(st, g, L.ln1, c.rms_eps, c.llm_flavor);
       if (rc == UVX_ERR_UNSUPPORTED) {
-        RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
+        if (!n1_ready) RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
         g.A = s.n;
         RC(gemm(st, dt, sk(g, s)));
       } else {
         RC(rc);
       }
     } else {
-      RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
+      if (!n1_ready) RC(rmsnorm_fwd(st, dt, s.x, L.ln1, s.n, nullptr, B, D, c.rms_eps, c.llm_flavor));
       RC(qkv_rope(st, c, w, L, s.n, s.qkv, positions, B, 1, s.QKV, l, &s));
     }
     // Gemma-3 sliding-window layer: the new token attends to the last `window` positions = cache slots (the slots of a sequence are
@@ -720,8 +736,8 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
       else hipLaunchKernelGGL((attn_decode_k<float, 128>), dim3(cdiv(nw, 4)), dim3(256), 0, st, (const float*)s.qkv, (const float*)ck, (const float*)cv, (float*)s.o, kv_start, B, Hq, Hkv, Tmax, cur_len + 1, s.QKV, scale, lo);
     }
     UVX_LAUNCH_CHECK();
-    RC(attn_out(st, c, L, s, B, s.o, s.OD, s.x, s.x2));
-    RC(mlp_block(st, c, L, s, B, s.x2, s.x));
+    RC(attn_out(st, c, L, s, B, s.o, s.OD, s.x, s.x2, &n2_ready));
+    RC(mlp_block(st, c, L, s, B, s.x2, s.x, n2_ready, l + 1 < c.llm_layers ? w->layers[l + 1].ln1 : nullptr, &n1_ready));
   }
   RC(rmsnorm_fwd(st, dt, s.x, w->norm, s.hn, nullptr, B, D, c.rms_eps, c.llm_flavor));
   return gemm(st, dt, sk(lin(s.hn, w->lm_head, logits, B, c.vocab, D), s));

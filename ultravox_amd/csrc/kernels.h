@@ -51,6 +51,16 @@ struct GemmDesc {
   void* splitk_ws = nullptr;
   size_t splitk_ws_bytes = 0;
   int splitk_force = 0;
+  // The RMSNorm that FOLLOWS this linear (bf16; decoder stack: o_proj -> post_attention_layernorm, down_proj -> the next layer's
+  // input_layernorm): when the problem is split, the reduce kernel also writes norm_out [M, N] (row stride norm_ld) = RMSNorm(C row; norm_w,
+  // norm_eps, flavor as rmsnorm_fwd) - bit for bit what rmsnorm_fwd computes from C - and sets *norm_done (host side, may be null).  A launch
+  // that is not split ignores these fields and leaves *norm_done alone: the caller then runs rmsnorm_fwd itself.
+  const void* norm_w = nullptr;
+  void* norm_out = nullptr;
+  int norm_ld = 0;
+  float norm_eps = 0.f;
+  int norm_flavor = 0;
+  bool* norm_done = nullptr;
 };
 size_t gemm_splitk_ws_bytes(int M, int N);   // enough scratch for any split gemm_nt picks on an M x N output
 int gemm_pick_split(int M, int N, int K, size_t ws_bytes, int* variant);   // host only: split factor (1 = none) and tile the model picks
