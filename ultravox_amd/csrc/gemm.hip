@@ -2038,7 +2038,9 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
       const long long items = (long long)d.M * (d.swiglu ? d.N / 16 : d.N / 8);
       const dim3 rgrid((unsigned)((items + 255) / 256));
       // the RMSNorm that follows this linear, in the same launch (one block per row), where the caller asked for it
+      // (N = 512 / 1024 / 2048: rmsnorm_fwd runs its one-wave-per-row kernel there - another summation order, so those widths keep the separate launch)
       const bool with_norm = d.norm_w && d.norm_out && !d.swiglu && uvx::g_options[17] && d.N <= 256 * 8 * kReduceNormMaxChunks &&
+                             d.N != 512 && d.N != 1024 && d.N != 2048 &&
                              d.norm_ld % 8 == 0 && ((uintptr_t)d.norm_w & 15) == 0 && ((uintptr_t)d.norm_out & 15) == 0;
       if (with_norm) {
         ReduceNormArgs q{r, (const bf16_t*)d.norm_w, (bf16_t*)d.norm_out, d.norm_ld, d.norm_eps, d.norm_flavor};
