@@ -479,46 +479,3 @@ def test_rmsnorm_inside_the_splitk_reduce_is_bit_identical(family):
     for a, b in zip(*runs):
         assert torch.equal(a, b)
     assert torch.isfinite(runs[0][1].float()).all()
-
-
-@pytest.mark.parametrize("family,B", [("llama", 3), ("llama", 9), ("llama", 16), ("gemma", 8), ("qwen3", 5)])
-def test_rmsnorm_by_the_last_block_of_a_few_row_linear_is_bit_identical(family, B):
-    """Round 5: in a decode step of 3..16 sequences the o / down projections run on the weight-streaming MFMA kernel, whose blocks own
-    16-32 output columns each; the RMSNorm that follows (post_attention_layernorm, the next layer's input_layernorm) is computed by the block
-    that finishes LAST (a device-scope fence + an arrival counter, no waiting), with rmsnorm_fwd_k's mapping and order (option 17).  Same
-    tokens, logits and cache rows as with the separate launches, over several steps (the counter must come back to zero every launch) and
-    through a later call.  Widths the fusion serves: more than 1536 columns, K % 2048 == 0 for the staged kernel (o: 2048, down: 4096)."""
-    from ultravox_amd import _lib
-    from ultravox_amd.config import UltravoxConfig
-    from ultravox_amd.model import UltravoxModel
-    text = dict(hidden_size=3072, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=16, num_key_value_heads=4, head_dim=128,
-                vocab_size=2048, eos_token_id=2, max_position_embeddings=1024)
-    if family != "llama":
-        text["model_type"] = family
-    cfg = UltravoxConfig(audio_config=dict(d_model=128, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=256),
-                         text_config=text, hidden_size=256, projector_ln_mid=True)
-    model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=17, rope_len=256, with_backward=False)
-    L = _lib.lib()
-    torch.manual_seed(B)
-    T, new = 9, 5
-    ids = torch.randint(3, 2048, (B, T))
-    am = torch.ones(B, T, dtype=torch.long)
-    for r in range(1, B, 3):
-        am[r, :r % 4 + 1] = 0
-    ids[am == 0] = 2
-    runs = []
-    try:
-        for opt in (1, 0, 1):
-            L.uvx_set_option(17, opt)
-            out = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=new, eos_token_id=-1, return_dict_in_generate=True,
-                                 output_logits=True)
-            st = out.past_key_values
-            kvd = text["num_key_value_heads"] * text["head_dim"]
-            cache = st.cache.view(torch.bfloat16).view(3, 2, B, st.Tmax, kvd)[:, :, :, :st.cur_len].clone()
-            step = model.forward(input_ids=out.sequences[:, -1:], past_key_values=st)      # one more position through the chunked path
-            runs.append((out.sequences, torch.stack(out.logits), cache, step.logits))
-    finally:
-        L.uvx_set_option(17, 1)
-    for a, b, c_ in zip(*runs):
-        assert torch.equal(a, b) and torch.equal(a, c_)
-    assert torch.isfinite(runs[0][1].float()).all()

@@ -25,9 +25,6 @@ struct SkinnyArgs {
   float alpha;
   // gemv_rows_bf16_k<.., NORM = true>: A is the RAW residual-stream row; RMSNorm(A; norm_w) is applied on the way in
   const bf16_t* norm_w; float norm_eps; int norm_flavor;
-  // gemm_skinny_bf16_k<.., STAGE, 1> (M = 3..16): the RMSNorm that FOLLOWS this linear - Y = RMSNorm(C rows; post_w) - computed by the
-  // block that finishes last (arrive: a device counter, zero before the launch and again after it)
-  const bf16_t* post_w; bf16_t* post_y; int post_ld; unsigned* arrive;
 };
 
 // TILES = 16-column MFMA tiles per block: 2 (needed by the fused SwiGLU: gate block + up block) or 1 (twice the blocks:
@@ -42,10 +39,8 @@ constexpr int SKS_PITCH = 528;                    // bytes per staged row: 256 b
 // MT (STAGE only): 16-row tiles of the ACTIVATION matrix served by one block - M <= 16 MT.  Every staged weight fragment is multiplied with
 // MT activation fragments, so batches up to 64 (M = 17..64 used to fall to the 128-row tiled kernels: a handful of active CUs at N = 8192)
 // stream the weights once at the same rate.
-// (STAGE, MT = 1: four waves per SIMD = two blocks per CU is what the M <= 16 kernels are tuned for - 128 VGPRs; the compiler lands there
-//  by itself without the norm tail below and two registers above it with the tail, so the bound is stated)
 template <int TILES, bool STAGE = false, int MT = 1>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((STAGE && MT == 1) ? 4 : 1))) void gemm_skinny_bf16_k(SkinnyArgs p) {
+__global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
   static_assert(STAGE || MT == 1, "several activation row tiles: staged kernel only");
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_dyn[];      // STAGE: 8 waves x 16 x SKS_PITCH bytes (then the reduction)
   __shared__ float red_static[STAGE ? 1 : 8 * 2 * 64 * 4];
@@ -159,9 +154,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((STAGE && M
 #pragma unroll
     for (int e = 0; e < 4; ++e) { red[w][0][mt][lane][e] = acc[mt][0][e]; red[w][1][mt][lane][e] = acc[mt][1][e]; }
   __syncthreads();
-  const bool post = STAGE && MT == 1 && p.post_w != nullptr;      // block-uniform
-  if (w >= MT && !post) return;          // wave mt finishes activation row tile mt
-  auto finish = [&]() {
+  if (w >= MT) return;          // wave mt finishes activation row tile mt
   const int mt = w;
   float s[2][4];
 #pragma unroll
@@ -214,77 +207,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((STAGE && M
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
     *reinterpret_cast<u16x4_t*>(p.C + (long long)m * p.ldc + n) = o;
-  }
-  };
-  if (w < MT) finish();
-  if constexpr (STAGE && MT == 1) {
-    if (!post) return;
-    // ---- the RMSNorm that follows this linear, by the block that finishes last (round 5) ----
-    // In the decode step every o_proj / down_proj (+ residual) is followed by an RMSNorm over the rows it has just completed: at 3..16
-    // rows that norm was a launch of its own - 8.7 us, 160 of them 1.4 ms of a 25.5 ms Llama-3.3-70B step at batch 8.  A block owns 16-32
-    // COLUMNS of C, so no block sees a whole row; instead every block publishes its columns (device-scope fence), counts itself in, and the
-    // one that arrives last - it can see every column - normalises the M rows: two groups of 256 threads, a row each at a time, with
-    // rmsnorm_fwd_k's thread -> column mapping, summation order and arithmetic (norms.hip; 256 threads per row, which is what rmsnorm_fwd uses
-    // for every width the host side lets through), so Y is bit for bit what the separate launch computes.  Nobody waits for anybody: no spin.
-    __shared__ int last_flag;
-    __shared__ float nred[8];
-    __threadfence();                                        // this block's C columns are visible device-wide ...
-    __syncthreads();                                        // ... before thread 0 counts the block in
-    if (w == 0 && lane == 0) {
-      const unsigned old = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      last_flag = old == gridDim.x - 1;
-      if (last_flag) __hip_atomic_store(p.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (stream order)
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every wave: nothing below is served from a stale line
-    constexpr int MAXC = 8;                                 // 8-column chunks per thread: N <= 256 * 8 * 8 = 16384
-    const int grp = w >> 2, tl = ((w & 3) << 6) | lane;      // (from the wave / lane ids the main loop keeps anyway)
-    for (int r0 = 0; r0 < p.M; r0 += 2) {
-      const int m = r0 + grp;
-      const bool row_ok = m < p.M;
-      uint4 xo[MAXC];
-      float ss = 0.f;
-#pragma unroll
-      for (int k = 0; k < MAXC; ++k) {
-        const int c = (tl + k * 256) * 8;
-        if (c >= p.N) break;
-        xo[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (row_ok) xo[k] = *reinterpret_cast<const uint4*>(p.C + (long long)m * p.ldc + c);
-        const unsigned xw[4] = {xo[k].x, xo[k].y, xo[k].z, xo[k].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = bf2f((bf16_t)(xw[e] & 0xffffu)), hi = bf2f((bf16_t)(xw[e] >> 16));
-          ss += lo * lo; ss += hi * hi;
-        }
-      }
-      ss = wave_sum(ss);                                    // block_sum's order within the row's group of four waves
-      __syncthreads();
-      if (lane == 0) nred[w] = ss;
-      __syncthreads();
-      float tot = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) tot += nred[grp * 4 + i];
-      const float rstd = rsqrtf(tot / p.N + p.norm_eps);
-      if (!row_ok) continue;
-#pragma unroll
-      for (int k = 0; k < MAXC; ++k) {
-        const int c = (tl + k * 256) * 8;
-        if (c >= p.N) break;
-        const uint4 w4 = *reinterpret_cast<const uint4*>(p.post_w + c);
-        const unsigned xw[4] = {xo[k].x, xo[k].y, xo[k].z, xo[k].w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
-        unsigned o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xl = bf2f((bf16_t)(xw[e] & 0xffffu)), xh = bf2f((bf16_t)(xw[e] >> 16));
-          const float wl = bf2f((bf16_t)(ww[e] & 0xffffu)), wh = bf2f((bf16_t)(ww[e] >> 16));
-          const float ol = p.norm_flavor ? (xl * rstd) * (1.0f + wl) : wl * bf2f(f2bf(xl * rstd));
-          const float oh = p.norm_flavor ? (xh * rstd) * (1.0f + wh) : wh * bf2f(f2bf(xh * rstd));
-          o[e] = (unsigned)f2bf(ol) | ((unsigned)f2bf(oh) << 16);
-        }
-        *reinterpret_cast<uint4*>(p.post_y + (long long)m * p.post_ld + c) = make_uint4(o[0], o[1], o[2], o[3]);
-      }
-    }
   }
 }
 
@@ -498,7 +420,6 @@ int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm
   a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr; a.ldc2 = d.ldc2;
   a.res_mod = d.res_mod; a.act = d.act; a.swiglu = d.swiglu; a.alpha = d.alpha;
   a.norm_w = (const bf16_t*)norm_w; a.norm_eps = eps; a.norm_flavor = flavor;
-  a.post_w = nullptr; a.post_y = nullptr; a.post_ld = 0; a.arrive = nullptr;
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 + (double)d.M * d.N * 2.0);
   if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, 1, 201);
@@ -533,7 +454,6 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
   a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc; a.ldr = d.ldr; a.ldc2 = d.ldc2;
   a.res_mod = d.res_mod; a.act = d.act; a.swiglu = d.swiglu; a.alpha = d.alpha;
   a.norm_w = nullptr; a.norm_eps = 0.f; a.norm_flavor = 0;
-  a.post_w = nullptr; a.post_y = nullptr; a.post_ld = 0; a.arrive = nullptr;
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 + (double)d.M * d.N * 2.0);
   if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, 1, 200);
@@ -561,15 +481,6 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
       static PerDeviceOnce attr2; \
       if (attr2.need()) UVX_HIP(hipFuncSetAttribute((const void*)gemm_skinny_bf16_k<TT, true, MTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
       hipLaunchKernelGGL((gemm_skinny_bf16_k<TT, true, MTT>), grid, dim3(512), sh, st, a); } while (0)
-    // the RMSNorm that follows this linear, by the block that finishes last (see the kernel): widths rmsnorm_fwd serves with 256 threads per
-    // row (more than 1536 columns, not its one-wave-per-row width 2048), 16-byte accesses, the caller's zeroed arrival counter
-    if (d.M <= 16 && d.norm_w && d.norm_out && d.norm_arrive && !d.swiglu && uvx::g_options[17] && d.N > 1536 && d.N != 2048 && d.N <= 16384 &&
-        d.N % 8 == 0 && d.ldc % 8 == 0 && d.norm_ld % 8 == 0 && ((uintptr_t)d.C & 15) == 0 && ((uintptr_t)d.norm_w & 15) == 0 &&
-        ((uintptr_t)d.norm_out & 15) == 0) {
-      a.post_w = (const bf16_t*)d.norm_w; a.post_y = (bf16_t*)d.norm_out; a.post_ld = d.norm_ld; a.arrive = (unsigned*)d.norm_arrive;
-      a.norm_eps = d.norm_eps; a.norm_flavor = d.norm_flavor;
-      if (d.norm_done) *d.norm_done = true;
-    }
     if (d.M <= 16) { if (two) UVX_SKS(2, 1); else UVX_SKS(1, 1); }
     else if (d.M <= 32) { if (two) UVX_SKS(2, 2); else UVX_SKS(1, 2); }
     else { if (two) UVX_SKS(2, 4); else UVX_SKS(1, 4); }

@@ -32,8 +32,6 @@ struct InferWs {
   int32_t *kvs, *kvl, *pos;
   int M, Tp, QKV, OD;
   void* sk; size_t sk_bytes;     // split-K scratch of the GEMMs (bf16 prefill of a few hundred rows; gemm.hip "Split-K"), or null
-  bool arrive_ok = false;        // the counter below was zeroed on this call's stream (uvx_llm_decode)
-  int32_t* arrive;               // block-arrival counter of the 3..16-row linears that also compute the following RMSNorm (gemm_skinny.hip); zeroed per call
 };
 InferWs carve(Arena& a, const uvx_config_t& c, int B, int T) {
   InferWs w;
@@ -52,7 +50,6 @@ InferWs carve(Arena& a, const uvx_config_t& c, int B, int T) {
   // MFMA kernel serves 16-row tiles: B = 32 runs at 0.44, B = 64 at 0.23 of the HBM roofline), too few tiles for the 256 CUs
   w.sk_bytes = c.dtype == DT_BF16 && M > 16 && M <= 1536 ? gemm_splitk_ws_bytes((int)M, std::max(std::max(w.QKV, 2 * c.llm_inter), c.llm_d)) : 0;
   w.sk = w.sk_bytes ? a.take(w.sk_bytes) : nullptr;
-  w.arrive = (int32_t*)a.take(256);
   return w;
 }
 // lends the split-K scratch to a GEMM of the layer loop
@@ -416,7 +413,6 @@ int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, I
   d.residual = x_mid; d.ldr = D;
   if (dt == DT_BF16 && next_ln1 && next_ready) {      // (s.n is free: the gate|up GEMM has consumed it)
     d.norm_w = next_ln1; d.norm_out = s.n; d.norm_ld = D; d.norm_eps = c.rms_eps; d.norm_flavor = c.llm_flavor; d.norm_done = next_ready;
-    d.norm_arrive = s.arrive_ok ? s.arrive : nullptr;
   }
   return gemm(st, dt, sk(d, s));
 }
@@ -435,7 +431,6 @@ int attn_out(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, In
   g.residual = x; g.ldr = D;
   if (dt == DT_BF16 && n_ready) {      // (s.n is free: the q|k|v GEMM has consumed it)
     g.norm_w = L.ln2; g.norm_out = s.n; g.norm_ld = D; g.norm_eps = c.rms_eps; g.norm_flavor = c.llm_flavor; g.norm_done = n_ready;
-    g.norm_arrive = s.arrive_ok ? s.arrive : nullptr;
   }
   return gemm(st, dt, sk(g, s));
 }
@@ -681,10 +676,6 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
   const size_t es = esz(dt);
   UVX_HIP(hipMemcpyAsync(s.x, token_embeds, (size_t)B * D * es, hipMemcpyDeviceToDevice, st));
   if (c.llm_flavor == UVX_LLM_GEMMA) RC(scale_inplace(st, dt, s.x, (long long)B * D, gemma_normalizer(c)));
-  if (dt == DT_BF16 && B >= 3 && B <= 16) {      // the 3..16-row linears hand the following RMSNorm to their last block: its counter starts at zero
-    UVX_HIP(hipMemsetAsync(s.arrive, 0, 256, st));
-    s.arrive_ok = true;
-  }
   const size_t layer_stride = (size_t)2 * B * Tmax * KVD;
   const float scale = attn_scale_of(c);
   bool n1_ready = false, n2_ready = false;      // batches beyond 16 rows (tiled split-K linears): the norms ride in the reduce kernels

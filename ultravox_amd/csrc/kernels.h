@@ -61,9 +61,6 @@ struct GemmDesc {
   float norm_eps = 0.f;
   int norm_flavor = 0;
   bool* norm_done = nullptr;
-  // (3..16 rows, the weight-streaming MFMA kernel: the block that finishes last computes that norm; it needs a device counter that is zero
-  //  before the launch - the kernel leaves it at zero)
-  int32_t* norm_arrive = nullptr;
 };
 size_t gemm_splitk_ws_bytes(int M, int N);   // enough scratch for any split gemm_nt picks on an M x N output
 int gemm_pick_split(int M, int N, int K, size_t ws_bytes, int* variant);   // host only: split factor (1 = none) and tile the model picks
