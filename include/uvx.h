@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 14
+#define UVX_ABI_VERSION 15
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -80,7 +80,17 @@ typedef struct {
    * in (q - window, q]: forward, dQ + dK/dV pair, chunked prefill), and the decode steps clamp the first visible cache slot. */
   float llm_attn_scale;
   int32_t llm_window;
+  /* UltravoxProjector's activation (config.projector_act, ultravox_model.py:754-755): UVX_PROJ_SWIGLU (the default and every release config:
+   * linear_1 -> SwiGLU halves the width -> linear_2 [D, hidden / 2]) or a plain activation of transformers' ACT2FN that keeps the width
+   * (linear_2 [D, hidden], ln_mid over hidden): UVX_PROJ_SILU ("silu" / "swish"), UVX_PROJ_GELU_TANH ("gelu_pytorch_tanh"),
+   * UVX_PROJ_GELU ("gelu", exact erf), UVX_PROJ_RELU. */
+  int32_t proj_act;
 } uvx_config_t;
+#define UVX_PROJ_SWIGLU 0
+#define UVX_PROJ_SILU 1
+#define UVX_PROJ_GELU_TANH 2
+#define UVX_PROJ_GELU 3
+#define UVX_PROJ_RELU 4
 #define UVX_ACT_SILU 0
 #define UVX_ACT_GELU_TANH 1
 #define UVX_ACT_GELU_ERF 2

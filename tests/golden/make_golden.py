@@ -9,6 +9,7 @@ What is recorded
   projector_*.npz — outputs AND weight/input gradients of the REFERENCE UltravoxProjector
                     (ultravox_model.py:745-800, imported with an in-memory `peft` stub) for seeded inputs,
                     both projector_ln_mid variants, T not a multiple of the stack factor.
+  projector_act.npz — the same for projector_act = gelu / silu / relu / gelu_pytorch_tanh (:754-755: the width is kept, linear_2 [D, hidden]).
   latency_mask.npz — ModifiedWhisperEncoder.init_latency_mask (ultravox_model.py:834-863).
   kl_loss.npz     — the REFERENCE UltravoxModel._get_prediction_mask / _compute_kl_loss (ultravox_model.py:157-256) called
                     unbound on a stub `self` whose language model returns recorded teacher logits: masks, loss and
@@ -194,6 +195,38 @@ def projector_cases():
         rec["stacked"] = stacked.numpy()
         np.savez_compressed(os.path.join(HERE, f"projector_ln_{'mid' if ln_mid else 'post'}.npz"), **rec)
     print("projector_*.npz written")
+
+
+def projector_act_cases():
+    """UltravoxProjector with projector_act != "swiglu" (ultravox_model.py:754-755: transformers.activations.get_activation, dim_mid = hidden
+    for every activation but swiglu): outputs and gradients for the four fused-op activations the HIP path builds, both norm placements."""
+    rec = {}
+    for act, ln_mid in (("gelu", True), ("silu", False), ("relu", True), ("gelu_pytorch_tanh", False)):
+        cfg = ultravox_config.UltravoxConfig(
+            audio_config={"model_type": "whisper", "d_model": 32, "encoder_layers": 1, "encoder_attention_heads": 2,
+                          "encoder_ffn_dim": 64, "num_mel_bins": 80},
+            text_config={"model_type": "llama", "hidden_size": 64, "intermediate_size": 64, "num_hidden_layers": 1,
+                         "num_attention_heads": 2, "num_key_value_heads": 2, "vocab_size": 128},
+            hidden_size=128, stack_factor=8, projector_ln_mid=ln_mid, projector_act=act)
+        torch.manual_seed(11)
+        proj = ultravox_model.UltravoxProjector(cfg).float()
+        assert proj.linear_2.weight.shape == (64, 128)                      # the width is kept (:755)
+        with torch.no_grad():
+            for p in proj.parameters():
+                if p.dim() == 1:
+                    p.mul_(1.0 + 0.2 * torch.randn_like(p))
+        x = torch.randn(3, 21, 32, requires_grad=True)
+        y = proj(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        rec.update({f"{act}.x": x.detach().numpy(), f"{act}.y": y.detach().numpy(), f"{act}.gy": gy.numpy(), f"{act}.gx": x.grad.numpy(),
+                    f"{act}.ln_mid": np.array(int(ln_mid))})
+        for k, v in proj.state_dict().items():
+            rec[f"{act}.w.{k}"] = v.numpy()
+        for k, v in proj.named_parameters():
+            rec[f"{act}.g.{k}"] = v.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "projector_act.npz"), **rec)
+    print("projector_act.npz written:", sorted({k.split(".")[0] for k in rec}))
 
 
 def latency_mask_cases():
@@ -832,6 +865,7 @@ if __name__ == "__main__":
     lora_cases()
     processor_cases()
     projector_cases()
+    projector_act_cases()
     latency_mask_cases()
     logmel_cases()
     logmel_speech_cases()

@@ -106,6 +106,58 @@ def test_projector_against_reference_fixture(golden_dir, variant):
             assert rel_l2(grads["multi_modal_projector." + k[2:]], torch.from_numpy(z[k])) < 3e-2, k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["gelu", "silu", "relu", "gelu_pytorch_tanh"])
+def test_projector_with_a_plain_activation_against_reference_fixture(golden_dir, act, dtype):
+    """projector_act != "swiglu" (round 5; ultravox_model.py:754-755: ACT2FN[projector_act], the width is kept): forward and every gradient
+    of uvx_projector_fwd / _bwd against the REFERENCE UltravoxProjector's (fixture projector_act.npz), f32 mode tight, bf16 at the stage bars;
+    and a whole training step with such a projector against the oracle."""
+    from oracle.reference_cpu import OracleModel, synthetic_batch
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    z = np.load(os.path.join(golden_dir, "projector_act.npz"))
+    cfg = UltravoxConfig(audio_config=dict(d_model=32, encoder_layers=1, encoder_attention_heads=1, encoder_ffn_dim=64),
+                         text_config=dict(hidden_size=64, intermediate_size=64, num_hidden_layers=1, num_attention_heads=1,
+                                          num_key_value_heads=1, vocab_size=128), hidden_size=128,
+                         projector_ln_mid=bool(z[f"{act}.ln_mid"]), projector_act=act)
+    sd = random_state_dict(cfg, seed=0)
+    assert tuple(sd["multi_modal_projector.linear_2.weight"].shape) == (64, 128)
+    for k in z.files:
+        if k.startswith(f"{act}.w."):
+            sd["multi_modal_projector." + k[len(act) + 3:]] = torch.from_numpy(z[k])
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    x = torch.from_numpy(z[f"{act}.x"]).to(DEV).to(dtype)
+    y = model.multi_modal_projector_forward(x)
+    f32 = dtype == torch.float32
+    assert tuple(y.shape) == z[f"{act}.y"].shape == (3, 3, 64)
+    assert rel_l2(y, torch.from_numpy(z[f"{act}.y"])) < (1e-5 if f32 else 1.5e-2)
+    model._projector_backward(torch.from_numpy(z[f"{act}.gy"]).to(DEV).to(dtype))
+    grads = model.projector_grads()
+    n = 0
+    for k in z.files:
+        if k.startswith(f"{act}.g."):
+            assert rel_l2(grads["multi_modal_projector." + k[len(act) + 3:]], torch.from_numpy(z[k])) < (2e-5 if f32 else 3e-2), k
+            n += 1
+    assert n == 4
+    # the whole step: encoder -> this projector -> LLM -> loss -> projector gradients, against the oracle's autograd
+    cfg2 = UltravoxConfig(**{**SMALL, "projector_act": act, "projector_ln_mid": act in ("gelu", "relu")})
+    sd2 = {k: v.to(dtype) for k, v in random_state_dict(cfg2, seed=31).items()}
+    m2, oracle = UltravoxModel(cfg2, state_dict=sd2, device=DEV, dtype=dtype), OracleModel(cfg2, sd2, dtype=torch.float32)
+    b = synthetic_batch(cfg2, 2, 3.0, n_text=24, audio_start=5, n_supervised=8)
+    pcm = b.pop("pcm")
+    mel = WhisperFeatureExtractor(cfg2.audio_config.num_mel_bins).logmel_device(pcm.to(DEV)).to(dtype)
+    ref, g_ref, _ = oracle.train_step({**b, "audio_values": mel.cpu().float()})
+    m2.train()
+    loss = m2.forward_backward(audio_values=mel, **{k: v.to(DEV) for k, v in b.items()})
+    assert abs(loss.item() - ref["loss"].item()) < (1e-4 if f32 else 2e-2) * abs(ref["loss"].item())
+    mine = m2.projector_grads()
+    assert set(mine) == set(g_ref)
+    for k, g in g_ref.items():
+        assert rel_l2(mine[k], g) < (2e-3 if f32 else 8e-2), k
+
+
 def test_forward_logits_loss_match_oracle():
     cfg, sd, model, oracle = build(3)
     b = batch_for(cfg)

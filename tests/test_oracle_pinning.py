@@ -42,6 +42,27 @@ def test_projector_matches_reference_fixture(golden_dir, variant):
         np.testing.assert_allclose(p[k].grad.numpy(), z["g." + k], rtol=1e-4, atol=1e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("act", ["gelu", "silu", "relu", "gelu_pytorch_tanh"])
+def test_projector_with_a_plain_activation_matches_reference_fixture(golden_dir, act):
+    """projector_act != "swiglu" (ultravox_model.py:754-755): the reference's UltravoxProjector keeps the width (linear_2 [D, hidden])
+    and applies transformers' ACT2FN[projector_act]; fixture projector_act.npz = outputs and gradients of the imported reference."""
+    z = np.load(os.path.join(golden_dir, "projector_act.npz"))
+    cfg = tiny_cfg(projector_ln_mid=bool(z[f"{act}.ln_mid"]), hidden_size=128, projector_act=act)
+    assert cfg.projector_mid_dim == 128
+    pre = f"{act}.w."
+    p = {k[len(pre):]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith(pre)}
+    assert tuple(p["linear_2.weight"].shape) == (64, 128)
+    x = torch.from_numpy(z[f"{act}.x"]).clone().requires_grad_(True)
+    y = O.projector_ref(p, cfg, x)
+    np.testing.assert_allclose(y.detach().numpy(), z[f"{act}.y"], rtol=1e-5, atol=1e-6)
+    y.backward(torch.from_numpy(z[f"{act}.gy"]))
+    np.testing.assert_allclose(x.grad.numpy(), z[f"{act}.gx"], rtol=1e-4, atol=1e-6)
+    for k in p:
+        np.testing.assert_allclose(p[k].grad.numpy(), z[f"{act}.g.{k}"], rtol=1e-4, atol=1e-5, err_msg=k)
+    with pytest.raises(ValueError, match="projector_act"):
+        tiny_cfg(projector_act="gelu_new")
+
+
 def test_latency_mask_matches_reference_fixture(golden_dir):
     z = np.load(os.path.join(golden_dir, "latency_mask.npz"))
     for block in (100, 300, 1500):

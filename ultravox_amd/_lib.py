@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 14  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+ABI_VERSION = 15  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
 
 
 def lib() -> C.CDLL:
@@ -96,7 +96,7 @@ class Config(C.Structure):
         ("llm_layers", C.c_int32), ("llm_d", C.c_int32), ("llm_heads", C.c_int32), ("llm_kv_heads", C.c_int32),
         ("llm_head_dim", C.c_int32), ("llm_inter", C.c_int32), ("vocab", C.c_int32), ("rms_eps", C.c_float),
         ("llm_flavor", C.c_int32), ("llm_act", C.c_int32), ("llm_qk_norm", C.c_int32), ("llm_wt_stream", C.c_int32),
-        ("llm_attn_scale", C.c_float), ("llm_window", C.c_int32),
+        ("llm_attn_scale", C.c_float), ("llm_window", C.c_int32), ("proj_act", C.c_int32),
     ]
 
 

@@ -350,6 +350,13 @@ def _check_supported(cls, get) -> None:
             raise ValueError("text_config.sliding_window is not built (full causal attention only)")
 
 
+# projector_act -> uvx_config_t.proj_act (include/uvx.h UVX_PROJ_*); the names are transformers' ACT2FN keys whose modules are ONE fused
+# torch op (one rounding of the result in bf16, which is what the kernel does): nn.SiLU ("swish" is the same class), F.gelu exact and
+# tanh-approximated, nn.ReLU.  ("gelu_new" is the same tanh formula evaluated op by op in the activation dtype - a different rounding
+# sequence in bf16 - and is left out rather than approximated.)
+PROJECTOR_ACTS = {"swiglu": 0, "silu": 1, "swish": 1, "gelu_pytorch_tanh": 2, "gelu": 3, "relu": 4}
+
+
 class UltravoxConfig:
     """Same constructor arguments and attributes as the reference's UltravoxConfig."""
 
@@ -380,8 +387,11 @@ class UltravoxConfig:
         self.vocab_size = self.text_config.vocab_size
         self.initializer_range = self.text_config.initializer_range
         self.torch_dtype = torch_dtype
-        if projector_act != "swiglu":
-            raise ValueError("only projector_act='swiglu' (the reference default, ultravox_config.py:126) is built")
+        # UltravoxProjector: transformers.activations.get_activation(projector_act) (ultravox_model.py:754); "swiglu" (the default, registered
+        # by the reference at :742) halves the width, every other activation keeps it (:755)
+        if projector_act not in PROJECTOR_ACTS:
+            raise ValueError(f"projector_act={projector_act!r} is not built: {sorted(PROJECTOR_ACTS)} are (the reference default is 'swiglu', "
+                             "ultravox_config.py:126)")
         # LoRA (apply_lora, ultravox_model.py:690-709): rank-r adapters on q_proj + k_proj (the default target_modules that
         # exist in Whisper / Llama) of the encoder (the release configs: r = 8) and / or the LLM
         for name, lc in (("audio", self.audio_model_lora_config), ("text", self.text_model_lora_config)):
@@ -400,6 +410,11 @@ class UltravoxConfig:
             if hit != {"q_proj", "k_proj"} or other:
                 raise ValueError(f"{name}_model_lora_config.target_modules = {tm}: only the default q_proj + k_proj adaptation is built")
         self.extra = kwargs
+
+    @property
+    def projector_mid_dim(self) -> int:
+        """dim_mid of UltravoxProjector (ultravox_model.py:753-755): hidden_size // 2 behind SwiGLU, hidden_size otherwise."""
+        return self.hidden_size // 2 if self.projector_act == "swiglu" else self.hidden_size
 
     def to_dict(self) -> Dict[str, Any]:
         d = {k: v for k, v in self.__dict__.items() if k not in ("text_config", "audio_config", "extra")}

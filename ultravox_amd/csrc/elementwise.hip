@@ -38,6 +38,38 @@ __device__ __forceinline__ void glu_act_grad(float g, float& a, float& da) {
   }
 }
 
+// Plain (un-gated) activations of the projector when config.projector_act is not "swiglu" (ultravox_model.py:754: transformers.activations
+// .get_activation): ACT 0 silu / swish, 1 gelu_new / gelu_pytorch_tanh, 2 gelu (exact), 3 relu.  One rounding of the f32 result, as the torch
+// module's output; the backward multiplies the incoming gradient with the exact derivative at the saved pre-activation.
+template <typename T, int ACT>
+__global__ void act_fwd_k(const T* __restrict__ in, T* __restrict__ out, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float v[8];
+  ld8<T>(in + i * 8, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = ACT == 3 ? fmaxf(v[k], 0.f) : glu_act<ACT == 3 ? 0 : ACT>(v[k]);
+  st8<T>(out + i * 8, v);
+}
+template <typename T, int ACT>
+__global__ void act_bwd_k(const T* __restrict__ dout, const T* __restrict__ in, T* __restrict__ din, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float x[8], g[8];
+  ld8<T>(in + i * 8, x);
+  ld8<T>(dout + i * 8, g);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (ACT == 3) g[k] = x[k] > 0.f ? g[k] : 0.f;
+    else {
+      float a, da;
+      glu_act_grad<ACT == 3 ? 0 : ACT>(x[k], a, da);
+      g[k] *= da;
+    }
+  }
+  st8<T>(din + i * 8, g);
+}
+
 template <typename T>
 __global__ void scale_k(T* __restrict__ x, long long n8, float s) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -681,6 +713,29 @@ int splitk_reduce_scatter(hipStream_t st, int dtype, const float* partial, int n
   if (cap <= 0) return UVX_OK;
   if (dtype == DT_BF16) hipLaunchKernelGGL(splitk_reduce_scatter_k<bf16_t>, dim3(cap), dim3(256), 0, st, partial, nsplit, cap, rows, n, (bf16_t*)dst, D);
   else hipLaunchKernelGGL(splitk_reduce_scatter_k<float>, dim3(cap), dim3(256), 0, st, partial, nsplit, cap, rows, n, (float*)dst, D);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int act_fwd(hipStream_t st, int dtype, const void* in, void* out, long long n, int act) {
+  UVX_CHECK(n % 8 == 0, UVX_ERR_SHAPE, "act_fwd: element count must be a multiple of 8");
+  UVX_CHECK(act >= 0 && act <= 3, UVX_ERR_INVALID, "act_fwd: unknown activation %d", act);
+  if (n == 0) return UVX_OK;
+#define L(T, A) hipLaunchKernelGGL((act_fwd_k<T, A>), dim3(grid1d(n / 8, 256)), dim3(256), 0, st, (const T*)in, (T*)out, n / 8)
+  if (dtype == DT_BF16) { if (act == 0) L(bf16_t, 0); else if (act == 1) L(bf16_t, 1); else if (act == 2) L(bf16_t, 2); else L(bf16_t, 3); }
+  else { if (act == 0) L(float, 0); else if (act == 1) L(float, 1); else if (act == 2) L(float, 2); else L(float, 3); }
+#undef L
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+int act_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, long long n, int act) {
+  UVX_CHECK(n % 8 == 0, UVX_ERR_SHAPE, "act_bwd: element count must be a multiple of 8");
+  UVX_CHECK(act >= 0 && act <= 3, UVX_ERR_INVALID, "act_bwd: unknown activation %d", act);
+  if (n == 0) return UVX_OK;
+#define L(T, A) hipLaunchKernelGGL((act_bwd_k<T, A>), dim3(grid1d(n / 8, 256)), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)din, n / 8)
+  if (dtype == DT_BF16) { if (act == 0) L(bf16_t, 0); else if (act == 1) L(bf16_t, 1); else if (act == 2) L(bf16_t, 2); else L(bf16_t, 3); }
+  else { if (act == 0) L(float, 0); else if (act == 1) L(float, 1); else if (act == 2) L(float, 2); else L(float, 3); }
+#undef L
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

@@ -145,6 +145,9 @@ int cast_f32_to(hipStream_t st, int dtype, const float* in, void* out, long long
 int fill_zero(hipStream_t st, void* p, long long bytes);
 // encoder LoRA training: GELU as a separate pass on the stashed pre-activation, its exact-derivative backward,
 // LayerNorm backward for a frozen affine (dx only, + optional residual)
+// un-gated activation y = act(x) and its backward (the projector with projector_act != "swiglu"): act 0 silu, 1 tanh-GELU, 2 exact GELU, 3 relu
+int act_fwd(hipStream_t st, int dtype, const void* in, void* out, long long n, int act);
+int act_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, long long n, int act);
 int gelu_fwd(hipStream_t st, int dtype, const void* pre, void* out, long long n);
 int gelu_bwd(hipStream_t st, int dtype, const void* dout, const void* pre, void* din, long long n);
 int layernorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w, const void* dx_add, void* dx,

@@ -150,7 +150,7 @@ ProjWs proj_carve(Arena& a, const uvx_config_t& c, int B, int Te) {
   w.Rp = rup(w.R, 64);
   w.C8 = c.enc_d * c.stack_factor;
   w.H = c.proj_hidden;
-  w.Hh = c.proj_hidden / 2;
+  w.Hh = c.proj_act == UVX_PROJ_SWIGLU ? c.proj_hidden / 2 : c.proj_hidden;     // SwiGLU halves the width, a plain activation keeps it
   w.D = c.llm_d;
   w.stacked = a.take((size_t)w.R * w.C8 * es);
   w.xn = a.take((size_t)w.R * w.C8 * es);
@@ -698,7 +698,9 @@ extern "C" int32_t uvx_projector_fwd(void* stream, const uvx_config_t* cfg, cons
     return g;
   };
   RC(gemm(st, dt, psk(lin(s.xn, w->w1, s.h1, s.R, s.H, s.C8))));            // linear_1 (:793)
-  RC(swiglu_fwd(st, dt, s.h1, s.a, s.R, s.Hh, /*gate_first=*/0));           // SwiGLU (:739-742, :795)
+  UVX_CHECK(c.proj_act >= UVX_PROJ_SWIGLU && c.proj_act <= UVX_PROJ_RELU, UVX_ERR_INVALID, "projector: unknown proj_act %d", c.proj_act);
+  if (c.proj_act == UVX_PROJ_SWIGLU) RC(swiglu_fwd(st, dt, s.h1, s.a, s.R, s.Hh, /*gate_first=*/0));           // SwiGLU (:739-742, :795)
+  else RC(act_fwd(st, dt, s.h1, s.a, (long long)s.R * s.H, c.proj_act - 1));                                   // ACT2FN[projector_act] (:754, :795)
   if (c.proj_ln_mid) {
     RC(rmsnorm_fwd(st, dt, s.a, w->ln_mid, s.an, nullptr, s.R, s.Hh, c.proj_eps));  // ln_mid (:796)
     RC(gemm(st, dt, psk(lin(s.an, w->w2, out, s.R, s.D, s.Hh))));                   // linear_2 (:798)
@@ -741,7 +743,8 @@ extern "C" int32_t uvx_projector_bwd(void* stream, const uvx_config_t* cfg, cons
   RC(gemm(st, dt, lin(dy, s.w2T, s.d_an, s.R, s.Hh, s.D)));
   if (c.proj_ln_mid)
     RC(rmsnorm_bwd(st, dt, s.d_an, s.a, w->ln_mid, nullptr, s.d_a, gr->ln_mid, s.R, s.Hh, c.proj_eps));
-  RC(swiglu_bwd(st, dt, s.d_a, s.h1, s.d_h1, s.R, s.Hh, 0));
+  if (c.proj_act == UVX_PROJ_SWIGLU) RC(swiglu_bwd(st, dt, s.d_a, s.h1, s.d_h1, s.R, s.Hh, 0));
+  else RC(act_bwd(st, dt, s.d_a, s.h1, s.d_h1, (long long)s.R * s.H, c.proj_act - 1));
   // linear_1: dW1[H, C8] = d_h1^T . xn ; d_xn = d_h1 . W1 (only needed for the ln_pre weight gradient)
   RC(transpose2d(st, dt, s.d_h1, s.dh1T, s.R, s.H, s.H, s.Rp, 1, 0, 0));
   RC(transpose2d(st, dt, s.xn, s.xnT, s.R, s.C8, s.C8, s.Rp, 1, 0, 0));

@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .config import LossConfig, LossFunction, UltravoxConfig
+from .config import PROJECTOR_ACTS, LossConfig, LossFunction, UltravoxConfig
 from .weights import (LORA_TARGETS, init_lora_state_dict, llm_lora_key, lora_key, pack_encoder, pack_llm, pack_wav2vec2,
                       unpack_encoder, unpack_llm,
                       random_state_dict)
@@ -267,6 +267,7 @@ class UltravoxModel:
         c.enc_block = cfg.audio_latency_block_size or 0
         c.ln_eps = a.layer_norm_eps
         c.stack_factor, c.proj_hidden, c.proj_ln_mid, c.proj_eps = cfg.stack_factor, cfg.hidden_size, int(cfg.projector_ln_mid), 1e-6
+        c.proj_act = PROJECTOR_ACTS[cfg.projector_act]      # UVX_PROJ_* (include/uvx.h): SwiGLU or a plain ACT2FN activation
         c.llm_layers, c.llm_d, c.llm_heads, c.llm_kv_heads = t.num_hidden_layers, t.hidden_size, t.num_attention_heads, t.num_key_value_heads
         c.llm_head_dim, c.llm_inter, c.vocab, c.rms_eps = t.head_dim, t.intermediate_size, t.vocab_size, t.rms_norm_eps
         c.llm_flavor = 2 if t.is_gemma3 else (1 if t.is_gemma else 0)      # UVX_LLM_GEMMA3 / UVX_LLM_GEMMA / UVX_LLM_LLAMA (include/uvx.h)

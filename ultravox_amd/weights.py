@@ -119,9 +119,10 @@ def _random_rest(sd, cfg, rn, near_one, device, dtype):
     dim_in, H, D = d * cfg.stack_factor, cfg.hidden_size, t.hidden_size
     sd[P + "ln_pre.weight"] = torch.full((dim_in,), cfg.norm_init, device=device, dtype=dtype)
     sd[P + "linear_1.weight"] = rn(H, dim_in, s=1.0 / math.sqrt(dim_in))
-    sd[P + "linear_2.weight"] = rn(D, H // 2, s=1.0 / math.sqrt(H // 2))
+    mid = cfg.projector_mid_dim                  # H // 2 behind SwiGLU, H behind a plain activation (ultravox_model.py:753-755)
+    sd[P + "linear_2.weight"] = rn(D, mid, s=1.0 / math.sqrt(mid))
     if cfg.projector_ln_mid:
-        sd[P + "ln_mid.weight"] = torch.full((H // 2,), cfg.norm_init, device=device, dtype=dtype)
+        sd[P + "ln_mid.weight"] = torch.full((mid,), cfg.norm_init, device=device, dtype=dtype)
     else:
         sd[P + "ln_post.weight"] = torch.full((D,), cfg.norm_init, device=device, dtype=dtype)
 
