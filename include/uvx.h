@@ -211,8 +211,9 @@ int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const uvx_encoder
                         const uvx_encoder_lora_grads_t* grads, void* workspace, size_t ws_bytes);
 
 /* Alt audio tower (BASELINE.json config 5): [3P] transformers Wav2Vec2Model.forward, the AutoModel branch of
- * UltravoxModel._create_audio_tower (ultravox_model.py:460-467, :476-485), for the facebook/wav2vec2-large-960h family
- * (GroupNorm after the first conv layer, bias-free convs, post-LN encoder).  Frozen tower: forward only.
+ * UltravoxModel._create_audio_tower (ultravox_model.py:460-467, :476-485): the facebook/wav2vec2-large-960h family (GroupNorm after the first
+ * conv layer, bias-free convs, post-LN encoder) and - round 5 - the layer-norm family (facebook/wav2vec2-large-lv60 / -960h-lv60-self:
+ * LayerNorm after every conv layer, conv biases, pre-LN "stable" encoder).  Frozen tower: forward only.
  * input_values [B, L] (f32 if values_is_f32 else cfg dtype): the zero-mean / unit-variance waveform of the `input_values`
  * fallback (ultravox_processing.py:308); out [B, frames, d] with frames = uvx_wav2vec2_frames(cfg, L).  No attention mask
  * (group-norm wav2vec2 models are used without one).
@@ -227,6 +228,11 @@ typedef struct {
   int32_t d, heads, ffn, layers;
   int32_t pos_k, pos_groups;
   float ln_eps;
+  /* round 5: the layer-norm ("-lv60") family next to the group-norm one.  feat_norm_layer = Wav2Vec2Config.feat_extract_norm == "layer": a
+   * LayerNorm over the channels after EVERY conv layer (conv_ln_w / conv_ln_b) instead of the GroupNorm after the first; conv_bias: the conv
+   * layers carry a bias (conv_b); stable_ln = do_stable_layer_norm: Wav2Vec2EncoderStableLayerNorm - pre-LN layers (layers.N.layer_norm in
+   * front of the attention, final_layer_norm in front of the feed-forward) and encoder.layer_norm AFTER the last layer instead of before the first. */
+  int32_t feat_norm_layer, conv_bias, stable_ln;
 } uvx_w2v_config_t;
 typedef struct {
   const void *conv0_w, *gn_w, *gn_b;
@@ -235,6 +241,8 @@ typedef struct {
   const void *pos_w, *pos_b;
   const void *ln_w, *ln_b;
   const uvx_enc_layer_t* layers; /* HOST array [layers] */
+  const void* conv_b[8];                       /* conv_layers.i.conv.bias [C] (conv_bias), else NULL */
+  const void *conv_ln_w[8], *conv_ln_b[8];     /* conv_layers.i.layer_norm.{weight,bias} [C] (feat_norm_layer), else NULL */
 } uvx_w2v_weights_t;
 int32_t uvx_wav2vec2_frames(const uvx_w2v_config_t* cfg, int32_t L); /* [3P] _get_feat_extract_output_lengths; -1 if too short */
 size_t uvx_wav2vec2_ws_bytes(const uvx_w2v_config_t* cfg, int32_t B, int32_t L);

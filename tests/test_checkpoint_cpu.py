@@ -166,9 +166,15 @@ def test_configs_outside_the_built_arithmetic_are_refused_not_run_as_llama():
     w = UltravoxConfig(audio_config={"model_type": "wav2vec2", "hidden_size": 64, "num_hidden_layers": 2, "num_attention_heads": 2,
                                      "intermediate_size": 128, "conv_dim": [64] * 7}).audio_config
     assert w.is_wav2vec2 and (w.d_model, w.encoder_layers, w.encoder_ffn_dim) == (64, 2, 128) and w.feat_extract_output_length(16000) == 49
-    for bad in ({"feat_extract_norm": "layer"}, {"do_stable_layer_norm": True}, {"conv_bias": True}):
-        with pytest.raises(ValueError, match="960h"):
-            UltravoxConfig(audio_config={"model_type": "wav2vec2", "hidden_size": 64, **bad})
+    # round 5: the layer-norm (-lv60) family is built too - the three Wav2Vec2Config switches are read, singly and together
+    for ok in ({"feat_extract_norm": "layer"}, {"do_stable_layer_norm": True}, {"conv_bias": True},
+               {"feat_extract_norm": "layer", "do_stable_layer_norm": True, "conv_bias": True}):
+        v = UltravoxConfig(audio_config={"model_type": "wav2vec2", "hidden_size": 64, **ok}).audio_config
+        assert all(getattr(v, k) == val for k, val in ok.items())
+    lv = UltravoxConfig(audio_model_id="facebook/wav2vec2-large-960h-lv60-self").audio_config
+    assert (lv.feat_extract_norm, lv.conv_bias, lv.do_stable_layer_norm, lv.d_model, lv.encoder_layers) == ("layer", True, True, 1024, 24)
+    with pytest.raises(ValueError, match="feat_extract_norm"):
+        UltravoxConfig(audio_config={"model_type": "wav2vec2", "hidden_size": 64, "feat_extract_norm": "batch"})
     with pytest.raises(ValueError, match="hidden_act"):
         UltravoxConfig(text_config={**ok_text, "model_type": "gemma", "hidden_act": "silu"})
     # apply_lora with r = 0 + unfreeze_layers (ultravox_model.py:694-703) is not built: refused, not silently frozen

@@ -500,15 +500,20 @@ W2V_TINY = {"model_type": "wav2vec2", "hidden_size": 64, "num_hidden_layers": 2,
             "conv_dim": [64] * 7, "num_conv_pos_embeddings": 16, "num_conv_pos_embedding_groups": 4}
 
 
-def test_wav2vec2_tower_matches_hf_model():
-    """BASELINE config 5's tower.  [3P] check: the restated Wav2Vec2Model.forward (GroupNorm conv stem, feature projection,
-    weight-normed grouped positional conv, post-LN layers) == the installed HF Wav2Vec2Model on the same weights."""
+@pytest.mark.parametrize("norm,bias,stable", [("group", False, False), ("layer", True, True), ("layer", False, False), ("group", True, True)])
+def test_wav2vec2_tower_matches_hf_model(norm, bias, stable):
+    """BASELINE config 5's tower.  [3P] check: the restated Wav2Vec2Model.forward (conv stem, feature projection, weight-normed grouped
+    positional conv, encoder layers) == the installed HF Wav2Vec2Model on the same weights - the group-norm family (wav2vec2-large-960h:
+    GroupNorm after the first conv, bias-free convs, post-LN layers), the layer-norm family (round 5; the -lv60 checkpoints: LayerNorm after
+    every conv, conv biases, pre-LN "stable" layers with the encoder's layer_norm at the end) and the two mixed settings of the three
+    independent Wav2Vec2Config switches."""
     from transformers import Wav2Vec2Config, Wav2Vec2Model
-    cfg = UltravoxConfig(audio_config=W2V_TINY, text_config=TINY["text_config"], hidden_size=64)
+    cfg = UltravoxConfig(audio_config={**W2V_TINY, "feat_extract_norm": norm, "conv_bias": bias, "do_stable_layer_norm": stable},
+                         text_config=TINY["text_config"], hidden_size=64)
     a = cfg.audio_config
     hf = Wav2Vec2Model(Wav2Vec2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
                                       conv_dim=[64] * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4,
-                                      feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False,
+                                      feat_extract_norm=norm, conv_bias=bias, do_stable_layer_norm=stable,
                                       attn_implementation="eager")).eval()
     sd = random_state_dict(cfg, seed=2)
     missing, unexpected = hf.load_state_dict({k[len("audio_tower."):]: v for k, v in sd.items() if k.startswith("audio_tower.")}, strict=False)

@@ -42,6 +42,43 @@ def test_wav2vec2_tower_matches_oracle(dtype, tol):
         model.audio_tower_forward(x[:, :300].to(DEV), None)
 
 
+@pytest.mark.parametrize("norm,bias,stable", [("layer", True, True), ("layer", False, False), ("group", True, True)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
+def test_wav2vec2_layer_norm_family_matches_oracle(dtype, tol, norm, bias, stable):
+    """Round 5: the layer-norm family of Wav2Vec2Model (the -lv60 checkpoints: feat_extract_norm "layer" = a LayerNorm over the channels after
+    every conv layer, conv biases, do_stable_layer_norm = pre-LN layers + encoder.layer_norm at the end) and the mixed settings of the three
+    independent switches, against the oracle's restatement (pinned to the installed HF Wav2Vec2Model for the same four settings,
+    tests/test_oracle_pinning.py); and a whole adapter-train step with the lv60 tower in front of the LLM."""
+    from oracle.reference_cpu import OracleModel, synthetic_batch, wav2vec2_encoder_ref, wav2vec2_normalize_ref
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = _cfg(audio={**W2V_SMALL, "feat_extract_norm": norm, "conv_bias": bias, "do_stable_layer_norm": stable})
+    sd = {k: v.to(dtype) for k, v in random_state_dict(cfg, seed=8).items()}
+    assert ("audio_tower.feature_extractor.conv_layers.3.layer_norm.weight" in sd) == (norm == "layer")
+    assert ("audio_tower.feature_extractor.conv_layers.3.conv.bias" in sd) == bias
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    torch.manual_seed(3)
+    x = wav2vec2_normalize_ref(0.1 * torch.randn(3, 9000) + 0.01)
+    got = model.audio_tower_forward(x.to(DEV), None)
+    with torch.no_grad():
+        want = wav2vec2_encoder_ref({k: v.float() for k, v in sd.items()}, cfg, x.to(dtype).float())
+    assert got.shape == want.shape
+    err = stage_errors(got, want)
+    assert err["rel_l2"] < tol, err
+    if not (norm == "layer" and stable):
+        return
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    b = synthetic_batch(cfg, 2, 2.0, n_text=24, audio_start=5, n_supervised=8)
+    b["audio_values"] = wav2vec2_normalize_ref(b.pop("pcm")).to(dtype)
+    ref, grads, _ = oracle.train_step({**b, "audio_values": b["audio_values"].float()})
+    model.train()
+    loss = model.forward_backward(**{k: v.to(DEV) for k, v in b.items()})
+    assert abs(loss.item() - ref["loss"].item()) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(ref["loss"].item())
+    mine = model.projector_grads()
+    for k, g in grads.items():
+        assert rel_l2(mine[k], g) < (2e-3 if dtype == torch.float32 else 8e-2), k
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_wav2vec2_llama_train_step_matches_oracle(dtype):
     """The alt tower in front of the (Llama) LLM: one adapter-train step, loss + projector gradients vs the oracle."""

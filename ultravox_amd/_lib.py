@@ -117,14 +117,16 @@ class W2vConfig(C.Structure):      # uvx_w2v_config_t
     _fields_ = [("dtype", C.c_int32), ("n_conv", C.c_int32), ("conv_dim", C.c_int32),
                 ("conv_kernel", C.c_int32 * 8), ("conv_stride", C.c_int32 * 8),
                 ("d", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32), ("layers", C.c_int32),
-                ("pos_k", C.c_int32), ("pos_groups", C.c_int32), ("ln_eps", C.c_float)]
+                ("pos_k", C.c_int32), ("pos_groups", C.c_int32), ("ln_eps", C.c_float),
+                ("feat_norm_layer", C.c_int32), ("conv_bias", C.c_int32), ("stable_ln", C.c_int32)]
 
 
 class W2vWeights(C.Structure):     # uvx_w2v_weights_t
     _fields_ = [("conv0_w", C.c_void_p), ("gn_w", C.c_void_p), ("gn_b", C.c_void_p), ("conv_w", C.c_void_p * 8),
                 ("fp_ln_w", C.c_void_p), ("fp_ln_b", C.c_void_p), ("fp_w", C.c_void_p), ("fp_b", C.c_void_p),
                 ("pos_w", C.c_void_p), ("pos_b", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
-                ("layers", C.POINTER(EncLayer))]
+                ("layers", C.POINTER(EncLayer)),
+                ("conv_b", C.c_void_p * 8), ("conv_ln_w", C.c_void_p * 8), ("conv_ln_b", C.c_void_p * 8)]
 
 
 class LoraProj(C.Structure):

@@ -58,7 +58,9 @@ class AudioConfig:
     # model_type "wav2vec2" (BASELINE.json config 5, the AutoModel branch of _create_audio_tower, ultravox_model.py:460-467,
     # :476-485): d_model / encoder_layers / encoder_attention_heads / encoder_ffn_dim carry Wav2Vec2Config's hidden_size /
     # num_hidden_layers / num_attention_heads / intermediate_size; the fields below are Wav2Vec2Config's own names.
-    # Built: the wav2vec2-large-960h family (GroupNorm on the first conv layer, bias-free convs, post-LN encoder).
+    # Built: the wav2vec2-base / -large-960h family (GroupNorm on the first conv layer, bias-free convs, post-LN encoder) and - round 5 -
+    # the layer-norm family (-large-lv60, -large-960h-lv60-self: feat_extract_norm "layer", conv_bias, do_stable_layer_norm); the
+    # three switches are independent, as in Wav2Vec2Config.
     conv_dim: Optional[List[int]] = None
     conv_kernel: Optional[List[int]] = None
     conv_stride: Optional[List[int]] = None
@@ -77,9 +79,9 @@ class AudioConfig:
             self.conv_stride = list(self.conv_stride or (5, 2, 2, 2, 2, 2, 2))
             if not (len(self.conv_dim) == len(self.conv_kernel) == len(self.conv_stride)):
                 raise ValueError("audio_config: conv_dim / conv_kernel / conv_stride must have one entry per conv layer")
-            if self.feat_extract_norm != "group" or self.conv_bias or self.do_stable_layer_norm:
-                raise ValueError("audio_config: only the wav2vec2-large-960h family is built (feat_extract_norm='group', "
-                                 "conv_bias=False, do_stable_layer_norm=False); the -lv60 layer-norm variants are not")
+            if self.feat_extract_norm not in ("group", "layer"):
+                raise ValueError(f"audio_config.feat_extract_norm {self.feat_extract_norm!r}: 'group' (wav2vec2-base / -large-960h) and "
+                                 "'layer' (the -lv60 family) are what Wav2Vec2Config knows")
             if len(set(self.conv_dim)) != 1 or self.conv_dim[0] % 64 or self.d_model % self.num_conv_pos_embedding_groups:
                 raise ValueError("audio_config: conv_dim must be one multiple of 64 for all layers; hidden size divisible by the "
                                  "positional-conv groups")
@@ -213,6 +215,12 @@ AUDIO_PRESETS: Dict[str, Dict[str, Any]] = {
     # conv feature encoder 512 x 7, kernels (10,3,3,3,3,2,2), strides (5,2,2,2,2,2,2) = 320x
     "facebook/wav2vec2-large-960h": dict(model_type="wav2vec2", d_model=1024, encoder_layers=24, encoder_attention_heads=16,
                                          encoder_ffn_dim=4096, layer_norm_eps=1e-5),
+    "facebook/wav2vec2-large-960h-lv60-self": dict(model_type="wav2vec2", d_model=1024, encoder_layers=24, encoder_attention_heads=16,
+                                                   encoder_ffn_dim=4096, layer_norm_eps=1e-5, feat_extract_norm="layer", conv_bias=True,
+                                                   do_stable_layer_norm=True),
+    "facebook/wav2vec2-large-lv60": dict(model_type="wav2vec2", d_model=1024, encoder_layers=24, encoder_attention_heads=16,
+                                         encoder_ffn_dim=4096, layer_norm_eps=1e-5, feat_extract_norm="layer", conv_bias=True,
+                                         do_stable_layer_norm=True),
     "facebook/wav2vec2-base-960h": dict(model_type="wav2vec2", d_model=768, encoder_layers=12, encoder_attention_heads=12,
                                         encoder_ffn_dim=3072, layer_norm_eps=1e-5),
     "openai/whisper-tiny": dict(d_model=384, encoder_layers=4, encoder_attention_heads=6, encoder_ffn_dim=1536, num_mel_bins=80),

@@ -168,7 +168,7 @@ inline unsigned g1(long long n, int b) { return (unsigned)((n + b - 1) / b); }
 struct W2vWs {
   int T[9];          // frames after conv layer i
   int Tn, Tp, M, nchunk;
-  void *im2col, *bufA, *bufB, *x, *n, *qkv, *vt, *o, *f, *xg;
+  void *im2col, *bufA, *bufB, *x, *n, *qkv, *vt, *o, *o2, *f, *xg;
   float *part, *stat, *acc;
 };
 
@@ -201,6 +201,7 @@ W2vWs carve(Arena& a, const uvx_w2v_config_t& c, int B, int L) {
   w.qkv = a.take((size_t)w.M * 3 * d * es);
   w.vt = a.take((size_t)B * c.heads * dh * w.Tp * es);
   w.o = a.take((size_t)w.M * d * es);
+  w.o2 = c.stable_ln ? a.take((size_t)w.M * d * es) : nullptr;      // second residual-stream buffer of the pre-LN layers
   w.f = a.take((size_t)w.M * c.ffn * es);
   w.xg = a.take((size_t)B * c.pos_groups * (w.Tn + c.pos_k) * (d / c.pos_groups) * es);
   w.acc = (float*)a.take(sizeof(float) * (size_t)w.M * d);
@@ -213,6 +214,7 @@ int check(const uvx_w2v_config_t* c) {
   UVX_CHECK(c->n_conv >= 2 && c->n_conv <= 8, UVX_ERR_SHAPE, "wav2vec2: %d conv layers (2..8)", c->n_conv);
   UVX_CHECK(c->conv_dim % 64 == 0 && c->conv_dim <= 8192, UVX_ERR_SHAPE, "wav2vec2: conv_dim %d must be a multiple of 64", c->conv_dim);
   UVX_CHECK(c->conv_kernel[0] <= K0P, UVX_ERR_SHAPE, "wav2vec2: first conv kernel %d > %d", c->conv_kernel[0], K0P);
+  UVX_CHECK(!c->feat_norm_layer || c->conv_dim % 8 == 0, UVX_ERR_SHAPE, "wav2vec2: conv_dim %d", c->conv_dim);
   UVX_CHECK(c->d % c->heads == 0 && c->d % c->pos_groups == 0 && (c->d / c->pos_groups) % 8 == 0 &&
                 (c->pos_k * (c->d / c->pos_groups)) % 64 == 0,
             UVX_ERR_SHAPE, "wav2vec2: hidden %d / heads %d / positional-conv groups %d, kernel %d unsupported", c->d, c->heads,
@@ -241,6 +243,11 @@ extern "C" int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, c
   UVX_CHECK(w && w->layers && input_values && out && workspace, UVX_ERR_INVALID, "wav2vec2_fwd: null argument");
   const uvx_w2v_config_t& c = *cfg;
   hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < c.n_conv; ++i) {
+    UVX_CHECK(!c.conv_bias || w->conv_b[i], UVX_ERR_INVALID, "wav2vec2_fwd: conv_bias is set but conv layer %d has no bias", i);
+    UVX_CHECK(!c.feat_norm_layer || (w->conv_ln_w[i] && w->conv_ln_b[i]), UVX_ERR_INVALID, "wav2vec2_fwd: conv layer %d has no layer norm", i);
+  }
+  UVX_CHECK(c.feat_norm_layer || (w->gn_w && w->gn_b), UVX_ERR_INVALID, "wav2vec2_fwd: the first conv layer's GroupNorm weights are missing");
   if (B == 0) return UVX_OK;
   Arena a(workspace, ws_bytes);
   W2vWs s = carve(a, c, B, L);
@@ -259,11 +266,17 @@ extern "C" int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, c
       hipLaunchKernelGGL((w2v_im2col0_k<float, float>), dim3(g1(n, 256)), dim3(256), 0, st, (const float*)input_values, (float*)s.im2col, rows, s.T[0], L, c.conv_kernel[0], c.conv_stride[0]);
     }
     UVX_LAUNCH_CHECK();
-    RC(gemm(st, dt, lin(s.im2col, w->conv0_w, s.bufA, (int)rows, C, K0P)));
-    // GroupNorm over time (per clip and channel) + GELU
+    {
+      GemmDesc g0 = lin(s.im2col, w->conv0_w, s.bufA, (int)rows, C, K0P);
+      g0.bias = c.conv_bias ? w->conv_b[0] : nullptr;
+      RC(gemm(st, dt, g0));
+    }
     const dim3 gp(s.nchunk, B);
     const long long n8 = rows * C / 8;
-    if (dt == DT_BF16) {
+    if (c.feat_norm_layer) {      // Wav2Vec2LayerNormConvLayer: conv -> LayerNorm over the channels -> GELU, each a rounded tensor
+      RC(layernorm_fwd(st, dt, s.bufA, w->conv_ln_w[0], w->conv_ln_b[0], s.bufA, (int)rows, C, 1e-5f));
+      RC(gelu_fwd(st, dt, s.bufA, s.bufA, rows * C));
+    } else if (dt == DT_BF16) {      // GroupNorm over time (per clip and channel) + GELU
       hipLaunchKernelGGL(w2v_gn_partial_k<bf16_t>, gp, dim3(C / 8), 0, st, (const bf16_t*)s.bufA, s.part, s.T[0], C, s.nchunk);
       hipLaunchKernelGGL(w2v_gn_final_k, dim3(g1(C, 128), B), dim3(128), 0, st, s.part, s.stat, s.T[0], C, s.nchunk, 1e-5f);
       hipLaunchKernelGGL(w2v_gn_gelu_k<bf16_t>, dim3(g1(n8, 256)), dim3(256), 0, st, (bf16_t*)s.bufA, s.stat, (const bf16_t*)w->gn_w, (const bf16_t*)w->gn_b, n8, s.T[0], C);
@@ -280,9 +293,14 @@ extern "C" int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, c
     UVX_CHECK(w->conv_w[i] != nullptr, UVX_ERR_INVALID, "wav2vec2_fwd: conv layer %d has no weights", i);
     const int k = c.conv_kernel[i], sd = c.conv_stride[i];
     GemmDesc g = lin(cur, w->conv_w[i], nxt, s.T[i], C, k * C);
-    g.lda = sd * C; g.act = 1; g.batch = B;
+    g.lda = sd * C; g.act = c.feat_norm_layer ? 0 : 1; g.batch = B;
     g.sA = (long long)s.T[i - 1] * C; g.sC = (long long)s.T[i] * C;
+    g.bias = c.conv_bias ? w->conv_b[i] : nullptr;
     RC(gemm(st, dt, g));
+    if (c.feat_norm_layer) {
+      RC(layernorm_fwd(st, dt, nxt, w->conv_ln_w[i], w->conv_ln_b[i], nxt, B * s.T[i], C, 1e-5f));
+      RC(gelu_fwd(st, dt, nxt, nxt, (long long)B * s.T[i] * C));
+    }
     void* t = cur; cur = nxt; nxt = t;
   }
   // ---- feature projection: LayerNorm(C) -> Linear(C, d) ----
@@ -309,6 +327,45 @@ extern "C" int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, c
     if (dt == DT_BF16) hipLaunchKernelGGL(w2v_pos_finish_k<bf16_t>, dim3(g1(m8, 256)), dim3(256), 0, st, (bf16_t*)s.x, s.acc, (const bf16_t*)w->pos_b, m8, d);
     else hipLaunchKernelGGL(w2v_pos_finish_k<float>, dim3(g1(m8, 256)), dim3(256), 0, st, (float*)s.x, s.acc, (const float*)w->pos_b, m8, d);
     UVX_LAUNCH_CHECK();
+  }
+  if (c.stable_ln) {
+    // ---- encoder, do_stable_layer_norm = True ([3P] Wav2Vec2EncoderStableLayerNorm / ...EncoderLayerStableLayerNorm): per layer
+    //      h = h + attention(layer_norm(h));  h = h + feed_forward(final_layer_norm(h));  encoder.layer_norm after the last layer ----
+    void* h = s.x;       // the residual stream alternates between s.x and s.o2
+    void* h2 = s.o2;
+    for (int l = 0; l < c.layers; ++l) {
+      const uvx_enc_layer_t& Lw = w->layers[l];
+      RC(layernorm_fwd(st, dt, h, Lw.ln1_w, Lw.ln1_b, s.n, M, d, c.ln_eps));
+      {
+        GemmDesc g = lin(s.n, Lw.wqkv, s.qkv, M, 3 * d, d);
+        g.bias = Lw.bqkv;
+        RC(gemm(st, dt, g));
+      }
+      if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(s.qkv, 2 * d, dt), s.vt, B, Tn, s.Tp, c.heads, dh, 3 * d));
+      AttnDesc ad;
+      ad.q = s.qkv; ad.k = at(s.qkv, d, dt); ad.v = at(s.qkv, 2 * d, dt); ad.vt = s.vt; ad.o = s.o;
+      ad.B = B; ad.T = Tn; ad.Tp = s.Tp; ad.Hq = c.heads; ad.Hkv = c.heads; ad.D = dh;
+      ad.ldq = ad.ldk = ad.ldv = 3 * d; ad.ldo = d; ad.causal = 0; ad.block = 0;
+      ad.scale = 1.0f;
+      RC(attention_fwd(st, dt, ad));
+      {
+        GemmDesc g = lin(s.o, Lw.wo, h2, M, d, d);
+        g.bias = Lw.bo; g.residual = h; g.ldr = d;
+        RC(gemm(st, dt, g));
+      }
+      RC(layernorm_fwd(st, dt, h2, Lw.ln2_w, Lw.ln2_b, s.n, M, d, c.ln_eps));
+      {
+        GemmDesc g = lin(s.n, Lw.fc1_w, s.f, M, c.ffn, d);
+        g.bias = Lw.fc1_b; g.act = 1;
+        RC(gemm(st, dt, g));
+      }
+      {
+        GemmDesc g = lin(s.f, Lw.fc2_w, h, M, d, c.ffn);
+        g.bias = Lw.fc2_b; g.residual = h2; g.ldr = d;
+        RC(gemm(st, dt, g));
+      }
+    }
+    return layernorm_fwd(st, dt, h, w->ln_w, w->ln_b, out, M, d, c.ln_eps);
   }
   // ---- encoder (post-LN, do_stable_layer_norm = False) ----
   void* x = s.n;     // x alternates between s.n and s.x

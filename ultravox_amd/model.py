@@ -291,11 +291,13 @@ class UltravoxModel:
                 wc.conv_kernel[i], wc.conv_stride[i] = k, st
             wc.d, wc.heads, wc.ffn, wc.layers = a.d_model, a.encoder_attention_heads, a.encoder_ffn_dim, a.encoder_layers
             wc.pos_k, wc.pos_groups, wc.ln_eps = a.num_conv_pos_embeddings, a.num_conv_pos_embedding_groups, a.layer_norm_eps
+            wc.feat_norm_layer, wc.conv_bias, wc.stable_ln = int(a.feat_extract_norm == "layer"), int(a.conv_bias), int(a.do_stable_layer_norm)
             ww = _lib.W2vWeights()
             for n in ("conv0_w", "gn_w", "gn_b", "fp_ln_w", "fp_ln_b", "fp_w", "fp_b", "pos_w", "pos_b", "ln_w", "ln_b"):
-                setattr(ww, n, e[n].data_ptr())
-            for i, t_ in enumerate(e["conv_w"]):
-                ww.conv_w[i] = 0 if t_ is None else t_.data_ptr()
+                setattr(ww, n, 0 if e[n] is None else e[n].data_ptr())
+            for name in ("conv_w", "conv_b", "conv_ln_w", "conv_ln_b"):
+                for i, t_ in enumerate(e[name]):
+                    getattr(ww, name)[i] = 0 if t_ is None else t_.data_ptr()
             ww.layers = self._enc_layers
             self._w2v_cfg, self._w2v_w, self._ew = wc, ww, None
         else:

@@ -54,11 +54,15 @@ def _random_wav2vec2(sd, a, rn, near_one, P):
     """HF Wav2Vec2Model key names (wav2vec2-large-960h family: GroupNorm after the first conv, bias-free convs, post-LN)."""
     d, Cc = a.d_model, a.conv_dim[0]
     cin = 1
+    layer_norm = a.feat_extract_norm == "layer"          # LayerNorm after every conv layer (else: GroupNorm after the first)
     for i, k in enumerate(a.conv_kernel):
         sd[P + f"feature_extractor.conv_layers.{i}.conv.weight"] = rn(Cc, cin, k, s=1.6 / math.sqrt(cin * k))
+        if a.conv_bias:
+            sd[P + f"feature_extractor.conv_layers.{i}.conv.bias"] = rn(Cc, s=0.1)
+        if layer_norm or i == 0:
+            sd[P + f"feature_extractor.conv_layers.{i}.layer_norm.weight"] = near_one(Cc)
+            sd[P + f"feature_extractor.conv_layers.{i}.layer_norm.bias"] = rn(Cc)
         cin = Cc
-    sd[P + "feature_extractor.conv_layers.0.layer_norm.weight"] = near_one(Cc)
-    sd[P + "feature_extractor.conv_layers.0.layer_norm.bias"] = rn(Cc)
     sd[P + "feature_projection.layer_norm.weight"] = near_one(Cc)
     sd[P + "feature_projection.layer_norm.bias"] = rn(Cc)
     sd[P + "feature_projection.projection.weight"] = rn(d, Cc, s=1.0 / math.sqrt(Cc))
@@ -216,11 +220,12 @@ def init_lora_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32
         out[keyfn(i, pj, "A")] = A.to(dtype)
         out[keyfn(i, pj, "B")] = B.to(dtype)
 
-    ra = int(cfg.audio_model_lora_config.get("r", 0) or 0)
+    # (a config that went through merge_and_unload no longer carries the LoRA configs - ultravox_model.py:555-557 - and means r = 0)
+    ra = int((getattr(cfg, "audio_model_lora_config", None) or {}).get("r", 0) or 0)
     for i in range(a.encoder_layers if ra else 0):
         for pj in LORA_TARGETS:
             add(lora_key, i, pj, ra, a.d_model, a.d_model)
-    rt = int(cfg.text_model_lora_config.get("r", 0) or 0)
+    rt = int((getattr(cfg, "text_model_lora_config", None) or {}).get("r", 0) or 0)
     for i in range(t.num_hidden_layers if rt else 0):
         add(llm_lora_key, i, "q_proj", rt, t.hidden_size, t.num_attention_heads * t.head_dim)
         add(llm_lora_key, i, "k_proj", rt, t.hidden_size, t.num_key_value_heads * t.head_dim)
@@ -237,9 +242,18 @@ def pack_wav2vec2(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.")
     w0 = W("feature_extractor.conv_layers.0.conv.weight")                       # [C, 1, k0]
     conv0 = torch.zeros(Cc, 64, dtype=w0.dtype, device=w0.device)
     conv0[:, : w0.shape[-1]] = w0[:, 0, :]
-    out = {"conv0_w": cv(conv0), "gn_w": cv(W("feature_extractor.conv_layers.0.layer_norm.weight")),
-           "gn_b": cv(W("feature_extractor.conv_layers.0.layer_norm.bias")), "conv_w": [None]}
-    for i in range(1, len(a.conv_kernel)):
+    layer_norm = a.feat_extract_norm == "layer"
+    n_conv = len(a.conv_kernel)
+    out = {"conv0_w": cv(conv0), "conv_w": [None],
+           # group-norm family: the first conv layer's GroupNorm; layer-norm family: a LayerNorm per conv layer; biases where conv_bias
+           "gn_w": None if layer_norm else cv(W("feature_extractor.conv_layers.0.layer_norm.weight")),
+           "gn_b": None if layer_norm else cv(W("feature_extractor.conv_layers.0.layer_norm.bias")),
+           "conv_b": [cv(W(f"feature_extractor.conv_layers.{i}.conv.bias")) if a.conv_bias else None for i in range(n_conv)],
+           "conv_ln_w": [cv(W(f"feature_extractor.conv_layers.{i}.layer_norm.weight")) if layer_norm else None for i in range(n_conv)],
+           "conv_ln_b": [cv(W(f"feature_extractor.conv_layers.{i}.layer_norm.bias")) if layer_norm else None for i in range(n_conv)]}
+    if not a.conv_bias and any(prefix + f"feature_extractor.conv_layers.{i}.conv.bias" in sd for i in range(n_conv)):
+        raise ValueError("the checkpoint carries conv biases but audio_config.conv_bias is False")
+    for i in range(1, n_conv):
         w = W(f"feature_extractor.conv_layers.{i}.conv.weight")                  # [C, C, k] -> [C, k*C], column k*C + c
         out["conv_w"].append(cv(w.permute(0, 2, 1).reshape(Cc, -1)))
     out["fp_ln_w"], out["fp_ln_b"] = cv(W("feature_projection.layer_norm.weight")), cv(W("feature_projection.layer_norm.bias"))
