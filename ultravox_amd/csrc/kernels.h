@@ -163,6 +163,10 @@ int lora_up(hipStream_t st, int dtype, const void* Y, long long ldy, const void*
 // out = alpha * Y[M, r]^T . X[M, C]  as [r][C] or, transpose_out, [C][r]  (f32; scratch: lora_wgrad_scratch_floats)
 long long lora_wgrad_scratch_floats(long long M, int C, int r);
 int lora_transpose(hipStream_t st, int dtype, const void* in, void* out, int C, int r);   // [C, r] -> [r, C]
+int lora_transpose2(hipStream_t st, int dtype, const void* in0, void* out0, int C0, const void* in1, void* out1, int C1, int r);   // two of them, one launch
+// up to four lora_wgrad products over the same rows and rank with ONE reduce launch (bit-identical to separate lora_wgrad calls)
+struct LoraWgradItem { const void* X; long long ldx; const void* Y; long long ldy; float* out; int C; int transpose_out; float alpha; };
+int lora_wgrad_batch(hipStream_t st, int dtype, const LoraWgradItem* items, int n, long long M, int r, float* scratch, long long scratch_floats);
 int lora_wgrad(hipStream_t st, int dtype, const void* X, long long ldx, const void* Y, long long ldy, float* out, long long M,
                int C, int r, int transpose_out, float alpha, float* scratch);
 

@@ -213,6 +213,35 @@ __global__ void lora_wgrad_reduce_k(const float* __restrict__ partial, int nchun
   out[transpose_out ? (long long)c * r + j : (long long)j * C + c] = s * alpha;
 }
 
+// The reduces of several weight-gradient products in ONE launch (round 5): a layer's backward has four of them (d lora_A / d lora_B of q_proj and
+// k_proj), each summing ~47 chunk partials for 8 K outputs - 15 us of latency per launch, 96 launches = 1.45 ms of the recipe's step
+// (profiles/r05_kernel_stats_kl_lora8.txt).  blockIdx.y = which product; same fixed-order sum per output as lora_wgrad_reduce_k: bit-identical.
+struct WgradReduceBatch {
+  const float* partial[4]; float* out[4]; int C[4]; int transpose_out[4]; float alpha[4];
+  int nchunks, r;
+};
+__global__ void lora_wgrad_reduce_batch_k(WgradReduceBatch b) {
+  const int w = blockIdx.y, C = b.C[w];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.r * C) return;
+  const int j = i / C, c = i % C;
+  const float* partial = b.partial[w];
+  float s = 0.f;
+  for (int k = 0; k < b.nchunks; ++k) s += partial[((long long)k * b.r + j) * C + c];   // fixed order: deterministic
+  b.out[w][b.transpose_out[w] ? (long long)c * b.r + j : (long long)j * C + c] = s * b.alpha[w];
+}
+// two [C, r] -> [r, C] transposes (lora_B of q_proj and k_proj) in one launch: blockIdx.y = which
+template <typename T>
+__global__ void lora_transpose2_k(const T* __restrict__ in0, T* __restrict__ out0, int C0, const T* __restrict__ in1, T* __restrict__ out1, int C1, int r) {
+  const T* in = blockIdx.y ? in1 : in0;
+  T* out = blockIdx.y ? out1 : out0;
+  const int C = blockIdx.y ? C1 : C0;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= r * C) return;
+  const int j = i / C, c = i % C;
+  out[i] = in[(long long)c * r + j];
+}
+
 // out[j][c] = in[c][j]: lora_B [C, r] -> [r, C] once per use, so that every product reads its narrow operand row-wise
 template <typename T>
 __global__ void lora_transpose_k(const T* __restrict__ in, T* __restrict__ out, int C, int r) {
@@ -282,6 +311,53 @@ int lora_wgrad(hipStream_t st, int dtype, const void* X, long long ldx, const vo
     else hipLaunchKernelGGL(lora_wgrad_k<float>, grid, dim3(256), 0, st, (const float*)X, ldx, (const float*)Y, ldy, scratch, M, C, r, j0);
   }
   hipLaunchKernelGGL(lora_wgrad_reduce_k, dim3((r * C + 255) / 256), dim3(256), 0, st, scratch, nchunks, r, C, out, transpose_out, alpha);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+// n <= 4 weight-gradient products over the same M rows and rank: the partial kernels as in lora_wgrad, into consecutive regions of the scratch,
+// then one reduce launch for all of them.  Falls back to n separate lora_wgrad calls when the regions do not fit the scratch.
+int lora_wgrad_batch(hipStream_t st, int dtype, const LoraWgradItem* items, int n, long long M, int r, float* scratch, long long scratch_floats) {
+  UVX_CHECK(n >= 1 && n <= 4 && r > 0 && r <= RMAX, UVX_ERR_INVALID, "lora_wgrad_batch: n=%d r=%d", n, r);
+  const int nchunks = (int)((M + RCH - 1) / RCH);
+  long long need = 0;
+  int cmax = 0;
+  for (int i = 0; i < n; ++i) {
+    UVX_CHECK(items[i].C % 8 == 0 && items[i].ldx % 8 == 0 && items[i].ldy % 8 == 0, UVX_ERR_SHAPE, "lora_wgrad_batch: C=%d unsupported", items[i].C);
+    need += (long long)nchunks * r * items[i].C;
+    cmax = items[i].C > cmax ? items[i].C : cmax;
+  }
+  if (M == 0 || need > scratch_floats || n == 1) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = lora_wgrad(st, dtype, items[i].X, items[i].ldx, items[i].Y, items[i].ldy, items[i].out, M, items[i].C, r, items[i].transpose_out,
+                                items[i].alpha, scratch);
+      if (rc != UVX_OK) return rc;
+    }
+    return UVX_OK;
+  }
+  WgradReduceBatch b = {};
+  b.nchunks = nchunks; b.r = r;
+  float* region = scratch;
+  for (int i = 0; i < n; ++i) {
+    const LoraWgradItem& it = items[i];
+    const dim3 grid((it.C + 63) / 64, nchunks);
+    for (int j0 = 0; j0 < r; j0 += 8) {
+      if (dtype == DT_BF16) hipLaunchKernelGGL(lora_wgrad_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)it.X, it.ldx, (const bf16_t*)it.Y, it.ldy, region, M, it.C, r, j0);
+      else hipLaunchKernelGGL(lora_wgrad_k<float>, grid, dim3(256), 0, st, (const float*)it.X, it.ldx, (const float*)it.Y, it.ldy, region, M, it.C, r, j0);
+    }
+    b.partial[i] = region; b.out[i] = it.out; b.C[i] = it.C; b.transpose_out[i] = it.transpose_out; b.alpha[i] = it.alpha;
+    region += (long long)nchunks * r * it.C;
+  }
+  hipLaunchKernelGGL(lora_wgrad_reduce_batch_k, dim3((r * cmax + 255) / 256, n), dim3(256), 0, st, b);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+int lora_transpose2(hipStream_t st, int dtype, const void* in0, void* out0, int C0, const void* in1, void* out1, int C1, int r) {
+  const int cmax = C0 > C1 ? C0 : C1;
+  const dim3 grid((r * cmax + 255) / 256, 2);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(lora_transpose2_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in0, (bf16_t*)out0, C0, (const bf16_t*)in1, (bf16_t*)out1, C1, r);
+  else hipLaunchKernelGGL(lora_transpose2_k<float>, grid, dim3(256), 0, st, (const float*)in0, (float*)out0, C0, (const float*)in1, (float*)out1, C1, r);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

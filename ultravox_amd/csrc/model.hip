@@ -538,8 +538,7 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
       // rank-r products on the VALU (lora.hip): HBM-bound, no padding to an MFMA tile
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r;
-      RC(lora_transpose(st, dt, R.q.b, S.bqT, d, r));
-      RC(lora_transpose(st, dt, R.k.b, S.bkT, d, r));
+      RC(lora_transpose2(st, dt, R.q.b, S.bqT, d, R.k.b, S.bkT, d, r));
       RC(lora_down(st, dt, s.n, d, R.q.a, 0, S.t, 128, M, d, r, 1.0f));
       RC(lora_down(st, dt, s.n, d, R.k.a, 0, at(S.t, 64, dt), 128, M, d, r, 1.0f));
       RC(lora_up(st, dt, S.t, 128, S.bqT, 1, qkv, 3 * d, M, d, r, lora->scaling * qscale, 1));
@@ -652,10 +651,12 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     RC(lora_down(st, dt, at(s.d_qkv, d, dt), 3 * d, S.bkT, 0, at(s.u, 64, dt), 128, M, d, r, lora->scaling));
     RC(layernorm_fwd(st, dt, S.x_in, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));      // n1 recomputed (not stashed)
     // d lora_A [r, d] = u^T . n;  d lora_B [d, r] = scale * dq^T . t
-    RC(lora_wgrad(st, dt, s.n, d, s.u, 128, G.q.a, M, d, r, 0, 1.0f, s.wg));
-    RC(lora_wgrad(st, dt, s.n, d, at(s.u, 64, dt), 128, G.k.a, M, d, r, 0, 1.0f, s.wg));
-    RC(lora_wgrad(st, dt, s.d_qkv, 3 * d, S.t, 128, G.q.b, M, d, r, 1, lora->scaling * qscale, s.wg));
-    RC(lora_wgrad(st, dt, at(s.d_qkv, d, dt), 3 * d, at(S.t, 64, dt), 128, G.k.b, M, d, r, 1, lora->scaling, s.wg));
+    {
+      const LoraWgradItem items[4] = {{s.n, d, s.u, 128, G.q.a, d, 0, 1.0f}, {s.n, d, at(s.u, 64, dt), 128, G.k.a, d, 0, 1.0f},
+                                      {s.d_qkv, 3 * d, S.t, 128, G.q.b, d, 1, lora->scaling * qscale},
+                                      {at(s.d_qkv, d, dt), 3 * d, at(S.t, 64, dt), 128, G.k.b, d, 1, lora->scaling}};
+      RC(lora_wgrad_batch(st, dt, items, 4, M, r, s.wg, lora_wgrad_scratch_floats(s.M, c.enc_d, 64)));      // (one reduce launch for the four)
+    }
     if (l == 0) break;   // nothing trainable below layer 0
     // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k], then LN1 backward into the residual stream ----
     RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d)));
@@ -888,8 +889,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     if (lora) {   // peft LoRA on q_proj / k_proj (text_model_lora_config): added to the projections, before RoPE
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r, qc = Hq * dh, kc = Hkv * dh;
-      RC(lora_transpose(sx, dt, R.q.b, cur.bqT, qc, r));
-      RC(lora_transpose(sx, dt, R.k.b, cur.bkT, kc, r));
+      RC(lora_transpose2(sx, dt, R.q.b, cur.bqT, qc, R.k.b, cur.bkT, kc, r));
       RC(lora_down(sx, dt, v.n, D, R.q.a, 0, cur.t, 128, Mv, D, r, 1.0f));
       RC(lora_down(sx, dt, v.n, D, R.k.a, 0, at(cur.t, 64, dt), 128, Mv, D, r, 1.0f));
       RC(lora_up(sx, dt, cur.t, 128, cur.bqT, 1, cur.qkv, s.QKV, Mv, qc, r, lora->scaling, 1));
@@ -1235,10 +1235,11 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       RC(lora_down(sx, dt, v.d_qkv, s.QKV, cur.bqT, 0, v.lu, 128, Mv, qc, r, lora->scaling));
       RC(lora_down(sx, dt, dk, s.QKV, cur.bkT, 0, at(v.lu, 64, dt), 128, Mv, kc, r, lora->scaling));
       RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, v.n, nullptr, Mv, D, c.rms_eps, fl));        // n1 recomputed
-      RC(lora_wgrad(sx, dt, v.n, D, v.lu, 128, G.q.a, Mv, D, r, 0, 1.0f, v.lwg));
-      RC(lora_wgrad(sx, dt, v.n, D, at(v.lu, 64, dt), 128, G.k.a, Mv, D, r, 0, 1.0f, v.lwg));
-      RC(lora_wgrad(sx, dt, v.d_qkv, s.QKV, cur.t, 128, G.q.b, Mv, qc, r, 1, lora->scaling, v.lwg));
-      RC(lora_wgrad(sx, dt, dk, s.QKV, at(cur.t, 64, dt), 128, G.k.b, Mv, kc, r, 1, lora->scaling, v.lwg));
+      {
+        const LoraWgradItem items[4] = {{v.n, D, v.lu, 128, G.q.a, D, 0, 1.0f}, {v.n, D, at(v.lu, 64, dt), 128, G.k.a, D, 0, 1.0f},
+                                        {v.d_qkv, s.QKV, cur.t, 128, G.q.b, qc, 1, lora->scaling}, {dk, s.QKV, at(cur.t, 64, dt), 128, G.k.b, kc, 1, lora->scaling}};
+        RC(lora_wgrad_batch(sx, dt, items, 4, Mv, r, v.lwg, lora_wgrad_scratch_floats(s.M, c.llm_d > s.OD ? c.llm_d : s.OD, 64)));
+      }
       RC(lora_up(sx, dt, v.lu, 128, R.q.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
       RC(lora_up(sx, dt, at(v.lu, 64, dt), 128, R.k.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
     }
