@@ -447,7 +447,8 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
  * 16 RMSNorm forward, 32 RoPE forward, 64 encoder attention, 128 encoder LayerNorm, key 16 = the prefill's rotary embedding and KV-cache
  * append in one launch per layer (default 1; 0 = the rope + append pair; bit-identical), key 17 = a split-K linear of generate() that is
  * followed by an RMSNorm (o_proj -> post_attention_layernorm, down_proj -> the next layer's input_layernorm) has that norm computed by its
- * reduce kernel (default 1; 0 = the separate rmsnorm launch; bit-identical).  Keys 18..23: reserved (0). */
+ * reduce kernel (default 1; 0 = the separate rmsnorm launch; bit-identical), key 18 = 1: the RMSNorm forward of plain rows runs the two-pass kernel
+ * instead of the one that keeps the row in registers (default 0; bit-identical; A/B).  Keys 19..23: reserved (0). */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* the current value of a tuning option (-1: unknown key) */
 int32_t uvx_get_option(int32_t key);

@@ -834,3 +834,27 @@ def test_fused_attention_backward_matches_reference_and_the_kernel_pair(T, Hq, H
         s1, e2 = int(kv_start[1]), int(kv_len[2])
         assert fused[1][1, :s1].abs().max().item() == 0 and fused[2][1, :s1].abs().max().item() == 0
         assert fused[1][2, e2:].abs().max().item() == 0 and fused[2][2, e2:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("rows,cols", [(8, 8192), (3, 4096), (316, 8192), (2528, 4096), (5, 3584), (64, 1536), (7, 5120), (2, 7168)])
+def test_rmsnorm_forward_with_the_row_in_registers_is_bit_identical(rows, cols):
+    """Round 5: rows of at most 8192 columns keep their values in registers between the sum of squares and the scaling and request the weight
+    vectors together with them (one round trip to memory instead of two: the decode step's few-row norms are pure latency) - the same per-thread
+    and block summation order, arithmetic and rounding points as the two-pass kernel (option 18 = 1): bit-identical outputs, and the
+    bf16-vs-torch check of the rounding-points test still holds for it."""
+    from ultravox_amd import _lib, ops
+    L = _lib.lib()
+    torch.manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, device=DEV) * 1.7).bfloat16()
+    w = (1.0 + 0.2 * torch.randn(cols, device=DEV)).bfloat16()
+    try:
+        L.uvx_set_option(18, 0)
+        a = ops.rmsnorm(x, w, 1e-5)
+        L.uvx_set_option(18, 1)
+        b = ops.rmsnorm(x, w, 1e-5)
+    finally:
+        L.uvx_set_option(18, 0)
+    assert torch.equal(a, b)
+    xf = x.float()
+    want = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).bfloat16().float()
+    assert rel_l2(a, want) < 3e-3

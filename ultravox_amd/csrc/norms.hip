@@ -251,6 +251,54 @@ __global__ void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w, 
   }
 }
 
+// The same for rows of at most 8 x blockDim x NV columns that are plain (no frame stacking): the row stays in registers between the two passes and
+// the weight vectors are requested together with it, BEFORE the reduction - one round trip to memory instead of two.  At the decode step's few rows
+// the kernel is pure latency (8.7 us per launch, 161 launches per 70B token at 3..16 sequences: profiles/r05_decode70_b8_kernel_stats.txt); same
+// per-thread and block summation order, same arithmetic and rounding points as rmsnorm_fwd_k: bit-identical.
+template <typename T, int NV>
+__global__ void rmsnorm_fwd_reg_k(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, float* __restrict__ rstd_out, int cols,
+                                  float eps, int flavor, const int32_t* __restrict__ rows_dev, const T* __restrict__ resid) {
+  __shared__ float red[16];
+  const long long row = blockIdx.x;
+  if (rows_dev && row >= *rows_dev) return;     // block-uniform
+  const T* xr = x + row * cols;
+  float v[NV][8], wv[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (threadIdx.x + k * blockDim.x) * 8;
+    if (c < cols) {
+      ld8<T>(xr + c, v[k]);
+      ld8<T>(w + c, wv[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (threadIdx.x + k * blockDim.x) * 8;
+    if (c < cols) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[k][i] * v[k][i];
+    }
+  }
+  const float rstd = rsqrtf(block_sum(s, red) / cols + eps);
+  if (rstd_out && threadIdx.x == 0) rstd_out[row] = rstd;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (threadIdx.x + k * blockDim.x) * 8;
+    if (c >= cols) continue;
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = flavor ? (v[k][i] * rstd) * (1.0f + wv[k][i]) : wv[k][i] * rnd<T>(v[k][i] * rstd);
+    if (resid) {
+      float rv[8];
+      ld8<T>(resid + row * cols + c, rv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = rnd<T>(o[i]) + rv[i];
+    }
+    st8<T>(y + row * cols + c, o);
+  }
+}
+
 // One block handles `rpb` consecutive rows; each thread owns fixed columns so the weight gradient
 // is accumulated in registers and flushed with one atomicAdd per column per block.
 // MV: 8-element vectors per thread (static trip count; the launcher picks the smallest that covers the row - at the LLM's 4096
@@ -392,6 +440,11 @@ static int rms_launch(hipStream_t st, int dtype, const void* x, const void* w, v
 #define LW(NV) hipLaunchKernelGGL(rmsnorm_fwd_wave_k<NV>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, eps, flavor)
     if (cols == 512) LW(1); else if (cols == 1024) LW(2); else LW(4);
 #undef LW
+  } else if (dtype == DT_BF16 && map.S == 0 && !stacked && cols <= th * 8 * 4 && uvx::g_options[18] == 0) {
+    // (option 18 = 1: the two-pass kernel, for A/B)
+    if (cols <= th * 8) hipLaunchKernelGGL((rmsnorm_fwd_reg_k<bf16_t, 1>), dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, cols, eps, flavor, rows_dev, (const bf16_t*)resid);
+    else if (cols <= th * 8 * 2) hipLaunchKernelGGL((rmsnorm_fwd_reg_k<bf16_t, 2>), dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, cols, eps, flavor, rows_dev, (const bf16_t*)resid);
+    else hipLaunchKernelGGL((rmsnorm_fwd_reg_k<bf16_t, 4>), dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, cols, eps, flavor, rows_dev, (const bf16_t*)resid);
   } else if (dtype == DT_BF16)
     hipLaunchKernelGGL(rmsnorm_fwd_k<bf16_t>, dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w,
                        (bf16_t*)y, (bf16_t*)stacked, rstd, cols, eps, map, flavor, rows_dev, (const bf16_t*)resid);
