@@ -440,8 +440,10 @@ static int rms_launch(hipStream_t st, int dtype, const void* x, const void* w, v
 #define LW(NV) hipLaunchKernelGGL(rmsnorm_fwd_wave_k<NV>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, eps, flavor)
     if (cols == 512) LW(1); else if (cols == 1024) LW(2); else LW(4);
 #undef LW
-  } else if (dtype == DT_BF16 && map.S == 0 && !stacked && cols <= th * 8 * 4 && uvx::g_options[18] == 0) {
-    // (option 18 = 1: the two-pass kernel, for A/B)
+  } else if (dtype == DT_BF16 && map.S == 0 && !stacked && cols <= th * 8 * 4 && rows <= 512 && uvx::g_options[18] == 0) {
+    // few rows - the decode step, a prompt's prefill: latency-bound, one round trip instead of two (70B decode 25.64 -> 25.34 ms per token at
+    // B = 8, the 8B model 4.08 -> 3.98; profiles/r05_rmsnorm_reg_ab.txt).  The training step's 2528 rows are throughput-bound and read
+    // 0.1-0.2 ms per step SLOWER with it: they keep the two-pass kernel.  (option 18 = 1: the two-pass kernel everywhere, for A/B)
     if (cols <= th * 8) hipLaunchKernelGGL((rmsnorm_fwd_reg_k<bf16_t, 1>), dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, cols, eps, flavor, rows_dev, (const bf16_t*)resid);
     else if (cols <= th * 8 * 2) hipLaunchKernelGGL((rmsnorm_fwd_reg_k<bf16_t, 2>), dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, cols, eps, flavor, rows_dev, (const bf16_t*)resid);
     else hipLaunchKernelGGL((rmsnorm_fwd_reg_k<bf16_t, 4>), dim3(rows), dim3(th), 0, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, cols, eps, flavor, rows_dev, (const bf16_t*)resid);
