@@ -365,6 +365,55 @@ def pmc_traffic_per_launch(profiles_dir=None):
         return None
 
 
+def pmc_gemm_counter_per_launch(csv_path: str):
+    """(launches, mean Counter_Value per launch) over the gemm_nt_bf16_* rows of a rocprofv3 counter_collection.csv"""
+    import csv
+    n, total = 0, 0.0
+    with open(csv_path) as f:
+        for r in csv.DictReader(f):
+            if "gemm_nt" in r.get("Kernel_Name", ""):
+                n += 1
+                total += float(r["Counter_Value"])
+    return n, (total / n if n else None)
+
+
+def measure_traffic_live(child_args, timeout_s: int = 180):
+    """roofline.traffic MEASURED IN THIS RUN (round 5; before, the line quoted the committed profiles/rNN_pmc_traffic.json and a traffic regression
+    would have gone unseen): two short sub-runs of this same command under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
+    passes: the two derived counters do not fit the TCC's counters together; 2 timed + 1 warm-up step each, no CPU leg, no HIP-event timing), summed
+    over the gemm_nt_bf16_* dispatches, FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 bytes: MI355X_MICROARCH.md).  Memory-side (fabric)
+    counters: L2-miss traffic, Infinity-Cache hits included.  Returns (bytes per launch, detail dict) or (None, reason): never raises."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rp:
+        return None, "rocprofv3 not found"
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="uvx_pmc_", dir="/tmp")
+            try:
+                cmd = [rp, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                       os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-prof", "--no-live-traffic", *child_args]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+                files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    return None, f"rocprofv3 --pmc {counter} sub-run failed (rc {r.returncode})"
+                n, per = pmc_gemm_counter_per_launch(files[0])
+                if not n:
+                    return None, f"no gemm_nt dispatch in the {counter} pass"
+                got[counter] = (n, per)
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except Exception as e:  # a missing tool, a timeout, an unreadable CSV: the committed figure is quoted instead, and the line says so
+        return None, f"{type(e).__name__}: {e}"
+    fetch_kb, write_kb = got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]
+    return (2.0 * fetch_kb + write_kb) * 1024.0, {"launches_per_pass": got["FETCH_SIZE"][0], "fetch_kb_per_launch_raw": fetch_kb,
+                                                   "write_kb_per_launch": write_kb, "gfx950_fetch_correction": 2.0}
+
+
 def _f32_mode_record(path: str):
     """north_star's "logits within 1e-3": the f32 compute mode (dtype UVX_F32, not the benchmarked path) at the C2 width, depth 2"""
     try:
@@ -444,6 +493,8 @@ def main():
     ap.add_argument("--cpu-baseline-full", default=None, metavar="OUT.json",
                     help="CPU only: time ONE WHOLE step of the workload at B = 1 through the oracle (all layers) and write the record")
     ap.add_argument("--no-prof", action="store_true", help="skip the live HIP-event timing of the GEMM kernel")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="quote roofline.traffic from the committed PMC summary instead of measuring it in two rocprofv3 --pmc sub-runs (~15 s each)")
     ap.add_argument("--audio-lora-r", type=int, default=0,
                     help="train rank-r LoRA on the encoder's q_proj/k_proj too (the reference's release recipe, "
                          "audio_model_lora_config.r = 8); 0 = frozen towers, the BASELINE.json configuration")
@@ -681,9 +732,21 @@ def main():
             ach = prof[2] / (gemm_ms * 1e-3) / 1e12
             # memory-side traffic per GEMM launch from the PMC passes of the SAME command (tools/pmc_traffic.sh,
             # separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 on gfx950), committed under profiles/
-            traffic = pmc_traffic_per_launch() if args.workload == "c2" else None
+            traffic, traffic_source, traffic_detail = None, None, None
+            if args.workload == "c2":
+                plain = args.loss == "ce" and not args.audio_lora_r and not args.opt and not args.gemm_override and world == 1
+                if plain and not args.no_live_traffic and not args.no_cpu_baseline:      # (the probes' A/B arms pass --no-cpu-baseline: no sub-runs there)
+                    traffic, traffic_detail = measure_traffic_live(["--workload", "c2"])
+                    traffic_source = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE sub-runs of this command "
+                                      "(2 + 1 steps each), gemm_nt_bf16_* dispatches, FETCH_SIZE x 2 (gfx950)") if traffic else None
+                if traffic is None:
+                    why = traffic_detail if isinstance(traffic_detail, str) else None
+                    traffic, traffic_detail = pmc_traffic_per_launch(), None
+                    traffic_source = "profiles/rNN_pmc_traffic.json (newest committed PMC summary of this command)" + (f"; live measurement skipped: {why}" if why else "")
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_* (all tile variants)", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                               "traffic_detail": traffic_detail,
+                               "traffic_note": "memory-side (L2-miss) bytes per GEMM launch, Infinity-Cache hits included: an upper bound on HBM bytes",
                                "algorithmic_bytes_per_launch": prof[3] / prof[0],
                                "launches_per_step": prof[0] / profiled_steps, "gemm_ms_per_step": gemm_ms / profiled_steps,
                                "gemm_ms_per_step_summed_intervals": prof[1] / profiled_steps,

@@ -1,6 +1,7 @@
 """bench.py's host-side definitions, checked without a GPU: the algorithmic FLOP count against SURVEY.md §8(d)'s figures
 for C2 / C3 and the lookup of the committed PMC traffic summary."""
 import json
+import os
 
 import pytest
 
@@ -118,3 +119,28 @@ def test_parity_object_cites_the_newest_committed_full_depth_record(tmp_path):
     assert bench.parity_record("c2", str(tmp_path)) is None
     committed = bench.parity_record("c2")
     assert committed is not None and 1e-3 < committed["logits_rel_l2_vs_f32_oracle"] < 2.8e-2      # the bar of tests/test_c2_full_depth_gpu.py
+
+
+def test_live_traffic_measurement_parses_the_counter_csv_and_never_raises(tmp_path, monkeypatch):
+    """bench.py measures roofline.traffic in the run itself (two rocprofv3 --pmc sub-runs); the host-side pieces: the per-launch mean over the
+    gemm_nt rows of a counter_collection.csv, and the fall-back to the committed summary when the tool is missing or a sub-run fails."""
+    import bench
+    csv_file = tmp_path / "p_counter_collection.csv"
+    csv_file.write_text("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+                        '1,"void (anonymous namespace)::gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2, false>(GemmArgs)",FETCH_SIZE,300.0\n'
+                        '2,"void (anonymous namespace)::rmsnorm_fwd_k<unsigned short>(...)",FETCH_SIZE,9999.0\n'
+                        '3,"void (anonymous namespace)::gemm_nt_bf16_kernel(GemmArgs)",FETCH_SIZE,100.0\n')
+    assert bench.pmc_gemm_counter_per_launch(str(csv_file)) == (2, 200.0)
+    import shutil
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    monkeypatch.setattr(os.path, "exists", lambda p: False)
+    got, why = bench.measure_traffic_live(["--workload", "c2"])
+    assert got is None and "rocprofv3" in why
+    monkeypatch.undo()
+    # a tool that "runs" but leaves no CSV behind: reported, not raised
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/sh\nexit 0\n")
+    fake.chmod(0o755)
+    monkeypatch.setattr(shutil, "which", lambda name: str(fake))
+    got, why = bench.measure_traffic_live(["--workload", "c2"], timeout_s=20)
+    assert got is None and "sub-run failed" in why
