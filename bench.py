@@ -340,7 +340,7 @@ def cpu_baseline_full(cfg, seconds: float, n_text: int = 128, steps: int = 1):
     def step():
         mel = O.logmel_ref(pcm, a.num_mel_bins)
         out, grads, _ = om.train_step({**b, "audio_values": mel})
-        return float(out["loss"])
+        return float(out["loss"].detach())
 
     times = []
     for _ in range(steps):
