@@ -377,7 +377,7 @@ def pmc_gemm_counter_per_launch(csv_path: str):
     return n, (total / n if n else None)
 
 
-def measure_traffic_live(child_args, timeout_s: int = 180):
+def measure_traffic_live(child_args, timeout_s: int = 90):
     """roofline.traffic MEASURED IN THIS RUN (round 5; before, the line quoted the committed profiles/rNN_pmc_traffic.json and a traffic regression
     would have gone unseen): two short sub-runs of this same command under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
     passes: the two derived counters do not fit the TCC's counters together; 2 timed + 1 warm-up step each, no CPU leg, no HIP-event timing), summed
