@@ -397,10 +397,23 @@ def measure_traffic_live(child_args, timeout_s: int = 90):
             try:
                 cmd = [rp, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
                        os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-prof", "--no-live-traffic", *child_args]
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+                # the sub-run is rocprofv3 -> python: its own session / process group, so that a timeout ends BOTH (killing only
+                # rocprofv3 would leave the grandchild python running on the GPU next to the parent - ADVICE r5)
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                        start_new_session=True)
+                try:
+                    rc = proc.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    import signal
+                    try:
+                        os.killpg(proc.pid, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
+                    proc.wait()
+                    return None, f"rocprofv3 --pmc {counter} sub-run timed out after {timeout_s} s (its process group was killed)"
                 files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-                if r.returncode != 0 or not files:
-                    return None, f"rocprofv3 --pmc {counter} sub-run failed (rc {r.returncode})"
+                if rc != 0 or not files:
+                    return None, f"rocprofv3 --pmc {counter} sub-run failed (rc {rc})"
                 n, per = pmc_gemm_counter_per_launch(files[0])
                 if not n:
                     return None, f"no gemm_nt dispatch in the {counter} pass"
@@ -736,6 +749,8 @@ def main():
             if args.workload == "c2":
                 plain = args.loss == "ce" and not args.audio_lora_r and not args.opt and not args.gemm_override and world == 1
                 if plain and not args.no_live_traffic and not args.no_cpu_baseline:      # (the probes' A/B arms pass --no-cpu-baseline: no sub-runs there)
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()          # the sub-runs build their own model next to this process's: hand back every cached block first
                     traffic, traffic_detail = measure_traffic_live(["--workload", "c2"])
                     traffic_source = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE sub-runs of this command "
                                       "(2 + 1 steps each), gemm_nt_bf16_* dispatches, FETCH_SIZE x 2 (gfx950)") if traffic else None

@@ -394,7 +394,9 @@ typedef struct {
   int32_t M, N, K, lda, ldb, ldc, ldr;
   int32_t res_mod, batch;
   int64_t stride_a, stride_b, stride_c, stride_r;
-  int32_t act;        /* 0 none, 1 exact-erf GELU */
+  int32_t act;        /* 0 none, 1 exact-erf GELU; bf16 only: 2 = GELU that keeps its pre-activation - C = acc * alpha + bias (rounded), C2 [M, N] (row
+                       * stride ldc2) = gelu(C); 3 = GELU backward - C = (acc * alpha, rounded) * gelu'(C2), C2 [M, N] = the saved pre-activation.
+                       * 2 and 3 equal uvx_gemm + uvx_gelu / uvx_gelu_bwd bit for bit; no residual, epilogue, f32 output or batch with them */
   int32_t out_f32;    /* bf16 inputs, f32 output (weight gradients) */
   int32_t accumulate; /* C += (f32 output only) */
   float alpha;
@@ -448,7 +450,11 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
  * append in one launch per layer (default 1; 0 = the rope + append pair; bit-identical), key 17 = a split-K linear of generate() that is
  * followed by an RMSNorm (o_proj -> post_attention_layernorm, down_proj -> the next layer's input_layernorm) has that norm computed by its
  * reduce kernel (default 1; 0 = the separate rmsnorm launch; bit-identical), key 18 = 1: the RMSNorm forward of plain rows runs the two-pass kernel
- * instead of the one that keeps the row in registers (default 0; bit-identical; A/B).  Keys 19..23: reserved (0). */
+ * instead of the one that keeps the row in registers (default 0; bit-identical; A/B), key 19 = tile form of the head_dim-64 attention backward pair (the
+ * Whisper tower under LoRA training): 0 = two 16-query tiles per wave in the dQ kernel (default), 1 = one tile per wave in both kernels (rounds 1-5), 2 = two in
+ * both, 3 = two in the dK/dV kernel only, 4 = 64-row steps, 5 / 6 = eight-wave blocks (all bit-identical; A/B), key 20 = 1: the head_dim-64 forward kernel takes
+ * its row max through ds_bpermute shuffles instead of v_permlane swaps (default 0; bit-identical; A/B), key 21 = 1: the training tower's GELU and GELU backward
+ * run as separate kernels instead of in the fc1 / fc2-dgrad GEMM epilogues (uvx_gemm_desc_t.act 2 / 3; default 0; bit-identical; A/B).  Keys 22, 23: reserved (0). */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* the current value of a tuning option (-1: unknown key) */
 int32_t uvx_get_option(int32_t key);

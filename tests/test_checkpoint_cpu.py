@@ -312,6 +312,9 @@ def test_unpack_inverts_the_packed_tower_layouts(family, dtype):
     back = {**unpack_encoder(pack_encoder(sd, cfg, dtype, "cpu"), cfg), **unpack_llm(pack_llm(sd, cfg, dtype, "cpu", with_transposes=False), cfg)}
     towers = {k for k in sd if not k.startswith("multi_modal_projector.")}
     assert set(back) == towers
+    # the name-only helpers merge_and_unload uses (no tensor is touched: ADVICE r5) list exactly the unpacked keys, in the same order
+    from ultravox_amd.weights import encoder_param_names, llm_param_names
+    assert encoder_param_names(cfg) + llm_param_names(pack_llm(sd, cfg, dtype, "cpu", with_transposes=False), cfg) == list(back)
     for k in sorted(towers):
         assert back[k].dtype == dtype and back[k].shape == sd[k].shape and torch.equal(back[k], sd[k]), k
 
@@ -325,3 +328,6 @@ def test_unpack_refuses_a_scale_it_cannot_undo_exactly():
     sd = random_state_dict(cfg, seed=3, dtype=torch.float32)
     with pytest.raises(ValueError, match="power of two"):
         unpack_encoder(pack_encoder(sd, cfg, torch.float32, "cpu"), cfg)      # head_dim 32: scale 2^-2.5
+    from ultravox_amd.weights import check_encoder_exportable
+    with pytest.raises(ValueError, match="power of two"):
+        check_encoder_exportable(cfg)                # what merge_and_unload asks BEFORE it folds any adapter

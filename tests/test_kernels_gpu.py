@@ -858,3 +858,105 @@ def test_rmsnorm_forward_with_the_row_in_registers_is_bit_identical(rows, cols):
     xf = x.float()
     want = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).bfloat16().float()
     assert rel_l2(a, want) < 3e-3
+
+
+@pytest.mark.parametrize("Hq,Hkv,T,causal,block", [(3, 3, 1500, False, 0), (2, 2, 333, False, 50), (4, 2, 130, True, 0), (2, 2, 97, False, 0)])
+def test_head_dim_64_attention_tile_forms_are_bit_identical(Hq, Hkv, T, causal, block):
+    """Round 6: the head_dim-64 backward pair with two 16-row tiles per wave (tuning option 19: 0 = the dQ kernel, 1 = the round 1-5
+    one-tile form, 2..6 = both kernels / 64-row-step / 8-wave forms kept for A/B) and the forward row max through v_permlane swaps
+    (option 20: 1 = the ds_bpermute shuffles).  Every output element sums the same terms in the same order in every form."""
+    from ultravox_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(23)
+    B, D = 2, 64
+    q = bf(torch.randn(B, T, Hq, D, device=DEV))
+    k = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    v = bf(torch.randn(B, T, Hkv, D, device=DEV))
+    do = bf(torch.randn(B, T, Hq * D, device=DEV))
+    kv_len = torch.tensor([T, max(1, T - 37)], device=DEV, dtype=torch.int32) if not causal else None
+    try:
+        L.uvx_set_option(20, 1)
+        o0, lse0 = ops().attention(q, k, v, causal=causal, block=block, kv_len=kv_len)
+        L.uvx_set_option(20, 0)
+        o, lse = ops().attention(q, k, v, causal=causal, block=block, kv_len=kv_len)
+        assert torch.equal(o, o0) and torch.equal(lse, lse0)
+        L.uvx_set_option(19, 1)
+        want = ops().attention_bwd(q, k, v, o, lse, do, causal=causal, block=block, kv_len=kv_len)
+        for form in (0, 2, 3, 4, 5, 6):
+            L.uvx_set_option(19, form)
+            got = ops().attention_bwd(q, k, v, o, lse, do, causal=causal, block=block, kv_len=kv_len)
+            for a, b, name in zip(got, want, ("dq", "dk", "dv")):
+                assert torch.equal(a, b), (form, name)
+    finally:
+        L.uvx_set_option(19, 0)
+        L.uvx_set_option(20, 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(1504, 2048, 1024), (12000, 4096, 1024), (300, 1024, 4096), (100, 132, 192), (37, 8, 64), (515, 1000, 128)])
+def test_gemm_gelu_epilogues_that_keep_and_consume_the_pre_activation(M, N, K):
+    """Round 6 (the Whisper tower under LoRA training): act 2 = fc1 whose epilogue writes the pre-activation AND gelu of it, act 3 = the
+    fc2 dgrad whose epilogue multiplies by gelu'(pre) - against uvx_gemm + uvx_gelu / uvx_gelu_bwd, bit for bit, on aligned shapes (the
+    LDS-staged whole-line epilogue), ragged ones (the fragment-layout fallback) and a tail-split launch; and against torch within bf16."""
+    import ctypes as C
+    from ultravox_amd import _lib
+    torch.manual_seed(31)
+    a, w = bf(torch.randn(M, K, device=DEV)), bf(torch.randn(N, K, device=DEV) * K ** -0.5)
+    bias = bf(torch.randn(N, device=DEV))
+    L = _lib.lib()
+    pre_ref = ops().gemm(a, w, bias=bias)
+    act_ref = torch.empty_like(pre_ref)
+    _lib.check(L.uvx_gelu(None, _lib.BF16, C.c_void_p(pre_ref.data_ptr()), C.c_void_p(act_ref.data_ptr()), C.c_longlong(pre_ref.numel())), "uvx_gelu")
+    act = torch.empty_like(pre_ref)
+    pre = ops().gemm(a, w, bias=bias, act="gelu_keep", c2=act)
+    assert torch.equal(pre, pre_ref) and torch.equal(act, act_ref)
+    want = torch.nn.functional.gelu(pre_ref.float())
+    assert rel_l2(act, want) < 4e-3
+    # backward: d = a . w^T (no bias), times gelu'(x) with x = any saved pre-activation of that shape
+    x = bf(torch.randn(M, N, device=DEV) * 1.5)
+    d_ref = ops().gemm(a, w)
+    g_ref = torch.empty_like(d_ref)
+    _lib.check(L.uvx_gelu_bwd(None, _lib.BF16, C.c_void_p(d_ref.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(g_ref.data_ptr()),
+                              C.c_longlong(d_ref.numel())), "uvx_gelu_bwd")
+    g = ops().gemm(a, w, act="gelu_bwd", c2=x)
+    assert torch.equal(g, g_ref)
+    xf = x.float().requires_grad_(True)
+    torch.nn.functional.gelu(xf).backward(d_ref.float())
+    assert rel_l2(g, xf.grad) < 4e-3
+
+
+@pytest.mark.parametrize("variant,twin", [(61, 31), (62, 34)])
+def test_mfma_32x32x16_merged_phase_kernels(variant, twin):
+    """Round 6: the merged-phase GEMM on v_mfma_f32_32x32x16_bf16 (61 = 256 x 256, 62 = 128 x 256; LDS image swizzled with (row >> 1) & 7,
+    its own whole-line epilogue for bias / GELU / residual) against the f32 reference at the production bar and against its 16 x 16 x 32
+    twin to summation order (16-column vs 32-column k steps); epilogues it does not carry (f32 output, ragged N) run the twin bit for bit;
+    20 repeats bit-identical (race screen on the new swizzle / fragment reads)."""
+    from ultravox_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(variant)
+
+    def run(v, fn):
+        L.uvx_gemm_force_variant(v)
+        try:
+            return fn()
+        finally:
+            L.uvx_gemm_force_variant(-1)
+
+    for (M, N, K) in [(256, 256, 64), (300, 520, 128), (128, 256, 192), (1000, 1032, 256), (2528, 6144, 4096), (12000, 1024, 1024), (316, 768, 8192)]:
+        a = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+        b = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
+        bias = torch.randn(N, device=DEV, generator=g).bfloat16()
+        resid = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+        ref = a.float() @ b.float().t()
+        modes = {"plain": (lambda: ops().gemm(a, b), ref), "bias+res": (lambda: ops().gemm(a, b, bias=bias, residual=resid), ref + bias.float() + resid.float()),
+                 "bias+gelu": (lambda: ops().gemm(a, b, bias=bias, act="gelu"), F.gelu(ref + bias.float()))}
+        for name, (fn, want) in modes.items():
+            got, tw = run(variant, fn), run(twin, fn)
+            assert rel_l2(got, want) < 5e-3, (variant, (M, N, K), name, rel_l2(got, want))
+            assert rel_l2(got, tw) < 2e-3 and (got == tw).float().mean().item() > 0.9, (variant, (M, N, K), name)
+        first = run(variant, modes["plain"][0])
+        for _ in range(20):
+            assert torch.equal(run(variant, modes["plain"][0]), first), (variant, (M, N, K), "repeat")
+        assert torch.equal(run(variant, lambda: ops().gemm(a, b, out_f32=True)), run(twin, lambda: ops().gemm(a, b, out_f32=True)))
+    a = (torch.randn(200, 128, device=DEV, generator=g)).bfloat16()
+    b = (torch.randn(132, 128, device=DEV, generator=g)).bfloat16()          # N % 8 != 0: the twin's fragment-layout epilogue
+    assert torch.equal(run(variant, lambda: ops().gemm(a, b)), run(twin, lambda: ops().gemm(a, b)))

@@ -80,6 +80,36 @@ __device__ __forceinline__ void rope_inverse_tiles(float (&v)[DT][4], const floa
   }
 }
 
+// Reductions over the four lanes that share a query column (lanes l, l ^ 16, l ^ 32, l ^ 48) on the VALU: v_permlane16_swap exchanges
+// the odd 16-lane rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the
+// lower half of the second - with both operands = x the two results are x's two halves broadcast, so one max / add of them is the
+// pairwise reduction.  __shfl_xor(x, 16 / 32) compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): an LDS round trip that also
+// waits for every fragment read in flight (twice per 16 query rows and key tile in the forward loop).  Same values bit for bit:
+// max is exact, and a + b == b + a.
+// (the two results are copied into scalars before the casts: __builtin_bit_cast applied to an ELEMENT of the returned ext-vector reads
+//  element 0 whichever index is written - hipcc 7.2 - which silently turns the max / add into a no-op)
+__device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
+// one v_max_f32 (fmaxf on values that come out of a cross-lane op is preceded by two canonicalising v_max x, x, x)
+__device__ __forceinline__ float vmax1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float quad_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  const unsigned w = __builtin_bit_cast(unsigned, vmax1(u2f(a0), u2f(a1)));
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  const unsigned b0 = b[0], b1 = b[1];
+  return vmax1(u2f(b0), u2f(b1));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  const unsigned w = __builtin_bit_cast(unsigned, u2f(a0) + u2f(a1));
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  const unsigned b0 = b[0], b1 = b[1];
+  return u2f(b0) + u2f(b1);
+}
+
 __device__ __forceinline__ bf16x8_t lds_b128(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
 // two 8-byte LDS reads -> one 8 x bf16 fragment
@@ -242,7 +272,8 @@ __device__ __forceinline__ void store_rows(char* stage, const u16x4_t (&v)[DT], 
 
 // =================================== forward ===================================
 // TR: V is staged in its natural [key][d] layout and read through the transposing LDS read (no V^T copy in global memory)
-template <int D, int QT, bool TR>
+// PL: the cross-lane max / sum of a query row through v_permlane*_swap (quad_max) instead of two ds_bpermute shuffles
+template <int D, int QT, bool TR, bool PL = true>
 __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   constexpr int BQ = 4 * QT * 16;
   constexpr int KS = D / 32;   // k-steps of the QK^T product
@@ -371,8 +402,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[t][kt][e]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if constexpr (PL) mx = quad_max(mx);
+      else { mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64)); }
       mx *= p.sc;  // (-inf stays -inf)
       const float m_new = fmaxf(m_run[t], mx);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
@@ -438,8 +469,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   for (int t = 0; t < QT; ++t) {
     const int q = q0 + t * 16 + fr;
     float l = l_run[t];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    if constexpr (PL) l = quad_sum(l);
+    else { l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64); }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     u16x4_t o4[DT];
 #pragma unroll
@@ -462,9 +493,9 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
 // hide (PMC, round 2: 8 000 wave cycles per 32-query step for ~400 instructions), so the fixed part is paid half as often.
 // DEEP: two-deep register prefetch (two staging sets, alternating) instead of one step ahead.
 // TR: only the natural Q / dO tiles are staged; their transposes come from the transposing LDS read (no Q^T / dO^T copies).
-template <int D, int NT, int ST, bool DEEP, bool TR>
+template <int D, int NT, int ST, bool DEEP, bool TR, int WT = 1>
 __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
-  constexpr int KB = NT / 4;        // keys per block
+  constexpr int KB = NT / 4 * WT;   // keys per block
   constexpr int KS = D / 32, DT = D / 16, QT = ST / 16, KP = ST / 32;
   constexpr int TILE = ST * D * 2;
   constexpr int NTILE = TR ? 2 : 4;   // tiles per buffer
@@ -486,23 +517,28 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   const int grp = split ? 1 : grp_all;
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
-  const int key = kb0 + w * 16 + fr;  // this lane's key (B-operand column)
+  const int key_w0 = kb0 + w * 16 * WT;   // this wave's 16 WT keys: tile wt holds key_w0 + 16 wt + (lane & 15) (B-operand column)
 
-  // K, V fragments for this wave's 16 keys: B operand, [key = fr][d = ks*32 + g*8 ..]
-  bf16x8_t kf[KS], vf[KS];
+  // K, V fragments for this wave's WT 16-key tiles: B operand, [key = fr][d = ks*32 + g*8 ..]
+  bf16x8_t kf[WT][KS], vf[WT][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (key < p.T) {
-      a = *reinterpret_cast<const u16x8_t*>(p.k + ((long long)b * p.T + key) * p.ldk + hk * D + ks * 32 + g * 8);
-      c = *reinterpret_cast<const u16x8_t*>(p.v + ((long long)b * p.T + key) * p.ldv + hk * D + ks * 32 + g * 8);
+  for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int key = key_w0 + wt * 16 + fr;
+      u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (key < p.T) {
+        a = *reinterpret_cast<const u16x8_t*>(p.k + ((long long)b * p.T + key) * p.ldk + hk * D + ks * 32 + g * 8);
+        c = *reinterpret_cast<const u16x8_t*>(p.v + ((long long)b * p.T + key) * p.ldv + hk * D + ks * 32 + g * 8);
+      }
+      kf[wt][ks] = __builtin_bit_cast(bf16x8_t, a);
+      vf[wt][ks] = __builtin_bit_cast(bf16x8_t, c);
     }
-    kf[ks] = __builtin_bit_cast(bf16x8_t, a);
-    vf[ks] = __builtin_bit_cast(bf16x8_t, c);
-  }
-  f32x4_t acc_dk[DT], acc_dv[DT];
+  f32x4_t acc_dk[WT][DT], acc_dv[WT][DT];
 #pragma unroll
-  for (int d = 0; d < DT; ++d) { acc_dk[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc_dv[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { acc_dk[wt][d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc_dv[wt][d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
   int q_begin = 0;
   if (p.causal) q_begin = kb0;
@@ -552,45 +588,56 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   auto compute = [&](int cur) {
     const int qs = cqs;
     cqs = cqs < q_last ? cqs + ST : q_begin;
-    const int key_w0 = kb0 + w * 16;  // this wave's 16 keys
-    // nothing to add when every (query, key) pair of this wave's tile is masked: its keys lie after the step's last query
+    constexpr int KW = 16 * WT;       // this wave's keys: key_w0 .. key_w0 + KW - 1
+    // nothing to add when every (query, key) pair of this wave's tiles is masked: its keys lie after the step's last query
     // (the first steps of a causal block) or outside the valid key range
-    if ((p.causal && key_w0 > qs + ST - 1) || key_w0 >= k_hi || key_w0 + 16 <= k_lo || (p.window > 0 && key_w0 + 15 <= qs - p.window)) return;
+    if ((p.causal && key_w0 > qs + ST - 1) || key_w0 >= k_hi || key_w0 + KW <= k_lo || (p.window > 0 && key_w0 + KW - 1 <= qs - p.window)) return;
     const char* ldsQ = ldsAll + cur * NTILE * TILE;
     const char* ldsDO = ldsQ + TILE;
     const char* ldsQT = ldsQ + 2 * TILE;      // (!TR)
     const char* ldsDOT = ldsQ + 3 * TILE;     // (!TR)
     const float* ldsL = ldsStat + cur * 2 * ST;
     const float* ldsDl = ldsL + ST;
-    // S[q][key] and dP[q][key] for the QT 16-query tiles: A = Q / dO rows, B = K / V fragments
-    f32x4_t s[QT], dp[QT];
+    // S[q][key] and dP[q][key] for the QT 16-query tiles x WT 16-key tiles: A = Q / dO rows (read ONCE for all WT key tiles),
+    // B = K / V fragments
+    f32x4_t s[WT][QT], dp[WT][QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int wt = 0; wt < WT; ++wt) { s[wt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[wt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8_t a = lds_b128(ldsQ + nat_off<D>(t * 16 + fr, ks * 4 + g));
         const bf16x8_t c = lds_b128(ldsDO + nat_off<D>(t * 16 + fr, ks * 4 + g));
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kf[ks], s[t], 0, 0, 0);
-        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, vf[ks], dp[t], 0, 0, 0);
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt) {
+          s[wt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kf[wt][ks], s[wt][t], 0, 0, 0);
+          dp[wt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, vf[wt][ks], dp[wt][t], 0, 0, 0);
+        }
       }
     }
-    // accumulator element e of tile t: q = qs + t*16 + g*4 + e, key = this lane's key
-    float pr[QT][4], ds[QT][4];
-    bool need_mask = key_w0 < k_lo || key_w0 + 16 > k_hi || qs + ST > p.T;
-    if (p.causal) need_mask = need_mask || key_w0 + 15 > qs;
-    if (p.block > 0) need_mask = need_mask || (key_w0 + 15) / p.block > qs / p.block;
+    // accumulator element e of tile (wt, t): q = qs + t*16 + g*4 + e, key = key_w0 + 16 wt + fr
+    float pr[WT][QT][4], ds[WT][QT][4];
+    bool need_mask = key_w0 < k_lo || key_w0 + KW > k_hi || qs + ST > p.T;
+    if (p.causal) need_mask = need_mask || key_w0 + KW - 1 > qs;
+    if (p.block > 0) need_mask = need_mask || (key_w0 + KW - 1) / p.block > qs / p.block;
     if (p.window > 0) need_mask = need_mask || key_w0 <= qs + ST - 1 - p.window;
-    unsigned okbits = 0xffffu;        // bit t*4 + e: the (query, key) pair of that accumulator element takes part
+    unsigned okbits[WT];              // bit t*4 + e: the (query, key) pair of that accumulator element takes part
+#pragma unroll
+    for (int wt = 0; wt < WT; ++wt) okbits[wt] = 0xffffu;
     if (need_mask) {
-      okbits = 0u;
 #pragma unroll
-      for (int t = 0; t < QT; ++t)
+      for (int wt = 0; wt < WT; ++wt) {
+        const int key = key_w0 + wt * 16 + fr;
+        okbits[wt] = 0u;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int q = qs + t * 16 + g * 4 + e;
-          okbits |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block, p.window)) << (t * 4 + e);
-        }
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int q = qs + t * 16 + g * 4 + e;
+            okbits[wt] |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block, p.window)) << (t * 4 + e);
+          }
+      }
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -598,17 +645,21 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
       const float4 d4 = *reinterpret_cast<const float4*>(ldsDl + t * 16 + g * 4);
       const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float ev = __builtin_amdgcn_exp2f(s[t][e] * p.sc - lq[e]);
-        const float pv = (okbits >> (t * 4 + e)) & 1u ? ev : 0.f;
-        pr[t][e] = pv;
-        ds[t][e] = pv * (dp[t][e] - dq[e]);
-      }
+      for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ev = __builtin_amdgcn_exp2f(s[wt][t][e] * p.sc - lq[e]);
+          const float pv = (okbits[wt] >> (t * 4 + e)) & 1u ? ev : 0.f;
+          pr[wt][t][e] = pv;
+          ds[wt][t][e] = pv * (dp[wt][t][e] - dq[e]);
+        }
     }
     // B operands per 32-query chunk kp: slot (g, s) <-> q = qs + 32*kp + 16*(s>>2) + 4*g + (s&3)
-    bf16x8_t pB[KP], dsB[KP];
+    bf16x8_t pB[WT][KP], dsB[WT][KP];
 #pragma unroll
-    for (int kp = 0; kp < KP; ++kp) { pB[kp] = pack8(pr[2 * kp], pr[2 * kp + 1]); dsB[kp] = pack8(ds[2 * kp], ds[2 * kp + 1]); }
+    for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) { pB[wt][kp] = pack8(pr[wt][2 * kp], pr[wt][2 * kp + 1]); dsB[wt][kp] = pack8(ds[wt][2 * kp], ds[wt][2 * kp + 1]); }
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       const int row = d * 16 + fr;
@@ -622,8 +673,11 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
           a = lds_2xb64(ldsDOT + tr_off8<ST>(row, kp * 8 + g), ldsDOT + tr_off8<ST>(row, kp * 8 + 4 + g));
           c = lds_2xb64(ldsQT + tr_off8<ST>(row, kp * 8 + g), ldsQT + tr_off8<ST>(row, kp * 8 + 4 + g));
         }
-        acc_dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB[kp], acc_dv[d], 0, 0, 0);
-        acc_dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB[kp], acc_dk[d], 0, 0, 0);
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt) {
+          acc_dv[wt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pB[wt][kp], acc_dv[wt][d], 0, 0, 0);
+          acc_dk[wt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dsB[wt][kp], acc_dk[wt][d], 0, 0, 0);
+        }
       }
     }
   };
@@ -657,8 +711,10 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
   // free: every wave passes its rows through a private piece of them and stores whole 128-byte segments (store_rows_staged).
   char* stage = ldsAll + w * STAGE_BYTES;
   static_assert((NT / 64) * STAGE_BYTES <= 2 * NTILE * TILE, "stage fits the staging buffers");
-  const int key0 = kb0 + w * 16;
-  if (key0 < p.T) {    // wave-uniform
+#pragma unroll
+  for (int wt = 0; wt < WT; ++wt) {
+    const int key0 = key_w0 + wt * 16, key = key0 + fr;
+    if (key0 >= p.T) continue;    // wave-uniform
     u16x4_t ok[DT], ov[DT];
     if (split) {
       // per-query-head dK / dV, rounded to bf16 like the un-grouped result below: that is where the reference rounds too (SDPA
@@ -666,7 +722,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
 #pragma unroll
       for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(acc_dk[d][e] * p.scale); ov[d][e] = f2bf(acc_dv[d][e]); }
+        for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(acc_dk[wt][d][e] * p.scale); ov[d][e] = f2bf(acc_dv[wt][d][e]); }
       bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dkv_part) + (((long long)b * p.T + key0) * p.Hq + h_first) * D;
       bf16_t* dvp = dkp + (long long)p.B * p.T * p.Hq * D;
       store_rows<DT>(stage, ok, dkp, (long long)p.Hq * D, p.T - key0, lane);
@@ -676,12 +732,12 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
 #pragma unroll
       for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dkv[d][e] = bf2f(f2bf(acc_dk[d][e] * p.scale));
+        for (int e = 0; e < 4; ++e) dkv[d][e] = bf2f(f2bf(acc_dk[wt][d][e] * p.scale));
       if (p.rope) rope_inverse_tiles<DT>(dkv, p.rope, min(key, p.T - 1), g);
 #pragma unroll
       for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(dkv[d][e]); ov[d][e] = f2bf(acc_dv[d][e]); }
+        for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(dkv[d][e]); ov[d][e] = f2bf(acc_dv[wt][d][e]); }
       store_rows<DT>(stage, ok, p.dk + ((long long)b * p.T + key0) * p.lddk + hk * D, p.lddk, p.T - key0, lane);
       store_rows<DT>(stage, ov, p.dv + ((long long)b * p.T + key0) * p.lddv + hk * D, p.lddv, p.T - key0, lane);
     }
@@ -691,9 +747,9 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
 // =================================== backward: dQ ===================================
 // Block = (query block of NT/4, head, batch): NT/64 waves, wave w owns queries qb0 + w*16 .. +16; loops over ST-key steps
 // (NT, ST, DEEP as in the dK/dV kernel).
-template <int D, int NT, int ST, bool DEEP, bool TR>
+template <int D, int NT, int ST, bool DEEP, bool TR, int WT = 1>
 __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
-  constexpr int QB = NT / 4;        // queries per block
+  constexpr int QB = NT / 4 * WT;   // queries per block (WT 16-query tiles per wave)
   constexpr int KS = D / 32, DT = D / 16, KT = ST / 16, KP = ST / 32;
   constexpr int TILE = ST * D * 2;
   constexpr int NTILE = TR ? 2 : 3;   // tiles per buffer
@@ -705,36 +761,43 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   // the most key steps (longest-first dispatch, as in the dK/dV kernel)
   const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);
   const int qb0 = (p.causal ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z) * QB;
-  const int q = qb0 + w * 16 + fr;
+  const int q_w0 = qb0 + w * 16 * WT;  // this wave's 16 WT queries: tile wt holds q_w0 + 16 wt + (lane & 15)
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
 
   // delta[q] = sum_d dO[q, d] * O[q, d] is computed HERE (this kernel runs first): the four lanes that share a query row hold
   // its dO fragments, so the row dot product costs one extra O load per fragment and two shuffles - and the separate
   // delta kernel (one launch per layer, 20 us at T = 316) is gone.  The result is also written out for the dK/dV kernel.
-  bf16x8_t qf[KS], dof[KS];
-  float dl = 0.f;
+  bf16x8_t qf[WT][KS], dof[WT][KS];
+  float dl[WT], lse[WT];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0}, o8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (q < p.T) {
-      a = *reinterpret_cast<const u16x8_t*>(p.q + ((long long)b * p.T + q) * p.ldq + h * D + ks * 32 + g * 8);
-      c = *reinterpret_cast<const u16x8_t*>(p.dout + ((long long)b * p.T + q) * p.ldo + h * D + ks * 32 + g * 8);
-      o8 = *reinterpret_cast<const u16x8_t*>(p.o + ((long long)b * p.T + q) * p.ldo + h * D + ks * 32 + g * 8);
+  for (int wt = 0; wt < WT; ++wt) {
+    const int q = q_w0 + wt * 16 + fr;
+    dl[wt] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0}, o8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (q < p.T) {
+        a = *reinterpret_cast<const u16x8_t*>(p.q + ((long long)b * p.T + q) * p.ldq + h * D + ks * 32 + g * 8);
+        c = *reinterpret_cast<const u16x8_t*>(p.dout + ((long long)b * p.T + q) * p.ldo + h * D + ks * 32 + g * 8);
+        o8 = *reinterpret_cast<const u16x8_t*>(p.o + ((long long)b * p.T + q) * p.ldo + h * D + ks * 32 + g * 8);
+      }
+      qf[wt][ks] = __builtin_bit_cast(bf16x8_t, a);
+      dof[wt][ks] = __builtin_bit_cast(bf16x8_t, c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl[wt] += bf2f(c[e]) * bf2f(o8[e]);
     }
-    qf[ks] = __builtin_bit_cast(bf16x8_t, a);
-    dof[ks] = __builtin_bit_cast(bf16x8_t, c);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dl += bf2f(c[e]) * bf2f(o8[e]);
+    dl[wt] += __shfl_xor(dl[wt], 16, 64);
+    dl[wt] += __shfl_xor(dl[wt], 32, 64);
+    if (g == 0 && q < p.T) p.delta[((long long)b * p.Hq + h) * p.T + q] = dl[wt];
+    lse[wt] = q < p.T ? p.lse[((long long)b * p.Hq + h) * p.T + q] : __builtin_huge_valf();
   }
-  dl += __shfl_xor(dl, 16, 64);
-  dl += __shfl_xor(dl, 32, 64);
-  if (g == 0 && q < p.T) p.delta[((long long)b * p.Hq + h) * p.T + q] = dl;
-  const float lse = q < p.T ? p.lse[((long long)b * p.Hq + h) * p.T + q] : __builtin_huge_valf();
 
-  f32x4_t acc[DT];
+  f32x4_t acc[WT][DT];
 #pragma unroll
-  for (int d = 0; d < DT; ++d) acc[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+    for (int d = 0; d < DT; ++d) acc[wt][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   int kend = p.T;
   if (p.causal) kend = min(kend, qb0 + QB);
@@ -766,51 +829,65 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
   auto compute = [&](int cur) {
     const int ks0 = cks;
     cks += ST;
-    const int q_w0 = qb0 + w * 16;  // this wave's 16 queries
-    // every pair of this wave's tile masked (its queries lie before the step's first key, or past the sequence): nothing to add
-    if ((p.causal && ks0 > q_w0 + 15) || q_w0 >= p.T || (p.window > 0 && ks0 + ST - 1 <= q_w0 - p.window)) return;
+    constexpr int QW = 16 * WT;     // this wave's queries: q_w0 .. q_w0 + QW - 1
+    // every pair of this wave's tiles masked (its queries lie before the step's first key, or past the sequence): nothing to add
+    if ((p.causal && ks0 > q_w0 + QW - 1) || q_w0 >= p.T || (p.window > 0 && ks0 + ST - 1 <= q_w0 - p.window)) return;
     const char* ldsK = ldsAll + cur * NTILE * TILE;
     const char* ldsV = ldsK + TILE;
     const char* ldsKT = ldsK + 2 * TILE;      // (!TR)
-    f32x4_t s[KT], dp[KT];
+    f32x4_t s[WT][KT], dp[WT][KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-      s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int wt = 0; wt < WT; ++wt) { s[wt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[wt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t a = lds_b128(ldsK + nat_off<D>(t * 16 + fr, ks * 4 + g));
+        const bf16x8_t a = lds_b128(ldsK + nat_off<D>(t * 16 + fr, ks * 4 + g));     // (read ONCE for all WT query tiles)
         const bf16x8_t c = lds_b128(ldsV + nat_off<D>(t * 16 + fr, ks * 4 + g));
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[t], 0, 0, 0);     // S^T[key][q]
-        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dof[ks], dp[t], 0, 0, 0);  // dP^T[key][q]
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt) {
+          s[wt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[wt][ks], s[wt][t], 0, 0, 0);     // S^T[key][q]
+          dp[wt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, dof[wt][ks], dp[wt][t], 0, 0, 0);  // dP^T[key][q]
+        }
       }
     }
-    float ds[KT][4];
-    bool need_mask = ks0 < k_lo || ks0 + ST > k_hi || q_w0 + 16 > p.T;
+    float ds[WT][KT][4];
+    bool need_mask = ks0 < k_lo || ks0 + ST > k_hi || q_w0 + QW > p.T;
     if (p.causal) need_mask = need_mask || ks0 + ST - 1 > q_w0;
     if (p.block > 0) need_mask = need_mask || (ks0 + ST - 1) / p.block > q_w0 / p.block;
-    if (p.window > 0) need_mask = need_mask || ks0 <= q_w0 + 15 - p.window;
-    unsigned okbits = 0xffffu;        // bit t*4 + e: the (key, query) pair of that accumulator element takes part
+    if (p.window > 0) need_mask = need_mask || ks0 <= q_w0 + QW - 1 - p.window;
+    unsigned okbits[WT];              // bit t*4 + e: the (key, query) pair of that accumulator element takes part
+#pragma unroll
+    for (int wt = 0; wt < WT; ++wt) okbits[wt] = 0xffffu;
     if (need_mask) {
-      okbits = 0u;
+#pragma unroll
+      for (int wt = 0; wt < WT; ++wt) {
+        const int q = q_w0 + wt * 16 + fr;
+        okbits[wt] = 0u;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int key = ks0 + t * 16 + g * 4 + e;
+            okbits[wt] |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block, p.window)) << (t * 4 + e);
+          }
+      }
+    }
+#pragma unroll
+    for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
       for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int key = ks0 + t * 16 + g * 4 + e;
-          okbits |= (unsigned)((q < p.T) & key_ok(key, q, k_lo, k_hi, p.causal, p.block, p.window)) << (t * 4 + e);
+          const float ev = __builtin_amdgcn_exp2f(s[wt][t][e] * p.sc - lse[wt]);
+          const float pv = (okbits[wt] >> (t * 4 + e)) & 1u ? ev : 0.f;
+          ds[wt][t][e] = pv * (dp[wt][t][e] - dl[wt]);
         }
-    }
+    bf16x8_t dsB[WT][KP];
 #pragma unroll
-    for (int t = 0; t < KT; ++t)
+    for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float ev = __builtin_amdgcn_exp2f(s[t][e] * p.sc - lse);
-        const float pv = (okbits >> (t * 4 + e)) & 1u ? ev : 0.f;
-        ds[t][e] = pv * (dp[t][e] - dl);
-      }
-    bf16x8_t dsB[KP];
-#pragma unroll
-    for (int kp = 0; kp < KP; ++kp) dsB[kp] = pack8(ds[2 * kp], ds[2 * kp + 1]);
+      for (int kp = 0; kp < KP; ++kp) dsB[wt][kp] = pack8(ds[wt][2 * kp], ds[wt][2 * kp + 1]);
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       const int row = d * 16 + fr;
@@ -819,7 +896,8 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
         bf16x8_t a;
         if constexpr (TR) a = tr_frag<D>(ldsK, kp * 32, d * 16, lane);
         else a = lds_2xb64(ldsKT + tr_off8<ST>(row, kp * 8 + g), ldsKT + tr_off8<ST>(row, kp * 8 + 4 + g));
-        acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB[kp], acc[d], 0, 0, 0);  // dQ^T[d][q]
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt) acc[wt][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsB[wt][kp], acc[wt][d], 0, 0, 0);  // dQ^T[d][q]
       }
     }
   };
@@ -849,20 +927,23 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
       __syncthreads();
     }
   }
-  if (qb0 + w * 16 < p.T) {   // wave-uniform; rows leave through the (now free) staging buffers as 128-byte segments
+#pragma unroll
+  for (int wt = 0; wt < WT; ++wt) {
+    const int q0 = q_w0 + wt * 16, q = q0 + fr;
+    if (q0 >= p.T) continue;   // wave-uniform; rows leave through the (now free) staging buffers as 128-byte segments
     char* stage = ldsAll + w * STAGE_BYTES;
     float dqv[DT][4];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dqv[d][e] = bf2f(f2bf(acc[d][e] * p.scale));
+      for (int e = 0; e < 4; ++e) dqv[d][e] = bf2f(f2bf(acc[wt][d][e] * p.scale));
     if (p.rope) rope_inverse_tiles<DT>(dqv, p.rope, min(q, p.T - 1), g);
     u16x4_t oq[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int e = 0; e < 4; ++e) oq[d][e] = f2bf(dqv[d][e]);
-    store_rows<DT>(stage, oq, p.dq + ((long long)b * p.T + qb0 + w * 16) * p.lddq + h * D, p.lddq, p.T - (qb0 + w * 16), lane);
+    store_rows<DT>(stage, oq, p.dq + ((long long)b * p.T + q0) * p.lddq + h * D, p.lddq, p.T - q0, lane);
   }
 }
 
@@ -1242,7 +1323,11 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
   if (d.D == 64) {
     if (qt == 4) FWD(64, 4);
     else if (qt == 3) FWD(64, 3);
-    else if (qt == 2) FWD(64, 2);
+    else if (qt == 2) {
+      // tuning option 20 = 1: the rounds 1-5 form of the row max (ds_bpermute shuffles) - A/B only, bit-identical
+      if (g_options[20] == 1 && tr) hipLaunchKernelGGL((attn_fwd_k<64, 2, true, false>), grid, dim3(256), 0, st, a);
+      else FWD(64, 2);
+    }
     else FWD(64, 1);
   } else if (d.D == 128) {
     if (qt == 2) FWD(128, 2);
@@ -1278,18 +1363,18 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   a.tl = (unsigned long long*)g_attn_tl;
   // dQ first: it computes delta = rowsum(dO * O) on the fly and leaves it in d.delta for the dK/dV kernel
   const int kv_heads = a.dkv_part ? d.f.Hq : d.f.Hkv;
-  dim3 gk(kv_heads, d.f.B, cdiv(d.f.T, 64)), gk128(kv_heads, d.f.B, cdiv(d.f.T, 128)), gq(d.f.Hq, d.f.B, cdiv(d.f.T, 64));
   // head_dim 128 (the LLM): 128 queries / keys per block (8 waves), 32-row steps, two-deep prefetch.  64-row steps (ST = 64,
   // with or without the second staging set) were measured within 3 % of this at the C2 shape in round 2 and again on the
   // transposing-read kernels in round 3 (85.15 vs 84.96 ms per step, profiles/r03_call5_ab.txt): not instantiated.
   const bool tr = attention_tr_reads(dtype);   // natural tiles + transposing LDS reads (no Q^T / K^T / dO^T copies) - option 12
   UVX_CHECK(tr || (d.qt && d.kt && d.dot), UVX_ERR_INVALID, "attention_bwd: transposed operand copies are null");
   UVX_CHECK(d.f.v != nullptr, UVX_ERR_INVALID, "attention_bwd: v is null");
-#define BWD(DD, NTH, STEP, DEEP, GQ, GK) do { \
-    if (tr) { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, STEP, DEEP, true>), GQ, dim3(NTH), 0, st, a); \
-              hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, true>), GK, dim3(NTH), 0, st, a); } \
-    else { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, STEP, DEEP, false>), GQ, dim3(NTH), 0, st, a); \
-           hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, false>), GK, dim3(NTH), 0, st, a); } } while (0)
+#define BWD(DD, NTH, STEP, DEEP, WQ, WK) do { \
+    const dim3 GQ(d.f.Hq, d.f.B, cdiv(d.f.T, (NTH) / 4 * (WQ))), GK(kv_heads, d.f.B, cdiv(d.f.T, (NTH) / 4 * (WK))); \
+    if (tr) { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, STEP, DEEP, true, WQ>), GQ, dim3(NTH), 0, st, a); \
+              hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, true, WK>), GK, dim3(NTH), 0, st, a); } \
+    else { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, STEP, DEEP, false, WQ>), GQ, dim3(NTH), 0, st, a); \
+           hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, false, WK>), GK, dim3(NTH), 0, st, a); } } while (0)
   // head_dim 128, causal, at most 320 positions (the LLM's training sequences): ONE fused kernel per (batch, query head) -
   // S and dP once, dS through LDS (tuning option 13, default on)
   constexpr int FUSED_TMAX = 320;
@@ -1299,13 +1384,28 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
     constexpr int smem = (FUSED_TMAX / 16) * (FUSED_TMAX / 16 + 1) / 2 * 512 + 2 * 64 * 128 * 2 + 2 * FUSED_TMAX * 4 + 8 * STAGE_BYTES;
     static_assert(smem <= 160 * 1024, "LDS of one CU");
     static PerDeviceOnce attr_set;
-    if (attr_set.need()) UVX_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_k<128, FUSED_TMAX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    UVX_SET_ATTR_ONCE(attr_set, (attn_bwd_fused_k<128, FUSED_TMAX, 2>), smem);
     // (64-query steps, NQT = 4: 87.9 vs 87.5 ms per step - profiles/r03_call13_probes.txt - not instantiated)
     hipLaunchKernelGGL((attn_bwd_fused_k<128, FUSED_TMAX, 2>), dim3(d.f.Hq, d.f.B), dim3(512), smem, st, a);
   }
-  else if (d.f.D == 64) BWD(64, 256, 32, true, gq, gk);
-  else if (d.f.D == 128) BWD(128, 512, 32, true, dim3(d.f.Hq, d.f.B, cdiv(d.f.T, 128)), gk128);
-  else BWD(256, 256, 32, false, gq, gk);
+  else if (d.f.D == 64) {
+    // head_dim 64 (the Whisper tower under LoRA training, 1500 frames): WQ / WK = 16-row tiles per wave of the dQ / dK,dV kernel.  Two
+    // tiles per wave read every staged K / V (Q / dO) fragment once for twice the MFMAs and halve the steps + barriers per output row
+    // (bit-identical: each output element still sums its steps in the same order).  Measured (profiles/r06_attn_bwd64_ab.txt, B = 8, 16
+    // heads, 1500 frames, pair per layer): one tile each 393.9 us, dQ x2 388.9, both x2 391.0, dK,dV x2 only 399.4, 64-row steps 556,
+    // eight-wave blocks 450-469 - a 1 % effect: the pair is latency-, not bandwidth-bound.  Tuning option 19 picks the form (A/B).
+    switch (g_options[19]) {
+      case 1: BWD(64, 256, 32, true, 1, 1); break;     // rounds 1-5: one tile per wave
+      case 2: BWD(64, 256, 32, true, 2, 2); break;
+      case 3: BWD(64, 256, 32, true, 1, 2); break;
+      case 4: BWD(64, 256, 64, true, 2, 2); break;     // 64-row steps
+      case 5: BWD(64, 512, 64, true, 1, 1); break;     // eight waves, 128 rows per block
+      case 6: BWD(64, 512, 64, true, 2, 1); break;     // (two dK,dV tiles per wave of a 512-thread block spill)
+      default: BWD(64, 256, 32, true, 2, 1); break;
+    }
+  }
+  else if (d.f.D == 128) BWD(128, 512, 32, true, 1, 1);
+  else BWD(256, 256, 32, false, 1, 1);
 #undef BWD
   if (a.dkv_part) {
     const long long n16 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 16);

@@ -151,22 +151,40 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float pe = poly * e;                       // = erfc(|x|/sqrt2): no cancellation in the negative tail
   return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
 }
+// d gelu(x) / dx = Phi(x) + x phi(x) with the same erfc approximation (and the same exp2) as gelu_fast: the bf16 path's GELU backward,
+// as a kernel of its own (gelu_bwd_k) and inside the GEMM epilogue (GemmDesc::act == 3) - one arithmetic, bit-identical either way.
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);      // exp(-x^2 / 2)
+  const float hp = 0.5f * poly * e;                                           // erfc(|x| / sqrt 2) / 2
+  return (x < 0.f ? hp : 1.0f - hp) + x * (0.3989422804014327f * e);
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: one of these per call site remembers which
 // devices have had it set (bit d of the mask; ADVICE r4: a process-wide `static bool` would leave a second device of the same process
-// at the 64 KB default).  Two threads may both see "not yet" and both set it - harmless, the call is idempotent.
+// at the 64 KB default).  The bit is published by done() AFTER the attribute call succeeded: a second host thread either
+// sees the bit - and the attribute is in place - or sets the attribute itself (idempotent); a failed call leaves the bit clear and is
+// retried by the next launch.  Use through UVX_SET_ATTR_ONCE.
 #include <atomic>
 struct PerDeviceOnce {
   std::atomic<unsigned long long> mask{0};
-  bool need() {
+  static unsigned long long bit() {
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess) return true;
-    const unsigned long long bit = 1ull << (d & 63);
-    if (mask.load(std::memory_order_relaxed) & bit) return false;
-    mask.fetch_or(bit, std::memory_order_relaxed);
-    return true;
+    if (hipGetDevice(&d) != hipSuccess) return 0;      // unknown device: set the attribute every time, never publish
+    return 1ull << (d & 63);
   }
+  bool need() const { const unsigned long long b = bit(); return b == 0 || !(mask.load(std::memory_order_acquire) & b); }
+  void done() { mask.fetch_or(bit(), std::memory_order_release); }
 };
+#define UVX_SET_ATTR_ONCE(once, fn, bytes)                                                                          \
+  do {                                                                                                              \
+    if ((once).need()) {                                                                                            \
+      UVX_HIP(hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));    \
+      (once).done();                                                                                                \
+    }                                                                                                               \
+  } while (0)

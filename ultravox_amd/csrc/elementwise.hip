@@ -420,7 +420,8 @@ __global__ void cast_from_f32_k(const float* __restrict__ in, T* __restrict__ ou
 }
 
 // GELU as a separate pass (encoder LoRA training keeps the pre-activation for the backward pass).  Forward = the
-// arithmetic of the fused GEMM epilogue (bf16: gelu_fast + round; f32: erff); backward = exact derivative.
+// arithmetic of the fused GEMM epilogue (bf16: gelu_fast + round; f32: erff); backward = the derivative (bf16: gelu_fast_grad,
+// the arithmetic of the act == 3 GEMM epilogue; f32: erff / expf).
 template <typename T>
 __global__ void gelu_fwd_k(const T* __restrict__ pre, T* __restrict__ out, long long n8) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -440,6 +441,7 @@ __global__ void gelu_bwd_k(const T* __restrict__ dout, const T* __restrict__ pre
   ld8<T>(dout + i * 8, g);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
+    if (sizeof(T) == 2) { g[k] *= gelu_fast_grad(x[k]); continue; }     // bf16: the arithmetic of the fused epilogue (GemmDesc::act == 3)
     const float cdf = 0.5f * (1.0f + erff(x[k] * 0.70710678118654752440f));
     const float pdf = 0.3989422804014327f * expf(-0.5f * x[k] * x[k]);
     g[k] *= cdf + x[k] * pdf;

@@ -101,6 +101,10 @@ __device__ __forceinline__ void frag_pair_swap(uint32_t (&a)[2], uint32_t (&b)[2
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 __device__ __forceinline__ float unpack_lo(uint32_t v) { return bf2f((bf16_t)(v & 0xffffu)); }
 __device__ __forceinline__ float unpack_hi(uint32_t v) { return bf2f((bf16_t)(v >> 16)); }
+// act == 3 (GELU backward): two bf16 gradients x gelu'(two bf16 pre-activations), rounded
+__device__ __forceinline__ uint32_t mul_gelu_grad2(uint32_t d, uint32_t x) {
+  return pack2(unpack_lo(d) * gelu_fast_grad(unpack_lo(x)), unpack_hi(d) * gelu_fast_grad(unpack_hi(x)));
+}
 // fragment-layout pair -> one 16-byte store at `dst` (the lane's row / 8-column slot), if ok
 __device__ __forceinline__ void store_pair16(bf16_t* dst, bool ok, uint32_t (&a)[2], uint32_t (&b)[2]) {
   frag_pair_swap(a, b);
@@ -193,7 +197,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
   }
   if (NJ == 4 && stage && p.wide_io == 2 && bf16_out && p.swiglu != 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.sC & 7) == 0 &&
       ((uintptr_t)p.C & 15) == 0 &&
-      (p.swiglu == 0 || ((p.ldc2 & 7) == 0 && ((uintptr_t)p.C2 & 15) == 0)) &&
+      ((p.swiglu == 0 && p.act < 2) || ((p.ldc2 & 7) == 0 && ((uintptr_t)p.C2 & 15) == 0)) &&
       (!p.residual || ((p.ldr & 7) == 0 && (p.sR & 7) == 0 && ((uintptr_t)p.residual & 15) == 0))) {
     constexpr int ROWS = GI * 16;
     static_assert(MI % GI == 0, "row fragments per pass must divide the wave tile");
@@ -224,7 +228,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float t = bf2f(f2bf(acc[j][i0 + ii][e] * p.alpha + bv[j][e]));
-            if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));
+            if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));      // (act 2: C keeps the pre-activation, pass 2 writes gelu; act 3: below)
             v[e] = t;
           }
           *reinterpret_cast<uint2*>(stage_slot<ROWS, 8>(stage, ii * 16 + frow, 2 * j + (fg >> 1)) + (fg & 1) * 8) =
@@ -239,6 +243,10 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
           const int row = it * 8 + (lane >> 3), m = m_base + i0 * 16 + row;
           uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 8>(stage, row, c8));
           if (m < p.M && n8 < p.N) {
+            if (p.act == 3) {       // GELU backward: the saved pre-activation arrives as whole lines, like a residual
+              const uint4 x = *reinterpret_cast<const uint4*>(p.C2 + (long long)m * p.ldc2 + n8);
+              o.x = mul_gelu_grad2(o.x, x.x); o.y = mul_gelu_grad2(o.y, x.y); o.z = mul_gelu_grad2(o.z, x.z); o.w = mul_gelu_grad2(o.w, x.w);
+            }
             if (p.residual) {
               const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
               const uint4 r = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
@@ -250,6 +258,30 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
             *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n8) = o;
           }
         }
+      }
+      if (p.act == 2) {
+        // ---- pass 2 (GELU that keeps its pre-activation): round(gelu(round(acc * alpha + bias))), [ROWS x 64] -> C2 ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pass-1 reads done before the slice is overwritten
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int ii = 0; ii < GI; ++ii) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(bf2f(f2bf(acc[j][i0 + ii][e] * p.alpha + bv[j][e])));
+            *reinterpret_cast<uint2*>(stage_slot<ROWS, 8>(stage, ii * 16 + frow, 2 * j + (fg >> 1)) + (fg & 1) * 8) =
+                make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int c8 = lane & 7, n8 = n_base + c8 * 8;
+#pragma unroll
+        for (int it = 0; it < ROWS / 8; ++it) {
+          const int row = it * 8 + (lane >> 3), m = m_base + i0 * 16 + row;
+          const uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 8>(stage, row, c8));
+          if (m < p.M && n8 < p.N) *reinterpret_cast<uint4*>(p.C2 + (long long)m * p.ldc2 + n8) = o;
+        }
+        continue;
       }
       if (p.swiglu != 1) continue;
       // ---- pass 2 (fused SwiGLU): act = round(silu(gate)) * up, [ROWS x 32] -> C2; gate = fragment j (even), up = j + 1 ----
@@ -433,7 +465,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
     return;
   }
   // bf16 output: 16-byte stores (and residual loads) for the paired row fragments; the rest takes the 8-byte path below
-  const bool wide_store = p.wide_io && bf16_out && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.sC & 7) == 0 && ((uintptr_t)p.C & 15) == 0;
+  const bool wide_store = p.wide_io && bf16_out && p.act < 2 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.sC & 7) == 0 && ((uintptr_t)p.C & 15) == 0;
   const bool wide_res = p.residual && p.res_mod == 0 && (p.ldr & 7) == 0 && (p.sR & 7) == 0 && ((uintptr_t)p.residual & 15) == 0;
   if (wide_store) {
 #pragma unroll
@@ -503,6 +535,19 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
         }
         v[e] = t;
       }
+      if (p.act >= 2) {       // (bf16 output only - gemm_nt checks; fragment-layout form of the staged passes above)
+        bf16_t* x2 = p.C2 + (long long)m * p.ldc2 + n;
+        if (p.act == 2) {
+          u16x4_t g4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g4[e] = f2bf(gelu_fast(v[e]));
+          *reinterpret_cast<u16x4_t*>(x2) = g4;
+        } else {
+          const u16x4_t x4 = *reinterpret_cast<const u16x4_t*>(x2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= gelu_fast_grad(bf2f(x4[e]));
+        }
+      }
       if (p.residual) {
         const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
         u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.residual + z * p.sR + (long long)rm * p.ldr + n);
@@ -523,6 +568,58 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
         }
         *dst = make_float4(v[0], v[1], v[2], v[3]);
       }
+    }
+  }
+}
+
+// Epilogue of the 32 x 32 x 16 kernels (M32): acc[nb][im] is the 32 x 32 accumulator of output columns n_base + 32 nb + .. and rows
+// m_base + 32 im + ..; element e of lane l: column 8 (e >> 2) + 4 (l >> 5) + (e & 3), row l & 31 (the MFMA's D rows are the W rows).
+// Plain epilogues only - bias, GELU (act 1), residual, bf16 output, 16-byte-aligned operands (launch_variant sends everything else to the
+// 16 x 16 x 32 twin): the wave parks its IM * 32 rows x 64 columns as bf16 in its LDS slice and stores whole 128-byte lines, with
+// store_tile's arithmetic and rounding points.
+template <int IM>
+__device__ __forceinline__ void store_tile32(const GemmArgs& p, f32x16_t (&acc)[2][IM], int m_base, int n_base, int lane, long long z, char* stage) {
+  constexpr int ROWS = IM * 32;
+  const int r32 = lane & 31, h32 = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n_base + nb * 32 + q * 8 + h32 * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.N) {
+        const u16x4_t b4 = *reinterpret_cast<const u16x4_t*>(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+      }
+#pragma unroll
+      for (int im = 0; im < IM; ++im) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = bf2f(f2bf(acc[nb][im][q * 4 + e] * p.alpha + bv[e]));
+          if (p.act == 1) t = bf2f(f2bf(gelu_fast(t)));
+          v[e] = t;
+        }
+        *reinterpret_cast<uint2*>(stage_slot<ROWS, 8>(stage, im * 32 + r32, nb * 4 + q) + h32 * 8) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+      }
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int c8 = lane & 7, n8 = n_base + c8 * 8;
+#pragma unroll
+  for (int it = 0; it < ROWS / 8; ++it) {
+    const int row = it * 8 + (lane >> 3), m = m_base + row;
+    uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 8>(stage, row, c8));
+    if (m < p.M && n8 < p.N) {
+      if (p.residual) {
+        const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+        const uint4 r = *reinterpret_cast<const uint4*>(p.residual + z * p.sR + (long long)rm * p.ldr + n8);
+        o.x = pack2(unpack_lo(o.x) + unpack_lo(r.x), unpack_hi(o.x) + unpack_hi(r.x));
+        o.y = pack2(unpack_lo(o.y) + unpack_lo(r.y), unpack_hi(o.y) + unpack_hi(r.y));
+        o.z = pack2(unpack_lo(o.z) + unpack_lo(r.z), unpack_hi(o.z) + unpack_hi(r.z));
+        o.w = pack2(unpack_lo(o.w) + unpack_lo(r.w), unpack_hi(o.w) + unpack_hi(r.w));
+      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + z * p.sC + (long long)m * p.ldc + n8) = o;
     }
   }
 }
@@ -704,9 +801,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 // Progress: owners wait only on blocks of higher index, a contribution never waits, and blocks are dispatched in index
 // order, so the wait ends as soon as the needed blocks are resident; a bounded spin (then a counted timeout and a wrong
 // tile, never a hung queue) guards the case of a device with < 9 free CUs.  Deterministic: fixed ranges, fixed sum order.
-template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false, int PH = 4, bool SK = false>
+// M32 (round 6, variants 61 / 62): the merged-phase kernel on v_mfma_f32_32x32x16_bf16 - the same tile, wave grid, DMA schedule and LDS
+// regions, 8 accumulators of 32 x 32 per wave instead of 32 of 16 x 16: half the MFMA issues and half the operand-register reads per flop
+// (a power experiment on a clock-capped matrix pipe; round 1 measured a 32 x 32 flavour of a kernel two generations older 10-20 % slower).
+// A 32-row operand read has 16 lanes of one LDS lane group on 16 rows of the SAME 16-byte chunk column; rows are 128 bytes, so with the
+// production swizzle (chunk ^ (row & 7)) rows r and r + 8 collide - two-way conflicts on every fragment read.  The M32 image is therefore
+// swizzled with (row >> 1) & 7, which is distinct over the 8 even and the 8 odd rows of every ds_read_b128 lane group
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and their upper-half twins).  k order inside a K-tile = ascending 16-column steps: the
+// summation order differs from the 16 x 16 x 32 kernels (two 32-column steps), results agree to f32 rounding, not bitwise.
+template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false, int PH = 4, bool SK = false, bool M32 = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   static_assert(PH == 4 || (PH == 2 && (NS == 2 || NS == 3) && MODE == 0), "the merged-phase schedule: two or three buffer sets");
+  static_assert(!M32 || (PH == 2 && !PERSIST && !SK && (BM / 32) % 4 == 0), "32 x 32 MFMAs: merged-phase schedule, 32-row halves");
   static_assert(!SK || (PH == 2 && !PERSIST), "stream-K is built on the merged-phase kernel");
   constexpr int BNW = 256;
   constexpr int MI = BM / 32, MA = (MI + 1) / 2, MB = MI - MA;
@@ -794,18 +900,20 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
 
   // one DMA instruction = rows 8q .. 8q+7 of a region; lane -> row 8q + (lane >> 3), LDS chunk position lane & 7
   // holds source chunk (lane & 7) ^ (row & 7)
+  // (M32: the image is swizzled with (region row >> 1) & 7 instead of row & 7 - see the template comment; region row = 8 q + srow)
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+  auto sch = [&](int q) { return M32 ? ((lane & 7) ^ (((q * 8 + srow) >> 1) & 7)) : schunk; };
   struct Slot { const bf16_t* g; int off; };
   auto x_slot = [&](bool half_b, int q) {
     const int per = (half_b ? MB : MA) * 16;
     const int hr = q * 8 + srow, wrr = hr / per, rem = hr - wrr * per;
     const int row = wrr * (BM / 2) + (half_b ? MA * 16 : 0) + rem;
-    return Slot{A + (long long)min(m0 + row, p.M - 1) * p.lda + schunk * 8, (half_b ? O_XB : O_XA) + q * 1024};
+    return Slot{A + (long long)min(m0 + row, p.M - 1) * p.lda + sch(q) * 8, (half_b ? O_XB : O_XA) + q * 1024};
   };
   auto w_slot = [&](bool half_b, int q) {
     const int hr = q * 8 + srow;
     const int n = (hr >> 5) * 64 + (half_b ? 32 : 0) + (hr & 31);
-    return Slot{B + (long long)min(n0 + n, p.N - 1) * p.ldb + schunk * 8, (half_b ? O_WB : O_WA) + q * 1024};
+    return Slot{B + (long long)min(n0 + n, p.N - 1) * p.ldb + sch(q) * 8, (half_b ? O_WB : O_WA) + q * 1024};
   };
   Slot sxb[N1], srest[N234];
   auto fill_slots = [&](Slot (&sxb_)[N1], Slot (&srest_)[N234]) {   // for the tile at (m0, n0)
@@ -895,11 +1003,27 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
   __builtin_amdgcn_sched_barrier(0);
 
-  f32x4_t acc[4][MI];
+  f32x4_t acc[4][MI];                    // (unused - and removed by the compiler - in the M32 build)
+  f32x16_t acc32[2][(MI + 1) / 2];       // (M32) [WA | WB][32-row block of X: MA / 2 from half A, then MB / 2 from half B]
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < (MI + 1) / 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc32[j][i][e] = 0.f;
+  // (M32) fragment byte offsets: row r32 = lane & 31 of a 32-row block, 16-byte chunk 2 ks + (lane >> 5) of its K-tile row
+  const int r32 = lane & 31, h32 = lane >> 5;
+  int wo32[4], xo32[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int rw = wc * 32 + r32;                       // row inside the WA / WB region
+    wo32[ks] = rw * 128 + (((2 * ks + h32) ^ ((rw >> 1) & 7)) << 4);
+    xo32[ks] = r32 * 128 + (((2 * ks + h32) ^ ((r32 >> 1) & 7)) << 4);     // (+ a multiple of 32 rows: the swizzle key is unchanged)
+  }
 
   int cs = 0;   // t % NS
   typedef __attribute__((address_space(3))) unsigned lds_u32;
@@ -909,6 +1033,59 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     const char* set = lds + cs * SET;
     const int ps = cs == 0 ? NS - 1 : cs - 1;   // (t + NS - 1) % NS
     bf16x8_t xa[MA][2], wa[2][2], wb[2][2];
+    if constexpr (M32) {
+      constexpr int XH = MA / 2;      // 32-row blocks of X per half and wave row
+      bf16x8_t wa3[4], wb3[4], x3[XH][4];
+      // ---- section A: read XA, WA, WB; DMA: XB of tile t+1; wait: XB(t) ----
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        wa3[ks] = *reinterpret_cast<const bf16x8_t*>(set + O_WA + wo32[ks]);
+        wb3[ks] = *reinterpret_cast<const bf16x8_t*>(set + O_WB + wo32[ks]);
+      }
+#pragma unroll
+      for (int i = 0; i < XH; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x3[i][ks] = *reinterpret_cast<const bf16x8_t*>(set + xa_base + xo32[ks] + i * 32 * 128);
+      if (t + NS - 1 < nks) {
+#pragma unroll
+        for (int k = 0; k < N1; ++k) dma(sxb[k], t + NS - 1, ps);
+        UVX_VMCNT((NS - 1) * (N234 + N1));
+      } else {
+        UVX_VMCNT(0);
+      }
+      UVX_PHASE_SYNC();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < XH; ++i) acc32[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa3[ks], x3[i][ks], acc32[0][i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < XH; ++i) acc32[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb3[ks], x3[i][ks], acc32[1][i], 0, 0, 0);
+      }
+      UVX_PHASE_END();
+      // ---- section B: read XB (WA, WB stay in registers); DMA: [XA | WA | WB] of tile t+2; wait: REST(t+1) ----
+#pragma unroll
+      for (int i = 0; i < XH; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x3[i][ks] = *reinterpret_cast<const bf16x8_t*>(set + xb_base + xo32[ks] + i * 32 * 128);
+      if (t + NS < nks) {
+#pragma unroll
+        for (int k = 0; k < N234; ++k) dma(srest[k], t + NS, cs);
+        UVX_VMCNT((NS - 1) * (N234 + N1));
+      } else {
+        UVX_VMCNT(0);
+      }
+      UVX_PHASE_SYNC();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int i = 0; i < XH; ++i) acc32[1][XH + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb3[ks], x3[i][ks], acc32[1][XH + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < XH; ++i) acc32[0][XH + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa3[ks], x3[i][ks], acc32[0][XH + i], 0, 0, 0);
+      }
+      UVX_PHASE_END();
+      cs = cs == NS - 1 ? 0 : cs + 1;
+      continue;
+    }
     if (PH == 2) {
       // ---- section A: read XA, WA, WB; DMA: XB of tile t+1; wait: XB(t) (issued one K-tile ago) ----
 #pragma unroll
@@ -1147,7 +1324,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   }
   if (!PERSIST) {
     __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
-    store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
+    if constexpr (M32) store_tile32<(MI + 1) / 2>(p, acc32, m0 + wr * (BM / 2), n0 + wc * 64, lane, z, lds + w * (MI * 16 * 128));
+    else store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
     break;
   }
   // every wave has passed its last fragment read (the barriers above): the operand buffers are free.  Start the next
@@ -1472,7 +1650,7 @@ struct Variant { int bm, bn; double speed; double c; };
 // as the training step does: 16 GB of frozen weights per pass never sit in the 256 MB Infinity Cache, and a
 // back-to-back probe on one weight buffer overstates the shallow-prefetch kernels by 10-25 % and ranks them wrongly.
 // speed 0 = probe only.
-constexpr int kNumVariants = 61;
+constexpr int kNumVariants = 63;
 const Variant kVariants[kNumVariants] = {
     {128, 128, 880., 2.},   {128, 256, 935., 4.75}, {160, 256, 1020., 4.75}, {192, 256, 1024., 4.75}, {256, 256, 1250., 8.7},
     {128, 256, 980., 9.},   {160, 256, 1106., 9.},  {192, 256, 1118., 9.},   {256, 256, 1283., 9.3},  {128, 256, 0., 9.},
@@ -1504,8 +1682,14 @@ const Variant kVariants[kNumVariants] = {
     // 55 = eight waves, PING-PONG by wave row (pure MFMA phase / load phase, DMA split by operand); 56..58 = its timing probes
     {256, 256, 0., 7.},     {256, 256, 0., 7.},      {256, 256, 0., 7.},     {256, 256, 0., 7.},
     // 59, 60 = merged-phase {160,128} x 256 with THREE buffer sets (round 5): twice the DMA look-ahead, for problems whose weights all come
-    // from HBM (the prefill).  Speed 0: the training-shape picker never takes them; pick_split does (kt1_us).
-    {160, 256, 0., 9.},     {128, 256, 0., 6.}};
+    // from HBM (the prefill).  Measured within +-2 % of their two-set twins 33 / 34 at every prefill shape and split factor
+    // (profiles/r05_gemm_splitk_probe_three_buffer_sets.txt), so NEITHER picker takes them: speed 0 keeps them out of pick_variant, and
+    // pick_split's filter admits only 0 and 31..34 unless a variant is forced.  They stay in the product library as forced / override-table
+    // choices (uvx_gemm_force_variant, uvx_gemm_override_variant) with their bit-identity test against the twins.
+    {160, 256, 0., 9.},     {128, 256, 0., 6.},
+    // 61, 62 = merged-phase {256,128} x 256 on 32 x 32 x 16 MFMAs (round 6, M32; plain epilogues - anything else runs the twin 31 / 34).
+    // Speed 0: forced / override-table choices only (profiles/r06_gemm_mfma32_probe.txt).
+    {256, 256, 0., 8.5},    {128, 256, 0., 6.}};
 // (round 5, tried: the merged-phase kernel at 320 x 256 - both 160-row tiles of a 316-row prompt in ONE block, every weight byte staged once
 //  per K-tile for all rows.  160 accumulator + 72 fragment registers per wave leave hipcc 35 spills at two waves per SIMD, and the spilled
 //  registers are the DMA source pointers: each reload sits behind an s_waitcnt vmcnt(0) inside the K loop, which drains the LDS-DMA
@@ -1513,7 +1697,8 @@ const Variant kVariants[kNumVariants] = {
    // 23..26 = persistent eight-phase {256,192,160,128} x 256   // 18, 19 = eight-phase {160,128} x 256 with three buffer sets (+1-2 % on single-round shapes)
 // The production set: 128x128 (0) and the eight-phase kernels (11, 15..19).  Everything else is a superseded family or a
 // probe build of the eight-phase kernel and exists only in libuvx_probes.so (-DUVX_PROBES); the picker never selects it.
-constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34) || v == 59 || v == 60; }
+// (59, 60: built, never picked - see the table)
+constexpr bool is_production(int v) { return v == 0 || v == 11 || (v >= 15 && v <= 19) || (v >= 31 && v <= 34) || (v >= 59 && v <= 62); }
 constexpr bool is_a4(int v) { return v >= 43 && v <= 58; }
 constexpr bool is_streamk(int v) { return v >= 39 && v <= 42; }
 bool variant_available(int v) {
@@ -1671,6 +1856,17 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 34: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2>), grid, dim3(512), st, a); break;
     case 59: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 3, 0, false, 2>), grid, dim3(512), st, a); break;
     case 60: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 3, 0, false, 2>), grid, dim3(512), st, a); break;
+    case 61: case 62: {
+      // the 32 x 32 x 16 kernels carry the plain whole-line epilogue only
+      const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+      const bool plain = !a.out_f32 && a.swiglu == 0 && a.act < 2 && a.wide_io == 2 && a.ksplit <= 1 && !a.m_dev && (a.N & 7) == 0 && (a.ldc & 7) == 0 &&
+                         (a.sC & 7) == 0 && al16(a.C) && (!a.bias || ((uintptr_t)a.bias & 7) == 0) &&
+                         (!a.residual || ((a.ldr & 7) == 0 && (a.sR & 7) == 0 && al16(a.residual)));
+      if (!plain) { launch_variant(st, variant == 61 ? 31 : 34, a, M, N, batch); return; }
+      if (variant == 61) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2, false, true>), grid, dim3(512), st, a);
+      else UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2, false, true>), grid, dim3(512), st, a);
+      break;
+    }
 #ifdef UVX_PROBES
     case 43: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<2, 8, 0>), grid, dim3(256), st, a); break;
     case 49: UVX_GEMM_LAUNCH((gemm_nt_bf16_a4_kernel<4, 8, 0>), grid, dim3(512), st, a); break;
@@ -1913,7 +2109,7 @@ SplitPick pick_split(int M, int N, int K, size_t ws_bytes, bool gelu, int force_
   const int nk = K / 64, fv = forced_variant(M, N, K);
   SplitPick best{fv >= 0 ? fv : 0, 1, 1e30};
   for (int v : {0, 34, 33, 32, 31, 59, 60, 18, 19, 11, 15, 16, 17}) {
-    if (fv >= 0 ? v != fv : (v > 34 || v < 31) && v != 0) continue;      // (outside the merged-phase set: only when forced - probes)
+    if (fv >= 0 ? v != fv : (v > 34 || v < 31) && v != 0) continue;      // (outside the two-set merged-phase kernels - incl. the three-set 59 / 60: only when forced)
     if (fv < 0 && !uvx::g_options[6] && v != 0) continue;                // (option 6 = 0, the round-1 four-phase set: A/B builds, never split)
     const long long tiles = (long long)cdiv(M, kVariants[v].bm) * cdiv(N, kVariants[v].bn);
     for (int s = 1; s <= kSplitMax; ++s) {
@@ -1986,11 +2182,16 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   // few rows: stream the weights.  Beyond 16 rows the weight-streaming kernels serve 16-row tiles one after the other (MT = 2, 4) and lose to a
   // 128 x 256 tile whose K loop is cut over 6-8 blocks wherever the caller lent split-K scratch (Llama-3.3-70B's four linears, us per
   // launch, staged kernel / tiled split-K: 32 rows 447 / 345, 64 rows 871 / 358 - profiles/r05_gemm_splitk_decode_rows.txt)
-  const bool split_ok = d.splitk_ws && d.batch <= 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
+  const bool split_ok = d.splitk_ws && d.batch <= 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.act < 2 && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
       ((uintptr_t)d.C & 15) == 0 && ((uintptr_t)d.splitk_ws & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
       (!d.residual || (d.ldr % 8 == 0 && ((uintptr_t)d.residual & 15) == 0)) &&
       (!d.swiglu || (d.ldc2 % 8 == 0 && ((uintptr_t)d.C2 & 15) == 0));      // (the reduce kernel's 16-byte accesses apply)
-  if (uvx::g_gemm_variant < 0 && !(split_ok && d.M > 16) && uvx::gemm_skinny_applicable(d)) return uvx::gemm_skinny_bf16(st, d);
+  if (uvx::g_gemm_variant < 0 && uvx::gemm_skinny_applicable(d)) {
+    // (M = 17..64 with scratch: the tiled split-K path only where the picker really splits - K/64 < 8, too little scratch or option 6 = 0
+    //  leave s = 1, and an UNSPLIT 128 x 128 / 128 x 256 tile on a handful of CUs is slower than the staged skinny kernel: ADVICE r5)
+    const bool tiled = split_ok && d.M > 16 && pick_split(d.M, d.N, d.K, d.splitk_ws_bytes, d.act == 1, d.splitk_force).s > 1;
+    if (!tiled) return uvx::gemm_skinny_bf16(st, d);
+  }
   GemmArgs a;
   a.A = (const bf16_t*)d.A; a.B = (const bf16_t*)d.B; a.C = d.C;
   a.bias = (const bf16_t*)d.bias; a.residual = (const bf16_t*)d.residual;
@@ -2009,9 +2210,11 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
   UVX_CHECK(d.swiglu != 2 || (d.N % 16 == 0 && d.ldc >= 2 * d.N && d.ldc2 >= 2 * d.N), UVX_ERR_INVALID,
             "gemm: swiglu-backward epilogue writes [M, 2N]: ldc=%d / ldc2=%d too small for N=%d", d.ldc, d.ldc2, d.N);
+  UVX_CHECK(d.act < 2 || (d.act <= 3 && d.C2 && !d.out_f32 && !d.residual && !d.swiglu && d.ldc2 % 4 == 0 && d.batch <= 1 && (d.act == 2 || !d.bias)),
+            UVX_ERR_INVALID, "gemm: act %d (GELU keeping / consuming the pre-activation) needs C2 [M, N], bf16 output and no residual / swiglu / batch", d.act);
   const int batch = d.batch > 0 ? d.batch : 1;
   double cost_whole = 0.;
-  const bool gelu = d.act == 1;
+  const bool gelu = d.act == 1 || d.act == 2 || d.act == 3;
   int sparse_variant = -1;       // the split picker's unsplit choice for a launch of at most one block per CU (its model, not the tile model's)
   // split-K (see splitk_reduce_k): only where the caller lent scratch for the partial tiles and the reduce kernel's 16-byte accesses apply
   if (split_ok) {
@@ -2096,6 +2299,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
     if (a.bias) t.bias = a.bias + n_main;
     if (a.residual) t.residual = a.residual + n_main;
     if (a.swiglu == 1) t.C2 = a.C2 + n_main / 2;
+    if (a.act >= 2) t.C2 = a.C2 + n_main;
     t.C = a.out_f32 ? (void*)((float*)a.C + n_main) : (void*)((bf16_t*)a.C + n_main);
     if (a.swiglu == 2) { t.C2 = a.C2 + 2 * n_main; t.C = (void*)((bf16_t*)a.C + 2 * n_main); }   // [M, 2N] operands
     g_launch_ev = LaunchEvents{nullptr, ev_b};

@@ -429,7 +429,7 @@ int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm
   const size_t sh = (size_t)mb * d.K * 2;
 #define UVX_GEMVN(MB, RBV) do { \
     static PerDeviceOnce attr; \
-    if (attr.need()) UVX_HIP(hipFuncSetAttribute((const void*)gemv_rows_bf16_k<MB, 4, RBV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+    UVX_SET_ATTR_ONCE(attr, (gemv_rows_bf16_k<MB, 4, RBV, true>), 64 * 1024); \
     hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, RBV, true>), grid, dim3(512), sh, st, a); } while (0)
   if (rb == 32) { if (mb == 1) UVX_GEMVN(1, 32); else UVX_GEMVN(2, 32); }
   else if (rb == 16) { if (mb == 1) UVX_GEMVN(1, 16); else UVX_GEMVN(2, 16); }
@@ -442,7 +442,7 @@ int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm
 bool gemm_skinny_applicable(const GemmDesc& d) {
   // (M = 17..64: only the staged kernel serves several activation row tiles)
   const bool rows_ok = d.M <= 16 || (d.M <= 64 && d.K % 2048 == 0 && uvx::g_options[4] != 2);
-  return d.M > 0 && rows_ok && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 &&
+  return d.M > 0 && rows_ok && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 && d.act < 2 &&
          d.K % 32 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.N % 4 == 0 && d.ldc % 4 == 0 &&
          (!d.swiglu || (d.N % 32 == 0 && d.ldc2 % 4 == 0)) && (!d.residual || d.ldr % 4 == 0) && uvx::g_options[4];
 }
@@ -479,7 +479,7 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
     const dim3 grid(two ? (d.N + 31) / 32 : (d.N + 15) / 16);
 #define UVX_SKS(TT, MTT) do { \
       static PerDeviceOnce attr2; \
-      if (attr2.need()) UVX_HIP(hipFuncSetAttribute((const void*)gemm_skinny_bf16_k<TT, true, MTT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+      UVX_SET_ATTR_ONCE(attr2, (gemm_skinny_bf16_k<TT, true, MTT>), sh); \
       hipLaunchKernelGGL((gemm_skinny_bf16_k<TT, true, MTT>), grid, dim3(512), sh, st, a); } while (0)
     if (d.M <= 16) { if (two) UVX_SKS(2, 1); else UVX_SKS(1, 1); }
     else if (d.M <= 32) { if (two) UVX_SKS(2, 2); else UVX_SKS(1, 2); }

@@ -323,7 +323,7 @@ template <int DD, int GG>
 int launch_decode_grp(hipStream_t st, size_t sh, int blocks, const bf16_t* qkv, const bf16_t* ck, const bf16_t* cv, bf16_t* o,
                       const int32_t* kv_start, int Hq, int Hkv, int Tmax, int len, int QKV, float scale, int lo, int hsplit) {
   static PerDeviceOnce attr_set;
-  if (attr_set.need()) UVX_HIP(hipFuncSetAttribute((const void*)attn_decode_grp_k<bf16_t, DD, GG, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  UVX_SET_ATTR_ONCE(attr_set, (attn_decode_grp_k<bf16_t, DD, GG, 1024>), 64 * 1024);
   hipLaunchKernelGGL((attn_decode_grp_k<bf16_t, DD, GG, 1024>), dim3(blocks), dim3(1024), sh, st, qkv, ck, cv, o, kv_start, Hq, Hkv, Tmax, len,
                      QKV, scale, lo, hsplit);
   return UVX_OK;

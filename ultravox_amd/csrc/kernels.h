@@ -33,7 +33,11 @@ struct GemmDesc {
   int res_mod = 0;   // >0: residual row = m % res_mod (positional-embedding add)
   int batch = 1;
   long long sA = 0, sB = 0, sC = 0, sR = 0;  // batch strides in elements
-  int act = 0;       // 0 none, 1 exact-erf GELU
+  int act = 0;       // 0 none, 1 exact-erf GELU; bf16 path, round 6 (the Whisper tower under LoRA training):
+                     // 2 = GELU that KEEPS the pre-activation: C = round(acc * alpha + bias), C2 [M, N] (row stride ldc2) = round(gelu(C))
+                     //     - what gemm + gelu_fwd produce, bit for bit;
+                     // 3 = GELU BACKWARD: C = round(round(acc * alpha) * gelu'(C2)) with C2 [M, N] the saved pre-activation - what
+                     //     gemm + gelu_bwd produce, bit for bit.  No residual / swiglu / f32 output / split-K with 2 and 3.
   int out_f32 = 0;   // bf16 path only: write f32 (wgrad)
   int accumulate = 0;
   float alpha = 1.0f;

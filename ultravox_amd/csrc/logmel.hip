@@ -181,7 +181,7 @@ int logmel(hipStream_t st, const float* pcm, const float* window, const float* t
   const int nblk = cdiv(F, FR);
   const size_t sh = sizeof(float) * (FR * XS + FR * PS);
   static PerDeviceOnce attr_set;
-  if (attr_set.need()) UVX_HIP(hipFuncSetAttribute((const void*)logmel_pass1_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+  UVX_SET_ATTR_ONCE(attr_set, logmel_pass1_k, sh);
   hipLaunchKernelGGL(logmel_pass1_k, dim3(nblk, B), dim3(256), sh, st, pcm, window, tw_cos, tw_sin, mel_fb, out, scratch,
                      L, n_mels, F, F_stride);
   hipLaunchKernelGGL(logmel_pass2_k, dim3(32, B), dim3(256), 0, st, out, scratch, nblk, n_mels, F, F_stride);

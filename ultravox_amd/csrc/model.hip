@@ -560,8 +560,12 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     if (train) {   // keep the fc1 pre-activation for the GELU backward
       GemmDesc g = lin(s.n, L.fc1_w, S.pre, M, c.enc_ffn, d);
       g.bias = L.fc1_b;
+      // bf16: the GELU runs in the GEMM's epilogue, which writes the pre-activation AND the activation (act 2; tuning option 21 = 1: the
+      // separate gelu_fwd pass of rounds 3-5 - bit-identical)
+      const bool fused = dt == DT_BF16 && g_options[21] != 1;
+      if (fused) { g.act = 2; g.C2 = s.f; g.ldc2 = c.enc_ffn; }
       RC(gemm(st, dt, g));
-      RC(gelu_fwd(st, dt, S.pre, s.f, (long long)M * c.enc_ffn));
+      if (!fused) RC(gelu_fwd(st, dt, S.pre, s.f, (long long)M * c.enc_ffn));
     } else {
       GemmDesc g = lin(s.n, L.fc1_w, s.f, M, c.enc_ffn, d);
       g.bias = L.fc1_b; g.act = 1;
@@ -624,8 +628,13 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     UVX_CHECK(L.wqkv_t && L.wo_t && L.fc1_t && L.fc2_t, UVX_ERR_INVALID, "encoder_bwd: layer %d lacks transposed weights", l);
     EncLayerStash S = enc_layer(s, l);
     // ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ----
-    RC(gemm(st, dt, lin(s.dx, L.fc2_t, s.d_f, M, c.enc_ffn, d)));
-    RC(gelu_bwd(st, dt, s.d_f, S.pre, s.d_f, (long long)M * c.enc_ffn));
+    {  // d f = (d x . W_fc2) * gelu'(pre): bf16 - in the dgrad GEMM's epilogue (act 3; option 21 = 1: the separate gelu_bwd pass, bit-identical)
+      GemmDesc g = lin(s.dx, L.fc2_t, s.d_f, M, c.enc_ffn, d);
+      const bool fused = dt == DT_BF16 && g_options[21] != 1;
+      if (fused) { g.act = 3; g.C2 = S.pre; g.ldc2 = c.enc_ffn; }
+      RC(gemm(st, dt, g));
+      if (!fused) RC(gelu_bwd(st, dt, s.d_f, S.pre, s.d_f, (long long)M * c.enc_ffn));
+    }
     RC(gemm(st, dt, lin(s.d_f, L.fc1_t, s.d_n, M, d, c.enc_ffn)));
     RC(layernorm_bwd(st, dt, s.d_n, S.x_mid, L.ln2_w, s.dx, s.dx, M, d, c.ln_eps));
     // ---- attention: x_mid = x_in + wo(attn(q, k, v)) ----

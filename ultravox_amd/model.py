@@ -23,7 +23,7 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .config import PROJECTOR_ACTS, LossConfig, LossFunction, UltravoxConfig
 from .weights import (LORA_TARGETS, init_lora_state_dict, llm_lora_key, lora_key, pack_encoder, pack_llm, pack_wav2vec2,
-                      unpack_encoder, unpack_llm,
+                      unpack_encoder, unpack_llm, check_encoder_exportable, encoder_param_names, llm_param_names,
                       random_state_dict)
 
 
@@ -452,6 +452,8 @@ class UltravoxModel:
             w_rows.copy_((w_rows.float() + scale * (B.float() @ A.float())).to(w_rows.dtype))
         kept = getattr(self, "_kept_tensors", {})
         if self.lora_r > 0:
+            check_encoder_exportable(self.config)      # BEFORE any weight changes: a tower that cannot be re-exported is not half-merged
+        if self.lora_r > 0:
             d = self.config.audio_config.d_model
             qs = (d // self.config.audio_config.encoder_attention_heads) ** -0.5      # folded into the packed q rows
             sc = float(self._lora.scaling)
@@ -492,8 +494,8 @@ class UltravoxModel:
         if prefix == "audio_tower.":
             if self.is_wav2vec2:
                 raise ValueError("the wav2vec2 tower carries no adapters and is never re-exported")
-            return list(unpack_encoder(self._enc, self.config, prefix, device="meta"))
-        return list(unpack_llm(self._llm, self.config, prefix, device="meta"))
+            return encoder_param_names(self.config, prefix)
+        return llm_param_names(self._llm, self.config, prefix)
 
     def projector_grads(self) -> Dict[str, torch.Tensor]:
         P = "multi_modal_projector."

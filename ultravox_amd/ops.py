@@ -36,7 +36,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     d.ldr = 0 if residual is None else residual.stride(0)
     d.res_mod = res_mod
     d.batch = 1
-    d.act = {"none": 0, "gelu": 1}[act]
+    d.act = {"none": 0, "gelu": 1, "gelu_keep": 2, "gelu_bwd": 3}[act]      # 2 / 3: include/uvx.h uvx_gemm_desc_t.act (c2 = activation out / pre-activation in)
     d.out_f32 = int(out_f32)
     d.accumulate = int(accumulate)
     d.alpha = alpha

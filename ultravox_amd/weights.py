@@ -12,7 +12,7 @@ transpose them ONCE at load time into the layouts the HIP kernels want (include/
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Dict, Optional, List
 
 import torch
 
@@ -398,6 +398,50 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
 # from the tensors the kernels actually run on.  Exact inverses of pack_encoder / pack_llm: a split, a de-interleave, a
 # power-of-two scale - no arithmetic that rounds.
 
+def check_encoder_exportable(cfg: UltravoxConfig) -> None:
+    """unpack_encoder divides the packed q_proj by head_dim^-0.5: exact only when that scale is a power of two (head_dim a power of 4;
+    64 for every released Whisper).  Raises the ValueError unpack_encoder would - callers that are about to MUTATE the packed weights
+    (merge_and_unload) ask first."""
+    a = cfg.audio_config
+    dh = a.d_model // a.encoder_attention_heads
+    if dh & (dh - 1) or (dh.bit_length() - 1) % 2:
+        raise ValueError(f"encoder head_dim {dh}: head_dim^-0.5 is not a power of two, the packed q_proj cannot be unscaled exactly")
+
+
+def encoder_param_names(cfg: UltravoxConfig, prefix: str = "audio_tower.") -> List[str]:
+    """The keys unpack_encoder produces (HF WhisperEncoder named_parameters()), without touching a tensor."""
+    out = [prefix + n for n in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "embed_positions.weight",
+                                "layer_norm.weight", "layer_norm.bias")]
+    for i in range(cfg.audio_config.encoder_layers):
+        L = f"{prefix}layers.{i}."
+        out += [L + n for n in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.q_proj.bias",
+                                "self_attn.v_proj.bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias",
+                                "self_attn_layer_norm.weight", "self_attn_layer_norm.bias", "final_layer_norm.weight", "final_layer_norm.bias",
+                                "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")]
+    return out
+
+
+def llm_param_names(llm: Dict[str, object], cfg: UltravoxConfig, prefix: str = "language_model.") -> List[str]:
+    """The keys unpack_llm produces, without touching a tensor (which family extras exist is read off the packed layer dicts)."""
+    P = prefix + "model."
+    out = [P + "embed_tokens.weight", P + "norm.weight"]
+    if llm["lm_head"] is not llm["embed"]:
+        out.append(prefix + "lm_head.weight")
+    g3 = bool(getattr(cfg.text_config, "is_gemma3", False))
+    for i, lay in enumerate(llm["layers"]):
+        L = f"{P}layers.{i}."
+        out += [L + n for n in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                                "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight", "input_layernorm.weight",
+                                "post_attention_layernorm.weight")]
+        if g3:
+            out += [L + "pre_feedforward_layernorm.weight", L + "post_feedforward_layernorm.weight"]
+        if lay.get("bqkv") is not None:
+            out += [L + "self_attn.q_proj.bias", L + "self_attn.k_proj.bias", L + "self_attn.v_proj.bias"]
+        if lay.get("q_norm") is not None:
+            out += [L + "self_attn.q_norm.weight", L + "self_attn.k_norm.weight"]
+    return out
+
+
 def unpack_encoder(enc: Dict[str, object], cfg: UltravoxConfig, prefix: str = "audio_tower.", device="cpu") -> Dict[str, torch.Tensor]:
     """pack_encoder's operands -> HF WhisperEncoder names under `prefix` (no peft infix: a merged tower is a plain module).
     q_proj's weight and bias were stored pre-multiplied by head_dim^-0.5; Whisper's head_dim is 64 for every released size,
@@ -406,8 +450,7 @@ def unpack_encoder(enc: Dict[str, object], cfg: UltravoxConfig, prefix: str = "a
     a = cfg.audio_config
     d, H = a.d_model, a.encoder_attention_heads
     dh = d // H
-    if dh & (dh - 1) or (dh.bit_length() - 1) % 2:
-        raise ValueError(f"encoder head_dim {dh}: head_dim^-0.5 is not a power of two, the packed q_proj cannot be unscaled exactly")
+    check_encoder_exportable(cfg)
     inv = float(dh) ** 0.5
     cv = lambda x: x.detach().to(device).contiguous()
     nm = a.num_mel_bins
