@@ -300,7 +300,31 @@ def cpu_baseline(cfg, seconds: float, n_text: int = 128):
     }
 
 
-def cpu_baseline_full(cfg, seconds: float, n_text: int = 128, steps: int = 1):
+def hip_step_for_live_parity(cfg, sd, batch, pcm, dev):
+    """The HIP side of the bench line's LIVE parity figure (`parity.live`): one B = 1 forward + backward of the production bf16 path at
+    FULL depth on the weights and the batch the cpu_baseline leg is about to push through the f32 oracle (the oracle is the checker; this is
+    the thing checked).  Returns host-side results; the model is freed before the oracle runs."""
+    import gc
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    sd16 = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    model = UltravoxModel(cfg, state_dict=sd16, device=str(dev), dtype=torch.bfloat16, rope_len=1024, consume_state_dict=True)
+    del sd16
+    mel = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins).logmel_device(pcm.to(dev))
+    gb = {k: v.to(dev) for k, v in batch.items()}
+    out = model.forward(audio_values=mel, **gb)                      # full logits + loss
+    logits = out.logits.float().cpu()
+    model.train()
+    loss = float(model.forward_backward(audio_values=mel, **gb).item())
+    grads = {k: g.float().cpu() for k, g in model.projector_grads().items()}
+    torch.cuda.synchronize()
+    del model, out, gb, mel
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"logits": logits, "loss": loss, "grads": grads}
+
+
+def cpu_baseline_full(cfg, seconds: float, n_text: int = 128, steps: int = 1, parity_dev=None):
     """ONE WHOLE adapter-train step of the workload at B = 1 through the oracle on the host cores - all encoder and LLM layers,
     nothing extrapolated (the default run's `cpu_baseline` leg when the box has the memory; `python bench.py
     --cpu-baseline-full OUT.json` runs it alone).  Weights: one seeded random layer per tower, copied into DISTINCT memory for every
@@ -332,14 +356,27 @@ def cpu_baseline_full(cfg, seconds: float, n_text: int = 128, steps: int = 1):
     for i in range(1, t.num_hidden_layers):
         for k in [k for k in sd if k.startswith("language_model.model.layers.0.")]:
             sd[k.replace("layers.0.", f"layers.{i}.", 1)] = sd[k].clone()
-    om = O.OracleModel(cfg, sd, dtype=torch.float32)
-    del sd
     b = O.synthetic_batch(cfg, 1, seconds, n_text=n_text)
     pcm = b.pop("pcm")
+    hip = None
+    if parity_dev is not None:
+        # live parity (round 6): the weights take bf16-representable values (timing is indifferent to the values) so that the HIP path - run
+        # FIRST, then freed - and the f32 oracle see the same numbers
+        for k in sd:
+            sd[k] = sd[k].to(torch.bfloat16).float()
+        try:
+            hip = hip_step_for_live_parity(cfg, sd, b, pcm, parity_dev)
+        except Exception as e:          # the CPU leg does not depend on it
+            hip = {"error": f"{type(e).__name__}: {e}"}
+    om = O.OracleModel(cfg, sd, dtype=torch.float32)
+    del sd
+    ref = {}
 
     def step():
         mel = O.logmel_ref(pcm, a.num_mel_bins)
         out, grads, _ = om.train_step({**b, "audio_values": mel})
+        if hip is not None and "error" not in hip and not ref:
+            ref.update(logits=out["logits"].detach().float(), grads={k: g.float() for k, g in grads.items()})
         return float(out["loss"].detach())
 
     times = []
@@ -349,9 +386,21 @@ def cpu_baseline_full(cfg, seconds: float, n_text: int = 128, steps: int = 1):
         times.append(time.perf_counter() - t0)
     best = min(times)
     del om
-    return {"value": seconds / best, "unit": "audio-seconds/sec", "cores": cores, "kind": "port", "step_seconds": times,
-            "sample": f"oracle f32, ONE WHOLE step at B=1x{seconds:g}s: log-mel, {a.encoder_layers} encoder layers, projector, "
-                      f"{t.num_hidden_layers} LLM layers + lm_head + CE forward and backward (nothing extrapolated; loss {loss:.3f})"}
+    rec = {"value": seconds / best, "unit": "audio-seconds/sec", "cores": cores, "kind": "port", "step_seconds": times,
+           "sample": f"oracle f32, ONE WHOLE step at B=1x{seconds:g}s: log-mel, {a.encoder_layers} encoder layers, projector, "
+                     f"{t.num_hidden_layers} LLM layers + lm_head + CE forward and backward (nothing extrapolated; loss {loss:.3f})"}
+    if hip is not None:
+        if "error" in hip:
+            rec["_live_parity"] = {"error": hip["error"]}
+        else:
+            rl2 = lambda x, y: float((x - y).norm() / (y.norm() + 1e-30))
+            rec["_live_parity"] = {
+                "measured": "in THIS run: production bf16 HIP path vs the f32 oracle of the cpu_baseline leg, same weights (bf16-representable), same B = 1 batch, FULL depth",
+                "logits_rel_l2_vs_f32_oracle": rl2(hip["logits"], ref["logits"].reshape(hip["logits"].shape)),
+                "logits_max_abs_diff": float((hip["logits"] - ref["logits"].reshape(hip["logits"].shape)).abs().max()),
+                "loss": {"hip": hip["loss"], "f32_oracle": loss},
+                "projector_grads_rel_l2_vs_f32_oracle": {k.split("multi_modal_projector.")[-1]: rl2(hip["grads"][k], g) for k, g in ref["grads"].items() if k in hip["grads"]}}
+    return rec
 
 
 def pmc_traffic_per_launch(profiles_dir=None):
@@ -506,6 +555,10 @@ def main():
     ap.add_argument("--cpu-baseline-full", default=None, metavar="OUT.json",
                     help="CPU only: time ONE WHOLE step of the workload at B = 1 through the oracle (all layers) and write the record")
     ap.add_argument("--no-prof", action="store_true", help="skip the live HIP-event timing of the GEMM kernel")
+    ap.add_argument("--parity-live", action="store_true",
+                    help="with the cpu_baseline leg: also run its weights and B = 1 batch through the HIP path at full depth and report the measured "
+                         "distances as parity.live (default on for the plain c2 line; adds ~10 s)")
+    ap.add_argument("--no-parity-live", action="store_true", help="never run the live parity check")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="quote roofline.traffic from the committed PMC summary instead of measuring it in two rocprofv3 --pmc sub-runs (~15 s each)")
     ap.add_argument("--audio-lora-r", type=int, default=0,
@@ -773,7 +826,22 @@ def main():
             # CPU work + ~15 s of weight set-up) - needs ~45 GB of host memory for the f32 weights of an 8B-parameter LLM.
             # Otherwise the bounded sample (2 encoder layers + 1 LLM layer timed, scaled to full depth).
             try:
-                out["cpu_baseline"] = cpu_baseline_full(cfg, wl["seconds"])
+                # (with --parity-live, or by default on the BASELINE workload: free this process's model and let the leg also push its
+                #  weights and batch through the HIP path - the `parity.live` object is then measured in this very run)
+                live = (args.parity_live or (args.workload == "c2" and args.loss == "ce" and not args.audio_lora_r)) and not args.no_parity_live
+                if live:
+                    import gc
+                    del trainer, model
+                    gc.collect()
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                out["cpu_baseline"] = cpu_baseline_full(cfg, wl["seconds"], parity_dev=dev if live else None)
+                lp = out["cpu_baseline"].pop("_live_parity", None)
+                if lp is not None:
+                    out.setdefault("parity", {})
+                    if out["parity"] is None:
+                        out["parity"] = {}
+                    out["parity"]["live"] = lp
             except MemoryError as e:
                 try:
                     out["cpu_baseline"] = cpu_baseline(cfg, wl["seconds"])

@@ -266,3 +266,33 @@ def test_kl_step_under_llm_lora_matches_the_reference_model_fixture(dtype):
     assert sorted(mine) == sorted(exp["grads"])
     for k, g in exp["grads"].items():
         assert rel_l2(mine[k], g) < (2e-3 if dtype == torch.float32 else 0.1), k
+
+
+@pytest.mark.parametrize("r", [4, 8])
+def test_lora_and_gelu_epilogues_are_bit_identical_to_the_separate_kernels(r):
+    """Round 6: the training tower's GELU / GELU backward in the fc1 / fc2-dgrad GEMM epilogues (tuning option 21) and the LoRA up-projections in the
+    q|k|v GEMM's and its dgrad's epilogues (option 22) against the separate gelu_* / lora_up launches of rounds 3-5: same loss, same logits and
+    the same projector + adapter gradients, bit for bit (the epilogues restate the kernels' arithmetic and rounding points)."""
+    from ultravox_amd import _lib
+    L = _lib.lib()
+    cfg, sd, model, oracle, gb, ob, mel = _setup(torch.bfloat16, r=r)
+    model.train()
+
+    def run():
+        loss = model.forward_backward(audio_values=mel, **gb)
+        torch.cuda.synchronize()
+        return loss.clone(), model.proj_grad.clone()
+
+    try:
+        L.uvx_set_option(21, 1)
+        L.uvx_set_option(22, 1)
+        loss0, g0 = run()
+        for o21, o22 in ((0, 1), (1, 0), (0, 0)):
+            L.uvx_set_option(21, o21)
+            L.uvx_set_option(22, o22)
+            loss, g = run()
+            assert torch.equal(loss, loss0) and torch.equal(g, g0), (o21, o22, (g != g0).sum().item())
+        assert g0.abs().sum().item() > 0
+    finally:
+        L.uvx_set_option(21, 0)
+        L.uvx_set_option(22, 0)

@@ -77,6 +77,9 @@ struct GemmArgs {
   // split-K launches (round 5): blockIdx.y = z of ksplit takes K-tiles [z nk / ksplit, (z + 1) nk / ksplit) and writes its f32 partial
   // tile to slab z of C (stride sC); sA = sB = 0.  splitk_reduce_k sums the slabs in a fixed order and runs the epilogue.
   int ksplit;
+  // LoRA up-projection terms of the epilogue (GemmDesc::lora); col0 = absolute output column of this launch's column 0 (tail-split launches)
+  struct Lt { const bf16_t* t; const bf16_t* w; int ldt, ldw, c0, c1, r; float alpha; } lt[2];
+  int n_lt, col0;
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -243,6 +246,27 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
           const int row = it * 8 + (lane >> 3), m = m_base + i0 * 16 + row;
           uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 8>(stage, row, c8));
           if (m < p.M && n8 < p.N) {
+            if (p.n_lt > 0) {       // rank-r LoRA up-projections (GemmDesc::lora): lora_up_k's arithmetic on this lane's 8 columns of row m
+              const int ca = p.col0 + n8;
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                if (q >= p.n_lt || ca < p.lt[q].c0 || ca >= p.lt[q].c1) continue;
+                const GemmArgs::Lt& T = p.lt[q];
+                const uint4 yv = *reinterpret_cast<const uint4*>(T.t + (long long)m * T.ldt);
+                const float y[8] = {unpack_lo(yv.x), unpack_hi(yv.x), unpack_lo(yv.y), unpack_hi(yv.y), unpack_lo(yv.z), unpack_hi(yv.z), unpack_lo(yv.w), unpack_hi(yv.w)};
+                float la[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < T.r; ++j) {
+                  const uint4 wv = *reinterpret_cast<const uint4*>(T.w + (long long)j * T.ldw + (ca - T.c0));
+                  const float wf[8] = {unpack_lo(wv.x), unpack_hi(wv.x), unpack_lo(wv.y), unpack_hi(wv.y), unpack_lo(wv.z), unpack_hi(wv.z), unpack_lo(wv.w), unpack_hi(wv.w)};
+#pragma unroll
+                  for (int k = 0; k < 8; ++k) la[k] += y[j] * wf[k];
+                }
+                o.x = pack2(unpack_lo(o.x) + bf2f(f2bf(la[0] * T.alpha)), unpack_hi(o.x) + bf2f(f2bf(la[1] * T.alpha)));
+                o.y = pack2(unpack_lo(o.y) + bf2f(f2bf(la[2] * T.alpha)), unpack_hi(o.y) + bf2f(f2bf(la[3] * T.alpha)));
+                o.z = pack2(unpack_lo(o.z) + bf2f(f2bf(la[4] * T.alpha)), unpack_hi(o.z) + bf2f(f2bf(la[5] * T.alpha)));
+                o.w = pack2(unpack_lo(o.w) + bf2f(f2bf(la[6] * T.alpha)), unpack_hi(o.w) + bf2f(f2bf(la[7] * T.alpha)));
+              }
+            }
             if (p.act == 3) {       // GELU backward: the saved pre-activation arrives as whole lines, like a residual
               const uint4 x = *reinterpret_cast<const uint4*>(p.C2 + (long long)m * p.ldc2 + n8);
               o.x = mul_gelu_grad2(o.x, x.x); o.y = mul_gelu_grad2(o.y, x.y); o.z = mul_gelu_grad2(o.z, x.z); o.w = mul_gelu_grad2(o.w, x.w);
@@ -1859,7 +1883,7 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
     case 61: case 62: {
       // the 32 x 32 x 16 kernels carry the plain whole-line epilogue only
       const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-      const bool plain = !a.out_f32 && a.swiglu == 0 && a.act < 2 && a.wide_io == 2 && a.ksplit <= 1 && !a.m_dev && (a.N & 7) == 0 && (a.ldc & 7) == 0 &&
+      const bool plain = !a.out_f32 && a.swiglu == 0 && a.act < 2 && a.n_lt == 0 && a.wide_io == 2 && a.ksplit <= 1 && !a.m_dev && (a.N & 7) == 0 && (a.ldc & 7) == 0 &&
                          (a.sC & 7) == 0 && al16(a.C) && (!a.bias || ((uintptr_t)a.bias & 7) == 0) &&
                          (!a.residual || ((a.ldr & 7) == 0 && (a.sR & 7) == 0 && al16(a.residual)));
       if (!plain) { launch_variant(st, variant == 61 ? 31 : 34, a, M, N, batch); return; }
@@ -2182,7 +2206,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   // few rows: stream the weights.  Beyond 16 rows the weight-streaming kernels serve 16-row tiles one after the other (MT = 2, 4) and lose to a
   // 128 x 256 tile whose K loop is cut over 6-8 blocks wherever the caller lent split-K scratch (Llama-3.3-70B's four linears, us per
   // launch, staged kernel / tiled split-K: 32 rows 447 / 345, 64 rows 871 / 358 - profiles/r05_gemm_splitk_decode_rows.txt)
-  const bool split_ok = d.splitk_ws && d.batch <= 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.act < 2 && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
+  const bool split_ok = d.splitk_ws && d.batch <= 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.act < 2 && d.n_lora == 0 && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
       ((uintptr_t)d.C & 15) == 0 && ((uintptr_t)d.splitk_ws & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
       (!d.residual || (d.ldr % 8 == 0 && ((uintptr_t)d.residual & 15) == 0)) &&
       (!d.swiglu || (d.ldc2 % 8 == 0 && ((uintptr_t)d.C2 & 15) == 0));      // (the reduce kernel's 16-byte accesses apply)
@@ -2206,6 +2230,17 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.m_major = uvx::g_options[7] && d.M > d.N && (d.batch <= 1);
   a.m_dev = d.m_dev; a.m_dev_off = d.m_dev_off;
   a.sk_full = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0; a.ksplit = 1;
+  a.n_lt = d.n_lora; a.col0 = 0;
+  for (int q = 0; q < 2; ++q) {
+    const GemmDesc::LoraTerm& T = d.lora[q];
+    a.lt[q] = GemmArgs::Lt{(const bf16_t*)T.t, (const bf16_t*)T.w, T.ldt, T.ldw, T.c0, T.c1, T.r, T.alpha};
+    UVX_CHECK(q >= d.n_lora || (T.t && T.w && T.r > 0 && T.r <= 8 && T.ldt % 8 == 0 && T.ldw % 8 == 0 && T.c0 % 64 == 0 && T.c1 % 64 == 0 &&
+                               ((uintptr_t)T.t & 15) == 0 && ((uintptr_t)T.w & 15) == 0), UVX_ERR_INVALID,
+              "gemm: LoRA epilogue term %d needs rank <= 8, 16-byte-aligned t / w with ldt, ldw multiples of 8 and a 64-aligned column range", q);
+  }
+  UVX_CHECK(d.n_lora == 0 || (d.n_lora <= 2 && !d.out_f32 && !d.residual && d.act == 0 && !d.swiglu && d.batch <= 1 && !d.m_dev && uvx::g_options[1] == 2 &&
+                              d.N % 8 == 0 && d.ldc % 8 == 0 && ((uintptr_t)d.C & 15) == 0), UVX_ERR_INVALID,
+            "gemm: the LoRA epilogue needs the whole-line bf16 epilogue (N, ldc multiples of 8, aligned C) and no residual / act / swiglu / batch");
   UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
   UVX_CHECK(d.swiglu != 2 || (d.N % 16 == 0 && d.ldc >= 2 * d.N && d.ldc2 >= 2 * d.N), UVX_ERR_INVALID,
@@ -2300,6 +2335,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
     if (a.residual) t.residual = a.residual + n_main;
     if (a.swiglu == 1) t.C2 = a.C2 + n_main / 2;
     if (a.act >= 2) t.C2 = a.C2 + n_main;
+    t.col0 = n_main;
     t.C = a.out_f32 ? (void*)((float*)a.C + n_main) : (void*)((bf16_t*)a.C + n_main);
     if (a.swiglu == 2) { t.C2 = a.C2 + 2 * n_main; t.C = (void*)((bf16_t*)a.C + 2 * n_main); }   // [M, 2N] operands
     g_launch_ev = LaunchEvents{nullptr, ev_b};

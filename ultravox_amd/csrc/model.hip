@@ -527,20 +527,30 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     void* x_mid = train ? S.x_mid : x;            // inference: the residual stream is updated in place
     void* x_out = !train ? x : (l + 1 < c.enc_layers ? enc_layer(s, l + 1).x_in : s.x);
     if (!probe_skip(128)) RC(layernorm_fwd(st, dt, x, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));
-    {
-      GemmDesc g = lin(s.n, L.wqkv, qkv, M, 3 * d, d);
-      g.bias = L.bqkv;
-      RC(gemm(st, dt, enc_sk(g, s)));
-    }
+    // peft LoRA on q_proj / k_proj: result += lora_B(lora_A(x)) * scaling (and q carries Whisper's head_dim^-0.5, folded into wqkv at pack
+    // time).  Rank-r products on the VALU (lora.hip): HBM-bound, no padding to an MFMA tile.  bf16, r <= 8 (round 6): the two up-projections
+    // ride in the q|k|v GEMM's epilogue (GemmDesc::lora - lora_up's arithmetic on the staged rows; tuning option 22 = 1: the separate
+    // lora_up launches, each a read-modify-write of its [M, d] slice of qkv; bit-identical)
+    const bool lora_epi = train && dt == DT_BF16 && lora->r <= 8 && g_options[22] != 1 && g_options[1] == 2;
     if (train) {
-      // peft LoRA on q_proj / k_proj: result += lora_B(lora_A(x)) * scaling (and q carries Whisper's head_dim^-0.5,
-      // folded into wqkv at pack time).  A_q | A_k share one rank-padded GEMM; K = 64 (zero padded rank) for the B side.
-      // rank-r products on the VALU (lora.hip): HBM-bound, no padding to an MFMA tile
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r;
       RC(lora_transpose2(st, dt, R.q.b, S.bqT, d, R.k.b, S.bkT, d, r));
       RC(lora_down(st, dt, s.n, d, R.q.a, 0, S.t, 128, M, d, r, 1.0f));
       RC(lora_down(st, dt, s.n, d, R.k.a, 0, at(S.t, 64, dt), 128, M, d, r, 1.0f));
+    }
+    {
+      GemmDesc g = lin(s.n, L.wqkv, qkv, M, 3 * d, d);
+      g.bias = L.bqkv;
+      if (lora_epi) {
+        g.n_lora = 2;
+        g.lora[0] = GemmDesc::LoraTerm{S.t, S.bqT, 128, d, 0, d, lora->r, lora->scaling * qscale};
+        g.lora[1] = GemmDesc::LoraTerm{at(S.t, 64, dt), S.bkT, 128, d, d, 2 * d, lora->r, lora->scaling};
+      }
+      RC(gemm(st, dt, enc_sk(g, s)));
+    }
+    if (train && !lora_epi) {
+      const int r = lora->r;
       RC(lora_up(st, dt, S.t, 128, S.bqT, 1, qkv, 3 * d, M, d, r, lora->scaling * qscale, 1));
       RC(lora_up(st, dt, at(S.t, 64, dt), 128, S.bkT, 1, at(qkv, d, dt), 3 * d, M, d, r, lora->scaling, 1));
     }
@@ -668,9 +678,20 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     }
     if (l == 0) break;   // nothing trainable below layer 0
     // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k], then LN1 backward into the residual stream ----
-    RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d)));
-    RC(lora_up(st, dt, s.u, 128, R.q.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
-    RC(lora_up(st, dt, at(s.u, 64, dt), 128, R.k.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+    {
+      GemmDesc g = lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d);
+      const bool lora_epi = dt == DT_BF16 && r <= 8 && g_options[22] != 1 && g_options[1] == 2;      // (as in the forward pass)
+      if (lora_epi) {
+        g.n_lora = 2;
+        g.lora[0] = GemmDesc::LoraTerm{s.u, R.q.a, 128, d, 0, d, r, 1.0f};
+        g.lora[1] = GemmDesc::LoraTerm{at(s.u, 64, dt), R.k.a, 128, d, 0, d, r, 1.0f};
+      }
+      RC(gemm(st, dt, g));
+      if (!lora_epi) {
+        RC(lora_up(st, dt, s.u, 128, R.q.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+        RC(lora_up(st, dt, at(s.u, 64, dt), 128, R.k.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+      }
+    }
     RC(layernorm_bwd(st, dt, s.d_n, S.x_in, L.ln1_w, s.dx, s.dx, M, d, c.ln_eps));
   }
   return UVX_OK;
