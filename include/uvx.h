@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 15
+#define UVX_ABI_VERSION 16
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -361,6 +361,15 @@ int32_t uvx_llm_prefill_chunk_logits(void* stream, const uvx_config_t* cfg, cons
                                      const int32_t* kv_start, void* logits_all, void* workspace, size_t ws_bytes);
 /* out[r] = argmax_v logits[r, v] (lowest index on ties, like torch.argmax) */
 int32_t uvx_argmax(void* stream, int32_t dtype, const void* logits, int32_t rows, int32_t V, int64_t* out);
+/* One step of the greedy generate() loop's bookkeeping on the device ([3P] GenerationMixin._sample with do_sample = False, what
+ * ultravox_model.py:422-426 -> language_model.generate runs per token): for every row b
+ *   tok = unfinished[b] ? argmax_v logits[b, v] : pad;   next_tokens[b] = sequences[b * stride + col] = tok;
+ *   unfinished[b] &= tok not in eos_ids[0 .. n_eos);      positions[b] = positions0[b] + step (positions may be NULL);
+ * counter[step & 1] (device, int32 x 2, both zero before step 0) receives the number of rows still unfinished - the host reads that one
+ * word to decide whether to stop - and the other slot is cleared for the next step.  Calls of one loop must be ordered on one stream. */
+int32_t uvx_greedy_select(void* stream, int32_t dtype, const void* logits, int32_t B, int32_t V, const int64_t* eos_ids, int32_t n_eos,
+                          int64_t pad, int32_t* unfinished, int64_t* next_tokens, int64_t* sequences, int64_t stride, int64_t col,
+                          const int32_t* positions0, int32_t* positions, int32_t step, int32_t* counter);
 
 /* clip_grad_norm_(max_norm) + torch.optim.AdamW step over one flat parameter bucket (train.py:260,
  * config_base.py:149-154).  grad: f32 [n] (already DP-averaged).  state_dtype selects the storage of
@@ -455,16 +464,11 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
  * both, 3 = two in the dK/dV kernel only, 4 = 64-row steps, 5 / 6 = eight-wave blocks (all bit-identical; A/B), key 20 = 1: the head_dim-64 forward kernel takes
  * its row max through ds_bpermute shuffles instead of v_permlane swaps (default 0; bit-identical; A/B), key 21 = 1: the training tower's GELU and GELU backward
  * run as separate kernels instead of in the fc1 / fc2-dgrad GEMM epilogues (uvx_gemm_desc_t.act 2 / 3; default 0; bit-identical; A/B), key 22 = 1: the training
- * tower's LoRA up-projections (rank <= 8) run as separate read-modify-write passes over q|k|v / d n instead of in the q|k|v GEMM's and its dgrad's epilogues
- * (default 0; bit-identical; A/B).  Key 23: reserved (0). */
+ * tower's LoRA up-projections (rank <= 8) run in the q|k|v GEMM's and its dgrad's epilogues instead of as separate read-modify-write passes over q|k|v / d n
+ * (default 0: measured 0.25 ms per step slower; bit-identical; A/B).  Key 23: reserved (0). */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* the current value of a tuning option (-1: unknown key) */
 int32_t uvx_get_option(int32_t key);
-/* Diagnostic for the stream-K GEMM launches (probe builds only - libuvx_probes.so; the production picker never selects
- * them and this returns 0): blocks that wait for another block's partial sums spin for a bounded time (~1 s) and then give
- * up rather than hang the queue.  Returns how many did since the last call (0 on a healthy run; a non-zero count means
- * wrong output tiles), -1 on a HIP error.  Synchronises the device. */
-int32_t uvx_gemm_streamk_timeouts(void);
 /* host only (no GPU work): the bf16 GEMM tile variant the cost model picks for this problem */
 int32_t uvx_gemm_pick_variant(int32_t M, int32_t N, int32_t K, int32_t batch);
 /* probes: use `variant` for problems of exactly this shape (in-situ A/B inside bench.py); variant < 0 clears the table */
@@ -475,13 +479,6 @@ int32_t uvx_gemm_override_variant(int32_t M, int32_t N, int32_t K, int32_t varia
 int32_t uvx_probe_lds_tr(void* stream, const int32_t* addr, int32_t* out);
 /* probes: force the attention forward q-tile count per wave (1 or 2; 0 = automatic) */
 int32_t uvx_attention_force_qt(int32_t qt);
-/* probes (libuvx_probes.so; UVX_ERR_UNSUPPORTED in libuvx.so): while `stamps` is non-null, every wave of the fused attention
- * backward kernel writes a 16 x u64 record of cycle-counter stamps into stamps[((b * Hq + h) * 8 + wave) * 16 + slot]: 0 start,
- * 1 prologue done, 2 + 2 p / 3 + 2 p pass p of phase 1 done / its dK, dV stored, 8 phase 2 done, 9 dQ stored, 10 cycles inside
- * phase-1 steps, 11 cycles at phase-1 barriers + staging stores, 12 steps taken, 13 cycles inside phase-2 products.
- * tools/gpu_attn_timeline.py prints the breakdown.  null switches the stamps off. */
-int32_t uvx_probe_attn_timeline(void* stamps);
-
 int32_t uvx_layernorm(void* stream, int32_t dtype, const void* x, const void* w, const void* b, void* y, int32_t rows,
                       int32_t cols, float eps);
 int32_t uvx_rmsnorm(void* stream, int32_t dtype, const void* x, const void* w, void* y, int32_t rows, int32_t cols,

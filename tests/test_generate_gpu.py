@@ -479,3 +479,31 @@ def test_rmsnorm_inside_the_splitk_reduce_is_bit_identical(family):
     for a, b in zip(*runs):
         assert torch.equal(a, b)
     assert torch.isfinite(runs[0][1].float()).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_greedy_bookkeeping_in_one_launch_equals_the_generic_loop(dtype, monkeypatch):
+    """Round 6: uvx_greedy_select (argmax + pad-after-finish + EOS test + next RoPE position + unfinished count in ONE launch) against the
+    generic loop's torch bookkeeping (UVX_GREEDY_SELECT=0): same sequences when the rows of a batch stop at DIFFERENT steps (the finished
+    ones are padded), when none stops, with a list of terminators and a pad id that is not an EOS id, and the same KV state."""
+    cfg, model, oracle = _build(dtype, 29)
+    torch.manual_seed(9)
+    B, T, N = 4, 14, 12
+    ids = torch.randint(3, 512, (B, T)).to(DEV)
+    am = torch.ones(B, T, dtype=torch.long)
+    am[2, :4] = 0
+    monkeypatch.setenv("UVX_GREEDY_SELECT", "0")
+    free = model.generate(ids, attention_mask=am.to(DEV), max_new_tokens=N, eos_token_id=-1).cpu()
+    stops = [int(free[0, T + 2]), int(free[1, T + 6])]           # row 0 stops at step 2 (or earlier), row 1 at step 6 (or earlier)
+    for kw in (dict(eos_token_id=-1), dict(eos_token_id=stops, pad_token_id=1), dict(eos_token_id=stops[0])):
+        monkeypatch.setenv("UVX_GREEDY_SELECT", "0")
+        want = model.generate(ids, attention_mask=am.to(DEV), max_new_tokens=N, return_dict_in_generate=True, **kw)
+        monkeypatch.setenv("UVX_GREEDY_SELECT", "1")
+        got = model.generate(ids, attention_mask=am.to(DEV), max_new_tokens=N, return_dict_in_generate=True, **kw)
+        assert torch.equal(got.sequences, want.sequences), kw
+        assert got.past_key_values.cur_len == want.past_key_values.cur_len
+        assert torch.equal(got.past_key_values.pos_next, want.past_key_values.pos_next)
+        if "pad_token_id" in kw:           # a finished row is padded with pad_token_id from the step after its terminator on
+            row = got.sequences[0, T:].tolist()
+            first = next(i for i, t in enumerate(row) if t in stops)
+            assert all(t == 1 for t in row[first + 1:])

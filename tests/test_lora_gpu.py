@@ -271,7 +271,7 @@ def test_kl_step_under_llm_lora_matches_the_reference_model_fixture(dtype):
 @pytest.mark.parametrize("r", [4, 8])
 def test_lora_and_gelu_epilogues_are_bit_identical_to_the_separate_kernels(r):
     """Round 6: the training tower's GELU / GELU backward in the fc1 / fc2-dgrad GEMM epilogues (tuning option 21) and the LoRA up-projections in the
-    q|k|v GEMM's and its dgrad's epilogues (option 22) against the separate gelu_* / lora_up launches of rounds 3-5: same loss, same logits and
+    q|k|v GEMM's and its dgrad's epilogues (option 22 = 1) against the separate gelu_* / lora_up launches of rounds 3-5: same loss, same logits and
     the same projector + adapter gradients, bit for bit (the epilogues restate the kernels' arithmetic and rounding points)."""
     from ultravox_amd import _lib
     L = _lib.lib()
@@ -281,18 +281,76 @@ def test_lora_and_gelu_epilogues_are_bit_identical_to_the_separate_kernels(r):
     def run():
         loss = model.forward_backward(audio_values=mel, **gb)
         torch.cuda.synchronize()
-        return loss.clone(), model.proj_grad.clone()
+        return loss.clone(), {k: v.clone() for k, v in model.projector_grads().items()}
 
     try:
         L.uvx_set_option(21, 1)
-        L.uvx_set_option(22, 1)
+        L.uvx_set_option(22, 0)
         loss0, g0 = run()
-        for o21, o22 in ((0, 1), (1, 0), (0, 0)):
+        for o21, o22 in ((0, 0), (1, 1), (0, 1)):
             L.uvx_set_option(21, o21)
             L.uvx_set_option(22, o22)
             loss, g = run()
-            assert torch.equal(loss, loss0) and torch.equal(g, g0), (o21, o22, (g != g0).sum().item())
-        assert g0.abs().sum().item() > 0
+            assert torch.equal(loss, loss0), (o21, o22)
+            for k in g0:
+                # (the RMSNorm weight gradients of the projector are summed with f32 atomics - norms.hip rmsnorm_bwd_k - and move by an ulp from
+                #  run to run with ANY setting; everything else is order-deterministic)
+                if k.endswith(("ln_pre.weight", "ln_mid.weight", "ln_post.weight")):
+                    assert torch.allclose(g[k], g0[k], rtol=1e-3, atol=1e-6), (o21, o22, k)
+                else:
+                    assert torch.equal(g[k], g0[k]), (o21, o22, k, (g[k] != g0[k]).sum().item())
+        assert sum(v.abs().sum().item() for v in g0.values()) > 0
     finally:
         L.uvx_set_option(21, 0)
         L.uvx_set_option(22, 0)
+
+
+def test_llm_only_training_builds_the_language_model_alone(tmp_path):
+    """config.llm_only_training (ultravox_config.py:120; ultravox_model.py:62-67; the LLMOnlyModelPack of training/model_types.py:139-163: the
+    reference's text-only LoRA pre-stage): no audio tower, no projector - the state dict needs (and the model holds) the language model and
+    its adapters only; a text batch trains exactly as in the full model (same loss, same adapter gradients, bit for bit); audio inputs hit the
+    missing attribute; without adapters there is nothing to optimise; save / load round-trips the adapter keys."""
+    from oracle.reference_cpu import synthetic_batch
+    from test_model_gpu import SMALL
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel, UltravoxTrainer
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    dtype = torch.bfloat16
+    full_cfg = UltravoxConfig(**SMALL, text_model_lora_config={"r": 8, "lora_alpha": 16})
+    sd = random_state_dict(full_cfg, seed=43, dtype=dtype)
+    sd.update(init_lora_state_dict(full_cfg, seed=43, dtype=dtype, random_b=True))
+    cfg = UltravoxConfig(**SMALL, text_model_lora_config={"r": 8, "lora_alpha": 16}, llm_only_training=True)
+    text_sd = {k: v for k, v in sd.items() if k.startswith("language_model.")}
+    model = UltravoxModel(cfg, state_dict=text_sd, device=DEV, dtype=dtype)           # tower / projector keys are not needed
+    full = UltravoxModel(full_cfg, state_dict=sd, device=DEV, dtype=dtype)
+    names = model.trainable_parameter_names()
+    assert names and all(k.startswith("language_model.") and "lora_" in k for k in names)
+    assert len(names) == 4 * cfg.text_config.num_hidden_layers
+    b = synthetic_batch(full_cfg, 2, 1.0, n_text=24, audio_start=5, n_supervised=8)
+    tb = {k: b[k].to(DEV) for k in ("input_ids", "attention_mask", "labels")}
+    model.train(); full.train()
+    loss, ref = model.forward_backward(**tb), full.forward_backward(**tb)
+    assert torch.equal(loss, ref)
+    mine, theirs = model.projector_grads(), full.projector_grads()
+    assert set(mine) == set(names)
+    for k in names:
+        assert torch.equal(mine[k], theirs[k]), k
+    assert max(g.abs().max().item() for g in mine.values()) > 0
+    with pytest.raises(AttributeError, match="audio_tower"):
+        model.forward(audio_values=torch.zeros(2, 80, 100, device=DEV), audio_token_start_idx=torch.zeros(2, dtype=torch.long),
+                      audio_token_len=torch.ones(2, dtype=torch.long), audio_lens=torch.full((2,), 100), audio_batch_size=torch.ones(2, dtype=torch.long),
+                      **{k: v for k, v in tb.items() if k != "labels"})
+    trainer = UltravoxTrainer(model, lr=1e-3)
+    before = {k: v.clone() for k, v in model.projector_state_dict().items()}
+    trainer.train_step(**tb)
+    assert any(not torch.equal(before[k], v) for k, v in model.projector_state_dict().items())
+    model.save_pretrained(str(tmp_path))
+    from safetensors.torch import load_file
+    saved = load_file(str(tmp_path / "model.safetensors"))
+    assert set(saved) == set(names)
+    frozen = UltravoxModel(UltravoxConfig(**SMALL, llm_only_training=True), state_dict=text_sd, device=DEV, dtype=dtype)
+    assert frozen.trainable_parameter_names() == []
+    with pytest.raises(ValueError, match="empty parameter list"):
+        UltravoxTrainer(frozen)
+    out = frozen.generate(tb["input_ids"][:, :10], max_new_tokens=3, eos_token_id=-1)      # inference works as for any text prompt
+    assert out.shape == (2, 13)

@@ -5,10 +5,14 @@
 #include "common.h"
 #include "kernels.h"
 #include "../../include/uvx.h"
+#ifdef UVX_PROBES
+#include "../../include/uvx_probes.h"
+#endif
 
 static thread_local char g_err[512] = "";
 
-extern "C" void uvx_set_error(const char* fmt, ...) {
+// (internal: hidden visibility keeps it out of the dynamic symbol table - the exported set is exactly what include/uvx.h declares)
+extern "C" __attribute__((visibility("hidden"))) void uvx_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -19,15 +23,13 @@ extern "C" const char* uvx_last_error(void) { return g_err; }
 extern "C" int32_t uvx_abi_version(void) { return UVX_ABI_VERSION; }
 namespace uvx { extern int g_attn_qt; extern void* g_attn_tl; }
 extern "C" int32_t uvx_attention_force_qt(int32_t qt) { uvx::g_attn_qt = qt; return UVX_OK; }
-extern "C" int32_t uvx_probe_attn_timeline(void* stamps) {
 #ifdef UVX_PROBES
+extern "C" int32_t uvx_probe_attn_timeline(void* stamps) {
   uvx::g_attn_tl = stamps;
   return UVX_OK;
-#else
-  if (!stamps) return UVX_OK;   // "off" is what this build always is
-  UVX_CHECK(false, UVX_ERR_UNSUPPORTED, "uvx_probe_attn_timeline: the stamps exist in libuvx_probes.so only (built with -DUVX_PROBES)");
-#endif
 }
+extern "C" int32_t uvx_gemm_streamk_timeouts(void) { return uvx::gemm_streamk_timeouts(); }
+#endif
 extern "C" int32_t uvx_gemm_force_variant(int32_t v) {
   if (v <= -2) { uvx::g_gemm_variant = -1; uvx::g_gemm_split = 0; }  // -2: automatic variant, tail split off (A/B probes)
   else { uvx::g_gemm_variant = v; uvx::g_gemm_split = 1; }
@@ -47,7 +49,6 @@ extern "C" int32_t uvx_probe_lds_tr(void* stream, const int32_t* addr, int32_t* 
   return uvx::lds_tr_probe((hipStream_t)stream, addr, out);
 }
 
-extern "C" int32_t uvx_gemm_streamk_timeouts(void) { return uvx::gemm_streamk_timeouts(); }
 extern "C" int32_t uvx_gemm_pick_variant(int32_t M, int32_t N, int32_t K, int32_t batch) { return uvx::gemm_pick_variant(M, N, K, batch); }
 
 extern "C" int32_t uvx_gemm_override_variant(int32_t M, int32_t N, int32_t K, int32_t variant) {

@@ -21,7 +21,7 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
 #define UVX_ERR_UNSUPPORTED (-4)
 #define UVX_ERR_RUNTIME (-5)
 
-extern "C" void uvx_set_error(const char* fmt, ...);
+extern "C" __attribute__((visibility("hidden"))) void uvx_set_error(const char* fmt, ...);
 
 #define UVX_CHECK(cond, code, ...)        \
   do {                                    \

@@ -329,11 +329,9 @@ int launch_decode_grp(hipStream_t st, size_t sh, int blocks, const bf16_t* qkv, 
   return UVX_OK;
 }
 
+// argmax of one logits row by the whole block (1024 threads; bv / bi: LDS scratch of blockDim.x entries); the result is valid in thread 0
 template <typename T>
-__global__ void argmax_k(const T* __restrict__ logits, int64_t* __restrict__ out, int V) {
-  __shared__ float bv[1024];
-  __shared__ int bi[1024];
-  const T* r = logits + (long long)blockIdx.x * V;
+__device__ __forceinline__ int row_argmax(const T* __restrict__ r, int V, float* bv, int* bi) {
   float best = -__builtin_huge_valf();
   int idx = 0x7fffffff;
   // 16-byte loads, 1024 threads per row (a 128256-wide row took 190 us with 256 threads and 2-byte loads)
@@ -359,7 +357,42 @@ __global__ void argmax_k(const T* __restrict__ logits, int64_t* __restrict__ out
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = bi[0] == 0x7fffffff ? 0 : bi[0];   // nothing above -inf: index 0, like torch.argmax
+  return bi[0] == 0x7fffffff ? 0 : bi[0];   // nothing above -inf: index 0, like torch.argmax
+}
+
+template <typename T>
+__global__ void argmax_k(const T* __restrict__ logits, int64_t* __restrict__ out, int V) {
+  __shared__ float bv[1024];
+  __shared__ int bi[1024];
+  const int idx = row_argmax<T>(logits + (long long)blockIdx.x * V, V, bv, bi);
+  if (threadIdx.x == 0) out[blockIdx.x] = idx;
+}
+
+// The per-token bookkeeping of a greedy generate() loop ([3P] GenerationMixin._sample with do_sample = False, as the reference's
+// inference path reaches it: ultravox_model.py:422-426 -> language_model.generate) in ONE launch instead of argmax + eight small torch
+// kernels: next token = argmax of the row while the sequence is unfinished, pad_token_id afterwards; it is appended to the sequences
+// buffer; a sequence is finished once it has produced an EOS id; the next decode step's RoPE position is written; the number of still
+// unfinished rows goes to counter[step & 1] (block 0 zeroes the other slot for the next launch: launches of one loop are stream-ordered).
+template <typename T>
+__global__ void greedy_select_k(const T* __restrict__ logits, int V, const int64_t* __restrict__ eos_ids, int n_eos, int64_t pad,
+                                int32_t* __restrict__ unfinished, int64_t* __restrict__ next_tokens, int64_t* __restrict__ sequences,
+                                long long stride, long long col, const int32_t* __restrict__ pos0, int32_t* __restrict__ pos, int step,
+                                int32_t* __restrict__ counter) {
+  __shared__ float bv[1024];
+  __shared__ int bi[1024];
+  const int b = blockIdx.x;
+  const int idx = row_argmax<T>(logits + (long long)b * V, V, bv, bi);
+  if (threadIdx.x != 0) return;
+  if (b == 0) counter[(step & 1) ^ 1] = 0;
+  const bool live = unfinished[b] != 0;
+  const int64_t tok = live ? (int64_t)idx : pad;
+  next_tokens[b] = tok;
+  sequences[(long long)b * stride + col] = tok;
+  bool still = live;
+  for (int e = 0; e < n_eos; ++e) still = still && tok != eos_ids[e];
+  unfinished[b] = still ? 1 : 0;
+  if (pos) pos[b] = pos0[b] + step;
+  if (still) atomicAdd(&counter[step & 1], 1);
 }
 
 // [3P] transformers 4.51.3 GemmaModel.forward: hidden_states * tensor(hidden_size ** 0.5, dtype) - the normaliser is rounded
@@ -741,6 +774,24 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
   }
   RC(rmsnorm_fwd(st, dt, s.x, w->norm, s.hn, nullptr, B, D, c.rms_eps, c.llm_flavor));
   return gemm(st, dt, sk(lin(s.hn, w->lm_head, logits, B, c.vocab, D), s));
+}
+
+extern "C" int32_t uvx_greedy_select(void* stream, int32_t dtype, const void* logits, int32_t B, int32_t V, const int64_t* eos_ids,
+                                     int32_t n_eos, int64_t pad, int32_t* unfinished, int64_t* next_tokens, int64_t* sequences,
+                                     int64_t stride, int64_t col, const int32_t* positions0, int32_t* positions, int32_t step,
+                                     int32_t* counter) {
+  UVX_CHECK(logits && unfinished && next_tokens && sequences && counter && (n_eos == 0 || eos_ids) && (!positions || positions0), UVX_ERR_INVALID,
+            "greedy_select: null argument");
+  UVX_CHECK(B >= 0 && V > 0 && n_eos >= 0 && step >= 0 && col >= 0 && col < stride, UVX_ERR_SHAPE, "greedy_select: B=%d V=%d col=%lld stride=%lld", B, V,
+            (long long)col, (long long)stride);
+  if (B == 0) return UVX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(greedy_select_k<bf16_t>, dim3(B), dim3(1024), 0, st, (const bf16_t*)logits, V, eos_ids, n_eos, pad, unfinished,
+                                           next_tokens, sequences, (long long)stride, (long long)col, positions0, positions, step, counter);
+  else hipLaunchKernelGGL(greedy_select_k<float>, dim3(B), dim3(1024), 0, st, (const float*)logits, V, eos_ids, n_eos, pad, unfinished, next_tokens,
+                          sequences, (long long)stride, (long long)col, positions0, positions, step, counter);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
 }
 
 extern "C" int32_t uvx_argmax(void* stream, int32_t dtype, const void* logits, int32_t rows, int32_t V, int64_t* out) {

@@ -528,10 +528,11 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     void* x_out = !train ? x : (l + 1 < c.enc_layers ? enc_layer(s, l + 1).x_in : s.x);
     if (!probe_skip(128)) RC(layernorm_fwd(st, dt, x, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));
     // peft LoRA on q_proj / k_proj: result += lora_B(lora_A(x)) * scaling (and q carries Whisper's head_dim^-0.5, folded into wqkv at pack
-    // time).  Rank-r products on the VALU (lora.hip): HBM-bound, no padding to an MFMA tile.  bf16, r <= 8 (round 6): the two up-projections
-    // ride in the q|k|v GEMM's epilogue (GemmDesc::lora - lora_up's arithmetic on the staged rows; tuning option 22 = 1: the separate
-    // lora_up launches, each a read-modify-write of its [M, d] slice of qkv; bit-identical)
-    const bool lora_epi = train && dt == DT_BF16 && lora->r <= 8 && g_options[22] != 1 && g_options[1] == 2;
+    // time).  Rank-r products on the VALU (lora.hip): HBM-bound, no padding to an MFMA tile.  Tuning option 22 = 1 (bf16, r <= 8; round 6): the two
+    // up-projections ride in the q|k|v GEMM's epilogue (GemmDesc::lora - lora_up's arithmetic on the staged rows) instead of the separate
+    // lora_up launches, each a read-modify-write of its [M, d] slice of qkv.  Bit-identical, and measured 0.25 ms per step SLOWER
+    // (profiles/r06_flavours.txt: 48 launches saved, but the terms' loads sit in an epilogue nothing overlaps) - off by default.
+    const bool lora_epi = train && dt == DT_BF16 && lora->r <= 8 && g_options[22] == 1 && g_options[1] == 2;
     if (train) {
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r;
@@ -680,7 +681,7 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k], then LN1 backward into the residual stream ----
     {
       GemmDesc g = lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d);
-      const bool lora_epi = dt == DT_BF16 && r <= 8 && g_options[22] != 1 && g_options[1] == 2;      // (as in the forward pass)
+      const bool lora_epi = dt == DT_BF16 && r <= 8 && g_options[22] == 1 && g_options[1] == 2;      // (as in the forward pass: off by default)
       if (lora_epi) {
         g.n_lora = 2;
         g.lora[0] = GemmDesc::LoraTerm{s.u, R.q.a, 128, d, 0, d, r, 1.0f};

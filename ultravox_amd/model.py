@@ -140,8 +140,9 @@ class UltravoxModel:
         _lib.lib()  # fail loudly if the HIP library is missing
         if not torch.cuda.is_available():
             raise _lib.UvxError("UltravoxModel needs a GPU (MI355X / gfx950); there is no CPU path")
-        if config.llm_only_training:
-            raise ValueError("llm_only_training is outside the built scope")
+        # llm_only_training (ultravox_config.py:120; ultravox_model.py:62-67: no audio tower, no projector - the reference's text-only LoRA
+        # pre-stage, training/model_types.py:139-163): only the language model and its adapters exist; audio inputs are refused
+        self.llm_only = bool(config.llm_only_training)
         self.config = config
         self.device = torch.device(device)
         self.dtype = _torch_dtype(config, dtype)
@@ -186,7 +187,9 @@ class UltravoxModel:
         a, t = cfg.audio_config, cfg.text_config
         self.lora_r = int((getattr(cfg, "audio_model_lora_config", None) or {}).get("r", 0) or 0)      # encoder LoRA rank (0: frozen tower)
         self.is_wav2vec2 = bool(getattr(a, "is_wav2vec2", False))
-        if self.is_wav2vec2:
+        if self.llm_only:
+            self.lora_r, self.is_wav2vec2, self._enc = 0, False, None      # (LLMOnlyModelPack passes audio_model_lora_config = None)
+        elif self.is_wav2vec2:
             if self.lora_r > 0:
                 raise ValueError("audio_model_lora_config.r > 0 is built for the Whisper tower only (the wav2vec2 tower is frozen)")
             self._enc = pack_wav2vec2(sd, cfg, dt, dev)
@@ -197,9 +200,9 @@ class UltravoxModel:
         # projector: one flat trainable bucket with views (ln_pre | linear_1 | ln_mid/ln_post | linear_2)
         P = "multi_modal_projector."
         norm_key = "ln_mid" if cfg.projector_ln_mid else "ln_post"
-        parts = [sd[P + "ln_pre.weight"], sd[P + "linear_1.weight"], sd[P + norm_key + ".weight"],
-                 sd[P + "linear_2.weight"]]
-        names = list(_PROJ_ORDER)
+        parts = [] if self.llm_only else [sd[P + "ln_pre.weight"], sd[P + "linear_1.weight"], sd[P + norm_key + ".weight"],
+                                          sd[P + "linear_2.weight"]]
+        names = [] if self.llm_only else list(_PROJ_ORDER)
         # encoder LoRA: lora_A / lora_B of q_proj and k_proj of every layer join the SAME flat trainable bucket (one
         # all-reduce, one AdamW launch); missing keys get peft's initialisation (A kaiming-uniform, B zero)
         self._lora_names = []
@@ -279,7 +282,7 @@ class UltravoxModel:
         c.llm_wt_stream = int(self.stream_weight_transposes)
         self._c = c
 
-        e = self._enc
+        e = self._enc if not self.llm_only else {"layers": []}
         self._enc_layers = (_lib.EncLayer * a.encoder_layers)()
         for i, L in enumerate(e["layers"]):
             for n in _lib._ENC_LAYER_FIELDS:
@@ -300,6 +303,8 @@ class UltravoxModel:
                     getattr(ww, name)[i] = 0 if t_ is None else t_.data_ptr()
             ww.layers = self._enc_layers
             self._w2v_cfg, self._w2v_w, self._ew = wc, ww, None
+        elif self.llm_only:
+            self._ew = None
         else:
             ew = _lib.EncoderWeights()
             for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "pos", "lnf_w", "lnf_b"):
@@ -307,16 +312,16 @@ class UltravoxModel:
             ew.layers = self._enc_layers
             self._ew = ew
 
-        pw = _lib.ProjectorWeights()
-        pw.ln_pre = self._proj_views["ln_pre"].data_ptr()
-        pw.w1 = self._proj_views["linear_1"].data_ptr()
-        pw.w2 = self._proj_views["linear_2"].data_ptr()
-        pg = _lib.ProjectorGrads()
-        pg.ln_pre = self._grad_views["ln_pre"].data_ptr()
-        pg.w1 = self._grad_views["linear_1"].data_ptr()
-        pg.w2 = self._grad_views["linear_2"].data_ptr()
-        setattr(pw, norm_key, self._proj_views["ln_norm"].data_ptr())
-        setattr(pg, norm_key, self._grad_views["ln_norm"].data_ptr())
+        pw, pg = _lib.ProjectorWeights(), _lib.ProjectorGrads()
+        if not self.llm_only:
+            pw.ln_pre = self._proj_views["ln_pre"].data_ptr()
+            pw.w1 = self._proj_views["linear_1"].data_ptr()
+            pw.w2 = self._proj_views["linear_2"].data_ptr()
+            pg.ln_pre = self._grad_views["ln_pre"].data_ptr()
+            pg.w1 = self._grad_views["linear_1"].data_ptr()
+            pg.w2 = self._grad_views["linear_2"].data_ptr()
+            setattr(pw, norm_key, self._proj_views["ln_norm"].data_ptr())
+            setattr(pg, norm_key, self._grad_views["ln_norm"].data_ptr())
         self._pw, self._pg = pw, pg
 
         m = self._llm
@@ -338,9 +343,9 @@ class UltravoxModel:
         """Trainable keys under the reference's checkpoint names (ultravox_model.py:565-594 saves these): the projector
         and, with audio_model_lora_config.r > 0, the encoder's LoRA matrices under peft's names."""
         P = "multi_modal_projector."
-        out = {P + "ln_pre.weight": self._proj_views["ln_pre"], P + "linear_1.weight": self._proj_views["linear_1"],
-               P + self._norm_key + ".weight": self._proj_views["ln_norm"],
-               P + "linear_2.weight": self._proj_views["linear_2"]}
+        out = {} if self.llm_only else {P + "ln_pre.weight": self._proj_views["ln_pre"], P + "linear_1.weight": self._proj_views["linear_1"],
+                                        P + self._norm_key + ".weight": self._proj_views["ln_norm"],
+                                        P + "linear_2.weight": self._proj_views["linear_2"]}
         out.update({k: self._proj_views[k] for k in self._lora_names})
         return out
 
@@ -360,7 +365,7 @@ class UltravoxModel:
         sd = {**getattr(self, "_kept_tensors", {}), **self.projector_state_dict()}
         # frozen-tower keys nobody retained on the host are read back from the packed device weights (exact inverses of the
         # packing: weights.unpack_*) - the merged towers after merge_and_unload, or keep_params a caller added by name
-        for prefix, ok, unpack, packed in (("audio_tower.", not self.is_wav2vec2 and self.lora_r == 0, unpack_encoder, self._enc),
+        for prefix, ok, unpack, packed in (("audio_tower.", not self.llm_only and not self.is_wav2vec2 and self.lora_r == 0, unpack_encoder, self._enc),
                                            ("language_model.", self.text_lora_r == 0, unpack_llm, self._llm)):
             if ok and any(k.startswith(prefix) and k not in sd for k in self.keep_params):
                 sd = {**unpack(packed, self.config, prefix), **sd}
@@ -499,6 +504,8 @@ class UltravoxModel:
 
     def projector_grads(self) -> Dict[str, torch.Tensor]:
         P = "multi_modal_projector."
+        if self.llm_only:
+            return {k: self._grad_views[k] for k in self._lora_names}
         out = {P + "ln_pre.weight": self._grad_views["ln_pre"], P + "linear_1.weight": self._grad_views["linear_1"],
                P + self._norm_key + ".weight": self._grad_views["ln_norm"],
                P + "linear_2.weight": self._grad_views["linear_2"]}
@@ -533,6 +540,8 @@ class UltravoxModel:
     def audio_tower_forward(self, audio_values: torch.Tensor, audio_len: Optional[torch.Tensor]) -> torch.Tensor:
         """ModifiedWhisperEncoder.forward(input_features, audio_len) -> last_hidden_state [A, Te, d]."""
         l = _lib.lib()
+        if self.llm_only:      # the reference's module simply has no such attribute (ultravox_model.py:62-65)
+            raise AttributeError("'UltravoxModel' object has no attribute 'audio_tower' (config.llm_only_training: text-only model)")
         if self.is_wav2vec2:
             return self._wav2vec2_forward(audio_values)
         A, n_mels, F = audio_values.shape
@@ -1106,6 +1115,32 @@ class UltravoxModel:
         offs = torch.empty(B + 1, device=dev, dtype=torch.int32)
         unfinished = torch.ones(B, device=dev, dtype=torch.bool)
         n_decoded = 0
+        # Greedy decoding without score processors (the BASELINE inference configuration): the loop's per-token bookkeeping - argmax, pad once a
+        # sequence has finished, the EOS test, the next RoPE position - is ONE launch (uvx_greedy_select) and one 4-byte read-back instead of
+        # argmax + eight small torch kernels (round 6; profiles/r05_decode70_b8_kernel_stats.txt lists them as at::native rows).  Same tokens.
+        if rep is None and not do_sample and not want_logits and os.environ.get("UVX_GREEDY_SELECT", "1") != "0":
+            seq = torch.empty(B, T + max_new_tokens, device=dev, dtype=torch.int64)
+            seq[:, :T] = ids_dev
+            live = torch.ones(B, device=dev, dtype=torch.int32)
+            counter = torch.zeros(2, device=dev, dtype=torch.int32)
+            pos = torch.empty(B, device=dev, dtype=torch.int32)
+            n_out = 0
+            for step in range(max_new_tokens):
+                check(l.uvx_greedy_select(stream_ptr(), self.code, ptr(logits), B, V, ptr(eos_ids), len(eos_list), C.c_int64(int(pad)), ptr(live),
+                                          ptr(nxt), ptr(seq), C.c_int64(seq.stride(0)), C.c_int64(T + step), ptr(next_pos), ptr(pos), step,
+                                          ptr(counter)), "uvx_greedy_select")
+                n_out = step + 1
+                if streamer is not None:
+                    streamer.put(nxt.cpu())
+                if step + 1 == max_new_tokens or int(counter[step & 1]) == 0:
+                    break
+                check(l.uvx_embed_merge(stream_ptr(), C.byref(self._c), ptr(self._llm["embed"]), ptr(nxt), None, None, None,
+                                        None, B, 1, 0, 0, ptr(emb), ptr(offs)), "uvx_embed_merge")
+                check(l.uvx_llm_decode(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(emb), ptr(pos), ptr(kv_start),
+                                       ptr(cache), Tmax, T + step, B, ptr(logits), ptr(ws), C.c_size_t(nb)), "uvx_llm_decode")
+                n_decoded += 1
+            out = [seq[:, :T + n_out]]
+            max_new_tokens = 0          # (the generic loop below is skipped)
         for step in range(max_new_tokens):
             if want_logits:
                 step_logits.append(logits.clone())
@@ -1217,6 +1252,9 @@ class UltravoxTrainer:
         self._accum = None                    # f32 sum of the (1 / grad_accum)-scaled micro-batch gradients
         self.overlap_comm = overlap_comm
         n = model.proj_flat.numel()
+        if n == 0:      # llm_only_training without text_model_lora_config.r > 0: torch.optim raises the same way in the reference's Trainer
+            raise ValueError("optimizer got an empty parameter list (llm_only_training trains the language model's LoRA adapters: "
+                             "set text_model_lora_config.r > 0)")
         dev = model.device
         self.master = model.proj_flat.float().clone() if master_weights else None
         st_dtype = torch.float32 if (master_weights or model.dtype == torch.float32) else model.dtype
