@@ -547,6 +547,9 @@ def main():
                     help="untimed steps first; fewer than ~4 leave the clock / power ramp of a just-initialised GPU inside the timed region "
                          "(5 timed + 2 warm-up steps read 10-25 %% slow, profiles/r04_bench_short_run_bias.txt)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dgrad-nn", action="store_true",
+                    help="no transposed weight copies at all: the frozen LLM's dgrads read the forward weights through the GEMM's NN form "
+                         "(bit-identical results; -14 GB at Llama-3-8B; A/B against the resident / streamed copies)")
     ap.add_argument("--stream-wt", default="auto", choices=["auto", "on", "off"],
                     help="transposed weight copies of the frozen LLM for the backward pass: made on the fly on a side stream (on), resident (off), "
                          "or resident unless the LLM exceeds a third of the GPU's memory (auto, the model's default)")
@@ -654,7 +657,7 @@ def main():
                          projector_ln_mid=True, torch_dtype="bfloat16",
                          audio_model_lora_config={"r": args.audio_lora_r} if args.audio_lora_r else None)
     model = UltravoxModel(cfg, device=str(dev), dtype=torch.bfloat16, seed=0, rope_len=1024,
-                          stream_weight_transposes={"auto": None, "on": True, "off": False}[args.stream_wt])
+                          stream_weight_transposes={"auto": None, "on": True, "off": False}[args.stream_wt], dgrad_nn=args.dgrad_nn)
     comm = None
     if args.comm == "abi" and world > 1 and not share_gpu:
         from ultravox_amd.parallel import UvxComm

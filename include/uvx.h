@@ -414,6 +414,9 @@ typedef struct {
    * C2 [M, N/2] = silu(gate) * up.  epilogue 2: the tile is d act [M, N]; with C2 = gate|up [M, 2N] (input) it is turned
    * into d gate|up written to C [M, 2N] (ldc >= 2N). */
   void* C2; int32_t ldc2; int32_t epilogue;
+  int32_t b_kn;       /* ABI 16, bf16 only: 1 = B is stored [K, N] (row stride ldb) - C = A . B, the form a dgrad d x = d y . W takes on the forward weight
+                       * W [N_out, N_in] as it lies (no transposed copy); N % 8 == 0; bit-identical to uvx_gemm on the transposed matrix */
+  int32_t reserved_;
 } uvx_gemm_desc_t;
 /* C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual — torch.nn.Linear semantics. */
 int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* desc);
@@ -463,9 +466,7 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
  * Whisper tower under LoRA training): 0 = two 16-query tiles per wave in the dQ kernel (default), 1 = one tile per wave in both kernels (rounds 1-5), 2 = two in
  * both, 3 = two in the dK/dV kernel only, 4 = 64-row steps, 5 / 6 = eight-wave blocks (all bit-identical; A/B), key 20 = 1: the head_dim-64 forward kernel takes
  * its row max through ds_bpermute shuffles instead of v_permlane swaps (default 0; bit-identical; A/B), key 21 = 1: the training tower's GELU and GELU backward
- * run as separate kernels instead of in the fc1 / fc2-dgrad GEMM epilogues (uvx_gemm_desc_t.act 2 / 3; default 0; bit-identical; A/B), key 22 = 1: the training
- * tower's LoRA up-projections (rank <= 8) run in the q|k|v GEMM's and its dgrad's epilogues instead of as separate read-modify-write passes over q|k|v / d n
- * (default 0: measured 0.25 ms per step slower; bit-identical; A/B).  Key 23: reserved (0). */
+ * run as separate kernels instead of in the fc1 / fc2-dgrad GEMM epilogues (uvx_gemm_desc_t.act 2 / 3; default 0; bit-identical; A/B).  Keys 22, 23: reserved (0). */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* the current value of a tuning option (-1: unknown key) */
 int32_t uvx_get_option(int32_t key);

@@ -960,3 +960,32 @@ def test_mfma_32x32x16_merged_phase_kernels(variant, twin):
     a = (torch.randn(200, 128, device=DEV, generator=g)).bfloat16()
     b = (torch.randn(132, 128, device=DEV, generator=g)).bfloat16()          # N % 8 != 0: the twin's fragment-layout epilogue
     assert torch.equal(run(variant, lambda: ops().gemm(a, b)), run(twin, lambda: ops().gemm(a, b)))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 128), (2528, 4096, 6144), (2528, 4096, 4096), (1000, 1032, 256), (12000, 1024, 3072), (2528, 4096, 28672),
+                                   (316, 8192, 1024), (128, 264, 192)])
+def test_gemm_nn_form_equals_the_nt_kernel_on_the_transposed_matrix(M, N, K):
+    """Round 6: C = A . B with B stored [K, N] (uvx_gemm_desc_t.b_kn; the dgrad d x = d y . W on the forward weight as it lies): the W tile is
+    staged [k][n] and read through ds_read_b64_tr_b16 in natural k order, so every MFMA sees the operands of the NT kernel on B^T - bit-identical
+    output on every merged-phase tile (31..34), ragged M / N (N % 8 == 0), tail-split launches, with a residual; 10 repeats bit-identical."""
+    from ultravox_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(K, N, device=DEV, generator=g) * K ** -0.5).bfloat16()          # [K, N]: the forward weight of a dgrad
+    wt = w.t().contiguous()                                                           # [N, K]: the copy the NT kernel reads
+    resid = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    try:
+        for v in (31, 32, 33, 34, -1):
+            L.uvx_gemm_force_variant(v)
+            want = ops().gemm(a, wt)
+            got = ops().gemm(a, w, b_kn=True)
+            assert torch.equal(got, want), (v, int((got != want).sum()))
+            assert torch.equal(ops().gemm(a, w, b_kn=True, residual=resid), ops().gemm(a, wt, residual=resid)), v
+        L.uvx_gemm_force_variant(-1)
+        first = ops().gemm(a, w, b_kn=True)
+        for _ in range(10):
+            assert torch.equal(ops().gemm(a, w, b_kn=True), first)
+        assert rel_l2(first, a.float() @ w.float()) < 5e-3
+    finally:
+        L.uvx_gemm_force_variant(-1)

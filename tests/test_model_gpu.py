@@ -535,3 +535,35 @@ def test_attention_masks_with_holes_are_rejected_on_host_and_device():
     model.raise_pending_errors()                                                       # flag consumed
     with pytest.raises(ValueError, match="contiguous run"):                            # a NEW shape with holes: caught at once
         model.forward(input_ids=ids[:, :20].to(DEV), attention_mask=holes[:, :20].to(DEV))
+
+
+def test_llm_backward_without_transposed_copies_is_bit_identical():
+    """Round 6 (the review's "NN dgrad" item): UltravoxModel(dgrad_nn=True) keeps NO transposed copy of the frozen LLM's linears (only lm_head^T) -
+    the backward's dgrads read the forward weights through the GEMM's NN form (uvx_gemm_desc_t.b_kn) - and one training step gives the loss and the
+    projector gradients of the model with resident W^T, bit for bit (the linear weights' gradients; the two RMSNorm weight gradients are summed
+    with atomics and agree to rounding)."""
+    from oracle.reference_cpu import synthetic_batch
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = UltravoxConfig(**SMALL)
+    sd = {k: v.bfloat16() for k, v in random_state_dict(cfg, seed=7).items()}
+    b = synthetic_batch(cfg, 2, 3.0, n_text=40, audio_start=5, n_supervised=12)
+    pcm = b.pop("pcm")
+    mel = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins).logmel_device(pcm.to(DEV))
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    res = []
+    for nn in (False, True):
+        m = UltravoxModel(cfg, state_dict=dict(sd), device=DEV, dtype=torch.bfloat16, dgrad_nn=nn)
+        assert all((L["wqkv_t"] is None) == nn for L in m._llm["layers"]) and m._llm["lm_head_t"] is not None
+        m.train()
+        loss = m.forward_backward(audio_values=mel, **gb)
+        res.append((loss.clone(), {k: v.clone() for k, v in m.projector_grads().items()}))
+    (l0, g0), (l1, g1) = res
+    assert torch.equal(l0, l1)
+    for k in g0:
+        if k.endswith(("ln_pre.weight", "ln_mid.weight", "ln_post.weight")):
+            assert torch.allclose(g0[k], g1[k], rtol=1e-3, atol=1e-6), k
+        else:
+            assert torch.equal(g0[k], g1[k]), (k, int((g0[k] != g1[k]).sum()))

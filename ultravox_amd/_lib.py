@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("stride_r", C.c_int64),
         ("act", C.c_int32), ("out_f32", C.c_int32), ("accumulate", C.c_int32), ("alpha", C.c_float),
         ("C2", C.c_void_p), ("ldc2", C.c_int32), ("epilogue", C.c_int32),
+        ("b_kn", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

@@ -68,7 +68,7 @@ extern "C" int32_t uvx_gemm(void* stream, int32_t dtype, const uvx_gemm_desc_t* 
   d.res_mod = g->res_mod; d.batch = g->batch;
   d.sA = g->stride_a; d.sB = g->stride_b; d.sC = g->stride_c; d.sR = g->stride_r;
   d.act = g->act; d.out_f32 = g->out_f32; d.accumulate = g->accumulate; d.alpha = g->alpha;
-  d.C2 = g->C2; d.ldc2 = g->ldc2; d.swiglu = g->epilogue;
+  d.C2 = g->C2; d.ldc2 = g->ldc2; d.swiglu = g->epilogue; d.b_kn = g->b_kn;
   UVX_CHECK(g->epilogue == 0 || dtype == uvx::DT_BF16, UVX_ERR_UNSUPPORTED, "uvx_gemm: fused SwiGLU epilogues are bf16 only");
   return uvx::gemm((hipStream_t)stream, dtype, d);
 }

@@ -77,9 +77,7 @@ struct GemmArgs {
   // split-K launches (round 5): blockIdx.y = z of ksplit takes K-tiles [z nk / ksplit, (z + 1) nk / ksplit) and writes its f32 partial
   // tile to slab z of C (stride sC); sA = sB = 0.  splitk_reduce_k sums the slabs in a fixed order and runs the epilogue.
   int ksplit;
-  // LoRA up-projection terms of the epilogue (GemmDesc::lora); col0 = absolute output column of this launch's column 0 (tail-split launches)
-  struct Lt { const bf16_t* t; const bf16_t* w; int ldt, ldw, c0, c1, r; float alpha; } lt[2];
-  int n_lt, col0;
+  int b_kn;        // B is stored [K, N] (row stride ldb): the "NN" form - a dgrad reads the forward weight [N_out, N_in] as it lies (GemmDesc::b_kn)
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -136,7 +134,10 @@ __device__ __forceinline__ char* stage_slot(char* stage, int row, int chunk) {
 
 // GI = row fragments staged per pass: MI (the whole wave tile, MI*16 x 128 B of LDS per wave) or 1 (16 rows = 2 KiB per
 // wave: the persistent kernels, whose operand buffers are already being refilled for the next tile).
-template <int NJ, int MI, int GI = MI>
+// ACT23: the instantiation that also carries the GELU epilogues which keep / consume the pre-activation (act 2 / 3, round 6).  They are a
+// build of their own: compiled into the one epilogue, their live values cost the 256-row tile its spill-free register budget (276 bytes of
+// scratch per lane in EVERY launch of that tile, with or without act 2 / 3 - the first form of this round, caught by tools/isa_resources.py).
+template <int NJ, int MI, int GI = MI, bool ACT23 = false>
 __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ][MI], int m_base, int n_base, int frow,
                                            int fg, long long z, char* stage = nullptr) {
   const bool bf16_out = !p.out_f32;
@@ -246,28 +247,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
           const int row = it * 8 + (lane >> 3), m = m_base + i0 * 16 + row;
           uint4 o = *reinterpret_cast<const uint4*>(stage_slot<ROWS, 8>(stage, row, c8));
           if (m < p.M && n8 < p.N) {
-            if (p.n_lt > 0) {       // rank-r LoRA up-projections (GemmDesc::lora): lora_up_k's arithmetic on this lane's 8 columns of row m
-              const int ca = p.col0 + n8;
-#pragma unroll
-              for (int q = 0; q < 2; ++q) {
-                if (q >= p.n_lt || ca < p.lt[q].c0 || ca >= p.lt[q].c1) continue;
-                const GemmArgs::Lt& T = p.lt[q];
-                const uint4 yv = *reinterpret_cast<const uint4*>(T.t + (long long)m * T.ldt);
-                const float y[8] = {unpack_lo(yv.x), unpack_hi(yv.x), unpack_lo(yv.y), unpack_hi(yv.y), unpack_lo(yv.z), unpack_hi(yv.z), unpack_lo(yv.w), unpack_hi(yv.w)};
-                float la[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int j = 0; j < T.r; ++j) {
-                  const uint4 wv = *reinterpret_cast<const uint4*>(T.w + (long long)j * T.ldw + (ca - T.c0));
-                  const float wf[8] = {unpack_lo(wv.x), unpack_hi(wv.x), unpack_lo(wv.y), unpack_hi(wv.y), unpack_lo(wv.z), unpack_hi(wv.z), unpack_lo(wv.w), unpack_hi(wv.w)};
-#pragma unroll
-                  for (int k = 0; k < 8; ++k) la[k] += y[j] * wf[k];
-                }
-                o.x = pack2(unpack_lo(o.x) + bf2f(f2bf(la[0] * T.alpha)), unpack_hi(o.x) + bf2f(f2bf(la[1] * T.alpha)));
-                o.y = pack2(unpack_lo(o.y) + bf2f(f2bf(la[2] * T.alpha)), unpack_hi(o.y) + bf2f(f2bf(la[3] * T.alpha)));
-                o.z = pack2(unpack_lo(o.z) + bf2f(f2bf(la[4] * T.alpha)), unpack_hi(o.z) + bf2f(f2bf(la[5] * T.alpha)));
-                o.w = pack2(unpack_lo(o.w) + bf2f(f2bf(la[6] * T.alpha)), unpack_hi(o.w) + bf2f(f2bf(la[7] * T.alpha)));
-              }
-            }
-            if (p.act == 3) {       // GELU backward: the saved pre-activation arrives as whole lines, like a residual
+            if (ACT23 && p.act == 3) {       // GELU backward: the saved pre-activation arrives as whole lines, like a residual
               const uint4 x = *reinterpret_cast<const uint4*>(p.C2 + (long long)m * p.ldc2 + n8);
               o.x = mul_gelu_grad2(o.x, x.x); o.y = mul_gelu_grad2(o.y, x.y); o.z = mul_gelu_grad2(o.z, x.z); o.w = mul_gelu_grad2(o.w, x.w);
             }
@@ -283,7 +263,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
           }
         }
       }
-      if (p.act == 2) {
+      if (ACT23 && p.act == 2) {
         // ---- pass 2 (GELU that keeps its pre-activation): round(gelu(round(acc * alpha + bias))), [ROWS x 64] -> C2 ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pass-1 reads done before the slice is overwritten
 #pragma unroll
@@ -559,7 +539,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[NJ]
         }
         v[e] = t;
       }
-      if (p.act >= 2) {       // (bf16 output only - gemm_nt checks; fragment-layout form of the staged passes above)
+      if (ACT23 && p.act >= 2) {       // (bf16 output only - gemm_nt checks; fragment-layout form of the staged passes above)
         bf16_t* x2 = p.C2 + (long long)m * p.ldc2 + n;
         if (p.act == 2) {
           u16x4_t g4;
@@ -648,6 +628,7 @@ __device__ __forceinline__ void store_tile32(const GemmArgs& p, f32x16_t (&acc)[
   }
 }
 
+template <bool ACT23 = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[2 * BM * BK * 2];
   char* ldsX = lds;
@@ -735,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 
   // ---- epilogue ----
   __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
-  store_tile<4, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, frow, fg, z, lds + w * (4 * 16 * 128));
+  store_tile<4, 4, 4, ACT23>(p, acc, m0 + wr * 64, n0 + wc * 64, frow, fg, z, lds + w * (4 * 16 * 128));
 }
 
 
@@ -833,8 +814,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(GemmArgs p) {
 // swizzled with (row >> 1) & 7, which is distinct over the 8 even and the 8 odd rows of every ds_read_b128 lane group
 // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and their upper-half twins).  k order inside a K-tile = ascending 16-column steps: the
 // summation order differs from the 16 x 16 x 32 kernels (two 32-column steps), results agree to f32 rounding, not bitwise.
-template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false, int PH = 4, bool SK = false, bool M32 = false>
+// NN (round 6): B is stored [K, N] row-major - C = A . B instead of A . B^T - so that the frozen towers' dgrads (d x = d y . W) read the forward
+// weight W [N_out, N_in] as it lies and the transposed copies (16 GB at C2; streamed at 70B for 6 % of the step) are not needed.  Only the W
+// side changes: a K-tile's WA / WB regions are staged as [k 64][region column 128] images (256-byte rows; one DMA instruction = 4 k-rows x
+// 16 chunks; a row's region columns are the four waves' 32-column pieces, 64 contiguous bytes each in global memory), and a wave's A-operand
+// fragment [16 n][32 k] comes out of the image through the transposing LDS read: ds_read_b64_tr_b16 hands lane (i, g) the four consecutive
+// k-rows r0 .. r0 + 3 of column c0 + i when lane i of the group points at row r0 + (i >> 2), columns c0 + 4 (i & 3) - two reads (r0 = 32 kh +
+// 8 g and + 4) fill the fragment's 8 slots in NATURAL k order, so the X fragments, the MFMA sequence and therefore every result bit are those
+// of the NT kernel on the transposed copy.  Rows are 256 bytes apart (all on the same banks): 16-byte chunk c of k-row r sits at position
+// c ^ f(r), f(r) = 2 ((r & 3) | ((r >> 1) & 4)) - distinct over the 8 rows {r0..r0+3, r0+8..r0+11} one 32-lane half of a read touches.
+template <int BM, int NS = 2, int MODE = 0, bool PERSIST = false, int PH = 4, bool SK = false, bool M32 = false, bool NN = false, bool ACT23 = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
+  static_assert(!NN || (PH == 2 && !PERSIST && !SK && !M32 && MODE == 0), "the NN form exists for the merged-phase production kernels");
   static_assert(PH == 4 || (PH == 2 && (NS == 2 || NS == 3) && MODE == 0), "the merged-phase schedule: two or three buffer sets");
   static_assert(!M32 || (PH == 2 && !PERSIST && !SK && (BM / 32) % 4 == 0), "32 x 32 MFMAs: merged-phase schedule, 32-row halves");
   static_assert(!SK || (PH == 2 && !PERSIST), "stream-K is built on the merged-phase kernel");
@@ -920,7 +911,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   else if (!next_tile(orig, m0, n0)) return;   // (before any barrier)
   const long long z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA + ks_first * BK;
-  const bf16_t* B = p.B + z * p.sB + ks_first * BK;
+  const bf16_t* B = p.B + z * p.sB + (NN ? (long long)ks_first * BK * p.ldb : (long long)ks_first * BK);
 
   // one DMA instruction = rows 8q .. 8q+7 of a region; lane -> row 8q + (lane >> 3), LDS chunk position lane & 7
   // holds source chunk (lane & 7) ^ (row & 7)
@@ -928,6 +919,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
   auto sch = [&](int q) { return M32 ? ((lane & 7) ^ (((q * 8 + srow) >> 1) & 7)) : schunk; };
   struct Slot { const bf16_t* g; int off; };
+  constexpr int W_FLAG = 1 << 30;      // (NN) set in `off` of a W slot: its K-tiles are BK ROWS (BK * ldb elements) apart, not BK elements
+  const long long wstep = NN ? (long long)BK * p.ldb : (long long)BK;
+  auto nn_f = [](int r) { return 2 * ((r & 3) | ((r >> 1) & 4)); };   // (NN) chunk swizzle of k-row r
   auto x_slot = [&](bool half_b, int q) {
     const int per = (half_b ? MB : MA) * 16;
     const int hr = q * 8 + srow, wrr = hr / per, rem = hr - wrr * per;
@@ -935,6 +929,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     return Slot{A + (long long)min(m0 + row, p.M - 1) * p.lda + sch(q) * 8, (half_b ? O_XB : O_XA) + q * 1024};
   };
   auto w_slot = [&](bool half_b, int q) {
+    if constexpr (NN) {
+      // instruction q = k-rows 4 q .. 4 q + 3 of the region; lane -> row 4 q + (lane >> 4), LDS chunk position lane & 15 holds region chunk
+      // (lane & 15) ^ f(row); region chunk c' = columns 64 (c' >> 2) + (half_b ? 32 : 0) + 8 (c' & 3) .. + 7 of the tile
+      const int row = q * 4 + (lane >> 4), cc = (lane & 15) ^ nn_f(row);
+      const int n = (cc >> 2) * 64 + (half_b ? 32 : 0) + (cc & 3) * 8;
+      return Slot{B + (long long)row * p.ldb + min(n0 + n, p.N - 8), ((half_b ? O_WB : O_WA) + q * 1024) | W_FLAG};
+    }
     const int hr = q * 8 + srow;
     const int n = (hr >> 5) * 64 + (half_b ? 32 : 0) + (hr & 31);
     return Slot{B + (long long)min(n0 + n, p.N - 1) * p.ldb + sch(q) * 8, (half_b ? O_WB : O_WA) + q * 1024};
@@ -963,10 +964,26 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
     wo[kh] = (wc * 32 + frow) * 128 + c;
   }
   const int xa_base = O_XA + wr * MA * 16 * 128, xb_base = O_XB + wr * MB * 16 * 128;
+  // (NN) A-operand fragment (16 region columns wc * 32 + j * 16 + .., k = 32 kh + 8 fg + 0..7) of a [64 k][128 columns] image: two transposing reads
+  auto nn_frag = [&](const char* region, int j, int kh) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const int i = lane & 15, r0 = kh * 32 + fg * 8 + (i >> 2);
+    const int c = wc * 4 + j * 2 + ((i & 3) >> 1), half = (i & 1) * 8;
+    const char* p0 = region + r0 * 256 + ((c ^ nn_f(r0)) << 4) + half;
+    const char* p1 = region + (r0 + 4) * 256 + ((c ^ nn_f(r0 + 4)) << 4) + half;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
 
   auto dma = [&](const Slot& sl, int t, int set_idx) {   // set_idx = t % NS, tracked by the caller
     if (MODE == 2 && t >= NS) return;
-    glds16(sl.g + (SK ? kbase + t : t) * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_idx * SET));
+    if constexpr (NN) {
+      const bool isw = sl.off >= 0 && (sl.off & W_FLAG);
+      glds16(sl.g + (long long)t * (isw ? wstep : (long long)BK), lds + (sl.off < 0 ? O_DUMMY : (sl.off & ~W_FLAG) + set_idx * SET));
+    } else {
+      glds16(sl.g + (SK ? kbase + t : t) * BK, lds + (sl.off < 0 ? O_DUMMY : sl.off + set_idx * SET));
+    }
   };
 #define UVX_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 // PRIO: who gets issue priority on a SIMD shared by a wave in its MFMA section and one in its load section.
@@ -1116,8 +1133,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-          wa[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + O_WA + wo[kh] + j * 16 * 128);
-          wb[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + O_WB + wo[kh] + j * 16 * 128);
+          if constexpr (NN) {
+            wa[j][kh] = nn_frag(set + O_WA, j, kh);
+            wb[j][kh] = nn_frag(set + O_WB, j, kh);
+          } else {
+            wa[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + O_WA + wo[kh] + j * 16 * 128);
+            wb[j][kh] = *reinterpret_cast<const bf16x8_t*>(set + O_WB + wo[kh] + j * 16 * 128);
+          }
         }
 #pragma unroll
       for (int i = 0; i < MA; ++i)
@@ -1349,7 +1371,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_ph8_kernel(GemmArgs p) {
   if (!PERSIST) {
     __syncthreads();   // every wave is done with the staged operand tiles: the LDS becomes the output stage
     if constexpr (M32) store_tile32<(MI + 1) / 2>(p, acc32, m0 + wr * (BM / 2), n0 + wc * 64, lane, z, lds + w * (MI * 16 * 128));
-    else store_tile<4, MI>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
+    else store_tile<4, MI, MI, ACT23>(p, acc, m0 + wr * (BM / 2), n0 + wc * 64, frow, fg, z, lds + w * (MI * 16 * 128));
     break;
   }
   // every wave has passed its last fragment read (the barriers above): the operand buffers are free.  Start the next
@@ -1849,6 +1871,8 @@ thread_local LaunchEvents g_launch_ev;
   } while (0)
 
 void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int batch) {
+  if (a.b_kn && (variant < 31 || variant > 34)) variant = 34;     // (the NN form exists for the merged-phase tiles: a tail launch's small-tile pick)
+  if (a.act >= 2 && variant != 0 && (variant < 32 || variant > 34)) variant = variant == 31 || variant == 11 || variant == 16 ? 32 : variant == 15 || variant == 18 || variant == 59 ? 33 : 34;   // (act 2 / 3: builds of 0 and 32..34 - the 256-row tile would spill)
   a.M = M; a.N = N;
   a.tiles_m = cdiv(M, kVariants[variant].bm); a.tiles_n = cdiv(N, kVariants[variant].bn);
   dim3 grid(a.tiles_m * a.tiles_n, batch);
@@ -1867,23 +1891,36 @@ void launch_variant(hipStream_t st, int variant, GemmArgs a, int M, int N, int b
   }
 #endif
   switch (variant) {
-    case 0: UVX_GEMM_LAUNCH(gemm_nt_bf16_kernel, grid, dim3(256), st, a); break;
+    case 0:
+      if (a.act >= 2) UVX_GEMM_LAUNCH(gemm_nt_bf16_kernel<true>, grid, dim3(256), st, a);
+      else UVX_GEMM_LAUNCH(gemm_nt_bf16_kernel<false>, grid, dim3(256), st, a);
+      break;
     case 11: UVX_GEMM_LAUNCH(gemm_nt_bf16_ph8_kernel<256>, grid, dim3(512), st, a); break;
     case 15: UVX_GEMM_LAUNCH(gemm_nt_bf16_ph8_kernel<160>, grid, dim3(512), st, a); break;
     case 16: UVX_GEMM_LAUNCH(gemm_nt_bf16_ph8_kernel<192>, grid, dim3(512), st, a); break;
     case 17: UVX_GEMM_LAUNCH(gemm_nt_bf16_ph8_kernel<128>, grid, dim3(512), st, a); break;
     case 18: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 3>), grid, dim3(512), st, a); break;
     case 19: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 3>), grid, dim3(512), st, a); break;
-    case 31: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2>), grid, dim3(512), st, a); break;
-    case 32: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<192, 2, 0, false, 2>), grid, dim3(512), st, a); break;
-    case 33: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 2, 0, false, 2>), grid, dim3(512), st, a); break;
-    case 34: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 2, 0, false, 2>), grid, dim3(512), st, a); break;
+#define UVX_PH2(BMV)                                                                                                          \
+  do {                                                                                                                        \
+    if (a.b_kn) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<BMV, 2, 0, false, 2, false, false, true>), grid, dim3(512), st, a);  \
+    else if (a.act >= 2) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<BMV, 2, 0, false, 2, false, false, false, true>), grid, dim3(512), st, a); \
+    else UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<BMV, 2, 0, false, 2>), grid, dim3(512), st, a);                             \
+  } while (0)
+    case 31:      // (no act 2 / 3 build of the 256-row tile: it would spill - launch_variant sends those launches to the 192-row tile)
+      if (a.b_kn) UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2, false, false, true>), grid, dim3(512), st, a);
+      else UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<256, 2, 0, false, 2>), grid, dim3(512), st, a);
+      break;
+    case 32: UVX_PH2(192); break;
+    case 33: UVX_PH2(160); break;
+    case 34: UVX_PH2(128); break;
+#undef UVX_PH2
     case 59: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<160, 3, 0, false, 2>), grid, dim3(512), st, a); break;
     case 60: UVX_GEMM_LAUNCH((gemm_nt_bf16_ph8_kernel<128, 3, 0, false, 2>), grid, dim3(512), st, a); break;
     case 61: case 62: {
       // the 32 x 32 x 16 kernels carry the plain whole-line epilogue only
       const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-      const bool plain = !a.out_f32 && a.swiglu == 0 && a.act < 2 && a.n_lt == 0 && a.wide_io == 2 && a.ksplit <= 1 && !a.m_dev && (a.N & 7) == 0 && (a.ldc & 7) == 0 &&
+      const bool plain = !a.out_f32 && a.swiglu == 0 && a.act < 2 && a.wide_io == 2 && a.ksplit <= 1 && !a.m_dev && (a.N & 7) == 0 && (a.ldc & 7) == 0 &&
                          (a.sC & 7) == 0 && al16(a.C) && (!a.bias || ((uintptr_t)a.bias & 7) == 0) &&
                          (!a.residual || ((a.ldr & 7) == 0 && (a.sR & 7) == 0 && al16(a.residual)));
       if (!plain) { launch_variant(st, variant == 61 ? 31 : 34, a, M, N, batch); return; }
@@ -2206,7 +2243,7 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   // few rows: stream the weights.  Beyond 16 rows the weight-streaming kernels serve 16-row tiles one after the other (MT = 2, 4) and lose to a
   // 128 x 256 tile whose K loop is cut over 6-8 blocks wherever the caller lent split-K scratch (Llama-3.3-70B's four linears, us per
   // launch, staged kernel / tiled split-K: 32 rows 447 / 345, 64 rows 871 / 358 - profiles/r05_gemm_splitk_decode_rows.txt)
-  const bool split_ok = d.splitk_ws && d.batch <= 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.act < 2 && d.n_lora == 0 && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
+  const bool split_ok = d.splitk_ws && d.batch <= 1 && !d.out_f32 && !d.m_dev && d.swiglu != 2 && d.act < 2 && !d.b_kn && d.splitk_force != 1 && d.N % 8 == 0 && d.ldc % 8 == 0 &&
       ((uintptr_t)d.C & 15) == 0 && ((uintptr_t)d.splitk_ws & 15) == 0 && (!d.bias || ((uintptr_t)d.bias & 15) == 0) &&
       (!d.residual || (d.ldr % 8 == 0 && ((uintptr_t)d.residual & 15) == 0)) &&
       (!d.swiglu || (d.ldc2 % 8 == 0 && ((uintptr_t)d.C2 & 15) == 0));      // (the reduce kernel's 16-byte accesses apply)
@@ -2230,17 +2267,9 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   a.m_major = uvx::g_options[7] && d.M > d.N && (d.batch <= 1);
   a.m_dev = d.m_dev; a.m_dev_off = d.m_dev_off;
   a.sk_full = 0; a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0; a.ksplit = 1;
-  a.n_lt = d.n_lora; a.col0 = 0;
-  for (int q = 0; q < 2; ++q) {
-    const GemmDesc::LoraTerm& T = d.lora[q];
-    a.lt[q] = GemmArgs::Lt{(const bf16_t*)T.t, (const bf16_t*)T.w, T.ldt, T.ldw, T.c0, T.c1, T.r, T.alpha};
-    UVX_CHECK(q >= d.n_lora || (T.t && T.w && T.r > 0 && T.r <= 8 && T.ldt % 8 == 0 && T.ldw % 8 == 0 && T.c0 % 64 == 0 && T.c1 % 64 == 0 &&
-                               ((uintptr_t)T.t & 15) == 0 && ((uintptr_t)T.w & 15) == 0), UVX_ERR_INVALID,
-              "gemm: LoRA epilogue term %d needs rank <= 8, 16-byte-aligned t / w with ldt, ldw multiples of 8 and a 64-aligned column range", q);
-  }
-  UVX_CHECK(d.n_lora == 0 || (d.n_lora <= 2 && !d.out_f32 && !d.residual && d.act == 0 && !d.swiglu && d.batch <= 1 && !d.m_dev && uvx::g_options[1] == 2 &&
-                              d.N % 8 == 0 && d.ldc % 8 == 0 && ((uintptr_t)d.C & 15) == 0), UVX_ERR_INVALID,
-            "gemm: the LoRA epilogue needs the whole-line bf16 epilogue (N, ldc multiples of 8, aligned C) and no residual / act / swiglu / batch");
+  a.b_kn = d.b_kn;
+  UVX_CHECK(!d.b_kn || (d.N % 8 == 0 && d.N >= 8 && d.batch <= 1 && ((uintptr_t)d.B & 15) == 0), UVX_ERR_INVALID,
+            "gemm: the NN form (B stored [K, N]) needs N %% 8 == 0, a 16-byte-aligned B and no batch");
   UVX_CHECK(!d.swiglu || (d.C2 && !d.out_f32 && !d.bias && !d.residual && d.act == 0 && d.N % 32 == 0 && d.ldc2 % 4 == 0 && (d.batch <= 1)),
             UVX_ERR_INVALID, "gemm: swiglu epilogue needs C2, bf16 output, N %% 32 == 0 and no bias/act/residual/batch");
   UVX_CHECK(d.swiglu != 2 || (d.N % 16 == 0 && d.ldc >= 2 * d.N && d.ldc2 >= 2 * d.N), UVX_ERR_INVALID,
@@ -2296,6 +2325,14 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   int variant = pick_variant(d.M, d.N, d.K, batch, &cost_whole, gelu);
   if (sparse_variant >= 0 && sparse_variant != variant) { variant = sparse_variant; cost_whole = variant_cost(variant, d.M, d.N, d.K, batch, gelu); }
   if (is_a4(variant) && !a4_applicable(d)) variant = 31;     // (the eight-wave 256 x 256 kernel takes any alignment)
+  if (d.b_kn && (variant < 31 || variant > 34)) {             // the NN form exists for the merged-phase tiles: the cheapest of them
+    double best = 1e300;
+    for (int v = 31; v <= 34; ++v) {
+      const double cst = variant_cost(v, d.M, d.N, d.K, batch, gelu);
+      if (cst < best) { best = cst; variant = v; }
+    }
+    cost_whole = best;
+  }
   UVX_CHECK(variant_available(variant), UVX_ERR_INVALID,
             "gemm: tile variant %d is not in this build (probe variants live in libuvx_probes.so, built with -DUVX_PROBES)", variant);
   // (device-side row count: the true work is unknown here, such launches are left out of the timing)
@@ -2330,12 +2367,11 @@ int uvx::gemm_nt(hipStream_t st, const GemmDesc& d) {
   g_launch_ev = LaunchEvents{};
   if (tail_variant >= 0) {
     GemmArgs t = a;
-    t.B = a.B + (long long)n_main * a.ldb;
+    t.B = a.b_kn ? a.B + n_main : a.B + (long long)n_main * a.ldb;
     if (a.bias) t.bias = a.bias + n_main;
     if (a.residual) t.residual = a.residual + n_main;
     if (a.swiglu == 1) t.C2 = a.C2 + n_main / 2;
     if (a.act >= 2) t.C2 = a.C2 + n_main;
-    t.col0 = n_main;
     t.C = a.out_f32 ? (void*)((float*)a.C + n_main) : (void*)((bf16_t*)a.C + n_main);
     if (a.swiglu == 2) { t.C2 = a.C2 + 2 * n_main; t.C = (void*)((bf16_t*)a.C + 2 * n_main); }   // [M, 2N] operands
     g_launch_ev = LaunchEvents{nullptr, ev_b};

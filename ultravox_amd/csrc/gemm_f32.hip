@@ -87,7 +87,7 @@ int uvx::gemm_nt_f32(hipStream_t st, const GemmDesc& d) {
   UVX_CHECK(d.M > 0 && d.N > 0 && d.K > 0, UVX_ERR_SHAPE, "gemm_f32: empty problem %dx%dx%d", d.M, d.N, d.K);
   UVX_CHECK(d.K % TK == 0, UVX_ERR_SHAPE, "gemm_f32: K=%d must be a multiple of %d", d.K, TK);
   UVX_CHECK(d.lda % 4 == 0 && d.ldb % 4 == 0, UVX_ERR_SHAPE, "gemm_f32: lda/ldb must be multiples of 4");
-  UVX_CHECK(d.act < 2 && d.n_lora == 0, UVX_ERR_UNSUPPORTED, "gemm_f32: the act 2 / 3 and LoRA epilogues exist on the bf16 path only");
+  UVX_CHECK(d.act < 2 && !d.b_kn, UVX_ERR_UNSUPPORTED, "gemm_f32: the act 2 / 3 epilogues and the NN form exist on the bf16 path only");
   GemmF32Args a;
   a.A = (const float*)d.A; a.B = (const float*)d.B; a.C = (float*)d.C;
   a.bias = (const float*)d.bias; a.residual = (const float*)d.residual;

@@ -442,7 +442,7 @@ int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm
 bool gemm_skinny_applicable(const GemmDesc& d) {
   // (M = 17..64: only the staged kernel serves several activation row tiles)
   const bool rows_ok = d.M <= 16 || (d.M <= 64 && d.K % 2048 == 0 && uvx::g_options[4] != 2);
-  return d.M > 0 && rows_ok && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 && d.act < 2 && d.n_lora == 0 &&
+  return d.M > 0 && rows_ok && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 && d.act < 2 && !d.b_kn &&
          d.K % 32 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.N % 4 == 0 && d.ldc % 4 == 0 &&
          (!d.swiglu || (d.N % 32 == 0 && d.ldc2 % 4 == 0)) && (!d.residual || d.ldr % 4 == 0) && uvx::g_options[4];
 }

@@ -41,14 +41,9 @@ struct GemmDesc {
   int out_f32 = 0;   // bf16 path only: write f32 (wgrad)
   int accumulate = 0;
   float alpha = 1.0f;
-  // Rank-r LoRA up-projections added in the epilogue (bf16 path, round 6; r <= 8): for output columns c0 <= c < c1
-  //   C[m, c] = round(C[m, c] + round(alpha * sum_j t[m, j] * w[j, c - c0]))          t [M, ldt] (rows padded to 8 values, zeros beyond r), w [r, ldw]
-  // - what lora_up(accumulate) does to the finished GEMM output, bit for bit (peft: result + lora_B(lora_A(x)) * scaling).  Up to two terms,
-  // applied in order (they may cover the same columns: the encoder's d n = d qkv . Wqkv + u_q . A_q + u_k . A_k).  Needs the whole-line
-  // epilogue (bf16 output, N % 8 == 0, 16-byte-aligned C, c0 / c1 multiples of 64); no residual / act / swiglu with it.
-  struct LoraTerm { const void* t = nullptr; const void* w = nullptr; int ldt = 0, ldw = 0, c0 = 0, c1 = 0, r = 0; float alpha = 1.0f; };
-  LoraTerm lora[2];
-  int n_lora = 0;
+  // bf16 path, round 6: B is stored [K, N] (row stride ldb) - C = A . B, the "NN" form: a dgrad d x = d y . W reads the forward weight
+  // W [N_out, N_in] as it lies instead of a transposed copy.  Merged-phase tiles only (N % 8 == 0); bit-identical to the NT kernel on B^T.
+  int b_kn = 0;
   // fused LlamaMLP activation (bf16 path): B's rows alternate 16 gate / 16 up rows; C gets gate|up in that
   // interleaved order, C2 [M, N/2] (row stride ldc2) gets silu(gate) * up
   void* C2 = nullptr;

@@ -456,6 +456,14 @@ GemmDesc lin(const void* A, const void* W, void* C, int M, int N, int K) {
   g.A = A; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
   return g;
 }
+// The dgrad of a frozen linear y = x . W^T (W [N_out, N_in]):  d x [M, N_in] = d y [M, N_out] . W.  With the transposed copy Wt [N_in, N_out]
+// it is the NT problem lin(d y, Wt, ..); without one (Wt == NULL; bf16, round 6) the NN form reads W as it lies (GemmDesc::b_kn: B [K, N],
+// row stride N) - bit-identical, and the copy (16 GB of them for Llama-3-8B) need not exist.
+GemmDesc lin_dgrad(const void* dY, const void* Wt, const void* W, void* dX, int M, int N_in, int N_out) {
+  GemmDesc g = lin(dY, Wt ? Wt : W, dX, M, N_in, N_out);
+  if (!Wt) { g.b_kn = 1; g.ldb = N_in; }
+  return g;
+}
 
 }  // namespace
 
@@ -527,31 +535,22 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
     void* x_mid = train ? S.x_mid : x;            // inference: the residual stream is updated in place
     void* x_out = !train ? x : (l + 1 < c.enc_layers ? enc_layer(s, l + 1).x_in : s.x);
     if (!probe_skip(128)) RC(layernorm_fwd(st, dt, x, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));
-    // peft LoRA on q_proj / k_proj: result += lora_B(lora_A(x)) * scaling (and q carries Whisper's head_dim^-0.5, folded into wqkv at pack
-    // time).  Rank-r products on the VALU (lora.hip): HBM-bound, no padding to an MFMA tile.  Tuning option 22 = 1 (bf16, r <= 8; round 6): the two
-    // up-projections ride in the q|k|v GEMM's epilogue (GemmDesc::lora - lora_up's arithmetic on the staged rows) instead of the separate
-    // lora_up launches, each a read-modify-write of its [M, d] slice of qkv.  Bit-identical, and measured 0.25 ms per step SLOWER
-    // (profiles/r06_flavours.txt: 48 launches saved, but the terms' loads sit in an epilogue nothing overlaps) - off by default.
-    const bool lora_epi = train && dt == DT_BF16 && lora->r <= 8 && g_options[22] == 1 && g_options[1] == 2;
+    {
+      GemmDesc g = lin(s.n, L.wqkv, qkv, M, 3 * d, d);
+      g.bias = L.bqkv;
+      RC(gemm(st, dt, enc_sk(g, s)));
+    }
     if (train) {
+      // peft LoRA on q_proj / k_proj: result += lora_B(lora_A(x)) * scaling (and q carries Whisper's head_dim^-0.5,
+      // folded into wqkv at pack time).  Rank-r products on the VALU (lora.hip): HBM-bound, no padding to an MFMA tile.
+      // (Round 6, tried and removed: the two up-projections as terms of the q|k|v GEMM's whole-line epilogue - and of its dgrad's - instead
+      //  of read-modify-write passes over qkv / d n.  Bit-identical, 96 launches fewer per step and 0.25 ms per step SLOWER: the terms'
+      //  loads sit in an epilogue nothing overlaps, and their registers cost the 256-row tile its spill-free budget - profiles/r06_flavours.txt.)
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r;
       RC(lora_transpose2(st, dt, R.q.b, S.bqT, d, R.k.b, S.bkT, d, r));
       RC(lora_down(st, dt, s.n, d, R.q.a, 0, S.t, 128, M, d, r, 1.0f));
       RC(lora_down(st, dt, s.n, d, R.k.a, 0, at(S.t, 64, dt), 128, M, d, r, 1.0f));
-    }
-    {
-      GemmDesc g = lin(s.n, L.wqkv, qkv, M, 3 * d, d);
-      g.bias = L.bqkv;
-      if (lora_epi) {
-        g.n_lora = 2;
-        g.lora[0] = GemmDesc::LoraTerm{S.t, S.bqT, 128, d, 0, d, lora->r, lora->scaling * qscale};
-        g.lora[1] = GemmDesc::LoraTerm{at(S.t, 64, dt), S.bkT, 128, d, d, 2 * d, lora->r, lora->scaling};
-      }
-      RC(gemm(st, dt, enc_sk(g, s)));
-    }
-    if (train && !lora_epi) {
-      const int r = lora->r;
       RC(lora_up(st, dt, S.t, 128, S.bqT, 1, qkv, 3 * d, M, d, r, lora->scaling * qscale, 1));
       RC(lora_up(st, dt, at(S.t, 64, dt), 128, S.bkT, 1, at(qkv, d, dt), 3 * d, M, d, r, lora->scaling, 1));
     }
@@ -679,20 +678,9 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     }
     if (l == 0) break;   // nothing trainable below layer 0
     // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k], then LN1 backward into the residual stream ----
-    {
-      GemmDesc g = lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d);
-      const bool lora_epi = dt == DT_BF16 && r <= 8 && g_options[22] == 1 && g_options[1] == 2;      // (as in the forward pass: off by default)
-      if (lora_epi) {
-        g.n_lora = 2;
-        g.lora[0] = GemmDesc::LoraTerm{s.u, R.q.a, 128, d, 0, d, r, 1.0f};
-        g.lora[1] = GemmDesc::LoraTerm{at(s.u, 64, dt), R.k.a, 128, d, 0, d, r, 1.0f};
-      }
-      RC(gemm(st, dt, g));
-      if (!lora_epi) {
-        RC(lora_up(st, dt, s.u, 128, R.q.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
-        RC(lora_up(st, dt, at(s.u, 64, dt), 128, R.k.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
-      }
-    }
+    RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d)));
+    RC(lora_up(st, dt, s.u, 128, R.q.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+    RC(lora_up(st, dt, at(s.u, 64, dt), 128, R.k.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
     RC(layernorm_bwd(st, dt, s.d_n, S.x_in, L.ln1_w, s.dx, s.dx, M, d, c.ln_eps));
   }
   return UVX_OK;
@@ -1109,6 +1097,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   // llm_wt_stream: a side stream transposes lm_head and then, one layer ahead of the layer being differentiated, each layer's
   // four matrices into the alternating buffers s.wt[l & 1]; e_ready[b] = buffer b holds its layer, e_free[b] = the caller's stream
   // is done with buffer b.  (One chain only: the chains' side streams would each need the same waits.)
+  // (neither resident copies nor the stream, bf16: the transposed pointers stay NULL and lin_dgrad takes the NN form on the forward weights)
   struct LayerT { const void *wqkv_t, *wo_t, *wgu_t, *wd_t; };
   WtStream* wt = nullptr;
   auto layer_t = [&](int l) -> LayerT {
@@ -1203,23 +1192,23 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     if (g3) {
       // x_out = x_mid + post_ffw_norm(m_pre): d m_pre = norm'(dx) -> d act -> d gate|up -> d n2; d x_mid = dx + pre_ffw_norm'(d n2)
       RC(rmsnorm_bwd(sx, dt, v.dx, cur.m_pre, L.ln2_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
-      RC(gemm(sx, dt, lin(v.d_n, layer_t(l).wd_t, v.d_act, Mv, c.llm_inter, D)));
+      RC(gemm(sx, dt, lin_dgrad(v.d_n, layer_t(l).wd_t, L.wd, v.d_act, Mv, c.llm_inter, D)));
       RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
-      RC(gemm(sx, dt, lin(v.d_gu, layer_t(l).wgu_t, v.d_n, Mv, D, 2 * c.llm_inter)));
+      RC(gemm(sx, dt, lin_dgrad(v.d_gu, layer_t(l).wgu_t, L.wgu, v.d_n, Mv, D, 2 * c.llm_inter)));
       return rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl);
     }
     if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
-      GemmDesc g = lin(v.dx, layer_t(l).wd_t, v.d_gu, Mv, c.llm_inter, D);
+      GemmDesc g = lin_dgrad(v.dx, layer_t(l).wd_t, L.wd, v.d_gu, Mv, c.llm_inter, D);
       g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     } else {
-      GemmDesc g = lin(v.dx, layer_t(l).wd_t, v.d_act, Mv, c.llm_inter, D);
+      GemmDesc g = lin_dgrad(v.dx, layer_t(l).wd_t, L.wd, v.d_act, Mv, c.llm_inter, D);
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
       if (!probe_skip(4)) RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act, mdev));
     }
     {
-      GemmDesc g = lin(v.d_gu, layer_t(l).wgu_t, v.d_n, Mv, D, 2 * c.llm_inter);
+      GemmDesc g = lin_dgrad(v.d_gu, layer_t(l).wgu_t, L.wgu, v.d_n, Mv, D, 2 * c.llm_inter);
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
@@ -1233,8 +1222,8 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     const int Mv = v.M;
     if (g3) {      // x_mid = x_in + post_attention_norm(o_pre): d o_pre = norm'(d x_mid), then the o_proj dgrad
       RC(rmsnorm_bwd(sx, dt, v.dx, cur.o_pre, L.ln1_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
-      RC(gemm(sx, dt, lin(v.d_n, layer_t(l).wo_t, v.d_o, Mv, s.OD, D)));
-    } else if (!d_o_ready) RC(gemm(sx, dt, lin(v.dx, layer_t(l).wo_t, v.d_o, Mv, s.OD, D)));
+      RC(gemm(sx, dt, lin_dgrad(v.d_n, layer_t(l).wo_t, L.wo, v.d_o, Mv, s.OD, D)));
+    } else if (!d_o_ready) RC(gemm(sx, dt, lin_dgrad(v.dx, layer_t(l).wo_t, L.wo, v.d_o, Mv, s.OD, D)));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, cur.qkv, v.qT, Bv, T, s.Tp, Hq, dh, s.QKV));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, at(cur.qkv, (size_t)Hq * dh, dt), v.kT, Bv, T, s.Tp, Hkv, dh, s.QKV));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, v.d_o, v.doT, Bv, T, s.Tp, Hq, dh, s.OD));
@@ -1257,7 +1246,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     if (!probe_skip(1)) RC(attention_bwd(sx, dt, bd));
     if (!rope_fused) RC(rope_inplace(sx, dt, v.d_qkv, rope, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
     if (c.llm_qk_norm) RC(qk_norm_bwd(sx, dt, v.d_qkv, cur.qk_raw, L.q_norm, L.k_norm, Mv, Hq, Hkv, dh, s.QKV, c.rms_eps, g3 ? 1 : 0));
-    RC(gemm(sx, dt, lin(v.d_qkv, layer_t(l).wqkv_t, v.d_n, Mv, D, s.QKV)));
+    RC(gemm(sx, dt, lin_dgrad(v.d_qkv, layer_t(l).wqkv_t, L.wqkv, v.d_n, Mv, D, s.QKV)));
     if (lora) {   // LoRA gradients of q_proj / k_proj and their contribution to d n1 (rank-r products, lora.hip)
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const uvx_enc_lora_layer_grads_t& G = lgrads->layers[l];
@@ -1278,14 +1267,15 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   };
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
-    UVX_CHECK(wts || (L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t), UVX_ERR_INVALID, "llm_bwd: layer %d lacks transposed weights", l);
+    UVX_CHECK(wts || dt == DT_BF16 || (L.wd_t && L.wgu_t && L.wo_t && L.wqkv_t), UVX_ERR_INVALID,
+              "llm_bwd: layer %d lacks transposed weights (f32: the NN form of the dgrads exists on the bf16 path only)", l);
   }
   const int top = c.llm_layers - 1;
   if (wts) UVX_HIP(hipStreamWaitEvent(st, wt->e_ready[top & 1], 0));
   if (tc) {   // last layer of the training pair: MLP and o_proj gradients on the compact supervised rows (whole batch, this
               // stream), then d o and the residual-stream gradient go back to their full rows for the attention backward
     RC(layer_mlp_bwd(st, s, top, true));
-    GemmDesc g = lin(s.dx, layer_t(top).wo_t, s.doT, M, s.OD, D);     // doT ([B, Hq, Tp, dh] >= M * OD) is free until the transpose
+    GemmDesc g = lin_dgrad(s.dx, layer_t(top).wo_t, w->layers[top].wo, s.doT, M, s.OD, D);     // doT ([B, Hq, Tp, dh] >= M * OD) is free until the transpose
     g.m_dev = mdev_top;
     RC(gemm(st, dt, g));
     UVX_HIP(hipMemsetAsync(s.d_o, 0, (size_t)M * s.OD * es, st));

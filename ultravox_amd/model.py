@@ -130,7 +130,7 @@ class UltravoxModel:
     def __init__(self, config: UltravoxConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  device: str = "cuda", dtype: Optional[torch.dtype] = None, seed: int = 0,
                  with_backward: bool = True, rope_len: Optional[int] = None, consume_state_dict: bool = False,
-                 stream_weight_transposes: Optional[bool] = None):
+                 stream_weight_transposes: Optional[bool] = None, dgrad_nn: bool = False):
         """consume_state_dict: pop the LLM's q/k/v/gate/up tensors from `state_dict` as they are packed (the dict is left
         without them) so that loading peaks at one copy of the model plus a layer - for the 70B-parameter LLM (C4).
         stream_weight_transposes: the backward pass needs the frozen LLM's weights transposed; True = made on the fly, one layer
@@ -175,6 +175,11 @@ class UltravoxModel:
             llm_bytes = (per_layer * t.num_hidden_layers + 2 * t.vocab_size * t.hidden_size) * (2 if self.dtype == torch.bfloat16 else 4)
             total = torch.cuda.get_device_properties(self.device).total_memory
             stream_weight_transposes = llm_bytes > total / 3
+        # dgrad_nn (bf16, round 6): neither resident nor streamed W^T - the frozen LLM's dgrads read the forward weights through the GEMM's NN
+        # form (uvx_gemm_desc_t.b_kn; bit-identical results): -14 GB at Llama-3-8B, no transposing side stream at 70B.  lm_head^T stays.
+        self.dgrad_nn = bool(dgrad_nn) and with_backward and self.dtype == torch.bfloat16
+        if self.dgrad_nn:
+            stream_weight_transposes = False
         self.stream_weight_transposes = bool(stream_weight_transposes) and with_backward
         self._load(state_dict, rope_len)
         self._ws: Dict[str, torch.Tensor] = {}
@@ -195,7 +200,7 @@ class UltravoxModel:
             self._enc = pack_wav2vec2(sd, cfg, dt, dev)
         else:
             self._enc = pack_encoder(sd, cfg, dt, dev, with_transposes=self.lora_r > 0 and self.with_backward)
-        self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=self.with_backward and not self.stream_weight_transposes, rope_len=rope_len,
+        self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=("head" if self.dgrad_nn else self.with_backward and not self.stream_weight_transposes), rope_len=rope_len,
                              consume=getattr(self, "_consume_sd", False))
         # projector: one flat trainable bucket with views (ln_pre | linear_1 | ln_mid/ln_post | linear_2)
         P = "multi_modal_projector."

@@ -17,12 +17,12 @@ from ._lib import check, dtype_code, ptr, stream_ptr
 def gemm(a: torch.Tensor, b: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, act: str = "none", out: Optional[torch.Tensor] = None,
          out_f32: bool = False, accumulate: bool = False, alpha: float = 1.0, res_mod: int = 0,
-         epilogue: int = 0, c2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) + residual   (nn.Linear layout)."""
-    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1]
+         epilogue: int = 0, c2: Optional[torch.Tensor] = None, b_kn: bool = False) -> torch.Tensor:
+    """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) + residual   (nn.Linear layout); b_kn: b is [K, N] and out = a @ b (the NN form)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[0 if b_kn else 1]
     assert a.stride(1) == 1 and b.stride(1) == 1
     M, K = a.shape
-    N = b.shape[0]
+    N = b.shape[1 if b_kn else 0]
     dt = dtype_code(a.dtype)
     if out is None:
         out = torch.empty((M, N), device=a.device,
@@ -42,6 +42,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     d.alpha = alpha
     d.epilogue = epilogue
     d.C2, d.ldc2 = (0, 0) if c2 is None else (c2.data_ptr(), c2.stride(0))
+    d.b_kn = int(b_kn)
     check(_lib.lib().uvx_gemm(stream_ptr(), dt, C.byref(d)), "uvx_gemm")
     return out
 

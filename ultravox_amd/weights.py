@@ -336,7 +336,10 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
     plus one layer (what a 70B-parameter LLM needs to load into 288 GB next to its KV cache) — `sd` is left without them."""
     t = cfg.text_config
     cv = lambda x: x.to(device=device, dtype=dtype).contiguous()
-    tr = lambda x: x.t().contiguous() if with_transposes else None
+    # with_transposes: True = a resident W^T per frozen linear + lm_head^T (the NT dgrads), False = none (inference, or the streamed copies),
+    # "head" = lm_head^T only: the layers' dgrads then take the NN form on the forward weights (csrc/model.hip lin_dgrad; bf16, round 6)
+    tr_head = lambda x: x.t().contiguous() if with_transposes else None
+    tr = lambda x: x.t().contiguous() if with_transposes is True else None
     if prefix + "model.embed_tokens.weight" not in sd and prefix + "base_model.model.model.embed_tokens.weight" in sd:
         prefix = prefix + "base_model.model."          # a peft-wrapped LLM (LoRA checkpoints)
     P = prefix + "model."
@@ -348,7 +351,7 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
     if prefix + "lm_head.weight" not in sd and not getattr(t, "ties_head", getattr(t, "is_gemma", False)):
         raise KeyError(f"{prefix}lm_head.weight is missing and the config does not tie the head to embed_tokens "
                        "(tie_word_embeddings; Gemma always ties)")
-    out["lm_head_t"] = tr(out["lm_head"])
+    out["lm_head_t"] = tr_head(out["lm_head"])
     for i in range(t.num_hidden_layers):
         L = f"{P}layers.{i}."
         wqkv = cv(torch.cat([sd[L + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0))
