@@ -466,7 +466,9 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
  * Whisper tower under LoRA training): 0 = two 16-query tiles per wave in the dQ kernel (default), 1 = one tile per wave in both kernels (rounds 1-5), 2 = two in
  * both, 3 = two in the dK/dV kernel only, 4 = 64-row steps, 5 / 6 = eight-wave blocks (all bit-identical; A/B), key 20 = 1: the head_dim-64 forward kernel takes
  * its row max through ds_bpermute shuffles instead of v_permlane swaps (default 0; bit-identical; A/B), key 21 = 1: the training tower's GELU and GELU backward
- * run as separate kernels instead of in the fc1 / fc2-dgrad GEMM epilogues (uvx_gemm_desc_t.act 2 / 3; default 0; bit-identical; A/B).  Keys 22, 23: reserved (0). */
+ * run as separate kernels instead of in the fc1 / fc2-dgrad GEMM epilogues (uvx_gemm_desc_t.act 2 / 3; default 0; bit-identical; A/B), key 23 = 1: the decode step's rotary embedding and
+ * KV-cache append of the new token run as their own launch per layer instead of inside the grouped decode-attention kernel (default 0; bit-identical; A/B).
+ * Key 22: reserved (0). */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* the current value of a tuning option (-1: unknown key) */
 int32_t uvx_get_option(int32_t key);

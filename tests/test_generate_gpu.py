@@ -507,3 +507,44 @@ def test_greedy_bookkeeping_in_one_launch_equals_the_generic_loop(dtype, monkeyp
             row = got.sequences[0, T:].tolist()
             first = next(i for i, t in enumerate(row) if t in stops)
             assert all(t == 1 for t in row[first + 1:])
+
+
+@pytest.mark.parametrize("heads,kv_heads,head_dim", [(4, 2, 64), (8, 2, 128), (8, 1, 128), (4, 4, 128)])
+def test_rope_and_cache_append_inside_the_decode_attention_is_bit_identical(heads, kv_heads, head_dim):
+    """Round 6 (tuning option 23): the grouped decode-attention kernel rotates the new token's q / k and appends its k / v rows to the cache itself
+    instead of after a rope_kv_append_k launch per layer - same step logits at every decoded position and the same KV cache, bit for bit, for
+    group sizes 1 / 2 / 4 / 8 (incl. the head-split blocks that write the same cache row), left padding, B = 3."""
+    from test_model_gpu import SMALL
+    from ultravox_amd import _lib
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    L = _lib.lib()
+    small = dict(SMALL)
+    small["text_config"] = dict(small["text_config"], num_attention_heads=heads, num_key_value_heads=kv_heads, head_dim=head_dim,
+                                hidden_size=heads * head_dim if heads * head_dim >= 256 else 256)
+    cfg = UltravoxConfig(**small)
+    sd = {k: v.bfloat16() for k, v in random_state_dict(cfg, seed=37).items()}
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16, rope_len=512, with_backward=False)
+    torch.manual_seed(2)
+    ids = torch.randint(3, cfg.vocab_size - 1, (3, 21)).to(DEV)
+    am = torch.ones(3, 21, dtype=torch.long)
+    am[1, :5] = 0
+    res = []
+    try:
+        for opt in (1, 0):
+            L.uvx_set_option(23, opt)
+            out = model.generate(ids, attention_mask=am.to(DEV), max_new_tokens=9, eos_token_id=-1, return_dict_in_generate=True, output_logits=True)
+            torch.cuda.synchronize()
+            st = out.past_key_values
+            t = cfg.text_config
+            planes = t.num_hidden_layers * 2 * 3
+            rows = st.cache.view(torch.bfloat16)[:planes * st.Tmax * kv_heads * head_dim].view(planes, st.Tmax, kv_heads * head_dim)[:, :st.cur_len]
+            res.append((out.sequences.clone(), [x.clone() for x in out.logits], rows.clone(), st.cur_len))      # (rows beyond cur_len are never written)
+    finally:
+        L.uvx_set_option(23, 0)
+    (s0, l0, c0, n0), (s1, l1, c1, n1) = res
+    assert torch.equal(s0, s1) and n0 == n1
+    for a, b in zip(l0, l1):
+        assert torch.equal(a, b)
+    assert torch.equal(c0, c1)

@@ -211,11 +211,16 @@ __global__ void attn_decode_k(const T* __restrict__ qkv, const T* __restrict__ c
 //   phase 3  P . V: thread = (key residue class, query head, 8 output dimensions): 16-byte V loads, four keys in flight, the residue
 //            classes folded through LDS in a fixed order.
 // sc: dynamic LDS, G * len floats.
+// rope_cs != NULL (round 6, tuning option 23): the kernel ALSO does what rope_kv_append_k did for the new token in a launch of its own (4.9 us per
+// layer: 5 % of a Llama-3-8B token) - the block's G query heads are rotated while they are loaded, and the new token's key (rotated) and value rows of
+// its KV head are written to cache row len - 1 before the scores are taken.  With hsplit > 1 several blocks write the same values to the same row
+// (benign); a block reads the row only after its own stores are fenced and barriered.  rope_kv_append_k's arithmetic and rounding points: bit-identical.
 template <typename T, int D, int G, int NTH>
-__global__ __launch_bounds__(NTH) void attn_decode_grp_k(const T* __restrict__ qkv, const T* __restrict__ cache_k,
-                                                         const T* __restrict__ cache_v, T* __restrict__ out,
+__global__ __launch_bounds__(NTH) void attn_decode_grp_k(const T* __restrict__ qkv, T* __restrict__ cache_k,
+                                                         T* __restrict__ cache_v, T* __restrict__ out,
                                                          const int32_t* __restrict__ kv_start, int Hq, int Hkv, int Tmax,
-                                                         int len, int QKV, float scale, int lo_clamp, int hsplit) {
+                                                         int len, int QKV, float scale, int lo_clamp, int hsplit,
+                                                         const float* __restrict__ rope_cs, const int32_t* __restrict__ rope_pos) {
   // hsplit: the query heads of a KV head are dealt to `hsplit` blocks of G heads each (G = group size / hsplit): at batch 1 a 70B
   // decode step had 8 blocks of 8 heads - 20 us of latency on 8 of 256 CUs; 64 blocks of one head re-read K / V from L2 and finish sooner
   extern __shared__ float sc[];                 // [G][len]
@@ -234,8 +239,35 @@ __global__ __launch_bounds__(NTH) void attn_decode_grp_k(const T* __restrict__ q
   const int KVD = Hkv * D;
   const T* kbase = cache_k + (long long)b * Tmax * KVD + hk * D + ch * 8;
   const T* vbase = cache_v + (long long)b * Tmax * KVD + hk * D;
-  for (int i = tid; i < G * D; i += NTH) qs[i / D][i % D] = ldf<T>(qkv + (long long)b * QKV + (hq0 + i / D) * D + i % D);
+  if (rope_cs) {
+    const float* t = rope_cs + (long long)rope_pos[b] * (D / 2) * 2;
+    const T* row = qkv + (long long)b * QKV;
+    // items: (head among the G query heads + the KV head's key, pair index d < D / 2); then the value row's 8-element chunks
+    for (int i = tid; i < (G + 1) * (D / 2); i += NTH) {
+      const int hh = i / (D / 2), d = i % (D / 2);
+      const T* base = hh < G ? row + (hq0 + hh) * D : row + (Hq + hk) * D;
+      const float lo = ldf<T>(base + d), hi = ldf<T>(base + D / 2 + d);
+      const float co = rnd<T>(t[2 * d]), si = rnd<T>(t[2 * d + 1]);
+      const float olo = rnd<T>(rnd<T>(lo * co) + rnd<T>(-hi * si)), ohi = rnd<T>(rnd<T>(hi * co) + rnd<T>(lo * si));
+      if (hh < G) { qs[hh][d] = olo; qs[hh][D / 2 + d] = ohi; }
+      else {
+        T* kc = cache_k + ((long long)b * Tmax + len - 1) * KVD + hk * D;
+        stf<T>(kc + d, olo); stf<T>(kc + D / 2 + d, ohi);
+      }
+    }
+    if (tid < D / 8) {
+      float v[8];
+      ld8<T>(row + (Hq + Hkv) * D + hk * D + tid * 8, v);
+      st8<T>(cache_v + ((long long)b * Tmax + len - 1) * KVD + hk * D + tid * 8, v);
+    }
+    // the row is read back below by other threads of THIS block only: a workgroup-scope release (the stores have left the wave) + the barrier;
+    // a device-scope fence here costs a cache write-back per block (first form of this change: 3.31 -> 3.44 ms per token, B = 8 3.9 -> 5.7)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  } else {
+    for (int i = tid; i < G * D; i += NTH) qs[i / D][i % D] = ldf<T>(qkv + (long long)b * QKV + (hq0 + i / D) * D + i % D);
+  }
   __syncthreads();
+  if (rope_cs) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   // ---- phase 1: scores (two passes of keys in flight per trip) ----
   {
     float q[G][8];
@@ -320,12 +352,13 @@ __global__ __launch_bounds__(NTH) void attn_decode_grp_k(const T* __restrict__ q
 
 // launch helper: static LDS (~36 KB) + the dynamic score array (<= 48 KB) exceed the 64 KB a launch gets by default
 template <int DD, int GG>
-int launch_decode_grp(hipStream_t st, size_t sh, int blocks, const bf16_t* qkv, const bf16_t* ck, const bf16_t* cv, bf16_t* o,
-                      const int32_t* kv_start, int Hq, int Hkv, int Tmax, int len, int QKV, float scale, int lo, int hsplit) {
+int launch_decode_grp(hipStream_t st, size_t sh, int blocks, const bf16_t* qkv, bf16_t* ck, bf16_t* cv, bf16_t* o,
+                      const int32_t* kv_start, int Hq, int Hkv, int Tmax, int len, int QKV, float scale, int lo, int hsplit,
+                      const float* rope_cs, const int32_t* rope_pos) {
   static PerDeviceOnce attr_set;
   UVX_SET_ATTR_ONCE(attr_set, (attn_decode_grp_k<bf16_t, DD, GG, 1024>), 64 * 1024);
   hipLaunchKernelGGL((attn_decode_grp_k<bf16_t, DD, GG, 1024>), dim3(blocks), dim3(1024), sh, st, qkv, ck, cv, o, kv_start, Hq, Hkv, Tmax, len,
-                     QKV, scale, lo, hsplit);
+                     QKV, scale, lo, hsplit, rope_cs, rope_pos);
   return UVX_OK;
 }
 
@@ -739,18 +772,24 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
     const long long n = (long long)B * (KVD / 8);
     const int nw = B * Hq;
     if (dt == DT_BF16) {
-      if (fuse_rope_append) {
-        launch_rope_kv_append<bf16_t>(st, s.qkv, w->rope_cos_sin, positions, ck, cv, B, 1, Tmax, cur_len, Hq, Hkv, dh, s.QKV);
-      } else {
-        hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
-      }
       const int Gall = Hq / Hkv, len = cur_len + 1;
       // query heads of a KV head per block: split the group until ~256 blocks are in flight (powers of two that divide the group)
       int hsplit = 1;
       while (hsplit * 2 <= Gall && Gall % (hsplit * 2) == 0 && B * Hkv * hsplit < 256) hsplit *= 2;
       const int G = Gall / hsplit;
       const size_t sh = sizeof(float) * (size_t)G * len;
-#define UVX_DEC(DD, GG) RC((launch_decode_grp<DD, GG>(st, sh, B * Hkv * hsplit, (const bf16_t*)s.qkv, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale, lo, hsplit)))
+      // the grouped attention kernel rotates q / k and appends the new k / v rows itself (option 23; Gemma-3's local layers have their own table:
+      // they keep the separate launch) - otherwise rope_kv_append_k (or, with q / k norms, kv_append_k after qkv_rope) runs first
+      const bool grp = sh <= 48 * 1024 && ((dh == 128 && (G == 1 || G == 2 || G == 4 || G == 8)) || (dh == 64 && (G == 1 || G == 2 || G == 4)));
+      const bool in_attn = fuse_rope_append && grp && g_options[23] != 1 && c.llm_flavor != UVX_LLM_GEMMA3;
+      const float* rcs = in_attn ? w->rope_cos_sin : nullptr;
+      if (in_attn) {
+      } else if (fuse_rope_append) {
+        launch_rope_kv_append<bf16_t>(st, s.qkv, w->rope_cos_sin, positions, ck, cv, B, 1, Tmax, cur_len, Hq, Hkv, dh, s.QKV);
+      } else {
+        hipLaunchKernelGGL(kv_append_k<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, B, 1, Tmax, cur_len, s.QKV, Hq * dh, KVD);
+      }
+#define UVX_DEC(DD, GG) RC((launch_decode_grp<DD, GG>(st, sh, B * Hkv * hsplit, (const bf16_t*)s.qkv, (bf16_t*)ck, (bf16_t*)cv, (bf16_t*)s.o, kv_start, Hq, Hkv, Tmax, len, s.QKV, scale, lo, hsplit, rcs, positions)))
       if (sh <= 48 * 1024 && dh == 128 && G == 4) UVX_DEC(128, 4);
       else if (sh <= 48 * 1024 && dh == 128 && G == 8) UVX_DEC(128, 8);
       else if (sh <= 48 * 1024 && dh == 128 && G == 2) UVX_DEC(128, 2);
