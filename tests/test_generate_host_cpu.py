@@ -78,6 +78,19 @@ class FakeLib:
         out.copy_(logits.argmax(-1))
         return 0
 
+    def uvx_greedy_select(self, st, code, logits, B, Vv, eos_ids, n_eos, pad, live, nxt, seq, stride, col, pos0, pos, step, counter):
+        """include/uvx.h: tok = unfinished ? argmax : pad; appended; unfinished &= tok not an EOS id; positions = positions0 + step; the count of
+        unfinished rows goes to counter[step & 1] and the other slot is cleared."""
+        tok = torch.where(live.bool(), logits.argmax(-1), torch.full((B,), int(pad.value), dtype=torch.int64))
+        nxt.copy_(tok)
+        seq[:, int(col.value)] = tok
+        live.copy_((live.bool() & ~torch.isin(tok, eos_ids[:n_eos])).int())
+        if pos is not None:
+            pos.copy_(pos0 + step)
+        counter[step & 1] = int(live.sum())
+        counter[(step & 1) ^ 1] = 0
+        return 0
+
 
 @pytest.fixture()
 def model(monkeypatch):
