@@ -290,13 +290,8 @@ def test_gelu_epilogues_in_the_training_tower_are_bit_identical_to_the_separate_
             L.uvx_set_option(21, o21)
             loss, g = run()
             assert torch.equal(loss, loss0), o21
-            for k in g0:
-                # (the RMSNorm weight gradients of the projector are summed with f32 atomics - norms.hip rmsnorm_bwd_k - and move by an ulp from
-                #  run to run with ANY setting; everything else is order-deterministic)
-                if k.endswith(("ln_pre.weight", "ln_mid.weight", "ln_post.weight")):
-                    assert torch.allclose(g[k], g0[k], rtol=1e-3, atol=1e-6), (o21, k)
-                else:
-                    assert torch.equal(g[k], g0[k]), (o21, k, (g[k] != g0[k]).sum().item())
+            for k in g0:      # (every gradient, the RMSNorm weights' included: their block partials are summed in a fixed order since round 6)
+                assert torch.equal(g[k], g0[k]), (o21, k, (g[k] != g0[k]).sum().item())
         assert sum(v.abs().sum().item() for v in g0.values()) > 0
     finally:
         L.uvx_set_option(21, 0)

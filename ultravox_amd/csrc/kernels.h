@@ -106,7 +106,10 @@ int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y
 // (f32 [cols], atomically accumulated; must be zeroed by the caller).
 int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w,
                 const void* dx_add, void* dx, float* dw, int rows, int cols, float eps, int flavor = 0,
-                const int32_t* rows_dev = nullptr);
+                const int32_t* rows_dev = nullptr, float* dw_part = nullptr);
+// dw_part: scratch of rmsnorm_bwd_dw_scratch_floats(rows, cols) floats - the weight gradient is then summed over the blocks in a fixed order
+// (dw += the sum; bit-reproducible) instead of with atomics
+long long rmsnorm_bwd_dw_scratch_floats(int rows, int cols);
 // StackAudioFrames + RMSNorm (ultravox_model.py:722-730, 791): x [B, T, C] -> y [B, Tp/S, C*S]
 int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y, void* stacked,
                       int B, int T, int C, int S, float eps);

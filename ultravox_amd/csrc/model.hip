@@ -3,6 +3,7 @@
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
+#include <algorithm>
 #include "common.h"
 #include "kernels.h"
 #include "../../include/uvx.h"
@@ -140,6 +141,7 @@ EncWs enc_carve(Arena& a, const uvx_config_t& c, int B, int F, bool train = fals
 struct ProjWs {
   void *stacked, *xn, *h1, *a, *an, *ypre;                                        // forward stash
   void *dy2, *dyT, *anT, *w2T, *d_an, *d_a, *d_h1, *dh1T, *xnT, *w1T, *d_xn;      // backward temps
+  float* dwp;                                                                     // per-block partials of the RMSNorm weight gradients (fixed-order sum)
   int J, R, Rp, C8, H, Hh, D;
 };
 ProjWs proj_carve(Arena& a, const uvx_config_t& c, int B, int Te) {
@@ -169,6 +171,7 @@ ProjWs proj_carve(Arena& a, const uvx_config_t& c, int B, int Te) {
   w.xnT = a.take((size_t)w.C8 * w.Rp * es);
   w.w1T = a.take((size_t)w.C8 * w.H * es);
   w.d_xn = a.take((size_t)w.R * w.C8 * es);
+  w.dwp = (float*)a.take(sizeof(float) * (size_t)rmsnorm_bwd_dw_scratch_floats(w.R, std::max(std::max(w.C8, w.D), w.Hh)));
   return w;
 }
 
@@ -748,7 +751,7 @@ extern "C" int32_t uvx_projector_bwd(void* stream, const uvx_config_t* cfg, cons
   if (c.proj_ln_mid) RC(fill_zero(st, gr->ln_mid, sizeof(float) * s.Hh));
   else {
     RC(fill_zero(st, gr->ln_post, sizeof(float) * s.D));
-    RC(rmsnorm_bwd(st, dt, dout, s.ypre, w->ln_post, nullptr, s.dy2, gr->ln_post, s.R, s.D, c.proj_eps));
+    RC(rmsnorm_bwd(st, dt, dout, s.ypre, w->ln_post, nullptr, s.dy2, gr->ln_post, s.R, s.D, c.proj_eps, 0, nullptr, s.dwp));
     dy = s.dy2;
   }
   // linear_2: dW2[D, Hh] = dy^T . an ; d_an = dy . W2
@@ -762,7 +765,7 @@ extern "C" int32_t uvx_projector_bwd(void* stream, const uvx_config_t* cfg, cons
   RC(transpose2d(st, dt, w->w2, s.w2T, s.D, s.Hh, s.Hh, s.D, 1, 0, 0));
   RC(gemm(st, dt, lin(dy, s.w2T, s.d_an, s.R, s.Hh, s.D)));
   if (c.proj_ln_mid)
-    RC(rmsnorm_bwd(st, dt, s.d_an, s.a, w->ln_mid, nullptr, s.d_a, gr->ln_mid, s.R, s.Hh, c.proj_eps));
+    RC(rmsnorm_bwd(st, dt, s.d_an, s.a, w->ln_mid, nullptr, s.d_a, gr->ln_mid, s.R, s.Hh, c.proj_eps, 0, nullptr, s.dwp));
   if (c.proj_act == UVX_PROJ_SWIGLU) RC(swiglu_bwd(st, dt, s.d_a, s.h1, s.d_h1, s.R, s.Hh, 0));
   else RC(act_bwd(st, dt, s.d_a, s.h1, s.d_h1, (long long)s.R * s.H, c.proj_act - 1));
   // linear_1: dW1[H, C8] = d_h1^T . xn ; d_xn = d_h1 . W1 (only needed for the ln_pre weight gradient)
@@ -776,12 +779,12 @@ extern "C" int32_t uvx_projector_bwd(void* stream, const uvx_config_t* cfg, cons
   RC(transpose2d(st, dt, w->w1, s.w1T, s.H, s.C8, s.C8, s.H, 1, 0, 0));
   RC(gemm(st, dt, lin(s.d_h1, s.w1T, s.d_xn, s.R, s.C8, s.H)));
   if (!d_enc_out) {
-    RC(rmsnorm_bwd(st, dt, s.d_xn, s.stacked, w->ln_pre, nullptr, nullptr, gr->ln_pre, s.R, s.C8, c.proj_eps));
+    RC(rmsnorm_bwd(st, dt, s.d_xn, s.stacked, w->ln_pre, nullptr, nullptr, gr->ln_pre, s.R, s.C8, c.proj_eps, 0, nullptr, s.dwp));
     return UVX_OK;
   }
   // the encoder trains too (LoRA): d stacked [R, S*C] in place of d_xn, then un-stack: clip b's frames are the first
   // Te * C elements of its J * S * C block (the padded tail frames get no gradient consumer)
-  RC(rmsnorm_bwd(st, dt, s.d_xn, s.stacked, w->ln_pre, nullptr, s.d_xn, gr->ln_pre, s.R, s.C8, c.proj_eps));
+  RC(rmsnorm_bwd(st, dt, s.d_xn, s.stacked, w->ln_pre, nullptr, s.d_xn, gr->ln_pre, s.R, s.C8, c.proj_eps, 0, nullptr, s.dwp));
   const size_t es = esz(dt);
   UVX_HIP(hipMemcpy2DAsync(d_enc_out, (size_t)Te * c.enc_d * es, s.d_xn, (size_t)s.J * s.C8 * es, (size_t)Te * c.enc_d * es, B,
                            hipMemcpyDeviceToDevice, st));

@@ -300,13 +300,16 @@ __global__ void rmsnorm_fwd_reg_k(const T* __restrict__ x, const T* __restrict__
 }
 
 // One block handles `rpb` consecutive rows; each thread owns fixed columns so the weight gradient
-// is accumulated in registers and flushed with one atomicAdd per column per block.
+// is accumulated in registers and flushed once per column per block: into dw_part [block][cols] when the caller lends that scratch
+// (round 6: rmsnorm_dw_reduce_k then sums the blocks in block order - the projector's norm-weight gradients were the one output of a
+// training step that moved by an ulp from run to run), else with an atomicAdd into dw (uvx_rmsnorm_bwd: the ABI has no scratch argument).
 // MV: 8-element vectors per thread (static trip count; the launcher picks the smallest that covers the row - at the LLM's 4096
 // columns MV = 2 needs half the registers of MV = 6 and twice as many rows are in flight per CU)
 template <typename T, bool WANT_DX, bool WANT_DW, int MV>
 __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
                               const T* __restrict__ dx_add, T* __restrict__ dx, float* __restrict__ dw,
-                              int rows, int cols, float eps, int rpb, int flavor, const int32_t* __restrict__ rows_dev) {
+                              int rows, int cols, float eps, int rpb, int flavor, const int32_t* __restrict__ rows_dev,
+                              float* __restrict__ dw_part) {
   if (rows_dev) rows = min(rows, *rows_dev);     // device-side row count (row-compacted buffers)
   // flavor 1 (Gemma): y = x_hat * (1 + w) with no intermediate rounding -> the effective weight is 1 + w and
   // d w gets the UNROUNDED x_hat
@@ -378,10 +381,24 @@ __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
     for (int j = 0; j < MV; ++j) {
       const int c = (j * blockDim.x + threadIdx.x) * 8;
       if (c >= cols) continue;
+      if (dw_part) {
+        *reinterpret_cast<float4*>(dw_part + (long long)blockIdx.x * cols + c) = make_float4(dwacc[j][0], dwacc[j][1], dwacc[j][2], dwacc[j][3]);
+        *reinterpret_cast<float4*>(dw_part + (long long)blockIdx.x * cols + c + 4) = make_float4(dwacc[j][4], dwacc[j][5], dwacc[j][6], dwacc[j][7]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) atomicAdd(dw + c + i, dwacc[j][i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(dw + c + i, dwacc[j][i]);
+      }
     }
   }
+}
+
+// dw[c] += sum over blocks (ascending) of dw_part[block][c]: fixed order, bit-reproducible
+__global__ void rmsnorm_dw_reduce_k(const float* __restrict__ part, int nblocks, int cols, float* __restrict__ dw) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[(long long)b * cols + c];
+  dw[c] += s;
 }
 
 int norm_threads(int cols) {
@@ -471,7 +488,7 @@ int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, v
 
 template <typename T>
 static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const void* w, const void* dx_add,
-                          void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev) {
+                          void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev, float* dw_part) {
   const int th = 256;   // (512 threads with one vector each: 20.4 vs 17.7 us at 2528 x 4096 - profiles/r03_rmsnorm_bwd_variants.txt)
   UVX_CHECK(cols % 8 == 0 && cols <= th * 8 * MAXV, UVX_ERR_SHAPE, "rmsnorm_bwd: cols=%d unsupported", cols);
   if (rows == 0) return UVX_OK;
@@ -481,26 +498,29 @@ static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const v
   do {                                                                                                            \
     if (cols <= th * 8)                                                                                           \
       hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, 1>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x,   \
-                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev);     \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev, dw ? dw_part : nullptr);     \
     else if (cols <= th * 8 * 2)                                                                                  \
       hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, 2>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x,   \
-                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev);     \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev, dw ? dw_part : nullptr);     \
     else                                                                                                          \
       hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, MAXV>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x, \
-                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev);     \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev, dw ? dw_part : nullptr);     \
   } while (0)
   if (dx && dw) L(true, true);
   else if (dx) L(true, false);
   else if (dw) L(false, true);
 #undef L
+  if (dw && dw_part) hipLaunchKernelGGL(rmsnorm_dw_reduce_k, dim3(cdiv(cols, 256)), dim3(256), 0, st, dw_part, grid, cols, dw);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }
 
+long long rmsnorm_bwd_dw_scratch_floats(int rows, int cols) { return (long long)((rows + 15) / 16) * cols; }
+
 int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w, const void* dx_add,
-                void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev) {
-  return dtype == DT_BF16 ? rms_bwd_launch<bf16_t>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev)
-                          : rms_bwd_launch<float>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev);
+                void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev, float* dw_part) {
+  return dtype == DT_BF16 ? rms_bwd_launch<bf16_t>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev, dw_part)
+                          : rms_bwd_launch<float>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev, dw_part);
 }
 
 }  // namespace uvx
