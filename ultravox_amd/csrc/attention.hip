@@ -274,6 +274,7 @@ __device__ __forceinline__ void store_rows(char* stage, const u16x4_t (&v)[DT], 
 // TR: V is staged in its natural [key][d] layout and read through the transposing LDS read (no V^T copy in global memory)
 // PL: the cross-lane max / sum of a query row through v_permlane*_swap (quad_max) instead of two ds_bpermute shuffles
 // (tried, round 6: the tile's V fragments read into registers BEFORE the softmax - 184 registers, occupancy 2: 7 % slower, profiles/r06_attn_fwd64_ab.txt)
+// (tried, round 6: s_setprio 1 around the two MFMA clusters of a tile - 111.6 / 114.9 us against 112.4 / 113.6: neutral, same file)
 template <int D, int QT, bool TR, bool PL = true>
 __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   constexpr int BQ = 4 * QT * 16;
