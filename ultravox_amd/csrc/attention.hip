@@ -275,6 +275,8 @@ __device__ __forceinline__ void store_rows(char* stage, const u16x4_t (&v)[DT], 
 // PL: the cross-lane max / sum of a query row through v_permlane*_swap (quad_max) instead of two ds_bpermute shuffles
 // (tried, round 6: the tile's V fragments read into registers BEFORE the softmax - 184 registers, occupancy 2: 7 % slower, profiles/r06_attn_fwd64_ab.txt)
 // (tried, round 6: s_setprio 1 around the two MFMA clusters of a tile - 111.6 / 114.9 us against 112.4 / 113.6: neutral, same file)
+// (tried, round 6: the softmax row sums from a fifth "d-tile" of ones in the P.V product instead of 16 v_add_f32 per 16 scores - 111.3 / 113.0 us
+//  against 113.9 / 113.4: within noise, and the normaliser then sums bf16-rounded probabilities (max |d O| 2e-3); not kept)
 template <int D, int QT, bool TR, bool PL = true>
 __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   constexpr int BQ = 4 * QT * 16;
