@@ -467,8 +467,8 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
  * both, 3 = two in the dK/dV kernel only, 4 = 64-row steps, 5 / 6 = eight-wave blocks (all bit-identical; A/B), key 20 = 1: the head_dim-64 forward kernel takes
  * its row max through ds_bpermute shuffles instead of v_permlane swaps (default 0; bit-identical; A/B), key 21 = 1: the training tower's GELU and GELU backward
  * run as separate kernels instead of in the fc1 / fc2-dgrad GEMM epilogues (uvx_gemm_desc_t.act 2 / 3; default 0; bit-identical; A/B), key 23 = 1: the decode step's rotary embedding and
- * KV-cache append of the new token run as their own launch per layer instead of inside the grouped decode-attention kernel (default 0; bit-identical; A/B).
- * Key 22: reserved (0). */
+ * KV-cache append of the new token run as their own launch per layer instead of inside the grouped decode-attention kernel (default 0; bit-identical; A/B)., key 22 = 1: the training tower's q_proj / k_proj adapter products run as
+ * separate launches instead of paired ones (lora_down2 / lora_up2 / one partial-sum launch for the four weight gradients; default 0; bit-identical; A/B). */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* the current value of a tuning option (-1: unknown key) */
 int32_t uvx_get_option(int32_t key);

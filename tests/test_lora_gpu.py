@@ -269,7 +269,7 @@ def test_kl_step_under_llm_lora_matches_the_reference_model_fixture(dtype):
 
 
 @pytest.mark.parametrize("r", [4, 8])
-def test_gelu_epilogues_in_the_training_tower_are_bit_identical_to_the_separate_kernels(r):
+def test_gelu_epilogues_and_paired_adapter_launches_are_bit_identical_to_the_separate_kernels(r):
     """Round 6: the training tower's GELU / GELU backward in the fc1 / fc2-dgrad GEMM epilogues (tuning option 21 = 0, the default) against the
     separate gelu_* launches of rounds 3-5 (option 21 = 1): same loss and the same projector + adapter gradients, bit for bit (the epilogues
     restate the kernels' arithmetic and rounding points)."""
@@ -285,9 +285,11 @@ def test_gelu_epilogues_in_the_training_tower_are_bit_identical_to_the_separate_
 
     try:
         L.uvx_set_option(21, 1)
+        L.uvx_set_option(22, 1)      # (and the q_proj / k_proj adapter products as separate launches: option 22 = 1; paired by default)
         loss0, g0 = run()
         for o21 in (0, 1, 0):
             L.uvx_set_option(21, o21)
+            L.uvx_set_option(22, o21)
             loss, g = run()
             assert torch.equal(loss, loss0), o21
             for k in g0:      # (every gradient, the RMSNorm weights' included: their block partials are summed in a fixed order since round 6)
@@ -295,6 +297,7 @@ def test_gelu_epilogues_in_the_training_tower_are_bit_identical_to_the_separate_
         assert sum(v.abs().sum().item() for v in g0.values()) > 0
     finally:
         L.uvx_set_option(21, 0)
+        L.uvx_set_option(22, 0)
 
 
 def test_llm_only_training_builds_the_language_model_alone(tmp_path):

@@ -170,6 +170,11 @@ int lora_down(hipStream_t st, int dtype, const void* X, long long ldx, const voi
 // columns (zeros beyond r, as lora_down leaves them) with ldy % 8 == 0 and 16-byte-aligned Y / W / Z - checked.
 int lora_up(hipStream_t st, int dtype, const void* Y, long long ldy, const void* W, int w_is_rc, void* Z, long long ldz,
             long long M, int C, int r, float alpha, int accumulate);
+// round 6: the q_proj / k_proj pair of a layer in ONE launch each (blockIdx.y = which; bit-identical to two calls; tuning option 22 = 1: two launches)
+int lora_down2(hipStream_t st, int dtype, const void* X0, const void* X1, long long ldx, const void* W0, const void* W1, void* Y0, void* Y1,
+               long long ldy, long long M, int C, int r, float alpha0, float alpha1);
+int lora_up2(hipStream_t st, int dtype, const void* Y0, const void* Y1, long long ldy, const void* W0, const void* W1, void* Z0, void* Z1,
+             long long ldz, long long M, int C0, int C1, int r, float alpha0, float alpha1);
 // out = alpha * Y[M, r]^T . X[M, C]  as [r][C] or, transpose_out, [C][r]  (f32; scratch: lora_wgrad_scratch_floats)
 long long lora_wgrad_scratch_floats(long long M, int C, int r);
 int lora_transpose(hipStream_t st, int dtype, const void* in, void* out, int C, int r);   // [C, r] -> [r, C]

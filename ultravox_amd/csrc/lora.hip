@@ -66,8 +66,8 @@ __device__ __forceinline__ float ldot8(const lu32x4_t a, const lu32x4_t b, float
   return ldot2(a3, b3, ldot2(a2, b2, ldot2(a1, b1, ldot2(a0, b0, c))));
 }
 template <int NCH>
-__global__ __launch_bounds__(256) void lora_down_reg_k(const bf16_t* __restrict__ X, long long ldx, const bf16_t* __restrict__ W,
-                                                       bf16_t* __restrict__ Y, long long ldy, long long M, int C, int r, float alpha, int rpw) {
+__device__ __forceinline__ void lora_down_reg_body(const bf16_t* __restrict__ X, long long ldx, const bf16_t* __restrict__ W,
+                                                   bf16_t* __restrict__ Y, long long ldy, long long M, int C, int r, float alpha, int rpw) {
   const int lane = threadIdx.x & 63;
   const long long m0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw;
   if (m0 >= M) return;
@@ -102,12 +102,25 @@ __global__ __launch_bounds__(256) void lora_down_reg_k(const bf16_t* __restrict_
     }
   }
 }
+template <int NCH>
+__global__ __launch_bounds__(256) void lora_down_reg_k(const bf16_t* __restrict__ X, long long ldx, const bf16_t* __restrict__ W,
+                                                       bf16_t* __restrict__ Y, long long ldy, long long M, int C, int r, float alpha, int rpw) {
+  lora_down_reg_body<NCH>(X, ldx, W, Y, ldy, M, C, r, alpha, rpw);
+}
+// two down-projections over the same M rows in ONE launch (round 6: q_proj and k_proj of a layer - the adapters' products were 12 launches per
+// layer and pass): blockIdx.y picks the problem; the arithmetic per output is lora_down_reg_k's
+struct LoraDown2 { const bf16_t* X[2]; const bf16_t* W[2]; bf16_t* Y[2]; float alpha[2]; };
+template <int NCH>
+__global__ __launch_bounds__(256) void lora_down_reg2_k(LoraDown2 q, long long ldx, long long ldy, long long M, int C, int r, int rpw) {
+  const int z = blockIdx.y;
+  lora_down_reg_body<NCH>(q.X[z], ldx, q.W[z], q.Y[z], ldy, M, C, r, q.alpha[z], rpw);
+}
 
 // Z[m, c] = round(Z[m, c] + round(alpha * sum_j Y[m, j] * W[c, j]))   (accumulate = false: Z = round(alpha * ...))
 // W_RC: W is stored [r][C] (lora_A used as an up-projection in the backward pass) instead of [C][r]
 template <typename T, bool ACC, bool W_RC>
-__global__ void lora_up_k(const T* __restrict__ Y, long long ldy, const T* __restrict__ W, T* __restrict__ Z, long long ldz,
-                          long long M, int C, int r, float alpha) {
+__device__ __forceinline__ void lora_up_body(const T* __restrict__ Y, long long ldy, const T* __restrict__ W, T* __restrict__ Z, long long ldz,
+                                             long long M, int C, int r, float alpha) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int cv = C / 8;
   if (i >= M * cv) return;
@@ -148,6 +161,20 @@ __global__ void lora_up_k(const T* __restrict__ Y, long long ldy, const T* __res
   for (int k = 0; k < 8; ++k) z[k] = ACC ? z[k] + rnd<T>(acc[k] * alpha) : acc[k] * alpha;
   st8<T>(Z + m * ldz + c, z);
 }
+template <typename T, bool ACC, bool W_RC>
+__global__ void lora_up_k(const T* __restrict__ Y, long long ldy, const T* __restrict__ W, T* __restrict__ Z, long long ldz,
+                          long long M, int C, int r, float alpha) {
+  lora_up_body<T, ACC, W_RC>(Y, ldy, W, Z, ldz, M, C, r, alpha);
+}
+// two accumulating up-projections over the same M rows in ONE launch (blockIdx.y picks; C = the wider of the two, the narrower one's surplus
+// blocks exit).  When both write the SAME rows of Z (the backward's d n += u_q . A_q + u_k . A_k) the launch would race: that case keeps two launches.
+template <typename T>
+struct LoraUp2 { const T* Y[2]; const T* W[2]; T* Z[2]; int C[2]; float alpha[2]; };
+template <typename T, bool W_RC>
+__global__ void lora_up2_k(LoraUp2<T> q, long long ldy, long long ldz, long long M, int r) {
+  const int z = blockIdx.y;
+  lora_up_body<T, true, W_RC>(q.Y[z], ldy, q.W[z], q.Z[z], ldz, M, q.C[z], r, q.alpha[z]);
+}
 
 // Weight-gradient contraction over the tokens: P[j][c] = sum_m Y[m, j] * X[m, c]  (j < 8 per pass, c < C).
 // Grid = (C / 64 column tiles) x (row chunks of RCH rows).  A block is 4 waves; in a wave, lane = (row lane 0..7) x
@@ -156,9 +183,8 @@ __global__ void lora_up_k(const T* __restrict__ Y, long long ldy, const T* __res
 // partial[chunk][j][c]; lora_wgrad_reduce_k sums the few chunks in a fixed order.
 constexpr int RCH = 256;      // (round 4: 1024 gave 16 x 12 = 192 blocks at the encoder's 12000 x 1024 - fewer than CUs; 256 -> 752 blocks)
 template <typename T>
-__global__ __launch_bounds__(256) void lora_wgrad_k(const T* __restrict__ X, long long ldx, const T* __restrict__ Y, long long ldy,
-                                                    float* __restrict__ partial, long long M, int C, int r, int j0) {
-  __shared__ float red[4][8][64];
+__device__ __forceinline__ void lora_wgrad_body(const T* __restrict__ X, long long ldx, const T* __restrict__ Y, long long ldy,
+                                                float* __restrict__ partial, long long M, int C, int r, int j0, float (*red)[8][64]) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cv = lane & 7, rl = lane >> 3;
   const int c = blockIdx.x * 64 + cv * 8;
@@ -200,6 +226,23 @@ __global__ __launch_bounds__(256) void lora_wgrad_k(const T* __restrict__ X, lon
       partial[((long long)blockIdx.y * r + j0 + jj) * C + blockIdx.x * 64 + cc] =
           red[0][jj][cc] + red[1][jj][cc] + red[2][jj][cc] + red[3][jj][cc];
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lora_wgrad_k(const T* __restrict__ X, long long ldx, const T* __restrict__ Y, long long ldy,
+                                                    float* __restrict__ partial, long long M, int C, int r, int j0) {
+  __shared__ float red[4][8][64];
+  lora_wgrad_body<T>(X, ldx, Y, ldy, partial, M, C, r, j0, red);
+}
+// the partial sums of up to four weight-gradient products in ONE launch (blockIdx.z picks the product; a narrower product's surplus column
+// blocks exit): the same per-block arithmetic and the same scratch regions as four lora_wgrad_k launches
+template <typename T>
+struct LoraWgrad4 { const T* X[4]; const T* Y[4]; float* partial[4]; long long ldx[4], ldy[4]; int C[4]; };
+template <typename T>
+__global__ __launch_bounds__(256) void lora_wgrad4_k(LoraWgrad4<T> q, long long M, int r, int j0) {
+  __shared__ float red[4][8][64];
+  const int z = blockIdx.z;
+  if ((int)blockIdx.x * 64 >= q.C[z]) return;
+  lora_wgrad_body<T>(q.X[z], q.ldx[z], q.Y[z], q.ldy[z], q.partial[z], M, q.C[z], r, j0, red);
 }
 
 // out = alpha * sum_chunk partial[chunk]  as [r][C] (transpose_out = 0: lora_A) or [C][r] (1: lora_B)
@@ -276,6 +319,47 @@ int lora_down(hipStream_t st, int dtype, const void* X, long long ldx, const voi
   return UVX_OK;
 }
 
+// q_proj and k_proj together (same M, ldx, ldy, C, r; bf16 register kernel) - else two lora_down calls
+int lora_down2(hipStream_t st, int dtype, const void* X0, const void* X1, long long ldx, const void* W0, const void* W1, void* Y0, void* Y1,
+               long long ldy, long long M, int C, int r, float alpha0, float alpha1) {
+  if (M > 0 && dtype == DT_BF16 && r <= 8 && (C == 512 || C == 1024) && M >= 1024 && C % 8 == 0 && ldx % 8 == 0 && g_options[22] != 1) {
+    const int rpw = 8;
+    const dim3 g2((unsigned)((M + 4 * rpw - 1) / (4 * rpw)), 2);
+    LoraDown2 q = {{(const bf16_t*)X0, (const bf16_t*)X1}, {(const bf16_t*)W0, (const bf16_t*)W1}, {(bf16_t*)Y0, (bf16_t*)Y1}, {alpha0, alpha1}};
+    if (C == 512) hipLaunchKernelGGL((lora_down_reg2_k<1>), g2, dim3(256), 0, st, q, ldx, ldy, M, C, r, rpw);
+    else hipLaunchKernelGGL((lora_down_reg2_k<2>), g2, dim3(256), 0, st, q, ldx, ldy, M, C, r, rpw);
+    UVX_LAUNCH_CHECK();
+    return UVX_OK;
+  }
+  const int rc = lora_down(st, dtype, X0, ldx, W0, 0, Y0, ldy, M, C, r, alpha0);
+  return rc ? rc : lora_down(st, dtype, X1, ldx, W1, 0, Y1, ldy, M, C, r, alpha1);
+}
+
+// two ACCUMULATING up-projections into DIFFERENT outputs (q and k columns) with W stored [r][C]; else two lora_up calls
+int lora_up2(hipStream_t st, int dtype, const void* Y0, const void* Y1, long long ldy, const void* W0, const void* W1, void* Z0, void* Z1,
+             long long ldz, long long M, int C0, int C1, int r, float alpha0, float alpha1) {
+  const size_t esz_ = dtype == DT_BF16 ? 2 : 4;
+  const bool ok = M > 0 && Z0 != Z1 && r <= 8 && C0 % 8 == 0 && C1 % 8 == 0 && ldz % 8 == 0 && ldy % 8 == 0 && g_options[22] != 1 &&
+                  ((uintptr_t)Y0 % (8 * esz_)) == 0 && ((uintptr_t)Y1 % (8 * esz_)) == 0 && ((uintptr_t)W0 % 16) == 0 && ((uintptr_t)W1 % 16) == 0 &&
+                  ((uintptr_t)Z0 % 16) == 0 && ((uintptr_t)Z1 % 16) == 0;
+  if (ok) {
+    const int cmax = C0 > C1 ? C0 : C1;
+    const long long n = M * (cmax / 8);
+    const dim3 grid((unsigned)((n + 255) / 256), 2);
+    if (dtype == DT_BF16) {
+      LoraUp2<bf16_t> q = {{(const bf16_t*)Y0, (const bf16_t*)Y1}, {(const bf16_t*)W0, (const bf16_t*)W1}, {(bf16_t*)Z0, (bf16_t*)Z1}, {C0, C1}, {alpha0, alpha1}};
+      hipLaunchKernelGGL((lora_up2_k<bf16_t, true>), grid, dim3(256), 0, st, q, ldy, ldz, M, r);
+    } else {
+      LoraUp2<float> q = {{(const float*)Y0, (const float*)Y1}, {(const float*)W0, (const float*)W1}, {(float*)Z0, (float*)Z1}, {C0, C1}, {alpha0, alpha1}};
+      hipLaunchKernelGGL((lora_up2_k<float, true>), grid, dim3(256), 0, st, q, ldy, ldz, M, r);
+    }
+    UVX_LAUNCH_CHECK();
+    return UVX_OK;
+  }
+  const int rc = lora_up(st, dtype, Y0, ldy, W0, 1, Z0, ldz, M, C0, r, alpha0, 1);
+  return rc ? rc : lora_up(st, dtype, Y1, ldy, W1, 1, Z1, ldz, M, C1, r, alpha1, 1);
+}
+
 int lora_up(hipStream_t st, int dtype, const void* Y, long long ldy, const void* W, int w_is_rc, void* Z, long long ldz,
             long long M, int C, int r, float alpha, int accumulate) {
   UVX_CHECK(C % 8 == 0 && ldz % 8 == 0 && r > 0 && r <= RMAX, UVX_ERR_SHAPE, "lora_up: C=%d r=%d unsupported", C, r);
@@ -340,13 +424,31 @@ int lora_wgrad_batch(hipStream_t st, int dtype, const LoraWgradItem* items, int 
   float* region = scratch;
   for (int i = 0; i < n; ++i) {
     const LoraWgradItem& it = items[i];
-    const dim3 grid((it.C + 63) / 64, nchunks);
-    for (int j0 = 0; j0 < r; j0 += 8) {
-      if (dtype == DT_BF16) hipLaunchKernelGGL(lora_wgrad_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)it.X, it.ldx, (const bf16_t*)it.Y, it.ldy, region, M, it.C, r, j0);
-      else hipLaunchKernelGGL(lora_wgrad_k<float>, grid, dim3(256), 0, st, (const float*)it.X, it.ldx, (const float*)it.Y, it.ldy, region, M, it.C, r, j0);
-    }
     b.partial[i] = region; b.out[i] = it.out; b.C[i] = it.C; b.transpose_out[i] = it.transpose_out; b.alpha[i] = it.alpha;
     region += (long long)nchunks * r * it.C;
+  }
+  if (g_options[22] != 1) {      // (round 6) the n products' partial sums in ONE launch per 8 ranks: blockIdx.z = product
+    const dim3 grid((cmax + 63) / 64, nchunks, n);
+    for (int j0 = 0; j0 < r; j0 += 8) {
+      if (dtype == DT_BF16) {
+        LoraWgrad4<bf16_t> q = {};
+        for (int i = 0; i < n; ++i) { q.X[i] = (const bf16_t*)items[i].X; q.Y[i] = (const bf16_t*)items[i].Y; q.partial[i] = const_cast<float*>(b.partial[i]); q.ldx[i] = items[i].ldx; q.ldy[i] = items[i].ldy; q.C[i] = items[i].C; }
+        hipLaunchKernelGGL(lora_wgrad4_k<bf16_t>, grid, dim3(256), 0, st, q, M, r, j0);
+      } else {
+        LoraWgrad4<float> q = {};
+        for (int i = 0; i < n; ++i) { q.X[i] = (const float*)items[i].X; q.Y[i] = (const float*)items[i].Y; q.partial[i] = const_cast<float*>(b.partial[i]); q.ldx[i] = items[i].ldx; q.ldy[i] = items[i].ldy; q.C[i] = items[i].C; }
+        hipLaunchKernelGGL(lora_wgrad4_k<float>, grid, dim3(256), 0, st, q, M, r, j0);
+      }
+    }
+  } else {
+    for (int i = 0; i < n; ++i) {
+      const LoraWgradItem& it = items[i];
+      const dim3 grid((it.C + 63) / 64, nchunks);
+      for (int j0 = 0; j0 < r; j0 += 8) {
+        if (dtype == DT_BF16) hipLaunchKernelGGL(lora_wgrad_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)it.X, it.ldx, (const bf16_t*)it.Y, it.ldy, const_cast<float*>(b.partial[i]), M, it.C, r, j0);
+        else hipLaunchKernelGGL(lora_wgrad_k<float>, grid, dim3(256), 0, st, (const float*)it.X, it.ldx, (const float*)it.Y, it.ldy, const_cast<float*>(b.partial[i]), M, it.C, r, j0);
+      }
+    }
   }
   hipLaunchKernelGGL(lora_wgrad_reduce_batch_k, dim3((r * cmax + 255) / 256, n), dim3(256), 0, st, b);
   UVX_LAUNCH_CHECK();

@@ -552,10 +552,8 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r;
       RC(lora_transpose2(st, dt, R.q.b, S.bqT, d, R.k.b, S.bkT, d, r));
-      RC(lora_down(st, dt, s.n, d, R.q.a, 0, S.t, 128, M, d, r, 1.0f));
-      RC(lora_down(st, dt, s.n, d, R.k.a, 0, at(S.t, 64, dt), 128, M, d, r, 1.0f));
-      RC(lora_up(st, dt, S.t, 128, S.bqT, 1, qkv, 3 * d, M, d, r, lora->scaling * qscale, 1));
-      RC(lora_up(st, dt, at(S.t, 64, dt), 128, S.bkT, 1, at(qkv, d, dt), 3 * d, M, d, r, lora->scaling, 1));
+      RC(lora_down2(st, dt, s.n, s.n, d, R.q.a, R.k.a, S.t, at(S.t, 64, dt), 128, M, d, r, 1.0f, 1.0f));
+      RC(lora_up2(st, dt, S.t, at(S.t, 64, dt), 128, S.bqT, S.bkT, qkv, at(qkv, d, dt), 3 * d, M, d, d, r, lora->scaling * qscale, lora->scaling));
     }
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(qkv, 2 * d, dt), s.vt, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
     AttnDesc ad;
@@ -669,8 +667,7 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     const uvx_enc_lora_layer_t& R = lora->layers[l];
     const uvx_enc_lora_layer_grads_t& G = grads->layers[l];
     // u = [dq . B_q * (scaling * qscale) | dk . B_k * scaling]  [M, 128] (columns 0..r-1 and 64..64+r-1)
-    RC(lora_down(st, dt, s.d_qkv, 3 * d, S.bqT, 0, s.u, 128, M, d, r, lora->scaling * qscale));
-    RC(lora_down(st, dt, at(s.d_qkv, d, dt), 3 * d, S.bkT, 0, at(s.u, 64, dt), 128, M, d, r, lora->scaling));
+    RC(lora_down2(st, dt, s.d_qkv, at(s.d_qkv, d, dt), 3 * d, S.bqT, S.bkT, s.u, at(s.u, 64, dt), 128, M, d, r, lora->scaling * qscale, lora->scaling));
     RC(layernorm_fwd(st, dt, S.x_in, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));      // n1 recomputed (not stashed)
     // d lora_A [r, d] = u^T . n;  d lora_B [d, r] = scale * dq^T . t
     {
