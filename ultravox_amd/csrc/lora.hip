@@ -168,6 +168,36 @@ __global__ void lora_up_k(const T* __restrict__ Y, long long ldy, const T* __res
 }
 // two accumulating up-projections over the same M rows in ONE launch (blockIdx.y picks; C = the wider of the two, the narrower one's surplus
 // blocks exit).  When both write the SAME rows of Z (the backward's d n += u_q . A_q + u_k . A_k) the launch would race: that case keeps two launches.
+// Z = round(round(Z + round(a0 Y0 . W0)) + round(a1 Y1 . W1)): two accumulating up-projections into the SAME rows in one pass over Z (the encoder backward's
+// d n += u_q . A_q + u_k . A_k: lora_up twice = two read-modify-write passes).  W [r][C], r <= 8; the intermediate rounding is kept: bit-identical.
+template <typename T>
+__global__ void lora_up_same2_k(const T* __restrict__ Y0, const T* __restrict__ Y1, long long ldy, const T* __restrict__ W0, const T* __restrict__ W1,
+                                T* __restrict__ Z, long long ldz, long long M, int C, int r, float alpha0, float alpha1) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cv = C / 8;
+  if (i >= M * cv) return;
+  const long long m = i / cv;
+  const int c = (int)(i % cv) * 8;
+  float z[8];
+  ld8<T>(Z + m * ldz + c, z);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const T* Y = q ? Y1 : Y0;
+    const T* W = q ? W1 : W0;
+    const float alpha = q ? alpha1 : alpha0;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, y[8];
+    ld8<T>(Y + m * ldy, y);
+    for (int j = 0; j < r; ++j) {
+      float wv[8];
+      ld8<T>(W + (long long)j * C + c, wv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += y[j] * wv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = rnd<T>(z[k] + rnd<T>(acc[k] * alpha));
+  }
+  st8<T>(Z + m * ldz + c, z);
+}
 template <typename T>
 struct LoraUp2 { const T* Y[2]; const T* W[2]; T* Z[2]; int C[2]; float alpha[2]; };
 template <typename T, bool W_RC>
@@ -339,10 +369,20 @@ int lora_down2(hipStream_t st, int dtype, const void* X0, const void* X1, long l
 int lora_up2(hipStream_t st, int dtype, const void* Y0, const void* Y1, long long ldy, const void* W0, const void* W1, void* Z0, void* Z1,
              long long ldz, long long M, int C0, int C1, int r, float alpha0, float alpha1) {
   const size_t esz_ = dtype == DT_BF16 ? 2 : 4;
-  const bool ok = M > 0 && Z0 != Z1 && r <= 8 && C0 % 8 == 0 && C1 % 8 == 0 && ldz % 8 == 0 && ldy % 8 == 0 && g_options[22] != 1 &&
+  const bool ok = M > 0 && r <= 8 && C0 % 8 == 0 && C1 % 8 == 0 && ldz % 8 == 0 && ldy % 8 == 0 && g_options[22] != 1 &&
                   ((uintptr_t)Y0 % (8 * esz_)) == 0 && ((uintptr_t)Y1 % (8 * esz_)) == 0 && ((uintptr_t)W0 % 16) == 0 && ((uintptr_t)W1 % 16) == 0 &&
                   ((uintptr_t)Z0 % 16) == 0 && ((uintptr_t)Z1 % 16) == 0;
-  if (ok) {
+  if (ok && Z0 == Z1 && C0 == C1) {      // the same rows twice: one pass, the two terms in order
+    const long long n = M * (C0 / 8);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == DT_BF16) hipLaunchKernelGGL(lora_up_same2_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)Y0, (const bf16_t*)Y1, ldy, (const bf16_t*)W0, (const bf16_t*)W1,
+                                             (bf16_t*)Z0, ldz, M, C0, r, alpha0, alpha1);
+    else hipLaunchKernelGGL(lora_up_same2_k<float>, grid, dim3(256), 0, st, (const float*)Y0, (const float*)Y1, ldy, (const float*)W0, (const float*)W1, (float*)Z0, ldz,
+                            M, C0, r, alpha0, alpha1);
+    UVX_LAUNCH_CHECK();
+    return UVX_OK;
+  }
+  if (ok && Z0 != Z1) {
     const int cmax = C0 > C1 ? C0 : C1;
     const long long n = M * (cmax / 8);
     const dim3 grid((unsigned)((n + 255) / 256), 2);

@@ -679,8 +679,7 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     if (l == 0) break;   // nothing trainable below layer 0
     // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k], then LN1 backward into the residual stream ----
     RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d)));
-    RC(lora_up(st, dt, s.u, 128, R.q.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
-    RC(lora_up(st, dt, at(s.u, 64, dt), 128, R.k.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+    RC(lora_up2(st, dt, s.u, at(s.u, 64, dt), 128, R.q.a, R.k.a, s.d_n, s.d_n, d, M, d, d, r, 1.0f, 1.0f));      // (same rows: one pass, q term then k term)
     RC(layernorm_bwd(st, dt, s.d_n, S.x_in, L.ln1_w, s.dx, s.dx, M, d, c.ln_eps));
   }
   return UVX_OK;
