@@ -437,7 +437,8 @@ int32_t uvx_gemm_pick_split(int32_t M, int32_t N, int32_t K, size_t ws_bytes, in
 int32_t uvx_gemm_force_variant(int32_t variant);
 /* C = epilogue(RMSNorm(A; norm_w, eps) . B^T) - LlamaRMSNorm (flavor 0) / GemmaRMSNorm (1) feeding an nn.Linear, the pair the
  * decode step runs twice per layer ([3P] LlamaDecoderLayer: input_layernorm -> q|k|v, post_attention_layernorm -> gate|up).  bf16 with
- * at most 2 rows (and K <= 16384): ONE launch, the norm applied while the activation rows are staged; anything else: the two launches
+ * at most 2 rows (and K <= 16384) - or, with option 24 = 1, 3..16 rows with K % 2048 == 0 -: ONE launch, the norm applied while the activation rows are
+ * staged (resp. to the MFMA activation fragments in registers); anything else: the two launches
  * it replaces (norm_out [M, K] is the scratch for that case, may be NULL when the fused kernel is known to apply).  lda must equal K. */
 int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, const void* norm_w, float eps, int32_t flavor,
                          void* norm_out);
@@ -468,7 +469,10 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
  * its row max through ds_bpermute shuffles instead of v_permlane swaps (default 0; bit-identical; A/B), key 21 = 1: the training tower's GELU and GELU backward
  * run as separate kernels instead of in the fc1 / fc2-dgrad GEMM epilogues (uvx_gemm_desc_t.act 2 / 3; default 0; bit-identical; A/B), key 23 = 1: the decode step's rotary embedding and
  * KV-cache append of the new token run as their own launch per layer instead of inside the grouped decode-attention kernel (default 0; bit-identical; A/B)., key 22 = 1: the training tower's q_proj / k_proj adapter products run as
- * separate launches instead of paired ones (lora_down2 / lora_up2 / one partial-sum launch for the four weight gradients; default 0; bit-identical; A/B). */
+ * separate launches instead of paired ones (lora_down2 / lora_up2 / one partial-sum launch for the four weight gradients; default 0; bit-identical; A/B),
+ * key 24 = 1: uvx_gemm_rmsnorm / the decode step at 3..16 rows (K % 2048 == 0) normalise the activation fragments inside the staged weight-streaming
+ * kernel instead of running rmsnorm + linear as two launches (default 0: measured 19-32 % slower per token; same arithmetic and rounding points, rstd may
+ * differ in the last bit; A/B). */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* the current value of a tuning option (-1: unknown key) */
 int32_t uvx_get_option(int32_t key);

@@ -548,3 +548,56 @@ def test_rope_and_cache_append_inside_the_decode_attention_is_bit_identical(head
     for a, b in zip(l0, l1):
         assert torch.equal(a, b)
     assert torch.equal(c0, c1)
+
+
+@pytest.mark.parametrize("B,family", [(5, "llama"), (12, "llama"), (8, "gemma")])
+def test_decode_rmsnorm_inside_the_staged_skinny_kernel(B, family):
+    """Round 6 (opt-in, option 24 = 1: measured slower, profiles/r06_decode_norm_in_skinny_ab.txt): at 3..16 decode rows the input_layernorm /
+    post_attention_layernorm are applied to the activation fragments inside the staged weight-streaming kernel (gemm_skinny_bf16_k<.., NORM>,
+    K = hidden size a multiple of 2048) instead of 2 rmsnorm launches per layer.  Same arithmetic and rounding points; the sum of squares is folded in another order, so rstd may move by an ulp: every
+    step's logits within 5e-3 rel-L2 of the two-launch path (the bf16 path's own distance to f32 is 2e-2), the greedy tokens equal wherever
+    the two candidates are not a near-tie, and both paths consistent with the teacher-forced forward."""
+    from ultravox_amd import _lib
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.model import UltravoxModel
+    text = dict(hidden_size=2048, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=16, num_key_value_heads=4, head_dim=128,
+                vocab_size=1024, eos_token_id=2, max_position_embeddings=512)
+    if family == "gemma":
+        text.update(model_type="gemma", hidden_act="gelu_pytorch_tanh", head_dim=128)
+    cfg = UltravoxConfig(audio_config=dict(d_model=128, encoder_layers=1, encoder_attention_heads=2, encoder_ffn_dim=256),
+                         text_config=text, hidden_size=256, projector_ln_mid=True)
+    model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=21, rope_len=256)
+    torch.manual_seed(B)
+    T, new = 29, 5
+    ids = torch.randint(3, 1024, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    for r in range(1, B, 2):
+        am[r, :r + 2] = 0
+    ids[am == 0] = 2
+    L = _lib.lib()
+    runs = []
+    try:
+        for opt in (1, 0):
+            L.uvx_set_option(24, opt)
+            runs.append(model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=new, eos_token_id=-1, return_dict_in_generate=True,
+                                       output_logits=True))
+    finally:
+        L.uvx_set_option(24, 0)
+    fused, two = runs
+    for step in range(new):
+        a, b = fused.logits[step].float(), two.logits[step].float()
+        if step == 0 or torch.equal(fused.sequences[:, :T + step], two.sequences[:, :T + step]):
+            assert rel_l2(a, b) < 5e-3, (step, rel_l2(a, b))
+    same = fused.sequences == two.sequences
+    for r in range(B):
+        miss = (~same[r]).nonzero()
+        if miss.numel() == 0:
+            continue
+        step = int(miss[0]) - T
+        row = two.logits[step][r].float()
+        gap = (row[two.sequences[r, T + step]] - row[fused.sequences[r, T + step]]).abs().item()
+        assert gap <= 2e-2 * row.abs().max().item(), (r, step, gap)
+    am_full = torch.cat([am, torch.ones(B, new, dtype=torch.long)], 1).to(DEV)
+    tf = model.forward(input_ids=fused.sequences, attention_mask=am_full).logits.float()
+    for step in range(new):
+        assert rel_l2(fused.logits[step].float(), tf[:, T - 1 + step]) < 3e-2

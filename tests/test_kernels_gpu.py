@@ -533,11 +533,22 @@ def test_gemm_few_rows_weight_streaming_kernel(M, N, K):
 
 @pytest.mark.parametrize("M,N,K,flavor,swiglu", [(1, 10240, 8192, 0, False), (4, 6144, 4096, 0, False), (2, 28672, 4096, 0, True),
                                                   (1, 57344, 8192, 0, True), (2, 4096, 3072, 1, False), (3, 4096, 3072, 1, False), (8, 6144, 4096, 0, False),
-                                                  (4, 1024, 8192, 0, False)])
+                                                  (4, 1024, 8192, 0, False), (8, 57344, 8192, 0, True), (16, 10240, 8192, 0, False),
+                                                  (5, 4096, 4096, 1, False), (12, 28672, 4096, 0, True), (3, 10240, 8192, 0, False)])
 def test_gemm_with_fused_rmsnorm_matches_the_two_launches(M, N, K, flavor, swiglu):
-    """uvx_gemm_rmsnorm (the decode step's input_layernorm -> q|k|v and post_attention_layernorm -> gate|up in one launch, M <= 2) against
-    rmsnorm + gemm as two launches: the same rounding points, so the outputs agree to the last-bit noise of a differently ordered sum of
-    squares (rel-L2 < 2e-3, almost every element identical); M = 3, 4, 8 take the two-launch fallback inside the entry point."""
+    """uvx_gemm_rmsnorm (the decode step's input_layernorm -> q|k|v and post_attention_layernorm -> gate|up in one launch: M <= 2 in the
+    row-streaming kernel; round 6, opt-in through option 24 = 1: M = 3..16 with K % 2048 == 0 in the staged MFMA kernel) against rmsnorm + gemm
+    as two launches: the same rounding points, so the outputs agree to the last-bit noise of a differently ordered sum of squares (rel-L2 <
+    2e-3, almost every element identical); other shapes (K = 3072) take the two-launch fallback inside the entry point."""
+    from ultravox_amd import _lib
+    _lib.lib().uvx_set_option(24, 1)
+    try:
+        _fused_rmsnorm_case(M, N, K, flavor, swiglu)
+    finally:
+        _lib.lib().uvx_set_option(24, 0)
+
+
+def _fused_rmsnorm_case(M, N, K, flavor, swiglu):
     g = torch.Generator(device=DEV).manual_seed(13)
     a = (torch.randn(M, K, device=DEV, generator=g) * 1.7).bfloat16()
     w = (1.0 + 0.2 * torch.randn(K, device=DEV, generator=g)).bfloat16()
@@ -563,6 +574,26 @@ def test_gemm_with_fused_rmsnorm_matches_the_two_launches(M, N, K, flavor, swigl
     ref = normed.float() @ b.float().t()
     if not swiglu:
         assert rel_l2(got, (ref + bias.float())) < 5e-3
+
+
+def test_fused_rmsnorm_at_3_to_16_rows_is_opt_in():
+    """Default (option 24 = 0): the 3..16-row problem runs rmsnorm + gemm exactly as the caller would (bit-identical to the two launches);
+    option 24 = 1 takes the staged kernel with the norm inside."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = (torch.randn(8, 4096, device=DEV, generator=g) * 1.3).bfloat16()
+    w = (1.0 + 0.2 * torch.randn(4096, device=DEV, generator=g)).bfloat16()
+    b = (torch.randn(6144, 4096, device=DEV, generator=g) * 0.05).bfloat16()
+    want = ops().gemm(ops().rmsnorm(a, w, eps=1e-5), b)
+    from ultravox_amd import _lib
+    L = _lib.lib()
+    got = ops().gemm_rmsnorm(a, w, b, eps=1e-5)
+    assert torch.equal(got, want)
+    L.uvx_set_option(24, 1)
+    try:
+        fused = ops().gemm_rmsnorm(a, w, b, eps=1e-5)
+    finally:
+        L.uvx_set_option(24, 0)
+    assert rel_l2(fused, want) < 2e-3 and (fused == want).float().mean().item() > 0.9
 
 
 _A4_CHECK = r"""

@@ -37,12 +37,12 @@ extern "C" int32_t uvx_gemm_force_variant(int32_t v) {
 }
 
 extern "C" int32_t uvx_set_option(int32_t key, int32_t value) {
-  UVX_CHECK(key > 0 && key < 24, UVX_ERR_INVALID, "uvx_set_option: unknown key %d", key);
+  UVX_CHECK(key > 0 && key < 32, UVX_ERR_INVALID, "uvx_set_option: unknown key %d", key);
   uvx::g_options[key] = value;
   return UVX_OK;
 }
 
-extern "C" int32_t uvx_get_option(int32_t key) { return key > 0 && key < 24 ? uvx::g_options[key] : -1; }
+extern "C" int32_t uvx_get_option(int32_t key) { return key > 0 && key < 32 ? uvx::g_options[key] : -1; }
 
 extern "C" int32_t uvx_probe_lds_tr(void* stream, const int32_t* addr, int32_t* out) {
   UVX_CHECK(addr && out, UVX_ERR_INVALID, "uvx_probe_lds_tr: null argument");

@@ -40,7 +40,7 @@ int g_gemm_ovr_n = 0; int g_gemm_ovr[32][4];
 // [8] (probe builds) let the picker choose the stream-K variants 39..42 (off: measured slower, see the kernel),
 // [10] tail-split threshold in per cent of the whole launch's modelled cost (0 = 88),
 // [9] stream-K flavour: data-parallel rounds before the stream-K part: 1 = all but the last full round ("two-tile"), 0 = none
-int g_options[24] = {0, 2, 0, 1, 1, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, /*16*/ 1, 1, 0, 0, 0, 0, 0, 0};   // keys: include/uvx.h uvx_set_option
+int g_options[32] = {0, 2, 0, 1, 1, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, /*16*/ 1, 1, 0, 0, 0, 0, 0, 0, /*24*/ 0, 0, 0, 0, 0, 0, 0, 0};   // keys: include/uvx.h uvx_set_option
 }  // -1 = automatic; probes may force a tile variant / disable the tail split
 
 namespace {

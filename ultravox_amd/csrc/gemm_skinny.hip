@@ -39,9 +39,19 @@ constexpr int SKS_PITCH = 528;                    // bytes per staged row: 256 b
 // MT (STAGE only): 16-row tiles of the ACTIVATION matrix served by one block - M <= 16 MT.  Every staged weight fragment is multiplied with
 // MT activation fragments, so batches up to 64 (M = 17..64 used to fall to the 128-row tiled kernels: a handful of active CUs at N = 8192)
 // stream the weights once at the same rate.
-template <int TILES, bool STAGE = false, int MT = 1>
+// NORM (round 6, STAGE with MT = 1: the decode step at 3..16 rows; opt-in, option 24 = 1 - measured slower, see gemm_skinny_rmsnorm_bf16): A is the RAW residual-stream block and RMSNorm(A; norm_w) is applied on the
+// way in, as gemv_rows_bf16_k<.., NORM> does for M <= 2 - the separate rmsnorm_fwd_k launch on 8 rows costs 8.7 us, 161 of them 1.4 ms of a
+// 25 ms 70B token at B = 8.  A block reads every activation element once anyway (wave w: its K span of all 16 rows), so the prologue walks the
+// same addresses first: lane (row, g) squares its 8 elements of every k32 chunk of the wave's span, the four lane groups of a row and then
+// the eight waves are folded in a fixed order (LDS), rstd = rsqrt(sum / K + eps).  The main loop then normalises each activation fragment
+// in registers with rmsnorm_fwd_k's arithmetic and rounding points (flavor 0: w * round(x * rstd); 1, Gemma: (x * rstd) * (1 + w)) before
+// the MFMA - ~50 VALU instructions per fragment against the 16 KB of weights a wave streams per MFMA pair.  The first weight rows are already
+// in flight (issue(0, 0)) while the prologue runs.  rstd may differ from the separate kernel's in the last bit (summation order).
+template <int TILES, bool STAGE = false, int MT = 1, bool NORM = false>
 __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
   static_assert(STAGE || MT == 1, "several activation row tiles: staged kernel only");
+  static_assert(!NORM || (STAGE && MT == 1), "fused RMSNorm: the staged kernel on one activation row tile");
+  __shared__ float nss[NORM ? 8 * 16 : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_dyn[];      // STAGE: 8 waves x 16 x SKS_PITCH bytes (then the reduction)
   __shared__ float red_static[STAGE ? 1 : 8 * 2 * 64 * 4];
   float (*red)[2][MT][64][4] = reinterpret_cast<float (*)[2][MT][64][4]>(STAGE ? reinterpret_cast<float*>(sk_dyn) : red_static);
@@ -88,6 +98,39 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
       am[mt] = p.A + (long long)(mok[mt] ? mt * 16 + frow : 0) * p.lda + fg * 8;
     }
     bf16x8_t xf[MT][CH];
+    float rstd = 0.f;
+    if constexpr (NORM) {
+      float ss = 0.f;
+      for (int c0 = 0; c0 < kspan / 32; c0 += 8) {           // (kspan is a multiple of 256)
+        u16x8_t v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const u16x8_t*>(am[0] + k_begin + (c0 + c) * 32);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float f = bf2f(v[c][e]); ss += f * f; }
+      }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (fg == 0) nss[w * 16 + frow] = ss;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) tot += nss[ww * 16 + frow];
+      rstd = rsqrtf(tot / p.K + p.norm_eps);
+    }
+    // (NORM) one activation fragment: 8 raw elements of this lane's row -> RMSNorm'ed bf16 operand
+    auto norm_frag = [&](const bf16_t* src, int k) {
+      const u16x8_t raw = *reinterpret_cast<const u16x8_t*>(src + k);
+      const u16x8_t wv = *reinterpret_cast<const u16x8_t*>(p.norm_w + k + fg * 8);
+      u16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = bf2f(raw[e]) * rstd, g = bf2f(wv[e]);
+        o[e] = f2bf(p.norm_flavor ? x * (1.0f + g) : g * bf2f(f2bf(x)));
+      }
+      return __builtin_bit_cast(bf16x8_t, o);
+    };
     for (int st = 0; st < nst; ++st) {
       const int k0 = k_begin + st * 256;
 #pragma unroll
@@ -103,7 +146,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_bf16_k(SkinnyArgs p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-              for (int c = 0; c < CH; ++c) xf[mt][c] = mok[mt] ? *reinterpret_cast<const bf16x8_t*>(am[mt] + k0 + (h * CH + c) * 32) : zero;
+              for (int c = 0; c < CH; ++c) {
+                if constexpr (NORM) xf[mt][c] = mok[mt] ? norm_frag(am[mt], k0 + (h * CH + c) * 32) : zero;
+                else xf[mt][c] = mok[mt] ? *reinterpret_cast<const bf16x8_t*>(am[mt] + k0 + (h * CH + c) * 32) : zero;
+              }
           }
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
@@ -410,10 +456,15 @@ static int gemv_rows_per_block(const uvx::GemmDesc& d) {
 // C = epilogue(RMSNorm(A; norm_w, eps, flavor) . B^T) for the decode step's few rows: one launch instead of rmsnorm_fwd + gemm.
 // Returns UVX_ERR_UNSUPPORTED (no launch, no error text) when the fused kernel does not serve the problem: the caller then runs the two.
 int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm_w, float eps, int flavor) {
-  const bool ok = d.M > 0 && d.M <= 2 && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 && d.K % 8 == 0 &&
-                  d.K <= 16384 && d.lda % 8 == 0 && d.ldb % 8 == 0 && (!d.swiglu || (d.N % 32 == 0 && d.C2)) && norm_w &&
-                  (size_t)d.M * d.K * 2 <= 64 * 1024 && uvx::g_options[4] == 1;
-  if (!ok) return UVX_ERR_UNSUPPORTED;
+  const bool common = d.M > 0 && d.batch <= 1 && !d.out_f32 && !d.accumulate && !d.m_dev && d.swiglu != 2 && d.act < 2 && !d.b_kn && d.lda % 8 == 0 &&
+                      d.ldb % 8 == 0 && (!d.swiglu || (d.N % 32 == 0 && d.C2)) && norm_w && uvx::g_options[4] == 1;
+  const bool ok = common && d.M <= 2 && d.K % 8 == 0 && d.K <= 16384 && (size_t)d.M * d.K * 2 <= 64 * 1024;
+  // 3..16 rows: the staged MFMA kernel normalises its activation fragments in registers - OPT-IN (option 24 = 1): measured 19-32 % SLOWER per token than
+  // the two launches (profiles/r06_decode_norm_in_skinny_ab.txt): the kernel lives on loads in flight per wave and the ~70 VALU instructions per fragment
+  // lengthen every wave's step
+  const bool ok_staged = common && d.M >= 3 && d.M <= 16 && d.K % 2048 == 0 && d.N % 4 == 0 && d.ldc % 4 == 0 && (!d.swiglu || d.ldc2 % 4 == 0) &&
+                         (!d.residual || d.ldr % 4 == 0) && uvx::g_options[24] == 1;
+  if (!ok && !ok_staged) return UVX_ERR_UNSUPPORTED;
   SkinnyArgs a;
   a.A = (const bf16_t*)d.A; a.B = (const bf16_t*)d.B; a.C = (bf16_t*)d.C; a.bias = (const bf16_t*)d.bias;
   a.residual = (const bf16_t*)d.residual; a.C2 = (bf16_t*)d.C2;
@@ -422,7 +473,23 @@ int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm
   a.norm_w = (const bf16_t*)norm_w; a.norm_eps = eps; a.norm_flavor = flavor;
   uvx::ProfScope prof(st, uvx::PROF_GEMM, 2.0 * d.M * d.N * (double)d.K,
                       ((double)d.M * d.K + (double)d.N * d.K) * 2.0 + (double)d.M * d.N * 2.0);
-  if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, 1, 201);
+  if (uvx::g_prof_on) uvx::prof_tag(d.M, d.N, d.K, 1, ok ? 201 : 202);
+  if (!ok) {
+    constexpr size_t shs = 8 * 16 * SKS_PITCH;
+    const bool two = d.swiglu || d.N >= 16384;
+    const dim3 sgrid(two ? (d.N + 31) / 32 : (d.N + 15) / 16);
+    if (two) {
+      static PerDeviceOnce attr_n2;
+      UVX_SET_ATTR_ONCE(attr_n2, (gemm_skinny_bf16_k<2, true, 1, true>), shs);
+      hipLaunchKernelGGL((gemm_skinny_bf16_k<2, true, 1, true>), sgrid, dim3(512), shs, st, a);
+    } else {
+      static PerDeviceOnce attr_n1;
+      UVX_SET_ATTR_ONCE(attr_n1, (gemm_skinny_bf16_k<1, true, 1, true>), shs);
+      hipLaunchKernelGGL((gemm_skinny_bf16_k<1, true, 1, true>), sgrid, dim3(512), shs, st, a);
+    }
+    UVX_LAUNCH_CHECK();
+    return UVX_OK;
+  }
   const int rb = gemv_rows_per_block(d);
   const dim3 grid((d.N + rb - 1) / rb);
   const int mb = d.M;

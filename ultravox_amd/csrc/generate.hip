@@ -450,7 +450,7 @@ int mlp_block(hipStream_t st, const uvx_config_t& c, const uvx_llm_layer_t& L, I
               bool n_ready = false, const void* next_ln1 = nullptr, bool* next_ready = nullptr) {
   const int dt = c.dtype, D = c.llm_d;
   if (next_ready) *next_ready = false;
-  if (!n_ready && dt == DT_BF16 && M <= 2 && c.llm_flavor != UVX_LLM_GEMMA3) {     // decode: post_attention_layernorm inside the gate|up GEMV
+  if (!n_ready && dt == DT_BF16 && M <= 16 && c.llm_flavor != UVX_LLM_GEMMA3) {     // decode: post_attention_layernorm inside the gate|up GEMV (M <= 2) / the staged skinny kernel (M <= 16)
     GemmDesc g = lin(x_mid, L.wgu, s.gu, M, 2 * c.llm_inter, D);
     const bool fused = c.llm_flavor == UVX_LLM_LLAMA;
     if (fused) { g.C2 = s.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }

@@ -74,7 +74,7 @@ int gemm_pick_split(int M, int N, int K, size_t ws_bytes, int* variant);   // ho
 
 extern int g_gemm_variant;
 extern int g_gemm_split;
-extern int g_options[24];
+extern int g_options[32];
 int gemm_pick_variant(int M, int N, int K, int batch);  // host only: the tile variant the cost model picks
 int gemm_streamk_timeouts();   // stream-K waits that gave up since the last call (0 = healthy); synchronises
 extern int g_gemm_ovr_n;
