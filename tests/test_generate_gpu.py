@@ -601,3 +601,55 @@ def test_decode_rmsnorm_inside_the_staged_skinny_kernel(B, family):
     tf = model.forward(input_ids=fused.sequences, attention_mask=am_full).logits.float()
     for step in range(new):
         assert rel_l2(fused.logits[step].float(), tf[:, T - 1 + step]) < 3e-2
+
+
+@pytest.mark.parametrize("case", [dict(num_beams=3), dict(num_beams=4, length_penalty=0.0, num_return_sequences=2), dict(num_beams=2, early_stopping=True),
+                                  dict(num_beams=3, repetition_penalty=1.5)])
+@pytest.mark.parametrize("n_eos", [1, 120])
+def test_f32_beam_search_matches_the_oracle_tokens(case, n_eos):
+    """generate(num_beams > 1) (the reference forwards the keyword to HF's generate, ultravox_model.py:422-426): the HIP path (one
+    prefill, B * beams decode rows, KV-cache planes re-gathered to follow the surviving beams) in f32 against the oracle's cache-free
+    restatement of HF's beam search (pinned token for token to HF in tests/test_oracle_pinning.py), audio + left padding, with one
+    terminator and with 120 of 512 ids ending a hypothesis (finished-set and stopping logic)."""
+    from oracle.reference_cpu import logmel_ref, synthetic_batch
+    cfg, model, oracle = _build(torch.float32, 23)
+    b = synthetic_batch(cfg, 3, 2.0, n_text=20, audio_start=4, n_supervised=4)
+    b.pop("labels")
+    b["audio_values"] = logmel_ref(b.pop("pcm"), 80)
+    T = b["input_ids"].shape[1]
+    lp = [0, 5, 2]
+    width = T + max(lp)
+    ids = torch.full((3, width), 2, dtype=torch.long)
+    am = torch.zeros(3, width, dtype=torch.long)
+    for i, p in enumerate(lp):
+        ids[i, width - T:] = b["input_ids"][i]
+        am[i, width - T:] = 1
+    b["input_ids"], b["attention_mask"] = ids, am
+    b["audio_token_start_idx"] = b["audio_token_start_idx"] + (width - T)
+    eos = 2 if n_eos == 1 else list(range(7, 7 + n_eos))
+    want = oracle.generate_beam(7, eos_token_id=eos, pad_token_id=1, **case, **b)
+    got = model.generate(max_new_tokens=7, eos_token_id=eos, pad_token_id=1, **case, **{k: v.to(DEV) for k, v in b.items()}).cpu()
+    assert got.shape == want.shape and torch.equal(got, want), (got[:, width:], want[:, width:])
+
+
+def test_bf16_beam_search_is_consistent_with_its_own_scores():
+    """bf16 production path: the returned hypotheses of a 4-beam search re-scored by the teacher-forced forward of the same model
+    (sum of next-token log-probabilities / length) reproduce sequences_scores and the best-first order; the hypotheses of a prompt are distinct."""
+    cfg, model, _ = _build(torch.bfloat16, 24)
+    torch.manual_seed(5)
+    B, T, new, nb = 3, 15, 6, 4
+    ids = torch.randint(3, 512, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, :4] = 0
+    ids[am == 0] = 2
+    out = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=new, eos_token_id=-1, num_beams=nb, num_return_sequences=nb,
+                         return_dict_in_generate=True)
+    seq, sc = out.sequences, out.sequences_scores.float().view(B, nb)
+    assert tuple(seq.shape) == (B * nb, T + new)
+    am_full = torch.cat([am.repeat_interleave(nb, 0), torch.ones(B * nb, new, dtype=torch.long)], 1).to(DEV)
+    lp = torch.log_softmax(model.forward(input_ids=seq, attention_mask=am_full).logits.float(), -1)
+    tok_lp = lp[:, T - 1:-1].gather(-1, seq[:, T:, None])[..., 0].sum(-1) / new
+    assert (tok_lp.view(B, nb) - sc).abs().max().item() < 3e-2
+    assert bool((sc[:, :-1] >= sc[:, 1:]).all())
+    for b in range(B):
+        assert len({tuple(r.tolist()) for r in seq[b * nb:(b + 1) * nb]}) == nb

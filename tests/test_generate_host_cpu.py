@@ -198,9 +198,15 @@ def test_terminators_padding_streamer_and_repetition_penalty(model):
         assert out[1, 7:].tolist() == free[1].tolist()
     assert rec.ended and torch.equal(rec.puts[0], ids) and len(rec.puts) == out.shape[1] - 7 + 1
     with pytest.warns(UserWarning, match="no effect"):
-        model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, length_penalty=2.0)
+        model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, typical_p=0.9)
     with pytest.raises(NotImplementedError):
-        model.generate(ids, num_beams=4)
+        model.generate(ids, num_beams=4, do_sample=True)
+    with pytest.raises(ValueError):
+        model.generate(ids, num_beams=2, num_return_sequences=3)
+    with pytest.raises(ValueError):
+        model.generate(ids, num_return_sequences=2)
+    with pytest.raises(ValueError):
+        model.generate(ids, num_beams=2, streamer=rec)
     with pytest.raises(ValueError):
         model.generate(ids, do_sample=True, temperature=0.0)
     with pytest.raises(ValueError):
@@ -213,6 +219,46 @@ def test_terminators_padding_streamer_and_repetition_penalty(model):
     g = torch.Generator().manual_seed(0)
     b = model.generate(ids, attention_mask=am, max_new_tokens=4, eos_token_id=-1, do_sample=True, temperature=0.8, top_k=5, generator=g)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [dict(num_beams=3), dict(num_beams=4, length_penalty=0.0, num_return_sequences=2), dict(num_beams=2, early_stopping=True),
+                                  dict(num_beams=3, early_stopping="never", length_penalty=2.0), dict(num_beams=3, repetition_penalty=3.0)])
+@pytest.mark.parametrize("n_eos", [1, 30])
+def test_beam_search_host_logic_against_the_oracle_restatement(model, case, n_eos):
+    """generate(num_beams > 1) on the simulated device against the oracle's list-based restatement of HF's beam search
+    (oracle.reference_cpu.beam_search_ref, pinned to HF in tests/test_oracle_pinning.py) driven by a CACHE-FREE evaluation of the same
+    fake "model": its logits depend on every cached row of a hypothesis, so a cache plane that did not follow its beam changes the
+    tokens.  Tie-free logits (a triangular bump with different slopes left and right of the target)."""
+    from oracle.reference_cpu import beam_search_ref
+
+    def bump(target):
+        d = torch.arange(V, dtype=torch.float32) - target
+        return -(d.abs() * 0.31 + (d > 0) * 0.17)
+    model.fake._logits = lambda k, v, lo, hi, out: [out.__setitem__(b, bump(int(round(float((k[b, lo[b]:hi] * (v[b, lo[b]:hi] + 1.0)).sum()))) % V))
+                                                    for b in range(k.shape[0])]
+    ids, am = left_padded(3, 8, [0, 3, 1], seed=11)
+    eos = -1 if n_eos == 1 else list(range(5, 5 + n_eos))
+
+    def next_logits(hyps):
+        out = torch.empty(len(hyps), len(hyps[0]), V)
+        for b, item in enumerate(hyps):
+            keep = am[b].bool()
+            lo = int(torch.nonzero(keep)[0, 0])
+            for j, toks in enumerate(item):
+                feat = torch.cat([ids[b].float() + 1.0, torch.tensor(toks, dtype=torch.float32) + 1.0])
+                pos = torch.cumsum(keep.long(), 0) - 1
+                pos = torch.cat([pos, int(keep.sum()) + torch.arange(len(toks))]).float()
+                out[b, j] = bump(int(round(float((feat[lo:] * (pos[lo:] + 1.0)).sum()))) % V)
+        return out
+    kw = {k: v for k, v in case.items() if k != "num_beams"}
+    want = beam_search_ref(next_logits, ids, 6, eos, 1, case["num_beams"], kw.get("length_penalty", 1.0), kw.get("early_stopping", False),
+                           kw.get("num_return_sequences", 1), kw.get("repetition_penalty"))
+    model.fake.calls.clear()
+    got = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=eos, pad_token_id=1, **case)
+    assert got.shape == want.shape and torch.equal(got, want), (got[:, 8:], want[:, 8:])
+    assert model.fake.calls[0] == ("prefill", 8) and all(c[0] == "decode" for c in model.fake.calls[1:])      # one prefill of the B prompts
+    out = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=eos, pad_token_id=1, return_dict_in_generate=True, **case)
+    assert torch.equal(out.sequences, want) and out.sequences_scores.shape == (want.shape[0],) and out.past_key_values is None
 
 
 def test_longest_common_prefix_reuse_is_opt_in_and_keeps_the_old_state_intact(model):

@@ -240,6 +240,48 @@ def test_greedy_generate_matches_hf_generate_with_left_padding():
     assert torch.equal(got[:, :n], want[:, :n]), (got, want)
 
 
+BEAM_CASES = [dict(num_beams=3), dict(num_beams=4, length_penalty=0.0), dict(num_beams=2, early_stopping=True),
+              dict(num_beams=3, num_return_sequences=2, length_penalty=2.0), dict(num_beams=3, early_stopping="never"),
+              dict(num_beams=5, num_return_sequences=3, early_stopping=True), dict(num_beams=3, repetition_penalty=1.7)]
+
+
+@pytest.mark.parametrize("n_eos", [1, 85, 200])
+def test_beam_search_matches_hf_generate(n_eos):
+    """[3P] check of the oracle's beam-search restatement (OracleModel.generate_beam: explicit per-item hypothesis lists, no KV cache)
+    against HF LlamaForCausalLM.generate(num_beams=..) on a LEFT-padded batch: token for token, for several beam counts, length
+    penalties, early_stopping settings and num_return_sequences; with 85 / 200 terminator ids (of 512) hypotheses finish early and the
+    finished-list / stopping-heuristic logic is exercised."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = tiny_cfg()
+    t = cfg.text_config
+    hf = LlamaForCausalLM(LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size,
+                                      num_hidden_layers=t.num_hidden_layers, num_attention_heads=t.num_attention_heads,
+                                      num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size,
+                                      rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta,
+                                      max_position_embeddings=t.max_position_embeddings, tie_word_embeddings=False,
+                                      attn_implementation="eager", eos_token_id=3, pad_token_id=3)).eval()
+    sd = random_state_dict(cfg, seed=8)
+    sd["language_model.model.embed_tokens.weight"] = sd["language_model.model.embed_tokens.weight"] * 0.3
+    hf.load_state_dict({k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}, strict=False)
+    torch.manual_seed(4)
+    B, T = 3, 11
+    ids = torch.randint(4, t.vocab_size, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[0, :4] = 0
+    am[2, :1] = 0
+    ids[am == 0] = 3
+    eos = 3 if n_eos == 1 else list(range(3, 3 + n_eos))
+    om = O.OracleModel(cfg, sd)
+    short = 0
+    for case in BEAM_CASES:
+        with torch.no_grad():
+            want = hf.generate(input_ids=ids, attention_mask=am, max_new_tokens=7, do_sample=False, eos_token_id=eos, pad_token_id=3, **case)
+        got = om.generate_beam(7, eos_token_id=eos, pad_token_id=3, input_ids=ids, attention_mask=am, **case)
+        assert got.shape == want.shape and torch.equal(got, want), (case, got[:, T:], want[:, T:])
+        short += int(want.shape[1] < T + 7 or bool((want[:, -1] == 3).any()))
+    assert n_eos == 1 or short > 0          # (the many-terminator settings must actually end hypotheses early)
+
+
 KL_CASES = ["basic", "no_eot", "temp1_w05", "one_empty_row", "padded_tail"]
 
 

@@ -55,6 +55,7 @@ class GenerateOutput:
     sequences: torch.Tensor
     past_key_values: Optional[KVState] = None
     logits: Optional[tuple] = None      # output_logits=True: one [B, vocab] tensor of raw next-token logits per generated token (HF's field)
+    sequences_scores: Optional[torch.Tensor] = None      # beam search: final (length-normalised) score of every returned sequence (HF's field)
 
 
 @dataclasses.dataclass
@@ -1042,14 +1043,26 @@ class UltravoxModel:
             raise ValueError(f"`repetition_penalty` has to be a strictly positive float, but is {rep}")
         want_logits = bool(kwargs.get("output_logits", False)) and return_dict      # HF: only reported in the dict form
         step_logits = []
-        ignored = set(kwargs) - {"past_key_values", "return_dict_in_generate", "repetition_penalty", "num_beams", "use_cache", "output_logits"}
+        ignored = set(kwargs) - {"past_key_values", "return_dict_in_generate", "repetition_penalty", "num_beams", "use_cache", "output_logits",
+                                 "length_penalty", "early_stopping", "num_return_sequences", "output_scores"}
         if ignored:
             import warnings
             warnings.warn(f"generate(): these arguments have no effect here: {sorted(ignored)}")
         if past is not None and not isinstance(past, KVState):
             raise TypeError("past_key_values must be the KVState a previous generate(return_dict_in_generate=True) returned")
-        if kwargs.get("num_beams", 1) != 1:
-            raise NotImplementedError("beam search is not built (greedy and sampling are)")
+        num_beams = int(kwargs.get("num_beams", 1) or 1)
+        nrs = int(kwargs.get("num_return_sequences", 1) or 1)
+        if num_beams > 1:
+            if do_sample:
+                raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not built")
+            if streamer is not None:
+                raise ValueError("`streamer` cannot be used with beam search (yet!). Make sure that `num_beams` is set to 1.")
+            if past is not None:
+                raise NotImplementedError("beam search starts from the prompt: past_key_values is not supported with num_beams > 1")
+            if nrs > num_beams:
+                raise ValueError(f"`num_return_sequences` ({nrs}) has to be smaller or equal to `num_beams` ({num_beams}).")
+        elif nrs != 1:
+            raise ValueError(f"Greedy methods without beam search do not support `num_return_sequences` different than 1 (got {nrs}).")
         if do_sample and not temperature > 0:
             raise ValueError("`temperature` has to be a strictly positive float for sampling")
         l = _lib.lib()
@@ -1070,6 +1083,10 @@ class UltravoxModel:
             raise ValueError(f"prompt + max_new_tokens = {Tmax} exceeds the RoPE table ({self._llm['rope_len']})")
         ids_dev = input_ids.to(dev)
         am = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        if num_beams > 1:
+            lp = kwargs.get("length_penalty")
+            return self._beam_search(inputs_embeds, ids_dev, am, max_new_tokens, eos_list, pad_token_id, num_beams,
+                                     1.0 if lp is None else float(lp), kwargs.get("early_stopping", False), nrs, rep, return_dict)
         # A cache handed in is reused only while it still describes this prompt's prefix (HF trusts the caller here; a
         # re-tokenised reply that no longer matches would silently corrupt the dialogue, so it is checked and dropped).
         P = 0
@@ -1180,6 +1197,116 @@ class UltravoxModel:
                         kv_start=kv_start, tokens=sequences[:, :T + n_decoded].contiguous(),
                         partial_ok=bool(past is not None and past.partial_ok))
         return GenerateOutput(sequences=sequences, past_key_values=state, logits=tuple(step_logits) if want_logits else None)
+
+    def _beam_search(self, inputs_embeds: torch.Tensor, ids_dev: torch.Tensor, am: Optional[torch.Tensor], max_new_tokens: int, eos_list,
+                     pad_token_id: Optional[int], nb: int, length_penalty: float, early_stopping, nrs: int, rep: Optional[float],
+                     return_dict: bool):
+        """generate(num_beams > 1): the reference forwards the keyword to [3P] HF `generate` (ultravox_model.py:422-426), i.e. HF's beam
+        search.  Here: ONE prefill of the B prompts, the KV cache rows then replicated per beam ([L][2][B * beams][Tmax][..]); every step is
+        a decode batch of B * beams rows through uvx_llm_decode, the search policy runs on the [B, beams * V] f32 log-probabilities on the
+        device (top K = max(2, 1 + n_eos) * beams continuations; the `beams` best that do not end run on, ending ones among the first
+        `beams` enter the finished set scored sum_logprobs / generated_length ** length_penalty; stop when no prompt can still improve,
+        or - early_stopping=True - all have `beams` finished hypotheses, or the length limit ends everything), and the cache rows are
+        re-gathered to follow the surviving beams.  One host read-back per step (continue? / did the beams move?).  Returns
+        [B * num_return_sequences, T + longest returned hypothesis], shorter ones padded (pad_token_id, else the first terminator) -
+        token for token what HF returns (tests/test_generate_gpu.py, oracle: OracleModel.generate_beam pinned against HF)."""
+        l = _lib.lib()
+        dev = self.device
+        B, T, D = inputs_embeds.shape
+        V = self.config.vocab_size
+        BB, Lg = B * nb, max_new_tokens
+        Tmax = T + max_new_tokens
+        pad = int(pad_token_id) if pad_token_id else int(eos_list[0])
+        eos_ids = torch.tensor(eos_list, device=dev, dtype=torch.int64)
+        K = max(2, 1 + len(eos_list)) * nb
+        if K > nb * V:
+            raise ValueError(f"beam search: {K} continuations kept per step exceed beams * vocab = {nb * V}")
+        NEG = -1.0e9
+        # ---- prefill on the B prompts, then one cache plane per beam ----
+        nbytes = max(l.uvx_llm_infer_ws_bytes(C.byref(self._c), B, T), l.uvx_llm_infer_ws_bytes(C.byref(self._c), BB, 1))
+        ws = self._workspace("infer", nbytes)
+        bytes1 = l.uvx_kv_cache_bytes(C.byref(self._c), B, Tmax)
+        cache1 = torch.empty(bytes1, device=dev, dtype=torch.uint8)
+        next_pos = torch.empty(B, device=dev, dtype=torch.int32)
+        kv_start = torch.empty(B, device=dev, dtype=torch.int32)
+        logits1 = torch.empty(B, V, device=dev, dtype=self.dtype)
+        check(l.uvx_llm_prefill(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(inputs_embeds.contiguous()), ptr(am), B, T, ptr(cache1),
+                                Tmax, ptr(next_pos), ptr(kv_start), ptr(logits1), ptr(ws), C.c_size_t(nbytes)), "uvx_llm_prefill")
+        planes = self._c.llm_layers * 2
+        row = bytes1 // (planes * B * Tmax)                       # bytes of one cached position
+        assert l.uvx_kv_cache_bytes(C.byref(self._c), BB, Tmax) == planes * BB * Tmax * row
+        cache = cache1.view(planes, B, Tmax * row).repeat_interleave(nb, dim=1).contiguous()
+        del cache1
+        cv = cache.view(planes, BB, Tmax, row)
+        next_pos = next_pos.repeat_interleave(nb).contiguous()
+        kv_start = kv_start.repeat_interleave(nb).contiguous()
+        logits = logits1.repeat_interleave(nb, dim=0).contiguous()
+        prompt_flat = ids_dev.repeat_interleave(nb, dim=0)
+        # ---- search state (generated tokens only; the prompt is put back at the end) ----
+        run_seq = torch.full((B, nb, Lg), pad, device=dev, dtype=torch.int64)
+        run_sc = torch.zeros(B, nb, device=dev, dtype=torch.float32)
+        run_sc[:, 1:] = NEG                                       # step 0: all beams hold the same prompt, only the first may branch
+        fin_seq = run_seq.clone()
+        fin_sc = torch.full((B, nb), NEG, device=dev, dtype=torch.float32)
+        fin_done = torch.zeros(B, nb, device=dev, dtype=torch.bool)
+        fin_len = torch.zeros(B, nb, device=dev, dtype=torch.int64)
+        can_improve = torch.ones(B, 1, device=dev, dtype=torch.bool)
+        first_nb = (torch.arange(K, device=dev) < nb)[None, :]
+        item0 = (torch.arange(B, device=dev) * nb)[:, None]
+        identity = torch.arange(BB, device=dev)
+        emb = torch.empty(BB, D, device=dev, dtype=self.dtype)
+        offs = torch.empty(BB + 1, device=dev, dtype=torch.int32)
+        take = torch.take_along_dim
+        for s in range(Lg):
+            logp = torch.log_softmax(logits.float(), dim=-1)
+            if rep is not None:                                   # HF: the processors see the log-probabilities of the flat running sequences
+                logp = self._repetition_penalty(logp, torch.cat([prompt_flat, run_seq.view(BB, Lg)[:, :s]], dim=1), rep)
+            acc = (logp.view(B, nb, V) + run_sc[:, :, None]).view(B, nb * V)
+            vals, idx = torch.topk(acc, K, dim=1)
+            src, tok = idx // V, idx % V
+            cand = take(run_seq, src[:, :, None], 1)
+            cand[:, :, s] = tok
+            hit = torch.isin(tok, eos_ids)
+            if s + 1 >= Lg:
+                hit = torch.ones_like(hit)
+            masked = vals + hit.to(torch.float32) * NEG
+            keep = torch.topk(masked, nb, dim=1)[1]
+            run_seq, run_sc, moved = take(cand, keep[:, :, None], 1), take(masked, keep, 1), take(src, keep, 1)
+            # finished set: candidates that just ended among the first `nb`, length-normalised; merged with what is there, best nb kept
+            just = hit & first_nb
+            sc = vals / (float(s + 1) ** length_penalty)
+            sc = sc + (fin_done.all(dim=-1, keepdim=True) & (early_stopping is True)).to(torch.float32) * NEG
+            sc = sc + (~can_improve).to(torch.float32) * NEG
+            sc = sc + (~just).to(torch.float32) * NEG
+            m_sc = torch.cat([fin_sc, sc], dim=1)
+            order = torch.topk(m_sc, nb, dim=1)[1]
+            fin_seq = take(torch.cat([fin_seq, cand], dim=1), order[:, :, None], 1)
+            fin_sc = take(m_sc, order, 1)
+            fin_done = take(torch.cat([fin_done, just], dim=1), order, 1)
+            fin_len = take(torch.cat([fin_len, torch.full((B, K), s + 1, device=dev, dtype=torch.int64)], dim=1), order, 1)
+            best_len = Lg if (early_stopping == "never" and length_penalty > 0.0) else s + 1
+            best = run_sc[:, :1] / (float(best_len) ** length_penalty)
+            worst = torch.where(fin_done, fin_sc.min(dim=1, keepdim=True)[0], torch.full_like(fin_sc, NEG))
+            can_improve = can_improve & (best > worst).any(dim=-1, keepdim=True)
+            go = can_improve.any() & ~(fin_done.all() & (early_stopping is True)) & ~hit.all()
+            flat = (item0 + moved).view(BB)
+            go_h, still = torch.stack([go, (flat == identity).all()]).tolist()
+            if not go_h:
+                break
+            cur = T + s                                           # cache rows written so far
+            if not still:
+                cv[:, :, :cur] = cv[:, flat, :cur]
+            tok_next = run_seq[:, :, s].reshape(BB).contiguous()
+            check(l.uvx_embed_merge(stream_ptr(), C.byref(self._c), ptr(self._llm["embed"]), ptr(tok_next), None, None, None,
+                                    None, BB, 1, 0, 0, ptr(emb), ptr(offs)), "uvx_embed_merge")
+            pos = (next_pos + s).contiguous()
+            check(l.uvx_llm_decode(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(emb), ptr(pos), ptr(kv_start), ptr(cache), Tmax,
+                                   cur, BB, ptr(logits), ptr(ws), C.c_size_t(nbytes)), "uvx_llm_decode")
+        n = int(fin_len[:, :nrs].max())
+        sequences = torch.cat([ids_dev.repeat_interleave(nrs, dim=0), fin_seq[:, :nrs, :n].reshape(B * nrs, n)], dim=1)
+        if not return_dict:
+            return sequences
+        return GenerateOutput(sequences=sequences, past_key_values=None, logits=None, sequences_scores=fin_sc[:, :nrs].reshape(B * nrs))
 
     @staticmethod
     def _repetition_penalty(scores: torch.Tensor, seen_ids: torch.Tensor, penalty: float) -> torch.Tensor:
