@@ -223,7 +223,14 @@ def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int =
     top_skip = (T - n_supervised) * (2 * D * h * dh + 6 * D * I) if top_rows else 0
     M = body + head - top_skip
     step = E + 3 * P + M + (M + attn)
-    return dict(encoder=E, projector=P, llm_fwd=M, step=step, step_full_head=step + 2 * (head_full - head) + 2 * top_skip)
+    # recipe flavours (meta_config.yaml:5-6): the KL teacher = a forward of the same LLM over the text-only alternative (n_alt tokens, logits on
+    # the supervised rows), and - under encoder LoRA - the tower's backward: the dgrads of its layers' linears (= their forward FLOPs) and the
+    # attention backward (5 products against the forward's 2); the adapters' own rank-r products are not counted
+    n_alt = 16 + 48 + (n_text - 16)
+    teacher = L * (2 * n_alt * (2 * D * h * dh + 2 * D * kv * dh) + 6 * n_alt * D * I) + L * 2 * n_alt * n_alt * h * dh + head
+    enc_bwd = Le * (8 * Te * d * d + 4 * Te * d * ffn + 10 * Te * Te * d)
+    return dict(encoder=E, projector=P, llm_fwd=M, step=step, step_full_head=step + 2 * (head_full - head) + 2 * top_skip,
+                kl_teacher=teacher, encoder_lora_bwd=enc_bwd)
 
 
 def cpu_baseline(cfg, seconds: float, n_text: int = 128):
@@ -754,6 +761,9 @@ def main():
 
     if rank == 0:
         fl = flops_per_sample(cfg, wl["seconds"], top_rows=bool(model._llm_top_rows))    # what the measured step really skipped
+        flavour_extra = (fl["kl_teacher"] if args.loss == "kl" else 0) + (fl["encoder_lora_bwd"] if args.audio_lora_r else 0)
+        fl["step"] += flavour_extra          # (the recipe flavours do more work per step than the CE line: count it)
+        fl["step_full_head"] += flavour_extra
         audio_s = B * world * wl["seconds"] * args.steps
         ms = dt / args.steps * 1e3
         out = {

@@ -293,8 +293,9 @@ def test_forward_with_past_key_values_drives_a_decode_loop(dtype):
         assert torch.equal(outN.logits.float().argmax(-1).cpu(), want[:, T + 1:T + 4])
     else:
         assert rel_l2(outN.logits.float(), tf) < 2e-2
-    with pytest.raises(NotImplementedError, match="logits_to_keep=2"):
-        model.forward(input_ids=want[:, T:T + 3].to(DEV), past_key_values=outN.past_key_values, logits_to_keep=2)
+    two = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=1, eos_token_id=-1, return_dict_in_generate=True)
+    out2 = model.forward(input_ids=want[:, T:T + 3].to(DEV), past_key_values=two.past_key_values, logits_to_keep=2)
+    assert tuple(out2.logits.shape) == (B, 2, 512) and torch.equal(out2.logits, outN.logits[:, -2:]) and out2.past_key_values.cur_len == T + 3
     again = model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=1, eos_token_id=-1, return_dict_in_generate=True)
     out3 = model.forward(input_ids=want[:, T:T + 3].to(DEV), past_key_values=again.past_key_values, logits_to_keep=1)
     assert out3.past_key_values.cur_len == T + 3 and tuple(out3.logits.shape) == (B, 1, 512)

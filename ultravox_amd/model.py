@@ -832,10 +832,9 @@ class UltravoxModel:
         B, Tn, D = inputs_embeds.shape
         if B != past.tokens.shape[0]:
             raise ValueError(f"batch size {B} does not match the cache ({past.tokens.shape[0]})")
-        keep = int(logits_to_keep or 0)
-        if keep not in (0, 1) and keep < Tn:
-            raise NotImplementedError(f"logits_to_keep={keep}: 0 (every new position, HF's default) and 1 (the last one, what its "
-                                      "generate() asks for) are built")
+        keep = int(logits_to_keep or 0)      # HF: 0 = every new position, k = the last k (its generate() asks for 1)
+        if keep < 0:
+            raise ValueError(f"logits_to_keep={keep} must be >= 0")
         all_rows = Tn > 1 and keep != 1
         if attention_mask is not None and not bool(torch.as_tensor(attention_mask)[:, -Tn:].to("cpu").bool().all()):
             raise ValueError("padding inside the new positions of a cached sequence is not supported")
@@ -862,6 +861,8 @@ class UltravoxModel:
         new_ids = (input_ids.to(dev) if input_ids is not None else torch.full((B, Tn), -1, device=dev, dtype=torch.int64))
         state = KVState(cache=cache, Tmax=Tmax, cur_len=P + Tn, pos_next=(pos0 + Tn).contiguous(), kv_start=past.kv_start,
                         tokens=torch.cat([past.tokens, new_ids.to(torch.int64)], dim=1), partial_ok=past.partial_ok)
+        if all_rows and 1 < keep < Tn:         # the last `keep` positions (computed with the rest: one LM-head GEMM over the chunk either way)
+            logits = logits[:, Tn - keep:].contiguous()
         return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=state)
 
     def _kl_forward(self, inputs_embeds, labels, attention_mask, alt_input_ids, alt_attention_mask, alt_labels,
