@@ -194,7 +194,8 @@ def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int =
     is counted on the supervised positions only (the rows that enter the loss; the other rows of the logits have zero
     weight and zero gradient, and the training step does not compute them), and so is the last LLM layer's o_proj + MLP -
     `step_full_head` keeps the all-rows count.  top_rows = False: the step flavours that DO run the last layer on every row
-    (KL distillation, LLM LoRA, UVX_TOP_LAYER_ROWS=0: model._llm_train_pair is false) - nothing is subtracted for them."""
+    (LLM LoRA, UVX_TOP_LAYER_ROWS=0, the f32 / full-logits KL path) - nothing is subtracted for them.  (Round 6: the compact-rows KL step
+    - uvx_llm_fwd_rows / uvx_llm_bwd_rows - runs its last layer on the loss rows too, student and teacher.)"""
     a, t = cfg.audio_config, cfg.text_config
     F = int(seconds * 100)
     Te = F // 2
@@ -228,6 +229,8 @@ def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int =
     # attention backward (5 products against the forward's 2); the adapters' own rank-r products are not counted
     n_alt = 16 + 48 + (n_text - 16)
     teacher = L * (2 * n_alt * (2 * D * h * dh + 2 * D * kv * dh) + 6 * n_alt * D * I) + L * 2 * n_alt * n_alt * h * dh + head
+    if top_rows:
+        teacher -= (n_alt - n_supervised) * (2 * D * h * dh + 6 * D * I)
     enc_bwd = Le * (8 * Te * d * d + 4 * Te * d * ffn + 10 * Te * Te * d)
     return dict(encoder=E, projector=P, llm_fwd=M, step=step, step_full_head=step + 2 * (head_full - head) + 2 * top_skip,
                 kl_teacher=teacher, encoder_lora_bwd=enc_bwd)

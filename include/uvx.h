@@ -320,7 +320,8 @@ int32_t uvx_llm_bwd_lora(void* stream, const uvx_config_t* cfg, const uvx_llm_we
  *   uvx_llm_fwd_rows(student, rows_s, n_s, NULL, save_for_bwd = 1)         -- compact logits + list stay in `workspace`
  *   uvx_llm_kl_loss_rows(teacher [n_t, vocab], pair [2][n_s] = index into the teacher's rows or -1, pair_w [2][n_s], ...)
  *   uvx_llm_bwd_rows(...)
- * bf16 only. */
+ * bf16 only.  Nothing but the listed rows' logits leaves these calls, so the LAST layer's row-wise half (o_proj, MLP, final norm - and, in
+ * uvx_llm_bwd_rows, their gradients) runs on the listed rows only (round 6; option 3 = 0 restores every row; Gemma-3: every row). */
 int32_t uvx_llm_fwd_rows(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const void* inputs_embeds,
                          const int64_t* attention_mask, int32_t B, int32_t T, const int32_t* rows, int32_t n_rows,
                          void* logits_rows, int32_t save_for_bwd, void* workspace, size_t ws_bytes);

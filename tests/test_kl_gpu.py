@@ -160,3 +160,45 @@ def test_kl_step_matches_the_reference_forward_fixture(tag, dtype):
     for k in z.files:
         if k.startswith(tag + ".g."):
             assert rel_l2(mine[k[len(tag) + 3:]], torch.from_numpy(z[k])) < (1e-3 if dtype == torch.float32 else 0.1), k
+
+
+@pytest.mark.parametrize("side_stream", [True, False])
+def test_kl_rows_step_with_the_compact_last_layer_matches_the_full_row_one(side_stream):
+    """Round 6: uvx_llm_fwd_rows / uvx_llm_bwd_rows run the LAST layer's row-wise half (o_proj, MLP, final norm and their gradients) on
+    the listed rows only - student (stash kept for the backward) and teacher (no stash: the other layer slot is the gather scratch) -
+    as the CE pair does on the supervised rows.  Against the same step with that turned off (uvx_set_option(3, 0): every row through the
+    last layer): the same per-row arithmetic, so the loss agrees to the f32 row-sum grouping and the projector gradients to the bf16
+    round-off of one scatter (the CE pair's bar, tests/test_model_gpu.py)."""
+    from oracle.reference_cpu import synthetic_batch
+    from test_model_gpu import SMALL
+    from ultravox_amd import _lib
+    from ultravox_amd.config import LossConfig, LossFunction, UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    cfg = UltravoxConfig(**dict(SMALL, text_config=dict(SMALL["text_config"], num_hidden_layers=3)))
+    sd = random_state_dict(cfg, seed=31, dtype=torch.bfloat16)
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16)
+    model.set_loss_config(LossConfig(loss_function=LossFunction.KL_Divergence, kl_temperature=2.0, eot_loss_weight=1.0))
+    model.kl_teacher_side_stream = side_stream
+    b = synthetic_batch(cfg, 3, 2.0, n_text=24, audio_start=5, n_supervised=8)
+    pcm = b.pop("pcm")
+    b.update(_alt_fields(b, cfg, 5, 8))
+    mel = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins).logmel_device(pcm.to(DEV)).bfloat16()
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    model.train()
+    L = _lib.lib()
+    runs = []
+    try:
+        for opt in (1, 0, 1):
+            L.uvx_set_option(3, opt)
+            loss = model.forward_backward(audio_values=mel, **gb)
+            assert model._llm_top_rows == bool(opt)
+            runs.append((loss.clone(), model.proj_grad.clone()))
+    finally:
+        L.uvx_set_option(3, 1)
+    torch.cuda.synchronize()
+    (l1, g1), (l0, g0), (l2, g2) = runs
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)                     # the compact step is reproducible bit for bit
+    assert abs(l1.item() - l0.item()) < 1e-6 * abs(l0.item()) + 1e-9
+    assert rel_l2(g1, g0) < 5e-3 and g1.float().abs().max().item() > 0

@@ -881,10 +881,15 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   // rows (device-side list, no host sync; GEMMs clamp to the device count).  Same loss, same gradients.
   UVX_CHECK(!top_rows || (labels && loss && dt == DT_BF16 && save_for_bwd && !logits && !rows), UVX_ERR_INVALID,
             "llm_fwd_train: labels and a loss output are required, bf16 only");
+  UVX_CHECK(!rows || dt == DT_BF16, UVX_ERR_UNSUPPORTED, "llm_fwd_rows: bf16 only");
+  UVX_CHECK(!rows || (n_rows >= 0 && n_rows <= M), UVX_ERR_SHAPE, "llm_fwd_rows: %d rows of %d", n_rows, M);
   const int fl = c.llm_flavor;   // 0 Llama, 1 Gemma, 2 Gemma-3 (norm flavour - any non-zero value is Gemma's -, GLU activation, embedding scale)
   const bool g3 = fl == UVX_LLM_GEMMA3;
-  const bool tc = top_rows && g_options[3] && !g3;   // (tuning option 3 off, or Gemma-3's post norms: the plain full-row path, in both calls of the pair)
-  if (top_rows) note_pair(workspace, tc);
+  // uvx_llm_fwd_rows (round 6): the same holds for a caller-supplied row list - only the listed positions' logits leave the call (teacher)
+  // or are differentiated (student, uvx_llm_bwd_rows), so the last layer's row-wise half runs on them alone
+  const bool top = top_rows || (rows && !lora);
+  const bool tc = top && g_options[3] && !g3;   // (tuning option 3 off, or Gemma-3's post norms: the plain full-row path, in both calls of the pair)
+  if (top && save_for_bwd) note_pair(workspace, tc);
   const float attn_scale = c.llm_attn_scale > 0.f ? c.llm_attn_scale : 1.0f / sqrtf((float)dh);
   {
     LlmLayerStash l0 = llm_layer(s, 0);
@@ -950,14 +955,24 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       RC(gemm(sx, dt, lin(v.act, L.wd, cur.m_pre, Mv, D, c.llm_inter)));
       return rmsnorm_fwd(sx, dt, cur.m_pre, L.ln2_post, x_out, nullptr, Mv, D, c.rms_eps, fl, nullptr, cur.x_mid);
     }
-    if (compact) {   // gather the supervised rows of the attention output and of the residual stream (backward scratch is free here)
-      RC(sup_rows(sx, labels, v.sup, B, T, c.vocab));
-      RC(gather_rows(sx, dt, cur.o, v.sup, Mv, v.d_o, s.OD));
-      RC(gather_rows(sx, dt, cur.x_in, v.sup, Mv, v.dx, D));
+    // gather targets of the compact last layer: the idle backward scratch, or - a forward without stash (the KL teacher) - the other
+    // layer slot's o / x_in, dead since the previous layer finished
+    void* g_o = save_for_bwd ? v.d_o : llm_layer(v, slot_of(l) ^ 1).o;
+    void* g_x = save_for_bwd ? v.dx : llm_layer(v, slot_of(l) ^ 1).x_in;
+    if (compact) {   // gather the supervised rows of the attention output and of the residual stream
+      if (rows) {    // (uvx_llm_fwd_rows: the caller's list)
+        UVX_HIP(hipMemcpyAsync(v.sup, rows, sizeof(int32_t) * n_rows, hipMemcpyDeviceToDevice, sx));
+        hipLaunchKernelGGL(set_i32_k, dim3(1), dim3(1), 0, sx, v.sup + Mv, n_rows);
+        UVX_LAUNCH_CHECK();
+      } else {
+        RC(sup_rows(sx, labels, v.sup, B, T, c.vocab));
+      }
+      RC(gather_rows(sx, dt, cur.o, v.sup, Mv, g_o, s.OD));
+      RC(gather_rows(sx, dt, cur.x_in, v.sup, Mv, g_x, D));
     }
     {
-      GemmDesc g = lin(compact ? v.d_o : cur.o, L.wo, cur.x_mid, Mv, D, s.OD);
-      g.residual = compact ? v.dx : cur.x_in; g.ldr = D; g.m_dev = mdev;
+      GemmDesc g = lin(compact ? g_o : cur.o, L.wo, cur.x_mid, Mv, D, s.OD);
+      g.residual = compact ? g_x : cur.x_in; g.ldr = D; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
     if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, probe_skip(256) && save_for_bwd ? v.d_n : v.n, nullptr, Mv, D, c.rms_eps, fl, mdev));
@@ -994,14 +1009,14 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   if (tc) RC(layer_mlp(st, s, c.llm_layers - 1, true));
   RC(rmsnorm_fwd(st, dt, s.x_final, w->norm, s.hn, nullptr, M, D, c.rms_eps, fl, tc ? s.sup + M : nullptr));   // (compact last layer: its rows only)
   if (rows) {
-    UVX_CHECK(dt == DT_BF16, UVX_ERR_UNSUPPORTED, "llm_fwd_rows: bf16 only");
-    UVX_CHECK(n_rows >= 0 && n_rows <= M, UVX_ERR_SHAPE, "llm_fwd_rows: %d rows of %d", n_rows, M);
-    if (n_rows > 0) UVX_HIP(hipMemcpyAsync(s.sup, rows, sizeof(int32_t) * n_rows, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(set_i32_k, dim3(1), dim3(1), 0, st, s.sup + M, n_rows);
-    UVX_LAUNCH_CHECK();
+    if (!tc) {       // (compact last layer: the list is in place and s.hn holds its rows, in list order)
+      if (n_rows > 0) UVX_HIP(hipMemcpyAsync(s.sup, rows, sizeof(int32_t) * n_rows, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(set_i32_k, dim3(1), dim3(1), 0, st, s.sup + M, n_rows);
+      UVX_LAUNCH_CHECK();
+    }
     if (n_rows == 0) return UVX_OK;
-    RC(gather_rows(st, dt, s.hn, s.sup, M, s.n, D));
-    RC(gemm(st, dt, lin(s.n, w->lm_head, s.logits, n_rows, c.vocab, D)));
+    if (!tc) RC(gather_rows(st, dt, s.hn, s.sup, M, s.n, D));
+    RC(gemm(st, dt, lin(tc ? s.hn : s.n, w->lm_head, s.logits, n_rows, c.vocab, D)));
     if (logits_rows) UVX_HIP(hipMemcpyAsync(logits_rows, s.logits, (size_t)n_rows * c.vocab * es, hipMemcpyDeviceToDevice, st));
     return UVX_OK;
   }
@@ -1171,8 +1186,10 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   // top_rows (uvx_llm_bwd_train, after uvx_llm_fwd_train): the last layer's stash (x_final, x_mid, gate|up) holds the
   // supervised rows only; its MLP / o_proj gradients run on those rows and are scattered back before the attention backward
   UVX_CHECK(!top_rows || (!compact_in_place && labels && dt == DT_BF16), UVX_ERR_INVALID, "llm_bwd_train: labels are required, bf16 only");
-  const bool tc = top_rows && g_options[3] && !g3;
-  if (top_rows) RC(check_pair(workspace, tc));
+  UVX_CHECK(!compact_in_place || dt == DT_BF16, UVX_ERR_UNSUPPORTED, "llm_bwd_rows: bf16 only");
+  // (uvx_llm_bwd_rows after uvx_llm_fwd_rows: the same compact last-layer stash, keyed by the caller's row list)
+  const bool tc = (top_rows || (compact_in_place && !lora)) && g_options[3] && !g3;
+  if (top_rows || (compact_in_place && !lora)) RC(check_pair(workspace, tc));
   const int32_t* mdev_top = tc ? s.sup + M : nullptr;
   if (tc) {
     RC(gather_rows(st, dt, s.d_hn, s.sup, M, s.d_n, D));                 // d_hn was scattered to full rows: back to compact

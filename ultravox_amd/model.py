@@ -971,7 +971,8 @@ class UltravoxModel:
                                      ptr(ws), C.c_size_t(nb)), "uvx_llm_kl_loss_rows")
         self._llm_ctx = (B, T, nb, "rows")        # forward_backward: uvx_llm_bwd_rows
         self._llm_train_pair = False
-        self._llm_top_rows = False
+        # (round 6: uvx_llm_fwd_rows / uvx_llm_bwd_rows run the last layer's row-wise half on the listed rows only, like the CE pair)
+        self._llm_top_rows = not self.config.text_config.is_gemma3 and l.uvx_get_option(3) != 0
         return CausalLMOutputWithPast(loss=loss[0], logits=None)
 
     @torch.no_grad()
