@@ -41,6 +41,8 @@ What is recorded
                     LlamaForCausalLM with the reference's own LoraConfigSimplified defaults, through tests/peft_stub.py
                     (peft itself is not installable here: the stub restates peft 0.11.1's LoRA Linear and says so): adapted
                     module set, trainable names, state-dict key names, forward outputs and adapter gradients.
+  lora_targets_reference.npz / .json — the same with target_modules beyond the default: q / k / v / out_proj (Whisper) and q / k / v /
+                    o_proj (Llama, GQA), and a v + o-only list; peft's error text for a list that hits nothing.
 """
 import dataclasses
 import json
@@ -520,6 +522,97 @@ def lora_cases():
     print("lora_reference:", meta["encoder"]["adapted"], meta["llm"]["adapted"])
 
 
+def lora_targets_cases():
+    """apply_lora with target_modules BEYOND the default (ultravox_config.py:19-21 is only a default; the reference hands the list to peft,
+    ultravox_model.py:695, 707): q / k / v / out_proj of an HF WhisperEncoder, q / k / v / o_proj of an HF LlamaForCausalLM (GQA), and a
+    v + o-only list - which modules get adapted, under which names, forward and adapter gradients.  Same towers / seeds as lora_cases()."""
+    from transformers import LlamaConfig, LlamaForCausalLM, WhisperConfig
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import random_state_dict
+    tiny = dict(audio_config=dict(d_model=64, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=128, num_mel_bins=80,
+                                  max_source_positions=1500),
+                text_config=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                 num_key_value_heads=2, vocab_size=256, rope_theta=10000.0, max_position_embeddings=512,
+                                 rms_norm_eps=1e-5),
+                hidden_size=128, stack_factor=8, projector_ln_mid=True)
+    cfg = UltravoxConfig(**tiny)
+    a, t = cfg.audio_config, cfg.text_config
+    sd = random_state_dict(cfg, seed=17)
+    simp = ultravox_config.LoraConfigSimplified
+    arrays, meta = {}, {"tiny": tiny, "seed": 17, "cases": {}}
+
+    def randomise_b(model, seed):
+        g = torch.Generator().manual_seed(seed)
+        for n, p in model.named_parameters():
+            if "lora_B" in n:
+                p.data = 0.05 * torch.randn(p.shape, generator=g)
+
+    for case, targets, r in (("all", ["q_proj", "k_proj", "v_proj", "out_proj", "o_proj"], 4), ("vo", ["v_proj", "out_proj", "o_proj"], 2)):
+        lcfg = dataclasses.asdict(simp(r=r, lora_alpha=6, target_modules=targets))
+        cm = meta["cases"][case] = {"lora_config": dict(lcfg)}
+        # ---- encoder ----
+        enc = WhisperEncoder(WhisperConfig(d_model=a.d_model, encoder_layers=a.encoder_layers, encoder_attention_heads=a.encoder_attention_heads,
+                                           encoder_ffn_dim=a.encoder_ffn_dim, num_mel_bins=a.num_mel_bins,
+                                           max_source_positions=a.max_source_positions, attn_implementation="eager")).eval()
+        enc.load_state_dict({k[len("audio_tower."):]: v for k, v in sd.items() if k.startswith("audio_tower.")}, strict=False)
+        wrapped = ultravox_model.apply_lora(enc, dict(lcfg))
+        randomise_b(wrapped, 1)
+        names = [n for n, p in wrapped.named_parameters() if p.requires_grad]
+        cm["encoder"] = {"trainable": names, "adapted": sorted({n.split(".lora_")[0] for n in names})}
+        torch.manual_seed(0)
+        x, audio_len = torch.randn(2, 80, 120), torch.tensor([120, 75])
+        inner = wrapped.base_model.model
+        h = torch.nn.functional.gelu(inner.conv1(x))
+        h = torch.nn.functional.gelu(inner.conv2(h)).permute(0, 2, 1)
+        h = h + inner.embed_positions.weight[: h.size(-2)]
+        keep = torch.arange(h.shape[1])[None, :].lt(((audio_len - 1) // 2 + 1).view(-1, 1))
+        mask = (1.0 - keep[:, None, None, :].float()) * torch.finfo(torch.float32).min
+        for layer in inner.layers:
+            out = layer(h, mask)
+            h = out[0] if isinstance(out, tuple) else out
+        y = inner.layer_norm(h)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+        (y * gy).sum().backward()
+        arrays.update({f"{case}.enc.x": x.numpy(), f"{case}.enc.audio_len": audio_len.numpy(), f"{case}.enc.y": y.detach().numpy(),
+                       f"{case}.enc.gy": gy.numpy()})
+        for n, p in wrapped.named_parameters():
+            if p.requires_grad:
+                arrays[f"{case}.enc.w." + n], arrays[f"{case}.enc.g." + n] = p.detach().numpy(), p.grad.numpy()
+        # ---- language model ----
+        llm = LlamaForCausalLM(LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size, num_hidden_layers=t.num_hidden_layers,
+                                           num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+                                           vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta,
+                                           max_position_embeddings=t.max_position_embeddings, tie_word_embeddings=False,
+                                           attn_implementation="eager")).eval()
+        llm.load_state_dict({k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}, strict=False)
+        wl = ultravox_model.apply_lora(llm, dict(lcfg))
+        randomise_b(wl, 3)
+        names = [n for n, p in wl.named_parameters() if p.requires_grad]
+        cm["llm"] = {"trainable": names, "adapted": sorted({n.split(".lora_")[0] for n in names})}
+        emb = 0.5 * torch.randn(2, 21, t.hidden_size, generator=torch.Generator().manual_seed(4))
+        am = torch.ones(2, 21, dtype=torch.long)
+        am[1, -5:] = 0
+        logits = wl(inputs_embeds=emb, attention_mask=am).logits
+        gl = torch.randn(logits.shape, generator=torch.Generator().manual_seed(5)) * am[..., None]
+        (logits * gl).sum().backward()
+        arrays.update({f"{case}.llm.emb": emb.numpy(), f"{case}.llm.mask": am.numpy(), f"{case}.llm.logits": logits.detach().numpy(),
+                       f"{case}.llm.gl": gl.numpy()})
+        for n, p in wl.named_parameters():
+            if p.requires_grad:
+                arrays[f"{case}.llm.w." + n], arrays[f"{case}.llm.g." + n] = p.detach().numpy(), p.grad.numpy()
+    # a list none of whose names exist in the tower: peft raises (the text our config check repeats)
+    try:
+        ultravox_model.apply_lora(torch.nn.Sequential(torch.nn.Linear(3, 3)), dataclasses.asdict(simp(r=2, target_modules=["linear_k"])))
+        meta["no_hit_error"] = None
+    except ValueError as e:
+        meta["no_hit_error"] = str(e)
+    np.savez_compressed(os.path.join(HERE, "lora_targets_reference.npz"), **arrays)
+    with open(os.path.join(HERE, "lora_targets_reference.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("lora_targets_reference:", {c: (m["encoder"]["adapted"], m["llm"]["adapted"]) for c, m in meta["cases"].items()})
+
+
 CONFIG_SCALARS = ["ignore_index", "audio_model_id", "text_model_id", "audio_token_index", "hidden_size", "stack_factor", "norm_init",
                   "projector_act", "projector_ln_mid", "llm_only_training", "audio_latency_block_size", "vocab_size", "initializer_range"]
 CONFIG_TEXT = ["model_type", "hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "intermediate_size",
@@ -863,6 +956,7 @@ if __name__ == "__main__":
     forward_cases()
     config_cases()
     lora_cases()
+    lora_targets_cases()
     processor_cases()
     projector_cases()
     projector_act_cases()

@@ -349,3 +349,103 @@ def test_llm_only_training_builds_the_language_model_alone(tmp_path):
         UltravoxTrainer(frozen)
     out = frozen.generate(tb["input_ids"][:, :10], max_new_tokens=3, eos_token_id=-1)      # inference works as for any text prompt
     assert out.shape == (2, 13)
+
+
+ALL_A, ALL_T = ["q_proj", "k_proj", "v_proj", "out_proj", "o_proj"], ["q_proj", "k_proj", "v_proj", "out_proj", "o_proj"]
+VO = ["v_proj", "out_proj", "o_proj"]
+
+
+def _targets_setup(dtype, targets, seed=47):
+    from oracle.reference_cpu import OracleModel, synthetic_batch
+    from test_model_gpu import SMALL
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    cfg = UltravoxConfig(**SMALL, audio_model_lora_config={"r": 4, "lora_alpha": 8, "target_modules": targets},
+                         text_model_lora_config={"r": 8, "lora_alpha": 16, "target_modules": targets})
+    sd = random_state_dict(cfg, seed=seed, dtype=dtype)
+    sd.update(init_lora_state_dict(cfg, seed=seed, dtype=dtype, random_b=True))
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    b = synthetic_batch(cfg, 2, 3.0, n_text=24, audio_start=5, n_supervised=8)
+    b["audio_lens"] = torch.tensor([300, 230])
+    pcm = b.pop("pcm")
+    mel = WhisperFeatureExtractor(cfg.audio_config.num_mel_bins).logmel_device(pcm.to(DEV)).to(dtype)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    return cfg, sd, model, oracle, gb, {**b, "audio_values": mel.cpu().float()}, mel
+
+
+@pytest.mark.parametrize("targets", [ALL_A, VO, ["q_proj", "o_proj", "out_proj"]], ids=["qkvo", "vo", "qo"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lora_target_modules_beyond_q_and_k_train_step_matches_oracle(dtype, targets):
+    """target_modules beyond the reference's default list (ultravox_config.py:19-21 -> peft, ultravox_model.py:695-707): adapters on
+    v_proj and on the output projection (out_proj in Whisper, o_proj in the LLM), alone or next to q / k, in both towers - ABI 17's
+    uvx_enc_lora_layer_t.v / .o.  Loss, logits, the projector's and every adapter matrix's gradient against the oracle's autograd (the
+    oracle with these adapters is pinned to the reference's apply_lora by tests/golden/lora_targets_reference.npz)."""
+    cfg, sd, model, oracle, gb, ob, mel = _targets_setup(dtype, targets)
+    ne, nl = cfg.audio_config.encoder_layers, cfg.text_config.num_hidden_layers
+    n_a = len([m for m in targets if m != "o_proj"])
+    n_t = len([m for m in targets if m != "out_proj"])
+    assert len(oracle.trainable) == 4 + 2 * n_a * ne + 2 * n_t * nl
+    ref, grads, _ = oracle.train_step(ob)
+    out = model.forward(audio_values=mel, **gb)
+    if dtype == torch.float32:
+        assert (out.logits.cpu() - ref["logits"]).abs().max().item() < 1e-3
+    else:
+        assert rel_l2(out.logits, ref["logits"]) < 3e-2
+    model.train()
+    loss = model.forward_backward(audio_values=mel, **gb)
+    assert abs(loss.item() - ref["loss"].item()) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(ref["loss"].item())
+    mine = model.projector_grads()
+    assert set(mine) == set(grads)
+    tol = 2e-3 if dtype == torch.float32 else 8e-2
+    for k, g in grads.items():
+        assert g.abs().max().item() > 0, k
+        assert rel_l2(mine[k], g) < tol, (k, rel_l2(mine[k], g))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lora_on_v_and_o_merges_and_decodes_like_the_adapter_forward(dtype):
+    """merge_and_unload and the per-call fold of generate() / cached forward() with adapters on v_proj / o_proj: the folded wqkv rows and wo
+    give the adapter forward's logits; the un-merged model decodes the merged model's tokens and its weights come back bit for bit."""
+    cfg, sd, model, oracle, gb, ob, mel = _targets_setup(dtype, ALL_A, seed=53)
+    before = model.forward(audio_values=mel, **gb).logits.float()
+    keep = [(L["wqkv"].clone(), L["wo"].clone()) for L in model._llm["layers"]]
+    gen = {k: v for k, v in gb.items() if k != "labels"}
+    model.eval()
+    out = model.generate(audio_values=mel, max_new_tokens=4, eos_token_id=-1, **gen)
+    assert all(torch.equal(L["wqkv"], a) and torch.equal(L["wo"], b) for L, (a, b) in zip(model._llm["layers"], keep))
+    model.merge_and_unload()
+    assert any(not torch.equal(L["wo"], b) for L, (a, b) in zip(model._llm["layers"], keep))
+    after = model.forward(audio_values=mel, **gb).logits.float()
+    assert rel_l2(after, before) < (1e-5 if dtype == torch.float32 else 2e-2)
+    merged = model.generate(audio_values=mel, max_new_tokens=4, eos_token_id=-1, **gen)
+    assert torch.equal(merged, out)
+
+
+def test_lora_on_o_proj_of_a_gemma3_backbone_joins_the_branch_before_its_post_norm():
+    """Gemma-3's decoder layer normalises o_proj's output (post_attention_layernorm) before the residual add: the o_proj adapter's term and
+    its gradient sit BEHIND that norm (and q / k adapters in front of q_norm / k_norm).  f32 against the oracle's autograd."""
+    from oracle.reference_cpu import OracleModel, logmel_ref, synthetic_batch
+    from test_gemma3_gpu import _cfg
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    cfg = _cfg(layers=3, text_model_lora_config={"r": 4, "lora_alpha": 8, "target_modules": ["q_proj", "k_proj", "v_proj", "o_proj"]})
+    sd = random_state_dict(cfg, seed=59)
+    sd.update(init_lora_state_dict(cfg, seed=59, random_b=True))
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    assert len(oracle.trainable) == 4 + 8 * 3
+    b = synthetic_batch(cfg, 2, 2.0, n_text=24, audio_start=5, n_supervised=8)
+    b["audio_values"] = logmel_ref(b.pop("pcm"), 80)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    ref, grads, _ = oracle.train_step(b)
+    model.train()
+    loss = model.forward_backward(**gb)
+    assert abs(loss.item() - ref["loss"].item()) < 1e-4 * abs(ref["loss"].item())
+    mine = model.projector_grads()
+    assert set(mine) == set(grads)
+    for k, g in grads.items():
+        assert g.abs().max().item() > 0, k
+        assert rel_l2(mine[k], g) < 2e-3, (k, rel_l2(mine[k], g))

@@ -396,6 +396,55 @@ def test_lora_restatement_matches_reference_apply_lora_fixture(golden_dir):
         np.testing.assert_allclose(sd["language_model." + n].grad.numpy(), z["llm.g." + n], rtol=2e-4, atol=2e-5, err_msg=n)
 
 
+@pytest.mark.parametrize("case", ["all", "vo"])
+def test_lora_target_modules_beyond_the_default_match_the_reference_apply_lora(golden_dir, case):
+    """target_modules is a config field the reference hands to peft unchanged (ultravox_config.py:19-21, ultravox_model.py:695, 707).
+    Fixture lora_targets_reference.npz: the reference's apply_lora (tests/peft_stub.py) with q / k / v / out_proj / o_proj ("all") and a
+    v + o-only list ("vo") on an HF WhisperEncoder and a GQA LlamaForCausalLM - which modules our config resolves, the key names, and the
+    oracle's forward / adapter gradients with adapters on v_proj and on the output projection."""
+    import json
+    from ultravox_amd.config import lora_target_modules
+    from ultravox_amd.weights import init_lora_state_dict, lora_targets
+    z = np.load(os.path.join(golden_dir, "lora_targets_reference.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "lora_targets_reference.json")))
+    cm = meta["cases"][case]
+    lc = cm["lora_config"]
+    cfg = UltravoxConfig(**meta["tiny"], audio_model_lora_config=lc, text_model_lora_config=lc)
+    want_a = ("q_proj", "k_proj", "v_proj", "out_proj") if case == "all" else ("v_proj", "out_proj")
+    want_t = ("q_proj", "k_proj", "v_proj", "o_proj") if case == "all" else ("v_proj", "o_proj")
+    assert lora_targets(cfg, "audio") == want_a and lora_targets(cfg, "text") == want_t
+    enc_names = {"audio_tower." + n for n in cm["encoder"]["trainable"]}
+    llm_names = {"language_model." + n for n in cm["llm"]["trainable"]}
+    init = init_lora_state_dict(cfg)
+    assert set(init) == enc_names | llm_names
+    for k, v in init.items():      # shapes: lora_A [r, in], lora_B [out, r] (GQA: k / v are narrower than q; o_proj maps heads * head_dim -> hidden)
+        tower, name = ("enc", k[len("audio_tower."):]) if k.startswith("audio_tower.") else ("llm", k[len("language_model."):])
+        assert tuple(v.shape) == z[f"{case}.{tower}.w.{name}"].shape, k
+    # peft's error for a list that hits no module is the text the config check raises
+    with pytest.raises(ValueError) as e:
+        lora_target_modules({"r": 2, "target_modules": ["linear_k"]}, "audio")
+    assert meta["no_hit_error"] is not None and str(e.value) == meta["no_hit_error"]
+    with pytest.raises(ValueError, match="MLP"):
+        UltravoxConfig(**meta["tiny"], audio_model_lora_config={"r": 2, "target_modules": ["q_proj", "fc1"]})
+    sd = random_state_dict(cfg, seed=meta["seed"])
+    for tower, prefix in (("enc", "audio_tower."), ("llm", "language_model.")):
+        for k in z.files:
+            if k.startswith(f"{case}.{tower}.w."):
+                sd[prefix + k[len(case) + len(tower) + 4:]] = torch.from_numpy(z[k]).clone().requires_grad_(True)
+    scaling = lc["lora_alpha"] / lc["r"]
+    y = O.whisper_encoder_ref(sd, cfg, torch.from_numpy(z[f"{case}.enc.x"]), torch.from_numpy(z[f"{case}.enc.audio_len"]), lora={"scaling": scaling})
+    np.testing.assert_allclose(y.detach().numpy(), z[f"{case}.enc.y"], rtol=1e-4, atol=2e-5)
+    (y * torch.from_numpy(z[f"{case}.enc.gy"])).sum().backward()
+    for n in cm["encoder"]["trainable"]:
+        np.testing.assert_allclose(sd["audio_tower." + n].grad.numpy(), z[f"{case}.enc.g." + n], rtol=2e-4, atol=2e-5, err_msg=n)
+    logits = O.llama_ref(sd, cfg, torch.from_numpy(z[f"{case}.llm.emb"]), torch.from_numpy(z[f"{case}.llm.mask"]), lora={"scaling": scaling})
+    keep = torch.from_numpy(z[f"{case}.llm.mask"]).bool()
+    np.testing.assert_allclose(logits.detach()[keep].numpy(), z[f"{case}.llm.logits"][keep.numpy()], rtol=1e-4, atol=2e-5)
+    (logits * torch.from_numpy(z[f"{case}.llm.gl"])).sum().backward()
+    for n in cm["llm"]["trainable"]:
+        np.testing.assert_allclose(sd["language_model." + n].grad.numpy(), z[f"{case}.llm.g." + n], rtol=2e-4, atol=2e-5, err_msg=n)
+
+
 @pytest.mark.parametrize("hidden_act", ["gelu_pytorch_tanh", "gelu"])
 def test_gemma_backbone_matches_hf_blocks(hidden_act):
     """hidden_act "gelu": [3P] GemmaMLP applies ACT2FN[config.hidden_act], so a checkpoint whose config.json says "gelu" runs the

@@ -70,6 +70,7 @@ struct EncLayerStash {
   void *x_in, *qkv, *o, *x_mid, *pre, *t;   // t = [lora_A_q(n) | lora_A_k(n)], [M, 128] (columns 0..r-1 and 64..64+r-1)
   float* lse;
   void *bqT, *bkT;                           // lora_B^T [r, d] of this layer: every rank-r product reads rows
+  void *t2, *bvT, *boT;                      // v_proj / out_proj adapters (ABI 17): t2 = [lora_A_v(n) | lora_A_o(attention output)] [M, 128]
 };
 struct EncWs {
   void *im2col, *c1, *x, *n, *qkv, *vt, *o, *f;
@@ -78,7 +79,7 @@ struct EncWs {
   void* sk; size_t sk_bytes;    // inference at one or two clips: split-K scratch of the layer GEMMs (gemm.hip "Split-K"), else null
   // training only
   char* slots; size_t slot_bytes; EncLayerStash ls0;
-  void *dx, *d_n, *d_o, *d_f, *d_qkv, *qT, *kT, *doT, *u;
+  void *dx, *d_n, *d_o, *d_f, *d_qkv, *qT, *kT, *doT, *u, *u2;   // u2: [d v . B_v | d x_mid . B_o] [M, 128]
   float *delta, *wg;   // wg: lora_wgrad scratch
   int Mp;
 };
@@ -88,11 +89,12 @@ void enc_slot(Arena& a, const uvx_config_t& c, int B, int Te, EncLayerStash& s) 
   s.pre = a.take(M * c.enc_ffn * es); s.t = a.take(M * 128 * es);
   s.lse = (float*)a.take(sizeof(float) * (size_t)B * c.enc_heads * Te);
   s.bqT = a.take(64 * d * es); s.bkT = a.take(64 * d * es);
+  s.t2 = a.take(M * 128 * es); s.bvT = a.take(64 * d * es); s.boT = a.take(64 * d * es);
 }
 EncLayerStash enc_layer(const EncWs& w, int l) {
   EncLayerStash s = w.ls0;
   const size_t off = w.slot_bytes * l;
-  void** ps[] = {&s.x_in, &s.qkv, &s.o, &s.x_mid, &s.pre, &s.t, (void**)&s.lse, &s.bqT, &s.bkT};
+  void** ps[] = {&s.x_in, &s.qkv, &s.o, &s.x_mid, &s.pre, &s.t, (void**)&s.lse, &s.bqT, &s.bkT, &s.t2, &s.bvT, &s.boT};
   for (void** q : ps) if (*q) *q = (char*)*q + off;
   return s;
 }
@@ -130,7 +132,7 @@ EncWs enc_carve(Arena& a, const uvx_config_t& c, int B, int F, bool train = fals
     w.d_f = a.take(M * c.enc_ffn * es); w.d_qkv = a.take(M * 3 * d * es);
     const size_t ht = (size_t)B * c.enc_heads * dh * w.Tp * es;
     w.qT = a.take(ht); w.kT = a.take(ht); w.doT = a.take(ht);
-    w.u = a.take(M * 128 * es);
+    w.u = a.take(M * 128 * es); w.u2 = a.take(M * 128 * es);
     w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.enc_heads * w.Te);
     w.wg = (float*)a.take(sizeof(float) * (size_t)lora_wgrad_scratch_floats(w.M, c.enc_d, 64));
   }
@@ -180,6 +182,7 @@ struct LlmLayerStash {
   void *x_in, *qkv, *o, *x_mid, *gu;
   float* lse;
   void *t, *bqT, *bkT;   // LLM LoRA (text_model_lora_config): [lora_A_q(n) | lora_A_k(n)] [M, 128]; lora_B^T of q / k
+  void *t2, *bvT, *boT;  // v_proj / o_proj adapters (ABI 17): [lora_A_v(n) | lora_A_o(attention output)] [M, 128]; lora_B^T of v / o
   void* qk_raw;          // Qwen3 / Gemma-3 (llm_qk_norm): the q | k projections before q_norm / k_norm [M, (Hq + Hkv) * dh]
   void *o_pre, *m_pre;   // Gemma-3: o_proj / down_proj outputs BEFORE their post norms [M, D] (the post norms' backward needs them)
 };
@@ -195,7 +198,7 @@ struct LlmWs {
   void *dx, *d_hn, *d_act, *d_gu, *d_n, *d_o, *d_qkv, *qT, *kT, *doT;
   float* delta;
   float* dkv_part;
-  void* lu;      // LoRA backward: u = [dq . B_q | dk . B_k] [M, 128]
+  void *lu, *lu2; // LoRA backward: u = [dq . B_q | dk . B_k] [M, 128]; lu2 = [dv . B_v | d (o_proj output) . B_o]
   float* lwg;    // lora_wgrad scratch
   void *wt[2], *head_t;   // llm_wt_stream: two alternating sets of one layer's transposed weights, and lm_head^T
   int M, Tp, QKV, OD;
@@ -218,6 +221,9 @@ void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
   s.t = a.take(M * 128 * es);
   s.bqT = a.take((size_t)64 * c.llm_heads * c.llm_head_dim * es);
   s.bkT = a.take((size_t)64 * c.llm_kv_heads * c.llm_head_dim * es);
+  s.t2 = a.take(M * 128 * es);
+  s.bvT = a.take((size_t)64 * c.llm_kv_heads * c.llm_head_dim * es);
+  s.boT = a.take((size_t)64 * c.llm_d * es);
   s.qk_raw = a.take(c.llm_qk_norm ? M * (c.llm_heads + c.llm_kv_heads) * c.llm_head_dim * es : 0);
   s.o_pre = a.take(c.llm_flavor == UVX_LLM_GEMMA3 ? M * c.llm_d * es : 0);
   s.m_pre = a.take(c.llm_flavor == UVX_LLM_GEMMA3 ? M * c.llm_d * es : 0);
@@ -262,7 +268,7 @@ LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
     w.doT = a.take((size_t)B * c.llm_heads * c.llm_head_dim * w.Tp * es);
     w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.llm_heads * T);
     w.dkv_part = (float*)a.take(sizeof(float) * 2 * M * w.OD);
-    w.lu = a.take(M * 128 * es);
+    w.lu = a.take(M * 128 * es); w.lu2 = a.take(M * 128 * es);
     w.lwg = (float*)a.take(sizeof(float) * (size_t)lora_wgrad_scratch_floats(w.M, c.llm_d > w.OD ? c.llm_d : w.OD, 64));
     w.wt[0] = a.take(c.llm_wt_stream ? layer_wt_elems(c) * es : 0);
     w.wt[1] = a.take(c.llm_wt_stream ? layer_wt_elems(c) * es : 0);
@@ -277,6 +283,7 @@ LlmLayerStash llm_layer(const LlmWs& w, int slot) {
   s.x_in = (char*)s.x_in + d; s.qkv = (char*)s.qkv + d; s.o = (char*)s.o + d;
   s.x_mid = (char*)s.x_mid + d; s.gu = (char*)s.gu + d; s.lse = (float*)((char*)s.lse + d);
   s.t = (char*)s.t + d; s.bqT = (char*)s.bqT + d; s.bkT = (char*)s.bkT + d; s.qk_raw = (char*)s.qk_raw + d;
+  s.t2 = (char*)s.t2 + d; s.bvT = (char*)s.bvT + d; s.boT = (char*)s.boT + d;
   s.o_pre = (char*)s.o_pre + d; s.m_pre = (char*)s.m_pre + d;
   return s;
 }
@@ -484,6 +491,39 @@ extern "C" size_t uvx_encoder_ws_bytes(const uvx_config_t* cfg, int32_t B, int32
   return a.off + 256;
 }
 
+// One adapted linear (peft Linear.forward, dropout 0): y[M, cout] += round(scale * (x A^T) B^T).  t [M, 64 of a 128-column row] keeps
+// x A^T and bT [r, cout] the transposed lora_B for the backward.
+static int lora_apply(hipStream_t st, int dt, const void* x, long long ldx, const uvx_lora_proj_t& P, void* bT, void* t, void* y, long long ldy,
+                      long long M, int cin, int cout, int r, float scale) {
+  RC(lora_transpose(st, dt, P.b, bT, cout, r));
+  RC(lora_down(st, dt, x, ldx, P.a, 0, t, 128, M, cin, r, 1.0f));
+  return lora_up(st, dt, t, 128, bT, 1, y, ldy, M, cout, r, scale, 1);
+}
+// ... and its backward: u [M, 64 of 128] = round(scale * d y . B);  d A [r, cin] = u^T . x;  d B [cout, r] = scale * d y^T . t.  The caller adds
+// u . A to d x once the base dgrad has written it (lora_up, accumulate).
+static int lora_apply_bwd(hipStream_t st, int dt, const void* x, long long ldx, const void* dy, long long lddy, const void* bT, const void* t, void* u,
+                          const uvx_lora_proj_grad_t& G, long long M, int cin, int cout, int r, float scale, float* scratch, long long scratch_floats) {
+  RC(lora_down(st, dt, dy, lddy, bT, 0, u, 128, M, cout, r, scale));
+  const LoraWgradItem items[2] = {{x, ldx, u, 128, G.a, cin, 0, 1.0f}, {dy, lddy, t, 128, G.b, cout, 1, scale}};
+  return lora_wgrad_batch(st, dt, items, 2, M, r, scratch, scratch_floats);
+}
+
+// descriptor sanity: an adapted projection (a != NULL) has its lora_B and - with `grads` - both gradient buffers
+static int lora_check(const uvx_encoder_lora_t* lora, int n_layers, const uvx_encoder_lora_grads_t* grads, const char* who) {
+  UVX_CHECK(lora && lora->layers && lora->r > 0 && lora->r <= 64, UVX_ERR_INVALID, "%s: bad LoRA descriptor (rank must be in 1..64)", who);
+  for (int l = 0; l < n_layers; ++l) {
+    const uvx_lora_proj_t* P[4] = {&lora->layers[l].q, &lora->layers[l].k, &lora->layers[l].v, &lora->layers[l].o};
+    for (int j = 0; j < 4; ++j) {
+      UVX_CHECK(!P[j]->a || P[j]->b, UVX_ERR_INVALID, "%s: layer %d, projection %d has lora_A but no lora_B", who, l, j);
+      if (grads && P[j]->a) {
+        const uvx_lora_proj_grad_t* G[4] = {&grads->layers[l].q, &grads->layers[l].k, &grads->layers[l].v, &grads->layers[l].o};
+        UVX_CHECK(G[j]->a && G[j]->b, UVX_ERR_INVALID, "%s: layer %d, projection %d is adapted but has no gradient buffers", who, l, j);
+      }
+    }
+  }
+  return UVX_OK;
+}
+
 static GemmDesc enc_sk(GemmDesc g, const EncWs& s) { g.splitk_ws = s.sk; g.splitk_ws_bytes = s.sk_bytes; return g; }
 static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_weights_t* w, const uvx_encoder_lora_t* lora,
                        const void* mel, int mel_is_f32, const int64_t* audio_lens, int B, int F, void* out, void* workspace,
@@ -495,7 +535,7 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
   UVX_CHECK(c.enc_d % c.enc_heads == 0, UVX_ERR_SHAPE, "encoder: d=%d not divisible by heads=%d", c.enc_d, c.enc_heads);
   UVX_CHECK(c.enc_block == 0 || (c.enc_max_pos * 2) % c.enc_block == 0, UVX_ERR_SHAPE,
             "audio_latency_block_size %d must divide %d evenly.", c.enc_block, c.enc_max_pos * 2);
-  UVX_CHECK(!train || (lora->r > 0 && lora->r <= 64 && lora->layers), UVX_ERR_INVALID, "encoder LoRA: rank must be in 1..64");
+  if (train) RC(lora_check(lora, c.enc_layers, nullptr, "encoder LoRA"));
   if (B == 0 || F == 0) return UVX_OK;
   Arena a(workspace, ws_bytes);
   EncWs s = enc_carve(a, c, B, F, train);
@@ -551,9 +591,16 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
       //  loads sit in an epilogue nothing overlaps, and their registers cost the 256-row tile its spill-free budget - profiles/r06_flavours.txt.)
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r;
-      RC(lora_transpose2(st, dt, R.q.b, S.bqT, d, R.k.b, S.bkT, d, r));
-      RC(lora_down2(st, dt, s.n, s.n, d, R.q.a, R.k.a, S.t, at(S.t, 64, dt), 128, M, d, r, 1.0f, 1.0f));
-      RC(lora_up2(st, dt, S.t, at(S.t, 64, dt), 128, S.bqT, S.bkT, qkv, at(qkv, d, dt), 3 * d, M, d, d, r, lora->scaling * qscale, lora->scaling));
+      if (R.q.a && R.k.a) {      // the default target_modules: the pair in one launch each
+        RC(lora_transpose2(st, dt, R.q.b, S.bqT, d, R.k.b, S.bkT, d, r));
+        RC(lora_down2(st, dt, s.n, s.n, d, R.q.a, R.k.a, S.t, at(S.t, 64, dt), 128, M, d, r, 1.0f, 1.0f));
+        RC(lora_up2(st, dt, S.t, at(S.t, 64, dt), 128, S.bqT, S.bkT, qkv, at(qkv, d, dt), 3 * d, M, d, d, r, lora->scaling * qscale, lora->scaling));
+      } else {
+        if (R.q.a) RC(lora_apply(st, dt, s.n, d, R.q, S.bqT, S.t, qkv, 3 * d, M, d, d, r, lora->scaling * qscale));
+        if (R.k.a) RC(lora_apply(st, dt, s.n, d, R.k, S.bkT, at(S.t, 64, dt), at(qkv, d, dt), 3 * d, M, d, d, r, lora->scaling));
+      }
+      // v_proj (target_modules beyond the default; ABI 17): the same product into the v columns
+      if (R.v.a) RC(lora_apply(st, dt, s.n, d, R.v, S.bvT, S.t2, at(qkv, 2 * d, dt), 3 * d, M, d, d, r, lora->scaling));
     }
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(qkv, 2 * d, dt), s.vt, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
     AttnDesc ad;
@@ -567,6 +614,8 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
       g.bias = L.bo; g.residual = x; g.ldr = d;
       RC(gemm(st, dt, enc_sk(g, s)));
     }
+    // out_proj adapter: x_mid += lora_B(lora_A(attention output)) * scaling
+    if (train && lora->layers[l].o.a) RC(lora_apply(st, dt, o, d, lora->layers[l].o, S.boT, at(S.t2, 64, dt), x_mid, d, M, d, d, lora->r, lora->scaling));
     if (!probe_skip(128)) RC(layernorm_fwd(st, dt, x_mid, L.ln2_w, L.ln2_b, s.n, M, d, c.ln_eps));
     if (train) {   // keep the fc1 pre-activation for the GELU backward
       GemmDesc g = lin(s.n, L.fc1_w, S.pre, M, c.enc_ffn, d);
@@ -625,6 +674,7 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
   RC(check_cfg(cfg));
   UVX_CHECK(w && lora && d_out && grads && grads->layers && workspace, UVX_ERR_INVALID, "encoder_bwd: null argument");
   const uvx_config_t& c = *cfg;
+  RC(lora_check(lora, c.enc_layers, grads, "encoder_bwd"));
   hipStream_t st = (hipStream_t)stream;
   if (B == 0 || F == 0) return UVX_OK;
   Arena a(workspace, ws_bytes);
@@ -650,6 +700,13 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     RC(layernorm_bwd(st, dt, s.d_n, S.x_mid, L.ln2_w, s.dx, s.dx, M, d, c.ln_eps));
     // ---- attention: x_mid = x_in + wo(attn(q, k, v)) ----
     RC(gemm(st, dt, lin(s.dx, L.wo_t, s.d_o, M, d, d)));
+    const uvx_enc_lora_layer_t& R = lora->layers[l];
+    const uvx_enc_lora_layer_grads_t& G = grads->layers[l];
+    const long long wg_floats = lora_wgrad_scratch_floats(s.M, c.enc_d, 64);
+    if (R.o.a) {   // out_proj adapter: its gradients, and d o += (d x_mid . B_o * scaling) . A_o
+      RC(lora_apply_bwd(st, dt, S.o, d, s.dx, d, S.boT, at(S.t2, 64, dt), at(s.u2, 64, dt), G.o, M, d, d, r, lora->scaling, s.wg, wg_floats));
+      RC(lora_up(st, dt, at(s.u2, 64, dt), 128, R.o.a, 1, s.d_o, d, M, d, r, 1.0f, 1));
+    }
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, S.qkv, s.qT, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(S.qkv, d, dt), s.kT, B, Te, s.Tp, c.enc_heads, dh, 3 * d));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, s.d_o, s.doT, B, Te, s.Tp, c.enc_heads, dh, d));
@@ -663,23 +720,32 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     bd.dq = s.d_qkv; bd.dk = at(s.d_qkv, d, dt); bd.dv = at(s.d_qkv, 2 * d, dt);
     bd.lddq = bd.lddk = bd.lddv = 3 * d;
     RC(attention_bwd(st, dt, bd));
-    // ---- LoRA gradients of q_proj / k_proj (rank-r products on the VALU, lora.hip) ----
-    const uvx_enc_lora_layer_t& R = lora->layers[l];
-    const uvx_enc_lora_layer_grads_t& G = grads->layers[l];
-    // u = [dq . B_q * (scaling * qscale) | dk . B_k * scaling]  [M, 128] (columns 0..r-1 and 64..64+r-1)
-    RC(lora_down2(st, dt, s.d_qkv, at(s.d_qkv, d, dt), 3 * d, S.bqT, S.bkT, s.u, at(s.u, 64, dt), 128, M, d, r, lora->scaling * qscale, lora->scaling));
-    RC(layernorm_fwd(st, dt, S.x_in, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));      // n1 recomputed (not stashed)
-    // d lora_A [r, d] = u^T . n;  d lora_B [d, r] = scale * dq^T . t
-    {
+    // ---- LoRA gradients of q_proj / k_proj (/ v_proj) (rank-r products on the VALU, lora.hip) ----
+    const bool qk_pair = R.q.a && R.k.a;
+    if (R.q.a || R.k.a || R.v.a) RC(layernorm_fwd(st, dt, S.x_in, L.ln1_w, L.ln1_b, s.n, M, d, c.ln_eps));      // n1 recomputed (not stashed)
+    if (qk_pair) {
+      // u = [dq . B_q * (scaling * qscale) | dk . B_k * scaling]  [M, 128] (columns 0..r-1 and 64..64+r-1)
+      RC(lora_down2(st, dt, s.d_qkv, at(s.d_qkv, d, dt), 3 * d, S.bqT, S.bkT, s.u, at(s.u, 64, dt), 128, M, d, r, lora->scaling * qscale, lora->scaling));
+      // d lora_A [r, d] = u^T . n;  d lora_B [d, r] = scale * dq^T . t
       const LoraWgradItem items[4] = {{s.n, d, s.u, 128, G.q.a, d, 0, 1.0f}, {s.n, d, at(s.u, 64, dt), 128, G.k.a, d, 0, 1.0f},
                                       {s.d_qkv, 3 * d, S.t, 128, G.q.b, d, 1, lora->scaling * qscale},
                                       {at(s.d_qkv, d, dt), 3 * d, at(S.t, 64, dt), 128, G.k.b, d, 1, lora->scaling}};
-      RC(lora_wgrad_batch(st, dt, items, 4, M, r, s.wg, lora_wgrad_scratch_floats(s.M, c.enc_d, 64)));      // (one reduce launch for the four)
+      RC(lora_wgrad_batch(st, dt, items, 4, M, r, s.wg, wg_floats));      // (one reduce launch for the four)
+    } else {
+      if (R.q.a) RC(lora_apply_bwd(st, dt, s.n, d, s.d_qkv, 3 * d, S.bqT, S.t, s.u, G.q, M, d, d, r, lora->scaling * qscale, s.wg, wg_floats));
+      if (R.k.a) RC(lora_apply_bwd(st, dt, s.n, d, at(s.d_qkv, d, dt), 3 * d, S.bkT, at(S.t, 64, dt), at(s.u, 64, dt), G.k, M, d, d, r, lora->scaling, s.wg, wg_floats));
     }
+    if (R.v.a) RC(lora_apply_bwd(st, dt, s.n, d, at(s.d_qkv, 2 * d, dt), 3 * d, S.bvT, S.t2, s.u2, G.v, M, d, d, r, lora->scaling, s.wg, wg_floats));
     if (l == 0) break;   // nothing trainable below layer 0
-    // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k], then LN1 backward into the residual stream ----
+    // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k (; A_v)], then LN1 backward into the residual stream ----
     RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d)));
-    RC(lora_up2(st, dt, s.u, at(s.u, 64, dt), 128, R.q.a, R.k.a, s.d_n, s.d_n, d, M, d, d, r, 1.0f, 1.0f));      // (same rows: one pass, q term then k term)
+    if (qk_pair) {
+      RC(lora_up2(st, dt, s.u, at(s.u, 64, dt), 128, R.q.a, R.k.a, s.d_n, s.d_n, d, M, d, d, r, 1.0f, 1.0f));      // (same rows: one pass, q term then k term)
+    } else {
+      if (R.q.a) RC(lora_up(st, dt, s.u, 128, R.q.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+      if (R.k.a) RC(lora_up(st, dt, at(s.u, 64, dt), 128, R.k.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+    }
+    if (R.v.a) RC(lora_up(st, dt, s.u2, 128, R.v.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
     RC(layernorm_bwd(st, dt, s.d_n, S.x_in, L.ln1_w, s.dx, s.dx, M, d, c.ln_eps));
   }
   return UVX_OK;
@@ -909,14 +975,20 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       g.bias = L.bqkv;     // Qwen2: q / k / v projection biases (null otherwise)
       RC(gemm(sx, dt, g));
     }
-    if (lora) {   // peft LoRA on q_proj / k_proj (text_model_lora_config): added to the projections, before RoPE
+    if (lora) {   // peft LoRA on q_proj / k_proj (/ v_proj) (text_model_lora_config): added to the projections, before q_norm / RoPE
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const int r = lora->r, qc = Hq * dh, kc = Hkv * dh;
-      RC(lora_transpose2(sx, dt, R.q.b, cur.bqT, qc, R.k.b, cur.bkT, kc, r));
-      RC(lora_down(sx, dt, v.n, D, R.q.a, 0, cur.t, 128, Mv, D, r, 1.0f));
-      RC(lora_down(sx, dt, v.n, D, R.k.a, 0, at(cur.t, 64, dt), 128, Mv, D, r, 1.0f));
-      RC(lora_up(sx, dt, cur.t, 128, cur.bqT, 1, cur.qkv, s.QKV, Mv, qc, r, lora->scaling, 1));
-      RC(lora_up(sx, dt, at(cur.t, 64, dt), 128, cur.bkT, 1, at(cur.qkv, (size_t)qc, dt), s.QKV, Mv, kc, r, lora->scaling, 1));
+      if (R.q.a && R.k.a) {
+        RC(lora_transpose2(sx, dt, R.q.b, cur.bqT, qc, R.k.b, cur.bkT, kc, r));
+        RC(lora_down(sx, dt, v.n, D, R.q.a, 0, cur.t, 128, Mv, D, r, 1.0f));
+        RC(lora_down(sx, dt, v.n, D, R.k.a, 0, at(cur.t, 64, dt), 128, Mv, D, r, 1.0f));
+        RC(lora_up(sx, dt, cur.t, 128, cur.bqT, 1, cur.qkv, s.QKV, Mv, qc, r, lora->scaling, 1));
+        RC(lora_up(sx, dt, at(cur.t, 64, dt), 128, cur.bkT, 1, at(cur.qkv, (size_t)qc, dt), s.QKV, Mv, kc, r, lora->scaling, 1));
+      } else {
+        if (R.q.a) RC(lora_apply(sx, dt, v.n, D, R.q, cur.bqT, cur.t, cur.qkv, s.QKV, Mv, D, qc, r, lora->scaling));
+        if (R.k.a) RC(lora_apply(sx, dt, v.n, D, R.k, cur.bkT, at(cur.t, 64, dt), at(cur.qkv, (size_t)qc, dt), s.QKV, Mv, D, kc, r, lora->scaling));
+      }
+      if (R.v.a) RC(lora_apply(sx, dt, v.n, D, R.v, cur.bvT, cur.t2, at(cur.qkv, (size_t)(qc + kc), dt), s.QKV, Mv, D, kc, r, lora->scaling));
     }
     // (Gemma-3: the sliding-window layers rotate with their own table)
     const float* rope = g3 && w->layer_local && w->layer_local[l] ? w->rope_cos_sin_local : w->rope_cos_sin;
@@ -948,6 +1020,8 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       // Gemma3DecoderLayer: x_mid = x_in + post_attention_norm(o_proj(o));  x_out = x_mid + post_feedforward_norm(mlp(pre_feedforward_norm(x_mid)))
       // (the branch outputs before their post norms stay in the stash for the backward: o_pre, m_pre)
       RC(gemm(sx, dt, lin(cur.o, L.wo, cur.o_pre, Mv, D, s.OD)));
+      if (lora && lora->layers[l].o.a)      // o_proj adapter: joins the branch before its post norm
+        RC(lora_apply(sx, dt, cur.o, s.OD, lora->layers[l].o, cur.boT, at(cur.t2, 64, dt), cur.o_pre, D, Mv, s.OD, D, lora->r, lora->scaling));
       RC(rmsnorm_fwd(sx, dt, cur.o_pre, L.ln1_post, cur.x_mid, nullptr, Mv, D, c.rms_eps, fl, nullptr, cur.x_in));
       RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, v.n, nullptr, Mv, D, c.rms_eps, fl));
       RC(gemm(sx, dt, lin(v.n, L.wgu, cur.gu, Mv, 2 * c.llm_inter, D)));
@@ -975,6 +1049,8 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       g.residual = compact ? g_x : cur.x_in; g.ldr = D; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
+    if (lora && lora->layers[l].o.a)        // o_proj adapter (never on the compact path: top is false under LoRA)
+      RC(lora_apply(sx, dt, cur.o, s.OD, lora->layers[l].o, cur.boT, at(cur.t2, 64, dt), cur.x_mid, D, Mv, s.OD, D, lora->r, lora->scaling));
     if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, probe_skip(256) && save_for_bwd ? v.d_n : v.n, nullptr, Mv, D, c.rms_eps, fl, mdev));
     {  // gate|up projection; wgu rows are packed as alternating 16-row gate / up blocks (weights.py)
       GemmDesc g = lin(v.n, L.wgu, cur.gu, Mv, 2 * c.llm_inter, D);
@@ -1240,6 +1316,13 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       RC(rmsnorm_bwd(sx, dt, v.dx, cur.o_pre, L.ln1_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
       RC(gemm(sx, dt, lin_dgrad(v.d_n, layer_t(l).wo_t, L.wo, v.d_o, Mv, s.OD, D)));
     } else if (!d_o_ready) RC(gemm(sx, dt, lin_dgrad(v.dx, layer_t(l).wo_t, L.wo, v.d_o, Mv, s.OD, D)));
+    const long long lwg_floats = lora_wgrad_scratch_floats(s.M, c.llm_d > s.OD ? c.llm_d : s.OD, 64);
+    if (lora && lora->layers[l].o.a) {   // o_proj adapter: its gradients from d (o_proj output) - Gemma-3: behind the post norm -, and d o += u . A_o
+      const void* d_y = g3 ? v.d_n : v.dx;
+      RC(lora_apply_bwd(sx, dt, cur.o, s.OD, d_y, D, cur.boT, at(cur.t2, 64, dt), at(v.lu2, 64, dt), lgrads->layers[l].o, Mv, s.OD, D, lora->r, lora->scaling,
+                        v.lwg, lwg_floats));
+      RC(lora_up(sx, dt, at(v.lu2, 64, dt), 128, lora->layers[l].o.a, 1, v.d_o, s.OD, Mv, s.OD, lora->r, 1.0f, 1));
+    }
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, cur.qkv, v.qT, Bv, T, s.Tp, Hq, dh, s.QKV));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, at(cur.qkv, (size_t)Hq * dh, dt), v.kT, Bv, T, s.Tp, Hkv, dh, s.QKV));
     if (attention_needs_transposed_copies(dt)) RC(heads_transpose(sx, dt, v.d_o, v.doT, Bv, T, s.Tp, Hq, dh, s.OD));
@@ -1263,21 +1346,27 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     if (!rope_fused) RC(rope_inplace(sx, dt, v.d_qkv, rope, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
     if (c.llm_qk_norm) RC(qk_norm_bwd(sx, dt, v.d_qkv, cur.qk_raw, L.q_norm, L.k_norm, Mv, Hq, Hkv, dh, s.QKV, c.rms_eps, g3 ? 1 : 0));
     RC(gemm(sx, dt, lin_dgrad(v.d_qkv, layer_t(l).wqkv_t, L.wqkv, v.d_n, Mv, D, s.QKV)));
-    if (lora) {   // LoRA gradients of q_proj / k_proj and their contribution to d n1 (rank-r products, lora.hip)
+    if (lora) {   // LoRA gradients of q_proj / k_proj (/ v_proj) and their contribution to d n1 (rank-r products, lora.hip)
       const uvx_enc_lora_layer_t& R = lora->layers[l];
       const uvx_enc_lora_layer_grads_t& G = lgrads->layers[l];
       const int r = lora->r, qc = Hq * dh, kc = Hkv * dh;
       void* dk = at(v.d_qkv, (size_t)qc, dt);
-      RC(lora_down(sx, dt, v.d_qkv, s.QKV, cur.bqT, 0, v.lu, 128, Mv, qc, r, lora->scaling));
-      RC(lora_down(sx, dt, dk, s.QKV, cur.bkT, 0, at(v.lu, 64, dt), 128, Mv, kc, r, lora->scaling));
-      RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, v.n, nullptr, Mv, D, c.rms_eps, fl));        // n1 recomputed
-      {
+      void* dv = at(v.d_qkv, (size_t)(qc + kc), dt);
+      if (R.q.a || R.k.a || R.v.a) RC(rmsnorm_fwd(sx, dt, cur.x_in, L.ln1, v.n, nullptr, Mv, D, c.rms_eps, fl));        // n1 recomputed
+      if (R.q.a && R.k.a) {
+        RC(lora_down(sx, dt, v.d_qkv, s.QKV, cur.bqT, 0, v.lu, 128, Mv, qc, r, lora->scaling));
+        RC(lora_down(sx, dt, dk, s.QKV, cur.bkT, 0, at(v.lu, 64, dt), 128, Mv, kc, r, lora->scaling));
         const LoraWgradItem items[4] = {{v.n, D, v.lu, 128, G.q.a, D, 0, 1.0f}, {v.n, D, at(v.lu, 64, dt), 128, G.k.a, D, 0, 1.0f},
                                         {v.d_qkv, s.QKV, cur.t, 128, G.q.b, qc, 1, lora->scaling}, {dk, s.QKV, at(cur.t, 64, dt), 128, G.k.b, kc, 1, lora->scaling}};
-        RC(lora_wgrad_batch(sx, dt, items, 4, Mv, r, v.lwg, lora_wgrad_scratch_floats(s.M, c.llm_d > s.OD ? c.llm_d : s.OD, 64)));
+        RC(lora_wgrad_batch(sx, dt, items, 4, Mv, r, v.lwg, lwg_floats));
+      } else {
+        if (R.q.a) RC(lora_apply_bwd(sx, dt, v.n, D, v.d_qkv, s.QKV, cur.bqT, cur.t, v.lu, G.q, Mv, D, qc, r, lora->scaling, v.lwg, lwg_floats));
+        if (R.k.a) RC(lora_apply_bwd(sx, dt, v.n, D, dk, s.QKV, cur.bkT, at(cur.t, 64, dt), at(v.lu, 64, dt), G.k, Mv, D, kc, r, lora->scaling, v.lwg, lwg_floats));
       }
-      RC(lora_up(sx, dt, v.lu, 128, R.q.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
-      RC(lora_up(sx, dt, at(v.lu, 64, dt), 128, R.k.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
+      if (R.v.a) RC(lora_apply_bwd(sx, dt, v.n, D, dv, s.QKV, cur.bvT, cur.t2, v.lu2, G.v, Mv, D, kc, r, lora->scaling, v.lwg, lwg_floats));
+      if (R.q.a) RC(lora_up(sx, dt, v.lu, 128, R.q.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
+      if (R.k.a) RC(lora_up(sx, dt, at(v.lu, 64, dt), 128, R.k.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
+      if (R.v.a) RC(lora_up(sx, dt, v.lu2, 128, R.v.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
     }
     return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_in, L.ln1, resid, dx_out, nullptr, Mv, D, c.rms_eps, fl);
   };
@@ -1348,14 +1437,17 @@ extern "C" int32_t uvx_llm_bwd_train(void* stream, const uvx_config_t* cfg, cons
 extern "C" int32_t uvx_llm_fwd_lora(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const uvx_encoder_lora_t* lora,
                                     const void* inputs_embeds, const int64_t* attention_mask, const int64_t* labels, int32_t B,
                                     int32_t T, void* logits, float* loss, int32_t save_for_bwd, void* workspace, size_t ws_bytes) {
-  UVX_CHECK(lora && lora->layers && lora->r > 0 && lora->r <= 64, UVX_ERR_INVALID, "llm_fwd_lora: bad LoRA descriptor");
+  RC(check_cfg(cfg));
+  RC(lora_check(lora, cfg->llm_layers, nullptr, "llm_fwd_lora"));
   return llm_forward(stream, cfg, w, inputs_embeds, attention_mask, labels, B, T, logits, loss, save_for_bwd, workspace, ws_bytes,
                      nullptr, 0, nullptr, lora);
 }
 extern "C" int32_t uvx_llm_bwd_lora(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const uvx_encoder_lora_t* lora,
                                     const int64_t* labels, int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds,
                                     const uvx_encoder_lora_grads_t* grads, void* workspace, size_t ws_bytes) {
-  UVX_CHECK(lora && lora->layers && grads && grads->layers, UVX_ERR_INVALID, "llm_bwd_lora: bad LoRA descriptor");
+  RC(check_cfg(cfg));
+  UVX_CHECK(grads && grads->layers, UVX_ERR_INVALID, "llm_bwd_lora: bad LoRA descriptor");
+  RC(lora_check(lora, cfg->llm_layers, grads, "llm_bwd_lora"));
   return llm_backward(stream, cfg, w, labels, B, T, grad_scale, d_inputs_embeds, workspace, ws_bytes, false, lora, grads);
 }
 

@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .config import PROJECTOR_ACTS, LossConfig, LossFunction, UltravoxConfig
-from .weights import (LORA_TARGETS, init_lora_state_dict, llm_lora_key, lora_key, pack_encoder, pack_llm, pack_wav2vec2,
+from .weights import (LORA_FIELD, LORA_TARGETS, init_lora_state_dict, lora_targets, llm_lora_key, lora_key, pack_encoder, pack_llm, pack_wav2vec2,
                       unpack_encoder, unpack_llm, check_encoder_exportable, encoder_param_names, llm_param_names,
                       random_state_dict)
 
@@ -215,10 +215,11 @@ class UltravoxModel:
         self.text_lora_r = int((getattr(cfg, "text_model_lora_config", None) or {}).get("r", 0) or 0)   # LLM LoRA rank (0: frozen LLM)
         if self.lora_r > 0 or self.text_lora_r > 0:
             init = init_lora_state_dict(cfg, seed=0, dtype=dt)
-            todo = [(lora_key, a.encoder_layers)] * (self.lora_r > 0) + [(llm_lora_key, t.num_hidden_layers)] * (self.text_lora_r > 0)
-            for keyfn, nl in todo:
+            todo = ([(lora_key, a.encoder_layers, lora_targets(cfg, "audio"))] * (self.lora_r > 0)
+                    + [(llm_lora_key, t.num_hidden_layers, lora_targets(cfg, "text"))] * (self.text_lora_r > 0))
+            for keyfn, nl, targets in todo:
                 for i in range(nl):
-                    for pj in LORA_TARGETS:
+                    for pj in targets:      # the adapted attention projections (target_modules; default q_proj + k_proj)
                         for which in "AB":
                             k = keyfn(i, pj, which)
                             parts.append(sd[k] if k in sd else init[k])
@@ -240,8 +241,9 @@ class UltravoxModel:
             nl = a.encoder_layers
             self._lora_layers = (_lib.EncLoraLayer * nl)()
             self._lora_grad_layers = (_lib.EncLoraLayer * nl)()
+            self._lora_targets = lora_targets(cfg, "audio")
             for i in range(nl):
-                for pj, fld in zip(LORA_TARGETS, ("q", "k")):
+                for pj, fld in ((pj, LORA_FIELD[pj]) for pj in self._lora_targets):      # projections not named keep NULL pointers: not adapted
                     getattr(self._lora_layers[i], fld).a = self._proj_views[lora_key(i, pj, "A")].data_ptr()
                     getattr(self._lora_layers[i], fld).b = self._proj_views[lora_key(i, pj, "B")].data_ptr()
                     getattr(self._lora_grad_layers[i], fld).a = self._grad_views[lora_key(i, pj, "A")].data_ptr()
@@ -256,8 +258,9 @@ class UltravoxModel:
             nl = t.num_hidden_layers
             self._tlora_layers = (_lib.EncLoraLayer * nl)()
             self._tlora_grad_layers = (_lib.EncLoraLayer * nl)()
+            self._tlora_targets = lora_targets(cfg, "text")
             for i in range(nl):
-                for pj, fld in zip(LORA_TARGETS, ("q", "k")):
+                for pj, fld in ((pj, LORA_FIELD[pj]) for pj in self._tlora_targets):
                     getattr(self._tlora_layers[i], fld).a = self._proj_views[llm_lora_key(i, pj, "A")].data_ptr()
                     getattr(self._tlora_layers[i], fld).b = self._proj_views[llm_lora_key(i, pj, "B")].data_ptr()
                     getattr(self._tlora_grad_layers[i], fld).a = self._grad_views[llm_lora_key(i, pj, "A")].data_ptr()
@@ -464,26 +467,31 @@ class UltravoxModel:
         kept = getattr(self, "_kept_tensors", {})
         if self.lora_r > 0:
             check_encoder_exportable(self.config)      # BEFORE any weight changes: a tower that cannot be re-exported is not half-merged
+        def fold_layer(L, rows, targets, keyfn, i, sc, q_scale=1.0) -> None:
+            for pj in targets:      # q / k / v: row blocks of the packed wqkv; out_proj / o_proj: the whole wo
+                A, B = self._proj_views[keyfn(i, pj, "A")], self._proj_views[keyfn(i, pj, "B")]
+                if pj in rows:
+                    lo, hi = rows[pj]
+                    fold(L["wqkv"][lo:hi], A, B, sc * (q_scale if pj == "q_proj" else 1.0))
+                else:
+                    fold(L["wo"], A, B, sc)
+            for n in ("wqkv", "wo"):
+                if L.get(n + "_t") is not None:
+                    L[n + "_t"].copy_(L[n].t())
         if self.lora_r > 0:
             d = self.config.audio_config.d_model
             qs = (d // self.config.audio_config.encoder_attention_heads) ** -0.5      # folded into the packed q rows
-            sc = float(self._lora.scaling)
+            rows = {"q_proj": (0, d), "k_proj": (d, 2 * d), "v_proj": (2 * d, 3 * d)}
             for i, L in enumerate(self._enc["layers"]):
-                fold(L["wqkv"][:d], self._proj_views[lora_key(i, "q_proj", "A")], self._proj_views[lora_key(i, "q_proj", "B")], sc * qs)
-                fold(L["wqkv"][d:2 * d], self._proj_views[lora_key(i, "k_proj", "A")], self._proj_views[lora_key(i, "k_proj", "B")], sc)
-                if L.get("wqkv_t") is not None:
-                    L["wqkv_t"].copy_(L["wqkv"].t())
+                fold_layer(L, rows, self._lora_targets, lora_key, i, float(self._lora.scaling), qs)
             self.lora_r = 0
             self._merged_tower("audio_tower.", "audio_model_id", kept)
         if self.text_lora_r > 0:
             t = self.config.text_config
             qc, kc = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim
-            sc = float(self._tlora.scaling)
+            rows = {"q_proj": (0, qc), "k_proj": (qc, qc + kc), "v_proj": (qc + kc, qc + 2 * kc)}
             for i, L in enumerate(self._llm["layers"]):
-                fold(L["wqkv"][:qc], self._proj_views[llm_lora_key(i, "q_proj", "A")], self._proj_views[llm_lora_key(i, "q_proj", "B")], sc)
-                fold(L["wqkv"][qc:qc + kc], self._proj_views[llm_lora_key(i, "k_proj", "A")], self._proj_views[llm_lora_key(i, "k_proj", "B")], sc)
-                if L.get("wqkv_t") is not None:
-                    L["wqkv_t"].copy_(L["wqkv"].t())
+                fold_layer(L, rows, self._tlora_targets, llm_lora_key, i, float(self._tlora.scaling))
             self.text_lora_r = 0
             self._merged_tower("language_model.", "text_model_id", kept)
         self._lora_names = []        # the adapters are gone: only the projector remains trainable
@@ -998,32 +1006,36 @@ class UltravoxModel:
 
     @contextlib.contextmanager
     def _llm_adapters_folded(self):
-        """Inference under an un-merged LLM LoRA adapter: q / k rows of every layer's packed wqkv <- W + scaling * B A for the body of
-        the `with`, the saved rows restored on exit (training continues on the un-merged pair; (Hq + Hkv) * dh * D elements per layer
-        of scratch: 1.3 GB for Llama-3-8B).  No-op without adapters."""
+        """Inference under an un-merged LLM LoRA adapter: the adapted rows of every layer's packed wqkv (and wo under an o_proj adapter)
+        <- W + scaling * B A for the body of the `with`, the saved matrices restored on exit (training continues on the un-merged
+        pair; one copy of wqkv per layer of scratch: 1.6 GB for Llama-3-8B).  No-op without adapters."""
         r = self.text_lora_r
         if r == 0:
             yield
             return
         t = self.config.text_config
         qc, kc = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim
+        spans = {"q_proj": (0, qc), "k_proj": (qc, qc + kc), "v_proj": (qc + kc, qc + 2 * kc)}
+        with_o = "o_proj" in self._tlora_targets
         sc = float(self._tlora.scaling)
         saved = []
         try:
             with torch.no_grad():
                 for i, L in enumerate(self._llm["layers"]):
-                    rows = L["wqkv"][:qc + kc]
-                    saved.append(rows.clone())
-                    for lo, hi, pj in ((0, qc, "q_proj"), (qc, qc + kc, "k_proj")):
+                    saved.append((L["wqkv"].clone(), L["wo"].clone() if with_o else None))
+                    for pj in self._tlora_targets:
                         A, B = self._proj_views[llm_lora_key(i, pj, "A")], self._proj_views[llm_lora_key(i, pj, "B")]
-                        rows[lo:hi].copy_((rows[lo:hi].float() + sc * (B.float() @ A.float())).to(rows.dtype))
+                        rows = L["wo"] if pj == "o_proj" else L["wqkv"][spans[pj][0]:spans[pj][1]]
+                        rows.copy_((rows.float() + sc * (B.float() @ A.float())).to(rows.dtype))
             self.text_lora_r = 0
             yield
         finally:
             self.text_lora_r = r
             with torch.no_grad():
-                for L, rows in zip(self._llm["layers"], saved):
-                    L["wqkv"][:qc + kc].copy_(rows)
+                for L, (wqkv, wo) in zip(self._llm["layers"], saved):
+                    L["wqkv"].copy_(wqkv)
+                    if wo is not None:
+                        L["wo"].copy_(wo)
 
     def _generate(self, input_ids: torch.Tensor, audio_values: Optional[torch.Tensor] = None,
                  inputs_embeds: Optional[torch.Tensor] = None, audio_token_start_idx: Optional[torch.Tensor] = None,

@@ -194,6 +194,24 @@ def rope_table(tc, length: int, device, local: bool = False) -> torch.Tensor:
 
 
 LORA_TARGETS = ("q_proj", "k_proj")     # of the encoder's self_attn (the default target_modules that exist in Whisper)
+LORA_FIELD = {"q_proj": "q", "k_proj": "k", "v_proj": "v", "out_proj": "o", "o_proj": "o"}      # module -> field of uvx_enc_lora_layer_t
+
+
+def lora_targets(cfg: UltravoxConfig, tower: str):
+    """The adapted attention projections of `tower` ("audio" / "text") under cfg's LoRA config, () when its rank is 0
+    (config.lora_target_modules: the reference's target_modules resolved against the tower's module names)."""
+    from .config import lora_target_modules
+    lc = getattr(cfg, f"{tower}_model_lora_config", None) or {}
+    return lora_target_modules(lc, tower) if int(lc.get("r", 0) or 0) > 0 else ()
+
+
+def lora_dims(cfg: UltravoxConfig, tower: str, proj: str):
+    """(in_features, out_features) of an adapted projection."""
+    a, t = cfg.audio_config, cfg.text_config
+    if tower == "audio":
+        return a.d_model, a.d_model
+    qc, kc = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim
+    return {"q_proj": (t.hidden_size, qc), "k_proj": (t.hidden_size, kc), "v_proj": (t.hidden_size, kc), "o_proj": (qc, t.hidden_size)}[proj]
 
 
 def lora_key(layer: int, proj: str, which: str, prefix="audio_tower.") -> str:
@@ -221,14 +239,11 @@ def init_lora_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32
         out[keyfn(i, pj, "B")] = B.to(dtype)
 
     # (a config that went through merge_and_unload no longer carries the LoRA configs - ultravox_model.py:555-557 - and means r = 0)
-    ra = int((getattr(cfg, "audio_model_lora_config", None) or {}).get("r", 0) or 0)
-    for i in range(a.encoder_layers if ra else 0):
-        for pj in LORA_TARGETS:
-            add(lora_key, i, pj, ra, a.d_model, a.d_model)
-    rt = int((getattr(cfg, "text_model_lora_config", None) or {}).get("r", 0) or 0)
-    for i in range(t.num_hidden_layers if rt else 0):
-        add(llm_lora_key, i, "q_proj", rt, t.hidden_size, t.num_attention_heads * t.head_dim)
-        add(llm_lora_key, i, "k_proj", rt, t.hidden_size, t.num_key_value_heads * t.head_dim)
+    for tower, keyfn, nl in (("audio", lora_key, a.encoder_layers), ("text", llm_lora_key, t.num_hidden_layers)):
+        r = int((getattr(cfg, f"{tower}_model_lora_config", None) or {}).get("r", 0) or 0)
+        for i in range(nl if r else 0):
+            for pj in lora_targets(cfg, tower):      # (q_proj, k_proj) unless target_modules says otherwise
+                add(keyfn, i, pj, r, *lora_dims(cfg, tower, pj))
     return out
 
 
