@@ -75,7 +75,8 @@ typedef struct {
   int32_t llm_wt_stream;
   /* UVX_LLM_GEMMA3 (the reference's v0.6_config_gemma3_27b.yaml: the text stack of google/gemma-3-27b-it, [3P] modeling_gemma3.py):
    * llm_attn_scale = query_pre_attn_scalar ** -0.5 (0 = head_dim ** -0.5, every other family); llm_window = sliding_window of the
-   * layers flagged in uvx_llm_weights_t.layer_local (their own rotary table).  Sequences of at most llm_window positions run those layers
+   * layers flagged in uvx_llm_weights_t.layer_local (Gemma-3: with their own rotary table; any other flavour - [3P] MistralConfig.sliding_window,
+   * every layer flagged - with the one table).  Sequences of at most llm_window positions run those layers
    * as plain causal attention (incl. the fused backward); longer ones run the WINDOWED forms of the same kernels (a query sees the keys
    * in (q - window, q]: forward, dQ + dK/dV pair, chunked prefill), and the decode steps clamp the first visible cache slot. */
   float llm_attn_scale;
@@ -163,8 +164,9 @@ typedef struct {
   const void* lm_head_t;         /* [D, vocab] or NULL */
   const float* rope_cos_sin;     /* [rope_len, head_dim/2, 2] f32 (cos, sin), built by the host */
   int32_t rope_len;
-  /* Gemma-3 (else NULL): the rotary table of the sliding-window layers (rope_local_base_freq, same shape) and a HOST array
-   * [llm_layers] of flags: 1 = sliding-window ("local") layer */
+  /* Gemma-3 (else NULL): the rotary table of the sliding-window layers (rope_local_base_freq, same shape).  layer_local: a HOST array
+   * [llm_layers] of flags, 1 = sliding-window ("local") layer of llm_window positions (Gemma-3's local layers; every layer of a Mistral
+   * config with a sliding_window); NULL = no windowed layer */
   const float* rope_cos_sin_local;
   const int32_t* layer_local;
 } uvx_llm_weights_t;

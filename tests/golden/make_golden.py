@@ -659,6 +659,8 @@ def config_cases():
                                              "num_attention_heads": 2, "intermediate_size": 128}),
         "partial_gemma_dict": dict(text_config={"model_type": "gemma", "vocab_size": 512}),
         "llm_only": dict(text_config=llama_small, llm_only_training=True),
+        # ultravox_config.py:68 "any of LlamaConfig or MistralConfig": the family defaults a partial Mistral dict resolves to
+        "partial_mistral_dict": dict(text_config={"model_type": "mistral", "hidden_size": 256, "num_attention_heads": 4, "vocab_size": 512}),
     }
     out = {}
     for name, kw in cases.items():

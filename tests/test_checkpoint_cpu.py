@@ -130,12 +130,17 @@ def test_configs_outside_the_built_arithmetic_are_refused_not_run_as_llama():
     from ultravox_amd.config import UltravoxConfig
     ok_text = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1, vocab_size=128)
     UltravoxConfig(text_config={**ok_text, "model_type": "llama", "attention_bias": False, "tie_word_embeddings": False})
-    for bad in ({"model_type": "mistral"}, {"attention_bias": True}, {"mlp_bias": True}, {"sliding_window": 4096},
+    for bad in ({"model_type": "mixtral"}, {"model_type": "gemma2"}, {"attention_bias": True}, {"mlp_bias": True}, {"sliding_window": 4096},
                 {"hidden_act": "gelu_pytorch_tanh"},
                 {"model_type": "qwen2", "sliding_window": 4096, "use_sliding_window": True}, {"model_type": "qwen3", "attention_bias": True},
                 {"model_type": "qwen3", "layer_types": ["sliding_attention"]}):
         with pytest.raises(ValueError):
             UltravoxConfig(text_config={**ok_text, **bad})
+    # Mistral (ultravox_config.py:68 names MistralConfig): built - a Llama block with the sliding window on EVERY layer, or none under an explicit null
+    mi = UltravoxConfig(text_config={**ok_text, "model_type": "mistral", "sliding_window": 64}).text_config
+    assert mi.window_layers == [1] and mi.sliding_window == 64 and not mi.has_qk_norm and not mi.has_qkv_bias and mi.hidden_act == "silu"
+    assert UltravoxConfig(text_config={**ok_text, "model_type": "mistral", "sliding_window": None}).text_config.window_layers is None
+    assert UltravoxConfig(text_config={**ok_text, "model_type": "llama"}).text_config.window_layers is None
     # the Qwen families (the reference's v0.6 recipe: Qwen/Qwen3-32B): built; their configs always carry a sliding_window VALUE,
     # which is live only with use_sliding_window
     q3 = UltravoxConfig(text_config={**ok_text, "model_type": "qwen3", "head_dim": 64, "sliding_window": 4096, "use_sliding_window": False,

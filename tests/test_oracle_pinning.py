@@ -534,6 +534,53 @@ def test_qwen_backbones_match_hf_blocks(family):
     np.testing.assert_allclose(emb_or.grad[keep].numpy(), emb_hf.grad[keep].numpy(), rtol=2e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("window", [7, None])
+def test_mistral_backbone_matches_hf_blocks(window):
+    """`text_config` "can be any of LlamaConfig or MistralConfig" (ultravox_config.py:68; README.md:27 "trained versions on Llama 3, Mistral, and
+    Gemma"), reached through the same AutoModelForCausalLM call (ultravox_model.py:499-526).  [3P] check: the oracle's mistral flavour - a Llama
+    block, every layer behind the sliding-window causal mask when config.sliding_window is set (Mistral-7B-v0.1), plain causal when it is null
+    (v0.2 / v0.3 / Nemo) - == the installed HF MistralForCausalLM on the same weights with a window SHORTER than the sequence: logits, loss,
+    the gradient reaching inputs_embeds; and that the two settings differ (the window is live)."""
+    import transformers
+    kw = dict(hidden_size=96, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+              vocab_size=160, rms_norm_eps=1e-5, max_position_embeddings=512)
+    hf_cfg = transformers.MistralConfig(**kw, sliding_window=window, tie_word_embeddings=False, attn_implementation="eager")
+    cfg = UltravoxConfig(audio_config=TINY["audio_config"], hidden_size=64, text_config=hf_cfg)      # the HF config object, as the reference passes it
+    t = cfg.text_config
+    assert t.model_type == "mistral" and t.head_dim == 24 and t.rope_theta == 10000.0 and t.hidden_act == "silu"
+    assert t.window_layers == ([1, 1] if window else None) and (t.sliding_window or None) == window
+    # a config.json dict with an explicit null means "no window", not the family default of 4096
+    assert UltravoxConfig(text_config=dict(model_type="mistral", sliding_window=None, **kw)).text_config.window_layers is None
+    assert UltravoxConfig(text_config=dict(model_type="mistral", **kw)).text_config.sliding_window == 4096
+    hf = transformers.MistralForCausalLM(hf_cfg).eval()
+    sd = random_state_dict(cfg, seed=8)
+    llm_sd = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}
+    missing, unexpected = hf.load_state_dict(llm_sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    torch.manual_seed(0)
+    B, T = 2, 19
+    labels = torch.randint(0, 160, (B, T))
+    labels[:, :9] = -100
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, -4:] = 0
+    emb_hf = (torch.randn(B, T, 96) * 0.1).requires_grad_(True)
+    emb_or = emb_hf.detach().clone().requires_grad_(True)
+    out = hf(inputs_embeds=emb_hf, attention_mask=am, labels=labels)
+    out.loss.backward()
+    logits = O.llama_ref(sd, cfg, emb_or, am)
+    loss = O.causal_lm_loss_ref(logits, labels)
+    loss.backward()
+    keep = am.bool()
+    np.testing.assert_allclose(logits.detach()[keep].numpy(), out.logits.detach()[keep].numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(loss.item(), out.loss.item(), rtol=1e-5)
+    np.testing.assert_allclose(emb_or.grad[keep].numpy(), emb_hf.grad[keep].numpy(), rtol=2e-4, atol=1e-7)
+    if window:      # the same weights without the window give other logits beyond position `window`
+        plain = O.llama_ref(sd, UltravoxConfig(audio_config=TINY["audio_config"], hidden_size=64,
+                                               text_config=dict(model_type="mistral", sliding_window=None, **kw)), emb_or.detach(), am)
+        assert (plain[:, :window] - logits.detach()[:, :window]).abs().max().item() < 1e-6
+        assert (plain[0, window:] - logits.detach()[0, window:]).abs().max().item() > 1e-3
+
+
 def test_gemma3_backbone_matches_hf_blocks():
     """The reference's other v0.6 recipe trains on google/gemma-3-27b-it (ultravox/training/configs/v0.6_config_gemma3_27b.yaml).
     [3P] check: the oracle's gemma3 flavour - four Gemma norms per layer (post-norms before each residual add), q / k norms over

@@ -104,7 +104,7 @@ class AudioConfig:
 
 @dataclasses.dataclass
 class TextConfig:
-    """Field names of transformers.LlamaConfig / GemmaConfig / Qwen2Config / Qwen3Config that the LLM path reads.  model_type
+    """Field names of transformers.LlamaConfig / MistralConfig / GemmaConfig / Qwen2Config / Qwen3Config that the LLM path reads.  model_type
     "llama" (default); "gemma" (BASELINE.json config 5, the alt backbone behind AutoModelForCausalLM, ultravox_model.py:499-526):
     GemmaRMSNorm, GeGLU (hidden_act gelu_pytorch_tanh), sqrt(hidden_size) embedding scale, explicit head_dim, lm_head tied to
     embed_tokens; "qwen3" (the reference's v0.6 recipe, ultravox/training/configs/v0.6_config_qwen3_32b.yaml: text_model
@@ -158,8 +158,14 @@ class TextConfig:
                        tie_word_embeddings=True, query_pre_attn_scalar=256, sliding_window=4096, sliding_window_pattern=6,
                        rope_local_base_freq=10000.0, rope_theta=1000000.0),     # Gemma3TextConfig: 1e6 (the published
                        # google/gemma-3-27b-it config.json leaves the field out)
+        # [3P] MistralConfig defaults (Mistral-7B-v0.1; ultravox_config.py:68 names MistralConfig next to LlamaConfig, README.md:27 "Llama 3,
+        # Mistral, and Gemma"): a Llama block whose EVERY layer attends to the last sliding_window positions (MistralModel.forward:
+        # create_sliding_window_causal_mask unless config.sliding_window is None - v0.2 / v0.3 / Nemo say null and are plain causal)
+        "mistral": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+                        vocab_size=32000, rms_norm_eps=1e-6, max_position_embeddings=131072, eos_token_id=2, tie_word_embeddings=False,
+                        rope_theta=10000.0, sliding_window=4096),
     }
-    FAMILIES = ("llama", "gemma", "qwen2", "qwen3", "gemma3")
+    FAMILIES = ("llama", "gemma", "qwen2", "qwen3", "gemma3", "mistral")
 
     def __post_init__(self):
         if self.model_type == "gemma3_text":        # the text stack of a Gemma3ForConditionalGeneration checkpoint
@@ -189,6 +195,16 @@ class TextConfig:
             rs = self.rope_scaling
             if rs and rs.get("rope_type", rs.get("type", "default")) not in ("default", "linear"):
                 raise ValueError(f"gemma3 rope_scaling {rs}: default or linear (the global layers) are built")
+
+    @property
+    def window_layers(self) -> Optional[List[int]]:
+        """Per-layer flags "attends to the last sliding_window positions only", or None when no layer does: Gemma-3's
+        "sliding_attention" layers, every layer of a Mistral config whose sliding_window is set (0 / null = plain causal)."""
+        if self.model_type == "gemma3":
+            return [int(lt == "sliding_attention") for lt in self.layer_types]
+        if self.model_type == "mistral" and self.sliding_window:
+            return [1] * self.num_hidden_layers
+        return None
 
     @property
     def is_gemma(self) -> bool:        # Gemma-1: GemmaRMSNorm, GeGLU, the embedding scale applied INSIDE the model (4.51.3)
@@ -283,6 +299,17 @@ TEXT_PRESETS["google/gemma-3-27b-it"] = dict(model_type="gemma3", hidden_size=53
                                              rms_norm_eps=1e-6, rope_theta=1000000.0, rope_scaling=dict(rope_type="linear", factor=8.0),
                                              rope_local_base_freq=10000.0, query_pre_attn_scalar=168, sliding_window=1024,
                                              sliding_window_pattern=6, max_position_embeddings=131072, eos_token_id=1)
+# Mistral backbones (ultravox_config.py:68 names MistralConfig; README.md:27; the published config.json files): v0.1 carries the 4096-position
+# sliding window on every layer, v0.3 and Nemo say "sliding_window": null (0 here: plain causal attention)
+TEXT_PRESETS["mistralai/Mistral-7B-Instruct-v0.1"] = dict(model_type="mistral", hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                                                          num_attention_heads=32, num_key_value_heads=8, vocab_size=32000, rms_norm_eps=1e-5,
+                                                          rope_theta=10000.0, max_position_embeddings=32768, sliding_window=4096, eos_token_id=2)
+TEXT_PRESETS["mistralai/Mistral-7B-Instruct-v0.3"] = dict(TEXT_PRESETS["mistralai/Mistral-7B-Instruct-v0.1"], vocab_size=32768,
+                                                          rope_theta=1000000.0, sliding_window=0)
+TEXT_PRESETS["mistralai/Mistral-Nemo-Instruct-2407"] = dict(model_type="mistral", hidden_size=5120, intermediate_size=14336, num_hidden_layers=40,
+                                                            num_attention_heads=32, num_key_value_heads=8, head_dim=128, vocab_size=131072,
+                                                            rms_norm_eps=1e-5, rope_theta=1000000.0, max_position_embeddings=1024000,
+                                                            sliding_window=0, eos_token_id=2)
 TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat"] = TEXT_PRESETS["TinyLlama/TinyLlama-1.1B-Chat-v1.0"]
 TEXT_PRESETS["meta-llama/Meta-Llama-3-8B"] = TEXT_PRESETS["meta-llama/Meta-Llama-3-8B-Instruct"]
 
@@ -320,6 +347,9 @@ def _mk(cls, value, presets, model_id):
                 kw["rope_theta"] = float(rp["rope_theta"])
             if rp.get("rope_type", rp.get("type", "default")) != "default" and get("rope_scaling") is None:
                 kw["rope_scaling"] = {k: v for k, v in rp.items() if k != "rope_theta"}
+        if get("model_type") == "mistral" and get("sliding_window") is None and (
+                ("sliding_window" in value) if isinstance(value, dict) else hasattr(value, "sliding_window")):
+            kw["sliding_window"] = 0      # "sliding_window": null (Mistral v0.2 / v0.3 / Nemo): plain causal attention, NOT the family default
         rs = kw.get("rope_scaling")      # (5.x config objects alias rope_scaling to the rope_parameters dict)
         if isinstance(rs, dict) and isinstance(rs.get("full_attention"), dict):
             rs = rs["full_attention"]
@@ -352,6 +382,8 @@ def _check_supported(cls, get) -> None:
             for flag in ("attn_logit_softcapping", "final_logit_softcapping", "use_bidirectional_attention"):
                 if get(flag):
                     raise ValueError(f"text_config.{flag} is not built")
+            return
+        if mt == "mistral":      # the window is the family's own: every layer (TextConfig.window_layers)
             return
         live_window = get("sliding_window") and (mt not in ("qwen2", "qwen3") or get("use_sliding_window"))
         if live_window or any(lt != "full_attention" for lt in (get("layer_types") or ())):

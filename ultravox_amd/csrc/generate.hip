@@ -606,7 +606,7 @@ extern "C" int32_t uvx_llm_prefill(void* stream, const uvx_config_t* cfg, const 
     ad.vt = s.vt; ad.o = s.o; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = s.kvl;
     ad.B = B; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.scale = attn_scale_of(c);
-    ad.window = c.llm_flavor == UVX_LLM_GEMMA3 && c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
+    ad.window = c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
     RC(attention_fwd(st, dt, ad));
     RC(attn_out(st, c, L, s, M, s.o, s.OD, s.x, s.x2, &n2_ready));
     RC(mlp_block(st, c, L, s, M, s.x2, s.x, n2_ready, l + 1 < c.llm_layers ? w->layers[l + 1].ln1 : nullptr, &n1_ready));
@@ -693,7 +693,7 @@ static int32_t prefill_chunk_impl(void* stream, const uvx_config_t* cfg, const u
     ad.vt = k.fvt; ad.o = k.fo; ad.lse = nullptr; ad.kv_start = kv_start; ad.kv_len = nullptr;
     ad.B = B; ad.T = Tf; ad.Tp = k.Tfp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.q_begin = cur_len; ad.scale = attn_scale_of(c);
-    ad.window = c.llm_flavor == UVX_LLM_GEMMA3 && c.llm_window > 0 && Tf > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
+    ad.window = c.llm_window > 0 && Tf > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
     RC(attention_fwd(st, dt, ad));
     for (int b = 0; b < B; ++b)
       UVX_HIP(hipMemcpyAsync(at(s.o, (size_t)b * Tn * s.OD, dt), at(k.fo, ((size_t)b * Tf + cur_len) * s.OD, dt), (size_t)Tn * s.OD * es,
@@ -766,7 +766,7 @@ extern "C" int32_t uvx_llm_decode(void* stream, const uvx_config_t* cfg, const u
     }
     // Gemma-3 sliding-window layer: the new token attends to the last `window` positions = cache slots (the slots of a sequence are
     // contiguous, so the window is a clamp of the first visible slot)
-    const int lo = (c.llm_flavor == UVX_LLM_GEMMA3 && c.llm_window > 0 && w->layer_local && w->layer_local[l]) ? max(0, cur_len + 1 - c.llm_window) : 0;
+    const int lo = (c.llm_window > 0 && w->layer_local && w->layer_local[l]) ? max(0, cur_len + 1 - c.llm_window) : 0;
     char* ck = at(kv_cache, l * layer_stride, dt);
     char* cv = at(kv_cache, l * layer_stride + (size_t)B * Tmax * KVD, dt);
     const long long n = (long long)B * (KVD / 8);

@@ -1004,7 +1004,7 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
     ad.scale = attn_scale;
     // Gemma-3 sliding-window layer over a sequence LONGER than the window (up to the window it is plain causal attention)
-    ad.window = g3 && c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
+    ad.window = c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;      // (any flavour: Gemma-3's local layers, every Mistral layer)
     return probe_skip(2) ? UVX_OK : attention_fwd(sx, dt, ad);
   };
   // second half: o_proj + residual, norm, gate|up (+ SwiGLU), down + residual.  compact (last layer of the training pair,
@@ -1334,7 +1334,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     ad.B = Bv; ad.T = T; ad.Tp = s.Tp; ad.Hq = Hq; ad.Hkv = Hkv; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = s.QKV; ad.ldo = s.OD; ad.causal = 1; ad.block = 0;
     ad.scale = attn_scale;
-    ad.window = g3 && c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;
+    ad.window = c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l] ? c.llm_window : 0;      // (any flavour: Gemma-3's local layers, every Mistral layer)
     bd.dout = v.d_o; bd.qt = v.qT; bd.kt = v.kT; bd.dot = v.doT; bd.delta = v.delta; bd.dkv_part = v.dkv_part;
     bd.dq = v.d_qkv; bd.dk = at(v.d_qkv, (size_t)Hq * dh, dt); bd.dv = at(v.d_qkv, (size_t)(Hq + Hkv) * dh, dt);
     bd.lddq = bd.lddk = bd.lddv = s.QKV;

@@ -286,6 +286,8 @@ class UltravoxModel:
         if t.is_gemma3:      # [3P] Gemma3Attention: scaling = query_pre_attn_scalar ** -0.5; sliding-window layers (window checked per call)
             c.llm_attn_scale = float(t.query_pre_attn_scalar) ** -0.5
             c.llm_window = int(t.sliding_window or 0)
+        elif t.window_layers:      # Mistral with a live sliding_window: every layer windowed, head_dim ** -0.5 scale, one rotary table
+            c.llm_window = int(t.sliding_window)
         c.llm_act = {"silu": 0, "gelu_pytorch_tanh": 1, "gelu": 2}[t.hidden_act]      # UVX_ACT_* : [3P] ACT2FN[hidden_act]
         c.llm_qk_norm = int(t.has_qk_norm)         # Qwen3: per-head q_norm / k_norm before RoPE
         c.llm_wt_stream = int(self.stream_weight_transposes)
@@ -343,9 +345,11 @@ class UltravoxModel:
         lw.lm_head_t = 0 if m["lm_head_t"] is None else m["lm_head_t"].data_ptr()
         lw.layers = self._llm_layers
         lw.rope_cos_sin, lw.rope_len = m["rope"].data_ptr(), m["rope_len"]
-        if m.get("rope_local") is not None:        # Gemma-3: the sliding-window layers' table and the per-layer flags (host array)
+        if m.get("layer_local") is not None:       # the per-layer sliding-window flags (host array): Gemma-3's local layers, every Mistral layer
             self._layer_local = (C.c_int32 * t.num_hidden_layers)(*m["layer_local"])
-            lw.rope_cos_sin_local, lw.layer_local = m["rope_local"].data_ptr(), self._layer_local
+            lw.layer_local = self._layer_local
+        if m.get("rope_local") is not None:        # Gemma-3: the sliding-window layers' own rotary table
+            lw.rope_cos_sin_local = m["rope_local"].data_ptr()
         self._lw = lw
 
     def projector_state_dict(self) -> Dict[str, torch.Tensor]:

@@ -403,9 +403,10 @@ def pack_llm(sd, cfg: UltravoxConfig, dtype, device, with_transposes: bool = Tru
         })
     out["rope_len"] = rope_len or min(t.max_position_embeddings, 8192)
     out["rope"] = rope_table(t, out["rope_len"], device)
-    if getattr(t, "is_gemma3", False):          # second table + per-layer flags for the sliding-window layers
+    if getattr(t, "is_gemma3", False):          # second rotary table for the sliding-window layers
         out["rope_local"] = rope_table(t, out["rope_len"], device, local=True)
-        out["layer_local"] = [int(lt == "sliding_attention") for lt in t.layer_types]
+    if getattr(t, "window_layers", None):       # per-layer flags: Gemma-3's local layers, every layer of a windowed Mistral
+        out["layer_local"] = list(t.window_layers)
     return out
 
 
