@@ -252,6 +252,17 @@ int32_t uvx_wav2vec2_frames(const uvx_w2v_config_t* cfg, int32_t L); /* [3P] _ge
 size_t uvx_wav2vec2_ws_bytes(const uvx_w2v_config_t* cfg, int32_t B, int32_t L);
 int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_weights_t* w, const void* input_values,
                          int32_t values_is_f32, int32_t B, int32_t L, void* out, void* workspace, size_t ws_bytes);
+/* ABI 17: the AutoModel tower under apply_lora (ultravox_model.py:460-467: `apply_lora(audio_tower, audio_model_lora_config)` wraps whatever tower was
+ * loaded; :690-709) - adapters on the attention projections of every encoder layer (uvx_enc_lora_layer_t: q_proj / k_proj / v_proj / out_proj of
+ * [3P] Wav2Vec2Attention), both encoder families (post-LN and do_stable_layer_norm).  uvx_wav2vec2_fwd_train = uvx_wav2vec2_fwd + the adapters'
+ * terms + a per-layer stash in a workspace of uvx_wav2vec2_train_ws_bytes; uvx_wav2vec2_bwd walks it: d_out [B, frames, d] (the gradient
+ * uvx_projector_bwd hands over) -> f32 gradients of every lora_A / lora_B.  The feature encoder, feature projection and positional conv carry no
+ * adapter and receive no gradient (the walk stops at layer 0's input); uvx_enc_layer_t.*_t (transposed copies) are required. */
+size_t uvx_wav2vec2_train_ws_bytes(const uvx_w2v_config_t* cfg, int32_t B, int32_t L);
+int32_t uvx_wav2vec2_fwd_train(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_weights_t* w, const uvx_encoder_lora_t* lora,
+                               const void* input_values, int32_t values_is_f32, int32_t B, int32_t L, void* out, void* workspace, size_t ws_bytes);
+int32_t uvx_wav2vec2_bwd(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_weights_t* w, const uvx_encoder_lora_t* lora, const void* d_out,
+                         int32_t B, int32_t L, const uvx_encoder_lora_grads_t* grads, void* workspace, size_t ws_bytes);
 
 /* embed_tokens + the in-place audio overwrite loop (ultravox_model.py:314-316, :390-394, :259-275).
  * input_ids [B, T] int64; audio_embeds [n_items, Na, D]; audio_batch_size [B] int64;

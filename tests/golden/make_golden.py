@@ -43,6 +43,8 @@ What is recorded
                     module set, trainable names, state-dict key names, forward outputs and adapter gradients.
   lora_targets_reference.npz / .json — the same with target_modules beyond the default: q / k / v / out_proj (Whisper) and q / k / v /
                     o_proj (Llama, GQA), and a v + o-only list; peft's error text for a list that hits nothing.
+  lora_w2v_reference.npz / .json — the REFERENCE apply_lora on an installed-HF Wav2Vec2Model (the AutoModel tower, both encoder families): adapted
+                    modules and names, last_hidden_state, adapter gradients.
 """
 import dataclasses
 import json
@@ -613,6 +615,52 @@ def lora_targets_cases():
     print("lora_targets_reference:", {c: (m["encoder"]["adapted"], m["llm"]["adapted"]) for c, m in meta["cases"].items()})
 
 
+def lora_w2v_cases():
+    """apply_lora on the AutoModel branch's tower (ultravox_model.py:460-467: whatever tower was loaded is wrapped): the reference's apply_lora with
+    its default target_modules and with q / k / v / out_proj on an installed-HF Wav2Vec2Model, both encoder families (post-LN; do_stable_layer_norm) -
+    which modules are adapted, under which names, last_hidden_state and the adapter gradients."""
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import random_state_dict
+    w2v_tiny = dict(model_type="wav2vec2", hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128, conv_dim=[64] * 7,
+                    num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+    text_tiny = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, vocab_size=256)
+    simp = ultravox_config.LoraConfigSimplified
+    arrays, meta = {}, {"w2v_tiny": w2v_tiny, "text_tiny": text_tiny, "seed": 19, "cases": {}}
+    for case, stable, norm, bias, targets in (("post_ln_default", False, "group", False, None),
+                                              ("stable_all", True, "layer", True, ["q_proj", "k_proj", "v_proj", "out_proj"]),
+                                              ("post_ln_all", False, "group", False, ["q_proj", "k_proj", "v_proj", "out_proj"])):
+        fam = dict(feat_extract_norm=norm, conv_bias=bias, do_stable_layer_norm=stable)
+        cfg = UltravoxConfig(audio_config={**w2v_tiny, **fam}, text_config=text_tiny, hidden_size=64)
+        sd = random_state_dict(cfg, seed=19)
+        hf = Wav2Vec2Model(Wav2Vec2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128, conv_dim=[64] * 7,
+                                          num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, attn_implementation="eager", **fam)).eval()
+        missing, unexpected = hf.load_state_dict({k[len("audio_tower."):]: v for k, v in sd.items() if k.startswith("audio_tower.")}, strict=False)
+        assert not unexpected and missing == ["masked_spec_embed"]
+        lcfg = dataclasses.asdict(simp(r=4, lora_alpha=6) if targets is None else simp(r=4, lora_alpha=6, target_modules=targets))
+        wrapped = ultravox_model.apply_lora(hf, dict(lcfg))
+        g = torch.Generator().manual_seed(1)
+        for n, p in wrapped.named_parameters():
+            if "lora_B" in n:
+                p.data = 0.05 * torch.randn(p.shape, generator=g)
+        names = [n for n, p in wrapped.named_parameters() if p.requires_grad]
+        torch.manual_seed(0)
+        x = torch.randn(2, 6000) * 0.1 + 0.02
+        x = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-7)
+        y = wrapped(x).last_hidden_state
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+        (y * gy).sum().backward()
+        meta["cases"][case] = {"family": fam, "lora_config": lcfg, "trainable": names, "adapted": sorted({n.split(".lora_")[0] for n in names})}
+        arrays.update({f"{case}.x": x.numpy(), f"{case}.y": y.detach().numpy(), f"{case}.gy": gy.numpy()})
+        for n, p in wrapped.named_parameters():
+            if p.requires_grad:
+                arrays[f"{case}.w." + n], arrays[f"{case}.g." + n] = p.detach().numpy(), p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "lora_w2v_reference.npz"), **arrays)
+    with open(os.path.join(HERE, "lora_w2v_reference.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("lora_w2v_reference:", {c: m["adapted"][:2] for c, m in meta["cases"].items()})
+
+
 CONFIG_SCALARS = ["ignore_index", "audio_model_id", "text_model_id", "audio_token_index", "hidden_size", "stack_factor", "norm_init",
                   "projector_act", "projector_ln_mid", "llm_only_training", "audio_latency_block_size", "vocab_size", "initializer_range"]
 CONFIG_TEXT = ["model_type", "hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "intermediate_size",
@@ -959,6 +1007,7 @@ if __name__ == "__main__":
     config_cases()
     lora_cases()
     lora_targets_cases()
+    lora_w2v_cases()
     processor_cases()
     projector_cases()
     projector_act_cases()

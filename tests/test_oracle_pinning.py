@@ -666,6 +666,39 @@ def test_wav2vec2_tower_matches_hf_model(norm, bias, stable):
     assert hf._get_feat_extract_output_lengths(480000) == a.feat_extract_output_length(480000) == 1499
 
 
+@pytest.mark.parametrize("case", ["post_ln_default", "stable_all", "post_ln_all"])
+def test_wav2vec2_tower_under_apply_lora_matches_the_reference(golden_dir, case):
+    """`apply_lora(audio_tower, audio_model_lora_config)` wraps whatever AutoModel tower was loaded (ultravox_model.py:460-467, 690-709).  Fixture
+    lora_w2v_reference.npz: the reference's apply_lora (tests/peft_stub.py) on an installed-HF Wav2Vec2Model - post-LN family with the default
+    target_modules, both families with q / k / v / out_proj: adapted modules, key names, last_hidden_state, adapter gradients."""
+    import json
+    from ultravox_amd.weights import init_lora_state_dict, lora_targets, w2v_lora_key
+    z = np.load(os.path.join(golden_dir, "lora_w2v_reference.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "lora_w2v_reference.json")))
+    cm = meta["cases"][case]
+    cfg = UltravoxConfig(audio_config={**meta["w2v_tiny"], **cm["family"]}, text_config=meta["text_tiny"], hidden_size=64,
+                         audio_model_lora_config=cm["lora_config"])
+    assert lora_targets(cfg, "audio") == (("q_proj", "k_proj") if case == "post_ln_default" else ("q_proj", "k_proj", "v_proj", "out_proj"))
+    names = {"audio_tower." + n for n in cm["trainable"]}
+    init = init_lora_state_dict(cfg)
+    assert set(init) == names and w2v_lora_key(1, "k_proj", "B") in names
+    assert all(tuple(v.shape) == z[f"{case}.w." + k[len("audio_tower."):]].shape for k, v in init.items())
+    sd = random_state_dict(cfg, seed=meta["seed"])
+    for k in z.files:
+        if k.startswith(case + ".w."):
+            sd["audio_tower." + k[len(case) + 3:]] = torch.from_numpy(z[k]).clone().requires_grad_(True)
+    lc = cm["lora_config"]
+    y = O.wav2vec2_encoder_ref(sd, cfg, torch.from_numpy(z[f"{case}.x"]), lora={"scaling": lc["lora_alpha"] / lc["r"]})
+    np.testing.assert_allclose(y.detach().numpy(), z[f"{case}.y"], rtol=1e-4, atol=2e-5)
+    (y * torch.from_numpy(z[f"{case}.gy"])).sum().backward()
+    for n in cm["trainable"]:
+        np.testing.assert_allclose(sd["audio_tower." + n].grad.numpy(), z[f"{case}.g." + n], rtol=3e-4, atol=2e-5, err_msg=n)
+    # without the adapters the tower gives another output (lora_B is non-zero in the fixture)
+    with torch.no_grad():
+        plain = O.wav2vec2_encoder_ref(sd, cfg, torch.from_numpy(z[f"{case}.x"]))
+    assert (plain - y.detach()).abs().max().item() > 1e-3
+
+
 def test_wav2vec2_feature_extractor_contract_matches_hf():
     from transformers import Wav2Vec2FeatureExtractor as HF
     from ultravox_amd.frontend import Wav2Vec2FeatureExtractor

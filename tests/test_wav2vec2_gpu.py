@@ -193,3 +193,76 @@ def test_wav2vec2_large_tower_bf16_distance_is_calibrated_over_clips():
     assert max(eh) < 2.2e-2, eh                          # the C5 full-depth bar on the tower output
     assert sum(eh) / sum(et) <= 1.08, (eh, et)
     assert max(ratios) <= 1.3, ratios
+
+
+@pytest.mark.parametrize("stable,targets", [(False, None), (True, None), (False, ["q_proj", "k_proj", "v_proj", "out_proj"]),
+                                            (True, ["v_proj", "out_proj"])], ids=["post_ln-qk", "stable-qk", "post_ln-qkvo", "stable-vo"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wav2vec2_tower_under_lora_train_step_matches_oracle(dtype, stable, targets):
+    """apply_lora wraps whatever AutoModel tower was loaded (ultravox_model.py:460-467, 690-709): the wav2vec2 tower with adapters on its attention
+    projections - uvx_wav2vec2_fwd_train / uvx_wav2vec2_bwd (ABI 17), both encoder families (post-LN; do_stable_layer_norm), the reference's default
+    target_modules and lists beyond it.  One training step: logits, loss, the projector's and every adapter matrix's gradient against the oracle's
+    autograd (the oracle's adapted tower is pinned to the reference's apply_lora on HF Wav2Vec2Model: tests/golden/lora_w2v_reference.npz)."""
+    from oracle.reference_cpu import OracleModel, synthetic_batch, wav2vec2_normalize_ref
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict, w2v_lora_key
+    fam = {"feat_extract_norm": "layer", "conv_bias": True, "do_stable_layer_norm": True} if stable else {}
+    lc = {"r": 4, "lora_alpha": 8, **({"target_modules": targets} if targets else {})}
+    cfg = _cfg(audio={**W2V_SMALL, **fam}, audio_model_lora_config=lc)
+    sd = {k: v.to(dtype) for k, v in random_state_dict(cfg, seed=16).items()}
+    sd.update(init_lora_state_dict(cfg, seed=16, dtype=dtype, random_b=True))
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    n_adapted = len(targets) if targets else 2
+    assert len(oracle.trainable) == 4 + 2 * n_adapted * 2
+    b = synthetic_batch(cfg, 2, 2.0, n_text=24, audio_start=5, n_supervised=8)
+    b["audio_values"] = wav2vec2_normalize_ref(b.pop("pcm")).to(dtype)
+    ref, grads, _ = oracle.train_step({**b, "audio_values": b["audio_values"].float()})
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    out = model.forward(**gb)
+    model.train()
+    loss = model.forward_backward(**gb)
+    mine = model.projector_grads()
+    f32 = dtype == torch.float32
+    assert rel_l2(out.logits, ref["logits"]) < (1e-4 if f32 else 3e-2)
+    assert abs(loss.item() - ref["loss"].item()) < (1e-4 if f32 else 2e-2) * abs(ref["loss"].item())
+    assert set(mine) == set(grads) and w2v_lora_key(1, (targets or ["q_proj"])[0], "A") in mine
+    for k, g in grads.items():
+        assert g.abs().max().item() > 0, k
+        assert rel_l2(mine[k], g) < (2e-3 if f32 else 8e-2), (k, rel_l2(mine[k], g))
+
+
+def test_wav2vec2_lora_zero_b_is_the_frozen_tower_and_the_trainer_saves_peft_names(tmp_path):
+    """peft initialises lora_B to zero: the adapted tower reproduces the frozen one bit for bit; an optimizer step moves the adapters; the diff state dict
+    carries them under peft's names for the wrapped Wav2Vec2Model; merge_and_unload refuses (no re-export of a merged wav2vec2 tower) without touching
+    the weights."""
+    from oracle.reference_cpu import synthetic_batch, wav2vec2_normalize_ref
+    from ultravox_amd import checkpoint
+    from ultravox_amd.model import UltravoxModel, UltravoxTrainer
+    from ultravox_amd.weights import random_state_dict
+    dtype = torch.bfloat16
+    cfg0, cfg1 = _cfg(), _cfg(audio_model_lora_config={"r": 8})
+    sd = random_state_dict(cfg0, seed=17, dtype=dtype)
+    m0 = UltravoxModel(cfg0, state_dict=sd, device=DEV, dtype=dtype)
+    m1 = UltravoxModel(cfg1, state_dict=sd, device=DEV, dtype=dtype)
+    torch.manual_seed(5)
+    x = wav2vec2_normalize_ref(0.1 * torch.randn(2, 9000)).to(DEV)
+    assert torch.equal(m0.audio_tower_forward(x, None), m1.audio_tower_forward(x, None))
+    b = synthetic_batch(cfg1, 2, 2.0, n_text=24, audio_start=5, n_supervised=8)
+    b["audio_values"] = wav2vec2_normalize_ref(b.pop("pcm")).to(dtype)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    trainer = UltravoxTrainer(m1, lr=2e-3)
+    before = {k: v.clone() for k, v in m1.projector_state_dict().items()}
+    trainer.train_step(**gb)
+    trainer.train_step(**gb)                                    # (B starts at zero: A moves from the second step on)
+    after = m1.projector_state_dict()
+    moved = [k for k in after if not torch.equal(after[k], before[k])]
+    assert any("lora_B" in k for k in moved) and any("lora_A" in k for k in moved) and any(k.startswith("multi_modal_projector.") for k in moved)
+    m1.save_pretrained(str(tmp_path))
+    _, ck = checkpoint.load_pretrained(str(tmp_path))
+    assert "audio_tower.base_model.model.encoder.layers.0.attention.q_proj.lora_A.default.weight" in ck
+    assert sum(".lora_" in k for k in ck) == 4 * cfg1.audio_config.encoder_layers
+    w = [L["wqkv"].clone() for L in m1._enc["layers"]]
+    with pytest.raises(NotImplementedError, match="wav2vec2"):
+        m1.merge_and_unload()
+    assert m1.lora_r == 8 and all(torch.equal(L["wqkv"], a) for L, a in zip(m1._enc["layers"], w))

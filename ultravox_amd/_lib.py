@@ -189,7 +189,7 @@ EXPORTS = [
     "uvx_encoder_train_ws_bytes", "uvx_encoder_fwd_train", "uvx_encoder_bwd", "uvx_layernorm_bwd", "uvx_gelu", "uvx_gelu_bwd",
     "uvx_llm_fwd_rows", "uvx_llm_kl_loss_rows", "uvx_llm_bwd_rows", "uvx_llm_fwd_lora", "uvx_llm_bwd_lora",
     "uvx_llm_fwd_train", "uvx_llm_bwd_train",
-    "uvx_wav2vec2_frames", "uvx_wav2vec2_ws_bytes", "uvx_wav2vec2_fwd",
+    "uvx_wav2vec2_frames", "uvx_wav2vec2_ws_bytes", "uvx_wav2vec2_fwd", "uvx_wav2vec2_train_ws_bytes", "uvx_wav2vec2_fwd_train", "uvx_wav2vec2_bwd",
     "uvx_gemm_splitk_ws_bytes", "uvx_gemm_splitk", "uvx_gemm_pick_split",
     "uvx_comm_unique_id", "uvx_comm_init", "uvx_comm_world_size", "uvx_comm_version", "uvx_comm_allreduce_f32", "uvx_comm_destroy",
 ]
@@ -198,7 +198,7 @@ EXPORTS = [
 def _declare(l: C.CDLL) -> None:
     for name in ("uvx_encoder_ws_bytes", "uvx_projector_ws_bytes", "uvx_llm_ws_bytes", "uvx_attention_ws_bytes",
                  "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes", "uvx_llm_prefill_chunk_ws_bytes", "uvx_encoder_train_ws_bytes",
-                 "uvx_wav2vec2_ws_bytes", "uvx_gemm_splitk_ws_bytes"):
+                 "uvx_wav2vec2_ws_bytes", "uvx_wav2vec2_train_ws_bytes", "uvx_gemm_splitk_ws_bytes"):
         getattr(l, name).restype = C.c_size_t
     for name in EXPORTS:
         f = getattr(l, name)

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/uvx.h"      // (the LoRA descriptor structs the helpers at the end of lora.hip take)
 
 namespace uvx {
 
@@ -184,6 +185,13 @@ struct LoraWgradItem { const void* X; long long ldx; const void* Y; long long ld
 int lora_wgrad_batch(hipStream_t st, int dtype, const LoraWgradItem* items, int n, long long M, int r, float* scratch, long long scratch_floats);
 int lora_wgrad(hipStream_t st, int dtype, const void* X, long long ldx, const void* Y, long long ldy, float* out, long long M,
                int C, int r, int transpose_out, float alpha, float* scratch);
+
+// whole adapted linears (peft Linear.forward / its autograd) built from the products above; descriptor check.  (The structs are include/uvx.h's.)
+int lora_apply(hipStream_t st, int dt, const void* x, long long ldx, const uvx_lora_proj_t& P, void* bT, void* t, void* y, long long ldy,
+               long long M, int cin, int cout, int r, float scale);
+int lora_apply_bwd(hipStream_t st, int dt, const void* x, long long ldx, const void* dy, long long lddy, const void* bT, const void* t, void* u,
+                   const uvx_lora_proj_grad_t& G, long long M, int cin, int cout, int r, float scale, float* scratch, long long scratch_floats);
+int lora_check(const uvx_encoder_lora_t* lora, int n_layers, const uvx_encoder_lora_grads_t* grads, const char* who);
 
 // ---- attention.hip ----
 struct AttnDesc {

@@ -491,39 +491,6 @@ extern "C" size_t uvx_encoder_ws_bytes(const uvx_config_t* cfg, int32_t B, int32
   return a.off + 256;
 }
 
-// One adapted linear (peft Linear.forward, dropout 0): y[M, cout] += round(scale * (x A^T) B^T).  t [M, 64 of a 128-column row] keeps
-// x A^T and bT [r, cout] the transposed lora_B for the backward.
-static int lora_apply(hipStream_t st, int dt, const void* x, long long ldx, const uvx_lora_proj_t& P, void* bT, void* t, void* y, long long ldy,
-                      long long M, int cin, int cout, int r, float scale) {
-  RC(lora_transpose(st, dt, P.b, bT, cout, r));
-  RC(lora_down(st, dt, x, ldx, P.a, 0, t, 128, M, cin, r, 1.0f));
-  return lora_up(st, dt, t, 128, bT, 1, y, ldy, M, cout, r, scale, 1);
-}
-// ... and its backward: u [M, 64 of 128] = round(scale * d y . B);  d A [r, cin] = u^T . x;  d B [cout, r] = scale * d y^T . t.  The caller adds
-// u . A to d x once the base dgrad has written it (lora_up, accumulate).
-static int lora_apply_bwd(hipStream_t st, int dt, const void* x, long long ldx, const void* dy, long long lddy, const void* bT, const void* t, void* u,
-                          const uvx_lora_proj_grad_t& G, long long M, int cin, int cout, int r, float scale, float* scratch, long long scratch_floats) {
-  RC(lora_down(st, dt, dy, lddy, bT, 0, u, 128, M, cout, r, scale));
-  const LoraWgradItem items[2] = {{x, ldx, u, 128, G.a, cin, 0, 1.0f}, {dy, lddy, t, 128, G.b, cout, 1, scale}};
-  return lora_wgrad_batch(st, dt, items, 2, M, r, scratch, scratch_floats);
-}
-
-// descriptor sanity: an adapted projection (a != NULL) has its lora_B and - with `grads` - both gradient buffers
-static int lora_check(const uvx_encoder_lora_t* lora, int n_layers, const uvx_encoder_lora_grads_t* grads, const char* who) {
-  UVX_CHECK(lora && lora->layers && lora->r > 0 && lora->r <= 64, UVX_ERR_INVALID, "%s: bad LoRA descriptor (rank must be in 1..64)", who);
-  for (int l = 0; l < n_layers; ++l) {
-    const uvx_lora_proj_t* P[4] = {&lora->layers[l].q, &lora->layers[l].k, &lora->layers[l].v, &lora->layers[l].o};
-    for (int j = 0; j < 4; ++j) {
-      UVX_CHECK(!P[j]->a || P[j]->b, UVX_ERR_INVALID, "%s: layer %d, projection %d has lora_A but no lora_B", who, l, j);
-      if (grads && P[j]->a) {
-        const uvx_lora_proj_grad_t* G[4] = {&grads->layers[l].q, &grads->layers[l].k, &grads->layers[l].v, &grads->layers[l].o};
-        UVX_CHECK(G[j]->a && G[j]->b, UVX_ERR_INVALID, "%s: layer %d, projection %d is adapted but has no gradient buffers", who, l, j);
-      }
-    }
-  }
-  return UVX_OK;
-}
-
 static GemmDesc enc_sk(GemmDesc g, const EncWs& s) { g.splitk_ws = s.sk; g.splitk_ws_bytes = s.sk_bytes; return g; }
 static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_weights_t* w, const uvx_encoder_lora_t* lora,
                        const void* mel, int mel_is_f32, const int64_t* audio_lens, int B, int F, void* out, void* workspace,

@@ -1,6 +1,7 @@
 // Alt audio tower (BASELINE.json config 5): [3P] transformers Wav2Vec2Model.forward behind the C ABI - the AutoModel branch
 // of UltravoxModel._create_audio_tower (ultravox_model.py:460-467, :476-485) for facebook/wav2vec2-large-960h-style towers
-// (GroupNorm after the first conv layer, bias-free convs, post-LN encoder).  Frozen tower: forward only.
+// (GroupNorm after the first conv layer, bias-free convs, post-LN encoder) and the layer-norm (-lv60) family.  Frozen tower: forward only; under
+// apply_lora (audio_model_lora_config.r > 0): uvx_wav2vec2_fwd_train / uvx_wav2vec2_bwd at the end of this file.
 //
 //   input_values [B, L]  (zero-mean / unit-variance waveform; the `input_values` fallback of ultravox_processing.py:308)
 //   -> 7 x Conv1d(+GELU): layer 0 (1 -> C, k 10, s 5) as im2col + GEMM, then GroupNorm(C groups) over time + GELU;
@@ -165,12 +166,30 @@ __global__ void w2v_pos_finish_k(T* __restrict__ h, const float* __restrict__ ac
 
 inline unsigned g1(long long n, int b) { return (unsigned)((n + b - 1) / b); }
 
+// per-layer stash of the LoRA-training forward (uvx_wav2vec2_fwd_train -> uvx_wav2vec2_bwd).  x_in = the layer's input (pre-LN: the residual
+// stream h; post-LN: the normalised x), mid = x_in + attention branch, y2 = LN1(mid) + feed-forward branch (post-LN only: the input of
+// final_layer_norm), pre = fc1's pre-activation; t / t2 = the adapters' down-projections [M, 128] (q | k and v | out_proj), b?T = lora_B^T [r, d]
+struct W2vLayerStash {
+  void *x_in, *qkv, *o, *mid, *y2, *pre, *t, *t2, *bqT, *bkT, *bvT, *boT;
+  float* lse;
+};
 struct W2vWs {
   int T[9];          // frames after conv layer i
   int Tn, Tp, M, nchunk;
   void *im2col, *bufA, *bufB, *x, *n, *qkv, *vt, *o, *o2, *f, *xg;
   float *part, *stat, *acc;
+  // training only
+  char* slots; size_t slot_bytes; W2vLayerStash ls0;
+  void *dx, *d_n, *d_o, *d_f, *d_qkv, *qT, *kT, *doT, *u, *u2;
+  float *delta, *wg;
 };
+W2vLayerStash w2v_layer(const W2vWs& w, int l) {
+  W2vLayerStash s = w.ls0;
+  const size_t off = w.slot_bytes * l;
+  void** ps[] = {&s.x_in, &s.qkv, &s.o, &s.mid, &s.y2, &s.pre, &s.t, &s.t2, &s.bqT, &s.bkT, &s.bvT, &s.boT, (void**)&s.lse};
+  for (void** q : ps) if (*q) *q = (char*)*q + off;
+  return s;
+}
 
 int frames(const uvx_w2v_config_t& c, int L, int* T) {
   int n = L;
@@ -182,7 +201,7 @@ int frames(const uvx_w2v_config_t& c, int L, int* T) {
   return n;
 }
 
-W2vWs carve(Arena& a, const uvx_w2v_config_t& c, int B, int L) {
+W2vWs carve(Arena& a, const uvx_w2v_config_t& c, int B, int L, bool train = false) {
   W2vWs w = {};
   w.Tn = frames(c, L, w.T);
   if (w.Tn <= 0) return w;
@@ -205,6 +224,28 @@ W2vWs carve(Arena& a, const uvx_w2v_config_t& c, int B, int L) {
   w.f = a.take((size_t)w.M * c.ffn * es);
   w.xg = a.take((size_t)B * c.pos_groups * (w.Tn + c.pos_k) * (d / c.pos_groups) * es);
   w.acc = (float*)a.take(sizeof(float) * (size_t)w.M * d);
+  if (train) {
+    const size_t M = (size_t)w.M;
+    const size_t start = (a.off + 255) & ~(size_t)255;
+    a.off = start;
+    W2vLayerStash& s = w.ls0;
+    s.x_in = a.take(M * d * es); s.qkv = a.take(M * 3 * d * es); s.o = a.take(M * d * es); s.mid = a.take(M * d * es);
+    s.y2 = c.stable_ln ? nullptr : a.take(M * d * es);
+    s.pre = a.take(M * c.ffn * es); s.t = a.take(M * 128 * es); s.t2 = a.take(M * 128 * es);
+    s.bqT = a.take((size_t)64 * d * es); s.bkT = a.take((size_t)64 * d * es); s.bvT = a.take((size_t)64 * d * es); s.boT = a.take((size_t)64 * d * es);
+    s.lse = (float*)a.take(sizeof(float) * (size_t)B * c.heads * w.Tn);
+    a.off = (a.off + 255) & ~(size_t)255;
+    w.slot_bytes = a.off - start;
+    w.slots = a.base ? a.base + start : nullptr;
+    a.off = start + w.slot_bytes * c.layers;
+    w.dx = a.take(M * d * es); w.d_n = a.take(M * d * es); w.d_o = a.take(M * d * es);
+    w.d_f = a.take(M * c.ffn * es); w.d_qkv = a.take(M * 3 * d * es);
+    const size_t ht = (size_t)B * c.heads * dh * w.Tp * es;
+    w.qT = a.take(ht); w.kT = a.take(ht); w.doT = a.take(ht);
+    w.u = a.take(M * 128 * es); w.u2 = a.take(M * 128 * es);
+    w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.heads * w.Tn);
+    w.wg = (float*)a.take(sizeof(float) * (size_t)lora_wgrad_scratch_floats(w.M, d, 64));
+  }
   return w;
 }
 
@@ -237,12 +278,16 @@ extern "C" size_t uvx_wav2vec2_ws_bytes(const uvx_w2v_config_t* cfg, int32_t B, 
   return a.off + 256;
 }
 
-extern "C" int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_weights_t* w, const void* input_values,
-                                    int32_t values_is_f32, int32_t B, int32_t L, void* out, void* workspace, size_t ws_bytes) {
+// lora != NULL: the LoRA-training forward (apply_lora on the AutoModel tower, ultravox_model.py:460-467, 690-709) - adapters on the attention
+// projections and a per-layer stash for uvx_wav2vec2_bwd; the feature encoder, projection and positional conv have no adapter and stay forward-only
+static int w2v_forward(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_weights_t* w, const uvx_encoder_lora_t* lora, const void* input_values,
+                       int32_t values_is_f32, int32_t B, int32_t L, void* out, void* workspace, size_t ws_bytes) {
   RC(check(cfg));
   UVX_CHECK(w && w->layers && input_values && out && workspace, UVX_ERR_INVALID, "wav2vec2_fwd: null argument");
   const uvx_w2v_config_t& c = *cfg;
   hipStream_t st = (hipStream_t)stream;
+  const bool train = lora != nullptr;
+  if (train) RC(lora_check(lora, c.layers, nullptr, "wav2vec2 LoRA"));
   for (int i = 0; i < c.n_conv; ++i) {
     UVX_CHECK(!c.conv_bias || w->conv_b[i], UVX_ERR_INVALID, "wav2vec2_fwd: conv_bias is set but conv layer %d has no bias", i);
     UVX_CHECK(!c.feat_norm_layer || (w->conv_ln_w[i] && w->conv_ln_b[i]), UVX_ERR_INVALID, "wav2vec2_fwd: conv layer %d has no layer norm", i);
@@ -250,7 +295,7 @@ extern "C" int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, c
   UVX_CHECK(c.feat_norm_layer || (w->gn_w && w->gn_b), UVX_ERR_INVALID, "wav2vec2_fwd: the first conv layer's GroupNorm weights are missing");
   if (B == 0) return UVX_OK;
   Arena a(workspace, ws_bytes);
-  W2vWs s = carve(a, c, B, L);
+  W2vWs s = carve(a, c, B, L, train);
   UVX_CHECK(s.Tn > 0, UVX_ERR_SHAPE, "wav2vec2_fwd: %d samples are shorter than the conv stack's receptive field", L);
   UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "wav2vec2_fwd: workspace %zu < %zu bytes", ws_bytes, a.off);
   const int dt = c.dtype, C = c.conv_dim, d = c.d, dh = d / c.heads, M = s.M, Tn = s.Tn;
@@ -328,82 +373,215 @@ extern "C" int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, c
     else hipLaunchKernelGGL(w2v_pos_finish_k<float>, dim3(g1(m8, 256)), dim3(256), 0, st, (float*)s.x, s.acc, (const float*)w->pos_b, m8, d);
     UVX_LAUNCH_CHECK();
   }
-  if (c.stable_ln) {
-    // ---- encoder, do_stable_layer_norm = True ([3P] Wav2Vec2EncoderStableLayerNorm / ...EncoderLayerStableLayerNorm): per layer
-    //      h = h + attention(layer_norm(h));  h = h + feed_forward(final_layer_norm(h));  encoder.layer_norm after the last layer ----
-    void* h = s.x;       // the residual stream alternates between s.x and s.o2
-    void* h2 = s.o2;
-    for (int l = 0; l < c.layers; ++l) {
-      const uvx_enc_layer_t& Lw = w->layers[l];
-      RC(layernorm_fwd(st, dt, h, Lw.ln1_w, Lw.ln1_b, s.n, M, d, c.ln_eps));
-      {
-        GemmDesc g = lin(s.n, Lw.wqkv, s.qkv, M, 3 * d, d);
-        g.bias = Lw.bqkv;
-        RC(gemm(st, dt, g));
-      }
-      if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(s.qkv, 2 * d, dt), s.vt, B, Tn, s.Tp, c.heads, dh, 3 * d));
-      AttnDesc ad;
-      ad.q = s.qkv; ad.k = at(s.qkv, d, dt); ad.v = at(s.qkv, 2 * d, dt); ad.vt = s.vt; ad.o = s.o;
-      ad.B = B; ad.T = Tn; ad.Tp = s.Tp; ad.Hq = c.heads; ad.Hkv = c.heads; ad.D = dh;
-      ad.ldq = ad.ldk = ad.ldv = 3 * d; ad.ldo = d; ad.causal = 0; ad.block = 0;
-      ad.scale = 1.0f;
-      RC(attention_fwd(st, dt, ad));
-      {
-        GemmDesc g = lin(s.o, Lw.wo, h2, M, d, d);
-        g.bias = Lw.bo; g.residual = h; g.ldr = d;
-        RC(gemm(st, dt, g));
-      }
-      RC(layernorm_fwd(st, dt, h2, Lw.ln2_w, Lw.ln2_b, s.n, M, d, c.ln_eps));
-      {
-        GemmDesc g = lin(s.n, Lw.fc1_w, s.f, M, c.ffn, d);
-        g.bias = Lw.fc1_b; g.act = 1;
-        RC(gemm(st, dt, g));
-      }
-      {
-        GemmDesc g = lin(s.f, Lw.fc2_w, h, M, d, c.ffn);
-        g.bias = Lw.fc2_b; g.residual = h2; g.ldr = d;
-        RC(gemm(st, dt, g));
-      }
-    }
-    return layernorm_fwd(st, dt, h, w->ln_w, w->ln_b, out, M, d, c.ln_eps);
-  }
-  // ---- encoder (post-LN, do_stable_layer_norm = False) ----
-  void* x = s.n;     // x alternates between s.n and s.x
-  void* y = s.x;
-  RC(layernorm_fwd(st, dt, s.x, w->ln_w, w->ln_b, x, M, d, c.ln_eps));
-  for (int l = 0; l < c.layers; ++l) {
+  const float qscale = 1.0f / sqrtf((float)dh);
+  // one attention branch: q|k|v projection of `in` (+ adapters), attention, out_proj + residual `res` (+ adapter) -> `dst`
+  auto attn_branch = [&](int l, const void* in, const void* res, void* dst) -> int {
     const uvx_enc_layer_t& Lw = w->layers[l];
+    W2vLayerStash S = train ? w2v_layer(s, l) : W2vLayerStash{};
+    void* qkv = train ? S.qkv : s.qkv;
+    void* o = train ? S.o : s.o;
     {
-      GemmDesc g = lin(x, Lw.wqkv, s.qkv, M, 3 * d, d);
+      GemmDesc g = lin(in, Lw.wqkv, qkv, M, 3 * d, d);
       g.bias = Lw.bqkv;
       RC(gemm(st, dt, g));
     }
-    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(s.qkv, 2 * d, dt), s.vt, B, Tn, s.Tp, c.heads, dh, 3 * d));
+    if (train) {      // peft: result += lora_B(lora_A(x)) * scaling; q carries head_dim^-0.5 (folded into the packed q rows)
+      const uvx_enc_lora_layer_t& R = lora->layers[l];
+      if (R.q.a) RC(lora_apply(st, dt, in, d, R.q, S.bqT, S.t, qkv, 3 * d, M, d, d, lora->r, lora->scaling * qscale));
+      if (R.k.a) RC(lora_apply(st, dt, in, d, R.k, S.bkT, at(S.t, 64, dt), at(qkv, d, dt), 3 * d, M, d, d, lora->r, lora->scaling));
+      if (R.v.a) RC(lora_apply(st, dt, in, d, R.v, S.bvT, S.t2, at(qkv, 2 * d, dt), 3 * d, M, d, d, lora->r, lora->scaling));
+    }
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(qkv, 2 * d, dt), s.vt, B, Tn, s.Tp, c.heads, dh, 3 * d));
     AttnDesc ad;
-    ad.q = s.qkv; ad.k = at(s.qkv, d, dt); ad.v = at(s.qkv, 2 * d, dt); ad.vt = s.vt; ad.o = s.o;
+    ad.q = qkv; ad.k = at(qkv, d, dt); ad.v = at(qkv, 2 * d, dt); ad.vt = s.vt; ad.o = o; ad.lse = train ? S.lse : nullptr;
     ad.B = B; ad.T = Tn; ad.Tp = s.Tp; ad.Hq = c.heads; ad.Hkv = c.heads; ad.D = dh;
     ad.ldq = ad.ldk = ad.ldv = 3 * d; ad.ldo = d; ad.causal = 0; ad.block = 0;
     ad.scale = 1.0f;   // q_proj (weight and bias) pre-scaled by head_dim^-0.5 at pack time: exact for a power of two
     RC(attention_fwd(st, dt, ad));
     {
-      GemmDesc g = lin(s.o, Lw.wo, y, M, d, d);
-      g.bias = Lw.bo; g.residual = x; g.ldr = d;
+      GemmDesc g = lin(o, Lw.wo, dst, M, d, d);
+      g.bias = Lw.bo; g.residual = res; g.ldr = d;
       RC(gemm(st, dt, g));
     }
-    RC(layernorm_fwd(st, dt, y, Lw.ln1_w, Lw.ln1_b, x, M, d, c.ln_eps));       // layers.N.layer_norm
-    {
-      GemmDesc g = lin(x, Lw.fc1_w, s.f, M, c.ffn, d);
+    if (train && lora->layers[l].o.a) RC(lora_apply(st, dt, o, d, lora->layers[l].o, S.boT, at(S.t2, 64, dt), dst, d, M, d, d, lora->r, lora->scaling));
+    return UVX_OK;
+  };
+  // one feed-forward branch: fc1 + GELU (training: the pre-activation is kept), fc2 + residual `res` -> `dst`
+  auto ffn_branch = [&](int l, const void* in, const void* res, void* dst) -> int {
+    const uvx_enc_layer_t& Lw = w->layers[l];
+    if (train) {
+      W2vLayerStash S = w2v_layer(s, l);
+      GemmDesc g = lin(in, Lw.fc1_w, S.pre, M, c.ffn, d);
+      g.bias = Lw.fc1_b;
+      RC(gemm(st, dt, g));
+      RC(gelu_fwd(st, dt, S.pre, s.f, (long long)M * c.ffn));
+    } else {
+      GemmDesc g = lin(in, Lw.fc1_w, s.f, M, c.ffn, d);
       g.bias = Lw.fc1_b; g.act = 1;
       RC(gemm(st, dt, g));
     }
-    {
-      GemmDesc g = lin(s.f, Lw.fc2_w, y, M, d, c.ffn);
-      g.bias = Lw.fc2_b; g.residual = x; g.ldr = d;
-      RC(gemm(st, dt, g));
+    GemmDesc g = lin(s.f, Lw.fc2_w, dst, M, d, c.ffn);
+    g.bias = Lw.fc2_b; g.residual = res; g.ldr = d;
+    return gemm(st, dt, g);
+  };
+  if (c.stable_ln) {
+    // ---- encoder, do_stable_layer_norm = True ([3P] Wav2Vec2EncoderStableLayerNorm / ...EncoderLayerStableLayerNorm): per layer
+    //      h = h + attention(layer_norm(h));  h = h + feed_forward(final_layer_norm(h));  encoder.layer_norm after the last layer ----
+    // inference: the residual stream alternates between s.x and s.o2; training: it lives in the layer stashes (x_in -> mid -> next x_in)
+    void* h = s.x;
+    if (train && c.layers > 0) {
+      UVX_HIP(hipMemcpyAsync(w2v_layer(s, 0).x_in, s.x, (size_t)M * d * esz(dt), hipMemcpyDeviceToDevice, st));
+      h = w2v_layer(s, 0).x_in;
     }
-    void* dst = l + 1 == c.layers ? out : x;
-    RC(layernorm_fwd(st, dt, y, Lw.ln2_w, Lw.ln2_b, dst, M, d, c.ln_eps));     // layers.N.final_layer_norm
+    for (int l = 0; l < c.layers; ++l) {
+      const uvx_enc_layer_t& Lw = w->layers[l];
+      void* h2 = train ? w2v_layer(s, l).mid : s.o2;
+      void* h_next = !train ? h : (l + 1 < c.layers ? w2v_layer(s, l + 1).x_in : s.x);
+      RC(layernorm_fwd(st, dt, h, Lw.ln1_w, Lw.ln1_b, s.n, M, d, c.ln_eps));
+      RC(attn_branch(l, s.n, h, h2));
+      RC(layernorm_fwd(st, dt, h2, Lw.ln2_w, Lw.ln2_b, s.n, M, d, c.ln_eps));
+      RC(ffn_branch(l, s.n, h2, h_next));
+      h = h_next;
+    }
+    return layernorm_fwd(st, dt, h, w->ln_w, w->ln_b, out, M, d, c.ln_eps);      // (training: h == s.x, kept for the backward)
+  }
+  // ---- encoder (post-LN, do_stable_layer_norm = False): x = LN(x + attention(x)); x = LN(x + feed_forward(x)) ----
+  // inference: x alternates between s.n and s.x; training: x_in / mid / y2 of the layer stashes, x1 = LN1(mid) in s.n
+  void* x = train && c.layers > 0 ? w2v_layer(s, 0).x_in : s.n;
+  void* y = s.x;
+  RC(layernorm_fwd(st, dt, s.x, w->ln_w, w->ln_b, x, M, d, c.ln_eps));
+  for (int l = 0; l < c.layers; ++l) {
+    const uvx_enc_layer_t& Lw = w->layers[l];
+    void* mid = train ? w2v_layer(s, l).mid : y;
+    void* x1 = train ? s.n : x;
+    void* y2 = train ? w2v_layer(s, l).y2 : y;
+    RC(attn_branch(l, x, x, mid));
+    RC(layernorm_fwd(st, dt, mid, Lw.ln1_w, Lw.ln1_b, x1, M, d, c.ln_eps));       // layers.N.layer_norm
+    RC(ffn_branch(l, x1, x1, y2));
+    void* dst = l + 1 == c.layers ? out : (train ? w2v_layer(s, l + 1).x_in : x);
+    RC(layernorm_fwd(st, dt, y2, Lw.ln2_w, Lw.ln2_b, dst, M, d, c.ln_eps));     // layers.N.final_layer_norm
+    x = dst;
   }
   if (c.layers == 0) UVX_HIP(hipMemcpyAsync(out, x, (size_t)M * d * esz(dt), hipMemcpyDeviceToDevice, st));
+  return UVX_OK;
+}
+
+extern "C" int32_t uvx_wav2vec2_fwd(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_weights_t* w, const void* input_values,
+                                    int32_t values_is_f32, int32_t B, int32_t L, void* out, void* workspace, size_t ws_bytes) {
+  return w2v_forward(stream, cfg, w, nullptr, input_values, values_is_f32, B, L, out, workspace, ws_bytes);
+}
+
+extern "C" size_t uvx_wav2vec2_train_ws_bytes(const uvx_w2v_config_t* cfg, int32_t B, int32_t L) {
+  if (!cfg) return 0;
+  Arena a(nullptr, 0);
+  carve(a, *cfg, B, L, true);
+  return a.off + 256;
+}
+
+extern "C" int32_t uvx_wav2vec2_fwd_train(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_weights_t* w, const uvx_encoder_lora_t* lora,
+                                          const void* input_values, int32_t values_is_f32, int32_t B, int32_t L, void* out, void* workspace,
+                                          size_t ws_bytes) {
+  UVX_CHECK(lora != nullptr, UVX_ERR_INVALID, "wav2vec2_fwd_train: null LoRA descriptor");
+  return w2v_forward(stream, cfg, w, lora, input_values, values_is_f32, B, L, out, workspace, ws_bytes);
+}
+
+// Backward of the LoRA-adapted wav2vec2 encoder: d last_hidden_state [B, frames, d] -> the adapters' gradients in every layer (everything else is
+// frozen: apply_lora, ultravox_model.py:690-709).  Walks the stash of uvx_wav2vec2_fwd_train; nothing below layer 0's q|k|v input is trainable, so the
+// walk stops there (no gradient for the positional conv / feature projection / feature encoder).
+extern "C" int32_t uvx_wav2vec2_bwd(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_weights_t* w, const uvx_encoder_lora_t* lora,
+                                    const void* d_out, int32_t B, int32_t L, const uvx_encoder_lora_grads_t* grads, void* workspace, size_t ws_bytes) {
+  RC(check(cfg));
+  UVX_CHECK(w && w->layers && lora && d_out && grads && grads->layers && workspace, UVX_ERR_INVALID, "wav2vec2_bwd: null argument");
+  const uvx_w2v_config_t& c = *cfg;
+  RC(lora_check(lora, c.layers, grads, "wav2vec2_bwd"));
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || c.layers == 0) return UVX_OK;
+  Arena a(workspace, ws_bytes);
+  W2vWs s = carve(a, c, B, L, true);
+  UVX_CHECK(s.Tn > 0, UVX_ERR_SHAPE, "wav2vec2_bwd: %d samples are shorter than the conv stack's receptive field", L);
+  UVX_CHECK(a.fits(), UVX_ERR_WORKSPACE, "wav2vec2_bwd: workspace %zu < %zu bytes", ws_bytes, a.off);
+  const int dt = c.dtype, d = c.d, dh = d / c.heads, M = s.M, Tn = s.Tn, r = lora->r;
+  const float qscale = 1.0f / sqrtf((float)dh);
+  const long long wg_floats = lora_wgrad_scratch_floats(s.M, d, 64);
+  // gradient of the attention branch's output `dy` [M, d] (d_o scratch: s.d_o) -> adapter gradients; unless `last`, d (branch input) in s.d_n =
+  // d qkv . Wqkv + u . A (+ `add`: the residual path's gradient, folded into the dgrad's epilogue)
+  auto attn_branch_bwd = [&](int l, const void* dy, const void* add, bool last) -> int {
+    const uvx_enc_layer_t& Lw = w->layers[l];
+    UVX_CHECK(Lw.wqkv_t && Lw.wo_t && Lw.fc1_t && Lw.fc2_t, UVX_ERR_INVALID, "wav2vec2_bwd: layer %d lacks transposed weights", l);
+    W2vLayerStash S = w2v_layer(s, l);
+    const uvx_enc_lora_layer_t& R = lora->layers[l];
+    const uvx_enc_lora_layer_grads_t& G = grads->layers[l];
+    // the branch input: pre-LN = layer_norm(x_in), recomputed; post-LN = x_in itself
+    const void* in = S.x_in;
+    if (c.stable_ln) {
+      RC(layernorm_fwd(st, dt, S.x_in, Lw.ln1_w, Lw.ln1_b, s.n, M, d, c.ln_eps));
+      in = s.n;
+    }
+    RC(gemm(st, dt, lin(dy, Lw.wo_t, s.d_o, M, d, d)));
+    if (R.o.a) {
+      RC(lora_apply_bwd(st, dt, S.o, d, dy, d, S.boT, at(S.t2, 64, dt), at(s.u2, 64, dt), G.o, M, d, d, r, lora->scaling, s.wg, wg_floats));
+      RC(lora_up(st, dt, at(s.u2, 64, dt), 128, R.o.a, 1, s.d_o, d, M, d, r, 1.0f, 1));
+    }
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, S.qkv, s.qT, B, Tn, s.Tp, c.heads, dh, 3 * d));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, at(S.qkv, d, dt), s.kT, B, Tn, s.Tp, c.heads, dh, 3 * d));
+    if (attention_needs_transposed_copies(dt)) RC(heads_transpose(st, dt, s.d_o, s.doT, B, Tn, s.Tp, c.heads, dh, d));
+    AttnBwdDesc bd;
+    AttnDesc& ad = bd.f;
+    ad.q = S.qkv; ad.k = at(S.qkv, d, dt); ad.v = at(S.qkv, 2 * d, dt); ad.o = S.o; ad.lse = S.lse;
+    ad.B = B; ad.T = Tn; ad.Tp = s.Tp; ad.Hq = c.heads; ad.Hkv = c.heads; ad.D = dh;
+    ad.ldq = ad.ldk = ad.ldv = 3 * d; ad.ldo = d; ad.causal = 0; ad.block = 0; ad.scale = 1.0f;
+    bd.dout = s.d_o; bd.qt = s.qT; bd.kt = s.kT; bd.dot = s.doT; bd.delta = s.delta; bd.dkv_part = nullptr;
+    bd.dq = s.d_qkv; bd.dk = at(s.d_qkv, d, dt); bd.dv = at(s.d_qkv, 2 * d, dt);
+    bd.lddq = bd.lddk = bd.lddv = 3 * d;
+    RC(attention_bwd(st, dt, bd));
+    if (R.q.a) RC(lora_apply_bwd(st, dt, in, d, s.d_qkv, 3 * d, S.bqT, S.t, s.u, G.q, M, d, d, r, lora->scaling * qscale, s.wg, wg_floats));
+    if (R.k.a) RC(lora_apply_bwd(st, dt, in, d, at(s.d_qkv, d, dt), 3 * d, S.bkT, at(S.t, 64, dt), at(s.u, 64, dt), G.k, M, d, d, r, lora->scaling, s.wg, wg_floats));
+    if (R.v.a) RC(lora_apply_bwd(st, dt, in, d, at(s.d_qkv, 2 * d, dt), 3 * d, S.bvT, S.t2, s.u2, G.v, M, d, d, r, lora->scaling, s.wg, wg_floats));
+    if (last) return UVX_OK;
+    {
+      GemmDesc g = lin(s.d_qkv, Lw.wqkv_t, s.d_n, M, d, 3 * d);
+      g.residual = add; g.ldr = d;
+      RC(gemm(st, dt, g));
+    }
+    if (R.q.a) RC(lora_up(st, dt, s.u, 128, R.q.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+    if (R.k.a) RC(lora_up(st, dt, at(s.u, 64, dt), 128, R.k.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+    if (R.v.a) RC(lora_up(st, dt, s.u2, 128, R.v.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+    return UVX_OK;
+  };
+  // gradient of the feed-forward branch's output `dy` -> s.d_n = (dy . W_fc2 * gelu'(pre)) . W_fc1 (+ `add`)
+  auto ffn_branch_bwd = [&](int l, const void* dy, const void* add) -> int {
+    const uvx_enc_layer_t& Lw = w->layers[l];
+    W2vLayerStash S = w2v_layer(s, l);
+    RC(gemm(st, dt, lin(dy, Lw.fc2_t, s.d_f, M, c.ffn, d)));
+    RC(gelu_bwd(st, dt, s.d_f, S.pre, s.d_f, (long long)M * c.ffn));
+    GemmDesc g = lin(s.d_f, Lw.fc1_t, s.d_n, M, d, c.ffn);
+    g.residual = add; g.ldr = d;
+    return gemm(st, dt, g);
+  };
+  if (c.stable_ln) {
+    // out = encoder.layer_norm(h_final); h_final = s.x (left there by the forward)
+    RC(layernorm_bwd(st, dt, d_out, s.x, w->ln_w, nullptr, s.dx, M, d, c.ln_eps));
+    for (int l = c.layers - 1; l >= 0; --l) {
+      const uvx_enc_layer_t& Lw = w->layers[l];
+      W2vLayerStash S = w2v_layer(s, l);
+      RC(ffn_branch_bwd(l, s.dx, nullptr));                                                     // d n2 in s.d_n
+      RC(layernorm_bwd(st, dt, s.d_n, S.mid, Lw.ln2_w, s.dx, s.dx, M, d, c.ln_eps));           // d h2 = d h + LN2'(d n2)
+      RC(attn_branch_bwd(l, s.dx, nullptr, l == 0));                                            // d n1 in s.d_n
+      if (l == 0) break;
+      RC(layernorm_bwd(st, dt, s.d_n, S.x_in, Lw.ln1_w, s.dx, s.dx, M, d, c.ln_eps));          // d h = d h2 + LN1'(d n1)
+    }
+    return UVX_OK;
+  }
+  // post-LN: the layer's output = final_layer_norm(y2), y2 = x1 + ffn(x1), x1 = layer_norm(mid), mid = x_in + attention(x_in)
+  const void* dx = d_out;
+  for (int l = c.layers - 1; l >= 0; --l) {
+    const uvx_enc_layer_t& Lw = w->layers[l];
+    W2vLayerStash S = w2v_layer(s, l);
+    RC(layernorm_bwd(st, dt, dx, S.y2, Lw.ln2_w, nullptr, s.dx, M, d, c.ln_eps));               // d y2 in s.dx
+    RC(ffn_branch_bwd(l, s.dx, s.dx));                                                          // d x1 = d y2 + ffn'(d y2) in s.d_n
+    RC(layernorm_bwd(st, dt, s.d_n, S.mid, Lw.ln1_w, nullptr, s.dx, M, d, c.ln_eps));           // d mid in s.dx
+    RC(attn_branch_bwd(l, s.dx, s.dx, l == 0));                                                 // d x_in = d mid + attention'(d mid) in s.d_n
+    dx = s.d_n;
+  }
   return UVX_OK;
 }

@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .config import PROJECTOR_ACTS, LossConfig, LossFunction, UltravoxConfig
-from .weights import (LORA_FIELD, LORA_TARGETS, init_lora_state_dict, lora_targets, llm_lora_key, lora_key, pack_encoder, pack_llm, pack_wav2vec2,
+from .weights import (LORA_FIELD, LORA_TARGETS, audio_lora_key, init_lora_state_dict, lora_targets, llm_lora_key, lora_key, pack_encoder, pack_llm, pack_wav2vec2,
                       unpack_encoder, unpack_llm, check_encoder_exportable, encoder_param_names, llm_param_names,
                       random_state_dict)
 
@@ -195,10 +195,8 @@ class UltravoxModel:
         self.is_wav2vec2 = bool(getattr(a, "is_wav2vec2", False))
         if self.llm_only:
             self.lora_r, self.is_wav2vec2, self._enc = 0, False, None      # (LLMOnlyModelPack passes audio_model_lora_config = None)
-        elif self.is_wav2vec2:
-            if self.lora_r > 0:
-                raise ValueError("audio_model_lora_config.r > 0 is built for the Whisper tower only (the wav2vec2 tower is frozen)")
-            self._enc = pack_wav2vec2(sd, cfg, dt, dev)
+        elif self.is_wav2vec2:      # (apply_lora wraps whatever AutoModel tower was loaded, ultravox_model.py:460-467: uvx_wav2vec2_fwd_train / _bwd)
+            self._enc = pack_wav2vec2(sd, cfg, dt, dev, with_transposes=self.lora_r > 0 and self.with_backward)
         else:
             self._enc = pack_encoder(sd, cfg, dt, dev, with_transposes=self.lora_r > 0 and self.with_backward)
         self._llm = pack_llm(sd, cfg, dt, dev, with_transposes=("head" if self.dgrad_nn else self.with_backward and not self.stream_weight_transposes), rope_len=rope_len,
@@ -215,7 +213,8 @@ class UltravoxModel:
         self.text_lora_r = int((getattr(cfg, "text_model_lora_config", None) or {}).get("r", 0) or 0)   # LLM LoRA rank (0: frozen LLM)
         if self.lora_r > 0 or self.text_lora_r > 0:
             init = init_lora_state_dict(cfg, seed=0, dtype=dt)
-            todo = ([(lora_key, a.encoder_layers, lora_targets(cfg, "audio"))] * (self.lora_r > 0)
+            self._audio_lora_key = audio_lora_key(cfg)      # Whisper: layers.N.self_attn..., wav2vec2: encoder.layers.N.attention...
+            todo = ([(self._audio_lora_key, a.encoder_layers, lora_targets(cfg, "audio"))] * (self.lora_r > 0)
                     + [(llm_lora_key, t.num_hidden_layers, lora_targets(cfg, "text"))] * (self.text_lora_r > 0))
             for keyfn, nl, targets in todo:
                 for i in range(nl):
@@ -244,10 +243,11 @@ class UltravoxModel:
             self._lora_targets = lora_targets(cfg, "audio")
             for i in range(nl):
                 for pj, fld in ((pj, LORA_FIELD[pj]) for pj in self._lora_targets):      # projections not named keep NULL pointers: not adapted
-                    getattr(self._lora_layers[i], fld).a = self._proj_views[lora_key(i, pj, "A")].data_ptr()
-                    getattr(self._lora_layers[i], fld).b = self._proj_views[lora_key(i, pj, "B")].data_ptr()
-                    getattr(self._lora_grad_layers[i], fld).a = self._grad_views[lora_key(i, pj, "A")].data_ptr()
-                    getattr(self._lora_grad_layers[i], fld).b = self._grad_views[lora_key(i, pj, "B")].data_ptr()
+                    ak = self._audio_lora_key
+                    getattr(self._lora_layers[i], fld).a = self._proj_views[ak(i, pj, "A")].data_ptr()
+                    getattr(self._lora_layers[i], fld).b = self._proj_views[ak(i, pj, "B")].data_ptr()
+                    getattr(self._lora_grad_layers[i], fld).a = self._grad_views[ak(i, pj, "A")].data_ptr()
+                    getattr(self._lora_grad_layers[i], fld).b = self._grad_views[ak(i, pj, "B")].data_ptr()
             self._lora = _lib.EncoderLora()
             self._lora.r = self.lora_r
             self._lora.scaling = float(cfg.audio_model_lora_config.get("lora_alpha", 8)) / self.lora_r
@@ -469,6 +469,11 @@ class UltravoxModel:
         def fold(w_rows: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scale: float) -> None:
             w_rows.copy_((w_rows.float() + scale * (B.float() @ A.float())).to(w_rows.dtype))
         kept = getattr(self, "_kept_tensors", {})
+        if self.lora_r > 0 and self.is_wav2vec2:
+            # the merged tower joins keep_params and is written whole by the next save_pretrained (ultravox_model.py:529-553): there is no inverse of
+            # pack_wav2vec2 (weight-normed positional conv, im2col conv stack) to re-export it with - refused before any weight changes
+            raise NotImplementedError("merge_and_unload with a LoRA-adapted wav2vec2 tower is not built (the merged tower could not be re-exported); "
+                                      "save_pretrained keeps the adapters under peft's names")
         if self.lora_r > 0:
             check_encoder_exportable(self.config)      # BEFORE any weight changes: a tower that cannot be re-exported is not half-merged
         def fold_layer(L, rows, targets, keyfn, i, sc, q_scale=1.0) -> None:
@@ -487,7 +492,7 @@ class UltravoxModel:
             qs = (d // self.config.audio_config.encoder_attention_heads) ** -0.5      # folded into the packed q rows
             rows = {"q_proj": (0, d), "k_proj": (d, 2 * d), "v_proj": (2 * d, 3 * d)}
             for i, L in enumerate(self._enc["layers"]):
-                fold_layer(L, rows, self._lora_targets, lora_key, i, float(self._lora.scaling), qs)
+                fold_layer(L, rows, self._lora_targets, self._audio_lora_key, i, float(self._lora.scaling), qs)
             self.lora_r = 0
             self._merged_tower("audio_tower.", "audio_model_id", kept)
         if self.text_lora_r > 0:
@@ -605,6 +610,13 @@ class UltravoxModel:
         if Tn <= 0:
             raise ValueError(f"{L} samples are shorter than the wav2vec2 feature encoder's receptive field")
         out = torch.empty((A, Tn, self.config.audio_config.d_model), device=self.device, dtype=self.dtype)
+        if self.lora_r > 0:      # the LoRA-adapted tower (adapters active in eval mode too, as peft's wrapped modules are); stash for uvx_wav2vec2_bwd
+            nb = l.uvx_wav2vec2_train_ws_bytes(C.byref(self._w2v_cfg), A, L)
+            ws = self._workspace("enc_train", nb)
+            check(l.uvx_wav2vec2_fwd_train(stream_ptr(), C.byref(self._w2v_cfg), C.byref(self._w2v_w), C.byref(self._lora), ptr(input_values),
+                                           int(is_f32), A, L, ptr(out), ptr(ws), C.c_size_t(nb)), "uvx_wav2vec2_fwd_train")
+            self._enc_ctx = (A, L, nb, None)
+            return out
         nb = l.uvx_wav2vec2_ws_bytes(C.byref(self._w2v_cfg), A, L)
         ws = self._workspace("enc", nb)
         check(l.uvx_wav2vec2_fwd(stream_ptr(), C.byref(self._w2v_cfg), C.byref(self._w2v_w), ptr(input_values), int(is_f32), A, L,
@@ -632,7 +644,11 @@ class UltravoxModel:
             d_enc = torch.empty((A, Te, self.config.audio_config.d_model), device=self.device, dtype=self.dtype)
         check(l.uvx_projector_bwd(stream_ptr(), C.byref(self._c), C.byref(self._pw), ptr(d_audio_embeds), A, Te,
                                   C.byref(self._pg), ptr(d_enc), ptr(self._ws["proj"]), C.c_size_t(nb)), "uvx_projector_bwd")
-        if self.lora_r > 0:
+        if self.lora_r > 0 and self.is_wav2vec2:
+            Ae, L, nbe, _ = self._enc_ctx
+            check(l.uvx_wav2vec2_bwd(stream_ptr(), C.byref(self._w2v_cfg), C.byref(self._w2v_w), C.byref(self._lora), ptr(d_enc), Ae, L,
+                                     C.byref(self._lora_grads), ptr(self._ws["enc_train"]), C.c_size_t(nbe)), "uvx_wav2vec2_bwd")
+        elif self.lora_r > 0:
             Ae, F, nbe, lens = self._enc_ctx
             check(l.uvx_encoder_bwd(stream_ptr(), C.byref(self._c), C.byref(self._ew), C.byref(self._lora), ptr(d_enc),
                                     ptr(lens), Ae, F, C.byref(self._lora_grads), ptr(self._ws["enc_train"]), C.c_size_t(nbe)),

@@ -220,6 +220,16 @@ def lora_key(layer: int, proj: str, which: str, prefix="audio_tower.") -> str:
     return f"{prefix}base_model.model.layers.{layer}.self_attn.{proj}.lora_{which}.default.weight"
 
 
+def w2v_lora_key(layer: int, proj: str, which: str, prefix="audio_tower.") -> str:
+    """... of the wrapped HF Wav2Vec2Model (the AutoModel tower, ultravox_model.py:460-467): its attention lives at encoder.layers.N.attention."""
+    return f"{prefix}base_model.model.encoder.layers.{layer}.attention.{proj}.lora_{which}.default.weight"
+
+
+def audio_lora_key(cfg: UltravoxConfig):
+    """The key function of cfg's audio tower: Whisper's `layers.N.self_attn` or wav2vec2's `encoder.layers.N.attention`."""
+    return w2v_lora_key if getattr(cfg.audio_config, "is_wav2vec2", False) else lora_key
+
+
 def llm_lora_key(layer: int, proj: str, which: str, prefix="language_model.") -> str:
     """peft's name for a LoRA matrix of the wrapped LlamaForCausalLM (whose own `model.` level follows peft's)."""
     return f"{prefix}base_model.model.model.layers.{layer}.self_attn.{proj}.lora_{which}.default.weight"
@@ -239,7 +249,7 @@ def init_lora_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32
         out[keyfn(i, pj, "B")] = B.to(dtype)
 
     # (a config that went through merge_and_unload no longer carries the LoRA configs - ultravox_model.py:555-557 - and means r = 0)
-    for tower, keyfn, nl in (("audio", lora_key, a.encoder_layers), ("text", llm_lora_key, t.num_hidden_layers)):
+    for tower, keyfn, nl in (("audio", audio_lora_key(cfg), a.encoder_layers), ("text", llm_lora_key, t.num_hidden_layers)):
         r = int((getattr(cfg, f"{tower}_model_lora_config", None) or {}).get("r", 0) or 0)
         for i in range(nl if r else 0):
             for pj in lora_targets(cfg, tower):      # (q_proj, k_proj) unless target_modules says otherwise
@@ -247,8 +257,9 @@ def init_lora_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32
     return out
 
 
-def pack_wav2vec2(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.") -> Dict[str, object]:
-    """HF Wav2Vec2Model weights -> the operands of csrc/wav2vec2.hip (layouts: include/uvx.h, uvx_w2v_weights_t)."""
+def pack_wav2vec2(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.", with_transposes: bool = False) -> Dict[str, object]:
+    """HF Wav2Vec2Model weights -> the operands of csrc/wav2vec2.hip (layouts: include/uvx.h, uvx_w2v_weights_t).  with_transposes: the
+    [K_in, N_out] copies of the encoder layers' linears that uvx_wav2vec2_bwd's dgrads read (LoRA training of the tower)."""
     a = cfg.audio_config
     d, H, Cc = a.d_model, a.encoder_attention_heads, a.conv_dim[0]
     scale = (d // H) ** -0.5
@@ -300,6 +311,9 @@ def pack_wav2vec2(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.")
             "fc1_w": cv(W(L + "feed_forward.intermediate_dense.weight")), "fc1_b": cv(W(L + "feed_forward.intermediate_dense.bias")),
             "fc2_w": cv(W(L + "feed_forward.output_dense.weight")), "fc2_b": cv(W(L + "feed_forward.output_dense.bias")),
         })
+        lay = out["layers"][-1]
+        for n, src in (("wqkv_t", "wqkv"), ("wo_t", "wo"), ("fc1_t", "fc1_w"), ("fc2_t", "fc2_w")):
+            lay[n] = lay[src].t().contiguous() if with_transposes else None
     return out
 
 
