@@ -654,3 +654,34 @@ def test_bf16_beam_search_is_consistent_with_its_own_scores():
     assert bool((sc[:, :-1] >= sc[:, 1:]).all())
     for b in range(B):
         assert len({tuple(r.tolist()) for r in seq[b * nb:(b + 1) * nb]}) == nb
+
+
+def test_f32_generate_with_hf_generation_keywords_matches_the_oracle_loop_over_hf_processors():
+    """generate(**kwargs): the reference forwards every keyword to HF `generate` (ultravox_model.py:422-426).  no_repeat_ngram_size / bad_words_ids /
+    min_new_tokens / suppress_tokens / repetition_penalty through the KV-cache decode loop (ultravox_amd/generation.py) against the oracle's cache-free
+    loop applying HF's OWN LogitsProcessorList (built here from transformers.generation.logits_process) - token for token, audio and left padding
+    included; the keywords are chosen from the plain continuation so that each one changes it."""
+    from transformers.generation import logits_process as LP
+    from oracle.reference_cpu import logmel_ref, synthetic_batch
+    cfg, model, oracle = _build(torch.float32, 23)
+    b = synthetic_batch(cfg, 2, 2.0, n_text=20, audio_start=4, n_supervised=4)
+    b.pop("labels")
+    b["audio_values"] = logmel_ref(b.pop("pcm"), 80)
+    b["attention_mask"][1, :3] = 0
+    b["input_ids"][1, :3] = 2
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    T, N, eos = b["input_ids"].shape[1], 8, 2
+    plain = model.generate(max_new_tokens=N, eos_token_id=-1, **gb).cpu()
+    p0, p1 = plain[0, T:].tolist(), plain[1, T:].tolist()
+    kw = dict(no_repeat_ngram_size=2, bad_words_ids=[[p0[1]], [p1[0], p1[1]]], min_new_tokens=5, suppress_tokens=[p1[3]], repetition_penalty=1.3)
+    cpu = torch.device("cpu")
+    procs = LP.LogitsProcessorList([LP.RepetitionPenaltyLogitsProcessor(1.3), LP.NoRepeatNGramLogitsProcessor(2),
+                                    LP.NoBadWordsLogitsProcessor(kw["bad_words_ids"], eos_token_id=[eos]), LP.MinNewTokensLengthLogitsProcessor(T, 5, [eos], device=cpu),
+                                    LP.SuppressTokensLogitsProcessor(kw["suppress_tokens"], device=cpu)])
+    want = oracle.generate_greedy(N, eos_token_id=eos, logits_processor=procs, **b)
+    got = model.generate(max_new_tokens=N, eos_token_id=eos, **kw, **gb).cpu()
+    n = min(got.shape[1], want.shape[1])
+    assert n >= T + 5 and torch.equal(got[:, :n], want[:, :n]), (got[:, T:], want[:, T:])
+    assert not torch.equal(got[:, :plain.shape[1]], plain[:, :got.shape[1]])
+    with pytest.raises(NotImplementedError, match="penalty_alpha"):
+        model.generate(max_new_tokens=2, penalty_alpha=0.6, top_k=4, **gb)

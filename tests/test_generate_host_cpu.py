@@ -197,8 +197,12 @@ def test_terminators_padding_streamer_and_repetition_penalty(model):
         assert out.shape[1] == 13 and out[0, 7 + first + 1:].tolist() == [1] * (5 - first)       # finished row padded
         assert out[1, 7:].tolist() == free[1].tolist()
     assert rec.ended and torch.equal(rec.puts[0], ids) and len(rec.puts) == out.shape[1] - 7 + 1
-    with pytest.warns(UserWarning, match="no effect"):
+    with pytest.warns(UserWarning, match="no effect"):      # reporting / cache-management keywords: no effect on the tokens
+        model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, use_cache=True, output_attentions=False)
+    with pytest.raises(NotImplementedError, match="typical_p"):      # HF would act on it: refused, not ignored
         model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, typical_p=0.9)
+    with pytest.raises(ValueError, match="not used by the model"):   # HF's own message for an unknown keyword
+        model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, no_repeat_ngram=2)
     with pytest.raises(NotImplementedError):
         model.generate(ids, num_beams=4, do_sample=True)
     with pytest.raises(ValueError):
@@ -312,3 +316,112 @@ def test_local_inference_marks_its_states_partial_ok():
     assert not state.partial_ok
     inf.infer(VoiceSample.from_prompt("Hi"))
     assert inf.past_key_values is state and state.partial_ok
+
+
+def _hf():
+    from transformers.generation import logits_process as LP
+    return LP
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_score_processors_match_the_hf_classes(seed):
+    """generation.py restates [3P] transformers.generation.logits_process; every function against the class it cites, on random rows with repeats
+    (prompt + generated ids, left padding included - HF hands the processors the whole row)."""
+    from ultravox_amd import generation as G
+    LP = _hf()
+    g = torch.Generator().manual_seed(seed)
+    B, L, Vv = 5, 17, 23
+    ids = torch.randint(0, 9, (B, L), generator=g)                  # small alphabet: n-grams repeat
+    scores = torch.randn(B, Vv, generator=g) * 3
+    for n in (1, 2, 3, 4, 18, 19):
+        want = LP.NoRepeatNGramLogitsProcessor(n)(ids, scores.clone())
+        assert torch.equal(G.no_repeat_ngram_(scores.clone(), ids, n), want), n
+    assert torch.equal(G.repetition_penalty_(scores.clone(), ids, 1.3), LP.RepetitionPenaltyLogitsProcessor(1.3)(ids, scores.clone()))
+    bad = [[3], [22], [int(ids[0, -1]), 5], [int(ids[1, -2]), int(ids[1, -1]), 7], [1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9], [2]]
+    want = LP.NoBadWordsLogitsProcessor(bad, eos_token_id=[2, 11])(ids, scores.clone())
+    assert torch.equal(G.bad_words_(scores.clone(), ids, bad, [2, 11]), want)
+    dev = torch.device("cpu")
+    assert torch.equal(G.suppress_(scores.clone(), [4, 6]), LP.SuppressTokensLogitsProcessor([4, 6], device=dev)(ids, scores.clone()))
+    assert torch.equal(G.force_(scores.clone(), [6]), LP.ForcedEOSTokenLogitsProcessor(L + 1, 6, device=dev)(ids, scores.clone()))
+    for mp in (0.05, 0.3, 0.9):
+        assert torch.equal(G.min_p_(scores.clone(), mp), LP.MinPLogitsWarper(mp)(ids, scores.clone())), mp
+    # the assembled list in HF's order
+    kw = dict(no_repeat_ngram_size=2, bad_words_ids=bad, min_length=L + 3, min_new_tokens=4, suppress_tokens=[4], begin_suppress_tokens=[8], forced_eos_token_id=6)
+    for prompt_len, cur in ((L, ids), (L - 3, ids), (L - 6, ids)):
+        for max_new in (L - prompt_len + 1, 30):
+            procs = G.ScoreProcessors(kw, prompt_len, max_new, [2, 11], repetition_penalty=1.2)
+            hf = LP.LogitsProcessorList([LP.RepetitionPenaltyLogitsProcessor(1.2), LP.NoRepeatNGramLogitsProcessor(2),
+                                         LP.NoBadWordsLogitsProcessor(bad, eos_token_id=[2, 11]), LP.MinLengthLogitsProcessor(L + 3, [2, 11], device=dev),
+                                         LP.MinNewTokensLengthLogitsProcessor(prompt_len, 4, [2, 11], device=dev),
+                                         LP.ForcedEOSTokenLogitsProcessor(prompt_len + max_new, 6, device=dev), LP.SuppressTokensLogitsProcessor([4], device=dev),
+                                         LP.SuppressTokensAtBeginLogitsProcessor([8], prompt_len, device=dev)])
+            assert procs.active and torch.equal(procs(cur, scores.clone()), hf(cur, scores.clone())), (prompt_len, max_new)
+    assert not G.ScoreProcessors({}, 5, 5, [2]).active
+
+
+@pytest.mark.parametrize("kind", ["ngram", "bad_words", "min_length", "begin_forced_rep"])
+def test_generate_with_score_processors_equals_a_loop_over_the_hf_classes(model, kind):
+    """The decode loop with HF's generation keywords (ultravox_model.py:422-426 forwards them all) against a plain loop that builds HF's OWN
+    LogitsProcessorList and applies it to the same step logits (the simulated device): same tokens, EOS / padding handling included.  The keyword
+    values are chosen from the un-processed continuation so that every processor bites."""
+    LP = _hf()
+    ids, am = left_padded(2, 7, [0, 2], seed=9)
+    N, pad = 8, 1
+    plain = model.generate(ids, attention_mask=am, max_new_tokens=N, eos_token_id=-1)
+    p0, p1 = plain[0, 7:].tolist(), plain[1, 7:].tolist()
+    eos = [p0[3]]                                                   # row 0 would stop at its 4th token
+    kw = {"ngram": dict(no_repeat_ngram_size=1),                     # every id of the prompt (and every earlier pick) is banned
+          "bad_words": dict(bad_words_ids=[[p1[0]], [p0[0], p0[1]]], min_new_tokens=6),
+          "min_length": dict(min_length=7 + 6, suppress_tokens=[p0[1], p1[2]]),
+          "begin_forced_rep": dict(begin_suppress_tokens=[p0[0], p1[0]], forced_eos_token_id=eos[0], repetition_penalty=1.4)}[kind]
+    got = model.generate(ids, attention_mask=am, max_new_tokens=N, eos_token_id=eos, pad_token_id=pad, **kw)
+    dev = torch.device("cpu")
+    procs = LP.LogitsProcessorList()
+    if "repetition_penalty" in kw:
+        procs.append(LP.RepetitionPenaltyLogitsProcessor(kw["repetition_penalty"]))
+    if "no_repeat_ngram_size" in kw:
+        procs.append(LP.NoRepeatNGramLogitsProcessor(kw["no_repeat_ngram_size"]))
+    if "bad_words_ids" in kw:
+        procs.append(LP.NoBadWordsLogitsProcessor(kw["bad_words_ids"], eos_token_id=eos))
+    if "min_length" in kw:
+        procs.append(LP.MinLengthLogitsProcessor(kw["min_length"], eos, device=dev))
+    if "min_new_tokens" in kw:
+        procs.append(LP.MinNewTokensLengthLogitsProcessor(7, kw["min_new_tokens"], eos, device=dev))
+    if "forced_eos_token_id" in kw:
+        procs.append(LP.ForcedEOSTokenLogitsProcessor(7 + N, kw["forced_eos_token_id"], device=dev))
+    if "suppress_tokens" in kw:
+        procs.append(LP.SuppressTokensLogitsProcessor(kw["suppress_tokens"], device=dev))
+    if "begin_suppress_tokens" in kw:
+        procs.append(LP.SuppressTokensAtBeginLogitsProcessor(kw["begin_suppress_tokens"], 7, device=dev))
+    # reference loop on the same simulated device: step logits come from a processor-free generate() that is FORCED along the reference's own tokens
+    seq, unfinished = ids.clone(), torch.ones(2, dtype=torch.bool)
+    for step in range(N):
+        cur_am = torch.cat([am, torch.ones(2, seq.shape[1] - 7, dtype=torch.long)], 1)
+        logits = model.generate(seq, attention_mask=cur_am, max_new_tokens=1, eos_token_id=-1, return_dict_in_generate=True, output_logits=True).logits[0]
+        nxt = procs(seq, logits.float().clone()).argmax(-1)
+        tok = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+        seq = torch.cat([seq, tok[:, None]], 1)
+        unfinished = unfinished & ~torch.isin(tok, torch.tensor(eos))
+        if not bool(unfinished.any()):
+            break
+    assert torch.equal(got, seq)
+    assert not torch.equal(model.generate(ids, attention_mask=am, max_new_tokens=N, eos_token_id=eos, pad_token_id=pad), got)      # the keywords bite
+
+
+def test_custom_logits_processors_and_stopping_criteria(model):
+    """`logits_processor=` / `stopping_criteria=` callables, HF's calling convention: (input_ids incl. the prompt, f32 scores)."""
+    ids, am = left_padded(2, 7, [0, 2], seed=11)
+    seen = []
+
+    def only_even(input_ids, scores):
+        seen.append(input_ids.shape[1])
+        scores[:, 1::2] = float("-inf")
+        return scores
+    out = model.generate(ids, attention_mask=am, max_new_tokens=5, eos_token_id=-1, logits_processor=[only_even])
+    assert seen == [7, 8, 9, 10, 11] and bool((out[:, 7:] % 2 == 0).all())
+    stop_at = lambda input_ids, scores: torch.tensor([input_ids.shape[1] >= 10, False])       # row 0 stops once it is 10 long
+    out = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1, pad_token_id=1, stopping_criteria=[stop_at])
+    assert out.shape[1] == 13 and out[0, 10:].tolist() == [1, 1, 1] and 1 not in out[1, 7:].tolist()
+    assert model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1, stopping_criteria=[lambda i, s: i.shape[1] >= 9]).shape[1] == 9
+    with pytest.raises(NotImplementedError, match="beam search with score processors"):
+        model.generate(ids, attention_mask=am, num_beams=2, no_repeat_ngram_size=2)

@@ -1077,11 +1077,16 @@ class UltravoxModel:
             raise ValueError(f"`repetition_penalty` has to be a strictly positive float, but is {rep}")
         want_logits = bool(kwargs.get("output_logits", False)) and return_dict      # HF: only reported in the dict form
         step_logits = []
-        ignored = set(kwargs) - {"past_key_values", "return_dict_in_generate", "repetition_penalty", "num_beams", "use_cache", "output_logits",
-                                 "length_penalty", "early_stopping", "num_return_sequences", "output_scores"}
+        # the rest of HF's generation keywords (ultravox_model.py:422-426 forwards them all): score processors / stopping criteria are applied in the
+        # loop below (generation.py); fields HF would act on and this loop does not build RAISE - ignoring them would return other tokens
+        from . import generation
+        ignored = generation.check_kwargs(kwargs, ("past_key_values", "return_dict_in_generate", "repetition_penalty", "num_beams", "output_logits",
+                                                   "length_penalty", "early_stopping", "num_return_sequences", "output_scores"))
         if ignored:
             import warnings
-            warnings.warn(f"generate(): these arguments have no effect here: {sorted(ignored)}")
+            warnings.warn(f"generate(): these arguments have no effect here: {ignored}")
+        crit = list(kwargs.get("stopping_criteria") or [])
+        min_p = kwargs.get("min_p")
         if past is not None and not isinstance(past, KVState):
             raise TypeError("past_key_values must be the KVState a previous generate(return_dict_in_generate=True) returned")
         num_beams = int(kwargs.get("num_beams", 1) or 1)
@@ -1095,6 +1100,9 @@ class UltravoxModel:
                 raise NotImplementedError("beam search starts from the prompt: past_key_values is not supported with num_beams > 1")
             if nrs > num_beams:
                 raise ValueError(f"`num_return_sequences` ({nrs}) has to be smaller or equal to `num_beams` ({num_beams}).")
+            if crit or any(kwargs.get(k) for k in generation.HANDLED):
+                raise NotImplementedError("beam search with score processors other than repetition_penalty / stopping criteria is not built: "
+                                          f"{sorted(k for k in generation.HANDLED if kwargs.get(k))}")
         elif nrs != 1:
             raise ValueError(f"Greedy methods without beam search do not support `num_return_sequences` different than 1 (got {nrs}).")
         if do_sample and not temperature > 0:
@@ -1117,6 +1125,7 @@ class UltravoxModel:
             raise ValueError(f"prompt + max_new_tokens = {Tmax} exceeds the RoPE table ({self._llm['rope_len']})")
         ids_dev = input_ids.to(dev)
         am = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        procs = generation.ScoreProcessors(kwargs, T, max_new_tokens, eos_list, rep)
         if num_beams > 1:
             lp = kwargs.get("length_penalty")
             return self._beam_search(inputs_embeds, ids_dev, am, max_new_tokens, eos_list, pad_token_id, num_beams,
@@ -1174,7 +1183,7 @@ class UltravoxModel:
         # Greedy decoding without score processors (the BASELINE inference configuration): the loop's per-token bookkeeping - argmax, pad once a
         # sequence has finished, the EOS test, the next RoPE position - is ONE launch (uvx_greedy_select) and one 4-byte read-back instead of
         # argmax + eight small torch kernels (round 6; profiles/r05_decode70_b8_kernel_stats.txt lists them as at::native rows).  Same tokens.
-        if rep is None and not do_sample and not want_logits and os.environ.get("UVX_GREEDY_SELECT", "1") != "0":
+        if not procs.active and not crit and not do_sample and not want_logits and os.environ.get("UVX_GREEDY_SELECT", "1") != "0":
             seq = torch.empty(B, T + max_new_tokens, device=dev, dtype=torch.int64)
             seq[:, :T] = ids_dev
             live = torch.ones(B, device=dev, dtype=torch.int32)
@@ -1200,11 +1209,11 @@ class UltravoxModel:
         for step in range(max_new_tokens):
             if want_logits:
                 step_logits.append(logits.clone())
-            if rep is not None:      # HF order: logits processors on f32 scores first, then the warpers / argmax
-                scores = self._repetition_penalty(logits.float(), torch.cat(out, dim=1), rep)
-                nxt = self._sample(scores, temperature, top_k, top_p, generator) if do_sample else torch.argmax(scores, dim=-1)
+            if procs.active:      # HF order: logits processors on f32 scores first (generation.py), then the warpers / argmax
+                scores = procs(torch.cat(out, dim=1), logits.float())
+                nxt = self._sample(scores, temperature, top_k, top_p, generator, min_p) if do_sample else torch.argmax(scores, dim=-1)
             elif do_sample:
-                nxt = self._sample(logits, temperature, top_k, top_p, generator)
+                nxt = self._sample(logits, temperature, top_k, top_p, generator, min_p)
             else:
                 check(l.uvx_argmax(stream_ptr(), self.code, ptr(logits), B, V, ptr(nxt)), "uvx_argmax")
             tok = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
@@ -1212,6 +1221,8 @@ class UltravoxModel:
             if streamer is not None:
                 streamer.put(tok.cpu())
             unfinished = unfinished & ~torch.isin(tok, eos_ids)
+            if crit:              # [3P] StoppingCriteriaList on the sequence INCLUDING the new token, OR-ed with the EOS test
+                unfinished = unfinished & ~generation.stopped(crit, torch.cat(out, dim=1), logits.float())
             if step + 1 == max_new_tokens or not bool(unfinished.any()):
                 break
             tok = tok.contiguous()
@@ -1352,9 +1363,9 @@ class UltravoxModel:
         return scores.scatter_(1, seen_ids, s)
 
     @staticmethod
-    def _sample(logits: torch.Tensor, temperature: float, top_k, top_p, generator) -> torch.Tensor:
+    def _sample(logits: torch.Tensor, temperature: float, top_k, top_p, generator, min_p=None) -> torch.Tensor:
         """HF's sampling policy on the last-position logits (the reference's inference default, infer.py:317-324):
-        TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> multinomial.  Host-side policy on [B, V]."""
+        TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper (-> MinPLogitsWarper) -> multinomial.  Host-side policy on [B, V]."""
         x = logits.float() / temperature
         if top_k is not None and top_k > 0:
             kth = torch.topk(x, min(int(top_k), x.shape[-1]), dim=-1).values[:, -1:]
@@ -1365,6 +1376,9 @@ class UltravoxModel:
             remove = cum <= (1.0 - top_p)
             remove[:, -1] = False                                  # keep at least the most likely token
             x = x.masked_fill(remove.scatter(1, si, remove), float("-inf"))
+        if min_p is not None:
+            from .generation import min_p_
+            x = min_p_(x, float(min_p))
         return torch.multinomial(torch.softmax(x, dim=-1), 1, generator=generator)[:, 0]
 
     def forward_backward(self, grad_scale: float = 1.0, **batch) -> torch.Tensor:
