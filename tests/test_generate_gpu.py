@@ -605,7 +605,7 @@ def test_decode_rmsnorm_inside_the_staged_skinny_kernel(B, family):
 
 
 @pytest.mark.parametrize("case", [dict(num_beams=3), dict(num_beams=4, length_penalty=0.0, num_return_sequences=2), dict(num_beams=2, early_stopping=True),
-                                  dict(num_beams=3, repetition_penalty=1.5)])
+                                  dict(num_beams=3, repetition_penalty=1.5), dict(num_beams=3, no_repeat_ngram_size=2, min_new_tokens=4, bad_words_ids=[[40], [41, 42]])])
 @pytest.mark.parametrize("n_eos", [1, 120])
 def test_f32_beam_search_matches_the_oracle_tokens(case, n_eos):
     """generate(num_beams > 1) (the reference forwards the keyword to HF's generate, ultravox_model.py:422-426): the HIP path (one
@@ -628,7 +628,9 @@ def test_f32_beam_search_matches_the_oracle_tokens(case, n_eos):
     b["input_ids"], b["attention_mask"] = ids, am
     b["audio_token_start_idx"] = b["audio_token_start_idx"] + (width - T)
     eos = 2 if n_eos == 1 else list(range(7, 7 + n_eos))
-    want = oracle.generate_beam(7, eos_token_id=eos, pad_token_id=1, **case, **b)
+    from test_oracle_pinning import hf_processor_list
+    plain, procs = hf_processor_list(case, width, eos)      # (HF's own processor classes for the oracle; the keywords themselves for the HIP path)
+    want = oracle.generate_beam(7, eos_token_id=eos, pad_token_id=1, logits_processor=procs, **plain, **b)
     got = model.generate(max_new_tokens=7, eos_token_id=eos, pad_token_id=1, **case, **{k: v.to(DEV) for k, v in b.items()}).cpu()
     assert got.shape == want.shape and torch.equal(got, want), (got[:, width:], want[:, width:])
 

@@ -226,7 +226,8 @@ def test_terminators_padding_streamer_and_repetition_penalty(model):
 
 
 @pytest.mark.parametrize("case", [dict(num_beams=3), dict(num_beams=4, length_penalty=0.0, num_return_sequences=2), dict(num_beams=2, early_stopping=True),
-                                  dict(num_beams=3, early_stopping="never", length_penalty=2.0), dict(num_beams=3, repetition_penalty=3.0)])
+                                  dict(num_beams=3, early_stopping="never", length_penalty=2.0), dict(num_beams=3, repetition_penalty=3.0),
+                                  dict(num_beams=3, no_repeat_ngram_size=1, min_new_tokens=3, bad_words_ids=[[50], [51, 52]])])
 @pytest.mark.parametrize("n_eos", [1, 30])
 def test_beam_search_host_logic_against_the_oracle_restatement(model, case, n_eos):
     """generate(num_beams > 1) on the simulated device against the oracle's list-based restatement of HF's beam search
@@ -254,9 +255,10 @@ def test_beam_search_host_logic_against_the_oracle_restatement(model, case, n_eo
                 pos = torch.cat([pos, int(keep.sum()) + torch.arange(len(toks))]).float()
                 out[b, j] = bump(int(round(float((feat[lo:] * (pos[lo:] + 1.0)).sum()))) % V)
         return out
-    kw = {k: v for k, v in case.items() if k != "num_beams"}
+    from test_oracle_pinning import hf_processor_list
+    kw, procs = hf_processor_list({k: v for k, v in case.items() if k != "num_beams"}, 8, eos)
     want = beam_search_ref(next_logits, ids, 6, eos, 1, case["num_beams"], kw.get("length_penalty", 1.0), kw.get("early_stopping", False),
-                           kw.get("num_return_sequences", 1), kw.get("repetition_penalty"))
+                           kw.get("num_return_sequences", 1), kw.get("repetition_penalty"), procs)
     model.fake.calls.clear()
     got = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=eos, pad_token_id=1, **case)
     assert got.shape == want.shape and torch.equal(got, want), (got[:, 8:], want[:, 8:])
@@ -423,5 +425,5 @@ def test_custom_logits_processors_and_stopping_criteria(model):
     out = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1, pad_token_id=1, stopping_criteria=[stop_at])
     assert out.shape[1] == 13 and out[0, 10:].tolist() == [1, 1, 1] and 1 not in out[1, 7:].tolist()
     assert model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1, stopping_criteria=[lambda i, s: i.shape[1] >= 9]).shape[1] == 9
-    with pytest.raises(NotImplementedError, match="beam search with score processors"):
-        model.generate(ids, attention_mask=am, num_beams=2, no_repeat_ngram_size=2)
+    with pytest.raises(NotImplementedError, match="beam search with stopping_criteria"):
+        model.generate(ids, attention_mask=am, num_beams=2, stopping_criteria=[stop_at])

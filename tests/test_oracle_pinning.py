@@ -242,7 +242,24 @@ def test_greedy_generate_matches_hf_generate_with_left_padding():
 
 BEAM_CASES = [dict(num_beams=3), dict(num_beams=4, length_penalty=0.0), dict(num_beams=2, early_stopping=True),
               dict(num_beams=3, num_return_sequences=2, length_penalty=2.0), dict(num_beams=3, early_stopping="never"),
-              dict(num_beams=5, num_return_sequences=3, early_stopping=True), dict(num_beams=3, repetition_penalty=1.7)]
+              dict(num_beams=5, num_return_sequences=3, early_stopping=True), dict(num_beams=3, repetition_penalty=1.7),
+              # HF's other score processors inside the beam search (they see the log-probabilities of prompt + hypothesis)
+              dict(num_beams=3, no_repeat_ngram_size=2), dict(num_beams=2, min_new_tokens=4, bad_words_ids=[[40], [41, 42]], repetition_penalty=1.3)]
+PROC_KEYS = ("no_repeat_ngram_size", "min_new_tokens", "bad_words_ids")
+
+
+def hf_processor_list(case, prompt_len, eos):
+    """(the case without the processor keywords, a [3P] HF LogitsProcessorList for them - HF's own classes, for the oracle's loops)"""
+    from transformers.generation import logits_process as LP
+    eos = list(eos) if isinstance(eos, (list, tuple)) else [eos]
+    procs = LP.LogitsProcessorList()
+    if "no_repeat_ngram_size" in case:
+        procs.append(LP.NoRepeatNGramLogitsProcessor(case["no_repeat_ngram_size"]))
+    if "bad_words_ids" in case:
+        procs.append(LP.NoBadWordsLogitsProcessor(case["bad_words_ids"], eos_token_id=eos))
+    if "min_new_tokens" in case:
+        procs.append(LP.MinNewTokensLengthLogitsProcessor(prompt_len, case["min_new_tokens"], eos, device=torch.device("cpu")))
+    return {k: v for k, v in case.items() if k not in PROC_KEYS}, (procs if len(procs) else None)
 
 
 @pytest.mark.parametrize("n_eos", [1, 85, 200])
@@ -276,7 +293,8 @@ def test_beam_search_matches_hf_generate(n_eos):
     for case in BEAM_CASES:
         with torch.no_grad():
             want = hf.generate(input_ids=ids, attention_mask=am, max_new_tokens=7, do_sample=False, eos_token_id=eos, pad_token_id=3, **case)
-        got = om.generate_beam(7, eos_token_id=eos, pad_token_id=3, input_ids=ids, attention_mask=am, **case)
+        plain, procs = hf_processor_list(case, T, eos)
+        got = om.generate_beam(7, eos_token_id=eos, pad_token_id=3, input_ids=ids, attention_mask=am, logits_processor=procs, **plain)
         assert got.shape == want.shape and torch.equal(got, want), (case, got[:, T:], want[:, T:])
         short += int(want.shape[1] < T + 7 or bool((want[:, -1] == 3).any()))
     assert n_eos == 1 or short > 0          # (the many-terminator settings must actually end hypotheses early)

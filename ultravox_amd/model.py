@@ -1100,9 +1100,8 @@ class UltravoxModel:
                 raise NotImplementedError("beam search starts from the prompt: past_key_values is not supported with num_beams > 1")
             if nrs > num_beams:
                 raise ValueError(f"`num_return_sequences` ({nrs}) has to be smaller or equal to `num_beams` ({num_beams}).")
-            if crit or any(kwargs.get(k) for k in generation.HANDLED):
-                raise NotImplementedError("beam search with score processors other than repetition_penalty / stopping criteria is not built: "
-                                          f"{sorted(k for k in generation.HANDLED if kwargs.get(k))}")
+            if crit or min_p is not None:
+                raise NotImplementedError("beam search with stopping_criteria / sampling warpers is not built")
         elif nrs != 1:
             raise ValueError(f"Greedy methods without beam search do not support `num_return_sequences` different than 1 (got {nrs}).")
         if do_sample and not temperature > 0:
@@ -1129,7 +1128,7 @@ class UltravoxModel:
         if num_beams > 1:
             lp = kwargs.get("length_penalty")
             return self._beam_search(inputs_embeds, ids_dev, am, max_new_tokens, eos_list, pad_token_id, num_beams,
-                                     1.0 if lp is None else float(lp), kwargs.get("early_stopping", False), nrs, rep, return_dict)
+                                     1.0 if lp is None else float(lp), kwargs.get("early_stopping", False), nrs, procs, return_dict)
         # A cache handed in is reused only while it still describes this prompt's prefix (HF trusts the caller here; a
         # re-tokenised reply that no longer matches would silently corrupt the dialogue, so it is checked and dropped).
         P = 0
@@ -1244,8 +1243,7 @@ class UltravoxModel:
         return GenerateOutput(sequences=sequences, past_key_values=state, logits=tuple(step_logits) if want_logits else None)
 
     def _beam_search(self, inputs_embeds: torch.Tensor, ids_dev: torch.Tensor, am: Optional[torch.Tensor], max_new_tokens: int, eos_list,
-                     pad_token_id: Optional[int], nb: int, length_penalty: float, early_stopping, nrs: int, rep: Optional[float],
-                     return_dict: bool):
+                     pad_token_id: Optional[int], nb: int, length_penalty: float, early_stopping, nrs: int, procs, return_dict: bool):
         """generate(num_beams > 1): the reference forwards the keyword to [3P] HF `generate` (ultravox_model.py:422-426), i.e. HF's beam
         search.  Here: ONE prefill of the B prompts, the KV cache rows then replicated per beam ([L][2][B * beams][Tmax][..]); every step is
         a decode batch of B * beams rows through uvx_llm_decode, the search policy runs on the [B, beams * V] f32 log-probabilities on the
@@ -1304,8 +1302,8 @@ class UltravoxModel:
         take = torch.take_along_dim
         for s in range(Lg):
             logp = torch.log_softmax(logits.float(), dim=-1)
-            if rep is not None:                                   # HF: the processors see the log-probabilities of the flat running sequences
-                logp = self._repetition_penalty(logp, torch.cat([prompt_flat, run_seq.view(BB, Lg)[:, :s]], dim=1), rep)
+            if procs.active:                                      # HF: the processors (generation.py) see the log-probabilities of the flat running sequences
+                logp = procs(torch.cat([prompt_flat, run_seq.view(BB, Lg)[:, :s]], dim=1), logp)
             acc = (logp.view(B, nb, V) + run_sc[:, :, None]).view(B, nb * V)
             vals, idx = torch.topk(acc, K, dim=1)
             src, tok = idx // V, idx % V
