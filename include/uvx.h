@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 17
+#define UVX_ABI_VERSION 18
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -122,16 +122,17 @@ typedef struct {
  * applied by peft through apply_lora, ultravox_model.py:690-709): peft layouts, lora_A.weight [r, in] and lora_B.weight [out, r] in
  * the cfg dtype; result += lora_B(lora_A(x)) * scaling with scaling = lora_alpha / r.  Gradients: f32, same shapes.
  * q, k = q_proj / k_proj (the reference's default target_modules that exist in Whisper / Llama); v = v_proj; o = out_proj (Whisper) /
- * o_proj (the LLMs) - ABI 17.  A projection whose `a` is NULL is not adapted (its `b` and its gradient pointers are ignored). */
+ * o_proj (the LLMs) - ABI 17; g, u, d = the MLP's linears (ABI 18): g = fc1 (Whisper) / gate_proj (the LLMs), u = up_proj (the LLMs only), d = fc2 /
+ * down_proj.  A projection whose `a` is NULL is not adapted (its `b` and its gradient pointers are ignored). */
 typedef struct { const void *a, *b; } uvx_lora_proj_t;
-typedef struct { uvx_lora_proj_t q, k, v, o; } uvx_enc_lora_layer_t;
+typedef struct { uvx_lora_proj_t q, k, v, o, g, u, d; } uvx_enc_lora_layer_t;
 typedef struct {
   int32_t r;       /* 1..64 */
   float scaling;
   const uvx_enc_lora_layer_t* layers; /* HOST array [enc_layers] */
 } uvx_encoder_lora_t;
 typedef struct { float *a, *b; } uvx_lora_proj_grad_t;
-typedef struct { uvx_lora_proj_grad_t q, k, v, o; } uvx_enc_lora_layer_grads_t;
+typedef struct { uvx_lora_proj_grad_t q, k, v, o, g, u, d; } uvx_enc_lora_layer_grads_t;
 typedef struct { const uvx_enc_lora_layer_grads_t* layers; } uvx_encoder_lora_grads_t;
 
 /* multi_modal_projector.{ln_pre,linear_1,ln_mid|ln_post,linear_2}.weight (ultravox_model.py:749-766) */

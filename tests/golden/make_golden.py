@@ -550,7 +550,8 @@ def lora_targets_cases():
             if "lora_B" in n:
                 p.data = 0.05 * torch.randn(p.shape, generator=g)
 
-    for case, targets, r in (("all", ["q_proj", "k_proj", "v_proj", "out_proj", "o_proj"], 4), ("vo", ["v_proj", "out_proj", "o_proj"], 2)):
+    for case, targets, r in (("all", ["q_proj", "k_proj", "v_proj", "out_proj", "o_proj"], 4), ("vo", ["v_proj", "out_proj", "o_proj"], 2),
+                             ("mlp", ["q_proj", "fc1", "fc2", "gate_proj", "up_proj", "down_proj"], 4)):      # the MLP's linears next to one attention projection
         lcfg = dataclasses.asdict(simp(r=r, lora_alpha=6, target_modules=targets))
         cm = meta["cases"][case] = {"lora_config": dict(lcfg)}
         # ---- encoder ----

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in header_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in include/uvx.h but not exported by libuvx.so: {missing}"
     assert set(_lib.EXPORTS) == set(header_functions())
-    assert lib.uvx_abi_version() == _lib.ABI_VERSION == 17
+    assert lib.uvx_abi_version() == _lib.ABI_VERSION == 18
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():
@@ -60,7 +60,7 @@ def test_struct_mirrors_match_header_sizes():
     assert n_fields == len(_lib.Config._fields_)
     assert ctypes.sizeof(_lib.Config) == 4 * n_fields
     assert ctypes.sizeof(_lib.EncLayer) == 8 * 16 and ctypes.sizeof(_lib.LlmLayer) == 8 * 15
-    assert ctypes.sizeof(_lib.EncLoraLayer) == 64 and ctypes.sizeof(_lib.EncoderLora) == 16
+    assert ctypes.sizeof(_lib.EncLoraLayer) == 112 and ctypes.sizeof(_lib.EncoderLora) == 16
 
 
 def test_argument_errors_are_reported_without_a_gpu():

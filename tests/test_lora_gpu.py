@@ -424,6 +424,86 @@ def test_lora_on_v_and_o_merges_and_decodes_like_the_adapter_forward(dtype):
     assert torch.equal(merged, out)
 
 
+MLP_T = ["q_proj", "fc1", "fc2", "gate_proj", "up_proj", "down_proj"]
+
+
+@pytest.mark.parametrize("targets", [MLP_T, ["fc2", "up_proj"], ["fc1", "gate_proj", "down_proj", "v_proj"]], ids=["q+mlp", "fc2+up", "fc1+gate+down+v"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lora_on_the_mlp_linears_train_step_matches_oracle(dtype, targets):
+    """target_modules naming the MLP's linears (ultravox_config.py:19-21 hands any list to peft, ultravox_model.py:695-707): fc1 / fc2 in the
+    Whisper encoder, gate_proj / up_proj / down_proj in the LLM - ABI 18's uvx_enc_lora_layer_t.g / .u / .d.  The fc1 / gate / up terms join the
+    pre-activation (so the fused GELU / SwiGLU epilogues step aside), the fc2 / down terms the residual branch.  Loss, logits, the projector's and
+    every adapter matrix's gradient against the oracle's autograd (pinned to the reference's apply_lora by lora_targets_reference.npz, case "mlp")."""
+    from ultravox_amd.config import LORA_ATTN_MODULES, LORA_MLP_MODULES
+    cfg, sd, model, oracle, gb, ob, mel = _targets_setup(dtype, targets)
+    ne, nl = cfg.audio_config.encoder_layers, cfg.text_config.num_hidden_layers
+    n_a = len([m for m in targets if m in LORA_ATTN_MODULES["audio"] + LORA_MLP_MODULES["audio"]])
+    n_t = len([m for m in targets if m in LORA_ATTN_MODULES["text"] + LORA_MLP_MODULES["text"]])
+    assert len(oracle.trainable) == 4 + 2 * n_a * ne + 2 * n_t * nl
+    ref, grads, _ = oracle.train_step(ob)
+    out = model.forward(audio_values=mel, **gb)
+    if dtype == torch.float32:
+        assert (out.logits.cpu() - ref["logits"]).abs().max().item() < 1e-3
+    else:
+        assert rel_l2(out.logits, ref["logits"]) < 3e-2
+    model.train()
+    loss = model.forward_backward(audio_values=mel, **gb)
+    assert abs(loss.item() - ref["loss"].item()) < (1e-4 if dtype == torch.float32 else 2e-2) * abs(ref["loss"].item())
+    mine = model.projector_grads()
+    assert set(mine) == set(grads)
+    tol = 2e-3 if dtype == torch.float32 else 8e-2
+    for k, g in grads.items():
+        assert g.abs().max().item() > 0, k
+        assert rel_l2(mine[k], g) < tol, (k, rel_l2(mine[k], g))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lora_on_the_mlp_linears_merges_and_decodes_like_the_adapter_forward(dtype):
+    """merge_and_unload and the per-call fold of generate() with MLP adapters: the folded fc1 / fc2 / gate|up rows (alternating 16-row blocks of
+    the packed matrix) / down_proj give the adapter forward's logits; the un-merged model decodes the merged model's tokens and its weights come
+    back bit for bit."""
+    cfg, sd, model, oracle, gb, ob, mel = _targets_setup(dtype, MLP_T, seed=61)
+    before = model.forward(audio_values=mel, **gb).logits.float()
+    keep = [(L["wgu"].clone(), L["wd"].clone()) for L in model._llm["layers"]]
+    gen = {k: v for k, v in gb.items() if k != "labels"}
+    model.eval()
+    out = model.generate(audio_values=mel, max_new_tokens=4, eos_token_id=-1, **gen)
+    assert all(torch.equal(L["wgu"], a) and torch.equal(L["wd"], b) for L, (a, b) in zip(model._llm["layers"], keep))
+    model.merge_and_unload()
+    assert all(not torch.equal(L["wgu"], a) and not torch.equal(L["wd"], b) for L, (a, b) in zip(model._llm["layers"], keep))
+    after = model.forward(audio_values=mel, **gb).logits.float()
+    assert rel_l2(after, before) < (1e-5 if dtype == torch.float32 else 2e-2)
+    merged = model.generate(audio_values=mel, max_new_tokens=4, eos_token_id=-1, **gen)
+    assert torch.equal(merged, out)
+
+
+def test_lora_on_the_mlp_of_a_gemma3_backbone_joins_the_branch_before_its_post_norm():
+    """Gemma-3: down_proj's output is normalised (post_feedforward_layernorm) before the residual add, the activation is GeGLU - the down_proj
+    adapter's term and its gradient sit BEHIND that norm.  f32 against the oracle's autograd."""
+    from oracle.reference_cpu import OracleModel, logmel_ref, synthetic_batch
+    from test_gemma3_gpu import _cfg
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    cfg = _cfg(layers=3, text_model_lora_config={"r": 4, "lora_alpha": 8, "target_modules": ["q_proj", "gate_proj", "up_proj", "down_proj"]})
+    sd = random_state_dict(cfg, seed=67)
+    sd.update(init_lora_state_dict(cfg, seed=67, random_b=True))
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.float32)
+    oracle = OracleModel(cfg, sd, dtype=torch.float32)
+    assert len(oracle.trainable) == 4 + 8 * 3
+    b = synthetic_batch(cfg, 2, 2.0, n_text=24, audio_start=5, n_supervised=8)
+    b["audio_values"] = logmel_ref(b.pop("pcm"), 80)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    ref, grads, _ = oracle.train_step(b)
+    model.train()
+    loss = model.forward_backward(**gb)
+    assert abs(loss.item() - ref["loss"].item()) < 1e-4 * abs(ref["loss"].item())
+    mine = model.projector_grads()
+    assert set(mine) == set(grads)
+    for k, g in grads.items():
+        assert g.abs().max().item() > 0, k
+        assert rel_l2(mine[k], g) < 2e-3, (k, rel_l2(mine[k], g))
+
+
 def test_lora_on_o_proj_of_a_gemma3_backbone_joins_the_branch_before_its_post_norm():
     """Gemma-3's decoder layer normalises o_proj's output (post_attention_layernorm) before the residual add: the o_proj adapter's term and
     its gradient sit BEHIND that norm (and q / k adapters in front of q_norm / k_norm).  f32 against the oracle's autograd."""

@@ -414,12 +414,13 @@ def test_lora_restatement_matches_reference_apply_lora_fixture(golden_dir):
         np.testing.assert_allclose(sd["language_model." + n].grad.numpy(), z["llm.g." + n], rtol=2e-4, atol=2e-5, err_msg=n)
 
 
-@pytest.mark.parametrize("case", ["all", "vo"])
+@pytest.mark.parametrize("case", ["all", "vo", "mlp"])
 def test_lora_target_modules_beyond_the_default_match_the_reference_apply_lora(golden_dir, case):
     """target_modules is a config field the reference hands to peft unchanged (ultravox_config.py:19-21, ultravox_model.py:695, 707).
     Fixture lora_targets_reference.npz: the reference's apply_lora (tests/peft_stub.py) with q / k / v / out_proj / o_proj ("all") and a
     v + o-only list ("vo") on an HF WhisperEncoder and a GQA LlamaForCausalLM - which modules our config resolves, the key names, and the
-    oracle's forward / adapter gradients with adapters on v_proj and on the output projection."""
+    oracle's forward / adapter gradients with adapters on v_proj and on the output projection.  "mlp": q_proj next to the MLP's linears
+    (fc1 / fc2 in Whisper, gate_proj / up_proj / down_proj in Llama; ABI 18)."""
     import json
     from ultravox_amd.config import lora_target_modules
     from ultravox_amd.weights import init_lora_state_dict, lora_targets
@@ -428,8 +429,8 @@ def test_lora_target_modules_beyond_the_default_match_the_reference_apply_lora(g
     cm = meta["cases"][case]
     lc = cm["lora_config"]
     cfg = UltravoxConfig(**meta["tiny"], audio_model_lora_config=lc, text_model_lora_config=lc)
-    want_a = ("q_proj", "k_proj", "v_proj", "out_proj") if case == "all" else ("v_proj", "out_proj")
-    want_t = ("q_proj", "k_proj", "v_proj", "o_proj") if case == "all" else ("v_proj", "o_proj")
+    want_a = {"all": ("q_proj", "k_proj", "v_proj", "out_proj"), "vo": ("v_proj", "out_proj"), "mlp": ("q_proj", "fc1", "fc2")}[case]
+    want_t = {"all": ("q_proj", "k_proj", "v_proj", "o_proj"), "vo": ("v_proj", "o_proj"), "mlp": ("q_proj", "gate_proj", "up_proj", "down_proj")}[case]
     assert lora_targets(cfg, "audio") == want_a and lora_targets(cfg, "text") == want_t
     enc_names = {"audio_tower." + n for n in cm["encoder"]["trainable"]}
     llm_names = {"language_model." + n for n in cm["llm"]["trainable"]}
@@ -442,8 +443,8 @@ def test_lora_target_modules_beyond_the_default_match_the_reference_apply_lora(g
     with pytest.raises(ValueError) as e:
         lora_target_modules({"r": 2, "target_modules": ["linear_k"]}, "audio")
     assert meta["no_hit_error"] is not None and str(e.value) == meta["no_hit_error"]
-    with pytest.raises(ValueError, match="MLP"):
-        UltravoxConfig(**meta["tiny"], audio_model_lora_config={"r": 2, "target_modules": ["q_proj", "fc1"]})
+    with pytest.raises(ValueError, match="lm_head"):      # what is not built is refused by name, not silently left un-adapted
+        UltravoxConfig(**meta["tiny"], text_model_lora_config={"r": 2, "target_modules": ["q_proj", "lm_head"]})
     sd = random_state_dict(cfg, seed=meta["seed"])
     for tower, prefix in (("enc", "audio_tower."), ("llm", "language_model.")):
         for k in z.files:

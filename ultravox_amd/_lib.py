@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 17  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+ABI_VERSION = 18  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
 
 
 def lib() -> C.CDLL:
@@ -135,7 +135,7 @@ class LoraProj(C.Structure):
 
 
 class EncLoraLayer(C.Structure):
-    _fields_ = [("q", LoraProj), ("k", LoraProj), ("v", LoraProj), ("o", LoraProj)]      # a NULL `a` = not adapted (ABI 17)
+    _fields_ = [("q", LoraProj), ("k", LoraProj), ("v", LoraProj), ("o", LoraProj), ("g", LoraProj), ("u", LoraProj), ("d", LoraProj)]      # a NULL `a` = not adapted (ABI 17 / 18)
 
 
 class EncoderLora(C.Structure):

@@ -397,23 +397,26 @@ def _check_supported(cls, get) -> None:
 PROJECTOR_ACTS = {"swiglu": 0, "silu": 1, "swish": 1, "gelu_pytorch_tanh": 2, "gelu": 3, "relu": 4}
 
 
-# the attention projections a tower has, in the order of uvx_enc_lora_layer_t's fields (q, k, v, o), and its other nn.Linear leaves
-LORA_ATTN_MODULES = {"audio": ("q_proj", "k_proj", "v_proj", "out_proj"), "text": ("q_proj", "k_proj", "v_proj", "o_proj")}
-LORA_MLP_MODULES = {"audio": ("fc1", "fc2"), "text": ("gate_proj", "up_proj", "down_proj")}
+# the nn.Linear leaves of a tower's layers, in the order of uvx_enc_lora_layer_t's fields (q, k, v, o | g, u, d).  "audio_w2v": the wav2vec2 tower, whose
+# feed-forward linears (intermediate_dense / output_dense) have no adapter slot
+LORA_ATTN_MODULES = {"audio": ("q_proj", "k_proj", "v_proj", "out_proj"), "audio_w2v": ("q_proj", "k_proj", "v_proj", "out_proj"),
+                     "text": ("q_proj", "k_proj", "v_proj", "o_proj")}
+LORA_MLP_MODULES = {"audio": ("fc1", "fc2"), "audio_w2v": (), "text": ("gate_proj", "up_proj", "down_proj")}
+LORA_UNBUILT_MODULES = {"audio": (), "audio_w2v": ("intermediate_dense", "output_dense", "projection"), "text": ("lm_head",)}
 LORA_DEFAULT_TARGETS = ("k_proj", "q_proj", "linear_k", "linear_q")      # LoraConfigSimplified.target_modules, ultravox_config.py:19-21
 
 
 def lora_target_modules(lora_config, tower: str):
-    """Which attention projections of `tower` ("audio": WhisperEncoder, "text": the LLM) peft adapts for this
-    LoraConfigSimplified dict: target_modules is matched by module-name suffix ([3P] peft check_target_module_exists, restated in
-    tests/peft_stub.py), so names a tower does not have (linear_k, o_proj in Whisper, out_proj in Llama) are ignored as long as one
-    name hits.  Returned in the field order of uvx_enc_lora_layer_t."""
+    """Which linears of `tower` ("audio": WhisperEncoder, "audio_w2v": Wav2Vec2Model, "text": the LLM) peft adapts for this LoraConfigSimplified
+    dict: target_modules is matched by module-name suffix ([3P] peft check_target_module_exists, restated in tests/peft_stub.py), so names a tower
+    does not have (linear_k, o_proj in Whisper, out_proj in Llama) are ignored as long as one name hits.  Returned in the field order of
+    uvx_enc_lora_layer_t: the attention projections, then the MLP's linears (ABI 18)."""
     tm = list((lora_config or {}).get("target_modules") or LORA_DEFAULT_TARGETS)
-    mlp = [m for m in LORA_MLP_MODULES[tower] if m in tm]
-    if mlp:
-        raise ValueError(f"{tower}_model_lora_config.target_modules = {tm}: adapters on the MLP linears {mlp} are not built "
-                         f"(the attention projections {list(LORA_ATTN_MODULES[tower])} are)")
-    hit = tuple(m for m in LORA_ATTN_MODULES[tower] if m in tm)
+    unbuilt = [m for m in LORA_UNBUILT_MODULES[tower] if m in tm]
+    if unbuilt:
+        raise ValueError(f"{tower}_model_lora_config.target_modules = {tm}: adapters on {unbuilt} are not built "
+                         f"({list(LORA_ATTN_MODULES[tower] + LORA_MLP_MODULES[tower])} are)")
+    hit = tuple(m for m in LORA_ATTN_MODULES[tower] + LORA_MLP_MODULES[tower] if m in tm)
     if not hit:
         raise ValueError(f"Target modules {tm} not found in the base model.")      # peft's message
     return hit
@@ -456,7 +459,7 @@ class UltravoxConfig:
                              "ultravox_config.py:126)")
         # LoRA (apply_lora, ultravox_model.py:690-709): rank-r adapters on the attention projections target_modules names (peft's
         # suffix match; the default list hits q_proj + k_proj in Whisper / Llama) of the encoder (the release configs: r = 8) and / or
-        # the LLM.  lora_target_modules() below resolves the list; MLP linears are refused, not silently left un-adapted.
+        # the LLM.  lora_target_modules() above resolves the list (attention projections and the MLP's linears; what is not built is refused by name).
         for name, lc in (("audio", self.audio_model_lora_config), ("text", self.text_model_lora_config)):
             ar = int(lc.get("r", 0) or 0)
             if lc.get("unfreeze_layers"):
@@ -467,7 +470,7 @@ class UltravoxConfig:
                 continue
             if not 0 < ar <= 64:
                 raise ValueError(f"{name}_model_lora_config.r = {ar}: ranks 1..64 are built")
-            lora_target_modules(lc, name)
+            lora_target_modules(lc, "audio_w2v" if name == "audio" and getattr(self.audio_config, "is_wav2vec2", False) else name)
         self.extra = kwargs
 
     @property

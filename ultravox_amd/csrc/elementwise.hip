@@ -520,6 +520,45 @@ int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void
   return UVX_OK;
 }
 
+}  // namespace uvx
+namespace {
+using namespace uvx;
+// One half (gate: which = 0, up: which = 1) of a gate|up tensor [M, 2 I] in the GEMM's interleaved layout (16-column gate / up blocks alternating:
+// column c of the half sits at (c / 16) * 32 + 16 which + c % 16) <-> a contiguous [M, I] tensor.  ADD: gu = round(gu + src) (the accumulate rounding
+// of lora_up); else dst = gu.  For the MLP adapters of the LLM (ABI 18), whose rank-r kernels work on contiguous columns.
+template <typename T, bool ADD>
+__global__ void gu_half_k(T* __restrict__ gu, T* __restrict__ flat, long long n8, int I, int which) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int cv = I / 8;
+  const long long m = i / cv;
+  const int c = (int)(i % cv) * 8;
+  T* g = gu + m * 2 * I + (c / 16) * 32 + 16 * which + (c % 16);
+  float a[8], b[8];
+  ld8<T>(g, a);
+  if (ADD) {
+    ld8<T>(flat + m * I + c, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = rnd<T>(a[k] + b[k]);
+    st8<T>(g, a);
+  } else {
+    st8<T>(flat + m * I + c, a);
+  }
+}
+}  // namespace
+namespace uvx {
+int gu_half(hipStream_t st, int dtype, void* gu, void* flat, long long M, int I, int which, int add) {
+  UVX_CHECK(I % 16 == 0 && (which == 0 || which == 1), UVX_ERR_SHAPE, "gu_half: I=%d which=%d", I, which);
+  const long long n8 = M * (I / 8);
+  if (n8 == 0) return UVX_OK;
+#define L(T, A) hipLaunchKernelGGL((gu_half_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (T*)gu, (T*)flat, n8, I, which)
+  if (dtype == DT_BF16) { if (add) L(bf16_t, true); else L(bf16_t, false); }
+  else { if (add) L(float, true); else L(float, false); }
+#undef L
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
 int scale_inplace(hipStream_t st, int dtype, void* x, long long n, float s) {
   UVX_CHECK(n % 8 == 0, UVX_ERR_SHAPE, "scale: n=%lld must be a multiple of 8", n);
   if (n == 0) return UVX_OK;

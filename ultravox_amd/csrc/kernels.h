@@ -125,6 +125,8 @@ int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, i
                const int32_t* rows_dev = nullptr);
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
                int gate_first, int act = 0, const int32_t* rows_dev = nullptr);
+// one half (0 gate / 1 up) of an interleaved gate|up tensor [M, 2 I] <-> contiguous [M, I]: add != 0: gu += flat (rounded once); else flat = gu
+int gu_half(hipStream_t st, int dtype, void* gu, void* flat, long long M, int I, int which, int add);
 // x[i] = round(x[i] * s) in place over n elements (Gemma: inputs_embeds * sqrt(hidden_size), and its gradient)
 int scale_inplace(hipStream_t st, int dtype, void* x, long long n, float s);
 int rope_inplace(hipStream_t st, int dtype, void* qkv, const float* cos_sin, const int32_t* pos, int rows,

@@ -535,11 +535,13 @@ int lora_apply_bwd(hipStream_t st, int dt, const void* x, long long ldx, const v
 int lora_check(const uvx_encoder_lora_t* lora, int n_layers, const uvx_encoder_lora_grads_t* grads, const char* who) {
   UVX_CHECK(lora && lora->layers && lora->r > 0 && lora->r <= 64, UVX_ERR_INVALID, "%s: bad LoRA descriptor (rank must be in 1..64)", who);
   for (int l = 0; l < n_layers; ++l) {
-    const uvx_lora_proj_t* P[4] = {&lora->layers[l].q, &lora->layers[l].k, &lora->layers[l].v, &lora->layers[l].o};
-    for (int j = 0; j < 4; ++j) {
+    const uvx_enc_lora_layer_t& R = lora->layers[l];
+    const uvx_lora_proj_t* P[7] = {&R.q, &R.k, &R.v, &R.o, &R.g, &R.u, &R.d};
+    for (int j = 0; j < 7; ++j) {
       UVX_CHECK(!P[j]->a || P[j]->b, UVX_ERR_INVALID, "%s: layer %d, projection %d has lora_A but no lora_B", who, l, j);
       if (grads && P[j]->a) {
-        const uvx_lora_proj_grad_t* G[4] = {&grads->layers[l].q, &grads->layers[l].k, &grads->layers[l].v, &grads->layers[l].o};
+        const uvx_enc_lora_layer_grads_t& GG = grads->layers[l];
+        const uvx_lora_proj_grad_t* G[7] = {&GG.q, &GG.k, &GG.v, &GG.o, &GG.g, &GG.u, &GG.d};
         UVX_CHECK(G[j]->a && G[j]->b, UVX_ERR_INVALID, "%s: layer %d, projection %d is adapted but has no gradient buffers", who, l, j);
       }
     }

@@ -71,6 +71,7 @@ struct EncLayerStash {
   float* lse;
   void *bqT, *bkT;                           // lora_B^T [r, d] of this layer: every rank-r product reads rows
   void *t2, *bvT, *boT;                      // v_proj / out_proj adapters (ABI 17): t2 = [lora_A_v(n) | lora_A_o(attention output)] [M, 128]
+  void* t3;                                  // fc1 / fc2 adapters (ABI 18): [lora_A_fc1(n2) | lora_A_fc2(gelu(fc1))] [M, 128]
 };
 struct EncWs {
   void *im2col, *c1, *x, *n, *qkv, *vt, *o, *f;
@@ -80,6 +81,7 @@ struct EncWs {
   // training only
   char* slots; size_t slot_bytes; EncLayerStash ls0;
   void *dx, *d_n, *d_o, *d_f, *d_qkv, *qT, *kT, *doT, *u, *u2;   // u2: [d v . B_v | d x_mid . B_o] [M, 128]
+  void *u3, *lbT;   // u3: [d pre . B_fc1 | d x_out . B_fc2] [M, 128]; lbT: one MLP adapter's lora_B^T [r, max(d, ffn)] (transposed again in the backward)
   float *delta, *wg;   // wg: lora_wgrad scratch
   int Mp;
 };
@@ -90,11 +92,12 @@ void enc_slot(Arena& a, const uvx_config_t& c, int B, int Te, EncLayerStash& s) 
   s.lse = (float*)a.take(sizeof(float) * (size_t)B * c.enc_heads * Te);
   s.bqT = a.take(64 * d * es); s.bkT = a.take(64 * d * es);
   s.t2 = a.take(M * 128 * es); s.bvT = a.take(64 * d * es); s.boT = a.take(64 * d * es);
+  s.t3 = a.take(M * 128 * es);
 }
 EncLayerStash enc_layer(const EncWs& w, int l) {
   EncLayerStash s = w.ls0;
   const size_t off = w.slot_bytes * l;
-  void** ps[] = {&s.x_in, &s.qkv, &s.o, &s.x_mid, &s.pre, &s.t, (void**)&s.lse, &s.bqT, &s.bkT, &s.t2, &s.bvT, &s.boT};
+  void** ps[] = {&s.x_in, &s.qkv, &s.o, &s.x_mid, &s.pre, &s.t, (void**)&s.lse, &s.bqT, &s.bkT, &s.t2, &s.bvT, &s.boT, &s.t3};
   for (void** q : ps) if (*q) *q = (char*)*q + off;
   return s;
 }
@@ -132,9 +135,10 @@ EncWs enc_carve(Arena& a, const uvx_config_t& c, int B, int F, bool train = fals
     w.d_f = a.take(M * c.enc_ffn * es); w.d_qkv = a.take(M * 3 * d * es);
     const size_t ht = (size_t)B * c.enc_heads * dh * w.Tp * es;
     w.qT = a.take(ht); w.kT = a.take(ht); w.doT = a.take(ht);
-    w.u = a.take(M * 128 * es); w.u2 = a.take(M * 128 * es);
+    w.u = a.take(M * 128 * es); w.u2 = a.take(M * 128 * es); w.u3 = a.take(M * 128 * es);
+    w.lbT = a.take((size_t)64 * std::max(c.enc_d, c.enc_ffn) * es);
     w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.enc_heads * w.Te);
-    w.wg = (float*)a.take(sizeof(float) * (size_t)lora_wgrad_scratch_floats(w.M, c.enc_d, 64));
+    w.wg = (float*)a.take(sizeof(float) * (size_t)lora_wgrad_scratch_floats(w.M, std::max(c.enc_d, c.enc_ffn), 64));
   }
   return w;
 }
@@ -183,6 +187,7 @@ struct LlmLayerStash {
   float* lse;
   void *t, *bqT, *bkT;   // LLM LoRA (text_model_lora_config): [lora_A_q(n) | lora_A_k(n)] [M, 128]; lora_B^T of q / k
   void *t2, *bvT, *boT;  // v_proj / o_proj adapters (ABI 17): [lora_A_v(n) | lora_A_o(attention output)] [M, 128]; lora_B^T of v / o
+  void *t3, *t4;         // MLP adapters (ABI 18): t3 = [lora_A_gate(n2) | lora_A_up(n2)], t4 = [lora_A_down(act) | -]  [M, 128] each
   void* qk_raw;          // Qwen3 / Gemma-3 (llm_qk_norm): the q | k projections before q_norm / k_norm [M, (Hq + Hkv) * dh]
   void *o_pre, *m_pre;   // Gemma-3: o_proj / down_proj outputs BEFORE their post norms [M, D] (the post norms' backward needs them)
 };
@@ -199,6 +204,7 @@ struct LlmWs {
   float* delta;
   float* dkv_part;
   void *lu, *lu2; // LoRA backward: u = [dq . B_q | dk . B_k] [M, 128]; lu2 = [dv . B_v | d (o_proj output) . B_o]
+  void *lu3, *lu4, *lbT;   // MLP adapters: lu3 = [d gate . B_g | d up . B_u], lu4 = [d (down output) . B_d | -]; lbT = one adapter's lora_B^T [r, max(D, I)]
   float* lwg;    // lora_wgrad scratch
   void *wt[2], *head_t;   // llm_wt_stream: two alternating sets of one layer's transposed weights, and lm_head^T
   int M, Tp, QKV, OD;
@@ -207,6 +213,10 @@ struct LlmWs {
 inline size_t layer_wt_elems(const uvx_config_t& c) {
   const size_t QKV = (size_t)(c.llm_heads + 2 * c.llm_kv_heads) * c.llm_head_dim, OD = (size_t)c.llm_heads * c.llm_head_dim;
   return (QKV + OD + 3 * (size_t)c.llm_inter) * c.llm_d;
+}
+// lora_wgrad scratch of the LLM's adapters: the widest adapted linear (hidden, heads * head_dim or the MLP width)
+inline long long llm_wg_floats(const uvx_config_t& c, int M) {
+  return lora_wgrad_scratch_floats(M, std::max(std::max(c.llm_d, c.llm_heads * c.llm_head_dim), c.llm_inter), 64);
 }
 void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
   const size_t es = esz(c.dtype);
@@ -224,6 +234,8 @@ void llm_slot(Arena& a, const uvx_config_t& c, int B, int T, LlmLayerStash& s) {
   s.t2 = a.take(M * 128 * es);
   s.bvT = a.take((size_t)64 * c.llm_kv_heads * c.llm_head_dim * es);
   s.boT = a.take((size_t)64 * c.llm_d * es);
+  s.t3 = a.take(M * 128 * es);
+  s.t4 = a.take(M * 128 * es);
   s.qk_raw = a.take(c.llm_qk_norm ? M * (c.llm_heads + c.llm_kv_heads) * c.llm_head_dim * es : 0);
   s.o_pre = a.take(c.llm_flavor == UVX_LLM_GEMMA3 ? M * c.llm_d * es : 0);
   s.m_pre = a.take(c.llm_flavor == UVX_LLM_GEMMA3 ? M * c.llm_d * es : 0);
@@ -251,6 +263,7 @@ LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
   w.act = a.take(M * c.llm_inter * es);
   w.vt = a.take((size_t)B * c.llm_kv_heads * c.llm_head_dim * w.Tp * es);
   w.logits = a.take(M * c.vocab * es);
+  w.lbT = a.take((size_t)64 * std::max(c.llm_d, c.llm_inter) * es);
   w.ce_scratch = (float*)a.take(sizeof(float) * (2 + M));
   w.sup = (int32_t*)a.take(sizeof(int32_t) * (M + 1));
   w.kvs = (int32_t*)a.take(sizeof(int32_t) * B);
@@ -268,8 +281,8 @@ LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
     w.doT = a.take((size_t)B * c.llm_heads * c.llm_head_dim * w.Tp * es);
     w.delta = (float*)a.take(sizeof(float) * (size_t)B * c.llm_heads * T);
     w.dkv_part = (float*)a.take(sizeof(float) * 2 * M * w.OD);
-    w.lu = a.take(M * 128 * es); w.lu2 = a.take(M * 128 * es);
-    w.lwg = (float*)a.take(sizeof(float) * (size_t)lora_wgrad_scratch_floats(w.M, c.llm_d > w.OD ? c.llm_d : w.OD, 64));
+    w.lu = a.take(M * 128 * es); w.lu2 = a.take(M * 128 * es); w.lu3 = a.take(M * 128 * es); w.lu4 = a.take(M * 128 * es);
+    w.lwg = (float*)a.take(sizeof(float) * (size_t)llm_wg_floats(c, w.M));
     w.wt[0] = a.take(c.llm_wt_stream ? layer_wt_elems(c) * es : 0);
     w.wt[1] = a.take(c.llm_wt_stream ? layer_wt_elems(c) * es : 0);
     w.head_t = a.take(c.llm_wt_stream ? (size_t)c.vocab * c.llm_d * es : 0);
@@ -284,6 +297,7 @@ LlmLayerStash llm_layer(const LlmWs& w, int slot) {
   s.x_mid = (char*)s.x_mid + d; s.gu = (char*)s.gu + d; s.lse = (float*)((char*)s.lse + d);
   s.t = (char*)s.t + d; s.bqT = (char*)s.bqT + d; s.bkT = (char*)s.bkT + d; s.qk_raw = (char*)s.qk_raw + d;
   s.t2 = (char*)s.t2 + d; s.bvT = (char*)s.bvT + d; s.boT = (char*)s.boT + d;
+  s.t3 = (char*)s.t3 + d; s.t4 = (char*)s.t4 + d;
   s.o_pre = (char*)s.o_pre + d; s.m_pre = (char*)s.m_pre + d;
   return s;
 }
@@ -503,6 +517,8 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
   UVX_CHECK(c.enc_block == 0 || (c.enc_max_pos * 2) % c.enc_block == 0, UVX_ERR_SHAPE,
             "audio_latency_block_size %d must divide %d evenly.", c.enc_block, c.enc_max_pos * 2);
   if (train) RC(lora_check(lora, c.enc_layers, nullptr, "encoder LoRA"));
+  for (int l = 0; train && l < c.enc_layers; ++l)
+    UVX_CHECK(!lora->layers[l].u.a, UVX_ERR_INVALID, "encoder LoRA: layer %d has an up_proj adapter (the Whisper MLP is fc1 / fc2: g / d)", l);
   if (B == 0 || F == 0) return UVX_OK;
   Arena a(workspace, ws_bytes);
   EncWs s = enc_carve(a, c, B, F, train);
@@ -589,9 +605,11 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
       g.bias = L.fc1_b;
       // bf16: the GELU runs in the GEMM's epilogue, which writes the pre-activation AND the activation (act 2; tuning option 21 = 1: the
       // separate gelu_fwd pass of rounds 3-5 - bit-identical)
-      const bool fused = dt == DT_BF16 && g_options[21] != 1;
+      const uvx_lora_proj_t& A1 = lora->layers[l].g;      // fc1 adapter (ABI 18): joins the pre-activation, so the GELU runs after it
+      const bool fused = dt == DT_BF16 && g_options[21] != 1 && !A1.a;
       if (fused) { g.act = 2; g.C2 = s.f; g.ldc2 = c.enc_ffn; }
       RC(gemm(st, dt, g));
+      if (A1.a) RC(lora_apply(st, dt, s.n, d, A1, s.lbT, S.t3, S.pre, c.enc_ffn, M, d, c.enc_ffn, lora->r, lora->scaling));
       if (!fused) RC(gelu_fwd(st, dt, S.pre, s.f, (long long)M * c.enc_ffn));
     } else {
       GemmDesc g = lin(s.n, L.fc1_w, s.f, M, c.enc_ffn, d);
@@ -603,6 +621,8 @@ static int enc_forward(hipStream_t st, const uvx_config_t& c, const uvx_encoder_
       g.bias = L.fc2_b; g.residual = x_mid; g.ldr = d;
       RC(gemm(st, dt, enc_sk(g, s)));
     }
+    if (train && lora->layers[l].d.a)      // fc2 adapter
+      RC(lora_apply(st, dt, s.f, c.enc_ffn, lora->layers[l].d, s.lbT, at(S.t3, 64, dt), x_out, d, M, c.enc_ffn, d, lora->r, lora->scaling));
     x = x_out;
   }
   RC(layernorm_fwd(st, dt, x, w->lnf_w, w->lnf_b, out, M, d, c.ln_eps));  // :980
@@ -657,19 +677,35 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     EncLayerStash S = enc_layer(s, l);
     // ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))) ----
     {  // d f = (d x . W_fc2) * gelu'(pre): bf16 - in the dgrad GEMM's epilogue (act 3; option 21 = 1: the separate gelu_bwd pass, bit-identical)
+      const uvx_enc_lora_layer_t& Rm = lora->layers[l];
+      const uvx_enc_lora_layer_grads_t& Gm = grads->layers[l];
+      const long long wgf = lora_wgrad_scratch_floats(s.M, std::max(c.enc_d, c.enc_ffn), 64);
       GemmDesc g = lin(s.dx, L.fc2_t, s.d_f, M, c.enc_ffn, d);
-      const bool fused = dt == DT_BF16 && g_options[21] != 1;
+      const bool fused = dt == DT_BF16 && g_options[21] != 1 && !Rm.d.a;
       if (fused) { g.act = 3; g.C2 = S.pre; g.ldc2 = c.enc_ffn; }
       RC(gemm(st, dt, g));
+      if (Rm.d.a) {      // fc2 adapter: its input gelu(pre) is recomputed; d f += (d x . B * scaling) . A BEFORE the GELU backward
+        RC(gelu_fwd(st, dt, S.pre, s.f, (long long)M * c.enc_ffn));
+        RC(lora_transpose(st, dt, Rm.d.b, s.lbT, d, r));
+        RC(lora_apply_bwd(st, dt, s.f, c.enc_ffn, s.dx, d, s.lbT, at(S.t3, 64, dt), at(s.u3, 64, dt), Gm.d, M, c.enc_ffn, d, r, lora->scaling, s.wg, wgf));
+        RC(lora_up(st, dt, at(s.u3, 64, dt), 128, Rm.d.a, 1, s.d_f, c.enc_ffn, M, c.enc_ffn, r, 1.0f, 1));
+      }
       if (!fused) RC(gelu_bwd(st, dt, s.d_f, S.pre, s.d_f, (long long)M * c.enc_ffn));
     }
     RC(gemm(st, dt, lin(s.d_f, L.fc1_t, s.d_n, M, d, c.enc_ffn)));
+    if (lora->layers[l].g.a) {      // fc1 adapter: its input LN2(x_mid) is recomputed; d n2 += (d pre . B * scaling) . A
+      const long long wgf = lora_wgrad_scratch_floats(s.M, std::max(c.enc_d, c.enc_ffn), 64);
+      RC(layernorm_fwd(st, dt, S.x_mid, L.ln2_w, L.ln2_b, s.n, M, d, c.ln_eps));
+      RC(lora_transpose(st, dt, lora->layers[l].g.b, s.lbT, c.enc_ffn, r));
+      RC(lora_apply_bwd(st, dt, s.n, d, s.d_f, c.enc_ffn, s.lbT, S.t3, s.u3, grads->layers[l].g, M, d, c.enc_ffn, r, lora->scaling, s.wg, wgf));
+      RC(lora_up(st, dt, s.u3, 128, lora->layers[l].g.a, 1, s.d_n, d, M, d, r, 1.0f, 1));
+    }
     RC(layernorm_bwd(st, dt, s.d_n, S.x_mid, L.ln2_w, s.dx, s.dx, M, d, c.ln_eps));
     // ---- attention: x_mid = x_in + wo(attn(q, k, v)) ----
     RC(gemm(st, dt, lin(s.dx, L.wo_t, s.d_o, M, d, d)));
     const uvx_enc_lora_layer_t& R = lora->layers[l];
     const uvx_enc_lora_layer_grads_t& G = grads->layers[l];
-    const long long wg_floats = lora_wgrad_scratch_floats(s.M, c.enc_d, 64);
+    const long long wg_floats = lora_wgrad_scratch_floats(s.M, std::max(c.enc_d, c.enc_ffn), 64);
     if (R.o.a) {   // out_proj adapter: its gradients, and d o += (d x_mid . B_o * scaling) . A_o
       RC(lora_apply_bwd(st, dt, S.o, d, s.dx, d, S.boT, at(S.t2, 64, dt), at(s.u2, 64, dt), G.o, M, d, d, r, lora->scaling, s.wg, wg_floats));
       RC(lora_up(st, dt, at(s.u2, 64, dt), 128, R.o.a, 1, s.d_o, d, M, d, r, 1.0f, 1));
@@ -976,8 +1012,25 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
   };
   // second half: o_proj + residual, norm, gate|up (+ SwiGLU), down + residual.  compact (last layer of the training pair,
   // whole batch only): on the supervised rows gathered into the idle backward scratch.
+  // MLP adapters (ABI 18).  gate_proj / up_proj: result += lora_B(lora_A(n2)) * scaling on the gate / up half of the interleaved gate|up tensor -
+  // the rank-r kernels work on contiguous columns, so the term is formed in v.act (free until the GLU writes it) and added half by half
+  auto mlp_in_adapters = [&](hipStream_t sx, const LlmWs& v, const LlmLayerStash& cur, int l) -> int {
+    const uvx_enc_lora_layer_t& R = lora->layers[l];
+    const int I = c.llm_inter, r = lora->r;
+    for (int which = 0; which < 2; ++which) {
+      const uvx_lora_proj_t& P = which ? R.u : R.g;
+      if (!P.a) continue;
+      void* t = at(cur.t3, 64 * which, dt);
+      RC(lora_transpose(sx, dt, P.b, v.lbT, I, r));
+      RC(lora_down(sx, dt, v.n, D, P.a, 0, t, 128, v.M, D, r, 1.0f));
+      RC(lora_up(sx, dt, t, 128, v.lbT, 1, v.act, I, v.M, I, r, lora->scaling, 0));
+      RC(gu_half(sx, dt, cur.gu, v.act, v.M, I, which, 1));
+    }
+    return UVX_OK;
+  };
   auto layer_mlp = [&](hipStream_t sx, const LlmWs& v, int l, bool compact) -> int {
     const uvx_llm_layer_t& L = w->layers[l];
+    const bool ad_in = lora && (lora->layers[l].g.a || lora->layers[l].u.a), ad_out = lora && lora->layers[l].d.a;
     const bool last = l + 1 == c.llm_layers;
     LlmLayerStash cur = llm_layer(v, slot_of(l));
     void* x_out = last ? v.x_final : llm_layer(v, slot_of(l + 1)).x_in;
@@ -992,8 +1045,11 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       RC(rmsnorm_fwd(sx, dt, cur.o_pre, L.ln1_post, cur.x_mid, nullptr, Mv, D, c.rms_eps, fl, nullptr, cur.x_in));
       RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, v.n, nullptr, Mv, D, c.rms_eps, fl));
       RC(gemm(sx, dt, lin(v.n, L.wgu, cur.gu, Mv, 2 * c.llm_inter, D)));
+      if (ad_in) RC(mlp_in_adapters(sx, v, cur, l));
       RC(swiglu_fwd(sx, dt, cur.gu, v.act, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
       RC(gemm(sx, dt, lin(v.act, L.wd, cur.m_pre, Mv, D, c.llm_inter)));
+      if (ad_out)      // down_proj adapter: joins the branch before its post norm
+        RC(lora_apply(sx, dt, v.act, c.llm_inter, lora->layers[l].d, v.lbT, cur.t4, cur.m_pre, D, Mv, c.llm_inter, D, lora->r, lora->scaling));
       return rmsnorm_fwd(sx, dt, cur.m_pre, L.ln2_post, x_out, nullptr, Mv, D, c.rms_eps, fl, nullptr, cur.x_mid);
     }
     // gather targets of the compact last layer: the idle backward scratch, or - a forward without stash (the KL teacher) - the other
@@ -1021,10 +1077,11 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
     if (!probe_skip(16)) RC(rmsnorm_fwd(sx, dt, cur.x_mid, L.ln2, probe_skip(256) && save_for_bwd ? v.d_n : v.n, nullptr, Mv, D, c.rms_eps, fl, mdev));
     {  // gate|up projection; wgu rows are packed as alternating 16-row gate / up blocks (weights.py)
       GemmDesc g = lin(v.n, L.wgu, cur.gu, Mv, 2 * c.llm_inter, D);
-      const bool fused = dt == DT_BF16 && fl == UVX_LLM_LLAMA;   // SwiGLU fused into the epilogue (GeGLU: separate kernel)
+      const bool fused = dt == DT_BF16 && fl == UVX_LLM_LLAMA && !ad_in;   // SwiGLU fused into the epilogue (GeGLU, or adapters on gate / up: separate kernel)
       if (fused) { g.C2 = v.act; g.ldc2 = c.llm_inter; g.swiglu = 1; }
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
+      if (ad_in) RC(mlp_in_adapters(sx, v, cur, l));
       if (!fused) RC(swiglu_fwd(sx, dt, cur.gu, v.act, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act, mdev));
     }
     {
@@ -1032,6 +1089,8 @@ static int llm_forward(void* stream, const uvx_config_t* cfg, const uvx_llm_weig
       g.residual = cur.x_mid; g.ldr = D; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
+    if (ad_out)      // down_proj adapter (never on the compact path: top is false under LoRA)
+      RC(lora_apply(sx, dt, v.act, c.llm_inter, lora->layers[l].d, v.lbT, cur.t4, x_out, D, Mv, c.llm_inter, D, lora->r, lora->scaling));
     return UVX_OK;
   };
   // schedule: one chain on the caller's stream, or (option 11) the batch slices on several streams - see Fork above.  The
@@ -1243,20 +1302,51 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   const size_t es = esz(dt);
   // MLP half of a layer's backward on the rows of the view v: v.dx (gradient of the layer's output) -> v.dx (gradient of
   // x_mid: residual + norm branch).  compact: the supervised rows of the last layer (whole batch, device-side count).
+  // MLP adapters, backward.  down_proj: dy = the gradient of the down projection's output; its input act = GLU(gate|up) is recomputed into v.act;
+  // d act += u . A_d BEFORE the GLU backward.
+  auto mlp_out_adapter_bwd = [&](hipStream_t sx, const LlmWs& v, const LlmLayerStash& cur, int l, const void* dy) -> int {
+    const uvx_lora_proj_t& P = lora->layers[l].d;
+    const int I = c.llm_inter, r = lora->r;
+    RC(swiglu_fwd(sx, dt, cur.gu, v.act, v.M, I, /*layout=*/2, /*act=*/c.llm_act));
+    RC(lora_transpose(sx, dt, P.b, v.lbT, D, r));
+    RC(lora_apply_bwd(sx, dt, v.act, I, dy, D, v.lbT, cur.t4, v.lu4, lgrads->layers[l].d, v.M, I, D, r, lora->scaling, v.lwg, llm_wg_floats(c, s.M)));
+    return lora_up(sx, dt, v.lu4, 128, P.a, 1, v.d_act, I, v.M, I, r, 1.0f, 1);
+  };
+  // gate_proj / up_proj: dy = the gate / up half of d gate|up, extracted into v.d_act (free once the GLU backward has consumed it); their input
+  // n2 = norm(x_mid) is recomputed into v.n; d n2 += u . A after the dgrad GEMM has written v.d_n
+  auto mlp_in_adapters_bwd = [&](hipStream_t sx, const LlmWs& v, const LlmLayerStash& cur, int l, const void* ln2) -> int {
+    const uvx_enc_lora_layer_t& R = lora->layers[l];
+    const int I = c.llm_inter, r = lora->r;
+    RC(rmsnorm_fwd(sx, dt, cur.x_mid, ln2, v.n, nullptr, v.M, D, c.rms_eps, c.llm_flavor));
+    for (int which = 0; which < 2; ++which) {
+      const uvx_lora_proj_t& P = which ? R.u : R.g;
+      if (!P.a) continue;
+      void* u = at(v.lu3, 64 * which, dt);
+      RC(gu_half(sx, dt, v.d_gu, v.d_act, v.M, I, which, 0));
+      RC(lora_transpose(sx, dt, P.b, v.lbT, I, r));
+      RC(lora_apply_bwd(sx, dt, v.n, D, v.d_act, I, v.lbT, at(cur.t3, 64 * which, dt), u, which ? lgrads->layers[l].u : lgrads->layers[l].g, v.M, D, I, r,
+                        lora->scaling, v.lwg, llm_wg_floats(c, s.M)));
+      RC(lora_up(sx, dt, u, 128, P.a, 1, v.d_n, D, v.M, D, r, 1.0f, 1));
+    }
+    return UVX_OK;
+  };
   auto layer_mlp_bwd = [&](hipStream_t sx, const LlmWs& v, int l, bool compact) -> int {
     const uvx_llm_layer_t& L = w->layers[l];
     LlmLayerStash cur = llm_layer(v, l);
     const int Mv = v.M;
     const int32_t* mdev = compact ? v.sup + Mv : nullptr;
+    const bool ad_in = lora && (lora->layers[l].g.a || lora->layers[l].u.a), ad_out = lora && lora->layers[l].d.a;
     if (g3) {
       // x_out = x_mid + post_ffw_norm(m_pre): d m_pre = norm'(dx) -> d act -> d gate|up -> d n2; d x_mid = dx + pre_ffw_norm'(d n2)
       RC(rmsnorm_bwd(sx, dt, v.dx, cur.m_pre, L.ln2_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
       RC(gemm(sx, dt, lin_dgrad(v.d_n, layer_t(l).wd_t, L.wd, v.d_act, Mv, c.llm_inter, D)));
+      if (ad_out) RC(mlp_out_adapter_bwd(sx, v, cur, l, v.d_n));      // (d m_pre: behind the post norm)
       RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
       RC(gemm(sx, dt, lin_dgrad(v.d_gu, layer_t(l).wgu_t, L.wgu, v.d_n, Mv, D, 2 * c.llm_inter)));
+      if (ad_in) RC(mlp_in_adapters_bwd(sx, v, cur, l, L.ln2));
       return rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl);
     }
-    if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
+    if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA && !ad_out) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
       GemmDesc g = lin_dgrad(v.dx, layer_t(l).wd_t, L.wd, v.d_gu, Mv, c.llm_inter, D);
       g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
@@ -1264,6 +1354,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       GemmDesc g = lin_dgrad(v.dx, layer_t(l).wd_t, L.wd, v.d_act, Mv, c.llm_inter, D);
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
+      if (ad_out) RC(mlp_out_adapter_bwd(sx, v, cur, l, v.dx));
       if (!probe_skip(4)) RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act, mdev));
     }
     {
@@ -1271,6 +1362,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
     }
+    if (ad_in) RC(mlp_in_adapters_bwd(sx, v, cur, l, L.ln2));
     return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl, mdev);
   };
   // attention half: v.dx (gradient of x_mid) -> dx_out (gradient of the layer's input).  d_o_ready: v.d_o and the residual
@@ -1283,7 +1375,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       RC(rmsnorm_bwd(sx, dt, v.dx, cur.o_pre, L.ln1_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
       RC(gemm(sx, dt, lin_dgrad(v.d_n, layer_t(l).wo_t, L.wo, v.d_o, Mv, s.OD, D)));
     } else if (!d_o_ready) RC(gemm(sx, dt, lin_dgrad(v.dx, layer_t(l).wo_t, L.wo, v.d_o, Mv, s.OD, D)));
-    const long long lwg_floats = lora_wgrad_scratch_floats(s.M, c.llm_d > s.OD ? c.llm_d : s.OD, 64);
+    const long long lwg_floats = llm_wg_floats(c, s.M);
     if (lora && lora->layers[l].o.a) {   // o_proj adapter: its gradients from d (o_proj output) - Gemma-3: behind the post norm -, and d o += u . A_o
       const void* d_y = g3 ? v.d_n : v.dx;
       RC(lora_apply_bwd(sx, dt, cur.o, s.OD, d_y, D, cur.boT, at(cur.t2, 64, dt), at(v.lu2, 64, dt), lgrads->layers[l].o, Mv, s.OD, D, lora->r, lora->scaling,

@@ -288,6 +288,9 @@ static int w2v_forward(void* stream, const uvx_w2v_config_t* cfg, const uvx_w2v_
   hipStream_t st = (hipStream_t)stream;
   const bool train = lora != nullptr;
   if (train) RC(lora_check(lora, c.layers, nullptr, "wav2vec2 LoRA"));
+  for (int l = 0; train && l < c.layers; ++l)
+    UVX_CHECK(!lora->layers[l].g.a && !lora->layers[l].u.a && !lora->layers[l].d.a, UVX_ERR_UNSUPPORTED,
+              "wav2vec2 LoRA: layer %d has a feed-forward adapter (the attention projections q / k / v / out_proj are built for this tower)", l);
   for (int i = 0; i < c.n_conv; ++i) {
     UVX_CHECK(!c.conv_bias || w->conv_b[i], UVX_ERR_INVALID, "wav2vec2_fwd: conv_bias is set but conv layer %d has no bias", i);
     UVX_CHECK(!c.feat_norm_layer || (w->conv_ln_w[i] && w->conv_ln_b[i]), UVX_ERR_INVALID, "wav2vec2_fwd: conv layer %d has no layer norm", i);

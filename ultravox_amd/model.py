@@ -477,16 +477,19 @@ class UltravoxModel:
         if self.lora_r > 0:
             check_encoder_exportable(self.config)      # BEFORE any weight changes: a tower that cannot be re-exported is not half-merged
         def fold_layer(L, rows, targets, keyfn, i, sc, q_scale=1.0) -> None:
-            for pj in targets:      # q / k / v: row blocks of the packed wqkv; out_proj / o_proj: the whole wo
+            for pj in targets:      # q / k / v: row blocks of the packed wqkv; out_proj / o_proj: the whole wo; the MLP's linears (ABI 18)
                 A, B = self._proj_views[keyfn(i, pj, "A")], self._proj_views[keyfn(i, pj, "B")]
                 if pj in rows:
                     lo, hi = rows[pj]
                     fold(L["wqkv"][lo:hi], A, B, sc * (q_scale if pj == "q_proj" else 1.0))
+                elif pj in ("gate_proj", "up_proj"):      # rows of the packed gate|up matrix: alternating 16-row gate / up blocks (weights.pack_llm)
+                    idx = _gu_rows(L["wgu"].shape[0] // 2, pj == "up_proj", L["wgu"].device)
+                    L["wgu"][idx] = (L["wgu"][idx].float() + sc * (B.float() @ A.float())).to(L["wgu"].dtype)
                 else:
-                    fold(L["wo"], A, B, sc)
-            for n in ("wqkv", "wo"):
-                if L.get(n + "_t") is not None:
-                    L[n + "_t"].copy_(L[n].t())
+                    fold(L[{"fc1": "fc1_w", "fc2": "fc2_w", "down_proj": "wd"}.get(pj, "wo")], A, B, sc)
+            for n, nt in (("wqkv", "wqkv_t"), ("wo", "wo_t"), ("wgu", "wgu_t"), ("wd", "wd_t"), ("fc1_w", "fc1_t"), ("fc2_w", "fc2_t")):
+                if L.get(nt) is not None:
+                    L[nt].copy_(L[n].t())
         if self.lora_r > 0:
             d = self.config.audio_config.d_model
             qs = (d // self.config.audio_config.encoder_attention_heads) ** -0.5      # folded into the packed q rows
@@ -1036,26 +1039,31 @@ class UltravoxModel:
         t = self.config.text_config
         qc, kc = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim
         spans = {"q_proj": (0, qc), "k_proj": (qc, qc + kc), "v_proj": (qc + kc, qc + 2 * kc)}
-        with_o = "o_proj" in self._tlora_targets
+        whole = {"o_proj": "wo", "down_proj": "wd"}
+        touched = sorted({"wqkv" if pj in spans else "wgu" if pj in ("gate_proj", "up_proj") else whole[pj] for pj in self._tlora_targets})
         sc = float(self._tlora.scaling)
         saved = []
         try:
             with torch.no_grad():
                 for i, L in enumerate(self._llm["layers"]):
-                    saved.append((L["wqkv"].clone(), L["wo"].clone() if with_o else None))
+                    saved.append({n: L[n].clone() for n in touched})
                     for pj in self._tlora_targets:
                         A, B = self._proj_views[llm_lora_key(i, pj, "A")], self._proj_views[llm_lora_key(i, pj, "B")]
-                        rows = L["wo"] if pj == "o_proj" else L["wqkv"][spans[pj][0]:spans[pj][1]]
-                        rows.copy_((rows.float() + sc * (B.float() @ A.float())).to(rows.dtype))
+                        delta = sc * (B.float() @ A.float())
+                        if pj in ("gate_proj", "up_proj"):
+                            idx = _gu_rows(L["wgu"].shape[0] // 2, pj == "up_proj", L["wgu"].device)
+                            L["wgu"][idx] = (L["wgu"][idx].float() + delta).to(L["wgu"].dtype)
+                        else:
+                            rows = L[whole[pj]] if pj in whole else L["wqkv"][spans[pj][0]:spans[pj][1]]
+                            rows.copy_((rows.float() + delta).to(rows.dtype))
             self.text_lora_r = 0
             yield
         finally:
             self.text_lora_r = r
             with torch.no_grad():
-                for L, (wqkv, wo) in zip(self._llm["layers"], saved):
-                    L["wqkv"].copy_(wqkv)
-                    if wo is not None:
-                        L["wo"].copy_(wo)
+                for L, keep in zip(self._llm["layers"], saved):
+                    for n, w in keep.items():
+                        L[n].copy_(w)
 
     def _generate(self, input_ids: torch.Tensor, audio_values: Optional[torch.Tensor] = None,
                  inputs_embeds: Optional[torch.Tensor] = None, audio_token_start_idx: Optional[torch.Tensor] = None,
@@ -1406,6 +1414,12 @@ class UltravoxModel:
         self._projector_backward(d_audio)
         self._last_d_embeds, self._last_d_audio = d_embeds, d_audio
         return out.loss
+
+
+def _gu_rows(inter: int, up: bool, device) -> torch.Tensor:
+    """Rows of the packed gate|up matrix [2 I, D] that hold gate_proj (up = False) / up_proj (True) row 0 .. I - 1: alternating 16-row blocks."""
+    c = torch.arange(inter, device=device)
+    return (c // 16) * 32 + (16 if up else 0) + (c % 16)
 
 
 class UltravoxTrainer:

@@ -194,7 +194,8 @@ def rope_table(tc, length: int, device, local: bool = False) -> torch.Tensor:
 
 
 LORA_TARGETS = ("q_proj", "k_proj")     # of the encoder's self_attn (the default target_modules that exist in Whisper)
-LORA_FIELD = {"q_proj": "q", "k_proj": "k", "v_proj": "v", "out_proj": "o", "o_proj": "o"}      # module -> field of uvx_enc_lora_layer_t
+LORA_FIELD = {"q_proj": "q", "k_proj": "k", "v_proj": "v", "out_proj": "o", "o_proj": "o",      # module -> field of uvx_enc_lora_layer_t
+              "fc1": "g", "fc2": "d", "gate_proj": "g", "up_proj": "u", "down_proj": "d"}
 
 
 def lora_targets(cfg: UltravoxConfig, tower: str):
@@ -202,22 +203,24 @@ def lora_targets(cfg: UltravoxConfig, tower: str):
     (config.lora_target_modules: the reference's target_modules resolved against the tower's module names)."""
     from .config import lora_target_modules
     lc = getattr(cfg, f"{tower}_model_lora_config", None) or {}
-    return lora_target_modules(lc, tower) if int(lc.get("r", 0) or 0) > 0 else ()
+    kind = "audio_w2v" if tower == "audio" and getattr(cfg.audio_config, "is_wav2vec2", False) else tower
+    return lora_target_modules(lc, kind) if int(lc.get("r", 0) or 0) > 0 else ()
 
 
 def lora_dims(cfg: UltravoxConfig, tower: str, proj: str):
     """(in_features, out_features) of an adapted projection."""
     a, t = cfg.audio_config, cfg.text_config
     if tower == "audio":
-        return a.d_model, a.d_model
-    qc, kc = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim
-    return {"q_proj": (t.hidden_size, qc), "k_proj": (t.hidden_size, kc), "v_proj": (t.hidden_size, kc), "o_proj": (qc, t.hidden_size)}[proj]
+        return {"fc1": (a.d_model, a.encoder_ffn_dim), "fc2": (a.encoder_ffn_dim, a.d_model)}.get(proj, (a.d_model, a.d_model))
+    qc, kc, D, I = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim, t.hidden_size, t.intermediate_size
+    return {"q_proj": (D, qc), "k_proj": (D, kc), "v_proj": (D, kc), "o_proj": (qc, D), "gate_proj": (D, I), "up_proj": (D, I), "down_proj": (I, D)}[proj]
 
 
 def lora_key(layer: int, proj: str, which: str, prefix="audio_tower.") -> str:
     """peft's parameter name for a LoRA matrix of the wrapped encoder (get_peft_model, ultravox_model.py:707): the base
     model sits under `base_model.model.` and the adapter is called `default`."""
-    return f"{prefix}base_model.model.layers.{layer}.self_attn.{proj}.lora_{which}.default.weight"
+    sub = "" if proj in ("fc1", "fc2") else "self_attn."      # WhisperEncoderLayer: fc1 / fc2 sit next to self_attn
+    return f"{prefix}base_model.model.layers.{layer}.{sub}{proj}.lora_{which}.default.weight"
 
 
 def w2v_lora_key(layer: int, proj: str, which: str, prefix="audio_tower.") -> str:
@@ -232,7 +235,8 @@ def audio_lora_key(cfg: UltravoxConfig):
 
 def llm_lora_key(layer: int, proj: str, which: str, prefix="language_model.") -> str:
     """peft's name for a LoRA matrix of the wrapped LlamaForCausalLM (whose own `model.` level follows peft's)."""
-    return f"{prefix}base_model.model.model.layers.{layer}.self_attn.{proj}.lora_{which}.default.weight"
+    sub = "mlp." if proj in ("gate_proj", "up_proj", "down_proj") else "self_attn."
+    return f"{prefix}base_model.model.model.layers.{layer}.{sub}{proj}.lora_{which}.default.weight"
 
 
 def init_lora_state_dict(cfg: UltravoxConfig, seed: int = 0, dtype=torch.float32, device="cpu", random_b: bool = False):
