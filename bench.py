@@ -189,7 +189,7 @@ def run_inference(args, wl, dev) -> None:
         "output_shape": list(out.shape)}))
 
 
-def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int = 32, top_rows: bool = True):
+def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int = 32, top_rows: bool = True, bwd_skip_rows: int = 0):
     """Algorithmic FLOPs of one sample: matmul [m,k]x[k,n] = 2mkn, causal attention = 1/2.  The LM head
     is counted on the supervised positions only (the rows that enter the loss; the other rows of the logits have zero
     weight and zero gradient, and the training step does not compute them), and so is the last LLM layer's o_proj + MLP -
@@ -223,7 +223,10 @@ def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int =
     # the last layer's o_proj + MLP (row-wise, after the last position mixing) likewise run on the supervised rows only
     top_skip = (T - n_supervised) * (2 * D * h * dh + 6 * D * I) if top_rows else 0
     M = body + head - top_skip
-    step = E + 3 * P + M + (M + attn)
+    # bwd_skip_rows: positions per sample whose row-wise backward is not run (uvx_llm_bwd_train_from: the text before the first audio token) - the
+    # q|k|v dgrad of every layer, the o_proj + MLP dgrads of every layer but a row-compacted last one; the attention backward still runs on all rows
+    prefix_skip = bwd_skip_rows * (L * (2 * D * h * dh + 4 * D * kv * dh) + (L - (1 if top_rows else 0)) * (2 * D * h * dh + 6 * D * I))
+    step = E + 3 * P + M + (M + attn) - prefix_skip
     # recipe flavours (meta_config.yaml:5-6): the KL teacher = a forward of the same LLM over the text-only alternative (n_alt tokens, logits on
     # the supervised rows), and - under encoder LoRA - the tower's backward: the dgrads of its layers' linears (= their forward FLOPs) and the
     # attention backward (5 products against the forward's 2); the adapters' own rank-r products are not counted
@@ -232,7 +235,7 @@ def flops_per_sample(cfg, seconds: float, n_text: int = 128, n_supervised: int =
     if top_rows:
         teacher -= (n_alt - n_supervised) * (2 * D * h * dh + 6 * D * I)
     enc_bwd = Le * (8 * Te * d * d + 4 * Te * d * ffn + 10 * Te * Te * d)
-    return dict(encoder=E, projector=P, llm_fwd=M, step=step, step_full_head=step + 2 * (head_full - head) + 2 * top_skip,
+    return dict(encoder=E, projector=P, llm_fwd=M, step=step, step_full_head=step + 2 * (head_full - head) + 2 * top_skip + prefix_skip, bwd_prefix_skip=prefix_skip,
                 kl_teacher=teacher, encoder_lora_bwd=enc_bwd)
 
 
@@ -572,6 +575,8 @@ def main():
                     help="with the cpu_baseline leg: also run its weights and B = 1 batch through the HIP path at full depth and report the measured "
                          "distances as parity.live (default on for the plain c2 line; adds ~10 s)")
     ap.add_argument("--no-parity-live", action="store_true", help="never run the live parity check")
+    ap.add_argument("--no-prefix-skip", action="store_true",
+                    help="A/B: run the LLM backward on every row (uvx_llm_bwd_train) instead of from the first audio token (uvx_llm_bwd_train_from)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="quote roofline.traffic from the committed PMC summary instead of measuring it in two rocprofv3 --pmc sub-runs (~15 s each)")
     ap.add_argument("--audio-lora-r", type=int, default=0,
@@ -668,6 +673,7 @@ def main():
                          audio_model_lora_config={"r": args.audio_lora_r} if args.audio_lora_r else None)
     model = UltravoxModel(cfg, device=str(dev), dtype=torch.bfloat16, seed=0, rope_len=1024,
                           stream_weight_transposes={"auto": None, "on": True, "off": False}[args.stream_wt], dgrad_nn=args.dgrad_nn)
+    model.skip_prefix_backward = not args.no_prefix_skip
     comm = None
     if args.comm == "abi" and world > 1 and not share_gpu:
         from ultravox_amd.parallel import UvxComm
@@ -763,7 +769,11 @@ def main():
     dt = max(rank_s)                                        # the contract: MAX over ranks
 
     if rank == 0:
-        fl = flops_per_sample(cfg, wl["seconds"], top_rows=bool(model._llm_top_rows))    # what the measured step really skipped
+        # rows per clip whose backward the step really skipped (uvx_llm_bwd_train_from): read off the last d inputs_embeds, whose skipped rows are zeros
+        s16 = 16 // 16 * 16      # synthetic_batch(audio_start = 16)
+        d_last = model.__dict__.get("_last_d_embeds")
+        bwd_skip = s16 if (d_last is not None and model.skip_prefix_backward and float(d_last[:, :s16].abs().max()) == 0.0) else 0
+        fl = flops_per_sample(cfg, wl["seconds"], top_rows=bool(model._llm_top_rows), bwd_skip_rows=bwd_skip)    # what the measured step really skipped
         flavour_extra = (fl["kl_teacher"] if args.loss == "kl" else 0) + (fl["encoder_lora_bwd"] if args.audio_lora_r else 0)
         fl["step"] += flavour_extra          # (the recipe flavours do more work per step than the CE line: count it)
         fl["step_full_head"] += flavour_extra
@@ -781,7 +791,8 @@ def main():
                        "loss": "cross-entropy" if args.loss == "ce" else "KL distillation (teacher: text-only pass of the same LLM over 176 tokens)",
                        "trainable": "projector" + (f" + encoder LoRA r={args.audio_lora_r} (q_proj, k_proj)" if args.audio_lora_r else ""),
                        "supervised_tokens_per_clip": 32,
-                       "loss_head": "LM head + CE on the supervised positions only (identical loss and gradients)"},
+                       "loss_head": "LM head + CE on the supervised positions only (identical loss and gradients)",
+                       "llm_backward_from_position": bwd_skip},
             "samples_per_sec": B * world * args.steps / dt,
             "step_tflops_algorithmic": fl["step"] * B / 1e12,
             "step_tflops_with_full_logits": fl["step_full_head"] * B / 1e12,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVX_ABI_VERSION 18
+#define UVX_ABI_VERSION 19
 #define UVX_BF16 0
 #define UVX_F32 1
 
@@ -301,6 +301,16 @@ int32_t uvx_llm_fwd_train(void* stream, const uvx_config_t* cfg, const uvx_llm_w
                           void* workspace, size_t ws_bytes);
 int32_t uvx_llm_bwd_train(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels, int32_t B,
                           int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes);
+/* uvx_llm_bwd_train for a caller that needs no gradient below position `first_pos` of any sequence (ABI 19).  In the adapter-training step the
+ * only consumer of d_inputs_embeds is the scatter back to the audio rows (_prepare_audio_embeds' inverse, uvx_merge_embeds_bwd), and under the
+ * causal mask a position feeds later positions only: nothing trainable is reachable from the text before the first audio token, so
+ * first_pos = min(audio_token_start_idx) over the batch.  Below the last layer the gradient tensors are then row-compacted to the positions
+ * >= first_pos rounded down to a multiple of 16 (dgrad GEMMs, SwiGLU / RMSNorm backward on B * (T - first_pos) rows; the attention backward
+ * still reads every key).  d_inputs_embeds rows at or above first_pos: bit-identical to uvx_llm_bwd_train's; rows below it (rounded down):
+ * zeros.  Where the compacted form does not apply (T > 320, sliding-window layers, q / k norms, tuning options 3 = 0 or 11 >= 2) or
+ * first_pos < 16 the call IS uvx_llm_bwd_train. */
+int32_t uvx_llm_bwd_train_from(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels, int32_t B,
+                               int32_t T, int32_t first_pos, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes);
 /* labels == NULL: the saved logits already hold d loss / d logits (see uvx_llm_kl_loss). */
 
 /* KL-distillation loss: UltravoxModel._compute_kl_loss (ultravox_model.py:200-256) with the
@@ -346,6 +356,9 @@ int32_t uvx_llm_kl_loss_rows(void* stream, const uvx_config_t* cfg, const void* 
                              float* loss, void* workspace, size_t ws_bytes);
 int32_t uvx_llm_bwd_rows(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, int32_t B, int32_t T,
                          void* d_inputs_embeds, void* workspace, size_t ws_bytes);
+/* ... from position first_pos on (the KL recipe's counterpart of uvx_llm_bwd_train_from, ABI 19: same conditions, same guarantees) */
+int32_t uvx_llm_bwd_rows_from(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, int32_t B, int32_t T, int32_t first_pos,
+                              void* d_inputs_embeds, void* workspace, size_t ws_bytes);
 
 /* ---- inference: prefill + KV-cache decode.  Replaces the [3P] HF language_model.generate
  * that UltravoxModel.generate delegates to (ultravox_model.py:398-426) for GREEDY decoding.

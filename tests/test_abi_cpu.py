@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in header_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in include/uvx.h but not exported by libuvx.so: {missing}"
     assert set(_lib.EXPORTS) == set(header_functions())
-    assert lib.uvx_abi_version() == _lib.ABI_VERSION == 18
+    assert lib.uvx_abi_version() == _lib.ABI_VERSION == 19
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():

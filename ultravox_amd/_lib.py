@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 18  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
+ABI_VERSION = 19  # UVX_ABI_VERSION of include/uvx.h that the struct mirrors below follow
 
 
 def lib() -> C.CDLL:
@@ -187,8 +187,8 @@ EXPORTS = [
     "uvx_attention_fwd", "uvx_attention_bwd", "uvx_ce_loss", "uvx_prof_begin", "uvx_prof_enable", "uvx_prof_end", "uvx_prof_records", "uvx_prof_union_ms", "uvx_probe_lds_tr", "uvx_gemm_force_variant", "uvx_attention_force_qt", "uvx_kv_cache_bytes", "uvx_llm_infer_ws_bytes",
     "uvx_llm_prefill", "uvx_llm_prefill_chunk", "uvx_llm_prefill_chunk_logits", "uvx_llm_prefill_chunk_ws_bytes", "uvx_llm_decode", "uvx_argmax", "uvx_greedy_select", "uvx_llm_kl_loss", "uvx_kl_loss", "uvx_gemm_override_variant", "uvx_gemm_pick_variant", "uvx_set_option", "uvx_get_option",
     "uvx_encoder_train_ws_bytes", "uvx_encoder_fwd_train", "uvx_encoder_bwd", "uvx_layernorm_bwd", "uvx_gelu", "uvx_gelu_bwd",
-    "uvx_llm_fwd_rows", "uvx_llm_kl_loss_rows", "uvx_llm_bwd_rows", "uvx_llm_fwd_lora", "uvx_llm_bwd_lora",
-    "uvx_llm_fwd_train", "uvx_llm_bwd_train",
+    "uvx_llm_fwd_rows", "uvx_llm_kl_loss_rows", "uvx_llm_bwd_rows", "uvx_llm_bwd_rows_from", "uvx_llm_fwd_lora", "uvx_llm_bwd_lora",
+    "uvx_llm_fwd_train", "uvx_llm_bwd_train", "uvx_llm_bwd_train_from",
     "uvx_wav2vec2_frames", "uvx_wav2vec2_ws_bytes", "uvx_wav2vec2_fwd", "uvx_wav2vec2_train_ws_bytes", "uvx_wav2vec2_fwd_train", "uvx_wav2vec2_bwd",
     "uvx_gemm_splitk_ws_bytes", "uvx_gemm_splitk", "uvx_gemm_pick_split",
     "uvx_comm_unique_id", "uvx_comm_init", "uvx_comm_world_size", "uvx_comm_version", "uvx_comm_allreduce_f32", "uvx_comm_destroy",

@@ -43,6 +43,7 @@ struct AttnArgs {
   const float* rope;  // backward: [T_table, D/2, 2] f32 cos / sin - dQ and dK leave the kernels RoPE-INVERTED (the gradient of q, k
                       // before the rotary embedding), position = the row's index in its sequence; null = none
   unsigned long long* tl;  // probes build: per-wave s_memtime stamps of the fused backward kernel (uvx_probe_attn_timeline); else null
+  int dfirst;  // fused backward only (AttnBwdDesc::d_first): dout / dq / dk / dv hold the rows of positions >= dfirst, sequence b at row b * (T - dfirst)
 };
 // Timeline stamps (libuvx_probes.so only): lane 0 of every wave writes slot `s` of its 16-slot record.
 #ifdef UVX_PROBES
@@ -192,6 +193,16 @@ __device__ __forceinline__ void load_nat(NatRegs<D, R, NT>& g, const bf16_t* bas
     // s_waitcnt vmcnt(N) instead of draining the prefetch with vmcnt(0); rows >= rmax repeat row rmax-1 and are
     // always masked out by the callers (they are finite, so 0 * x stays 0)
     g.v[k] = *reinterpret_cast<const u16x8_t*>(base + (long long)min(r0 + r, rmax - 1) * ld + c * 8);
+  }
+}
+// the same with rows clamped to [rmin, rmax - 1]: a matrix whose rows below rmin do not exist (the fused backward's row-compacted dO)
+template <int D, int R, int NT = 256>
+__device__ __forceinline__ void load_nat_from(NatRegs<D, R, NT>& g, const bf16_t* base, long long ld, int r0, int rmin, int rmax, int tid) {
+  constexpr int NCH = D / 8, N = R * NCH / NT;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int i = tid + k * NT, r = i / NCH, c = i % NCH;
+    g.v[k] = *reinterpret_cast<const u16x8_t*>(base + (long long)max(min(r0 + r, rmax - 1), rmin) * ld + c * 8);
   }
 }
 template <int D, int R, int NT = 256>
@@ -990,7 +1001,13 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
   const int k_hi = p.kv_len ? min(p.kv_len[b], T) : T;
   char* stage = ldsStage + w * STAGE_BYTES;
   const bf16_t* qbase = p.q + (long long)b * T * p.ldq + h * D;
-  const bf16_t* dobase = p.dout + (long long)b * T * p.ldo + h * D;
+  // Row-compacted gradients (p.dfirst = s > 0, a multiple of 16): dout / dq / dk / dv hold positions >= s only, sequence b at row b * (T - s) - the
+  // caller needs no gradient below position s (model.hip: the text prefix before the first audio token; under the causal mask nothing trainable is
+  // reachable from it).  Position t of this sequence is row drow0 + t; rows of positions < s do not exist: dO is read clamped to position s there
+  // (finite copies - a query below s only meets keys below s, whose dK / dV, like its own dQ, are never stored) and the stores skip those tiles.
+  const int s0 = p.dfirst;
+  const long long drow0 = (long long)b * (T - s0) - s0;
+  const bf16_t* dobase = p.dout + drow0 * p.ldo + h * D;
   const bf16_t* obase = p.o + (long long)b * T * p.ldo + h * D;
   const bf16_t* kbase = p.k + (long long)b * T * p.ldk + hk * D;
   const bf16_t* vbase = p.v + (long long)b * T * p.ldv + hk * D;
@@ -1032,7 +1049,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
     for (int d = 0; d < DT; ++d) { acc_dk[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc_dv[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     const int c_first = (j_min * 16) / CH;         // causal: queries below the pass's first key see none of its keys
     load_nat<D, CH, 512>(rq, qbase, p.ldq, c_first * CH, T, tid);
-    load_nat<D, CH, 512>(rdo, dobase, p.ldo, c_first * CH, T, tid);
+    load_nat_from<D, CH, 512>(rdo, dobase, p.ldo, c_first * CH, s0, T, tid);
     if (pass == 0) load_nat<D, CH, 512>(ro, obase, p.ldo, 0, T, tid);
 #pragma unroll 1
     for (int c = c_first; c < nch; ++c) {
@@ -1055,7 +1072,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
       tl_wait += TL_NOW() - tl_a;
       if (c + 1 < nch) {                            // next chunk's loads fly under this chunk's products
         load_nat<D, CH, 512>(rq, qbase, p.ldq, (c + 1) * CH, T, tid);
-        load_nat<D, CH, 512>(rdo, dobase, p.ldo, (c + 1) * CH, T, tid);
+        load_nat_from<D, CH, 512>(rdo, dobase, p.ldo, (c + 1) * CH, s0, T, tid);
         if (pass == 0) load_nat<D, CH, 512>(ro, obase, p.ldo, (c + 1) * CH, T, tid);
       }
       if (!have) continue;
@@ -1118,7 +1135,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
     TL_STAMP(2 + 2 * pass);
     // dK^T / dV^T of this wave's key tile: row d = dt*16 + g*4 + e, col key = fr (per query head under GQA: gqa_reduce_k sums);
     // stored through the wave's LDS stage as whole 128-byte row segments
-    if (j < nt && (pass < 2 || w < 4)) {
+    if (j < nt && (pass < 2 || w < 4) && j * 16 >= s0) {
       u16x4_t ok[DT], ov[DT];
       if (p.dkv_part) {
 #pragma unroll
@@ -1140,8 +1157,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
         for (int d = 0; d < DT; ++d)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(dkv[d][e]); ov[d][e] = f2bf(acc_dv[d][e]); }
-        store_rows_staged<DT>(stage, ok, p.dk + ((long long)b * T + j * 16) * p.lddk + hk * D, p.lddk, T - j * 16, lane);
-        store_rows_staged<DT>(stage, ov, p.dv + ((long long)b * T + j * 16) * p.lddv + hk * D, p.lddv, T - j * 16, lane);
+        store_rows_staged<DT>(stage, ok, p.dk + (drow0 + j * 16) * p.lddk + hk * D, p.lddk, T - j * 16, lane);
+        store_rows_staged<DT>(stage, ov, p.dv + (drow0 + j * 16) * p.lddv + hk * D, p.lddv, T - j * 16, lane);
       }
     }
     TL_STAMP(3 + 2 * pass);
@@ -1194,7 +1211,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
   TL_STAMP(8);
 #pragma unroll
   for (int z = 0; z < 3; ++z) {
-    if (qi[z] >= nt) continue;                      // wave-uniform
+    if (qi[z] >= nt || qi[z] * 16 < s0) continue;   // wave-uniform
     const int q = qi[z] * 16 + fr;
     float dqv[DT][4];
 #pragma unroll
@@ -1207,7 +1224,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int e = 0; e < 4; ++e) oq[d][e] = f2bf(dqv[d][e]);
-    store_rows_staged<DT>(stage, oq, p.dq + ((long long)b * T + qi[z] * 16) * p.lddq + h * D, p.lddq, T - qi[z] * 16, lane);
+    store_rows_staged<DT>(stage, oq, p.dq + (drow0 + qi[z] * 16) * p.lddq + h * D, p.lddq, T - qi[z] * 16, lane);
   }
   TL_STAMP(9);
   TL_PUT(10, tl_step); TL_PUT(11, tl_wait); TL_PUT(12, tl_n); TL_PUT(13, tl_p2);
@@ -1216,14 +1233,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_k(AttnArgs p) {
 // dk/dv[b, t, hk, :] = sum over the GQA group (fixed order, f32) of the bf16 per-query-head results; with `rope` the summed dK is
 // then RoPE-inverted (same arithmetic as rope_k on the bf16-rounded sum).  One thread = 8 columns c..c+7 of the first half of
 // the head AND their partners c + D/2.. (the rotary pairs) of one (b, t, hk).
+// dfirst > 0 (AttnBwdDesc::d_first): dk / dv are row-compacted - positions below dfirst are skipped, (b, t) is row b * (T - dfirst) + t - dfirst.
 __global__ void gqa_reduce_k(const bf16_t* __restrict__ part, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int B, int T,
-                             int Hq, int Hkv, int D, int lddk, int lddv, const float* __restrict__ rope) {
+                             int Hq, int Hkv, int D, int lddk, int lddv, const float* __restrict__ rope, int dfirst) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int dv16 = D / 16;
   const long long n = (long long)B * T * Hkv * dv16;
   if (i >= n) return;
   const int c = (int)(i % dv16) * 8, hk = (int)((i / dv16) % Hkv);
   const long long bt = i / ((long long)dv16 * Hkv);
+  if ((int)(bt % T) < dfirst) return;
+  const long long drow = bt - (bt / T + 1) * dfirst;
   const int grp = Hq / Hkv, half_d = D / 2;
   const long long half = (long long)B * T * Hq * D;
   float sk[2][8], sv[2][8];
@@ -1260,8 +1280,8 @@ __global__ void gqa_reduce_k(const bf16_t* __restrict__ part, bf16_t* __restrict
     u16x8_t ok, ov;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ok[e] = f2bf(sk[z][e]); ov[e] = f2bf(sv[z][e]); }
-    *reinterpret_cast<u16x8_t*>(dk + bt * lddk + hk * D + z * half_d + c) = ok;
-    *reinterpret_cast<u16x8_t*>(dv + bt * lddv + hk * D + z * half_d + c) = ov;
+    *reinterpret_cast<u16x8_t*>(dk + drow * lddk + hk * D + z * half_d + c) = ok;
+    *reinterpret_cast<u16x8_t*>(dv + drow * lddv + hk * D + z * half_d + c) = ov;
   }
 }
 
@@ -1351,6 +1371,13 @@ int lds_tr_probe(hipStream_t st, const int32_t* addr, int32_t* out) {
   return UVX_OK;
 }
 
+// head_dim 128, causal, at most 320 positions (the LLM's training sequences): ONE fused kernel per (batch, query head)
+constexpr int FUSED_TMAX = 320;
+bool attention_bwd_is_fused(int dtype, const AttnDesc& f) {
+  return dtype == DT_BF16 && attention_tr_reads(dtype) && f.D == 128 && f.causal && f.block == 0 && f.T <= FUSED_TMAX && g_options[13] &&
+         (f.window <= 0 || f.window >= f.T);   // (a window that covers the sequence is plain causal attention)
+}
+
 int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   if (d.f.B == 0 || d.f.T == 0) return UVX_OK;
   if (dtype != DT_BF16) return attention_bwd_f32(st, d);
@@ -1379,11 +1406,11 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
               hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, true, WK>), GK, dim3(NTH), 0, st, a); } \
     else { hipLaunchKernelGGL((attn_bwd_dq_k<DD, NTH, STEP, DEEP, false, WQ>), GQ, dim3(NTH), 0, st, a); \
            hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, false, WK>), GK, dim3(NTH), 0, st, a); } } while (0)
-  // head_dim 128, causal, at most 320 positions (the LLM's training sequences): ONE fused kernel per (batch, query head) -
-  // S and dP once, dS through LDS (tuning option 13, default on)
-  constexpr int FUSED_TMAX = 320;
-  const bool fused = tr && d.f.D == 128 && d.f.causal && d.f.block == 0 && d.f.T <= FUSED_TMAX && g_options[13] &&
-                     (d.f.window <= 0 || d.f.window >= d.f.T);   // (a window that covers the sequence is plain causal attention)
+  // (attention_bwd_is_fused above) S and dP once, dS through LDS (tuning option 13, default on)
+  const bool fused = attention_bwd_is_fused(dtype, d.f);
+  UVX_CHECK(d.d_first == 0 || (fused && d.d_first > 0 && d.d_first % 16 == 0 && d.d_first < d.f.T), UVX_ERR_UNSUPPORTED,
+            "attention_bwd: d_first = %d needs the fused backward kernel (head_dim 128, causal, T <= 320) and a multiple of 16 below T", d.d_first);
+  a.dfirst = d.d_first;
   if (fused) {
     constexpr int smem = (FUSED_TMAX / 16) * (FUSED_TMAX / 16 + 1) / 2 * 512 + 2 * 64 * 128 * 2 + 2 * FUSED_TMAX * 4 + 8 * STAGE_BYTES;
     static_assert(smem <= 160 * 1024, "LDS of one CU");
@@ -1414,7 +1441,7 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   if (a.dkv_part) {
     const long long n16 = (long long)d.f.B * d.f.T * d.f.Hkv * (d.f.D / 16);
     hipLaunchKernelGGL(gqa_reduce_k, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const bf16_t*)a.dkv_part, a.dk, a.dv, d.f.B, d.f.T, d.f.Hq,
-                       d.f.Hkv, d.f.D, a.lddk, a.lddv, a.rope);
+                       d.f.Hkv, d.f.D, a.lddk, a.lddv, a.rope, a.dfirst);
   }
   UVX_LAUNCH_CHECK();
   return UVX_OK;

@@ -103,14 +103,14 @@ __global__ void swiglu_fwd_k(const T* __restrict__ in, T* __restrict__ out, long
 
 template <typename T, int ACT>
 __global__ void swiglu_bwd_k(const T* __restrict__ dout, const T* __restrict__ in, T* __restrict__ din,
-                             long long n8, int half, int gate_first, const int32_t* __restrict__ rows_dev) {
+                             long long n8, int half, int gate_first, const int32_t* __restrict__ rows_dev, uvx::RowSkip in_map) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   const int hv = half / 8;
   const long long row = i / hv;
   if (rows_dev && row >= *rows_dev) return;
   const int c = (int)(i % hv) * 8;
-  const T* r = in + row * 2 * half;
+  const T* r = in + (in_map.skip ? row + (row / in_map.tc + 1) * in_map.skip : row) * 2 * half;
   T* dr = din + row * 2 * half;
   const int voff = gate_first == 2 ? (c / 16) * 32 + (c % 16) + 16 : (gate_first ? half + c : c);
   const int goff = gate_first == 2 ? (c / 16) * 32 + (c % 16) : (gate_first ? c : half + c);
@@ -507,12 +507,12 @@ int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, i
 }
 
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
-               int gate_first, int act, const int32_t* rows_dev) {
+               int gate_first, int act, const int32_t* rows_dev, RowSkip in_map) {
   UVX_CHECK(half % 8 == 0, UVX_ERR_SHAPE, "swiglu_bwd: half=%d must be a multiple of 8", half);
   UVX_CHECK(act >= 0 && act <= 2, UVX_ERR_INVALID, "swiglu_bwd: unknown activation %d", act);
   const long long n8 = (long long)rows * half / 8;
   if (n8 == 0) return UVX_OK;
-#define L(T, A) hipLaunchKernelGGL((swiglu_bwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)din, n8, half, gate_first, rows_dev)
+#define L(T, A) hipLaunchKernelGGL((swiglu_bwd_k<T, A>), dim3(grid1d(n8, 256)), dim3(256), 0, st, (const T*)dout, (const T*)in, (T*)din, n8, half, gate_first, rows_dev, in_map)
   if (dtype == DT_BF16) { if (act == 2) L(bf16_t, 2); else if (act) L(bf16_t, 1); else L(bf16_t, 0); }
   else { if (act == 2) L(float, 2); else if (act) L(float, 1); else L(float, 0); }
 #undef L
@@ -555,6 +555,24 @@ int gu_half(hipStream_t st, int dtype, void* gu, void* flat, long long M, int I,
   if (dtype == DT_BF16) { if (add) L(bf16_t, true); else L(bf16_t, false); }
   else { if (add) L(float, true); else L(float, false); }
 #undef L
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
+
+}  // namespace uvx
+namespace {
+__global__ void compact_row_list_k(const int32_t* __restrict__ rows, int32_t* __restrict__ out, int n, int T, int skip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  if (i == n) { out[n] = rows[n]; return; }
+  if (i >= rows[n]) return;
+  const int r = rows[i], b = r / T, t = r % T;
+  out[i] = t >= skip ? r - (b + 1) * skip : n - 1;
+}
+}  // namespace
+namespace uvx {
+int compact_row_list(hipStream_t st, const int32_t* rows, int32_t* out, int n, int T, int skip) {
+  hipLaunchKernelGGL(compact_row_list_k, dim3((n + 256) / 256), dim3(256), 0, st, rows, out, n, T, skip);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

@@ -94,6 +94,13 @@ inline int gemm(hipStream_t st, int dtype, const GemmDesc& d) {
   return dtype == DT_BF16 ? gemm_nt(st, d) : gemm_nt_f32(st, d);
 }
 
+// Row-compacted backward (model.hip: the LLM backward below the first position that needs a gradient): a gradient tensor holds only the positions
+// >= skip of every sequence, sequence b at row b * tc (tc = T - skip), while the forward stash keeps all T rows per sequence.  Row r of the
+// compact tensor is row r + (r / tc + 1) * skip of the stash.  skip == 0: no mapping.
+struct RowSkip {
+  int tc = 0, skip = 0;
+};
+
 // ---- norms.hip ----
 int layernorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, const void* b, void* y,
                   int rows, int cols, float eps);
@@ -107,7 +114,8 @@ int rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, void* y
 // (f32 [cols], atomically accumulated; must be zeroed by the caller).
 int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w,
                 const void* dx_add, void* dx, float* dw, int rows, int cols, float eps, int flavor = 0,
-                const int32_t* rows_dev = nullptr, float* dw_part = nullptr);
+                const int32_t* rows_dev = nullptr, float* dw_part = nullptr, RowSkip x_map = RowSkip(), bool map_dx = false);
+// x_map: dy / dx_add / dx are row-compacted, x is read through the map; map_dx: dx is written through the map as well (full-row output)
 // dw_part: scratch of rmsnorm_bwd_dw_scratch_floats(rows, cols) floats - the weight gradient is then summed over the blocks in a fixed order
 // (dw += the sum; bit-reproducible) instead of with atomics
 long long rmsnorm_bwd_dw_scratch_floats(int rows, int cols);
@@ -124,7 +132,11 @@ int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, v
 int swiglu_fwd(hipStream_t st, int dtype, const void* in, void* out, int rows, int half, int gate_first, int act = 0,
                const int32_t* rows_dev = nullptr);
 int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void* din, int rows, int half,
-               int gate_first, int act = 0, const int32_t* rows_dev = nullptr);
+               int gate_first, int act = 0, const int32_t* rows_dev = nullptr, RowSkip in_map = RowSkip());
+// in_map: dout / din are row-compacted, `in` (the stashed gate|up) is read through the map
+// out[i] = rows[i] - (rows[i] / T + 1) * skip for i < rows[n] (RowSkip: the index of a full-layout row among the row-compacted gradients; a row of a
+// position below `skip` has none and goes to the unused last row n - 1), out[n] = rows[n]
+int compact_row_list(hipStream_t st, const int32_t* rows, int32_t* out, int n, int T, int skip);
 // one half (0 gate / 1 up) of an interleaved gate|up tensor [M, 2 I] <-> contiguous [M, I]: add != 0: gu += flat (rounded once); else flat = gu
 int gu_half(hipStream_t st, int dtype, void* gu, void* flat, long long M, int I, int which, int add);
 // x[i] = round(x[i] * s) in place over n elements (Gemma: inputs_embeds * sqrt(hidden_size), and its gradient)
@@ -227,7 +239,11 @@ struct AttnBwdDesc {
   // bf16 kernels only (attention_bwd_fuses_rope): [T_table, D/2, 2] f32 cos / sin of the rotary embedding that produced q and k -
   // dq and dk are then written RoPE-INVERTED (gradients of the projections' outputs), saving the separate inverse-RoPE pass
   const float* rope_cos_sin = nullptr;
+  // > 0 (a multiple of 16; fused kernel only - attention_bwd_is_fused): dout / dq / dk / dv are ROW-COMPACTED - they hold the rows of positions
+  // >= d_first only, sequence b at row b * (T - d_first); gradients of positions below it are neither read nor written
+  int d_first = 0;
 };
+bool attention_bwd_is_fused(int dtype, const AttnDesc& f);
 inline bool attention_bwd_fuses_rope(int dtype) { return dtype == DT_BF16; }
 int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d);
 // true: the attention kernels of this dtype read vt / qt / kt / dot (callers run heads_transpose first); false (bf16 with tuning

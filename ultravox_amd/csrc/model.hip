@@ -198,6 +198,7 @@ struct LlmWs {
   void *x_final, *hn, *n, *act, *vt, *logits;
   float* ce_scratch;
   int32_t* sup;          // supervised-row compaction list (sup_rows), count at [M]
+  int32_t* sup_c;        // the same rows' indices among the row-compacted gradients (llm_backward, first_pos > 0)
   int32_t *kvs, *kvl;
   // backward
   void *dx, *d_hn, *d_act, *d_gu, *d_n, *d_o, *d_qkv, *qT, *kT, *doT;
@@ -266,6 +267,7 @@ LlmWs llm_carve(Arena& a, const uvx_config_t& c, int B, int T, int save) {
   w.lbT = a.take((size_t)64 * std::max(c.llm_d, c.llm_inter) * es);
   w.ce_scratch = (float*)a.take(sizeof(float) * (2 + M));
   w.sup = (int32_t*)a.take(sizeof(int32_t) * (M + 1));
+  w.sup_c = (int32_t*)a.take(sizeof(int32_t) * (M + 1));
   w.kvs = (int32_t*)a.take(sizeof(int32_t) * B);
   w.kvl = (int32_t*)a.take(sizeof(int32_t) * B);
   if (save) {
@@ -1196,9 +1198,10 @@ extern "C" int32_t uvx_llm_kl_loss(void* stream, const uvx_config_t* cfg, const 
 static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
                         int32_t B, int32_t T, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes,
                         bool compact_in_place, const uvx_encoder_lora_t* lora = nullptr,
-                        const uvx_encoder_lora_grads_t* lgrads = nullptr, bool top_rows = false) {
+                        const uvx_encoder_lora_grads_t* lgrads = nullptr, bool top_rows = false, int first_pos = 0) {
   RC(check_cfg(cfg));
   UVX_CHECK(w && d_inputs_embeds && workspace, UVX_ERR_INVALID, "llm_bwd: null argument");
+  UVX_CHECK(first_pos >= 0 && first_pos <= T, UVX_ERR_INVALID, "llm_bwd: first_pos %d outside [0, T = %d]", first_pos, T);
   const uvx_config_t& c = *cfg;
   RC(llm_check(c, w, T));
   const bool wts = c.llm_wt_stream != 0;      // transposed weights made on the fly (include/uvx.h)
@@ -1293,6 +1296,24 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   const bool tc = (top_rows || (compact_in_place && !lora)) && g_options[3] && !g3;
   if (top_rows || (compact_in_place && !lora)) RC(check_pair(workspace, tc));
   const int32_t* mdev_top = tc ? s.sup + M : nullptr;
+  // first_pos (uvx_llm_bwd_train_from): the caller needs no gradient below that position of any sequence - the text prefix before the first audio
+  // token: under the causal mask a position only feeds later ones, so nothing the adapter training updates is reachable from it.  Below the
+  // row-compacted last layer every gradient tensor then holds the positions >= rs.skip only (sequence b at row b * rs.tc): the dgrad GEMMs, the SwiGLU
+  // and norm backward run on B * rs.tc rows and read the stash through the map (kernels.h RowSkip), the fused attention backward takes the
+  // compacted d o / d q|k|v (AttnBwdDesc::d_first; it still needs every key for d q).  Same arithmetic per remaining row: the audio rows of
+  // d_inputs_embeds are bit-identical; its rows below rs.skip are zeros.  Conditions: the training pair's compact last layer (tc), the fused
+  // attention kernel on every layer, one chain, no per-row stash reader outside the three kernels above (adapters, q/k norms, Gemma-3's post norms).
+  RowSkip rs;
+  {
+    AttnDesc f;
+    f.B = B; f.T = T; f.D = dh; f.causal = 1; f.block = 0;
+    bool windowed = false;
+    for (int l = 0; l < c.llm_layers; ++l) windowed = windowed || (c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l]);
+    const int s16 = first_pos / 16 * 16;
+    if (s16 > 0 && s16 < T && tc && !lora && !c.llm_qk_norm && !windowed && g_options[11] < 2 && attention_bwd_is_fused(dt, f)) { rs.skip = s16; rs.tc = T - s16; }
+  }
+  auto rows_bwd = [&](const LlmWs& v) -> int { return rs.skip ? v.M / T * rs.tc : v.M; };
+  if (rs.skip) UVX_HIP(hipMemsetAsync(d_inputs_embeds, 0, (size_t)M * D * esz(dt), st));      // (layer 0 writes the rows >= rs.skip of every sequence)
   if (tc) {
     RC(gather_rows(st, dt, s.d_hn, s.sup, M, s.d_n, D));                 // d_hn was scattered to full rows: back to compact
     RC(rmsnorm_bwd(st, dt, s.d_n, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl, mdev_top));
@@ -1333,8 +1354,9 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   auto layer_mlp_bwd = [&](hipStream_t sx, const LlmWs& v, int l, bool compact) -> int {
     const uvx_llm_layer_t& L = w->layers[l];
     LlmLayerStash cur = llm_layer(v, l);
-    const int Mv = v.M;
-    const int32_t* mdev = compact ? v.sup + Mv : nullptr;
+    const int Mv = compact ? v.M : rows_bwd(v);      // (rs: the gradient tensors hold the positions >= rs.skip only; the stash is read through the map)
+    const RowSkip map = compact ? RowSkip() : rs;
+    const int32_t* mdev = compact ? v.sup + v.M : nullptr;
     const bool ad_in = lora && (lora->layers[l].g.a || lora->layers[l].u.a), ad_out = lora && lora->layers[l].d.a;
     if (g3) {
       // x_out = x_mid + post_ffw_norm(m_pre): d m_pre = norm'(dx) -> d act -> d gate|up -> d n2; d x_mid = dx + pre_ffw_norm'(d n2)
@@ -1346,7 +1368,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       if (ad_in) RC(mlp_in_adapters_bwd(sx, v, cur, l, L.ln2));
       return rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl);
     }
-    if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA && !ad_out) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
+    if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA && !ad_out && !map.skip) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
       GemmDesc g = lin_dgrad(v.dx, layer_t(l).wd_t, L.wd, v.d_gu, Mv, c.llm_inter, D);
       g.ldc = 2 * c.llm_inter; g.C2 = cur.gu; g.ldc2 = 2 * c.llm_inter; g.swiglu = 2; g.m_dev = mdev;
       RC(gemm(sx, dt, g));
@@ -1355,7 +1377,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       g.m_dev = mdev;
       RC(gemm(sx, dt, g));
       if (ad_out) RC(mlp_out_adapter_bwd(sx, v, cur, l, v.dx));
-      if (!probe_skip(4)) RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act, mdev));
+      if (!probe_skip(4)) RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act, mdev, map));
     }
     {
       GemmDesc g = lin_dgrad(v.d_gu, layer_t(l).wgu_t, L.wgu, v.d_n, Mv, D, 2 * c.llm_inter);
@@ -1363,14 +1385,14 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       RC(gemm(sx, dt, g));
     }
     if (ad_in) RC(mlp_in_adapters_bwd(sx, v, cur, l, L.ln2));
-    return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl, mdev);
+    return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl, mdev, nullptr, map);
   };
   // attention half: v.dx (gradient of x_mid) -> dx_out (gradient of the layer's input).  d_o_ready: v.d_o and the residual
   // gradient `resid` were already produced for the whole batch (compact last layer), else d_o = dx . W_o^T here.
-  auto layer_attn_bwd = [&](hipStream_t sx, const LlmWs& v, int Bv, int l, bool d_o_ready, const void* resid, void* dx_out) -> int {
+  auto layer_attn_bwd = [&](hipStream_t sx, const LlmWs& v, int Bv, int l, bool d_o_ready, const void* resid, void* dx_out, bool dx_full = false) -> int {
     const uvx_llm_layer_t& L = w->layers[l];
     LlmLayerStash cur = llm_layer(v, l);
-    const int Mv = v.M;
+    const int Mv = rows_bwd(v);      // (dx_full: dx_out keeps every row - layer 0 writes the caller's d_inputs_embeds through the map)
     if (g3) {      // x_mid = x_in + post_attention_norm(o_pre): d o_pre = norm'(d x_mid), then the o_proj dgrad
       RC(rmsnorm_bwd(sx, dt, v.dx, cur.o_pre, L.ln1_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
       RC(gemm(sx, dt, lin_dgrad(v.d_n, layer_t(l).wo_t, L.wo, v.d_o, Mv, s.OD, D)));
@@ -1397,6 +1419,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     bd.dout = v.d_o; bd.qt = v.qT; bd.kt = v.kT; bd.dot = v.doT; bd.delta = v.delta; bd.dkv_part = v.dkv_part;
     bd.dq = v.d_qkv; bd.dk = at(v.d_qkv, (size_t)Hq * dh, dt); bd.dv = at(v.d_qkv, (size_t)(Hq + Hkv) * dh, dt);
     bd.lddq = bd.lddk = bd.lddv = s.QKV;
+    bd.d_first = rs.skip;
     // the bf16 kernels write dq / dk RoPE-inverted (epilogue of the dQ kernel, GQA group reduction): no separate pass
     const bool rope_fused = attention_bwd_fuses_rope(dt) && g_options[14];
     const float* rope = g3 && w->layer_local && w->layer_local[l] ? w->rope_cos_sin_local : w->rope_cos_sin;
@@ -1427,7 +1450,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       if (R.k.a) RC(lora_up(sx, dt, at(v.lu, 64, dt), 128, R.k.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
       if (R.v.a) RC(lora_up(sx, dt, v.lu2, 128, R.v.a, 1, v.d_n, D, Mv, D, r, 1.0f, 1));
     }
-    return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_in, L.ln1, resid, dx_out, nullptr, Mv, D, c.rms_eps, fl);
+    return probe_skip(8) ? UVX_OK : rmsnorm_bwd(sx, dt, v.d_n, cur.x_in, L.ln1, resid, dx_out, nullptr, Mv, D, c.rms_eps, fl, nullptr, nullptr, rs, dx_full && rs.skip);
   };
   for (int l = 0; l < c.llm_layers; ++l) {
     const uvx_llm_layer_t& L = w->layers[l];
@@ -1442,10 +1465,15 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     GemmDesc g = lin_dgrad(s.dx, layer_t(top).wo_t, w->layers[top].wo, s.doT, M, s.OD, D);     // doT ([B, Hq, Tp, dh] >= M * OD) is free until the transpose
     g.m_dev = mdev_top;
     RC(gemm(st, dt, g));
+    const int32_t* rows_to = s.sup;
+    if (rs.skip) {      // the supervised rows' places among the row-compacted gradients
+      RC(compact_row_list(st, s.sup, s.sup_c, M, T, rs.skip));
+      rows_to = s.sup_c;
+    }
     UVX_HIP(hipMemsetAsync(s.d_o, 0, (size_t)M * s.OD * es, st));
-    RC(scatter_rows(st, dt, s.doT, s.sup, M, s.d_o, s.OD));
+    RC(scatter_rows(st, dt, s.doT, rows_to, M, s.d_o, s.OD));
     UVX_HIP(hipMemsetAsync(s.d_hn, 0, (size_t)M * D * es, st));
-    RC(scatter_rows(st, dt, s.dx, s.sup, M, s.d_hn, D));
+    RC(scatter_rows(st, dt, s.dx, rows_to, M, s.d_hn, D));
   }
   // schedule: one chain on the caller's stream, or (option 11) the batch slices on several streams - see Fork above
   const Chains ch = make_chains(st, s, c, B, T, dt == DT_BF16 && !lora && !wts);
@@ -1461,7 +1489,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
       const LlmWs& v = ch.v[h];
       if (!compact) rc_layers = layer_mlp_bwd(ch.st[h], v, l, false);
       void* dx_out = l == 0 ? (void*)((char*)d_inputs_embeds + (size_t)ch.b0[h] * T * D * es) : v.dx;
-      if (rc_layers == UVX_OK) rc_layers = layer_attn_bwd(ch.st[h], v, ch.b0[h + 1] - ch.b0[h], l, compact, compact ? v.d_hn : v.dx, dx_out);
+      if (rc_layers == UVX_OK) rc_layers = layer_attn_bwd(ch.st[h], v, ch.b0[h + 1] - ch.b0[h], l, compact, compact ? v.d_hn : v.dx, dx_out, l == 0);
     }
     if (wts && hipEventRecord(wt->e_free[l & 1], st) != hipSuccess && rc_layers == UVX_OK) rc_layers = UVX_ERR_RUNTIME;
   }
@@ -1490,6 +1518,12 @@ extern "C" int32_t uvx_llm_bwd_train(void* stream, const uvx_config_t* cfg, cons
                                      size_t ws_bytes) {
   return llm_backward(stream, cfg, w, labels, B, T, grad_scale, d_inputs_embeds, workspace, ws_bytes, false, nullptr, nullptr, true);
 }
+// ... when the caller needs no gradient below position first_pos of any sequence (include/uvx.h)
+extern "C" int32_t uvx_llm_bwd_train_from(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels,
+                                          int32_t B, int32_t T, int32_t first_pos, float grad_scale, void* d_inputs_embeds, void* workspace,
+                                          size_t ws_bytes) {
+  return llm_backward(stream, cfg, w, labels, B, T, grad_scale, d_inputs_embeds, workspace, ws_bytes, false, nullptr, nullptr, true, first_pos);
+}
 
 // LLM under LoRA training (text_model_lora_config.r > 0, apply_lora on the language model, ultravox_model.py:500-526):
 // the forward adds the adapters to q_proj / k_proj, the backward also returns their gradients.
@@ -1513,6 +1547,10 @@ extern "C" int32_t uvx_llm_bwd_lora(void* stream, const uvx_config_t* cfg, const
 extern "C" int32_t uvx_llm_bwd_rows(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, int32_t B, int32_t T,
                                     void* d_inputs_embeds, void* workspace, size_t ws_bytes) {
   return llm_backward(stream, cfg, w, nullptr, B, T, 1.0f, d_inputs_embeds, workspace, ws_bytes, true);
+}
+extern "C" int32_t uvx_llm_bwd_rows_from(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, int32_t B, int32_t T, int32_t first_pos,
+                                         void* d_inputs_embeds, void* workspace, size_t ws_bytes) {
+  return llm_backward(stream, cfg, w, nullptr, B, T, 1.0f, d_inputs_embeds, workspace, ws_bytes, true, nullptr, nullptr, false, first_pos);
 }
 
 extern "C" int32_t uvx_adamw_clip_step(void* stream, int32_t state_dtype, void* param, float* master, const float* grad,

@@ -309,7 +309,7 @@ template <typename T, bool WANT_DX, bool WANT_DW, int MV>
 __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ w,
                               const T* __restrict__ dx_add, T* __restrict__ dx, float* __restrict__ dw,
                               int rows, int cols, float eps, int rpb, int flavor, const int32_t* __restrict__ rows_dev,
-                              float* __restrict__ dw_part) {
+                              float* __restrict__ dw_part, uvx::RowSkip x_map, bool map_dx) {
   if (rows_dev) rows = min(rows, *rows_dev);     // device-side row count (row-compacted buffers)
   // flavor 1 (Gemma): y = x_hat * (1 + w) with no intermediate rounding -> the effective weight is 1 + w and
   // d w gets the UNROUNDED x_hat
@@ -325,7 +325,8 @@ __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
   const int r0 = blockIdx.x * rpb;
   const int r1 = min(rows, r0 + rpb);
   for (int row = r0; row < r1; ++row) {
-    const T* xr = x + (long long)row * cols;
+    const long long xrow = x_map.skip ? row + (row / x_map.tc + 1) * x_map.skip : row;      // (kernels.h RowSkip: the stash keeps every row)
+    const T* xr = x + xrow * cols;
     const T* dyr = dy + (long long)row * cols;
     float s1 = 0.f, s2 = 0.f;
     // the row is read from global memory ONCE: x, dy and w stay in registers between the reduction and the update
@@ -368,7 +369,7 @@ __global__ void rmsnorm_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] += r * gv[i] * (flavor ? 1.0f + wv[i] : wv[i]) - xv[i] * coef;
-        st8<T>(dx + (long long)row * cols + c, o);
+        st8<T>(dx + (map_dx ? xrow : (long long)row) * cols + c, o);
       }
       if (WANT_DW) {
 #pragma unroll
@@ -488,7 +489,8 @@ int stack_rmsnorm_fwd(hipStream_t st, int dtype, const void* x, const void* w, v
 
 template <typename T>
 static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const void* w, const void* dx_add,
-                          void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev, float* dw_part) {
+                          void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev, float* dw_part,
+                          uvx::RowSkip x_map, bool map_dx) {
   const int th = 256;   // (512 threads with one vector each: 20.4 vs 17.7 us at 2528 x 4096 - profiles/r03_rmsnorm_bwd_variants.txt)
   UVX_CHECK(cols % 8 == 0 && cols <= th * 8 * MAXV, UVX_ERR_SHAPE, "rmsnorm_bwd: cols=%d unsupported", cols);
   if (rows == 0) return UVX_OK;
@@ -498,13 +500,13 @@ static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const v
   do {                                                                                                            \
     if (cols <= th * 8)                                                                                           \
       hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, 1>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x,   \
-                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev, dw ? dw_part : nullptr);     \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev, dw ? dw_part : nullptr, x_map, map_dx);     \
     else if (cols <= th * 8 * 2)                                                                                  \
       hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, 2>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x,   \
-                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev, dw ? dw_part : nullptr);     \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev, dw ? dw_part : nullptr, x_map, map_dx);     \
     else                                                                                                          \
       hipLaunchKernelGGL((rmsnorm_bwd_k<T, DX, DW, MAXV>), dim3(grid), dim3(th), 0, st, (const T*)dy, (const T*)x, \
-                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev, dw ? dw_part : nullptr);     \
+                         (const T*)w, (const T*)dx_add, (T*)dx, dw, rows, cols, eps, rpb, flavor, rows_dev, dw ? dw_part : nullptr, x_map, map_dx);     \
   } while (0)
   if (dx && dw) L(true, true);
   else if (dx) L(true, false);
@@ -518,9 +520,9 @@ static int rms_bwd_launch(hipStream_t st, const void* dy, const void* x, const v
 long long rmsnorm_bwd_dw_scratch_floats(int rows, int cols) { return (long long)((rows + 15) / 16) * cols; }
 
 int rmsnorm_bwd(hipStream_t st, int dtype, const void* dy, const void* x, const void* w, const void* dx_add,
-                void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev, float* dw_part) {
-  return dtype == DT_BF16 ? rms_bwd_launch<bf16_t>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev, dw_part)
-                          : rms_bwd_launch<float>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev, dw_part);
+                void* dx, float* dw, int rows, int cols, float eps, int flavor, const int32_t* rows_dev, float* dw_part, RowSkip x_map, bool map_dx) {
+  return dtype == DT_BF16 ? rms_bwd_launch<bf16_t>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev, dw_part, x_map, map_dx)
+                          : rms_bwd_launch<float>(st, dy, x, w, dx_add, dx, dw, rows, cols, eps, flavor, rows_dev, dw_part, x_map, map_dx);
 }
 
 }  // namespace uvx

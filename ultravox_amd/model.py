@@ -737,20 +737,27 @@ class UltravoxModel:
         self._llm_top_rows = bool(train_pair) and not self.config.text_config.is_gemma3
         return CausalLMOutputWithPast(loss=None if loss is None else loss[0], logits=logits)
 
-    def language_model_backward(self, grad_scale: float = 1.0) -> torch.Tensor:
+    def language_model_backward(self, grad_scale: float = 1.0, first_pos: int = 0) -> torch.Tensor:
         """d loss / d inputs_embeds of the last ``language_model_forward(save_for_bwd=True)`` (or KL forward): the uvx_llm_bwd*
-        entry point that pairs with the forward that ran.  LoRA gradients (text_model_lora_config) land in their buffers."""
+        entry point that pairs with the forward that ran.  LoRA gradients (text_model_lora_config) land in their buffers.
+        first_pos > 0 (the training pair only): the caller needs no gradient below that position - uvx_llm_bwd_train_from."""
         l = _lib.lib()
         B, T, nb, lab = self._llm_ctx
         D = self.config.text_config.hidden_size
         d_embeds = torch.empty((B, T, D), device=self.device, dtype=self.dtype)
-        if isinstance(lab, str):      # "rows": the compact KL path left d logits for its row list in the workspace
+        if isinstance(lab, str) and first_pos > 0:
+            check(l.uvx_llm_bwd_rows_from(stream_ptr(), C.byref(self._c), C.byref(self._lw), B, T, int(first_pos), ptr(d_embeds),
+                                          ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_rows_from")
+        elif isinstance(lab, str):      # "rows": the compact KL path left d logits for its row list in the workspace
             check(l.uvx_llm_bwd_rows(stream_ptr(), C.byref(self._c), C.byref(self._lw), B, T, ptr(d_embeds),
                                      ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_rows")
         elif self.text_lora_r > 0:
             check(l.uvx_llm_bwd_lora(stream_ptr(), C.byref(self._c), C.byref(self._lw), C.byref(self._tlora), ptr(lab), B, T,
                                      C.c_float(grad_scale), ptr(d_embeds), C.byref(self._tlora_grads), ptr(self._ws["llm"]),
                                      C.c_size_t(nb)), "uvx_llm_bwd_lora")
+        elif self._llm_train_pair and first_pos > 0:
+            check(l.uvx_llm_bwd_train_from(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, int(first_pos), C.c_float(grad_scale),
+                                           ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_train_from")
         elif self._llm_train_pair:
             check(l.uvx_llm_bwd_train(stream_ptr(), C.byref(self._c), C.byref(self._lw), ptr(lab), B, T, C.c_float(grad_scale),
                                       ptr(d_embeds), ptr(self._ws["llm"]), C.c_size_t(nb)), "uvx_llm_bwd_train")
@@ -1387,6 +1394,29 @@ class UltravoxModel:
             x = min_p_(x, float(min_p))
         return torch.multinomial(torch.softmax(x, dim=-1), 1, generator=generator)[:, 0]
 
+    # The text before the first audio token needs no backward (include/uvx.h uvx_llm_bwd_train_from): the smallest audio_token_start_idx of the
+    # batch as a HOST integer.  Collator output on the host: free.  A device tensor: its minimum is copied to pinned memory right away (queued
+    # before the forward) and waited for only when the backward is about to be launched - the GPU has the whole forward queued by then.
+    skip_prefix_backward = True
+
+    def _first_audio_pos_begin(self, start):
+        if not self.skip_prefix_backward or start is None or start.numel() == 0 or self.text_lora_r > 0:
+            return 0
+        if not start.is_cuda:
+            return int(start.min())
+        if self.__dict__.get("_first_pos_host") is None:
+            self._first_pos_host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            self._first_pos_event = torch.cuda.Event()
+        self._first_pos_host.copy_(start.min().reshape(1), non_blocking=True)
+        self._first_pos_event.record()
+        return None
+
+    def _first_audio_pos_end(self, first) -> int:
+        if first is not None:
+            return first
+        self._first_pos_event.synchronize()
+        return int(self._first_pos_host[0])
+
     def forward_backward(self, grad_scale: float = 1.0, **batch) -> torch.Tensor:
         """loss = model(**batch).loss; (loss * grad_scale).backward() for the trainable (projector)
         parameters.  Gradients land in `self.proj_grad` (flat f32 bucket, overwritten)."""
@@ -1394,9 +1424,10 @@ class UltravoxModel:
             raise _lib.UvxError("model was built with with_backward=False")
         assert batch.get("labels") is not None, "labels are required for a training step"
         self._kl_grad_scale = grad_scale
+        first = self._first_audio_pos_begin(batch.get("audio_token_start_idx"))
         out = self.forward(return_logits=False, _save_for_bwd=True, **batch)
         self._kl_grad_scale = 1.0
-        d_embeds = self.language_model_backward(grad_scale)
+        d_embeds = self.language_model_backward(grad_scale, self._first_audio_pos_end(first))
         l = _lib.lib()
         D = self.config.text_config.hidden_size
         st, tl, B, T, n_items, Na, scratch = self._merge_ctx
