@@ -149,3 +149,37 @@ def test_kl_step_backward_from_the_first_audio_token_is_bit_identical(audio_lora
         assert g0[k].abs().max().item() > 0, k
         assert torch.equal(g0[k], g1[k]), (k, int((g0[k] != g1[k]).sum()))
     assert torch.equal(d0[:, 16:], d1[:, 16:]) and d1[:, :16].abs().max().item() == 0 and d0[:, :16].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("family", ["qwen3", "qwen2", "gemma3"])
+def test_backward_from_the_first_audio_token_on_the_other_backbones(family):
+    """The v0.6 recipes' backbones at head_dim 128: Qwen3 (per-head q / k norms: their backward reads the raw rows through the map), Qwen2 (q|k|v
+    bias) and Gemma-3 (no compact last layer - the final norm's backward runs on every row and the kept rows move to the front; post norms on both
+    branches, GeGLU, local layers whose window covers the sequence) - bit-identical to the full backward."""
+    from oracle.reference_cpu import synthetic_batch
+    from ultravox_amd.frontend import WhisperFeatureExtractor
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import random_state_dict
+    if family == "gemma3":
+        from test_gemma3_gpu import _cfg
+        cfg = _cfg(head_dim=128, layers=4)
+    elif family == "qwen3":
+        from test_qwen_gpu import _cfg
+        cfg = _cfg(family, head_dim=128)
+    else:      # qwen2: head_dim = hidden / heads
+        from ultravox_amd.config import UltravoxConfig
+        tc = dict(model_type="qwen2", hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                  vocab_size=512, rms_norm_eps=1e-6, rope_theta=1000000.0, eos_token_id=1)
+        cfg = UltravoxConfig(audio_config=dict(d_model=128, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=256), text_config=tc,
+                             hidden_size=256, projector_ln_mid=True)
+    sd = {k: v.bfloat16() for k, v in random_state_dict(cfg, seed=13).items()}
+    b = synthetic_batch(cfg, 2, 3.0, n_text=70, audio_start=35, n_supervised=12)
+    mel = WhisperFeatureExtractor(80).logmel_device(b.pop("pcm").to(DEV))
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16)
+    model.train()
+    l0, g0, d0 = _step(model, b, mel, skip=False)
+    l1, g1, d1 = _step(model, b, mel, skip=True)
+    assert torch.equal(l0, l1)
+    for k in g0:
+        assert g0[k].abs().max().item() > 0 and torch.equal(g0[k], g1[k]), (k, int((g0[k] != g1[k]).sum()))
+    assert torch.equal(d0[:, 32:], d1[:, 32:]) and d1[:, :32].abs().max().item() == 0 and d0[:, :32].abs().max().item() > 0

@@ -210,7 +210,7 @@ __global__ void qk_norm_rope_k(T* __restrict__ x, const T* __restrict__ wq, cons
 // rmsnorm_bwd_k's arithmetic per row of D: r = rsqrt(mean(x^2) + eps), dx = r dy w - x r^3 mean(dy w x).  One thread = 8 columns.
 template <typename T>
 __global__ void qk_norm_bwd_k(T* __restrict__ dqk, const T* __restrict__ raw, const T* __restrict__ wq, const T* __restrict__ wk,
-                              long long n_items, int Hq, int Hkv, int D, int ld, float eps, int flavor) {
+                              long long n_items, int Hq, int Hkv, int D, int ld, float eps, int flavor, uvx::RowSkip raw_map) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items) return;
   const int per_head = D / 8, H = Hq + Hkv;
@@ -221,7 +221,8 @@ __global__ void qk_norm_bwd_k(T* __restrict__ dqk, const T* __restrict__ raw, co
   T* g = dqk + row * ld + h * D + c;
   const T* w = (h < Hq ? wq : wk) + c;
   float xv[8], gv[8], wv[8], o[8];
-  ld8<T>(raw + (row * H + h) * D + c, xv);
+  const long long xrow = raw_map.skip ? row + (row / raw_map.tc + 1) * raw_map.skip : row;      // (kernels.h RowSkip: the stash keeps every row)
+  ld8<T>(raw + (xrow * H + h) * D + c, xv);
   ld8<T>(g, gv);
   ld8<T>(w, wv);
   if (flavor) {
@@ -569,8 +570,28 @@ __global__ void compact_row_list_k(const int32_t* __restrict__ rows, int32_t* __
   const int r = rows[i], b = r / T, t = r % T;
   out[i] = t >= skip ? r - (b + 1) * skip : n - 1;
 }
+template <typename T>
+__global__ void take_rows_from_k(const T* __restrict__ src, T* __restrict__ dst, long long n8, int cols, uvx::RowSkip map) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int cv = cols / 8;
+  const long long r = i / cv;
+  const int c = (int)(i % cv) * 8;
+  float v[8];
+  ld8<T>(src + (r + (r / map.tc + 1) * map.skip) * cols + c, v);
+  st8<T>(dst + r * cols + c, v);
+}
 }  // namespace
 namespace uvx {
+int take_rows_from(hipStream_t st, int dtype, const void* src, void* dst, int rows, int cols, RowSkip map) {
+  UVX_CHECK(cols % 8 == 0 && map.tc > 0 && src != dst, UVX_ERR_SHAPE, "take_rows_from: cols=%d tc=%d", cols, map.tc);
+  const long long n8 = (long long)rows * (cols / 8);
+  if (n8 == 0) return UVX_OK;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(take_rows_from_k<bf16_t>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n8, cols, map);
+  else hipLaunchKernelGGL(take_rows_from_k<float>, dim3(grid1d(n8, 256)), dim3(256), 0, st, (const float*)src, (float*)dst, n8, cols, map);
+  UVX_LAUNCH_CHECK();
+  return UVX_OK;
+}
 int compact_row_list(hipStream_t st, const int32_t* rows, int32_t* out, int n, int T, int skip) {
   hipLaunchKernelGGL(compact_row_list_k, dim3((n + 256) / 256), dim3(256), 0, st, rows, out, n, T, skip);
   UVX_LAUNCH_CHECK();
@@ -618,7 +639,7 @@ int qk_norm_rope(hipStream_t st, int dtype, void* qkv, const void* wq, const voi
 }
 
 int qk_norm_bwd(hipStream_t st, int dtype, void* d_qkv, const void* raw, const void* wq, const void* wk, int rows, int Hq, int Hkv,
-                int head_dim, int ld, float eps, int flavor) {
+                int head_dim, int ld, float eps, int flavor, RowSkip raw_map) {
   UVX_CHECK((head_dim == 64 || head_dim == 128 || head_dim == 256) && ld % 8 == 0, UVX_ERR_SHAPE,
             "qk_norm_bwd: head_dim=%d ld=%d unsupported", head_dim, ld);
   UVX_CHECK(d_qkv && raw && wq && wk, UVX_ERR_INVALID, "qk_norm_bwd: null argument");
@@ -626,10 +647,10 @@ int qk_norm_bwd(hipStream_t st, int dtype, void* d_qkv, const void* raw, const v
   if (n == 0) return UVX_OK;
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(qk_norm_bwd_k<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, (bf16_t*)d_qkv, (const bf16_t*)raw, (const bf16_t*)wq,
-                       (const bf16_t*)wk, n, Hq, Hkv, head_dim, ld, eps, flavor);
+                       (const bf16_t*)wk, n, Hq, Hkv, head_dim, ld, eps, flavor, raw_map);
   else
     hipLaunchKernelGGL(qk_norm_bwd_k<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, (float*)d_qkv, (const float*)raw, (const float*)wq,
-                       (const float*)wk, n, Hq, Hkv, head_dim, ld, eps, flavor);
+                       (const float*)wk, n, Hq, Hkv, head_dim, ld, eps, flavor, raw_map);
   UVX_LAUNCH_CHECK();
   return UVX_OK;
 }

@@ -137,6 +137,8 @@ int swiglu_bwd(hipStream_t st, int dtype, const void* dout, const void* in, void
 // out[i] = rows[i] - (rows[i] / T + 1) * skip for i < rows[n] (RowSkip: the index of a full-layout row among the row-compacted gradients; a row of a
 // position below `skip` has none and goes to the unused last row n - 1), out[n] = rows[n]
 int compact_row_list(hipStream_t st, const int32_t* rows, int32_t* out, int n, int T, int skip);
+// dst[r] = src[r + (r / map.tc + 1) * map.skip] for r < rows: the rows a RowSkip keeps, moved to the front (dst != src)
+int take_rows_from(hipStream_t st, int dtype, const void* src, void* dst, int rows, int cols, RowSkip map);
 // one half (0 gate / 1 up) of an interleaved gate|up tensor [M, 2 I] <-> contiguous [M, I]: add != 0: gu += flat (rounded once); else flat = gu
 int gu_half(hipStream_t st, int dtype, void* gu, void* flat, long long M, int I, int which, int add);
 // x[i] = round(x[i] * s) in place over n elements (Gemma: inputs_embeds * sqrt(hidden_size), and its gradient)
@@ -149,7 +151,7 @@ int rope_inplace(hipStream_t st, int dtype, void* qkv, const float* cos_sin, con
 int qk_norm_rope(hipStream_t st, int dtype, void* qkv, const void* wq, const void* wk, void* raw, const float* cos_sin,
                  const int32_t* pos, int rows, int T, int Hq, int Hkv, int head_dim, int ld, float eps, int flavor = 0);
 int qk_norm_bwd(hipStream_t st, int dtype, void* d_qkv, const void* raw, const void* wq, const void* wk, int rows, int Hq, int Hkv,
-                int head_dim, int ld, float eps, int flavor = 0);
+                int head_dim, int ld, float eps, int flavor = 0, RowSkip raw_map = RowSkip());
 int embed_gather(hipStream_t st, int dtype, const void* table, const int64_t* ids, void* out, int rows,
                  int D, int vocab);
 // owner[B*T] / item_batch[n_items] are int32 scratch filled by merge_owner and reused by the backward.

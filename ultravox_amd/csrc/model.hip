@@ -1301,8 +1301,8 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   // row-compacted last layer every gradient tensor then holds the positions >= rs.skip only (sequence b at row b * rs.tc): the dgrad GEMMs, the SwiGLU
   // and norm backward run on B * rs.tc rows and read the stash through the map (kernels.h RowSkip), the fused attention backward takes the
   // compacted d o / d q|k|v (AttnBwdDesc::d_first; it still needs every key for d q).  Same arithmetic per remaining row: the audio rows of
-  // d_inputs_embeds are bit-identical; its rows below rs.skip are zeros.  Conditions: the training pair's compact last layer (tc), the fused
-  // attention kernel on every layer, one chain, no per-row stash reader outside the three kernels above (adapters, q/k norms, Gemma-3's post norms).
+  // d_inputs_embeds are bit-identical; its rows below rs.skip are zeros.  Conditions: the training step's entry points, the fused attention kernel on
+  // every layer, one chain, no per-row stash reader outside the kernels that take the map (the LLM adapters' products do not).
   RowSkip rs;
   {
     AttnDesc f;
@@ -1310,13 +1310,16 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     bool windowed = false;
     for (int l = 0; l < c.llm_layers; ++l) windowed = windowed || (c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l]);
     const int s16 = first_pos / 16 * 16;
-    if (s16 > 0 && s16 < T && tc && !lora && !c.llm_qk_norm && !windowed && g_options[11] < 2 && attention_bwd_is_fused(dt, f)) { rs.skip = s16; rs.tc = T - s16; }
+    if (s16 > 0 && s16 < T && (top_rows || compact_in_place) && !lora && !windowed && g_options[11] < 2 && g_options[14] && attention_bwd_is_fused(dt, f)) { rs.skip = s16; rs.tc = T - s16; }      // (option 14: RoPE inverted inside the attention backward, by position - rope_k would take the row index)
   }
   auto rows_bwd = [&](const LlmWs& v) -> int { return rs.skip ? v.M / T * rs.tc : v.M; };
   if (rs.skip) UVX_HIP(hipMemsetAsync(d_inputs_embeds, 0, (size_t)M * D * esz(dt), st));      // (layer 0 writes the rows >= rs.skip of every sequence)
   if (tc) {
     RC(gather_rows(st, dt, s.d_hn, s.sup, M, s.d_n, D));                 // d_hn was scattered to full rows: back to compact
     RC(rmsnorm_bwd(st, dt, s.d_n, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl, mdev_top));
+  } else if (rs.skip) {      // (no compact last layer - Gemma-3, option 3 = 0: the final norm's backward on every row, then the kept rows to the front)
+    RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.d_n, nullptr, M, D, c.rms_eps, fl));
+    RC(take_rows_from(st, dt, s.d_n, s.dx, B * rs.tc, D, rs));
   } else {
     RC(rmsnorm_bwd(st, dt, s.d_hn, s.x_final, w->norm, nullptr, s.dx, nullptr, M, D, c.rms_eps, fl));
   }
@@ -1360,13 +1363,13 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     const bool ad_in = lora && (lora->layers[l].g.a || lora->layers[l].u.a), ad_out = lora && lora->layers[l].d.a;
     if (g3) {
       // x_out = x_mid + post_ffw_norm(m_pre): d m_pre = norm'(dx) -> d act -> d gate|up -> d n2; d x_mid = dx + pre_ffw_norm'(d n2)
-      RC(rmsnorm_bwd(sx, dt, v.dx, cur.m_pre, L.ln2_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
+      RC(rmsnorm_bwd(sx, dt, v.dx, cur.m_pre, L.ln2_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl, nullptr, nullptr, map));
       RC(gemm(sx, dt, lin_dgrad(v.d_n, layer_t(l).wd_t, L.wd, v.d_act, Mv, c.llm_inter, D)));
       if (ad_out) RC(mlp_out_adapter_bwd(sx, v, cur, l, v.d_n));      // (d m_pre: behind the post norm)
-      RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act));
+      RC(swiglu_bwd(sx, dt, v.d_act, cur.gu, v.d_gu, Mv, c.llm_inter, /*layout=*/2, /*act=*/c.llm_act, nullptr, map));
       RC(gemm(sx, dt, lin_dgrad(v.d_gu, layer_t(l).wgu_t, L.wgu, v.d_n, Mv, D, 2 * c.llm_inter)));
       if (ad_in) RC(mlp_in_adapters_bwd(sx, v, cur, l, L.ln2));
-      return rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl);
+      return rmsnorm_bwd(sx, dt, v.d_n, cur.x_mid, L.ln2, v.dx, v.dx, nullptr, Mv, D, c.rms_eps, fl, nullptr, nullptr, map);
     }
     if (dt == DT_BF16 && g_options[2] && fl == UVX_LLM_LLAMA && !ad_out && !map.skip) {   // d act = dx . W_down^T with the SwiGLU backward fused into the epilogue: writes d gate|up directly
       GemmDesc g = lin_dgrad(v.dx, layer_t(l).wd_t, L.wd, v.d_gu, Mv, c.llm_inter, D);
@@ -1394,7 +1397,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     LlmLayerStash cur = llm_layer(v, l);
     const int Mv = rows_bwd(v);      // (dx_full: dx_out keeps every row - layer 0 writes the caller's d_inputs_embeds through the map)
     if (g3) {      // x_mid = x_in + post_attention_norm(o_pre): d o_pre = norm'(d x_mid), then the o_proj dgrad
-      RC(rmsnorm_bwd(sx, dt, v.dx, cur.o_pre, L.ln1_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl));
+      RC(rmsnorm_bwd(sx, dt, v.dx, cur.o_pre, L.ln1_post, nullptr, v.d_n, nullptr, Mv, D, c.rms_eps, fl, nullptr, nullptr, rs));
       RC(gemm(sx, dt, lin_dgrad(v.d_n, layer_t(l).wo_t, L.wo, v.d_o, Mv, s.OD, D)));
     } else if (!d_o_ready) RC(gemm(sx, dt, lin_dgrad(v.dx, layer_t(l).wo_t, L.wo, v.d_o, Mv, s.OD, D)));
     const long long lwg_floats = llm_wg_floats(c, s.M);
@@ -1426,7 +1429,7 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
     if (rope_fused) bd.rope_cos_sin = rope;
     if (!probe_skip(1)) RC(attention_bwd(sx, dt, bd));
     if (!rope_fused) RC(rope_inplace(sx, dt, v.d_qkv, rope, nullptr, Mv, T, Hq + Hkv, dh, s.QKV, 1));
-    if (c.llm_qk_norm) RC(qk_norm_bwd(sx, dt, v.d_qkv, cur.qk_raw, L.q_norm, L.k_norm, Mv, Hq, Hkv, dh, s.QKV, c.rms_eps, g3 ? 1 : 0));
+    if (c.llm_qk_norm) RC(qk_norm_bwd(sx, dt, v.d_qkv, cur.qk_raw, L.q_norm, L.k_norm, Mv, Hq, Hkv, dh, s.QKV, c.rms_eps, g3 ? 1 : 0, rs));
     RC(gemm(sx, dt, lin_dgrad(v.d_qkv, layer_t(l).wqkv_t, L.wqkv, v.d_n, Mv, D, s.QKV)));
     if (lora) {   // LoRA gradients of q_proj / k_proj (/ v_proj) and their contribution to d n1 (rank-r products, lora.hip)
       const uvx_enc_lora_layer_t& R = lora->layers[l];
