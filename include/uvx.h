@@ -307,8 +307,7 @@ int32_t uvx_llm_bwd_train(void* stream, const uvx_config_t* cfg, const uvx_llm_w
  * first_pos = min(audio_token_start_idx) over the batch.  Below the last layer the gradient tensors are then row-compacted to the positions
  * >= first_pos rounded down to a multiple of 16 (dgrad GEMMs, SwiGLU / RMSNorm backward on B * (T - first_pos) rows; the attention backward
  * still reads every key).  d_inputs_embeds rows at or above first_pos: bit-identical to uvx_llm_bwd_train's; rows below it (rounded down):
- * zeros.  Where the compacted form does not apply (T > 320 or head_dim != 128: no fused attention backward; a sliding window shorter than T;
- * tuning options 11 >= 2, 13 = 0 or 14 = 0) or first_pos < 16 the call IS uvx_llm_bwd_train. */
+ * zeros.  Where the compacted form does not apply (tuning options 11 >= 2, 12 = 0 or 14 = 0) or first_pos < 16 the call IS uvx_llm_bwd_train. */
 int32_t uvx_llm_bwd_train_from(void* stream, const uvx_config_t* cfg, const uvx_llm_weights_t* w, const int64_t* labels, int32_t B,
                                int32_t T, int32_t first_pos, float grad_scale, void* d_inputs_embeds, void* workspace, size_t ws_bytes);
 /* labels == NULL: the saved logits already hold d loss / d logits (see uvx_llm_kl_loss). */

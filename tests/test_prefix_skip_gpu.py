@@ -87,31 +87,44 @@ def test_backward_from_the_first_audio_token_is_bit_identical(case):
     assert torch.equal(l1, l2) and torch.equal(d1, d2)
 
 
-def test_backward_from_a_position_below_16_or_on_an_unfused_path_is_the_full_backward():
-    """first_pos < 16 (nothing to skip after rounding), T > 320 (the attention backward pair, not the fused kernel), head_dim 64: the entry point
-    falls back to uvx_llm_bwd_train - every row of d inputs_embeds is written."""
+def test_backward_from_a_position_below_16_is_the_full_backward():
+    """first_pos < 16 (nothing to skip after rounding down to the 16-row tiles): the entry point IS uvx_llm_bwd_train - every row of d inputs_embeds is written."""
     cfg, model, b, mel = _setup(audio_start=9)
     _, _, d = _step(model, b, mel, skip=True)
     assert d[:, :9].abs().max().item() > 0
-    cfg, model, b, mel = _setup(audio_start=20, n_text=330, B=2)      # T = 330 + 19 audio tokens > 320
+
+
+@pytest.mark.parametrize("case", ["long", "head_dim_64", "window"])
+def test_backward_from_the_first_audio_token_on_the_unfused_attention_kernels(case):
+    """Sequences beyond the fused attention backward's 320 positions, head_dim 64 and sliding-window layers take the dQ + dK/dV kernel pair, which reads /
+    writes the row-compacted gradients the same way (AttnBwdDesc::d_first)."""
+    if case == "long":
+        cfg, model, b, mel = _setup(audio_start=20, n_text=330, B=2)      # T = 330 + 19 audio tokens > 320
+        s16 = 16
+    elif case == "window":      # Mistral: a 64-position window on every layer, shorter than the sequence
+        cfg, model, b, mel = _setup(audio_start=37, n_text=90, B=2, text_config=dict(HD128["text_config"], model_type="mistral", sliding_window=64))
+        assert model._c.llm_window == 64
+        s16 = 32
+    else:
+        from test_model_gpu import SMALL
+        from oracle.reference_cpu import synthetic_batch
+        from ultravox_amd.config import UltravoxConfig
+        from ultravox_amd.frontend import WhisperFeatureExtractor
+        from ultravox_amd.model import UltravoxModel
+        from ultravox_amd.weights import random_state_dict
+        cfg = UltravoxConfig(**SMALL)
+        sd = {k: v.bfloat16() for k, v in random_state_dict(cfg, seed=5).items()}
+        b = synthetic_batch(cfg, 2, 3.0, n_text=60, audio_start=33, n_supervised=12)
+        mel = WhisperFeatureExtractor(80).logmel_device(b.pop("pcm").to(DEV))
+        model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16)
+        model.train()
+        s16 = 32
     l0, g0, d0 = _step(model, b, mel, skip=False)
     l1, g1, d1 = _step(model, b, mel, skip=True)
-    assert torch.equal(l0, l1) and torch.equal(d0, d1) and d1[:, :16].abs().max().item() > 0
-    from test_model_gpu import SMALL      # head_dim 64
-    from oracle.reference_cpu import synthetic_batch
-    from ultravox_amd.config import UltravoxConfig
-    from ultravox_amd.frontend import WhisperFeatureExtractor
-    from ultravox_amd.model import UltravoxModel
-    from ultravox_amd.weights import random_state_dict
-    cfg = UltravoxConfig(**SMALL)
-    sd = {k: v.bfloat16() for k, v in random_state_dict(cfg, seed=5).items()}
-    b = synthetic_batch(cfg, 2, 3.0, n_text=60, audio_start=33, n_supervised=12)
-    mel = WhisperFeatureExtractor(80).logmel_device(b.pop("pcm").to(DEV))
-    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=torch.bfloat16)
-    model.train()
-    l0, g0, d0 = _step(model, b, mel, skip=False)
-    l1, g1, d1 = _step(model, b, mel, skip=True)
-    assert torch.equal(l0, l1) and torch.equal(d0, d1)
+    assert torch.equal(l0, l1)
+    for k in g0:
+        assert g0[k].abs().max().item() > 0 and torch.equal(g0[k], g1[k]), (k, int((g0[k] != g1[k]).sum()))
+    assert torch.equal(d0[:, s16:], d1[:, s16:]) and d1[:, :s16].abs().max().item() == 0 and d0[:, :s16].abs().max().item() > 0
 
 
 def test_trainer_steps_with_and_without_the_prefix_backward_give_the_same_weights():
@@ -160,7 +173,7 @@ def test_backward_from_the_first_audio_token_on_the_other_backbones(family):
     from ultravox_amd.frontend import WhisperFeatureExtractor
     from ultravox_amd.model import UltravoxModel
     from ultravox_amd.weights import random_state_dict
-    if family == "gemma3":
+    if family == "gemma3":      # (window 512 > T: the local layers' window covers the sequence)
         from test_gemma3_gpu import _cfg
         cfg = _cfg(head_dim=128, layers=4)
     elif family == "qwen3":

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
     if (iqs < q_last) iqs += ST;
     else if (ih < h_last) { iqs = q_begin; ++ih; }
     load_nat<D, ST, NT>(r.q, p.q + (long long)b * p.T * p.ldq + h * D, p.ldq, qs, p.T, tid);
-    load_nat<D, ST, NT>(r.d_o, p.dout + (long long)b * p.T * p.ldo + h * D, p.ldo, qs, p.T, tid);
+    load_nat_from<D, ST, NT>(r.d_o, p.dout + ((long long)b * (p.T - p.dfirst) - p.dfirst) * p.ldo + h * D, p.ldo, qs, p.dfirst, p.T, tid);      // (dfirst: see attn_bwd_fused_k)
     if constexpr (!TR) {
       load_tr<D, ST, NT>(r.qt, p.qt + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
       load_tr<D, ST, NT>(r.dot, p.dot + ((long long)b * p.Hq + h) * D * p.Tp, p.Tp, qs, tid);
@@ -729,7 +729,8 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
 #pragma unroll
   for (int wt = 0; wt < WT; ++wt) {
     const int key0 = key_w0 + wt * 16, key = key0 + fr;
-    if (key0 >= p.T) continue;    // wave-uniform
+    if (key0 >= p.T || key0 < p.dfirst) continue;    // wave-uniform (dfirst: row-compacted gradients - positions below it are not stored)
+    const long long drow0 = (long long)b * (p.T - p.dfirst) - p.dfirst;
     u16x4_t ok[DT], ov[DT];
     if (split) {
       // per-query-head dK / dV, rounded to bf16 like the un-grouped result below: that is where the reference rounds too (SDPA
@@ -753,8 +754,8 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkdv_k(AttnArgs p) {
       for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ok[d][e] = f2bf(dkv[d][e]); ov[d][e] = f2bf(acc_dv[wt][d][e]); }
-      store_rows<DT>(stage, ok, p.dk + ((long long)b * p.T + key0) * p.lddk + hk * D, p.lddk, p.T - key0, lane);
-      store_rows<DT>(stage, ov, p.dv + ((long long)b * p.T + key0) * p.lddv + hk * D, p.lddv, p.T - key0, lane);
+      store_rows<DT>(stage, ok, p.dk + (drow0 + key0) * p.lddk + hk * D, p.lddk, p.T - key0, lane);
+      store_rows<DT>(stage, ov, p.dv + (drow0 + key0) * p.lddv + hk * D, p.lddv, p.T - key0, lane);
     }
   }
 }
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
       u16x8_t a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0}, o8 = {0, 0, 0, 0, 0, 0, 0, 0};
       if (q < p.T) {
         a = *reinterpret_cast<const u16x8_t*>(p.q + ((long long)b * p.T + q) * p.ldq + h * D + ks * 32 + g * 8);
-        c = *reinterpret_cast<const u16x8_t*>(p.dout + ((long long)b * p.T + q) * p.ldo + h * D + ks * 32 + g * 8);
+        c = *reinterpret_cast<const u16x8_t*>(p.dout + ((long long)b * (p.T - p.dfirst) - p.dfirst + max(q, p.dfirst)) * p.ldo + h * D + ks * 32 + g * 8);
         o8 = *reinterpret_cast<const u16x8_t*>(p.o + ((long long)b * p.T + q) * p.ldo + h * D + ks * 32 + g * 8);
       }
       qf[wt][ks] = __builtin_bit_cast(bf16x8_t, a);
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
 #pragma unroll
   for (int wt = 0; wt < WT; ++wt) {
     const int q0 = q_w0 + wt * 16, q = q0 + fr;
-    if (q0 >= p.T) continue;   // wave-uniform; rows leave through the (now free) staging buffers as 128-byte segments
+    if (q0 >= p.T || q0 < p.dfirst) continue;   // wave-uniform; rows leave through the (now free) staging buffers as 128-byte segments
     char* stage = ldsAll + w * STAGE_BYTES;
     float dqv[DT][4];
 #pragma unroll
@@ -958,7 +959,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(AttnArgs p) {
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int e = 0; e < 4; ++e) oq[d][e] = f2bf(dqv[d][e]);
-    store_rows<DT>(stage, oq, p.dq + ((long long)b * p.T + q0) * p.lddq + h * D, p.lddq, p.T - q0, lane);
+    store_rows<DT>(stage, oq, p.dq + ((long long)b * (p.T - p.dfirst) - p.dfirst + q0) * p.lddq + h * D, p.lddq, p.T - q0, lane);
   }
 }
 
@@ -1378,6 +1379,12 @@ bool attention_bwd_is_fused(int dtype, const AttnDesc& f) {
          (f.window <= 0 || f.window >= f.T);   // (a window that covers the sequence is plain causal attention)
 }
 
+// row-compacted gradients (AttnBwdDesc::d_first): the bf16 kernels that read the natural-layout operands (no transposed copy of d o), causal masks
+// only - "a query below d_first meets keys below d_first only" is what makes the clamped d o reads harmless
+bool attention_bwd_takes_d_first(int dtype, const AttnDesc& f) {
+  return dtype == DT_BF16 && attention_tr_reads(dtype) && f.causal && f.block == 0 && (f.D == 64 || f.D == 128 || f.D == 256);
+}
+
 int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
   if (d.f.B == 0 || d.f.T == 0) return UVX_OK;
   if (dtype != DT_BF16) return attention_bwd_f32(st, d);
@@ -1408,8 +1415,8 @@ int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d) {
            hipLaunchKernelGGL((attn_bwd_dkdv_k<DD, NTH, STEP, DEEP, false, WK>), GK, dim3(NTH), 0, st, a); } } while (0)
   // (attention_bwd_is_fused above) S and dP once, dS through LDS (tuning option 13, default on)
   const bool fused = attention_bwd_is_fused(dtype, d.f);
-  UVX_CHECK(d.d_first == 0 || (fused && d.d_first > 0 && d.d_first % 16 == 0 && d.d_first < d.f.T), UVX_ERR_UNSUPPORTED,
-            "attention_bwd: d_first = %d needs the fused backward kernel (head_dim 128, causal, T <= 320) and a multiple of 16 below T", d.d_first);
+  UVX_CHECK(d.d_first == 0 || (attention_bwd_takes_d_first(dtype, d.f) && d.d_first > 0 && d.d_first % 16 == 0 && d.d_first < d.f.T), UVX_ERR_UNSUPPORTED,
+            "attention_bwd: d_first = %d needs the bf16 causal kernels on natural-layout operands and a multiple of 16 below T", d.d_first);
   a.dfirst = d.d_first;
   if (fused) {
     constexpr int smem = (FUSED_TMAX / 16) * (FUSED_TMAX / 16 + 1) / 2 * 512 + 2 * 64 * 128 * 2 + 2 * FUSED_TMAX * 4 + 8 * STAGE_BYTES;

@@ -241,11 +241,12 @@ struct AttnBwdDesc {
   // bf16 kernels only (attention_bwd_fuses_rope): [T_table, D/2, 2] f32 cos / sin of the rotary embedding that produced q and k -
   // dq and dk are then written RoPE-INVERTED (gradients of the projections' outputs), saving the separate inverse-RoPE pass
   const float* rope_cos_sin = nullptr;
-  // > 0 (a multiple of 16; fused kernel only - attention_bwd_is_fused): dout / dq / dk / dv are ROW-COMPACTED - they hold the rows of positions
+  // > 0 (a multiple of 16; attention_bwd_takes_d_first): dout / dq / dk / dv are ROW-COMPACTED - they hold the rows of positions
   // >= d_first only, sequence b at row b * (T - d_first); gradients of positions below it are neither read nor written
   int d_first = 0;
 };
 bool attention_bwd_is_fused(int dtype, const AttnDesc& f);
+bool attention_bwd_takes_d_first(int dtype, const AttnDesc& f);
 inline bool attention_bwd_fuses_rope(int dtype) { return dtype == DT_BF16; }
 int attention_bwd(hipStream_t st, int dtype, const AttnBwdDesc& d);
 // true: the attention kernels of this dtype read vt / qt / kt / dot (callers run heads_transpose first); false (bf16 with tuning

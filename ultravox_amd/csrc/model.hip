@@ -1301,16 +1301,14 @@ static int llm_backward(void* stream, const uvx_config_t* cfg, const uvx_llm_wei
   // row-compacted last layer every gradient tensor then holds the positions >= rs.skip only (sequence b at row b * rs.tc): the dgrad GEMMs, the SwiGLU
   // and norm backward run on B * rs.tc rows and read the stash through the map (kernels.h RowSkip), the fused attention backward takes the
   // compacted d o / d q|k|v (AttnBwdDesc::d_first; it still needs every key for d q).  Same arithmetic per remaining row: the audio rows of
-  // d_inputs_embeds are bit-identical; its rows below rs.skip are zeros.  Conditions: the training step's entry points, the fused attention kernel on
-  // every layer, one chain, no per-row stash reader outside the kernels that take the map (the LLM adapters' products do not).
+  // d_inputs_embeds are bit-identical; its rows below rs.skip are zeros.  Conditions: the training step's entry points, the bf16 attention kernels on
+  // natural-layout operands, one chain, no per-row stash reader outside the kernels that take the map (the LLM adapters' products do not).
   RowSkip rs;
   {
     AttnDesc f;
     f.B = B; f.T = T; f.D = dh; f.causal = 1; f.block = 0;
-    bool windowed = false;
-    for (int l = 0; l < c.llm_layers; ++l) windowed = windowed || (c.llm_window > 0 && T > c.llm_window && w->layer_local && w->layer_local[l]);
     const int s16 = first_pos / 16 * 16;
-    if (s16 > 0 && s16 < T && (top_rows || compact_in_place) && !lora && !windowed && g_options[11] < 2 && g_options[14] && attention_bwd_is_fused(dt, f)) { rs.skip = s16; rs.tc = T - s16; }      // (option 14: RoPE inverted inside the attention backward, by position - rope_k would take the row index)
+    if (s16 > 0 && s16 < T && (top_rows || compact_in_place) && !lora && g_options[11] < 2 && g_options[14] && attention_bwd_takes_d_first(dt, f)) { rs.skip = s16; rs.tc = T - s16; }      // (option 14: RoPE inverted inside the attention backward, by position - rope_k would take the row index)
   }
   auto rows_bwd = [&](const LlmWs& v) -> int { return rs.skip ? v.M / T * rs.tc : v.M; };
   if (rs.skip) UVX_HIP(hipMemsetAsync(d_inputs_embeds, 0, (size_t)M * D * esz(dt), st));      // (layer 0 writes the rows >= rs.skip of every sequence)
