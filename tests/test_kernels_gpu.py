@@ -1020,3 +1020,29 @@ def test_gemm_nn_form_equals_the_nt_kernel_on_the_transposed_matrix(M, N, K):
         assert rel_l2(first, a.float() @ w.float()) < 5e-3
     finally:
         L.uvx_gemm_force_variant(-1)
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,T", [(8, 32, 8, 316), (3, 8, 2, 77), (2, 16, 2, 512), (1, 64, 8, 316)])
+def test_attention_forward_grouped_query_block_form_is_bit_identical(B, Hq, Hkv, T):
+    """attn_fwd_k<128, .., GQ> (tuning option 25): the four waves of a block take four query heads of ONE KV head - per (head, query row) the key tiles arrive
+    in the same order as in the default form, so o and the log-sum-exp agree bit for bit, with padding on either side, in every tile count."""
+    from ultravox_amd import _lib, ops
+    L = _lib.lib()
+    torch.manual_seed(B * 1000 + T)
+    D = 128
+    qkv = torch.randn(B, T, (Hq + 2 * Hkv) * D, device=DEV).bfloat16()
+    q = qkv[..., :Hq * D].view(B, T, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hkv) * D].view(B, T, Hkv, D)
+    v = qkv[..., (Hq + Hkv) * D:].view(B, T, Hkv, D)
+    kv_start = torch.zeros(B, dtype=torch.int32, device=DEV)
+    kv_len = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    kv_start[0], kv_len[B - 1] = 5, T - 9
+    try:
+        L.uvx_set_option(25, 5)
+        o_ref, lse_ref = ops.attention(q, k, v, causal=True, kv_start=kv_start, kv_len=kv_len)
+        for form in (0, 1, 3, 4):
+            L.uvx_set_option(25, form)
+            o, lse = ops.attention(q, k, v, causal=True, kv_start=kv_start, kv_len=kv_len)
+            assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), form
+    finally:
+        L.uvx_set_option(25, 0)

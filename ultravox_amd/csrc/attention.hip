@@ -288,9 +288,12 @@ __device__ __forceinline__ void store_rows(char* stage, const u16x4_t (&v)[DT], 
 // (tried, round 6: s_setprio 1 around the two MFMA clusters of a tile - 111.6 / 114.9 us against 112.4 / 113.6: neutral, same file)
 // (tried, round 6: the softmax row sums from a fifth "d-tile" of ones in the P.V product instead of 16 v_add_f32 per 16 scores - 111.3 / 113.0 us
 //  against 113.9 / 113.4: within noise, and the normaliser then sums bf16-rounded probabilities (max |d O| 2e-3); not kept)
-template <int D, int QT, bool TR, bool PL = true>
+// GQ (round 6, short causal sequences under grouped-query attention): the block's four waves take the SAME QT query tiles of FOUR query heads of one KV
+// head instead of four query ranges of one head - the K / V tiles a block stages serve four heads (a quarter of the L2 -> LDS traffic and of the blocks'
+// prologues per head), the grid is (Hq / 4, B, T / (16 QT)).  Per (head, query row) the key tiles arrive in the same order: bit-identical results.
+template <int D, int QT, bool TR, bool PL = true, bool GQ = false>
 __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
-  constexpr int BQ = 4 * QT * 16;
+  constexpr int BQ = (GQ ? 1 : 4) * QT * 16;
   constexpr int KS = D / 32;   // k-steps of the QK^T product
   constexpr int DT = D / 16;   // 16-row tiles of O^T
   constexpr int TILE = 64 * D * 2;  // bytes of one K tile == one V^T tile
@@ -300,10 +303,10 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs p) {
   const int fr = lane & 15, g = lane >> 4;
   // grid = (heads, batch, query blocks): the query block is the slowest index and, under a causal mask, the LAST block -
   // the one with the most key tiles - is dispatched first (longest-first: the short blocks fill the tail of the launch)
-  const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);
+  const int b = blockIdx.y, h = GQ ? (int)blockIdx.x * 4 + w : (int)blockIdx.x, hk = h / (p.Hq / p.Hkv);      // (GQ: Hq / Hkv is a multiple of 4 - hk is block-uniform)
   const int qb0 = (p.causal ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z) * BQ;
   if (qb0 + BQ <= p.q_begin) return;   // chunked prefill: these query rows belong to the cached prefix (block-uniform exit)
-  const int q0 = qb0 + w * QT * 16;
+  const int q0 = GQ ? qb0 : qb0 + w * QT * 16;
   const int k_lo = p.kv_start ? p.kv_start[b] : 0;
   const int k_hi = p.kv_len ? min(p.kv_len[b], p.T) : p.T;
 
@@ -1355,7 +1358,16 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
     }
     else FWD(64, 1);
   } else if (d.D == 128) {
-    if (qt == 2) FWD(128, 2);
+    // The grouped-query form (GQ above) for short causal sequences: two query tiles per wave, taken when the launch still has two blocks per CU
+    // (profiles/r06_attn_fwd_gq_probe.txt: C2's 8 x 32 heads x 316 positions 30.3 -> 26.3 us, Llama-3.3-70B's 8 x 64 heads 57.7 -> 39.9; one prompt's
+    // 160 blocks are 6 % slower and keep the default form).  Tuning option 25: 0 = this rule, 1 / 3 / 4 = force two / three / one query tiles per wave
+    // (four spill), 5 = never.  Bit-identical in every form.
+    const bool gq_ok = tr && d.causal && d.block == 0 && d.T <= 512 && d.Hkv > 0 && (d.Hq / d.Hkv) % 4 == 0 && d.q_begin == 0;
+    const int gq = !gq_ok || g_options[25] == 5 ? 0 : g_options[25] ? g_options[25] : ((long long)(d.Hq / 4) * d.B * cdiv(d.T, 32) >= 512 ? 1 : 0);
+    if (gq == 1) { grid = dim3(d.Hq / 4, d.B, cdiv(d.T, 32)); hipLaunchKernelGGL((attn_fwd_k<128, 2, true, true, true>), grid, dim3(256), 0, st, a); }
+    else if (gq == 4) { grid = dim3(d.Hq / 4, d.B, cdiv(d.T, 16)); hipLaunchKernelGGL((attn_fwd_k<128, 1, true, true, true>), grid, dim3(256), 0, st, a); }
+    else if (gq == 3) { grid = dim3(d.Hq / 4, d.B, cdiv(d.T, 48)); hipLaunchKernelGGL((attn_fwd_k<128, 3, true, true, true>), grid, dim3(256), 0, st, a); }
+    else if (qt == 2) FWD(128, 2);
     else FWD(128, 1);
   } else {   // head_dim 256 (Gemma): one q tile per wave keeps the O accumulators (64 registers) + Q fragments in budget
     grid = dim3(d.Hq, d.B, cdiv(d.T, 64));
