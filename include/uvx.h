@@ -503,7 +503,8 @@ int32_t uvx_gemm_rmsnorm(void* stream, int32_t dtype, const uvx_gemm_desc_t* g, 
  * kernel instead of running rmsnorm + linear as two launches (default 0: measured 19-32 % slower per token; same arithmetic and rounding points, rstd may
  * differ in the last bit; A/B), key 25: the head_dim-128 causal attention forward under grouped-query attention (Hq / Hkv a multiple of 4, T <= 512) - 0 (default):
  * blocks whose four waves take four query heads of one KV head when the launch has >= 512 of them, 5: never, 1 / 3 / 4: always, with two / three / one
- * query tiles per wave (bit-identical in every form; A/B). */
+ * query tiles per wave (bit-identical in every form; A/B), key 26: weight rows in flight per wave of the one-row decode GEMV - 0 (default): 2, 4 / 8 / 16: that many
+ * (agree to rounding, not bitwise; A/B). */
 int32_t uvx_set_option(int32_t key, int32_t value);
 /* the current value of a tuning option (-1: unknown key) */
 int32_t uvx_get_option(int32_t key);

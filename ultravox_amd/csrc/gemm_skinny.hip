@@ -498,6 +498,14 @@ int gemm_skinny_rmsnorm_bf16(hipStream_t st, const GemmDesc& d, const void* norm
     static PerDeviceOnce attr; \
     UVX_SET_ATTR_ONCE(attr, (gemv_rows_bf16_k<MB, 4, RBV, true>), 64 * 1024); \
     hipLaunchKernelGGL((gemv_rows_bf16_k<MB, 4, RBV, true>), grid, dim3(512), sh, st, a); } while (0)
+#define UVX_GEMVN_R(RR, RBV) do { \
+    static PerDeviceOnce attr; \
+    UVX_SET_ATTR_ONCE(attr, (gemv_rows_bf16_k<1, RR, RBV, true>), 64 * 1024); \
+    hipLaunchKernelGGL((gemv_rows_bf16_k<1, RR, RBV, true>), grid, dim3(512), sh, st, a); } while (0)
+  if (mb == 1 && uvx::g_options[26] == 8) { if (rb == 32) UVX_GEMVN_R(8, 32); else if (rb == 16) UVX_GEMVN_R(8, 16); else UVX_GEMVN_R(8, 8); }
+  else if (mb == 1 && uvx::g_options[26] == 0) { if (rb == 32) UVX_GEMVN_R(2, 32); else if (rb == 16) UVX_GEMVN_R(2, 16); else UVX_GEMVN_R(2, 8); }
+  else if (mb == 1 && uvx::g_options[26] == 16) { if (rb == 32) UVX_GEMVN_R(16, 32); else if (rb == 16) UVX_GEMVN_R(16, 16); else UVX_GEMVN_R(8, 8); }
+  else
   if (rb == 32) { if (mb == 1) UVX_GEMVN(1, 32); else UVX_GEMVN(2, 32); }
   else if (rb == 16) { if (mb == 1) UVX_GEMVN(1, 16); else UVX_GEMVN(2, 16); }
   else { if (mb == 1) UVX_GEMVN(1, 8); else UVX_GEMVN(2, 8); }
@@ -535,7 +543,15 @@ int gemm_skinny_bf16(hipStream_t st, const GemmDesc& d) {
 #define UVX_GEMV(MB, RR) do { if (rb == 32) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, RR, 32>), grid, dim3(512), 0, st, a); \
                           else if (rb == 16) hipLaunchKernelGGL((gemv_rows_bf16_k<MB, RR, 16>), grid, dim3(512), 0, st, a); \
                           else hipLaunchKernelGGL((gemv_rows_bf16_k<MB, RR, 8>), grid, dim3(512), 0, st, a); } while (0)
-    if (d.M == 1) UVX_GEMV(1, 4); else UVX_GEMV(2, 4);
+    // Weight rows in flight per wave at M = 1 (tuning option 26; profiles/r06_decode_gemv_rows_in_flight_ab.txt, ms per decoded token, 8B / 70B): 16 rows 4.53 / 28.98,
+    // 8 rows 3.70 / 24.41, 4 rows (rounds 4-5) 3.27 / 22.79, 2 rows 3.25 / 22.65 - the default since round 6; 0 = 2 rows, 4 / 8 / 16 force (the lane butterfly
+    // folds R values at once, so the forms agree to rounding, not bitwise)
+    if (d.M == 1 && uvx::g_options[26] == 8) UVX_GEMV(1, 8);
+    else if (d.M == 1 && uvx::g_options[26] == 0) UVX_GEMV(1, 2);
+    else if (d.M == 1 && uvx::g_options[26] == 16) { if (rb == 32) hipLaunchKernelGGL((gemv_rows_bf16_k<1, 16, 32>), grid, dim3(512), 0, st, a);
+                                                      else if (rb == 16) hipLaunchKernelGGL((gemv_rows_bf16_k<1, 16, 16>), grid, dim3(512), 0, st, a);
+                                                      else hipLaunchKernelGGL((gemv_rows_bf16_k<1, 8, 8>), grid, dim3(512), 0, st, a); }
+    else if (d.M == 1) UVX_GEMV(1, 4); else UVX_GEMV(2, 4);
 #undef UVX_GEMV
     UVX_LAUNCH_CHECK();
     return UVX_OK;
