@@ -1022,14 +1022,13 @@ def test_gemm_nn_form_equals_the_nt_kernel_on_the_transposed_matrix(M, N, K):
         L.uvx_gemm_force_variant(-1)
 
 
-@pytest.mark.parametrize("B,Hq,Hkv,T", [(8, 32, 8, 316), (3, 8, 2, 77), (2, 16, 2, 512), (1, 64, 8, 316)])
-def test_attention_forward_grouped_query_block_form_is_bit_identical(B, Hq, Hkv, T):
+@pytest.mark.parametrize("B,Hq,Hkv,T,D", [(8, 32, 8, 316, 128), (3, 8, 2, 77, 128), (2, 16, 2, 512, 128), (1, 64, 8, 316, 128), (8, 32, 8, 316, 64), (2, 8, 2, 90, 64)])
+def test_attention_forward_grouped_query_block_form_is_bit_identical(B, Hq, Hkv, T, D):
     """attn_fwd_k<128, .., GQ> (tuning option 25): the four waves of a block take four query heads of ONE KV head - per (head, query row) the key tiles arrive
     in the same order as in the default form, so o and the log-sum-exp agree bit for bit, with padding on either side, in every tile count."""
     from ultravox_amd import _lib, ops
     L = _lib.lib()
     torch.manual_seed(B * 1000 + T)
-    D = 128
     qkv = torch.randn(B, T, (Hq + 2 * Hkv) * D, device=DEV).bfloat16()
     q = qkv[..., :Hq * D].view(B, T, Hq, D)
     k = qkv[..., Hq * D:(Hq + Hkv) * D].view(B, T, Hkv, D)

@@ -1349,6 +1349,12 @@ int attention_fwd(hipStream_t st, int dtype, const AttnDesc& d) {
 #define FWD(DD, Q) do { if (tr) hipLaunchKernelGGL((attn_fwd_k<DD, Q, true>), grid, dim3(256), 0, st, a); \
                         else hipLaunchKernelGGL((attn_fwd_k<DD, Q, false>), grid, dim3(256), 0, st, a); } while (0)
   if (d.D == 64) {
+    // (the grouped-query form of the head_dim-128 branch below, for the LLMs with 64-wide heads - Llama-3.2-1B: 32 query / 8 KV heads; same rule, option 25)
+    const bool gq64_ok = tr && d.causal && d.block == 0 && d.T <= 512 && d.Hkv > 0 && d.Hq != d.Hkv && (d.Hq / d.Hkv) % 4 == 0 && d.q_begin == 0 && uvx::g_attn_qt == 0;
+    const int gq64 = !gq64_ok || g_options[25] == 5 ? 0 : g_options[25] ? g_options[25] : ((long long)(d.Hq / 4) * d.B * cdiv(d.T, 32) >= 512 ? 1 : 0);
+    if (gq64 == 1 || gq64 == 3) { grid = dim3(d.Hq / 4, d.B, cdiv(d.T, 32)); hipLaunchKernelGGL((attn_fwd_k<64, 2, true, true, true>), grid, dim3(256), 0, st, a); }
+    else if (gq64 == 4) { grid = dim3(d.Hq / 4, d.B, cdiv(d.T, 16)); hipLaunchKernelGGL((attn_fwd_k<64, 1, true, true, true>), grid, dim3(256), 0, st, a); }
+    else
     if (qt == 4) FWD(64, 4);
     else if (qt == 3) FWD(64, 3);
     else if (qt == 2) {
