@@ -196,3 +196,28 @@ def test_backward_from_the_first_audio_token_on_the_other_backbones(family):
     for k in g0:
         assert g0[k].abs().max().item() > 0 and torch.equal(g0[k], g1[k]), (k, int((g0[k] != g1[k]).sum()))
     assert torch.equal(d0[:, 32:], d1[:, 32:]) and d1[:, :32].abs().max().item() == 0 and d0[:, :32].abs().max().item() > 0
+
+
+def test_text_only_sample_with_labels_in_front_of_the_first_audio_token():
+    """A batch that mixes audio samples with a text-only one (audio_batch_size 0) whose supervised positions lie BELOW the batch's first audio position: their
+    gradient can only reach text rows, so they drop out of the compacted backward (compact_row_list sends them to an unused row) - the loss still counts
+    them, and the projector gradients are those of the full backward, bit for bit."""
+    cfg, model, b, mel = _setup(B=3, audio_start=37, n_text=70)
+    T = b["input_ids"].shape[1]
+    g = torch.Generator().manual_seed(5)
+    b["input_ids"][1] = torch.randint(3, 500, (T,), generator=g)      # sample 1: text only (no placeholder run), supervised on positions 4 .. 19
+    b["labels"][1] = -100
+    b["labels"][1, 4:20] = b["input_ids"][1, 4:20]
+    b["attention_mask"][1, 40:] = 0
+    keep = torch.tensor([0, 2])
+    for k in ("audio_token_start_idx", "audio_lens", "audio_token_len"):
+        b[k] = b[k][keep]
+    b["audio_batch_size"] = torch.tensor([1, 0, 1])
+    mel = mel[keep.to(mel.device)]
+    l0, g0, d0 = _step(model, b, mel, skip=False)
+    l1, g1, d1 = _step(model, b, mel, skip=True)
+    assert torch.equal(l0, l1)
+    for k in g0:
+        assert g0[k].abs().max().item() > 0 and torch.equal(g0[k], g1[k]), (k, int((g0[k] != g1[k]).sum()))
+    assert torch.equal(d0[:, 32:], d1[:, 32:]) and d1[:, :32].abs().max().item() == 0
+    assert d0[1, :20].abs().max().item() > 0      # the full backward did carry the text-only sample's gradient
