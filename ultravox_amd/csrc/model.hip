@@ -743,6 +743,7 @@ extern "C" int32_t uvx_encoder_bwd(void* stream, const uvx_config_t* cfg, const 
     if (R.v.a) RC(lora_apply_bwd(st, dt, s.n, d, at(s.d_qkv, 2 * d, dt), 3 * d, S.bvT, S.t2, s.u2, G.v, M, d, d, r, lora->scaling, s.wg, wg_floats));
     if (l == 0) break;   // nothing trainable below layer 0
     // ---- d n1 = d qkv . Wqkv + u . [A_q ; A_k (; A_v)], then LN1 backward into the residual stream ----
+    if (l == 0) break;      // nothing below the first layer is trainable (frozen conv stem and positions): its input gradient has no consumer
     RC(gemm(st, dt, lin(s.d_qkv, L.wqkv_t, s.d_n, M, d, 3 * d)));
     if (qk_pair) {
       RC(lora_up2(st, dt, s.u, at(s.u, 64, dt), 128, R.q.a, R.k.a, s.d_n, s.d_n, d, M, d, d, r, 1.0f, 1.0f));      // (same rows: one pass, q term then k term)
