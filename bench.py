@@ -770,7 +770,7 @@ def main():
 
     if rank == 0:
         # rows per clip whose backward the step really skipped (uvx_llm_bwd_train_from): read off the last d inputs_embeds, whose skipped rows are zeros
-        s16 = 16 // 16 * 16      # synthetic_batch(audio_start = 16)
+        s16 = 16      # synthetic_batch(audio_start = 16), already a multiple of the 16-row tiles
         d_last = model.__dict__.get("_last_d_embeds")
         bwd_skip = s16 if (d_last is not None and model.skip_prefix_backward and float(d_last[:, :s16].abs().max()) == 0.0) else 0
         fl = flops_per_sample(cfg, wl["seconds"], top_rows=bool(model._llm_top_rows), bwd_skip_rows=bwd_skip)    # what the measured step really skipped
