@@ -324,6 +324,30 @@ def test_unpack_inverts_the_packed_tower_layouts(family, dtype):
         assert back[k].dtype == dtype and back[k].shape == sd[k].shape and torch.equal(back[k], sd[k]), k
 
 
+@pytest.mark.parametrize("family", ["group_norm", "layer_norm"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_unpack_wav2vec2_inverts_the_packed_tower_layouts(family, dtype):
+    """weights.unpack_wav2vec2 (what re-exports a LoRA-merged wav2vec2 tower): the im2col conv weights, the fused q|k|v with the pre-scaled q rows and
+    the rest go back to HF Wav2Vec2Model's checkpoint names bit for bit; the positional conv's weight-norm tensors and masked_spec_embed (a parameter
+    no kernel reads) come back as the checkpoint had them - every tower key, nothing else, in the order the name-only helper lists."""
+    from ultravox_amd.config import UltravoxConfig
+    from ultravox_amd.weights import pack_wav2vec2, random_state_dict, unpack_wav2vec2, wav2vec2_param_names
+    ac = {"model_type": "wav2vec2", "hidden_size": 128, "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 256, "conv_dim": [64] * 7,
+          "num_conv_pos_embeddings": 16, "num_conv_pos_embedding_groups": 4}
+    if family == "layer_norm":
+        ac.update(feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True)
+    cfg = UltravoxConfig(audio_config=ac, text_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                                           num_key_value_heads=2, head_dim=32, vocab_size=64), hidden_size=64)
+    sd = random_state_dict(cfg, seed=3, dtype=dtype)
+    sd["audio_tower.masked_spec_embed"] = torch.randn(128).to(dtype)
+    enc = pack_wav2vec2(sd, cfg, dtype, "cpu")
+    back = unpack_wav2vec2(enc, cfg)
+    tower = {k for k in sd if k.startswith("audio_tower.")}
+    assert set(back) == tower and wav2vec2_param_names(enc, cfg) == list(back)
+    for k in sorted(tower):
+        assert back[k].dtype == dtype and back[k].shape == sd[k].shape and torch.equal(back[k], sd[k]), k
+
+
 def test_unpack_refuses_a_scale_it_cannot_undo_exactly():
     from ultravox_amd.config import UltravoxConfig
     from ultravox_amd.weights import pack_encoder, random_state_dict, unpack_encoder

@@ -674,7 +674,7 @@ def test_wav2vec2_tower_matches_hf_model(norm, bias, stable):
                                       attn_implementation="eager")).eval()
     sd = random_state_dict(cfg, seed=2)
     missing, unexpected = hf.load_state_dict({k[len("audio_tower."):]: v for k, v in sd.items() if k.startswith("audio_tower.")}, strict=False)
-    assert not unexpected and missing == ["masked_spec_embed"]
+    assert not unexpected and not missing      # (masked_spec_embed, which no kernel reads, is part of the random tower since round 6)
     torch.manual_seed(1)
     x = O.wav2vec2_normalize_ref(torch.randn(2, 6000) * 0.1 + 0.02)
     with torch.no_grad():

@@ -262,7 +262,46 @@ def test_wav2vec2_lora_zero_b_is_the_frozen_tower_and_the_trainer_saves_peft_nam
     _, ck = checkpoint.load_pretrained(str(tmp_path))
     assert "audio_tower.base_model.model.encoder.layers.0.attention.q_proj.lora_A.default.weight" in ck
     assert sum(".lora_" in k for k in ck) == 4 * cfg1.audio_config.encoder_layers
-    w = [L["wqkv"].clone() for L in m1._enc["layers"]]
-    with pytest.raises(NotImplementedError, match="wav2vec2"):
-        m1.merge_and_unload()
-    assert m1.lora_r == 8 and all(torch.equal(L["wqkv"], a) for L, a in zip(m1._enc["layers"], w))
+    # (merge_and_unload of this tower: test_wav2vec2_merge_and_unload_matches_the_adapter_forward_and_is_re_exported below)
+
+
+@pytest.mark.parametrize("stable", [False, True], ids=["post_ln", "stable"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wav2vec2_merge_and_unload_matches_the_adapter_forward_and_is_re_exported(dtype, stable):
+    """UltravoxModel.merge_and_unload (ultravox_model.py:528-559) on a LoRA-adapted wav2vec2 tower: W += scaling * B A folded into the packed q|k|v rows
+    (q rows carry head_dim^-0.5) and out_proj; the merged tower computes the adapter forward's logits, joins keep_params under HF Wav2Vec2Model's names
+    and is written whole by save_pretrained (weights.unpack_wav2vec2: the weight-normed positional conv and masked_spec_embed exactly as loaded) - a
+    reload from that directory alone reproduces the logits bit for bit."""
+    import tempfile
+    from oracle.reference_cpu import synthetic_batch, wav2vec2_normalize_ref
+    from ultravox_amd.model import UltravoxModel
+    from ultravox_amd.weights import init_lora_state_dict, random_state_dict
+    fam = {"feat_extract_norm": "layer", "conv_bias": True, "do_stable_layer_norm": True} if stable else {}
+    cfg = _cfg(audio={**W2V_SMALL, **fam}, audio_model_lora_config={"r": 4, "lora_alpha": 8, "target_modules": ["q_proj", "k_proj", "v_proj", "out_proj"]})
+    sd = {k: v.to(dtype) for k, v in random_state_dict(cfg, seed=21).items()}
+    sd.update(init_lora_state_dict(cfg, seed=21, dtype=dtype, random_b=True))
+    model = UltravoxModel(cfg, state_dict=sd, device=DEV, dtype=dtype)
+    b = synthetic_batch(cfg, 2, 2.0, n_text=24, audio_start=5, n_supervised=8)
+    b["audio_values"] = wav2vec2_normalize_ref(b.pop("pcm")).to(dtype)
+    gb = {k: v.to(DEV) for k, v in b.items()}
+    before = model.forward(**gb).logits.float()
+    keep = [L["wqkv"].clone() for L in model._enc["layers"]]
+    model.merge_and_unload()
+    assert model.lora_r == 0 and all(not torch.equal(L["wqkv"], a) for L, a in zip(model._enc["layers"], keep))
+    after = model.forward(**gb).logits.float()
+    assert rel_l2(after, before) < (1e-5 if dtype == torch.float32 else 2e-2)
+    tower = {k for k in sd if k.startswith("audio_tower.") and ".lora_" not in k}
+    assert model.config.audio_model_id is None and tower <= model.keep_params and not any("lora_" in k for k in model.keep_params)
+    with tempfile.TemporaryDirectory() as d:
+        saved = model.save_pretrained(d)
+        assert tower <= set(saved) and torch.equal(saved["audio_tower.masked_spec_embed"].cpu(), sd["audio_tower.masked_spec_embed"])
+        for k in tower:      # what no adapter touched comes back as it was loaded
+            if "attention." not in k:
+                assert torch.equal(saved[k].cpu(), sd[k]), k
+        # the LLM was not adapted and is not in the checkpoint: it comes from the base (here: the same tensors); the tower of the base is ANOTHER random
+        # tower, so every tower tensor of the reloaded model is the checkpoint's
+        base = {**{k: v.to(dtype) for k, v in random_state_dict(_cfg(audio={**W2V_SMALL, **fam}), seed=999).items()},
+                **{k: v for k, v in sd.items() if k.startswith("language_model.")}}
+        again = UltravoxModel.from_pretrained(d, base_state_dict=base, device=DEV, dtype=dtype)
+    assert again.lora_r == 0 and again.is_wav2vec2
+    assert torch.equal(again.forward(**gb).logits, model.forward(**gb).logits)

@@ -23,7 +23,7 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .config import PROJECTOR_ACTS, LossConfig, LossFunction, UltravoxConfig
 from .weights import (LORA_FIELD, LORA_TARGETS, audio_lora_key, init_lora_state_dict, lora_targets, llm_lora_key, lora_key, pack_encoder, pack_llm, pack_wav2vec2,
-                      unpack_encoder, unpack_llm, check_encoder_exportable, encoder_param_names, llm_param_names,
+                      unpack_encoder, unpack_llm, unpack_wav2vec2, wav2vec2_param_names, check_encoder_exportable, encoder_param_names, llm_param_names,
                       random_state_dict)
 
 
@@ -371,14 +371,14 @@ class UltravoxModel:
         (`keep_params`, retained on the host by from_pretrained).  Deviation from the reference, stated: there `keep_params`
         may name ANY key of the module's state dict (ultravox_model.py:59, :565-584: the whole model lives in one nn.Module);
         here the frozen towers exist as packed device weights: a keep_param nobody retained on the host is read back from them
-        under its plain HF name (weights.unpack_encoder / unpack_llm).  What still cannot be re-saved: wav2vec2 tower keys, and
+        under its plain HF name (weights.unpack_encoder / unpack_wav2vec2 / unpack_llm).  What still cannot be re-saved:
         tower keys while that tower's adapters are un-merged (peft then nests the base weights under other names).
         strict=True (what save_pretrained / save_checkpoint use by default) raises for those; otherwise they are reported with a
         warning and left out (the reload then takes that tower from its base model id)."""
         sd = {**getattr(self, "_kept_tensors", {}), **self.projector_state_dict()}
         # frozen-tower keys nobody retained on the host are read back from the packed device weights (exact inverses of the
         # packing: weights.unpack_*) - the merged towers after merge_and_unload, or keep_params a caller added by name
-        for prefix, ok, unpack, packed in (("audio_tower.", not self.llm_only and not self.is_wav2vec2 and self.lora_r == 0, unpack_encoder, self._enc),
+        for prefix, ok, unpack, packed in (("audio_tower.", not self.llm_only and self.lora_r == 0, unpack_wav2vec2 if self.is_wav2vec2 else unpack_encoder, self._enc),
                                            ("language_model.", self.text_lora_r == 0, unpack_llm, self._llm)):
             if ok and any(k.startswith(prefix) and k not in sd for k in self.keep_params):
                 sd = {**unpack(packed, self.config, prefix), **sd}
@@ -465,15 +465,10 @@ class UltravoxModel:
         base weights, W += scaling * B @ A, and drop the adapters - afterwards the towers run their plain (frozen) kernels.
         As in the reference, a tower that carried adapters can no longer be re-created from its base model id: the id is
         cleared, every parameter of that tower joins keep_params (the next save_pretrained writes the merged tower whole, read
-        back from the packed device weights - weights.unpack_encoder / unpack_llm) and the two LoRA configs leave the config."""
+        back from the packed device weights - weights.unpack_encoder / unpack_wav2vec2 / unpack_llm) and the two LoRA configs leave the config."""
         def fold(w_rows: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scale: float) -> None:
             w_rows.copy_((w_rows.float() + scale * (B.float() @ A.float())).to(w_rows.dtype))
         kept = getattr(self, "_kept_tensors", {})
-        if self.lora_r > 0 and self.is_wav2vec2:
-            # the merged tower joins keep_params and is written whole by the next save_pretrained (ultravox_model.py:529-553): there is no inverse of
-            # pack_wav2vec2 (weight-normed positional conv, im2col conv stack) to re-export it with - refused before any weight changes
-            raise NotImplementedError("merge_and_unload with a LoRA-adapted wav2vec2 tower is not built (the merged tower could not be re-exported); "
-                                      "save_pretrained keeps the adapters under peft's names")
         if self.lora_r > 0:
             check_encoder_exportable(self.config)      # BEFORE any weight changes: a tower that cannot be re-exported is not half-merged (ADVICE r5)
         def fold_layer(L, rows, targets, keyfn, i, sc, q_scale=1.0) -> None:
@@ -524,7 +519,7 @@ class UltravoxModel:
         """named_parameters() of a (plain, un-wrapped) tower under the reference's key names."""
         if prefix == "audio_tower.":
             if self.is_wav2vec2:
-                raise ValueError("the wav2vec2 tower carries no adapters and is never re-exported")
+                return wav2vec2_param_names(self._enc, self.config, prefix)
             return encoder_param_names(self.config, prefix)
         return llm_param_names(self._llm, self.config, prefix)
 

@@ -88,6 +88,10 @@ def _random_wav2vec2(sd, a, rn, near_one, P):
         sd[L + "feed_forward.output_dense.bias"] = rn(d)
         sd[L + "final_layer_norm.weight"] = near_one(d)
         sd[L + "final_layer_norm.bias"] = rn(d)
+    # Wav2Vec2Model.masked_spec_embed (SpecAugment's fill vector; a parameter of every released checkpoint, read by no kernel here) - from a generator of
+    # its own so that the tensors above keep their values
+    sd[P + "masked_spec_embed"] = torch.rand(d, generator=torch.Generator().manual_seed(977)).to(device=sd[P + "encoder.layer_norm.bias"].device,
+                                                                                                  dtype=sd[P + "encoder.layer_norm.bias"].dtype)
 
 
 def _random_whisper(sd, a, rn, near_one, P, device, dtype):
@@ -296,6 +300,10 @@ def pack_wav2vec2(sd, cfg: UltravoxConfig, dtype, device, prefix="audio_tower.",
         g, v = sd[P + "weight_g"], sd[P + "weight_v"]
     else:
         g, v = None, sd[P + "weight"]
+    # (the parametrisation's own tensors - and masked_spec_embed, a Wav2Vec2Model parameter no kernel reads - are kept on the host as they came, for
+    #  unpack_wav2vec2: the fold below has no exact inverse)
+    out["host_keep"] = {k[len(prefix):]: sd[k].detach().to("cpu").clone() for k in sd
+                        if k.startswith(P) and not k.endswith("conv.bias") or k == prefix + "masked_spec_embed"}
     wpos = v if g is None else v * (g / v.float().norm(dim=(0, 1), keepdim=True).to(v.dtype))      # [d, d/G, K]
     G, K = a.num_conv_pos_embedding_groups, a.num_conv_pos_embeddings
     dg = d // G
@@ -443,6 +451,75 @@ def check_encoder_exportable(cfg: UltravoxConfig) -> None:
     dh = a.d_model // a.encoder_attention_heads
     if dh & (dh - 1) or (dh.bit_length() - 1) % 2:
         raise ValueError(f"encoder head_dim {dh}: head_dim^-0.5 is not a power of two, the packed q_proj cannot be unscaled exactly")
+
+
+def wav2vec2_param_names(enc: Dict[str, object], cfg: UltravoxConfig, prefix: str = "audio_tower.") -> List[str]:
+    """The keys unpack_wav2vec2 produces (HF Wav2Vec2Model named_parameters(), checkpoint names), without touching a tensor."""
+    a = cfg.audio_config
+    layer_norm = a.feat_extract_norm == "layer"
+    out = [prefix + "masked_spec_embed"] if "masked_spec_embed" in enc["host_keep"] else []
+    for i in range(len(a.conv_kernel)):
+        C = f"{prefix}feature_extractor.conv_layers.{i}."
+        out.append(C + "conv.weight")
+        if a.conv_bias:
+            out.append(C + "conv.bias")
+        if layer_norm or i == 0:
+            out += [C + "layer_norm.weight", C + "layer_norm.bias"]
+    out += [prefix + "feature_projection.layer_norm.weight", prefix + "feature_projection.layer_norm.bias",
+            prefix + "feature_projection.projection.weight", prefix + "feature_projection.projection.bias"]
+    out += [prefix + k for k in enc["host_keep"] if k != "masked_spec_embed"] + [prefix + "encoder.pos_conv_embed.conv.bias"]
+    out += [prefix + "encoder.layer_norm.weight", prefix + "encoder.layer_norm.bias"]
+    for i in range(a.encoder_layers):
+        L = f"{prefix}encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            out += [L + f"attention.{nm}.weight", L + f"attention.{nm}.bias"]
+        out += [L + "layer_norm.weight", L + "layer_norm.bias", L + "feed_forward.intermediate_dense.weight", L + "feed_forward.intermediate_dense.bias",
+                L + "feed_forward.output_dense.weight", L + "feed_forward.output_dense.bias", L + "final_layer_norm.weight", L + "final_layer_norm.bias"]
+    return out
+
+
+def unpack_wav2vec2(enc: Dict[str, object], cfg: UltravoxConfig, prefix: str = "audio_tower.", device="cpu") -> Dict[str, torch.Tensor]:
+    """pack_wav2vec2's operands -> HF Wav2Vec2Model names under `prefix` (what re-exports a LoRA-merged tower, ultravox_model.py:528-559): the im2col
+    conv weights back to [C_out, C_in, k], q_proj un-scaled (head_dim^-0.5 folded into its packed rows: exact for a power-of-two scale only -
+    check_encoder_exportable), the positional conv's weight-norm tensors as the checkpoint had them (kept on the host by pack_wav2vec2: the fold has no
+    exact inverse and no adapter touches them)."""
+    a = cfg.audio_config
+    d, H, Cc = a.d_model, a.encoder_attention_heads, a.conv_dim[0]
+    check_encoder_exportable(cfg)
+    inv = float(d // H) ** 0.5
+    cv = lambda x: x.detach().to(device).contiguous()
+    layer_norm = a.feat_extract_norm == "layer"
+    out: Dict[str, torch.Tensor] = {}
+    if "masked_spec_embed" in enc["host_keep"]:
+        out[prefix + "masked_spec_embed"] = cv(enc["host_keep"]["masked_spec_embed"])
+    for i, k in enumerate(a.conv_kernel):
+        C = f"{prefix}feature_extractor.conv_layers.{i}."
+        out[C + "conv.weight"] = cv(enc["conv0_w"][:, :k].reshape(Cc, 1, k)) if i == 0 else cv(enc["conv_w"][i].reshape(Cc, k, Cc).permute(0, 2, 1))
+        if a.conv_bias:
+            out[C + "conv.bias"] = cv(enc["conv_b"][i])
+        if layer_norm:
+            out[C + "layer_norm.weight"], out[C + "layer_norm.bias"] = cv(enc["conv_ln_w"][i]), cv(enc["conv_ln_b"][i])
+        elif i == 0:
+            out[C + "layer_norm.weight"], out[C + "layer_norm.bias"] = cv(enc["gn_w"]), cv(enc["gn_b"])
+    out[prefix + "feature_projection.layer_norm.weight"], out[prefix + "feature_projection.layer_norm.bias"] = cv(enc["fp_ln_w"]), cv(enc["fp_ln_b"])
+    out[prefix + "feature_projection.projection.weight"], out[prefix + "feature_projection.projection.bias"] = cv(enc["fp_w"]), cv(enc["fp_b"])
+    for k, v in enc["host_keep"].items():
+        if k != "masked_spec_embed":
+            out[prefix + k] = cv(v)
+    out[prefix + "encoder.pos_conv_embed.conv.bias"] = cv(enc["pos_b"])
+    out[prefix + "encoder.layer_norm.weight"], out[prefix + "encoder.layer_norm.bias"] = cv(enc["ln_w"]), cv(enc["ln_b"])
+    for i, lay in enumerate(enc["layers"]):
+        L = f"{prefix}encoder.layers.{i}."
+        w, b = lay["wqkv"], lay["bqkv"]
+        for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+            sc = inv if j == 0 else 1.0
+            out[L + f"attention.{nm}.weight"], out[L + f"attention.{nm}.bias"] = cv(w[j * d:(j + 1) * d] * sc), cv(b[j * d:(j + 1) * d] * sc)
+        out[L + "attention.out_proj.weight"], out[L + "attention.out_proj.bias"] = cv(lay["wo"]), cv(lay["bo"])
+        out[L + "layer_norm.weight"], out[L + "layer_norm.bias"] = cv(lay["ln1_w"]), cv(lay["ln1_b"])
+        out[L + "feed_forward.intermediate_dense.weight"], out[L + "feed_forward.intermediate_dense.bias"] = cv(lay["fc1_w"]), cv(lay["fc1_b"])
+        out[L + "feed_forward.output_dense.weight"], out[L + "feed_forward.output_dense.bias"] = cv(lay["fc2_w"]), cv(lay["fc2_b"])
+        out[L + "final_layer_norm.weight"], out[L + "final_layer_norm.bias"] = cv(lay["ln2_w"]), cv(lay["ln2_b"])
+    return out
 
 
 def encoder_param_names(cfg: UltravoxConfig, prefix: str = "audio_tower.") -> List[str]:
