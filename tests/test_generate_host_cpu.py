@@ -267,6 +267,54 @@ def test_beam_search_host_logic_against_the_oracle_restatement(model, case, n_eo
     assert torch.equal(out.sequences, want) and out.sequences_scores.shape == (want.shape[0],) and out.past_key_values is None
 
 
+@pytest.mark.parametrize("case", [dict(num_beams=3), dict(num_beams=2, temperature=0.8, top_k=20), dict(num_beams=3, top_p=0.9, repetition_penalty=2.0, num_return_sequences=2),
+                                  dict(num_beams=4, temperature=1.5, top_k=30, top_p=0.95, length_penalty=0.0)])
+@pytest.mark.parametrize("n_eos", [1, 2])
+def test_beam_sampling_host_logic_against_the_oracle_restatement(model, case, n_eos):
+    """generate(num_beams > 1, do_sample=True) on the simulated device against the oracle's restatement of HF's beam sampling (pinned to HF generate in
+    tests/test_oracle_pinning.py), both drawing from the CPU generator after the same torch.manual_seed: one multinomial on the [B, beams * V] matrix per
+    step, the warpers ([3P] HF's own classes on the oracle's side, UltravoxModel._warp on ours) behind the score processors with 1 + n_terminators tokens
+    kept - token for token, and not what plain beam search returns."""
+    from oracle.reference_cpu import beam_search_ref
+    from transformers.generation import logits_process as LP
+
+    def bump(target):
+        d = torch.arange(V, dtype=torch.float32) - target
+        return -(d.abs() * 0.11 + (d > 0) * 0.07)
+    model.fake._logits = lambda k, v, lo, hi, out: [out.__setitem__(b, bump(int(round(float((k[b, lo[b]:hi] * (v[b, lo[b]:hi] + 1.0)).sum()))) % V))
+                                                    for b in range(k.shape[0])]
+    ids, am = left_padded(3, 8, [0, 3, 1], seed=11)
+    eos = -1 if n_eos == 1 else [5, 9]
+
+    def next_logits(hyps):
+        out = torch.empty(len(hyps), len(hyps[0]), V)
+        for b, item in enumerate(hyps):
+            keep = am[b].bool()
+            lo = int(torch.nonzero(keep)[0, 0])
+            for j, toks in enumerate(item):
+                feat = torch.cat([ids[b].float() + 1.0, torch.tensor(toks, dtype=torch.float32) + 1.0])
+                pos = torch.cumsum(keep.long(), 0) - 1
+                pos = torch.cat([pos, int(keep.sum()) + torch.arange(len(toks))]).float()
+                out[b, j] = bump(int(round(float((feat[lo:] * (pos[lo:] + 1.0)).sum()))) % V)
+        return out
+    warp = LP.LogitsProcessorList()
+    if case.get("temperature", 1.0) != 1.0:
+        warp.append(LP.TemperatureLogitsWarper(case["temperature"]))
+    if case.get("top_k"):
+        warp.append(LP.TopKLogitsWarper(case["top_k"], min_tokens_to_keep=n_eos + 1))
+    if case.get("top_p", 1.0) < 1.0:
+        warp.append(LP.TopPLogitsWarper(case["top_p"], min_tokens_to_keep=n_eos + 1))
+    torch.manual_seed(31)
+    want = beam_search_ref(next_logits, ids, 6, eos, 1, case["num_beams"], case.get("length_penalty", 1.0), False, case.get("num_return_sequences", 1),
+                           case.get("repetition_penalty"), warp, do_sample=True)
+    torch.manual_seed(31)
+    got = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=eos, pad_token_id=1, do_sample=True, **case)
+    assert got.shape == want.shape and torch.equal(got, want), (got[:, 8:], want[:, 8:])
+    plain = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=eos, pad_token_id=1,
+                           **{k: v for k, v in case.items() if k not in ("temperature", "top_k", "top_p")})
+    assert plain.shape != got.shape or not torch.equal(plain, got)
+
+
 def test_longest_common_prefix_reuse_is_opt_in_and_keeps_the_old_state_intact(model):
     ids, am = left_padded(2, 10, [0, 2], seed=7)
     out = model.generate(ids, attention_mask=am, max_new_tokens=8, eos_token_id=-1, return_dict_in_generate=True)

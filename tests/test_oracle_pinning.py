@@ -300,6 +300,56 @@ def test_beam_search_matches_hf_generate(n_eos):
     assert n_eos == 1 or short > 0          # (the many-terminator settings must actually end hypotheses early)
 
 
+BEAM_SAMPLE_CASES = [dict(num_beams=3, top_k=0), dict(num_beams=4, top_k=12, temperature=0.7), dict(num_beams=2, top_k=0, top_p=0.8, length_penalty=0.0),
+                     dict(num_beams=3, top_k=0, temperature=1.3, num_return_sequences=2, repetition_penalty=1.4)]
+
+
+@pytest.mark.parametrize("n_eos", [1, 2])
+def test_beam_sampling_matches_hf_generate(n_eos):
+    """[3P] HF beam SAMPLING (generate(num_beams > 1, do_sample=True): GenerationMixin._get_top_k_continuations draws the K continuations with ONE
+    torch.multinomial on softmax(running score + warped log-probabilities) per step) against the oracle's restatement, both on the CPU generator after
+    the same torch.manual_seed: token for token.  The warpers (temperature, top-k, top-p) are HF's own classes at the tail of the processor list."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from transformers.generation import logits_process as LP
+    cfg = tiny_cfg()
+    t = cfg.text_config
+    hf = LlamaForCausalLM(LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size, num_hidden_layers=t.num_hidden_layers,
+                                      num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size,
+                                      rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta, max_position_embeddings=t.max_position_embeddings,
+                                      tie_word_embeddings=False, attn_implementation="eager", eos_token_id=3, pad_token_id=3)).eval()
+    sd = random_state_dict(cfg, seed=8)
+    sd["language_model.model.embed_tokens.weight"] = sd["language_model.model.embed_tokens.weight"] * 0.3
+    hf.load_state_dict({k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}, strict=False)
+    torch.manual_seed(4)
+    B, T = 3, 11
+    ids = torch.randint(4, t.vocab_size, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[0, :4] = 0
+    ids[am == 0] = 3
+    eos = 3 if n_eos == 1 else list(range(3, 3 + n_eos))
+    om = O.OracleModel(cfg, sd)
+    distinct = 0
+    for i, case in enumerate(BEAM_SAMPLE_CASES):
+        torch.manual_seed(100 + i)
+        with torch.no_grad():
+            want = hf.generate(input_ids=ids, attention_mask=am, max_new_tokens=7, do_sample=True, eos_token_id=eos, pad_token_id=3, **case)
+            greedy = hf.generate(input_ids=ids, attention_mask=am, max_new_tokens=7, do_sample=False, eos_token_id=eos, pad_token_id=3,
+                                 **{k: v for k, v in case.items() if k not in ("top_k", "top_p", "temperature")})
+        warp = LP.LogitsProcessorList()
+        if case.get("temperature", 1.0) != 1.0:
+            warp.append(LP.TemperatureLogitsWarper(case["temperature"]))
+        if case.get("top_k", 0):
+            warp.append(LP.TopKLogitsWarper(case["top_k"], min_tokens_to_keep=n_eos + 1))      # (HF, beam methods: one non-terminator must survive)
+        if case.get("top_p", 1.0) < 1.0:
+            warp.append(LP.TopPLogitsWarper(case["top_p"], min_tokens_to_keep=n_eos + 1))
+        plain = {k: v for k, v in case.items() if k not in ("top_k", "top_p", "temperature")}
+        torch.manual_seed(100 + i)
+        got = om.generate_beam(7, eos_token_id=eos, pad_token_id=3, input_ids=ids, attention_mask=am, logits_processor=warp, do_sample=True, **plain)
+        assert got.shape == want.shape and torch.equal(got, want), (case, got[:, T:], want[:, T:])
+        distinct += int(want.shape != greedy.shape or not torch.equal(want, greedy))
+    assert distinct > 0      # (the draws did change the result against plain beam search)
+
+
 KL_CASES = ["basic", "no_eot", "temp1_w05", "one_empty_row", "padded_tail"]
 
 

@@ -1102,16 +1102,14 @@ class UltravoxModel:
         num_beams = int(kwargs.get("num_beams", 1) or 1)
         nrs = int(kwargs.get("num_return_sequences", 1) or 1)
         if num_beams > 1:
-            if do_sample:
-                raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not built")
             if streamer is not None:
                 raise ValueError("`streamer` cannot be used with beam search (yet!). Make sure that `num_beams` is set to 1.")
             if past is not None:
                 raise NotImplementedError("beam search starts from the prompt: past_key_values is not supported with num_beams > 1")
             if nrs > num_beams:
                 raise ValueError(f"`num_return_sequences` ({nrs}) has to be smaller or equal to `num_beams` ({num_beams}).")
-            if crit or min_p is not None:
-                raise NotImplementedError("beam search with stopping_criteria / sampling warpers is not built")
+            if crit or (min_p is not None and not do_sample):
+                raise NotImplementedError("beam search with stopping_criteria is not built" if crit else "min_p is a sampling warper: it needs do_sample=True")
         elif nrs != 1:
             raise ValueError(f"Greedy methods without beam search do not support `num_return_sequences` different than 1 (got {nrs}).")
         if do_sample and not temperature > 0:
@@ -1137,8 +1135,10 @@ class UltravoxModel:
         procs = generation.ScoreProcessors(kwargs, T, max_new_tokens, eos_list, rep)
         if num_beams > 1:
             lp = kwargs.get("length_penalty")
+            # do_sample: HF's beam sampling - the warpers join the processor list with min_tokens_to_keep = 1 + the number of terminators
+            sample = dict(temperature=float(temperature), top_k=top_k, top_p=top_p, min_p=min_p, keep=len(eos_list) + 1, generator=generator) if do_sample else None
             return self._beam_search(inputs_embeds, ids_dev, am, max_new_tokens, eos_list, pad_token_id, num_beams,
-                                     1.0 if lp is None else float(lp), kwargs.get("early_stopping", False), nrs, procs, return_dict)
+                                     1.0 if lp is None else float(lp), kwargs.get("early_stopping", False), nrs, procs, return_dict, sample)
         # A cache handed in is reused only while it still describes this prompt's prefix (HF trusts the caller here; a
         # re-tokenised reply that no longer matches would silently corrupt the dialogue, so it is checked and dropped).
         P = 0
@@ -1253,7 +1253,7 @@ class UltravoxModel:
         return GenerateOutput(sequences=sequences, past_key_values=state, logits=tuple(step_logits) if want_logits else None)
 
     def _beam_search(self, inputs_embeds: torch.Tensor, ids_dev: torch.Tensor, am: Optional[torch.Tensor], max_new_tokens: int, eos_list,
-                     pad_token_id: Optional[int], nb: int, length_penalty: float, early_stopping, nrs: int, procs, return_dict: bool):
+                     pad_token_id: Optional[int], nb: int, length_penalty: float, early_stopping, nrs: int, procs, return_dict: bool, sample=None):
         """generate(num_beams > 1): the reference forwards the keyword to [3P] HF `generate` (ultravox_model.py:422-426), i.e. HF's beam
         search.  Here: ONE prefill of the B prompts, the KV cache rows then replicated per beam ([L][2][B * beams][Tmax][..]); every step is
         a decode batch of B * beams rows through uvx_llm_decode, the search policy runs on the [B, beams * V] f32 log-probabilities on the
@@ -1262,7 +1262,12 @@ class UltravoxModel:
         or - early_stopping=True - all have `beams` finished hypotheses, or the length limit ends everything), and the cache rows are
         re-gathered to follow the surviving beams.  One host read-back per step (continue? / did the beams move?).  Returns
         [B * num_return_sequences, T + longest returned hypothesis], shorter ones padded (pad_token_id, else the first terminator) -
-        token for token what HF returns (tests/test_generate_gpu.py, oracle: OracleModel.generate_beam pinned against HF)."""
+        token for token what HF returns (tests/test_generate_gpu.py, oracle: OracleModel.generate_beam pinned against HF).
+        sample (do_sample=True: HF's beam sampling, GenerationMixin._get_top_k_continuations): the K continuations are DRAWN without replacement
+        from softmax(running score + warped log-probabilities) - one torch.multinomial on the [B, beams * V] matrix per step, the draws unsorted -
+        instead of taken by top-k; temperature / top-k / top-p / min-p act on the log-probabilities behind the score processors, each keeping at
+        least 1 + n_terminators tokens.  (Token-exact against HF on the CPU generator: tests/test_generate_host_cpu.py; a CUDA generator draws other
+        numbers.)"""
         l = _lib.lib()
         dev = self.device
         B, T, D = inputs_embeds.shape
@@ -1314,8 +1319,14 @@ class UltravoxModel:
             logp = torch.log_softmax(logits.float(), dim=-1)
             if procs.active:                                      # HF: the processors (generation.py) see the log-probabilities of the flat running sequences
                 logp = procs(torch.cat([prompt_flat, run_seq.view(BB, Lg)[:, :s]], dim=1), logp)
+            if sample is not None:
+                logp = self._warp(logp, sample["temperature"], sample["top_k"], sample["top_p"], sample["min_p"], keep=sample["keep"])
             acc = (logp.view(B, nb, V) + run_sc[:, :, None]).view(B, nb * V)
-            vals, idx = torch.topk(acc, K, dim=1)
+            if sample is not None:
+                idx = torch.multinomial(torch.softmax(acc, dim=-1), K, generator=sample["generator"])
+                vals = take(acc, idx, 1)
+            else:
+                vals, idx = torch.topk(acc, K, dim=1)
             src, tok = idx // V, idx % V
             cand = take(run_seq, src[:, :, None], 1)
             cand[:, :, s] = tok
@@ -1374,20 +1385,28 @@ class UltravoxModel:
     def _sample(logits: torch.Tensor, temperature: float, top_k, top_p, generator, min_p=None) -> torch.Tensor:
         """HF's sampling policy on the last-position logits (the reference's inference default, infer.py:317-324):
         TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper (-> MinPLogitsWarper) -> multinomial.  Host-side policy on [B, V]."""
-        x = logits.float() / temperature
+        return torch.multinomial(torch.softmax(UltravoxModel._warp(logits, temperature, top_k, top_p, min_p), dim=-1), 1, generator=generator)[:, 0]
+
+    @staticmethod
+    def _warp(scores: torch.Tensor, temperature: float, top_k, top_p, min_p=None, keep: int = 1) -> torch.Tensor:
+        """[3P] HF's sampling warpers on a [rows, V] score matrix, in HF's order: TemperatureLogitsWarper (only when != 1), TopKLogitsWarper,
+        TopPLogitsWarper, MinPLogitsWarper, each with min_tokens_to_keep = `keep` (1; beam sampling: 1 + the number of terminators)."""
+        x = scores.float()
+        if temperature != 1.0:
+            x = x / temperature
         if top_k is not None and top_k > 0:
-            kth = torch.topk(x, min(int(top_k), x.shape[-1]), dim=-1).values[:, -1:]
+            kth = torch.topk(x, min(max(int(top_k), keep), x.shape[-1]), dim=-1).values[:, -1:]
             x = x.masked_fill(x < kth, float("-inf"))
         if top_p is not None and top_p < 1.0:
             sv, si = torch.sort(x, dim=-1, descending=False)
             cum = torch.softmax(sv, dim=-1).cumsum(dim=-1)
             remove = cum <= (1.0 - top_p)
-            remove[:, -1] = False                                  # keep at least the most likely token
+            remove[:, -keep:] = False                              # keep at least the `keep` most likely tokens
             x = x.masked_fill(remove.scatter(1, si, remove), float("-inf"))
         if min_p is not None:
             from .generation import min_p_
-            x = min_p_(x, float(min_p))
-        return torch.multinomial(torch.softmax(x, dim=-1), 1, generator=generator)[:, 0]
+            x = min_p_(x, float(min_p), keep)
+        return x
 
     # The text before the first audio token needs no backward (include/uvx.h uvx_llm_bwd_train_from): the smallest audio_token_start_idx of the
     # batch as a HOST integer.  Collator output on the host: free.  A device tensor: its minimum is copied to pinned memory right away (queued
