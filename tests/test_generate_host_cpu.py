@@ -203,8 +203,8 @@ def test_terminators_padding_streamer_and_repetition_penalty(model):
         model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, typical_p=0.9)
     with pytest.raises(ValueError, match="not used by the model"):   # HF's own message for an unknown keyword
         model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, no_repeat_ngram=2)
-    with pytest.raises(NotImplementedError):
-        model.generate(ids, num_beams=4, do_sample=True)
+    with pytest.raises(NotImplementedError, match="stopping_criteria"):      # (beam sampling itself is built: test_beam_sampling_host_logic_... below)
+        model.generate(ids, num_beams=4, stopping_criteria=[lambda i, s: torch.zeros(i.shape[0], dtype=torch.bool)])
     with pytest.raises(ValueError):
         model.generate(ids, num_beams=2, num_return_sequences=3)
     with pytest.raises(ValueError):
