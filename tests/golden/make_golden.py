@@ -637,7 +637,7 @@ def lora_w2v_cases():
         hf = Wav2Vec2Model(Wav2Vec2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128, conv_dim=[64] * 7,
                                           num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, attn_implementation="eager", **fam)).eval()
         missing, unexpected = hf.load_state_dict({k[len("audio_tower."):]: v for k, v in sd.items() if k.startswith("audio_tower.")}, strict=False)
-        assert not unexpected and missing == ["masked_spec_embed"]
+        assert not unexpected and not missing      # (random_state_dict carries masked_spec_embed since round 6; the eval forward does not read it)
         lcfg = dataclasses.asdict(simp(r=4, lora_alpha=6) if targets is None else simp(r=4, lora_alpha=6, target_modules=targets))
         wrapped = ultravox_model.apply_lora(hf, dict(lcfg))
         g = torch.Generator().manual_seed(1)
