@@ -203,8 +203,8 @@ def test_terminators_padding_streamer_and_repetition_penalty(model):
         model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, typical_p=0.9)
     with pytest.raises(ValueError, match="not used by the model"):   # HF's own message for an unknown keyword
         model.generate(ids, attention_mask=am, max_new_tokens=1, eos_token_id=-1, no_repeat_ngram=2)
-    with pytest.raises(NotImplementedError, match="stopping_criteria"):      # (beam sampling itself is built: test_beam_sampling_host_logic_... below)
-        model.generate(ids, num_beams=4, stopping_criteria=[lambda i, s: torch.zeros(i.shape[0], dtype=torch.bool)])
+    with pytest.raises(NotImplementedError, match="min_p"):      # (a sampling warper without do_sample; beam sampling and stopping criteria are built: tests below)
+        model.generate(ids, num_beams=4, min_p=0.1)
     with pytest.raises(ValueError):
         model.generate(ids, num_beams=2, num_return_sequences=3)
     with pytest.raises(ValueError):
@@ -313,6 +313,39 @@ def test_beam_sampling_host_logic_against_the_oracle_restatement(model, case, n_
     plain = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=eos, pad_token_id=1,
                            **{k: v for k, v in case.items() if k not in ("temperature", "top_k", "top_p")})
     assert plain.shape != got.shape or not torch.equal(plain, got)
+
+
+@pytest.mark.parametrize("case", [dict(num_beams=3), dict(num_beams=2, early_stopping=True), dict(num_beams=4, length_penalty=0.0, num_return_sequences=2)])
+def test_beam_search_with_stopping_criteria_against_the_oracle_restatement(model, case):
+    """generate(num_beams > 1, stopping_criteria=[..]) on the simulated device against the oracle's restatement (pinned to HF generate in
+    tests/test_oracle_pinning.py): the caller's criteria see prompt + candidate of the K continuations of every step and end hypotheses like a terminator."""
+    from oracle.reference_cpu import beam_search_ref
+
+    def bump(target):
+        d = torch.arange(V, dtype=torch.float32) - target
+        return -(d.abs() * 0.31 + (d > 0) * 0.17)
+    model.fake._logits = lambda k, v, lo, hi, out: [out.__setitem__(b, bump(int(round(float((k[b, lo[b]:hi] * (v[b, lo[b]:hi] + 1.0)).sum()))) % V))
+                                                    for b in range(k.shape[0])]
+    ids, am = left_padded(3, 8, [0, 3, 1], seed=11)
+
+    def next_logits(hyps):
+        out = torch.empty(len(hyps), len(hyps[0]), V)
+        for b, item in enumerate(hyps):
+            keep = am[b].bool()
+            lo = int(torch.nonzero(keep)[0, 0])
+            for j, toks in enumerate(item):
+                feat = torch.cat([ids[b].float() + 1.0, torch.tensor(toks, dtype=torch.float32) + 1.0])
+                pos = torch.cumsum(keep.long(), 0) - 1
+                pos = torch.cat([pos, int(keep.sum()) + torch.arange(len(toks))]).float()
+                out[b, j] = bump(int(round(float((feat[lo:] * (pos[lo:] + 1.0)).sum()))) % V)
+        return out
+    crit = [lambda seq, scores: (seq[:, -1] % 3) == 0, lambda seq, scores: seq[:, 8:].sum(-1) > 250]      # (the second reads the whole hypothesis behind the 8-token prompt)
+    want = beam_search_ref(next_logits, ids, 6, -1, 1, case["num_beams"], case.get("length_penalty", 1.0), case.get("early_stopping", False),
+                           case.get("num_return_sequences", 1), None, None, False, crit)
+    got = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1, pad_token_id=1, stopping_criteria=crit, **case)
+    assert got.shape == want.shape and torch.equal(got, want), (got[:, 8:], want[:, 8:])
+    free = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1, pad_token_id=1, **case)
+    assert free.shape != got.shape or not torch.equal(free, got)
 
 
 def test_longest_common_prefix_reuse_is_opt_in_and_keeps_the_old_state_intact(model):
@@ -473,5 +506,4 @@ def test_custom_logits_processors_and_stopping_criteria(model):
     out = model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1, pad_token_id=1, stopping_criteria=[stop_at])
     assert out.shape[1] == 13 and out[0, 10:].tolist() == [1, 1, 1] and 1 not in out[1, 7:].tolist()
     assert model.generate(ids, attention_mask=am, max_new_tokens=6, eos_token_id=-1, stopping_criteria=[lambda i, s: i.shape[1] >= 9]).shape[1] == 9
-    with pytest.raises(NotImplementedError, match="beam search with stopping_criteria"):
-        model.generate(ids, attention_mask=am, num_beams=2, stopping_criteria=[stop_at])
+    # (with beams the criteria see the B * K candidates of a step: test_beam_search_with_stopping_criteria_against_the_oracle_restatement)

@@ -300,6 +300,42 @@ def test_beam_search_matches_hf_generate(n_eos):
     assert n_eos == 1 or short > 0          # (the many-terminator settings must actually end hypotheses early)
 
 
+def test_beam_search_with_a_callers_stopping_criterion_matches_hf_generate():
+    """generate(num_beams > 1, stopping_criteria=[..]): HF evaluates the caller's criteria on the flattened top-K candidates (prompt + hypothesis) of every
+    step next to its terminator / length criteria; a hypothesis that hits one ends like one that produced a terminator."""
+    from transformers import LlamaConfig, LlamaForCausalLM, StoppingCriteria, StoppingCriteriaList
+    cfg = tiny_cfg()
+    t = cfg.text_config
+    hf = LlamaForCausalLM(LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size, num_hidden_layers=t.num_hidden_layers,
+                                      num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size,
+                                      rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta, max_position_embeddings=t.max_position_embeddings,
+                                      tie_word_embeddings=False, attn_implementation="eager", eos_token_id=3, pad_token_id=3)).eval()
+    sd = random_state_dict(cfg, seed=8)
+    sd["language_model.model.embed_tokens.weight"] = sd["language_model.model.embed_tokens.weight"] * 0.3
+    hf.load_state_dict({k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}, strict=False)
+    torch.manual_seed(4)
+    B, T = 3, 11
+    ids = torch.randint(4, t.vocab_size, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[0, :4] = 0
+    ids[am == 0] = 3
+
+    class LastTokenBelow(StoppingCriteria):      # (about a fifth of the vocabulary ends a hypothesis)
+        def __call__(self, input_ids, scores, **kw):
+            return input_ids[:, -1] < 100
+    om = O.OracleModel(cfg, sd)
+    ended = 0
+    for case in (dict(num_beams=3), dict(num_beams=4, length_penalty=0.0, num_return_sequences=2), dict(num_beams=2, early_stopping=True)):
+        with torch.no_grad():
+            want = hf.generate(input_ids=ids, attention_mask=am, max_new_tokens=7, do_sample=False, eos_token_id=3, pad_token_id=3,
+                               stopping_criteria=StoppingCriteriaList([LastTokenBelow()]), **case)
+            free = hf.generate(input_ids=ids, attention_mask=am, max_new_tokens=7, do_sample=False, eos_token_id=3, pad_token_id=3, **case)
+        got = om.generate_beam(7, eos_token_id=3, pad_token_id=3, input_ids=ids, attention_mask=am, stopping_criteria=[LastTokenBelow()], **case)
+        assert got.shape == want.shape and torch.equal(got, want), (case, got[:, T:], want[:, T:])
+        ended += int(want.shape != free.shape or not torch.equal(want, free))
+    assert ended > 0
+
+
 BEAM_SAMPLE_CASES = [dict(num_beams=3, top_k=0), dict(num_beams=4, top_k=12, temperature=0.7), dict(num_beams=2, top_k=0, top_p=0.8, length_penalty=0.0),
                      dict(num_beams=3, top_k=0, temperature=1.3, num_return_sequences=2, repetition_penalty=1.4)]
 

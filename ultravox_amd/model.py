@@ -1108,8 +1108,8 @@ class UltravoxModel:
                 raise NotImplementedError("beam search starts from the prompt: past_key_values is not supported with num_beams > 1")
             if nrs > num_beams:
                 raise ValueError(f"`num_return_sequences` ({nrs}) has to be smaller or equal to `num_beams` ({num_beams}).")
-            if crit or (min_p is not None and not do_sample):
-                raise NotImplementedError("beam search with stopping_criteria is not built" if crit else "min_p is a sampling warper: it needs do_sample=True")
+            if min_p is not None and not do_sample:
+                raise NotImplementedError("min_p is a sampling warper: it needs do_sample=True")
         elif nrs != 1:
             raise ValueError(f"Greedy methods without beam search do not support `num_return_sequences` different than 1 (got {nrs}).")
         if do_sample and not temperature > 0:
@@ -1138,7 +1138,7 @@ class UltravoxModel:
             # do_sample: HF's beam sampling - the warpers join the processor list with min_tokens_to_keep = 1 + the number of terminators
             sample = dict(temperature=float(temperature), top_k=top_k, top_p=top_p, min_p=min_p, keep=len(eos_list) + 1, generator=generator) if do_sample else None
             return self._beam_search(inputs_embeds, ids_dev, am, max_new_tokens, eos_list, pad_token_id, num_beams,
-                                     1.0 if lp is None else float(lp), kwargs.get("early_stopping", False), nrs, procs, return_dict, sample)
+                                     1.0 if lp is None else float(lp), kwargs.get("early_stopping", False), nrs, procs, return_dict, sample, crit)
         # A cache handed in is reused only while it still describes this prompt's prefix (HF trusts the caller here; a
         # re-tokenised reply that no longer matches would silently corrupt the dialogue, so it is checked and dropped).
         P = 0
@@ -1253,7 +1253,7 @@ class UltravoxModel:
         return GenerateOutput(sequences=sequences, past_key_values=state, logits=tuple(step_logits) if want_logits else None)
 
     def _beam_search(self, inputs_embeds: torch.Tensor, ids_dev: torch.Tensor, am: Optional[torch.Tensor], max_new_tokens: int, eos_list,
-                     pad_token_id: Optional[int], nb: int, length_penalty: float, early_stopping, nrs: int, procs, return_dict: bool, sample=None):
+                     pad_token_id: Optional[int], nb: int, length_penalty: float, early_stopping, nrs: int, procs, return_dict: bool, sample=None, crit=()):
         """generate(num_beams > 1): the reference forwards the keyword to [3P] HF `generate` (ultravox_model.py:422-426), i.e. HF's beam
         search.  Here: ONE prefill of the B prompts, the KV cache rows then replicated per beam ([L][2][B * beams][Tmax][..]); every step is
         a decode batch of B * beams rows through uvx_llm_decode, the search policy runs on the [B, beams * V] f32 log-probabilities on the
@@ -1331,6 +1331,10 @@ class UltravoxModel:
             cand = take(run_seq, src[:, :, None], 1)
             cand[:, :, s] = tok
             hit = torch.isin(tok, eos_ids)
+            if crit:      # the caller's stopping criteria see prompt + candidate (HF: the flattened top-K running sequences; scores None), OR-ed with the terminators
+                from .generation import stopped
+                flat_c = torch.cat([ids_dev.repeat_interleave(K, dim=0), cand[:, :, :s + 1].reshape(B * K, s + 1)], dim=1)
+                hit = hit | stopped(crit, flat_c, None).view(B, K)
             if s + 1 >= Lg:
                 hit = torch.ones_like(hit)
             masked = vals + hit.to(torch.float32) * NEG
